@@ -1,0 +1,199 @@
+"""Pins the CPU oracle (C and numpy restatements) to every known-answer vector
+of SURVEY.md Appendix A.4 -- the upstream reed-solomon-erasure / Backblaze
+JavaReedSolomon KATs.  The reference tree itself holds no vectors for this path
+("parity unpinned")."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import rs_oracle as O
+
+
+def sha(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint8).tobytes()).hexdigest()
+
+
+# A.1 ----------------------------------------------------------------------
+def test_field_tables():
+    assert list(O.EXP[:16]) == [1, 2, 4, 8, 16, 32, 64, 128, 29, 58, 116, 232, 205, 135, 19, 38]
+    assert list(O.LOG[1:12]) == [0, 1, 25, 2, 50, 26, 198, 3, 223, 51, 238]
+
+
+# A.4.1 --------------------------------------------------------------------
+def test_field_spot_values(coracle):
+    for impl_mul, impl_exp in ((O.gf_mul, O.gf_exp), (coracle.lib.rso_gf_mul, coracle.lib.rso_gf_exp)):
+        assert impl_mul(3, 4) == 12
+        assert impl_mul(7, 7) == 21
+        assert impl_mul(23, 45) == 41
+        assert impl_exp(2, 2) == 4
+        assert impl_exp(5, 20) == 235
+        assert impl_exp(13, 7) == 43
+
+
+def test_field_axioms_exhaustive(coracle):
+    # C table == numpy table, commutativity, a*inv(a)=1, distributivity on a sample
+    cm = np.array([[coracle.lib.rso_gf_mul(a, b) for b in range(256)] for a in range(256)], dtype=np.uint8)
+    assert np.array_equal(cm, O.MUL)
+    assert np.array_equal(O.MUL, O.MUL.T)
+    for a in range(1, 256):
+        assert O.gf_mul(a, O.gf_div(1, a)) == 1
+        assert coracle.lib.rso_gf_div(a, a) == 1
+    a = np.arange(256)
+    for b, c in ((3, 200), (77, 91), (255, 1)):
+        assert np.array_equal(O.MUL[a, b ^ c], O.MUL[a, b] ^ O.MUL[a, c])
+
+
+# A.4.2 --------------------------------------------------------------------
+def test_inverse_kat(coracle):
+    m = np.array([[56, 23, 98], [3, 100, 200], [45, 201, 123]], dtype=np.uint8)
+    want = np.array([[175, 133, 33], [130, 13, 245], [112, 35, 126]], dtype=np.uint8)
+    assert np.array_equal(O.invert(m), want)
+    assert np.array_equal(coracle.invert(m), want)
+    assert np.array_equal(O.mat_mul(m, want), np.eye(3, dtype=np.uint8))
+
+
+def test_inverse_needs_row_swap(coracle):
+    m = np.array([[0, 1, 0], [1, 0, 0], [0, 0, 7]], dtype=np.uint8)
+    inv = O.invert(m)
+    assert np.array_equal(O.mat_mul(m, inv), np.eye(3, dtype=np.uint8))
+    assert np.array_equal(coracle.invert(m), inv)
+    with pytest.raises(ValueError):
+        O.invert(np.array([[1, 1], [1, 1]], dtype=np.uint8))
+    with pytest.raises(ValueError):
+        coracle.invert(np.array([[1, 1], [1, 1]], dtype=np.uint8))
+
+
+# A.4.3 --------------------------------------------------------------------
+def test_one_encode_5_5(coracle):
+    data = np.array([[0, 1], [4, 5], [2, 3], [6, 7], [8, 9]], dtype=np.uint8)
+    want = np.array([[12, 13], [10, 11], [14, 15], [90, 91], [94, 95]], dtype=np.uint8)
+    assert np.array_equal(O.encode(5, 5, data), want)
+    for variant in (coracle.SCALAR, coracle.AVX2):
+        assert np.array_equal(coracle.encode_batch(5, 5, data[None], variant)[0], want)
+
+
+# A.4.4 / A.4.5 ------------------------------------------------------------
+PARITY_ROWS_10_4 = [
+    [129, 150, 175, 184, 210, 196, 254, 232, 3, 2],
+    [150, 129, 184, 175, 196, 210, 232, 254, 2, 3],
+    [191, 214, 98, 10, 6, 111, 223, 183, 5, 4],
+    [214, 191, 10, 98, 111, 6, 183, 223, 4, 5],
+]
+MATRIX_SHA = {
+    (3, 1): "75c8fd04ad916aec3e3d5cb76a452b116b3d4d0912a0a485e9fb8e3d240e210c",
+    (10, 4): "6aea6e4fb966660ad42092d4bbd140751dfe0a8214d9170d34e7f4207b86f882",
+    (20, 8): "2fca8cfa87d3a034bbf6c5ecc3f79d238c4163a83e9929b64d749b75fd26d1cc",
+}
+
+
+@pytest.mark.parametrize("km", list(MATRIX_SHA))
+def test_parity_matrix_digests(coracle, km):
+    k, m = km
+    M = O.build_matrix(k, m)
+    assert np.array_equal(M[:k], np.eye(k, dtype=np.uint8)), "systematic"
+    assert np.array_equal(coracle.build_matrix(k, m), M)
+    assert sha(M[k:]) == MATRIX_SHA[km]
+
+
+def test_parity_rows_listed():
+    assert O.parity_matrix(3, 1).tolist() == [[1, 1, 1]]
+    assert O.parity_matrix(10, 4).tolist() == PARITY_ROWS_10_4
+    assert O.parity_matrix(20, 8)[0].tolist() == [
+        143, 174, 91, 112, 208, 205, 84, 67, 57, 163, 201, 88, 27, 187, 179, 24, 27, 28, 18, 20]
+
+
+# A.4.6 --------------------------------------------------------------------
+GOLDEN_ENCODE = [
+    (3, 1, 64, "a1a2e6472297a6c8fc595265fbc01ecb82954e148bc46107d916c1f876f5dbb6", [130, 141, 136, 147, 158, 169, 180, 191]),
+    (10, 4, 64, "716c5f64eecea82d320f527c7837757e9a9effaaf219169d6e52e2e5f80b021d", [201, 45, 47, 141, 127, 204, 171, 51]),
+    (10, 4, 4096, "473009bcb1d7ca2a705463acf8a5788977d23115a3d6a3bb29b880dcbb7a5860", None),
+    (20, 8, 64, "9faa9f8192c1e5573f78dac342858bbc6b2cd98f46f118d467e84d3cfc2c42a5", [20, 222, 172, 50, 76, 49, 116, 202]),
+]
+
+
+@pytest.mark.parametrize("k,m,L,digest,p0", GOLDEN_ENCODE)
+def test_golden_encode(coracle, k, m, L, digest, p0):
+    data = O.golden_pattern(k, L)
+    par = O.encode(k, m, data)
+    assert sha(par) == digest
+    if p0:
+        assert par[0, :8].tolist() == p0
+    for variant in (coracle.SCALAR, coracle.AVX2):
+        assert np.array_equal(coracle.encode_batch(k, m, data[None], variant)[0], par)
+
+
+# A.4.7 --------------------------------------------------------------------
+def test_decode_matrix_kat(coracle):
+    k, m = 10, 4
+    present = [j not in (0, 3, 7, 11) for j in range(14)]
+    valid, D = O.decode_matrix(k, m, present)
+    assert valid == [1, 2, 4, 5, 6, 8, 9, 10, 12, 13]
+    assert D[0].tolist() == [204, 75, 104, 156, 114, 211, 108, 57, 186, 60]
+    assert sha(D) == "bc2a101e23e1e2ea8d759ed119ec103d2596a8d5a422f8d4e734f34e8bbe5210"
+    cvalid, cD = coracle.decode_matrix(k, m, present)
+    assert cvalid == valid and np.array_equal(cD, D)
+    data = O.golden_pattern(k, 256)
+    full = np.concatenate([data, O.encode(k, m, data)])
+    broken = full.copy()
+    broken[[0, 3, 7, 11]] = 0xEE
+    assert np.array_equal(O.reconstruct(k, m, broken, present), full)
+    assert np.array_equal(coracle.reconstruct_batch(k, m, broken[None], present)[0], full)
+
+
+# properties -----------------------------------------------------------------
+@pytest.mark.parametrize("k,m", [(3, 1), (10, 4), (20, 8), (1, 1), (2, 3), (17, 3)])
+def test_roundtrip_any_k_survivors(coracle, k, m):
+    rng = np.random.default_rng(k * 100 + m)
+    S = 192
+    data = rng.integers(0, 256, (k, S), dtype=np.uint8)
+    full = np.concatenate([data, O.encode(k, m, data)])
+    assert O.verify(k, m, full)
+    for trial in range(6):
+        lost = rng.choice(k + m, size=rng.integers(1, m + 1), replace=False)
+        present = [j not in lost for j in range(k + m)]
+        broken = full.copy()
+        broken[lost] = rng.integers(0, 256, (len(lost), S), dtype=np.uint8)
+        assert np.array_equal(O.reconstruct(k, m, broken, present), full)
+        assert np.array_equal(coracle.reconstruct_batch(k, m, broken[None], present)[0], full)
+        d_only = O.reconstruct(k, m, broken, present, data_only=True)
+        assert np.array_equal(d_only[:k], data)
+
+
+def test_too_few_present(coracle):
+    k, m = 4, 2
+    st = np.zeros((1, 6, 64), dtype=np.uint8)
+    present = [1, 1, 1, 0, 0, 0]
+    with pytest.raises(ValueError):
+        O.reconstruct(k, m, st[0], present)
+    with pytest.raises(ValueError):
+        coracle.reconstruct_batch(k, m, st, present)
+
+
+def test_linearity_and_scalar_vs_avx2(coracle):
+    k, m, S = 10, 4, 104896  # config-2 shard length
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, 256, (2, k, S), dtype=np.uint8)
+    pa = coracle.encode_batch(k, m, a, coracle.SCALAR, threads=2)
+    pb = coracle.encode_batch(k, m, a, coracle.AVX2, threads=2)
+    assert np.array_equal(pa, pb)
+    px = coracle.encode_batch(k, m, (a[0] ^ a[1])[None], coracle.AVX2)[0]
+    assert np.array_equal(px, pa[0] ^ pa[1])
+    assert np.array_equal(pa[0][:, :4096], O.encode(k, m, a[0][:, :4096]))
+
+
+def test_shard_len_and_split():
+    assert O.shard_len(3, 65536) == 21888
+    assert O.shard_len(10, 1048576) == 104896
+    assert O.shard_len(20, 4194304) == 209728
+    assert O.shard_len(10, 1) == 64
+    blk = bytes(range(200)) * 3
+    sh = O.split_block(4, blk)
+    assert sh.shape == (4, 192)
+    assert bytes(sh.reshape(-1)[: len(blk)]) == blk and not sh.reshape(-1)[len(blk):].any()
+
+
+def test_splitmix64_known():
+    # SplitMix64 reference outputs for seed 1234567 (Vigna's splitmix64.c)
+    b = O.splitmix64_bytes(1234567, 24).view("<u8")
+    assert [int(x) for x in b] == [6457827717110365317, 3203168211198807973, 9817491932198370423]
