@@ -1,0 +1,96 @@
+"""ctypes binding of libgarage_ec.so (include/garage_ec.h).
+
+The library is the product; this module only declares prototypes.  There is no
+fallback of any kind: if the shared object is missing, import fails loudly with
+the command that builds it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgarage_ec.so")
+
+GEC_OK = 0
+GEC_E_TOO_FEW_SHARDS = -1
+GEC_E_TOO_MANY_SHARDS = -2
+GEC_E_TOO_FEW_DATA = -3
+GEC_E_TOO_MANY_DATA = -4
+GEC_E_TOO_FEW_PARITY = -5
+GEC_E_TOO_MANY_PARITY = -6
+GEC_E_INCORRECT_SHARD_SIZE = -7
+GEC_E_TOO_FEW_PRESENT = -8
+GEC_E_EMPTY_SHARD = -9
+GEC_E_INVALID_INDEX = -10
+GEC_E_DEVICE = -100
+GEC_E_NOMEM = -101
+GEC_E_INVALID_ARG = -102
+
+# every symbol include/garage_ec.h declares (tests/test_cabi_symbols.py checks
+# this list against the header and against the built library)
+SYMBOLS = [
+    "gec_version", "gec_device_count", "gec_strerror", "gec_last_error",
+    "gec_shard_len", "gec_build_matrix", "gec_build_decode_matrix",
+    "gec_codec_create", "gec_codec_destroy", "gec_codec_k", "gec_codec_m",
+    "gec_codec_device", "gec_parity_matrix", "gec_codec_cache_stats",
+    "gec_encode_batch", "gec_verify_batch", "gec_reconstruct_batch",
+    "gec_encode_batch_dev", "gec_verify_batch_dev", "gec_reconstruct_batch_dev",
+    "gec_reconstruct_range_dev", "gec_set_kernel_variant", "gec_get_kernel_variant",
+]
+
+
+class GecError(RuntimeError):
+    """A non-zero return code from libgarage_ec (mirrors reed_solomon_erasure::Error)."""
+
+    def __init__(self, code: int, what: str, detail: str):
+        super().__init__(f"{what}: {detail} (code {code})" if detail else f"{what} (code {code})")
+        self.code = code
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: libgarage_ec has not been built. Run "
+            "`make -C garage_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback for the erasure-coding data path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    pp = ctypes.POINTER(ctypes.c_void_p)
+    lib.gec_version.restype = ctypes.c_uint32
+    lib.gec_device_count.restype = ci
+    lib.gec_strerror.restype = ctypes.c_char_p
+    lib.gec_strerror.argtypes = [ci]
+    lib.gec_last_error.restype = ctypes.c_char_p
+    lib.gec_shard_len.restype = sz
+    lib.gec_shard_len.argtypes = [ci, sz]
+    lib.gec_build_matrix.argtypes = [ci, ci, u8p]
+    lib.gec_build_decode_matrix.argtypes = [ci, ci, u8p, ctypes.POINTER(ctypes.c_int32), u8p]
+    lib.gec_codec_create.argtypes = [ci, ci, ci, pp]
+    lib.gec_codec_destroy.argtypes = [vp]
+    lib.gec_codec_destroy.restype = None
+    for f in ("gec_codec_k", "gec_codec_m", "gec_codec_device"):
+        getattr(lib, f).argtypes = [vp]
+    lib.gec_parity_matrix.argtypes = [vp, u8p]
+    lib.gec_codec_cache_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    lib.gec_encode_batch.argtypes = [vp, sz, pp, ctypes.POINTER(sz), sz, pp]
+    lib.gec_verify_batch.argtypes = [vp, sz, pp, sz, u8p]
+    lib.gec_reconstruct_batch.argtypes = [vp, sz, pp, pp, sz, ci]
+    lib.gec_encode_batch_dev.argtypes = [vp, sz, vp, sz, sz, vp, sz, vp]
+    lib.gec_verify_batch_dev.argtypes = [vp, sz, vp, sz, sz, vp, vp]
+    lib.gec_reconstruct_batch_dev.argtypes = [vp, sz, vp, sz, sz, u8p, ci, vp]
+    lib.gec_reconstruct_range_dev.argtypes = [vp, sz, vp, sz, sz, u8p, ci, sz, sz, vp]
+    lib.gec_set_kernel_variant.argtypes = [ci]
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != GEC_OK:
+        detail = (lib.gec_last_error() or b"").decode("utf-8", "replace")
+        name = (lib.gec_strerror(rc) or b"").decode()
+        raise GecError(rc, f"{what}: {name}", detail)

@@ -1,0 +1,234 @@
+"""Host-side mirror of the `reed_solomon_erasure::galois_8::ReedSolomon` API
+[EXT] over libgarage_ec's C ABI, so that parity tests read like the crate's own
+tests (`new`, `encode_sep`, `verify`, `reconstruct`, `reconstruct_data`).
+
+PyTorch is used only as plumbing for device memory and streams: tensors are
+handed to the C ABI as raw pointers + the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import GecError, check, lib
+
+
+def shard_len(k: int, block_len: int) -> int:
+    """S = round_up(ceil(L/k), 64) -- gec_shard_len."""
+    return int(lib.gec_shard_len(k, block_len))
+
+
+def build_matrix(k: int, m: int) -> np.ndarray:
+    out = np.zeros((max(k + m, 1), max(k, 1)), dtype=np.uint8)
+    check(lib.gec_build_matrix(k, m, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), "gec_build_matrix")
+    return out
+
+
+def build_decode_matrix(k: int, m: int, present: Sequence[int]):
+    pres = np.ascontiguousarray(np.asarray(present, dtype=np.uint8))
+    if pres.size != k + m:
+        raise GecError(_lib.GEC_E_INVALID_ARG, "gec_build_decode_matrix", "present must have k+m entries")
+    valid = (ctypes.c_int32 * max(k, 1))()
+    out = np.zeros((max(k, 1), max(k, 1)), dtype=np.uint8)
+    check(lib.gec_build_decode_matrix(k, m, pres.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), valid,
+                                      out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))),
+          "gec_build_decode_matrix")
+    return list(valid)[:k], out
+
+
+def _u8p(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+def _stream_handle(device_index: int) -> int:
+    import torch
+
+    return int(torch.cuda.current_stream(device_index).cuda_stream)
+
+
+class ReedSolomon:
+    """`ReedSolomon::new(data_shards, parity_shards)` bound to one GPU."""
+
+    def __init__(self, data_shards: int, parity_shards: int, device: int = 0):
+        h = ctypes.c_void_p()
+        check(lib.gec_codec_create(data_shards, parity_shards, device, ctypes.byref(h)), "gec_codec_create")
+        self._h = h
+        self.k = data_shards
+        self.m = parity_shards
+        self.n = data_shards + parity_shards
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib.gec_codec_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # -- introspection -----------------------------------------------------
+    def data_shard_count(self) -> int:
+        return int(lib.gec_codec_k(self._h))
+
+    def parity_shard_count(self) -> int:
+        return int(lib.gec_codec_m(self._h))
+
+    def total_shard_count(self) -> int:
+        return self.n
+
+    def parity_matrix(self) -> np.ndarray:
+        out = np.zeros((self.m, self.k), dtype=np.uint8)
+        check(lib.gec_parity_matrix(self._h, _u8p(out)), "gec_parity_matrix")
+        return out
+
+    def cache_stats(self) -> tuple[int, int]:
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        check(lib.gec_codec_cache_stats(self._h, ctypes.byref(a), ctypes.byref(b)), "gec_codec_cache_stats")
+        return int(a.value), int(b.value)
+
+    # -- device-resident (torch uint8 CUDA tensors) ---------------------------
+    def _check_dev(self, t, shards: int, name: str):
+        import torch
+
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8):
+            raise TypeError(f"{name} must be a uint8 CUDA tensor")
+        if t.dim() != 3 or t.shape[1] != shards or not t.is_contiguous():
+            raise GecError(_lib.GEC_E_INCORRECT_SHARD_SIZE, name, f"expected contiguous (nblocks, {shards}, S)")
+        if t.device.index != self.device:
+            raise GecError(_lib.GEC_E_INVALID_ARG, name, "tensor is on a different device than the codec")
+
+    def encode_sep_dev(self, data, parity=None):
+        """data: (nblocks, k, S) uint8 on the codec's GPU -> parity (nblocks, m, S).
+        Asynchronous on torch's current stream."""
+        import torch
+
+        self._check_dev(data, self.k, "data")
+        nb, _, S = data.shape
+        if parity is None:
+            parity = torch.empty((nb, self.m, S), dtype=torch.uint8, device=data.device)
+        else:
+            self._check_dev(parity, self.m, "parity")
+            if parity.shape[0] != nb or parity.shape[2] != S:
+                raise GecError(_lib.GEC_E_INCORRECT_SHARD_SIZE, "parity", "shape mismatch with data")
+        check(lib.gec_encode_batch_dev(self._h, nb, data.data_ptr(), self.k * S, S, parity.data_ptr(),
+                                       self.m * S, _stream_handle(self.device)), "gec_encode_batch_dev")
+        return parity
+
+    def encode_dev(self, stripes):
+        """stripes: (nblocks, k+m, S); parity rows are overwritten in place
+        (`ReedSolomon::encode(&mut shards)`)."""
+        self._check_dev(stripes, self.n, "stripes")
+        nb, _, S = stripes.shape
+        base = stripes.data_ptr()
+        check(lib.gec_encode_batch_dev(self._h, nb, base, self.n * S, S, base + self.k * S, self.n * S,
+                                       _stream_handle(self.device)), "gec_encode_batch_dev")
+        return stripes
+
+    def verify_dev(self, stripes):
+        """-> bool tensor (nblocks,), True where parity is consistent."""
+        import torch
+
+        self._check_dev(stripes, self.n, "stripes")
+        nb, _, S = stripes.shape
+        bad = torch.empty((nb,), dtype=torch.int32, device=stripes.device)
+        check(lib.gec_verify_batch_dev(self._h, nb, stripes.data_ptr(), self.n * S, S, bad.data_ptr(),
+                                       _stream_handle(self.device)), "gec_verify_batch_dev")
+        return bad == 0
+
+    def reconstruct_dev(self, stripes, present: Sequence[int], data_only: bool = False,
+                        byte_range: Optional[tuple[int, int]] = None):
+        """Rebuild the shards with present[j]==0 in place, one pattern per batch.
+        byte_range=(off, len) restricts the work to that slice of every shard."""
+        self._check_dev(stripes, self.n, "stripes")
+        nb, _, S = stripes.shape
+        pres = np.ascontiguousarray(np.asarray(present, dtype=np.uint8))
+        if pres.size != self.n:
+            raise GecError(_lib.GEC_E_INVALID_INDEX, "present", "must have k+m entries")
+        off, ln = (0, S) if byte_range is None else byte_range
+        check(lib.gec_reconstruct_range_dev(self._h, nb, stripes.data_ptr(), self.n * S, S, _u8p(pres),
+                                            int(bool(data_only)), off, ln, _stream_handle(self.device)),
+              "gec_reconstruct_range_dev")
+        return stripes
+
+    # -- host buffers (what the Rust shim calls) -----------------------------
+    def encode_blocks(self, blocks: Sequence[bytes], S: Optional[int] = None) -> list[np.ndarray]:
+        """blocks: byte strings (any lengths) -> per block a (m, S) parity array."""
+        nb = len(blocks)
+        if nb == 0:
+            return []
+        if S is None:
+            S = max(shard_len(self.k, len(b)) for b in blocks)
+        bufs = [np.frombuffer(bytes(b), dtype=np.uint8) if len(b) else np.zeros(1, dtype=np.uint8) for b in blocks]
+        lens = (ctypes.c_size_t * nb)(*[len(b) for b in blocks])
+        ptrs = (ctypes.c_void_p * nb)(*[a.ctypes.data for a in bufs])
+        outs = [np.empty((self.m, S), dtype=np.uint8) for _ in range(nb)]
+        optrs = (ctypes.c_void_p * nb)(*[o.ctypes.data for o in outs])
+        check(lib.gec_encode_batch(self._h, nb, ptrs, lens, S, optrs), "gec_encode_batch")
+        return outs
+
+    def verify(self, stripes: np.ndarray) -> np.ndarray:
+        """stripes: (nblocks, k+m, S) host array -> bool (nblocks,)."""
+        st = np.ascontiguousarray(stripes, dtype=np.uint8)
+        if st.ndim != 3 or st.shape[1] != self.n:
+            raise GecError(_lib.GEC_E_TOO_FEW_SHARDS if st.ndim == 3 and st.shape[1] < self.n else _lib.GEC_E_TOO_MANY_SHARDS,
+                           "verify", f"expected (nblocks, {self.n}, S)")
+        nb, _, S = st.shape
+        ptrs = (ctypes.c_void_p * (nb * self.n))(*[st[b, j].ctypes.data for b in range(nb) for j in range(self.n)])
+        ok = np.zeros(nb, dtype=np.uint8)
+        check(lib.gec_verify_batch(self._h, nb, ptrs, S, _u8p(ok)), "gec_verify_batch")
+        return ok.astype(bool)
+
+    def reconstruct(self, shards: Sequence[Sequence[Optional[np.ndarray]]], data_only: bool = False):
+        """shards[b][j] is a uint8 array of S bytes or None (missing).  Returns a
+        list of lists with the missing entries filled (`reconstruct` /
+        `reconstruct_data` when data_only)."""
+        nb = len(shards)
+        if nb == 0:
+            return []
+        S = None
+        for row in shards:
+            if len(row) != self.n:
+                raise GecError(_lib.GEC_E_TOO_FEW_SHARDS if len(row) < self.n else _lib.GEC_E_TOO_MANY_SHARDS,
+                               "reconstruct", f"each block needs {self.n} shard slots")
+            for s in row:
+                if s is not None:
+                    if S is None:
+                        S = len(s)
+                    elif len(s) != S:
+                        raise GecError(_lib.GEC_E_INCORRECT_SHARD_SIZE, "reconstruct", "shards differ in length")
+        if S is None:
+            raise GecError(_lib.GEC_E_TOO_FEW_PRESENT, "reconstruct", "no shard present")
+        keep, inp, outp, result = [], [], [], []
+        for row in shards:
+            res_row = []
+            for j, s in enumerate(row):
+                if s is not None:
+                    a = np.ascontiguousarray(s, dtype=np.uint8)
+                    keep.append(a)
+                    inp.append(a.ctypes.data)
+                    outp.append(None)
+                    res_row.append(a)
+                else:
+                    inp.append(None)
+                    if data_only and j >= self.k:
+                        outp.append(None)
+                        res_row.append(None)
+                    else:
+                        o = np.empty(S, dtype=np.uint8)
+                        keep.append(o)
+                        outp.append(o.ctypes.data)
+                        res_row.append(o)
+            result.append(res_row)
+        ip = (ctypes.c_void_p * len(inp))(*inp)
+        op = (ctypes.c_void_p * len(outp))(*outp)
+        check(lib.gec_reconstruct_batch(self._h, nb, ip, op, S, int(bool(data_only))), "gec_reconstruct_batch")
+        return result
+
+    def reconstruct_data(self, shards):
+        return self.reconstruct(shards, data_only=True)
+
+
+def set_kernel_variant(v: int) -> None:
+    check(lib.gec_set_kernel_variant(v), "gec_set_kernel_variant")

@@ -1,0 +1,785 @@
+// garage_ec.hip -- host side + C ABI of libgarage_ec.so (see include/garage_ec.h).
+//
+// Host responsibilities (all tiny): coding matrices, erasure-pattern -> decode
+// plan (LRU-cached like the crate's decode-matrix cache [EXT core.rs]), shard
+// geometry, argument checking, H2D/D2H staging for the host-pointer entry
+// points.  Every shard byte is produced by the kernels in kernels.hpp; there is
+// no CPU data path.
+#include "../../include/garage_ec.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <list>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "gf256.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+std::atomic<int> g_variant{0};
+
+int fail(int code, const std::string &detail)
+{
+	g_last_error = detail;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+	do {                                                                           \
+		hipError_t e_ = (expr);                                                \
+		if (e_ != hipSuccess)                                                  \
+			return fail(GEC_E_DEVICE, std::string(#expr) + ": " +          \
+							  hipGetErrorString(e_));      \
+	} while (0)
+
+// Restores the calling thread's current device on scope exit (torch and other
+// callers keep their own notion of "current device").
+struct DeviceGuard {
+	int prev = -1;
+	bool ok = false;
+	explicit DeviceGuard(int dev)
+	{
+		if (hipGetDevice(&prev) != hipSuccess)
+			prev = -1;
+		ok = (prev == dev) || hipSetDevice(dev) == hipSuccess;
+	}
+	~DeviceGuard()
+	{
+		if (prev >= 0)
+			(void)hipSetDevice(prev);
+	}
+};
+
+int check_km(int k, int m)
+{
+	// same order of checks as ReedSolomon::new [EXT]
+	if (k <= 0)
+		return fail(GEC_E_TOO_FEW_DATA, "data shards must be >= 1");
+	if (m <= 0)
+		return fail(GEC_E_TOO_FEW_PARITY, "parity shards must be >= 1");
+	if (k + m > GEC_MAX_SHARDS)
+		return fail(GEC_E_TOO_MANY_SHARDS, "k + m must be <= 256 in GF(2^8)");
+	return GEC_OK;
+}
+
+// What to compute for one erasure pattern: out[missing[r]] = rows[r] . in[valid[*]]
+struct Plan {
+	std::vector<int> valid;    // k input shard indices
+	std::vector<int> missing;  // output shard indices
+	gec::Matrix rows;          // missing.size() x k
+};
+
+// Staging resources for the host-pointer entry points (one per in-flight call).
+struct Staging {
+	hipStream_t stream = nullptr;
+	uint8_t *h_buf = nullptr, *d_buf = nullptr;
+	size_t cap = 0;
+	uint32_t *d_bad = nullptr, *h_bad = nullptr;
+	size_t bad_cap = 0;
+
+	int ensure(size_t bytes, size_t nbad)
+	{
+		if (!stream)
+			HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+		if (bytes > cap) {
+			if (h_buf)
+				(void)hipHostFree(h_buf);
+			if (d_buf)
+				(void)hipFree(d_buf);
+			h_buf = d_buf = nullptr;
+			cap = 0;
+			HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_buf), bytes, hipHostMallocDefault));
+			HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_buf), bytes));
+			cap = bytes;
+		}
+		if (nbad > bad_cap) {
+			if (h_bad)
+				(void)hipHostFree(h_bad);
+			if (d_bad)
+				(void)hipFree(d_bad);
+			h_bad = d_bad = nullptr;
+			bad_cap = 0;
+			HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_bad), nbad * sizeof(uint32_t), hipHostMallocDefault));
+			HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_bad), nbad * sizeof(uint32_t)));
+			bad_cap = nbad;
+		}
+		return GEC_OK;
+	}
+	void release()
+	{
+		if (h_buf)
+			(void)hipHostFree(h_buf);
+		if (d_buf)
+			(void)hipFree(d_buf);
+		if (h_bad)
+			(void)hipHostFree(h_bad);
+		if (d_bad)
+			(void)hipFree(d_bad);
+		if (stream)
+			(void)hipStreamDestroy(stream);
+		*this = Staging();
+	}
+};
+
+}  // namespace
+
+struct gec_codec {
+	int k = 0, m = 0, device = 0;
+	int num_cu = 256;
+	gec::Matrix enc;               // (k+m) x k
+	gec::LogExp *d_logexp = nullptr;
+
+	// decode-plan LRU, keyed by present bitmap + data_only
+	static constexpr size_t kCacheCap = 254;
+	mutable std::mutex cache_mu;
+	mutable std::list<std::string> lru;
+	mutable std::unordered_map<std::string, std::pair<std::shared_ptr<const Plan>, std::list<std::string>::iterator>> cache;
+	mutable uint64_t inversions = 0;
+
+	mutable std::mutex pool_mu;
+	mutable std::vector<Staging> pool;
+};
+
+namespace {
+
+int get_plan(const gec_codec *c, const uint8_t *present, bool data_only, std::shared_ptr<const Plan> &out)
+{
+	const int k = c->k, n = c->k + c->m;
+	std::string key(reinterpret_cast<const char *>(present), n);
+	for (auto &ch : key)
+		ch = ch ? 1 : 0;
+	key.push_back(data_only ? 1 : 0);
+	{
+		std::lock_guard<std::mutex> g(c->cache_mu);
+		auto it = c->cache.find(key);
+		if (it != c->cache.end()) {
+			c->lru.splice(c->lru.begin(), c->lru, it->second.second);
+			out = it->second.first;
+			return GEC_OK;
+		}
+	}
+	auto plan = std::make_shared<Plan>();
+	for (int j = 0; j < n && (int)plan->valid.size() < k; ++j)
+		if (present[j])
+			plan->valid.push_back(j);
+	if ((int)plan->valid.size() < k)
+		return fail(GEC_E_TOO_FEW_PRESENT, "fewer than k shards present");
+	for (int j = 0; j < n; ++j)
+		if (!present[j] && !(data_only && j >= k))
+			plan->missing.push_back(j);
+	if (!plan->missing.empty()) {
+		gec::Matrix sub(k, k), dec;
+		for (int t = 0; t < k; ++t)
+			std::memcpy(&sub.at(t, 0), c->enc.row(plan->valid[t]), k);
+		if (!gec::invert(sub, dec))
+			return fail(GEC_E_INVALID_ARG, "decode sub-matrix singular (cannot happen for an MDS code)");
+		// missing data j: row j of dec.  missing parity p: enc[p] * dec, which
+		// equals re-encoding p from the completed data (crate order) because GF
+		// arithmetic is exact.
+		plan->rows = gec::Matrix((int)plan->missing.size(), k);
+		for (size_t r = 0; r < plan->missing.size(); ++r) {
+			int j = plan->missing[r];
+			if (j < k) {
+				std::memcpy(&plan->rows.at((int)r, 0), dec.row(j), k);
+			} else {
+				gec::Matrix prow(1, k);
+				std::memcpy(&prow.at(0, 0), c->enc.row(j), k);
+				gec::Matrix comp = gec::matmul(prow, dec);
+				std::memcpy(&plan->rows.at((int)r, 0), comp.row(0), k);
+			}
+		}
+	}
+	{
+		std::lock_guard<std::mutex> g(c->cache_mu);
+		++c->inversions;
+		if (c->cache.find(key) == c->cache.end()) {
+			c->lru.push_front(key);
+			c->cache[key] = {plan, c->lru.begin()};
+			if (c->cache.size() > gec_codec::kCacheCap) {
+				c->cache.erase(c->lru.back());
+				c->lru.pop_back();
+			}
+		}
+	}
+	out = plan;
+	return GEC_OK;
+}
+
+template <int MW, int MODE>
+void launch_nibble(const gec::ApplyArgs &a, const gec::LogExp *le, unsigned grid, size_t lds, hipStream_t s)
+{
+	// loads in flight per lane: whole k when it is small enough to keep 8 waves/SIMD
+	if (a.k <= 5)
+		hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 5>), dim3(grid), dim3(gec::BLOCK), lds, s, a, le);
+	else
+		hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 10>), dim3(grid), dim3(gec::BLOCK), lds, s, a, le);
+}
+
+// out rows `out_idx[0..nout)` = coef(nout x k) applied to shards `in_idx[0..k)`.
+// Shards are addressed as base + b*stride + idx*S.  rows are processed in groups
+// of RMAX per launch.
+int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_t *out, size_t out_stride,
+		 uint32_t *bad, size_t S, size_t byte_off, size_t byte_len, size_t nblocks, const int *in_idx,
+		 const size_t *in_base_off, const int *out_idx, const size_t *out_base_off, int nout,
+		 const uint8_t *coef /* nout x k */, int mode, hipStream_t stream)
+{
+	(void)in_idx;
+	(void)out_idx;
+	const int k = c->k;
+	if (nblocks == 0 || nout == 0 || byte_len == 0)
+		return GEC_OK;
+	if (nblocks > 0xffffffffull / 4096 || (byte_len / 16) > 0x7fffffffull)
+		return fail(GEC_E_INVALID_ARG, "batch too large for one call");
+	gec::ApplyArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.in = in;
+	a.out = out;
+	a.bad = bad;
+	a.in_stride = in_stride;
+	a.out_stride = out_stride;
+	a.col0 = (uint32_t)(byte_off / 16);
+	a.cols = (uint32_t)(byte_len / 16);
+	a.nblocks = (uint32_t)nblocks;
+	a.tiles_per_block = (a.cols + gec::BLOCK - 1) / gec::BLOCK;
+	a.k = (uint32_t)k;
+	for (int t = 0; t < k; ++t) {
+		if (in_base_off[t] / 16 > 0xffffffffull)
+			return fail(GEC_E_INVALID_ARG, "stripe too large");
+		a.in_off[t] = (uint32_t)(in_base_off[t] / 16);
+	}
+	const uint64_t ntiles = (uint64_t)a.nblocks * a.tiles_per_block;
+	if (ntiles > 0xffffffffull)
+		return fail(GEC_E_INVALID_ARG, "batch too large for one call");
+	const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * 8);
+	const int variant = g_variant.load(std::memory_order_relaxed);
+	(void)S;
+	for (int r0 = 0; r0 < nout; r0 += gec::RMAX) {
+		const int rows = std::min(gec::RMAX, nout - r0);
+		a.rows = (uint32_t)rows;
+		for (int r = 0; r < rows; ++r) {
+			a.out_off[r] = (uint32_t)(out_base_off[r0 + r] / 16);
+			std::memcpy(a.mat[r], coef + (size_t)(r0 + r) * k, k);
+		}
+		if (variant == 1) {
+			if (mode == gec::MODE_STORE)
+				hipLaunchKernelGGL((gec::gf_apply_logexp<gec::MODE_STORE>), dim3(grid), dim3(gec::BLOCK), 0, stream, a, c->d_logexp);
+			else
+				hipLaunchKernelGGL((gec::gf_apply_logexp<gec::MODE_COMPARE>), dim3(grid), dim3(gec::BLOCK), 0, stream, a, c->d_logexp);
+		} else {
+			const int mw = rows <= 4 ? 1 : 2;
+			const size_t lds = (size_t)k * 32 * 4 * mw + 768;
+			if (mw == 1 && mode == gec::MODE_STORE)
+				launch_nibble<1, gec::MODE_STORE>(a, c->d_logexp, grid, lds, stream);
+			else if (mw == 1)
+				launch_nibble<1, gec::MODE_COMPARE>(a, c->d_logexp, grid, lds, stream);
+			else if (mode == gec::MODE_STORE)
+				launch_nibble<2, gec::MODE_STORE>(a, c->d_logexp, grid, lds, stream);
+			else
+				launch_nibble<2, gec::MODE_COMPARE>(a, c->d_logexp, grid, lds, stream);
+		}
+		HIP_TRY(hipGetLastError());
+	}
+	return GEC_OK;
+}
+
+int check_dev_layout(const void *p, size_t stride, size_t S, size_t need)
+{
+	if (S == 0)
+		return fail(GEC_E_EMPTY_SHARD, "shard length is 0");
+	if (S % 64 != 0)
+		return fail(GEC_E_INCORRECT_SHARD_SIZE, "S must be a multiple of 64");
+	if (!p)
+		return fail(GEC_E_INVALID_ARG, "NULL device pointer");
+	if (reinterpret_cast<uintptr_t>(p) % 16 != 0 || stride % 16 != 0)
+		return fail(GEC_E_INVALID_ARG, "device pointer/stride must be 16-byte aligned");
+	if (stride < need)
+		return fail(GEC_E_INCORRECT_SHARD_SIZE, "stride smaller than the shards it must hold");
+	return GEC_OK;
+}
+
+int encode_dev(const gec_codec *c, size_t nblocks, const uint8_t *d_data, size_t data_stride, size_t S,
+	       uint8_t *d_parity, size_t parity_stride, hipStream_t stream)
+{
+	const int k = c->k, m = c->m;
+	std::vector<size_t> in_off(k), out_off(m);
+	for (int t = 0; t < k; ++t)
+		in_off[t] = (size_t)t * S;
+	for (int r = 0; r < m; ++r)
+		out_off[r] = (size_t)r * S;
+	return launch_apply(c, d_data, data_stride, d_parity, parity_stride, nullptr, S, 0, S, nblocks, nullptr,
+			    in_off.data(), nullptr, out_off.data(), m, c->enc.row(k), gec::MODE_STORE, stream);
+}
+
+int verify_dev(const gec_codec *c, size_t nblocks, const uint8_t *d_stripes, size_t stride, size_t S,
+	       uint32_t *d_bad, hipStream_t stream)
+{
+	const int k = c->k, m = c->m;
+	std::vector<size_t> in_off(k), out_off(m);
+	for (int t = 0; t < k; ++t)
+		in_off[t] = (size_t)t * S;
+	for (int r = 0; r < m; ++r)
+		out_off[r] = (size_t)(k + r) * S;
+	HIP_TRY(hipMemsetAsync(d_bad, 0, nblocks * sizeof(uint32_t), stream));
+	return launch_apply(c, d_stripes, stride, const_cast<uint8_t *>(d_stripes), stride, d_bad, S, 0, S, nblocks,
+			    nullptr, in_off.data(), nullptr, out_off.data(), m, c->enc.row(k), gec::MODE_COMPARE,
+			    stream);
+}
+
+int reconstruct_dev(const gec_codec *c, size_t nblocks, uint8_t *d_stripes, size_t stride, size_t S,
+		    const uint8_t *present, bool data_only, size_t byte_off, size_t byte_len, hipStream_t stream)
+{
+	std::shared_ptr<const Plan> plan;
+	int rc = get_plan(c, present, data_only, plan);
+	if (rc)
+		return rc;
+	if (plan->missing.empty())
+		return GEC_OK;
+	const int k = c->k;
+	std::vector<size_t> in_off(k), out_off(plan->missing.size());
+	for (int t = 0; t < k; ++t)
+		in_off[t] = (size_t)plan->valid[t] * S;
+	for (size_t r = 0; r < plan->missing.size(); ++r)
+		out_off[r] = (size_t)plan->missing[r] * S;
+	return launch_apply(c, d_stripes, stride, d_stripes, stride, nullptr, S, byte_off, byte_len, nblocks, nullptr,
+			    in_off.data(), nullptr, out_off.data(), (int)plan->missing.size(), plan->rows.v.data(),
+			    gec::MODE_STORE, stream);
+}
+
+struct StagingLease {
+	const gec_codec *c;
+	Staging st;
+	explicit StagingLease(const gec_codec *cc) : c(cc)
+	{
+		std::lock_guard<std::mutex> g(c->pool_mu);
+		if (!c->pool.empty()) {
+			st = c->pool.back();
+			c->pool.pop_back();
+		}
+	}
+	~StagingLease()
+	{
+		std::lock_guard<std::mutex> g(c->pool_mu);
+		c->pool.push_back(st);
+	}
+};
+
+// blocks per staging chunk: keep chunks around 64 MiB so that staging memory is
+// bounded regardless of batch size.
+size_t chunk_blocks(size_t bytes_per_block, size_t nblocks)
+{
+	const size_t target = 64ull << 20;
+	size_t n = std::max<size_t>(1, target / std::max<size_t>(bytes_per_block, 1));
+	return std::min(n, nblocks);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+uint32_t gec_version(void) { return GEC_VERSION; }
+
+int gec_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+const char *gec_strerror(int code)
+{
+	switch (code) {
+	case GEC_OK: return "ok";
+	case GEC_E_TOO_FEW_SHARDS: return "too few shards";
+	case GEC_E_TOO_MANY_SHARDS: return "too many shards";
+	case GEC_E_TOO_FEW_DATA: return "too few data shards";
+	case GEC_E_TOO_MANY_DATA: return "too many data shards";
+	case GEC_E_TOO_FEW_PARITY: return "too few parity shards";
+	case GEC_E_TOO_MANY_PARITY: return "too many parity shards";
+	case GEC_E_INCORRECT_SHARD_SIZE: return "incorrect shard size";
+	case GEC_E_TOO_FEW_PRESENT: return "too few shards present";
+	case GEC_E_EMPTY_SHARD: return "empty shard";
+	case GEC_E_INVALID_INDEX: return "invalid index";
+	case GEC_E_DEVICE: return "device (HIP) error";
+	case GEC_E_NOMEM: return "out of memory";
+	case GEC_E_INVALID_ARG: return "invalid argument";
+	default: return "unknown error";
+	}
+}
+
+const char *gec_last_error(void) { return g_last_error.c_str(); }
+
+size_t gec_shard_len(int k, size_t block_len)
+{
+	if (k <= 0)
+		return 0;
+	size_t per = (std::max<size_t>(block_len, 1) + (size_t)k - 1) / (size_t)k;
+	return (per + 63) / 64 * 64;
+}
+
+int gec_build_matrix(int k, int m, uint8_t *out)
+{
+	int rc = check_km(k, m);
+	if (rc)
+		return rc;
+	if (!out)
+		return fail(GEC_E_INVALID_ARG, "NULL output");
+	gec::Matrix enc;
+	if (!gec::build_encoding_matrix(k, m, enc))
+		return fail(GEC_E_INVALID_ARG, "vandermonde top block singular");
+	std::memcpy(out, enc.v.data(), enc.v.size());
+	return GEC_OK;
+}
+
+int gec_build_decode_matrix(int k, int m, const uint8_t *present, int32_t *valid_out, uint8_t *out)
+{
+	int rc = check_km(k, m);
+	if (rc)
+		return rc;
+	if (!present || !valid_out || !out)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	gec::Matrix enc;
+	if (!gec::build_encoding_matrix(k, m, enc))
+		return fail(GEC_E_INVALID_ARG, "vandermonde top block singular");
+	int nv = 0;
+	for (int j = 0; j < k + m && nv < k; ++j)
+		if (present[j])
+			valid_out[nv++] = j;
+	if (nv < k)
+		return fail(GEC_E_TOO_FEW_PRESENT, "fewer than k shards present");
+	gec::Matrix sub(k, k), dec;
+	for (int t = 0; t < k; ++t)
+		std::memcpy(&sub.at(t, 0), enc.row(valid_out[t]), k);
+	if (!gec::invert(sub, dec))
+		return fail(GEC_E_INVALID_ARG, "decode sub-matrix singular");
+	std::memcpy(out, dec.v.data(), dec.v.size());
+	return GEC_OK;
+}
+
+int gec_codec_create(int k, int m, int device, gec_codec **out)
+{
+	if (!out)
+		return fail(GEC_E_INVALID_ARG, "NULL out");
+	*out = nullptr;
+	int rc = check_km(k, m);
+	if (rc)
+		return rc;
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0)
+		return fail(GEC_E_DEVICE, std::string("no HIP device available (libgarage_ec has no CPU fallback): ") +
+						  (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+	if (device < 0 || device >= ndev)
+		return fail(GEC_E_INVALID_ARG, "device index out of range");
+	std::unique_ptr<gec_codec> c(new (std::nothrow) gec_codec());
+	if (!c)
+		return fail(GEC_E_NOMEM, "alloc codec");
+	c->k = k;
+	c->m = m;
+	c->device = device;
+	if (!gec::build_encoding_matrix(k, m, c->enc))
+		return fail(GEC_E_INVALID_ARG, "vandermonde top block singular");
+	DeviceGuard g(device);
+	if (!g.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	gec::LogExp le;
+	const gec::Field &f = gec::field();
+	std::memcpy(le.exp, f.exp.data(), 512);
+	std::memcpy(le.log, f.log.data(), 256);
+	HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_logexp), sizeof(le)));
+	HIP_TRY(hipMemcpy(c->d_logexp, &le, sizeof(le), hipMemcpyHostToDevice));
+	*out = c.release();
+	return GEC_OK;
+}
+
+void gec_codec_destroy(gec_codec *c)
+{
+	if (!c)
+		return;
+	{
+		DeviceGuard g(c->device);
+		for (auto &s : c->pool)
+			s.release();
+		if (c->d_logexp)
+			(void)hipFree(c->d_logexp);
+	}
+	delete c;
+}
+
+int gec_codec_k(const gec_codec *c) { return c ? c->k : 0; }
+int gec_codec_m(const gec_codec *c) { return c ? c->m : 0; }
+int gec_codec_device(const gec_codec *c) { return c ? c->device : -1; }
+
+int gec_parity_matrix(const gec_codec *c, uint8_t *out)
+{
+	if (!c || !out)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	std::memcpy(out, c->enc.row(c->k), (size_t)c->m * c->k);
+	return GEC_OK;
+}
+
+int gec_codec_cache_stats(const gec_codec *c, uint64_t *cached, uint64_t *inversions)
+{
+	if (!c)
+		return fail(GEC_E_INVALID_ARG, "NULL codec");
+	std::lock_guard<std::mutex> g(c->cache_mu);
+	if (cached)
+		*cached = c->cache.size();
+	if (inversions)
+		*inversions = c->inversions;
+	return GEC_OK;
+}
+
+int gec_set_kernel_variant(int variant)
+{
+	if (variant < 0 || variant > 1)
+		return fail(GEC_E_INVALID_ARG, "unknown kernel variant");
+	g_variant.store(variant);
+	return GEC_OK;
+}
+
+int gec_get_kernel_variant(void) { return g_variant.load(); }
+
+// ------------------------------------------------------------ device API
+int gec_encode_batch_dev(const gec_codec *c, size_t nblocks, const void *d_data, size_t data_stride, size_t S,
+			 void *d_parity, size_t parity_stride, void *hip_stream)
+{
+	if (!c)
+		return fail(GEC_E_INVALID_ARG, "NULL codec");
+	if (nblocks == 0)
+		return GEC_OK;
+	int rc = check_dev_layout(d_data, data_stride, S, (size_t)c->k * S);
+	if (rc)
+		return rc;
+	rc = check_dev_layout(d_parity, parity_stride, S, (size_t)c->m * S);
+	if (rc)
+		return rc;
+	DeviceGuard g(c->device);
+	if (!g.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	return encode_dev(c, nblocks, static_cast<const uint8_t *>(d_data), data_stride, S,
+			  static_cast<uint8_t *>(d_parity), parity_stride, static_cast<hipStream_t>(hip_stream));
+}
+
+int gec_verify_batch_dev(const gec_codec *c, size_t nblocks, const void *d_stripes, size_t stride, size_t S,
+			 uint32_t *d_bad, void *hip_stream)
+{
+	if (!c || !d_bad)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (nblocks == 0)
+		return GEC_OK;
+	int rc = check_dev_layout(d_stripes, stride, S, (size_t)(c->k + c->m) * S);
+	if (rc)
+		return rc;
+	DeviceGuard g(c->device);
+	if (!g.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	return verify_dev(c, nblocks, static_cast<const uint8_t *>(d_stripes), stride, S, d_bad,
+			  static_cast<hipStream_t>(hip_stream));
+}
+
+int gec_reconstruct_range_dev(const gec_codec *c, size_t nblocks, void *d_stripes, size_t stride, size_t S,
+			      const uint8_t *present, int data_only, size_t byte_off, size_t byte_len,
+			      void *hip_stream)
+{
+	if (!c || !present)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (nblocks == 0)
+		return GEC_OK;
+	int rc = check_dev_layout(d_stripes, stride, S, (size_t)(c->k + c->m) * S);
+	if (rc)
+		return rc;
+	if (byte_off % 16 || byte_len % 16 || byte_off > S || byte_len > S - byte_off)
+		return fail(GEC_E_INVALID_ARG, "byte range must be 16-byte aligned and inside the shard");
+	DeviceGuard g(c->device);
+	if (!g.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	return reconstruct_dev(c, nblocks, static_cast<uint8_t *>(d_stripes), stride, S, present, data_only != 0,
+			       byte_off, byte_len, static_cast<hipStream_t>(hip_stream));
+}
+
+int gec_reconstruct_batch_dev(const gec_codec *c, size_t nblocks, void *d_stripes, size_t stride, size_t S,
+			      const uint8_t *present, int data_only, void *hip_stream)
+{
+	return gec_reconstruct_range_dev(c, nblocks, d_stripes, stride, S, present, data_only, 0, S, hip_stream);
+}
+
+// -------------------------------------------------------- host-pointer API
+int gec_encode_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *blocks, const size_t *block_len,
+		     size_t S, uint8_t *const *parity)
+{
+	if (!c)
+		return fail(GEC_E_INVALID_ARG, "NULL codec");
+	if (nblocks == 0)
+		return GEC_OK;
+	if (!blocks || !block_len || !parity)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (S == 0)
+		return fail(GEC_E_EMPTY_SHARD, "shard length is 0");
+	if (S % 64)
+		return fail(GEC_E_INCORRECT_SHARD_SIZE, "S must be a multiple of 64");
+	const size_t k = c->k, m = c->m, n = k + m;
+	for (size_t b = 0; b < nblocks; ++b) {
+		if (!blocks[b] || !parity[b])
+			return fail(GEC_E_INVALID_ARG, "NULL block/parity pointer");
+		if (block_len[b] > k * S)
+			return fail(GEC_E_INCORRECT_SHARD_SIZE, "block longer than k*S");
+	}
+	DeviceGuard g(c->device);
+	if (!g.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	StagingLease lease(c);
+	Staging &st = lease.st;
+	const size_t stripe = n * S;
+	const size_t ch = chunk_blocks(stripe, nblocks);
+	int rc = st.ensure(ch * stripe, 0);
+	if (rc)
+		return rc;
+	for (size_t b0 = 0; b0 < nblocks; b0 += ch) {
+		const size_t nb = std::min(ch, nblocks - b0);
+		for (size_t i = 0; i < nb; ++i) {
+			uint8_t *dst = st.h_buf + i * stripe;
+			const size_t len = block_len[b0 + i];
+			std::memcpy(dst, blocks[b0 + i], len);
+			std::memset(dst + len, 0, k * S - len);
+		}
+		// data shards only travel H2D (k*S per stripe); parity comes back D2H
+		HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, st.h_buf, stripe, k * S, nb, hipMemcpyHostToDevice, st.stream));
+		rc = encode_dev(c, nb, st.d_buf, stripe, S, st.d_buf + k * S, stripe, st.stream);
+		if (rc)
+			return rc;
+		HIP_TRY(hipMemcpy2DAsync(st.h_buf + k * S, stripe, st.d_buf + k * S, stripe, m * S, nb, hipMemcpyDeviceToHost, st.stream));
+		HIP_TRY(hipStreamSynchronize(st.stream));
+		for (size_t i = 0; i < nb; ++i)
+			std::memcpy(parity[b0 + i], st.h_buf + i * stripe + k * S, m * S);
+	}
+	return GEC_OK;
+}
+
+int gec_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, size_t S, uint8_t *ok)
+{
+	if (!c)
+		return fail(GEC_E_INVALID_ARG, "NULL codec");
+	if (nblocks == 0)
+		return GEC_OK;
+	if (!shards || !ok)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (S == 0)
+		return fail(GEC_E_EMPTY_SHARD, "shard length is 0");
+	if (S % 64)
+		return fail(GEC_E_INCORRECT_SHARD_SIZE, "S must be a multiple of 64");
+	const size_t n = c->k + c->m;
+	for (size_t i = 0; i < nblocks * n; ++i)
+		if (!shards[i])
+			return fail(GEC_E_TOO_FEW_SHARDS, "verify needs all k+m shards");
+	DeviceGuard g(c->device);
+	if (!g.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	StagingLease lease(c);
+	Staging &st = lease.st;
+	const size_t stripe = n * S;
+	const size_t ch = chunk_blocks(stripe, nblocks);
+	int rc = st.ensure(ch * stripe, ch);
+	if (rc)
+		return rc;
+	for (size_t b0 = 0; b0 < nblocks; b0 += ch) {
+		const size_t nb = std::min(ch, nblocks - b0);
+		for (size_t i = 0; i < nb; ++i)
+			for (size_t j = 0; j < n; ++j)
+				std::memcpy(st.h_buf + i * stripe + j * S, shards[(b0 + i) * n + j], S);
+		HIP_TRY(hipMemcpyAsync(st.d_buf, st.h_buf, nb * stripe, hipMemcpyHostToDevice, st.stream));
+		rc = verify_dev(c, nb, st.d_buf, stripe, S, st.d_bad, st.stream);
+		if (rc)
+			return rc;
+		HIP_TRY(hipMemcpyAsync(st.h_bad, st.d_bad, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st.stream));
+		HIP_TRY(hipStreamSynchronize(st.stream));
+		for (size_t i = 0; i < nb; ++i)
+			ok[b0 + i] = st.h_bad[i] ? 0 : 1;
+	}
+	return GEC_OK;
+}
+
+int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, uint8_t *const *out,
+			  size_t S, int data_only)
+{
+	if (!c)
+		return fail(GEC_E_INVALID_ARG, "NULL codec");
+	if (nblocks == 0)
+		return GEC_OK;
+	if (!shards || !out)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (S == 0)
+		return fail(GEC_E_EMPTY_SHARD, "shard length is 0");
+	if (S % 64)
+		return fail(GEC_E_INCORRECT_SHARD_SIZE, "S must be a multiple of 64");
+	const size_t k = c->k, n = c->k + c->m;
+	// bucket blocks by erasure pattern: one decode plan + one launch per bucket chunk
+	std::map<std::string, std::vector<size_t>> buckets;
+	for (size_t b = 0; b < nblocks; ++b) {
+		std::string key(n, 0);
+		size_t npresent = 0;
+		for (size_t j = 0; j < n; ++j) {
+			key[j] = shards[b * n + j] ? 1 : 0;
+			npresent += key[j];
+		}
+		if (npresent < k)
+			return fail(GEC_E_TOO_FEW_PRESENT, "fewer than k shards present");
+		for (size_t j = 0; j < n; ++j)
+			if (!key[j] && !(data_only && j >= k) && !out[b * n + j])
+				return fail(GEC_E_INVALID_ARG, "NULL output for a missing shard");
+		if (npresent < n)
+			buckets[key].push_back(b);
+	}
+	if (buckets.empty())
+		return GEC_OK;
+	DeviceGuard g(c->device);
+	if (!g.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	StagingLease lease(c);
+	Staging &st = lease.st;
+	const size_t stripe = n * S;
+	for (auto &kv : buckets) {
+		const std::string &key = kv.first;
+		const std::vector<size_t> &ids = kv.second;
+		const uint8_t *present = reinterpret_cast<const uint8_t *>(key.data());
+		const size_t ch = chunk_blocks(stripe, ids.size());
+		int rc = st.ensure(ch * stripe, 0);
+		if (rc)
+			return rc;
+		for (size_t i0 = 0; i0 < ids.size(); i0 += ch) {
+			const size_t nb = std::min(ch, ids.size() - i0);
+			for (size_t i = 0; i < nb; ++i)
+				for (size_t j = 0; j < n; ++j)
+					if (present[j])
+						std::memcpy(st.h_buf + i * stripe + j * S, shards[ids[i0 + i] * n + j], S);
+			HIP_TRY(hipMemcpyAsync(st.d_buf, st.h_buf, nb * stripe, hipMemcpyHostToDevice, st.stream));
+			rc = reconstruct_dev(c, nb, st.d_buf, stripe, S, present, data_only != 0, 0, S, st.stream);
+			if (rc)
+				return rc;
+			HIP_TRY(hipMemcpyAsync(st.h_buf, st.d_buf, nb * stripe, hipMemcpyDeviceToHost, st.stream));
+			HIP_TRY(hipStreamSynchronize(st.stream));
+			for (size_t i = 0; i < nb; ++i)
+				for (size_t j = 0; j < n; ++j)
+					if (!present[j] && !(data_only && j >= k))
+						std::memcpy(out[ids[i0 + i] * n + j], st.h_buf + i * stripe + j * S, S);
+		}
+	}
+	return GEC_OK;
+}
+
+}  // extern "C"

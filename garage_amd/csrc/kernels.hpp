@@ -1,0 +1,312 @@
+// kernels.hpp -- gfx950 (CDNA4) device code of libgarage_ec.
+//
+// One operation covers encode, reconstruct and verify:
+//
+//     out[r][b] = XOR_{t<k} mul(mat[r][t], in[t][b])      r < rows, b < S
+//
+// over GF(2^8)/0x11D, i.e. what reed-solomon-erasure's code_some_slices does
+// one MUL_TABLE lookup at a time [EXT core.rs; SURVEY.md Appendix A.3].
+//
+// MI355X mapping (DESIGN.md "Kernels" has the full derivation):
+//  * HBM-bound byte streaming, no MFMA: (k+rows) bytes of traffic per k payload
+//    bytes.  Each lane owns 16-byte columns: one global_load_dwordx4 per input
+//    shard (a wave covers 1 KiB contiguous per shard, 64-B aligned by the shard
+//    geometry), one global_store_dwordx4 per output shard.
+//  * GF multiply = two LDS lookups per data byte in *wide nibble product
+//    tables*: for input shard t, T_lo[t][x&15] and T_hi[t][x>>4] are 4-byte
+//    (rows<=4) or 8-byte (rows<=8) entries holding the products for ALL output
+//    rows at once, so one ds_read feeds every parity accumulator.  A 16-entry
+//    table occupies 16 (resp. 32) distinct LDS banks, and lanes that hit the
+//    same entry broadcast, so the lookups are bank-conflict-free for any data.
+//  * The tables are expanded per workgroup from the k x rows coefficient
+//    matrix with log/antilog LUTs that are themselves pinned in LDS.
+//  * Accumulators stay in VGPRs in "row-interleaved" form (byte r of a dword =
+//    output row r); a v_perm_b32 4x4 byte transpose per 4 columns turns them
+//    into per-shard dwords just before the store.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gec {
+
+constexpr int KMAX = 256;    // input shards per launch (k + m <= 256 => k <= 255)
+constexpr int RMAX = 8;      // output rows per launch
+constexpr int BLOCK = 256;   // threads per workgroup (4 waves)
+constexpr int MODE_STORE = 0, MODE_COMPARE = 2;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct ApplyArgs {
+	const uint8_t *in;   // input stripes base
+	uint8_t *out;        // output base (may alias `in`: rows never overlap inputs)
+	uint32_t *bad;       // MODE_COMPARE: bad[b] |= 1 on mismatch
+	uint64_t in_stride;  // bytes between consecutive blocks
+	uint64_t out_stride;
+	uint32_t col0;       // first 16-byte column of every shard to process
+	uint32_t cols;       // number of 16-byte columns to process
+	uint32_t nblocks;
+	uint32_t tiles_per_block;
+	uint32_t k;          // inputs  (<= KMAX)
+	uint32_t rows;       // outputs (<= RMAX)
+	uint32_t in_off[KMAX];   // shard offsets inside a block, in 16-byte units
+	uint32_t out_off[RMAX];
+	uint8_t mat[RMAX][KMAX];
+};
+
+// exp[512] | log[256], filled by the host from gec::Field (768 bytes).
+struct LogExp {
+	uint8_t exp[512];
+	uint8_t log[256];
+};
+
+__device__ __forceinline__ void transpose4x4(uint32_t a0, uint32_t a1, uint32_t a2,
+					     uint32_t a3, uint32_t &p0, uint32_t &p1,
+					     uint32_t &p2, uint32_t &p3)
+{
+	// a_j = (row0,row1,row2,row3) bytes at column j  ->  p_r = row r, columns 0..3
+	uint32_t t0 = __builtin_amdgcn_perm(a1, a0, 0x05010400u);
+	uint32_t t1 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+	uint32_t t2 = __builtin_amdgcn_perm(a3, a2, 0x05010400u);
+	uint32_t t3 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+	p0 = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+	p1 = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+	p2 = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+	p3 = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+}
+
+
+typedef __attribute__((address_space(3))) const uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) const u32x2 lds_u32x2_t;
+
+// base + byte P of `packed` in ONE VALU op: SDWA selects the byte, the table base
+// rides in as the scalar operand.  (hipcc emits shift+and+add for the same C.)
+template <int P>
+__device__ __forceinline__ uint32_t add_byte(uint32_t sbase, uint32_t packed)
+{
+	uint32_t r;
+	if (P == 0)
+		asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(sbase), "v"(packed));
+	else if (P == 1)
+		asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(sbase), "v"(packed));
+	else if (P == 2)
+		asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "s"(sbase), "v"(packed));
+	else
+		asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "s"(sbase), "v"(packed));
+	return r;
+}
+
+// acc ^= T_lo[lo nibble of byte P] ^ T_hi[hi nibble of byte P]
+template <int MW, int P>
+__device__ __forceinline__ void lut_acc(uint32_t tb, uint32_t lo, uint32_t hi, uint32_t (&acc)[MW])
+{
+	const uint32_t al = add_byte<P>(tb, lo);
+	const uint32_t ah = add_byte<P>(tb, hi);
+	if (MW == 1) {
+		acc[0] ^= *reinterpret_cast<lds_u32_t *>(al) ^ *reinterpret_cast<lds_u32_t *>(ah + 64);
+	} else {
+		const u32x2 vl = *reinterpret_cast<lds_u32x2_t *>(al);
+		const u32x2 vh = *reinterpret_cast<lds_u32x2_t *>(ah + 128);
+		acc[0] ^= vl.x ^ vh.x;
+		acc[MW - 1] ^= vl.y ^ vh.y;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Default kernel: wide nibble product tables in LDS.
+//   MW   = dwords per table entry (1: rows<=4, 2: rows<=8)
+//   MODE = store / xor-into-existing / compare-with-existing
+//   KC   = input shards loaded per batch (loads in flight per lane)
+// ---------------------------------------------------------------------------
+template <int MW, int MODE, int KC>
+__global__ __launch_bounds__(BLOCK) void gf_apply_nibble(const ApplyArgs a, const LogExp *__restrict__ le)
+{
+	constexpr int ENT = 4 * MW;            // bytes per table entry
+	constexpr int TBL = 32 * ENT;          // bytes per input shard (lo 16 | hi 16)
+	// single dynamic LDS object (no static __shared__ in front of it, so the base
+	// stays 16-byte aligned): [tables k*TBL][exp 512][log 256]
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t k = a.k, rows = a.rows;
+	uint8_t *lexp = lds + k * TBL;
+	uint8_t *llog = lexp + 512;
+	const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds;
+
+	// -- prologue 1: pin log/antilog in LDS
+	for (uint32_t i = tid; i < 768 / 4; i += BLOCK)
+		reinterpret_cast<uint32_t *>(lexp)[i] = reinterpret_cast<const uint32_t *>(le)[i];
+	__syncthreads();
+	// -- prologue 2: expand mat[rows][k] into wide nibble product tables
+	for (uint32_t idx = tid; idx < k * 32; idx += BLOCK) {
+		const uint32_t t = idx >> 5, e = idx & 31;
+		const uint32_t x = e < 16 ? e : (e - 16) << 4;
+		uint32_t w[2] = {0, 0};
+		if (x) {
+			const uint32_t lx = llog[x];
+#pragma unroll
+			for (int r = 0; r < 4 * MW; ++r) {
+				uint32_t c = (r < (int)rows) ? a.mat[r][t] : 0;
+				uint32_t p = c ? lexp[llog[c] + lx] : 0;
+				w[r >> 2] |= p << (8 * (r & 3));
+			}
+		}
+		uint32_t *dst = reinterpret_cast<uint32_t *>(lds + t * TBL + e * ENT);
+		dst[0] = w[0];
+		if (MW == 2)
+			dst[1] = w[1];
+	}
+	__syncthreads();
+
+	const uint32_t ntiles = a.nblocks * a.tiles_per_block;
+	for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		const uint32_t b = tile / a.tiles_per_block;
+		const uint32_t col = (tile - b * a.tiles_per_block) * BLOCK + tid;
+		if (col >= a.cols)
+			continue;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.in + (uint64_t)b * a.in_stride) + a.col0 + col;
+		u32x4 *dst = reinterpret_cast<u32x4 *>(a.out + (uint64_t)b * a.out_stride) + a.col0 + col;
+
+		// acc[w][j][h]: dword w of the column, byte position j, row half h
+		uint32_t acc[4][4][MW];
+#pragma unroll
+		for (int w = 0; w < 4; ++w)
+#pragma unroll
+			for (int j = 0; j < 4; ++j)
+#pragma unroll
+				for (int h = 0; h < MW; ++h)
+					acc[w][j][h] = 0;
+
+		for (uint32_t t0 = 0; t0 < k; t0 += KC) {
+			u32x4 d[KC];
+#pragma unroll
+			for (int j = 0; j < KC; ++j)
+				if (t0 + j < k)
+					d[j] = __builtin_nontemporal_load(src + a.in_off[t0 + j]);
+#pragma unroll
+			for (int j = 0; j < KC; ++j) {
+				if (t0 + j >= k)
+					break;
+				// absolute LDS byte address of this shard's lo table (wave-uniform -> SGPR)
+				const uint32_t tb = __builtin_amdgcn_readfirstlane(lds_base + (t0 + j) * TBL);
+				const uint32_t xs[4] = {d[j].x, d[j].y, d[j].z, d[j].w};
+#pragma unroll
+				for (int w = 0; w < 4; ++w) {
+					const uint32_t x = xs[w];
+					// entry byte offsets of the lo / hi nibbles of all 4 bytes at once
+					const uint32_t lo = (MW == 1) ? ((x << 2) & 0x3C3C3C3Cu) : ((x << 3) & 0x78787878u);
+					const uint32_t hi = (MW == 1) ? ((x >> 2) & 0x3C3C3C3Cu) : ((x >> 1) & 0x78787878u);
+					lut_acc<MW, 0>(tb, lo, hi, acc[w][0]);
+					lut_acc<MW, 1>(tb, lo, hi, acc[w][1]);
+					lut_acc<MW, 2>(tb, lo, hi, acc[w][2]);
+					lut_acc<MW, 3>(tb, lo, hi, acc[w][3]);
+				}
+			}
+		}
+
+		// row-interleaved accumulators -> per-shard dwords
+		uint32_t P[4 * MW][4];
+#pragma unroll
+		for (int h = 0; h < MW; ++h)
+#pragma unroll
+			for (int w = 0; w < 4; ++w)
+				transpose4x4(acc[w][0][h], acc[w][1][h], acc[w][2][h], acc[w][3][h],
+					     P[4 * h + 0][w], P[4 * h + 1][w], P[4 * h + 2][w], P[4 * h + 3][w]);
+
+		uint32_t diff = 0;
+#pragma unroll
+		for (int r = 0; r < 4 * MW; ++r) {
+			if (r >= (int)rows)
+				break;
+			u32x4 v = {P[r][0], P[r][1], P[r][2], P[r][3]};
+			u32x4 *o = dst + a.out_off[r];
+			if (MODE == MODE_STORE) {
+				__builtin_nontemporal_store(v, o);
+			} else {
+				u32x4 old = __builtin_nontemporal_load(o);
+				diff |= (v.x ^ old.x) | (v.y ^ old.y) | (v.z ^ old.z) | (v.w ^ old.w);
+			}
+		}
+		if (MODE == MODE_COMPARE && diff)
+			a.bad[b] = 1u;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// Baseline kernel (variant 1): the literal north_star formulation -- per-byte
+// log/antilog lookups in LDS, one GF multiply per (byte, row).  Kept only as the
+// measured "before" of DESIGN.md; same results, ~an order of magnitude more LDS
+// traffic (conflict-prone byte gathers) than the nibble product tables.
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void gf_apply_logexp(const ApplyArgs a, const LogExp *__restrict__ le)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t lds[768 + RMAX * KMAX];
+	uint8_t *lexp = lds;
+	uint8_t *llog = lds + 512;
+	uint8_t *lcoef = lds + 768;  // log of coefficient, 0xff marks a zero coefficient
+	const uint32_t tid = threadIdx.x;
+	const uint32_t k = a.k, rows = a.rows;
+	for (uint32_t i = tid; i < 768 / 4; i += BLOCK)
+		reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(le)[i];
+	__syncthreads();
+	for (uint32_t i = tid; i < RMAX * KMAX; i += BLOCK) {
+		uint32_t r = i / KMAX, t = i % KMAX;
+		uint8_t c = (r < rows && t < k) ? a.mat[r][t] : 0;
+		lcoef[i] = c ? llog[c] : 0xff;
+	}
+	__syncthreads();
+
+	const uint32_t ntiles = a.nblocks * a.tiles_per_block;
+	for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		const uint32_t b = tile / a.tiles_per_block;
+		const uint32_t col = (tile - b * a.tiles_per_block) * BLOCK + tid;
+		if (col >= a.cols)
+			continue;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.in + (uint64_t)b * a.in_stride) + a.col0 + col;
+		u32x4 *dst = reinterpret_cast<u32x4 *>(a.out + (uint64_t)b * a.out_stride) + a.col0 + col;
+		uint32_t P[RMAX][4];
+#pragma unroll
+		for (int r = 0; r < RMAX; ++r)
+#pragma unroll
+			for (int w = 0; w < 4; ++w)
+				P[r][w] = 0;
+		for (uint32_t t = 0; t < k; ++t) {
+			const u32x4 d = src[a.in_off[t]];
+			const uint32_t xs[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+			for (int w = 0; w < 4; ++w)
+#pragma unroll
+				for (int p = 0; p < 4; ++p) {
+					const uint32_t x = (xs[w] >> (8 * p)) & 0xffu;
+					const uint32_t lx = llog[x];
+#pragma unroll
+					for (int r = 0; r < RMAX; ++r) {
+						if (r >= (int)rows)
+							break;
+						const uint32_t lc = lcoef[r * KMAX + t];
+						const uint32_t prod = (x && lc != 0xff) ? lexp[lx + lc] : 0;
+						P[r][w] ^= prod << (8 * p);
+					}
+				}
+		}
+		uint32_t diff = 0;
+#pragma unroll
+		for (int r = 0; r < RMAX; ++r) {
+			if (r >= (int)rows)
+				break;
+			u32x4 v = {P[r][0], P[r][1], P[r][2], P[r][3]};
+			u32x4 *o = dst + a.out_off[r];
+			if (MODE == MODE_STORE) {
+				*o = v;
+			} else {
+				u32x4 old = *o;
+				diff |= (v.x ^ old.x) | (v.y ^ old.y) | (v.z ^ old.z) | (v.w ^ old.w);
+			}
+		}
+		if (MODE == MODE_COMPARE && diff)
+			a.bad[b] = 1u;
+	}
+}
+
+}  // namespace gec

@@ -1,0 +1,180 @@
+/*
+ * garage_ec.h -- C ABI of libgarage_ec.so, the MI355X (gfx950) Reed-Solomon
+ * engine for Garage's object-block write/read path.
+ *
+ * Garage has NO plugin/FFI interface at this spot: the
+ * only codec hook is the hard-wired zstd call in
+ *   src/block/manager.rs:375-378  (DataBlock::from_buffer inside rpc_put_block)
+ * so every entry point below cites the reference code it slots in next to /
+ * replaces, and -- for the arithmetic -- the `reed-solomon-erasure::galois_8`
+ * API [EXT, crate not vendored] whose results it must reproduce bit-exactly.
+ * A Rust caller uses it exactly like zstd is used today: a blocking call inside
+ * tokio::task::spawn_blocking (src/block/block.rs:85-96).  INTEGRATION.md has
+ * the `extern "C"` binding a Garage maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no exceptions/aborts cross the boundary;
+ *  - return 0 (GEC_OK) or a negative code; gec_last_error() gives thread-local
+ *    detail (e.g. hipGetErrorString);
+ *  - a codec is immutable after creation and may be shared by any number of
+ *    threads (Rust: Send + Sync); every entry point is blocking w.r.t. host
+ *    buffers; *_dev entry points are asynchronous on the given HIP stream;
+ *  - all shard data is computed on the GPU by hand-written HIP kernels; there
+ *    is NO CPU fallback: without a usable device gec_codec_create fails with
+ *    GEC_E_DEVICE.
+ *
+ * Shard geometry: a block of L bytes is cut into k
+ * data shards of S = round_up(ceil(L/k), 64) bytes, shard i = block bytes
+ * [i*S, (i+1)*S) zero-extended, so data shards are zero-copy slices of the
+ * (padded) block buffer and every shard starts on a 64-byte line.
+ */
+#ifndef GARAGE_EC_H
+#define GARAGE_EC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEC_VERSION 0x00010000u /* major.minor.patch = 0.1.0 */
+#define GEC_MAX_SHARDS 256      /* GF(2^8): k + m <= 256 [EXT] */
+
+typedef struct gec_codec gec_codec; /* opaque */
+
+/* Error codes: -1..-10 mirror reed_solomon_erasure::Error [EXT]; the Rust shim
+ * maps them next to Error::CorruptData / Error::MissingBlock
+ * (src/util/error.rs:70-77). */
+enum {
+	GEC_OK = 0,
+	GEC_E_TOO_FEW_SHARDS = -1,
+	GEC_E_TOO_MANY_SHARDS = -2,
+	GEC_E_TOO_FEW_DATA = -3,
+	GEC_E_TOO_MANY_DATA = -4,
+	GEC_E_TOO_FEW_PARITY = -5,
+	GEC_E_TOO_MANY_PARITY = -6,
+	GEC_E_INCORRECT_SHARD_SIZE = -7,
+	GEC_E_TOO_FEW_PRESENT = -8,
+	GEC_E_EMPTY_SHARD = -9,
+	GEC_E_INVALID_INDEX = -10,
+	GEC_E_DEVICE = -100,     /* HIP failure / no GPU; see gec_last_error() */
+	GEC_E_NOMEM = -101,
+	GEC_E_INVALID_ARG = -102 /* NULL pointer, misaligned device buffer, ... */
+};
+
+/* ------------------------------------------------------------- library */
+uint32_t gec_version(void);
+/* Number of usable HIP devices (0 => every gec_codec_create fails). */
+int gec_device_count(void);
+const char *gec_strerror(int code);
+/* Thread-local detail string of the last failing call on this thread. */
+const char *gec_last_error(void);
+
+/* ------------------------------------------------- host logic (no GPU) */
+/* S = round_up(ceil(block_len/k), 64); 0 if k <= 0.  Decides how
+ * rpc_put_block's `data: Bytes` (src/block/manager.rs:366-371) is sliced. */
+size_t gec_shard_len(int k, size_t block_len);
+/* (k+m) x k systematic encoding matrix, row-major.
+ * == ReedSolomon::new(k,m) internal matrix [EXT core.rs build_matrix]. */
+int gec_build_matrix(int k, int m, uint8_t *out_n_by_k);
+/* present[k+m] (0/1).  valid_out[k] = first k present shard indices,
+ * out_k_by_k = inverse of those rows [EXT core.rs get_data_decode_matrix]. */
+int gec_build_decode_matrix(int k, int m, const uint8_t *present,
+			    int32_t *valid_out, uint8_t *out_k_by_k);
+
+/* --------------------------------------------------------------- codec */
+/* == ReedSolomon::new(data_shards, parity_shards) [EXT]; belongs in
+ * BlockManager::new (src/block/manager.rs:122-192) next to the
+ * compression_level / data_fsync fields, built from new Config keys.
+ * Argument errors are reported before the device is touched. */
+int gec_codec_create(int k, int m, int device, gec_codec **out);
+void gec_codec_destroy(gec_codec *c);
+int gec_codec_k(const gec_codec *c);
+int gec_codec_m(const gec_codec *c);
+int gec_codec_device(const gec_codec *c);
+/* m x k parity rows of this codec (test introspection). */
+int gec_parity_matrix(const gec_codec *c, uint8_t *out_m_by_k);
+/* Number of decode matrices currently cached / total inversions performed
+ * (the crate keeps an LRU of decode matrices per erasure pattern [EXT]). */
+int gec_codec_cache_stats(const gec_codec *c, uint64_t *cached,
+			  uint64_t *inversions);
+
+/* ------------------------------------------------ host-pointer entry points
+ * What the Rust shim calls.  Caller owns every buffer for the duration of the
+ * call; the library keeps no pointer after return. */
+
+/* == ReedSolomon::encode_sep(&data, &mut parity) [EXT], batched.
+ * Replaces the "clone the same Bytes to rf nodes" fan-out payload of
+ * rpc_put_block (src/block/manager.rs:387-405; src/rpc/rpc_helper.rs:493):
+ * blocks[b] is block b's payload (block_len[b] bytes); data shard i is bytes
+ * [i*S,(i+1)*S) zero-extended; parity[b] receives m consecutive shards of S
+ * bytes.  S must be a multiple of 64 and >= gec_shard_len(k, block_len[b]). */
+int gec_encode_batch(const gec_codec *c, size_t nblocks,
+		     const uint8_t *const *blocks, const size_t *block_len,
+		     size_t S, uint8_t *const *parity);
+
+/* == ReedSolomon::verify(&shards) [EXT], batched; the scrub-worker check that
+ * replaces DataBlock::verify's blake2 compare for shards
+ * (src/block/block.rs:69-83, src/block/repair.rs:450-458).
+ * shards[b*(k+m) + j] = shard j of block b (S bytes); ok[b] = 1 iff consistent. */
+int gec_verify_batch(const gec_codec *c, size_t nblocks,
+		     const uint8_t *const *shards, size_t S, uint8_t *ok);
+
+/* == ReedSolomon::reconstruct / reconstruct_data [EXT], batched; sits where
+ * rpc_get_raw_block_internal returns the first whole block it finds
+ * (src/block/manager.rs:292-334) and where resync_block fetches an absent
+ * block (src/block/resync.rs:485-499).
+ * shards[b*n + j] == NULL => shard j of block b is missing and is written to
+ * out[b*n + j] (S bytes); out entries of present shards are ignored; with
+ * data_only != 0 missing parity shards are skipped (out entry may be NULL).
+ * Fewer than k present shards in any block => GEC_E_TOO_FEW_PRESENT. */
+int gec_reconstruct_batch(const gec_codec *c, size_t nblocks,
+			  const uint8_t *const *shards, uint8_t *const *out,
+			  size_t S, int data_only);
+
+/* --------------------------------------------- device-resident entry points
+ * Used by bench.py (no PCIe in the timed region) and by callers that already
+ * hold blocks in HBM.  All device pointers must be 16-byte aligned, strides
+ * multiples of 16, S a multiple of 64; `hip_stream` is a hipStream_t (NULL =
+ * default stream).  Asynchronous: returns after enqueueing. */
+
+/* data shard i of block b at d_data + b*data_stride + i*S; parity r of block b
+ * at d_parity + b*parity_stride + r*S. */
+int gec_encode_batch_dev(const gec_codec *c, size_t nblocks, const void *d_data,
+			 size_t data_stride, size_t S, void *d_parity,
+			 size_t parity_stride, void *hip_stream);
+
+/* stripe layout: shard j (0..k+m) of block b at d_stripes + b*stride + j*S.
+ * d_bad[b] (uint32) is set to 0 if parity is consistent, else non-zero. */
+int gec_verify_batch_dev(const gec_codec *c, size_t nblocks,
+			 const void *d_stripes, size_t stride, size_t S,
+			 uint32_t *d_bad, void *hip_stream);
+
+/* One erasure pattern for the whole batch: present[k+m] (host, 0/1).  Missing
+ * shards are rebuilt in place inside each stripe.  Host-side decode-matrix
+ * inversion happens here (cached per pattern). */
+int gec_reconstruct_batch_dev(const gec_codec *c, size_t nblocks,
+			      void *d_stripes, size_t stride, size_t S,
+			      const uint8_t *present, int data_only,
+			      void *hip_stream);
+
+/* Same, restricted to bytes [byte_off, byte_off+byte_len) of every shard
+ * (both multiples of 16): after the all-gather of a striped object each GPU
+ * rebuilds its 1/n byte-range of every missing shard. */
+int gec_reconstruct_range_dev(const gec_codec *c, size_t nblocks,
+			      void *d_stripes, size_t stride, size_t S,
+			      const uint8_t *present, int data_only,
+			      size_t byte_off, size_t byte_len,
+			      void *hip_stream);
+
+/* Kernel selection for A/B measurements (bench.py --variant).  0 = default
+ * (nibble product tables in LDS), 1 = log/antilog tables in LDS (the literal
+ * north_star formulation, kept as the measured baseline).  Process-wide. */
+int gec_set_kernel_variant(int variant);
+int gec_get_kernel_variant(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GARAGE_EC_H */

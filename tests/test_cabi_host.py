@@ -1,0 +1,102 @@
+"""CPU-only checks of the drop-in boundary: libgarage_ec.so loads, exports every
+symbol include/garage_ec.h declares, and its host logic (geometry, matrices,
+argument/error behaviour) agrees with the oracle.  No kernels run here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import garage_amd as g
+from garage_amd import _lib
+from oracle import rs_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "garage_ec.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gec_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported():
+    names = header_functions()
+    assert len(names) >= 20
+    assert sorted(_lib.SYMBOLS) == names, "garage_amd/_lib.py SYMBOLS out of sync with the header"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_version_and_strerror():
+    assert _lib.lib.gec_version() == 0x00010000
+    assert _lib.lib.gec_strerror(0) == b"ok"
+    assert b"present" in _lib.lib.gec_strerror(_lib.GEC_E_TOO_FEW_PRESENT)
+    assert _lib.lib.gec_device_count() >= 0
+
+
+@pytest.mark.parametrize("k,L,S", [(3, 65536, 21888), (10, 1048576, 104896), (20, 4194304, 209728),
+                                   (10, 0, 64), (10, 1, 64), (10, 640, 64), (10, 641, 128), (1, 100, 128)])
+def test_shard_len(k, L, S):
+    assert g.shard_len(k, L) == S == O.shard_len(k, L)
+
+
+def test_shard_len_bad_k():
+    assert g.shard_len(0, 100) == 0
+
+
+@pytest.mark.parametrize("k,m", [(3, 1), (10, 4), (20, 8), (5, 5), (1, 1), (2, 3), (17, 3), (100, 20), (200, 56), (255, 1)])
+def test_encoding_matrix_matches_oracle(k, m):
+    M = g.build_matrix(k, m)
+    assert np.array_equal(M, O.build_matrix(k, m))
+    assert np.array_equal(M[:k], np.eye(k, dtype=np.uint8))
+
+
+def test_decode_matrix_matches_oracle_and_kat():
+    present = [j not in (0, 3, 7, 11) for j in range(14)]
+    valid, D = g.build_decode_matrix(10, 4, present)
+    assert valid == [1, 2, 4, 5, 6, 8, 9, 10, 12, 13]
+    assert D[0].tolist() == [204, 75, 104, 156, 114, 211, 108, 57, 186, 60]
+    rng = np.random.default_rng(3)
+    for k, m in [(3, 1), (10, 4), (20, 8), (6, 6)]:
+        for _ in range(10):
+            lost = rng.choice(k + m, size=rng.integers(0, m + 1), replace=False)
+            present = [j not in lost for j in range(k + m)]
+            v, D = g.build_decode_matrix(k, m, present)
+            v2, D2 = O.decode_matrix(k, m, present)
+            assert v == v2 and np.array_equal(D, D2)
+
+
+def test_error_codes_mirror_the_crate():
+    # ReedSolomon::new argument errors come before any device access
+    for k, m, code in [(0, 4, _lib.GEC_E_TOO_FEW_DATA), (-1, 4, _lib.GEC_E_TOO_FEW_DATA),
+                       (4, 0, _lib.GEC_E_TOO_FEW_PARITY), (200, 57, _lib.GEC_E_TOO_MANY_SHARDS)]:
+        with pytest.raises(g.GecError) as ei:
+            g.ReedSolomon(k, m)
+        assert ei.value.code == code
+        with pytest.raises(g.GecError) as ei:
+            g.build_matrix(k, m)
+        assert ei.value.code == code
+    with pytest.raises(g.GecError) as ei:
+        g.build_decode_matrix(4, 2, [1, 1, 1, 0, 0, 0])
+    assert ei.value.code == _lib.GEC_E_TOO_FEW_PRESENT
+
+
+def test_no_cpu_fallback_without_gpu():
+    if _lib.lib.gec_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(g.GecError) as ei:
+        g.ReedSolomon(10, 4)
+    assert ei.value.code == _lib.GEC_E_DEVICE
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "garage_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "rs_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f

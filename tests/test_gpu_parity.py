@@ -1,0 +1,407 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs -- bit-exact (integer/byte arithmetic, no
+tolerance).  Small cases compare every byte with the oracle; BASELINE.json's
+full-size configs use size-independent properties (encode -> erase -> decode
+round trip, verify, linearity) plus an oracle spot-check of a few blocks."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import garage_amd as g  # noqa: E402
+from garage_amd import _lib  # noqa: E402
+from oracle import rs_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def sha(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint8).tobytes()).hexdigest()
+
+
+def rand_blocks(seed, nb, k, S):
+    return O.splitmix64_bytes(0x6761726167650001 + seed, nb * k * S).reshape(nb, k, S)
+
+
+def gpu_encode(rs, data_np):
+    d = torch.from_numpy(data_np).to(DEV)
+    p = rs.encode_sep_dev(d)
+    torch.cuda.synchronize()
+    return p.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def rs104():
+    return g.ReedSolomon(10, 4)
+
+
+# ------------------------------------------------------------ known answers
+def test_kat_one_encode_5_5_through_cabi():
+    # SURVEY.md Appendix A.4.3, shards padded to the 64-byte geometry
+    rs = g.ReedSolomon(5, 5)
+    data = np.zeros((1, 5, 64), dtype=np.uint8)
+    data[0, :, :2] = [[0, 1], [4, 5], [2, 3], [6, 7], [8, 9]]
+    par = gpu_encode(rs, data)
+    assert par[0, :, :2].tolist() == [[12, 13], [10, 11], [14, 15], [90, 91], [94, 95]]
+    assert not par[0, :, 2:].any()
+
+
+@pytest.mark.parametrize("k,m,L,digest", [
+    (3, 1, 64, "a1a2e6472297a6c8fc595265fbc01ecb82954e148bc46107d916c1f876f5dbb6"),
+    (10, 4, 64, "716c5f64eecea82d320f527c7837757e9a9effaaf219169d6e52e2e5f80b021d"),
+    (10, 4, 4096, "473009bcb1d7ca2a705463acf8a5788977d23115a3d6a3bb29b880dcbb7a5860"),
+    (20, 8, 64, "9faa9f8192c1e5573f78dac342858bbc6b2cd98f46f118d467e84d3cfc2c42a5"),
+])
+def test_golden_encode_digests(k, m, L, digest):
+    # SURVEY.md Appendix A.4.6
+    rs = g.ReedSolomon(k, m)
+    par = gpu_encode(rs, O.golden_pattern(k, L)[None])
+    assert sha(par[0]) == digest
+
+
+def test_parity_matrix_introspection(rs104):
+    assert np.array_equal(rs104.parity_matrix(), O.parity_matrix(10, 4))
+    assert rs104.data_shard_count() == 10 and rs104.parity_shard_count() == 4
+
+
+# ------------------------------------------------- encode == oracle, bytewise
+ENCODE_CASES = [
+    # (k, m, S, nblocks)
+    (3, 1, 21888, 16),     # BASELINE config 1 shape
+    (10, 4, 104896, 3),    # config 2 shard length
+    (20, 8, 209728, 2),    # config 5 shard length
+    (10, 4, 64, 1),        # one 16-byte-column row per lane, mostly idle lanes
+    (10, 4, 4160, 5),      # ragged tile (260 columns)
+    (1, 1, 128, 2), (2, 3, 192, 3), (5, 5, 320, 2), (17, 3, 1024, 2),
+    (4, 8, 512, 2),        # 8-byte table entries
+    (11, 7, 4096, 2),
+    (40, 12, 2048, 2),     # k beyond one load batch, rows > 8 (two launches)
+    (100, 20, 256, 1),
+    (200, 56, 64, 1),      # k + m = 256
+]
+
+
+@pytest.mark.parametrize("k,m,S,nb", ENCODE_CASES)
+def test_encode_matches_oracle(coracle, k, m, S, nb):
+    rs = g.ReedSolomon(k, m)
+    data = rand_blocks(k * 31 + m, nb, k, S)
+    data[0, 0, :] = 0          # all-zero shard
+    data[-1, -1, :] = 0xFF     # all-0xFF shard
+    want = coracle.encode_batch(k, m, data, coracle.AVX2, threads=4)
+    got = gpu_encode(rs, data)
+    assert np.array_equal(got, want)
+
+
+def test_encode_logexp_variant_matches(coracle):
+    k, m, S, nb = 10, 4, 8192, 3
+    rs = g.ReedSolomon(k, m)
+    data = rand_blocks(99, nb, k, S)
+    want = coracle.encode_batch(k, m, data, coracle.AVX2)
+    try:
+        g.set_kernel_variant(1)
+        got = gpu_encode(rs, data)
+    finally:
+        g.set_kernel_variant(0)
+    assert np.array_equal(got, want)
+    rs8 = g.ReedSolomon(6, 8)
+    d8 = rand_blocks(98, 2, 6, 1024)
+    try:
+        g.set_kernel_variant(1)
+        got8 = gpu_encode(rs8, d8)
+    finally:
+        g.set_kernel_variant(0)
+    assert np.array_equal(got8, coracle.encode_batch(6, 8, d8, coracle.AVX2))
+
+
+def test_encode_in_place_stripes_and_nondefault_stream(coracle):
+    k, m, S, nb = 10, 4, 4096, 4
+    rs = g.ReedSolomon(k, m)
+    data = rand_blocks(5, nb, k, S)
+    st = torch.zeros((nb, k + m, S), dtype=torch.uint8, device=DEV)
+    st[:, :k] = torch.from_numpy(data).to(DEV)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        rs.encode_dev(st)
+    s.synchronize()
+    out = st.cpu().numpy()
+    assert np.array_equal(out[:, :k], data)
+    assert np.array_equal(out[:, k:], coracle.encode_batch(k, m, data, coracle.AVX2))
+
+
+# ----------------------------------------------------------- reconstruct
+PATTERNS_10_4 = [
+    (0, 3, 7, 9),      # BASELINE config 3 worst case: 4 data shards
+    (0, 3, 7, 11),     # mixed (Appendix A.4.7 KAT pattern)
+    (10, 11, 12, 13),  # parity only
+    (4,), (13,), (0, 13), (9, 10, 11),
+]
+
+
+@pytest.mark.parametrize("lost", PATTERNS_10_4)
+@pytest.mark.parametrize("data_only", [False, True])
+def test_reconstruct_matches_oracle(coracle, rs104, lost, data_only):
+    k, m, S, nb = 10, 4, 8256, 3
+    data = rand_blocks(17, nb, k, S)
+    full = np.concatenate([data, coracle.encode_batch(k, m, data, coracle.AVX2)], axis=1)
+    present = [j not in lost for j in range(k + m)]
+    broken = full.copy()
+    broken[:, list(lost)] = 0xA5
+    want = coracle.reconstruct_batch(k, m, broken, present, data_only=data_only)
+    st = torch.from_numpy(broken).to(DEV)
+    rs104.reconstruct_dev(st, present, data_only=data_only)
+    torch.cuda.synchronize()
+    got = st.cpu().numpy()
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[:, :k], data)
+    if not data_only:
+        assert np.array_equal(got, full)
+    else:
+        for j in lost:
+            if j >= k:
+                assert (got[:, j] == 0xA5).all(), "data_only must not touch missing parity"
+
+
+@pytest.mark.parametrize("k,m", [(3, 1), (20, 8), (5, 5), (2, 3), (40, 12)])
+def test_reconstruct_random_patterns(coracle, k, m):
+    rs = g.ReedSolomon(k, m)
+    rng = np.random.default_rng(k * 7 + m)
+    S, nb = 1088, 2
+    data = rand_blocks(k + m, nb, k, S)
+    full = np.concatenate([data, coracle.encode_batch(k, m, data, coracle.AVX2)], axis=1)
+    for _ in range(5):
+        lost = rng.choice(k + m, size=rng.integers(1, m + 1), replace=False)
+        present = [j not in lost for j in range(k + m)]
+        broken = full.copy()
+        broken[:, lost] = rng.integers(0, 256, dtype=np.uint8)
+        st = torch.from_numpy(broken).to(DEV)
+        rs.reconstruct_dev(st, present)
+        torch.cuda.synchronize()
+        assert np.array_equal(st.cpu().numpy(), full)
+    cached, inversions = rs.cache_stats()
+    assert 1 <= cached <= inversions
+
+
+def test_reconstruct_too_few_present(rs104):
+    st = torch.zeros((1, 14, 64), dtype=torch.uint8, device=DEV)
+    present = [1] * 9 + [0] * 5
+    with pytest.raises(g.GecError) as ei:
+        rs104.reconstruct_dev(st, present)
+    assert ei.value.code == _lib.GEC_E_TOO_FEW_PRESENT
+
+
+def test_reconstruct_all_present_is_noop(rs104):
+    st = torch.full((2, 14, 128), 7, dtype=torch.uint8, device=DEV)
+    rs104.reconstruct_dev(st, [1] * 14)
+    torch.cuda.synchronize()
+    assert (st == 7).all()
+
+
+def test_decode_plan_cache_hit(rs104):
+    k, m, S = 10, 4, 256
+    st = torch.zeros((1, k + m, S), dtype=torch.uint8, device=DEV)
+    present = [j not in (1, 2, 3, 5) for j in range(k + m)]
+    _, inv0 = rs104.cache_stats()
+    rs104.reconstruct_dev(st, present)
+    _, inv1 = rs104.cache_stats()
+    rs104.reconstruct_dev(st, present)
+    _, inv2 = rs104.cache_stats()
+    torch.cuda.synchronize()
+    assert inv1 == inv0 + 1 and inv2 == inv1, "second call must reuse the cached decode matrix"
+
+
+def test_reconstruct_byte_range(coracle, rs104):
+    k, m, S, nb = 10, 4, 4096, 2
+    data = rand_blocks(23, nb, k, S)
+    full = np.concatenate([data, coracle.encode_batch(k, m, data, coracle.AVX2)], axis=1)
+    lost = (2, 6, 11)
+    present = [j not in lost for j in range(k + m)]
+    broken = full.copy()
+    broken[:, list(lost)] = 0x5A
+    # 8 equal ranges, as 8 ranks would do after the all-gather of a striped object
+    st = torch.from_numpy(broken).to(DEV)
+    for r in range(8):
+        rs104.reconstruct_dev(st, present, byte_range=(r * S // 8, S // 8))
+        torch.cuda.synchronize()
+        got = st.cpu().numpy()
+        hi = (r + 1) * S // 8
+        assert np.array_equal(got[:, :, :hi], full[:, :, :hi])
+        if hi < S:
+            assert (got[:, list(lost), hi:] == 0x5A).all()
+    with pytest.raises(g.GecError):
+        rs104.reconstruct_dev(st, present, byte_range=(8, 64))      # misaligned
+    with pytest.raises(g.GecError):
+        rs104.reconstruct_dev(st, present, byte_range=(S, 64))      # outside
+
+
+# ---------------------------------------------------------------- verify
+def test_verify_detects_any_single_byte_flip(coracle):
+    k, m, S, nb = 10, 4, 2112, 14
+    rs = g.ReedSolomon(k, m)
+    data = rand_blocks(41, nb, k, S)
+    full = np.concatenate([data, coracle.encode_batch(k, m, data, coracle.AVX2)], axis=1)
+    st = torch.from_numpy(full).to(DEV)
+    assert rs.verify_dev(st).all()
+    # flip one bit in shard j of block j (every shard index once), varied offsets
+    bad = full.copy()
+    for j in range(k + m):
+        bad[j, j, (j * 151) % S] ^= 1 << (j % 8)
+    ok = rs.verify_dev(torch.from_numpy(bad).to(DEV)).cpu().numpy()
+    assert not ok.any()
+    bad2 = full.copy()
+    bad2[5, 3, S - 1] ^= 0x80
+    ok2 = rs.verify_dev(torch.from_numpy(bad2).to(DEV)).cpu().numpy()
+    assert ok2.tolist() == [i != 5 for i in range(nb)]
+
+
+# ------------------------------------------------------- host-pointer API
+def test_host_encode_ragged_blocks(coracle):
+    k, m = 10, 4
+    rs = g.ReedSolomon(k, m)
+    lens = [1048576, 1, 0, 640, 641, 65536, 99999, 1048575]
+    blocks = [bytes(O.splitmix64_bytes(1000 + i, n)) for i, n in enumerate(lens)]
+    S = g.shard_len(k, max(lens))
+    pars = rs.encode_blocks(blocks, S)
+    for blk, par in zip(blocks, pars):
+        want = coracle.encode_batch(k, m, O.split_block(k, blk, S)[None], coracle.AVX2)[0]
+        assert np.array_equal(par, want)
+    # per-block natural S as a Garage caller would use for a short last block
+    par_small = rs.encode_blocks([blocks[3]])[0]
+    assert par_small.shape == (m, 64)
+    assert np.array_equal(par_small, coracle.encode_batch(k, m, O.split_block(k, blocks[3])[None])[0])
+
+
+def test_host_config1_rs_3_1_64k(coracle):
+    # BASELINE config 1 shape (RS(3,1), 64 KiB, batch 16): parity == XOR of the data shards
+    k, m, L, nb = 3, 1, 65536, 16
+    rs = g.ReedSolomon(k, m)
+    blocks = [bytes(O.splitmix64_bytes(0x6761726167650001 + 1 + i, L)) for i in range(nb)]
+    blocks[0] = bytes(L)
+    blocks[1] = b"\xff" * L
+    pars = rs.encode_blocks(blocks)
+    for blk, par in zip(blocks, pars):
+        sh = O.split_block(k, blk)
+        assert np.array_equal(par[0], sh[0] ^ sh[1] ^ sh[2])
+    # lose one shard of each block (rotating), rebuild through the host API
+    stripes = []
+    for i, (blk, par) in enumerate(zip(blocks, pars)):
+        sh = list(O.split_block(k, blk)) + [par[0]]
+        sh[i % 4] = None
+        stripes.append(sh)
+    rec = rs.reconstruct(stripes)
+    for blk, row in zip(blocks, rec):
+        assert bytes(np.concatenate(row[:k]).tobytes()[:L]) == blk
+
+
+def test_host_verify_and_reconstruct_mixed_patterns(coracle):
+    k, m, S, nb = 10, 4, 1024, 9
+    rs = g.ReedSolomon(k, m)
+    data = rand_blocks(61, nb, k, S)
+    full = np.concatenate([data, coracle.encode_batch(k, m, data, coracle.AVX2)], axis=1)
+    assert rs.verify(full).all()
+    corrupt = full.copy()
+    corrupt[4, 12, 100] ^= 1
+    assert rs.verify(corrupt).tolist() == [i != 4 for i in range(nb)]
+    patterns = [(0,), (0, 3, 7, 9), (), (13,), (0, 3, 7, 9), (1, 2), (10, 11, 12, 13), (5, 12), (0,)]
+    shards = [[None if j in patterns[b] else full[b, j] for j in range(k + m)] for b in range(nb)]
+    rec = rs.reconstruct(shards)
+    for b in range(nb):
+        for j in range(k + m):
+            assert np.array_equal(rec[b][j], full[b, j])
+    rec_d = rs.reconstruct_data(shards)
+    for b in range(nb):
+        for j in range(k + m):
+            if j in patterns[b] and j >= k:
+                assert rec_d[b][j] is None
+            else:
+                assert np.array_equal(rec_d[b][j], full[b, j])
+    shards[2] = [None] * 5 + [full[2, j] for j in range(5, 14)]
+    with pytest.raises(g.GecError) as ei:
+        rs.reconstruct(shards)
+    assert ei.value.code == _lib.GEC_E_TOO_FEW_PRESENT
+
+
+def test_dev_argument_errors(rs104):
+    st = torch.zeros((1, 14, 64), dtype=torch.uint8, device=DEV)
+    lib = _lib.lib
+    h = rs104._h
+    # S not a multiple of 64 / zero / misaligned pointer / short stride
+    assert lib.gec_encode_batch_dev(h, 1, st.data_ptr(), 14 * 48, 48, st.data_ptr() + 10 * 48, 14 * 48, None) == _lib.GEC_E_INCORRECT_SHARD_SIZE
+    assert lib.gec_encode_batch_dev(h, 1, st.data_ptr(), 0, 0, st.data_ptr(), 0, None) == _lib.GEC_E_EMPTY_SHARD
+    assert lib.gec_encode_batch_dev(h, 1, st.data_ptr() + 4, 14 * 64, 64, st.data_ptr() + 640, 14 * 64, None) == _lib.GEC_E_INVALID_ARG
+    assert lib.gec_encode_batch_dev(h, 1, st.data_ptr(), 64, 64, st.data_ptr() + 640, 14 * 64, None) == _lib.GEC_E_INCORRECT_SHARD_SIZE
+    assert lib.gec_encode_batch_dev(h, 0, None, 0, 64, None, 0, None) == 0   # empty batch is a no-op
+    with pytest.raises(g.GecError):
+        rs104.encode_sep_dev(torch.zeros((1, 9, 64), dtype=torch.uint8, device=DEV))
+
+
+# ------------------------------------------ BASELINE full-size properties
+def test_config2_full_size_properties(coracle, rs104):
+    """RS(10,4), 1 MiB blocks, batch 1024 (BASELINE configs 2 and 3): too big for
+    the oracle in seconds, so: oracle spot-check of 6 blocks + verify +
+    erase-4 -> reconstruct round trip + linearity."""
+    k, m, L, nb = 10, 4, 1 << 20, 1024
+    S = g.shard_len(k, L)
+    assert S == 104896
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(0x67617261)
+    st = torch.zeros((nb, k + m, S), dtype=torch.uint8, device=DEV)
+    # payload = L bytes per block; tail of the last data shard stays zero (geometry)
+    flat = st[:, :k].reshape(nb, k * S)
+    flat[:, :L] = torch.randint(0, 256, (nb, L), dtype=torch.uint8, device=DEV, generator=gen)
+    st[0, :k] = 0
+    st[1, :k].reshape(-1)[:L] = 0xFF
+    rs104.encode_dev(st)
+    torch.cuda.synchronize()
+    assert rs104.verify_dev(st).all()
+    idx = [0, 1, 2, 511, 1022, 1023]
+    host = st[idx].cpu().numpy()
+    want = coracle.encode_batch(k, m, host[:, :k], coracle.AVX2, threads=4)
+    assert np.array_equal(host[:, k:], want)
+    assert not host[0, k:].any(), "zero block -> zero parity"
+    # linearity: parity(a ^ b) == parity(a) ^ parity(b) on device, 64 block pairs
+    a, b = st[100:164], st[300:364]
+    x = (a ^ b).contiguous()
+    px = rs104.encode_sep_dev(x[:, :k].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(px, a[:, k:] ^ b[:, k:])
+    # erase -> reconstruct round trips (config 3 patterns)
+    ref = st.clone()
+    for lost in [(0, 3, 7, 9), (0, 3, 7, 11)]:
+        present = [j not in lost for j in range(k + m)]
+        st[:, list(lost)] = 0xEE
+        rs104.reconstruct_dev(st, present)
+        torch.cuda.synchronize()
+        assert torch.equal(st, ref)
+    # verify flags exactly the corrupted blocks
+    st[17, 3, 12345] ^= 1
+    st[1000, 13, S - 1] ^= 0x40
+    ok = rs104.verify_dev(st)
+    bad = (~ok).nonzero().flatten().tolist()
+    assert bad == [17, 1000]
+
+
+def test_config5_shape_rs_20_8_4mib(coracle):
+    k, m, L, nb = 20, 8, 4 << 20, 8
+    S = g.shard_len(k, L)
+    assert S == 209728
+    rs = g.ReedSolomon(k, m)
+    data = rand_blocks(5, nb, k, S)
+    st = torch.zeros((nb, k + m, S), dtype=torch.uint8, device=DEV)
+    st[:, :k] = torch.from_numpy(data).to(DEV)
+    rs.encode_dev(st)
+    torch.cuda.synchronize()
+    got = st[:2].cpu().numpy()
+    assert np.array_equal(got[:, k:], coracle.encode_batch(k, m, data[:2], coracle.AVX2, threads=4))
+    ref = st.clone()
+    lost = (0, 1, 5, 9, 13, 19, 21, 27)   # 8 erasures, 6 data + 2 parity
+    present = [j not in lost for j in range(k + m)]
+    st[:, list(lost)] = 0
+    rs.reconstruct_dev(st, present)
+    torch.cuda.synchronize()
+    assert torch.equal(st, ref)
+    assert rs.verify_dev(st).all()
