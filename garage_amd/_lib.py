@@ -55,6 +55,17 @@ def _load() -> ctypes.CDLL:
             "`make -C garage_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "There is no CPU fallback for the erasure-coding data path."
         )
+    # One HIP runtime per process: PyTorch's ROCm wheel bundles its own
+    # libamdhip64.so (SONAME libamdhip64.so.7).  If libgarage_ec were loaded first it
+    # would pull /opt/rocm's copy through its RUNPATH, torch would then load its
+    # bundled one as a SECOND runtime, and whichever initialises second sees "no
+    # GPUs".  Importing torch first makes the dynamic linker satisfy our NEEDED
+    # libamdhip64.so.7 with the already-loaded runtime.  (A C/Rust host without
+    # torch simply gets /opt/rocm's runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover - torch is plumbing, not required to load
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     u8p = ctypes.POINTER(ctypes.c_uint8)

@@ -216,26 +216,70 @@ int get_plan(const gec_codec *c, const uint8_t *present, bool data_only, std::sh
 	return GEC_OK;
 }
 
-template <int MW, int MODE>
-void launch_nibble(const gec::ApplyArgs &a, const gec::LogExp *le, unsigned grid, size_t lds, hipStream_t s)
+// Launch geometry of the default kernel, tuned on MI355X with tools/kbench
+// (profiles/r01_kbench_*.txt): one tile per workgroup, 1 column per thread.
+//   4-byte table entries (rows <= 4): 256 threads, up to 10 shards loaded per batch
+//     (RS(10,4): all 10 loads go out before the table expansion; 72% of 8 TB/s)
+//   8-byte table entries (rows <= 8): 512 threads, up to 6 per batch (register budget)
+constexpr int kCPT = 1;
+constexpr int kThreadsMW1 = 256;
+constexpr int kThreadsMW2 = 512;
+constexpr uint64_t kMaxGrid = 1u << 22;  // workgroups per launch (HIP: grid*block < 2^32)
+
+// Loads per batch: k itself when small, else the candidate that wastes the fewest
+// clamped duplicate loads in the last batch (ties: the earlier = larger candidate).
+int choose_kc(int k, int mw)
 {
-	// loads in flight per lane: whole k when it is small enough to keep 8 waves/SIMD
-	if (a.k <= 5)
-		hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 5>), dim3(grid), dim3(gec::BLOCK), lds, s, a, le);
-	else
-		hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 10>), dim3(grid), dim3(gec::BLOCK), lds, s, a, le);
+	if (k <= 6)
+		return k;
+	int best = 0, waste = 1 << 30;
+	for (int kc : {10, 5, 6, 4}) {
+		if (kc == 10 && mw != 1)
+			continue;
+		int w = (k + kc - 1) / kc * kc - k;
+		if (w < waste) {
+			waste = w;
+			best = kc;
+		}
+	}
+	return best;
 }
 
-// out rows `out_idx[0..nout)` = coef(nout x k) applied to shards `in_idx[0..k)`.
-// Shards are addressed as base + b*stride + idx*S.  rows are processed in groups
-// of RMAX per launch.
-int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_t *out, size_t out_stride,
-		 uint32_t *bad, size_t S, size_t byte_off, size_t byte_len, size_t nblocks, const int *in_idx,
-		 const size_t *in_base_off, const int *out_idx, const size_t *out_base_off, int nout,
-		 const uint8_t *coef /* nout x k */, int mode, hipStream_t stream)
+template <int MW, int MODE, int TPB>
+void launch_nibble(const gec::ApplyArgs &a, const gec::LogExp *le, unsigned grid, size_t lds, hipStream_t s)
 {
-	(void)in_idx;
-	(void)out_idx;
+	const int kc = choose_kc((int)a.k, MW);
+	if constexpr (MW == 1) {
+		if (kc == 10) {
+			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 10, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, a, le);
+			return;
+		}
+	}
+	switch (kc) {
+#define GEC_CASE(KC)                                                                                              \
+	case KC:                                                                                                  \
+		hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, KC, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, \
+				   a, le);                                                                        \
+		break;
+		GEC_CASE(1)
+		GEC_CASE(2)
+		GEC_CASE(3)
+		GEC_CASE(4)
+		GEC_CASE(5)
+		GEC_CASE(6)
+#undef GEC_CASE
+	}
+}
+
+// out[r] = XOR_t coef[r][t] * in[t] for r < nout: shard t of block b is read at
+// in + b*in_stride + in_base_off[t], row r written at out + b*out_stride +
+// out_base_off[r]; only bytes [byte_off, byte_off+byte_len) of every shard are
+// touched.  Rows go out in groups of RMAX per launch.
+int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_t *out, size_t out_stride,
+		 uint32_t *bad, size_t byte_off, size_t byte_len, size_t nblocks, const size_t *in_base_off,
+		 const size_t *out_base_off, int nout, const uint8_t *coef /* nout x k */, int mode,
+		 hipStream_t stream)
+{
 	const int k = c->k;
 	if (nblocks == 0 || nout == 0 || byte_len == 0)
 		return GEC_OK;
@@ -251,44 +295,52 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 	a.col0 = (uint32_t)(byte_off / 16);
 	a.cols = (uint32_t)(byte_len / 16);
 	a.nblocks = (uint32_t)nblocks;
-	a.tiles_per_block = (a.cols + gec::BLOCK - 1) / gec::BLOCK;
 	a.k = (uint32_t)k;
 	for (int t = 0; t < k; ++t) {
 		if (in_base_off[t] / 16 > 0xffffffffull)
 			return fail(GEC_E_INVALID_ARG, "stripe too large");
 		a.in_off[t] = (uint32_t)(in_base_off[t] / 16);
 	}
-	const uint64_t ntiles = (uint64_t)a.nblocks * a.tiles_per_block;
-	if (ntiles > 0xffffffffull)
-		return fail(GEC_E_INVALID_ARG, "batch too large for one call");
-	const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * 8);
 	const int variant = g_variant.load(std::memory_order_relaxed);
-	(void)S;
 	for (int r0 = 0; r0 < nout; r0 += gec::RMAX) {
 		const int rows = std::min(gec::RMAX, nout - r0);
 		a.rows = (uint32_t)rows;
-		for (int r = 0; r < rows; ++r) {
-			a.out_off[r] = (uint32_t)(out_base_off[r0 + r] / 16);
-			std::memcpy(a.mat[r], coef + (size_t)(r0 + r) * k, k);
+		for (int r = 0; r < gec::RMAX; ++r) {
+			if (r < rows)
+				a.out_off[r] = (uint32_t)(out_base_off[r0 + r] / 16);
+			for (int t = 0; t < k; ++t)
+				a.coef[t][r] = r < rows ? coef[(size_t)(r0 + r) * k + t] : 0;
 		}
+		const int mw = rows <= 4 ? 1 : 2;
+		const int threads = variant == 1 ? gec::BLOCK : (mw == 1 ? kThreadsMW1 : kThreadsMW2);
+		a.tiles_per_block = (a.cols + threads * kCPT - 1) / (threads * kCPT);
+		const uint64_t ntiles = (uint64_t)a.nblocks * a.tiles_per_block;
+		if (ntiles > 0xffffffffull)
+			return fail(GEC_E_INVALID_ARG, "batch too large for one call");
 		if (variant == 1) {
+			// measured baseline: persistent grid-stride log/antilog kernel
+			const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * 8);
 			if (mode == gec::MODE_STORE)
 				hipLaunchKernelGGL((gec::gf_apply_logexp<gec::MODE_STORE>), dim3(grid), dim3(gec::BLOCK), 0, stream, a, c->d_logexp);
 			else
 				hipLaunchKernelGGL((gec::gf_apply_logexp<gec::MODE_COMPARE>), dim3(grid), dim3(gec::BLOCK), 0, stream, a, c->d_logexp);
-		} else {
-			const int mw = rows <= 4 ? 1 : 2;
-			const size_t lds = (size_t)k * 32 * 4 * mw + 768;
-			if (mw == 1 && mode == gec::MODE_STORE)
-				launch_nibble<1, gec::MODE_STORE>(a, c->d_logexp, grid, lds, stream);
-			else if (mw == 1)
-				launch_nibble<1, gec::MODE_COMPARE>(a, c->d_logexp, grid, lds, stream);
-			else if (mode == gec::MODE_STORE)
-				launch_nibble<2, gec::MODE_STORE>(a, c->d_logexp, grid, lds, stream);
-			else
-				launch_nibble<2, gec::MODE_COMPARE>(a, c->d_logexp, grid, lds, stream);
+			HIP_TRY(hipGetLastError());
+			continue;
 		}
-		HIP_TRY(hipGetLastError());
+		const size_t lds = (size_t)k * 32 * 4 * mw + 768 + (size_t)k * gec::RMAX;
+		for (uint64_t t0 = 0; t0 < ntiles; t0 += kMaxGrid) {
+			a.tile0 = (uint32_t)t0;
+			const unsigned grid = (unsigned)std::min<uint64_t>(ntiles - t0, kMaxGrid);
+			if (mw == 1 && mode == gec::MODE_STORE)
+				launch_nibble<1, gec::MODE_STORE, kThreadsMW1>(a, c->d_logexp, grid, lds, stream);
+			else if (mw == 1)
+				launch_nibble<1, gec::MODE_COMPARE, kThreadsMW1>(a, c->d_logexp, grid, lds, stream);
+			else if (mode == gec::MODE_STORE)
+				launch_nibble<2, gec::MODE_STORE, kThreadsMW2>(a, c->d_logexp, grid, lds, stream);
+			else
+				launch_nibble<2, gec::MODE_COMPARE, kThreadsMW2>(a, c->d_logexp, grid, lds, stream);
+			HIP_TRY(hipGetLastError());
+		}
 	}
 	return GEC_OK;
 }
@@ -317,8 +369,8 @@ int encode_dev(const gec_codec *c, size_t nblocks, const uint8_t *d_data, size_t
 		in_off[t] = (size_t)t * S;
 	for (int r = 0; r < m; ++r)
 		out_off[r] = (size_t)r * S;
-	return launch_apply(c, d_data, data_stride, d_parity, parity_stride, nullptr, S, 0, S, nblocks, nullptr,
-			    in_off.data(), nullptr, out_off.data(), m, c->enc.row(k), gec::MODE_STORE, stream);
+	return launch_apply(c, d_data, data_stride, d_parity, parity_stride, nullptr, 0, S, nblocks, in_off.data(),
+			    out_off.data(), m, c->enc.row(k), gec::MODE_STORE, stream);
 }
 
 int verify_dev(const gec_codec *c, size_t nblocks, const uint8_t *d_stripes, size_t stride, size_t S,
@@ -331,9 +383,8 @@ int verify_dev(const gec_codec *c, size_t nblocks, const uint8_t *d_stripes, siz
 	for (int r = 0; r < m; ++r)
 		out_off[r] = (size_t)(k + r) * S;
 	HIP_TRY(hipMemsetAsync(d_bad, 0, nblocks * sizeof(uint32_t), stream));
-	return launch_apply(c, d_stripes, stride, const_cast<uint8_t *>(d_stripes), stride, d_bad, S, 0, S, nblocks,
-			    nullptr, in_off.data(), nullptr, out_off.data(), m, c->enc.row(k), gec::MODE_COMPARE,
-			    stream);
+	return launch_apply(c, d_stripes, stride, const_cast<uint8_t *>(d_stripes), stride, d_bad, 0, S, nblocks,
+			    in_off.data(), out_off.data(), m, c->enc.row(k), gec::MODE_COMPARE, stream);
 }
 
 int reconstruct_dev(const gec_codec *c, size_t nblocks, uint8_t *d_stripes, size_t stride, size_t S,
@@ -351,8 +402,8 @@ int reconstruct_dev(const gec_codec *c, size_t nblocks, uint8_t *d_stripes, size
 		in_off[t] = (size_t)plan->valid[t] * S;
 	for (size_t r = 0; r < plan->missing.size(); ++r)
 		out_off[r] = (size_t)plan->missing[r] * S;
-	return launch_apply(c, d_stripes, stride, d_stripes, stride, nullptr, S, byte_off, byte_len, nblocks, nullptr,
-			    in_off.data(), nullptr, out_off.data(), (int)plan->missing.size(), plan->rows.v.data(),
+	return launch_apply(c, d_stripes, stride, d_stripes, stride, nullptr, byte_off, byte_len, nblocks,
+			    in_off.data(), out_off.data(), (int)plan->missing.size(), plan->rows.v.data(),
 			    gec::MODE_STORE, stream);
 }
 

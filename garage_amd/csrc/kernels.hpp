@@ -50,9 +50,10 @@ struct ApplyArgs {
 	uint32_t tiles_per_block;
 	uint32_t k;          // inputs  (<= KMAX)
 	uint32_t rows;       // outputs (<= RMAX)
+	uint32_t tile0;      // first tile of this launch (launches are split at HIP's grid limit)
 	uint32_t in_off[KMAX];   // shard offsets inside a block, in 16-byte units
 	uint32_t out_off[RMAX];
-	uint8_t mat[RMAX][KMAX];
+	uint8_t coef[KMAX][RMAX];  // coef[t][r] = mat[r][t]: one 8-byte row per input shard
 };
 
 // exp[512] | log[256], filled by the host from gec::Field (768 bytes).
@@ -116,29 +117,98 @@ __device__ __forceinline__ void lut_acc(uint32_t tb, uint32_t lo, uint32_t hi, u
 // ---------------------------------------------------------------------------
 // Default kernel: wide nibble product tables in LDS.
 //   MW   = dwords per table entry (1: rows<=4, 2: rows<=8)
-//   MODE = store / xor-into-existing / compare-with-existing
-//   KC   = input shards loaded per batch (loads in flight per lane)
+//   MODE = store / compare-with-existing
+//   KC   = input shards loaded per batch (loads in flight per lane = KC*CPT)
+//   CPT  = 16-byte columns per thread per tile (strided by blockDim for coalescing)
+//   NT   = non-temporal (streaming) global loads/stores
+//   TPB  = threads per workgroup (launch bound; the register budget follows it)
+// gf_apply_nibble uses hipcc's default register heuristics; gf_apply_nibble_w pins
+// the minimum waves per SIMD (MINW) the register allocator must leave room for.
 // ---------------------------------------------------------------------------
-template <int MW, int MODE, int KC>
-__global__ __launch_bounds__(BLOCK) void gf_apply_nibble(const ApplyArgs a, const LogExp *__restrict__ le)
+template <bool NT>
+__device__ __forceinline__ u32x4 ld16(const u32x4 *p)
+{
+	return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st16(u32x4 v, u32x4 *p)
+{
+	if (NT)
+		__builtin_nontemporal_store(v, p);
+	else
+		*p = v;
+}
+
+template <int MW, int MODE, int KC, int CPT, bool NT, int TPB>
+__device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const LogExp *__restrict__ le)
 {
 	constexpr int ENT = 4 * MW;            // bytes per table entry
 	constexpr int TBL = 32 * ENT;          // bytes per input shard (lo 16 | hi 16)
+	constexpr uint32_t nthr = TPB;
+	static_assert(TPB >= 192, "the log/antilog image is fetched one dword per thread");
 	// single dynamic LDS object (no static __shared__ in front of it, so the base
-	// stays 16-byte aligned): [tables k*TBL][exp 512][log 256]
+	// stays 16-byte aligned): [tables k*TBL][exp 512][log 256][coef k*8]
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const uint32_t tid = threadIdx.x;
-	const uint32_t k = a.k, rows = a.rows;
+	const uint32_t k = a.k;
+	const uint32_t rows = a.rows;
 	uint8_t *lexp = lds + k * TBL;
 	uint8_t *llog = lexp + 512;
+	uint8_t *lcoef = llog + 256;
 	const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds;
 
-	// -- prologue 1: pin log/antilog in LDS
-	for (uint32_t i = tid; i < 768 / 4; i += BLOCK)
-		reinterpret_cast<uint32_t *>(lexp)[i] = reinterpret_cast<const uint32_t *>(le)[i];
+	// One tile (TPB*CPT 16-byte columns of one block) per workgroup, dispatched by
+	// the hardware: on MI355X this beats a persistent grid-stride loop because fast
+	// CUs/XCDs simply pull more tiles (profiles/r01_kbench_*.txt).  Everything up to
+	// the first barrier is straight-line code with unconditional (index-clamped)
+	// loads so that hipcc can count them: the waits below are vmcnt(N), not vmcnt(0).
+	const uint32_t tile = a.tile0 + blockIdx.x;
+	const uint32_t b = tile / a.tiles_per_block;
+	const uint32_t col = (tile - b * a.tiles_per_block) * (nthr * CPT) + tid;
+	const bool active = col < a.cols;
+	// lanes past the ragged end of the last tile re-do the tile's first column
+	// (in-bounds, discarded) instead of diverging
+	bool live[CPT];
+	uint32_t cc[CPT];
+#pragma unroll
+	for (int c = 0; c < CPT; ++c) {
+		cc[c] = col + c * nthr;
+		live[c] = cc[c] < a.cols;
+		if (!live[c])
+			cc[c] = col - tid;
+	}
+	const u32x4 *src = reinterpret_cast<const u32x4 *>(a.in + (uint64_t)b * a.in_stride) + a.col0;
+	u32x4 *dst = reinterpret_cast<u32x4 *>(a.out + (uint64_t)b * a.out_stride) + a.col0;
+
+	// -- prologue 0: log/antilog image (768 B) and coefficient rows (k*8 B) are
+	//    requested FIRST, so their wait does not drain the data loads behind them
+	//    (index-clamped and stored unconditionally below: a `tid <` branch would let
+	//    hipcc sink the load into it, behind the data loads, where it waits vmcnt(0))
+	const uint32_t le_idx = tid < 192 ? tid : 191;
+	const uint32_t le_word = reinterpret_cast<const uint32_t *>(le)[le_idx];
+	const uint32_t ncw = 2 * k;  // coefficient dwords
+	const uint32_t coef_idx = tid < ncw ? tid : ncw - 1;
+	const uint32_t coef_word = reinterpret_cast<const uint32_t *>(&a.coef[0][0])[coef_idx];
+
+	// -- first batch of data loads goes out now; HBM latency covers the table expansion
+	u32x4 d[KC][CPT];
+#pragma unroll
+	for (int j = 0; j < KC; ++j) {
+		const uint32_t off = a.in_off[(uint32_t)j < k ? j : k - 1];
+#pragma unroll
+		for (int c = 0; c < CPT; ++c)
+			d[j][c] = ld16<NT>(src + off + cc[c]);
+	}
+
+	// -- prologue 1: pin log/antilog + coefficients in LDS
+	reinterpret_cast<uint32_t *>(lexp)[le_idx] = le_word;
+	reinterpret_cast<uint32_t *>(lcoef)[coef_idx] = coef_word;
+#pragma unroll 1
+	for (uint32_t i = tid + nthr; i < ncw; i += nthr)  // k > TPB/2 only
+		reinterpret_cast<uint32_t *>(lcoef)[i] = reinterpret_cast<const uint32_t *>(&a.coef[0][0])[i];
 	__syncthreads();
-	// -- prologue 2: expand mat[rows][k] into wide nibble product tables
-	for (uint32_t idx = tid; idx < k * 32; idx += BLOCK) {
+	// -- prologue 2: expand coef[k][rows] into wide nibble product tables
+	for (uint32_t idx = tid; idx < k * 32; idx += nthr) {
 		const uint32_t t = idx >> 5, e = idx & 31;
 		const uint32_t x = e < 16 ? e : (e - 16) << 4;
 		uint32_t w[2] = {0, 0};
@@ -146,90 +216,107 @@ __global__ __launch_bounds__(BLOCK) void gf_apply_nibble(const ApplyArgs a, cons
 			const uint32_t lx = llog[x];
 #pragma unroll
 			for (int r = 0; r < 4 * MW; ++r) {
-				uint32_t c = (r < (int)rows) ? a.mat[r][t] : 0;
-				uint32_t p = c ? lexp[llog[c] + lx] : 0;
+				const uint32_t c = lcoef[t * RMAX + r];  // rows beyond `rows` are 0
+				const uint32_t p = c ? lexp[llog[c] + lx] : 0;
 				w[r >> 2] |= p << (8 * (r & 3));
 			}
 		}
-		uint32_t *dst = reinterpret_cast<uint32_t *>(lds + t * TBL + e * ENT);
-		dst[0] = w[0];
+		uint32_t *tdst = reinterpret_cast<uint32_t *>(lds + t * TBL + e * ENT);
+		tdst[0] = w[0];
 		if (MW == 2)
-			dst[1] = w[1];
+			tdst[1] = w[1];
 	}
 	__syncthreads();
+	if (!active)
+		return;
 
-	const uint32_t ntiles = a.nblocks * a.tiles_per_block;
-	for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-		const uint32_t b = tile / a.tiles_per_block;
-		const uint32_t col = (tile - b * a.tiles_per_block) * BLOCK + tid;
-		if (col >= a.cols)
-			continue;
-		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.in + (uint64_t)b * a.in_stride) + a.col0 + col;
-		u32x4 *dst = reinterpret_cast<u32x4 *>(a.out + (uint64_t)b * a.out_stride) + a.col0 + col;
-
-		// acc[w][j][h]: dword w of the column, byte position j, row half h
-		uint32_t acc[4][4][MW];
+	// acc[c][w][j][h]: column c, dword w of the column, byte position j, row half h
+	uint32_t acc[CPT][4][4][MW];
+#pragma unroll
+	for (int c = 0; c < CPT; ++c)
 #pragma unroll
 		for (int w = 0; w < 4; ++w)
 #pragma unroll
 			for (int j = 0; j < 4; ++j)
 #pragma unroll
 				for (int h = 0; h < MW; ++h)
-					acc[w][j][h] = 0;
+					acc[c][w][j][h] = 0;
 
-		for (uint32_t t0 = 0; t0 < k; t0 += KC) {
-			u32x4 d[KC];
-#pragma unroll
-			for (int j = 0; j < KC; ++j)
-				if (t0 + j < k)
-					d[j] = __builtin_nontemporal_load(src + a.in_off[t0 + j]);
+	for (uint32_t t0 = 0; t0 < k; t0 += KC) {
+		if (t0 > 0) {
 #pragma unroll
 			for (int j = 0; j < KC; ++j) {
-				if (t0 + j >= k)
-					break;
-				// absolute LDS byte address of this shard's lo table (wave-uniform -> SGPR)
-				const uint32_t tb = __builtin_amdgcn_readfirstlane(lds_base + (t0 + j) * TBL);
-				const uint32_t xs[4] = {d[j].x, d[j].y, d[j].z, d[j].w};
+				const uint32_t off = a.in_off[t0 + j < k ? t0 + j : k - 1];
+#pragma unroll
+				for (int c = 0; c < CPT; ++c)
+					d[j][c] = ld16<NT>(src + off + cc[c]);
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < KC; ++j) {
+			if (t0 + j >= k)
+				break;
+			// absolute LDS byte address of this shard's lo table (wave-uniform -> SGPR)
+			const uint32_t tb = __builtin_amdgcn_readfirstlane(lds_base + (t0 + j) * TBL);
+#pragma unroll
+			for (int c = 0; c < CPT; ++c) {
+				const uint32_t xs[4] = {d[j][c].x, d[j][c].y, d[j][c].z, d[j][c].w};
 #pragma unroll
 				for (int w = 0; w < 4; ++w) {
 					const uint32_t x = xs[w];
 					// entry byte offsets of the lo / hi nibbles of all 4 bytes at once
 					const uint32_t lo = (MW == 1) ? ((x << 2) & 0x3C3C3C3Cu) : ((x << 3) & 0x78787878u);
 					const uint32_t hi = (MW == 1) ? ((x >> 2) & 0x3C3C3C3Cu) : ((x >> 1) & 0x78787878u);
-					lut_acc<MW, 0>(tb, lo, hi, acc[w][0]);
-					lut_acc<MW, 1>(tb, lo, hi, acc[w][1]);
-					lut_acc<MW, 2>(tb, lo, hi, acc[w][2]);
-					lut_acc<MW, 3>(tb, lo, hi, acc[w][3]);
+					lut_acc<MW, 0>(tb, lo, hi, acc[c][w][0]);
+					lut_acc<MW, 1>(tb, lo, hi, acc[c][w][1]);
+					lut_acc<MW, 2>(tb, lo, hi, acc[c][w][2]);
+					lut_acc<MW, 3>(tb, lo, hi, acc[c][w][3]);
 				}
 			}
 		}
+	}
 
+	uint32_t diff = 0;
+#pragma unroll
+	for (int c = 0; c < CPT; ++c) {
 		// row-interleaved accumulators -> per-shard dwords
 		uint32_t P[4 * MW][4];
 #pragma unroll
 		for (int h = 0; h < MW; ++h)
 #pragma unroll
 			for (int w = 0; w < 4; ++w)
-				transpose4x4(acc[w][0][h], acc[w][1][h], acc[w][2][h], acc[w][3][h],
+				transpose4x4(acc[c][w][0][h], acc[c][w][1][h], acc[c][w][2][h], acc[c][w][3][h],
 					     P[4 * h + 0][w], P[4 * h + 1][w], P[4 * h + 2][w], P[4 * h + 3][w]);
-
-		uint32_t diff = 0;
+		if (!live[c])
+			continue;
 #pragma unroll
 		for (int r = 0; r < 4 * MW; ++r) {
 			if (r >= (int)rows)
 				break;
 			u32x4 v = {P[r][0], P[r][1], P[r][2], P[r][3]};
-			u32x4 *o = dst + a.out_off[r];
-			if (MODE == MODE_STORE) {
-				__builtin_nontemporal_store(v, o);
-			} else {
-				u32x4 old = __builtin_nontemporal_load(o);
+			u32x4 *o = dst + a.out_off[r] + cc[c];
+			if (MODE == MODE_COMPARE) {
+				u32x4 old = ld16<NT>(o);
 				diff |= (v.x ^ old.x) | (v.y ^ old.y) | (v.z ^ old.z) | (v.w ^ old.w);
+			} else {
+				st16<NT>(v, o);
 			}
 		}
-		if (MODE == MODE_COMPARE && diff)
-			a.bad[b] = 1u;
 	}
+	if (MODE == MODE_COMPARE && diff)
+		a.bad[b] = 1u;
+}
+
+template <int MW, int MODE, int KC, int CPT, bool NT, int TPB>
+__global__ __launch_bounds__(TPB) void gf_apply_nibble(const ApplyArgs a, const LogExp *__restrict__ le)
+{
+	gf_apply_nibble_body<MW, MODE, KC, CPT, NT, TPB>(a, le);
+}
+
+template <int MW, int MODE, int KC, int CPT, bool NT, int TPB, int MINW>
+__global__ __launch_bounds__(TPB, MINW) void gf_apply_nibble_w(const ApplyArgs a, const LogExp *__restrict__ le)
+{
+	gf_apply_nibble_body<MW, MODE, KC, CPT, NT, TPB>(a, le);
 }
 
 // ---------------------------------------------------------------------------
@@ -252,7 +339,7 @@ __global__ __launch_bounds__(BLOCK) void gf_apply_logexp(const ApplyArgs a, cons
 	__syncthreads();
 	for (uint32_t i = tid; i < RMAX * KMAX; i += BLOCK) {
 		uint32_t r = i / KMAX, t = i % KMAX;
-		uint8_t c = (r < rows && t < k) ? a.mat[r][t] : 0;
+		uint8_t c = (r < rows && t < k) ? a.coef[t][r] : 0;
 		lcoef[i] = c ? llog[c] : 0xff;
 	}
 	__syncthreads();

@@ -1,0 +1,292 @@
+// kbench.hip -- within-process A/B bench of the gf_apply kernel variants
+// (guide rule: perf deltas come from interleaved rounds in ONE process).
+// Standalone: build with `make -C tools`, run on the GPU box.
+//
+//   kbench [k m L nblocks rounds]
+//
+// Prints one line per variant: median / min kernel time (HIP events), algorithmic
+// GB/s ((k+m)*S*nblocks per launch) and whether the parity equals variant 0's.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../garage_amd/csrc/gf256.hpp"
+#include "../garage_amd/csrc/kernels.hpp"
+
+#define CK(x)                                                                          \
+	do {                                                                           \
+		hipError_t e_ = (x);                                                   \
+		if (e_ != hipSuccess) {                                                \
+			fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));        \
+			exit(1);                                                       \
+		}                                                                      \
+	} while (0)
+
+__global__ void fill_random(uint32_t *p, size_t n, uint32_t seed)
+{
+	size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (; i < n; i += stride) {
+		uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		p[i] = (uint32_t)(z ^ (z >> 31));
+	}
+}
+
+// plain streaming copy of known size: HBM ceiling + FETCH_SIZE/WRITE_SIZE calibration
+__global__ void copy16(const gec::u32x4 *__restrict__ src, gec::u32x4 *__restrict__ dst, size_t n)
+{
+	size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (; i < n; i += stride)
+		__builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+// 4 independent 16-byte loads in flight per lane, block-contiguous
+__global__ void copy16x4(const gec::u32x4 *__restrict__ src, gec::u32x4 *__restrict__ dst, size_t n)
+{
+	size_t base = (size_t)blockIdx.x * blockDim.x * 4 + threadIdx.x;
+	if (base + 3 * (size_t)blockDim.x < n) {
+		gec::u32x4 v0 = __builtin_nontemporal_load(src + base);
+		gec::u32x4 v1 = __builtin_nontemporal_load(src + base + blockDim.x);
+		gec::u32x4 v2 = __builtin_nontemporal_load(src + base + 2 * blockDim.x);
+		gec::u32x4 v3 = __builtin_nontemporal_load(src + base + 3 * blockDim.x);
+		__builtin_nontemporal_store(v0, dst + base);
+		__builtin_nontemporal_store(v1, dst + base + blockDim.x);
+		__builtin_nontemporal_store(v2, dst + base + 2 * blockDim.x);
+		__builtin_nontemporal_store(v3, dst + base + 3 * blockDim.x);
+	}
+}
+
+// read-only stream (10 reads : 0 writes) -- upper bound for the read side
+__global__ void read16x4(const gec::u32x4 *__restrict__ src, gec::u32x4 *__restrict__ dst, size_t n)
+{
+	size_t base = (size_t)blockIdx.x * blockDim.x * 4 + threadIdx.x;
+	if (base + 3 * (size_t)blockDim.x < n) {
+		gec::u32x4 v0 = __builtin_nontemporal_load(src + base);
+		gec::u32x4 v1 = __builtin_nontemporal_load(src + base + blockDim.x);
+		gec::u32x4 v2 = __builtin_nontemporal_load(src + base + 2 * blockDim.x);
+		gec::u32x4 v3 = __builtin_nontemporal_load(src + base + 3 * blockDim.x);
+		gec::u32x4 x = v0 ^ v1 ^ v2 ^ v3;
+		if ((x.x ^ x.y ^ x.z ^ x.w) == 0x12345678u)  // practically never: keeps the loads live
+			dst[base] = x;
+	}
+}
+
+__global__ void diff_count(const uint32_t *a, const uint32_t *b, size_t n, unsigned long long *out)
+{
+	size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	unsigned long long c = 0;
+	for (; i < n; i += stride)
+		c += a[i] != b[i];
+	if (c)
+		atomicAdd(out, c);
+}
+
+typedef void (*kern_t)(const gec::ApplyArgs, const gec::LogExp *);
+
+struct Variant {
+	std::string name;
+	kern_t fn;
+	int threads, cpt, wg_per_cu;  // wg_per_cu <= 0: one tile per workgroup
+	bool nibble;
+	bool check;
+};
+
+int main(int argc, char **argv)
+{
+	int k = argc > 1 ? atoi(argv[1]) : 10;
+	int m = argc > 2 ? atoi(argv[2]) : 4;
+	size_t L = argc > 3 ? strtoull(argv[3], 0, 0) : (1u << 20);
+	size_t nb = argc > 4 ? strtoull(argv[4], 0, 0) : 1024;
+	int rounds = argc > 5 ? atoi(argv[5]) : 7;
+	size_t S = ((L + k - 1) / k + 63) / 64 * 64;
+	int n = k + m;
+	hipDeviceProp_t prop;
+	CK(hipGetDeviceProperties(&prop, 0));
+	int cus = prop.multiProcessorCount;
+	printf("# %s CUs=%d  RS(%d,%d) L=%zu S=%zu nblocks=%zu  algorithmic bytes/launch=%zu\n", prop.name, cus, k, m, L,
+	       S, nb, (size_t)n * S * nb);
+
+	size_t bytes = nb * n * S;
+	uint8_t *d_st, *d_ref;
+	CK(hipMalloc((void **)&d_st, bytes));
+	CK(hipMalloc((void **)&d_ref, nb * (size_t)m * S));
+	fill_random<<<4096, 256>>>((uint32_t *)d_st, bytes / 4, 12345u);
+	CK(hipDeviceSynchronize());
+
+	gec::Matrix enc;
+	gec::build_encoding_matrix(k, m, enc);
+	gec::LogExp le, *d_le;
+	memcpy(le.exp, gec::field().exp.data(), 512);
+	memcpy(le.log, gec::field().log.data(), 256);
+	CK(hipMalloc((void **)&d_le, sizeof(le)));
+	CK(hipMemcpy(d_le, &le, sizeof(le), hipMemcpyHostToDevice));
+	unsigned long long *d_cnt;
+	CK(hipMalloc((void **)&d_cnt, 8));
+
+	using namespace gec;
+	std::vector<Variant> vs;
+#define NIBW(MW, KC, CPT, NT, THREADS, MINW, WG, TAG) \
+	vs.push_back({TAG, gf_apply_nibble_w<MW, MODE_STORE, KC, CPT, NT, THREADS, MINW>, THREADS, CPT, WG, true, true})
+#define NIB(MW, KC, CPT, NT, THREADS, MINW, WG, TAG) \
+	vs.push_back({TAG, gf_apply_nibble<MW, MODE_STORE, KC, CPT, NT, THREADS>, THREADS, CPT, WG, true, true})
+	const int MW = m <= 4 ? 1 : 2;
+	if (MW == 1) {
+		NIB(1, 5, 1, true, 256, 0, 0, "nib kc5  cpt1 nt  t256 (default)");
+		NIB(1, 10, 1, true, 256, 0, 0, "nib kc10 cpt1 nt  t256");
+		NIB(1, 4, 1, true, 256, 0, 0, "nib kc4  cpt1 nt  t256");
+		NIB(1, 6, 1, true, 256, 0, 0, "nib kc6  cpt1 nt  t256");
+		NIB(1, 3, 1, true, 256, 0, 0, "nib kc3  cpt1 nt  t256");
+		NIB(1, 2, 1, true, 256, 0, 0, "nib kc2  cpt1 nt  t256");
+		NIB(1, 5, 1, false, 256, 0, 0, "nib kc5  cpt1 tmp t256");
+		NIB(1, 5, 2, true, 256, 0, 0, "nib kc5  cpt2 nt  t256");
+		NIB(1, 3, 2, true, 256, 0, 0, "nib kc3  cpt2 nt  t256");
+		NIB(1, 2, 2, true, 256, 0, 0, "nib kc2  cpt2 nt  t256");
+		NIB(1, 5, 1, true, 512, 0, 0, "nib kc5  cpt1 nt  t512");
+		NIB(1, 10, 1, true, 512, 0, 0, "nib kc10 cpt1 nt  t512");
+		NIB(1, 5, 1, true, 1024, 0, 0, "nib kc5  cpt1 nt  t1024");
+		NIB(1, 5, 1, true, 192, 0, 0, "nib kc5  cpt1 nt  t192");
+		NIBW(1, 10, 1, true, 256, 6, 0, "nib kc10 cpt1 nt  t256 w6");
+		NIBW(1, 5, 2, true, 256, 6, 0, "nib kc5  cpt2 nt  t256 w6");
+	} else {
+		NIB(2, 5, 1, true, 512, 0, 0, "nib8 kc5  cpt1 nt t512 (default)");
+		NIB(2, 5, 1, true, 256, 0, 0, "nib8 kc5  cpt1 nt t256");
+		NIB(2, 4, 1, true, 512, 0, 0, "nib8 kc4  cpt1 nt t512");
+		NIB(2, 4, 1, true, 256, 0, 0, "nib8 kc4  cpt1 nt t256");
+		NIB(2, 10, 1, true, 512, 0, 0, "nib8 kc10 cpt1 nt t512");
+		NIB(2, 10, 1, true, 256, 0, 0, "nib8 kc10 cpt1 nt t256");
+		NIB(2, 2, 1, true, 512, 0, 0, "nib8 kc2  cpt1 nt t512");
+		NIB(2, 5, 1, true, 1024, 0, 0, "nib8 kc5  cpt1 nt t1024");
+		NIBW(2, 5, 1, true, 512, 6, 0, "nib8 kc5  cpt1 nt t512 w6");
+		NIBW(2, 5, 1, true, 256, 6, 0, "nib8 kc5  cpt1 nt t256 w6");
+	}
+	vs.push_back({"logexp baseline (north_star literal)", gf_apply_logexp<MODE_STORE>, 256, 1, 8, false, true});
+
+	ApplyArgs a;
+	memset(&a, 0, sizeof(a));
+	a.in = d_st;
+	a.out = d_st;
+	a.in_stride = a.out_stride = (uint64_t)n * S;
+	a.col0 = 0;
+	a.cols = (uint32_t)(S / 16);
+	a.nblocks = (uint32_t)nb;
+	a.k = k;
+	a.rows = std::min(m, RMAX);
+	for (int t = 0; t < k; ++t)
+		a.in_off[t] = (uint32_t)((size_t)t * S / 16);
+	for (int r = 0; r < (int)a.rows; ++r) {
+		a.out_off[r] = (uint32_t)((size_t)(k + r) * S / 16);
+		for (int t = 0; t < k; ++t)
+			a.coef[t][r] = enc.row(k + r)[t];
+	}
+
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	std::vector<std::vector<float>> times(vs.size());
+	std::vector<long long> diffs(vs.size(), -1);
+	const size_t lds = (size_t)k * 32 * 4 * MW + 768 + (size_t)k * RMAX;
+	const double algo = (double)(k + a.rows) * S * nb;
+
+	auto launch = [&](const Variant &v) {
+		ApplyArgs aa = a;
+		aa.tiles_per_block = (a.cols + v.threads * v.cpt - 1) / (v.threads * v.cpt);
+		uint64_t ntiles = (uint64_t)aa.nblocks * aa.tiles_per_block;
+		unsigned grid = (v.wg_per_cu > 0 && !v.nibble) ? (unsigned)std::min<uint64_t>(ntiles, (uint64_t)cus * v.wg_per_cu) : (unsigned)ntiles;
+		if (!v.nibble)
+			aa.tiles_per_block = (a.cols + BLOCK - 1) / BLOCK;
+		hipLaunchKernelGGL(v.fn, dim3(grid), dim3(v.nibble ? v.threads : BLOCK), v.nibble ? lds : 0, 0, aa, d_le);
+	};
+
+	// correctness: every variant's parity vs variant 0's
+	launch(vs[0]);
+	CK(hipDeviceSynchronize());
+	for (size_t b = 0; b < nb; ++b)  // gather parity rows into d_ref
+		CK(hipMemcpyAsync(d_ref + b * (size_t)m * S, d_st + b * (size_t)n * S + (size_t)k * S, (size_t)a.rows * S, hipMemcpyDeviceToDevice, 0));
+	CK(hipDeviceSynchronize());
+	for (size_t i = 0; i < vs.size(); ++i) {
+		if (!vs[i].check)
+			continue;
+		CK(hipMemsetAsync(d_cnt, 0, 8, 0));
+		for (size_t b = 0; b < nb; b += 97)  // poison a sample of parity rows first
+			CK(hipMemsetAsync(d_st + b * (size_t)n * S + (size_t)k * S, 0xCD, (size_t)a.rows * S, 0));
+		launch(vs[i]);
+		for (size_t b = 0; b < nb; b += 97)
+			diff_count<<<64, 256>>>((const uint32_t *)(d_st + b * (size_t)n * S + (size_t)k * S), (const uint32_t *)(d_ref + b * (size_t)m * S), (size_t)a.rows * S / 4, d_cnt);
+		unsigned long long c = 0;
+		CK(hipMemcpy(&c, d_cnt, 8, hipMemcpyDeviceToHost));
+		diffs[i] = (long long)c;
+	}
+
+	for (int r = 0; r < rounds; ++r)
+		for (size_t i = 0; i < vs.size(); ++i) {
+			if (r == 0)
+				launch(vs[i]);  // warm
+			const int reps = vs[i].nibble ? 5 : 2;
+			CK(hipEventRecord(e0, 0));
+			for (int q = 0; q < reps; ++q)
+				launch(vs[i]);
+			CK(hipEventRecord(e1, 0));
+			CK(hipEventSynchronize(e1));
+			float ms;
+			CK(hipEventElapsedTime(&ms, e0, e1));
+			times[i].push_back(ms / reps);
+		}
+	// known-size copy for the HBM ceiling / PMC calibration
+	{
+		size_t nvec = bytes / 2 / 16;
+		std::vector<float> t;
+		for (int r = 0; r < rounds + 1; ++r) {
+			CK(hipEventRecord(e0, 0));
+			copy16<<<cus * 8, 256>>>((const u32x4 *)d_st, (u32x4 *)(d_st + bytes / 2), nvec);
+			CK(hipEventRecord(e1, 0));
+			CK(hipEventSynchronize(e1));
+			float ms;
+			CK(hipEventElapsedTime(&ms, e0, e1));
+			if (r)
+				t.push_back(ms);
+		}
+		std::sort(t.begin(), t.end());
+		printf("%-52s med %8.1f us  min %8.1f us  %7.1f GB/s (read %zu + write %zu bytes)\n", "copy16 nt grid-stride (known bytes)",
+		       t[t.size() / 2] * 1e3, t[0] * 1e3, 2.0 * nvec * 16 / (t[t.size() / 2] * 1e-3) / 1e9, nvec * 16, nvec * 16);
+		for (int which = 0; which < 2; ++which) {
+			t.clear();
+			unsigned grid = (unsigned)((nvec + 1023) / 1024);
+			for (int r = 0; r < rounds + 1; ++r) {
+				CK(hipEventRecord(e0, 0));
+				if (which == 0)
+					copy16x4<<<grid, 256>>>((const u32x4 *)d_st, (u32x4 *)(d_st + bytes / 2), nvec);
+				else
+					read16x4<<<grid, 256>>>((const u32x4 *)d_st, (u32x4 *)(d_st + bytes / 2), nvec);
+				CK(hipEventRecord(e1, 0));
+				CK(hipEventSynchronize(e1));
+				float ms;
+				CK(hipEventElapsedTime(&ms, e0, e1));
+				if (r)
+					t.push_back(ms);
+			}
+			std::sort(t.begin(), t.end());
+			double bytes_moved = which == 0 ? 2.0 * nvec * 16 : 1.0 * nvec * 16;
+			printf("%-52s med %8.1f us  min %8.1f us  %7.1f GB/s\n", which == 0 ? "copy16x4 nt one-tile/wg (HBM copy ceiling)" : "read16x4 nt one-tile/wg (HBM read ceiling)",
+			       t[t.size() / 2] * 1e3, t[0] * 1e3, bytes_moved / (t[t.size() / 2] * 1e-3) / 1e9);
+		}
+	}
+	for (size_t i = 0; i < vs.size(); ++i) {
+		auto t = times[i];
+		std::sort(t.begin(), t.end());
+		float med = t[t.size() / 2], mn = t[0];
+		printf("%-52s med %8.1f us  min %8.1f us  %7.1f GB/s  %5.1f%% of 8TB/s  payload %7.1f GiB/s  %s\n", vs[i].name.c_str(),
+		       med * 1e3, mn * 1e3, algo / (med * 1e-3) / 1e9, 100.0 * algo / (med * 1e-3) / 8e12,
+		       (double)nb * L / (med * 1e-3) / (1ull << 30),
+		       diffs[i] < 0 ? "-" : (diffs[i] == 0 ? "parity==v0" : "PARITY MISMATCH"));
+	}
+	return 0;
+}
