@@ -12,6 +12,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
 `roofline` (HIP-event kernel time vs the 8 TB/s HBM peak), `cpu_baseline` (the
 oracle's C restatement timed on this host's cores) and a `decode` object for
 BASELINE config 3 (4 erasures).
+
+Defaults (--steps 1000 --warmup 100, ~0.3 s of GPU time) measure the steady
+state: MI355X's power management slows the first few milliseconds of a burst of
+this kernel by up to 1.5x before settling (profiles/r01_bench_kernel_stats.txt).
 """
 from __future__ import annotations
 
@@ -44,6 +48,17 @@ def synthetic_hashes(n_total: int):
 
     raw = b"".join(block_hash(struct.pack("<QQ", 0x6761726167650004, i)) for i in range(n_total))
     return np.frombuffer(raw, dtype=np.uint8).reshape(n_total, 32)
+
+
+def measured_traffic(nblocks: int):
+    """HBM bytes per launch measured with rocprofv3 PMC counters for exactly this
+    workload (committed under profiles/); None for any other batch size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f)["rs10_4_encode_1MiB_x1024"]
+    except (OSError, KeyError, ValueError):
+        return None
+    return rec["traffic_bytes"] if nblocks == BATCH else None
 
 
 def cpu_baseline(S: int):
@@ -89,8 +104,8 @@ def cpu_baseline(S: int):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--batch", type=int, default=BATCH, help="blocks per GPU (default 1024 = BASELINE config 2)")
     ap.add_argument("--variant", type=int, default=0, help="0 nibble product tables (default), 1 log/antilog baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -248,8 +263,9 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
-                "kernel": "gf_apply_nibble<1,0,10>" if args.variant == 0 else "gf_apply_logexp<0>",
+                "traffic": measured_traffic(nb) if args.variant == 0 else None,
+                "traffic_source": "rocprofv3 PMC pass, profiles/r01_pmc_hbm_traffic.txt (2*FETCH_SIZE + WRITE_SIZE, per launch)",
+                "kernel": "gf_apply_nibble<1,0,10,1,true,256>" if args.variant == 0 else "gf_apply_logexp<0>",
                 "kernel_ms": round(kern_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },

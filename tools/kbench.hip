@@ -226,6 +226,40 @@ int main(int argc, char **argv)
 		diffs[i] = (long long)c;
 	}
 
+	const int sustained = getenv("KBENCH_SUSTAINED") ? atoi(getenv("KBENCH_SUSTAINED")) : 0;
+	if (sustained > 0) {
+		// steady-state (power-managed) rate: N untimed launches to let the DVFS
+		// controller settle on this kernel's power draw, then N timed ones
+		printf("# sustained mode: %d warm + %d timed back-to-back launches per variant\n", sustained, sustained);
+		for (size_t i = 0; i < vs.size(); ++i) {
+			for (int q = 0; q < sustained; ++q)
+				launch(vs[i]);
+			CK(hipEventRecord(e0, 0));
+			for (int q = 0; q < sustained; ++q)
+				launch(vs[i]);
+			CK(hipEventRecord(e1, 0));
+			CK(hipEventSynchronize(e1));
+			float ms;
+			CK(hipEventElapsedTime(&ms, e0, e1));
+			float per = ms / sustained;
+			printf("%-52s sustained %8.1f us  %7.1f GB/s  %5.1f%% of 8TB/s  payload %7.1f GiB/s  %s\n", vs[i].name.c_str(), per * 1e3,
+			       algo / (per * 1e-3) / 1e9, 100.0 * algo / (per * 1e-3) / 8e12, (double)nb * L / (per * 1e-3) / (1ull << 30),
+			       diffs[i] < 0 ? "-" : (diffs[i] == 0 ? "parity==v0" : "PARITY MISMATCH"));
+		}
+		size_t nvec = bytes / 2 / 16;
+		unsigned grid = (unsigned)((nvec + 1023) / 1024);
+		for (int q = 0; q < sustained; ++q)
+			copy16x4<<<grid, 256>>>((const u32x4 *)d_st, (u32x4 *)(d_st + bytes / 2), nvec);
+		CK(hipEventRecord(e0, 0));
+		for (int q = 0; q < sustained; ++q)
+			copy16x4<<<grid, 256>>>((const u32x4 *)d_st, (u32x4 *)(d_st + bytes / 2), nvec);
+		CK(hipEventRecord(e1, 0));
+		CK(hipEventSynchronize(e1));
+		float ms;
+		CK(hipEventElapsedTime(&ms, e0, e1));
+		printf("%-52s sustained %8.1f us  %7.1f GB/s\n", "copy16x4 nt (HBM copy ceiling)", ms / sustained * 1e3, 2.0 * nvec * 16 / (ms / sustained * 1e-3) / 1e9);
+		return 0;
+	}
 	for (int r = 0; r < rounds; ++r)
 		for (size_t i = 0; i < vs.size(); ++i) {
 			if (r == 0)
