@@ -152,6 +152,33 @@ class ReedSolomon:
               "gec_reconstruct_range_dev")
         return stripes
 
+    def reconstruct_scattered_dev(self, buf, nblocks: int, block_stride: int, shard_off: Sequence[int], S: int,
+                                  present: Sequence[int], data_only: bool = False,
+                                  byte_range: Optional[tuple[int, int]] = None):
+        """Shard j of block b at buf.data_ptr() + b*block_stride + shard_off[j]
+        (gec_reconstruct_scattered_dev).  `buf` is any uint8 CUDA tensor that
+        covers those addresses; missing shards are rebuilt in place."""
+        import torch
+
+        if not (isinstance(buf, torch.Tensor) and buf.is_cuda and buf.dtype == torch.uint8 and buf.is_contiguous()):
+            raise TypeError("buf must be a contiguous uint8 CUDA tensor")
+        if buf.device.index != self.device:
+            raise GecError(_lib.GEC_E_INVALID_ARG, "buf", "tensor is on a different device than the codec")
+        if len(shard_off) != self.n:
+            raise GecError(_lib.GEC_E_INVALID_INDEX, "shard_off", "must have k+m entries")
+        top = (nblocks - 1) * block_stride + max(shard_off) + S
+        if nblocks > 0 and top > buf.numel():
+            raise GecError(_lib.GEC_E_INCORRECT_SHARD_SIZE, "buf", "layout reaches past the end of the tensor")
+        pres = np.ascontiguousarray(np.asarray(present, dtype=np.uint8))
+        if pres.size != self.n:
+            raise GecError(_lib.GEC_E_INVALID_INDEX, "present", "must have k+m entries")
+        offs = (ctypes.c_size_t * self.n)(*[int(o) for o in shard_off])
+        off, ln = (0, S) if byte_range is None else byte_range
+        check(lib.gec_reconstruct_scattered_dev(self._h, nblocks, buf.data_ptr(), block_stride, offs, S, _u8p(pres),
+                                                int(bool(data_only)), off, ln, _stream_handle(self.device)),
+              "gec_reconstruct_scattered_dev")
+        return buf
+
     # -- host buffers (what the Rust shim calls) -----------------------------
     def encode_blocks(self, blocks: Sequence[bytes], S: Optional[int] = None) -> list[np.ndarray]:
         """blocks: byte strings (any lengths) -> per block a (m, S) parity array."""

@@ -387,7 +387,7 @@ int verify_dev(const gec_codec *c, size_t nblocks, const uint8_t *d_stripes, siz
 			    in_off.data(), out_off.data(), m, c->enc.row(k), gec::MODE_COMPARE, stream);
 }
 
-int reconstruct_dev(const gec_codec *c, size_t nblocks, uint8_t *d_stripes, size_t stride, size_t S,
+int reconstruct_dev(const gec_codec *c, size_t nblocks, uint8_t *d_base, size_t stride, const size_t *shard_off,
 		    const uint8_t *present, bool data_only, size_t byte_off, size_t byte_len, hipStream_t stream)
 {
 	std::shared_ptr<const Plan> plan;
@@ -399,12 +399,20 @@ int reconstruct_dev(const gec_codec *c, size_t nblocks, uint8_t *d_stripes, size
 	const int k = c->k;
 	std::vector<size_t> in_off(k), out_off(plan->missing.size());
 	for (int t = 0; t < k; ++t)
-		in_off[t] = (size_t)plan->valid[t] * S;
+		in_off[t] = shard_off[plan->valid[t]];
 	for (size_t r = 0; r < plan->missing.size(); ++r)
-		out_off[r] = (size_t)plan->missing[r] * S;
-	return launch_apply(c, d_stripes, stride, d_stripes, stride, nullptr, byte_off, byte_len, nblocks,
-			    in_off.data(), out_off.data(), (int)plan->missing.size(), plan->rows.v.data(),
-			    gec::MODE_STORE, stream);
+		out_off[r] = shard_off[plan->missing[r]];
+	return launch_apply(c, d_base, stride, d_base, stride, nullptr, byte_off, byte_len, nblocks, in_off.data(),
+			    out_off.data(), (int)plan->missing.size(), plan->rows.v.data(), gec::MODE_STORE, stream);
+}
+
+// contiguous stripe: shard j at j*S
+std::vector<size_t> stripe_offsets(const gec_codec *c, size_t S)
+{
+	std::vector<size_t> off((size_t)c->k + c->m);
+	for (size_t j = 0; j < off.size(); ++j)
+		off[j] = j * S;
+	return off;
 }
 
 struct StagingLease {
@@ -660,8 +668,31 @@ int gec_reconstruct_range_dev(const gec_codec *c, size_t nblocks, void *d_stripe
 	DeviceGuard g(c->device);
 	if (!g.ok)
 		return fail(GEC_E_DEVICE, "hipSetDevice failed");
-	return reconstruct_dev(c, nblocks, static_cast<uint8_t *>(d_stripes), stride, S, present, data_only != 0,
-			       byte_off, byte_len, static_cast<hipStream_t>(hip_stream));
+	return reconstruct_dev(c, nblocks, static_cast<uint8_t *>(d_stripes), stride, stripe_offsets(c, S).data(), present,
+			       data_only != 0, byte_off, byte_len, static_cast<hipStream_t>(hip_stream));
+}
+
+int gec_reconstruct_scattered_dev(const gec_codec *c, size_t nblocks, void *d_base, size_t block_stride,
+				  const size_t *shard_off, size_t S, const uint8_t *present, int data_only,
+				  size_t byte_off, size_t byte_len, void *hip_stream)
+{
+	if (!c || !present || !shard_off)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (nblocks == 0)
+		return GEC_OK;
+	int rc = check_dev_layout(d_base, block_stride, S, S);
+	if (rc)
+		return rc;
+	for (int j = 0; j < c->k + c->m; ++j)
+		if (shard_off[j] % 16)
+			return fail(GEC_E_INVALID_ARG, "shard offsets must be multiples of 16");
+	if (byte_off % 16 || byte_len % 16 || byte_off > S || byte_len > S - byte_off)
+		return fail(GEC_E_INVALID_ARG, "byte range must be 16-byte aligned and inside the shard");
+	DeviceGuard g(c->device);
+	if (!g.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	return reconstruct_dev(c, nblocks, static_cast<uint8_t *>(d_base), block_stride, shard_off, present,
+			       data_only != 0, byte_off, byte_len, static_cast<hipStream_t>(hip_stream));
 }
 
 int gec_reconstruct_batch_dev(const gec_codec *c, size_t nblocks, void *d_stripes, size_t stride, size_t S,
@@ -819,7 +850,8 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 					if (present[j])
 						std::memcpy(st.h_buf + i * stripe + j * S, shards[ids[i0 + i] * n + j], S);
 			HIP_TRY(hipMemcpyAsync(st.d_buf, st.h_buf, nb * stripe, hipMemcpyHostToDevice, st.stream));
-			rc = reconstruct_dev(c, nb, st.d_buf, stripe, S, present, data_only != 0, 0, S, st.stream);
+			rc = reconstruct_dev(c, nb, st.d_buf, stripe, stripe_offsets(c, S).data(), present, data_only != 0, 0, S,
+					     st.stream);
 			if (rc)
 				return rc;
 			HIP_TRY(hipMemcpyAsync(st.h_buf, st.d_buf, nb * stripe, hipMemcpyDeviceToHost, st.stream));

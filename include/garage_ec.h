@@ -168,6 +168,21 @@ int gec_reconstruct_range_dev(const gec_codec *c, size_t nblocks,
 			      size_t byte_off, size_t byte_len,
 			      void *hip_stream);
 
+/* Most general device form: shard j of block b lives at
+ *   d_base + b*block_stride + shard_off[j]        (shard_off: host array, k+m entries)
+ * so the shards of one stripe need not be adjacent.  This is what decodes the
+ * output of the all-gather of a striped object in place: with the gathered
+ * buffer laid out [rank][object][slot][S], shard j = slot j/N of rank j%N has
+ * shard_off[j] = (j%N)*nobjects*slots*S + (j/N)*S and block_stride = slots*S.
+ * All offsets/strides multiples of 16; rebuilt shards are written to their own
+ * (shard_off) positions. */
+int gec_reconstruct_scattered_dev(const gec_codec *c, size_t nblocks,
+				  void *d_base, size_t block_stride,
+				  const size_t *shard_off, size_t S,
+				  const uint8_t *present, int data_only,
+				  size_t byte_off, size_t byte_len,
+				  void *hip_stream);
+
 /* Kernel selection for A/B measurements (bench.py --variant).  0 = default
  * (nibble product tables in LDS), 1 = log/antilog tables in LDS (the literal
  * north_star formulation, kept as the measured baseline).  Process-wide. */
