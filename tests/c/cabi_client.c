@@ -1,0 +1,150 @@
+/* A plain-C client of libgarage_ec.so -- what a non-Python host (the Rust shim's
+ * moral equivalent) does: only include/garage_ec.h, plain pointers and sizes.
+ *
+ *   cabi_client            host-logic checks only (runs without a GPU)
+ *   cabi_client gpu        + encode / verify / reconstruct through the host API,
+ *                            checked against the RS(3,1) parity == XOR identity and
+ *                            an encode -> erase -> reconstruct round trip; also runs
+ *                            4 threads on one shared codec.
+ * exit code 0 = all good. */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "garage_ec.h"
+
+#define CHECK(cond)                                                            \
+	do {                                                                   \
+		if (!(cond)) {                                                 \
+			fprintf(stderr, "FAIL %s:%d: %s (last error: %s)\n",   \
+				__FILE__, __LINE__, #cond, gec_last_error());  \
+			exit(1);                                               \
+		}                                                              \
+	} while (0)
+
+static void fill(uint8_t *p, size_t n, unsigned seed)
+{
+	unsigned long long z = seed * 0x9E3779B97F4A7C15ull + 1;
+	for (size_t i = 0; i < n; i++) {
+		z ^= z << 13;
+		z ^= z >> 7;
+		z ^= z << 17;
+		p[i] = (uint8_t)(z >> 24);
+	}
+}
+
+struct job {
+	const gec_codec *c;
+	int id;
+	int ok;
+};
+
+static void *worker(void *arg)
+{
+	struct job *j = (struct job *)arg;
+	const int k = gec_codec_k(j->c), m = gec_codec_m(j->c), n = k + m;
+	const size_t L = 200000 + 1000 * j->id, S = gec_shard_len(k, L);
+	enum { NB = 6 };
+	uint8_t *blk[NB], *par[NB];
+	size_t len[NB];
+	for (int b = 0; b < NB; b++) {
+		blk[b] = (uint8_t *)calloc(k * S, 1);
+		par[b] = (uint8_t *)malloc(m * S);
+		fill(blk[b], L, 100 * j->id + b);
+		len[b] = L;
+	}
+	for (int rep = 0; rep < 5; rep++) {
+		if (gec_encode_batch(j->c, NB, (const uint8_t *const *)blk, len, S, par) != GEC_OK)
+			return NULL;
+		/* drop data shard (id % k) and parity shard 0 of every block, rebuild */
+		const uint8_t *sh[NB * 64];
+		uint8_t *out[NB * 64];
+		uint8_t *tmp = (uint8_t *)malloc((size_t)NB * 2 * S);
+		int lost = j->id % k;
+		for (int b = 0; b < NB; b++)
+			for (int s = 0; s < n; s++) {
+				sh[b * n + s] = s < k ? blk[b] + s * S : par[b] + (s - k) * S;
+				out[b * n + s] = NULL;
+				if (s == lost) {
+					sh[b * n + s] = NULL;
+					out[b * n + s] = tmp + (size_t)(2 * b) * S;
+				} else if (s == k) {
+					sh[b * n + s] = NULL;
+					out[b * n + s] = tmp + (size_t)(2 * b + 1) * S;
+				}
+			}
+		if (gec_reconstruct_batch(j->c, NB, sh, out, S, 0) != GEC_OK)
+			return NULL;
+		for (int b = 0; b < NB; b++)
+			if (memcmp(tmp + (size_t)(2 * b) * S, blk[b] + lost * S, S) ||
+			    memcmp(tmp + (size_t)(2 * b + 1) * S, par[b], S))
+				return NULL;
+		free(tmp);
+	}
+	j->ok = 1;
+	return NULL;
+}
+
+int main(int argc, char **argv)
+{
+	(void)argv;
+	/* ---- host logic, no GPU needed ---- */
+	CHECK(gec_version() == GEC_VERSION);
+	CHECK(gec_shard_len(10, 1 << 20) == 104896 && gec_shard_len(3, 65536) == 21888);
+	uint8_t mat[14 * 10];
+	CHECK(gec_build_matrix(10, 4, mat) == GEC_OK);
+	static const uint8_t row0[10] = {129, 150, 175, 184, 210, 196, 254, 232, 3, 2};
+	CHECK(memcmp(mat + 10 * 10, row0, 10) == 0); /* SURVEY Appendix A.4.4 */
+	CHECK(gec_build_matrix(0, 4, mat) == GEC_E_TOO_FEW_DATA);
+	CHECK(gec_build_matrix(250, 7, mat) == GEC_E_TOO_MANY_SHARDS);
+	gec_codec *c = NULL;
+	CHECK(gec_codec_create(10, 0, 0, &c) == GEC_E_TOO_FEW_PARITY && c == NULL);
+	if (gec_device_count() == 0) {
+		CHECK(gec_codec_create(10, 4, 0, &c) == GEC_E_DEVICE && c == NULL);
+		CHECK(strstr(gec_last_error(), "no CPU fallback") != NULL);
+		printf("cabi_client: host-logic checks OK (no GPU: codec creation refused as designed)\n");
+		return argc > 1 ? 2 : 0;
+	}
+	if (argc < 2)
+		return 0;
+
+	/* ---- RS(3,1): parity must be the XOR of the three data shards ---- */
+	CHECK(gec_codec_create(3, 1, 0, &c) == GEC_OK);
+	const size_t L = 65536, S = gec_shard_len(3, L);
+	uint8_t *blk = (uint8_t *)calloc(3 * S, 1), *par = (uint8_t *)malloc(S);
+	fill(blk, L, 7);
+	const uint8_t *blocks[1] = {blk};
+	uint8_t *parity[1] = {par};
+	CHECK(gec_encode_batch(c, 1, blocks, &L, S, parity) == GEC_OK);
+	for (size_t i = 0; i < S; i++)
+		CHECK(par[i] == (uint8_t)(blk[i] ^ blk[S + i] ^ blk[2 * S + i]));
+	const uint8_t *sh[4] = {blk, blk + S, blk + 2 * S, par};
+	uint8_t ok = 0;
+	CHECK(gec_verify_batch(c, 1, sh, S, &ok) == GEC_OK && ok == 1);
+	par[5] ^= 1;
+	CHECK(gec_verify_batch(c, 1, sh, S, &ok) == GEC_OK && ok == 0);
+	par[5] ^= 1;
+	const uint8_t *sh2[4] = {blk, NULL, NULL, par};
+	uint8_t *outp[4] = {NULL, NULL, NULL, NULL};
+	CHECK(gec_reconstruct_batch(c, 1, sh2, outp, S, 0) == GEC_E_TOO_FEW_PRESENT);
+	gec_codec_destroy(c);
+
+	/* ---- 4 threads sharing one RS(10,4) codec (Send + Sync on the Rust side) ---- */
+	CHECK(gec_codec_create(10, 4, 0, &c) == GEC_OK);
+	pthread_t th[4];
+	struct job jobs[4];
+	for (int i = 0; i < 4; i++) {
+		jobs[i].c = c;
+		jobs[i].id = i;
+		jobs[i].ok = 0;
+		pthread_create(&th[i], NULL, worker, &jobs[i]);
+	}
+	for (int i = 0; i < 4; i++) {
+		pthread_join(th[i], NULL);
+		CHECK(jobs[i].ok);
+	}
+	gec_codec_destroy(c);
+	printf("cabi_client: GPU checks OK\n");
+	return 0;
+}
