@@ -379,7 +379,7 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 	const int k = c->k;
 	if (nblocks == 0 || nout == 0 || byte_len == 0)
 		return GEC_OK;
-	if (nblocks > 0xffffffffull / 4096 || (byte_len / 16) > 0x7fffffffull)
+	if (nblocks > 0xffffffffull || (byte_len / 16) > 0x7fffffffull)
 		return fail(GEC_E_INVALID_ARG, "batch too large for one call");
 	gec::ApplyArgs a;
 	std::memset(&a, 0, sizeof(a));
@@ -535,6 +535,49 @@ size_t chunk_blocks(size_t bytes_per_block, size_t nblocks, size_t target = 64ul
 {
 	size_t n = std::max<size_t>(1, target / std::max<size_t>(bytes_per_block, 1));
 	return std::min(n, nblocks);
+}
+
+constexpr size_t kChunkBytes = 16ull << 20;  // staging chunk: small enough to overlap, big enough to fill the GPU
+
+// Host-pointer calls run their chunks through two staging slots, each with its own
+// stream: while chunk i is on the PCIe bus / in the kernel, the host drains chunk
+// i-1 and fills chunk i+1.  fill/drain run on the calling thread (+ copy pool),
+// enqueue only queues asynchronous work on st.stream.
+template <class Fill, class Enqueue, class Drain>
+int run_pipeline(const gec_codec *c, size_t nchunks, size_t slot_bytes, size_t nbad, Fill fill, Enqueue enqueue,
+		 Drain drain)
+{
+	DeviceGuard g(c->device);
+	if (!g.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	StagingLease lease0(c), lease1(c);
+	Staging *slot[2] = {&lease0.st, &lease1.st};
+	for (size_t i = 0; i < std::min<size_t>(nchunks, 2); ++i) {
+		int rc = slot[i]->ensure(slot_bytes, nbad);
+		if (rc)
+			return rc;
+	}
+	int rc = GEC_OK;
+	for (size_t ci = 0; ci <= nchunks && rc == GEC_OK; ++ci) {
+		if (ci < nchunks) {
+			Staging &st = *slot[ci % 2];
+			fill(ci, st);
+			rc = enqueue(ci, st);
+		}
+		if (ci >= 1 && rc == GEC_OK) {
+			Staging &st = *slot[(ci - 1) % 2];
+			hipError_t e = hipStreamSynchronize(st.stream);
+			if (e != hipSuccess)
+				rc = fail(GEC_E_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+			else
+				drain(ci - 1, st);
+		}
+	}
+	if (rc != GEC_OK)  // leave no work in flight on pooled buffers
+		for (Staging *st : slot)
+			if (st->stream)
+				(void)hipStreamSynchronize(st->stream);
+	return rc;
 }
 
 }  // namespace
@@ -817,26 +860,12 @@ int gec_encode_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *b
 		if (block_len[b] > k * S)
 			return fail(GEC_E_INCORRECT_SHARD_SIZE, "block longer than k*S");
 	}
-	DeviceGuard g(c->device);
-	if (!g.ok)
-		return fail(GEC_E_DEVICE, "hipSetDevice failed");
-	// Two staging slots, each with its own stream: while chunk i is on the PCIe bus /
-	// in the kernel, the host copies chunk i-1's parity out and chunk i+1's data in.
-	StagingLease lease0(c), lease1(c);
-	Staging *slot[2] = {&lease0.st, &lease1.st};
 	const size_t stripe = n * S;
-	const size_t ch = chunk_blocks(stripe, nblocks, 16ull << 20);
-	const size_t nchunks = (nblocks + ch - 1) / ch;
-	for (int i = 0; i < (nchunks > 1 ? 2 : 1); ++i) {
-		int rc = slot[i]->ensure(ch * stripe, 0);
-		if (rc)
-			return rc;
-	}
+	const size_t ch = chunk_blocks(stripe, nblocks, kChunkBytes);
 	CopyPool &pool = copy_pool();
-	int rc = GEC_OK;
-	for (size_t ci = 0; ci <= nchunks && rc == GEC_OK; ++ci) {
-		if (ci < nchunks) {
-			Staging &st = *slot[ci % 2];
+	return run_pipeline(
+		c, (nblocks + ch - 1) / ch, ch * stripe, 0,
+		[&](size_t ci, Staging &st) {  // host: user blocks -> pinned, zero-padded to k*S
 			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
 			pool.parallel_for(nb, [&](size_t i) {
 				uint8_t *dst = st.h_buf + i * stripe;
@@ -844,32 +873,20 @@ int gec_encode_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *b
 				std::memcpy(dst, blocks[b0 + i], len);
 				std::memset(dst + len, 0, k * S - len);
 			});
-			// only the data shards travel H2D (k*S per stripe); only parity comes back
-			hipError_t e = hipMemcpy2DAsync(st.d_buf, stripe, st.h_buf, stripe, k * S, nb, hipMemcpyHostToDevice, st.stream);
-			if (e == hipSuccess)
-				rc = encode_dev(c, nb, st.d_buf, stripe, S, st.d_buf + k * S, stripe, st.stream);
-			if (e == hipSuccess && rc == GEC_OK)
-				e = hipMemcpy2DAsync(st.h_buf + k * S, stripe, st.d_buf + k * S, stripe, m * S, nb, hipMemcpyDeviceToHost, st.stream);
-			if (e != hipSuccess)
-				rc = fail(GEC_E_DEVICE, std::string("staging copy: ") + hipGetErrorString(e));
-		}
-		if (ci >= 1 && rc == GEC_OK) {
-			Staging &st = *slot[(ci - 1) % 2];
-			const size_t b0 = (ci - 1) * ch, nb = std::min(ch, nblocks - b0);
-			hipError_t e = hipStreamSynchronize(st.stream);
-			if (e != hipSuccess) {
-				rc = fail(GEC_E_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
-				break;
-			}
+		},
+		[&](size_t ci, Staging &st) -> int {  // device: only data shards go H2D, only parity comes back
+			const size_t nb = std::min(ch, nblocks - ci * ch);
+			HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, st.h_buf, stripe, k * S, nb, hipMemcpyHostToDevice, st.stream));
+			int rc = encode_dev(c, nb, st.d_buf, stripe, S, st.d_buf + k * S, stripe, st.stream);
+			if (rc)
+				return rc;
+			HIP_TRY(hipMemcpy2DAsync(st.h_buf + k * S, stripe, st.d_buf + k * S, stripe, m * S, nb, hipMemcpyDeviceToHost, st.stream));
+			return GEC_OK;
+		},
+		[&](size_t ci, Staging &st) {  // host: parity -> user buffers
+			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
 			pool.parallel_for(nb, [&](size_t i) { std::memcpy(parity[b0 + i], st.h_buf + i * stripe + k * S, m * S); });
-		}
-	}
-	if (rc != GEC_OK) {  // leave no work in flight on pooled buffers
-		(void)hipStreamSynchronize(slot[0]->stream);
-		if (slot[1]->stream)
-			(void)hipStreamSynchronize(slot[1]->stream);
-	}
-	return rc;
+		});
 }
 
 int gec_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, size_t S, uint8_t *ok)
@@ -888,31 +905,31 @@ int gec_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *s
 	for (size_t i = 0; i < nblocks * n; ++i)
 		if (!shards[i])
 			return fail(GEC_E_TOO_FEW_SHARDS, "verify needs all k+m shards");
-	DeviceGuard g(c->device);
-	if (!g.ok)
-		return fail(GEC_E_DEVICE, "hipSetDevice failed");
-	StagingLease lease(c);
-	Staging &st = lease.st;
 	const size_t stripe = n * S;
-	const size_t ch = chunk_blocks(stripe, nblocks);
-	int rc = st.ensure(ch * stripe, ch);
-	if (rc)
-		return rc;
-	for (size_t b0 = 0; b0 < nblocks; b0 += ch) {
-		const size_t nb = std::min(ch, nblocks - b0);
-		for (size_t i = 0; i < nb; ++i)
-			for (size_t j = 0; j < n; ++j)
-				std::memcpy(st.h_buf + i * stripe + j * S, shards[(b0 + i) * n + j], S);
-		HIP_TRY(hipMemcpyAsync(st.d_buf, st.h_buf, nb * stripe, hipMemcpyHostToDevice, st.stream));
-		rc = verify_dev(c, nb, st.d_buf, stripe, S, st.d_bad, st.stream);
-		if (rc)
-			return rc;
-		HIP_TRY(hipMemcpyAsync(st.h_bad, st.d_bad, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st.stream));
-		HIP_TRY(hipStreamSynchronize(st.stream));
-		for (size_t i = 0; i < nb; ++i)
-			ok[b0 + i] = st.h_bad[i] ? 0 : 1;
-	}
-	return GEC_OK;
+	const size_t ch = chunk_blocks(stripe, nblocks, kChunkBytes);
+	CopyPool &pool = copy_pool();
+	return run_pipeline(
+		c, (nblocks + ch - 1) / ch, ch * stripe, ch,
+		[&](size_t ci, Staging &st) {
+			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
+			pool.parallel_for(nb * n, [&](size_t q) {
+				std::memcpy(st.h_buf + (q / n) * stripe + (q % n) * S, shards[(b0 + q / n) * n + q % n], S);
+			});
+		},
+		[&](size_t ci, Staging &st) -> int {
+			const size_t nb = std::min(ch, nblocks - ci * ch);
+			HIP_TRY(hipMemcpyAsync(st.d_buf, st.h_buf, nb * stripe, hipMemcpyHostToDevice, st.stream));
+			int rc = verify_dev(c, nb, st.d_buf, stripe, S, st.d_bad, st.stream);
+			if (rc)
+				return rc;
+			HIP_TRY(hipMemcpyAsync(st.h_bad, st.d_bad, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st.stream));
+			return GEC_OK;
+		},
+		[&](size_t ci, Staging &st) {
+			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
+			for (size_t i = 0; i < nb; ++i)
+				ok[b0 + i] = st.h_bad[i] ? 0 : 1;
+		});
 }
 
 int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, uint8_t *const *out,
@@ -929,7 +946,7 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 	if (S % 64)
 		return fail(GEC_E_INCORRECT_SHARD_SIZE, "S must be a multiple of 64");
 	const size_t k = c->k, n = c->k + c->m;
-	// bucket blocks by erasure pattern: one decode plan + one launch per bucket chunk
+	// bucket blocks by erasure pattern: one decode plan per bucket, one launch per chunk
 	std::map<std::string, std::vector<size_t>> buckets;
 	for (size_t b = 0; b < nblocks; ++b) {
 		std::string key(n, 0);
@@ -946,40 +963,54 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 		if (npresent < n)
 			buckets[key].push_back(b);
 	}
-	if (buckets.empty())
-		return GEC_OK;
-	DeviceGuard g(c->device);
-	if (!g.ok)
-		return fail(GEC_E_DEVICE, "hipSetDevice failed");
-	StagingLease lease(c);
-	Staging &st = lease.st;
-	const size_t stripe = n * S;
+	CopyPool &pool = copy_pool();
 	for (auto &kv : buckets) {
-		const std::string &key = kv.first;
 		const std::vector<size_t> &ids = kv.second;
-		const uint8_t *present = reinterpret_cast<const uint8_t *>(key.data());
-		const size_t ch = chunk_blocks(stripe, ids.size());
-		int rc = st.ensure(ch * stripe, 0);
+		const uint8_t *present = reinterpret_cast<const uint8_t *>(kv.first.data());
+		// compact staging: only the k shards the decode reads go H2D (slots 0..k-1 of the
+		// staging stripe), only the rebuilt shards come back (slots k..k+nmiss-1)
+		std::shared_ptr<const Plan> plan;
+		int rc = get_plan(c, present, data_only != 0, plan);
 		if (rc)
 			return rc;
-		for (size_t i0 = 0; i0 < ids.size(); i0 += ch) {
-			const size_t nb = std::min(ch, ids.size() - i0);
-			for (size_t i = 0; i < nb; ++i)
-				for (size_t j = 0; j < n; ++j)
-					if (present[j])
-						std::memcpy(st.h_buf + i * stripe + j * S, shards[ids[i0 + i] * n + j], S);
-			HIP_TRY(hipMemcpyAsync(st.d_buf, st.h_buf, nb * stripe, hipMemcpyHostToDevice, st.stream));
-			rc = reconstruct_dev(c, nb, st.d_buf, stripe, stripe_offsets(c, S).data(), present, data_only != 0, 0, S,
-					     st.stream);
-			if (rc)
-				return rc;
-			HIP_TRY(hipMemcpyAsync(st.h_buf, st.d_buf, nb * stripe, hipMemcpyDeviceToHost, st.stream));
-			HIP_TRY(hipStreamSynchronize(st.stream));
-			for (size_t i = 0; i < nb; ++i)
-				for (size_t j = 0; j < n; ++j)
-					if (!present[j] && !(data_only && j >= k))
-						std::memcpy(out[ids[i0 + i] * n + j], st.h_buf + i * stripe + j * S, S);
-		}
+		const size_t nmiss = plan->missing.size();
+		if (nmiss == 0)
+			continue;
+		const size_t stripe = (k + nmiss) * S;
+		const size_t ch = chunk_blocks(stripe, ids.size(), kChunkBytes);
+		std::vector<size_t> in_off(k), out_off(nmiss);
+		for (size_t t = 0; t < k; ++t)
+			in_off[t] = t * S;
+		for (size_t r = 0; r < nmiss; ++r)
+			out_off[r] = (k + r) * S;
+		rc = run_pipeline(
+			c, (ids.size() + ch - 1) / ch, ch * stripe, 0,
+			[&](size_t ci, Staging &st) {
+				const size_t i0 = ci * ch, nb = std::min(ch, ids.size() - i0);
+				pool.parallel_for(nb * k, [&](size_t q) {
+					const size_t i = q / k, t = q % k;
+					std::memcpy(st.h_buf + i * stripe + t * S, shards[ids[i0 + i] * n + plan->valid[t]], S);
+				});
+			},
+			[&](size_t ci, Staging &st) -> int {
+				const size_t nb = std::min(ch, ids.size() - ci * ch);
+				HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, st.h_buf, stripe, k * S, nb, hipMemcpyHostToDevice, st.stream));
+				int r2 = launch_apply(c, st.d_buf, stripe, st.d_buf, stripe, nullptr, 0, S, nb, in_off.data(),
+						      out_off.data(), (int)nmiss, plan->rows.v.data(), gec::MODE_STORE, st.stream);
+				if (r2)
+					return r2;
+				HIP_TRY(hipMemcpy2DAsync(st.h_buf + k * S, stripe, st.d_buf + k * S, stripe, nmiss * S, nb, hipMemcpyDeviceToHost, st.stream));
+				return GEC_OK;
+			},
+			[&](size_t ci, Staging &st) {
+				const size_t i0 = ci * ch, nb = std::min(ch, ids.size() - i0);
+				pool.parallel_for(nb * nmiss, [&](size_t q) {
+					const size_t i = q / nmiss, r = q % nmiss;
+					std::memcpy(out[ids[i0 + i] * n + plan->missing[r]], st.h_buf + i * stripe + (k + r) * S, S);
+				});
+			});
+		if (rc)
+			return rc;
 	}
 	return GEC_OK;
 }

@@ -9,6 +9,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -512,4 +513,85 @@ int rso_reconstruct_batch(int k, int m, size_t S, size_t nblocks,
 			err = r;
 	}
 	return err;
+}
+
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+static int cmp_double(const void *a, const void *b)
+{
+	double x = *(const double *)a, y = *(const double *)b;
+	return x < y ? -1 : x > y;
+}
+
+double rso_bench_encode(int k, int m, size_t S, size_t nblocks, int reps,
+			int variant, int threads, uint64_t seed, uint8_t *checksum)
+{
+	if (check_km(k, m) || S == 0 || nblocks == 0 || reps <= 0)
+		return -1.0;
+	int n = k + m;
+	size_t stride = (size_t)n * S;
+	uint8_t *buf = (uint8_t *)malloc(stride * nblocks);
+	uint8_t *M = (uint8_t *)malloc((size_t)n * k);
+	double *t = (double *)malloc(sizeof(double) * reps);
+	if (!buf || !M || !t || rso_build_matrix(k, m, M)) {
+		free(buf);
+		free(M);
+		free(t);
+		return -1.0;
+	}
+#ifdef _OPENMP
+	if (threads <= 0)
+		threads = omp_get_max_threads();
+#else
+	threads = 1;
+#endif
+	/* first touch by the thread that will encode the block */
+#pragma omp parallel for schedule(static) num_threads(threads)
+	for (long b = 0; b < (long)nblocks; b++) {
+		uint64_t *p = (uint64_t *)(buf + (size_t)b * stride);
+		uint64_t x = seed + (uint64_t)b * 0xD1B54A32D192ED03ull;
+		for (size_t i = 0; i < (size_t)k * S / 8; i++) {
+			uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+			z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+			z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+			p[i] = z ^ (z >> 31);
+		}
+		memset(buf + (size_t)b * stride + (size_t)k * S, 0, (size_t)m * S);
+	}
+	for (int r = -1; r < reps; r++) { /* r == -1: warm-up */
+		double t0 = now_s();
+#pragma omp parallel for schedule(static) num_threads(threads)
+		for (long b = 0; b < (long)nblocks; b++) {
+			const uint8_t *in[256];
+			uint8_t *out[256];
+			const uint8_t *rows[256];
+			uint8_t *base = buf + (size_t)b * stride;
+			for (int i = 0; i < k; i++)
+				in[i] = base + (size_t)i * S;
+			for (int j = 0; j < m; j++) {
+				out[j] = base + (size_t)(k + j) * S;
+				rows[j] = M + (size_t)(k + j) * k;
+			}
+			code_some(k, m, rows, in, out, S, variant);
+		}
+		if (r >= 0)
+			t[r] = now_s() - t0;
+	}
+	uint8_t acc = 0;
+	for (size_t b = 0; b < nblocks; b++)
+		for (size_t i = 0; i < (size_t)m * S; i += 4099)
+			acc ^= buf[b * stride + (size_t)k * S + i];
+	if (checksum)
+		*checksum = acc;
+	qsort(t, reps, sizeof(double), cmp_double);
+	double med = t[reps / 2];
+	free(buf);
+	free(M);
+	free(t);
+	return med;
 }

@@ -90,6 +90,13 @@ int rso_reconstruct_batch(int k, int m, size_t S, size_t nblocks,
 			  uint8_t *stripes, size_t stride,
 			  const uint8_t *present, int data_only, int threads);
 int rso_max_threads(void);
+/* Self-contained timing loop for bench.py's cpu_baseline leg: allocates
+ * nblocks stripes, fills the data shards with a SplitMix64 stream inside the
+ * same static OpenMP schedule that encodes them (NUMA first-touch), runs `reps`
+ * encodes and returns seconds per rep (median of reps); *checksum gets the XOR
+ * of all parity bytes of the last rep so the work cannot be elided. */
+double rso_bench_encode(int k, int m, size_t S, size_t nblocks, int reps,
+			int variant, int threads, uint64_t seed, uint8_t *checksum);
 
 #ifdef __cplusplus
 }

@@ -261,6 +261,9 @@ class COracle:
             ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
             ctypes.c_void_p, ctypes.c_size_t, u8p, ctypes.c_int, ctypes.c_int,
         ]
+        L.rso_bench_encode.restype = ctypes.c_double
+        L.rso_bench_encode.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u8p]
         L.rso_has_avx2.restype = ctypes.c_int
         L.rso_max_threads.restype = ctypes.c_int
 
@@ -273,6 +276,15 @@ class COracle:
 
     def max_threads(self) -> int:
         return int(self.lib.rso_max_threads())
+
+    def bench_encode(self, k: int, m: int, S: int, nblocks: int, reps: int, variant: int, threads: int,
+                     seed: int = 1) -> float:
+        """seconds per encode of `nblocks` blocks (median of reps), NUMA first-touch inside C."""
+        cs = ctypes.c_uint8()
+        t = self.lib.rso_bench_encode(k, m, S, nblocks, reps, variant, threads, seed, ctypes.byref(cs))
+        if t <= 0:
+            raise ValueError("rso_bench_encode failed")
+        return float(t)
 
     def invert(self, mat: np.ndarray) -> np.ndarray:
         mat = np.ascontiguousarray(mat, dtype=np.uint8)

@@ -405,3 +405,36 @@ def test_config5_shape_rs_20_8_4mib(coracle):
     torch.cuda.synchronize()
     assert torch.equal(st, ref)
     assert rs.verify_dev(st).all()
+
+
+def test_more_tiles_than_one_launch_holds():
+    """> 2^22 tiles forces the host to split the work into several launches
+    (ApplyArgs.tile0).  RS(3,1), S = 64: one tile per block, parity must be the
+    XOR of the three data shards (Appendix A.4.4) -- checked on device."""
+    k, m, S = 3, 1, 64
+    nb = (1 << 22) + 1000
+    rs = g.ReedSolomon(k, m)
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(5)
+    st = torch.randint(0, 256, (nb, k + m, S), dtype=torch.uint8, device=DEV, generator=gen)
+    rs.encode_dev(st)
+    torch.cuda.synchronize()
+    want = st[:, 0] ^ st[:, 1] ^ st[:, 2]
+    assert torch.equal(st[:, 3], want)
+    assert rs.verify_dev(st).all()
+    # reconstruct across the launch boundary too
+    ref = st[:, 1].clone()
+    st[:, 1] = 0
+    rs.reconstruct_dev(st, [1, 0, 1, 1])
+    torch.cuda.synchronize()
+    assert torch.equal(st[:, 1], ref)
+
+
+def test_large_shard_16mib(coracle):
+    """Maximum-size style case: one RS(4,2) stripe with 16 MiB shards (a 64 MiB block)."""
+    k, m, S = 4, 2, 16 << 20
+    rs = g.ReedSolomon(k, m)
+    data = rand_blocks(321, 1, k, S)
+    got = gpu_encode(rs, data)
+    want = coracle.encode_batch(k, m, data, coracle.AVX2, threads=4)
+    assert np.array_equal(got, want)

@@ -197,3 +197,10 @@ def test_splitmix64_known():
     # SplitMix64 reference outputs for seed 1234567 (Vigna's splitmix64.c)
     b = O.splitmix64_bytes(1234567, 24).view("<u8")
     assert [int(x) for x in b] == [6457827717110365317, 3203168211198807973, 9817491932198370423]
+
+
+def test_bench_helper_runs(coracle):
+    # the timing helper of bench.py's cpu_baseline leg: sane, positive, both variants
+    for variant in (coracle.SCALAR, coracle.AVX2):
+        t = coracle.bench_encode(10, 4, 4096, 8, 3, variant, 2)
+        assert 0 < t < 5
