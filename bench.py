@@ -116,21 +116,15 @@ def main() -> None:
     import garage_amd as g
     from garage_amd.partition import gpu_of_hash
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from garage_amd import distrib
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU (libgarage_ec has no CPU path)"
+    R = distrib.init_from_env()
+    world, rank, local_rank, dev = R.world, R.rank, R.local_rank, R.device
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (libgarage_ec has no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.init_process_group("nccl", device_id=dev)
 
     g.set_kernel_variant(args.variant)
     S = g.shard_len(K, BLOCK_LEN)
@@ -162,8 +156,7 @@ def main() -> None:
             g._lib.check(rc, "gec_encode_batch_dev")
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        distrib.barrier(R)
 
     for _ in range(args.warmup):
         encode_step()
@@ -182,15 +175,8 @@ def main() -> None:
     elapsed = t1 - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps  # avg launch duration, HIP events on the launch stream
 
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        cnt = torch.tensor([nb], dtype=torch.int64, device=dev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        blocks_all = int(cnt.item())
-    else:
-        blocks_all = nb
+    elapsed = distrib.max_over_ranks(R, elapsed)      # MAX over ranks
+    blocks_all = distrib.sum_over_ranks(R, nb)        # units all ranks processed
 
     # correctness gate inside the bench: parity written by the timed kernel verifies
     assert bool(rs.verify_dev(st).all()), "verify failed on bench output"
@@ -216,11 +202,7 @@ def main() -> None:
             rs.reconstruct_dev(st, present)  # warm: cached decode matrix
         torch.cuda.synchronize()
         barrier()
-        dt = time.perf_counter() - d0
-        if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+        dt = distrib.max_over_ranks(R, time.perf_counter() - d0)
         decode = {
             "workload": "RS(10,4) reconstruct, data shards {0,3,7,9} lost, 1 MiB blocks",
             "value": round(blocks_all * BLOCK_LEN * dsteps / dt / 2**30, 2),
@@ -274,8 +256,7 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(S)
         print(json.dumps(out), flush=True)
 
-    if dist is not None:
-        dist.destroy_process_group()
+    distrib.shutdown(R)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,83 @@
+"""One process per GPU: the few collectives the bench / multi-GPU paths need.
+
+Launched as `python -m torch.distributed.run --nproc-per-node N ...`; reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  Backend "nccl"
+(= RCCL over xGMI on MI355X) when a GPU is visible, "gloo" otherwise (CPU tests).
+The encode path itself needs NO collective: blocks are independent units.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+import torch
+
+
+@dataclass
+class Ranks:
+    rank: int
+    world: int
+    local_rank: int
+    device: torch.device
+    backend: str | None  # None: single process, no process group
+
+    @property
+    def distributed(self) -> bool:
+        return self.backend is not None
+
+
+def init_from_env(force_backend: str | None = None) -> Ranks:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_cuda = torch.cuda.is_available() and force_backend != "gloo"
+    if use_cuda:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
+    if world == 1:
+        return Ranks(rank, world, local_rank, device, None)
+    import torch.distributed as dist
+
+    backend = force_backend or ("nccl" if use_cuda else "gloo")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return Ranks(rank, world, local_rank, device, backend)
+
+
+def barrier(r: Ranks) -> None:
+    if r.distributed:
+        import torch.distributed as dist
+
+        dist.barrier()
+
+
+def max_over_ranks(r: Ranks, value: float) -> float:
+    if not r.distributed:
+        return float(value)
+    import torch.distributed as dist
+
+    t = torch.tensor([value], dtype=torch.float64, device=r.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(r: Ranks, value: int) -> int:
+    if not r.distributed:
+        return int(value)
+    import torch.distributed as dist
+
+    t = torch.tensor([value], dtype=torch.int64, device=r.device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def shutdown(r: Ranks) -> None:
+    if r.distributed:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()

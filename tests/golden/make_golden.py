@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/rs_golden.json: SHA-256 digests of parity and of
+reconstructed shards for BASELINE-sized inputs, computed with the CPU oracle
+(oracle/rs_oracle.c, AVX2 and scalar paths must agree) on SplitMix64 payloads.
+
+The reference tree holds no vectors for this path and cannot be executed here
+(SURVEY.md section 8c), so these fixtures are oracle outputs, pinned in turn by the
+upstream known-answer vectors in tests/test_oracle_kat.py.  They let the GPU
+tests check full-size configurations byte-for-byte without running the oracle.
+
+usage: python tests/golden/make_golden.py   (rewrites rs_golden.json)
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import rs_oracle as O  # noqa: E402
+
+SEED = 0x6761726167650001
+
+
+def sha(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint8).tobytes()).hexdigest()
+
+
+def case(co, name, cfg, k, m, L, nb, lost):
+    S = O.shard_len(k, L)
+    data = np.zeros((nb, k * S), dtype=np.uint8)
+    payload = O.splitmix64_bytes(SEED + cfg, nb * L).reshape(nb, L)
+    data[:, :L] = payload
+    data[0, :L] = 0            # one all-zero block
+    if nb > 1:
+        data[1, :L] = 0xFF     # one all-0xFF block
+    data = data.reshape(nb, k, S)
+    par = co.encode_batch(k, m, data, co.AVX2, threads=8)
+    par_s = co.encode_batch(k, m, data[:1], co.SCALAR, threads=1)
+    assert np.array_equal(par[:1], par_s)
+    full = np.concatenate([data, par], axis=1)
+    broken = full.copy()
+    broken[:, list(lost)] = 0
+    present = [j not in lost for j in range(k + m)]
+    rec = co.reconstruct_batch(k, m, broken, present, threads=8)
+    assert np.array_equal(rec, full)
+    valid, D = O.decode_matrix(k, m, present)
+    return {
+        "name": name, "config": cfg, "k": k, "m": m, "block_len": L, "shard_len": S, "nblocks": nb,
+        "seed": SEED + cfg, "payload_sha256": sha(data),
+        "parity_sha256": sha(par), "parity_first16": par[min(2, nb - 1), 0, :16].tolist(),
+        "lost": list(lost), "valid": valid, "decode_matrix_sha256": sha(D),
+        "reconstructed_sha256": sha(rec[:, list(lost)]),
+    }
+
+
+def main():
+    co = O.COracle()
+    cases = [
+        case(co, "config1_rs3_1_64KiB", 1, 3, 1, 65536, 16, (1,)),
+        case(co, "config2_3_rs10_4_1MiB", 2, 10, 4, 1 << 20, 8, (0, 3, 7, 9)),
+        case(co, "config3_mixed_rs10_4_1MiB", 3, 10, 4, 1 << 20, 4, (0, 3, 7, 11)),
+        case(co, "config5_rs20_8_4MiB", 5, 20, 8, 4 << 20, 2, (0, 1, 5, 9, 13, 19, 21, 27)),
+        case(co, "ragged_rs10_4_999999", 6, 10, 4, 999_999, 3, (9, 13)),
+    ]
+    with open(os.path.join(HERE, "rs_golden.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_golden.py (CPU oracle)", "cases": cases}, f, indent=1)
+    print("wrote", len(cases), "cases")
+
+
+if __name__ == "__main__":
+    main()

@@ -119,3 +119,42 @@ def test_hash_partition_properties():
     h = hashes.copy()
     h[:, [0, 2, 3]] ^= 0xFF
     assert np.array_equal(gpu_of_hash(h, 8), gpu_of_hash(hashes, 8))
+
+
+# ------------------------------------------- bench.py's multi-rank plumbing
+def _dist_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                          WORLD_SIZE=str(world))
+        from garage_amd import distrib
+
+        R = distrib.init_from_env(force_backend="gloo")
+        assert (R.rank, R.world, R.distributed) == (rank, world, True)
+        distrib.barrier(R)
+        mx = distrib.max_over_ranks(R, 1.5 + rank)
+        hashes = np.frombuffer(b"".join(block_hash(i.to_bytes(8, "little")) for i in range(512 * world)),
+                               dtype=np.uint8).reshape(-1, 32)
+        mine = int((gpu_of_hash(hashes, world) == rank).sum())
+        total = distrib.sum_over_ranks(R, mine)
+        distrib.shutdown(R)
+        q.put((rank, mx == 1.5 + world - 1 and total == 512 * world and mine > 0, f"mx={mx} total={total}"))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, False, traceback.format_exc()))
+
+
+@pytest.mark.timeout(180)
+def test_bench_rank_plumbing_world2():
+    """The barrier / max-over-ranks / sum-of-units contract bench.py uses at N>1."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    for rank, ok, msg in res:
+        assert ok, f"rank {rank}: {msg}"
