@@ -36,7 +36,8 @@ SYMBOLS = [
     "gec_codec_device", "gec_parity_matrix", "gec_codec_cache_stats",
     "gec_encode_batch", "gec_verify_batch", "gec_reconstruct_batch",
     "gec_encode_batch_dev", "gec_verify_batch_dev", "gec_reconstruct_batch_dev",
-    "gec_reconstruct_range_dev", "gec_reconstruct_scattered_dev", "gec_set_kernel_variant", "gec_get_kernel_variant",
+    "gec_reconstruct_range_dev", "gec_reconstruct_scattered_dev", "gec_blake2sum_batch_dev", "gec_blake2sum_batch",
+    "gec_encode_hash_batch", "gec_set_kernel_variant", "gec_get_kernel_variant",
 ]
 
 
@@ -94,6 +95,9 @@ def _load() -> ctypes.CDLL:
     lib.gec_reconstruct_batch_dev.argtypes = [vp, sz, vp, sz, sz, u8p, ci, vp]
     lib.gec_reconstruct_range_dev.argtypes = [vp, sz, vp, sz, sz, u8p, ci, sz, sz, vp]
     lib.gec_reconstruct_scattered_dev.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), sz, u8p, ci, sz, sz, vp]
+    lib.gec_blake2sum_batch_dev.argtypes = [vp, sz, vp, sz, sz, vp, vp]
+    lib.gec_blake2sum_batch.argtypes = [vp, sz, pp, ctypes.POINTER(sz), u8p]
+    lib.gec_encode_hash_batch.argtypes = [vp, sz, pp, ctypes.POINTER(sz), sz, pp, u8p]
     lib.gec_set_kernel_variant.argtypes = [ci]
     return lib
 

@@ -1,0 +1,202 @@
+"""ctypes binding of libgarage_block.so (include/garage_block.h): the C++
+host-side mirror of garage_block::BlockManager with EC fan-out.  Method names
+follow the reference (rpc_put_block, rpc_get_block, block_incref, ...)."""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence
+
+from . import _lib  # loads libgarage_ec.so first (single HIP runtime, see _lib.py)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgarage_block.so")
+
+GBM_OK, GBM_E_MISSING_BLOCK, GBM_E_CORRUPT_DATA, GBM_E_QUORUM = 0, -1, -2, -3
+GBM_E_INVALID_ARG, GBM_E_EC, GBM_E_IO, GBM_E_BUFFER_TOO_SMALL = -4, -5, -6, -7
+
+SYMBOLS = [
+    "gbm_last_error", "gbm_blake2sum", "gbm_create", "gbm_destroy", "gbm_storage_nodes_of",
+    "gbm_rpc_put_block", "gbm_rpc_put_blocks", "gbm_rpc_get_block", "gbm_rpc_get_blocks",
+    "gbm_block_incref", "gbm_block_decref", "gbm_resync_block", "gbm_resync_all", "gbm_resync_queue_len",
+    "gbm_scrub", "gbm_node_set_down", "gbm_node_has_shard", "gbm_node_delete_shard",
+    "gbm_node_corrupt_shard", "gbm_metrics", "gbm_gpu_hashed",
+]
+
+
+class BlockError(RuntimeError):
+    def __init__(self, code: int, what: str, detail: str):
+        super().__init__(f"{what}: {detail} (code {code})")
+        self.code = code
+
+
+class MissingBlock(BlockError):
+    pass
+
+
+class CorruptData(BlockError):
+    pass
+
+
+class Quorum(BlockError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `make -C garage_amd/csrc`")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    pp = ctypes.POINTER(ctypes.c_void_p)
+    lib.gbm_last_error.restype = ctypes.c_char_p
+    lib.gbm_blake2sum.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p]
+    lib.gbm_blake2sum.restype = None
+    lib.gbm_create.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), ci, pp]
+    lib.gbm_destroy.argtypes = [vp]
+    lib.gbm_destroy.restype = None
+    lib.gbm_storage_nodes_of.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ci)]
+    lib.gbm_rpc_put_block.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, sz]
+    lib.gbm_rpc_put_blocks.argtypes = [vp, sz, ctypes.c_char_p, pp, ctypes.POINTER(sz)]
+    lib.gbm_rpc_get_block.argtypes = [vp, ctypes.c_char_p, vp, sz, ctypes.POINTER(sz)]
+    lib.gbm_rpc_get_blocks.argtypes = [vp, sz, ctypes.c_char_p, pp, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(ci)]
+    for f in ("gbm_block_incref", "gbm_block_decref"):
+        getattr(lib, f).argtypes = [vp, ctypes.c_char_p]
+    lib.gbm_resync_block.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ci)]
+    lib.gbm_resync_all.argtypes = [vp, ctypes.POINTER(ci)]
+    lib.gbm_resync_queue_len.argtypes = [vp]
+    lib.gbm_resync_queue_len.restype = sz
+    lib.gbm_scrub.argtypes = [vp, sz, ctypes.c_char_p, u8p]
+    lib.gbm_node_set_down.argtypes = [vp, ci, ci]
+    lib.gbm_node_has_shard.argtypes = [vp, ci, ctypes.c_char_p, ci]
+    lib.gbm_node_delete_shard.argtypes = [vp, ci, ctypes.c_char_p, ci]
+    lib.gbm_node_corrupt_shard.argtypes = [vp, ci, ctypes.c_char_p, ci, sz, ctypes.c_uint8, ci]
+    lib.gbm_metrics.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.gbm_gpu_hashed.argtypes = [vp]
+    lib.gbm_gpu_hashed.restype = ctypes.c_uint64
+    return lib
+
+
+lib = _load()
+
+
+def _check(rc: int, what: str) -> None:
+    if rc == GBM_OK:
+        return
+    detail = (lib.gbm_last_error() or b"").decode("utf-8", "replace")
+    cls = {GBM_E_MISSING_BLOCK: MissingBlock, GBM_E_CORRUPT_DATA: CorruptData, GBM_E_QUORUM: Quorum}.get(rc, BlockError)
+    raise cls(rc, what, detail)
+
+
+def blake2sum(data: bytes) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    lib.gbm_blake2sum(data, len(data), out)
+    return out.raw
+
+
+class NativeBlockManager:
+    """garage_block::BlockManager mirror (C++), `codec` is a garage_amd.ReedSolomon."""
+
+    METRICS = ("bytes_written", "bytes_read", "corruption_counter", "ec_reconstructs", "blocks_put", "blocks_get")
+
+    def __init__(self, codec, nnodes: int, node_dirs: Optional[Sequence[str]] = None, write_quorum: int = 0):
+        self.codec = codec  # keep the borrowed codec alive
+        self.k, self.m, self.n, self.nnodes = codec.k, codec.m, codec.k + codec.m, nnodes
+        dirs = None
+        if node_dirs is not None:
+            assert len(node_dirs) == nnodes
+            dirs = (ctypes.c_char_p * nnodes)(*[d.encode() for d in node_dirs])
+        h = ctypes.c_void_p()
+        _check(lib.gbm_create(codec._h, nnodes, dirs, write_quorum, ctypes.byref(h)), "gbm_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.gbm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def storage_nodes_of(self, hash_: bytes) -> list[int]:
+        out = (ctypes.c_int * self.n)()
+        _check(lib.gbm_storage_nodes_of(self._h, hash_, out), "gbm_storage_nodes_of")
+        return list(out)
+
+    def rpc_put_block(self, hash_: bytes, data: bytes, prevent_compression: bool = False, order_tag=None) -> None:
+        _check(lib.gbm_rpc_put_block(self._h, hash_, data, len(data)), "rpc_put_block")
+
+    def rpc_put_blocks(self, items: Sequence[tuple[bytes, bytes]]) -> None:
+        n = len(items)
+        hashes = b"".join(h for h, _ in items)
+        bufs = [ctypes.create_string_buffer(d, len(d)) for _, d in items]
+        ptrs = (ctypes.c_void_p * n)(*[ctypes.addressof(b) for b in bufs])
+        lens = (ctypes.c_size_t * n)(*[len(d) for _, d in items])
+        _check(lib.gbm_rpc_put_blocks(self._h, n, hashes, ptrs, lens), "rpc_put_blocks")
+
+    def rpc_get_block(self, hash_: bytes, max_len: int = 1 << 26, order_tag=None) -> bytes:
+        ln = ctypes.c_size_t()
+        buf = ctypes.create_string_buffer(min(max_len, 1 << 22))
+        rc = lib.gbm_rpc_get_block(self._h, hash_, buf, len(buf), ctypes.byref(ln))
+        if rc == GBM_E_BUFFER_TOO_SMALL and ln.value <= max_len:
+            buf = ctypes.create_string_buffer(ln.value)
+            rc = lib.gbm_rpc_get_block(self._h, hash_, buf, len(buf), ctypes.byref(ln))
+        _check(rc, "rpc_get_block")
+        return buf.raw[: ln.value]
+
+    def rpc_get_blocks(self, hashes: Sequence[bytes], max_len: int) -> list:
+        """Batched get: returns bytes per block, or the BlockError class on failure."""
+        n = len(hashes)
+        bufs = [ctypes.create_string_buffer(max_len) for _ in range(n)]
+        ptrs = (ctypes.c_void_p * n)(*[ctypes.addressof(b) for b in bufs])
+        caps = (ctypes.c_size_t * n)(*[max_len] * n)
+        lens = (ctypes.c_size_t * n)()
+        rcs = (ctypes.c_int * n)()
+        _check(lib.gbm_rpc_get_blocks(self._h, n, b"".join(hashes), ptrs, caps, lens, rcs), "rpc_get_blocks")
+        return [bufs[i].raw[: lens[i]] if rcs[i] == 0 else rcs[i] for i in range(n)]
+
+    def block_incref(self, hash_: bytes) -> None:
+        _check(lib.gbm_block_incref(self._h, hash_), "block_incref")
+
+    def block_decref(self, hash_: bytes) -> None:
+        _check(lib.gbm_block_decref(self._h, hash_), "block_decref")
+
+    def resync_block(self, hash_: bytes) -> int:
+        c = ctypes.c_int()
+        _check(lib.gbm_resync_block(self._h, hash_, ctypes.byref(c)), "resync_block")
+        return c.value
+
+    def resync_all(self) -> int:
+        c = ctypes.c_int()
+        _check(lib.gbm_resync_all(self._h, ctypes.byref(c)), "resync_all")
+        return c.value
+
+    def resync_queue_len(self) -> int:
+        return int(lib.gbm_resync_queue_len(self._h))
+
+    def scrub(self, hashes: Sequence[bytes]) -> list[bytes]:
+        n = len(hashes)
+        bad = (ctypes.c_uint8 * n)()
+        _check(lib.gbm_scrub(self._h, n, b"".join(hashes), bad), "scrub")
+        return [h for h, b in zip(hashes, bad) if b]
+
+    # fault injection -------------------------------------------------------------
+    def node_set_down(self, node: int, down: bool) -> None:
+        _check(lib.gbm_node_set_down(self._h, node, int(down)), "node_set_down")
+
+    def node_has_shard(self, node: int, hash_: bytes, idx: int) -> bool:
+        return bool(lib.gbm_node_has_shard(self._h, node, hash_, idx))
+
+    def node_delete_shard(self, node: int, hash_: bytes, idx: int) -> None:
+        _check(lib.gbm_node_delete_shard(self._h, node, hash_, idx), "node_delete_shard")
+
+    def node_corrupt_shard(self, node: int, hash_: bytes, idx: int, offset: int, mask: int = 1, fix_checksum: bool = False):
+        _check(lib.gbm_node_corrupt_shard(self._h, node, hash_, idx, offset, mask, int(fix_checksum)), "node_corrupt_shard")
+
+    def gpu_hashed(self) -> int:
+        return int(lib.gbm_gpu_hashed(self._h))
+
+    @property
+    def metrics(self) -> dict:
+        out = (ctypes.c_uint64 * 6)()
+        _check(lib.gbm_metrics(self._h, out), "gbm_metrics")
+        return dict(zip(self.METRICS, [int(x) for x in out]))

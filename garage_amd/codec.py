@@ -195,6 +195,47 @@ class ReedSolomon:
         check(lib.gec_encode_batch(self._h, nb, ptrs, lens, S, optrs), "gec_encode_batch")
         return outs
 
+    def encode_hash_blocks(self, blocks: Sequence[bytes], S: Optional[int] = None):
+        """encode_blocks + the blake2sum of every shard, hashed on the GPU while the
+        stripe is resident: -> (parities, sums) with sums shape (nblocks, k+m, 32)."""
+        nb = len(blocks)
+        if nb == 0:
+            return [], np.zeros((0, self.n, 32), dtype=np.uint8)
+        if S is None:
+            S = max(shard_len(self.k, len(b)) for b in blocks)
+        bufs = [np.frombuffer(bytes(b), dtype=np.uint8) if len(b) else np.zeros(1, dtype=np.uint8) for b in blocks]
+        lens = (ctypes.c_size_t * nb)(*[len(b) for b in blocks])
+        ptrs = (ctypes.c_void_p * nb)(*[a.ctypes.data for a in bufs])
+        outs = [np.empty((self.m, S), dtype=np.uint8) for _ in range(nb)]
+        optrs = (ctypes.c_void_p * nb)(*[o.ctypes.data for o in outs])
+        sums = np.empty((nb, self.n, 32), dtype=np.uint8)
+        check(lib.gec_encode_hash_batch(self._h, nb, ptrs, lens, S, optrs, _u8p(sums)), "gec_encode_hash_batch")
+        return outs, sums
+
+    def blake2sum_batch(self, msgs: Sequence[bytes]) -> list[bytes]:
+        """Garage's blake2sum (blake2b-512[..32]) of every message, on the GPU."""
+        n = len(msgs)
+        if n == 0:
+            return []
+        bufs = [np.frombuffer(bytes(x), dtype=np.uint8) if len(x) else np.zeros(1, dtype=np.uint8) for x in msgs]
+        ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in bufs])
+        lens = (ctypes.c_size_t * n)(*[len(x) for x in msgs])
+        out = np.empty((n, 32), dtype=np.uint8)
+        check(lib.gec_blake2sum_batch(self._h, n, ptrs, lens, _u8p(out)), "gec_blake2sum_batch")
+        return [out[i].tobytes() for i in range(n)]
+
+    def blake2sum_dev(self, t):
+        """t: (n, len) uint8 CUDA tensor, rows 16-byte aligned -> (n, 32) uint8 tensor."""
+        import torch
+
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.dim() == 2 and t.is_contiguous()):
+            raise TypeError("expected a contiguous 2-D uint8 CUDA tensor")
+        n, ln = t.shape
+        out = torch.empty((n, 32), dtype=torch.uint8, device=t.device)
+        check(lib.gec_blake2sum_batch_dev(self._h, n, t.data_ptr(), ln, ln, out.data_ptr(), _stream_handle(self.device)),
+              "gec_blake2sum_batch_dev")
+        return out
+
     def verify(self, stripes: np.ndarray) -> np.ndarray:
         """stripes: (nblocks, k+m, S) host array -> bool (nblocks,)."""
         st = np.ascontiguousarray(stripes, dtype=np.uint8)

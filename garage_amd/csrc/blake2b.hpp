@@ -1,0 +1,162 @@
+// blake2b.hpp -- batched BLAKE2b-512 on gfx950, truncated to Garage's 32-byte
+// `blake2sum` (src/util/data.rs:130-138: blake2b-512, first 32 bytes; NOT blake2b-256).
+// once RS encode runs at TB/s the CPU hash pass
+// (~1 GiB/s/core) is the pipeline bottleneck, so shard checksums are computed
+// where the shards already are.
+//
+// BLAKE2b is a serial chain per message (RFC 7693), so the parallelism is ACROSS
+// messages: one lane per message, all state in VGPRs (v[16], m[16], h[8] as
+// 64-bit pairs), 12 rounds x 8 G per 128-byte block = ~2600 VALU ops per block.
+// That makes it VALU-bound (~20 ops/byte): the loads (each lane streams its own
+// message, 128 contiguous bytes per round) are <10% of the issue slots.  A batch of
+// 1024 RS(10,4) stripes = 14336 shard messages = 224 waves.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gec {
+
+struct Blake2Args {
+	const uint8_t *base;
+	const uint64_t *off;   // per-message byte offset from base (NULL: i * stride)
+	const uint64_t *len;   // per-message length (NULL: uniform_len)
+	uint64_t stride;
+	uint64_t uniform_len;
+	uint8_t *out;          // 32 bytes per message
+	uint32_t n;
+};
+
+// rotr64 as two v_alignbit_b32 on the 32-bit halves (hipcc's generic lowering is a
+// 64-bit shift + shift + or); n = 32 is a free register swap.
+template <int N>
+__device__ __forceinline__ uint64_t b2_rotr(uint64_t x)
+{
+	const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+	if (N == 32)
+		return ((uint64_t)lo << 32) | hi;
+	if (N < 32) {
+		const uint32_t nlo = __builtin_amdgcn_alignbit(hi, lo, N);
+		const uint32_t nhi = __builtin_amdgcn_alignbit(lo, hi, N);
+		return ((uint64_t)nhi << 32) | nlo;
+	}
+	// N > 32: rotate by 32 (swap) then by N - 32
+	const uint32_t nlo = __builtin_amdgcn_alignbit(lo, hi, N - 32);
+	const uint32_t nhi = __builtin_amdgcn_alignbit(hi, lo, N - 32);
+	return ((uint64_t)nhi << 32) | nlo;
+}
+
+// 64-bit add as add + add-with-carry on the halves (two full-rate VALU ops); hipcc's
+// own choice, v_lshl_add_u64, issues at the 64-bit rate and made the chain ~1.6x slower.
+template <bool ADD32>
+__device__ __forceinline__ uint64_t b2_add(uint64_t a, uint64_t b)
+{
+	if (!ADD32)
+		return a + b;
+	uint32_t lo, hi;
+	const uint32_t carry = __builtin_uadd_overflow((uint32_t)a, (uint32_t)b, &lo);
+	hi = (uint32_t)(a >> 32) + (uint32_t)(b >> 32) + carry;
+	return ((uint64_t)hi << 32) | lo;
+}
+
+#define GEC_B2_G(a, b, c, d, x, y)       \
+	a = b2_add<ADD32>(b2_add<ADD32>(a, b), (x));   \
+	d = b2_rotr<32>(d ^ a);          \
+	c = b2_add<ADD32>(c, d);               \
+	b = b2_rotr<24>(b ^ c);          \
+	a = b2_add<ADD32>(b2_add<ADD32>(a, b), (y));   \
+	d = b2_rotr<16>(d ^ a);          \
+	c = b2_add<ADD32>(c, d);               \
+	b = b2_rotr<63>(b ^ c);
+
+#define GEC_B2_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+	GEC_B2_G(v0, v4, v8, v12, m[s0], m[s1]);                                           \
+	GEC_B2_G(v1, v5, v9, v13, m[s2], m[s3]);                                           \
+	GEC_B2_G(v2, v6, v10, v14, m[s4], m[s5]);                                          \
+	GEC_B2_G(v3, v7, v11, v15, m[s6], m[s7]);                                          \
+	GEC_B2_G(v0, v5, v10, v15, m[s8], m[s9]);                                          \
+	GEC_B2_G(v1, v6, v11, v12, m[s10], m[s11]);                                        \
+	GEC_B2_G(v2, v7, v8, v13, m[s12], m[s13]);                                         \
+	GEC_B2_G(v3, v4, v9, v14, m[s14], m[s15]);
+
+template <bool ADD32>
+__device__ __forceinline__ void b2_compress(uint64_t (&h)[8], const uint64_t (&m)[16], uint64_t t, bool last)
+{
+	const uint64_t IV0 = 0x6a09e667f3bcc908ULL, IV1 = 0xbb67ae8584caa73bULL, IV2 = 0x3c6ef372fe94f82bULL,
+		       IV3 = 0xa54ff53a5f1d36f1ULL, IV4 = 0x510e527fade682d1ULL, IV5 = 0x9b05688c2b3e6c1fULL,
+		       IV6 = 0x1f83d9abfb41bd6bULL, IV7 = 0x5be0cd19137e2179ULL;
+	uint64_t v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
+	uint64_t v8 = IV0, v9 = IV1, v10 = IV2, v11 = IV3, v12 = IV4 ^ t, v13 = IV5, v14 = last ? ~IV6 : IV6, v15 = IV7;
+	// sigma permutations are compile-time, so m[] stays in registers
+	GEC_B2_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+	GEC_B2_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+	GEC_B2_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+	GEC_B2_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+	GEC_B2_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+	GEC_B2_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+	GEC_B2_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+	GEC_B2_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+	GEC_B2_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+	GEC_B2_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+	GEC_B2_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+	GEC_B2_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+	h[0] ^= v0 ^ v8;
+	h[1] ^= v1 ^ v9;
+	h[2] ^= v2 ^ v10;
+	h[3] ^= v3 ^ v11;
+	h[4] ^= v4 ^ v12;
+	h[5] ^= v5 ^ v13;
+	h[6] ^= v6 ^ v14;
+	h[7] ^= v7 ^ v15;
+}
+
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+
+// Messages must start on 16-byte boundaries (shards do: 64-byte geometry; the host
+// API stages each message into a 16-byte aligned slot).
+template <bool ADD32>
+__global__ __launch_bounds__(64) void blake2b_batch(const Blake2Args a)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= a.n)
+		return;
+	const uint8_t *p = a.base + (a.off ? a.off[i] : (uint64_t)i * a.stride);
+	const uint64_t len = a.len ? a.len[i] : a.uniform_len;
+	uint64_t h[8] = {0x6a09e667f3bcc908ULL ^ 0x01010040ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL,
+			 0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL,
+			 0x5be0cd19137e2179ULL};
+	uint64_t m[16];
+	uint64_t done = 0;
+	// full blocks, all but the last one
+	while (len - done > 128) {
+		const u64x2 *q = reinterpret_cast<const u64x2 *>(p + done);
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			u64x2 w = __builtin_nontemporal_load(q + j);
+			m[2 * j] = w.x;
+			m[2 * j + 1] = w.y;
+		}
+		done += 128;
+		b2_compress<ADD32>(h, m, done, false);
+	}
+	// last block: 0..128 bytes, zero-padded; never reads past p + len
+	const uint64_t rem = len - done;
+#pragma unroll
+	for (int j = 0; j < 16; ++j) {
+		uint64_t w = 0;
+		if ((uint64_t)(8 * j + 8) <= rem) {
+			w = *reinterpret_cast<const uint64_t *>(p + done + 8 * j);
+		} else if ((uint64_t)(8 * j) < rem) {
+			for (uint64_t b = 0; b < rem - 8 * j; ++b)
+				w |= (uint64_t)p[done + 8 * j + b] << (8 * b);
+		}
+		m[j] = w;
+	}
+	b2_compress<ADD32>(h, m, len, true);
+	u64x2 *o = reinterpret_cast<u64x2 *>(a.out + (uint64_t)i * 32);
+	u64x2 lo = {h[0], h[1]}, hi = {h[2], h[3]};
+	o[0] = lo;
+	o[1] = hi;
+}
+
+}  // namespace gec

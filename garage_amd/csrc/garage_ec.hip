@@ -15,6 +15,7 @@
 #include <functional>
 #include <thread>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <list>
 #include <map>
@@ -26,6 +27,7 @@
 
 #include "gf256.hpp"
 #include "kernels.hpp"
+#include "blake2b.hpp"
 
 namespace {
 
@@ -483,6 +485,35 @@ int verify_dev(const gec_codec *c, size_t nblocks, const uint8_t *d_stripes, siz
 			    in_off.data(), out_off.data(), m, c->enc.row(k), gec::MODE_COMPARE, stream);
 }
 
+// one lane per message, one wave per workgroup so that few messages still spread
+// over many SIMDs (the kernel is VALU-bound, occupancy per SIMD does not matter)
+int blake2_dev(size_t n, const uint8_t *d_base, const uint64_t *d_off, const uint64_t *d_len, size_t stride,
+	       size_t len, uint8_t *d_out, hipStream_t stream)
+{
+	if (n == 0)
+		return GEC_OK;
+	if (n > 0xffffffffull)
+		return fail(GEC_E_INVALID_ARG, "too many messages for one call");
+	gec::Blake2Args a;
+	a.base = d_base;
+	a.off = d_off;
+	a.len = d_len;
+	a.stride = stride;
+	a.uniform_len = len;
+	a.out = d_out;
+	a.n = (uint32_t)n;
+	static const bool add32 = [] {
+		const char *e = getenv("GEC_BLAKE2_ADD32");  // A/B knob, see DESIGN.md
+		return e ? e[0] != '0' : false;  // measured: 64-bit v_lshl_add_u64 adds are 1.44x faster
+	}();
+	if (add32)
+		hipLaunchKernelGGL(gec::blake2b_batch<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a);
+	else
+		hipLaunchKernelGGL(gec::blake2b_batch<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a);
+	HIP_TRY(hipGetLastError());
+	return GEC_OK;
+}
+
 int reconstruct_dev(const gec_codec *c, size_t nblocks, uint8_t *d_base, size_t stride, const size_t *shard_off,
 		    const uint8_t *present, bool data_only, size_t byte_off, size_t byte_len, hipStream_t stream)
 {
@@ -840,8 +871,8 @@ int gec_reconstruct_batch_dev(const gec_codec *c, size_t nblocks, void *d_stripe
 }
 
 // -------------------------------------------------------- host-pointer API
-int gec_encode_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *blocks, const size_t *block_len,
-		     size_t S, uint8_t *const *parity)
+static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *const *blocks, const size_t *block_len,
+			     size_t S, uint8_t *const *parity, uint8_t *shard_sums)
 {
 	if (!c)
 		return fail(GEC_E_INVALID_ARG, "NULL codec");
@@ -861,10 +892,13 @@ int gec_encode_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *b
 			return fail(GEC_E_INCORRECT_SHARD_SIZE, "block longer than k*S");
 	}
 	const size_t stripe = n * S;
-	const size_t ch = chunk_blocks(stripe, nblocks, kChunkBytes);
+	// the hash kernel's serial chain costs ~3.5 ms per launch whatever the batch, so
+	// chunks are 8x larger when checksums are requested
+	const size_t ch = chunk_blocks(stripe, nblocks, shard_sums ? 8 * kChunkBytes : kChunkBytes);
+	const size_t sums_off = ch * stripe;  // checksum area behind the stripes of a slot
 	CopyPool &pool = copy_pool();
 	return run_pipeline(
-		c, (nblocks + ch - 1) / ch, ch * stripe, 0,
+		c, (nblocks + ch - 1) / ch, ch * stripe + (shard_sums ? ch * n * 32 : 0), 0,
 		[&](size_t ci, Staging &st) {  // host: user blocks -> pinned, zero-padded to k*S
 			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
 			pool.parallel_for(nb, [&](size_t i) {
@@ -874,18 +908,119 @@ int gec_encode_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *b
 				std::memset(dst + len, 0, k * S - len);
 			});
 		},
-		[&](size_t ci, Staging &st) -> int {  // device: only data shards go H2D, only parity comes back
+		[&](size_t ci, Staging &st) -> int {  // device: only data shards go H2D, only parity (+sums) comes back
 			const size_t nb = std::min(ch, nblocks - ci * ch);
 			HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, st.h_buf, stripe, k * S, nb, hipMemcpyHostToDevice, st.stream));
 			int rc = encode_dev(c, nb, st.d_buf, stripe, S, st.d_buf + k * S, stripe, st.stream);
 			if (rc)
 				return rc;
 			HIP_TRY(hipMemcpy2DAsync(st.h_buf + k * S, stripe, st.d_buf + k * S, stripe, m * S, nb, hipMemcpyDeviceToHost, st.stream));
+			if (shard_sums) {  // all nb*n shards are S bytes, S apart: one uniform launch
+				rc = blake2_dev(nb * n, st.d_buf, nullptr, nullptr, S, S, st.d_buf + sums_off, st.stream);
+				if (rc)
+					return rc;
+				HIP_TRY(hipMemcpyAsync(st.h_buf + sums_off, st.d_buf + sums_off, nb * n * 32, hipMemcpyDeviceToHost, st.stream));
+			}
 			return GEC_OK;
 		},
-		[&](size_t ci, Staging &st) {  // host: parity -> user buffers
+		[&](size_t ci, Staging &st) {  // host: parity (+sums) -> user buffers
 			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
 			pool.parallel_for(nb, [&](size_t i) { std::memcpy(parity[b0 + i], st.h_buf + i * stripe + k * S, m * S); });
+			if (shard_sums)
+				std::memcpy(shard_sums + b0 * n * 32, st.h_buf + sums_off, nb * n * 32);
+		});
+}
+
+int gec_encode_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *blocks, const size_t *block_len,
+		     size_t S, uint8_t *const *parity)
+{
+	return encode_batch_impl(c, nblocks, blocks, block_len, S, parity, nullptr);
+}
+
+int gec_encode_hash_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *blocks, const size_t *block_len,
+			  size_t S, uint8_t *const *parity, uint8_t *shard_sums)
+{
+	if (!shard_sums)
+		return fail(GEC_E_INVALID_ARG, "NULL shard_sums");
+	return encode_batch_impl(c, nblocks, blocks, block_len, S, parity, shard_sums);
+}
+
+int gec_blake2sum_batch_dev(const gec_codec *c, size_t n, const void *d_base, size_t stride, size_t len, void *d_out,
+			    void *hip_stream)
+{
+	if (!c || (n && (!d_base || !d_out)))
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (reinterpret_cast<uintptr_t>(d_base) % 16 || stride % 16 || reinterpret_cast<uintptr_t>(d_out) % 16)
+		return fail(GEC_E_INVALID_ARG, "device pointers/stride must be 16-byte aligned");
+	if (n > 1 && stride < len)
+		return fail(GEC_E_INVALID_ARG, "stride smaller than the message length");
+	DeviceGuard g(c->device);
+	if (!g.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	return blake2_dev(n, static_cast<const uint8_t *>(d_base), nullptr, nullptr, stride, len,
+			  static_cast<uint8_t *>(d_out), static_cast<hipStream_t>(hip_stream));
+}
+
+int gec_blake2sum_batch(const gec_codec *c, size_t n, const uint8_t *const *msgs, const size_t *lens, uint8_t *out)
+{
+	if (!c)
+		return fail(GEC_E_INVALID_ARG, "NULL codec");
+	if (n == 0)
+		return GEC_OK;
+	if (!msgs || !lens || !out)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	for (size_t i = 0; i < n; ++i)
+		if (!msgs[i] && lens[i])
+			return fail(GEC_E_INVALID_ARG, "NULL message pointer");
+	// greedy chunks of <= kChunkBytes of (16-byte aligned) message slots
+	struct Chunk {
+		size_t first, count, bytes;
+	};
+	std::vector<Chunk> chunks;
+	std::vector<uint64_t> slot_off(n);
+	size_t max_bytes = 0, max_count = 0;
+	for (size_t i = 0; i < n;) {
+		Chunk ck{i, 0, 0};
+		while (i < n && (ck.count == 0 || ck.bytes + lens[i] <= 4 * kChunkBytes)) {
+			slot_off[i] = ck.bytes;
+			ck.bytes += (lens[i] + 15) / 16 * 16;
+			++ck.count;
+			++i;
+		}
+		chunks.push_back(ck);
+		max_bytes = std::max(max_bytes, ck.bytes);
+		max_count = std::max(max_count, ck.count);
+	}
+	// slot layout: [messages][off u64 x count][len u64 x count][out 32 x count]
+	const size_t meta_off = (max_bytes + 63) / 64 * 64;
+	const size_t out_off = meta_off + 16 * max_count;
+	CopyPool &pool = copy_pool();
+	return run_pipeline(
+		c, chunks.size(), out_off + 32 * max_count, 0,
+		[&](size_t ci, Staging &st) {
+			const Chunk &ck = chunks[ci];
+			uint64_t *offs = reinterpret_cast<uint64_t *>(st.h_buf + meta_off);
+			uint64_t *ls = offs + ck.count;
+			pool.parallel_for(ck.count, [&](size_t i) {
+				std::memcpy(st.h_buf + slot_off[ck.first + i], msgs[ck.first + i], lens[ck.first + i]);
+				offs[i] = slot_off[ck.first + i];
+				ls[i] = lens[ck.first + i];
+			});
+		},
+		[&](size_t ci, Staging &st) -> int {
+			const Chunk &ck = chunks[ci];
+			HIP_TRY(hipMemcpyAsync(st.d_buf, st.h_buf, ck.bytes, hipMemcpyHostToDevice, st.stream));
+			HIP_TRY(hipMemcpyAsync(st.d_buf + meta_off, st.h_buf + meta_off, 16 * ck.count, hipMemcpyHostToDevice, st.stream));
+			const uint64_t *d_off = reinterpret_cast<const uint64_t *>(st.d_buf + meta_off);
+			int rc = blake2_dev(ck.count, st.d_buf, d_off, d_off + ck.count, 0, 0, st.d_buf + out_off, st.stream);
+			if (rc)
+				return rc;
+			HIP_TRY(hipMemcpyAsync(st.h_buf + out_off, st.d_buf + out_off, 32 * ck.count, hipMemcpyDeviceToHost, st.stream));
+			return GEC_OK;
+		},
+		[&](size_t ci, Staging &st) {
+			const Chunk &ck = chunks[ci];
+			std::memcpy(out + 32 * ck.first, st.h_buf + out_off, 32 * ck.count);
 		});
 }
 

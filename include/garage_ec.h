@@ -183,6 +183,32 @@ int gec_reconstruct_scattered_dev(const gec_codec *c, size_t nblocks,
 				  size_t byte_off, size_t byte_len,
 				  void *hip_stream);
 
+/* ------------------------------------------------------- blake2sum on the GPU
+ * SURVEY.md section 8 row f4.  Garage's content hash `blake2sum` = blake2b-512
+ * truncated to 32 bytes (src/util/data.rs:130-138); today it is a CPU pass in
+ * spawn_blocking (src/api/s3/put.rs:440-456, src/block/block.rs:69-77).  Shards
+ * are not self-verifying by name like blocks are, so every shard carries such a
+ * checksum; computing it where the shards already are removes the CPU pass
+ * (~1 GiB/s/core) that otherwise dominates put/get once encode runs at TB/s. */
+
+/* n messages of `len` bytes, message i at d_base + i*stride (stride multiple of
+ * 16, base 16-byte aligned); d_out receives 32 bytes per message.  Async. */
+int gec_blake2sum_batch_dev(const gec_codec *c, size_t n, const void *d_base,
+			    size_t stride, size_t len, void *d_out,
+			    void *hip_stream);
+
+/* Host buffers of arbitrary lengths; out = n*32 bytes.  Blocking. */
+int gec_blake2sum_batch(const gec_codec *c, size_t n,
+			const uint8_t *const *msgs, const size_t *lens,
+			uint8_t *out);
+
+/* gec_encode_batch + the blake2sum of all k+m shards of every block, computed on
+ * the device while the stripe is resident: shard_sums[(b*(k+m) + j)*32 ..] is the
+ * checksum of shard j of block b (data shards as zero-extended to S bytes). */
+int gec_encode_hash_batch(const gec_codec *c, size_t nblocks,
+			  const uint8_t *const *blocks, const size_t *block_len,
+			  size_t S, uint8_t *const *parity, uint8_t *shard_sums);
+
 /* Kernel selection for A/B measurements (bench.py --variant).  0 = default
  * (nibble product tables in LDS), 1 = log/antilog tables in LDS (the literal
  * north_star formulation, kept as the measured baseline).  Process-wide. */

@@ -1,0 +1,71 @@
+"""GPU blake2sum against the CPU oracle for this
+row: Python's hashlib.blake2b (RFC 7693 reference implementation in CPython),
+truncated to 32 bytes the way Garage's blake2sum does (src/util/data.rs:130-138).
+Bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import garage_amd as g  # noqa: E402
+from oracle import rs_oracle as O  # noqa: E402
+
+
+def ref(b: bytes) -> bytes:
+    return hashlib.blake2b(b, digest_size=64).digest()[:32]
+
+
+@pytest.fixture(scope="module")
+def rs():
+    return g.ReedSolomon(10, 4)
+
+
+def test_rfc7693_abc(rs):
+    # RFC 7693 Appendix A: BLAKE2b-512("abc")
+    want = bytes.fromhex("ba80a53f981c4d0d6a2797b69f12f6e94c212f14685ac4b74b12bb6fdbffa2d1"
+                         "7d87c5392aab792dc252d5de4533cc9518d38aa8dbf1925ab92386edd4009923")
+    assert ref(b"abc") == want[:32]
+    assert rs.blake2sum_batch([b"abc"]) == [want[:32]]
+
+
+def test_ragged_lengths_host_api(rs):
+    lens = [0, 1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 3072, 65535, 65536, 104896,
+            1 << 20, (1 << 20) + 3]
+    msgs = [bytes(O.splitmix64_bytes(900 + i, n)) for i, n in enumerate(lens)]
+    got = rs.blake2sum_batch(msgs)
+    assert got == [ref(m) for m in msgs]
+    # many small messages (more lanes than one wave, several workgroups)
+    small = [bytes([i % 251]) * (i % 300) for i in range(1000)]
+    assert rs.blake2sum_batch(small) == [ref(m) for m in small]
+
+
+def test_uniform_device_api_shard_shape(rs):
+    # config-2 shard shape: 14 shards of 104896 bytes per stripe
+    n, S = 14 * 16, 104896
+    data = O.splitmix64_bytes(4242, n * S).reshape(n, S)
+    out = rs.blake2sum_dev(torch.from_numpy(data).to("cuda:0"))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for i in range(n):
+        assert got[i].tobytes() == ref(data[i].tobytes()), i
+    with pytest.raises(g.GecError):
+        rs.blake2sum_dev(torch.zeros((4, 100), dtype=torch.uint8, device="cuda:0"))   # rows not 16-byte aligned
+
+
+def test_encode_hash_batch_sums_every_shard(coracle, rs):
+    k, m = 10, 4
+    lens = [1 << 20, 999_999, 65536, 1, 0, 500_000]
+    blocks = [bytes(O.splitmix64_bytes(70 + i, n)) for i, n in enumerate(lens)]
+    S = g.shard_len(k, max(lens))
+    pars, sums = rs.encode_hash_blocks(blocks, S)
+    for b, blk in enumerate(blocks):
+        shards = O.split_block(k, blk, S)
+        want_par = coracle.encode_batch(k, m, shards[None], coracle.AVX2)[0]
+        assert np.array_equal(pars[b], want_par)
+        for j in range(k + m):
+            payload = shards[j] if j < k else want_par[j - k]
+            assert sums[b, j].tobytes() == ref(payload.tobytes()), (b, j)

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""GPU blake2sum rate on shard-shaped batches (device-resident, HIP events)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import garage_amd as g  # noqa: E402
+
+
+def main():
+    rs = g.ReedSolomon(10, 4)
+    S = 104896
+    res = {}
+    for nblocks in (64, 256, 1024, 4096):
+        n = nblocks * 14
+        t = torch.randint(0, 256, (n, S), dtype=torch.uint8, device="cuda:0")
+        for _ in range(2):
+            rs.blake2sum_dev(t)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            rs.blake2sum_dev(t)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        res[f"{nblocks}_stripes_{n}_shards"] = {"ms": round(ms, 3), "GBps": round(n * S / ms / 1e6, 1)}
+        del t
+    print(json.dumps({"what": "blake2b_batch kernel, one lane per 104896-byte shard, device-resident", "results": res}))
+
+
+if __name__ == "__main__":
+    main()
