@@ -140,33 +140,27 @@ int main(int argc, char **argv)
 	vs.push_back({TAG, gf_apply_nibble<MW, MODE_STORE, KC, CPT, NT, THREADS>, THREADS, CPT, WG, true, true})
 	const int MW = m <= 4 ? 1 : 2;
 	if (MW == 1) {
-		NIB(1, 5, 1, true, 256, 0, 0, "nib kc5  cpt1 nt  t256 (default)");
-		NIB(1, 10, 1, true, 256, 0, 0, "nib kc10 cpt1 nt  t256");
-		NIB(1, 4, 1, true, 256, 0, 0, "nib kc4  cpt1 nt  t256");
-		NIB(1, 6, 1, true, 256, 0, 0, "nib kc6  cpt1 nt  t256");
-		NIB(1, 3, 1, true, 256, 0, 0, "nib kc3  cpt1 nt  t256");
-		NIB(1, 2, 1, true, 256, 0, 0, "nib kc2  cpt1 nt  t256");
-		NIB(1, 5, 1, false, 256, 0, 0, "nib kc5  cpt1 tmp t256");
-		NIB(1, 5, 2, true, 256, 0, 0, "nib kc5  cpt2 nt  t256");
-		NIB(1, 3, 2, true, 256, 0, 0, "nib kc3  cpt2 nt  t256");
-		NIB(1, 2, 2, true, 256, 0, 0, "nib kc2  cpt2 nt  t256");
-		NIB(1, 5, 1, true, 512, 0, 0, "nib kc5  cpt1 nt  t512");
-		NIB(1, 10, 1, true, 512, 0, 0, "nib kc10 cpt1 nt  t512");
-		NIB(1, 5, 1, true, 1024, 0, 0, "nib kc5  cpt1 nt  t1024");
-		NIB(1, 5, 1, true, 192, 0, 0, "nib kc5  cpt1 nt  t192");
+		NIB(1, 10, 1, true, 256, 0, 0, "nib kc10 cpt1 nt  t256 (default)");
+		NIBW(1, 10, 1, true, 256, 5, 0, "nib kc10 cpt1 nt  t256 w5");
 		NIBW(1, 10, 1, true, 256, 6, 0, "nib kc10 cpt1 nt  t256 w6");
-		NIBW(1, 5, 2, true, 256, 6, 0, "nib kc5  cpt2 nt  t256 w6");
+		NIBW(1, 10, 1, true, 256, 4, 0, "nib kc10 cpt1 nt  t256 w4");
+		NIBW(1, 10, 1, true, 256, 3, 0, "nib kc10 cpt1 nt  t256 w3");
+		NIB(1, 5, 1, true, 256, 0, 0, "nib kc5  cpt1 nt  t256");
+		NIB(1, 10, 1, true, 320, 0, 0, "nib kc10 cpt1 nt  t320");
+		NIB(1, 10, 1, true, 384, 0, 0, "nib kc10 cpt1 nt  t384");
+		NIB(1, 10, 1, true, 192, 0, 0, "nib kc10 cpt1 nt  t192");
+		NIB(1, 10, 1, true, 448, 0, 0, "nib kc10 cpt1 nt  t448");
+		NIB(1, 10, 1, true, 512, 0, 0, "nib kc10 cpt1 nt  t512");
 	} else {
 		NIB(2, 5, 1, true, 512, 0, 0, "nib8 kc5  cpt1 nt t512 (default)");
-		NIB(2, 5, 1, true, 256, 0, 0, "nib8 kc5  cpt1 nt t256");
-		NIB(2, 4, 1, true, 512, 0, 0, "nib8 kc4  cpt1 nt t512");
-		NIB(2, 4, 1, true, 256, 0, 0, "nib8 kc4  cpt1 nt t256");
-		NIB(2, 10, 1, true, 512, 0, 0, "nib8 kc10 cpt1 nt t512");
+		NIB(2, 5, 1, true, 384, 0, 0, "nib8 kc5  cpt1 nt t384");
+		NIB(2, 5, 1, true, 448, 0, 0, "nib8 kc5  cpt1 nt t448");
+		NIB(2, 5, 1, true, 640, 0, 0, "nib8 kc5  cpt1 nt t640");
+		NIB(2, 6, 1, true, 512, 0, 0, "nib8 kc6  cpt1 nt t512");
 		NIB(2, 10, 1, true, 256, 0, 0, "nib8 kc10 cpt1 nt t256");
-		NIB(2, 2, 1, true, 512, 0, 0, "nib8 kc2  cpt1 nt t512");
-		NIB(2, 5, 1, true, 1024, 0, 0, "nib8 kc5  cpt1 nt t1024");
+		NIBW(2, 10, 1, true, 256, 4, 0, "nib8 kc10 cpt1 nt t256 w4");
 		NIBW(2, 5, 1, true, 512, 6, 0, "nib8 kc5  cpt1 nt t512 w6");
-		NIBW(2, 5, 1, true, 256, 6, 0, "nib8 kc5  cpt1 nt t256 w6");
+		NIBW(2, 5, 1, true, 512, 5, 0, "nib8 kc5  cpt1 nt t512 w5");
 	}
 	vs.push_back({"logexp baseline (north_star literal)", gf_apply_logexp<MODE_STORE>, 256, 1, 8, false, true});
 
