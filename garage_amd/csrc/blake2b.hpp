@@ -159,4 +159,155 @@ __global__ __launch_bounds__(64) void blake2b_batch(const Blake2Args a)
 	o[1] = hi;
 }
 
+
+// ---------------------------------------------------------------------------
+// Quad variant: FOUR lanes per message (the classic SIMD BLAKE2 layout).  Lane q of
+// a quad owns column q of the 4x4 state (a,b,c,d = v[q], v[4+q], v[8+q], v[12+q]);
+// the four G of a column step run in the four lanes, the diagonal step first rotates
+// b/c/d by 1/2/3 lanes inside the quad with DPP quad_perm moves.  The 128-byte
+// message block is staged in LDS (each lane loads 32 bytes) and every lane gathers
+// the two words its G needs from there: the sigma schedule becomes a packed
+// per-round constant of four 7-bit byte offsets, one v_bfe_u32 away.
+// The per-message chain is ~4x shorter and 4x more lanes are busy, which is what a
+// moderate batch needs: 14336 shard messages = 224 waves with the one-lane kernel
+// (22% of the SIMDs), 896 waves here.  Peak rate with very many messages is lower
+// than the one-lane kernel's (DPP + LDS overhead), so the host picks by batch size.
+// ---------------------------------------------------------------------------
+constexpr int B2Q_SLOT = 144;  // LDS bytes per message block: 128 + pad (bank spread, 16-B aligned)
+
+template <int CTRL>
+__device__ __forceinline__ uint64_t b2_quad_perm(uint64_t x)
+{
+	const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)x, CTRL, 0xf, 0xf, false);
+	const int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(x >> 32), CTRL, 0xf, 0xf, false);
+	return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+// byte offsets (8 * word index, 7 bits each) of sigma[r][i0 + 2q], q = 0..3
+constexpr uint32_t b2q_pack(const uint8_t (&s)[16], int i0)
+{
+	return (uint32_t)(s[i0] * 8) | ((uint32_t)(s[i0 + 2] * 8) << 7) | ((uint32_t)(s[i0 + 4] * 8) << 14) |
+	       ((uint32_t)(s[i0 + 6] * 8) << 21);
+}
+
+struct B2QSchedule {
+	uint32_t w[12][4];  // [round][col x, col y, diag x, diag y]
+};
+
+constexpr B2QSchedule b2q_schedule()
+{
+	constexpr uint8_t SIG[12][16] = {
+		{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+		{11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+		{9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+		{12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+		{6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+		{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+	B2QSchedule t{};
+	for (int r = 0; r < 12; ++r) {
+		t.w[r][0] = b2q_pack(SIG[r], 0);
+		t.w[r][1] = b2q_pack(SIG[r], 1);
+		t.w[r][2] = b2q_pack(SIG[r], 8);
+		t.w[r][3] = b2q_pack(SIG[r], 9);
+	}
+	return t;
+}
+
+typedef __attribute__((address_space(3))) const uint64_t lds_u64_t;
+
+__device__ __forceinline__ void b2q_compress(uint64_t &ha, uint64_t &hb, uint32_t slot_addr, uint32_t q7, uint32_t q,
+					     uint64_t t, bool last)
+{
+	constexpr B2QSchedule SCH = b2q_schedule();
+	const uint64_t IVq = q == 0 ? 0x6a09e667f3bcc908ULL : q == 1 ? 0xbb67ae8584caa73bULL
+			   : q == 2 ? 0x3c6ef372fe94f82bULL : 0xa54ff53a5f1d36f1ULL;
+	const uint64_t IVq4 = q == 0 ? 0x510e527fade682d1ULL : q == 1 ? 0x9b05688c2b3e6c1fULL
+			    : q == 2 ? 0x1f83d9abfb41bd6bULL : 0x5be0cd19137e2179ULL;
+	uint64_t a = ha, b = hb, c = IVq, d = IVq4;
+	if (q == 0)
+		d ^= t;
+	if (q == 2 && last)
+		d = ~d;
+#define GEC_B2Q_WORD(packed) (*reinterpret_cast<lds_u64_t *>(slot_addr + __builtin_amdgcn_ubfe((packed), q7, 7)))
+#pragma unroll
+	for (int r = 0; r < 12; ++r) {
+		{  // column step
+			const uint64_t x = GEC_B2Q_WORD(SCH.w[r][0]);
+			const uint64_t y = GEC_B2Q_WORD(SCH.w[r][1]);
+			constexpr bool ADD32 = false;
+			GEC_B2_G(a, b, c, d, x, y)
+		}
+		b = b2_quad_perm<0x39>(b);
+		c = b2_quad_perm<0x4E>(c);
+		d = b2_quad_perm<0x93>(d);
+		{  // diagonal step
+			const uint64_t x = GEC_B2Q_WORD(SCH.w[r][2]);
+			const uint64_t y = GEC_B2Q_WORD(SCH.w[r][3]);
+			constexpr bool ADD32 = false;
+			GEC_B2_G(a, b, c, d, x, y)
+		}
+		b = b2_quad_perm<0x93>(b);
+		c = b2_quad_perm<0x4E>(c);
+		d = b2_quad_perm<0x39>(d);
+	}
+#undef GEC_B2Q_WORD
+	ha ^= a ^ c;
+	hb ^= b ^ d;
+}
+
+__global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t lds[16 * B2Q_SLOT];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t q = lane & 3;
+	const uint32_t i = blockIdx.x * 16 + (lane >> 2);
+	const bool live = i < a.n;
+	const uint32_t ii = live ? i : a.n - 1;  // dead quads shadow the last message (no stores)
+	const uint8_t *p = a.base + (a.off ? a.off[ii] : (uint64_t)ii * a.stride);
+	const uint64_t len = a.len ? a.len[ii] : a.uniform_len;
+	uint8_t *slot = lds + (lane >> 2) * B2Q_SLOT;
+	const uint32_t slot_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)slot;
+	const uint32_t q7 = q * 7;
+	uint64_t ha = (q == 0 ? 0x6a09e667f3bcc908ULL ^ 0x01010040ULL : q == 1 ? 0xbb67ae8584caa73bULL
+		       : q == 2 ? 0x3c6ef372fe94f82bULL : 0xa54ff53a5f1d36f1ULL);
+	uint64_t hb = (q == 0 ? 0x510e527fade682d1ULL : q == 1 ? 0x9b05688c2b3e6c1fULL
+		       : q == 2 ? 0x1f83d9abfb41bd6bULL : 0x5be0cd19137e2179ULL);
+	uint64_t done = 0;
+	// full blocks, all but the last: each lane stages its 32-byte quarter of the block
+	while (len - done > 128) {
+		const u64x2 *g = reinterpret_cast<const u64x2 *>(p + done + 32 * q);
+		const u64x2 w0 = __builtin_nontemporal_load(g);
+		const u64x2 w1 = __builtin_nontemporal_load(g + 1);
+		u64x2 *s = reinterpret_cast<u64x2 *>(slot + 32 * q);
+		s[0] = w0;
+		s[1] = w1;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		done += 128;
+		b2q_compress(ha, hb, slot_addr, q7, q, done, false);
+		__builtin_amdgcn_wave_barrier();
+	}
+	// last block: 0..128 bytes, zero-padded; never reads past p + len
+	const uint64_t rem = len - done;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const uint64_t o = 32 * q + 8 * j;
+		uint64_t w = 0;
+		if (o + 8 <= rem) {
+			w = *reinterpret_cast<const uint64_t *>(p + done + o);
+		} else if (o < rem) {
+			for (uint64_t b = 0; b < rem - o; ++b)
+				w |= (uint64_t)p[done + o + b] << (8 * b);
+		}
+		reinterpret_cast<uint64_t *>(slot + 32 * q)[j] = w;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	b2q_compress(ha, hb, slot_addr, q7, q, len, true);
+	if (live)
+		reinterpret_cast<uint64_t *>(a.out + (uint64_t)i * 32)[q] = ha;  // h[0..3] = first 32 bytes
+}
+
 }  // namespace gec

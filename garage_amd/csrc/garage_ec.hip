@@ -502,12 +502,16 @@ int blake2_dev(size_t n, const uint8_t *d_base, const uint64_t *d_off, const uin
 	a.uniform_len = len;
 	a.out = d_out;
 	a.n = (uint32_t)n;
-	static const bool add32 = [] {
-		const char *e = getenv("GEC_BLAKE2_ADD32");  // A/B knob, see DESIGN.md
-		return e ? e[0] != '0' : false;  // measured: 64-bit v_lshl_add_u64 adds are 1.44x faster
+	// one lane per message is the faster kernel once there are enough messages to put a
+	// wave on every SIMD (1024 SIMDs x 64 lanes); below that the quad kernel (4 lanes per
+	// message, ~4x shorter chain) wins.  GEC_BLAKE2_KERNEL=lane|quad forces one (A/B).
+	static const int forced = [] {
+		const char *e = getenv("GEC_BLAKE2_KERNEL");
+		return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'q' ? 2 : 0));
 	}();
-	if (add32)
-		hipLaunchKernelGGL(gec::blake2b_batch<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a);
+	const bool quad = forced ? forced == 2 : n < 40000;
+	if (quad)
+		hipLaunchKernelGGL(gec::blake2b_batch_quad, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, stream, a);
 	else
 		hipLaunchKernelGGL(gec::blake2b_batch<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a);
 	HIP_TRY(hipGetLastError());

@@ -69,3 +69,32 @@ def test_encode_hash_batch_sums_every_shard(coracle, rs):
         for j in range(k + m):
             payload = shards[j] if j < k else want_par[j - k]
             assert sums[b, j].tobytes() == ref(payload.tobytes()), (b, j)
+
+
+@pytest.mark.parametrize("kernel", ["lane", "quad"])
+def test_both_kernels_forced(kernel):
+    """The host picks the one-lane or the four-lane kernel by batch size; force each
+    (GEC_BLAKE2_KERNEL is read once per process) and check ragged + uniform inputs."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import hashlib, sys
+import numpy as np, torch
+import garage_amd as g
+from oracle import rs_oracle as O
+rs = g.ReedSolomon(10, 4)
+ref = lambda b: hashlib.blake2b(b, digest_size=64).digest()[:32]
+lens = [0, 1, 31, 32, 33, 64, 96, 127, 128, 129, 160, 255, 256, 257, 1000, 4097, 104896, 300001]
+msgs = [bytes(O.splitmix64_bytes(50 + i, n)) for i, n in enumerate(lens)] + [bytes([i]) * (i * 7 % 400) for i in range(150)]
+assert rs.blake2sum_batch(msgs) == [ref(m) for m in msgs], "ragged"
+data = O.splitmix64_bytes(9, 70 * 4160).reshape(70, 4160)
+out = rs.blake2sum_dev(torch.from_numpy(data).to("cuda:0")).cpu().numpy()
+assert all(out[i].tobytes() == ref(data[i].tobytes()) for i in range(70)), "uniform"
+print("OK")
+'''
+    env = dict(os.environ, GEC_BLAKE2_KERNEL=kernel)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr

@@ -32,7 +32,7 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         res[f"{nblocks}_stripes_{n}_shards"] = {"ms": round(ms, 3), "GBps": round(n * S / ms / 1e6, 1)}
         del t
-    print(json.dumps({"what": "blake2b_batch kernel, one lane per 104896-byte shard, device-resident", "results": res}))
+    print(json.dumps({"what": "GPU blake2sum of 104896-byte shards, device-resident, kernel = " + os.environ.get("GEC_BLAKE2_KERNEL", "auto (quad < 40000 messages <= lane)"), "results": res}))
 
 
 if __name__ == "__main__":
