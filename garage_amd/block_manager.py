@@ -37,10 +37,7 @@ from .partition import block_hash
 
 INLINE_THRESHOLD = 3072  # src/block/manager.rs:46
 
-try:  # Garage compresses with zstd (src/block/block.rs:99-106); optional here
-    import zstandard as _zstd
-except ImportError:  # pragma: no cover - not installed in this image
-    _zstd = None
+from . import zstd_ffi  # Garage compresses with zstd (src/block/block.rs:99-106)
 
 
 # ------------------------------------------------------------------ errors
@@ -112,8 +109,8 @@ class DataBlock:
 
     @classmethod
     def from_buffer(cls, data: bytes, level: Optional[int]) -> "DataBlock":
-        """zstd at `level` when available, Plain on None or on any encoder error
-        (src/block/block.rs:85-96)."""
+        """zstd at `level` (Garage's default config is Some(1)), Plain on None or on
+        any encoder error (src/block/block.rs:85-96)."""
         if level is not None:
             try:
                 return cls.compressed(zstd_encode(data, level))
@@ -123,15 +120,12 @@ class DataBlock:
 
 
 def zstd_encode(data: bytes, level: int) -> bytes:
-    if _zstd is None:
-        raise RuntimeError("zstd is not available")
-    return _zstd.ZstdCompressor(level=level, write_checksum=True).compress(data)
+    """One frame with the content checksum on, like the reference's zstd_encode."""
+    return zstd_ffi.zstd_encode(data, level)
 
 
 def zstd_decode(data: bytes) -> bytes:
-    if _zstd is None:
-        raise RuntimeError("zstd is not available")
-    return _zstd.ZstdDecompressor().decompress(data)
+    return zstd_ffi.zstd_decode(data)
 
 
 # ------------------------------------------------------------ shard format

@@ -7,6 +7,7 @@
 // computed.  No GF arithmetic happens here.
 #include "../../include/garage_block.h"
 
+#include <dlfcn.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -97,6 +98,80 @@ void blake2sum(const uint8_t *data, size_t len, uint8_t out[32])
 	std::memcpy(last, data + off, len - off);
 	b2_compress(h, last, len, true);
 	std::memcpy(out, h, 32);
+}
+
+// --------------------------------------------------------------------- zstd
+// DataBlock::from_buffer / zstd_encode (src/block/block.rs:85-106): one frame, level
+// from the config, content checksum ON.  This image ships libzstd.so.1 but no headers,
+// so the handful of entry points are resolved at run time.
+struct Zstd {
+	void *(*createCCtx)() = nullptr;
+	size_t (*freeCCtx)(void *) = nullptr;
+	size_t (*setParameter)(void *, int, int) = nullptr;
+	size_t (*compress2)(void *, void *, size_t, const void *, size_t) = nullptr;
+	size_t (*compressBound)(size_t) = nullptr;
+	size_t (*decompress)(void *, size_t, const void *, size_t) = nullptr;
+	unsigned long long (*getFrameContentSize)(const void *, size_t) = nullptr;
+	unsigned (*isError)(size_t) = nullptr;
+	bool ok = false;
+
+	Zstd()
+	{
+		void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+		if (!h)
+			return;
+#define GBM_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(h, name))
+		GBM_SYM(createCCtx, "ZSTD_createCCtx");
+		GBM_SYM(freeCCtx, "ZSTD_freeCCtx");
+		GBM_SYM(setParameter, "ZSTD_CCtx_setParameter");
+		GBM_SYM(compress2, "ZSTD_compress2");
+		GBM_SYM(compressBound, "ZSTD_compressBound");
+		GBM_SYM(decompress, "ZSTD_decompress");
+		GBM_SYM(getFrameContentSize, "ZSTD_getFrameContentSize");
+		GBM_SYM(isError, "ZSTD_isError");
+#undef GBM_SYM
+		ok = createCCtx && freeCCtx && setParameter && compress2 && compressBound && decompress &&
+		     getFrameContentSize && isError;
+	}
+	// false on any error: the caller then stores the block Plain (block.rs:88-93)
+	bool encode(const uint8_t *data, size_t len, int level, std::vector<uint8_t> &out) const
+	{
+		if (!ok)
+			return false;
+		void *c = createCCtx();
+		if (!c)
+			return false;
+		bool good = !isError(setParameter(c, 100 /* ZSTD_c_compressionLevel */, level)) &&
+			    !isError(setParameter(c, 201 /* ZSTD_c_checksumFlag */, 1));
+		if (good) {
+			out.resize(compressBound(len));
+			size_t n = compress2(c, out.data(), out.size(), data, len);
+			good = !isError(n);
+			if (good)
+				out.resize(n);
+		}
+		freeCCtx(c);
+		return good;
+	}
+	// verifies the frame checksum; false = corrupt
+	bool decode(const uint8_t *data, size_t len, std::vector<uint8_t> &out) const
+	{
+		if (!ok)
+			return false;
+		unsigned long long sz = getFrameContentSize(data, len);
+		if (sz >= (1ull << 40))  // CONTENTSIZE_ERROR / UNKNOWN are huge sentinels
+			return false;
+		out.resize((size_t)sz);
+		uint8_t dummy;
+		size_t n = decompress(sz ? out.data() : &dummy, (size_t)sz, data, len);
+		return !isError(n) && n == sz;
+	}
+};
+
+const Zstd &zstd()
+{
+	static const Zstd z;
+	return z;
 }
 
 using Hash = std::string;  // 32 raw bytes
@@ -240,6 +315,8 @@ struct gbm_manager {
 	std::vector<Hash> resync_queue;
 	uint64_t metrics[6] = {0, 0, 0, 0, 0, 0};
 	uint64_t gpu_hashed = 0;  // messages hashed on the device
+	bool compress = false;    // Config.compression_level (src/util/config.rs:52-58); Garage's default is Some(1)
+	int compression_level = 1;
 
 	void nodes_of(const Hash &h, std::vector<int> &who) const
 	{
@@ -386,7 +463,7 @@ int gather(gbm_manager *mg, const Hash &h, int want, Gathered &g)
 }
 
 int store_shard(gbm_manager *mg, int node, const Hash &h, int idx, const uint8_t *payload, size_t S,
-		uint64_t orig_len, const uint8_t *checksum = nullptr)
+		uint64_t orig_len, bool compressed, const uint8_t *checksum = nullptr)
 {
 	Node &nd = *mg->nodes[node];
 	if (nd.down)
@@ -395,6 +472,7 @@ int store_shard(gbm_manager *mg, int node, const Hash &h, int idx, const uint8_t
 	hd.k = (uint8_t)mg->k;
 	hd.m = (uint8_t)mg->m;
 	hd.idx = (uint8_t)idx;
+	hd.compressed = compressed ? 1 : 0;
 	hd.orig_len = orig_len;
 	hd.shard_len = (uint32_t)S;
 	if (checksum)
@@ -468,6 +546,20 @@ int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const 
 	if (nb == 0)
 		return GBM_OK;
 	const int k = mg->k, m = mg->m, n = mg->n;
+	// DataBlock::from_buffer: zstd when a level is configured, Plain on any encoder error
+	std::vector<std::vector<uint8_t>> zbuf(nb);
+	std::vector<const uint8_t *> dptr(data, data + nb);
+	std::vector<size_t> dlen(len, len + nb);
+	std::vector<uint8_t> is_z(nb, 0);
+	if (mg->compress)
+		for (size_t b = 0; b < nb; ++b)
+			if (zstd().encode(data[b], len[b], mg->compression_level, zbuf[b])) {
+				dptr[b] = zbuf[b].data();
+				dlen[b] = zbuf[b].size();
+				is_z[b] = 1;
+			}
+	data = dptr.data();
+	len = dlen.data();
 	size_t S = 0;
 	for (size_t b = 0; b < nb; ++b)
 		S = std::max(S, gec_shard_len(k, len[b]));
@@ -508,7 +600,7 @@ int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const 
 			} else {
 				payload = pp[b] + (size_t)(j - k) * S;
 			}
-			if (store_shard(mg, who[j], h, j, payload, S, len[b], sums.data() + (b * n + j) * 32) == 0) {
+			if (store_shard(mg, who[j], h, j, payload, S, len[b], is_z[b] != 0, sums.data() + (b * n + j) * 32) == 0) {
 				++ok;
 				std::lock_guard<std::mutex> lk(mg->mu);
 				mg->metrics[0] += S;
@@ -605,6 +697,23 @@ int gbm_rpc_get_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, uint8_
 			if (lo >= L)
 				break;
 			std::memcpy(whole[b].data() + lo, g[b].shard[j].data(), std::min(S, L - lo));
+		}
+		if (g[b].meta.compressed) {
+			// DataBlock::verify for Compressed = "the zstd stream decodes" (frame checksum)
+			std::vector<uint8_t> plain;
+			if (!zstd().decode(whole[b].data(), L, plain)) {
+				rcs[b] = GBM_E_CORRUPT_DATA;
+				continue;
+			}
+			len_out[b] = plain.size();
+			if (cap[b] < plain.size()) {
+				rcs[b] = GBM_E_BUFFER_TOO_SMALL;
+				continue;
+			}
+			std::memcpy(out[b], plain.data(), plain.size());
+			std::lock_guard<std::mutex> lk(mg->mu);
+			mg->metrics[5]++;
+			continue;
 		}
 		ptrs.push_back(whole[b].data());
 		lens.push_back(L);
@@ -726,7 +835,7 @@ int gbm_resync_block(gbm_manager *mg, const uint8_t hash[32], int *changed)
 		for (int j = 0; j < mg->n; ++j) {
 			if (sp[j])
 				continue;
-			if (store_shard(mg, who[j], h, j, g.shard[j].data(), S, g.meta.orig_len) == 0)
+			if (store_shard(mg, who[j], h, j, g.shard[j].data(), S, g.meta.orig_len, g.meta.compressed != 0) == 0)
 				++nchanged;
 			else
 				mg->enqueue(h);
@@ -843,6 +952,17 @@ int gbm_node_corrupt_shard(gbm_manager *m, int node, const uint8_t hash[32], int
 		hd.pack(raw.data());
 	}
 	return m->nodes[node]->put(h, idx, std::move(raw)) ? GBM_OK : fail(GBM_E_IO, "rewrite failed");
+}
+
+int gbm_set_compression_level(gbm_manager *m, int enabled, int level)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	if (enabled && !zstd().ok)
+		return fail(GBM_E_IO, "libzstd.so.1 not available");
+	m->compress = enabled != 0;
+	m->compression_level = level;
+	return GBM_OK;
 }
 
 uint64_t gbm_gpu_hashed(const gbm_manager *m)

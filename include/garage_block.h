@@ -12,9 +12,9 @@
  *   blake2sum (blake2b-512 truncated to 32 bytes)   src/util/data.rs:130-138
  * Storage nodes are in-process objects (memory- or directory-backed) -- the way
  * the reference tests multi-node logic on loopback (src/net/test.rs:15-118);
- * the network, metadata tables and zstd (no headers in this image: blocks are
- * stored Plain, as DataBlock::from_buffer does on an encoder error,
- * src/block/block.rs:88-93) are out of scope.
+ * the network and the metadata tables are out of scope.  zstd (DataBlock::
+ * from_buffer, src/block/block.rs:85-106) goes through the system's libzstd.so.1,
+ * resolved at run time.
  */
 #ifndef GARAGE_BLOCK_H
 #define GARAGE_BLOCK_H
@@ -56,6 +56,12 @@ void gbm_blake2sum(const uint8_t *data, size_t len, uint8_t out[32]);
 int gbm_create(const gec_codec *codec, int nnodes, const char *const *node_dirs,
 	       int write_quorum, gbm_manager **out);
 void gbm_destroy(gbm_manager *m);
+
+/* Config.compression_level (src/util/config.rs:52-58): enabled=0 is "none";
+ * Garage's default is level 1.  Blocks are compressed (one zstd frame, content
+ * checksum on) before they are cut into shards; on any encoder error the block
+ * is stored Plain (src/block/block.rs:88-93). */
+int gbm_set_compression_level(gbm_manager *m, int enabled, int level);
 
 /* nodes_out[k+m]: node index that stores shard j of this hash. */
 int gbm_storage_nodes_of(const gbm_manager *m, const uint8_t hash[32], int *nodes_out);

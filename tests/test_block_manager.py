@@ -39,3 +39,36 @@ def test_needs_enough_nodes():
 
     with pytest.raises(Error):
         BlockManager(OracleCodec(10, 4), [MemoryShardStore() for _ in range(13)])
+
+
+def test_compressed_put_get_and_corruption():
+    """compression_level = Some(1): zstd frame with content checksum; shards are cut from
+    the compressed payload; a flipped byte inside the payload is caught by zstd's
+    checksum (DataBlock::verify, src/block/block.rs:78-82)."""
+    from garage_amd.block_manager import (BlockManager, CorruptData, DataBlock, DataBlockHeader, MemoryShardStore,
+                                          ShardHeader)
+    from garage_amd.partition import block_hash
+
+    codec = OracleCodec(3, 1)
+    stores = [MemoryShardStore() for _ in range(5)]
+    mgr = BlockManager(codec, stores, compression_level=1)
+    data = C.pattern_block(300_000, 5)
+    h = block_hash(data)
+    mgr.rpc_put_block(h, data)
+    raw = mgr.rpc_get_raw_block(h)
+    assert raw.header is DataBlockHeader.Compressed and len(raw.elem) < 20_000
+    assert mgr.rpc_get_block(h) == data
+    mgr.rpc_put_block(h, data, prevent_compression=True)
+    assert mgr.rpc_get_raw_block(h).header is DataBlockHeader.Plain
+    # corrupt the compressed payload consistently with the shard checksum
+    mgr.rpc_put_block(h, data)
+    who = mgr.storage_nodes_of(h)
+    rawshard = bytearray(stores[who[0]].get(h, 0))
+    rawshard[ShardHeader.SIZE + 40] ^= 0x10
+    hdr = ShardHeader.unpack(bytes(rawshard))
+    hdr.checksum = block_hash(bytes(rawshard[ShardHeader.SIZE:]))
+    stores[who[0]].put(h, 0, hdr.pack() + bytes(rawshard[ShardHeader.SIZE:]))
+    with pytest.raises(CorruptData):
+        mgr.rpc_get_block(h)
+    with pytest.raises(CorruptData):
+        DataBlock.compressed(b"not a zstd frame").verify(h)

@@ -163,3 +163,37 @@ def test_native_and_python_mirrors_interoperate(tmp_path):
     pym.rpc_put_block(hb, b)
     assert pym.rpc_get_block(ha) == a
     assert native.rpc_get_block(hb) == b
+
+
+@pytest.mark.gpu
+def test_compressed_blocks_native_and_python(tmp_path):
+    """compression_level = Some(1) (Garage's default): blocks are zstd frames with the
+    content checksum on before they are cut into shards; both mirrors read each
+    other's compressed blocks; a corrupted compressed payload is CorruptData."""
+    from garage_amd.block_manager import BlockManager, DataBlockHeader, DirShardStore
+
+    codec = g.ReedSolomon(10, 4)
+    dirs = [str(tmp_path / f"node{i}") for i in range(14)]
+    native = bn.NativeBlockManager(codec, 14, dirs, compression_level=1)
+    pym = BlockManager(codec, [DirShardStore(d) for d in dirs], compression_level=1)
+    a, b = pattern_block(1 << 20, 3), pattern_block(700_001, 4)     # compressible patterns
+    ha, hb = bn.blake2sum(a), bn.blake2sum(b)
+    native.rpc_put_block(ha, a)
+    pym.rpc_put_block(hb, b)
+    raw = pym.rpc_get_raw_block(ha)
+    assert raw.header is DataBlockHeader.Compressed and len(raw.elem) < len(a) // 4
+    assert pym.rpc_get_block(ha) == a and native.rpc_get_block(hb) == b
+    # shards are cut from the COMPRESSED payload: they are much smaller than for a plain block
+    who = native.storage_nodes_of(ha)
+    hx = ha.hex()
+    shard_file = tmp_path / f"node{who[0]}" / hx[:2] / hx[2:4] / f"{hx}.s0"
+    assert shard_file.stat().st_size < 64 + g.shard_len(10, len(a)) // 4
+    # lose 4 shards incl. data shards -> decode of the compressed payload, then zstd
+    for j in (0, 1, 2, 11):
+        native.node_delete_shard(who[j], ha, j)
+    assert native.rpc_get_block(ha) == a
+    # prevent_compression / random data: falls back to what zstd produces (still a frame)
+    rnd = bytes(np.random.default_rng(1).integers(0, 256, 100_000, dtype=np.uint8))
+    hr = bn.blake2sum(rnd)
+    native.rpc_put_block(hr, rnd)
+    assert pym.rpc_get_block(hr) == rnd
