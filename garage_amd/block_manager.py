@@ -283,38 +283,51 @@ class BlockManager:
         to the device in ONE encode call."""
         level = None if prevent_compression else self.compression_level
         blocks = [DataBlock.from_buffer(data, level) for _, data in items]
-        payloads = [b.elem for b in blocks]
-        S = max(shard_len(self.k, len(p)) for p in payloads)
-        parities = self.codec.encode_blocks(payloads, S)
-        for (hash_, _), blk, par in zip(items, blocks, parities):
-            padded = np.zeros(self.k * S, dtype=np.uint8)
-            padded[: len(blk.elem)] = np.frombuffer(blk.elem, dtype=np.uint8)
-            shards = [padded[j * S:(j + 1) * S] for j in range(self.k)] + [np.asarray(par[r]) for r in range(self.m)]
-            who = self.storage_nodes_of(hash_)
-            ok, errors = 0, []
-            for j, node in enumerate(who):
-                payload = shards[j].tobytes()
-                hdr = ShardHeader(self.k, self.m, j, blk.header.is_compressed(), len(blk.elem), S, block_hash(payload))
-                try:
-                    self.stores[node].put(hash_, j, hdr.pack() + payload)
-                    ok += 1
-                    self.metrics["bytes_written"] += len(payload)
-                except Exception as e:  # node down: stragglers are retried by resync
-                    errors.append(f"node {node}: {e}")
-            if ok < self.write_quorum:
-                raise Quorum(self.write_quorum, ok, self.n, errors)
-            if ok < self.n:
-                self.resync_queue.append(hash_)
+        # Shard geometry is a pure function of the block: S = shard_len(k, payload length),
+        # never the batch maximum -- a later put of the same block must produce compatible
+        # shards.  Blocks of equal S share ONE device call.
+        by_s: dict[int, list[int]] = {}
+        for i, blk in enumerate(blocks):
+            by_s.setdefault(shard_len(self.k, len(blk.elem)), []).append(i)
+        failure = None
+        for S, ids in by_s.items():
+            parities = self.codec.encode_blocks([blocks[i].elem for i in ids], S)
+            for i, par in zip(ids, parities):
+                hash_, blk = items[i][0], blocks[i]
+                padded = np.zeros(self.k * S, dtype=np.uint8)
+                padded[: len(blk.elem)] = np.frombuffer(blk.elem, dtype=np.uint8)
+                shards = [padded[j * S:(j + 1) * S] for j in range(self.k)] + [np.asarray(par[r]) for r in range(self.m)]
+                who = self.storage_nodes_of(hash_)
+                ok, errors = 0, []
+                for j, node in enumerate(who):
+                    payload = shards[j].tobytes()
+                    hdr = ShardHeader(self.k, self.m, j, blk.header.is_compressed(), len(blk.elem), S, block_hash(payload))
+                    try:
+                        self.stores[node].put(hash_, j, hdr.pack() + payload)
+                        ok += 1
+                        self.metrics["bytes_written"] += len(payload)
+                    except Exception as e:  # node down: stragglers are retried by resync
+                        errors.append(f"node {node}: {e}")
+                if ok < self.write_quorum:
+                    failure = Quorum(self.write_quorum, ok, self.n, errors)
+                elif ok < self.n:
+                    self.resync_queue.append(hash_)
+        if failure is not None:
+            raise failure
 
     # -- read path ------------------------------------------------------------
     def _gather(self, hash_: bytes, want: int):
-        """Fetch shards in node order until `want` valid ones are in hand.  A shard
-        whose checksum does not match is treated as missing and queued for resync."""
+        """Fetch shards in node order until `want` mutually consistent ones are in hand.
+        A shard whose checksum does not match is treated as missing and queued for
+        resync.  Shards are grouped by geometry (compressed, orig_len, shard_len): a
+        block can have leftovers of another geometry on disk (e.g. a later put with
+        compression enabled that failed its quorum half-way); the largest consistent
+        group wins, like find_block chooses between <hash> and <hash>.zst
+        (src/block/manager.rs:627-662)."""
         who = self.storage_nodes_of(hash_)
-        got: dict[int, np.ndarray] = {}
-        meta: Optional[ShardHeader] = None
+        groups: dict[tuple, tuple[ShardHeader, dict[int, np.ndarray]]] = {}
         for j, node in enumerate(who):
-            if len(got) >= want:
+            if groups and max(len(g[1]) for g in groups.values()) >= want:
                 break
             try:
                 raw = self.stores[node].get(hash_, j)
@@ -335,9 +348,14 @@ class BlockManager:
                 if hasattr(store, "mark_corrupted"):
                     store.mark_corrupted(hash_, j)
                 continue
-            got[j] = np.frombuffer(payload, dtype=np.uint8)
-            meta = meta or hdr
+            key = (hdr.compressed, hdr.orig_len, hdr.shard_len)
+            groups.setdefault(key, (hdr, {}))[1][j] = np.frombuffer(payload, dtype=np.uint8)
             self.metrics["bytes_read"] += len(payload)
+        if not groups:
+            return {}, None
+        if len(groups) > 1:
+            self.resync_queue.append(hash_)
+        meta, got = max(groups.values(), key=lambda g: len(g[1]))
         return got, meta
 
     def rpc_get_raw_block(self, hash_: bytes, order_tag=None) -> DataBlock:

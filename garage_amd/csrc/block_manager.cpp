@@ -19,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -335,12 +336,41 @@ struct gbm_manager {
 
 namespace {
 
+// Shards of one block are only usable together when they were cut from the same
+// payload with the same geometry.  A block can legitimately have shards of two
+// geometries on disk at once -- e.g. it was first stored Plain and a later put with
+// compression enabled reached only some nodes before failing its quorum -- so shards
+// are grouped by geometry and the largest consistent group is used (find_block makes
+// the same kind of choice between <hash> and <hash>.zst, manager.rs:627-662).
+struct Geometry {
+	uint8_t compressed = 0;
+	uint64_t orig_len = 0;
+	uint32_t shard_len = 0;
+	bool operator<(const Geometry &o) const
+	{
+		return std::tie(compressed, orig_len, shard_len) < std::tie(o.compressed, o.orig_len, o.shard_len);
+	}
+};
+
 struct Gathered {
 	std::vector<std::vector<uint8_t>> shard;  // n entries; empty = not in hand
 	ShardHeader meta;
 	bool have_meta = false;
 	int count = 0;
 	int next = 0;  // next shard index to try
+	struct Group {
+		ShardHeader meta;
+		std::vector<std::vector<uint8_t>> shard;
+		int count = 0;
+	};
+	std::map<Geometry, Group> groups;
+	int best() const
+	{
+		int c = 0;
+		for (auto &kv : groups)
+			c = std::max(c, kv.second.count);
+		return c;
+	}
 };
 
 // blake2sum of many buffers: on the GPU (gec_blake2sum_batch) once the batch is big
@@ -394,7 +424,7 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, int want, std::vec
 		for (size_t b = 0; b < hs.size(); ++b) {
 			Gathered &g = gs[b];
 			int pending = 0;
-			while (g.next < n && g.count + pending < want) {
+			while (g.next < n && g.best() + pending < want) {
 				const int j = g.next++;
 				Node &nd = *mg->nodes[who[b][j]];
 				if (nd.down)
@@ -418,7 +448,7 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, int want, std::vec
 			}
 		}
 		if (cands.empty())
-			return GBM_OK;
+			break;
 		std::vector<const uint8_t *> ptrs(cands.size());
 		std::vector<size_t> lens(cands.size());
 		for (size_t i = 0; i < cands.size(); ++i) {
@@ -441,17 +471,43 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, int want, std::vec
 				mg->nodes[who[c.b][c.j]]->mark_corrupted(hs[c.b], c.j);
 				continue;
 			}
-			if (!g.have_meta) {
-				g.meta = c.hd;
-				g.have_meta = true;
+			Geometry geo;
+			geo.compressed = c.hd.compressed;
+			geo.orig_len = c.hd.orig_len;
+			geo.shard_len = c.hd.shard_len;
+			Gathered::Group &grp = g.groups[geo];
+			if (grp.shard.empty()) {
+				grp.shard.assign(n, {});
+				grp.meta = c.hd;
 			}
 			c.raw.erase(c.raw.begin(), c.raw.begin() + GBM_SHARD_HEADER_SIZE);
-			g.shard[c.j] = std::move(c.raw);
-			g.count++;
+			grp.shard[c.j] = std::move(c.raw);
+			grp.count++;
 			std::lock_guard<std::mutex> lk(mg->mu);
 			mg->metrics[1] += c.hd.shard_len;
 		}
 	}
+	// settle on the largest consistent group; the stragglers of other geometries are
+	// stale leftovers that resync will overwrite
+	for (size_t b = 0; b < hs.size(); ++b) {
+		Gathered &g = gs[b];
+		Gathered::Group *bestg = nullptr;
+		for (auto &kv : g.groups)
+			if (!bestg || kv.second.count > bestg->count)
+				bestg = &kv.second;
+		if (bestg) {
+			g.shard = std::move(bestg->shard);
+			g.meta = bestg->meta;
+			g.have_meta = true;
+			g.count = bestg->count;
+			if (g.groups.size() > 1) {
+				std::lock_guard<std::mutex> lk(mg->mu);
+				mg->resync_queue.push_back(hs[b]);
+			}
+		}
+		g.groups.clear();
+	}
+	return GBM_OK;
 }
 
 int gather(gbm_manager *mg, const Hash &h, int want, Gathered &g)
@@ -560,62 +616,73 @@ int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const 
 			}
 	data = dptr.data();
 	len = dlen.data();
-	size_t S = 0;
+	// Shard geometry is a pure function of the block: S = gec_shard_len(k, payload length).
+	// (Never the batch maximum: a later put of the same block must produce compatible
+	// shards.)  Blocks of equal S -- in practice all full block_size blocks -- share ONE
+	// device call that returns parity and the checksums of all k+m shards.
+	std::map<size_t, std::vector<size_t>> by_s;
 	for (size_t b = 0; b < nb; ++b)
-		S = std::max(S, gec_shard_len(k, len[b]));
-	// one device call for the whole batch (the coalescing queue in front of the FFI)
-	std::vector<uint8_t> parity(nb * (size_t)m * S);
-	std::vector<uint8_t *> pp(nb);
-	for (size_t b = 0; b < nb; ++b)
-		pp[b] = parity.data() + b * (size_t)m * S;
-	// parity AND the checksum of all k+m shards come back from the device: no CPU hash pass
-	std::vector<uint8_t> sums(nb * (size_t)n * 32);
-	int rc = gec_encode_hash_batch(mg->codec, nb, data, len, S, pp.data(), sums.data());
-	if (rc)
-		return ec_fail(rc, "gec_encode_hash_batch");
-	{
-		std::lock_guard<std::mutex> lk(mg->mu);
-		mg->gpu_hashed += nb * (size_t)n;
-	}
+		by_s[gec_shard_len(k, len[b])].push_back(b);
 	int result = GBM_OK;
-	std::vector<uint8_t> last(S);
-	for (size_t b = 0; b < nb; ++b) {
-		Hash h((const char *)hashes + 32 * b, 32);
-		std::vector<int> who;
-		mg->nodes_of(h, who);
-		int ok = 0;
-		for (int j = 0; j < n; ++j) {
-			const uint8_t *payload;
-			if (j < k) {
-				// data shard j = block bytes [j*S, (j+1)*S) zero-extended
-				size_t lo = (size_t)j * S, hi = std::min(len[b], lo + S);
-				if (hi >= lo + S) {
-					payload = data[b] + lo;
-				} else {
-					std::fill(last.begin(), last.end(), 0);
-					if (hi > lo)
-						std::memcpy(last.data(), data[b] + lo, hi - lo);
-					payload = last.data();
-				}
-			} else {
-				payload = pp[b] + (size_t)(j - k) * S;
-			}
-			if (store_shard(mg, who[j], h, j, payload, S, len[b], is_z[b] != 0, sums.data() + (b * n + j) * 32) == 0) {
-				++ok;
-				std::lock_guard<std::mutex> lk(mg->mu);
-				mg->metrics[0] += S;
-			}
+	for (auto &kv : by_s) {
+		const size_t S = kv.first;
+		const std::vector<size_t> &ids = kv.second;
+		const size_t gn = ids.size();
+		std::vector<uint8_t> parity(gn * (size_t)m * S), sums(gn * (size_t)n * 32), last(S);
+		std::vector<uint8_t *> pp(gn);
+		std::vector<const uint8_t *> gd(gn);
+		std::vector<size_t> gl(gn);
+		for (size_t i = 0; i < gn; ++i) {
+			pp[i] = parity.data() + i * (size_t)m * S;
+			gd[i] = data[ids[i]];
+			gl[i] = len[ids[i]];
 		}
+		int rc = gec_encode_hash_batch(mg->codec, gn, gd.data(), gl.data(), S, pp.data(), sums.data());
+		if (rc)
+			return ec_fail(rc, "gec_encode_hash_batch");
 		{
 			std::lock_guard<std::mutex> lk(mg->mu);
-			mg->metrics[4]++;
+			mg->gpu_hashed += gn * (size_t)n;
 		}
-		if (ok < mg->write_quorum) {
-			result = fail(GBM_E_QUORUM, "Could not reach quorum of " + std::to_string(mg->write_quorum) + ". " +
-							    std::to_string(ok) + " of " + std::to_string(n) +
-							    " request succeeded");
-		} else if (ok < n) {
-			mg->enqueue(h);  // stragglers are finished by resync
+		for (size_t i = 0; i < gn; ++i) {
+			const size_t b = ids[i];
+			Hash h((const char *)hashes + 32 * b, 32);
+			std::vector<int> who;
+			mg->nodes_of(h, who);
+			int ok = 0;
+			for (int j = 0; j < n; ++j) {
+				const uint8_t *payload;
+				if (j < k) {
+					// data shard j = payload bytes [j*S, (j+1)*S) zero-extended
+					size_t lo = (size_t)j * S, hi = std::min(len[b], lo + S);
+					if (hi >= lo + S) {
+						payload = data[b] + lo;
+					} else {
+						std::fill(last.begin(), last.end(), 0);
+						if (hi > lo)
+							std::memcpy(last.data(), data[b] + lo, hi - lo);
+						payload = last.data();
+					}
+				} else {
+					payload = pp[i] + (size_t)(j - k) * S;
+				}
+				if (store_shard(mg, who[j], h, j, payload, S, len[b], is_z[b] != 0, sums.data() + (i * n + j) * 32) == 0) {
+					++ok;
+					std::lock_guard<std::mutex> lk(mg->mu);
+					mg->metrics[0] += S;
+				}
+			}
+			{
+				std::lock_guard<std::mutex> lk(mg->mu);
+				mg->metrics[4]++;
+			}
+			if (ok < mg->write_quorum) {
+				result = fail(GBM_E_QUORUM, "Could not reach quorum of " + std::to_string(mg->write_quorum) + ". " +
+								    std::to_string(ok) + " of " + std::to_string(n) +
+								    " request succeeded");
+			} else if (ok < n) {
+				mg->enqueue(h);  // stragglers are finished by resync
+			}
 		}
 	}
 	return result;

@@ -156,3 +156,27 @@ def scenario_datablock_api():
     assert len(hdr.pack()) == 64 and ShardHeader.unpack(hdr.pack()) == hdr
     with pytest.raises(ValueError):
         ShardHeader.unpack(b"\0" * 64)
+
+
+def scenario_geometry_is_a_function_of_the_block(codec):
+    """Regression (found by ASan in tests/c/block_manager_host_test): a block put in a
+    batch with a larger block must get the same shards as when put alone, and a
+    half-failed re-put must not poison reads."""
+    mgr, stores = make_manager(codec)
+    small, big = pattern_block(200_000, 21), pattern_block(1 << 20, 22)
+    hs, hb = block_hash(small), block_hash(big)
+    mgr.rpc_put_blocks([(hb, big), (hs, small)])
+    who = mgr.storage_nodes_of(hs)
+    batched = [stores[who[j]].get(hs, j) for j in range(codec.k + codec.m)]
+    mgr.rpc_put_block(hs, small)
+    alone = [stores[who[j]].get(hs, j) for j in range(codec.k + codec.m)]
+    assert batched == alone
+    import garage_amd
+
+    assert ShardHeader.unpack(alone[0]).shard_len == garage_amd.shard_len(codec.k, len(small))
+    mgr.block_incref(hs)
+    hdr = ShardHeader(codec.k, codec.m, 0, False, 1000, 64, block_hash(bytes(64)))
+    stores[who[0]].put(hs, 0, hdr.pack() + bytes(64))     # stale shard of another geometry
+    assert mgr.rpc_get_block(hs) == small                  # majority geometry wins
+    assert mgr.resync_all() >= 1                           # and resync overwrites the stray shard
+    assert ShardHeader.unpack(stores[who[0]].get(hs, 0)).orig_len == len(small)

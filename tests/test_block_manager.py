@@ -30,6 +30,10 @@ def test_scrub_finds_silent_corruption(codec):
     C.scenario_scrub_finds_silent_corruption(codec)
 
 
+def test_geometry_is_a_function_of_the_block(codec):
+    C.scenario_geometry_is_a_function_of_the_block(codec)
+
+
 def test_datablock_api():
     C.scenario_datablock_api()
 

@@ -31,3 +31,7 @@ def test_corrupt_shard_detected_and_resynced(codec, tmp_path):
 
 def test_scrub_finds_silent_corruption(codec):
     C.scenario_scrub_finds_silent_corruption(codec)
+
+
+def test_geometry_is_a_function_of_the_block(codec):
+    C.scenario_geometry_is_a_function_of_the_block(codec)
