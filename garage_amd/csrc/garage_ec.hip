@@ -480,7 +480,8 @@ int verify_dev(const gec_codec *c, size_t nblocks, const uint8_t *d_stripes, siz
 		in_off[t] = (size_t)t * S;
 	for (int r = 0; r < m; ++r)
 		out_off[r] = (size_t)(k + r) * S;
-	HIP_TRY(hipMemsetAsync(d_bad, 0, nblocks * sizeof(uint32_t), stream));
+	hipLaunchKernelGGL(gec::clear_flags, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, stream, d_bad, (uint32_t)nblocks);
+	HIP_TRY(hipGetLastError());
 	return launch_apply(c, d_stripes, stride, const_cast<uint8_t *>(d_stripes), stride, d_bad, 0, S, nblocks,
 			    in_off.data(), out_off.data(), m, c->enc.row(k), gec::MODE_COMPARE, stream);
 }

@@ -319,6 +319,18 @@ __global__ __launch_bounds__(TPB, MINW) void gf_apply_nibble_w(const ApplyArgs a
 	gf_apply_nibble_body<MW, MODE, KC, CPT, NT, TPB>(a, le);
 }
 
+// Clears the per-block mismatch flags ahead of a MODE_COMPARE launch.  A kernel rather
+// than hipMemsetAsync: inside a captured hipGraph (ROCm 7.0/7.2) the memset node did not
+// order the compare kernel behind the preceding encode kernel, so verify could race with
+// the encode that produces its input (tests/test_gpu_parity.py::test_device_api_is_
+// hipgraph_capturable caught it); kernel -> kernel edges are reliable.
+__global__ void clear_flags(uint32_t *p, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+		p[i] = 0;
+}
+
 // ---------------------------------------------------------------------------
 // Baseline kernel (variant 1): the literal north_star formulation -- per-byte
 // log/antilog lookups in LDS, one GF multiply per (byte, row).  Kept only as the
