@@ -99,6 +99,61 @@ def cpu_baseline(S: int):
     }
 
 
+def striped_decode_bench(args, R, distrib) -> None:
+    """BASELINE config 5 (secondary line, not the headline metric): 256 objects of 4 MiB,
+    RS(20,8), shard j on rank j % N; 8 shards erased; one RCCL all-gather of the slot
+    buffers, every rank rebuilds its 1/N byte range of each missing shard in place on the
+    gathered buffer, second all-gather of the rebuilt ranges."""
+    import torch
+
+    import garage_amd as g
+    from garage_amd.striped import StripeLayout, striped_reconstruct
+
+    if not R.distributed:  # world 1 still goes through RCCL so the code path is the same
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's banner off stdout
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=R.device)
+    k, m, L, nobj = 20, 8, 4 << 20, 256
+    S = g.shard_len(k, L)
+    layout = StripeLayout(k, m, R.world)
+    rs = g.ReedSolomon(k, m, device=R.local_rank)
+    gen = torch.Generator(device=R.device)
+    gen.manual_seed(0x6761726167650005 + R.rank)
+    # this rank's slots of already-encoded stripes: contents do not affect the timing,
+    # correctness of the flow is covered by tests/test_gpu_striped.py and the gloo tests
+    local = torch.randint(0, 256, (nobj, layout.slots, S), dtype=torch.uint8, device=R.device, generator=gen)
+    lost = (0, 1, 5, 9, 13, 19, 21, 27)
+    present = [j not in lost for j in range(k + m)]
+    for _ in range(max(1, args.warmup // 10)):
+        striped_reconstruct(rs, local, present, layout)
+    torch.cuda.synchronize()
+    distrib.barrier(R)
+    steps = max(3, args.steps // 20)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        striped_reconstruct(rs, local, present, layout)
+    torch.cuda.synchronize()
+    distrib.barrier(R)
+    dt = distrib.max_over_ranks(R, time.perf_counter() - t0)
+    if R.rank == 0:
+        print(json.dumps({
+            "metric": "RS(20,8) striped-object decode payload throughput, 4 MiB objects (all-gather + range reconstruct)",
+            "value": round(nobj * L * steps / dt / 2**30, 2), "unit": "GiB/s", "n_gpus": R.world, "steps": steps,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE config 5: RS(20,8), 256 x 4 MiB objects striped over the ranks, 8 erasures",
+                       "k": k, "m": m, "shard_len": S, "slots_per_rank": layout.slots,
+                       "allgather_bytes_per_rank": nobj * layout.slots * S, "parallelism": f"stripe x{R.world}"},
+        }), flush=True)
+    if not R.distributed:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +163,9 @@ def main() -> None:
     ap.add_argument("--variant", type=int, default=0, help="0 nibble product tables (default), 1 log/antilog baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--op", choices=["encode", "striped-decode"], default="encode",
+                    help="encode = the BASELINE metric (default); striped-decode = BASELINE config 5: RS(20,8), 4 MiB objects "
+                         "striped over the ranks, all-gather + per-rank byte-range reconstruct")
     args = ap.parse_args()
 
     import numpy as np
@@ -127,6 +185,10 @@ def main() -> None:
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
     g.set_kernel_variant(args.variant)
+    if args.op == "striped-decode":
+        striped_decode_bench(args, R, distrib)
+        distrib.shutdown(R)
+        return
     S = g.shard_len(K, BLOCK_LEN)
     n = K + M
 

@@ -42,6 +42,10 @@ def init_from_env(force_backend: str | None = None) -> Ranks:
 
     backend = force_backend or ("nccl" if use_cuda else "gloo")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # RCCL prints a version banner on STDOUT at NCCL_DEBUG=VERSION/INFO; bench.py's contract
+    # is ONE JSON line on stdout, so keep RCCL at WARN unless the caller insists.
+    if os.environ.get("GARAGE_KEEP_NCCL_DEBUG") is None:
+        os.environ["NCCL_DEBUG"] = "WARN"
     if backend == "nccl":
         dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
     else:

@@ -467,3 +467,41 @@ def test_device_api_is_hipgraph_capturable(coracle, rs104):
         assert bool(ok.all())
         out = st.cpu().numpy()
         assert np.array_equal(out[:, :k], data) and np.array_equal(out[:, k:], want)
+
+
+# ------------------------------------------------- randomized shapes (hypothesis)
+from hypothesis import HealthCheck, given, settings  # noqa: E402
+from hypothesis import strategies as hst  # noqa: E402
+
+
+@settings(max_examples=120, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(k=hst.integers(1, 33), m=hst.integers(1, 9), cols4=hst.integers(1, 80), nb=hst.integers(1, 4),
+       seed=hst.integers(0, 2**31), data_only=hst.booleans())
+def test_random_codes_encode_verify_reconstruct(coracle, k, m, cols4, nb, seed, data_only):
+    """Every (k, m) lands on a different load-batch size / table width / launch count
+    (k mod KC remainders use clamped duplicate loads; m > 8 needs two launches);
+    S sweeps ragged tile fills.  Encode, verify and a random reconstruct, all bit-exact."""
+    S = 64 * cols4
+    rng = np.random.default_rng(seed)
+    data = rng.integers(0, 256, (nb, k, S), dtype=np.uint8)
+    rs = g.ReedSolomon(k, m)
+    want = coracle.encode_batch(k, m, data, coracle.AVX2)
+    st = torch.zeros((nb, k + m, S), dtype=torch.uint8, device=DEV)
+    st[:, :k] = torch.from_numpy(data).to(DEV)
+    rs.encode_dev(st)
+    assert bool(rs.verify_dev(st).all())
+    full = st.cpu().numpy()
+    assert np.array_equal(full[:, k:], want)
+    lost = rng.choice(k + m, size=int(rng.integers(1, m + 1)), replace=False)
+    present = [j not in lost for j in range(k + m)]
+    st[:, torch.from_numpy(lost).to(DEV)] = 0xC3
+    rs.reconstruct_dev(st, present, data_only=data_only)
+    torch.cuda.synchronize()
+    got = st.cpu().numpy()
+    exp = full.copy()
+    if data_only:
+        for j in lost:
+            if j >= k:
+                exp[:, j] = 0xC3
+    assert np.array_equal(got, exp)
+    rs.close()
