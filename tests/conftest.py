@@ -10,6 +10,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+    # A fresh checkout has no built artefacts (they are git-ignored): build them once.
+    # hipcc cross-compiles gfx950 without a GPU; the oracle needs only gcc.
+    import subprocess
+
+    need = [os.path.join(ROOT, "garage_amd", "libgarage_ec.so"), os.path.join(ROOT, "garage_amd", "libgarage_block.so"),
+            os.path.join(ROOT, "oracle", "librs_oracle.so")]
+    if not all(os.path.exists(p) for p in need):
+        for d in (os.path.join(ROOT, "garage_amd", "csrc"), os.path.join(ROOT, "oracle")):
+            r = subprocess.run(["make", "-C", d], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"make -C {d} failed:\n{r.stdout}\n{r.stderr}")
 
 
 @pytest.fixture(scope="session")
