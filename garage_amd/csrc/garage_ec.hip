@@ -317,12 +317,23 @@ int get_plan(const gec_codec *c, const uint8_t *present, bool data_only, std::sh
 // Launch geometry of the default kernel, tuned on MI355X with tools/kbench
 // (profiles/r01_kbench_*.txt): one tile per workgroup, 1 column per thread.
 //   4-byte table entries (rows <= 4): 256 threads, up to 10 shards loaded per batch
-//     (RS(10,4): all 10 loads go out before the table expansion; 72% of 8 TB/s)
+//     (RS(10,4): all 10 loads go out before the table expansion; 72-74% of 8 TB/s)
 //   8-byte table entries (rows <= 8): 512 threads, up to 6 per batch (register budget)
 constexpr int kCPT = 1;
 constexpr int kThreadsMW1 = 256;
 constexpr int kThreadsMW2 = 512;
-constexpr uint64_t kMaxGrid = 1u << 22;  // workgroups per launch (HIP: grid*block < 2^32)
+
+// Test hook: GEC_MAX_COLS_PER_LAUNCH caps the columns one launch may cover, so the
+// multi-launch split (normally only beyond 2^32 columns = 64 GiB per shard slot) can be
+// exercised on small inputs.  Read once.
+uint64_t launch_cols_limit()
+{
+	static const uint64_t v = [] {
+		const char *e = getenv("GEC_MAX_COLS_PER_LAUNCH");
+		return e ? strtoull(e, nullptr, 0) : 0ull;
+	}();
+	return v;
+}
 
 // Loads per batch: k itself when small, else the candidate that wastes the fewest
 // clamped duplicate loads in the last batch (ties: the earlier = larger candidate).
@@ -410,13 +421,13 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 				a.coef[t][r] = r < rows ? coef[(size_t)(r0 + r) * k + t] : 0;
 		}
 		const int mw = rows <= 4 ? 1 : 2;
-		const int threads = variant == 1 ? gec::BLOCK : (mw == 1 ? kThreadsMW1 : kThreadsMW2);
-		a.tiles_per_block = (a.cols + threads * kCPT - 1) / (threads * kCPT);
-		const uint64_t ntiles = (uint64_t)a.nblocks * a.tiles_per_block;
-		if (ntiles > 0xffffffffull)
-			return fail(GEC_E_INVALID_ARG, "batch too large for one call");
 		if (variant == 1) {
-			// measured baseline: persistent grid-stride log/antilog kernel
+			// measured baseline: persistent grid-stride log/antilog kernel, one tile = 256
+			// columns of one block
+			a.tiles_per_block = (a.cols + gec::BLOCK - 1) / gec::BLOCK;
+			const uint64_t ntiles = (uint64_t)a.nblocks * a.tiles_per_block;
+			if (ntiles > 0xffffffffull)
+				return fail(GEC_E_INVALID_ARG, "batch too large for the baseline kernel");
 			const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)c->num_cu * 8);
 			if (mode == gec::MODE_STORE)
 				hipLaunchKernelGGL((gec::gf_apply_logexp<gec::MODE_STORE>), dim3(grid), dim3(gec::BLOCK), 0, stream, a, c->d_logexp);
@@ -425,18 +436,34 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 			HIP_TRY(hipGetLastError());
 			continue;
 		}
+		// The (block, column) space is flattened: a launch covers a range of whole blocks
+		// whose columns fit 32 bits and whose tiles fit HIP's grid limit (grid*block < 2^32).
+		const int threads = mw == 1 ? kThreadsMW1 : kThreadsMW2;
+		const uint64_t tile_cols = (uint64_t)threads * kCPT;
+		uint64_t max_cols = std::min<uint64_t>(0xfffff000ull, (0xffffffffull / threads) * tile_cols);
+		if (launch_cols_limit())
+			max_cols = std::min<uint64_t>(max_cols, launch_cols_limit());
+		if (a.cols > max_cols)
+			return fail(GEC_E_INVALID_ARG, "shard too large for one launch");
+		const uint64_t blocks_per_launch = std::max<uint64_t>(1, max_cols / a.cols);
 		const size_t lds = (size_t)k * 32 * 4 * mw + 768 + (size_t)k * gec::RMAX;
-		for (uint64_t t0 = 0; t0 < ntiles; t0 += kMaxGrid) {
-			a.tile0 = (uint32_t)t0;
-			const unsigned grid = (unsigned)std::min<uint64_t>(ntiles - t0, kMaxGrid);
+		gec::ApplyArgs la = a;
+		for (uint64_t b0 = 0; b0 < nblocks; b0 += blocks_per_launch) {
+			const uint64_t nb = std::min<uint64_t>(blocks_per_launch, nblocks - b0);
+			la.in = in + b0 * in_stride;
+			la.out = out + b0 * out_stride;
+			la.bad = bad ? bad + b0 : nullptr;
+			la.nblocks = (uint32_t)nb;
+			la.total_cols = (uint32_t)(nb * a.cols);
+			const unsigned grid = (unsigned)((la.total_cols + tile_cols - 1) / tile_cols);
 			if (mw == 1 && mode == gec::MODE_STORE)
-				launch_nibble<1, gec::MODE_STORE, kThreadsMW1>(a, c->d_logexp, grid, lds, stream);
+				launch_nibble<1, gec::MODE_STORE, kThreadsMW1>(la, c->d_logexp, grid, lds, stream);
 			else if (mw == 1)
-				launch_nibble<1, gec::MODE_COMPARE, kThreadsMW1>(a, c->d_logexp, grid, lds, stream);
+				launch_nibble<1, gec::MODE_COMPARE, kThreadsMW1>(la, c->d_logexp, grid, lds, stream);
 			else if (mode == gec::MODE_STORE)
-				launch_nibble<2, gec::MODE_STORE, kThreadsMW2>(a, c->d_logexp, grid, lds, stream);
+				launch_nibble<2, gec::MODE_STORE, kThreadsMW2>(la, c->d_logexp, grid, lds, stream);
 			else
-				launch_nibble<2, gec::MODE_COMPARE, kThreadsMW2>(a, c->d_logexp, grid, lds, stream);
+				launch_nibble<2, gec::MODE_COMPARE, kThreadsMW2>(la, c->d_logexp, grid, lds, stream);
 			HIP_TRY(hipGetLastError());
 		}
 	}

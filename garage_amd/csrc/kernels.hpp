@@ -47,10 +47,10 @@ struct ApplyArgs {
 	uint32_t col0;       // first 16-byte column of every shard to process
 	uint32_t cols;       // number of 16-byte columns to process
 	uint32_t nblocks;
-	uint32_t tiles_per_block;
+	uint32_t tiles_per_block;  // baseline kernel only
+	uint32_t total_cols;       // nblocks * cols (< 2^32: the host splits larger batches by blocks)
 	uint32_t k;          // inputs  (<= KMAX)
 	uint32_t rows;       // outputs (<= RMAX)
-	uint32_t tile0;      // first tile of this launch (launches are split at HIP's grid limit)
 	uint32_t in_off[KMAX];   // shard offsets inside a block, in 16-byte units
 	uint32_t out_off[RMAX];
 	uint8_t coef[KMAX][RMAX];  // coef[t][r] = mat[r][t]: one 8-byte row per input shard
@@ -157,28 +157,30 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 	uint8_t *lcoef = llog + 256;
 	const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds;
 
-	// One tile (TPB*CPT 16-byte columns of one block) per workgroup, dispatched by
-	// the hardware: on MI355X this beats a persistent grid-stride loop because fast
-	// CUs/XCDs simply pull more tiles (profiles/r01_kbench_*.txt).  Everything up to
-	// the first barrier is straight-line code with unconditional (index-clamped)
-	// loads so that hipcc can count them: the waits below are vmcnt(N), not vmcnt(0).
-	const uint32_t tile = a.tile0 + blockIdx.x;
-	const uint32_t b = tile / a.tiles_per_block;
-	const uint32_t col = (tile - b * a.tiles_per_block) * (nthr * CPT) + tid;
-	const bool active = col < a.cols;
-	// lanes past the ragged end of the last tile re-do the tile's first column
-	// (in-bounds, discarded) instead of diverging
+	// One tile = TPB*CPT consecutive columns of the FLATTENED (block, column) space per
+	// workgroup, dispatched by the hardware: on MI355X this beats a persistent grid-stride
+	// loop because fast CUs/XCDs simply pull more tiles (profiles/r01_kbench_*.txt).
+	// Flattening means a tile may straddle blocks: no ragged last tile per block, and
+	// batches of small blocks (fewer columns per shard than lanes per workgroup) still
+	// fill every lane.  Everything up to the first barrier is straight-line code with
+	// unconditional (index-clamped) loads so that hipcc can count them: the waits below
+	// are vmcnt(N), not vmcnt(0).
+	const uint32_t g0 = blockIdx.x * (nthr * CPT);  // < total_cols by grid sizing
 	bool live[CPT];
-	uint32_t cc[CPT];
+	uint32_t bb[CPT];
+	const u32x4 *srcp[CPT];
+	u32x4 *dstp[CPT];
 #pragma unroll
 	for (int c = 0; c < CPT; ++c) {
-		cc[c] = col + c * nthr;
-		live[c] = cc[c] < a.cols;
+		uint32_t gcol = g0 + tid + c * nthr;
+		live[c] = gcol < a.total_cols;
 		if (!live[c])
-			cc[c] = col - tid;
+			gcol = g0;  // lanes past the end shadow the tile's first column (loads only)
+		bb[c] = gcol / a.cols;
+		const uint32_t col = gcol - bb[c] * a.cols;
+		srcp[c] = reinterpret_cast<const u32x4 *>(a.in + (uint64_t)bb[c] * a.in_stride) + a.col0 + col;
+		dstp[c] = reinterpret_cast<u32x4 *>(a.out + (uint64_t)bb[c] * a.out_stride) + a.col0 + col;
 	}
-	const u32x4 *src = reinterpret_cast<const u32x4 *>(a.in + (uint64_t)b * a.in_stride) + a.col0;
-	u32x4 *dst = reinterpret_cast<u32x4 *>(a.out + (uint64_t)b * a.out_stride) + a.col0;
 
 	// -- prologue 0: log/antilog image (768 B) and coefficient rows (k*8 B) are
 	//    requested FIRST, so their wait does not drain the data loads behind them
@@ -197,7 +199,7 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 		const uint32_t off = a.in_off[(uint32_t)j < k ? j : k - 1];
 #pragma unroll
 		for (int c = 0; c < CPT; ++c)
-			d[j][c] = ld16<NT>(src + off + cc[c]);
+			d[j][c] = ld16<NT>(srcp[c] + off);
 	}
 
 	// -- prologue 1: pin log/antilog + coefficients in LDS
@@ -227,8 +229,6 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 			tdst[1] = w[1];
 	}
 	__syncthreads();
-	if (!active)
-		return;
 
 	// acc[c][w][j][h]: column c, dword w of the column, byte position j, row half h
 	uint32_t acc[CPT][4][4][MW];
@@ -249,7 +249,7 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 				const uint32_t off = a.in_off[t0 + j < k ? t0 + j : k - 1];
 #pragma unroll
 				for (int c = 0; c < CPT; ++c)
-					d[j][c] = ld16<NT>(src + off + cc[c]);
+					d[j][c] = ld16<NT>(srcp[c] + off);
 			}
 		}
 #pragma unroll
@@ -276,9 +276,9 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 		}
 	}
 
-	uint32_t diff = 0;
 #pragma unroll
 	for (int c = 0; c < CPT; ++c) {
+		uint32_t diff = 0;
 		// row-interleaved accumulators -> per-shard dwords
 		uint32_t P[4 * MW][4];
 #pragma unroll
@@ -294,7 +294,7 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 			if (r >= (int)rows)
 				break;
 			u32x4 v = {P[r][0], P[r][1], P[r][2], P[r][3]};
-			u32x4 *o = dst + a.out_off[r] + cc[c];
+			u32x4 *o = dstp[c] + a.out_off[r];
 			if (MODE == MODE_COMPARE) {
 				u32x4 old = ld16<NT>(o);
 				diff |= (v.x ^ old.x) | (v.y ^ old.y) | (v.z ^ old.z) | (v.w ^ old.w);
@@ -302,9 +302,9 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 				st16<NT>(v, o);
 			}
 		}
+		if (MODE == MODE_COMPARE && diff)
+			a.bad[bb[c]] = 1u;
 	}
-	if (MODE == MODE_COMPARE && diff)
-		a.bad[b] = 1u;
 }
 
 template <int MW, int MODE, int KC, int CPT, bool NT, int TPB>

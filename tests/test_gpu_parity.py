@@ -407,10 +407,10 @@ def test_config5_shape_rs_20_8_4mib(coracle):
     assert rs.verify_dev(st).all()
 
 
-def test_more_tiles_than_one_launch_holds():
-    """> 2^22 tiles forces the host to split the work into several launches
-    (ApplyArgs.tile0).  RS(3,1), S = 64: one tile per block, parity must be the
-    XOR of the three data shards (Appendix A.4.4) -- checked on device."""
+def test_many_tiny_blocks_fill_tiles():
+    """4.2 M blocks of RS(3,1) with S = 64: a shard has only 4 columns, so a 256-lane tile
+    spans 64 blocks (flattened block/column space).  Parity must be the XOR of the three
+    data shards (Appendix A.4.4) -- checked on device; then a reconstruct."""
     k, m, S = 3, 1, 64
     nb = (1 << 22) + 1000
     rs = g.ReedSolomon(k, m)
@@ -422,12 +422,51 @@ def test_more_tiles_than_one_launch_holds():
     want = st[:, 0] ^ st[:, 1] ^ st[:, 2]
     assert torch.equal(st[:, 3], want)
     assert rs.verify_dev(st).all()
-    # reconstruct across the launch boundary too
+    st[12345, 3, 7] ^= 1
+    bad = (~rs.verify_dev(st)).nonzero().flatten().tolist()
+    assert bad == [12345]
+    st[12345, 3, 7] ^= 1
     ref = st[:, 1].clone()
     st[:, 1] = 0
     rs.reconstruct_dev(st, [1, 0, 1, 1])
     torch.cuda.synchronize()
     assert torch.equal(st[:, 1], ref)
+
+
+def test_launch_split_by_block_ranges():
+    """A batch whose flattened column count exceeds what one launch may cover is split
+    into launches over block ranges.  The real limit is 2^32 columns (64 GiB per shard
+    slot); GEC_MAX_COLS_PER_LAUNCH lowers it so the split runs on a small input."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import numpy as np, torch
+import garage_amd as g
+from oracle import rs_oracle as O
+k, m, S, nb = 10, 4, 4160, 23          # 260 columns per shard; limit 1000 -> 3 blocks per launch, 8 launches
+rs = g.ReedSolomon(k, m)
+co = O.COracle()
+data = O.splitmix64_bytes(77, nb * k * S).reshape(nb, k, S)
+st = torch.zeros((nb, k + m, S), dtype=torch.uint8, device="cuda:0")
+st[:, :k] = torch.from_numpy(data).to("cuda:0")
+rs.encode_dev(st)
+assert np.array_equal(st[:, k:].cpu().numpy(), co.encode_batch(k, m, data, co.AVX2))
+st[20, 11, 99] ^= 4
+assert (~rs.verify_dev(st)).nonzero().flatten().tolist() == [20]
+st[20, 11, 99] ^= 4
+ref = st.clone()
+st[:, [0, 3, 7, 9]] = 0
+rs.reconstruct_dev(st, [j not in (0, 3, 7, 9) for j in range(14)])
+torch.cuda.synchronize()
+assert torch.equal(st, ref)
+print("OK")
+'''
+    env = dict(os.environ, GEC_MAX_COLS_PER_LAUNCH="1000")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_large_shard_16mib(coracle):

@@ -192,11 +192,14 @@ int main(int argc, char **argv)
 
 	auto launch = [&](const Variant &v) {
 		ApplyArgs aa = a;
+		aa.total_cols = aa.nblocks * a.cols;
 		aa.tiles_per_block = (a.cols + v.threads * v.cpt - 1) / (v.threads * v.cpt);
-		uint64_t ntiles = (uint64_t)aa.nblocks * aa.tiles_per_block;
+		uint64_t ntiles = ((uint64_t)aa.total_cols + v.threads * v.cpt - 1) / (v.threads * v.cpt);
 		unsigned grid = (v.wg_per_cu > 0 && !v.nibble) ? (unsigned)std::min<uint64_t>(ntiles, (uint64_t)cus * v.wg_per_cu) : (unsigned)ntiles;
-		if (!v.nibble)
+		if (!v.nibble) {
 			aa.tiles_per_block = (a.cols + BLOCK - 1) / BLOCK;
+			grid = (unsigned)std::min<uint64_t>((uint64_t)aa.nblocks * aa.tiles_per_block, (uint64_t)cus * 8);
+		}
 		hipLaunchKernelGGL(v.fn, dim3(grid), dim3(v.nibble ? v.threads : BLOCK), v.nibble ? lds : 0, 0, aa, d_le);
 	};
 
