@@ -15,7 +15,7 @@ BASELINE config 3 (4 erasures).
 
 Defaults (--steps 1000 --warmup 100, ~0.3 s of GPU time) measure the steady
 state: MI355X's power management slows the first few milliseconds of a burst of
-this kernel by up to 1.5x before settling (profiles/r01_bench_kernel_stats.txt).
+this kernel by up to 1.5x before settling (profiles/r01_early_20step_burst_dvfs_transient.txt).
 """
 from __future__ import annotations
 
