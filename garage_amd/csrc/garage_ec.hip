@@ -440,7 +440,7 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 		// whose columns fit 32 bits and whose tiles fit HIP's grid limit (grid*block < 2^32).
 		const int threads = mw == 1 ? kThreadsMW1 : kThreadsMW2;
 		const uint64_t tile_cols = (uint64_t)threads * kCPT;
-		uint64_t max_cols = std::min<uint64_t>(0xfffff000ull, (0xffffffffull / threads) * tile_cols);
+		uint64_t max_cols = std::min<uint64_t>(0xfffff000ull, (0xffffffffull / threads - 8) * tile_cols);
 		if (launch_cols_limit())
 			max_cols = std::min<uint64_t>(max_cols, launch_cols_limit());
 		if (a.cols > max_cols)
@@ -455,7 +455,8 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 			la.bad = bad ? bad + b0 : nullptr;
 			la.nblocks = (uint32_t)nb;
 			la.total_cols = (uint32_t)(nb * a.cols);
-			const unsigned grid = (unsigned)((la.total_cols + tile_cols - 1) / tile_cols);
+			// multiple of 8: the kernel hands each XCD a contiguous range of tiles
+			const unsigned grid = (unsigned)(((la.total_cols + tile_cols - 1) / tile_cols + 7) / 8 * 8);
 			if (mw == 1 && mode == gec::MODE_STORE)
 				launch_nibble<1, gec::MODE_STORE, kThreadsMW1>(la, c->d_logexp, grid, lds, stream);
 			else if (mw == 1)

@@ -196,6 +196,8 @@ int main(int argc, char **argv)
 		aa.tiles_per_block = (a.cols + v.threads * v.cpt - 1) / (v.threads * v.cpt);
 		uint64_t ntiles = ((uint64_t)aa.total_cols + v.threads * v.cpt - 1) / (v.threads * v.cpt);
 		unsigned grid = (v.wg_per_cu > 0 && !v.nibble) ? (unsigned)std::min<uint64_t>(ntiles, (uint64_t)cus * v.wg_per_cu) : (unsigned)ntiles;
+		if (v.nibble)
+			grid = (grid + 7) / 8 * 8;  // XCD-aware tile order needs a multiple of 8
 		if (!v.nibble) {
 			aa.tiles_per_block = (a.cols + BLOCK - 1) / BLOCK;
 			grid = (unsigned)std::min<uint64_t>((uint64_t)aa.nblocks * aa.tiles_per_block, (uint64_t)cus * 8);

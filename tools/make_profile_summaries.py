@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Turns the raw rocprofv3 CSV output of the round's final profiling call
+(gpurun_out/prof_final*, bench_final.json) into the summaries under profiles/.
+usage: make_profile_summaries.py <round-tag, e.g. r01>"""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def last_json(path):
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+def per_dispatch(csvpath, kernel_substr, counter):
+    acc = {}
+    for r in csv.DictReader(open(csvpath)):
+        if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            acc[r["Dispatch_Id"]] = acc.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    return sum(acc.values()) / len(acc)
+
+
+d = last_json(os.path.join(G, "prof_final_bench.json"))
+d2 = last_json(os.path.join(G, "bench_final.json"))
+rows = list(csv.DictReader(open(os.path.join(G, "prof_final", "d_kernel_stats.csv"))))
+tr = list(csv.DictReader(open(os.path.join(G, "prof_final", "d_kernel_trace.csv"))))
+ds = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            for r in tr if "gf_apply_nibble<1, 0" in r["Kernel_Name"])
+enc = [x for _, x in ds[100:1100]]
+with open(os.path.join(P, f"{tag}_bench_default_kernel_stats.txt"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py     (defaults: --steps 1000 --warmup 100)\n")
+    f.write(f"# {tag} FINAL kernel (flattened, XCD-aware tiles), MI355X.  gf_apply_nibble<1,0,10,1,true,256> = 100 warm-up + 1000 timed encode + 501 reconstruct launches\n")
+    f.write(f"# bench.py printed in this profiled run: value {d['value']} GiB/s, ms_per_step {d['ms_per_step']}, roofline.kernel_ms {d['roofline']['kernel_ms']} (HIP events over the 1000 timed steps), frac {d['roofline']['frac']}\n")
+    f.write(f"# rocprofv3, the 1000 timed encode launches alone: avg {sum(enc)/len(enc)/1e3:.1f} us, min {min(enc)/1e3:.1f}, max {max(enc)/1e3:.1f}  -> agrees with kernel_ms\n")
+    f.write(f"# un-profiled run right after, same box: value {d2['value']} GiB/s, frac {d2['roofline']['frac']}, decode {d2['decode']['value']} GiB/s, cpu_baseline {d2['cpu_baseline']['value']} GiB/s on {d2['cpu_baseline']['cores']} threads\n")
+    f.write(f"{'calls':>6} {'avg_us':>9} {'min_us':>9} {'max_us':>9} {'total_us':>11} {'%':>6}  kernel\n")
+    for r in rows[:8]:
+        n = r["Name"].replace("void ", "")
+        n = n if len(n) < 100 else n[:97] + "..."
+        f.write(f"{int(r['Calls']):>6} {float(r['AverageNs'])/1e3:>9.1f} {int(r['MinNs'])/1e3:>9.1f} {int(r['MaxNs'])/1e3:>9.1f} {int(r['TotalDurationNs'])/1e3:>11.1f} {float(r['Percentage']):>6.2f}  {n}\n")
+    f.write("\n# first 60 launches (us), showing the DVFS transient the warm-up absorbs:\n# " + " ".join(f"{x/1e3:.0f}" for _, x in ds[:60]) + "\n")
+
+K = "gf_apply_nibble<1, 0, 10"
+fetch = per_dispatch(os.path.join(G, "prof_final_fetch", "f_counter_collection.csv"), K, "FETCH_SIZE")
+write = per_dispatch(os.path.join(G, "prof_final_write", "w_counter_collection.csv"), K, "WRITE_SIZE")
+vfetch = per_dispatch(os.path.join(G, "prof_final_fetch", "f_counter_collection.csv"), "gf_apply_nibble<1, 2, 10", "FETCH_SIZE")
+rd, wr = 2 * fetch * 1024, write * 1024
+algo = 1503789056
+json.dump({"_comment": "HBM bytes per launch from rocprofv3 PMC passes (profiles/%s_pmc_hbm_traffic.txt): 2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes, per the gfx950 correction in MI355X_MICROARCH.md. bench.py reports this as roofline.traffic for the matching workload." % tag,
+           "rs10_4_encode_1MiB_x1024": {"traffic_bytes": int(round(rd + wr)), "algorithmic_bytes": algo, "round": int(tag[1:])}},
+          open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+summ = lambda *dirs: subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), *dirs], capture_output=True, text=True).stdout
+with open(os.path.join(P, f"{tag}_pmc_hbm_traffic.txt"), "w") as f:
+    f.write(f"# rocprofv3 --pmc <counter> --kernel-trace --output-format csv, one counter group per pass ({tag} FINAL kernel, MI355X)\n")
+    f.write("# FETCH_SIZE / WRITE_SIZE are in KiB.  Calibration on kbench's copy16x4 (reads 751894528 B = 734272 KiB, writes the same):\n")
+    f.write("#   FETCH_SIZE reports 367139.5 -> exactly 1/2 of the bytes read (guide: double it); WRITE_SIZE reports 734319 -> 1.00x.\n")
+    f.write("# gf_apply_nibble<1,0,10,1,true,256> on BASELINE config 2 (algorithmic: read 1074135040 B, write 429654016 B, total 1503789056 B):\n")
+    f.write(f"#   read  = 2 * {fetch:.1f} KiB = {rd:.0f} B ({rd/1074135040:.3f}x algorithmic: + per-workgroup log/antilog and coefficient fetches)\n")
+    f.write(f"#   write =     {write:.1f} KiB = {wr:.0f} B ({wr/429654016:.3f}x)\n")
+    f.write(f"#   total traffic = {rd+wr:.0f} B per launch = {(rd+wr)/algo:.4f}x algorithmic -> no wasted re-reads\n")
+    f.write(f"# verify (MODE_COMPARE): read = 2 * {vfetch:.1f} KiB = {2*vfetch*1024:.0f} B vs algorithmic (k+m)*S*n = {algo} B ({2*vfetch*1024/algo:.3f}x), writes ~0\n\n")
+    f.write(summ(os.path.join(G, "prof_final_fetch"), os.path.join(G, "prof_final_write")))
+sqp = os.path.join(G, "prof_final_sq", "sq_counter_collection.csv")
+lds = per_dispatch(sqp, K, "SQ_LDS_IDX_ACTIVE")
+conf = per_dispatch(sqp, K, "SQ_LDS_BANK_CONFLICT")
+wave = per_dispatch(sqp, K, "SQ_WAVE_CYCLES")
+wait = per_dispatch(sqp, K, "SQ_WAIT_ANY")
+with open(os.path.join(P, f"{tag}_pmc_sq.txt"), "w") as f:
+    f.write(f"# rocprofv3 --pmc SQ_* (one pass), bench.py --steps 3, {tag} FINAL kernel gf_apply_nibble<1,0,10,1,true,256>, MI355X\n")
+    f.write(f"# LDS pipe: SQ_LDS_IDX_ACTIVE {lds:.0f} array-cycles / 256 CUs = {lds/256/1e3:.0f}k per CU per launch; bank conflicts {conf:.0f} = {100*conf/lds:.1f}% (table-expansion prologue only; the nibble lookups are conflict-free)\n")
+    f.write(f"# SQ_WAIT_ANY / SQ_WAVE_CYCLES = {100*wait/wave:.0f}% of wave time parked on s_waitcnt (HBM latency)\n\n")
+    f.write(summ(os.path.join(G, "prof_final_sq")))
+for cfg in ("10_4", "20_8"):
+    src = os.path.join(G, f"kbench_final_{cfg}.txt")
+    if os.path.exists(src):
+        open(os.path.join(P, f"{tag}_kbench_rs{cfg}_final.txt"), "w").write(open(src).read())
+print("profiled bench:", d["value"], d["roofline"]["frac"], "| unprofiled:", d2["value"], d2["roofline"]["frac"], "| traffic x", (rd + wr) / algo)
