@@ -31,6 +31,13 @@ def init_from_env(force_backend: str | None = None) -> Ranks:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available() and force_backend != "gloo"
+    # Dry-run hook for boxes with ONE GPU: every rank uses device 0 and the collectives go
+    # through gloo (RCCL refuses two ranks on one device).  Exercises the N>1 control flow of
+    # bench.py end to end; the numbers it prints are meaningless.
+    dryrun = os.environ.get("GARAGE_DRYRUN_ONE_GPU") == "1"
+    if dryrun:
+        local_rank = 0
+        force_backend = "gloo"
     if use_cuda:
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
@@ -65,7 +72,7 @@ def max_over_ranks(r: Ranks, value: float) -> float:
         return float(value)
     import torch.distributed as dist
 
-    t = torch.tensor([value], dtype=torch.float64, device=r.device)
+    t = torch.tensor([value], dtype=torch.float64, device=r.device if r.backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -75,7 +82,7 @@ def sum_over_ranks(r: Ranks, value: int) -> int:
         return int(value)
     import torch.distributed as dist
 
-    t = torch.tensor([value], dtype=torch.int64, device=r.device)
+    t = torch.tensor([value], dtype=torch.int64, device=r.device if r.backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
 
