@@ -163,6 +163,9 @@ def main() -> None:
     ap.add_argument("--variant", type=int, default=0, help="0 nibble product tables (default), 1 log/antilog baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--precondition-ms", type=float, default=200.0,
+                    help="untimed device pre-conditioning before the W warm-up steps: the same encode launches for this "
+                         "long, so a short K/W does not measure MI355X's idle-to-load DVFS transient (0 disables)")
     ap.add_argument("--op", choices=["encode", "striped-decode"], default="encode",
                     help="encode = the BASELINE metric (default); striped-decode = BASELINE config 5: RS(20,8), 4 MiB objects "
                          "striped over the ranks, all-gather + per-rank byte-range reconstruct")
@@ -220,6 +223,14 @@ def main() -> None:
     def barrier():
         distrib.barrier(R)
 
+    # device pre-conditioning (disclosed in the JSON line): bring clocks / power management to
+    # the loaded steady state; see DESIGN.md "DVFS transient".  Not part of W or K.
+    if args.precondition_ms > 0:
+        tpre = time.perf_counter()
+        while (time.perf_counter() - tpre) * 1e3 < args.precondition_ms:
+            for _ in range(20):
+                encode_step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         encode_step()
     torch.cuda.synchronize()
@@ -283,6 +294,7 @@ def main() -> None:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "preconditioning_ms": args.precondition_ms,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
