@@ -273,14 +273,25 @@ __global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
 	uint64_t hb = (q == 0 ? 0x510e527fade682d1ULL : q == 1 ? 0x9b05688c2b3e6c1fULL
 		       : q == 2 ? 0x1f83d9abfb41bd6bULL : 0x5be0cd19137e2179ULL);
 	uint64_t done = 0;
-	// full blocks, all but the last: each lane stages its 32-byte quarter of the block
+	// full blocks, all but the last: each lane stages its 32-byte quarter of the block.
+	// Software-pipelined: the quarter of block i+1 is requested before block i is
+	// compressed, so the HBM latency of a lane's private stream hides under the ~750
+	// instructions of the compression instead of adding to every link of the chain.
+	u64x2 w0 = {0, 0}, w1 = {0, 0};
+	if (len > 128) {
+		const u64x2 *g = reinterpret_cast<const u64x2 *>(p + 32 * q);
+		w0 = __builtin_nontemporal_load(g);
+		w1 = __builtin_nontemporal_load(g + 1);
+	}
 	while (len - done > 128) {
-		const u64x2 *g = reinterpret_cast<const u64x2 *>(p + done + 32 * q);
-		const u64x2 w0 = __builtin_nontemporal_load(g);
-		const u64x2 w1 = __builtin_nontemporal_load(g + 1);
 		u64x2 *s = reinterpret_cast<u64x2 *>(slot + 32 * q);
 		s[0] = w0;
 		s[1] = w1;
+		if (len - done > 256) {  // block i+1 is also a full, non-final block: prefetch it
+			const u64x2 *g = reinterpret_cast<const u64x2 *>(p + done + 128 + 32 * q);
+			w0 = __builtin_nontemporal_load(g);
+			w1 = __builtin_nontemporal_load(g + 1);
+		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
