@@ -26,13 +26,14 @@ GEC_E_INVALID_INDEX = -10
 GEC_E_DEVICE = -100
 GEC_E_NOMEM = -101
 GEC_E_INVALID_ARG = -102
+GEC_MATRIX_VANDERMONDE, GEC_MATRIX_CAUCHY = 0, 1
 
 # every symbol include/garage_ec.h declares (tests/test_cabi_symbols.py checks
 # this list against the header and against the built library)
 SYMBOLS = [
     "gec_version", "gec_device_count", "gec_strerror", "gec_last_error",
-    "gec_shard_len", "gec_build_matrix", "gec_build_decode_matrix",
-    "gec_codec_create", "gec_codec_destroy", "gec_codec_k", "gec_codec_m",
+    "gec_shard_len", "gec_build_matrix", "gec_build_matrix_ex", "gec_build_decode_matrix",
+    "gec_codec_create", "gec_codec_create_ex", "gec_codec_destroy", "gec_codec_k", "gec_codec_m",
     "gec_codec_device", "gec_parity_matrix", "gec_codec_cache_stats",
     "gec_encode_batch", "gec_verify_batch", "gec_reconstruct_batch",
     "gec_encode_batch_dev", "gec_verify_batch_dev", "gec_reconstruct_batch_dev",
@@ -79,6 +80,8 @@ def _load() -> ctypes.CDLL:
     lib.gec_shard_len.restype = sz
     lib.gec_shard_len.argtypes = [ci, sz]
     lib.gec_build_matrix.argtypes = [ci, ci, u8p]
+    lib.gec_build_matrix_ex.argtypes = [ci, ci, ci, u8p]
+    lib.gec_codec_create_ex.argtypes = [ci, ci, ci, ci, pp]
     lib.gec_build_decode_matrix.argtypes = [ci, ci, u8p, ctypes.POINTER(ctypes.c_int32), u8p]
     lib.gec_codec_create.argtypes = [ci, ci, ci, pp]
     lib.gec_codec_destroy.argtypes = [vp]

@@ -21,9 +21,13 @@ def shard_len(k: int, block_len: int) -> int:
     return int(lib.gec_shard_len(k, block_len))
 
 
-def build_matrix(k: int, m: int) -> np.ndarray:
+MATRIX_KINDS = {"vandermonde": _lib.GEC_MATRIX_VANDERMONDE, "cauchy": _lib.GEC_MATRIX_CAUCHY}
+
+
+def build_matrix(k: int, m: int, matrix: str = "vandermonde") -> np.ndarray:
     out = np.zeros((max(k + m, 1), max(k, 1)), dtype=np.uint8)
-    check(lib.gec_build_matrix(k, m, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), "gec_build_matrix")
+    check(lib.gec_build_matrix_ex(k, m, MATRIX_KINDS[matrix], out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))),
+          "gec_build_matrix_ex")
     return out
 
 
@@ -52,9 +56,13 @@ def _stream_handle(device_index: int) -> int:
 class ReedSolomon:
     """`ReedSolomon::new(data_shards, parity_shards)` bound to one GPU."""
 
-    def __init__(self, data_shards: int, parity_shards: int, device: int = 0):
+    def __init__(self, data_shards: int, parity_shards: int, device: int = 0, matrix: str = "vandermonde"):
+        """matrix="vandermonde" is the crate-compatible default; "cauchy" is the extra family
+        of include/garage_ec.h (not interchangeable with the default)."""
         h = ctypes.c_void_p()
-        check(lib.gec_codec_create(data_shards, parity_shards, device, ctypes.byref(h)), "gec_codec_create")
+        check(lib.gec_codec_create_ex(data_shards, parity_shards, device, MATRIX_KINDS[matrix], ctypes.byref(h)),
+              "gec_codec_create_ex")
+        self.matrix = matrix
         self._h = h
         self.k = data_shards
         self.m = parity_shards

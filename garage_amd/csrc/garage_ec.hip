@@ -690,7 +690,20 @@ size_t gec_shard_len(int k, size_t block_len)
 	return (per + 63) / 64 * 64;
 }
 
-int gec_build_matrix(int k, int m, uint8_t *out)
+static int build_matrix_kind(int k, int m, int matrix, gec::Matrix &enc)
+{
+	if (matrix == GEC_MATRIX_VANDERMONDE) {
+		if (!gec::build_encoding_matrix(k, m, enc))
+			return fail(GEC_E_INVALID_ARG, "vandermonde top block singular");
+	} else if (matrix == GEC_MATRIX_CAUCHY) {
+		gec::build_cauchy_matrix(k, m, enc);
+	} else {
+		return fail(GEC_E_INVALID_ARG, "unknown matrix family");
+	}
+	return GEC_OK;
+}
+
+int gec_build_matrix_ex(int k, int m, int matrix, uint8_t *out)
 {
 	int rc = check_km(k, m);
 	if (rc)
@@ -698,11 +711,14 @@ int gec_build_matrix(int k, int m, uint8_t *out)
 	if (!out)
 		return fail(GEC_E_INVALID_ARG, "NULL output");
 	gec::Matrix enc;
-	if (!gec::build_encoding_matrix(k, m, enc))
-		return fail(GEC_E_INVALID_ARG, "vandermonde top block singular");
+	rc = build_matrix_kind(k, m, matrix, enc);
+	if (rc)
+		return rc;
 	std::memcpy(out, enc.v.data(), enc.v.size());
 	return GEC_OK;
 }
+
+int gec_build_matrix(int k, int m, uint8_t *out) { return gec_build_matrix_ex(k, m, GEC_MATRIX_VANDERMONDE, out); }
 
 int gec_build_decode_matrix(int k, int m, const uint8_t *present, int32_t *valid_out, uint8_t *out)
 {
@@ -731,12 +747,19 @@ int gec_build_decode_matrix(int k, int m, const uint8_t *present, int32_t *valid
 
 int gec_codec_create(int k, int m, int device, gec_codec **out)
 {
+	return gec_codec_create_ex(k, m, device, GEC_MATRIX_VANDERMONDE, out);
+}
+
+int gec_codec_create_ex(int k, int m, int device, int matrix, gec_codec **out)
+{
 	if (!out)
 		return fail(GEC_E_INVALID_ARG, "NULL out");
 	*out = nullptr;
 	int rc = check_km(k, m);
 	if (rc)
 		return rc;
+	if (matrix != GEC_MATRIX_VANDERMONDE && matrix != GEC_MATRIX_CAUCHY)
+		return fail(GEC_E_INVALID_ARG, "unknown matrix family");
 	int ndev = 0;
 	hipError_t e = hipGetDeviceCount(&ndev);
 	if (e != hipSuccess || ndev <= 0)
@@ -750,8 +773,9 @@ int gec_codec_create(int k, int m, int device, gec_codec **out)
 	c->k = k;
 	c->m = m;
 	c->device = device;
-	if (!gec::build_encoding_matrix(k, m, c->enc))
-		return fail(GEC_E_INVALID_ARG, "vandermonde top block singular");
+	rc = build_matrix_kind(k, m, matrix, c->enc);
+	if (rc)
+		return rc;
 	DeviceGuard g(device);
 	if (!g.ok)
 		return fail(GEC_E_DEVICE, "hipSetDevice failed");

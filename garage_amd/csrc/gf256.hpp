@@ -142,4 +142,19 @@ inline bool build_encoding_matrix(int k, int m, Matrix &out)
 	return true;
 }
 
+// Systematic Cauchy matrix: identity on top, parity row r / column c = 1 / ((k+r) ^ c).
+// x_r = k + r and y_c = c are disjoint sets of field elements, so every square
+// sub-matrix of the parity block is invertible and the code is MDS.
+inline bool build_cauchy_matrix(int k, int m, Matrix &out)
+{
+	const Field &f = field();
+	out = Matrix(k + m, k);
+	for (int r = 0; r < k; ++r)
+		out.at(r, r) = 1;
+	for (int r = 0; r < m; ++r)
+		for (int c = 0; c < k; ++c)
+			out.at(k + r, c) = f.inv(static_cast<uint8_t>((k + r) ^ c));  // (k+r)^c != 0 since c < k <= k+r
+	return true;
+}
+
 }  // namespace gec

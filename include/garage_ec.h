@@ -78,6 +78,16 @@ size_t gec_shard_len(int k, size_t block_len);
 /* (k+m) x k systematic encoding matrix, row-major.
  * == ReedSolomon::new(k,m) internal matrix [EXT core.rs build_matrix]. */
 int gec_build_matrix(int k, int m, uint8_t *out_n_by_k);
+
+/* Coding-matrix families.  VANDERMONDE is the reed-solomon-erasure / Backblaze
+ * systematic matrix and the only one that is bit-compatible with the crate (the
+ * default everywhere).  CAUCHY is the extra mode the project brief names:
+ * parity row r, column c = 1 / ((k + r) XOR c) over GF(2^8)/0x11D -- every square
+ * sub-matrix of a Cauchy matrix is invertible, so [I; C] is MDS by construction
+ * (the same formula as klauspost/reedsolomon's WithCauchyMatrix).  Shards encoded
+ * with one family cannot be decoded with the other. */
+enum { GEC_MATRIX_VANDERMONDE = 0, GEC_MATRIX_CAUCHY = 1 };
+int gec_build_matrix_ex(int k, int m, int matrix, uint8_t *out_n_by_k);
 /* present[k+m] (0/1).  valid_out[k] = first k present shard indices,
  * out_k_by_k = inverse of those rows [EXT core.rs get_data_decode_matrix]. */
 int gec_build_decode_matrix(int k, int m, const uint8_t *present,
@@ -89,6 +99,8 @@ int gec_build_decode_matrix(int k, int m, const uint8_t *present,
  * compression_level / data_fsync fields, built from new Config keys.
  * Argument errors are reported before the device is touched. */
 int gec_codec_create(int k, int m, int device, gec_codec **out);
+/* Same with an explicit matrix family (gec_codec_create == GEC_MATRIX_VANDERMONDE). */
+int gec_codec_create_ex(int k, int m, int device, int matrix, gec_codec **out);
 void gec_codec_destroy(gec_codec *c);
 int gec_codec_k(const gec_codec *c);
 int gec_codec_m(const gec_codec *c);

@@ -124,6 +124,21 @@ def build_matrix(k: int, m: int) -> np.ndarray:
     return np.frombuffer(_build_matrix_cached(k, m), dtype=np.uint8).reshape(k + m, k).copy()
 
 
+def build_matrix_cauchy(k: int, m: int) -> np.ndarray:
+    """The project's extra matrix family (NOT the crate's): identity on top, parity row
+    r / column c = 1 / ((k + r) ^ c).  Same formula as klauspost/reedsolomon's
+    WithCauchyMatrix [EXT, recalled].  Restated here only so the GPU path has an
+    independent check for this mode."""
+    if k <= 0 or m <= 0 or k + m > 256:
+        raise ValueError("bad (k, m)")
+    M = np.zeros((k + m, k), dtype=np.uint8)
+    M[:k] = np.eye(k, dtype=np.uint8)
+    for r in range(m):
+        for c in range(k):
+            M[k + r, c] = gf_div(1, (k + r) ^ c)
+    return M
+
+
 def parity_matrix(k: int, m: int) -> np.ndarray:
     return build_matrix(k, m)[k:]
 

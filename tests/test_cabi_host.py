@@ -100,3 +100,22 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "rs_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+# ------------------------------------------------- Cauchy family (extra mode)
+def test_cauchy_matrix_matches_restatement_and_is_mds():
+    import itertools
+
+    for k, m in [(3, 1), (10, 4), (20, 8), (5, 5), (200, 56)]:
+        M = g.build_matrix(k, m, "cauchy")
+        assert np.array_equal(M, O.build_matrix_cauchy(k, m))
+        assert np.array_equal(M[:k], np.eye(k, dtype=np.uint8))
+    # exhaustive MDS check on a small code: every k rows of the (k+m) x k matrix are independent
+    k, m = 4, 3
+    M = g.build_matrix(k, m, "cauchy")
+    for rows in itertools.combinations(range(k + m), k):
+        O.invert(M[list(rows)])            # raises if singular
+    # not interchangeable with the crate-compatible default
+    assert not np.array_equal(g.build_matrix(10, 4, "cauchy"), g.build_matrix(10, 4))
+    with pytest.raises(g.GecError):
+        _lib.check(_lib.lib.gec_build_matrix_ex(10, 4, 7, M.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), "kind")

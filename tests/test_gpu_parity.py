@@ -544,3 +544,27 @@ def test_random_codes_encode_verify_reconstruct(coracle, k, m, cols4, nb, seed, 
                 exp[:, j] = 0xC3
     assert np.array_equal(got, exp)
     rs.close()
+
+
+@pytest.mark.parametrize("k,m", [(10, 4), (20, 8), (3, 1)])
+def test_cauchy_family_round_trips(k, m):
+    """The extra Cauchy matrix family: parity == numpy restatement of the same definition,
+    verify, and encode -> erase m -> reconstruct; and it is NOT the crate's parity."""
+    rs = g.ReedSolomon(k, m, matrix="cauchy")
+    assert np.array_equal(rs.parity_matrix(), O.build_matrix_cauchy(k, m)[k:])
+    S, nb = 2112, 3
+    data = rand_blocks(7 * k + m, nb, k, S)
+    st = torch.zeros((nb, k + m, S), dtype=torch.uint8, device=DEV)
+    st[:, :k] = torch.from_numpy(data).to(DEV)
+    rs.encode_dev(st)
+    assert bool(rs.verify_dev(st).all())
+    full = st.cpu().numpy()
+    want = O._apply(O.build_matrix_cauchy(k, m)[k:], data[0])
+    assert np.array_equal(full[0, k:], want)
+    assert not bool(g.ReedSolomon(k, m).verify_dev(st).any()), "the crate-compatible codec must reject Cauchy parity"
+    rng = np.random.default_rng(k)
+    lost = rng.choice(k + m, size=m, replace=False)
+    st[:, torch.from_numpy(lost).to(DEV)] = 0
+    rs.reconstruct_dev(st, [j not in lost for j in range(k + m)])
+    torch.cuda.synchronize()
+    assert np.array_equal(st.cpu().numpy(), full)
