@@ -23,6 +23,9 @@
 //  * Accumulators stay in VGPRs in "row-interleaved" form (byte r of a dword =
 //    output row r); a v_perm_b32 4x4 byte transpose per 4 columns turns them
 //    into per-shard dwords just before the store.
+//  * One tile of the flattened (block, column) space per workgroup, handed out so
+//    that each XCD walks a contiguous range; the prologue (table expansion) runs
+//    under the latency of the tile's data loads, which are issued first.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -32,8 +35,8 @@ namespace gec {
 
 constexpr int KMAX = 256;    // input shards per launch (k + m <= 256 => k <= 255)
 constexpr int RMAX = 8;      // output rows per launch
-constexpr int BLOCK = 256;   // threads per workgroup (4 waves)
-constexpr int MODE_STORE = 0, MODE_COMPARE = 2;
+constexpr int BLOCK = 256;   // threads per workgroup of the baseline kernel
+constexpr int MODE_STORE = 0, MODE_COMPARE = 2;  // write the rows / compare them with what is stored
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
