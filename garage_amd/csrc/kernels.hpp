@@ -170,9 +170,9 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 	// are vmcnt(N), not vmcnt(0).
 	// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order, used
 	// for speed only -- any placement is correct), so give each XCD a CONTIGUOUS range of
-	// tiles instead of every 8th one.  There is no data reuse to keep in an L2 here; the
-	// gain (+5.5 %, 264 -> 250 us on RS(10,4) x1024, tools/kbench A/B) comes from each
-	// XCD's memory requests walking consecutive DRAM pages.  The host rounds the grid up
+	// tiles instead of every 8th one.  There is no data reuse to keep in an L2 here, but it
+	// measures +5.5 % (264 -> 250 us on RS(10,4) x1024, same-box A/B) -- specific to this
+	// kernel's 14 streams per workgroup: a plain copy does not benefit (tools/kbench).  The host rounds the grid up
 	// to a multiple of 8; surplus workgroups exit here, before any barrier.
 	const uint32_t chunk = gridDim.x >> 3;
 	const uint32_t tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);

@@ -64,6 +64,24 @@ __global__ void copy16x4(const gec::u32x4 *__restrict__ src, gec::u32x4 *__restr
 	}
 }
 
+// copy16x4 with the XCD-aware block order of the RS kernel (each XCD a contiguous range)
+__global__ void copy16x4_xcd(const gec::u32x4 *__restrict__ src, gec::u32x4 *__restrict__ dst, size_t n)
+{
+	const unsigned chunk = gridDim.x >> 3;
+	const unsigned bid = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	size_t base = (size_t)bid * blockDim.x * 4 + threadIdx.x;
+	if (base + 3 * (size_t)blockDim.x < n) {
+		gec::u32x4 v0 = __builtin_nontemporal_load(src + base);
+		gec::u32x4 v1 = __builtin_nontemporal_load(src + base + blockDim.x);
+		gec::u32x4 v2 = __builtin_nontemporal_load(src + base + 2 * blockDim.x);
+		gec::u32x4 v3 = __builtin_nontemporal_load(src + base + 3 * blockDim.x);
+		__builtin_nontemporal_store(v0, dst + base);
+		__builtin_nontemporal_store(v1, dst + base + blockDim.x);
+		__builtin_nontemporal_store(v2, dst + base + 2 * blockDim.x);
+		__builtin_nontemporal_store(v3, dst + base + 3 * blockDim.x);
+	}
+}
+
 // read-only stream (10 reads : 0 writes) -- upper bound for the read side
 __global__ void read16x4(const gec::u32x4 *__restrict__ src, gec::u32x4 *__restrict__ dst, size_t n)
 {
@@ -290,15 +308,19 @@ int main(int argc, char **argv)
 		std::sort(t.begin(), t.end());
 		printf("%-52s med %8.1f us  min %8.1f us  %7.1f GB/s (read %zu + write %zu bytes)\n", "copy16 nt grid-stride (known bytes)",
 		       t[t.size() / 2] * 1e3, t[0] * 1e3, 2.0 * nvec * 16 / (t[t.size() / 2] * 1e-3) / 1e9, nvec * 16, nvec * 16);
-		for (int which = 0; which < 2; ++which) {
+		for (int which = 0; which < 3; ++which) {
 			t.clear();
 			unsigned grid = (unsigned)((nvec + 1023) / 1024);
+			if (which == 2)
+				grid = (grid + 7) / 8 * 8;
 			for (int r = 0; r < rounds + 1; ++r) {
 				CK(hipEventRecord(e0, 0));
 				if (which == 0)
 					copy16x4<<<grid, 256>>>((const u32x4 *)d_st, (u32x4 *)(d_st + bytes / 2), nvec);
-				else
+				else if (which == 1)
 					read16x4<<<grid, 256>>>((const u32x4 *)d_st, (u32x4 *)(d_st + bytes / 2), nvec);
+				else
+					copy16x4_xcd<<<grid, 256>>>((const u32x4 *)d_st, (u32x4 *)(d_st + bytes / 2), nvec);
 				CK(hipEventRecord(e1, 0));
 				CK(hipEventSynchronize(e1));
 				float ms;
@@ -307,8 +329,8 @@ int main(int argc, char **argv)
 					t.push_back(ms);
 			}
 			std::sort(t.begin(), t.end());
-			double bytes_moved = which == 0 ? 2.0 * nvec * 16 : 1.0 * nvec * 16;
-			printf("%-52s med %8.1f us  min %8.1f us  %7.1f GB/s\n", which == 0 ? "copy16x4 nt one-tile/wg (HBM copy ceiling)" : "read16x4 nt one-tile/wg (HBM read ceiling)",
+			double bytes_moved = which == 1 ? 1.0 * nvec * 16 : 2.0 * nvec * 16;
+			printf("%-52s med %8.1f us  min %8.1f us  %7.1f GB/s\n", which == 0 ? "copy16x4 nt one-tile/wg (HBM copy ceiling)" : which == 1 ? "read16x4 nt one-tile/wg (HBM read ceiling)" : "copy16x4 nt, XCD-contiguous block order",
 			       t[t.size() / 2] * 1e3, t[0] * 1e3, bytes_moved / (t[t.size() / 2] * 1e-3) / 1e9);
 		}
 	}
