@@ -7,7 +7,7 @@ import ctypes
 import os
 from typing import Optional, Sequence
 
-from . import _lib  # loads libgarage_ec.so first (single HIP runtime, see _lib.py)
+from . import _lib  # noqa: F401  -- loads libgarage_ec.so first (single HIP runtime, see _lib.py)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgarage_block.so")

@@ -70,9 +70,12 @@ class ReedSolomon:
         self.device = device
 
     def close(self) -> None:
-        if getattr(self, "_h", None):
-            lib.gec_codec_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib.gec_codec_destroy(h)
+            except Exception:  # interpreter shutdown: the library may already be gone
+                pass
 
     __del__ = close
 

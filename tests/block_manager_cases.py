@@ -2,7 +2,6 @@
 (tests/test_block_manager.py) and with the real GPU codec
 (tests/test_gpu_block_manager.py).  Style follows the reference: deterministic
 byte patterns, put -> get -> assert_eq (src/api/s3/encryption.rs:555-596)."""
-import numpy as np
 import pytest
 
 from garage_amd.block_manager import (BlockManager, CorruptData, DataBlock, DataBlockHeader, DirShardStore,

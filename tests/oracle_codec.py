@@ -5,7 +5,6 @@ over `gloo`.  The product never imports this; it lives under tests/."""
 from __future__ import annotations
 
 import numpy as np
-import torch
 
 from oracle import rs_oracle as O
 

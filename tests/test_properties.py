@@ -2,7 +2,6 @@
 other and the product's host logic against both, over random codes, shard
 lengths and erasure patterns."""
 import numpy as np
-import pytest
 from hypothesis import HealthCheck, given, settings
 from hypothesis import strategies as st
 
