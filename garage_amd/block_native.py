@@ -21,6 +21,7 @@ SYMBOLS = [
     "gbm_block_incref", "gbm_block_decref", "gbm_resync_block", "gbm_resync_all", "gbm_resync_queue_len",
     "gbm_scrub", "gbm_node_set_down", "gbm_node_has_shard", "gbm_node_delete_shard",
     "gbm_node_corrupt_shard", "gbm_metrics", "gbm_gpu_hashed",
+    "gbm_batcher_create", "gbm_batcher_destroy", "gbm_batcher_put_block", "gbm_batcher_stats",
 ]
 
 
@@ -73,6 +74,11 @@ def _load():
     lib.gbm_node_delete_shard.argtypes = [vp, ci, ctypes.c_char_p, ci]
     lib.gbm_node_corrupt_shard.argtypes = [vp, ci, ctypes.c_char_p, ci, sz, ctypes.c_uint8, ci]
     lib.gbm_metrics.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.gbm_batcher_create.argtypes = [vp, sz, ctypes.c_uint, pp]
+    lib.gbm_batcher_destroy.argtypes = [vp]
+    lib.gbm_batcher_destroy.restype = None
+    lib.gbm_batcher_put_block.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, sz]
+    lib.gbm_batcher_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.gbm_gpu_hashed.argtypes = [vp]
     lib.gbm_gpu_hashed.restype = ctypes.c_uint64
     return lib
@@ -204,3 +210,29 @@ class NativeBlockManager:
         out = (ctypes.c_uint64 * 6)()
         _check(lib.gbm_metrics(self._h, out), "gbm_metrics")
         return dict(zip(self.METRICS, [int(x) for x in out]))
+
+
+class Batcher:
+    """gbm_batcher: thread-safe put_block() calls coalesced into device batches."""
+
+    def __init__(self, manager: NativeBlockManager, max_blocks: int = 64, max_wait_us: int = 200):
+        self.manager = manager  # keep alive
+        h = ctypes.c_void_p()
+        _check(lib.gbm_batcher_create(manager._h, max_blocks, max_wait_us, ctypes.byref(h)), "gbm_batcher_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.gbm_batcher_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def put_block(self, hash_: bytes, data: bytes) -> None:
+        """Blocks until the batch containing this block is stored (ctypes drops the GIL)."""
+        _check(lib.gbm_batcher_put_block(self._h, hash_, data, len(data)), "batcher.put_block")
+
+    def stats(self) -> dict:
+        out = (ctypes.c_uint64 * 3)()
+        _check(lib.gbm_batcher_stats(self._h, out), "gbm_batcher_stats")
+        return {"batches": int(out[0]), "blocks": int(out[1]), "max_batch": int(out[2])}

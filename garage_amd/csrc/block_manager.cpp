@@ -12,6 +12,11 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <thread>
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
@@ -235,21 +240,28 @@ struct Node {
 };
 
 struct MemoryNode : Node {
+	std::mutex mu;  // puts (batcher thread) and gets (caller threads) may overlap
 	std::map<std::pair<Hash, int>, std::vector<uint8_t>> files;
 	bool put(const Hash &h, int idx, std::vector<uint8_t> &&raw) override
 	{
+		std::lock_guard<std::mutex> g(mu);
 		files[{h, idx}] = std::move(raw);
 		return true;
 	}
 	bool get(const Hash &h, int idx, std::vector<uint8_t> &raw) override
 	{
+		std::lock_guard<std::mutex> g(mu);
 		auto it = files.find({h, idx});
 		if (it == files.end())
 			return false;
 		raw = it->second;
 		return true;
 	}
-	void del(const Hash &h, int idx) override { files.erase({h, idx}); }
+	void del(const Hash &h, int idx) override
+	{
+		std::lock_guard<std::mutex> g(mu);
+		files.erase({h, idx});
+	}
 };
 
 // <root>/<h0>/<h1>/<hex>.s<idx>, tmp file + rename (write_block_inner, manager.rs:720-805);
@@ -594,13 +606,17 @@ int gbm_storage_nodes_of(const gbm_manager *m, const uint8_t hash[32], int *node
 	return GBM_OK;
 }
 
-int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data,
-		       const size_t *len)
+// rcs (optional): per-block result, GBM_OK or GBM_E_QUORUM; the return value is the last
+// failure (or a whole-batch error such as GBM_E_EC).
+static int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data,
+			   const size_t *len, int *rcs)
 {
 	if (!mg || (nb && (!hashes || !data || !len)))
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
 	if (nb == 0)
 		return GBM_OK;
+	if (rcs)
+		std::fill(rcs, rcs + nb, GBM_OK);
 	const int k = mg->k, m = mg->m, n = mg->n;
 	// DataBlock::from_buffer: zstd when a level is configured, Plain on any encoder error
 	std::vector<std::vector<uint8_t>> zbuf(nb);
@@ -680,12 +696,20 @@ int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const 
 				result = fail(GBM_E_QUORUM, "Could not reach quorum of " + std::to_string(mg->write_quorum) + ". " +
 								    std::to_string(ok) + " of " + std::to_string(n) +
 								    " request succeeded");
+				if (rcs)
+					rcs[b] = GBM_E_QUORUM;
 			} else if (ok < n) {
 				mg->enqueue(h);  // stragglers are finished by resync
 			}
 		}
 	}
 	return result;
+}
+
+int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data,
+		       const size_t *len)
+{
+	return put_blocks_impl(mg, nb, hashes, data, len, nullptr);
 }
 
 int gbm_rpc_put_block(gbm_manager *m, const uint8_t hash[32], const uint8_t *data, size_t len)
@@ -1029,6 +1053,136 @@ int gbm_set_compression_level(gbm_manager *m, int enabled, int level)
 		return fail(GBM_E_IO, "libzstd.so.1 not available");
 	m->compress = enabled != 0;
 	m->compression_level = level;
+	return GBM_OK;
+}
+
+// ------------------------------------------------------------------ batcher
+// The coalescing queue in front of the FFI.  Garage keeps <= 3 block puts in flight
+// per PutObject (PUT_BLOCKS_MAX_PARALLEL, src/api/s3/put.rs:42,486-511) and serves
+// many requests at once; each caller blocks in gbm_batcher_put_block (the way
+// `rpc_put_block(...).await` suspends) while ONE worker thread turns whatever has
+// queued up within max_wait_us (or max_blocks) into a single device batch.
+struct gbm_batcher {
+	struct Item {
+		const uint8_t *hash, *data;
+		size_t len;
+		int rc = GBM_OK;
+		bool done = false;
+	};
+	gbm_manager *mg = nullptr;
+	size_t max_blocks = 64;
+	unsigned max_wait_us = 200;
+	std::mutex mu;
+	std::condition_variable cv_work, cv_done;
+	std::deque<Item *> queue;
+	bool stop = false;
+	uint64_t batches = 0, blocks = 0, max_batch = 0;
+	std::thread worker;
+
+	void run()
+	{
+		std::unique_lock<std::mutex> lk(mu);
+		for (;;) {
+			cv_work.wait(lk, [&] { return stop || !queue.empty(); });
+			if (queue.empty()) {
+				if (stop)
+					return;
+				continue;
+			}
+			// linger a little so concurrent callers land in the same batch
+			// system_clock: libstdc++ maps it to pthread_cond_timedwait, which ThreadSanitizer
+			// understands (steady_clock -> pthread_cond_clockwait is not intercepted by gcc 11's
+			// TSan and floods the report with false "double lock" findings)
+			const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(max_wait_us);
+			while (!stop && queue.size() < max_blocks &&
+			       cv_work.wait_until(lk, deadline) != std::cv_status::timeout) {
+			}
+			std::vector<Item *> batch;
+			while (!queue.empty() && batch.size() < max_blocks) {
+				batch.push_back(queue.front());
+				queue.pop_front();
+			}
+			lk.unlock();
+			const size_t nb = batch.size();
+			std::vector<uint8_t> hashes(nb * 32);
+			std::vector<const uint8_t *> data(nb);
+			std::vector<size_t> lens(nb);
+			std::vector<int> rcs(nb, GBM_OK);
+			for (size_t i = 0; i < nb; ++i) {
+				std::memcpy(hashes.data() + 32 * i, batch[i]->hash, 32);
+				data[i] = batch[i]->data;
+				lens[i] = batch[i]->len;
+			}
+			int rc = put_blocks_impl(mg, nb, hashes.data(), data.data(), lens.data(), rcs.data());
+			lk.lock();
+			for (size_t i = 0; i < nb; ++i) {
+				// a whole-batch failure (device error) hits every block of the batch
+				batch[i]->rc = (rc != GBM_OK && rc != GBM_E_QUORUM) ? rc : rcs[i];
+				batch[i]->done = true;
+			}
+			++batches;
+			blocks += nb;
+			max_batch = std::max<uint64_t>(max_batch, nb);
+			cv_done.notify_all();
+		}
+	}
+};
+
+int gbm_batcher_create(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, gbm_batcher **out)
+{
+	if (!m || !out || max_blocks == 0)
+		return fail(GBM_E_INVALID_ARG, "bad batcher arguments");
+	auto *b = new gbm_batcher();
+	b->mg = m;
+	b->max_blocks = max_blocks;
+	b->max_wait_us = max_wait_us;
+	b->worker = std::thread([b] { b->run(); });
+	*out = b;
+	return GBM_OK;
+}
+
+void gbm_batcher_destroy(gbm_batcher *b)
+{
+	if (!b)
+		return;
+	{
+		std::lock_guard<std::mutex> g(b->mu);
+		b->stop = true;
+	}
+	b->cv_work.notify_all();
+	b->worker.join();
+	delete b;
+}
+
+int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t *data, size_t len)
+{
+	if (!b || !hash || (!data && len))
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	gbm_batcher::Item it;
+	it.hash = hash;
+	it.data = data;
+	it.len = len;
+	std::unique_lock<std::mutex> lk(b->mu);
+	if (b->stop)
+		return fail(GBM_E_INVALID_ARG, "batcher is shutting down");
+	b->queue.push_back(&it);
+	b->cv_work.notify_one();
+	b->cv_done.wait(lk, [&] { return it.done; });
+	if (it.rc == GBM_E_QUORUM)
+		return fail(it.rc, "Could not reach quorum");
+	if (it.rc != GBM_OK)
+		return fail(it.rc, "device batch failed");
+	return GBM_OK;
+}
+
+int gbm_batcher_stats(gbm_batcher *b, uint64_t out[3])
+{
+	if (!b || !out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	std::lock_guard<std::mutex> g(b->mu);
+	out[0] = b->batches;
+	out[1] = b->blocks;
+	out[2] = b->max_batch;
 	return GBM_OK;
 }
 

@@ -81,6 +81,20 @@ int gbm_rpc_get_block(gbm_manager *m, const uint8_t hash[32], uint8_t *out, size
 int gbm_rpc_get_blocks(gbm_manager *m, size_t n, const uint8_t *hashes, uint8_t *const *out,
 		       const size_t *cap, size_t *len_out, int *rc);
 
+/* Coalescing queue in front of the device: Garage keeps <= 3 block puts in flight
+ * per PutObject (PUT_BLOCKS_MAX_PARALLEL, src/api/s3/put.rs:42,486-511) across many
+ * concurrent requests.  gbm_batcher_put_block is thread-safe and blocks its caller
+ * (like `rpc_put_block(..).await`) until the batch that contains the block has been
+ * encoded and fanned out; one worker thread turns everything queued within
+ * max_wait_us (or max_blocks) into ONE device call.  Returns that block's own
+ * result (GBM_OK / GBM_E_QUORUM / a device error). */
+typedef struct gbm_batcher gbm_batcher;
+int gbm_batcher_create(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, gbm_batcher **out);
+void gbm_batcher_destroy(gbm_batcher *b);
+int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t *data, size_t len);
+/* out = { device batches issued, blocks put, largest batch } */
+int gbm_batcher_stats(gbm_batcher *b, uint64_t out[3]);
+
 int gbm_block_incref(gbm_manager *m, const uint8_t hash[32]);
 int gbm_block_decref(gbm_manager *m, const uint8_t hash[32]);
 

@@ -197,3 +197,40 @@ def test_compressed_blocks_native_and_python(tmp_path):
     hr = bn.blake2sum(rnd)
     native.rpc_put_block(hr, rnd)
     assert pym.rpc_get_block(hr) == rnd
+
+
+@pytest.mark.gpu
+def test_batcher_coalesces_concurrent_puts():
+    """16 caller threads (think: 16 PutObject requests) each put 6 blocks through the
+    batcher; every call blocks until ITS block is stored; the worker coalesces them into
+    far fewer device batches; everything reads back; a quorum failure reaches its caller."""
+    import threading
+
+    codec = g.ReedSolomon(10, 4)
+    mgr = bn.NativeBlockManager(codec, 16)
+    bt = bn.Batcher(mgr, max_blocks=32, max_wait_us=2000)
+    T, PER = 16, 6
+    blocks = [[pattern_block(262144 + 4096 * (t * PER + j), t * 100 + j) for j in range(PER)] for t in range(T)]
+    hashes = [[bn.blake2sum(b) for b in row] for row in blocks]
+    errors = []
+
+    def worker(t):
+        try:
+            for j in range(PER):
+                bt.put_block(hashes[t][j], blocks[t][j])
+                assert mgr.rpc_get_block(hashes[t][j]) == blocks[t][j]   # visible as soon as put returns
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errors, errors
+    st = bt.stats()
+    assert st["blocks"] == T * PER and st["batches"] < T * PER // 2 and 2 <= st["max_batch"] <= 32, st
+    who = mgr.storage_nodes_of(hashes[0][0])
+    for j in range(3):
+        mgr.node_set_down(who[j], True)
+    with pytest.raises(bn.Quorum):
+        bt.put_block(hashes[0][0], blocks[0][0])
+    bt.close()

@@ -31,3 +31,13 @@ def test_block_manager_host_logic_under_asan_ubsan(tmp_path):
     r = subprocess.run([os.path.join(CDIR, "block_manager_host_test"), str(tmp_path)], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "all scenarios OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_block_manager_batcher_under_tsan(tmp_path):
+    """ThreadSanitizer build: 8 producer threads through the coalescing batcher plus 2
+    concurrent readers."""
+    _make("block_manager_host_test_tsan")
+    r = subprocess.run([os.path.join(CDIR, "block_manager_host_test_tsan")], capture_output=True, text=True, timeout=900)
+    if "FATAL: ThreadSanitizer: unexpected memory mapping" in r.stderr:
+        pytest.skip("TSan cannot run in this container (ASLR/memory layout)")
+    assert r.returncode == 0 and "all scenarios OK" in r.stdout, r.stdout + r.stderr

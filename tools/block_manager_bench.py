@@ -46,6 +46,27 @@ def main():
     got = mgr.rpc_get_blocks(hashes, L)
     t_get_deg = time.perf_counter() - t0
     assert got == blocks
+    # concurrent callers through the coalescing batcher (16 threads, one block per call)
+    import threading
+
+    for node in range(4):
+        mgr.node_set_down(node, False)
+    bt = bn.Batcher(mgr, max_blocks=64, max_wait_us=300)
+    T = 16
+    per = max(1, nb // T)
+
+    def worker(t):
+        for j in range(per):
+            i = t * per + j
+            bt.put_block(hashes[i], blocks[i])
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    t0 = time.perf_counter()
+    [x.start() for x in th]
+    [x.join() for x in th]
+    t_bat = time.perf_counter() - t0
+    bstats = bt.stats()
+    bt.close()
     gib = nb * L / 2**30
     print(json.dumps({
         "what": "libgarage_block (C++ BlockManager mirror), RS(10,4), 1 MiB blocks, 16 in-memory nodes, single host thread",
@@ -54,6 +75,8 @@ def main():
         "rpc_put_blocks_GiBps": round(gib / t_put, 3),
         "rpc_get_blocks_GiBps": round(gib / t_get, 3),
         "rpc_get_blocks_4_nodes_down_GiBps": round(gib / t_get_deg, 3),
+        "batcher_16_threads_put_GiBps": round(T * per * L / 2**30 / t_bat, 3),
+        "batcher_stats": bstats,
         "ec_reconstructs": mgr.metrics["ec_reconstructs"],
         "messages_hashed_on_gpu": mgr.gpu_hashed(),
     }))
