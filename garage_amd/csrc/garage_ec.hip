@@ -411,8 +411,13 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 		a.in_off[t] = (uint32_t)(in_base_off[t] / 16);
 	}
 	const int variant = g_variant.load(std::memory_order_relaxed);
-	for (int r0 = 0; r0 < nout; r0 += gec::RMAX) {
-		const int rows = std::min(gec::RMAX, nout - r0);
+	int rows = 0;
+	for (int r0 = 0; r0 < nout; r0 += rows) {
+		rows = std::min(gec::RMAX, nout - r0);
+		// 8-byte table entries need k*256 bytes of LDS; beyond the 64 KiB a workgroup gets
+		// without opting in (k > ~245) fall back to groups of 4 rows (4-byte entries)
+		if (rows > 4 && (size_t)k * 256 + 768 + (size_t)k * gec::RMAX > 65536)
+			rows = 4;
 		a.rows = (uint32_t)rows;
 		for (int r = 0; r < gec::RMAX; ++r) {
 			if (r < rows)

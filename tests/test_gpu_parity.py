@@ -82,6 +82,8 @@ ENCODE_CASES = [
     (40, 12, 2048, 2),     # k beyond one load batch, rows > 8 (two launches)
     (100, 20, 256, 1),
     (200, 56, 64, 1),      # k + m = 256
+    (250, 6, 128, 1),      # 8-byte tables would need > 64 KiB of LDS: falls back to 4-row groups
+    (255, 1, 64, 2),       # largest k
 ]
 
 
