@@ -284,7 +284,8 @@ struct DirNode : Node {
 	bool put(const Hash &h, int idx, std::vector<uint8_t> &&raw) override
 	{
 		mkdirs(dir(h));
-		std::string p = path(h, idx), tmp = p + ".tmp" + std::to_string(::getpid());
+		static std::atomic<uint64_t> seq{0};  // unique per writer: two threads may store the same shard
+		std::string p = path(h, idx), tmp = p + ".tmp" + std::to_string(::getpid()) + "_" + std::to_string(seq++);
 		FILE *f = std::fopen(tmp.c_str(), "wb");
 		if (!f)
 			return false;

@@ -101,6 +101,8 @@ int gec_build_decode_matrix(int k, int m, const uint8_t *present,
 int gec_codec_create(int k, int m, int device, gec_codec **out);
 /* Same with an explicit matrix family (gec_codec_create == GEC_MATRIX_VANDERMONDE). */
 int gec_codec_create_ex(int k, int m, int device, int matrix, gec_codec **out);
+/* Must not run concurrently with any other call on the same codec, and only after
+ * work enqueued by *_dev calls on caller streams has completed. */
 void gec_codec_destroy(gec_codec *c);
 int gec_codec_k(const gec_codec *c);
 int gec_codec_m(const gec_codec *c);
