@@ -282,6 +282,8 @@ def main() -> None:
             "unit": "GiB/s",
             "ms_per_step": round(dt / dsteps * 1e3, 4),
             "cold_first_call_ms": round(cold_ms, 3),
+            # same algorithmic bytes as encode: read k surviving shards, write the 4 lost ones
+            "roofline_frac": round((K + len(lost)) * S * blocks_all / world / (dt / dsteps) / 1e9 / HBM_PEAK_GBS, 4),
         }
 
     if rank == 0:
