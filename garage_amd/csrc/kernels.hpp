@@ -101,6 +101,17 @@ __device__ __forceinline__ uint32_t add_byte(uint32_t sbase, uint32_t packed)
 	return r;
 }
 
+// a ^ b ^ c in ONE VALU op: gfx950's three-input boolean (truth table 0x96 = odd parity).
+// hipcc lowers a plain `a ^ b ^ c` to two v_xor_b32.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+#ifdef GEC_NO_XOR3  // A/B switch for tools/kbench
+	return a ^ b ^ c;
+#else
+	return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#endif
+}
+
 // acc ^= T_lo[lo nibble of byte P] ^ T_hi[hi nibble of byte P]
 template <int MW, int P>
 __device__ __forceinline__ void lut_acc(uint32_t tb, uint32_t lo, uint32_t hi, uint32_t (&acc)[MW])
@@ -108,12 +119,12 @@ __device__ __forceinline__ void lut_acc(uint32_t tb, uint32_t lo, uint32_t hi, u
 	const uint32_t al = add_byte<P>(tb, lo);
 	const uint32_t ah = add_byte<P>(tb, hi);
 	if (MW == 1) {
-		acc[0] ^= *reinterpret_cast<lds_u32_t *>(al) ^ *reinterpret_cast<lds_u32_t *>(ah + 64);
+		acc[0] = xor3(acc[0], *reinterpret_cast<lds_u32_t *>(al), *reinterpret_cast<lds_u32_t *>(ah + 64));
 	} else {
 		const u32x2 vl = *reinterpret_cast<lds_u32x2_t *>(al);
 		const u32x2 vh = *reinterpret_cast<lds_u32x2_t *>(ah + 128);
-		acc[0] ^= vl.x ^ vh.x;
-		acc[MW - 1] ^= vl.y ^ vh.y;
+		acc[0] = xor3(acc[0], vl.x, vh.x);
+		acc[MW - 1] = xor3(acc[MW - 1], vl.y, vh.y);
 	}
 }
 
