@@ -205,7 +205,14 @@ int main(int argc, char **argv)
 	CK(hipEventCreate(&e1));
 	std::vector<std::vector<float>> times(vs.size());
 	std::vector<long long> diffs(vs.size(), -1);
-	const size_t lds = (size_t)k * 32 * 4 * MW + 768 + (size_t)k * RMAX;
+	// KBENCH_WG_PER_CU=n pads the dynamic LDS request so that at most n workgroups fit a CU's
+	// 160 KiB: an occupancy knob that does not touch the code under test
+	size_t lds = (size_t)k * 32 * 4 * MW + 768 + (size_t)k * RMAX;
+	if (getenv("KBENCH_WG_PER_CU")) {
+		const size_t cap = (160u << 10) / std::max(1, atoi(getenv("KBENCH_WG_PER_CU")));
+		lds = std::max(lds, std::min<size_t>(cap - 512, 64u << 10));
+		printf("# LDS request padded to %zu B per workgroup (<= %s workgroups per CU)\n", lds, getenv("KBENCH_WG_PER_CU"));
+	}
 	const double algo = (double)(k + a.rows) * S * nb;
 
 	auto launch = [&](const Variant &v) {
