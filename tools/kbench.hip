@@ -97,6 +97,41 @@ __global__ void read16x4(const gec::u32x4 *__restrict__ src, gec::u32x4 *__restr
 	}
 }
 
+// The RS kernel's ACCESS PATTERN with the arithmetic removed: same flattened XCD-ordered tiles,
+// K nt loads per lane (one per input shard), R nt stores (one per output shard), outputs = XOR of
+// the inputs rotated per row.  No LDS, no prologue: what HBM gives this 10-read : 4-write
+// pattern -- the ceiling the real kernel is measured against.
+template <int K, int R, int TPB>
+__global__ __launch_bounds__(TPB) void stream_pattern(const gec::ApplyArgs a)
+{
+	const uint32_t chunk = gridDim.x >> 3;
+	const uint32_t tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	if ((uint64_t)tile_id * TPB >= a.total_cols)
+		return;
+	uint32_t gcol = tile_id * TPB + threadIdx.x;
+	const bool live = gcol < a.total_cols;
+	if (!live)
+		gcol = tile_id * TPB;
+	const uint32_t bb = gcol / a.cols, col = gcol - bb * a.cols;
+	const gec::u32x4 *src = reinterpret_cast<const gec::u32x4 *>(a.in + (uint64_t)bb * a.in_stride) + col;
+	gec::u32x4 *dst = reinterpret_cast<gec::u32x4 *>(a.out + (uint64_t)bb * a.out_stride) + col;
+	gec::u32x4 d[K];
+#pragma unroll
+	for (int j = 0; j < K; ++j)
+		d[j] = __builtin_nontemporal_load(src + a.in_off[j]);
+	gec::u32x4 x = d[0];
+#pragma unroll
+	for (int j = 1; j < K; ++j)
+		x ^= d[j];
+	if (!live)
+		return;
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		gec::u32x4 v = {x.x + r, x.y, x.z, x.w};
+		__builtin_nontemporal_store(v, dst + a.out_off[r]);
+	}
+}
+
 __global__ void diff_count(const uint32_t *a, const uint32_t *b, size_t n, unsigned long long *out)
 {
 	size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -282,6 +317,33 @@ int main(int argc, char **argv)
 		float ms;
 		CK(hipEventElapsedTime(&ms, e0, e1));
 		printf("%-52s sustained %8.1f us  %7.1f GB/s\n", "copy16x4 nt (HBM copy ceiling)", ms / sustained * 1e3, 2.0 * nvec * 16 / (ms / sustained * 1e-3) / 1e9);
+		// the RS kernel's own access pattern without the arithmetic (k, m of the headline shapes only).
+		// NOTE: overwrites the parity area with junk; runs last.
+		if ((k == 10 && m == 4) || (k == 20 && m == 8)) {
+			ApplyArgs aa = a;
+			aa.total_cols = aa.nblocks * a.cols;
+			auto run = [&](int tpb, auto kern, const char *tag) {
+				unsigned g = (unsigned)(((aa.total_cols + tpb - 1) / tpb + 7) / 8 * 8);
+				for (int q = 0; q < sustained; ++q)
+					hipLaunchKernelGGL(kern, dim3(g), dim3(tpb), 0, 0, aa);
+				CK(hipEventRecord(e0, 0));
+				for (int q = 0; q < sustained; ++q)
+					hipLaunchKernelGGL(kern, dim3(g), dim3(tpb), 0, 0, aa);
+				CK(hipEventRecord(e1, 0));
+				CK(hipEventSynchronize(e1));
+				CK(hipEventElapsedTime(&ms, e0, e1));
+				printf("%-52s sustained %8.1f us  %7.1f GB/s  %5.1f%% of 8TB/s\n", tag, ms / sustained * 1e3, algo / (ms / sustained * 1e-3) / 1e9,
+				       algo / (ms / sustained * 1e-3) / 8e12 * 100);
+			};
+			if (k == 10) {
+				run(256, stream_pattern<10, 4, 256>, "access pattern only 10r:4w t256 (pattern ceiling)");
+				run(512, stream_pattern<10, 4, 512>, "access pattern only 10r:4w t512");
+				run(128, stream_pattern<10, 4, 128>, "access pattern only 10r:4w t128");
+			} else {
+				run(512, stream_pattern<20, 8, 512>, "access pattern only 20r:8w t512 (pattern ceiling)");
+				run(256, stream_pattern<20, 8, 256>, "access pattern only 20r:8w t256");
+			}
+		}
 		return 0;
 	}
 	for (int r = 0; r < rounds; ++r)
