@@ -35,7 +35,7 @@ ds = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_T
 enc = [x for _, x in ds[100:1100]]
 with open(os.path.join(P, f"{tag}_bench_default_kernel_stats.txt"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py     (defaults: --steps 1000 --warmup 100)\n")
-    f.write(f"# {tag} FINAL kernel (flattened, XCD-aware tiles), MI355X.  gf_apply_nibble<1,0,10,1,true,256> = 100 warm-up + 1000 timed encode + 501 reconstruct launches\n")
+    f.write(f"# {tag} FINAL kernel (flattened, XCD-aware tiles, bitop3 XOR), MI355X.  gf_apply_nibble<1,0,10,1,true,256> = 100 warm-up + 1000 timed encode + 501 reconstruct launches\n")
     f.write(f"# bench.py printed in this profiled run: value {d['value']} GiB/s, ms_per_step {d['ms_per_step']}, roofline.kernel_ms {d['roofline']['kernel_ms']} (HIP events over the 1000 timed steps), frac {d['roofline']['frac']}\n")
     f.write(f"# rocprofv3, the 1000 timed encode launches alone: avg {sum(enc)/len(enc)/1e3:.1f} us, min {min(enc)/1e3:.1f}, max {max(enc)/1e3:.1f}  -> agrees with kernel_ms\n")
     f.write(f"# un-profiled run right after, same box: value {d2['value']} GiB/s, frac {d2['roofline']['frac']}, decode {d2['decode']['value']} GiB/s, cpu_baseline {d2['cpu_baseline']['value']} GiB/s on {d2['cpu_baseline']['cores']} threads\n")
