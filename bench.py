@@ -114,7 +114,7 @@ def striped_decode_bench(args, R, distrib) -> None:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's banner off stdout
+        distrib.quiet_rccl()  # keep RCCL's banner and warnings off stdout
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=R.device)
     k, m, L, nobj = 20, 8, 4 << 20, 256
     S = g.shard_len(k, L)
@@ -127,14 +127,23 @@ def striped_decode_bench(args, R, distrib) -> None:
     local = torch.randint(0, 256, (nobj, layout.slots, S), dtype=torch.uint8, device=R.device, generator=gen)
     lost = (0, 1, 5, 9, 13, 19, 21, 27)
     present = [j not in lost for j in range(k + m)]
+    if args.collective == "cabi":  # RCCL driven by libgarage_ec itself (gec_group_*), torch only carries the unique id
+        grp = g.Group.from_torch_distributed(rs)
+        out = torch.empty((R.world, nobj, layout.slots, S), dtype=torch.uint8, device=R.device)
+
+        def step():
+            grp.allgather_decode(local, present, out=out)
+    else:
+        def step():
+            striped_reconstruct(rs, local, present, layout)
     for _ in range(max(1, args.warmup // 10)):
-        striped_reconstruct(rs, local, present, layout)
+        step()
     torch.cuda.synchronize()
     distrib.barrier(R)
     steps = max(3, args.steps // 20)
     t0 = time.perf_counter()
     for _ in range(steps):
-        striped_reconstruct(rs, local, present, layout)
+        step()
     torch.cuda.synchronize()
     distrib.barrier(R)
     dt = distrib.max_over_ranks(R, time.perf_counter() - t0)
@@ -146,7 +155,9 @@ def striped_decode_bench(args, R, distrib) -> None:
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "BASELINE config 5: RS(20,8), 256 x 4 MiB objects striped over the ranks, 8 erasures",
                        "k": k, "m": m, "shard_len": S, "slots_per_rank": layout.slots,
-                       "allgather_bytes_per_rank": nobj * layout.slots * S, "parallelism": f"stripe x{R.world}"},
+                       "allgather_bytes_per_rank": nobj * layout.slots * S, "parallelism": f"stripe x{R.world}",
+                       "collective": "gec_group_allgather_decode (C ABI, RCCL)" if args.collective == "cabi"
+                                     else "torch.distributed all_gather_into_tensor (RCCL) + gec_reconstruct_scattered_dev"},
         }), flush=True)
     if not R.distributed:
         import torch.distributed as dist
@@ -169,6 +180,8 @@ def main() -> None:
     ap.add_argument("--op", choices=["encode", "striped-decode"], default="encode",
                     help="encode = the BASELINE metric (default); striped-decode = BASELINE config 5: RS(20,8), 4 MiB objects "
                          "striped over the ranks, all-gather + per-rank byte-range reconstruct")
+    ap.add_argument("--collective", choices=["torch", "cabi"], default="torch",
+                    help="striped-decode only: who drives RCCL -- torch.distributed (default) or libgarage_ec's gec_group_* C ABI")
     args = ap.parse_args()
 
     import numpy as np

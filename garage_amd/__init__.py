@@ -4,3 +4,4 @@ object-block write/read path.  The product is
 the thin Python host layer used by tests and bench.py."""
 from ._lib import GecError, LIB_PATH  # noqa: F401
 from .codec import ReedSolomon, build_decode_matrix, build_matrix, set_kernel_variant, shard_len  # noqa: F401
+from .group import Group  # noqa: F401

@@ -39,7 +39,12 @@ SYMBOLS = [
     "gec_encode_batch_dev", "gec_verify_batch_dev", "gec_reconstruct_batch_dev",
     "gec_reconstruct_range_dev", "gec_reconstruct_scattered_dev", "gec_blake2sum_batch_dev", "gec_blake2sum_batch",
     "gec_encode_hash_batch", "gec_set_kernel_variant", "gec_get_kernel_variant",
+    "gec_group_unique_id", "gec_group_create", "gec_group_create_with_transport", "gec_group_destroy",
+    "gec_group_rank", "gec_group_size", "gec_group_slots", "gec_group_allgather_decode",
 ]
+GEC_GROUP_ID_BYTES = 128
+# int (*gec_allgather_fn)(void *ctx, const void *d_send, void *d_recv, size_t bytes, void *hip_stream)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
 
 class GecError(RuntimeError):
@@ -66,6 +71,12 @@ def _load() -> ctypes.CDLL:
     # torch simply gets /opt/rocm's runtime.)
     try:
         import torch  # noqa: F401
+
+        # same reasoning for RCCL (gec_group_*, resolved with dlopen on first use): inside a
+        # torch process it must be the RCCL that is linked against torch's HIP runtime
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(bundled):
+            os.environ.setdefault("GEC_RCCL_LIB", bundled)
     except ImportError:  # pragma: no cover - torch is plumbing, not required to load
         pass
     lib = ctypes.CDLL(LIB_PATH)
@@ -102,6 +113,16 @@ def _load() -> ctypes.CDLL:
     lib.gec_blake2sum_batch.argtypes = [vp, sz, pp, ctypes.POINTER(sz), u8p]
     lib.gec_encode_hash_batch.argtypes = [vp, sz, pp, ctypes.POINTER(sz), sz, pp, u8p]
     lib.gec_set_kernel_variant.argtypes = [ci]
+    lib.gec_group_unique_id.argtypes = [u8p]
+    lib.gec_group_create.argtypes = [vp, ci, ci, u8p, pp]
+    lib.gec_group_create_with_transport.argtypes = [vp, ci, ci, vp, vp, pp]
+    lib.gec_group_destroy.argtypes = [vp]
+    lib.gec_group_destroy.restype = None
+    lib.gec_group_rank.argtypes = [vp]
+    lib.gec_group_size.argtypes = [vp]
+    lib.gec_group_slots.argtypes = [vp]
+    lib.gec_group_slots.restype = sz
+    lib.gec_group_allgather_decode.argtypes = [vp, sz, vp, sz, u8p, ci, ci, vp, vp]
     return lib
 
 

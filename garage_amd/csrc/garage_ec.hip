@@ -8,6 +8,9 @@
 #include "../../include/garage_ec.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: RCCL itself is resolved with dlopen (gec_group_*)
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -249,7 +252,72 @@ struct gec_codec {
 	mutable std::vector<Staging> pool;
 };
 
+// RCCL entry points, resolved on first use (the library must load on hosts without RCCL,
+// and inside a PyTorch process it must bind to the RCCL torch already loaded).
 namespace {
+struct Rccl {
+	void *handle = nullptr;
+	decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+	decltype(&ncclCommInitRank) CommInitRank = nullptr;
+	decltype(&ncclCommDestroy) CommDestroy = nullptr;
+	decltype(&ncclAllGather) AllGather = nullptr;
+	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	std::string error;
+};
+
+const Rccl &rccl()
+{
+	static const Rccl r = [] {
+		Rccl x;
+		std::vector<std::string> names;
+		if (const char *e = getenv("GEC_RCCL_LIB"))
+			names.push_back(e);
+		names.insert(names.end(), {"librccl.so.1", "librccl.so"});
+		for (const std::string &n : names) {
+			x.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
+			if (x.handle)
+				break;
+			const char *de = dlerror();
+			x.error += n + ": " + (de ? de : "?") + "; ";
+		}
+		if (!x.handle)
+			return x;
+		x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(x.handle, "ncclGetUniqueId"));
+		x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(x.handle, "ncclCommInitRank"));
+		x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.handle, "ncclCommDestroy"));
+		x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.handle, "ncclAllGather"));
+		x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.handle, "ncclGetErrorString"));
+		if (!x.GetUniqueId || !x.CommInitRank || !x.CommDestroy || !x.AllGather || !x.GetErrorString) {
+			x.error = "RCCL library lacks a required symbol";
+			x.handle = nullptr;
+		}
+		return x;
+	}();
+	return r;
+}
+}  // namespace
+
+struct gec_group {
+	const gec_codec *c = nullptr;
+	int rank = 0, nranks = 1;
+	gec_allgather_fn all_gather = nullptr;
+	void *ctx = nullptr;
+	ncclComm_t comm = nullptr;  // RCCL transport only
+	// scratch for the exchange of the rebuilt ranges (step 3)
+	uint8_t *d_send = nullptr, *d_recv = nullptr;
+	size_t send_cap = 0, recv_cap = 0;
+};
+
+namespace {
+
+int rccl_all_gather(void *ctx, const void *d_send, void *d_recv, size_t bytes, void *hip_stream)
+{
+	gec_group *g = static_cast<gec_group *>(ctx);
+	ncclResult_t r = rccl().AllGather(d_send, d_recv, bytes, ncclUint8, g->comm, static_cast<hipStream_t>(hip_stream));
+	if (r != ncclSuccess)
+		return fail(GEC_E_DEVICE, std::string("ncclAllGather: ") + rccl().GetErrorString(r));
+	return GEC_OK;
+}
 
 int get_plan(const gec_codec *c, const uint8_t *present, bool data_only, std::shared_ptr<const Plan> &out)
 {
@@ -930,6 +998,198 @@ int gec_reconstruct_batch_dev(const gec_codec *c, size_t nblocks, void *d_stripe
 			      const uint8_t *present, int data_only, void *hip_stream)
 {
 	return gec_reconstruct_range_dev(c, nblocks, d_stripes, stride, S, present, data_only, 0, S, hip_stream);
+}
+
+// ------------------------------------------------- striped objects over several GPUs
+int gec_group_unique_id(uint8_t id[GEC_GROUP_ID_BYTES])
+{
+	static_assert(sizeof(ncclUniqueId) == GEC_GROUP_ID_BYTES, "GEC_GROUP_ID_BYTES must equal sizeof(ncclUniqueId)");
+	if (!id)
+		return fail(GEC_E_INVALID_ARG, "NULL id");
+	const Rccl &R = rccl();
+	if (!R.handle)
+		return fail(GEC_E_DEVICE, "RCCL is not available: " + R.error);
+	ncclUniqueId u;
+	ncclResult_t r = R.GetUniqueId(&u);
+	if (r != ncclSuccess)
+		return fail(GEC_E_DEVICE, std::string("ncclGetUniqueId: ") + R.GetErrorString(r));
+	std::memcpy(id, &u, sizeof(u));
+	return GEC_OK;
+}
+
+static int group_new(const gec_codec *c, int rank, int nranks, gec_group **out, std::unique_ptr<gec_group> &g)
+{
+	if (!out)
+		return fail(GEC_E_INVALID_ARG, "NULL out");
+	*out = nullptr;
+	if (!c)
+		return fail(GEC_E_INVALID_ARG, "NULL codec");
+	if (nranks < 1 || rank < 0 || rank >= nranks)
+		return fail(GEC_E_INVALID_ARG, "need 0 <= rank < nranks");
+	g.reset(new (std::nothrow) gec_group());
+	if (!g)
+		return fail(GEC_E_NOMEM, "alloc group");
+	g->c = c;
+	g->rank = rank;
+	g->nranks = nranks;
+	return GEC_OK;
+}
+
+int gec_group_create(const gec_codec *c, int rank, int nranks, const uint8_t id[GEC_GROUP_ID_BYTES], gec_group **out)
+{
+	std::unique_ptr<gec_group> g;
+	int rc = group_new(c, rank, nranks, out, g);
+	if (rc)
+		return rc;
+	if (!id)
+		return fail(GEC_E_INVALID_ARG, "NULL id");
+	const Rccl &R = rccl();
+	if (!R.handle)
+		return fail(GEC_E_DEVICE, "RCCL is not available: " + R.error);
+	DeviceGuard dg(c->device);
+	if (!dg.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	ncclUniqueId u;
+	std::memcpy(&u, id, sizeof(u));
+	ncclResult_t r = R.CommInitRank(&g->comm, nranks, u, rank);
+	if (r != ncclSuccess)
+		return fail(GEC_E_DEVICE, std::string("ncclCommInitRank: ") + R.GetErrorString(r));
+	g->all_gather = rccl_all_gather;
+	g->ctx = g.get();
+	*out = g.release();
+	return GEC_OK;
+}
+
+int gec_group_create_with_transport(const gec_codec *c, int rank, int nranks, gec_allgather_fn all_gather, void *ctx,
+				    gec_group **out)
+{
+	std::unique_ptr<gec_group> g;
+	int rc = group_new(c, rank, nranks, out, g);
+	if (rc)
+		return rc;
+	if (!all_gather)
+		return fail(GEC_E_INVALID_ARG, "NULL all_gather");
+	g->all_gather = all_gather;
+	g->ctx = ctx;
+	*out = g.release();
+	return GEC_OK;
+}
+
+void gec_group_destroy(gec_group *g)
+{
+	if (!g)
+		return;
+	{
+		DeviceGuard dg(g->c->device);
+		if (g->d_send)
+			(void)hipFree(g->d_send);
+		if (g->d_recv)
+			(void)hipFree(g->d_recv);
+		if (g->comm)
+			(void)rccl().CommDestroy(g->comm);
+	}
+	delete g;
+}
+
+int gec_group_rank(const gec_group *g) { return g ? g->rank : -1; }
+int gec_group_size(const gec_group *g) { return g ? g->nranks : 0; }
+size_t gec_group_slots(const gec_group *g)
+{
+	return g ? ((size_t)(g->c->k + g->c->m) + g->nranks - 1) / g->nranks : 0;
+}
+
+int gec_group_allgather_decode(gec_group *g, size_t nobjects, const void *d_local_slots, size_t S,
+			       const uint8_t *present, int data_only, int complete, void *d_gathered, void *hip_stream)
+{
+	if (!g || !present)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (nobjects == 0)
+		return GEC_OK;
+	const gec_codec *c = g->c;
+	const size_t n = (size_t)c->k + c->m, N = (size_t)g->nranks, slots = gec_group_slots(g);
+	int rc = check_dev_layout(d_local_slots, slots * S, S, slots * S);
+	if (rc)
+		return rc;
+	rc = check_dev_layout(d_gathered, slots * S, S, slots * S);
+	if (rc)
+		return rc;
+	hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+	DeviceGuard dg(c->device);
+	if (!dg.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	std::shared_ptr<const Plan> plan;  // before the exchange: a bad pattern fails on every rank alike, no rank hangs
+	rc = get_plan(c, present, data_only != 0, plan);
+	if (rc)
+		return rc;
+	// (1) the exchange step: every rank's slot buffer to everybody
+	const size_t per_rank = nobjects * slots * S;
+	rc = g->all_gather(g->ctx, d_local_slots, d_gathered, per_rank, hip_stream);
+	if (rc)
+		return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+	if (plan->missing.empty())
+		return GEC_OK;
+	// (2) my byte range of every missing shard, in place in the gathered buffer
+	std::vector<size_t> shard_off(n);
+	for (size_t j = 0; j < n; ++j)
+		shard_off[j] = (j % N) * per_rank + (j / N) * S;
+	const size_t cols = S / 16;
+	auto range_lo = [&](size_t r) { return cols * r / N; };
+	const size_t lo = range_lo(g->rank), my_cols = range_lo(g->rank + 1) - lo;
+	if (my_cols) {
+		rc = reconstruct_dev(c, nobjects, static_cast<uint8_t *>(d_gathered), slots * S, shard_off.data(), present,
+				     data_only != 0, lo * 16, my_cols * 16, stream);
+		if (rc)
+			return rc;
+	}
+	if (!complete || N == 1)
+		return GEC_OK;
+	// (3) exchange the rebuilt ranges (ranges differ by at most one column: pad to the longest)
+	size_t max_cols = 0;
+	for (size_t r = 0; r < N; ++r)
+		max_cols = std::max(max_cols, range_lo(r + 1) - range_lo(r));
+	const size_t nmiss = plan->missing.size();
+	const size_t send_bytes = nmiss * nobjects * max_cols * 16;
+	if (nobjects > 0xffffffffull || cols > 0xffffffffull)
+		return fail(GEC_E_INVALID_ARG, "batch too large for one call");
+	if (send_bytes > g->send_cap || send_bytes * N > g->recv_cap) {
+		HIP_TRY(hipStreamSynchronize(stream));  // earlier calls may still use the old buffers
+		if (g->d_send)
+			(void)hipFree(g->d_send);
+		if (g->d_recv)
+			(void)hipFree(g->d_recv);
+		g->d_send = g->d_recv = nullptr;
+		g->send_cap = g->recv_cap = 0;
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_send), send_bytes));
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_recv), send_bytes * N));
+		HIP_TRY(hipMemsetAsync(g->d_send, 0, send_bytes, stream));  // pad columns: defined bytes on the wire
+		g->send_cap = send_bytes;
+		g->recv_cap = send_bytes * N;
+	}
+	gec::RangeArgs ra;
+	std::memset(&ra, 0, sizeof(ra));
+	ra.gathered = static_cast<uint8_t *>(d_gathered);
+	ra.obj_stride = slots * S;
+	ra.nobj = (uint32_t)nobjects;
+	ra.nmiss = (uint32_t)nmiss;
+	ra.cols = (uint32_t)cols;
+	ra.max_cols = (uint32_t)max_cols;
+	ra.world = (uint32_t)N;
+	ra.rank = (uint32_t)g->rank;
+	for (size_t i = 0; i < nmiss; ++i)
+		ra.shard_off[i] = shard_off[plan->missing[i]];
+	auto grid_for = [](size_t items) { return (unsigned)std::min<size_t>((items + 255) / 256, 1u << 16); };
+	if (my_cols) {
+		ra.packed = g->d_send;
+		hipLaunchKernelGGL(gec::range_pack, dim3(grid_for(nmiss * nobjects * my_cols)), dim3(256), 0, stream, ra);
+		HIP_TRY(hipGetLastError());
+	}
+	rc = g->all_gather(g->ctx, g->d_send, g->d_recv, send_bytes, hip_stream);
+	if (rc)
+		return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+	ra.packed = g->d_recv;
+	hipLaunchKernelGGL(gec::range_unpack, dim3(grid_for(send_bytes / 16 * N)), dim3(256), 0, stream, ra);
+	HIP_TRY(hipGetLastError());
+	return GEC_OK;
 }
 
 // -------------------------------------------------------- host-pointer API

@@ -356,6 +356,65 @@ __global__ void clear_flags(uint32_t *p, uint32_t n)
 }
 
 // ---------------------------------------------------------------------------
+// Striped decode, step 3 (gec_group_allgather_decode): after every rank rebuilt its byte
+// range of each missing shard inside the gathered buffer, the ranges are exchanged with a
+// second all-gather.  range_pack gathers THIS rank's ranges into a dense send buffer
+// [nmiss][nobj][max_cols], range_unpack scatters the other ranks' ranges from the receive
+// buffer [world][nmiss][nobj][max_cols] back into the shards.  Rank r owns columns
+// [cols*r/world, cols*(r+1)/world) of every shard (16-byte columns); ranges differ in
+// length by at most one column, max_cols is the longest.  Pure 16-byte copies, HBM-bound,
+// a few percent of the decode's traffic.
+// ---------------------------------------------------------------------------
+struct RangeArgs {
+	uint8_t *gathered;     // [rank][object][slot][S]
+	uint8_t *packed;       // pack: send buffer, unpack: receive buffer
+	uint64_t obj_stride;   // slots*S, bytes between consecutive objects of one rank
+	uint32_t nobj, nmiss;
+	uint32_t cols;         // S / 16
+	uint32_t max_cols;
+	uint32_t world, rank;
+	uint64_t shard_off[KMAX];  // missing shard i of object 0, byte offset in `gathered`
+};
+
+__device__ __forceinline__ uint32_t range_lo(uint32_t cols, uint32_t r, uint32_t world)
+{
+	return (uint32_t)((uint64_t)cols * r / world);
+}
+
+__global__ __launch_bounds__(256) void range_pack(const RangeArgs a)
+{
+	const uint32_t lo = range_lo(a.cols, a.rank, a.world), n = range_lo(a.cols, a.rank + 1, a.world) - lo;
+	const uint64_t total = (uint64_t)a.nmiss * a.nobj * n;
+	for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t c = (uint32_t)(q % n);
+		const uint64_t io = q / n;  // i*nobj + obj
+		const uint32_t obj = (uint32_t)(io % a.nobj), i = (uint32_t)(io / a.nobj);
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.gathered + a.shard_off[i] + obj * a.obj_stride) + lo + c;
+		reinterpret_cast<u32x4 *>(a.packed)[io * a.max_cols + c] = *src;
+	}
+}
+
+__global__ __launch_bounds__(256) void range_unpack(const RangeArgs a)
+{
+	const uint64_t per_rank = (uint64_t)a.nmiss * a.nobj * a.max_cols;
+	const uint64_t total = per_rank * a.world;
+	for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t r = (uint32_t)(q / per_rank);
+		if (r == a.rank)
+			continue;
+		const uint64_t w = q % per_rank;
+		const uint32_t c = (uint32_t)(w % a.max_cols);
+		const uint32_t lo = range_lo(a.cols, r, a.world), n = range_lo(a.cols, r + 1, a.world) - lo;
+		if (c >= n)
+			continue;
+		const uint64_t io = w / a.max_cols;
+		const uint32_t obj = (uint32_t)(io % a.nobj), i = (uint32_t)(io / a.nobj);
+		u32x4 *dst = reinterpret_cast<u32x4 *>(a.gathered + a.shard_off[i] + obj * a.obj_stride) + lo + c;
+		*dst = reinterpret_cast<const u32x4 *>(a.packed)[q];
+	}
+}
+
+// ---------------------------------------------------------------------------
 // Baseline kernel (variant 1): the literal north_star formulation -- per-byte
 // log/antilog lookups in LDS, one GF multiply per (byte, row).  Kept only as the
 // measured "before" of DESIGN.md; same results, ~an order of magnitude more LDS

@@ -51,13 +51,21 @@ def init_from_env(force_backend: str | None = None) -> Ranks:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     # RCCL prints a version banner on STDOUT at NCCL_DEBUG=VERSION/INFO; bench.py's contract
     # is ONE JSON line on stdout, so keep RCCL at WARN unless the caller insists.
-    if os.environ.get("GARAGE_KEEP_NCCL_DEBUG") is None:
-        os.environ["NCCL_DEBUG"] = "WARN"
+    # (its WARN lines go to stdout too -- e.g. "alt_rsmi.cc NCCL WARN Could not read node" on
+    # some boxes -- so send RCCL's log to stderr.)
+    quiet_rccl()
     if backend == "nccl":
         dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
     return Ranks(rank, world, local_rank, device, backend)
+
+
+def quiet_rccl() -> None:
+    """Keep RCCL's own output off stdout (bench.py prints ONE JSON line there)."""
+    if os.environ.get("GARAGE_KEEP_NCCL_DEBUG") is None:
+        os.environ["NCCL_DEBUG"] = "WARN"
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
 
 
 def barrier(r: Ranks) -> None:

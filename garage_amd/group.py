@@ -1,0 +1,98 @@
+"""Multi-GPU decode of a striped object through the C ABI (gec_group_*,
+include/garage_ec.h): the same three steps as ``garage_amd.striped`` -- all-gather
+of the slot buffers, per-rank byte-range reconstruct in place, exchange of the
+rebuilt ranges -- but with RCCL driven by libgarage_ec itself (``ncclAllGather``
+over xGMI), which is what a host without torch (Garage's Rust shim) calls.
+torch is only used here for device tensors and, in ``from_torch_distributed``,
+to carry rank 0's RCCL unique id to the other ranks.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import GecError, check, lib
+from .codec import ReedSolomon, _stream_handle, _u8p
+
+
+class Group:
+    def __init__(self, codec: ReedSolomon, rank: int, nranks: int, unique_id: Optional[bytes] = None,
+                 transport: Optional[tuple[int, int]] = None):
+        """RCCL group (``unique_id`` from ``Group.unique_id()`` on rank 0, identical on
+        all ranks; collective) or, with ``transport=(fn_ptr, ctx_ptr)``, a group over a
+        caller-supplied all-gather (``gec_allgather_fn``)."""
+        self.codec = codec
+        self.rank, self.nranks = rank, nranks
+        h = ctypes.c_void_p()
+        if transport is not None:
+            fn, ctx = transport
+            check(lib.gec_group_create_with_transport(codec._h, rank, nranks, fn, ctx, ctypes.byref(h)),
+                  "gec_group_create_with_transport")
+        else:
+            if unique_id is None or len(unique_id) != _lib.GEC_GROUP_ID_BYTES:
+                raise GecError(_lib.GEC_E_INVALID_ARG, "unique_id", f"must be {_lib.GEC_GROUP_ID_BYTES} bytes")
+            buf = (ctypes.c_uint8 * _lib.GEC_GROUP_ID_BYTES).from_buffer_copy(unique_id)
+            check(lib.gec_group_create(codec._h, rank, nranks, buf, ctypes.byref(h)), "gec_group_create")
+        self._h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (ctypes.c_uint8 * _lib.GEC_GROUP_ID_BYTES)()
+        check(lib.gec_group_unique_id(buf), "gec_group_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def from_torch_distributed(cls, codec: ReedSolomon, group=None) -> "Group":
+        """One rank per process, already inside a torch.distributed job: rank 0 draws
+        the RCCL unique id and the job's own (any-backend) process group carries it."""
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(codec, rank, world, box[0])
+
+    @property
+    def slots(self) -> int:
+        return int(lib.gec_group_slots(self._h))
+
+    def allgather_decode(self, local_slots, present: Sequence[int], data_only: bool = False, complete: bool = True,
+                         out=None):
+        """local_slots: (nobjects, slots, S) uint8 CUDA tensor (this rank's shards, slot s =
+        shard s*nranks + rank).  Returns the gathered buffer (nranks, nobjects, slots, S),
+        missing shards rebuilt (see gec_group_allgather_decode); stream-ordered on the
+        current torch stream."""
+        import torch
+
+        if not (isinstance(local_slots, torch.Tensor) and local_slots.is_cuda and local_slots.dtype == torch.uint8
+                and local_slots.dim() == 3 and local_slots.shape[1] == self.slots):
+            raise TypeError(f"local_slots must be a uint8 CUDA tensor (nobjects, {self.slots}, S)")
+        if local_slots.device.index != self.codec.device:
+            raise GecError(_lib.GEC_E_INVALID_ARG, "local_slots", "tensor is on a different device than the codec")
+        local_slots = local_slots.contiguous()
+        nobj, slots, S = local_slots.shape
+        pres = np.ascontiguousarray(np.asarray(present, dtype=np.uint8))
+        if pres.size != self.codec.n:
+            raise GecError(_lib.GEC_E_INVALID_INDEX, "present", "must have k+m entries")
+        if out is None:
+            out = torch.empty((self.nranks, nobj, slots, S), dtype=torch.uint8, device=local_slots.device)
+        elif not (out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.numel() == self.nranks * local_slots.numel()):
+            raise TypeError("out must be a contiguous uint8 CUDA tensor of nranks*nobjects*slots*S bytes")
+        check(lib.gec_group_allgather_decode(self._h, nobj, local_slots.data_ptr(), S, _u8p(pres), int(bool(data_only)),
+                                             int(bool(complete)), out.data_ptr(), _stream_handle(self.codec.device)),
+              "gec_group_allgather_decode")
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib.gec_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover - interpreter shutdown
+            pass

@@ -197,6 +197,61 @@ int gec_reconstruct_scattered_dev(const gec_codec *c, size_t nblocks,
 				  size_t byte_off, size_t byte_len,
 				  void *hip_stream);
 
+/* ------------------------------------------- multi-GPU decode of a striped object
+ * SURVEY.md section 8b ("gec_group_create/..._allgather_decode") and 8e, BASELINE
+ * config 5.  One process (or thread) per GPU; rank r of N owns shard j of every
+ * object iff j % N == r, in slot j / N of its slot buffer
+ *     d_local_slots  [nobjects][slots][S],   slots = ceil((k+m) / N)
+ * (slots whose shard is erased, or padding slots, may hold anything).  Decode is
+ * the path's one real exchange step:
+ *   1. ONE all-gather of the slot buffers into d_gathered [N][nobjects][slots][S]
+ *      (ncclAllGather, ncclUint8 -- RCCL over xGMI);
+ *   2. every rank rebuilds ITS 1/N byte range [16*floor(c*r/N), 16*floor(c*(r+1)/N)),
+ *      c = S/16, of every missing shard in place in d_gathered
+ *      (gec_reconstruct_scattered_dev: no permute copy);
+ *   3. complete != 0: a second all-gather of just the rebuilt ranges, so that
+ *      every rank ends up with every missing shard in full.
+ * Whole blocks never come through here: they are independent units, partitioned
+ * over GPUs by hash with no collective (the way Garage partitions,
+ * src/rpc/layout/version.rs:101-104).
+ *
+ * RCCL is resolved at run time (librccl.so.1, or $GEC_RCCL_LIB), so the library
+ * loads on hosts without it; the caller carries rank 0's unique id to the other
+ * ranks out of band (Garage: its own RPC; the tests: torch.distributed / a file).
+ * A group serves one call at a time; everything is enqueued on `hip_stream`. */
+typedef struct gec_group gec_group;
+#define GEC_GROUP_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+
+int gec_group_unique_id(uint8_t id[GEC_GROUP_ID_BYTES]);
+/* Collective: all nranks ranks call it with the same id (ncclCommInitRank on the
+ * codec's device).  The codec is borrowed and must outlive the group. */
+int gec_group_create(const gec_codec *c, int rank, int nranks,
+		     const uint8_t id[GEC_GROUP_ID_BYTES], gec_group **out);
+
+/* Bring-your-own transport instead of RCCL (another fabric, or N logical ranks on
+ * one device in the tests).  all_gather must deliver, for every rank q, rank q's
+ * `bytes` at d_recv + q*bytes on every rank, ordered with respect to `hip_stream`
+ * (it may enqueue asynchronously on it or block); 0 = success. */
+typedef int (*gec_allgather_fn)(void *ctx, const void *d_send, void *d_recv,
+				size_t bytes, void *hip_stream);
+int gec_group_create_with_transport(const gec_codec *c, int rank, int nranks,
+				    gec_allgather_fn all_gather, void *ctx,
+				    gec_group **out);
+void gec_group_destroy(gec_group *g);
+int gec_group_rank(const gec_group *g);
+int gec_group_size(const gec_group *g);
+size_t gec_group_slots(const gec_group *g);
+
+/* present[k+m] (host, 0/1) is the erasure pattern, identical on all ranks.
+ * d_gathered: caller-allocated, N*nobjects*slots*S bytes, 16-byte aligned; on
+ * return (stream order) shard j of object b is at
+ *     d_gathered + ((j % N)*nobjects + b)*slots*S + (j / N)*S.
+ * With complete == 0 only this rank's byte range of each missing shard is valid. */
+int gec_group_allgather_decode(gec_group *g, size_t nobjects,
+			       const void *d_local_slots, size_t S,
+			       const uint8_t *present, int data_only, int complete,
+			       void *d_gathered, void *hip_stream);
+
 /* ------------------------------------------------------- blake2sum on the GPU
  * SURVEY.md section 8 row f4.  Garage's content hash `blake2sum` = blake2b-512
  * truncated to 32 bytes (src/util/data.rs:130-138); today it is a CPU pass in

@@ -1,0 +1,171 @@
+"""gec_group_* (C ABI striped decode, BASELINE config 5 / SURVEY.md section 8b+8e) on the GPU:
+  * N logical ranks as threads of this process on the one visible device, exchanging through
+    the loopback gec_allgather_fn of tests/c/loopback_transport.cpp (RCCL refuses two ranks
+    on one device): the full flow incl. the range pack / second exchange / unpack;
+  * the real RCCL transport at world size 1 (ncclCommInitRank + ncclAllGather from the
+    library itself, no torch.distributed).
+Bit-exact against the oracle's stripes."""
+import ctypes
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import garage_amd as g  # noqa: E402
+from garage_amd.striped import StripeLayout, gather_stripes, scatter_stripes  # noqa: E402
+from oracle import rs_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def loopback():
+    so = os.path.join(HERE, "c", "libgec_loopback.so")
+    if not os.path.exists(so):
+        r = subprocess.run(["make", "-C", os.path.join(HERE, "c"), "libgec_loopback.so"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    lb = ctypes.CDLL(so)
+    lb.lb_create.restype = ctypes.c_void_p
+    lb.lb_create.argtypes = [ctypes.c_int]
+    lb.lb_destroy.argtypes = [ctypes.c_void_p]
+    lb.lb_rank_ctx.restype = ctypes.c_void_p
+    lb.lb_rank_ctx.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lb.lb_all_gather_ptr.restype = ctypes.c_void_p
+    return lb
+
+
+def _stripes(coracle, k, m, S, nobj, seed):
+    data = O.splitmix64_bytes(seed, nobj * k * S).reshape(nobj, k, S)
+    return np.concatenate([data, coracle.encode_batch(k, m, data, coracle.AVX2, threads=4)], axis=1)
+
+
+def _run_logical_ranks(lb, rs, world, broken, present, data_only, complete):
+    """-> per-rank gathered buffers (world, nobj, slots, S) as numpy arrays"""
+    layout = StripeLayout(rs.k, rs.m, world)
+    handle = lb.lb_create(world)
+    fn = lb.lb_all_gather_ptr()
+    outs, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(DEV)):
+                grp = g.Group(rs, r, world, transport=(fn, lb.lb_rank_ctx(handle, r)))
+                local = scatter_stripes(broken, layout, r)
+                local[:, [layout.slot(j) for j in layout.shards_of(r) if not present[j]]] = 0xA0 + r  # junk in erased slots
+                out = grp.allgather_decode(local, present, data_only=data_only, complete=complete)
+                torch.cuda.current_stream().synchronize()
+                outs[r] = out.cpu().numpy()
+                grp.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, e))
+
+    ts = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ts), "a logical rank hung"
+    lb.lb_destroy(handle)
+    assert not errs, errs
+    return outs, layout
+
+
+@pytest.mark.parametrize("k,m,world,S,lost", [
+    (10, 4, 2, 4160, (0, 3, 7, 9)),
+    (10, 4, 4, 4160, (1, 2, 11, 13)),
+    (20, 8, 8, 4096 + 64, (0, 1, 5, 9, 13, 19, 21, 27)),   # config 5's shape, short shards
+    (3, 1, 8, 64, (2,)),                                    # 4 columns over 8 ranks: most ranks own an EMPTY range
+    (10, 4, 3, 1984, (4, 12)),                              # world does not divide k+m nor the columns
+])
+def test_group_allgather_decode_logical_ranks(coracle, loopback, k, m, world, S, lost):
+    nobj = 5
+    full = _stripes(coracle, k, m, S, nobj, 900 + world)
+    present = [j not in lost for j in range(k + m)]
+    broken = torch.from_numpy(full).to(DEV)
+    rs = g.ReedSolomon(k, m)
+    outs, layout = _run_logical_ranks(loopback, rs, world, broken, present, data_only=False, complete=True)
+    for r in range(world):
+        got = gather_stripes(torch.from_numpy(outs[r]), layout).numpy()
+        assert np.array_equal(got, full), f"rank {r}"
+
+
+def test_group_partial_and_data_only(coracle, loopback):
+    """complete=0: only the rank's own byte range of each missing shard is rebuilt;
+    data_only: missing parity is left alone."""
+    k, m, world, S, nobj = 10, 4, 4, 2048, 3
+    lost = (2, 6, 10)
+    full = _stripes(coracle, k, m, S, nobj, 77)
+    present = [j not in lost for j in range(k + m)]
+    broken = torch.from_numpy(full).to(DEV)
+    rs = g.ReedSolomon(k, m)
+    outs, layout = _run_logical_ranks(loopback, rs, world, broken, present, data_only=True, complete=False)
+    for r in range(world):
+        got = gather_stripes(torch.from_numpy(outs[r]), layout).numpy()
+        off, ln = layout.byte_range(r, S)
+        for j in (2, 6):
+            assert np.array_equal(got[:, j, off:off + ln], full[:, j, off:off + ln])
+        present_idx = [j for j in range(k + m) if present[j]]
+        assert np.array_equal(got[:, present_idx], full[:, present_idx])
+        assert not np.array_equal(got[:, 10], full[:, 10])  # parity shard 10 was not asked for
+
+
+def test_group_full_size_config5_roundtrip(loopback):
+    """BASELINE config 5 geometry at full shard size (RS(20,8), 4 MiB objects, 8 ranks),
+    checked through the encode -> erase -> group decode round trip (size-independent
+    property; the oracle covers the small cases above)."""
+    k, m, world, nobj = 20, 8, 8, 6
+    S = g.shard_len(k, 4 << 20)
+    rs = g.ReedSolomon(k, m)
+    st = torch.randint(0, 256, (nobj, k + m, S), dtype=torch.uint8, device=DEV)
+    rs.encode_dev(st)
+    assert bool(rs.verify_dev(st).all())
+    lost = (0, 1, 5, 9, 13, 19, 21, 27)
+    present = [j not in lost for j in range(k + m)]
+    outs, layout = _run_logical_ranks(loopback, rs, world, st, present, data_only=False, complete=True)
+    full = st.cpu().numpy()
+    for r in (0, 3, 7):
+        assert np.array_equal(gather_stripes(torch.from_numpy(outs[r]), layout).numpy(), full)
+
+
+def test_group_rccl_world1(coracle):
+    """The library's own RCCL path: unique id, ncclCommInitRank, ncclAllGather."""
+    k, m, S, nobj = 10, 4, 4160, 3
+    full = _stripes(coracle, k, m, S, nobj, 58)
+    lost = (0, 3, 7, 9)
+    present = [j not in lost for j in range(k + m)]
+    broken = torch.from_numpy(full).to(DEV)
+    broken[:, list(lost)] = 0
+    rs = g.ReedSolomon(k, m)
+    uid = g.Group.unique_id()
+    assert len(uid) == 128 and any(uid)
+    grp = g.Group(rs, 0, 1, uid)
+    assert grp.slots == k + m
+    layout = StripeLayout(k, m, 1)
+    out = grp.allgather_decode(scatter_stripes(broken, layout, 0), present)
+    torch.cuda.synchronize()
+    assert np.array_equal(gather_stripes(out, layout).cpu().numpy(), full)
+    grp.close()
+
+
+def test_group_argument_errors(loopback):
+    rs = g.ReedSolomon(10, 4)
+    with pytest.raises(g.GecError):
+        g.Group(rs, 2, 2, transport=(loopback.lb_all_gather_ptr(), None))      # rank out of range
+    with pytest.raises(g.GecError):
+        g.Group(rs, 0, 1, unique_id=b"short")
+    handle = loopback.lb_create(1)
+    grp = g.Group(rs, 0, 1, transport=(loopback.lb_all_gather_ptr(), loopback.lb_rank_ctx(handle, 0)))
+    local = torch.zeros((2, 14, 64), dtype=torch.uint8, device=DEV)
+    with pytest.raises(g.GecError):
+        grp.allgather_decode(local, [1] * 9 + [0] * 5)                          # fewer than k present
+    with pytest.raises(TypeError):
+        grp.allgather_decode(local[:, :13], [1] * 14)                           # wrong slot count
+    grp.close()
+    loopback.lb_destroy(handle)
