@@ -93,6 +93,21 @@ def test_no_cpu_fallback_without_gpu():
     assert "no CPU fallback" in str(ei.value)
 
 
+def test_group_entry_points_reject_bad_arguments_without_a_gpu():
+    """gec_group_*: argument checks come before any device / RCCL work."""
+    import ctypes
+
+    lib = _lib.lib
+    h = ctypes.c_void_p()
+    fn = _lib.ALLGATHER_FN(lambda *a: 0)
+    assert lib.gec_group_create_with_transport(None, 0, 1, fn, None, ctypes.byref(h)) == _lib.GEC_E_INVALID_ARG
+    assert lib.gec_group_create(None, 0, 1, (ctypes.c_uint8 * 128)(), ctypes.byref(h)) == _lib.GEC_E_INVALID_ARG
+    assert lib.gec_group_unique_id(None) == _lib.GEC_E_INVALID_ARG
+    assert lib.gec_group_rank(None) == -1 and lib.gec_group_size(None) == 0 and lib.gec_group_slots(None) == 0
+    assert lib.gec_group_allgather_decode(None, 1, None, 64, None, 0, 1, None, None) == _lib.GEC_E_INVALID_ARG
+    lib.gec_group_destroy(None)
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "garage_amd")
     for dp, _, files in os.walk(pkg):
