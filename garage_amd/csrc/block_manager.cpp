@@ -101,7 +101,8 @@ void blake2sum(const uint8_t *data, size_t len, uint8_t out[32])
 		off += 128;
 	}
 	uint8_t last[128] = {0};
-	std::memcpy(last, data + off, len - off);
+	if (len > off)  // data may be NULL for the empty message
+		std::memcpy(last, data + off, len - off);
 	b2_compress(h, last, len, true);
 	std::memcpy(out, h, 32);
 }
@@ -231,7 +232,7 @@ struct ShardHeader {
 
 // -------------------------------------------------------------------- nodes
 struct Node {
-	bool down = false;
+	std::atomic<bool> down{false};  // flipped by gbm_node_set_down while the batcher thread may be fanning out
 	virtual ~Node() = default;
 	virtual bool put(const Hash &h, int idx, std::vector<uint8_t> &&raw) = 0;
 	virtual bool get(const Hash &h, int idx, std::vector<uint8_t> &raw) = 0;  // false: absent
