@@ -403,16 +403,21 @@ uint64_t launch_cols_limit()
 	return v;
 }
 
-// Loads per batch: k itself when small, else the candidate that wastes the fewest
-// clamped duplicate loads in the last batch (ties: the earlier = larger candidate).
+// Loads per batch (tools/kbench sweep over k = 8..32, profiles/r01_kbench_kc_sweep.txt): k itself
+// when small; with 4-byte entries a batch of 10 whenever the duplicate (index-clamped, cache-hit)
+// loads of its last batch stay within a quarter of k -- fewer, larger batches win even with some
+// waste; otherwise the candidate that wastes the fewest (ties: the larger).
 int choose_kc(int k, int mw)
 {
 	if (k <= 6)
 		return k;
+	if (mw == 1) {
+		const int w10 = (k + 9) / 10 * 10 - k;
+		if (k <= 10 || w10 * 4 <= k)
+			return 10;
+	}
 	int best = 0, waste = 1 << 30;
-	for (int kc : {10, 5, 6, 4}) {
-		if (kc == 10 && mw != 1)
-			continue;
+	for (int kc : {6, 5, 4}) {
 		int w = (k + kc - 1) / kc * kc - k;
 		if (w < waste) {
 			waste = w;
