@@ -175,9 +175,15 @@ private:
 	bool stop_ = false;
 };
 
+// Worker count: GEC_COPY_THREADS (0 = copy on the calling thread only), default 7 or fewer on small hosts.
 CopyPool &copy_pool()
 {
-	static CopyPool pool(std::min(7u, std::max(1u, std::thread::hardware_concurrency()) - 1));
+	static CopyPool pool([] {
+		const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+		if (const char *e = getenv("GEC_COPY_THREADS"))
+			return (unsigned)std::min<unsigned long>(strtoul(e, nullptr, 0), 64ul);
+		return std::min(7u, hw - 1);
+	}());
 	return pool;
 }
 
