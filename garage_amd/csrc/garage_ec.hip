@@ -176,15 +176,12 @@ private:
 };
 
 // Worker count: GEC_COPY_THREADS (0 = copy on the calling thread only), default 7 or fewer on small hosts.
-CopyPool &copy_pool()
+unsigned copy_pool_threads()
 {
-	static CopyPool pool([] {
-		const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-		if (const char *e = getenv("GEC_COPY_THREADS"))
-			return (unsigned)std::min<unsigned long>(strtoul(e, nullptr, 0), 64ul);
-		return std::min(7u, hw - 1);
-	}());
-	return pool;
+	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+	if (const char *e = getenv("GEC_COPY_THREADS"))
+		return (unsigned)std::min<unsigned long>(strtoul(e, nullptr, 0), 64ul);
+	return std::min(7u, hw - 1);
 }
 
 // Staging resources for the host-pointer entry points (one per in-flight call).
@@ -256,6 +253,17 @@ struct gec_codec {
 
 	mutable std::mutex pool_mu;
 	mutable std::vector<Staging> pool;
+
+	// One copy pool per codec = per device: a process that drives several GPUs (one codec each)
+	// must not funnel all their staging copies through one set of threads.  Created on the
+	// first host-pointer call; device-API-only users never start the threads.
+	mutable std::once_flag copy_once;
+	mutable std::unique_ptr<CopyPool> copy_threads;
+	CopyPool &copy_pool() const
+	{
+		std::call_once(copy_once, [this] { copy_threads.reset(new CopyPool(copy_pool_threads())); });
+		return *copy_threads;
+	}
 };
 
 // RCCL entry points, resolved on first use (the library must load on hosts without RCCL,
@@ -1229,7 +1237,7 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 	// chunks are 8x larger when checksums are requested
 	const size_t ch = chunk_blocks(stripe, nblocks, shard_sums ? 8 * kChunkBytes : kChunkBytes);
 	const size_t sums_off = ch * stripe;  // checksum area behind the stripes of a slot
-	CopyPool &pool = copy_pool();
+	CopyPool &pool = c->copy_pool();
 	return run_pipeline(
 		c, (nblocks + ch - 1) / ch, ch * stripe + (shard_sums ? ch * n * 32 : 0), 0,
 		[&](size_t ci, Staging &st) {  // host: user blocks -> pinned, zero-padded to k*S
@@ -1327,7 +1335,7 @@ int gec_blake2sum_batch(const gec_codec *c, size_t n, const uint8_t *const *msgs
 	// slot layout: [messages][off u64 x count][len u64 x count][out 32 x count]
 	const size_t meta_off = (max_bytes + 63) / 64 * 64;
 	const size_t out_off = meta_off + 16 * max_count;
-	CopyPool &pool = copy_pool();
+	CopyPool &pool = c->copy_pool();
 	return run_pipeline(
 		c, chunks.size(), out_off + 32 * max_count, 0,
 		[&](size_t ci, Staging &st) {
@@ -1375,7 +1383,7 @@ int gec_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *s
 			return fail(GEC_E_TOO_FEW_SHARDS, "verify needs all k+m shards");
 	const size_t stripe = n * S;
 	const size_t ch = chunk_blocks(stripe, nblocks, kChunkBytes);
-	CopyPool &pool = copy_pool();
+	CopyPool &pool = c->copy_pool();
 	return run_pipeline(
 		c, (nblocks + ch - 1) / ch, ch * stripe, ch,
 		[&](size_t ci, Staging &st) {
@@ -1431,7 +1439,7 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 		if (npresent < n)
 			buckets[key].push_back(b);
 	}
-	CopyPool &pool = copy_pool();
+	CopyPool &pool = c->copy_pool();
 	for (auto &kv : buckets) {
 		const std::vector<size_t> &ids = kv.second;
 		const uint8_t *present = reinterpret_cast<const uint8_t *>(kv.first.data());

@@ -277,6 +277,39 @@ def test_host_encode_ragged_blocks(coracle):
     assert np.array_equal(par_small, coracle.encode_batch(k, m, O.split_block(k, blocks[3])[None])[0])
 
 
+def test_several_codecs_from_one_process_concurrently(coracle):
+    """One process driving several devices = one codec per device, each with its own streams,
+    staging and copy threads.  Only one GPU is visible here, so three codecs on cuda:0 stand
+    in for three devices: concurrent host-pointer calls from three threads, every parity
+    byte compared with the oracle."""
+    import threading
+
+    k, m, L, nb = 10, 4, 1 << 18, 40
+    S = g.shard_len(k, L)
+    codecs = [g.ReedSolomon(k, m, device=0) for _ in range(3)]
+    blocks = [[bytes(O.splitmix64_bytes(7000 + 100 * d + i, L - 17 * i)) for i in range(nb)] for d in range(3)]
+    got, errs = [None] * 3, []
+
+    def work(d):
+        try:
+            for _ in range(3):
+                got[d] = codecs[d].encode_blocks(blocks[d], S)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(d,)) for d in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for d in range(3):
+        data = np.stack([O.split_block(k, b, S) for b in blocks[d]])
+        assert np.array_equal(np.stack(got[d]), coracle.encode_batch(k, m, data, coracle.AVX2, threads=4))
+    for c in codecs:
+        c.close()
+
+
 def test_host_config1_rs_3_1_64k(coracle):
     # BASELINE config 1 shape (RS(3,1), 64 KiB, batch 16): parity == XOR of the data shards
     k, m, L, nb = 3, 1, 65536, 16
