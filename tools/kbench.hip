@@ -101,7 +101,9 @@ __global__ void read16x4(const gec::u32x4 *__restrict__ src, gec::u32x4 *__restr
 // K nt loads per lane (one per input shard), R nt stores (one per output shard), outputs = XOR of
 // the inputs rotated per row.  No LDS, no prologue: what HBM gives this 10-read : 4-write
 // pattern -- the ceiling the real kernel is measured against.
-template <int K, int R, int TPB>
+// ROT: 0 = every wave opens the shards in order 0..K-1; 1 = wave w starts at shard 3w; 2 = tile t starts
+// at shard t % K (same set of loads, different issue order).  LNT / SNT: nt loads / stores.
+template <int K, int R, int TPB, int ROT = 0, bool LNT = true, bool SNT = true>
 __global__ __launch_bounds__(TPB) void stream_pattern(const gec::ApplyArgs a)
 {
 	const uint32_t chunk = gridDim.x >> 3;
@@ -115,10 +117,19 @@ __global__ __launch_bounds__(TPB) void stream_pattern(const gec::ApplyArgs a)
 	const uint32_t bb = gcol / a.cols, col = gcol - bb * a.cols;
 	const gec::u32x4 *src = reinterpret_cast<const gec::u32x4 *>(a.in + (uint64_t)bb * a.in_stride) + col;
 	gec::u32x4 *dst = reinterpret_cast<gec::u32x4 *>(a.out + (uint64_t)bb * a.out_stride) + col;
+	uint32_t rot = 0;
+	if (ROT == 1)
+		rot = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 3) % K;
+	if (ROT == 2)
+		rot = tile_id % K;
 	gec::u32x4 d[K];
 #pragma unroll
-	for (int j = 0; j < K; ++j)
-		d[j] = __builtin_nontemporal_load(src + a.in_off[j]);
+	for (int j = 0; j < K; ++j) {
+		uint32_t t = j + rot;
+		t = t >= K ? t - K : t;
+		const gec::u32x4 *p = src + a.in_off[ROT ? t : j];
+		d[j] = LNT ? __builtin_nontemporal_load(p) : *p;
+	}
 	gec::u32x4 x = d[0];
 #pragma unroll
 	for (int j = 1; j < K; ++j)
@@ -128,7 +139,10 @@ __global__ __launch_bounds__(TPB) void stream_pattern(const gec::ApplyArgs a)
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
 		gec::u32x4 v = {x.x + r, x.y, x.z, x.w};
-		__builtin_nontemporal_store(v, dst + a.out_off[r]);
+		if (SNT)
+			__builtin_nontemporal_store(v, dst + a.out_off[r]);
+		else
+			dst[a.out_off[r]] = v;
 	}
 }
 
@@ -341,6 +355,12 @@ int main(int argc, char **argv)
 				run(256, stream_pattern<10, 4, 256>, "access pattern only 10r:4w t256 (pattern ceiling)");
 				run(512, stream_pattern<10, 4, 512>, "access pattern only 10r:4w t512");
 				run(128, stream_pattern<10, 4, 128>, "access pattern only 10r:4w t128");
+				run(256, stream_pattern<10, 4, 256, 1>, "pattern t256, shard order rotated per wave");
+				run(256, stream_pattern<10, 4, 256, 2>, "pattern t256, shard order rotated per tile");
+				run(256, stream_pattern<10, 4, 256, 0, false, true>, "pattern t256, plain loads, nt stores");
+				run(256, stream_pattern<10, 4, 256, 0, true, false>, "pattern t256, nt loads, plain stores");
+				run(256, stream_pattern<10, 4, 256, 0, false, false>, "pattern t256, plain loads, plain stores");
+				run(256, stream_pattern<10, 4, 256>, "access pattern only 10r:4w t256 (again)");
 			} else {
 				run(512, stream_pattern<20, 8, 512>, "access pattern only 20r:8w t512 (pattern ceiling)");
 				run(256, stream_pattern<20, 8, 256>, "access pattern only 20r:8w t256");
