@@ -146,6 +146,68 @@ __global__ __launch_bounds__(TPB) void stream_pattern(const gec::ApplyArgs a)
 	}
 }
 
+// Same pattern with explicit cache-policy bits on the loads (LP) and stores (SP), via inline asm:
+// 0 = none, 1 = nt, 2 = sc1, 3 = sc0 sc1, 4 = sc0 sc1 nt, 5 = sc1 nt, 6 = sc0, 7 = sc0 nt
+#define KB_POLICY(P) ((P) == 0 ? "" : (P) == 1 ? " nt" : (P) == 2 ? " sc1" : (P) == 3 ? " sc0 sc1" : (P) == 4 ? " sc0 sc1 nt" : (P) == 5 ? " sc1 nt" : (P) == 6 ? " sc0" : " sc0 nt")
+template <int P>
+__device__ __forceinline__ gec::u32x4 asm_load(const gec::u32x4 *p)
+{
+	gec::u32x4 v;
+	if (P == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+	if (P == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+	if (P == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+	if (P == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+	if (P == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+	if (P == 5) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+	if (P == 6) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+	if (P == 7) asm volatile("global_load_dwordx4 %0, %1, off sc0 nt" : "=v"(v) : "v"(p) : "memory");
+	return v;
+}
+template <int P>
+__device__ __forceinline__ void asm_store(gec::u32x4 v, gec::u32x4 *p)
+{
+	if (P == 0) asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+	if (P == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+	if (P == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+	if (P == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+	if (P == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
+	if (P == 5) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory");
+	if (P == 6) asm volatile("global_store_dwordx4 %0, %1, off sc0" : : "v"(p), "v"(v) : "memory");
+	if (P == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" : : "v"(p), "v"(v) : "memory");
+}
+
+template <int K, int R, int TPB, int LP, int SP>
+__global__ __launch_bounds__(TPB) void stream_policy(const gec::ApplyArgs a)
+{
+	const uint32_t chunk = gridDim.x >> 3;
+	const uint32_t tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	if ((uint64_t)tile_id * TPB >= a.total_cols)
+		return;
+	uint32_t gcol = tile_id * TPB + threadIdx.x;
+	const bool live = gcol < a.total_cols;
+	if (!live)
+		gcol = tile_id * TPB;
+	const uint32_t bb = gcol / a.cols, col = gcol - bb * a.cols;
+	const gec::u32x4 *src = reinterpret_cast<const gec::u32x4 *>(a.in + (uint64_t)bb * a.in_stride) + col;
+	gec::u32x4 *dst = reinterpret_cast<gec::u32x4 *>(a.out + (uint64_t)bb * a.out_stride) + col;
+	gec::u32x4 d[K];
+#pragma unroll
+	for (int j = 0; j < K; ++j)
+		d[j] = asm_load<LP>(src + a.in_off[j]);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	gec::u32x4 x = d[0];
+#pragma unroll
+	for (int j = 1; j < K; ++j)
+		x ^= d[j];
+	if (!live)
+		return;
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		gec::u32x4 v = {x.x + r, x.y, x.z, x.w};
+		asm_store<SP>(v, dst + a.out_off[r]);
+	}
+}
+
 __global__ void diff_count(const uint32_t *a, const uint32_t *b, size_t n, unsigned long long *out)
 {
 	size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -361,6 +423,21 @@ int main(int argc, char **argv)
 				run(256, stream_pattern<10, 4, 256, 0, true, false>, "pattern t256, nt loads, plain stores");
 				run(256, stream_pattern<10, 4, 256, 0, false, false>, "pattern t256, plain loads, plain stores");
 				run(256, stream_pattern<10, 4, 256>, "access pattern only 10r:4w t256 (again)");
+				if (getenv("KBENCH_POLICY")) {
+					run(256, stream_policy<10, 4, 256, 1, 1>, "policy: loads nt          stores nt   (= the kernel)");
+					run(256, stream_policy<10, 4, 256, 2, 1>, "policy: loads sc1         stores nt");
+					run(256, stream_policy<10, 4, 256, 3, 1>, "policy: loads sc0 sc1     stores nt");
+					run(256, stream_policy<10, 4, 256, 4, 1>, "policy: loads sc0 sc1 nt  stores nt");
+					run(256, stream_policy<10, 4, 256, 5, 1>, "policy: loads sc1 nt      stores nt");
+					run(256, stream_policy<10, 4, 256, 6, 1>, "policy: loads sc0         stores nt");
+					run(256, stream_policy<10, 4, 256, 7, 1>, "policy: loads sc0 nt      stores nt");
+					run(256, stream_policy<10, 4, 256, 1, 2>, "policy: loads nt          stores sc1");
+					run(256, stream_policy<10, 4, 256, 1, 3>, "policy: loads nt          stores sc0 sc1");
+					run(256, stream_policy<10, 4, 256, 1, 4>, "policy: loads nt          stores sc0 sc1 nt");
+					run(256, stream_policy<10, 4, 256, 1, 5>, "policy: loads nt          stores sc1 nt");
+					run(256, stream_policy<10, 4, 256, 1, 7>, "policy: loads nt          stores sc0 nt");
+					run(256, stream_policy<10, 4, 256, 1, 1>, "policy: loads nt          stores nt   (again)");
+				}
 			} else {
 				run(512, stream_pattern<20, 8, 512>, "access pattern only 20r:8w t512 (pattern ceiling)");
 				run(256, stream_pattern<20, 8, 256>, "access pattern only 20r:8w t256");
