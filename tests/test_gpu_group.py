@@ -96,6 +96,33 @@ def test_group_allgather_decode_logical_ranks(coracle, loopback, k, m, world, S,
         assert np.array_equal(got, full), f"rank {r}"
 
 
+from hypothesis import HealthCheck, given, settings  # noqa: E402
+from hypothesis import strategies as hst  # noqa: E402
+
+
+@settings(max_examples=20, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(k=hst.integers(1, 12), m=hst.integers(1, 6), world=hst.integers(1, 8), cols4=hst.integers(1, 40),
+       nobj=hst.integers(1, 4), seed=hst.integers(0, 2**31), data_only=hst.booleans())
+def test_group_random_geometry(coracle, loopback, k, m, world, cols4, nobj, seed, data_only):
+    """Random code, world size, shard length (any multiple of 64) and erasure pattern: the byte-range
+    split, the pack / second exchange / unpack index math and the padding slots, against the oracle."""
+    S = 64 * cols4
+    rng = np.random.default_rng(seed)
+    nlost = int(rng.integers(0, m + 1))
+    lost = tuple(sorted(rng.choice(k + m, size=nlost, replace=False).tolist()))
+    full = _stripes(coracle, k, m, S, nobj, seed)
+    present = [j not in lost for j in range(k + m)]
+    broken = torch.from_numpy(full).to(DEV)
+    rs = g.ReedSolomon(k, m)
+    outs, layout = _run_logical_ranks(loopback, rs, world, broken, present, data_only=data_only, complete=True)
+    want_rebuilt = [j for j in lost if not (data_only and j >= k)]
+    keep = [j for j in range(k + m) if present[j] or j in want_rebuilt]
+    for r in range(world):
+        got = gather_stripes(torch.from_numpy(outs[r]), layout).numpy()
+        assert np.array_equal(got[:, keep], full[:, keep]), f"rank {r} lost {lost}"
+    rs.close()
+
+
 def test_group_partial_and_data_only(coracle, loopback):
     """complete=0: only the rank's own byte range of each missing shard is rebuilt;
     data_only: missing parity is left alone."""
