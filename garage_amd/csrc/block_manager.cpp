@@ -772,10 +772,20 @@ int gbm_rpc_get_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, uint8_
 		mg->metrics[3] += ids.size();
 	}
 	// assemble, then check every block's content against its name (DataBlock::verify,
-	// block.rs:69-77) -- all block hashes in one batch
-	std::vector<std::vector<uint8_t>> whole(nb);
+	// block.rs:69-77) -- all block hashes in one batch.  Plain blocks are assembled straight
+	// into the caller's buffer and hashed from there (on CORRUPT_DATA its contents are
+	// unspecified); only compressed blocks need an intermediate for the zstd frame.
 	std::vector<const uint8_t *> ptrs;
 	std::vector<size_t> lens, idx;
+	auto assemble = [&](size_t b, uint8_t *dst) {
+		const size_t L = g[b].meta.orig_len, S = g[b].meta.shard_len;
+		for (int j = 0; j < k; ++j) {
+			size_t lo = (size_t)j * S;
+			if (lo >= L)
+				break;
+			std::memcpy(dst + lo, g[b].shard[j].data(), std::min(S, L - lo));
+		}
+	};
 	for (size_t b = 0; b < nb; ++b) {
 		if (rcs[b] != GBM_OK)
 			continue;
@@ -784,17 +794,11 @@ int gbm_rpc_get_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, uint8_
 			rcs[b] = GBM_E_CORRUPT_DATA;
 			continue;
 		}
-		whole[b].resize(L);
-		for (int j = 0; j < k; ++j) {
-			size_t lo = (size_t)j * S;
-			if (lo >= L)
-				break;
-			std::memcpy(whole[b].data() + lo, g[b].shard[j].data(), std::min(S, L - lo));
-		}
 		if (g[b].meta.compressed) {
 			// DataBlock::verify for Compressed = "the zstd stream decodes" (frame checksum)
-			std::vector<uint8_t> plain;
-			if (!zstd().decode(whole[b].data(), L, plain)) {
+			std::vector<uint8_t> frame(L), plain;
+			assemble(b, frame.data());
+			if (!zstd().decode(frame.data(), L, plain)) {
 				rcs[b] = GBM_E_CORRUPT_DATA;
 				continue;
 			}
@@ -808,7 +812,12 @@ int gbm_rpc_get_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, uint8_
 			mg->metrics[5]++;
 			continue;
 		}
-		ptrs.push_back(whole[b].data());
+		if (cap[b] < L) {
+			rcs[b] = GBM_E_BUFFER_TOO_SMALL;
+			continue;
+		}
+		assemble(b, out[b]);
+		ptrs.push_back(out[b]);
 		lens.push_back(L);
 		idx.push_back(b);
 	}
@@ -822,11 +831,6 @@ int gbm_rpc_get_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, uint8_
 			rcs[b] = GBM_E_CORRUPT_DATA;
 			continue;
 		}
-		if (cap[b] < lens[i]) {
-			rcs[b] = GBM_E_BUFFER_TOO_SMALL;
-			continue;
-		}
-		std::memcpy(out[b], whole[b].data(), lens[i]);
 		std::lock_guard<std::mutex> lk(mg->mu);
 		mg->metrics[5]++;
 	}
