@@ -16,7 +16,8 @@ GBM_OK, GBM_E_MISSING_BLOCK, GBM_E_CORRUPT_DATA, GBM_E_QUORUM = 0, -1, -2, -3
 GBM_E_INVALID_ARG, GBM_E_EC, GBM_E_IO, GBM_E_BUFFER_TOO_SMALL = -4, -5, -6, -7
 
 SYMBOLS = [
-    "gbm_last_error", "gbm_blake2sum", "gbm_create", "gbm_destroy", "gbm_set_compression_level", "gbm_storage_nodes_of",
+    "gbm_last_error", "gbm_blake2sum", "gbm_create", "gbm_destroy", "gbm_set_compression_level", "gbm_set_data_fsync",
+    "gbm_storage_nodes_of",
     "gbm_rpc_put_block", "gbm_rpc_put_blocks", "gbm_rpc_get_block", "gbm_rpc_get_blocks",
     "gbm_block_incref", "gbm_block_decref", "gbm_resync_block", "gbm_resync_all", "gbm_resync_queue_len",
     "gbm_scrub", "gbm_node_set_down", "gbm_node_has_shard", "gbm_node_delete_shard",
@@ -57,6 +58,7 @@ def _load():
     lib.gbm_destroy.argtypes = [vp]
     lib.gbm_destroy.restype = None
     lib.gbm_set_compression_level.argtypes = [vp, ci, ci]
+    lib.gbm_set_data_fsync.argtypes = [vp, ci]
     lib.gbm_storage_nodes_of.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ci)]
     lib.gbm_rpc_put_block.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, sz]
     lib.gbm_rpc_put_blocks.argtypes = [vp, sz, ctypes.c_char_p, pp, ctypes.POINTER(sz)]
@@ -107,7 +109,7 @@ class NativeBlockManager:
     METRICS = ("bytes_written", "bytes_read", "corruption_counter", "ec_reconstructs", "blocks_put", "blocks_get")
 
     def __init__(self, codec, nnodes: int, node_dirs: Optional[Sequence[str]] = None, write_quorum: int = 0,
-                 compression_level: Optional[int] = None):
+                 compression_level: Optional[int] = None, data_fsync: bool = False):
         self.codec = codec  # keep the borrowed codec alive
         self.k, self.m, self.n, self.nnodes = codec.k, codec.m, codec.k + codec.m, nnodes
         dirs = None
@@ -119,6 +121,8 @@ class NativeBlockManager:
         self._h = h
         if compression_level is not None:
             _check(lib.gbm_set_compression_level(self._h, 1, compression_level), "gbm_set_compression_level")
+        if data_fsync:
+            _check(lib.gbm_set_data_fsync(self._h, 1), "gbm_set_data_fsync")
 
     def close(self):
         if getattr(self, "_h", None):

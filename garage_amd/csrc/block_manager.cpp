@@ -8,6 +8,7 @@
 #include "../../include/garage_block.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -269,6 +270,7 @@ struct MemoryNode : Node {
 // a corrupt shard is renamed *.corrupted (manager.rs:807-819).
 struct DirNode : Node {
 	std::string root;
+	std::atomic<bool> fsync_data{false};  // Config.data_fsync (src/util/config.rs:22-24), off by default
 	explicit DirNode(std::string r) : root(std::move(r)) {}
 	std::string dir(const Hash &h) const
 	{
@@ -291,11 +293,23 @@ struct DirNode : Node {
 		if (!f)
 			return false;
 		bool ok = std::fwrite(raw.data(), 1, raw.size(), f) == raw.size();
+		const bool sync = fsync_data.load();
+		if (ok && sync)  // file first, then (after the rename) its directory: manager.rs:775-800
+			ok = std::fflush(f) == 0 && ::fsync(::fileno(f)) == 0;
 		ok = (std::fclose(f) == 0) && ok;
 		if (ok)
 			ok = std::rename(tmp.c_str(), p.c_str()) == 0;
 		if (!ok)
 			std::remove(tmp.c_str());
+		if (ok && sync) {
+			int dfd = ::open(dir(h).c_str(), O_RDONLY | O_DIRECTORY);
+			if (dfd >= 0) {
+				ok = ::fsync(dfd) == 0;
+				::close(dfd);
+			} else {
+				ok = false;
+			}
+		}
 		return ok;
 	}
 	bool get(const Hash &h, int idx, std::vector<uint8_t> &raw) override
@@ -597,6 +611,16 @@ int gbm_create(const gec_codec *codec, int nnodes, const char *const *node_dirs,
 }
 
 void gbm_destroy(gbm_manager *m) { delete m; }
+
+int gbm_set_data_fsync(gbm_manager *m, int enabled)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	for (auto &nd : m->nodes)
+		if (DirNode *d = dynamic_cast<DirNode *>(nd.get()))
+			d->fsync_data = enabled != 0;
+	return GBM_OK;
+}
 
 int gbm_storage_nodes_of(const gbm_manager *m, const uint8_t hash[32], int *nodes_out)
 {

@@ -63,6 +63,11 @@ void gbm_destroy(gbm_manager *m);
  * is stored Plain (src/block/block.rs:88-93). */
 int gbm_set_compression_level(gbm_manager *m, int enabled, int level);
 
+/* Config.data_fsync (src/util/config.rs:22-24; off by default): directory-backed nodes
+ * fsync the shard file before the rename and its directory after it
+ * (write_block_inner, src/block/manager.rs:775-800).  No effect on in-memory nodes. */
+int gbm_set_data_fsync(gbm_manager *m, int enabled);
+
 /* nodes_out[k+m]: node index that stores shard j of this hash. */
 int gbm_storage_nodes_of(const gbm_manager *m, const uint8_t hash[32], int *nodes_out);
 

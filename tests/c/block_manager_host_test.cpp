@@ -45,6 +45,8 @@ static void run(int k, int m, const char *dir_root)
 	gbm_manager *mg = nullptr;
 	CHECK(gbm_create(codec, n - 1, nullptr, 0, &mg) == GBM_E_INVALID_ARG);  // replication_factor == k+m
 	CHECK(gbm_create(codec, nnodes, dir_root ? dirp.data() : nullptr, 0, &mg) == GBM_OK);
+	CHECK(gbm_set_data_fsync(nullptr, 1) == GBM_E_INVALID_ARG);
+	CHECK(gbm_set_data_fsync(mg, k == 10) == GBM_OK);  // Config.data_fsync on for one of the codes (dir nodes only)
 
 	// put / get round trips, ragged sizes, batched put
 	std::vector<std::vector<uint8_t>> blocks;
