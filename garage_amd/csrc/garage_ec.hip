@@ -36,6 +36,8 @@ namespace {
 
 thread_local std::string g_last_error;
 std::atomic<int> g_variant{0};
+// A/B switch (GEC_ROWS16=0): codes with 9..16 output rows as two 8-row passes instead of one 16-row pass
+std::atomic<int> g_rows16{[] { const char *e = getenv("GEC_ROWS16"); return e ? atoi(e) : 1; }()};
 
 int fail(int code, const std::string &detail)
 {
@@ -404,6 +406,7 @@ int get_plan(const gec_codec *c, const uint8_t *present, bool data_only, std::sh
 constexpr int kCPT = 1;
 constexpr int kThreadsMW1 = 256;
 constexpr int kThreadsMW2 = 512;
+constexpr int kThreadsMW4 = 512;  // 16-byte entries: 64 accumulator VGPRs per lane, 4 shards per batch (512 beats 256 by 2-5 %)
 
 // Test hook: GEC_MAX_COLS_PER_LAUNCH caps the columns one launch may cover, so the
 // multi-launch split (normally only beyond 2^32 columns = 64 GiB per shard slot) can be
@@ -444,27 +447,38 @@ int choose_kc(int k, int mw)
 template <int MW, int MODE, int TPB>
 void launch_nibble(const gec::ApplyArgs &a, const gec::LogExp *le, unsigned grid, size_t lds, hipStream_t s)
 {
-	const int kc = choose_kc((int)a.k, MW);
+	int kc = choose_kc((int)a.k, MW);
+	if constexpr (MW == 4)  // register budget (64 accumulator VGPRs): at most 4 shards in flight
+		kc = std::min<int>((int)a.k, 4);
 	if constexpr (MW == 1) {
 		if (kc == 10) {
 			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 10, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, a, le);
 			return;
 		}
 	}
-	switch (kc) {
 #define GEC_CASE(KC)                                                                                              \
 	case KC:                                                                                                  \
 		hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, KC, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, \
 				   a, le);                                                                        \
 		break;
-		GEC_CASE(1)
-		GEC_CASE(2)
-		GEC_CASE(3)
-		GEC_CASE(4)
-		GEC_CASE(5)
-		GEC_CASE(6)
-#undef GEC_CASE
+	if constexpr (MW == 4) {
+		switch (kc) {
+			GEC_CASE(1)
+			GEC_CASE(2)
+			GEC_CASE(3)
+			GEC_CASE(4)
+		}
+	} else {
+		switch (kc) {
+			GEC_CASE(1)
+			GEC_CASE(2)
+			GEC_CASE(3)
+			GEC_CASE(4)
+			GEC_CASE(5)
+			GEC_CASE(6)
+		}
 	}
+#undef GEC_CASE
 }
 
 // out[r] = XOR_t coef[r][t] * in[t] for r < nout: shard t of block b is read at
@@ -501,18 +515,25 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 	int rows = 0;
 	for (int r0 = 0; r0 < nout; r0 += rows) {
 		rows = std::min(gec::RMAX, nout - r0);
+		// More than 8 rows left: 16-byte table entries take up to 16 of them in ONE pass over
+		// the data (instead of one pass per 8 rows), as long as k*16 coefficient bytes fit the
+		// argument block and k*512 bytes of tables fit 64 KiB of LDS.
+		if (nout - r0 > gec::RMAX && k <= gec::K16MAX && variant == 0 && g_rows16.load(std::memory_order_relaxed))
+			rows = std::min(gec::RMAX16, nout - r0);
 		// 8-byte table entries need k*256 bytes of LDS; beyond the 64 KiB a workgroup gets
 		// without opting in (k > ~245) fall back to groups of 4 rows (4-byte entries)
-		if (rows > 4 && (size_t)k * 256 + 768 + (size_t)k * gec::RMAX > 65536)
+		if (rows > 4 && rows <= gec::RMAX && (size_t)k * 256 + 768 + (size_t)k * gec::RMAX > 65536)
 			rows = 4;
 		a.rows = (uint32_t)rows;
-		for (int r = 0; r < gec::RMAX; ++r) {
+		const int mw = rows <= 4 ? 1 : rows <= gec::RMAX ? 2 : 4;
+		const int cr = mw == 4 ? gec::RMAX16 : gec::RMAX;  // coefficient bytes per input shard
+		uint8_t *flat = &a.coef[0][0];
+		for (int r = 0; r < cr; ++r) {
 			if (r < rows)
 				a.out_off[r] = (uint32_t)(out_base_off[r0 + r] / 16);
 			for (int t = 0; t < k; ++t)
-				a.coef[t][r] = r < rows ? coef[(size_t)(r0 + r) * k + t] : 0;
+				flat[(size_t)t * cr + r] = r < rows ? coef[(size_t)(r0 + r) * k + t] : 0;
 		}
-		const int mw = rows <= 4 ? 1 : 2;
 		if (variant == 1) {
 			// measured baseline: persistent grid-stride log/antilog kernel, one tile = 256
 			// columns of one block
@@ -530,7 +551,7 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 		}
 		// The (block, column) space is flattened: a launch covers a range of whole blocks
 		// whose columns fit 32 bits and whose tiles fit HIP's grid limit (grid*block < 2^32).
-		const int threads = mw == 1 ? kThreadsMW1 : kThreadsMW2;
+		const int threads = mw == 1 ? kThreadsMW1 : mw == 2 ? kThreadsMW2 : kThreadsMW4;
 		const uint64_t tile_cols = (uint64_t)threads * kCPT;
 		uint64_t max_cols = std::min<uint64_t>(0xfffff000ull, (0xffffffffull / threads - 8) * tile_cols);
 		if (launch_cols_limit())
@@ -538,7 +559,7 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 		if (a.cols > max_cols)
 			return fail(GEC_E_INVALID_ARG, "shard too large for one launch");
 		const uint64_t blocks_per_launch = std::max<uint64_t>(1, max_cols / a.cols);
-		const size_t lds = (size_t)k * 32 * 4 * mw + 768 + (size_t)k * gec::RMAX;
+		const size_t lds = (size_t)k * 32 * 4 * mw + 768 + (size_t)k * cr;
 		gec::ApplyArgs la = a;
 		for (uint64_t b0 = 0; b0 < nblocks; b0 += blocks_per_launch) {
 			const uint64_t nb = std::min<uint64_t>(blocks_per_launch, nblocks - b0);
@@ -553,10 +574,14 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 				launch_nibble<1, gec::MODE_STORE, kThreadsMW1>(la, c->d_logexp, grid, lds, stream);
 			else if (mw == 1)
 				launch_nibble<1, gec::MODE_COMPARE, kThreadsMW1>(la, c->d_logexp, grid, lds, stream);
-			else if (mode == gec::MODE_STORE)
+			else if (mw == 2 && mode == gec::MODE_STORE)
 				launch_nibble<2, gec::MODE_STORE, kThreadsMW2>(la, c->d_logexp, grid, lds, stream);
-			else
+			else if (mw == 2)
 				launch_nibble<2, gec::MODE_COMPARE, kThreadsMW2>(la, c->d_logexp, grid, lds, stream);
+			else if (mode == gec::MODE_STORE)
+				launch_nibble<4, gec::MODE_STORE, kThreadsMW4>(la, c->d_logexp, grid, lds, stream);
+			else
+				launch_nibble<4, gec::MODE_COMPARE, kThreadsMW4>(la, c->d_logexp, grid, lds, stream);
 			HIP_TRY(hipGetLastError());
 		}
 	}

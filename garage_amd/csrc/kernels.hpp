@@ -34,7 +34,9 @@
 namespace gec {
 
 constexpr int KMAX = 256;    // input shards per launch (k + m <= 256 => k <= 255)
-constexpr int RMAX = 8;      // output rows per launch
+constexpr int RMAX = 8;      // output rows per launch with 4- and 8-byte table entries
+constexpr int RMAX16 = 16;   // ... with 16-byte entries (MW = 4): k <= K16MAX only
+constexpr int K16MAX = 120;  // 16 coefficient bytes per input shard must fit ApplyArgs.coef, the tables 64 KiB of LDS
 constexpr int BLOCK = 256;   // threads per workgroup of the baseline kernel
 constexpr int MODE_STORE = 0, MODE_COMPARE = 2;  // write the rows / compare them with what is stored
 
@@ -55,8 +57,10 @@ struct ApplyArgs {
 	uint32_t k;          // inputs  (<= KMAX)
 	uint32_t rows;       // outputs (<= RMAX)
 	uint32_t in_off[KMAX];   // shard offsets inside a block, in 16-byte units
-	uint32_t out_off[RMAX];
-	uint8_t coef[KMAX][RMAX];  // coef[t][r] = mat[r][t]: one 8-byte row per input shard
+	uint32_t out_off[RMAX16];
+	// coef[t][r] = mat[r][t]: one 8-byte row per input shard.  The 16-row kernel (MW = 4) reads the
+	// same bytes as a flat [k][16] array (k <= K16MAX).
+	uint8_t coef[KMAX][RMAX];
 };
 
 // exp[512] | log[256], filled by the host from gec::Field (768 bytes).
@@ -83,6 +87,7 @@ __device__ __forceinline__ void transpose4x4(uint32_t a0, uint32_t a1, uint32_t 
 
 typedef __attribute__((address_space(3))) const uint32_t lds_u32_t;
 typedef __attribute__((address_space(3))) const u32x2 lds_u32x2_t;
+typedef __attribute__((address_space(3))) const u32x4 lds_u32x4_t;
 
 // base + byte P of `packed` in ONE VALU op: SDWA selects the byte, the table base
 // rides in as the scalar operand.  (hipcc emits shift+and+add for the same C.)
@@ -118,19 +123,27 @@ __device__ __forceinline__ void lut_acc(uint32_t tb, uint32_t lo, uint32_t hi, u
 {
 	const uint32_t al = add_byte<P>(tb, lo);
 	const uint32_t ah = add_byte<P>(tb, hi);
-	if (MW == 1) {
+	if constexpr (MW == 1) {
 		acc[0] = xor3(acc[0], *reinterpret_cast<lds_u32_t *>(al), *reinterpret_cast<lds_u32_t *>(ah + 64));
-	} else {
+	} else if constexpr (MW == 2) {
 		const u32x2 vl = *reinterpret_cast<lds_u32x2_t *>(al);
 		const u32x2 vh = *reinterpret_cast<lds_u32x2_t *>(ah + 128);
 		acc[0] = xor3(acc[0], vl.x, vh.x);
-		acc[MW - 1] = xor3(acc[MW - 1], vl.y, vh.y);
+		acc[1] = xor3(acc[1], vl.y, vh.y);
+	} else {  // 16-byte entries: rows 0-3 | 4-7 | 8-11 | 12-15, one ds_read_b128 per nibble
+		const u32x4 vl = *reinterpret_cast<lds_u32x4_t *>(al);
+		const u32x4 vh = *reinterpret_cast<lds_u32x4_t *>(ah + 256);
+		acc[0] = xor3(acc[0], vl.x, vh.x);
+		acc[1] = xor3(acc[1], vl.y, vh.y);
+		acc[2] = xor3(acc[2], vl.z, vh.z);
+		acc[3] = xor3(acc[3], vl.w, vh.w);
 	}
 }
 
 // ---------------------------------------------------------------------------
 // Default kernel: wide nibble product tables in LDS.
-//   MW   = dwords per table entry (1: rows<=4, 2: rows<=8)
+//   MW   = dwords per table entry (1: rows<=4, 2: rows<=8, 4: rows<=16 -- reads the data ONCE for
+//          codes with 9..16 parity rows instead of once per 8-row group)
 //   MODE = store / compare-with-existing
 //   KC   = input shards loaded per batch (loads in flight per lane = KC*CPT)
 //   CPT  = 16-byte columns per thread per tile (strided by blockDim for coalescing)
@@ -160,6 +173,8 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 	constexpr int TBL = 32 * ENT;          // bytes per input shard (lo 16 | hi 16)
 	constexpr uint32_t nthr = TPB;
 	static_assert(TPB >= 192, "the log/antilog image is fetched one dword per thread");
+	static_assert(MW == 1 || MW == 2 || MW == 4, "table entries are 4, 8 or 16 bytes");
+	constexpr int CR = MW == 4 ? RMAX16 : RMAX;  // coefficient bytes per input shard in a.coef / lcoef
 	// single dynamic LDS object (no static __shared__ in front of it, so the base
 	// stays 16-byte aligned): [tables k*TBL][exp 512][log 256][coef k*8]
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -212,7 +227,7 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 	//    hipcc sink the load into it, behind the data loads, where it waits vmcnt(0))
 	const uint32_t le_idx = tid < 192 ? tid : 191;
 	const uint32_t le_word = reinterpret_cast<const uint32_t *>(le)[le_idx];
-	const uint32_t ncw = 2 * k;  // coefficient dwords
+	const uint32_t ncw = k * (CR / 4);  // coefficient dwords
 	const uint32_t coef_idx = tid < ncw ? tid : ncw - 1;
 	const uint32_t coef_word = reinterpret_cast<const uint32_t *>(&a.coef[0][0])[coef_idx];
 
@@ -237,20 +252,20 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 	for (uint32_t idx = tid; idx < k * 32; idx += nthr) {
 		const uint32_t t = idx >> 5, e = idx & 31;
 		const uint32_t x = e < 16 ? e : (e - 16) << 4;
-		uint32_t w[2] = {0, 0};
+		uint32_t w[MW] = {};
 		if (x) {
 			const uint32_t lx = llog[x];
 #pragma unroll
 			for (int r = 0; r < 4 * MW; ++r) {
-				const uint32_t c = lcoef[t * RMAX + r];  // rows beyond `rows` are 0
+				const uint32_t c = lcoef[t * CR + r];  // rows beyond `rows` are 0
 				const uint32_t p = c ? lexp[llog[c] + lx] : 0;
 				w[r >> 2] |= p << (8 * (r & 3));
 			}
 		}
 		uint32_t *tdst = reinterpret_cast<uint32_t *>(lds + t * TBL + e * ENT);
-		tdst[0] = w[0];
-		if (MW == 2)
-			tdst[1] = w[1];
+#pragma unroll
+		for (int h = 0; h < MW; ++h)
+			tdst[h] = w[h];
 	}
 	__syncthreads();
 
@@ -289,8 +304,8 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 				for (int w = 0; w < 4; ++w) {
 					const uint32_t x = xs[w];
 					// entry byte offsets of the lo / hi nibbles of all 4 bytes at once
-					const uint32_t lo = (MW == 1) ? ((x << 2) & 0x3C3C3C3Cu) : ((x << 3) & 0x78787878u);
-					const uint32_t hi = (MW == 1) ? ((x >> 2) & 0x3C3C3C3Cu) : ((x >> 1) & 0x78787878u);
+					const uint32_t lo = (MW == 1) ? ((x << 2) & 0x3C3C3C3Cu) : (MW == 2) ? ((x << 3) & 0x78787878u) : ((x << 4) & 0xF0F0F0F0u);
+					const uint32_t hi = (MW == 1) ? ((x >> 2) & 0x3C3C3C3Cu) : (MW == 2) ? ((x >> 1) & 0x78787878u) : (x & 0xF0F0F0F0u);
 					lut_acc<MW, 0>(tb, lo, hi, acc[c][w][0]);
 					lut_acc<MW, 1>(tb, lo, hi, acc[c][w][1]);
 					lut_acc<MW, 2>(tb, lo, hi, acc[c][w][2]);
@@ -315,8 +330,8 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 			continue;
 #pragma unroll
 		for (int r = 0; r < 4 * MW; ++r) {
-			if (r >= (int)rows)
-				break;
+			if (r >= (int)rows)  // `continue`, not `break`: with 16 rows hipcc keeps a `break` loop rolled and spills P[] to scratch
+				continue;
 			u32x4 v = {P[r][0], P[r][1], P[r][2], P[r][3]};
 			u32x4 *o = dstp[c] + a.out_off[r];
 			if (MODE == MODE_COMPARE) {

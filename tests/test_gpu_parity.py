@@ -79,8 +79,13 @@ ENCODE_CASES = [
     (1, 1, 128, 2), (2, 3, 192, 3), (5, 5, 320, 2), (17, 3, 1024, 2),
     (4, 8, 512, 2),        # 8-byte table entries
     (11, 7, 4096, 2),
-    (40, 12, 2048, 2),     # k beyond one load batch, rows > 8 (two launches)
-    (100, 20, 256, 1),
+    (40, 12, 2048, 2),     # k beyond one load batch, rows 9..16: ONE pass with 16-byte table entries
+    (3, 9, 640, 3),        # 16-byte entries, fewer shards than a load batch
+    (64, 16, 4160, 2),     # all 16 rows of an entry used, ragged tile
+    (120, 16, 256, 2),     # largest k the 16-row kernel takes
+    (121, 16, 256, 1),     # one beyond: two 8-row passes
+    (100, 20, 256, 1),     # 16 + 4 rows
+    (30, 40, 192, 2),      # 16 + 16 + 8
     (200, 56, 64, 1),      # k + m = 256
     (250, 6, 128, 1),      # 8-byte tables would need > 64 KiB of LDS: falls back to 4-row groups
     (255, 1, 64, 2),       # largest k
@@ -275,6 +280,27 @@ def test_host_encode_ragged_blocks(coracle):
     par_small = rs.encode_blocks([blocks[3]])[0]
     assert par_small.shape == (m, 64)
     assert np.array_equal(par_small, coracle.encode_batch(k, m, O.split_block(k, blocks[3])[None])[0])
+
+
+def test_sixteen_row_path_verify_and_reconstruct(coracle):
+    """Codes with 9..16 parity rows: verify (MODE_COMPARE) and a decode that rebuilds 13 shards
+    go through the 16-byte-entry kernel; same bytes as the oracle."""
+    k, m, S, nb = 24, 14, 1344, 4
+    rs = g.ReedSolomon(k, m)
+    data = rand_blocks(5, nb, k, S)
+    want = coracle.encode_batch(k, m, data, coracle.AVX2, threads=4)
+    full = np.concatenate([data, want], axis=1)
+    st = torch.from_numpy(full).to(DEV)
+    assert bool(rs.verify_dev(st).all())
+    st[2, k + 11, 777] ^= 0x40                      # a flip in a row only the upper half of an entry covers
+    ok = rs.verify_dev(st)
+    assert ok.tolist() == [True, True, False, True]
+    st[2, k + 11, 777] ^= 0x40
+    lost = [0, 1, 2, 5, 8, 13, 21, 23, 24, 25, 30, 36, 37]   # 8 data + 5 parity = 13 rows out
+    st[:, lost] = 0x33
+    rs.reconstruct_dev(st, [j not in lost for j in range(k + m)])
+    torch.cuda.synchronize()
+    assert np.array_equal(st.cpu().numpy(), full)
 
 
 def test_several_codecs_from_one_process_concurrently(coracle):

@@ -267,7 +267,7 @@ int main(int argc, char **argv)
 	vs.push_back({TAG, gf_apply_nibble_w<MW, MODE_STORE, KC, CPT, NT, THREADS, MINW>, THREADS, CPT, WG, true, true})
 #define NIB(MW, KC, CPT, NT, THREADS, MINW, WG, TAG) \
 	vs.push_back({TAG, gf_apply_nibble<MW, MODE_STORE, KC, CPT, NT, THREADS>, THREADS, CPT, WG, true, true})
-	const int MW = m <= 4 ? 1 : 2;
+	const int MW = m <= 4 ? 1 : m <= 8 ? 2 : 4;
 	if (MW == 1) {
 		NIB(1, 10, 1, true, 256, 0, 0, "nib kc10 cpt1 nt  t256 (default)");
 		NIBW(1, 10, 1, true, 256, 5, 0, "nib kc10 cpt1 nt  t256 w5");
@@ -282,6 +282,14 @@ int main(int argc, char **argv)
 		NIB(1, 10, 1, true, 192, 0, 0, "nib kc10 cpt1 nt  t192");
 		NIB(1, 10, 1, true, 448, 0, 0, "nib kc10 cpt1 nt  t448");
 		NIB(1, 10, 1, true, 512, 0, 0, "nib kc10 cpt1 nt  t512");
+	} else if (MW == 4) {
+		NIB(4, 4, 1, true, 512, 0, 0, "nib16 kc4 cpt1 nt t512 (default)");
+		NIB(4, 3, 1, true, 256, 0, 0, "nib16 kc3 cpt1 nt t256");
+		NIB(4, 2, 1, true, 256, 0, 0, "nib16 kc2 cpt1 nt t256");
+		NIB(4, 4, 1, true, 192, 0, 0, "nib16 kc4 cpt1 nt t192");
+		NIB(4, 4, 1, true, 320, 0, 0, "nib16 kc4 cpt1 nt t320");
+		NIB(4, 4, 1, true, 384, 0, 0, "nib16 kc4 cpt1 nt t384");
+		NIB(4, 4, 1, true, 256, 0, 0, "nib16 kc4 cpt1 nt t256");
 	} else {
 		NIB(2, 5, 1, true, 512, 0, 0, "nib8 kc5  cpt1 nt t512 (default)");
 		NIB(2, 5, 1, true, 384, 0, 0, "nib8 kc5  cpt1 nt t384");
@@ -293,7 +301,8 @@ int main(int argc, char **argv)
 		NIBW(2, 5, 1, true, 512, 6, 0, "nib8 kc5  cpt1 nt t512 w6");
 		NIBW(2, 5, 1, true, 512, 5, 0, "nib8 kc5  cpt1 nt t512 w5");
 	}
-	vs.push_back({"logexp baseline (north_star literal)", gf_apply_logexp<MODE_STORE>, 256, 1, 8, false, true});
+	if (MW != 4)  // the baseline kernel takes at most 8 rows (and the 8-byte coefficient layout)
+		vs.push_back({"logexp baseline (north_star literal)", gf_apply_logexp<MODE_STORE>, 256, 1, 8, false, true});
 
 	ApplyArgs a;
 	memset(&a, 0, sizeof(a));
@@ -304,13 +313,14 @@ int main(int argc, char **argv)
 	a.cols = (uint32_t)(S / 16);
 	a.nblocks = (uint32_t)nb;
 	a.k = k;
-	a.rows = std::min(m, RMAX);
+	a.rows = std::min(m, MW == 4 ? RMAX16 : RMAX);
+	const int CR = MW == 4 ? RMAX16 : RMAX;
 	for (int t = 0; t < k; ++t)
 		a.in_off[t] = (uint32_t)((size_t)t * S / 16);
 	for (int r = 0; r < (int)a.rows; ++r) {
 		a.out_off[r] = (uint32_t)((size_t)(k + r) * S / 16);
 		for (int t = 0; t < k; ++t)
-			a.coef[t][r] = enc.row(k + r)[t];
+			(&a.coef[0][0])[t * CR + r] = enc.row(k + r)[t];
 	}
 
 	hipEvent_t e0, e1;
@@ -320,7 +330,7 @@ int main(int argc, char **argv)
 	std::vector<long long> diffs(vs.size(), -1);
 	// KBENCH_WG_PER_CU=n pads the dynamic LDS request so that at most n workgroups fit a CU's
 	// 160 KiB: an occupancy knob that does not touch the code under test
-	size_t lds = (size_t)k * 32 * 4 * MW + 768 + (size_t)k * RMAX;
+	size_t lds = (size_t)k * 32 * 4 * MW + 768 + (size_t)k * CR;
 	if (getenv("KBENCH_WG_PER_CU")) {
 		const size_t cap = (160u << 10) / std::max(1, atoi(getenv("KBENCH_WG_PER_CU")));
 		lds = std::max(lds, std::min<size_t>(cap - 512, 64u << 10));
