@@ -14,10 +14,11 @@
 //    geometry), one global_store_dwordx4 per output shard.
 //  * GF multiply = two LDS lookups per data byte in *wide nibble product
 //    tables*: for input shard t, T_lo[t][x&15] and T_hi[t][x>>4] are 4-byte
-//    (rows<=4) or 8-byte (rows<=8) entries holding the products for ALL output
-//    rows at once, so one ds_read feeds every parity accumulator.  A 16-entry
-//    table occupies 16 (resp. 32) distinct LDS banks, and lanes that hit the
-//    same entry broadcast, so the lookups are bank-conflict-free for any data.
+//    (rows<=4), 8-byte (rows<=8) or 16-byte (rows<=16) entries holding the
+//    products for ALL output rows at once, so one ds_read feeds every parity
+//    accumulator.  A 16-entry table occupies 16 (resp. 32, 64) distinct LDS
+//    banks, and lanes that hit the same entry broadcast, so the lookups are
+//    bank-conflict-free for any data.
 //  * The tables are expanded per workgroup from the k x rows coefficient
 //    matrix with log/antilog LUTs that are themselves pinned in LDS.
 //  * Accumulators stay in VGPRs in "row-interleaved" form (byte r of a dword =
