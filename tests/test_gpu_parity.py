@@ -575,11 +575,11 @@ from hypothesis import strategies as hst  # noqa: E402
 
 
 @settings(max_examples=120, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
-@given(k=hst.integers(1, 33), m=hst.integers(1, 9), cols4=hst.integers(1, 80), nb=hst.integers(1, 4),
+@given(k=hst.integers(1, 33), m=hst.integers(1, 20), cols4=hst.integers(1, 80), nb=hst.integers(1, 4),
        seed=hst.integers(0, 2**31), data_only=hst.booleans())
 def test_random_codes_encode_verify_reconstruct(coracle, k, m, cols4, nb, seed, data_only):
     """Every (k, m) lands on a different load-batch size / table width / launch count
-    (k mod KC remainders use clamped duplicate loads; m > 8 needs two launches);
+    (k mod KC remainders use clamped duplicate loads; m in 9..16 takes the 16-byte-entry kernel, m > 16 several launches);
     S sweeps ragged tile fills.  Encode, verify and a random reconstruct, all bit-exact."""
     S = 64 * cols4
     rng = np.random.default_rng(seed)
