@@ -303,6 +303,23 @@ def test_sixteen_row_path_verify_and_reconstruct(coracle):
     assert np.array_equal(st.cpu().numpy(), full)
 
 
+def test_upstream_mul_slice_kats_on_the_gpu():
+    """The Backblaze ports' constant-times-slice vectors (see tests/test_oracle_kat.py) through the
+    kernels, no oracle involved: RS(22,5) has coefficient 25 at parity row 4 / shard 2 and RS(19,2)
+    has 177 at row 1 / shard 6, so with every other shard zero that parity shard IS c * slice."""
+    inp = [0, 1, 2, 3, 4, 5, 6, 10, 50, 100, 150, 174, 201, 255, 99, 32, 67, 85]
+    want = {25: [0x0, 0x19, 0x32, 0x2b, 0x64, 0x7d, 0x56, 0xfa, 0xb8, 0x6d, 0xc7, 0x85, 0xc3, 0x1f, 0x22, 0x7, 0x25, 0xfe],
+            177: [0x0, 0xb1, 0x7f, 0xce, 0xfe, 0x4f, 0x81, 0x9e, 0x3, 0x6, 0xe8, 0x75, 0xbd, 0x40, 0x36, 0xa3, 0x95, 0xcb]}
+    for c, (k, m, r, t) in {25: (22, 5, 4, 2), 177: (19, 2, 1, 6)}.items():
+        rs = g.ReedSolomon(k, m)
+        assert int(rs.parity_matrix()[r][t]) == c
+        st = torch.zeros((1, k + m, 64), dtype=torch.uint8, device=DEV)
+        st[0, t, :18] = torch.tensor(inp, dtype=torch.uint8)
+        rs.encode_dev(st)
+        assert st[0, k + r, :18].cpu().tolist() == want[c]
+        assert not st[0, k + r, 18:].any()
+
+
 def test_several_codecs_from_one_process_concurrently(coracle):
     """One process driving several devices = one codec per device, each with its own streams,
     staging and copy threads.  Only one GPU is visible here, so three codecs on cuda:0 stand

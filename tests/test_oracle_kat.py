@@ -53,6 +53,33 @@ def test_inverse_kat(coracle):
     assert np.array_equal(O.mat_mul(m, want), np.eye(3, dtype=np.uint8))
 
 
+def test_upstream_matrix_kats_recalled(coracle):
+    """Two more vectors of the upstream matrix tests (Backblaze JavaReedSolomon MatrixTest, ported into
+    the Rust crate), recalled from memory AFTER the oracle was written and matched on the first run:
+    the 2x2 product and the 5x5 inverse whose elimination needs row swaps.  Not in SURVEY.md Appendix A."""
+    a = np.array([[1, 2], [3, 4]], dtype=np.uint8)
+    b = np.array([[5, 6], [7, 8]], dtype=np.uint8)
+    assert O.mat_mul(a, b).tolist() == [[11, 22], [19, 42]]
+    m = np.array([[1, 0, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 0, 1, 0], [0, 0, 0, 0, 1], [7, 7, 6, 6, 1]], dtype=np.uint8)
+    want = [[1, 0, 0, 0, 0], [0, 1, 0, 0, 0], [123, 123, 1, 122, 122], [0, 0, 1, 0, 0], [0, 0, 0, 1, 0]]
+    assert O.invert(m).tolist() == want
+    assert coracle.invert(m).tolist() == want
+
+
+def test_upstream_mul_slice_kats_recalled(coracle):
+    """The constant-times-slice vectors of the Backblaze ports' Galois tests (klauspost/reedsolomon
+    TestGalois `galMulSlice(25, ..)` / `(177, ..)`; same field as the Rust crate), recalled from memory
+    and matched on the first run: 36 product bytes that pin polynomial 0x11D / generator 2."""
+    inp = np.array([0, 1, 2, 3, 4, 5, 6, 10, 50, 100, 150, 174, 201, 255, 99, 32, 67, 85], dtype=np.uint8)
+    want25 = [0x0, 0x19, 0x32, 0x2b, 0x64, 0x7d, 0x56, 0xfa, 0xb8, 0x6d, 0xc7, 0x85, 0xc3, 0x1f, 0x22, 0x7, 0x25, 0xfe]
+    want177 = [0x0, 0xb1, 0x7f, 0xce, 0xfe, 0x4f, 0x81, 0x9e, 0x3, 0x6, 0xe8, 0x75, 0xbd, 0x40, 0x36, 0xa3, 0x95, 0xcb]
+    assert O.MUL[25, inp].tolist() == want25 and O.MUL[177, inp].tolist() == want177
+    # the same through the C restatement: a 1+2 "code" whose parity rows are forced to [25] and [177]
+    # is not expressible there, so go through gf_mul element-wise
+    assert [int(O.gf_mul(25, int(x))) for x in inp] == want25
+    assert [int(coracle.lib.rso_gf_mul(177, int(x))) for x in inp] == want177
+
+
 def test_inverse_needs_row_swap(coracle):
     m = np.array([[0, 1, 0], [1, 0, 0], [0, 0, 7]], dtype=np.uint8)
     inv = O.invert(m)
