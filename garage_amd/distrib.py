@@ -39,6 +39,9 @@ def init_from_env(force_backend: str | None = None) -> Ranks:
         local_rank = 0
         force_backend = "gloo"
     if use_cuda:
+        # a launcher may already have narrowed each rank to its own GPU (HIP_VISIBLE_DEVICES):
+        # then every rank sees one device, index 0
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
     else:
