@@ -27,6 +27,13 @@
  * data shards of S = round_up(ceil(L/k), 64) bytes, shard i = block bytes
  * [i*S, (i+1)*S) zero-extended, so data shards are zero-copy slices of the
  * (padded) block buffer and every shard starts on a 64-byte line.
+ *
+ * Environment (all optional, read once per process; none changes results):
+ *   GEC_COPY_THREADS=n          staging-copy threads per codec for the host-pointer calls (default 7)
+ *   GEC_RCCL_LIB=path           RCCL to dlopen for gec_group_* (default librccl.so.1)
+ *   GEC_ROWS16=0                A/B: 9..16 output rows as 8-row passes instead of one 16-row pass
+ *   GEC_BLAKE2_KERNEL=lane|quad A/B: force one of the two blake2 kernels
+ *   GEC_MAX_COLS_PER_LAUNCH=n   test hook: exercise the multi-launch split on small inputs
  */
 #ifndef GARAGE_EC_H
 #define GARAGE_EC_H
