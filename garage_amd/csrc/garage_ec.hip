@@ -710,9 +710,9 @@ struct StagingLease {
 	}
 };
 
-// blocks per staging chunk: keep chunks around 64 MiB so that staging memory is
-// bounded regardless of batch size.
-size_t chunk_blocks(size_t bytes_per_block, size_t nblocks, size_t target = 64ull << 20)
+// blocks per staging chunk of about `target` bytes (callers pass kChunkBytes or a multiple):
+// staging memory stays bounded whatever the batch size.
+size_t chunk_blocks(size_t bytes_per_block, size_t nblocks, size_t target)
 {
 	size_t n = std::max<size_t>(1, target / std::max<size_t>(bytes_per_block, 1));
 	return std::min(n, nblocks);
