@@ -420,17 +420,26 @@ uint64_t launch_cols_limit()
 	return v;
 }
 
-// Loads per batch (tools/kbench sweep over k = 8..32, profiles/r01_kbench_kc_sweep.txt): k itself
-// when small; with 4-byte entries a batch of 10 whenever the duplicate (index-clamped, cache-hit)
-// loads of its last batch stay within a quarter of k -- fewer, larger batches win even with some
-// waste; otherwise the candidate that wastes the fewest (ties: the larger).
+// Loads per batch (tools/kbench sweeps, profiles/r01_kbench_kc_sweep.txt): k itself when small;
+// with 4-byte entries one batch of 10 / 12 / 16 for k <= 16, beyond that batches of 10 whenever
+// the duplicate (index-clamped, cache-hit) loads of the last batch stay within a quarter of k --
+// fewer, larger batches win even with some waste; otherwise the candidate that wastes the fewest
+// (ties: the larger).
 int choose_kc(int k, int mw)
 {
 	if (k <= 6)
 		return k;
 	if (mw == 1) {
+		// up to 16 shards: ONE batch (all loads in flight before the table expansion) beats two
+		// by 2-3 % even at 150 VGPRs / 3 waves per SIMD; 20 in one batch is too many (-10 %)
+		if (k <= 10)
+			return 10;
+		if (k <= 12)
+			return 12;
+		if (k <= 16)
+			return 16;
 		const int w10 = (k + 9) / 10 * 10 - k;
-		if (k <= 10 || w10 * 4 <= k)
+		if (w10 * 4 <= k)
 			return 10;
 	}
 	int best = 0, waste = 1 << 30;
@@ -453,6 +462,14 @@ void launch_nibble(const gec::ApplyArgs &a, const gec::LogExp *le, unsigned grid
 	if constexpr (MW == 1) {
 		if (kc == 10) {
 			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 10, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, a, le);
+			return;
+		}
+		if (kc == 12) {
+			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 12, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, a, le);
+			return;
+		}
+		if (kc == 16) {
+			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 16, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, a, le);
 			return;
 		}
 	}

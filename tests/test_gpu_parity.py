@@ -77,6 +77,7 @@ ENCODE_CASES = [
     (10, 4, 64, 1),        # one 16-byte-column row per lane, mostly idle lanes
     (10, 4, 4160, 5),      # ragged tile (260 columns)
     (1, 1, 128, 2), (2, 3, 192, 3), (5, 5, 320, 2), (17, 3, 1024, 2),
+    (11, 4, 4160, 2), (12, 3, 1024, 2), (13, 4, 4160, 2), (16, 4, 2048, 3),   # one batch of 12 / 16 loads
     (4, 8, 512, 2),        # 8-byte table entries
     (11, 7, 4096, 2),
     (40, 12, 2048, 2),     # k beyond one load batch, rows 9..16: ONE pass with 16-byte table entries

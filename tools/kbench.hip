@@ -276,6 +276,9 @@ int main(int argc, char **argv)
 		NIBW(1, 10, 1, true, 256, 3, 0, "nib kc10 cpt1 nt  t256 w3");
 		NIB(1, 5, 1, true, 256, 0, 0, "nib kc5  cpt1 nt  t256");
 		NIB(1, 4, 1, true, 256, 0, 0, "nib kc4  cpt1 nt  t256");
+		NIB(1, 12, 1, true, 256, 0, 0, "nib kc12 cpt1 nt  t256");
+		NIB(1, 16, 1, true, 256, 0, 0, "nib kc16 cpt1 nt  t256");
+		NIB(1, 20, 1, true, 256, 0, 0, "nib kc20 cpt1 nt  t256");
 		NIB(1, 6, 1, true, 256, 0, 0, "nib kc6  cpt1 nt  t256");
 		NIB(1, 10, 1, true, 320, 0, 0, "nib kc10 cpt1 nt  t320");
 		NIB(1, 10, 1, true, 384, 0, 0, "nib kc10 cpt1 nt  t384");
