@@ -429,6 +429,8 @@ int choose_kc(int k, int mw)
 {
 	if (k <= 6)
 		return k;
+	if (mw == 2 && k <= 10)  // one batch, in the 256-thread geometry (threads_for): +3-4 % on RS(8,8) / RS(10,8)
+		return 10;
 	if (mw == 1) {
 		// up to 16 shards: ONE batch (all loads in flight before the table expansion) beats two
 		// by 2-3 % even at 150 VGPRs / 3 waves per SIMD; 20 in one batch is too many (-10 %)
@@ -453,12 +455,28 @@ int choose_kc(int k, int mw)
 	return best;
 }
 
+// Workgroup size that goes with (table width, loads per batch).
+int threads_for(int mw, int kc)
+{
+	if (mw == 1)
+		return kThreadsMW1;
+	if (mw == 2)
+		return kc == 10 ? 256 : kThreadsMW2;  // 10 loads in flight per lane need the 256-thread register budget
+	return kThreadsMW4;
+}
+
 template <int MW, int MODE, int TPB>
 void launch_nibble(const gec::ApplyArgs &a, const gec::LogExp *le, unsigned grid, size_t lds, hipStream_t s)
 {
 	int kc = choose_kc((int)a.k, MW);
 	if constexpr (MW == 4)  // register budget (64 accumulator VGPRs): at most 4 shards in flight
 		kc = std::min<int>((int)a.k, 4);
+	if constexpr (MW == 2) {
+		if (kc == 10) {
+			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 10, kCPT, true, 256>), dim3(grid), dim3(256), lds, s, a, le);
+			return;
+		}
+	}
 	if constexpr (MW == 1) {
 		if (kc == 10) {
 			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 10, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, a, le);
@@ -568,7 +586,7 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 		}
 		// The (block, column) space is flattened: a launch covers a range of whole blocks
 		// whose columns fit 32 bits and whose tiles fit HIP's grid limit (grid*block < 2^32).
-		const int threads = mw == 1 ? kThreadsMW1 : mw == 2 ? kThreadsMW2 : kThreadsMW4;
+		const int threads = threads_for(mw, choose_kc(k, mw));
 		const uint64_t tile_cols = (uint64_t)threads * kCPT;
 		uint64_t max_cols = std::min<uint64_t>(0xfffff000ull, (0xffffffffull / threads - 8) * tile_cols);
 		if (launch_cols_limit())

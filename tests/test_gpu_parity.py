@@ -79,6 +79,7 @@ ENCODE_CASES = [
     (1, 1, 128, 2), (2, 3, 192, 3), (5, 5, 320, 2), (17, 3, 1024, 2),
     (11, 4, 4160, 2), (12, 3, 1024, 2), (13, 4, 4160, 2), (16, 4, 2048, 3),   # one batch of 12 / 16 loads
     (4, 8, 512, 2),        # 8-byte table entries
+    (7, 5, 1024, 2), (8, 8, 4160, 2), (10, 8, 104896, 2),   # 8-byte entries, one batch of 10 loads, 256 threads
     (11, 7, 4096, 2),
     (40, 12, 2048, 2),     # k beyond one load batch, rows 9..16: ONE pass with 16-byte table entries
     (3, 9, 640, 3),        # 16-byte entries, fewer shards than a load batch
