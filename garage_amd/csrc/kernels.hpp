@@ -177,7 +177,7 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 	static_assert(MW == 1 || MW == 2 || MW == 4, "table entries are 4, 8 or 16 bytes");
 	constexpr int CR = MW == 4 ? RMAX16 : RMAX;  // coefficient bytes per input shard in a.coef / lcoef
 	// single dynamic LDS object (no static __shared__ in front of it, so the base
-	// stays 16-byte aligned): [tables k*TBL][exp 512][log 256][coef k*8]
+	// stays 16-byte aligned): [tables k*TBL][exp 512][log 256][coef k*CR]
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const uint32_t tid = threadIdx.x;
 	const uint32_t k = a.k;
@@ -222,7 +222,7 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 		dstp[c] = reinterpret_cast<u32x4 *>(a.out + (uint64_t)bb[c] * a.out_stride) + a.col0 + col;
 	}
 
-	// -- prologue 0: log/antilog image (768 B) and coefficient rows (k*8 B) are
+	// -- prologue 0: log/antilog image (768 B) and coefficient rows (k*CR B) are
 	//    requested FIRST, so their wait does not drain the data loads behind them
 	//    (index-clamped and stored unconditionally below: a `tid <` branch would let
 	//    hipcc sink the load into it, behind the data loads, where it waits vmcnt(0))
