@@ -1,0 +1,46 @@
+"""bench.py's one-line JSON contract (task statement, section 4), checked on CPU against a line
+recorded on an MI355X (profiles/r01_bench_line.json = `python bench.py` with no flags) and against
+bench.py's source, so that a later edit cannot silently drop a field the driver or the judge reads."""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TOP = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "steps": int, "warmup": int,
+       "ms_per_step": (int, float), "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict,
+       "roofline": dict, "cpu_baseline": dict}
+ROOFLINE = {"bound": str, "achieved": (int, float), "peak": (int, float), "unit": str, "frac": (int, float)}
+CPU = {"value": (int, float), "unit": str, "cores": int, "kind": str, "sample": str}
+
+
+def test_recorded_line_has_the_contract_fields():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_line.json")))
+    for k, t in TOP.items():
+        assert isinstance(d[k], t), k
+    assert "vs_baseline" in d and d["vs_baseline"] is None          # BASELINE.md has no published number
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "u8" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k, t in ROOFLINE.items():
+        assert isinstance(r[k], t), k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
+    # achieved = algorithmic bytes per launch / average launch duration
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 2e-3
+    # config 2 batch = 1024 * 14 * 104896 bytes
+    assert r["algorithmic_bytes_per_launch"] == 1503789056
+    c = d["cpu_baseline"]
+    for k, t in CPU.items():
+        assert isinstance(c[k], t), k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+    # value = payload of all timed steps / time: 1024 blocks of 1 MiB per step
+    assert abs(d["value"] - 1024 * 2**20 / (d["ms_per_step"] * 1e-3) / 2**30) / d["value"] < 2e-3
+
+
+def test_bench_source_still_emits_every_field():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in list(TOP) + ["vs_baseline"] + list(ROOFLINE) + ["traffic"] + list(CPU):
+        assert re.search(rf'"{key}"\s*:', src) or f'out["{key}"]' in src, key
+    assert "max_over_ranks" in src and "barrier()" in src and "torch.cuda.synchronize()" in src
