@@ -49,8 +49,8 @@ int fail(int code, const std::string &detail)
 	do {                                                                           \
 		hipError_t e_ = (expr);                                                \
 		if (e_ != hipSuccess)                                                  \
-			return fail(GEC_E_DEVICE, std::string(#expr) + ": " +          \
-							  hipGetErrorString(e_));      \
+			return fail(e_ == hipErrorOutOfMemory ? GEC_E_NOMEM : GEC_E_DEVICE, \
+				    std::string(#expr) + ": " + hipGetErrorString(e_)); \
 	} while (0)
 
 // Restores the calling thread's current device on scope exit (torch and other
