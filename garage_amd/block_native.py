@@ -22,7 +22,7 @@ SYMBOLS = [
     "gbm_block_incref", "gbm_block_decref", "gbm_resync_block", "gbm_resync_all", "gbm_resync_queue_len",
     "gbm_scrub", "gbm_node_set_down", "gbm_node_has_shard", "gbm_node_delete_shard",
     "gbm_node_corrupt_shard", "gbm_metrics", "gbm_gpu_hashed",
-    "gbm_batcher_create", "gbm_batcher_destroy", "gbm_batcher_put_block", "gbm_batcher_stats",
+    "gbm_batcher_create", "gbm_batcher_destroy", "gbm_batcher_put_block", "gbm_batcher_set_ram_buffer_max", "gbm_batcher_stats",
 ]
 
 
@@ -81,6 +81,7 @@ def _load():
     lib.gbm_batcher_destroy.restype = None
     lib.gbm_batcher_put_block.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, sz]
     lib.gbm_batcher_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.gbm_batcher_set_ram_buffer_max.argtypes = [vp, ctypes.c_size_t]
     lib.gbm_gpu_hashed.argtypes = [vp]
     lib.gbm_gpu_hashed.restype = ctypes.c_uint64
     return lib
@@ -219,11 +220,14 @@ class NativeBlockManager:
 class Batcher:
     """gbm_batcher: thread-safe put_block() calls coalesced into device batches."""
 
-    def __init__(self, manager: NativeBlockManager, max_blocks: int = 64, max_wait_us: int = 200):
+    def __init__(self, manager: NativeBlockManager, max_blocks: int = 64, max_wait_us: int = 200,
+                 ram_buffer_max: Optional[int] = None):
         self.manager = manager  # keep alive
         h = ctypes.c_void_p()
         _check(lib.gbm_batcher_create(manager._h, max_blocks, max_wait_us, ctypes.byref(h)), "gbm_batcher_create")
         self._h = h
+        if ram_buffer_max is not None:  # Config.block_ram_buffer_max (default 256 MiB)
+            _check(lib.gbm_batcher_set_ram_buffer_max(self._h, ram_buffer_max), "gbm_batcher_set_ram_buffer_max")
 
     def close(self):
         if getattr(self, "_h", None):

@@ -1102,8 +1102,11 @@ struct gbm_batcher {
 	gbm_manager *mg = nullptr;
 	size_t max_blocks = 64;
 	unsigned max_wait_us = 200;
+	// buffer_kb_semaphore (src/block/manager.rs:96,156,380-384): KiB permits for the bytes of blocks on
+	// their way to the storage nodes, Config.block_ram_buffer_max (default 256 MiB, src/util/config.rs:276-278)
+	size_t ram_permits_kb = 256 * 1024, ram_in_use_kb = 0;
 	std::mutex mu;
-	std::condition_variable cv_work, cv_done;
+	std::condition_variable cv_work, cv_done, cv_ram;
 	std::deque<Item *> queue;
 	bool stop = false;
 	uint64_t batches = 0, blocks = 0, max_batch = 0;
@@ -1149,7 +1152,9 @@ struct gbm_batcher {
 				// a whole-batch failure (device error) hits every block of the batch
 				batch[i]->rc = (rc != GBM_OK && rc != GBM_E_QUORUM) ? rc : rcs[i];
 				batch[i]->done = true;
+				ram_in_use_kb -= batch[i]->len / 1024;  // the permit is dropped once all sends finished
 			}
+			cv_ram.notify_all();
 			++batches;
 			blocks += nb;
 			max_batch = std::max<uint64_t>(max_batch, nb);
@@ -1180,6 +1185,7 @@ void gbm_batcher_destroy(gbm_batcher *b)
 		b->stop = true;
 	}
 	b->cv_work.notify_all();
+	b->cv_ram.notify_all();
 	b->worker.join();
 	delete b;
 }
@@ -1193,8 +1199,15 @@ int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t 
 	it.data = data;
 	it.len = len;
 	std::unique_lock<std::mutex> lk(b->mu);
+	// acquire len/1024 permits; a block larger than the whole budget could never be sent (Garage's
+	// acquire_many would wait forever): refuse it instead
+	const size_t need_kb = len / 1024;
+	if (need_kb > b->ram_permits_kb)
+		return fail(GBM_E_INVALID_ARG, "could not reserve space for buffer of data to send to remote nodes");
+	b->cv_ram.wait(lk, [&] { return b->stop || b->ram_in_use_kb + need_kb <= b->ram_permits_kb; });
 	if (b->stop)
 		return fail(GBM_E_INVALID_ARG, "batcher is shutting down");
+	b->ram_in_use_kb += need_kb;
 	b->queue.push_back(&it);
 	b->cv_work.notify_one();
 	b->cv_done.wait(lk, [&] { return it.done; });
@@ -1202,6 +1215,16 @@ int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t 
 		return fail(it.rc, "Could not reach quorum");
 	if (it.rc != GBM_OK)
 		return fail(it.rc, "device batch failed");
+	return GBM_OK;
+}
+
+int gbm_batcher_set_ram_buffer_max(gbm_batcher *b, size_t bytes)
+{
+	if (!b || bytes < 1024)
+		return fail(GBM_E_INVALID_ARG, "bad ram buffer size");
+	std::lock_guard<std::mutex> g(b->mu);
+	b->ram_permits_kb = bytes / 1024;
+	b->cv_ram.notify_all();
 	return GBM_OK;
 }
 

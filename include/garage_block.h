@@ -97,6 +97,11 @@ typedef struct gbm_batcher gbm_batcher;
 int gbm_batcher_create(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, gbm_batcher **out);
 void gbm_batcher_destroy(gbm_batcher *b);
 int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t *data, size_t len);
+/* Config.block_ram_buffer_max (src/util/config.rs:74-76,276-278; default 256 MiB): bytes of blocks that
+ * may be on their way to the storage nodes at once.  gbm_batcher_put_block takes len/1024 permits before it
+ * queues the block and returns them when its batch has been fanned out (buffer_kb_semaphore,
+ * src/block/manager.rs:380-384); callers beyond the budget wait. */
+int gbm_batcher_set_ram_buffer_max(gbm_batcher *b, size_t bytes);
 /* out = { device batches issued, blocks put, largest batch } */
 int gbm_batcher_stats(gbm_batcher *b, uint64_t out[3]);
 

@@ -189,6 +189,29 @@ static void run_batcher(int k, int m)
 	uint64_t st[3];
 	CHECK(gbm_batcher_stats(bt, st) == GBM_OK);
 	CHECK(st[1] == (uint64_t)T * PER && st[0] < st[1] && st[2] >= 2 && st[2] <= 16);
+	// block_ram_buffer_max: with a budget of ~2 blocks the 8 callers still all get through (they wait for
+	// permits), batches can no longer exceed the budget, and an oversized block is refused, not queued
+	CHECK(gbm_batcher_set_ram_buffer_max(nullptr, 1 << 20) == GBM_E_INVALID_ARG);
+	CHECK(gbm_batcher_set_ram_buffer_max(bt, 100 * 1024) == GBM_OK);
+	uint64_t before[3], after[3];
+	CHECK(gbm_batcher_stats(bt, before) == GBM_OK);
+	{
+		std::vector<std::thread> th2;
+		std::vector<int> rc2(T, -999);
+		for (int t = 0; t < T; ++t)
+			th2.emplace_back([&, t] { rc2[t] = gbm_batcher_put_block(bt, hashes.data() + 32 * t, blocks[t].data(), blocks[t].size()); });
+		for (auto &x : th2)
+			x.join();
+		for (int t = 0; t < T; ++t)
+			CHECK(rc2[t] == GBM_OK);
+	}
+	CHECK(gbm_batcher_stats(bt, after) == GBM_OK);
+	CHECK(after[1] == before[1] + T && after[0] - before[0] >= (uint64_t)T / 2);  // <= 2 blocks (~40-47 KB each) per batch
+	std::vector<uint8_t> big(300 * 1024, 7);
+	uint8_t bigh[32];
+	gbm_blake2sum(big.data(), big.size(), bigh);
+	CHECK(gbm_batcher_put_block(bt, bigh, big.data(), big.size()) == GBM_E_INVALID_ARG);
+	CHECK(gbm_batcher_set_ram_buffer_max(bt, 256u << 20) == GBM_OK);
 	// a quorum failure is reported to the caller whose block it was
 	std::vector<int> who(k + m);
 	CHECK(gbm_storage_nodes_of(mg, hashes.data(), who.data()) == GBM_OK);
