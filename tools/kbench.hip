@@ -381,7 +381,8 @@ int main(int argc, char **argv)
 		// steady-state (power-managed) rate: N untimed launches to let the DVFS
 		// controller settle on this kernel's power draw, then N timed ones
 		printf("# sustained mode: %d warm + %d timed back-to-back launches per variant\n", sustained, sustained);
-		for (size_t i = 0; i < vs.size(); ++i) {
+		// KBENCH_FIRST_ONLY=1: only the default variant, then the ceilings (for power sampling)
+		for (size_t i = 0; i < (getenv("KBENCH_FIRST_ONLY") ? 1 : vs.size()); ++i) {
 			for (int q = 0; q < sustained; ++q)
 				launch(vs[i]);
 			CK(hipEventRecord(e0, 0));
