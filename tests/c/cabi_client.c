@@ -4,7 +4,8 @@
  *   cabi_client            host-logic checks only (runs without a GPU)
  *   cabi_client gpu        + encode / verify / reconstruct through the host API,
  *                            checked against the RS(3,1) parity == XOR identity and
- *                            an encode -> erase -> reconstruct round trip; also runs
+ *                            an encode -> erase -> reconstruct round trip; blake2sum
+ *                            on the device against the RFC 7693 vector; also runs
  *                            4 threads on one shared codec.
  * exit code 0 = all good. */
 #include <pthread.h>
@@ -128,6 +129,42 @@ int main(int argc, char **argv)
 	const uint8_t *sh2[4] = {blk, NULL, NULL, par};
 	uint8_t *outp[4] = {NULL, NULL, NULL, NULL};
 	CHECK(gec_reconstruct_batch(c, 1, sh2, outp, S, 0) == GEC_E_TOO_FEW_PRESENT);
+	gec_codec_destroy(c);
+
+	/* ---- blake2sum on the device: RFC 7693 "abc" (blake2b-512, first 32 bytes = Garage's blake2sum),
+	 *      the empty message, and encode + shard checksums in one call ---- */
+	CHECK(gec_codec_create(10, 4, 0, &c) == GEC_OK);
+	{
+		static const uint8_t abc_want[32] = {0xba, 0x80, 0xa5, 0x3f, 0x98, 0x1c, 0x4d, 0x0d, 0x6a, 0x27, 0x97,
+						     0xb6, 0x9f, 0x12, 0xf6, 0xe9, 0x4c, 0x21, 0x2f, 0x14, 0x68, 0x5a,
+						     0xc4, 0xb7, 0x4b, 0x12, 0xbb, 0x6f, 0xdb, 0xff, 0xa2, 0xd1};
+		static const uint8_t empty_want[8] = {0x78, 0x6a, 0x02, 0xf7, 0x42, 0x01, 0x59, 0x03};
+		const uint8_t *msgs[2] = {(const uint8_t *)"abc", (const uint8_t *)""};
+		const size_t lens[2] = {3, 0};
+		uint8_t sums[64];
+		CHECK(gec_blake2sum_batch(c, 2, msgs, lens, sums) == GEC_OK);
+		CHECK(memcmp(sums, abc_want, 32) == 0 && memcmp(sums + 32, empty_want, 8) == 0);
+
+		const size_t L2 = 300000, S2 = gec_shard_len(10, L2);
+		uint8_t *b2 = (uint8_t *)calloc(10 * S2, 1), *p2 = (uint8_t *)malloc(4 * S2), *p3 = (uint8_t *)malloc(4 * S2);
+		fill(b2, L2, 99);
+		const uint8_t *bl[1] = {b2};
+		uint8_t *pa[1] = {p2}, *pb[1] = {p3};
+		uint8_t shard_sums[14 * 32], direct[14 * 32];
+		CHECK(gec_encode_hash_batch(c, 1, bl, &L2, S2, pa, shard_sums) == GEC_OK);
+		CHECK(gec_encode_batch(c, 1, bl, &L2, S2, pb) == GEC_OK && memcmp(p2, p3, 4 * S2) == 0);
+		const uint8_t *sp[14];
+		size_t sl[14];
+		for (int j = 0; j < 14; j++) {
+			sp[j] = j < 10 ? b2 + j * S2 : p2 + (j - 10) * S2;
+			sl[j] = S2;
+		}
+		CHECK(gec_blake2sum_batch(c, 14, sp, sl, direct) == GEC_OK);
+		CHECK(memcmp(shard_sums, direct, sizeof direct) == 0);
+		free(b2);
+		free(p2);
+		free(p3);
+	}
 	gec_codec_destroy(c);
 
 	/* ---- 4 threads sharing one RS(10,4) codec (Send + Sync on the Rust side) ---- */
