@@ -41,6 +41,7 @@ SYMBOLS = [
     "gec_encode_hash_batch", "gec_set_kernel_variant", "gec_get_kernel_variant",
     "gec_group_unique_id", "gec_group_create", "gec_group_create_with_transport", "gec_group_destroy",
     "gec_group_rank", "gec_group_size", "gec_group_slots", "gec_group_allgather_decode",
+    "gec_launch_geometry",
 ]
 GEC_GROUP_ID_BYTES = 128
 # int (*gec_allgather_fn)(void *ctx, const void *d_send, void *d_recv, size_t bytes, void *hip_stream)
@@ -113,6 +114,8 @@ def _load() -> ctypes.CDLL:
     lib.gec_blake2sum_batch.argtypes = [vp, sz, pp, ctypes.POINTER(sz), u8p]
     lib.gec_encode_hash_batch.argtypes = [vp, sz, pp, ctypes.POINTER(sz), sz, pp, u8p]
     lib.gec_set_kernel_variant.argtypes = [ci]
+    ip = ctypes.POINTER(ci)
+    lib.gec_launch_geometry.argtypes = [ci, ci, ip, ip, ip, ip, ctypes.POINTER(sz)]
     lib.gec_group_unique_id.argtypes = [u8p]
     lib.gec_group_create.argtypes = [vp, ci, ci, u8p, pp]
     lib.gec_group_create_with_transport.argtypes = [vp, ci, ci, vp, vp, pp]

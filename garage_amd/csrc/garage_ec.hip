@@ -465,12 +465,41 @@ int threads_for(int mw, int kc)
 	return kThreadsMW4;
 }
 
-template <int MW, int MODE, int TPB>
-void launch_nibble(const gec::ApplyArgs &a, const gec::LogExp *le, unsigned grid, size_t lds, hipStream_t s)
+// Everything the host decides about one launch of the default kernel, in one place (also what
+// gec_launch_geometry reports, so the invariants -- LDS within 64 KiB, coefficients within the
+// argument block -- are testable without a GPU).
+struct Geometry {
+	int rows;     // output rows this launch takes (<= rows_left)
+	int mw;       // dwords per table entry: 1, 2 or 4
+	int kc;       // loads per batch
+	int threads;  // workgroup size
+	size_t lds;   // dynamic LDS bytes: tables + log/antilog image + coefficient rows
+};
+
+Geometry pick_geometry(int k, int rows_left, bool rows16_allowed)
 {
-	int kc = choose_kc((int)a.k, MW);
-	if constexpr (MW == 4)  // register budget (64 accumulator VGPRs): at most 4 shards in flight
-		kc = std::min<int>((int)a.k, 4);
+	Geometry g;
+	g.rows = std::min(gec::RMAX, rows_left);
+	// More than 8 rows left: 16-byte table entries take up to 16 of them in ONE pass over the
+	// data (instead of one pass per 8 rows), as long as k*16 coefficient bytes fit the argument
+	// block and k*512 bytes of tables fit 64 KiB of LDS.
+	if (rows_left > gec::RMAX && k <= gec::K16MAX && rows16_allowed)
+		g.rows = std::min(gec::RMAX16, rows_left);
+	// 8-byte table entries need k*256 bytes of LDS; beyond the 64 KiB a workgroup gets without
+	// opting in (k > ~245) fall back to groups of 4 rows (4-byte entries)
+	if (g.rows > 4 && g.rows <= gec::RMAX && (size_t)k * 256 + 768 + (size_t)k * gec::RMAX > 65536)
+		g.rows = 4;
+	g.mw = g.rows <= 4 ? 1 : g.rows <= gec::RMAX ? 2 : 4;
+	g.kc = g.mw == 4 ? std::min(k, 4) : choose_kc(k, g.mw);  // 16-byte entries: 64 accumulator VGPRs, 4 shards in flight
+	g.threads = threads_for(g.mw, g.kc);
+	const int cr = g.mw == 4 ? gec::RMAX16 : gec::RMAX;
+	g.lds = (size_t)k * 32 * 4 * g.mw + 768 + (size_t)k * cr;
+	return g;
+}
+
+template <int MW, int MODE, int TPB>
+void launch_nibble(const gec::ApplyArgs &a, const gec::LogExp *le, int kc, unsigned grid, size_t lds, hipStream_t s)
+{
 	if constexpr (MW == 2) {
 		if (kc == 10) {
 			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 10, kCPT, true, 256>), dim3(grid), dim3(256), lds, s, a, le);
@@ -549,18 +578,10 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 	const int variant = g_variant.load(std::memory_order_relaxed);
 	int rows = 0;
 	for (int r0 = 0; r0 < nout; r0 += rows) {
-		rows = std::min(gec::RMAX, nout - r0);
-		// More than 8 rows left: 16-byte table entries take up to 16 of them in ONE pass over
-		// the data (instead of one pass per 8 rows), as long as k*16 coefficient bytes fit the
-		// argument block and k*512 bytes of tables fit 64 KiB of LDS.
-		if (nout - r0 > gec::RMAX && k <= gec::K16MAX && variant == 0 && g_rows16.load(std::memory_order_relaxed))
-			rows = std::min(gec::RMAX16, nout - r0);
-		// 8-byte table entries need k*256 bytes of LDS; beyond the 64 KiB a workgroup gets
-		// without opting in (k > ~245) fall back to groups of 4 rows (4-byte entries)
-		if (rows > 4 && rows <= gec::RMAX && (size_t)k * 256 + 768 + (size_t)k * gec::RMAX > 65536)
-			rows = 4;
+		const Geometry geo = pick_geometry(k, nout - r0, variant == 0 && g_rows16.load(std::memory_order_relaxed) != 0);
+		rows = variant == 1 ? std::min(gec::RMAX, nout - r0) : geo.rows;  // the baseline kernel takes up to 8 rows
 		a.rows = (uint32_t)rows;
-		const int mw = rows <= 4 ? 1 : rows <= gec::RMAX ? 2 : 4;
+		const int mw = variant == 1 ? 2 : geo.mw;
 		const int cr = mw == 4 ? gec::RMAX16 : gec::RMAX;  // coefficient bytes per input shard
 		uint8_t *flat = &a.coef[0][0];
 		for (int r = 0; r < cr; ++r) {
@@ -586,7 +607,7 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 		}
 		// The (block, column) space is flattened: a launch covers a range of whole blocks
 		// whose columns fit 32 bits and whose tiles fit HIP's grid limit (grid*block < 2^32).
-		const int threads = threads_for(mw, choose_kc(k, mw));
+		const int threads = geo.threads;
 		const uint64_t tile_cols = (uint64_t)threads * kCPT;
 		uint64_t max_cols = std::min<uint64_t>(0xfffff000ull, (0xffffffffull / threads - 8) * tile_cols);
 		if (launch_cols_limit())
@@ -594,7 +615,7 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 		if (a.cols > max_cols)
 			return fail(GEC_E_INVALID_ARG, "shard too large for one launch");
 		const uint64_t blocks_per_launch = std::max<uint64_t>(1, max_cols / a.cols);
-		const size_t lds = (size_t)k * 32 * 4 * mw + 768 + (size_t)k * cr;
+		const size_t lds = geo.lds;
 		gec::ApplyArgs la = a;
 		for (uint64_t b0 = 0; b0 < nblocks; b0 += blocks_per_launch) {
 			const uint64_t nb = std::min<uint64_t>(blocks_per_launch, nblocks - b0);
@@ -606,17 +627,17 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 			// multiple of 8: the kernel hands each XCD a contiguous range of tiles
 			const unsigned grid = (unsigned)(((la.total_cols + tile_cols - 1) / tile_cols + 7) / 8 * 8);
 			if (mw == 1 && mode == gec::MODE_STORE)
-				launch_nibble<1, gec::MODE_STORE, kThreadsMW1>(la, c->d_logexp, grid, lds, stream);
+				launch_nibble<1, gec::MODE_STORE, kThreadsMW1>(la, c->d_logexp, geo.kc, grid, lds, stream);
 			else if (mw == 1)
-				launch_nibble<1, gec::MODE_COMPARE, kThreadsMW1>(la, c->d_logexp, grid, lds, stream);
+				launch_nibble<1, gec::MODE_COMPARE, kThreadsMW1>(la, c->d_logexp, geo.kc, grid, lds, stream);
 			else if (mw == 2 && mode == gec::MODE_STORE)
-				launch_nibble<2, gec::MODE_STORE, kThreadsMW2>(la, c->d_logexp, grid, lds, stream);
+				launch_nibble<2, gec::MODE_STORE, kThreadsMW2>(la, c->d_logexp, geo.kc, grid, lds, stream);
 			else if (mw == 2)
-				launch_nibble<2, gec::MODE_COMPARE, kThreadsMW2>(la, c->d_logexp, grid, lds, stream);
+				launch_nibble<2, gec::MODE_COMPARE, kThreadsMW2>(la, c->d_logexp, geo.kc, grid, lds, stream);
 			else if (mode == gec::MODE_STORE)
-				launch_nibble<4, gec::MODE_STORE, kThreadsMW4>(la, c->d_logexp, grid, lds, stream);
+				launch_nibble<4, gec::MODE_STORE, kThreadsMW4>(la, c->d_logexp, geo.kc, grid, lds, stream);
 			else
-				launch_nibble<4, gec::MODE_COMPARE, kThreadsMW4>(la, c->d_logexp, grid, lds, stream);
+				launch_nibble<4, gec::MODE_COMPARE, kThreadsMW4>(la, c->d_logexp, geo.kc, grid, lds, stream);
 			HIP_TRY(hipGetLastError());
 		}
 	}
@@ -979,6 +1000,25 @@ int gec_codec_cache_stats(const gec_codec *c, uint64_t *cached, uint64_t *invers
 		*cached = c->cache.size();
 	if (inversions)
 		*inversions = c->inversions;
+	return GEC_OK;
+}
+
+int gec_launch_geometry(int k, int rows_left, int *rows, int *entry_bytes, int *loads_per_batch, int *threads,
+			size_t *lds_bytes)
+{
+	if (k < 1 || k > GEC_MAX_SHARDS - 1 || rows_left < 1)
+		return fail(GEC_E_INVALID_ARG, "need 1 <= k <= 255 and rows_left >= 1");
+	const Geometry g = pick_geometry(k, rows_left, g_rows16.load(std::memory_order_relaxed) != 0);
+	if (rows)
+		*rows = g.rows;
+	if (entry_bytes)
+		*entry_bytes = 4 * g.mw;
+	if (loads_per_batch)
+		*loads_per_batch = g.kc;
+	if (threads)
+		*threads = g.threads;
+	if (lds_bytes)
+		*lds_bytes = g.lds;
 	return GEC_OK;
 }
 

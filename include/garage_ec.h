@@ -285,6 +285,15 @@ int gec_encode_hash_batch(const gec_codec *c, size_t nblocks,
 			  const uint8_t *const *blocks, const size_t *block_len,
 			  size_t S, uint8_t *const *parity, uint8_t *shard_sums);
 
+/* Introspection for tests (no device needed): what the host would decide for ONE launch of the
+ * default kernel with k input shards and rows_left output rows still to produce -- how many rows
+ * the launch takes, the table-entry width (4/8/16 bytes), loads per batch, workgroup size and
+ * dynamic LDS bytes.  Lets a CPU-only test sweep every (k, rows) for the invariants a launch
+ * failure would otherwise only reveal on a GPU: LDS <= 64 KiB, >= 1 row of progress, the
+ * 16-row form only where its coefficients fit the argument block. */
+int gec_launch_geometry(int k, int rows_left, int *rows, int *entry_bytes,
+			int *loads_per_batch, int *threads, size_t *lds_bytes);
+
 /* Kernel selection for A/B measurements (bench.py --variant).  0 = default
  * (nibble product tables in LDS), 1 = log/antilog tables in LDS (the literal
  * north_star formulation, kept as the measured baseline).  Process-wide. */

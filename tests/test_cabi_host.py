@@ -108,6 +108,40 @@ def test_group_entry_points_reject_bad_arguments_without_a_gpu():
     lib.gec_group_destroy(None)
 
 
+def test_launch_geometry_invariants_for_every_k_and_row_count():
+    """Every (k, rows_left) the library can be asked for: the launch makes progress, its tables fit
+    the 64 KiB of LDS a workgroup gets without opting in, the 16-row form stays within k <= 120
+    (k*16 coefficient bytes in the 2 KiB argument array), and the loads per batch never exceed
+    what the kernels are instantiated for."""
+    import ctypes
+
+    lib = _lib.lib
+    rows, ent, kc, thr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lds = ctypes.c_size_t()
+    seen = set()
+    for k in range(1, 256):
+        for left in list(range(1, 34)) + [64, 255]:
+            assert lib.gec_launch_geometry(k, left, rows, ent, kc, thr, lds) == 0
+            r, e, c, t, l = rows.value, ent.value, kc.value, thr.value, lds.value
+            assert 1 <= r <= min(left, 16)
+            assert e == (4 if r <= 4 else 8 if r <= 8 else 16)
+            assert l <= 65536 and l == k * 32 * e + 768 + k * (16 if e == 16 else 8)
+            assert t in (256, 512)
+            if e == 16:
+                assert k <= 120 and k * 16 <= 2048 and c == min(k, 4)
+            elif e == 8:
+                assert c in (1, 2, 3, 4, 5, 6, 10) and (c != 10 or t == 256)
+            else:
+                assert c in (1, 2, 3, 4, 5, 6, 10, 12, 16)
+            assert c <= k or (c in (10, 12, 16) and k <= c)   # more loads than shards only in the single-batch forms
+            if left > 8 and k <= 120:
+                assert r == min(left, 16)          # one pass over the data for up to 16 rows
+            seen.add((e, c, t))
+    assert (4, 10, 256) in seen and (8, 5, 512) in seen and (8, 10, 256) in seen and (16, 4, 512) in seen
+    assert lib.gec_launch_geometry(0, 1, rows, ent, kc, thr, lds) == _lib.GEC_E_INVALID_ARG
+    assert lib.gec_launch_geometry(10, 0, rows, ent, kc, thr, lds) == _lib.GEC_E_INVALID_ARG
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "garage_amd")
     for dp, _, files in os.walk(pkg):
