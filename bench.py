@@ -4,25 +4,41 @@
 A "step" is one pass of the hot path over one batch: RS(10,4) encode of the
 rank's batch of 1 MiB blocks already resident in HBM (one kernel launch through
 the C ABI).  At N=1 the workload is BASELINE config 2 (batch 1024).  At N>1 it
-is config 4: a stream of N*1024 blocks hash-partitioned across ranks with
-`hash[4] % N` on Garage-style 32-byte block hashes, one process per GPU, no
-data-path collective (weak scaling).
+is config 4: a stream of N*1024 blocks hash-partitioned across the GPUs with
+`hash[4] % N` on Garage-style 32-byte block hashes, no data-path collective
+(weak scaling).
+
+Launching (any of these gives the same JSON line):
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+    (what the driver does): one process per GPU, RCCL for barrier / reductions;
+  * `python bench.py --gpus N` with no WORLD_SIZE in the environment: bench.py
+    re-launches itself under torch.distributed.run on a free local port;
+  * `python bench.py --gpus N --mode threads`: ONE process, N codecs and N host
+    threads through the C ABI -- how a single Garage daemon per node would drive
+    the GPUs.  No process group, no RCCL.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-`roofline` (HIP-event kernel time vs the 8 TB/s HBM peak), `cpu_baseline` (the
-oracle's C restatement timed on this host's cores) and a `decode` object for
-BASELINE config 3 (4 erasures).
+`roofline` (HIP-event kernel time vs the 8 TB/s HBM peak, with the secondary
+LDS / VALU bounds beside it), `cpu_baseline` (the oracle's C restatement timed
+on this host's cores), a `decode` object for BASELINE config 3 (4 erasures),
+`pcie_inclusive` and `block_manager` (host-pointer API and BlockManager mirror;
+never the `value`) at N=1, and at N>1 a `striped_decode` object for BASELINE
+config 5 (RS(20,8), RCCL all-gather decode) with its own bit-exact check.
 
 Defaults (--steps 1000 --warmup 100, ~0.3 s of GPU time) measure the steady
 state: MI355X's power management slows the first few milliseconds of a burst of
-this kernel by up to 1.5x before settling (profiles/r01_early_20step_burst_dvfs_transient.txt).
+this kernel by up to 1.5x before settling (profiles/r01_early_20step_burst_dvfs_transient.txt);
+the cold burst is reported next to it as `cold_burst_frac`.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -33,6 +49,7 @@ K, M = 10, 4
 BLOCK_LEN = 1 << 20
 BATCH = 1024
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+ORACLE_SAMPLE = 32     # blocks of every rank's timed batch compared with the CPU oracle after the timed region
 
 
 def synthetic_hashes(n_total: int):
@@ -51,14 +68,28 @@ def synthetic_hashes(n_total: int):
 
 
 def measured_traffic(nblocks: int):
-    """HBM bytes per launch measured with rocprofv3 PMC counters for exactly this
-    workload (committed under profiles/); None for any other batch size."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of exactly this
+    workload (profiles/pmc_traffic.json); None for any other batch size.  A STATIC
+    figure (PMC counters cannot be collected inside this process); `traffic_source`
+    in the JSON line says so."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             rec = json.load(f)["rs10_4_encode_1MiB_x1024"]
     except (OSError, KeyError, ValueError):
+        return None, None
+    if nblocks != BATCH:
+        return None, None
+    return rec["traffic_bytes"], f"static: profiles/pmc_traffic.json ({rec.get('source', 'rocprofv3 PMC passes')}); 2*FETCH_SIZE + WRITE_SIZE per launch"
+
+
+def secondary_bounds():
+    """LDS / VALU cycles per tile next to the HBM cycles (hard part 1):
+    static, from the committed SQ counter pass."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get("rs10_4_secondary_bounds")
+    except (OSError, ValueError):
         return None
-    return rec["traffic_bytes"] if nblocks == BATCH else None
 
 
 def cpu_baseline(S: int):
@@ -99,193 +130,252 @@ def cpu_baseline(S: int):
     }
 
 
-def striped_decode_bench(args, R, distrib) -> None:
-    """BASELINE config 5 (secondary line, not the headline metric): 256 objects of 4 MiB,
-    RS(20,8), shard j on rank j % N; 8 shards erased; one RCCL all-gather of the slot
-    buffers, every rank rebuilds its 1/N byte range of each missing shard in place on the
-    gathered buffer, second all-gather of the rebuilt ranges."""
+def oracle_check_sample(st, nb: int, S: int) -> int:
+    """After (and outside) the timed region: the parity the timed kernel left in HBM for a
+    strided sample of this rank's batch, byte for byte against the CPU oracle.  Returns the
+    number of blocks compared; raises on any mismatch."""
+    import numpy as np
     import torch
 
-    import garage_amd as g
-    from garage_amd.striped import StripeLayout, striped_reconstruct
+    from oracle import rs_oracle as O
 
-    if not R.distributed:  # world 1 still goes through RCCL so the code path is the same
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        distrib.quiet_rccl()  # keep RCCL's banner and warnings off stdout
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=R.device)
-    k, m, L, nobj = 20, 8, 4 << 20, 256
-    S = g.shard_len(k, L)
-    layout = StripeLayout(k, m, R.world)
-    rs = g.ReedSolomon(k, m, device=R.local_rank)
-    gen = torch.Generator(device=R.device)
-    gen.manual_seed(0x6761726167650005 + R.rank)
-    # this rank's slots of already-encoded stripes: contents do not affect the timing,
-    # correctness of the flow is covered by tests/test_gpu_striped.py and the gloo tests
-    local = torch.randint(0, 256, (nobj, layout.slots, S), dtype=torch.uint8, device=R.device, generator=gen)
-    lost = (0, 1, 5, 9, 13, 19, 21, 27)
-    present = [j not in lost for j in range(k + m)]
-    if args.collective == "cabi":  # RCCL driven by libgarage_ec itself (gec_group_*), torch only carries the unique id
-        grp = g.Group.from_torch_distributed(rs)
-        out = torch.empty((R.world, nobj, layout.slots, S), dtype=torch.uint8, device=R.device)
-
-        def step():
-            grp.allgather_decode(local, present, out=out)
-    else:
-        def step():
-            striped_reconstruct(rs, local, present, layout)
-    for _ in range(max(1, args.warmup // 10)):
-        step()
-    torch.cuda.synchronize()
-    distrib.barrier(R)
-    steps = max(3, args.steps // 20)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    distrib.barrier(R)
-    dt = distrib.max_over_ranks(R, time.perf_counter() - t0)
-    if R.rank == 0:
-        print(json.dumps({
-            "metric": "RS(20,8) striped-object decode payload throughput, 4 MiB objects (all-gather + range reconstruct)",
-            "value": round(nobj * L * steps / dt / 2**30, 2), "unit": "GiB/s", "n_gpus": R.world, "steps": steps,
-            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE config 5: RS(20,8), 256 x 4 MiB objects striped over the ranks, 8 erasures",
-                       "k": k, "m": m, "shard_len": S, "slots_per_rank": layout.slots,
-                       "allgather_bytes_per_rank": nobj * layout.slots * S, "parallelism": f"stripe x{R.world}",
-                       "collective": "gec_group_allgather_decode (C ABI, RCCL)" if args.collective == "cabi"
-                                     else "torch.distributed all_gather_into_tensor (RCCL) + gec_reconstruct_scattered_dev"},
-        }), flush=True)
-    if not R.distributed:
-        import torch.distributed as dist
-
-        dist.destroy_process_group()
+    if nb == 0:
+        return 0
+    idx = sorted(set(np.linspace(0, nb - 1, min(ORACLE_SAMPLE, nb)).astype(int).tolist()))
+    host = st[torch.as_tensor(idx, device=st.device)].cpu().numpy()
+    co = O.COracle()
+    want = co.encode_batch(K, M, np.ascontiguousarray(host[:, :K]), co.AVX2 if co.has_avx2() else co.SCALAR, threads=4)
+    if not np.array_equal(host[:, K:], want):
+        raise AssertionError("bench output differs from the CPU oracle")
+    return len(idx)
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=BATCH, help="blocks per GPU (default 1024 = BASELINE config 2)")
-    ap.add_argument("--variant", type=int, default=0, help="0 nibble product tables (default), 1 log/antilog baseline")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-decode", action="store_true")
-    ap.add_argument("--precondition-ms", type=float, default=200.0,
-                    help="untimed device pre-conditioning before the W warm-up steps: the same encode launches for this "
-                         "long, so a short K/W does not measure MI355X's idle-to-load DVFS transient (0 disables)")
-    ap.add_argument("--op", choices=["encode", "striped-decode"], default="encode",
-                    help="encode = the BASELINE metric (default); striped-decode = BASELINE config 5: RS(20,8), 4 MiB objects "
-                         "striped over the ranks, all-gather + per-rank byte-range reconstruct")
-    ap.add_argument("--collective", choices=["torch", "cabi"], default="torch",
-                    help="striped-decode only: who drives RCCL -- torch.distributed (default) or libgarage_ec's gec_group_* C ABI")
-    args = ap.parse_args()
+# --------------------------------------------------------------------------- workload
+def make_stripes(dev, rank: int, nb: int, S: int):
+    """This rank's batch in the stripe layout, payload = seeded random bytes, the two edge
+    blocks of SURVEY.md section 8d (all-zero, all-0xFF) first."""
+    import torch
 
+    n = K + M
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x6761726167650002 + rank)
+    st = torch.zeros((nb, n, S), dtype=torch.uint8, device=dev)
+    if nb:
+        payload = st[:, :K].reshape(nb, K * S)
+        payload[:, :BLOCK_LEN] = torch.randint(0, 256, (nb, BLOCK_LEN), dtype=torch.uint8, device=dev, generator=gen)
+    if nb >= 2:
+        st[0, :K] = 0
+        st[1, :K].reshape(-1)[:BLOCK_LEN] = 0xFF
+    return st
+
+
+class EncodeJob:
+    """One GPU's share of the encode bench: buffers, codec, the step, and the timed loop.
+    Used by one process per GPU (procs mode) or one thread per GPU (threads mode)."""
+
+    def __init__(self, args, device_index: int, rank: int, nb: int, stream=None):
+        import torch
+
+        import garage_amd as g
+
+        self.torch, self.g = torch, g
+        self.args, self.rank, self.nb = args, rank, nb
+        self.dev = torch.device("cuda", device_index)
+        self.S = g.shard_len(K, BLOCK_LEN)
+        self.rs = g.ReedSolomon(K, M, device=device_index)
+        self.st = make_stripes(self.dev, rank, nb, self.S)
+        self.stream = stream if stream is not None else torch.cuda.current_stream(self.dev)
+        self.lib, self.h = g._lib.lib, self.rs._h
+        self.base = self.st.data_ptr() if nb else 0
+
+    def step(self):
+        n, S = K + M, self.S
+        rc = self.lib.gec_encode_batch_dev(self.h, self.nb, self.base, n * S, S, self.base + K * S, n * S,
+                                           self.stream.cuda_stream)
+        if rc:
+            self.g._lib.check(rc, "gec_encode_batch_dev")
+
+    def sync(self):
+        self.stream.synchronize()
+
+    def timed_burst(self, steps: int) -> float:
+        """avg ms per launch over `steps` back-to-back launches (HIP events on the launch stream)"""
+        ev0, ev1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        ev0.record(self.stream)
+        for _ in range(steps):
+            self.step()
+        ev1.record(self.stream)
+        self.sync()
+        return ev0.elapsed_time(ev1) / steps
+
+    def cold_burst(self):
+        """The first 50 launches from an idle device: module load and first-touch are paid by three
+        untimed launches, then the device idles 0.3 s so the clocks drop back (DESIGN.md 'DVFS transient')."""
+        for _ in range(3):
+            self.step()
+        self.sync()
+        time.sleep(0.3)
+        return self.timed_burst(50)
+
+    def precondition_and_warm(self):
+        a = self.args
+        if a.precondition_ms > 0:
+            tpre = time.perf_counter()
+            while (time.perf_counter() - tpre) * 1e3 < a.precondition_ms:
+                for _ in range(20):
+                    self.step()
+                self.sync()
+        for _ in range(a.warmup):
+            self.step()
+        self.sync()
+
+    def decode_setup(self):
+        import numpy as np
+
+        self.lost = (0, 3, 7, 9)
+        self.present = np.array([j not in self.lost for j in range(K + M)], dtype=np.uint8)
+        self.ref = self.st[:4].clone()
+        self.st[:, list(self.lost)] = 0
+
+    def decode_step(self):
+        with self.torch.cuda.stream(self.stream):
+            self.rs.reconstruct_dev(self.st, self.present)
+
+
+def algo_bytes(nb: int, S: int) -> int:
+    return (K + M) * S * nb  # SURVEY.md 8d: read k*S + write m*S per block
+
+
+def roofline_obj(args, nb: int, S: int, kern_ms: float, cold_ms):
+    ab = algo_bytes(nb, S)
+    achieved = ab / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    traffic, source = measured_traffic(nb) if args.variant == 0 else (None, None)
+    r = {
+        "bound": "hbm",
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": traffic,
+        "traffic_source": source,
+        "kernel": "gf_apply_nibble<1,0,10,1,true,256>" if args.variant == 0 else "gf_apply_logexp<0>",
+        "kernel_ms": round(kern_ms, 4),
+        "algorithmic_bytes_per_launch": ab,
+        "secondary": secondary_bounds() if args.variant == 0 else None,
+    }
+    if cold_ms:
+        r["cold_burst_frac"] = round(ab / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        r["cold_burst"] = "first 50 launches from an idle device, no pre-conditioning (DVFS transient, DESIGN.md section 4)"
+    return r
+
+
+def base_line(args, world: int, elapsed: float, blocks_all: int, per_rank, nb0: int, S: int, mode: str):
+    total_blocks = args.batch * world
+    return {
+        "metric": "RS(10,4) encode payload throughput, 1 MiB blocks",
+        "value": round(blocks_all * BLOCK_LEN * args.steps / elapsed / 2**30, 2),
+        "unit": "GiB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "preconditioning_ms": args.precondition_ms,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE config 2: RS(10,4) encode, 1 MiB blocks, batch 1024 per GPU, device-resident"
+                        if world == 1 else
+                        "BASELINE config 4: RS(10,4) encode, 1 MiB blocks, hash-partitioned stream of "
+                        f"{total_blocks} blocks over {world} GPUs (hash[4] % N), no collective",
+            "k": K, "m": M, "block_len": BLOCK_LEN, "shard_len": S,
+            "blocks_total": blocks_all, "blocks_rank0": nb0, "blocks_per_rank": per_rank,
+            "kernel_variant": args.variant,
+            "parallelism": f"hash-partition x{world}",
+            "mode": mode,
+        },
+    }
+
+
+# --------------------------------------------------------------- one process per GPU
+def run_procs(args) -> None:
     import numpy as np
     import torch
 
     import garage_amd as g
-    from garage_amd.partition import gpu_of_hash
-
     from garage_amd import distrib
+    from garage_amd.partition import gpu_of_hash
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (libgarage_ec has no CPU path)"
     R = distrib.init_from_env()
-    world, rank, local_rank, dev = R.world, R.rank, R.local_rank, R.device
+    world, rank = R.world, R.rank
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
-
     g.set_kernel_variant(args.variant)
     if args.op == "striped-decode":
-        striped_decode_bench(args, R, distrib)
+        out = striped_decode_bench(args, R, distrib)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
         distrib.shutdown(R)
         return
-    S = g.shard_len(K, BLOCK_LEN)
-    n = K + M
 
     # ---- hash-partition the (synthetic) PutObject block stream over the GPUs
     total_blocks = args.batch * world
     hashes = synthetic_hashes(total_blocks)
     mine = np.nonzero(gpu_of_hash(hashes, world) == rank)[0]
     nb = int(mine.size)
-
-    rs = g.ReedSolomon(K, M, device=local_rank)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0x6761726167650002 + rank)
-    st = torch.zeros((nb, n, S), dtype=torch.uint8, device=dev)
-    payload = st[:, :K].reshape(nb, K * S)
-    payload[:, :BLOCK_LEN] = torch.randint(0, 256, (nb, BLOCK_LEN), dtype=torch.uint8, device=dev, generator=gen)
-    if nb >= 2:  # edge blocks of SURVEY.md section 8d
-        st[0, :K] = 0
-        st[1, :K].reshape(-1)[:BLOCK_LEN] = 0xFF
-    data = st[:, :K]
-    base = st.data_ptr()
-    stream = torch.cuda.current_stream(dev)
-    lib, h = g._lib.lib, rs._h
-
-    def encode_step():
-        rc = lib.gec_encode_batch_dev(h, nb, base, n * S, S, base + K * S, n * S, stream.cuda_stream)
-        if rc:
-            g._lib.check(rc, "gec_encode_batch_dev")
+    job = EncodeJob(args, R.local_rank, rank, nb)
+    S = job.S
 
     def barrier():
         distrib.barrier(R)
 
-    # device pre-conditioning (disclosed in the JSON line): bring clocks / power management to
-    # the loaded steady state; see DESIGN.md "DVFS transient".  Not part of W or K.
-    if args.precondition_ms > 0:
-        tpre = time.perf_counter()
-        while (time.perf_counter() - tpre) * 1e3 < args.precondition_ms:
-            for _ in range(20):
-                encode_step()
-            torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        encode_step()
+    cold_ms = job.cold_burst() if (rank == 0 and nb) else None
+    barrier()
+    job.precondition_and_warm()
     torch.cuda.synchronize()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record(stream)
+    ev0.record(job.stream)
     for _ in range(args.steps):
-        encode_step()
-    ev1.record(stream)
+        job.step()
+    ev1.record(job.stream)
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps  # avg launch duration, HIP events on the launch stream
 
-    elapsed = distrib.max_over_ranks(R, elapsed)      # MAX over ranks
+    elapsed = distrib.max_over_ranks(R, t1 - t0)      # MAX over ranks
     blocks_all = distrib.sum_over_ranks(R, nb)        # units all ranks processed
+    per_rank = distrib.gather_ints(R, nb)
+    rccl = distrib.count_ranks(R)                     # an all-reduce of ones on the device: RCCL saw this many ranks
 
-    # correctness gate inside the bench: parity written by the timed kernel verifies
-    assert bool(rs.verify_dev(st).all()), "verify failed on bench output"
+    # correctness gates, after and outside the timed region: the kernel's own compare mode over the
+    # whole batch, and the CPU oracle byte for byte on a strided sample
+    assert bool(job.rs.verify_dev(job.st).all()), "verify failed on bench output"
+    checked = 0 if args.no_oracle_check else oracle_check_sample(job.st, nb, S)
+    checked_all = distrib.sum_over_ranks(R, checked)
 
     # ---- decode (BASELINE config 3): 4 data shards lost, reconstruct in place
     decode = None
-    if not args.no_decode:
-        lost = (0, 3, 7, 9)
-        present = np.array([j not in lost for j in range(n)], dtype=np.uint8)
-        ref = st[:4].clone()
-        st[:, list(lost)] = 0
+    if not args.no_decode and nb:
+        job.decode_setup()
         torch.cuda.synchronize()
         c0 = time.perf_counter()
-        rs.reconstruct_dev(st, present)      # cold: includes the host 10x10 inversion
+        job.decode_step()                     # cold: includes the host 10x10 inversion
         torch.cuda.synchronize()
-        cold_ms = (time.perf_counter() - c0) * 1e3
-        assert torch.equal(st[:4], ref), "reconstruct mismatch"
+        cold_dec_ms = (time.perf_counter() - c0) * 1e3
+        assert torch.equal(job.st[:4], job.ref), "reconstruct mismatch"
         dsteps = max(5, args.steps // 2)
         barrier()
         torch.cuda.synchronize()
         d0 = time.perf_counter()
         for _ in range(dsteps):
-            rs.reconstruct_dev(st, present)  # warm: cached decode matrix
+            job.decode_step()                 # warm: cached decode matrix
         torch.cuda.synchronize()
         barrier()
         dt = distrib.max_over_ranks(R, time.perf_counter() - d0)
@@ -294,58 +384,320 @@ def main() -> None:
             "value": round(blocks_all * BLOCK_LEN * dsteps / dt / 2**30, 2),
             "unit": "GiB/s",
             "ms_per_step": round(dt / dsteps * 1e3, 4),
-            "cold_first_call_ms": round(cold_ms, 3),
+            "cold_first_call_ms": round(cold_dec_ms, 3),
             # same algorithmic bytes as encode: read k surviving shards, write the 4 lost ones
-            "roofline_frac": round((K + len(lost)) * S * blocks_all / world / (dt / dsteps) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline_frac": round((K + len(job.lost)) * S * blocks_all / world / (dt / dsteps) / 1e9 / HBM_PEAK_GBS, 4),
         }
 
+    out = None
     if rank == 0:
-        algo_bytes = (K + M) * S * nb  # read k*S + write m*S per block
-        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-        out = {
-            "metric": "RS(10,4) encode payload throughput, 1 MiB blocks",
-            "value": round(blocks_all * BLOCK_LEN * args.steps / elapsed / 2**30, 2),
-            "unit": "GiB/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "preconditioning_ms": args.precondition_ms,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {
-                "workload": "BASELINE config 2: RS(10,4) encode, 1 MiB blocks, batch 1024 per GPU, device-resident"
-                            if world == 1 else
-                            "BASELINE config 4: RS(10,4) encode, 1 MiB blocks, hash-partitioned stream of "
-                            f"{total_blocks} blocks over {world} GPUs (hash[4] % N), no collective",
-                "k": K, "m": M, "block_len": BLOCK_LEN, "shard_len": S,
-                "blocks_total": blocks_all, "blocks_rank0": nb,
-                "kernel_variant": args.variant,
-                "parallelism": f"hash-partition x{world}",
-            },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic(nb) if args.variant == 0 else None,
-                "traffic_source": "rocprofv3 PMC pass, profiles/r01_pmc_hbm_traffic.txt (2*FETCH_SIZE + WRITE_SIZE, per launch)",
-                "kernel": "gf_apply_nibble<1,0,10,1,true,256>" if args.variant == 0 else "gf_apply_logexp<0>",
-                "kernel_ms": round(kern_ms, 4),
-                "algorithmic_bytes_per_launch": algo_bytes,
-            },
-        }
+        out = base_line(args, world, elapsed, blocks_all, per_rank, nb, S,
+                        "one process per GPU (torch.distributed.run)" + (", self-launched" if os.environ.get("GARAGE_BENCH_SELF_LAUNCHED") else ""))
+        out["roofline"] = roofline_obj(args, nb, S, kern_ms, cold_ms)
+        out["parity_checked_blocks"] = checked_all
+        out["parity_check"] = ("gec_verify_batch_dev over every block of every rank + CPU oracle byte-for-byte on "
+                               f"{checked_all} strided blocks, after the timed region")
+        out["rccl_ranks"] = rccl["ranks"]
+        out["collective_backend"] = rccl["backend"]
         if decode:
             out["decode"] = decode
+    del job
+    torch.cuda.empty_cache()
+
+    # ---- BASELINE config 5 beside it when there is more than one GPU (or on request): the path's one
+    # real exchange step.  Guarded by a watchdog so that a collective that hangs cannot take the
+    # headline line with it.
+    dry = os.environ.get("GARAGE_DRYRUN_ONE_GPU") == "1"  # gloo stand-in on one device: no RCCL to measure
+    if (world > 1 and not args.no_striped and not dry) or args.striped:
+        box = {}
+        done = threading.Event()
+
+        def emit_and_exit():
+            if not done.wait(args.striped_timeout):
+                if rank == 0:
+                    out["striped_decode"] = {"error": f"no result within {args.striped_timeout:.0f} s (watchdog)", **box}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+        threading.Thread(target=emit_and_exit, daemon=True).start()
+        try:
+            res = striped_decode_bench(args, R, distrib, box)
+        except Exception as e:  # noqa: BLE001 -- reported in the line, the headline number stands
+            res = {"error": f"{type(e).__name__}: {e}"[:400]}
+        done.set()
+        if rank == 0:
+            out["striped_decode"] = res
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S)
+        if world == 1 and not args.no_host_path:
+            out.update(host_path_objects())
         print(json.dumps(out), flush=True)
-
     distrib.shutdown(R)
+
+
+# ------------------------------------------------- one process, N codecs, N host threads
+def run_threads(args) -> None:
+    import numpy as np
+    import torch
+
+    import garage_amd as g
+    from garage_amd.partition import gpu_of_hash
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU (libgarage_ec has no CPU path)"
+    world = args.gpus
+    ndev = torch.cuda.device_count()
+    dry = os.environ.get("GARAGE_DRYRUN_ONE_GPU") == "1"
+    if ndev < world and not dry:
+        sys.exit(f"--gpus {world} --mode threads needs {world} visible GPUs, found {ndev} "
+                 "(GARAGE_DRYRUN_ONE_GPU=1 puts every codec on device 0: plumbing only, numbers meaningless)")
+    g.set_kernel_variant(args.variant)
+    total_blocks = args.batch * world
+    owner = gpu_of_hash(synthetic_hashes(total_blocks), world)
+    S = g.shard_len(K, BLOCK_LEN)
+    res = [None] * world
+    err = []
+    bar = threading.Barrier(world)
+
+    def worker(t: int):
+        try:
+            d = 0 if dry else t
+            torch.cuda.set_device(d)
+            stream = torch.cuda.Stream(device=d)
+            nb = int(np.count_nonzero(owner == t))
+            with torch.cuda.stream(stream):
+                job = EncodeJob(args, d, t, nb, stream=stream)
+            stream.synchronize()
+            cold = job.cold_burst() if (t == 0 and nb) else None
+            bar.wait()
+            job.precondition_and_warm()
+            bar.wait()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record(stream)
+            for _ in range(args.steps):
+                job.step()
+            ev1.record(stream)
+            stream.synchronize()
+            t1 = time.perf_counter()
+            bar.wait()
+            with torch.cuda.stream(stream):
+                ok = bool(job.rs.verify_dev(job.st).all())
+                checked = 0 if args.no_oracle_check else oracle_check_sample(job.st, nb, S)
+            if not ok:
+                raise AssertionError("verify failed on bench output")
+            res[t] = {"t0": t0, "t1": t1, "nb": nb, "kern_ms": ev0.elapsed_time(ev1) / args.steps, "cold": cold,
+                      "checked": checked}
+        except BaseException as e:  # noqa: BLE001
+            err.append(f"thread {t}: {type(e).__name__}: {e}")
+            bar.abort()
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(world)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    if err:
+        sys.exit("; ".join(err))
+    elapsed = max(r["t1"] for r in res) - min(r["t0"] for r in res)  # barrier release -> last thread done
+    blocks_all = sum(r["nb"] for r in res)
+    out = base_line(args, world, elapsed, blocks_all, [r["nb"] for r in res], res[0]["nb"], S,
+                    f"threads: one process, {world} codecs, {world} host threads through the C ABI"
+                    + (" (DRY RUN: all on device 0)" if dry else ""))
+    out["roofline"] = roofline_obj(args, res[0]["nb"], S, res[0]["kern_ms"], res[0]["cold"])
+    out["kernel_ms_per_gpu"] = [round(r["kern_ms"], 4) for r in res]
+    out["parity_checked_blocks"] = sum(r["checked"] for r in res)
+    out["rccl_ranks"] = None
+    out["collective_backend"] = "none (single process; the encode path has no collective)"
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(S)
+    print(json.dumps(out), flush=True)
+
+
+# ------------------------------------------------------------------ BASELINE config 5
+def striped_decode_bench(args, R, distrib, progress=None) -> dict:
+    """BASELINE config 5 (secondary to the headline metric): RS(20,8), 4 MiB objects, shard j on
+    rank j % N; 8 shards erased; the survivors' slots are exchanged over RCCL, every rank rebuilds
+    its 1/N byte range of each missing shard in place on the gathered buffer, then the rebuilt
+    ranges are exchanged.  First a bit-exact check on real data (every rank encodes the same seeded
+    objects, keeps only its own slots, and compares what comes back with the full stripes), then
+    the timing on 256 objects."""
+    import torch
+    import torch.distributed as dist
+
+    import garage_amd as g
+    from garage_amd.striped import StripeLayout, gather_stripes, scatter_stripes, striped_reconstruct
+
+    progress = progress if progress is not None else {}
+    own_pg = False
+    if not R.distributed:  # world 1 still goes through RCCL so the code path is the same
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        distrib.quiet_rccl()  # keep RCCL's banner and warnings off stdout
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=R.device)
+        own_pg = True
+    k, m, L, nobj = 20, 8, 4 << 20, args.striped_objects
+    S = g.shard_len(k, L)
+    layout = StripeLayout(k, m, R.world)
+    rs = g.ReedSolomon(k, m, device=R.local_rank)
+    lost = (0, 1, 5, 9, 13, 19, 21, 27)
+    present = [j not in lost for j in range(k + m)]
+    use_cabi = args.collective == "cabi" and dist.get_backend() == "nccl"
+    grp = g.Group.from_torch_distributed(rs) if use_cabi else None
+    progress["stage"] = "group created"
+
+    def run(local, out=None):
+        if grp is not None:
+            return grp.allgather_decode(local, present, out=out)
+        return striped_reconstruct(rs, local, present, layout)
+
+    # -- bit-exact check: same seeded objects on every rank
+    ncheck = 8
+    gen = torch.Generator(device=R.device)
+    gen.manual_seed(0x6761726167650005)
+    full = torch.zeros((ncheck, k + m, S), dtype=torch.uint8, device=R.device)
+    full[:, :k].reshape(ncheck, k * S)[:, :L] = torch.randint(0, 256, (ncheck, L), dtype=torch.uint8, device=R.device, generator=gen)
+    rs.encode_dev(full)
+    broken = full.clone()
+    broken[:, list(lost)] = 0xEE
+    got = gather_stripes(run(scatter_stripes(broken, layout, R.rank)), layout)
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(got, full))
+    ok_all = distrib.sum_over_ranks(R, int(ok)) == R.world
+    del full, broken, got
+    progress["stage"] = "bit-exact check done"
+
+    # -- timing: contents do not affect it
+    gen.manual_seed(0x6761726167650005 + 1 + R.rank)
+    local = torch.randint(0, 256, (nobj, layout.slots, S), dtype=torch.uint8, device=R.device, generator=gen)
+    out = torch.empty((R.world, nobj, layout.slots, S), dtype=torch.uint8, device=R.device) if grp is not None else None
+    for _ in range(3):
+        run(local, out)
+    torch.cuda.synchronize()
+    distrib.barrier(R)
+    steps = max(5, min(50, args.steps // 20))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run(local, out)
+    torch.cuda.synchronize()
+    distrib.barrier(R)
+    dt = distrib.max_over_ranks(R, time.perf_counter() - t0)
+    res = {
+        "metric": "RS(20,8) striped-object decode payload throughput, 4 MiB objects (all-gather + range reconstruct + range exchange)",
+        "value": round(nobj * L * steps / dt / 2**30, 2), "unit": "GiB/s", "n_gpus": R.world, "steps": steps,
+        "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "bit_exact": ok_all, "bit_exact_objects": ncheck,
+        "rccl_ranks": (grp.nranks if grp is not None else dist.get_world_size()),
+        "config": {"workload": f"BASELINE config 5: RS(20,8), {nobj} x 4 MiB objects striped over the ranks, 8 erasures",
+                   "k": k, "m": m, "shard_len": S, "slots_per_rank": layout.slots,
+                   "allgather_bytes_per_rank": nobj * layout.slots * S, "parallelism": f"stripe x{R.world}",
+                   "collective": "gec_group_allgather_decode (C ABI, RCCL ncclAllGather)" if grp is not None
+                                 else f"torch.distributed all_gather_into_tensor ({dist.get_backend()}) + gec_reconstruct_scattered_dev"},
+    }
+    if grp is not None:
+        grp.close()
+    if own_pg:
+        dist.destroy_process_group()
+    if not ok_all:
+        res["error"] = "striped decode result differs from the locally encoded stripes"
+    return res
+
+
+# ------------------------------------------------- the path above the kernel (N=1, rank 0)
+def host_path_objects() -> dict:
+    """PCIe-inclusive rate of the host-pointer C ABI and the C++ BlockManager mirror's put/get rate on
+    in-memory nodes -- reported next to the device-resident `value`, never as it."""
+    out = {}
+    try:
+        from tools.host_path_bench import block_manager_rates, pcie_inclusive_rates
+
+        out["pcie_inclusive"] = pcie_inclusive_rates()
+        out["block_manager"] = block_manager_rates()
+    except Exception as e:  # noqa: BLE001 -- secondary numbers must never cost the headline line
+        out.setdefault("pcie_inclusive", {"error": f"{type(e).__name__}: {e}"[:300]})
+    return out
+
+
+# --------------------------------------------------------------------------- launching
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no launcher: run ourselves under torch.distributed.run, one
+    rank per GPU, on a free local port.  stdout/stderr are inherited, so rank 0's JSON line is ours."""
+    env = dict(os.environ, GARAGE_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args) -> None:
+    """--launch-check: only the launch plumbing (rank discovery, process group, one reduction), no
+    GPU work -- runs on a CPU-only box with gloo.  tests/test_bench_launch.py."""
+    if args.mode == "threads":
+        seen = []
+        th = [threading.Thread(target=lambda t=t: seen.append(t)) for t in range(args.gpus)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        print(json.dumps({"launch_check": True, "mode": "threads", "world": args.gpus, "ranks_seen": len(seen)}), flush=True)
+        return
+    from garage_amd import distrib
+
+    R = distrib.init_from_env()
+    if R.world != args.gpus:
+        sys.exit(f"WORLD_SIZE={R.world} does not match --gpus {args.gpus}")
+    c = distrib.count_ranks(R)
+    per = distrib.gather_ints(R, R.rank)
+    if R.rank == 0:
+        print(json.dumps({"launch_check": True, "mode": "procs", "world": R.world, "ranks_seen": c["ranks"],
+                          "backend": c["backend"], "ranks": per,
+                          "self_launched": bool(os.environ.get("GARAGE_BENCH_SELF_LAUNCHED"))}), flush=True)
+    distrib.shutdown(R)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=BATCH, help="blocks per GPU (default 1024 = BASELINE config 2)")
+    ap.add_argument("--mode", choices=["procs", "threads"], default="procs",
+                    help="procs = one process per GPU (torch.distributed.run; self-launched when WORLD_SIZE is unset); "
+                         "threads = one process, N codecs, N host threads through the C ABI")
+    ap.add_argument("--variant", type=int, default=0, help="0 nibble product tables (default), 1 log/antilog baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-oracle-check", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the pcie_inclusive / block_manager objects (N=1)")
+    ap.add_argument("--no-striped", action="store_true", help="N>1: skip the BASELINE config 5 striped_decode object")
+    ap.add_argument("--striped", action="store_true", help="N=1: also run the striped_decode object (RCCL with one rank)")
+    ap.add_argument("--striped-objects", type=int, default=256)
+    ap.add_argument("--striped-timeout", type=float, default=240.0,
+                    help="watchdog for the striped_decode object: after this many seconds the line is printed without it")
+    ap.add_argument("--precondition-ms", type=float, default=200.0,
+                    help="untimed device pre-conditioning before the W warm-up steps: the same encode launches for this "
+                         "long, so a short K/W does not measure MI355X's idle-to-load DVFS transient (0 disables)")
+    ap.add_argument("--op", choices=["encode", "striped-decode"], default="encode",
+                    help="encode = the BASELINE metric (default); striped-decode = only BASELINE config 5: RS(20,8), 4 MiB "
+                         "objects striped over the ranks, all-gather + per-rank byte-range reconstruct")
+    ap.add_argument("--collective", choices=["torch", "cabi"], default="cabi",
+                    help="striped decode: who drives RCCL -- libgarage_ec's gec_group_* C ABI (default) or torch.distributed")
+    ap.add_argument("--launch-check", action="store_true", help="exercise only the launch plumbing (no GPU needed)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+
+    if args.mode == "procs" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.launch_check:
+        launch_check(args)
+    elif args.mode == "threads":
+        run_threads(args)
+    else:
+        run_procs(args)
 
 
 if __name__ == "__main__":

@@ -42,6 +42,7 @@ SYMBOLS = [
     "gec_group_unique_id", "gec_group_create", "gec_group_create_with_transport", "gec_group_destroy",
     "gec_group_rank", "gec_group_size", "gec_group_slots", "gec_group_allgather_decode",
     "gec_launch_geometry",
+    "gec_host_alloc", "gec_host_free", "gec_host_register", "gec_host_unregister", "gec_host_is_pinned",
 ]
 GEC_GROUP_ID_BYTES = 128
 # int (*gec_allgather_fn)(void *ctx, const void *d_send, void *d_recv, size_t bytes, void *hip_stream)
@@ -116,6 +117,13 @@ def _load() -> ctypes.CDLL:
     lib.gec_set_kernel_variant.argtypes = [ci]
     ip = ctypes.POINTER(ci)
     lib.gec_launch_geometry.argtypes = [ci, ci, ip, ip, ip, ip, ctypes.POINTER(sz)]
+    lib.gec_host_alloc.argtypes = [sz]
+    lib.gec_host_alloc.restype = vp
+    lib.gec_host_free.argtypes = [vp]
+    lib.gec_host_free.restype = None
+    lib.gec_host_register.argtypes = [vp, sz]
+    lib.gec_host_unregister.argtypes = [vp]
+    lib.gec_host_is_pinned.argtypes = [vp, sz]
     lib.gec_group_unique_id.argtypes = [u8p]
     lib.gec_group_create.argtypes = [vp, ci, ci, u8p, pp]
     lib.gec_group_create_with_transport.argtypes = [vp, ci, ci, vp, vp, pp]

@@ -309,5 +309,18 @@ class ReedSolomon:
         return self.reconstruct(shards, data_only=True)
 
 
+def host_alloc(nbytes: int) -> np.ndarray:
+    """A uint8 array over pinned host memory from gec_host_alloc: buffers handed to the host-pointer
+    calls from such arrays go over PCIe without the staging copy.  Release with host_free(arr)."""
+    p = lib.gec_host_alloc(nbytes)
+    if not p:
+        raise GecError(_lib.GEC_E_NOMEM, "gec_host_alloc", (lib.gec_last_error() or b"").decode("utf-8", "replace"))
+    return np.ctypeslib.as_array((ctypes.c_uint8 * max(nbytes, 1)).from_address(p))[:nbytes]
+
+
+def host_free(arr: np.ndarray) -> None:
+    lib.gec_host_free(ctypes.c_void_p(arr.ctypes.data))
+
+
 def set_kernel_variant(v: int) -> None:
     check(lib.gec_set_kernel_variant(v), "gec_set_kernel_variant")

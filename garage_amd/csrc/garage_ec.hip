@@ -186,6 +186,57 @@ unsigned copy_pool_threads()
 	return std::min(7u, hw - 1);
 }
 
+// Pinned host ranges the caller told us about (gec_host_alloc / gec_host_register): blocks and
+// output buffers that lie inside one go over PCIe by DMA straight from / to the caller's memory,
+// without the pageable -> pinned staging copy (which costs a third of the PCIe-inclusive rate).
+class PinnedRanges {
+public:
+	void add(const void *p, size_t n, bool owned)
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		ranges_[reinterpret_cast<uintptr_t>(p)] = {n, owned};
+	}
+	// returns true and whether the library allocated it
+	bool remove(const void *p, bool &owned)
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		auto it = ranges_.find(reinterpret_cast<uintptr_t>(p));
+		if (it == ranges_.end())
+			return false;
+		owned = it->second.owned;
+		ranges_.erase(it);
+		return true;
+	}
+	bool contains(const void *p, size_t n) const
+	{
+		if (!p)
+			return false;
+		const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+		std::lock_guard<std::mutex> g(mu_);
+		if (ranges_.empty())
+			return false;
+		auto it = ranges_.upper_bound(a);
+		if (it == ranges_.begin())
+			return false;
+		--it;
+		return a >= it->first && a + n <= it->first + it->second.len;
+	}
+
+private:
+	struct R {
+		size_t len;
+		bool owned;
+	};
+	mutable std::mutex mu_;
+	std::map<uintptr_t, R> ranges_;
+};
+
+PinnedRanges &pinned()
+{
+	static PinnedRanges r;
+	return r;
+}
+
 // Staging resources for the host-pointer entry points (one per in-flight call).
 struct Staging {
 	hipStream_t stream = nullptr;
@@ -1311,6 +1362,51 @@ int gec_group_allgather_decode(gec_group *g, size_t nobjects, const void *d_loca
 	return GEC_OK;
 }
 
+// ------------------------------------------------------------ pinned host memory
+void *gec_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	// portable: usable by every device's DMA engines (one process may drive several codecs)
+	hipError_t e = hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocPortable);
+	if (e != hipSuccess) {
+		fail(e == hipErrorOutOfMemory ? GEC_E_NOMEM : GEC_E_DEVICE, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+		return nullptr;
+	}
+	pinned().add(p, std::max<size_t>(bytes, 1), true);
+	return p;
+}
+
+void gec_host_free(void *p)
+{
+	bool owned = false;
+	if (p && pinned().remove(p, owned) && owned)
+		(void)hipHostFree(p);
+}
+
+int gec_host_register(void *p, size_t bytes)
+{
+	if (!p || bytes == 0)
+		return fail(GEC_E_INVALID_ARG, "NULL / empty range");
+	HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable));
+	pinned().add(p, bytes, false);
+	return GEC_OK;
+}
+
+int gec_host_unregister(void *p)
+{
+	bool owned = false;
+	if (!p || !pinned().remove(p, owned))
+		return fail(GEC_E_INVALID_ARG, "not a registered range");
+	if (owned) {  // it came from gec_host_alloc: treat like gec_host_free
+		(void)hipHostFree(p);
+		return GEC_OK;
+	}
+	HIP_TRY(hipHostUnregister(p));
+	return GEC_OK;
+}
+
+int gec_host_is_pinned(const void *p, size_t bytes) { return pinned().contains(p, bytes) ? 1 : 0; }
+
 // -------------------------------------------------------- host-pointer API
 static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *const *blocks, const size_t *block_len,
 			     size_t S, uint8_t *const *parity, uint8_t *shard_sums)
@@ -1337,10 +1433,25 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 	// chunks are 8x larger when checksums are requested
 	const size_t ch = chunk_blocks(stripe, nblocks, shard_sums ? 8 * kChunkBytes : kChunkBytes);
 	const size_t sums_off = ch * stripe;  // checksum area behind the stripes of a slot
+	const size_t nchunks = (nblocks + ch - 1) / ch;
 	CopyPool &pool = c->copy_pool();
+	// per chunk: are all its blocks / all its parity buffers in pinned memory the caller registered?
+	// Then the DMA engines read / write the caller's memory directly and the staging copy is skipped.
+	std::vector<uint8_t> in_pinned(nchunks, 1), out_pinned(nchunks, 1);
+	std::vector<size_t> min_len(nchunks, k * S);
+	for (size_t b = 0; b < nblocks; ++b) {
+		const size_t ci = b / ch;
+		if (in_pinned[ci] && !pinned().contains(blocks[b], block_len[b]))
+			in_pinned[ci] = 0;
+		if (out_pinned[ci] && !pinned().contains(parity[b], m * S))
+			out_pinned[ci] = 0;
+		min_len[ci] = std::min(min_len[ci], block_len[b]);
+	}
 	return run_pipeline(
-		c, (nblocks + ch - 1) / ch, ch * stripe + (shard_sums ? ch * n * 32 : 0), 0,
+		c, nchunks, ch * stripe + (shard_sums ? ch * n * 32 : 0), 0,
 		[&](size_t ci, Staging &st) {  // host: user blocks -> pinned, zero-padded to k*S
+			if (in_pinned[ci])
+				return;
 			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
 			pool.parallel_for(nb, [&](size_t i) {
 				uint8_t *dst = st.h_buf + i * stripe;
@@ -1350,12 +1461,45 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 			});
 		},
 		[&](size_t ci, Staging &st) -> int {  // device: only data shards go H2D, only parity (+sums) comes back
-			const size_t nb = std::min(ch, nblocks - ci * ch);
-			HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, st.h_buf, stripe, k * S, nb, hipMemcpyHostToDevice, st.stream));
+			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
+			if (in_pinned[ci]) {
+				// zero padding behind the shortest block of the chunk first (stream order), then
+				// every block straight from the caller's memory
+				if (min_len[ci] < k * S)
+					HIP_TRY(hipMemset2DAsync(st.d_buf + min_len[ci], stripe, 0, k * S - min_len[ci], nb, st.stream));
+				// equally spaced, equally long blocks (one big pinned arena): ONE strided copy
+				const size_t len0 = block_len[b0];
+				bool strided = nb > 1 && blocks[b0 + 1] > blocks[b0];
+				const size_t pitch = nb > 1 ? (size_t)(blocks[b0 + 1] - blocks[b0]) : 0;
+				for (size_t i = 0; i < nb && strided; ++i)
+					strided = block_len[b0 + i] == len0 && blocks[b0 + i] == blocks[b0] + i * pitch;
+				if (strided && pitch >= len0 && len0 > 0) {
+					HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, blocks[b0], pitch, len0, nb, hipMemcpyHostToDevice, st.stream));
+				} else {
+					for (size_t i = 0; i < nb; ++i)
+						if (block_len[b0 + i])
+							HIP_TRY(hipMemcpyAsync(st.d_buf + i * stripe, blocks[b0 + i], block_len[b0 + i], hipMemcpyHostToDevice, st.stream));
+				}
+			} else {
+				HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, st.h_buf, stripe, k * S, nb, hipMemcpyHostToDevice, st.stream));
+			}
 			int rc = encode_dev(c, nb, st.d_buf, stripe, S, st.d_buf + k * S, stripe, st.stream);
 			if (rc)
 				return rc;
-			HIP_TRY(hipMemcpy2DAsync(st.h_buf + k * S, stripe, st.d_buf + k * S, stripe, m * S, nb, hipMemcpyDeviceToHost, st.stream));
+			if (out_pinned[ci]) {
+				bool strided = nb > 1 && parity[b0 + 1] > parity[b0];
+				const size_t pitch = nb > 1 ? (size_t)(parity[b0 + 1] - parity[b0]) : 0;
+				for (size_t i = 0; i < nb && strided; ++i)
+					strided = parity[b0 + i] == parity[b0] + i * pitch;
+				if (strided && pitch >= m * S) {
+					HIP_TRY(hipMemcpy2DAsync(parity[b0], pitch, st.d_buf + k * S, stripe, m * S, nb, hipMemcpyDeviceToHost, st.stream));
+				} else {
+					for (size_t i = 0; i < nb; ++i)
+						HIP_TRY(hipMemcpyAsync(parity[b0 + i], st.d_buf + i * stripe + k * S, m * S, hipMemcpyDeviceToHost, st.stream));
+				}
+			} else {
+				HIP_TRY(hipMemcpy2DAsync(st.h_buf + k * S, stripe, st.d_buf + k * S, stripe, m * S, nb, hipMemcpyDeviceToHost, st.stream));
+			}
 			if (shard_sums) {  // all nb*n shards are S bytes, S apart: one uniform launch
 				rc = blake2_dev(nb * n, st.d_buf, nullptr, nullptr, S, S, st.d_buf + sums_off, st.stream);
 				if (rc)
@@ -1366,7 +1510,8 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 		},
 		[&](size_t ci, Staging &st) {  // host: parity (+sums) -> user buffers
 			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
-			pool.parallel_for(nb, [&](size_t i) { std::memcpy(parity[b0 + i], st.h_buf + i * stripe + k * S, m * S); });
+			if (!out_pinned[ci])
+				pool.parallel_for(nb, [&](size_t i) { std::memcpy(parity[b0 + i], st.h_buf + i * stripe + k * S, m * S); });
 			if (shard_sums)
 				std::memcpy(shard_sums + b0 * n * 32, st.h_buf + sums_off, nb * n * 32);
 		});
@@ -1559,9 +1704,25 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 			in_off[t] = t * S;
 		for (size_t r = 0; r < nmiss; ++r)
 			out_off[r] = (k + r) * S;
+		// chunks whose input shards (resp. output buffers) all lie in registered pinned memory go by
+		// DMA straight from / to the caller's memory; adjacent shards (slices of one block buffer)
+		// are merged into one copy
+		const size_t nchunks = (ids.size() + ch - 1) / ch;
+		std::vector<uint8_t> in_pinned(nchunks, 1), out_pinned(nchunks, 1);
+		for (size_t i = 0; i < ids.size(); ++i) {
+			const size_t ci = i / ch;
+			for (size_t t = 0; t < k && in_pinned[ci]; ++t)
+				if (!pinned().contains(shards[ids[i] * n + plan->valid[t]], S))
+					in_pinned[ci] = 0;
+			for (size_t r = 0; r < nmiss && out_pinned[ci]; ++r)
+				if (!pinned().contains(out[ids[i] * n + plan->missing[r]], S))
+					out_pinned[ci] = 0;
+		}
 		rc = run_pipeline(
-			c, (ids.size() + ch - 1) / ch, ch * stripe, 0,
+			c, nchunks, ch * stripe, 0,
 			[&](size_t ci, Staging &st) {
+				if (in_pinned[ci])
+					return;
 				const size_t i0 = ci * ch, nb = std::min(ch, ids.size() - i0);
 				pool.parallel_for(nb * k, [&](size_t q) {
 					const size_t i = q / k, t = q % k;
@@ -1569,16 +1730,44 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 				});
 			},
 			[&](size_t ci, Staging &st) -> int {
-				const size_t nb = std::min(ch, ids.size() - ci * ch);
-				HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, st.h_buf, stripe, k * S, nb, hipMemcpyHostToDevice, st.stream));
+				const size_t i0 = ci * ch, nb = std::min(ch, ids.size() - i0);
+				if (in_pinned[ci]) {
+					for (size_t i = 0; i < nb; ++i) {
+						const uint8_t *const *sh = shards + ids[i0 + i] * n;
+						for (size_t t = 0; t < k;) {
+							size_t run = 1;
+							while (t + run < k && sh[plan->valid[t + run]] == sh[plan->valid[t]] + run * S)
+								++run;
+							HIP_TRY(hipMemcpyAsync(st.d_buf + i * stripe + t * S, sh[plan->valid[t]], run * S, hipMemcpyHostToDevice, st.stream));
+							t += run;
+						}
+					}
+				} else {
+					HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, st.h_buf, stripe, k * S, nb, hipMemcpyHostToDevice, st.stream));
+				}
 				int r2 = launch_apply(c, st.d_buf, stripe, st.d_buf, stripe, nullptr, 0, S, nb, in_off.data(),
 						      out_off.data(), (int)nmiss, plan->rows.v.data(), gec::MODE_STORE, st.stream);
 				if (r2)
 					return r2;
-				HIP_TRY(hipMemcpy2DAsync(st.h_buf + k * S, stripe, st.d_buf + k * S, stripe, nmiss * S, nb, hipMemcpyDeviceToHost, st.stream));
+				if (out_pinned[ci]) {
+					for (size_t i = 0; i < nb; ++i) {
+						uint8_t *const *o = out + ids[i0 + i] * n;
+						for (size_t r = 0; r < nmiss;) {
+							size_t run = 1;
+							while (r + run < nmiss && o[plan->missing[r + run]] == o[plan->missing[r]] + run * S)
+								++run;
+							HIP_TRY(hipMemcpyAsync(o[plan->missing[r]], st.d_buf + i * stripe + (k + r) * S, run * S, hipMemcpyDeviceToHost, st.stream));
+							r += run;
+						}
+					}
+				} else {
+					HIP_TRY(hipMemcpy2DAsync(st.h_buf + k * S, stripe, st.d_buf + k * S, stripe, nmiss * S, nb, hipMemcpyDeviceToHost, st.stream));
+				}
 				return GEC_OK;
 			},
 			[&](size_t ci, Staging &st) {
+				if (out_pinned[ci])
+					return;
 				const size_t i0 = ci * ch, nb = std::min(ch, ids.size() - i0);
 				pool.parallel_for(nb * nmiss, [&](size_t q) {
 					const size_t i = q / nmiss, r = q % nmiss;

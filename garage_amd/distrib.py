@@ -41,7 +41,12 @@ def init_from_env(force_backend: str | None = None) -> Ranks:
     if use_cuda:
         # a launcher may already have narrowed each rank to its own GPU (HIP_VISIBLE_DEVICES):
         # then every rank sees one device, index 0
-        local_rank = local_rank % max(1, torch.cuda.device_count())
+        ndev = max(1, torch.cuda.device_count())
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        if not dryrun and ndev > 1 and ndev < local_world:
+            raise RuntimeError(f"{local_world} ranks on this node but only {ndev} GPUs are visible: RCCL refuses two ranks "
+                               "on one device (GARAGE_DRYRUN_ONE_GPU=1 gives a plumbing-only dry run on device 0)")
+        local_rank = local_rank % ndev
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
     else:
@@ -96,6 +101,33 @@ def sum_over_ranks(r: Ranks, value: int) -> int:
     t = torch.tensor([value], dtype=torch.int64, device=r.device if r.backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+def gather_ints(r: Ranks, value: int) -> list[int]:
+    """value of every rank, in rank order, on every rank."""
+    if not r.distributed:
+        return [int(value)]
+    import torch.distributed as dist
+
+    dev = r.device if r.backend == "nccl" else "cpu"
+    mine = torch.tensor([value], dtype=torch.int64, device=dev)
+    out = torch.empty((r.world,), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, mine)
+    return [int(x) for x in out.tolist()]
+
+
+def count_ranks(r: Ranks) -> dict:
+    """How many ranks the collective backend actually connected: an all-reduce (SUM) of ones --
+    on the device over RCCL when the backend is "nccl" -- so "RCCL saw N ranks" is a measured
+    statement, not WORLD_SIZE read back from the environment."""
+    if not r.distributed:
+        return {"ranks": 1, "backend": "none (single process)"}
+    import torch.distributed as dist
+
+    t = torch.ones(1, dtype=torch.int32, device=r.device if r.backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    name = "rccl (torch.distributed backend nccl)" if r.backend == "nccl" else r.backend
+    return {"ranks": int(t.item()), "backend": name}
 
 
 def shutdown(r: Ranks) -> None:

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GEC_VERSION 0x00010000u /* major.minor.patch = 0.1.0 */
+#define GEC_VERSION 0x00020000u /* major.minor.patch = 0.2.0 */
 #define GEC_MAX_SHARDS 256      /* GF(2^8): k + m <= 256 [EXT] */
 
 typedef struct gec_codec gec_codec; /* opaque */
@@ -124,6 +124,19 @@ int gec_codec_cache_stats(const gec_codec *c, uint64_t *cached,
 /* ------------------------------------------------ host-pointer entry points
  * What the Rust shim calls.  Caller owns every buffer for the duration of the
  * call; the library keeps no pointer after return. */
+
+/* Pinned (page-locked, DMA-able) host memory.  The host-pointer entry points below accept ANY
+ * memory; buffers that lie inside a range obtained here are moved over PCIe by DMA straight from /
+ * to the caller's memory, while ordinary pageable buffers are first copied through the library's
+ * own pinned staging slots (which costs about a third of the PCIe-inclusive rate).  The Rust
+ * shim would draw the block buffers PutObject fills (src/api/s3/put.rs:440-456) and the parity
+ * buffers from a pool allocated with gec_host_alloc, or register its existing arena once.
+ * Process-wide, thread-safe, usable with every device's codec. */
+void *gec_host_alloc(size_t bytes);   /* NULL on failure (gec_last_error) */
+void gec_host_free(void *p);
+int gec_host_register(void *p, size_t bytes);   /* pin caller-owned memory (hipHostRegister) */
+int gec_host_unregister(void *p);
+int gec_host_is_pinned(const void *p, size_t bytes); /* 1 if [p, p+bytes) lies inside one such range */
 
 /* == ReedSolomon::encode_sep(&data, &mut parity) [EXT], batched.
  * Replaces the "clone the same Bytes to rf nodes" fan-out payload of

@@ -65,6 +65,8 @@ def main():
         case(co, "config3_mixed_rs10_4_1MiB", 3, 10, 4, 1 << 20, 4, (0, 3, 7, 11)),
         case(co, "config5_rs20_8_4MiB", 5, 20, 8, 4 << 20, 2, (0, 1, 5, 9, 13, 19, 21, 27)),
         case(co, "ragged_rs10_4_999999", 6, 10, 4, 999_999, 3, (9, 13)),
+        # the headline batch itself (BASELINE config 2 / 3): 1024 blocks of 1 MiB, one digest over all parity
+        case(co, "config2_full_batch_rs10_4_1MiB_x1024", 7, 10, 4, 1 << 20, 1024, (0, 3, 7, 9)),
     ]
     with open(os.path.join(HERE, "rs_golden.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py (CPU oracle)", "cases": cases}, f, indent=1)

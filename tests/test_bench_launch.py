@@ -1,0 +1,98 @@
+"""bench.py must start however it is launched: under
+torch.distributed.run (what the driver does), plainly with --gpus N (it re-launches itself),
+and as one process with N codecs / N host threads (--mode threads).  On CPU only the launch
+plumbing runs (--launch-check: rank discovery, process group over gloo, one reduction); on a GPU
+box the real encode bench runs in both modes with every rank / codec on device 0
+(GARAGE_DRYRUN_ONE_GPU=1 -- numbers meaningless, control flow identical)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd, env=None, timeout=600):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, f"{' '.join(cmd)}\n{r.stdout}\n{r.stderr[-3000:]}"
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line on stdout, got {len(lines)}:\n{r.stdout}"
+    return json.loads(lines[0])
+
+
+def test_plain_invocation_self_launches_n_ranks():
+    d = _run([sys.executable, BENCH, "--gpus", "2", "--launch-check"])
+    assert d == {"launch_check": True, "mode": "procs", "world": 2, "ranks_seen": 2, "backend": "gloo",
+                 "ranks": [0, 1], "self_launched": True}
+
+
+def test_under_torch_distributed_run():
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+              "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "3", "--launch-check"])
+    assert d["world"] == 3 and d["ranks_seen"] == 3 and d["ranks"] == [0, 1, 2] and d["self_launched"] is False
+
+
+def test_threads_mode_launch_check():
+    d = _run([sys.executable, BENCH, "--gpus", "4", "--mode", "threads", "--launch-check"])
+    assert d["mode"] == "threads" and d["world"] == 4 and d["ranks_seen"] == 4
+
+
+def test_world_size_mismatch_is_an_error():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check"], cwd=ROOT, capture_output=True, text=True,
+                       env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "does not match --gpus" in (r.stderr + r.stdout)
+
+
+SMALL = ["--steps", "5", "--warmup", "2", "--precondition-ms", "0", "--batch", "64", "--no-cpu-baseline"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_gpu_procs_mode_two_ranks_on_one_gpu(launcher):
+    if launcher == "self":
+        cmd = [sys.executable, BENCH, "--gpus", "2"] + SMALL
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "2"] + SMALL
+    d = _run(cmd, env={"GARAGE_DRYRUN_ONE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak"
+    per = d["config"]["blocks_per_rank"]
+    assert len(per) == 2 and sum(per) == 128 == d["config"]["blocks_total"]
+    assert d["parity_checked_blocks"] >= 32 and d["roofline"]["frac"] > 0 and "decode" in d
+
+
+@pytest.mark.gpu
+def test_gpu_threads_mode_two_codecs_on_one_gpu():
+    d = _run([sys.executable, BENCH, "--gpus", "2", "--mode", "threads"] + SMALL, env={"GARAGE_DRYRUN_ONE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] is None and "threads" in d["config"]["mode"]
+    per = d["config"]["blocks_per_rank"]
+    assert len(per) == 2 and sum(per) == 128 and len(d["kernel_ms_per_gpu"]) == 2
+    assert d["parity_checked_blocks"] >= 32
+
+
+@pytest.mark.gpu
+def test_gpu_n1_modes_agree():
+    """N=1: the two modes run the same kernel on the same batch; their values agree within noise
+    (both short runs, so the bound is loose) and both carry the contract objects."""
+    a = _run([sys.executable, BENCH, "--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--no-host-path"])
+    b = _run([sys.executable, BENCH, "--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--mode", "threads"])
+    assert a["config"]["blocks_total"] == b["config"]["blocks_total"] == 1024
+    assert abs(a["value"] - b["value"]) / a["value"] < 0.10, (a["value"], b["value"])
+    for d in (a, b):
+        assert d["roofline"]["bound"] == "hbm" and 0.3 < d["roofline"]["frac"] < 1.0
+        assert d["roofline"]["cold_burst_frac"] > 0

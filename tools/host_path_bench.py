@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""The path above the kernel, bounded to a few seconds: (a) PCIe-inclusive rate of the
+host-pointer C ABI (what the Rust shim calls) and (b) put/get rate of the C++ BlockManager
+mirror on in-memory nodes.  bench.py embeds both objects in its JSON line at N=1
+(`pcie_inclusive`, `block_manager`) -- next to the device-resident `value`, never as it
+(SURVEY.md section 8d).  usage: host_path_bench.py [nblocks]"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+K, M, L = 10, 4, 1 << 20
+
+
+def _best(fn, reps):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return min(ts), sorted(ts)[len(ts) // 2]
+
+
+def pcie_inclusive_rates(nb: int = 512, reps: int = 5) -> dict:
+    """gec_encode_batch / gec_reconstruct_batch on host buffers: H2D of the data shards + kernel +
+    D2H of the parity (rebuilt shards).  Two flavours of caller memory: ordinary pageable buffers
+    (the library stages them through its own pinned slots) and buffers from gec_host_alloc (pinned:
+    DMA straight from / to the caller's memory, no staging copy)."""
+    import garage_amd as g
+    from garage_amd._lib import check, lib
+
+    S = g.shard_len(K, L)
+    n = K + M
+    rs = g.ReedSolomon(K, M)
+    rng = np.random.default_rng(1)
+    out = {"what": "host-pointer C ABI, RS(10,4), 1 MiB blocks: H2D data + kernel + D2H parity, payload GiB/s",
+           "nblocks": nb, "pcie_gen5_x16_spec_GBps": 63}
+
+    def run(kind, alloc, free):
+        blocks = [alloc(K * S) for _ in range(nb)]      # padded to k*S so that reconstruct can use them as shards
+        for b in blocks:
+            b[:L] = rng.integers(0, 256, L, dtype=np.uint8)
+            b[L:] = 0
+        outs = [alloc(M * S) for _ in range(nb)]
+        lens = (ctypes.c_size_t * nb)(*[L] * nb)
+        ptrs = (ctypes.c_void_p * nb)(*[b.ctypes.data for b in blocks])
+        optrs = (ctypes.c_void_p * nb)(*[o.ctypes.data for o in outs])
+        enc = lambda: check(lib.gec_encode_batch(rs._h, nb, ptrs, lens, S, optrs), "gec_encode_batch")  # noqa: E731
+        enc()
+        best, med = _best(enc, reps)
+        out[f"encode_{kind}_GiBps"] = round(nb * L / best / 2**30, 2)
+        out[f"encode_{kind}_median_GiBps"] = round(nb * L / med / 2**30, 2)
+        # reconstruct_data: data shards 0 and 3 of every block lost
+        rec = [alloc(2 * S) for _ in range(nb)]
+        sp = (ctypes.c_void_p * (nb * n))()
+        op = (ctypes.c_void_p * (nb * n))()
+        for b in range(nb):
+            for j in range(n):
+                if j in (0, 3):
+                    sp[b * n + j] = None
+                    op[b * n + j] = rec[b].ctypes.data + (0 if j == 0 else S)
+                else:
+                    sp[b * n + j] = blocks[b].ctypes.data + j * S if j < K else outs[b].ctypes.data + (j - K) * S
+        dec = lambda: check(lib.gec_reconstruct_batch(rs._h, nb, sp, op, S, 1), "gec_reconstruct_batch")  # noqa: E731
+        dec()
+        best, _ = _best(dec, reps)
+        assert np.array_equal(rec[0][:S], blocks[0][:S]) and np.array_equal(rec[-1][S:], blocks[-1][3 * S:4 * S])
+        out[f"reconstruct_data_2_lost_{kind}_GiBps"] = round(nb * L / best / 2**30, 2)
+        for a in blocks + outs + rec:
+            free(a)
+
+    run("pageable", lambda sz: np.empty(sz, dtype=np.uint8), lambda a: None)
+    if hasattr(lib, "gec_host_alloc"):
+        from garage_amd.codec import host_alloc, host_free
+
+        run("pinned", host_alloc, host_free)
+    return out
+
+
+def block_manager_rates(nb: int = 512, threads: int = 16) -> dict:
+    """libgarage_block (C++ BlockManager mirror) on 16 in-memory nodes: coalesced put, get, get with
+    4 nodes down (every block needs a decode), and concurrent single-block puts through the batcher."""
+    import garage_amd as g
+    from garage_amd import block_native as bn
+
+    codec = g.ReedSolomon(K, M)
+    mgr = bn.NativeBlockManager(codec, 16)
+    rng = np.random.default_rng(3)
+    blocks = [rng.integers(0, 256, L, dtype=np.uint8).tobytes() for _ in range(nb)]
+    hashes = codec.blake2sum_batch(blocks)          # Garage's block names, computed on the GPU
+    items = list(zip(hashes, blocks))
+    mgr.rpc_put_blocks(items)                       # warm: sizes the staging buffers
+    mgr.rpc_get_blocks(hashes, L)
+    gib = nb * L / 2**30
+    t_put, _ = _best(lambda: mgr.rpc_put_blocks(items), 3)
+    got = []
+    t_get, _ = _best(lambda: got.__setitem__(slice(None), mgr.rpc_get_blocks(hashes, L)), 3)
+    assert got == blocks
+    for node in range(4):
+        mgr.node_set_down(node, True)
+    t_deg, _ = _best(lambda: got.__setitem__(slice(None), mgr.rpc_get_blocks(hashes, L)), 3)
+    assert got == blocks
+    for node in range(4):
+        mgr.node_set_down(node, False)
+    bt = bn.Batcher(mgr, max_blocks=128, max_wait_us=300)
+    per = max(1, nb // threads)
+
+    def worker(t):
+        for j in range(per):
+            i = t * per + j
+            bt.put_block(hashes[i], blocks[i])
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    t0 = time.perf_counter()
+    [x.start() for x in th]
+    [x.join() for x in th]
+    t_bat = time.perf_counter() - t0
+    bstats = bt.stats()
+    bt.close()
+    res = {
+        "what": "libgarage_block (C++ BlockManager mirror over the C ABI), RS(10,4), 1 MiB blocks, 16 in-memory nodes, payload GiB/s",
+        "nblocks": nb,
+        "rpc_put_blocks_GiBps": round(gib / t_put, 2),
+        "rpc_get_blocks_GiBps": round(gib / t_get, 2),
+        "rpc_get_blocks_4_nodes_down_GiBps": round(gib / t_deg, 2),
+        f"batcher_{threads}_threads_put_GiBps": round(threads * per * L / 2**30 / t_bat, 2),
+        "batcher_stats": bstats,
+        "ec_reconstructs": mgr.metrics["ec_reconstructs"],
+        "messages_hashed_on_gpu": mgr.gpu_hashed(),
+    }
+    mgr.close()
+    return res
+
+
+if __name__ == "__main__":
+    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    print(json.dumps({"pcie_inclusive": pcie_inclusive_rates(nb), "block_manager": block_manager_rates(nb)}))
