@@ -247,6 +247,18 @@ class ReedSolomon:
               "gec_blake2sum_batch_dev")
         return out
 
+    def encode_hash_dev(self, stripes):
+        """encode_dev + the blake2sum of all k+m shards of every stripe, device-resident
+        (gec_encode_hash_batch_dev): -> (nblocks, k+m, 32) uint8 CUDA tensor of checksums."""
+        import torch
+
+        self._check_dev(stripes, self.n, "stripes")
+        nb, _, S = stripes.shape
+        sums = torch.empty((nb, self.n, 32), dtype=torch.uint8, device=stripes.device)
+        check(lib.gec_encode_hash_batch_dev(self._h, nb, stripes.data_ptr(), self.n * S, S, sums.data_ptr(),
+                                            _stream_handle(self.device)), "gec_encode_hash_batch_dev")
+        return sums
+
     def verify(self, stripes: np.ndarray) -> np.ndarray:
         """stripes: (nblocks, k+m, S) host array -> bool (nblocks,)."""
         st = np.ascontiguousarray(stripes, dtype=np.uint8)

@@ -19,35 +19,63 @@ namespace gec {
 
 struct Blake2Args {
 	const uint8_t *base;
-	const uint64_t *off;   // per-message byte offset from base (NULL: i * stride)
+	const uint64_t *off;   // per-message byte offset from base (NULL: computed, below)
 	const uint64_t *len;   // per-message length (NULL: uniform_len)
-	uint64_t stride;
-	uint64_t uniform_len;
-	uint8_t *out;          // 32 bytes per message
-	uint32_t n;
+	uint64_t stride;       // message i at base + i*stride, or with group != 0:
+	uint64_t uniform_len;  //   base + (i / group)*group_stride + (i % group)*stride
+	uint8_t *out;          // 32 bytes per message, at out + 32*i, or with group != 0:
+	uint32_t n;            //   out + 32*((i / group)*out_group + i % group)
+	uint32_t group;        // messages per group (e.g. the m parity shards of one stripe); 0 = flat
+	uint64_t group_stride;
+	uint32_t out_group;
 };
+
+__device__ __forceinline__ const uint8_t *b2_msg_ptr(const Blake2Args &a, uint32_t i)
+{
+	if (a.off)
+		return a.base + a.off[i];
+	if (a.group)
+		return a.base + (uint64_t)(i / a.group) * a.group_stride + (uint64_t)(i % a.group) * a.stride;
+	return a.base + (uint64_t)i * a.stride;
+}
+
+__device__ __forceinline__ uint8_t *b2_out_ptr(const Blake2Args &a, uint32_t i)
+{
+	if (a.group)
+		return a.out + 32ull * ((uint64_t)(i / a.group) * a.out_group + i % a.group);
+	return a.out + 32ull * i;
+}
 
 // rotr64 as two v_alignbit_b32 on the 32-bit halves (hipcc's generic lowering is a
 // 64-bit shift + shift + or); n = 32 is a free register swap.
+typedef uint32_t b2_u32x2 __attribute__((ext_vector_type(2)));
+
+// {lo, hi} -> u64 as a register pair.  NOT `(hi << 32) | lo`: LLVM turns that `or` of disjoint bits into
+// an add and then folds it into the following 64-bit add as TWO v_lshl_add_u64 (c + lo + (hi << 32)),
+// i.e. one more quarter-rate instruction on the dependency chain after every rotate.
+__device__ __forceinline__ uint64_t b2_mk64(uint32_t lo, uint32_t hi)
+{
+	const b2_u32x2 v = {lo, hi};
+	return __builtin_bit_cast(uint64_t, v);
+}
+
 template <int N>
 __device__ __forceinline__ uint64_t b2_rotr(uint64_t x)
 {
-	const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+	const b2_u32x2 h = __builtin_bit_cast(b2_u32x2, x);
+	const uint32_t lo = h.x, hi = h.y;
 	if (N == 32)
-		return ((uint64_t)lo << 32) | hi;
-	if (N < 32) {
-		const uint32_t nlo = __builtin_amdgcn_alignbit(hi, lo, N);
-		const uint32_t nhi = __builtin_amdgcn_alignbit(lo, hi, N);
-		return ((uint64_t)nhi << 32) | nlo;
-	}
+		return b2_mk64(hi, lo);
+	if (N < 32)
+		return b2_mk64(__builtin_amdgcn_alignbit(hi, lo, N), __builtin_amdgcn_alignbit(lo, hi, N));
 	// N > 32: rotate by 32 (swap) then by N - 32
-	const uint32_t nlo = __builtin_amdgcn_alignbit(lo, hi, N - 32);
-	const uint32_t nhi = __builtin_amdgcn_alignbit(hi, lo, N - 32);
-	return ((uint64_t)nhi << 32) | nlo;
+	return b2_mk64(__builtin_amdgcn_alignbit(lo, hi, N - 32), __builtin_amdgcn_alignbit(hi, lo, N - 32));
 }
 
-// 64-bit add as add + add-with-carry on the halves (two full-rate VALU ops); hipcc's
-// own choice, v_lshl_add_u64, issues at the 64-bit rate and made the chain ~1.6x slower.
+// 64-bit add: ADD32 = false keeps hipcc's own choice, v_lshl_add_u64 (one instruction), which is what
+// both kernels use.  ADD32 = true spells it as add + add-with-carry on the halves; measured 1.44x SLOWER
+// in round 1 (the carry travels through VCC, which serialises the four independent G chains), kept as the
+// A/B switch of tools/blake2_bench.py.
 template <bool ADD32>
 __device__ __forceinline__ uint64_t b2_add(uint64_t a, uint64_t b)
 {
@@ -120,7 +148,7 @@ __global__ __launch_bounds__(64) void blake2b_batch(const Blake2Args a)
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= a.n)
 		return;
-	const uint8_t *p = a.base + (a.off ? a.off[i] : (uint64_t)i * a.stride);
+	const uint8_t *p = b2_msg_ptr(a, i);
 	const uint64_t len = a.len ? a.len[i] : a.uniform_len;
 	uint64_t h[8] = {0x6a09e667f3bcc908ULL ^ 0x01010040ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL,
 			 0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL,
@@ -153,7 +181,7 @@ __global__ __launch_bounds__(64) void blake2b_batch(const Blake2Args a)
 		m[j] = w;
 	}
 	b2_compress<ADD32>(h, m, len, true);
-	u64x2 *o = reinterpret_cast<u64x2 *>(a.out + (uint64_t)i * 32);
+	u64x2 *o = reinterpret_cast<u64x2 *>(b2_out_ptr(a, i));
 	u64x2 lo = {h[0], h[1]}, hi = {h[2], h[3]};
 	o[0] = lo;
 	o[1] = hi;
@@ -168,10 +196,21 @@ __global__ __launch_bounds__(64) void blake2b_batch(const Blake2Args a)
 // message block is staged in LDS (each lane loads 32 bytes) and every lane gathers
 // the two words its G needs from there: the sigma schedule becomes a packed
 // per-round constant of four 7-bit byte offsets, one v_bfe_u32 away.
-// The per-message chain is ~4x shorter and 4x more lanes are busy, which is what a
-// moderate batch needs: 14336 shard messages = 224 waves with the one-lane kernel
-// (22% of the SIMDs), 896 waves here.  Peak rate with very many messages is lower
-// than the one-lane kernel's (DPP + LDS overhead), so the host picks by batch size.
+//
+// With 14336 shard messages (one 1024-stripe batch) this is 896 single-wave workgroups on
+// 1024 SIMDs: every wave has a SIMD to itself, so a launch lasts as long as ONE message's
+// dependency chain -- 820 blocks x 24 G steps.  Everything that is not on that chain is
+// therefore moved off it:
+//  * the two message words of a step are gathered from LDS ONE STEP AHEAD (they do not
+//    depend on the state), the first step's words of block i+1 during the last step of
+//    block i: two LDS slots per message, block i+1 is written to its slot before block i
+//    is compressed, block i+2 is already on its way from HBM;
+//  * a = a + b + x is evaluated as (a + x) + b: a has been ready for three steps, only b is
+//    fresh, so one 64-bit add instead of two sits on the chain (same for + y);
+//  * the waves raise their priority: when the hash runs beside the RS kernel (encode+hash),
+//    its chain must not queue behind the other kernel's VALU bursts on the same SIMD.
+// Peak rate with very many messages is lower than the one-lane kernel's (DPP + LDS overhead),
+// so the host picks by batch size.
 // ---------------------------------------------------------------------------
 constexpr int B2Q_SLOT = 144;  // LDS bytes per message block: 128 + pad (bank spread, 16-B aligned)
 
@@ -215,110 +254,162 @@ constexpr B2QSchedule b2q_schedule()
 
 typedef __attribute__((address_space(3))) const uint64_t lds_u64_t;
 
-__device__ __forceinline__ void b2q_compress(uint64_t &ha, uint64_t &hb, uint32_t slot_addr, uint32_t q7, uint32_t q,
-					     uint64_t t, bool last)
+// one G with the message words folded in off the dependency chain: (a + x) and, later, (a + y) only
+// need `a`, which is ready long before the freshly rotated `b`
+// b2_pin: an empty asm the optimiser cannot see through -- without it LLVM re-associates (a + x) + b
+// back to (b + x) + a and both adds wait for the freshly rotated b again.
+__device__ __forceinline__ uint64_t b2_pin(uint64_t v)
+{
+	asm("" : "+v"(v));
+	return v;
+}
+
+// One step (the four G of a column or diagonal step, one per lane).  Comes in with ax = a + x already
+// formed (x = this step's first message word), y = the second word, and nx = the NEXT step's first word;
+// leaves ax = a + nx, formed as soon as the new a exists, i.e. in the shadow of the d -> c -> b tail.
+// On the dependency chain per step: 4 adds, 4 xors, 3 rotates (rot 32 is a register swap).
+#define GEC_B2Q_STEP(ax, b, c, d, y, nx)  \
+	{                                     \
+		uint64_t a_ = ax + b;             \
+		d = b2_rotr<32>(d ^ a_);          \
+		c = c + d;                        \
+		b = b2_rotr<24>(b ^ c);           \
+		a_ = b2_pin(a_ + (y)) + b;        \
+		ax = b2_pin(a_ + (nx));           \
+		d = b2_rotr<16>(d ^ a_);          \
+		c = c + d;                        \
+		b = b2_rotr<63>(b ^ c);           \
+	}
+
+// Compresses the block staged in slot `cur`.  ax/y come in holding (a + x) and y of round 0's column
+// step (x, y gathered by the caller or by the previous call) and leave holding those of the NEXT
+// block's, whose words are read from slot `nxt` (garbage after the last block: never used).  The state
+// words a live inside ax: h_a is recovered at the end as ax - (next x).
+__device__ __forceinline__ void b2q_compress(uint64_t &ha, uint64_t &hb, uint32_t cur, uint32_t nxt, uint32_t q7, uint32_t q,
+					     uint64_t t, bool last, uint64_t &x, uint64_t &y)
 {
 	constexpr B2QSchedule SCH = b2q_schedule();
 	const uint64_t IVq = q == 0 ? 0x6a09e667f3bcc908ULL : q == 1 ? 0xbb67ae8584caa73bULL
 			   : q == 2 ? 0x3c6ef372fe94f82bULL : 0xa54ff53a5f1d36f1ULL;
 	const uint64_t IVq4 = q == 0 ? 0x510e527fade682d1ULL : q == 1 ? 0x9b05688c2b3e6c1fULL
 			    : q == 2 ? 0x1f83d9abfb41bd6bULL : 0x5be0cd19137e2179ULL;
-	uint64_t a = ha, b = hb, c = IVq, d = IVq4;
+	uint64_t b = hb, c = IVq, d = IVq4;
+	uint64_t ax = ha + x;
 	if (q == 0)
 		d ^= t;
 	if (q == 2 && last)
 		d = ~d;
-#define GEC_B2Q_WORD(packed) (*reinterpret_cast<lds_u64_t *>(slot_addr + __builtin_amdgcn_ubfe((packed), q7, 7)))
+#define GEC_B2Q_WORD(slot, packed) (*reinterpret_cast<lds_u64_t *>((slot) + __builtin_amdgcn_ubfe((packed), q7, 7)))
 #pragma unroll
 	for (int r = 0; r < 12; ++r) {
-		{  // column step
-			const uint64_t x = GEC_B2Q_WORD(SCH.w[r][0]);
-			const uint64_t y = GEC_B2Q_WORD(SCH.w[r][1]);
-			constexpr bool ADD32 = false;
-			GEC_B2_G(a, b, c, d, x, y)
-		}
+		// column step; the diagonal step's words are gathered first, a whole step ahead of their use
+		const uint64_t dx = GEC_B2Q_WORD(cur, SCH.w[r][2]);
+		const uint64_t dy = GEC_B2Q_WORD(cur, SCH.w[r][3]);
+		__builtin_amdgcn_sched_barrier(0);  // keep the gathers up here: hipcc otherwise sinks them next to their use
+		GEC_B2Q_STEP(ax, b, c, d, y, dx)
 		b = b2_quad_perm<0x39>(b);
 		c = b2_quad_perm<0x4E>(c);
 		d = b2_quad_perm<0x93>(d);
-		{  // diagonal step
-			const uint64_t x = GEC_B2Q_WORD(SCH.w[r][2]);
-			const uint64_t y = GEC_B2Q_WORD(SCH.w[r][3]);
-			constexpr bool ADD32 = false;
-			GEC_B2_G(a, b, c, d, x, y)
-		}
+		// diagonal step; the next column step's words (next round, or next block) are gathered first
+		x = r < 11 ? GEC_B2Q_WORD(cur, SCH.w[r < 11 ? r + 1 : 0][0]) : GEC_B2Q_WORD(nxt, SCH.w[0][0]);
+		y = r < 11 ? GEC_B2Q_WORD(cur, SCH.w[r < 11 ? r + 1 : 0][1]) : GEC_B2Q_WORD(nxt, SCH.w[0][1]);
+		__builtin_amdgcn_sched_barrier(0);
+		GEC_B2Q_STEP(ax, b, c, d, dy, x)
 		b = b2_quad_perm<0x93>(b);
 		c = b2_quad_perm<0x4E>(c);
 		d = b2_quad_perm<0x39>(d);
 	}
 #undef GEC_B2Q_WORD
+	const uint64_t a = ax - x;  // undo the look-ahead add of the (not yet started) next step
 	ha ^= a ^ c;
 	hb ^= b ^ d;
 }
 
+// Lane q's 32-byte quarter of the 128-byte block that starts at byte `off` of a `len`-byte message,
+// zero beyond the end; never reads past p + len.  Full quarters (all but a message's tail) are two
+// 16-byte streaming loads.
+__device__ __forceinline__ void b2q_fetch(const uint8_t *p, uint64_t off, uint64_t len, uint32_t q, u64x2 &w0, u64x2 &w1)
+{
+	const uint64_t o = off + 32 * q;
+	if (o + 32 <= len) {
+		const u64x2 *g = reinterpret_cast<const u64x2 *>(p + o);
+		w0 = __builtin_nontemporal_load(g);
+		w1 = __builtin_nontemporal_load(g + 1);
+		return;
+	}
+	uint64_t w[4];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const uint64_t oj = o + 8 * j;
+		uint64_t v = 0;
+		if (oj + 8 <= len) {
+			v = *reinterpret_cast<const uint64_t *>(p + oj);
+		} else if (oj < len) {
+			for (uint64_t b = 0; b < len - oj; ++b)
+				v |= (uint64_t)p[oj + b] << (8 * b);
+		}
+		w[j] = v;
+	}
+	w0 = u64x2{w[0], w[1]};
+	w1 = u64x2{w[2], w[3]};
+}
+
 __global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
 {
-	__shared__ __attribute__((aligned(16))) uint8_t lds[16 * B2Q_SLOT];
+	__shared__ __attribute__((aligned(16))) uint8_t lds[2 * 16 * B2Q_SLOT];
+	__builtin_amdgcn_s_setprio(3);
 	const uint32_t lane = threadIdx.x;
 	const uint32_t q = lane & 3;
 	const uint32_t i = blockIdx.x * 16 + (lane >> 2);
 	const bool live = i < a.n;
 	const uint32_t ii = live ? i : a.n - 1;  // dead quads shadow the last message (no stores)
-	const uint8_t *p = a.base + (a.off ? a.off[ii] : (uint64_t)ii * a.stride);
+	const uint8_t *p = b2_msg_ptr(a, ii);
 	const uint64_t len = a.len ? a.len[ii] : a.uniform_len;
-	uint8_t *slot = lds + (lane >> 2) * B2Q_SLOT;
-	const uint32_t slot_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)slot;
+	const uint32_t slot0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)(lds + (lane >> 2) * B2Q_SLOT);
+	const uint32_t slot_xor = 16 * B2Q_SLOT;  // slot1 = slot0 + 16*B2Q_SLOT (add/sub alternate below)
 	const uint32_t q7 = q * 7;
 	uint64_t ha = (q == 0 ? 0x6a09e667f3bcc908ULL ^ 0x01010040ULL : q == 1 ? 0xbb67ae8584caa73bULL
 		       : q == 2 ? 0x3c6ef372fe94f82bULL : 0xa54ff53a5f1d36f1ULL);
 	uint64_t hb = (q == 0 ? 0x510e527fade682d1ULL : q == 1 ? 0x9b05688c2b3e6c1fULL
 		       : q == 2 ? 0x1f83d9abfb41bd6bULL : 0x5be0cd19137e2179ULL);
-	uint64_t done = 0;
-	// full blocks, all but the last: each lane stages its 32-byte quarter of the block.
-	// Software-pipelined: the quarter of block i+1 is requested before block i is
-	// compressed, so the HBM latency of a lane's private stream hides under the ~750
-	// instructions of the compression instead of adding to every link of the chain.
-	u64x2 w0 = {0, 0}, w1 = {0, 0};
-	if (len > 128) {
-		const u64x2 *g = reinterpret_cast<const u64x2 *>(p + 32 * q);
-		w0 = __builtin_nontemporal_load(g);
-		w1 = __builtin_nontemporal_load(g + 1);
-	}
-	while (len - done > 128) {
-		u64x2 *s = reinterpret_cast<u64x2 *>(slot + 32 * q);
+	typedef __attribute__((address_space(3))) u64x2 lds_u64x2_w;
+	const uint64_t nblk = len ? (len + 127) / 128 : 1;  // the empty message still has one (all-zero, final) block
+	u64x2 w0, w1;
+	b2q_fetch(p, 0, len, q, w0, w1);
+	{
+		lds_u64x2_w *s = reinterpret_cast<lds_u64x2_w *>(slot0 + 32 * q);
 		s[0] = w0;
 		s[1] = w1;
-		if (len - done > 256) {  // block i+1 is also a full, non-final block: prefetch it
-			const u64x2 *g = reinterpret_cast<const u64x2 *>(p + done + 128 + 32 * q);
-			w0 = __builtin_nontemporal_load(g);
-			w1 = __builtin_nontemporal_load(g + 1);
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		done += 128;
-		b2q_compress(ha, hb, slot_addr, q7, q, done, false);
-		__builtin_amdgcn_wave_barrier();
 	}
-	// last block: 0..128 bytes, zero-padded; never reads past p + len
-	const uint64_t rem = len - done;
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		const uint64_t o = 32 * q + 8 * j;
-		uint64_t w = 0;
-		if (o + 8 <= rem) {
-			w = *reinterpret_cast<const uint64_t *>(p + done + o);
-		} else if (o < rem) {
-			for (uint64_t b = 0; b < rem - o; ++b)
-				w |= (uint64_t)p[done + o + b] << (8 * b);
-		}
-		reinterpret_cast<uint64_t *>(slot + 32 * q)[j] = w;
-	}
+	if (nblk > 1)
+		b2q_fetch(p, 128, len, q, w0, w1);
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-	b2q_compress(ha, hb, slot_addr, q7, q, len, true);
+	constexpr B2QSchedule SCH = b2q_schedule();
+	uint64_t x = *reinterpret_cast<lds_u64_t *>(slot0 + __builtin_amdgcn_ubfe(SCH.w[0][0], q7, 7));
+	uint64_t y = *reinterpret_cast<lds_u64_t *>(slot0 + __builtin_amdgcn_ubfe(SCH.w[0][1], q7, 7));
+	uint32_t cur = slot0, nxt = slot0 + slot_xor;
+	for (uint64_t blk = 0; blk < nblk; ++blk) {
+		if (blk + 1 < nblk) {  // block blk+1 has arrived (requested one iteration ago): stage it
+			lds_u64x2_w *s = reinterpret_cast<lds_u64x2_w *>(nxt + 32 * q);
+			s[0] = w0;
+			s[1] = w1;
+		}
+		if (blk + 2 < nblk)    // block blk+2: on its way from HBM while block blk is compressed
+			b2q_fetch(p, (blk + 2) * 128, len, q, w0, w1);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const bool last = blk + 1 == nblk;
+		b2q_compress(ha, hb, cur, nxt, q7, q, last ? len : (blk + 1) * 128, last, x, y);
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t tmp = cur;
+		cur = nxt;
+		nxt = tmp;
+	}
 	if (live)
-		reinterpret_cast<uint64_t *>(a.out + (uint64_t)i * 32)[q] = ha;  // h[0..3] = first 32 bytes
+		reinterpret_cast<uint64_t *>(b2_out_ptr(a, i))[q] = ha;  // h[0..3] = first 32 bytes
 }
 
 }  // namespace gec

@@ -240,6 +240,9 @@ PinnedRanges &pinned()
 // Staging resources for the host-pointer entry points (one per in-flight call).
 struct Staging {
 	hipStream_t stream = nullptr;
+	// fork/join partner of `stream`: the blake2 of the data shards runs here, beside the RS kernel
+	hipStream_t stream2 = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	uint8_t *h_buf = nullptr, *d_buf = nullptr;
 	size_t cap = 0;
 	uint32_t *d_bad = nullptr, *h_bad = nullptr;
@@ -249,6 +252,11 @@ struct Staging {
 	{
 		if (!stream)
 			HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+		if (!stream2) {
+			HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+			HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+		}
 		if (bytes > cap) {
 			if (h_buf)
 				(void)hipHostFree(h_buf);
@@ -285,6 +293,12 @@ struct Staging {
 			(void)hipFree(d_bad);
 		if (stream)
 			(void)hipStreamDestroy(stream);
+		if (stream2)
+			(void)hipStreamDestroy(stream2);
+		if (ev_fork)
+			(void)hipEventDestroy(ev_fork);
+		if (ev_join)
+			(void)hipEventDestroy(ev_join);
 		*this = Staging();
 	}
 };
@@ -740,8 +754,11 @@ int verify_dev(const gec_codec *c, size_t nblocks, const uint8_t *d_stripes, siz
 
 // one lane per message, one wave per workgroup so that few messages still spread
 // over many SIMDs (the kernel is VALU-bound, occupancy per SIMD does not matter)
+// group != 0: message i lives at d_base + (i / group)*group_stride + (i % group)*stride and its checksum goes to
+// d_out + 32*((i / group)*out_group + i % group) -- e.g. only the data (or only the parity) shards of every stripe.
 int blake2_dev(size_t n, const uint8_t *d_base, const uint64_t *d_off, const uint64_t *d_len, size_t stride,
-	       size_t len, uint8_t *d_out, hipStream_t stream)
+	       size_t len, uint8_t *d_out, hipStream_t stream, uint32_t group = 0, size_t group_stride = 0,
+	       uint32_t out_group = 0)
 {
 	if (n == 0)
 		return GEC_OK;
@@ -755,6 +772,9 @@ int blake2_dev(size_t n, const uint8_t *d_base, const uint64_t *d_off, const uin
 	a.uniform_len = len;
 	a.out = d_out;
 	a.n = (uint32_t)n;
+	a.group = group;
+	a.group_stride = group_stride;
+	a.out_group = out_group;
 	// one lane per message is the faster kernel once there are enough messages to put a
 	// wave on every SIMD (1024 SIMDs x 64 lanes); below that the quad kernel (4 lanes per
 	// message, ~4x shorter chain) wins.  GEC_BLAKE2_KERNEL=lane|quad forces one (A/B).
@@ -788,6 +808,31 @@ int reconstruct_dev(const gec_codec *c, size_t nblocks, uint8_t *d_base, size_t 
 		out_off[r] = shard_off[plan->missing[r]];
 	return launch_apply(c, d_base, stride, d_base, stride, nullptr, byte_off, byte_len, nblocks, in_off.data(),
 			    out_off.data(), (int)plan->missing.size(), plan->rows.v.data(), gec::MODE_STORE, stream);
+}
+
+// Encode + the blake2sum of all k+m shards of every stripe (d_stripes: shard j of block b at b*stride + j*S),
+// everything enqueued behind whatever `stream` already holds.  The checksums of the k data shards do not depend
+// on the encode, so they are computed on a second stream BESIDE the RS kernel (HBM-bound, it leaves the VALUs
+// mostly idle; the hash is a pure VALU dependency chain); only the m parity checksums follow the encode.
+// `aux` provides the partner stream and the fork/join events.
+int encode_hash_dev(const gec_codec *c, size_t nblocks, uint8_t *d_stripes, size_t stride, size_t S, uint8_t *d_sums,
+		    hipStream_t stream, Staging &aux)
+{
+	const size_t k = c->k, m = c->m, n = k + m;
+	HIP_TRY(hipEventRecord(aux.ev_fork, stream));
+	HIP_TRY(hipStreamWaitEvent(aux.stream2, aux.ev_fork, 0));
+	int rc = blake2_dev(nblocks * k, d_stripes, nullptr, nullptr, S, S, d_sums, aux.stream2, (uint32_t)k, stride, (uint32_t)n);
+	if (rc)
+		return rc;
+	HIP_TRY(hipEventRecord(aux.ev_join, aux.stream2));
+	rc = encode_dev(c, nblocks, d_stripes, stride, S, d_stripes + k * S, stride, stream);
+	if (rc)
+		return rc;
+	rc = blake2_dev(nblocks * m, d_stripes + k * S, nullptr, nullptr, S, S, d_sums + 32 * k, stream, (uint32_t)m, stride, (uint32_t)n);
+	if (rc)
+		return rc;
+	HIP_TRY(hipStreamWaitEvent(stream, aux.ev_join, 0));
+	return GEC_OK;
 }
 
 // contiguous stripe: shard j at j*S
@@ -1483,7 +1528,8 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 			} else {
 				HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, st.h_buf, stripe, k * S, nb, hipMemcpyHostToDevice, st.stream));
 			}
-			int rc = encode_dev(c, nb, st.d_buf, stripe, S, st.d_buf + k * S, stripe, st.stream);
+			int rc = shard_sums ? encode_hash_dev(c, nb, st.d_buf, stripe, S, st.d_buf + sums_off, st.stream, st)
+					    : encode_dev(c, nb, st.d_buf, stripe, S, st.d_buf + k * S, stripe, st.stream);
 			if (rc)
 				return rc;
 			if (out_pinned[ci]) {
@@ -1500,12 +1546,8 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 			} else {
 				HIP_TRY(hipMemcpy2DAsync(st.h_buf + k * S, stripe, st.d_buf + k * S, stripe, m * S, nb, hipMemcpyDeviceToHost, st.stream));
 			}
-			if (shard_sums) {  // all nb*n shards are S bytes, S apart: one uniform launch
-				rc = blake2_dev(nb * n, st.d_buf, nullptr, nullptr, S, S, st.d_buf + sums_off, st.stream);
-				if (rc)
-					return rc;
+			if (shard_sums)
 				HIP_TRY(hipMemcpyAsync(st.h_buf + sums_off, st.d_buf + sums_off, nb * n * 32, hipMemcpyDeviceToHost, st.stream));
-			}
 			return GEC_OK;
 		},
 		[&](size_t ci, Staging &st) {  // host: parity (+sums) -> user buffers
@@ -1529,6 +1571,29 @@ int gec_encode_hash_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 	if (!shard_sums)
 		return fail(GEC_E_INVALID_ARG, "NULL shard_sums");
 	return encode_batch_impl(c, nblocks, blocks, block_len, S, parity, shard_sums);
+}
+
+int gec_encode_hash_batch_dev(const gec_codec *c, size_t nblocks, void *d_stripes, size_t stride, size_t S, void *d_sums,
+			      void *hip_stream)
+{
+	if (!c || !d_sums)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (nblocks == 0)
+		return GEC_OK;
+	int rc = check_dev_layout(d_stripes, stride, S, (size_t)(c->k + c->m) * S);
+	if (rc)
+		return rc;
+	if (reinterpret_cast<uintptr_t>(d_sums) % 16)
+		return fail(GEC_E_INVALID_ARG, "d_sums must be 16-byte aligned");
+	DeviceGuard g(c->device);
+	if (!g.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	StagingLease aux(c);  // only its partner stream and events are used; enqueued work may outlive the lease
+	rc = aux.st.ensure(0, 0);
+	if (rc)
+		return rc;
+	return encode_hash_dev(c, nblocks, static_cast<uint8_t *>(d_stripes), stride, S, static_cast<uint8_t *>(d_sums),
+			       static_cast<hipStream_t>(hip_stream), aux.st);
 }
 
 int gec_blake2sum_batch_dev(const gec_codec *c, size_t n, const void *d_base, size_t stride, size_t len, void *d_out,

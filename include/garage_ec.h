@@ -298,6 +298,15 @@ int gec_encode_hash_batch(const gec_codec *c, size_t nblocks,
 			  const uint8_t *const *blocks, const size_t *block_len,
 			  size_t S, uint8_t *const *parity, uint8_t *shard_sums);
 
+/* Device-resident form: stripes already in HBM (shard j of block b at d_stripes + b*stride + j*S), parity
+ * written in place, d_sums (16-byte aligned device memory, nblocks*(k+m)*32 bytes) receives the checksums.
+ * Asynchronous: everything is ordered behind / ahead of the work on `hip_stream`; internally the checksums
+ * of the k data shards run on a second stream beside the RS kernel (they do not depend on it) and only the
+ * m parity checksums follow it. */
+int gec_encode_hash_batch_dev(const gec_codec *c, size_t nblocks, void *d_stripes,
+			      size_t stride, size_t S, void *d_sums,
+			      void *hip_stream);
+
 /* Introspection for tests (no device needed): what the host would decide for ONE launch of the
  * default kernel with k input shards and rows_left output rows still to produce -- how many rows
  * the launch takes, the table-entry width (4/8/16 bytes), loads per batch, workgroup size and

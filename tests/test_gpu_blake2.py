@@ -56,6 +56,49 @@ def test_uniform_device_api_shard_shape(rs):
         rs.blake2sum_dev(torch.zeros((4, 100), dtype=torch.uint8, device="cuda:0"))   # rows not 16-byte aligned
 
 
+@pytest.mark.parametrize("k,m,S,nb", [(10, 4, 104896, 24), (3, 1, 64, 70), (20, 8, 4160, 5), (10, 4, 128, 1), (10, 4, 192, 3)])
+def test_encode_hash_dev_fork_join(coracle, k, m, S, nb):
+    """gec_encode_hash_batch_dev: the checksums of the data shards are computed on a second stream beside
+    the RS kernel, the parity checksums behind it; parity vs the oracle, every checksum vs hashlib --
+    repeated back to back so that a missing stream dependency would show as a stale checksum."""
+    rs = g.ReedSolomon(k, m)
+    for rep in range(3):
+        data = O.splitmix64_bytes(7000 + rep, nb * k * S).reshape(nb, k, S)
+        st = torch.zeros((nb, k + m, S), dtype=torch.uint8, device="cuda:0")
+        st[:, :k] = torch.from_numpy(data).to("cuda:0")
+        sums = rs.encode_hash_dev(st)
+        torch.cuda.synchronize()
+        full = st.cpu().numpy()
+        assert np.array_equal(full[:, k:], coracle.encode_batch(k, m, data, coracle.AVX2, threads=4))
+        got = sums.cpu().numpy()
+        for b in range(nb):
+            for j in range(k + m):
+                assert got[b, j].tobytes() == ref(full[b, j].tobytes()), (rep, b, j)
+
+
+def test_blake2_quad_and_lane_kernels_agree_on_tails(rs):
+    """Both kernels on lengths around every block / quarter / word boundary (the quad kernel's lanes
+    each fetch a 32-byte quarter: partial quarters, empty quarters, the empty message)."""
+    import os
+    import subprocess
+    import sys
+
+    code = """
+import hashlib, sys
+sys.path.insert(0, %r)
+import garage_amd as g
+rs = g.ReedSolomon(10, 4)
+lens = list(range(0, 300)) + [383, 384, 385, 4095, 4096, 4097, 104896]
+msgs = [bytes((i * 7 + j) & 255 for j in range(n)) for i, n in enumerate(lens)]
+want = [hashlib.blake2b(x, digest_size=64).digest()[:32] for x in msgs]
+assert rs.blake2sum_batch(msgs) == want
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for kern in ("quad", "lane"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GEC_BLAKE2_KERNEL=kern))
+        assert r.returncode == 0 and "ok" in r.stdout, (kern, r.stdout, r.stderr[-2000:])
+
+
 def test_encode_hash_batch_sums_every_shard(coracle, rs):
     k, m = 10, 4
     lens = [1 << 20, 999_999, 65536, 1, 0, 500_000]

@@ -146,6 +146,75 @@ __global__ __launch_bounds__(TPB) void stream_pattern(const gec::ApplyArgs a)
 	}
 }
 
+// k-split pattern (the north_star's "k split across waves + XOR reduction" applied to
+// the 8-row shape): the tile is still TPB = 256 columns, but wave w of the 4 opens only shards t = w, w+4, ...
+// over ALL 256 columns (4 columns per lane: 4 KiB contiguous per shard per wave instead of 1 KiB), and writes
+// only rows r = w, w+4, ... -- 5 input + 2 output streams per wave instead of 20 + 8.  REDUCE = true adds
+// what the real kernel would need: every wave's partial vector goes through LDS and the row owner XORs the four.
+template <int K, int R, bool REDUCE>
+__global__ __launch_bounds__(256) void stream_pattern_ksplit(const gec::ApplyArgs a)
+{
+	__shared__ gec::u32x4 part[REDUCE ? 4 * 256 : 1];
+	const uint32_t chunk = gridDim.x >> 3;
+	const uint32_t tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	if ((uint64_t)tile_id * 256 >= a.total_cols)
+		return;
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const gec::u32x4 *src[4];
+	gec::u32x4 *dst[4];
+	bool live[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		uint32_t gcol = tile_id * 256 + c * 64 + lane;
+		live[c] = gcol < a.total_cols;
+		if (!live[c])
+			gcol = tile_id * 256;
+		const uint32_t bb = gcol / a.cols, col = gcol - bb * a.cols;
+		src[c] = reinterpret_cast<const gec::u32x4 *>(a.in + (uint64_t)bb * a.in_stride) + col;
+		dst[c] = reinterpret_cast<gec::u32x4 *>(a.out + (uint64_t)bb * a.out_stride) + col;
+	}
+	constexpr int KW = (K + 3) / 4;
+	gec::u32x4 d[KW][4];
+#pragma unroll
+	for (int j = 0; j < KW; ++j) {
+		const uint32_t t = __builtin_amdgcn_readfirstlane(wave + 4 * j < (uint32_t)K ? wave + 4 * j : wave);
+#pragma unroll
+		for (int c = 0; c < 4; ++c)
+			d[j][c] = __builtin_nontemporal_load(src[c] + a.in_off[t]);
+	}
+	gec::u32x4 x[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		x[c] = d[0][c];
+#pragma unroll
+		for (int j = 1; j < KW; ++j)
+			x[c] ^= d[j][c];
+	}
+	if (REDUCE) {
+		// partial of wave w for column (c*64 + lane): 16 KiB of LDS per workgroup
+#pragma unroll
+		for (int c = 0; c < 4; ++c)
+			part[wave * 256 + c * 64 + lane] = x[c];
+		__syncthreads();
+#pragma unroll
+		for (int c = 0; c < 4; ++c)
+			x[c] = part[c * 64 + lane] ^ part[256 + c * 64 + lane] ^ part[512 + c * 64 + lane] ^ part[768 + c * 64 + lane];
+	}
+#pragma unroll
+	for (int r = 0; r < (R + 3) / 4; ++r) {
+		const uint32_t row = __builtin_amdgcn_readfirstlane(wave + 4 * r);
+		if (row >= (uint32_t)R)
+			break;
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			if (!live[c])
+				continue;
+			gec::u32x4 v = {x[c].x + row, x[c].y, x[c].z, x[c].w};
+			__builtin_nontemporal_store(v, dst[c] + a.out_off[row]);
+		}
+	}
+}
+
 // Same pattern with explicit cache-policy bits on the loads (LP) and stores (SP), via inline asm:
 // 0 = none, 1 = nt, 2 = sc1, 3 = sc0 sc1, 4 = sc0 sc1 nt, 5 = sc1 nt, 6 = sc0, 7 = sc0 nt
 #define KB_POLICY(P) ((P) == 0 ? "" : (P) == 1 ? " nt" : (P) == 2 ? " sc1" : (P) == 3 ? " sc0 sc1" : (P) == 4 ? " sc0 sc1 nt" : (P) == 5 ? " sc1 nt" : (P) == 6 ? " sc0" : " sc0 nt")
@@ -437,6 +506,8 @@ int main(int argc, char **argv)
 				run(256, stream_pattern<10, 4, 256, 0, true, false>, "pattern t256, nt loads, plain stores");
 				run(256, stream_pattern<10, 4, 256, 0, false, false>, "pattern t256, plain loads, plain stores");
 				run(256, stream_pattern<10, 4, 256>, "access pattern only 10r:4w t256 (again)");
+				run(256, stream_pattern_ksplit<10, 4, false>, "k-split pattern 10r:4w t256: 3r+1w streams per wave, 4 KiB runs");
+				run(256, stream_pattern_ksplit<10, 4, true>, "k-split pattern 10r:4w t256 + LDS XOR reduction of partials");
 				if (getenv("KBENCH_POLICY")) {
 					run(256, stream_policy<10, 4, 256, 1, 1>, "policy: loads nt          stores nt   (= the kernel)");
 					run(256, stream_policy<10, 4, 256, 2, 1>, "policy: loads sc1         stores nt");
@@ -455,6 +526,10 @@ int main(int argc, char **argv)
 			} else {
 				run(512, stream_pattern<20, 8, 512>, "access pattern only 20r:8w t512 (pattern ceiling)");
 				run(256, stream_pattern<20, 8, 256>, "access pattern only 20r:8w t256");
+				run(256, stream_pattern_ksplit<20, 8, false>, "k-split pattern 20r:8w t256: 5r+2w streams per wave, 4 KiB runs");
+				run(256, stream_pattern_ksplit<20, 8, true>, "k-split pattern 20r:8w t256 + LDS XOR reduction of partials");
+				run(512, stream_pattern<20, 8, 512>, "access pattern only 20r:8w t512 (again)");
+				run(256, stream_pattern_ksplit<20, 8, false>, "k-split pattern 20r:8w t256 (again)");
 			}
 		}
 		return 0;
