@@ -265,8 +265,21 @@ class BlockManager:
         # writes must land on >= k shards to be readable at all; default margin = half the parity
         self.write_quorum = write_quorum if write_quorum is not None else self.k + (self.m + 1) // 2
         self.rc: dict[bytes, int] = {}
+        # RcEntry::Deletable{at_time} (src/block/rc.rs:122-240): a block whose count is zero may only be deleted
+        # once BLOCK_GC_DELAY (src/block/manager.rs:51) has passed; no entry at all = Absent = deletable
+        self.deletable_at: dict[bytes, int] = {}
+        self.gc_delay_ms = 600_000
+        self._clock_skew_ms = 0
         self.resync_queue: list[bytes] = []
         self.metrics = {"bytes_written": 0, "bytes_read": 0, "corruption_counter": 0, "ec_reconstructs": 0}
+
+    def now_ms(self) -> int:
+        import time
+
+        return int(time.time() * 1000) + self._clock_skew_ms
+
+    def clock_advance(self, ms: int) -> None:
+        self._clock_skew_ms += ms
 
     # -- placement: partition = top byte of the hash (src/rpc/layout/version.rs:101-104)
     def storage_nodes_of(self, hash_: bytes) -> list[int]:
@@ -310,8 +323,14 @@ class BlockManager:
                         errors.append(f"node {node}: {e}")
                 if ok < self.write_quorum:
                     failure = Quorum(self.write_quorum, ok, self.n, errors)
-                elif ok < self.n:
-                    self.resync_queue.append(hash_)
+                    continue
+                # a block nobody references yet (PutObject runs the put and the incref concurrently,
+                # src/api/s3/put.rs:545-581) is protected for BLOCK_GC_DELAY like one whose count just
+                # dropped to zero: resync must never delete what a put has just acknowledged
+                if self.rc.get(hash_, 0) == 0:
+                    self.deletable_at[hash_] = max(self.deletable_at.get(hash_, 0), self.now_ms() + self.gc_delay_ms)
+                if ok < self.n:
+                    self.resync_queue.append(hash_)  # stragglers are REBUILT by resync while the block is needed
         if failure is not None:
             raise failure
 
@@ -384,12 +403,22 @@ class BlockManager:
     def block_incref(self, hash_: bytes) -> None:
         self.rc[hash_] = self.rc.get(hash_, 0) + 1
         if self.rc[hash_] == 1:
+            self.deletable_at.pop(hash_, None)
             self.resync_queue.append(hash_)  # presence check later (manager.rs:452-475)
 
     def block_decref(self, hash_: bytes) -> None:
-        self.rc[hash_] = max(0, self.rc.get(hash_, 0) - 1)
+        if self.rc.get(hash_, 0) == 0:
+            return  # Deletable / Absent stay what they are (RcEntry::decrement)
+        self.rc[hash_] -= 1
         if self.rc[hash_] == 0:
-            self.resync_queue.append(hash_)
+            self.deletable_at[hash_] = self.now_ms() + self.gc_delay_ms
+            self.resync_queue.append(hash_)  # (the reference queues it BLOCK_GC_DELAY + 10 s later, manager.rs:478-500)
+
+    def _is_deletable(self, hash_: bytes) -> bool:
+        if self.rc.get(hash_, 0) > 0:
+            return False
+        at = self.deletable_at.get(hash_)
+        return at is None or self.now_ms() > at
 
     # -- repair ---------------------------------------------------------------
     def resync_block(self, hash_: bytes) -> int:
@@ -397,7 +426,7 @@ class BlockManager:
         all, rewrite the missing/corrupt ones).  rc == 0: delete.  Returns the
         number of shards rewritten or deleted."""
         who = self.storage_nodes_of(hash_)
-        if self.rc.get(hash_, 0) == 0:
+        if self._is_deletable(hash_):
             nd = 0
             for j, node in enumerate(who):
                 try:
@@ -406,6 +435,8 @@ class BlockManager:
                         nd += 1
                 except Exception:
                     pass
+            self.deletable_at.pop(hash_, None)  # clear_deleted_block_rc
+            self.rc.pop(hash_, None)
             return nd
         got, meta = self._gather(hash_, self.n)
         if meta is None or len(got) < self.k:
@@ -429,7 +460,12 @@ class BlockManager:
 
     def resync_all(self) -> int:
         todo, self.resync_queue = list(dict.fromkeys(self.resync_queue)), []
-        return sum(self.resync_block(h) for h in todo)
+        total = 0
+        for h in todo:
+            total += self.resync_block(h)
+            if self.rc.get(h, 0) == 0 and h in self.deletable_at:
+                self.resync_queue.append(h)  # still inside its GC delay: look again later
+        return total
 
     def scrub(self, hashes: Sequence[bytes]) -> list[bytes]:
         """Batch-verify stripes on the device (ReedSolomon::verify): returns the

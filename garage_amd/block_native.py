@@ -13,17 +13,39 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgarage_block.so")
 
 GBM_OK, GBM_E_MISSING_BLOCK, GBM_E_CORRUPT_DATA, GBM_E_QUORUM = 0, -1, -2, -3
-GBM_E_INVALID_ARG, GBM_E_EC, GBM_E_IO, GBM_E_BUFFER_TOO_SMALL = -4, -5, -6, -7
+GBM_E_INVALID_ARG, GBM_E_EC, GBM_E_IO, GBM_E_BUFFER_TOO_SMALL, GBM_E_ABORTED = -4, -5, -6, -7, -8
+GBM_BLOCK_GC_DELAY_MS, GBM_RESYNC_RETRY_DELAY_MS = 600_000, 60_000
 
 SYMBOLS = [
     "gbm_last_error", "gbm_blake2sum", "gbm_create", "gbm_destroy", "gbm_set_compression_level", "gbm_set_data_fsync",
-    "gbm_storage_nodes_of",
+    "gbm_set_verify_block_hash", "gbm_set_threads", "gbm_set_timing", "gbm_clock_advance",
+    "gbm_storage_nodes_of", "gbm_layout_update", "gbm_layout_trim",
     "gbm_rpc_put_block", "gbm_rpc_put_blocks", "gbm_rpc_get_block", "gbm_rpc_get_blocks",
-    "gbm_block_incref", "gbm_block_decref", "gbm_resync_block", "gbm_resync_all", "gbm_resync_queue_len",
+    "gbm_rpc_get_raw_block", "gbm_rpc_get_block_streaming", "gbm_rpc_get_raw_block_streaming",
+    "gbm_block_incref", "gbm_block_decref", "gbm_block_rc",
+    "gbm_put_to_resync", "gbm_resync_run", "gbm_resync_block", "gbm_resync_all", "gbm_resync_queue_len",
+    "gbm_resync_errors_len", "gbm_resync_worker_start", "gbm_resync_worker_stop",
     "gbm_scrub", "gbm_node_set_down", "gbm_node_has_shard", "gbm_node_delete_shard",
-    "gbm_node_corrupt_shard", "gbm_metrics", "gbm_gpu_hashed",
+    "gbm_node_corrupt_shard", "gbm_node_shard_header", "gbm_node_order_violations", "gbm_metrics", "gbm_gpu_hashed",
     "gbm_batcher_create", "gbm_batcher_destroy", "gbm_batcher_put_block", "gbm_batcher_set_ram_buffer_max", "gbm_batcher_stats",
 ]
+
+
+class OrderTag(ctypes.Structure):
+    """OrderTag(stream, order), src/net/message.rs:66-89."""
+    _fields_ = [("stream_id", ctypes.c_uint64), ("order", ctypes.c_uint64)]
+
+
+class DataBlockHeader(ctypes.Structure):
+    """DataBlockHeader::{Plain, Compressed}, src/block/block.rs:12-22."""
+    _fields_ = [("kind", ctypes.c_int)]
+    PLAIN, COMPRESSED = 0, 1
+
+    def is_compressed(self) -> bool:
+        return self.kind == self.COMPRESSED
+
+
+CHUNK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
 
 
 class BlockError(RuntimeError):
@@ -60,12 +82,33 @@ def _load():
     lib.gbm_set_compression_level.argtypes = [vp, ci, ci]
     lib.gbm_set_data_fsync.argtypes = [vp, ci]
     lib.gbm_storage_nodes_of.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ci)]
-    lib.gbm_rpc_put_block.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, sz]
-    lib.gbm_rpc_put_blocks.argtypes = [vp, sz, ctypes.c_char_p, pp, ctypes.POINTER(sz)]
-    lib.gbm_rpc_get_block.argtypes = [vp, ctypes.c_char_p, vp, sz, ctypes.POINTER(sz)]
-    lib.gbm_rpc_get_blocks.argtypes = [vp, sz, ctypes.c_char_p, pp, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(ci)]
+    tagp = ctypes.POINTER(OrderTag)
+    hdrp = ctypes.POINTER(DataBlockHeader)
+    lib.gbm_rpc_put_block.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, sz, ci, tagp]
+    lib.gbm_rpc_put_blocks.argtypes = [vp, sz, ctypes.c_char_p, pp, ctypes.POINTER(sz), ctypes.c_char_p, tagp]
+    lib.gbm_rpc_get_block.argtypes = [vp, ctypes.c_char_p, tagp, vp, sz, ctypes.POINTER(sz)]
+    lib.gbm_rpc_get_blocks.argtypes = [vp, sz, ctypes.c_char_p, tagp, pp, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(ci)]
+    lib.gbm_rpc_get_raw_block.argtypes = [vp, ctypes.c_char_p, tagp, hdrp, vp, sz, ctypes.POINTER(sz)]
+    lib.gbm_rpc_get_block_streaming.argtypes = [vp, ctypes.c_char_p, tagp, sz, CHUNK_FN, vp]
+    lib.gbm_rpc_get_raw_block_streaming.argtypes = [vp, ctypes.c_char_p, tagp, hdrp, sz, CHUNK_FN, vp]
     for f in ("gbm_block_incref", "gbm_block_decref"):
         getattr(lib, f).argtypes = [vp, ctypes.c_char_p]
+    lib.gbm_block_rc.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
+    lib.gbm_set_verify_block_hash.argtypes = [vp, ci]
+    lib.gbm_set_threads.argtypes = [vp, ci]
+    lib.gbm_set_timing.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+    lib.gbm_clock_advance.argtypes = [vp, ctypes.c_uint64]
+    lib.gbm_layout_update.argtypes = [vp]
+    lib.gbm_layout_trim.argtypes = [vp]
+    lib.gbm_put_to_resync.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64]
+    lib.gbm_resync_run.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint64)]
+    lib.gbm_resync_errors_len.argtypes = [vp]
+    lib.gbm_resync_errors_len.restype = sz
+    lib.gbm_resync_worker_start.argtypes = [vp]
+    lib.gbm_resync_worker_stop.argtypes = [vp]
+    lib.gbm_node_shard_header.argtypes = [vp, ci, ctypes.c_char_p, ci, ctypes.c_char_p]
+    lib.gbm_node_order_violations.argtypes = [vp, ci]
+    lib.gbm_node_order_violations.restype = ctypes.c_uint64
     lib.gbm_resync_block.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ci)]
     lib.gbm_resync_all.argtypes = [vp, ctypes.POINTER(ci)]
     lib.gbm_resync_queue_len.argtypes = [vp]
@@ -79,7 +122,7 @@ def _load():
     lib.gbm_batcher_create.argtypes = [vp, sz, ctypes.c_uint, pp]
     lib.gbm_batcher_destroy.argtypes = [vp]
     lib.gbm_batcher_destroy.restype = None
-    lib.gbm_batcher_put_block.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, sz]
+    lib.gbm_batcher_put_block.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, sz, ci, tagp]
     lib.gbm_batcher_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.gbm_batcher_set_ram_buffer_max.argtypes = [vp, ctypes.c_size_t]
     lib.gbm_gpu_hashed.argtypes = [vp]
@@ -137,36 +180,87 @@ class NativeBlockManager:
         _check(lib.gbm_storage_nodes_of(self._h, hash_, out), "gbm_storage_nodes_of")
         return list(out)
 
-    def rpc_put_block(self, hash_: bytes, data: bytes, prevent_compression: bool = False, order_tag=None) -> None:
-        _check(lib.gbm_rpc_put_block(self._h, hash_, data, len(data)), "rpc_put_block")
+    @staticmethod
+    def _tag(order_tag):
+        """order_tag: None, an OrderTag, or a (stream_id, order) pair."""
+        if order_tag is None:
+            return None
+        if isinstance(order_tag, OrderTag):
+            return ctypes.byref(order_tag)
+        return ctypes.byref(OrderTag(int(order_tag[0]), int(order_tag[1])))
 
-    def rpc_put_blocks(self, items: Sequence[tuple[bytes, bytes]]) -> None:
+    def rpc_put_block(self, hash_: bytes, data: bytes, prevent_compression: bool = False, order_tag=None) -> None:
+        """BlockManager::rpc_put_block(hash, data, prevent_compression, order_tag), src/block/manager.rs:366-408."""
+        _check(lib.gbm_rpc_put_block(self._h, hash_, data, len(data), int(bool(prevent_compression)), self._tag(order_tag)),
+               "rpc_put_block")
+
+    def rpc_put_blocks(self, items: Sequence[tuple[bytes, bytes]], prevent_compression: Optional[Sequence[bool]] = None,
+                       order_tags: Optional[Sequence[tuple[int, int]]] = None) -> None:
         n = len(items)
         hashes = b"".join(h for h, _ in items)
-        bufs = [ctypes.create_string_buffer(d, len(d)) for _, d in items]
-        ptrs = (ctypes.c_void_p * n)(*[ctypes.addressof(b) for b in bufs])
+        # bytes objects are immutable and stay alive in `items`: hand their buffers over without a copy
+        ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(d), ctypes.c_void_p).value for _, d in items])
         lens = (ctypes.c_size_t * n)(*[len(d) for _, d in items])
-        _check(lib.gbm_rpc_put_blocks(self._h, n, hashes, ptrs, lens), "rpc_put_blocks")
+        pc = bytes(int(bool(x)) for x in prevent_compression) if prevent_compression is not None else None
+        tags = (OrderTag * n)(*[OrderTag(int(s), int(o)) for s, o in order_tags]) if order_tags is not None else None
+        _check(lib.gbm_rpc_put_blocks(self._h, n, hashes, ptrs, lens, pc, tags), "rpc_put_blocks")
 
     def rpc_get_block(self, hash_: bytes, max_len: int = 1 << 26, order_tag=None) -> bytes:
         ln = ctypes.c_size_t()
         buf = ctypes.create_string_buffer(min(max_len, 1 << 22))
-        rc = lib.gbm_rpc_get_block(self._h, hash_, buf, len(buf), ctypes.byref(ln))
+        rc = lib.gbm_rpc_get_block(self._h, hash_, self._tag(order_tag), buf, len(buf), ctypes.byref(ln))
         if rc == GBM_E_BUFFER_TOO_SMALL and ln.value <= max_len:
             buf = ctypes.create_string_buffer(ln.value)
-            rc = lib.gbm_rpc_get_block(self._h, hash_, buf, len(buf), ctypes.byref(ln))
+            rc = lib.gbm_rpc_get_block(self._h, hash_, self._tag(order_tag), buf, len(buf), ctypes.byref(ln))
         _check(rc, "rpc_get_block")
         return buf.raw[: ln.value]
 
-    def rpc_get_blocks(self, hashes: Sequence[bytes], max_len: int) -> list:
-        """Batched get: returns bytes per block, or the BlockError class on failure."""
+    def rpc_get_raw_block(self, hash_: bytes, max_len: int = 1 << 26, order_tag=None) -> tuple[DataBlockHeader, bytes]:
+        """BlockManager::rpc_get_raw_block: (DataBlockHeader, stored bytes) -- not decompressed."""
+        ln = ctypes.c_size_t()
+        hdr = DataBlockHeader()
+        buf = ctypes.create_string_buffer(min(max_len, 1 << 22))
+        rc = lib.gbm_rpc_get_raw_block(self._h, hash_, self._tag(order_tag), ctypes.byref(hdr), buf, len(buf), ctypes.byref(ln))
+        if rc == GBM_E_BUFFER_TOO_SMALL and ln.value <= max_len:
+            buf = ctypes.create_string_buffer(ln.value)
+            rc = lib.gbm_rpc_get_raw_block(self._h, hash_, self._tag(order_tag), ctypes.byref(hdr), buf, len(buf), ctypes.byref(ln))
+        _check(rc, "rpc_get_raw_block")
+        return hdr, buf.raw[: ln.value]
+
+    def rpc_get_block_streaming(self, hash_: bytes, order_tag=None, chunk_bytes: int = 0, raw: bool = False):
+        """Generator-like: returns the list of chunks the sink received (rpc_get_block_streaming,
+        or rpc_get_raw_block_streaming with raw=True, in which case (header, chunks))."""
+        chunks: list[bytes] = []
+
+        def sink(_ctx, p, n):
+            chunks.append(ctypes.string_at(p, n))
+            return 0
+
+        cb = CHUNK_FN(sink)
+        if raw:
+            hdr = DataBlockHeader()
+            _check(lib.gbm_rpc_get_raw_block_streaming(self._h, hash_, self._tag(order_tag), ctypes.byref(hdr), chunk_bytes, cb, None),
+                   "rpc_get_raw_block_streaming")
+            return hdr, chunks
+        _check(lib.gbm_rpc_get_block_streaming(self._h, hash_, self._tag(order_tag), chunk_bytes, cb, None), "rpc_get_block_streaming")
+        return chunks
+
+    def rpc_get_blocks(self, hashes: Sequence[bytes], max_len: int, out: Optional[list] = None) -> list:
+        """Batched get: returns bytes per block, or the error code on failure.  `out` (optional): a list of
+        writable buffers (e.g. numpy arrays over pinned memory) that receive the blocks; then the result
+        holds the lengths instead of copies."""
         n = len(hashes)
-        bufs = [ctypes.create_string_buffer(max_len) for _ in range(n)]
-        ptrs = (ctypes.c_void_p * n)(*[ctypes.addressof(b) for b in bufs])
+        bufs = out if out is not None else [ctypes.create_string_buffer(max_len) for _ in range(n)]
+        if out is not None:
+            ptrs = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        else:
+            ptrs = (ctypes.c_void_p * n)(*[ctypes.addressof(b) for b in bufs])
         caps = (ctypes.c_size_t * n)(*[max_len] * n)
         lens = (ctypes.c_size_t * n)()
         rcs = (ctypes.c_int * n)()
-        _check(lib.gbm_rpc_get_blocks(self._h, n, b"".join(hashes), ptrs, caps, lens, rcs), "rpc_get_blocks")
+        _check(lib.gbm_rpc_get_blocks(self._h, n, b"".join(hashes), None, ptrs, caps, lens, rcs), "rpc_get_blocks")
+        if out is not None:
+            return [int(lens[i]) if rcs[i] == 0 else rcs[i] for i in range(n)]
         return [bufs[i].raw[: lens[i]] if rcs[i] == 0 else rcs[i] for i in range(n)]
 
     def block_incref(self, hash_: bytes) -> None:
@@ -187,6 +281,55 @@ class NativeBlockManager:
 
     def resync_queue_len(self) -> int:
         return int(lib.gbm_resync_queue_len(self._h))
+
+    def resync_errors_len(self) -> int:
+        return int(lib.gbm_resync_errors_len(self._h))
+
+    RESYNC_STATS = ("taken", "ok", "errors", "skipped", "rebuilt", "deleted", "offloaded", "device_calls")
+
+    def resync_run(self, max_blocks: int = 0, check: bool = True) -> dict:
+        """One pass of the resync queue over everything that is due."""
+        st = (ctypes.c_uint64 * 8)()
+        rc = lib.gbm_resync_run(self._h, max_blocks, st)
+        if check:
+            _check(rc, "resync_run")
+        d = dict(zip(self.RESYNC_STATS, [int(x) for x in st]))
+        d["rc"] = rc
+        return d
+
+    def put_to_resync(self, hash_: bytes, delay_ms: int = 0) -> None:
+        _check(lib.gbm_put_to_resync(self._h, hash_, delay_ms), "put_to_resync")
+
+    def block_rc(self, hash_: bytes) -> tuple[int, str, int]:
+        out = (ctypes.c_uint64 * 3)()
+        _check(lib.gbm_block_rc(self._h, hash_, out), "block_rc")
+        return int(out[0]), ("Absent", "Present", "Deletable")[int(out[1])], int(out[2])
+
+    def set_timing(self, gc_delay_ms: int = -1, resync_retry_delay_ms: int = -1, incref_check_delay_ms: int = -1) -> None:
+        _check(lib.gbm_set_timing(self._h, gc_delay_ms, resync_retry_delay_ms, incref_check_delay_ms), "set_timing")
+
+    def clock_advance(self, ms: int) -> None:
+        _check(lib.gbm_clock_advance(self._h, ms), "clock_advance")
+
+    def set_verify_block_hash(self, enabled: bool) -> None:
+        _check(lib.gbm_set_verify_block_hash(self._h, int(enabled)), "set_verify_block_hash")
+
+    def set_threads(self, n: int) -> None:
+        _check(lib.gbm_set_threads(self._h, n), "set_threads")
+
+    def layout_update(self) -> int:
+        return int(lib.gbm_layout_update(self._h))
+
+    def layout_trim(self) -> None:
+        _check(lib.gbm_layout_trim(self._h), "layout_trim")
+
+    def node_shard_header(self, node: int, hash_: bytes, idx: int) -> bytes:
+        out = ctypes.create_string_buffer(64)
+        _check(lib.gbm_node_shard_header(self._h, node, hash_, idx, out), "node_shard_header")
+        return out.raw
+
+    def node_order_violations(self, node: int) -> int:
+        return int(lib.gbm_node_order_violations(self._h, node))
 
     def scrub(self, hashes: Sequence[bytes]) -> list[bytes]:
         n = len(hashes)
@@ -236,9 +379,10 @@ class Batcher:
 
     __del__ = close
 
-    def put_block(self, hash_: bytes, data: bytes) -> None:
+    def put_block(self, hash_: bytes, data: bytes, prevent_compression: bool = False, order_tag=None) -> None:
         """Blocks until the batch containing this block is stored (ctypes drops the GIL)."""
-        _check(lib.gbm_batcher_put_block(self._h, hash_, data, len(data)), "batcher.put_block")
+        _check(lib.gbm_batcher_put_block(self._h, hash_, data, len(data), int(bool(prevent_compression)),
+                                         NativeBlockManager._tag(order_tag)), "batcher.put_block")
 
     def stats(self) -> dict:
         out = (ctypes.c_uint64 * 3)()

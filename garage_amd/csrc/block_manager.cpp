@@ -5,6 +5,18 @@
 // (gec_encode_hash_batch / gec_reconstruct_batch / gec_verify_batch /
 // gec_blake2sum_batch) for every shard byte and every large hash batch it needs
 // computed.  No GF arithmetic happens here.
+//
+// Shape (reference anchors in include/garage_block.h):
+//  * buffers are reference-counted and never copied once they exist: a put copies the block ONCE into a
+//    zero-padded k*S buffer (the k data shards are slices of it, the way the reference clones one `Bytes`
+//    per peer, src/rpc/rpc_helper.rs:493), parity lands in one m*S buffer per block; both come from a pool
+//    of pinned host memory (gec_host_alloc) so that libgarage_ec moves them by DMA without staging;
+//  * the manager talks to its nodes in ShardRpc messages (PutShard / GetShard / NeedShardQuery /
+//    DeleteShard), the per-shard analogue of BlockRpc (src/block/manager.rs:54-73);
+//  * refcounts are RcEntry {Present, Deletable{at}, Absent} (src/block/rc.rs), the resync queue is ordered
+//    by (due time, hash) with an ErrorCounter table for exponential back-off (src/block/resync.rs);
+//  * bulk work (copies, compression, fan-out, gathers) runs on an internal thread pool; rc and queue
+//    are striped / locked, nodes lock internally.
 #include "../../include/garage_block.h"
 
 #include <dlfcn.h>
@@ -17,6 +29,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <thread>
 #include <cerrno>
 #include <cstdio>
@@ -24,6 +37,8 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <set>
 #include <string>
 #include <tuple>
 #include <unordered_map>
@@ -161,18 +176,43 @@ struct Zstd {
 		freeCCtx(c);
 		return good;
 	}
-	// verifies the frame checksum; false = corrupt
-	bool decode(const uint8_t *data, size_t len, std::vector<uint8_t> &out) const
+	// verifies the frame checksum; false = corrupt.  `max_out` bounds the allocation: a damaged or
+	// forged frame header must not be able to ask for terabytes (Garage blocks are <= block_size, and a
+	// zstd frame cannot expand by more than ~2^17 per byte; the caller passes a generous multiple of
+	// block_size).  Frames without a content-size field (streaming encoders write those) are decoded
+	// into a buffer that grows up to the same bound.
+	bool decode(const uint8_t *data, size_t len, size_t max_out, std::vector<uint8_t> &out) const
 	{
 		if (!ok)
 			return false;
-		unsigned long long sz = getFrameContentSize(data, len);
-		if (sz >= (1ull << 40))  // CONTENTSIZE_ERROR / UNKNOWN are huge sentinels
+		const unsigned long long sz = getFrameContentSize(data, len);
+		const unsigned long long UNKNOWN = 0ULL - 1, ERROR_ = 0ULL - 2;
+		if (sz == ERROR_)
 			return false;
-		out.resize((size_t)sz);
-		uint8_t dummy;
-		size_t n = decompress(sz ? out.data() : &dummy, (size_t)sz, data, len);
-		return !isError(n) && n == sz;
+		try {
+			if (sz != UNKNOWN) {
+				if (sz > max_out)
+					return false;
+				out.resize((size_t)sz);
+				uint8_t dummy;
+				size_t n = decompress(sz ? out.data() : &dummy, (size_t)sz, data, len);
+				return !isError(n) && n == sz;
+			}
+			size_t cap = std::min<size_t>(std::max<size_t>(4 * len, 1 << 16), max_out);
+			for (;;) {
+				out.resize(cap);
+				size_t n = decompress(out.data(), cap, data, len);
+				if (!isError(n)) {
+					out.resize(n);
+					return true;
+				}
+				if (cap >= max_out)
+					return false;  // corrupt, or larger than any block can be
+				cap = std::min(cap * 4, max_out);
+			}
+		} catch (const std::bad_alloc &) {
+			return false;
+		}
 	}
 };
 
@@ -231,43 +271,312 @@ struct ShardHeader {
 	}
 };
 
-// -------------------------------------------------------------------- nodes
-struct Node {
-	std::atomic<bool> down{false};  // flipped by gbm_node_set_down while the batcher thread may be fanning out
-	virtual ~Node() = default;
-	virtual bool put(const Hash &h, int idx, std::vector<uint8_t> &&raw) = 0;
-	virtual bool get(const Hash &h, int idx, std::vector<uint8_t> &raw) = 0;  // false: absent
-	virtual void del(const Hash &h, int idx) = 0;
-	virtual void mark_corrupted(const Hash &h, int idx) { del(h, idx); }
+uint64_t real_now_ms()
+{
+	return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------ thread pool
+// fork-join: fn(i) for i in [0, n) on the workers and the calling thread.  Several callers may use it at
+// once (they queue on call_mu_); work items must not call parallel_for themselves.
+class Pool {
+public:
+	explicit Pool(unsigned n) { resize(n); }
+	~Pool() { stop_all(); }
+	void resize(unsigned n)
+	{
+		std::lock_guard<std::mutex> call(call_mu_);
+		stop_all();
+		stop_ = false;
+		for (unsigned i = 0; i < n; ++i)
+			workers_.emplace_back([this] { run(); });
+	}
+	void parallel_for(size_t n, const std::function<void(size_t)> &fn)
+	{
+		if (n == 0)
+			return;
+		if (n == 1) {
+			fn(0);
+			return;
+		}
+		std::unique_lock<std::mutex> call_lock(call_mu_);
+		if (workers_.empty()) {
+			call_lock.unlock();
+			for (size_t i = 0; i < n; ++i)
+				fn(i);
+			return;
+		}
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			fn_ = &fn;
+			n_ = n;
+			next_ = 0;
+			pending_ = n;
+			++epoch_;
+		}
+		cv_.notify_all();
+		work();
+		std::unique_lock<std::mutex> g(mu_);
+		done_cv_.wait(g, [this] { return pending_ == 0; });
+		fn_ = nullptr;
+	}
+
+private:
+	void stop_all()
+	{
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			stop_ = true;
+		}
+		cv_.notify_all();
+		for (auto &t : workers_)
+			t.join();
+		workers_.clear();
+	}
+	void work()
+	{
+		for (;;) {
+			size_t i;
+			const std::function<void(size_t)> *fn;
+			{
+				std::lock_guard<std::mutex> g(mu_);
+				if (!fn_ || next_ >= n_)
+					return;
+				i = next_++;
+				fn = fn_;
+			}
+			(*fn)(i);
+			std::lock_guard<std::mutex> g(mu_);
+			if (--pending_ == 0)
+				done_cv_.notify_all();
+		}
+	}
+	void run()
+	{
+		uint64_t seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> g(mu_);
+				cv_.wait(g, [&] { return stop_ || epoch_ != seen; });
+				if (stop_)
+					return;
+				seen = epoch_;
+			}
+			work();
+		}
+	}
+	std::vector<std::thread> workers_;
+	std::mutex mu_, call_mu_;
+	std::condition_variable cv_, done_cv_;
+	const std::function<void(size_t)> *fn_ = nullptr;
+	size_t n_ = 0, next_ = 0, pending_ = 0;
+	uint64_t epoch_ = 0;
+	bool stop_ = false;
 };
 
-struct MemoryNode : Node {
-	std::mutex mu;  // puts (batcher thread) and gets (caller threads) may overlap
-	std::map<std::pair<Hash, int>, std::vector<uint8_t>> files;
-	bool put(const Hash &h, int idx, std::vector<uint8_t> &&raw) override
+// ------------------------------------------------------------------ buffers
+// Bytes = shared, immutable-after-fill byte range; slices alias their parent (std::shared_ptr aliasing
+// constructor), so a data shard is a view into its block's buffer and lives as long as any node keeps it.
+struct Bytes {
+	std::shared_ptr<uint8_t> p;
+	size_t n = 0;
+	const uint8_t *data() const { return p.get(); }
+	uint8_t *mut() const { return p.get(); }
+	bool empty() const { return !p; }
+	Bytes slice(size_t off, size_t len) const
 	{
-		std::lock_guard<std::mutex> g(mu);
-		files[{h, idx}] = std::move(raw);
-		return true;
+		Bytes b;
+		b.p = std::shared_ptr<uint8_t>(p, p.get() + off);
+		b.n = len;
+		return b;
 	}
-	bool get(const Hash &h, int idx, std::vector<uint8_t> &raw) override
+};
+
+// Pool of pinned host buffers (gec_host_alloc): hipHostMalloc costs ~0.1 ms per MiB, so buffers are recycled
+// by size.  Without a device (CPU tests against the oracle stub) gec_host_alloc is plain malloc.
+class BufPool : public std::enable_shared_from_this<BufPool> {
+public:
+	static constexpr size_t kRetainMax = 2ull << 30;  // bytes kept for reuse; beyond that buffers are freed
+	~BufPool()
 	{
-		std::lock_guard<std::mutex> g(mu);
-		auto it = files.find({h, idx});
-		if (it == files.end())
+		for (auto &kv : free_)
+			for (uint8_t *p : kv.second)
+				gec_host_free(p);
+	}
+	Bytes get(size_t n)
+	{
+		const size_t cap = std::max<size_t>((n + 4095) / 4096 * 4096, 4096);
+		uint8_t *raw = nullptr;
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			auto it = free_.find(cap);
+			if (it != free_.end() && !it->second.empty()) {
+				raw = it->second.back();
+				it->second.pop_back();
+				retained_ -= cap;
+			}
+		}
+		if (!raw)
+			raw = static_cast<uint8_t *>(gec_host_alloc(cap));
+		if (!raw)
+			throw std::bad_alloc();
+		std::weak_ptr<BufPool> self = shared_from_this();
+		Bytes b;
+		b.n = n;
+		b.p = std::shared_ptr<uint8_t>(raw, [self, cap](uint8_t *q) {
+			if (auto sp = self.lock())
+				sp->put_back(q, cap);
+			else
+				gec_host_free(q);
+		});
+		return b;
+	}
+
+private:
+	void put_back(uint8_t *q, size_t cap)
+	{
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			if (retained_ + cap <= kRetainMax) {
+				free_[cap].push_back(q);
+				retained_ += cap;
+				return;
+			}
+		}
+		gec_host_free(q);
+	}
+	std::mutex mu_;
+	std::map<size_t, std::vector<uint8_t *>> free_;
+	size_t retained_ = 0;
+};
+
+// ------------------------------------------------------------------ ShardRpc
+// What the manager and a storage node say to each other: the per-shard analogue of BlockRpc
+// (src/block/manager.rs:54-73).  PutShard carries the shard header (the DataBlockHeader plus the EC
+// geometry and the shard's checksum) and the payload; GetShard is answered with a PutShard.
+struct Shard {
+	ShardHeader hd;
+	Bytes data;  // shard_len bytes
+};
+
+enum class RpcKind { PutShard, GetShard, NeedShardQuery, DeleteShard };
+
+struct ShardRpc {
+	RpcKind kind;
+	const Hash *hash;
+	int idx;
+	Shard shard;                        // PutShard
+	const gbm_order_tag *tag = nullptr; // PutShard / GetShard
+};
+
+struct ShardResp {
+	bool ok = false;     // PutShard stored / GetShard found / DeleteShard had something to delete
+	bool needed = false; // NeedShardReply
+	Shard shard;         // answer to GetShard
+};
+
+struct Node {
+	std::atomic<bool> down{false};  // flipped by gbm_node_set_down while other threads are talking to the node
+	std::atomic<uint64_t> order_violations{0};
+	std::shared_ptr<BufPool> bufs;
+	virtual ~Node() = default;
+	virtual bool put(const Hash &h, int idx, const Shard &s) = 0;
+	virtual bool get(const Hash &h, int idx, Shard &s) = 0;  // false: absent / unreadable
+	virtual bool has(const Hash &h, int idx) = 0;
+	virtual bool del(const Hash &h, int idx) = 0;
+	virtual void mark_corrupted(const Hash &h, int idx) { del(h, idx); }
+
+	// the node's endpoint (StreamingEndpointHandler<BlockRpc>::handle, src/block/manager.rs:692-707);
+	// false = could not be contacted
+	bool handle(const ShardRpc &rq, ShardResp &rs)
+	{
+		if (down.load(std::memory_order_acquire))
 			return false;
-		raw = it->second;
+		switch (rq.kind) {
+		case RpcKind::PutShard:
+			note_order(rq.tag);
+			rs.ok = put(*rq.hash, rq.idx, rq.shard);
+			return true;
+		case RpcKind::GetShard:
+			rs.ok = get(*rq.hash, rq.idx, rs.shard);
+			return true;
+		case RpcKind::NeedShardQuery:
+			rs.ok = true;
+			rs.needed = !has(*rq.hash, rq.idx);
+			return true;
+		case RpcKind::DeleteShard:
+			rs.ok = del(*rq.hash, rq.idx);
+			return true;
+		}
+		return false;
+	}
+
+private:
+	void note_order(const gbm_order_tag *tag)
+	{
+		if (!tag)
+			return;
+		std::lock_guard<std::mutex> g(order_mu_);
+		auto it = last_order_.find(tag->stream_id);
+		if (it != last_order_.end() && tag->order < it->second)
+			order_violations.fetch_add(1);
+		if (it == last_order_.end() || tag->order > it->second)
+			last_order_[tag->stream_id] = tag->order;
+		if (last_order_.size() > 4096)  // streams are short-lived (one per PutObject / GetObject)
+			last_order_.erase(last_order_.begin());
+	}
+	std::mutex order_mu_;
+	std::map<uint64_t, uint64_t> last_order_;
+};
+
+std::string shard_key(const Hash &h, int idx)
+{
+	std::string k(h);
+	k.push_back((char)idx);
+	return k;
+}
+
+struct MemoryNode : Node {
+	static constexpr int kStripes = 64;  // puts and gets of different hashes do not contend
+	struct Stripe {
+		std::mutex mu;
+		std::unordered_map<std::string, Shard> files;
+	};
+	Stripe stripes[kStripes];
+	Stripe &stripe_of(const Hash &h) { return stripes[((unsigned char)h[2] ^ (unsigned char)h[3]) % kStripes]; }
+	bool put(const Hash &h, int idx, const Shard &s) override
+	{
+		Stripe &st = stripe_of(h);
+		std::lock_guard<std::mutex> g(st.mu);
+		st.files[shard_key(h, idx)] = s;
 		return true;
 	}
-	void del(const Hash &h, int idx) override
+	bool get(const Hash &h, int idx, Shard &s) override
 	{
-		std::lock_guard<std::mutex> g(mu);
-		files.erase({h, idx});
+		Stripe &st = stripe_of(h);
+		std::lock_guard<std::mutex> g(st.mu);
+		auto it = st.files.find(shard_key(h, idx));
+		if (it == st.files.end())
+			return false;
+		s = it->second;
+		return true;
+	}
+	bool has(const Hash &h, int idx) override
+	{
+		Stripe &st = stripe_of(h);
+		std::lock_guard<std::mutex> g(st.mu);
+		return st.files.count(shard_key(h, idx)) != 0;
+	}
+	bool del(const Hash &h, int idx) override
+	{
+		Stripe &st = stripe_of(h);
+		std::lock_guard<std::mutex> g(st.mu);
+		return st.files.erase(shard_key(h, idx)) != 0;
 	}
 };
 
 // <root>/<h0>/<h1>/<hex>.s<idx>, tmp file + rename (write_block_inner, manager.rs:720-805);
-// a corrupt shard is renamed *.corrupted (manager.rs:807-819).
+// a corrupt shard is renamed *.corrupted (manager.rs:807-819).  File = 64-byte header + payload.
 struct DirNode : Node {
 	std::string root;
 	std::atomic<bool> fsync_data{false};  // Config.data_fsync (src/util/config.rs:22-24), off by default
@@ -284,7 +593,7 @@ struct DirNode : Node {
 			if (i == p.size() || p[i] == '/')
 				::mkdir(p.substr(0, i).c_str(), 0755);
 	}
-	bool put(const Hash &h, int idx, std::vector<uint8_t> &&raw) override
+	bool put(const Hash &h, int idx, const Shard &s) override
 	{
 		mkdirs(dir(h));
 		static std::atomic<uint64_t> seq{0};  // unique per writer: two threads may store the same shard
@@ -292,7 +601,10 @@ struct DirNode : Node {
 		FILE *f = std::fopen(tmp.c_str(), "wb");
 		if (!f)
 			return false;
-		bool ok = std::fwrite(raw.data(), 1, raw.size(), f) == raw.size();
+		uint8_t hdr[GBM_SHARD_HEADER_SIZE];
+		s.hd.pack(hdr);
+		bool ok = std::fwrite(hdr, 1, sizeof(hdr), f) == sizeof(hdr) &&
+			  std::fwrite(s.data.data(), 1, s.data.n, f) == s.data.n;
 		const bool sync = fsync_data.load();
 		if (ok && sync)  // file first, then (after the rename) its directory: manager.rs:775-800
 			ok = std::fflush(f) == 0 && ::fsync(::fileno(f)) == 0;
@@ -312,25 +624,61 @@ struct DirNode : Node {
 		}
 		return ok;
 	}
-	bool get(const Hash &h, int idx, std::vector<uint8_t> &raw) override
+	bool get(const Hash &h, int idx, Shard &s) override
 	{
 		FILE *f = std::fopen(path(h, idx).c_str(), "rb");
 		if (!f)
 			return false;
 		std::fseek(f, 0, SEEK_END);
-		long n = std::ftell(f);
+		const long n = std::ftell(f);
 		std::fseek(f, 0, SEEK_SET);
-		raw.resize(n > 0 ? (size_t)n : 0);
-		bool ok = n >= 0 && std::fread(raw.data(), 1, raw.size(), f) == raw.size();
+		uint8_t hdr[GBM_SHARD_HEADER_SIZE];
+		bool ok = n >= (long)sizeof(hdr) && std::fread(hdr, 1, sizeof(hdr), f) == sizeof(hdr);
+		// a file whose header does not parse is handed up as an invalid shard (shard_len != size) so that
+		// the reader treats it like a checksum failure: *.corrupted + resync
+		if (ok && !s.hd.unpack(hdr, sizeof(hdr))) {
+			s.hd = ShardHeader();
+			s.hd.idx = 0xff;
+		}
+		if (ok) {
+			const size_t len = (size_t)n - sizeof(hdr);
+			s.data = bufs->get(len);
+			ok = std::fread(s.data.mut(), 1, len, f) == len;
+		}
 		std::fclose(f);
 		return ok;
 	}
-	void del(const Hash &h, int idx) override { std::remove(path(h, idx).c_str()); }
+	bool has(const Hash &h, int idx) override
+	{
+		struct stat st;
+		return ::stat(path(h, idx).c_str(), &st) == 0;
+	}
+	bool del(const Hash &h, int idx) override { return std::remove(path(h, idx).c_str()) == 0; }
 	void mark_corrupted(const Hash &h, int idx) override
 	{
 		std::string p = path(h, idx);
 		std::rename(p.c_str(), (p + ".corrupted").c_str());
 	}
+};
+
+// RcEntry (src/block/rc.rs:122-240)
+struct RcEntry {
+	enum Kind : uint8_t { Absent = 0, Present = 1, Deletable = 2 } kind = Absent;
+	uint64_t v = 0;  // Present: count; Deletable: at_time (ms)
+	bool is_zero() const { return kind != Present; }
+	bool is_nonzero() const { return kind == Present; }
+	bool is_deletable(uint64_t now) const { return kind == Absent || (kind == Deletable && now > v); }
+	bool is_needed(uint64_t now) const { return !is_deletable(now); }
+};
+
+// ErrorCounter (src/block/resync.rs:604-648)
+struct ErrorCounter {
+	uint64_t errors = 0, last_try = 0;
+	uint64_t delay_ms(uint64_t base) const
+	{
+		return base << std::min<uint64_t>(errors - 1, GBM_RESYNC_RETRY_MAX_BACKOFF_POWER);
+	}
+	uint64_t next_try(uint64_t base) const { return last_try + delay_ms(base); }
 };
 
 }  // namespace
@@ -339,30 +687,104 @@ struct gbm_manager {
 	const gec_codec *codec = nullptr;
 	int k = 0, m = 0, n = 0, write_quorum = 0;
 	std::vector<std::unique_ptr<Node>> nodes;
-	std::mutex mu;  // rc / resync queue / metrics (lock_mutate's role, manager.rs:679-689)
-	std::unordered_map<Hash, uint64_t> rc;
-	std::vector<Hash> resync_queue;
-	uint64_t metrics[6] = {0, 0, 0, 0, 0, 0};
-	uint64_t gpu_hashed = 0;  // messages hashed on the device
-	bool compress = false;    // Config.compression_level (src/util/config.rs:52-58); Garage's default is Some(1)
-	int compression_level = 1;
+	std::shared_ptr<BufPool> bufs = std::make_shared<BufPool>();
+	std::unique_ptr<Pool> pool;
 
-	void nodes_of(const Hash &h, std::vector<int> &who) const
+	// cluster layout versions (src/rpc/layout/): reads consult [current .. oldest]
+	std::atomic<int> layout_cur{0}, layout_oldest{0};
+
+	// refcounts, striped like mutation_lock (manager.rs:679-689)
+	static constexpr int kRcStripes = 256;
+	struct RcStripe {
+		std::mutex mu;
+		std::unordered_map<Hash, RcEntry> map;
+	};
+	RcStripe rc[kRcStripes];
+	RcStripe &rc_of(const Hash &h) { return rc[(((unsigned char)h[0] << 8) | (unsigned char)h[1]) % kRcStripes]; }
+
+	// resync.queue / resync.errors (resync.rs:170-253)
+	mutable std::mutex rs_mu;
+	std::condition_variable rs_cv;
+	std::set<std::pair<uint64_t, Hash>> rs_queue;
+	std::unordered_map<Hash, ErrorCounter> rs_errors;
+	std::thread rs_worker;
+	bool rs_worker_stop = false;
+
+	std::atomic<uint64_t> gc_delay_ms{GBM_BLOCK_GC_DELAY_MS}, retry_delay_ms{GBM_RESYNC_RETRY_DELAY_MS},
+		incref_delay_ms{2 * 300000ull};  // 2 * rpc_timeout, DEFAULT_TIMEOUT = 300 s (rpc_helper.rs:33)
+	std::atomic<uint64_t> clock_skew_ms{0};
+	uint64_t now() const { return real_now_ms() + clock_skew_ms.load(); }
+
+	std::atomic<uint64_t> metrics[6] = {};
+	std::atomic<uint64_t> gpu_hashed{0};
+	std::atomic<bool> compress{false};    // Config.compression_level (src/util/config.rs:52-58); Garage's default is Some(1)
+	std::atomic<int> compression_level{1};
+	std::atomic<bool> verify_block_hash{true};
+
+	// storage nodes of a hash in layout version v: a deterministic stand-in for
+	// ClusterLayout::storage_nodes_of (partition = top bits of the hash, src/rpc/layout/version.rs:101-118)
+	void nodes_of(const Hash &h, int version, std::vector<int> &who) const
 	{
-		// partition = top byte(s) of the hash (src/rpc/layout/version.rs:101-104)
-		size_t start = ((unsigned char)h[0] * 31u + (unsigned char)h[1]) % nodes.size();
+		const size_t N = nodes.size();
+		const size_t start = ((unsigned char)h[0] * 31u + (unsigned char)h[1] + (size_t)version * (N / 2 + 1)) % N;
 		who.resize(n);
 		for (int j = 0; j < n; ++j)
-			who[j] = (int)((start + j) % nodes.size());
+			who[j] = (int)((start + j) % N);
 	}
-	void enqueue(const Hash &h)
+	void nodes_of(const Hash &h, std::vector<int> &who) const { nodes_of(h, layout_cur.load(), who); }
+
+	RcEntry get_rc(const Hash &h)
 	{
-		std::lock_guard<std::mutex> g(mu);
-		resync_queue.push_back(h);
+		RcStripe &s = rc_of(h);
+		std::lock_guard<std::mutex> g(s.mu);
+		auto it = s.map.find(h);
+		return it == s.map.end() ? RcEntry() : it->second;
 	}
+	void put_to_resync_at(const Hash &h, uint64_t when)
+	{
+		{
+			std::lock_guard<std::mutex> g(rs_mu);
+			rs_queue.insert({when, h});
+		}
+		rs_cv.notify_all();
+	}
+	void put_to_resync(const Hash &h, uint64_t delay) { put_to_resync_at(h, now() + delay); }
 };
 
 namespace {
+
+int ec_fail(int rc, const char *what)
+{
+	return fail(GBM_E_EC, std::string(what) + ": " + gec_strerror(rc) + " (" + gec_last_error() + ")");
+}
+
+// largest block a Garage node will ever hold decompresses to: block_size is configurable, 1 MiB by default and
+// "a few MiB" in practice; 1 GiB is far above any of it and still a harmless allocation bound
+constexpr size_t kMaxDecompressed = 1ull << 30;
+
+// blake2sum of many buffers: on the GPU (gec_blake2sum_batch) once the batch is big
+// enough to beat the CPU pool through PCIe + the kernel's ~1.5 ms chain latency, else on the pool's
+// threads.  SURVEY.md section 8 row f4.
+constexpr size_t kGpuHashMinMessages = 64;
+constexpr size_t kGpuHashMinBytes = 8u << 20;
+
+int hash_many(gbm_manager *mg, const std::vector<const uint8_t *> &ptrs, const std::vector<size_t> &lens,
+	      std::vector<uint8_t> &sums)
+{
+	sums.resize(ptrs.size() * 32);
+	size_t total = 0;
+	for (size_t l : lens)
+		total += l;
+	if (ptrs.size() >= kGpuHashMinMessages && total >= kGpuHashMinBytes) {
+		int rc = gec_blake2sum_batch(mg->codec, ptrs.size(), ptrs.data(), lens.data(), sums.data());
+		if (rc)
+			return ec_fail(rc, "gec_blake2sum_batch");
+		mg->gpu_hashed += ptrs.size();
+		return GBM_OK;
+	}
+	mg->pool->parallel_for(ptrs.size(), [&](size_t i) { blake2sum(ptrs[i], lens[i], sums.data() + 32 * i); });
+	return GBM_OK;
+}
 
 // Shards of one block are only usable together when they were cut from the same
 // payload with the same geometry.  A block can legitimately have shards of two
@@ -381,14 +803,15 @@ struct Geometry {
 };
 
 struct Gathered {
-	std::vector<std::vector<uint8_t>> shard;  // n entries; empty = not in hand
+	std::vector<Bytes> shard;  // n entries; empty = not in hand
 	ShardHeader meta;
 	bool have_meta = false;
 	int count = 0;
-	int next = 0;  // next shard index to try
+	size_t next = 0;  // next candidate (version-major, shard index minor) to try
+	bool mixed = false;
 	struct Group {
 		ShardHeader meta;
-		std::vector<std::vector<uint8_t>> shard;
+		std::vector<Bytes> shard;
 		int count = 0;
 	};
 	std::map<Geometry, Group> groups;
@@ -399,120 +822,108 @@ struct Gathered {
 			c = std::max(c, kv.second.count);
 		return c;
 	}
+	bool have_idx(int j) const
+	{
+		for (auto &kv : groups)
+			if (!kv.second.shard[j].empty())
+				return true;
+		return false;
+	}
 };
 
-// blake2sum of many buffers: on the GPU (gec_blake2sum_batch) once the batch is big
-// enough to beat one CPU thread (~1 GiB/s) through PCIe + the kernel's ~3.5 ms chain
-// latency, else inline.  SURVEY.md section 8 row f4.
-constexpr size_t kGpuHashMinMessages = 64;
-constexpr size_t kGpuHashMinBytes = 8u << 20;
-
-int hash_many(gbm_manager *mg, const std::vector<const uint8_t *> &ptrs, const std::vector<size_t> &lens,
-	      std::vector<uint8_t> &sums)
-{
-	sums.resize(ptrs.size() * 32);
-	size_t total = 0;
-	for (size_t l : lens)
-		total += l;
-	if (ptrs.size() >= kGpuHashMinMessages && total >= kGpuHashMinBytes) {
-		int rc = gec_blake2sum_batch(mg->codec, ptrs.size(), ptrs.data(), lens.data(), sums.data());
-		if (rc)
-			return fail(GBM_E_EC, std::string("gec_blake2sum_batch: ") + gec_strerror(rc) + " (" + gec_last_error() + ")");
-		std::lock_guard<std::mutex> lk(mg->mu);
-		mg->gpu_hashed += ptrs.size();
-		return GBM_OK;
-	}
-	for (size_t i = 0; i < ptrs.size(); ++i)
-		blake2sum(ptrs[i], lens[i], sums.data() + 32 * i);
-	return GBM_OK;
-}
-
-// Fetch shards in node order until every block has `want` valid ones in hand (or ran
-// out of nodes).  Checksums of each round's candidates are verified in ONE batch; a
-// shard whose checksum or geometry does not match is treated as missing, renamed
-// *.corrupted and queued for resync (read_block_from's behaviour, manager.rs:577-609),
-// and the next node is tried in the following round.
-int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, int want, std::vector<Gathered> &gs)
+// Fetch shards until every block has `want` valid ones of one geometry in hand (or ran out of nodes): shard
+// index order within the current layout version, then older versions (block_read_nodes_of interleaves
+// versions the same way, rpc_helper.rs:570-619).  The checksums of each round's candidates are verified in
+// ONE batch; a shard whose checksum or header does not match is treated as missing, renamed *.corrupted and
+// queued for resync (read_block_from's behaviour, manager.rs:577-609), and the next node is tried in the
+// following round.
+int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, int want, std::vector<Gathered> &gs)
 {
 	const int n = mg->n;
+	const int vcur = mg->layout_cur.load(), vold = mg->layout_oldest.load();
+	const size_t ncand = (size_t)(vcur - vold + 1) * n;
 	gs.assign(hs.size(), Gathered());
-	std::vector<std::vector<int>> who(hs.size());
-	for (size_t b = 0; b < hs.size(); ++b) {
-		mg->nodes_of(hs[b], who[b]);
-		gs[b].shard.assign(n, {});
-	}
 	struct Cand {
 		size_t b;
-		int j;
-		ShardHeader hd;
-		std::vector<uint8_t> raw;
+		int j, node;
+		Shard s;
 	};
 	for (;;) {
-		std::vector<Cand> cands;
-		for (size_t b = 0; b < hs.size(); ++b) {
+		std::vector<std::vector<Cand>> per(hs.size());
+		mg->pool->parallel_for(hs.size(), [&](size_t b) {
 			Gathered &g = gs[b];
 			int pending = 0;
-			while (g.next < n && g.best() + pending < want) {
-				const int j = g.next++;
-				Node &nd = *mg->nodes[who[b][j]];
-				if (nd.down)
+			std::vector<int> who;
+			int who_v = -1;
+			while (g.next < ncand && g.best() + pending < want) {
+				const size_t c = g.next++;
+				const int v = vcur - (int)(c / n), j = (int)(c % n);
+				if (g.have_idx(j))
 					continue;
-				Cand c{b, j, ShardHeader(), {}};
-				if (!nd.get(hs[b], j, c.raw))
+				bool dup = false;
+				for (const Cand &pc : per[b])
+					dup = dup || pc.j == j;
+				if (dup)
 					continue;
-				const bool ok = c.hd.unpack(c.raw.data(), c.raw.size()) && c.hd.idx == j && c.hd.k == mg->k &&
-						c.hd.m == mg->m && c.raw.size() == (size_t)GBM_SHARD_HEADER_SIZE + c.hd.shard_len;
+				if (v != who_v) {
+					mg->nodes_of(hs[b], v, who);
+					who_v = v;
+				}
+				ShardRpc rq{RpcKind::GetShard, &hs[b], j, Shard(), tags ? &tags[b] : nullptr};
+				ShardResp rs;
+				Node &nd = *mg->nodes[who[j]];
+				if (!nd.handle(rq, rs) || !rs.ok)
+					continue;
+				const ShardHeader &hd = rs.shard.hd;
+				const bool ok = hd.idx == j && hd.k == mg->k && hd.m == mg->m && rs.shard.data.n == hd.shard_len &&
+						hd.shard_len > 0 && hd.shard_len % 64 == 0;
 				if (!ok) {
-					{
-						std::lock_guard<std::mutex> lk(mg->mu);
-						mg->metrics[2]++;
-						mg->resync_queue.push_back(hs[b]);
-					}
+					mg->metrics[2]++;
 					nd.mark_corrupted(hs[b], j);
+					mg->put_to_resync(hs[b], 0);
 					continue;
 				}
-				cands.push_back(std::move(c));
+				per[b].push_back(Cand{b, j, who[j], std::move(rs.shard)});
 				++pending;
 			}
-		}
+		});
+		std::vector<Cand *> cands;
+		for (auto &v : per)
+			for (Cand &c : v)
+				cands.push_back(&c);
 		if (cands.empty())
 			break;
 		std::vector<const uint8_t *> ptrs(cands.size());
 		std::vector<size_t> lens(cands.size());
 		for (size_t i = 0; i < cands.size(); ++i) {
-			ptrs[i] = cands[i].raw.data() + GBM_SHARD_HEADER_SIZE;
-			lens[i] = cands[i].hd.shard_len;
+			ptrs[i] = cands[i]->s.data.data();
+			lens[i] = cands[i]->s.hd.shard_len;
 		}
 		std::vector<uint8_t> sums;
 		int rc = hash_many(mg, ptrs, lens, sums);
 		if (rc)
 			return rc;
 		for (size_t i = 0; i < cands.size(); ++i) {
-			Cand &c = cands[i];
+			Cand &c = *cands[i];
 			Gathered &g = gs[c.b];
-			if (std::memcmp(sums.data() + 32 * i, c.hd.checksum, 32) != 0) {
-				{
-					std::lock_guard<std::mutex> lk(mg->mu);
-					mg->metrics[2]++;
-					mg->resync_queue.push_back(hs[c.b]);
-				}
-				mg->nodes[who[c.b][c.j]]->mark_corrupted(hs[c.b], c.j);
+			if (std::memcmp(sums.data() + 32 * i, c.s.hd.checksum, 32) != 0) {
+				mg->metrics[2]++;
+				mg->nodes[c.node]->mark_corrupted(hs[c.b], c.j);
+				mg->put_to_resync(hs[c.b], 0);
 				continue;
 			}
 			Geometry geo;
-			geo.compressed = c.hd.compressed;
-			geo.orig_len = c.hd.orig_len;
-			geo.shard_len = c.hd.shard_len;
+			geo.compressed = c.s.hd.compressed;
+			geo.orig_len = c.s.hd.orig_len;
+			geo.shard_len = c.s.hd.shard_len;
 			Gathered::Group &grp = g.groups[geo];
 			if (grp.shard.empty()) {
-				grp.shard.assign(n, {});
-				grp.meta = c.hd;
+				grp.shard.assign(n, Bytes());
+				grp.meta = c.s.hd;
 			}
-			c.raw.erase(c.raw.begin(), c.raw.begin() + GBM_SHARD_HEADER_SIZE);
-			grp.shard[c.j] = std::move(c.raw);
+			mg->metrics[1] += c.s.hd.shard_len;
+			grp.shard[c.j] = std::move(c.s.data);
 			grp.count++;
-			std::lock_guard<std::mutex> lk(mg->mu);
-			mg->metrics[1] += c.hd.shard_len;
 		}
 	}
 	// settle on the largest consistent group; the stragglers of other geometries are
@@ -528,31 +939,23 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, int want, std::vec
 			g.meta = bestg->meta;
 			g.have_meta = true;
 			g.count = bestg->count;
-			if (g.groups.size() > 1) {
-				std::lock_guard<std::mutex> lk(mg->mu);
-				mg->resync_queue.push_back(hs[b]);
-			}
+			g.mixed = g.groups.size() > 1;
+			if (g.mixed)
+				mg->put_to_resync(hs[b], 0);
+		} else {
+			g.shard.assign(n, Bytes());
 		}
 		g.groups.clear();
 	}
 	return GBM_OK;
 }
 
-int gather(gbm_manager *mg, const Hash &h, int want, Gathered &g)
+// PutShard to one node; false = the node could not be contacted or refused
+bool send_shard(gbm_manager *mg, int node, const Hash &h, int idx, const Bytes &payload, size_t S, uint64_t orig_len,
+		bool compressed, const uint8_t *checksum, const gbm_order_tag *tag)
 {
-	std::vector<Gathered> gs;
-	int rc = gather_many(mg, {h}, want, gs);
-	g = std::move(gs[0]);
-	return rc;
-}
-
-int store_shard(gbm_manager *mg, int node, const Hash &h, int idx, const uint8_t *payload, size_t S,
-		uint64_t orig_len, bool compressed, const uint8_t *checksum = nullptr)
-{
-	Node &nd = *mg->nodes[node];
-	if (nd.down)
-		return -1;
-	ShardHeader hd;
+	ShardRpc rq{RpcKind::PutShard, &h, idx, Shard(), tag};
+	ShardHeader &hd = rq.shard.hd;
 	hd.k = (uint8_t)mg->k;
 	hd.m = (uint8_t)mg->m;
 	hd.idx = (uint8_t)idx;
@@ -562,16 +965,540 @@ int store_shard(gbm_manager *mg, int node, const Hash &h, int idx, const uint8_t
 	if (checksum)
 		std::memcpy(hd.checksum, checksum, 32);
 	else
-		blake2sum(payload, S, hd.checksum);
-	std::vector<uint8_t> raw(GBM_SHARD_HEADER_SIZE + S);
-	hd.pack(raw.data());
-	std::memcpy(raw.data() + GBM_SHARD_HEADER_SIZE, payload, S);
-	return nd.put(h, idx, std::move(raw)) ? 0 : -1;
+		blake2sum(payload.data(), S, hd.checksum);
+	rq.shard.data = payload;
+	ShardResp rs;
+	return mg->nodes[node]->handle(rq, rs) && rs.ok;
 }
 
-int ec_fail(int rc, const char *what)
+// rcs (optional): per-block result, GBM_OK or GBM_E_QUORUM; the return value is the last failure.  The device
+// work of the whole batch happens before anything is sent to a node, so a device error (GBM_E_EC) fails
+// every block of the batch and leaves no partial state behind.
+int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data, const size_t *len,
+		    const uint8_t *prevent_compression, const gbm_order_tag *tags, int *rcs)
 {
-	return fail(GBM_E_EC, std::string(what) + ": " + gec_strerror(rc) + " (" + gec_last_error() + ")");
+	if (!mg || (nb && (!hashes || !data || !len)))
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	if (nb == 0)
+		return GBM_OK;
+	for (size_t b = 0; b < nb; ++b)
+		if (!data[b] && len[b])
+			return fail(GBM_E_INVALID_ARG, "NULL block pointer");
+	if (rcs)
+		std::fill(rcs, rcs + nb, GBM_OK);
+	const int k = mg->k, m = mg->m, n = mg->n;
+	const bool compress = mg->compress.load();
+	const int level = mg->compression_level.load();
+	// -- DataBlock::from_buffer (zstd when a level is configured and the caller did not forbid it, Plain on any
+	//    encoder error), then ONE copy of the payload into a zero-padded k*S buffer whose slices are the k data
+	//    shards.  Shard geometry is a pure function of the block: S = gec_shard_len(k, payload length) --
+	//    never the batch maximum: a later put of the same block must produce compatible shards.
+	struct Prep {
+		Bytes block, parity;
+		size_t plen = 0, S = 0;
+		bool z = false;
+	};
+	std::vector<Prep> prep(nb);
+	std::atomic<bool> oom{false};
+	mg->pool->parallel_for(nb, [&](size_t b) {
+		try {
+			Prep &p = prep[b];
+			std::vector<uint8_t> zbuf;
+			const uint8_t *src = data[b];
+			p.plen = len[b];
+			if (compress && !(prevent_compression && prevent_compression[b]) &&
+			    zstd().encode(data[b], len[b], level, zbuf)) {
+				src = zbuf.data();
+				p.plen = zbuf.size();
+				p.z = true;
+			}
+			p.S = gec_shard_len(k, p.plen);
+			p.block = mg->bufs->get((size_t)k * p.S);
+			if (p.plen)
+				std::memcpy(p.block.mut(), src, p.plen);
+			std::memset(p.block.mut() + p.plen, 0, (size_t)k * p.S - p.plen);
+			p.parity = mg->bufs->get((size_t)m * p.S);
+		} catch (const std::bad_alloc &) {
+			oom = true;
+		}
+	});
+	if (oom)
+		return fail(GBM_E_IO, "out of (pinned) host memory for the shard buffers");
+	// Blocks of equal S -- in practice all full block_size blocks -- share ONE device call that returns
+	// parity and the checksums of all k+m shards.
+	std::map<size_t, std::vector<size_t>> by_s;
+	for (size_t b = 0; b < nb; ++b)
+		by_s[prep[b].S].push_back(b);
+	std::vector<uint8_t> sums(nb * (size_t)n * 32);
+	for (auto &kv : by_s) {
+		const size_t S = kv.first;
+		const std::vector<size_t> &ids = kv.second;
+		const size_t gn = ids.size();
+		std::vector<uint8_t *> pp(gn);
+		std::vector<const uint8_t *> gd(gn);
+		std::vector<size_t> gl(gn, (size_t)k * S);  // the buffers are already padded: whole data area
+		std::vector<uint8_t> gsums(gn * (size_t)n * 32);
+		for (size_t i = 0; i < gn; ++i) {
+			pp[i] = prep[ids[i]].parity.mut();
+			gd[i] = prep[ids[i]].block.data();
+		}
+		int rc = gec_encode_hash_batch(mg->codec, gn, gd.data(), gl.data(), S, pp.data(), gsums.data());
+		if (rc) {  // nothing has been sent to any node yet: the whole batch fails
+			if (rcs)
+				std::fill(rcs, rcs + nb, GBM_E_EC);
+			return ec_fail(rc, "gec_encode_hash_batch");
+		}
+		mg->gpu_hashed += gn * (size_t)n;
+		for (size_t i = 0; i < gn; ++i)
+			std::memcpy(sums.data() + ids[i] * (size_t)n * 32, gsums.data() + i * (size_t)n * 32, (size_t)n * 32);
+	}
+	// fan-out: shard j of every block to nodes_of(hash)[j].  With order tags the blocks go out one after the
+	// other in (stream, order) order -- requests of one stream reach a node in `order` order, whatever their
+	// shard geometry; without tags the blocks are independent and go out from the pool's threads.
+	std::vector<int> oks(nb, 0);
+	auto fan_out = [&](size_t b) {
+		Hash h((const char *)hashes + 32 * b, 32);
+		std::vector<int> who;
+		mg->nodes_of(h, who);
+		const size_t S = prep[b].S;
+		int ok = 0;
+		for (int j = 0; j < n; ++j) {
+			const Bytes payload = j < k ? prep[b].block.slice((size_t)j * S, S) : prep[b].parity.slice((size_t)(j - k) * S, S);
+			if (send_shard(mg, who[j], h, j, payload, S, prep[b].plen, prep[b].z, sums.data() + (b * n + j) * 32,
+				       tags ? &tags[b] : nullptr)) {
+				++ok;
+				mg->metrics[0] += S;
+			}
+		}
+		oks[b] = ok;
+	};
+	if (tags) {
+		std::vector<size_t> order(nb);
+		for (size_t i = 0; i < nb; ++i)
+			order[i] = i;
+		std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+			return std::tie(tags[x].stream_id, tags[x].order) < std::tie(tags[y].stream_id, tags[y].order);
+		});
+		for (size_t b : order)
+			fan_out(b);
+	} else {
+		mg->pool->parallel_for(nb, fan_out);
+	}
+	int result = GBM_OK;
+	for (size_t b = 0; b < nb; ++b) {
+		Hash h((const char *)hashes + 32 * b, 32);
+		mg->metrics[4]++;
+		if (oks[b] < mg->write_quorum) {
+			result = fail(GBM_E_QUORUM, "Could not reach quorum of " + std::to_string(mg->write_quorum) + ". " +
+							    std::to_string(oks[b]) + " of " + std::to_string(n) + " request succeeded");
+			if (rcs)
+				rcs[b] = GBM_E_QUORUM;
+			continue;
+		}
+		// A block that nobody references yet (PutObject runs the put and the block_ref incref
+		// concurrently, src/api/s3/put.rs:545-581) is protected for BLOCK_GC_DELAY exactly like one
+		// whose count just dropped to zero: resync must never delete what a put just acknowledged.
+		{
+			gbm_manager::RcStripe &st = mg->rc_of(h);
+			std::lock_guard<std::mutex> g(st.mu);
+			RcEntry &e = st.map[h];
+			if (e.kind != RcEntry::Present) {
+				e.kind = RcEntry::Deletable;
+				e.v = std::max(e.v, mg->now() + mg->gc_delay_ms.load());
+			}
+		}
+		if (oks[b] < n)
+			mg->put_to_resync(h, 0);  // stragglers: resync rebuilds what is absent (it only REBUILDS while the block is needed)
+	}
+	return result;
+}
+
+// gather + decode: on return, for every block with rcs[b] == GBM_OK, payload[b] holds orig_len bytes of the
+// stored DataBlock (plain bytes or one zstd frame) as k shard-sized pieces in g[b].shard[0..k-1].
+int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs)
+{
+	const int k = mg->k, n = mg->n;
+	const size_t nb = hs.size();
+	int grc = gather_many(mg, hs, tags, k, g);  // shard checksums verified in batches (GPU when large)
+	if (grc)
+		return grc;
+	// blocks that need a decode, grouped by shard length (one device call per group)
+	std::map<size_t, std::vector<size_t>> need;
+	for (size_t b = 0; b < nb; ++b) {
+		if (!g[b].have_meta || g[b].count < k) {
+			rcs[b] = GBM_E_MISSING_BLOCK;
+			continue;
+		}
+		rcs[b] = GBM_OK;
+		if (g[b].meta.orig_len > (uint64_t)k * g[b].meta.shard_len) {
+			rcs[b] = GBM_E_CORRUPT_DATA;
+			continue;
+		}
+		for (int j = 0; j < k; ++j)
+			if (g[b].shard[j].empty()) {
+				need[g[b].meta.shard_len].push_back(b);
+				break;
+			}
+	}
+	for (auto &kv : need) {
+		const size_t S = kv.first;
+		const std::vector<size_t> &ids = kv.second;
+		std::vector<const uint8_t *> sp(ids.size() * n, nullptr);
+		std::vector<uint8_t *> op(ids.size() * n, nullptr);
+		try {
+			for (size_t i = 0; i < ids.size(); ++i) {
+				Gathered &gb = g[ids[i]];
+				for (int j = 0; j < n; ++j) {
+					if (!gb.shard[j].empty()) {
+						sp[i * n + j] = gb.shard[j].data();
+					} else if (j < k) {
+						gb.shard[j] = mg->bufs->get(S);
+						op[i * n + j] = gb.shard[j].mut();
+					}
+				}
+			}
+		} catch (const std::bad_alloc &) {
+			return fail(GBM_E_IO, "out of (pinned) host memory");
+		}
+		int rc = gec_reconstruct_batch(mg->codec, ids.size(), sp.data(), op.data(), S, /*data_only=*/1);
+		if (rc)
+			return ec_fail(rc, "gec_reconstruct_batch");
+		mg->metrics[3] += ids.size();
+	}
+	return GBM_OK;
+}
+
+void assemble(const Gathered &g, int k, uint8_t *dst)
+{
+	const size_t L = g.meta.orig_len, S = g.meta.shard_len;
+	for (int j = 0; j < k; ++j) {
+		const size_t lo = (size_t)j * S;
+		if (lo >= L)
+			break;
+		std::memcpy(dst + lo, g.shard[j].data(), std::min(S, L - lo));
+	}
+}
+
+// raw == true: rpc_get_raw_block (stored bytes + header); false: rpc_get_block (plain bytes).
+int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
+		    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers)
+{
+	if (!mg || (nb && (!hashes || !out || !cap || !len_out || !rcs)))
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	const int k = mg->k;
+	std::vector<Hash> hs(nb);
+	for (size_t b = 0; b < nb; ++b)
+		hs[b].assign((const char *)hashes + 32 * b, 32);
+	std::vector<Gathered> g;
+	int frc = fetch_blocks(mg, hs, tags, g, rcs);
+	if (frc)
+		return frc;
+	// assemble (parallel), then check every Plain block's content against its name (DataBlock::verify,
+	// block.rs:69-77) -- all block hashes in one batch.  Plain blocks are assembled straight into the
+	// caller's buffer and hashed from there (on CORRUPT_DATA its contents are unspecified); compressed
+	// blocks go through an intermediate for the zstd frame, whose checksum is their verify.
+	std::vector<uint8_t> want_hash(nb, 0);
+	mg->pool->parallel_for(nb, [&](size_t b) {
+		len_out[b] = 0;
+		if (rcs[b] != GBM_OK)
+			return;
+		const size_t L = g[b].meta.orig_len;
+		const bool z = g[b].meta.compressed != 0;
+		if (headers)
+			headers[b].kind = z ? GBM_HEADER_COMPRESSED : GBM_HEADER_PLAIN;
+		len_out[b] = L;
+		if (z && !raw) {
+			std::vector<uint8_t> frame(L), plain;
+			assemble(g[b], k, frame.data());
+			if (!zstd().decode(frame.data(), L, kMaxDecompressed, plain)) {
+				rcs[b] = GBM_E_CORRUPT_DATA;
+				return;
+			}
+			len_out[b] = plain.size();
+			if (cap[b] < plain.size()) {
+				rcs[b] = GBM_E_BUFFER_TOO_SMALL;
+				return;
+			}
+			if (!plain.empty())
+				std::memcpy(out[b], plain.data(), plain.size());
+			mg->metrics[5]++;
+			return;
+		}
+		if (cap[b] < L) {
+			rcs[b] = GBM_E_BUFFER_TOO_SMALL;
+			return;
+		}
+		assemble(g[b], k, out[b]);
+		if (!z && mg->verify_block_hash.load())
+			want_hash[b] = 1;
+		else
+			mg->metrics[5]++;
+	});
+	std::vector<const uint8_t *> ptrs;
+	std::vector<size_t> lens, idx;
+	for (size_t b = 0; b < nb; ++b)
+		if (want_hash[b]) {
+			ptrs.push_back(out[b]);
+			lens.push_back(len_out[b]);
+			idx.push_back(b);
+		}
+	std::vector<uint8_t> sums;
+	int hrc = hash_many(mg, ptrs, lens, sums);
+	if (hrc)
+		return hrc;
+	for (size_t i = 0; i < idx.size(); ++i) {
+		const size_t b = idx[i];
+		if (std::memcmp(sums.data() + 32 * i, hashes + 32 * b, 32) != 0) {
+			rcs[b] = GBM_E_CORRUPT_DATA;
+			continue;
+		}
+		mg->metrics[5]++;
+	}
+	return GBM_OK;
+}
+
+int one_block_rc(int rc1)
+{
+	switch (rc1) {
+	case GBM_E_MISSING_BLOCK: return fail(rc1, "Missing block: no node returned a valid block");
+	case GBM_E_CORRUPT_DATA: return fail(rc1, "Corrupt data: does not match hash");
+	case GBM_E_BUFFER_TOO_SMALL: return fail(rc1, "output buffer too small");
+	default: return rc1;
+	}
+}
+
+// ------------------------------------------------------------------ resync
+struct ResyncStats {
+	uint64_t taken = 0, ok = 0, errors = 0, skipped = 0, rebuilt = 0, deleted = 0, offloaded = 0, device_calls = 0;
+};
+
+// What one block needs, decided from the refcount and a presence scan (NeedShardQuery to every node that
+// could hold a shard: no payload moves).
+struct ResyncTask {
+	Hash h;
+	std::vector<int> who;              // current layout
+	std::vector<uint8_t> present_cur;  // shard j present on its current node
+	std::vector<uint8_t> reachable;    // current node of shard j is up
+	struct Stray {
+		int version, idx, node;
+	};
+	std::vector<Stray> strays;         // shards sitting on nodes of older layout versions
+	bool exists = false;
+	RcEntry rc;
+	std::string error;
+	int changed = 0;
+	// rebuild
+	std::vector<int> want;             // absent on a reachable current node, not recoverable by offload
+	Gathered g;
+};
+
+void scan_block(gbm_manager *mg, ResyncTask &t)
+{
+	const int n = mg->n;
+	const int vcur = mg->layout_cur.load(), vold = mg->layout_oldest.load();
+	mg->nodes_of(t.h, vcur, t.who);
+	t.present_cur.assign(n, 0);
+	t.reachable.assign(n, 0);
+	for (int j = 0; j < n; ++j) {
+		ShardRpc rq{RpcKind::NeedShardQuery, &t.h, j, Shard(), nullptr};
+		ShardResp rs;
+		if (mg->nodes[t.who[j]]->handle(rq, rs)) {
+			t.reachable[j] = 1;
+			t.present_cur[j] = rs.needed ? 0 : 1;
+			t.exists = t.exists || !rs.needed;
+		}
+	}
+	std::vector<int> who;
+	for (int v = vcur - 1; v >= vold; --v) {
+		mg->nodes_of(t.h, v, who);
+		for (int j = 0; j < n; ++j) {
+			if (who[j] == t.who[j])
+				continue;
+			ShardRpc rq{RpcKind::NeedShardQuery, &t.h, j, Shard(), nullptr};
+			ShardResp rs;
+			if (mg->nodes[who[j]]->handle(rq, rs) && !rs.needed) {
+				t.strays.push_back({v, j, who[j]});
+				t.exists = true;
+			}
+		}
+	}
+	t.rc = mg->get_rc(t.h);
+}
+
+// resync_block for a set of blocks (src/block/resync.rs:354-503), with the device work of all of them batched.
+void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats &st)
+{
+	const int k = mg->k, n = mg->n;
+	const uint64_t now = mg->now();
+	mg->pool->parallel_for(tasks.size(), [&](size_t i) { scan_block(mg, tasks[i]); });
+	std::vector<size_t> rebuild;
+	std::atomic<uint64_t> deleted{0}, offloaded{0};
+	mg->pool->parallel_for(tasks.size(), [&](size_t i) {
+		ResyncTask &t = tasks[i];
+		if (t.exists && t.rc.is_deletable(now)) {
+			// "offloading and deleting" -- with one refcount for the whole (in-process) cluster a deletable
+			// block is needed by nobody, so NeedShardQuery has no taker and the offload set is empty
+			for (int j = 0; j < n; ++j)
+				if (t.present_cur[j]) {
+					ShardRpc rq{RpcKind::DeleteShard, &t.h, j, Shard(), nullptr};
+					ShardResp rs;
+					if (mg->nodes[t.who[j]]->handle(rq, rs) && rs.ok)
+						++t.changed;
+				}
+			for (auto &s : t.strays) {
+				ShardRpc rq{RpcKind::DeleteShard, &t.h, s.idx, Shard(), nullptr};
+				ShardResp rs;
+				if (mg->nodes[s.node]->handle(rq, rs) && rs.ok)
+					++t.changed;
+			}
+			deleted += t.changed;
+			// clear_deleted_block_rc
+			gbm_manager::RcStripe &rs = mg->rc_of(t.h);
+			std::lock_guard<std::mutex> g(rs.mu);
+			auto it = rs.map.find(t.h);
+			if (it != rs.map.end() && it->second.kind == RcEntry::Deletable && now > it->second.v)
+				rs.map.erase(it);
+			return;
+		}
+		if (!t.rc.is_needed(now))
+			return;  // nothing stored, nothing needed
+		// needed.  First the offload branch: a shard that a layout change left on its old node is sent to the
+		// owner that lacks it (PutShard), then deleted where it no longer belongs.
+		for (auto &s : t.strays) {
+			if (!t.present_cur[s.idx] && t.reachable[s.idx]) {
+				ShardRpc rq{RpcKind::GetShard, &t.h, s.idx, Shard(), nullptr};
+				ShardResp rs;
+				if (!mg->nodes[s.node]->handle(rq, rs) || !rs.ok)
+					continue;
+				uint8_t sum[32];
+				blake2sum(rs.shard.data.data(), rs.shard.data.n, sum);
+				if (rs.shard.data.n != rs.shard.hd.shard_len || std::memcmp(sum, rs.shard.hd.checksum, 32) != 0) {
+					mg->metrics[2]++;
+					mg->nodes[s.node]->mark_corrupted(t.h, s.idx);
+					continue;
+				}
+				ShardRpc pq{RpcKind::PutShard, &t.h, s.idx, rs.shard, nullptr};
+				ShardResp ps;
+				if (!mg->nodes[t.who[s.idx]]->handle(pq, ps) || !ps.ok) {
+					t.error = "offload: PutShard to the new owner failed";
+					continue;
+				}
+				t.present_cur[s.idx] = 1;
+				++t.changed;
+				++offloaded;
+			}
+			if (t.present_cur[s.idx]) {  // the owner has it: the stray copy is unneeded
+				ShardRpc rq{RpcKind::DeleteShard, &t.h, s.idx, Shard(), nullptr};
+				ShardResp rs;
+				(void)mg->nodes[s.node]->handle(rq, rs);
+			}
+		}
+		for (int j = 0; j < n; ++j)
+			if (!t.present_cur[j]) {
+				if (t.reachable[j])
+					t.want.push_back(j);
+				else
+					t.error = "storage node of shard " + std::to_string(j) + " could not be contacted";
+			}
+	});
+	st.deleted += deleted.load();
+	st.offloaded += offloaded.load();
+	for (size_t i = 0; i < tasks.size(); ++i)
+		if (!tasks[i].want.empty())
+			rebuild.push_back(i);
+	if (!rebuild.empty()) {
+		// "fetching absent but needed block": gather exactly k shards per block (checksums verified in one batch)
+		std::vector<Hash> hs;
+		for (size_t i : rebuild)
+			hs.push_back(tasks[i].h);
+		std::vector<Gathered> gs;
+		int grc = gather_many(mg, hs, nullptr, k, gs);
+		for (size_t q = 0; q < rebuild.size(); ++q) {
+			ResyncTask &t = tasks[rebuild[q]];
+			if (grc) {
+				t.error = std::string("gather: ") + g_err;
+				t.want.clear();
+				continue;
+			}
+			t.g = std::move(gs[q]);
+			if (!t.g.have_meta || t.g.count < k) {
+				t.error = "Missing block: fewer than k shards reachable";
+				t.want.clear();
+				continue;
+			}
+			// the read may have found corrupt shards (renamed away): those are absent now as well
+			for (int j = 0; j < n; ++j)
+				if (t.reachable[j] && t.g.shard[j].empty() && std::find(t.want.begin(), t.want.end(), j) == t.want.end()) {
+					ShardRpc rq{RpcKind::NeedShardQuery, &t.h, j, Shard(), nullptr};
+					ShardResp rs;
+					if (mg->nodes[t.who[j]]->handle(rq, rs) && rs.needed)
+						t.want.push_back(j);
+				}
+			// shards of a minority geometry are stale: overwrite them
+			if (t.g.mixed)
+				for (int j = 0; j < n; ++j)
+					if (t.reachable[j] && t.g.shard[j].empty() && std::find(t.want.begin(), t.want.end(), j) == t.want.end())
+						t.want.push_back(j);
+		}
+		// group by (shard length, which shards are in hand, which are wanted): ONE device call per group, and
+		// inside it one decode plan (gec_reconstruct_batch buckets by exactly this key)
+		std::map<std::tuple<size_t, std::string, std::string>, std::vector<size_t>> groups;
+		for (size_t i : rebuild) {
+			ResyncTask &t = tasks[i];
+			if (t.want.empty())
+				continue;
+			std::string pres(n, 0), want(n, 0);
+			for (int j = 0; j < n; ++j)
+				pres[j] = t.g.shard[j].empty() ? 0 : 1;
+			for (int j : t.want)
+				want[j] = 1;
+			groups[{t.g.meta.shard_len, pres, want}].push_back(i);
+		}
+		for (auto &kv : groups) {
+			const size_t S = std::get<0>(kv.first);
+			const std::vector<size_t> &ids = kv.second;
+			std::vector<const uint8_t *> sp(ids.size() * n, nullptr);
+			std::vector<uint8_t *> op(ids.size() * n, nullptr);
+			std::vector<std::vector<Bytes>> outb(ids.size(), std::vector<Bytes>(n));
+			bool oom = false;
+			for (size_t q = 0; q < ids.size() && !oom; ++q) {
+				ResyncTask &t = tasks[ids[q]];
+				for (int j = 0; j < n; ++j)
+					if (!t.g.shard[j].empty())
+						sp[q * n + j] = t.g.shard[j].data();
+				try {
+					for (int j : t.want) {
+						outb[q][j] = mg->bufs->get(S);
+						op[q * n + j] = outb[q][j].mut();
+					}
+				} catch (const std::bad_alloc &) {
+					oom = true;
+				}
+			}
+			int rc = oom ? GEC_E_NOMEM : gec_reconstruct_batch(mg->codec, ids.size(), sp.data(), op.data(), S, 0);
+			++st.device_calls;
+			if (rc) {
+				ec_fail(rc, "gec_reconstruct_batch");
+				for (size_t i : ids)
+					tasks[i].error = g_err;
+				continue;
+			}
+			mg->metrics[3] += ids.size();
+			std::atomic<uint64_t> rebuilt{0};
+			mg->pool->parallel_for(ids.size(), [&](size_t q) {
+				ResyncTask &t = tasks[ids[q]];
+				for (int j : t.want) {
+					if (send_shard(mg, t.who[j], t.h, j, outb[q][j], S, t.g.meta.orig_len, t.g.meta.compressed != 0, nullptr, nullptr)) {
+						++t.changed;
+						++rebuilt;
+					} else {
+						t.error = "PutShard of a rebuilt shard failed";
+					}
+				}
+			});
+			st.rebuilt += rebuilt.load();
+		}
+	}
 }
 
 }  // namespace
@@ -605,12 +1532,29 @@ int gbm_create(const gec_codec *codec, int nnodes, const char *const *node_dirs,
 			mg->nodes.emplace_back(new DirNode(node_dirs[i]));
 		else
 			mg->nodes.emplace_back(new MemoryNode());
+		mg->nodes.back()->bufs = mg->bufs;
 	}
+	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+	mg->pool.reset(new Pool(std::min(15u, hw - 1)));
 	*out = mg.release();
 	return GBM_OK;
 }
 
-void gbm_destroy(gbm_manager *m) { delete m; }
+void gbm_destroy(gbm_manager *m)
+{
+	if (!m)
+		return;
+	gbm_resync_worker_stop(m);
+	delete m;
+}
+
+int gbm_set_threads(gbm_manager *m, int nthreads)
+{
+	if (!m || nthreads < 1 || nthreads > 256)
+		return fail(GBM_E_INVALID_ARG, "need 1 <= nthreads <= 256");
+	m->pool->resize((unsigned)nthreads - 1);  // the calling thread works too
+	return GBM_OK;
+}
 
 int gbm_set_data_fsync(gbm_manager *m, int enabled)
 {
@@ -619,6 +1563,36 @@ int gbm_set_data_fsync(gbm_manager *m, int enabled)
 	for (auto &nd : m->nodes)
 		if (DirNode *d = dynamic_cast<DirNode *>(nd.get()))
 			d->fsync_data = enabled != 0;
+	return GBM_OK;
+}
+
+int gbm_set_verify_block_hash(gbm_manager *m, int enabled)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	m->verify_block_hash = enabled != 0;
+	return GBM_OK;
+}
+
+int gbm_set_timing(gbm_manager *m, int64_t gc_delay_ms, int64_t resync_retry_delay_ms, int64_t incref_check_delay_ms)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	if (gc_delay_ms >= 0)
+		m->gc_delay_ms = (uint64_t)gc_delay_ms;
+	if (resync_retry_delay_ms >= 0)
+		m->retry_delay_ms = (uint64_t)resync_retry_delay_ms;
+	if (incref_check_delay_ms >= 0)
+		m->incref_delay_ms = (uint64_t)incref_check_delay_ms;
+	return GBM_OK;
+}
+
+int gbm_clock_advance(gbm_manager *m, uint64_t ms)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	m->clock_skew_ms += ms;
+	m->rs_cv.notify_all();
 	return GBM_OK;
 }
 
@@ -632,249 +1606,133 @@ int gbm_storage_nodes_of(const gbm_manager *m, const uint8_t hash[32], int *node
 	return GBM_OK;
 }
 
-// rcs (optional): per-block result, GBM_OK or GBM_E_QUORUM; the return value is the last
-// failure (or a whole-batch error such as GBM_E_EC).
-static int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data,
-			   const size_t *len, int *rcs)
+int gbm_layout_update(gbm_manager *m)
 {
-	if (!mg || (nb && (!hashes || !data || !len)))
-		return fail(GBM_E_INVALID_ARG, "NULL argument");
-	if (nb == 0)
-		return GBM_OK;
-	if (rcs)
-		std::fill(rcs, rcs + nb, GBM_OK);
-	const int k = mg->k, m = mg->m, n = mg->n;
-	// DataBlock::from_buffer: zstd when a level is configured, Plain on any encoder error
-	std::vector<std::vector<uint8_t>> zbuf(nb);
-	std::vector<const uint8_t *> dptr(data, data + nb);
-	std::vector<size_t> dlen(len, len + nb);
-	std::vector<uint8_t> is_z(nb, 0);
-	if (mg->compress)
-		for (size_t b = 0; b < nb; ++b)
-			if (zstd().encode(data[b], len[b], mg->compression_level, zbuf[b])) {
-				dptr[b] = zbuf[b].data();
-				dlen[b] = zbuf[b].size();
-				is_z[b] = 1;
-			}
-	data = dptr.data();
-	len = dlen.data();
-	// Shard geometry is a pure function of the block: S = gec_shard_len(k, payload length).
-	// (Never the batch maximum: a later put of the same block must produce compatible
-	// shards.)  Blocks of equal S -- in practice all full block_size blocks -- share ONE
-	// device call that returns parity and the checksums of all k+m shards.
-	std::map<size_t, std::vector<size_t>> by_s;
-	for (size_t b = 0; b < nb; ++b)
-		by_s[gec_shard_len(k, len[b])].push_back(b);
-	int result = GBM_OK;
-	for (auto &kv : by_s) {
-		const size_t S = kv.first;
-		const std::vector<size_t> &ids = kv.second;
-		const size_t gn = ids.size();
-		std::vector<uint8_t> parity(gn * (size_t)m * S), sums(gn * (size_t)n * 32), last(S);
-		std::vector<uint8_t *> pp(gn);
-		std::vector<const uint8_t *> gd(gn);
-		std::vector<size_t> gl(gn);
-		for (size_t i = 0; i < gn; ++i) {
-			pp[i] = parity.data() + i * (size_t)m * S;
-			gd[i] = data[ids[i]];
-			gl[i] = len[ids[i]];
-		}
-		int rc = gec_encode_hash_batch(mg->codec, gn, gd.data(), gl.data(), S, pp.data(), sums.data());
-		if (rc)
-			return ec_fail(rc, "gec_encode_hash_batch");
-		{
-			std::lock_guard<std::mutex> lk(mg->mu);
-			mg->gpu_hashed += gn * (size_t)n;
-		}
-		for (size_t i = 0; i < gn; ++i) {
-			const size_t b = ids[i];
-			Hash h((const char *)hashes + 32 * b, 32);
-			std::vector<int> who;
-			mg->nodes_of(h, who);
-			int ok = 0;
-			for (int j = 0; j < n; ++j) {
-				const uint8_t *payload;
-				if (j < k) {
-					// data shard j = payload bytes [j*S, (j+1)*S) zero-extended
-					size_t lo = (size_t)j * S, hi = std::min(len[b], lo + S);
-					if (hi >= lo + S) {
-						payload = data[b] + lo;
-					} else {
-						std::fill(last.begin(), last.end(), 0);
-						if (hi > lo)
-							std::memcpy(last.data(), data[b] + lo, hi - lo);
-						payload = last.data();
-					}
-				} else {
-					payload = pp[i] + (size_t)(j - k) * S;
-				}
-				if (store_shard(mg, who[j], h, j, payload, S, len[b], is_z[b] != 0, sums.data() + (i * n + j) * 32) == 0) {
-					++ok;
-					std::lock_guard<std::mutex> lk(mg->mu);
-					mg->metrics[0] += S;
-				}
-			}
-			{
-				std::lock_guard<std::mutex> lk(mg->mu);
-				mg->metrics[4]++;
-			}
-			if (ok < mg->write_quorum) {
-				result = fail(GBM_E_QUORUM, "Could not reach quorum of " + std::to_string(mg->write_quorum) + ". " +
-								    std::to_string(ok) + " of " + std::to_string(n) +
-								    " request succeeded");
-				if (rcs)
-					rcs[b] = GBM_E_QUORUM;
-			} else if (ok < n) {
-				mg->enqueue(h);  // stragglers are finished by resync
-			}
-		}
-	}
-	return result;
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	return ++m->layout_cur;
 }
 
-int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data,
-		       const size_t *len)
+int gbm_layout_trim(gbm_manager *m)
 {
-	return put_blocks_impl(mg, nb, hashes, data, len, nullptr);
-}
-
-int gbm_rpc_put_block(gbm_manager *m, const uint8_t hash[32], const uint8_t *data, size_t len)
-{
-	const uint8_t *d[1] = {data};
-	return gbm_rpc_put_blocks(m, 1, hash, d, &len);
-}
-
-int gbm_rpc_get_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, uint8_t *const *out, const size_t *cap,
-		       size_t *len_out, int *rcs)
-{
-	if (!mg || (nb && (!hashes || !out || !cap || !len_out || !rcs)))
-		return fail(GBM_E_INVALID_ARG, "NULL argument");
-	const int k = mg->k, n = mg->n;
-	std::vector<Hash> hs(nb);
-	for (size_t b = 0; b < nb; ++b)
-		hs[b].assign((const char *)hashes + 32 * b, 32);
-	std::vector<Gathered> g;
-	int grc = gather_many(mg, hs, k, g);  // shard checksums verified in batches (GPU when large)
-	if (grc)
-		return grc;
-	// blocks that need a decode, grouped by shard length (one device call per group)
-	std::map<size_t, std::vector<size_t>> need;
-	for (size_t b = 0; b < nb; ++b) {
-		len_out[b] = 0;
-		if (!g[b].have_meta || g[b].count < k) {
-			rcs[b] = GBM_E_MISSING_BLOCK;
-			continue;
-		}
-		rcs[b] = GBM_OK;
-		len_out[b] = g[b].meta.orig_len;
-		for (int j = 0; j < k; ++j)
-			if (g[b].shard[j].empty()) {
-				need[g[b].meta.shard_len].push_back(b);
-				break;
-			}
-	}
-	for (auto &kv : need) {
-		const size_t S = kv.first;
-		const std::vector<size_t> &ids = kv.second;
-		std::vector<const uint8_t *> sp(ids.size() * n, nullptr);
-		std::vector<uint8_t *> op(ids.size() * n, nullptr);
-		for (size_t i = 0; i < ids.size(); ++i) {
-			Gathered &gb = g[ids[i]];
-			for (int j = 0; j < n; ++j) {
-				if (!gb.shard[j].empty()) {
-					sp[i * n + j] = gb.shard[j].data();
-				} else if (j < k) {
-					gb.shard[j].resize(S);
-					op[i * n + j] = gb.shard[j].data();
-				}
-			}
-		}
-		int rc = gec_reconstruct_batch(mg->codec, ids.size(), sp.data(), op.data(), S, /*data_only=*/1);
-		if (rc)
-			return ec_fail(rc, "gec_reconstruct_batch");
-		std::lock_guard<std::mutex> lk(mg->mu);
-		mg->metrics[3] += ids.size();
-	}
-	// assemble, then check every block's content against its name (DataBlock::verify,
-	// block.rs:69-77) -- all block hashes in one batch.  Plain blocks are assembled straight
-	// into the caller's buffer and hashed from there (on CORRUPT_DATA its contents are
-	// unspecified); only compressed blocks need an intermediate for the zstd frame.
-	std::vector<const uint8_t *> ptrs;
-	std::vector<size_t> lens, idx;
-	auto assemble = [&](size_t b, uint8_t *dst) {
-		const size_t L = g[b].meta.orig_len, S = g[b].meta.shard_len;
-		for (int j = 0; j < k; ++j) {
-			size_t lo = (size_t)j * S;
-			if (lo >= L)
-				break;
-			std::memcpy(dst + lo, g[b].shard[j].data(), std::min(S, L - lo));
-		}
-	};
-	for (size_t b = 0; b < nb; ++b) {
-		if (rcs[b] != GBM_OK)
-			continue;
-		const size_t L = g[b].meta.orig_len, S = g[b].meta.shard_len;
-		if (L > (size_t)k * S) {
-			rcs[b] = GBM_E_CORRUPT_DATA;
-			continue;
-		}
-		if (g[b].meta.compressed) {
-			// DataBlock::verify for Compressed = "the zstd stream decodes" (frame checksum)
-			std::vector<uint8_t> frame(L), plain;
-			assemble(b, frame.data());
-			if (!zstd().decode(frame.data(), L, plain)) {
-				rcs[b] = GBM_E_CORRUPT_DATA;
-				continue;
-			}
-			len_out[b] = plain.size();
-			if (cap[b] < plain.size()) {
-				rcs[b] = GBM_E_BUFFER_TOO_SMALL;
-				continue;
-			}
-			std::memcpy(out[b], plain.data(), plain.size());
-			std::lock_guard<std::mutex> lk(mg->mu);
-			mg->metrics[5]++;
-			continue;
-		}
-		if (cap[b] < L) {
-			rcs[b] = GBM_E_BUFFER_TOO_SMALL;
-			continue;
-		}
-		assemble(b, out[b]);
-		ptrs.push_back(out[b]);
-		lens.push_back(L);
-		idx.push_back(b);
-	}
-	std::vector<uint8_t> sums;
-	int hrc = hash_many(mg, ptrs, lens, sums);
-	if (hrc)
-		return hrc;
-	for (size_t i = 0; i < idx.size(); ++i) {
-		const size_t b = idx[i];
-		if (std::memcmp(sums.data() + 32 * i, hashes + 32 * b, 32) != 0) {
-			rcs[b] = GBM_E_CORRUPT_DATA;
-			continue;
-		}
-		std::lock_guard<std::mutex> lk(mg->mu);
-		mg->metrics[5]++;
-	}
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	m->layout_oldest = m->layout_cur.load();
 	return GBM_OK;
 }
 
-int gbm_rpc_get_block(gbm_manager *m, const uint8_t hash[32], uint8_t *out, size_t cap, size_t *len_out)
+int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data, const size_t *len,
+		       const uint8_t *prevent_compression, const gbm_order_tag *order_tags)
+{
+	try {
+		return put_blocks_impl(mg, nb, hashes, data, len, prevent_compression, order_tags, nullptr);
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("rpc_put_blocks: ") + e.what());
+	}
+}
+
+int gbm_rpc_put_block(gbm_manager *m, const uint8_t hash[32], const uint8_t *data, size_t len, int prevent_compression,
+		      const gbm_order_tag *order_tag)
+{
+	const uint8_t *d[1] = {data};
+	const uint8_t pc = prevent_compression ? 1 : 0;
+	return gbm_rpc_put_blocks(m, 1, hash, d, &len, &pc, order_tag);
+}
+
+int gbm_rpc_get_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *order_tags, uint8_t *const *out,
+		       const size_t *cap, size_t *len_out, int *rcs)
+{
+	try {
+		return get_blocks_impl(mg, nb, hashes, order_tags, out, cap, len_out, rcs, false, nullptr);
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("rpc_get_blocks: ") + e.what());
+	}
+}
+
+int gbm_rpc_get_block(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, uint8_t *out, size_t cap,
+		      size_t *len_out)
 {
 	if (!len_out)
 		return fail(GBM_E_INVALID_ARG, "NULL len_out");
 	uint8_t *o[1] = {out};
 	int rc1 = GBM_OK;
-	int rc = gbm_rpc_get_blocks(m, 1, hash, o, &cap, len_out, &rc1);
+	int rc = gbm_rpc_get_blocks(m, 1, hash, order_tag, o, &cap, len_out, &rc1);
+	return rc ? rc : one_block_rc(rc1);
+}
+
+int gbm_rpc_get_raw_block(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag,
+			  gbm_data_block_header *header_out, uint8_t *out, size_t cap, size_t *len_out)
+{
+	if (!len_out || !header_out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	uint8_t *o[1] = {out};
+	int rc1 = GBM_OK;
+	int rc;
+	try {
+		rc = get_blocks_impl(m, 1, hash, order_tag, o, &cap, len_out, &rc1, true, header_out);
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("rpc_get_raw_block: ") + e.what());
+	}
+	return rc ? rc : one_block_rc(rc1);
+}
+
+static int stream_out(const uint8_t *p, size_t len, size_t chunk_bytes, gbm_chunk_fn sink, void *ctx)
+{
+	const size_t ch = chunk_bytes ? chunk_bytes : 65536;
+	for (size_t off = 0; off < len; off += ch)
+		if (sink(ctx, p + off, std::min(ch, len - off)) != 0)
+			return fail(GBM_E_ABORTED, "the stream's consumer stopped");
+	return GBM_OK;
+}
+
+static int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, gbm_data_block_header *hdr,
+			 size_t chunk_bytes, gbm_chunk_fn sink, void *ctx, bool raw)
+{
+	if (!m || !hash || !sink)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	// the shards have to be complete before any byte can be trusted (checksums, decode), so the block is
+	// gathered first and then handed out in order; the size is learnt from a first, zero-capacity call
+	size_t len = 0, cap = 0;
+	int rc1 = GBM_OK;
+	uint8_t *none[1] = {nullptr};
+	gbm_data_block_header h0;
+	int rc = get_blocks_impl(m, 1, hash, order_tag, none, &cap, &len, &rc1, raw, &h0);
 	if (rc)
 		return rc;
-	switch (rc1) {
-	case GBM_E_MISSING_BLOCK: return fail(rc1, "Missing block: no node returned a valid block");
-	case GBM_E_CORRUPT_DATA: return fail(rc1, "Corrupt data: does not match hash");
-	case GBM_E_BUFFER_TOO_SMALL: return fail(rc1, "output buffer too small");
-	default: return rc1;
+	if (rc1 != GBM_OK && rc1 != GBM_E_BUFFER_TOO_SMALL)
+		return one_block_rc(rc1);
+	std::vector<uint8_t> buf(len);
+	uint8_t *o[1] = {buf.data()};
+	cap = len;
+	rc = get_blocks_impl(m, 1, hash, order_tag, o, &cap, &len, &rc1, raw, &h0);
+	if (rc)
+		return rc;
+	if (rc1 != GBM_OK)
+		return one_block_rc(rc1);
+	if (hdr)
+		*hdr = h0;
+	return stream_out(buf.data(), len, chunk_bytes, sink, ctx);
+}
+
+int gbm_rpc_get_block_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, size_t chunk_bytes,
+				gbm_chunk_fn sink, void *ctx)
+{
+	try {
+		return get_streaming(m, hash, order_tag, nullptr, chunk_bytes, sink, ctx, false);
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("rpc_get_block_streaming: ") + e.what());
+	}
+}
+
+int gbm_rpc_get_raw_block_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag,
+				    gbm_data_block_header *header_out, size_t chunk_bytes, gbm_chunk_fn sink, void *ctx)
+{
+	if (!header_out)
+		return fail(GBM_E_INVALID_ARG, "NULL header_out");
+	try {
+		return get_streaming(m, hash, order_tag, header_out, chunk_bytes, sink, ctx, true);
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("rpc_get_raw_block_streaming: ") + e.what());
 	}
 }
 
@@ -883,9 +1741,19 @@ int gbm_block_incref(gbm_manager *m, const uint8_t hash[32])
 	if (!m || !hash)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
 	Hash h((const char *)hash, 32);
-	std::lock_guard<std::mutex> lk(m->mu);
-	if (++m->rc[h] == 1)
-		m->resync_queue.push_back(h);  // presence check later (manager.rs:452-475)
+	bool was_zero;
+	{
+		gbm_manager::RcStripe &s = m->rc_of(h);
+		std::lock_guard<std::mutex> lk(s.mu);
+		RcEntry &e = s.map[h];
+		was_zero = e.is_zero();
+		e.v = e.kind == RcEntry::Present ? e.v + 1 : 1;
+		e.kind = RcEntry::Present;
+	}
+	// "there is normally a node that is responsible for sending us the data of the block.  However that
+	// operation may fail, so in all cases we add the block here to the todo list" (manager.rs:452-475)
+	if (was_zero)
+		m->put_to_resync(h, m->incref_delay_ms.load());
 	return GBM_OK;
 }
 
@@ -894,76 +1762,125 @@ int gbm_block_decref(gbm_manager *m, const uint8_t hash[32])
 	if (!m || !hash)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
 	Hash h((const char *)hash, 32);
-	std::lock_guard<std::mutex> lk(m->mu);
-	uint64_t &c = m->rc[h];
-	if (c > 0)
-		--c;
-	if (c == 0)
-		m->resync_queue.push_back(h);
+	bool deletable = false;
+	{
+		gbm_manager::RcStripe &s = m->rc_of(h);
+		std::lock_guard<std::mutex> lk(s.mu);
+		auto it = s.map.find(h);
+		if (it != s.map.end() && it->second.kind == RcEntry::Present) {
+			if (it->second.v > 1) {
+				--it->second.v;
+			} else {
+				it->second.kind = RcEntry::Deletable;
+				it->second.v = m->now() + m->gc_delay_ms.load();
+				deletable = true;
+			}
+		}  // Deletable / Absent stay what they are (RcEntry::decrement)
+	}
+	if (deletable)  // handled in the resync loop after the GC delay has passed (manager.rs:478-500)
+		m->put_to_resync(h, m->gc_delay_ms.load() + 10000);
 	return GBM_OK;
+}
+
+int gbm_block_rc(gbm_manager *m, const uint8_t hash[32], uint64_t out[3])
+{
+	if (!m || !hash || !out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	RcEntry e = m->get_rc(Hash((const char *)hash, 32));
+	out[0] = e.kind == RcEntry::Present ? e.v : 0;
+	out[1] = e.kind;
+	out[2] = e.kind == RcEntry::Deletable ? e.v : 0;
+	return GBM_OK;
+}
+
+int gbm_put_to_resync(gbm_manager *m, const uint8_t hash[32], uint64_t delay_ms)
+{
+	if (!m || !hash)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	m->put_to_resync(Hash((const char *)hash, 32), delay_ms);
+	return GBM_OK;
+}
+
+// One pass of resync_iter over everything that is due (resync.rs:255-337).
+int gbm_resync_run(gbm_manager *mg, size_t max_blocks, uint64_t stats[8])
+{
+	if (!mg)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	ResyncStats st;
+	std::vector<ResyncTask> tasks;
+	std::vector<std::pair<uint64_t, Hash>> taken;
+	const uint64_t now = mg->now(), base = mg->retry_delay_ms.load();
+	{
+		std::lock_guard<std::mutex> g(mg->rs_mu);
+		std::set<Hash> seen;
+		for (auto it = mg->rs_queue.begin(); it != mg->rs_queue.end() && it->first <= now;) {
+			if (max_blocks && taken.size() >= max_blocks)
+				break;
+			const Hash &h = it->second;
+			auto ec = mg->rs_errors.find(h);
+			if (ec != mg->rs_errors.end() && now < ec->second.next_try(base)) {
+				// still inside the back-off: keep the entry, at the time it may be retried
+				mg->rs_queue.insert({ec->second.next_try(base), h});
+				it = mg->rs_queue.erase(it);
+				++st.skipped;
+				continue;
+			}
+			if (seen.insert(h).second)
+				taken.push_back(*it);
+			it = mg->rs_queue.erase(it);
+		}
+	}
+	st.taken = taken.size();
+	tasks.resize(taken.size());
+	for (size_t i = 0; i < taken.size(); ++i)
+		tasks[i].h = taken[i].second;
+	int result = GBM_OK;
+	try {
+		resync_blocks(mg, tasks, st);
+	} catch (const std::exception &e) {
+		for (auto &t : tasks)
+			if (t.error.empty())
+				t.error = e.what();
+	}
+	{
+		std::lock_guard<std::mutex> g(mg->rs_mu);
+		for (auto &t : tasks) {
+			if (t.error.empty()) {
+				mg->rs_errors.erase(t.h);
+				++st.ok;
+				continue;
+			}
+			++st.errors;
+			result = fail(t.error.rfind("Missing block", 0) == 0 ? GBM_E_MISSING_BLOCK : GBM_E_IO, t.error);
+			ErrorCounter &ec = mg->rs_errors[t.h];
+			ec.errors += 1;
+			ec.last_try = now + 1;
+			mg->rs_queue.insert({ec.next_try(base), t.h});
+		}
+	}
+	if (stats) {
+		const uint64_t v[8] = {st.taken, st.ok, st.errors, st.skipped, st.rebuilt, st.deleted, st.offloaded, st.device_calls};
+		std::copy(v, v + 8, stats);
+	}
+	return result;
 }
 
 int gbm_resync_block(gbm_manager *mg, const uint8_t hash[32], int *changed)
 {
 	if (!mg || !hash)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
-	Hash h((const char *)hash, 32);
-	std::vector<int> who;
-	mg->nodes_of(h, who);
-	int nchanged = 0;
-	uint64_t refs;
-	{
-		std::lock_guard<std::mutex> lk(mg->mu);
-		auto it = mg->rc.find(h);
-		refs = it == mg->rc.end() ? 0 : it->second;
-	}
-	if (refs == 0) {  // unneeded: delete everywhere (resync.rs:369-458, without the offload step)
-		for (int j = 0; j < mg->n; ++j) {
-			Node &nd = *mg->nodes[who[j]];
-			std::vector<uint8_t> raw;
-			if (!nd.down && nd.get(h, j, raw)) {
-				nd.del(h, j);
-				++nchanged;
-			}
-		}
-		if (changed)
-			*changed = nchanged;
-		return GBM_OK;
-	}
-	Gathered g;
-	gather(mg, h, mg->n, g);
-	if (!g.have_meta || g.count < mg->k)
-		return fail(GBM_E_MISSING_BLOCK, "Missing block: fewer than k shards reachable");
-	if (g.count < mg->n) {  // needed but absent somewhere (resync.rs:460-500): rebuild and rewrite
-		const size_t S = g.meta.shard_len;
-		std::vector<const uint8_t *> sp(mg->n, nullptr);
-		std::vector<uint8_t *> op(mg->n, nullptr);
-		for (int j = 0; j < mg->n; ++j) {
-			if (!g.shard[j].empty()) {
-				sp[j] = g.shard[j].data();
-			} else {
-				g.shard[j].resize(S);
-				op[j] = g.shard[j].data();
-			}
-		}
-		int rc = gec_reconstruct_batch(mg->codec, 1, sp.data(), op.data(), S, 0);
-		if (rc)
-			return ec_fail(rc, "gec_reconstruct_batch");
-		{
-			std::lock_guard<std::mutex> lk(mg->mu);
-			mg->metrics[3]++;
-		}
-		for (int j = 0; j < mg->n; ++j) {
-			if (sp[j])
-				continue;
-			if (store_shard(mg, who[j], h, j, g.shard[j].data(), S, g.meta.orig_len, g.meta.compressed != 0) == 0)
-				++nchanged;
-			else
-				mg->enqueue(h);
-		}
+	std::vector<ResyncTask> tasks(1);
+	tasks[0].h.assign((const char *)hash, 32);
+	ResyncStats st;
+	try {
+		resync_blocks(mg, tasks, st);
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("resync_block: ") + e.what());
 	}
 	if (changed)
-		*changed = nchanged;
+		*changed = tasks[0].changed;
+	if (!tasks[0].error.empty())
+		return fail(tasks[0].error.rfind("Missing block", 0) == 0 ? GBM_E_MISSING_BLOCK : GBM_E_IO, tasks[0].error);
 	return GBM_OK;
 }
 
@@ -971,20 +1888,15 @@ int gbm_resync_all(gbm_manager *mg, int *changed)
 {
 	if (!mg)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
-	std::vector<Hash> todo;
-	{
-		std::lock_guard<std::mutex> lk(mg->mu);
-		todo.swap(mg->resync_queue);
-	}
-	std::sort(todo.begin(), todo.end());
-	todo.erase(std::unique(todo.begin(), todo.end()), todo.end());
 	int total = 0, result = GBM_OK;
-	for (const Hash &h : todo) {
-		int c = 0;
-		int rc = gbm_resync_block(mg, (const uint8_t *)h.data(), &c);
+	for (int round = 0; round < 64; ++round) {
+		uint64_t st[8];
+		int rc = gbm_resync_run(mg, 0, st);
 		if (rc)
 			result = rc;
-		total += c;
+		total += (int)(st[4] + st[5] + st[6]);
+		if (st[0] == 0)
+			break;
 	}
 	if (changed)
 		*changed = total;
@@ -995,39 +1907,96 @@ size_t gbm_resync_queue_len(const gbm_manager *m)
 {
 	if (!m)
 		return 0;
-	std::lock_guard<std::mutex> lk(const_cast<gbm_manager *>(m)->mu);
-	return m->resync_queue.size();
+	std::lock_guard<std::mutex> lk(m->rs_mu);
+	return m->rs_queue.size();
+}
+
+size_t gbm_resync_errors_len(const gbm_manager *m)
+{
+	if (!m)
+		return 0;
+	std::lock_guard<std::mutex> lk(m->rs_mu);
+	return m->rs_errors.size();
+}
+
+int gbm_resync_worker_start(gbm_manager *m)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	std::lock_guard<std::mutex> g(m->rs_mu);
+	if (m->rs_worker.joinable())
+		return GBM_OK;
+	m->rs_worker_stop = false;
+	m->rs_worker = std::thread([m] {
+		std::unique_lock<std::mutex> lk(m->rs_mu);
+		while (!m->rs_worker_stop) {
+			const uint64_t now = m->now();
+			if (!m->rs_queue.empty() && m->rs_queue.begin()->first <= now) {
+				lk.unlock();
+				(void)gbm_resync_run(m, 1024, nullptr);
+				lk.lock();
+				continue;
+			}
+			// idle until the first entry is due, something is queued, or 10 s pass (resync.rs:325-336)
+			uint64_t wait_ms = 10000;
+			if (!m->rs_queue.empty())
+				wait_ms = std::min<uint64_t>(wait_ms, m->rs_queue.begin()->first - now);
+			m->rs_cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(std::max<uint64_t>(wait_ms, 1)));
+		}
+	});
+	return GBM_OK;
+}
+
+int gbm_resync_worker_stop(gbm_manager *m)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	std::thread t;
+	{
+		std::lock_guard<std::mutex> g(m->rs_mu);
+		if (!m->rs_worker.joinable())
+			return GBM_OK;
+		m->rs_worker_stop = true;
+		t = std::move(m->rs_worker);
+	}
+	m->rs_cv.notify_all();
+	t.join();
+	return GBM_OK;
 }
 
 int gbm_scrub(gbm_manager *mg, size_t nb, const uint8_t *hashes, uint8_t *bad_out)
 {
 	if (!mg || (nb && (!hashes || !bad_out)))
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
-	std::vector<Hash> hs(nb);
-	for (size_t b = 0; b < nb; ++b)
-		hs[b].assign((const char *)hashes + 32 * b, 32);
-	std::vector<Gathered> g;
-	int grc = gather_many(mg, hs, mg->n, g);
-	if (grc)
-		return grc;
-	std::map<size_t, std::vector<size_t>> by_len;
-	for (size_t b = 0; b < nb; ++b) {
-		bad_out[b] = g[b].count == mg->n ? 0 : 1;
-		if (!bad_out[b])
-			by_len[g[b].meta.shard_len].push_back(b);
-	}
-	for (auto &kv : by_len) {
-		const std::vector<size_t> &ids = kv.second;
-		std::vector<const uint8_t *> sp(ids.size() * mg->n);
-		for (size_t i = 0; i < ids.size(); ++i)
-			for (int j = 0; j < mg->n; ++j)
-				sp[i * mg->n + j] = g[ids[i]].shard[j].data();
-		std::vector<uint8_t> ok(ids.size());
-		int rc = gec_verify_batch(mg->codec, ids.size(), sp.data(), kv.first, ok.data());
-		if (rc)
-			return ec_fail(rc, "gec_verify_batch");
-		for (size_t i = 0; i < ids.size(); ++i)
-			bad_out[ids[i]] = ok[i] ? 0 : 1;
+	try {
+		std::vector<Hash> hs(nb);
+		for (size_t b = 0; b < nb; ++b)
+			hs[b].assign((const char *)hashes + 32 * b, 32);
+		std::vector<Gathered> g;
+		int grc = gather_many(mg, hs, nullptr, mg->n, g);
+		if (grc)
+			return grc;
+		std::map<size_t, std::vector<size_t>> by_len;
+		for (size_t b = 0; b < nb; ++b) {
+			bad_out[b] = g[b].count == mg->n ? 0 : 1;
+			if (!bad_out[b])
+				by_len[g[b].meta.shard_len].push_back(b);
+		}
+		for (auto &kv : by_len) {
+			const std::vector<size_t> &ids = kv.second;
+			std::vector<const uint8_t *> sp(ids.size() * mg->n);
+			for (size_t i = 0; i < ids.size(); ++i)
+				for (int j = 0; j < mg->n; ++j)
+					sp[i * mg->n + j] = g[ids[i]].shard[j].data();
+			std::vector<uint8_t> ok(ids.size());
+			int rc = gec_verify_batch(mg->codec, ids.size(), sp.data(), kv.first, ok.data());
+			if (rc)
+				return ec_fail(rc, "gec_verify_batch");
+			for (size_t i = 0; i < ids.size(); ++i)
+				bad_out[ids[i]] = ok[i] ? 0 : 1;
+		}
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("scrub: ") + e.what());
 	}
 	return GBM_OK;
 }
@@ -1044,8 +2013,7 @@ int gbm_node_has_shard(gbm_manager *m, int node, const uint8_t hash[32], int idx
 {
 	if (!m || node < 0 || node >= (int)m->nodes.size())
 		return 0;
-	std::vector<uint8_t> raw;
-	return m->nodes[node]->get(Hash((const char *)hash, 32), idx, raw) ? 1 : 0;
+	return m->nodes[node]->has(Hash((const char *)hash, 32), idx) ? 1 : 0;
 }
 
 int gbm_node_delete_shard(gbm_manager *m, int node, const uint8_t hash[32], int idx)
@@ -1062,17 +2030,39 @@ int gbm_node_corrupt_shard(gbm_manager *m, int node, const uint8_t hash[32], int
 	if (!m || node < 0 || node >= (int)m->nodes.size())
 		return fail(GBM_E_INVALID_ARG, "bad node index");
 	Hash h((const char *)hash, 32);
-	std::vector<uint8_t> raw;
-	if (!m->nodes[node]->get(h, idx, raw) || raw.size() <= GBM_SHARD_HEADER_SIZE + offset)
+	Shard s;
+	if (!m->nodes[node]->get(h, idx, s) || s.data.n <= offset)
 		return fail(GBM_E_IO, "no such shard / offset");
-	raw[GBM_SHARD_HEADER_SIZE + offset] ^= mask;
-	if (fix_checksum) {
-		ShardHeader hd;
-		hd.unpack(raw.data(), raw.size());
-		blake2sum(raw.data() + GBM_SHARD_HEADER_SIZE, raw.size() - GBM_SHARD_HEADER_SIZE, hd.checksum);
-		hd.pack(raw.data());
+	try {
+		// shard buffers are shared (a data shard is a slice of its block's buffer): corrupt a private copy
+		Bytes copy = m->bufs->get(s.data.n);
+		std::memcpy(copy.mut(), s.data.data(), s.data.n);
+		copy.mut()[offset] ^= mask;
+		s.data = copy;
+	} catch (const std::bad_alloc &) {
+		return fail(GBM_E_IO, "out of memory");
 	}
-	return m->nodes[node]->put(h, idx, std::move(raw)) ? GBM_OK : fail(GBM_E_IO, "rewrite failed");
+	if (fix_checksum)
+		blake2sum(s.data.data(), s.data.n, s.hd.checksum);
+	return m->nodes[node]->put(h, idx, s) ? GBM_OK : fail(GBM_E_IO, "rewrite failed");
+}
+
+int gbm_node_shard_header(gbm_manager *m, int node, const uint8_t hash[32], int idx, uint8_t out[GBM_SHARD_HEADER_SIZE])
+{
+	if (!m || node < 0 || node >= (int)m->nodes.size() || !hash || !out)
+		return fail(GBM_E_INVALID_ARG, "bad argument");
+	Shard s;
+	if (!m->nodes[node]->get(Hash((const char *)hash, 32), idx, s))
+		return fail(GBM_E_IO, "no such shard");
+	s.hd.pack(out);
+	return GBM_OK;
+}
+
+uint64_t gbm_node_order_violations(gbm_manager *m, int node)
+{
+	if (!m || node < 0 || node >= (int)m->nodes.size())
+		return 0;
+	return m->nodes[node]->order_violations.load();
 }
 
 int gbm_set_compression_level(gbm_manager *m, int enabled, int level)
@@ -1081,8 +2071,8 @@ int gbm_set_compression_level(gbm_manager *m, int enabled, int level)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
 	if (enabled && !zstd().ok)
 		return fail(GBM_E_IO, "libzstd.so.1 not available");
-	m->compress = enabled != 0;
 	m->compression_level = level;
+	m->compress = enabled != 0;
 	return GBM_OK;
 }
 
@@ -1096,6 +2086,9 @@ struct gbm_batcher {
 	struct Item {
 		const uint8_t *hash, *data;
 		size_t len;
+		uint8_t prevent_compression = 0;
+		bool has_tag = false;
+		gbm_order_tag tag{0, 0};
 		int rc = GBM_OK;
 		bool done = false;
 	};
@@ -1137,20 +2130,34 @@ struct gbm_batcher {
 			}
 			lk.unlock();
 			const size_t nb = batch.size();
-			std::vector<uint8_t> hashes(nb * 32);
+			std::vector<uint8_t> hashes(nb * 32), pc(nb);
 			std::vector<const uint8_t *> data(nb);
 			std::vector<size_t> lens(nb);
+			std::vector<gbm_order_tag> tags(nb);
 			std::vector<int> rcs(nb, GBM_OK);
+			bool any_tag = false;
+			static const uint8_t kEmpty = 0;  // a zero-length block may come with a NULL pointer
 			for (size_t i = 0; i < nb; ++i) {
 				std::memcpy(hashes.data() + 32 * i, batch[i]->hash, 32);
-				data[i] = batch[i]->data;
+				data[i] = batch[i]->data ? batch[i]->data : &kEmpty;
 				lens[i] = batch[i]->len;
+				pc[i] = batch[i]->prevent_compression;
+				// untagged blocks sort after tagged ones of the same batch; their relative order is free
+				tags[i] = batch[i]->has_tag ? batch[i]->tag : gbm_order_tag{~0ull, i};
+				any_tag = any_tag || batch[i]->has_tag;
 			}
-			int rc = put_blocks_impl(mg, nb, hashes.data(), data.data(), lens.data(), rcs.data());
+			int rc;
+			try {
+				rc = put_blocks_impl(mg, nb, hashes.data(), data.data(), lens.data(), pc.data(), any_tag ? tags.data() : nullptr,
+						     rcs.data());
+			} catch (const std::exception &) {
+				rc = GBM_E_IO;
+				std::fill(rcs.begin(), rcs.end(), GBM_E_IO);
+			}
+			(void)rc;  // per-block results are in rcs (a whole-batch failure marks every block that was not stored)
 			lk.lock();
 			for (size_t i = 0; i < nb; ++i) {
-				// a whole-batch failure (device error) hits every block of the batch
-				batch[i]->rc = (rc != GBM_OK && rc != GBM_E_QUORUM) ? rc : rcs[i];
+				batch[i]->rc = rcs[i];
 				batch[i]->done = true;
 				ram_in_use_kb -= batch[i]->len / 1024;  // the permit is dropped once all sends finished
 			}
@@ -1190,7 +2197,8 @@ void gbm_batcher_destroy(gbm_batcher *b)
 	delete b;
 }
 
-int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t *data, size_t len)
+int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t *data, size_t len, int prevent_compression,
+			  const gbm_order_tag *order_tag)
 {
 	if (!b || !hash || (!data && len))
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
@@ -1198,6 +2206,11 @@ int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t 
 	it.hash = hash;
 	it.data = data;
 	it.len = len;
+	it.prevent_compression = prevent_compression ? 1 : 0;
+	if (order_tag) {
+		it.has_tag = true;
+		it.tag = *order_tag;
+	}
 	std::unique_lock<std::mutex> lk(b->mu);
 	// acquire len/1024 permits; a block larger than the whole budget could never be sent (Garage's
 	// acquire_many would wait forever): refuse it instead
@@ -1239,20 +2252,14 @@ int gbm_batcher_stats(gbm_batcher *b, uint64_t out[3])
 	return GBM_OK;
 }
 
-uint64_t gbm_gpu_hashed(const gbm_manager *m)
-{
-	if (!m)
-		return 0;
-	std::lock_guard<std::mutex> lk(const_cast<gbm_manager *>(m)->mu);
-	return m->gpu_hashed;
-}
+uint64_t gbm_gpu_hashed(const gbm_manager *m) { return m ? m->gpu_hashed.load() : 0; }
 
 int gbm_metrics(const gbm_manager *m, uint64_t out[6])
 {
 	if (!m || !out)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
-	std::lock_guard<std::mutex> lk(const_cast<gbm_manager *>(m)->mu);
-	std::copy(m->metrics, m->metrics + 6, out);
+	for (int i = 0; i < 6; ++i)
+		out[i] = m->metrics[i].load();
 	return GBM_OK;
 }
 

@@ -1732,33 +1732,50 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 	if (S % 64)
 		return fail(GEC_E_INCORRECT_SHARD_SIZE, "S must be a multiple of 64");
 	const size_t k = c->k, n = c->k + c->m;
-	// bucket blocks by erasure pattern: one decode plan per bucket, one launch per chunk
+	// bucket blocks by erasure pattern AND by which of the missing shards the caller wants back
+	// (out entry non-NULL; with data_only parity is never wanted): one decode plan per bucket, one
+	// launch per chunk, only the wanted rows computed.  key[j]: 1 present, 0 missing+wanted, 2 missing+unwanted
 	std::map<std::string, std::vector<size_t>> buckets;
 	for (size_t b = 0; b < nblocks; ++b) {
 		std::string key(n, 0);
-		size_t npresent = 0;
+		size_t npresent = 0, nwanted = 0;
 		for (size_t j = 0; j < n; ++j) {
-			key[j] = shards[b * n + j] ? 1 : 0;
-			npresent += key[j];
+			if (shards[b * n + j]) {
+				key[j] = 1;
+				++npresent;
+			} else if ((data_only && j >= k) || !out[b * n + j]) {
+				key[j] = 2;
+			} else {
+				++nwanted;
+			}
 		}
 		if (npresent < k)
 			return fail(GEC_E_TOO_FEW_PRESENT, "fewer than k shards present");
-		for (size_t j = 0; j < n; ++j)
-			if (!key[j] && !(data_only && j >= k) && !out[b * n + j])
-				return fail(GEC_E_INVALID_ARG, "NULL output for a missing shard");
-		if (npresent < n)
+		if (nwanted)
 			buckets[key].push_back(b);
 	}
 	CopyPool &pool = c->copy_pool();
 	for (auto &kv : buckets) {
 		const std::vector<size_t> &ids = kv.second;
-		const uint8_t *present = reinterpret_cast<const uint8_t *>(kv.first.data());
+		std::string pres(kv.first);
+		for (auto &ch : pres)
+			ch = ch == 1 ? 1 : 0;
 		// compact staging: only the k shards the decode reads go H2D (slots 0..k-1 of the
 		// staging stripe), only the rebuilt shards come back (slots k..k+nmiss-1)
-		std::shared_ptr<const Plan> plan;
-		int rc = get_plan(c, present, data_only != 0, plan);
+		std::shared_ptr<const Plan> full;
+		int rc = get_plan(c, reinterpret_cast<const uint8_t *>(pres.data()), false, full);
 		if (rc)
 			return rc;
+		auto sub = std::make_shared<Plan>();
+		sub->valid = full->valid;
+		for (size_t r = 0; r < full->missing.size(); ++r)
+			if (kv.first[full->missing[r]] == 0)
+				sub->missing.push_back(full->missing[r]);
+		sub->rows = gec::Matrix((int)sub->missing.size(), (int)k);
+		for (size_t r = 0, w = 0; r < full->missing.size(); ++r)
+			if (kv.first[full->missing[r]] == 0)
+				std::memcpy(&sub->rows.at((int)w++, 0), full->rows.row((int)r), k);
+		std::shared_ptr<const Plan> plan = sub;
 		const size_t nmiss = plan->missing.size();
 		if (nmiss == 0)
 			continue;

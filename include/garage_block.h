@@ -3,18 +3,24 @@
  * garage_block::BlockManager with erasure-coded shard fan-out, built on top of
  * libgarage_ec's C ABI (include/garage_ec.h).  SURVEY.md section 8 rows f1-f3.
  *
- * It mirrors, by name and behaviour:
- *   BlockManager::rpc_put_block          src/block/manager.rs:366-408
- *   BlockManager::rpc_get_block(_streaming) / rpc_get_raw_block   :243-363
- *   BlockManager::block_incref/decref    :452-500  (rc: src/block/rc.rs)
- *   BlockResyncManager::resync_block     src/block/resync.rs:354-503
- *   ScrubWorker verify                   src/block/repair.rs:438-490
- *   blake2sum (blake2b-512 truncated to 32 bytes)   src/util/data.rs:130-138
+ * It mirrors, by name, argument meaning and behaviour:
+ *   BlockManager::rpc_put_block(hash, data, prevent_compression, order_tag)   src/block/manager.rs:366-408
+ *   BlockManager::rpc_get_raw_block / rpc_get_raw_block_streaming             :243-274
+ *   BlockManager::rpc_get_block_streaming                                     :344-363
+ *   DataBlockHeader::{Plain, Compressed}                                      src/block/block.rs:12-22
+ *   BlockManager::block_incref / block_decref, RcEntry, BLOCK_GC_DELAY        :452-500, src/block/rc.rs
+ *   BlockResyncManager: put_to_resync, resync_iter, resync_block, ErrorCounter  src/block/resync.rs:170-503,604-648
+ *   BlockRpc::{GetBlock, PutBlock, NeedBlockQuery/Reply}                      src/block/manager.rs:54-73
+ *     -> ShardRpc::{GetShard, PutShard, NeedShardQuery/Reply} between the manager and its nodes
+ *   ScrubWorker verify                                                        src/block/repair.rs:438-490
+ *   blake2sum (blake2b-512 truncated to 32 bytes)                             src/util/data.rs:130-138
  * Storage nodes are in-process objects (memory- or directory-backed) -- the way
  * the reference tests multi-node logic on loopback (src/net/test.rs:15-118);
  * the network and the metadata tables are out of scope.  zstd (DataBlock::
  * from_buffer, src/block/block.rs:85-106) goes through the system's libzstd.so.1,
- * resolved at run time.
+ * resolved at run time.  The manager is thread-safe: per-hash striped locks like
+ * mutation_lock (src/block/manager.rs:679-689), nodes lock internally, and the bulk
+ * work (copies, fan-out, gathers) runs on an internal thread pool.
  */
 #ifndef GARAGE_BLOCK_H
 #define GARAGE_BLOCK_H
@@ -38,11 +44,28 @@ enum {
 	GBM_E_INVALID_ARG = -4,
 	GBM_E_EC = -5,            /* libgarage_ec returned an error; see gbm_last_error() */
 	GBM_E_IO = -6,
-	GBM_E_BUFFER_TOO_SMALL = -7
+	GBM_E_BUFFER_TOO_SMALL = -7,
+	GBM_E_ABORTED = -8        /* a streaming callback asked to stop */
 };
 
 #define GBM_INLINE_THRESHOLD 3072 /* src/block/manager.rs:46 */
 #define GBM_SHARD_HEADER_SIZE 64
+#define GBM_BLOCK_GC_DELAY_MS 600000ull      /* BLOCK_GC_DELAY, src/block/manager.rs:51 */
+#define GBM_RESYNC_RETRY_DELAY_MS 60000ull   /* RESYNC_RETRY_DELAY, src/block/resync.rs:37 */
+#define GBM_RESYNC_RETRY_MAX_BACKOFF_POWER 6 /* RESYNC_RETRY_DELAY_MAX_BACKOFF_POWER, :40 */
+
+/* OrderTag(stream, order) (src/net/message.rs:66-89): requests of one stream are handed to a node in
+ * `order` order.  NULL = None. */
+typedef struct {
+	uint64_t stream_id;
+	uint64_t order;
+} gbm_order_tag;
+
+/* DataBlockHeader (src/block/block.rs:12-22) */
+enum { GBM_HEADER_PLAIN = 0, GBM_HEADER_COMPRESSED = 1 };
+typedef struct {
+	int kind; /* GBM_HEADER_PLAIN / GBM_HEADER_COMPRESSED (one zstd frame) */
+} gbm_data_block_header;
 
 const char *gbm_last_error(void);
 
@@ -68,35 +91,78 @@ int gbm_set_compression_level(gbm_manager *m, int enabled, int level);
  * (write_block_inner, src/block/manager.rs:775-800).  No effect on in-memory nodes. */
 int gbm_set_data_fsync(gbm_manager *m, int enabled);
 
-/* nodes_out[k+m]: node index that stores shard j of this hash. */
+/* After decode, check a Plain block's content against its name (DataBlock::verify,
+ * src/block/block.rs:69-77).  On by default.  Every shard's own checksum is always verified --
+ * that is what replaces the serving node's verify of read_block_from (:577-609); this switch
+ * only controls the additional end-to-end pass over the assembled block. */
+int gbm_set_verify_block_hash(gbm_manager *m, int enabled);
+
+/* Worker threads of the manager's internal pool (copies, fan-out, gathers); default min(16, cores). */
+int gbm_set_threads(gbm_manager *m, int nthreads);
+
+/* BLOCK_GC_DELAY / RESYNC_RETRY_DELAY / the delay block_incref queues its presence check with
+ * (2 * rpc_timeout, src/block/manager.rs:466-475); any argument < 0 keeps the current value.
+ * gbm_clock_advance moves the manager's clock forward (tests: "ten minutes later"). */
+int gbm_set_timing(gbm_manager *m, int64_t gc_delay_ms, int64_t resync_retry_delay_ms, int64_t incref_check_delay_ms);
+int gbm_clock_advance(gbm_manager *m, uint64_t ms);
+
+/* nodes_out[k+m]: node index that stores shard j of this hash in the CURRENT layout version. */
 int gbm_storage_nodes_of(const gbm_manager *m, const uint8_t hash[32], int *nodes_out);
+/* A new cluster layout version: every hash's shards move to different nodes.  Reads look at the
+ * current version first, then at older ones (block_read_nodes_of, src/rpc/rpc_helper.rs:570-619);
+ * resync offloads misplaced shards to their new owners and deletes them locally
+ * (resync_block's offload branch, src/block/resync.rs:369-458).  Returns the new version. */
+int gbm_layout_update(gbm_manager *m);
+/* Forget versions older than the current one (after everything has been resynced). */
+int gbm_layout_trim(gbm_manager *m);
 
-/* Send block to nodes that should have it: shard j to nodes_of(hash)[j]. */
-int gbm_rpc_put_block(gbm_manager *m, const uint8_t hash[32], const uint8_t *data, size_t len);
-/* Coalesced form: ONE device encode for all n blocks (hashes = n*32 bytes). */
+/* ---------------------------------------------------------------- put */
+/* Send block to nodes that should have it: shard j to nodes_of(hash)[j].
+ * prevent_compression != 0: store Plain even when a compression level is configured (SSE-C blocks,
+ * src/api/s3/put.rs:576).  order_tag may be NULL. */
+int gbm_rpc_put_block(gbm_manager *m, const uint8_t hash[32], const uint8_t *data, size_t len,
+		      int prevent_compression, const gbm_order_tag *order_tag);
+/* Coalesced form: ONE device encode for all n blocks (hashes = n*32 bytes).
+ * prevent_compression: n flags or NULL (all 0); order_tags: n tags or NULL (all None). */
 int gbm_rpc_put_blocks(gbm_manager *m, size_t n, const uint8_t *hashes,
-		       const uint8_t *const *data, const size_t *len);
+		       const uint8_t *const *data, const size_t *len,
+		       const uint8_t *prevent_compression, const gbm_order_tag *order_tags);
 
-/* Gather >= k shards, reconstruct if a data shard is missing, check the
- * content against its name.  *len_out = block length (also on
- * GBM_E_BUFFER_TOO_SMALL). */
-int gbm_rpc_get_block(gbm_manager *m, const uint8_t hash[32], uint8_t *out, size_t cap, size_t *len_out);
+/* ---------------------------------------------------------------- get */
+/* rpc_get_block: gather >= k shards (each checked against its checksum), reconstruct if a data
+ * shard is missing, decompress if needed.  *len_out = block length (also on GBM_E_BUFFER_TOO_SMALL). */
+int gbm_rpc_get_block(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag,
+		      uint8_t *out, size_t cap, size_t *len_out);
 /* Batched: ONE device reconstruct for all blocks that need it.  out[i] has
- * cap[i] bytes; rc[i] receives the per-block result. */
-int gbm_rpc_get_blocks(gbm_manager *m, size_t n, const uint8_t *hashes, uint8_t *const *out,
-		       const size_t *cap, size_t *len_out, int *rc);
+ * cap[i] bytes; rc[i] receives the per-block result.  order_tags: n tags or NULL. */
+int gbm_rpc_get_blocks(gbm_manager *m, size_t n, const uint8_t *hashes, const gbm_order_tag *order_tags,
+		       uint8_t *const *out, const size_t *cap, size_t *len_out, int *rc);
+/* rpc_get_raw_block: the DataBlock as stored -- header + bytes, NOT decompressed. */
+int gbm_rpc_get_raw_block(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag,
+			  gbm_data_block_header *header_out, uint8_t *out, size_t cap, size_t *len_out);
+/* Streaming forms: the block is handed to `sink` in chunks of at most chunk_bytes (0 = 64 KiB), in
+ * order; a non-zero return from the sink stops the stream (GBM_E_ABORTED).
+ * rpc_get_block_streaming yields the plain bytes (zstd-decoded when the block is stored Compressed),
+ * rpc_get_raw_block_streaming yields the stored bytes and reports the header first. */
+typedef int (*gbm_chunk_fn)(void *ctx, const uint8_t *chunk, size_t len);
+int gbm_rpc_get_block_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag,
+				size_t chunk_bytes, gbm_chunk_fn sink, void *ctx);
+int gbm_rpc_get_raw_block_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag,
+				    gbm_data_block_header *header_out, size_t chunk_bytes,
+				    gbm_chunk_fn sink, void *ctx);
 
-/* Coalescing queue in front of the device: Garage keeps <= 3 block puts in flight
- * per PutObject (PUT_BLOCKS_MAX_PARALLEL, src/api/s3/put.rs:42,486-511) across many
- * concurrent requests.  gbm_batcher_put_block is thread-safe and blocks its caller
- * (like `rpc_put_block(..).await`) until the batch that contains the block has been
- * encoded and fanned out; one worker thread turns everything queued within
+/* ------------------------------------------------------- coalescing queue */
+/* Garage keeps <= 3 block puts in flight per PutObject (PUT_BLOCKS_MAX_PARALLEL,
+ * src/api/s3/put.rs:42,486-511) across many concurrent requests.  gbm_batcher_put_block is
+ * thread-safe and blocks its caller (like `rpc_put_block(..).await`) until the batch that contains
+ * the block has been encoded and fanned out; one worker thread turns everything queued within
  * max_wait_us (or max_blocks) into ONE device call.  Returns that block's own
  * result (GBM_OK / GBM_E_QUORUM / a device error). */
 typedef struct gbm_batcher gbm_batcher;
 int gbm_batcher_create(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, gbm_batcher **out);
 void gbm_batcher_destroy(gbm_batcher *b);
-int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t *data, size_t len);
+int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t *data, size_t len,
+			  int prevent_compression, const gbm_order_tag *order_tag);
 /* Config.block_ram_buffer_max (src/util/config.rs:74-76,276-278; default 256 MiB): bytes of blocks that
  * may be on their way to the storage nodes at once.  gbm_batcher_put_block takes len/1024 permits before it
  * queues the block and returns them when its batch has been fanned out (buffer_kb_semaphore,
@@ -105,14 +171,38 @@ int gbm_batcher_set_ram_buffer_max(gbm_batcher *b, size_t bytes);
 /* out = { device batches issued, blocks put, largest batch } */
 int gbm_batcher_stats(gbm_batcher *b, uint64_t out[3]);
 
+/* ------------------------------------------------------------- refcounts */
+/* block_incref: RcEntry::increment; when the count was zero a presence check is queued
+ * 2*rpc_timeout later.  block_decref: at zero the entry becomes Deletable{now + BLOCK_GC_DELAY} and a
+ * resync is queued BLOCK_GC_DELAY + 10 s later -- nothing is deleted before that. */
 int gbm_block_incref(gbm_manager *m, const uint8_t hash[32]);
 int gbm_block_decref(gbm_manager *m, const uint8_t hash[32]);
+/* out[0] = count, out[1] = state (0 Absent, 1 Present, 2 Deletable), out[2] = deletable-at (ms) */
+int gbm_block_rc(gbm_manager *m, const uint8_t hash[32], uint64_t out[3]);
 
-/* rc > 0: rewrite every missing/corrupt shard; rc == 0: delete all shards.
- * *changed = shards rewritten or deleted. */
+/* ---------------------------------------------------------------- resync */
+/* put_to_resync(hash, delay) (src/block/resync.rs:239-253): key = (due time, hash). */
+int gbm_put_to_resync(gbm_manager *m, const uint8_t hash[32], uint64_t delay_ms);
+/* One pass of the resync loop over everything that is due (at most max_blocks entries; 0 = all):
+ *  - entries whose block is still inside its error back-off are re-queued at next_try
+ *    (ErrorCounter: RESYNC_RETRY_DELAY << min(errors-1, 6));
+ *  - blocks that exist and are deletable are deleted everywhere (shards misplaced by a layout change
+ *    are first offloaded to the owner that needs them);
+ *  - needed blocks with absent shards: exactly k shards are gathered, blocks are grouped by
+ *    (shard length, erasure pattern) and each group is rebuilt with ONE gec_reconstruct_batch call
+ *    that produces only the shards that are actually absent; rebuilt shards go to their nodes.
+ * stats (may be NULL): [0] entries taken, [1] blocks resynced ok, [2] errors, [3] skipped (back-off),
+ * [4] shards rebuilt, [5] shards deleted, [6] shards offloaded, [7] device (reconstruct) calls. */
+int gbm_resync_run(gbm_manager *m, size_t max_blocks, uint64_t stats[8]);
+/* Run one block now, ignoring its queue entry and back-off.  *changed = shards written or deleted. */
 int gbm_resync_block(gbm_manager *m, const uint8_t hash[32], int *changed);
+/* gbm_resync_run until nothing is due any more.  *changed = shards written, offloaded or deleted. */
 int gbm_resync_all(gbm_manager *m, int *changed);
-size_t gbm_resync_queue_len(const gbm_manager *m);
+size_t gbm_resync_queue_len(const gbm_manager *m);   /* all entries, due or not */
+size_t gbm_resync_errors_len(const gbm_manager *m);  /* blocks in error back-off */
+/* Background worker (ResyncWorker, src/block/resync.rs:523-602): wakes when an entry becomes due. */
+int gbm_resync_worker_start(gbm_manager *m);
+int gbm_resync_worker_stop(gbm_manager *m);
 
 /* Batch verify on the device: bad_out[i] = 1 if block i is inconsistent or
  * not fully readable. */
@@ -126,6 +216,11 @@ int gbm_node_delete_shard(gbm_manager *m, int node, const uint8_t hash[32], int 
  * re-stamps the header checksum (silent corruption only scrub can find). */
 int gbm_node_corrupt_shard(gbm_manager *m, int node, const uint8_t hash[32], int idx,
 			   size_t offset, uint8_t mask, int fix_checksum);
+/* The stored shard's 64-byte header (GBM_E_IO if the node does not have it). */
+int gbm_node_shard_header(gbm_manager *m, int node, const uint8_t hash[32], int idx,
+			  uint8_t out[GBM_SHARD_HEADER_SIZE]);
+/* PutShard deliveries to this node whose order tag was lower than one it had already seen for the same stream */
+uint64_t gbm_node_order_violations(gbm_manager *m, int node);
 
 /* out[0..5] = bytes_written, bytes_read, corruption_counter, ec_reconstructs,
  * blocks_put, blocks_get */

@@ -160,8 +160,10 @@ int gec_verify_batch(const gec_codec *c, size_t nblocks,
  * (src/block/manager.rs:292-334) and where resync_block fetches an absent
  * block (src/block/resync.rs:485-499).
  * shards[b*n + j] == NULL => shard j of block b is missing and is written to
- * out[b*n + j] (S bytes); out entries of present shards are ignored; with
- * data_only != 0 missing parity shards are skipped (out entry may be NULL).
+ * out[b*n + j] (S bytes) -- unless that entry is NULL too, which means "not wanted":
+ * only the rows that are asked for are computed (resync rebuilds just the shards
+ * that are absent on reachable nodes).  out entries of present shards are ignored;
+ * with data_only != 0 missing parity shards are never rebuilt.
  * Fewer than k present shards in any block => GEC_E_TOO_FEW_PRESENT. */
 int gec_reconstruct_batch(const gec_codec *c, size_t nblocks,
 			  const uint8_t *const *shards, uint8_t *const *out,

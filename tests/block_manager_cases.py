@@ -110,8 +110,10 @@ def scenario_corrupt_shard_detected_and_resynced(codec, tmp_path):
     assert mgr.scrub([h]) == []
     for j, node in enumerate(who):
         assert stores[node].get(h, j) is not None
-    # rc -> 0: resync deletes all shards
+    # rc -> 0: nothing is deleted inside BLOCK_GC_DELAY, every shard after it
     mgr.block_decref(h)
+    assert mgr.resync_all() == 0 and mgr.rpc_get_block(h) == data
+    mgr.clock_advance(mgr.gc_delay_ms + 11_000)
     assert mgr.resync_all() == codec.k + codec.m
     with pytest.raises(MissingBlock):
         mgr.rpc_get_block(h)
@@ -179,3 +181,22 @@ def scenario_geometry_is_a_function_of_the_block(codec):
     assert mgr.rpc_get_block(hs) == small                  # majority geometry wins
     assert mgr.resync_all() >= 1                           # and resync overwrites the stray shard
     assert ShardHeader.unpack(stores[who[0]].get(hs, 0)).orig_len == len(small)
+
+
+def scenario_put_with_node_down_is_repaired_not_deleted(codec):
+    """a put that reached its quorum with a node down queues the block for resync; nobody
+    has incref'ed it yet (PutObject does that concurrently).  Resync must rebuild the straggler, never
+    delete the block."""
+    mgr, stores = make_manager(codec, write_quorum=codec.k)
+    data = pattern_block(250_000, 31)
+    h = block_hash(data)
+    who = mgr.storage_nodes_of(h)
+    stores[who[-1]].down = True
+    mgr.rpc_put_block(h, data)
+    stores[who[-1]].down = False
+    assert mgr.resync_all() == 1                       # the missing shard, rebuilt
+    assert stores[who[-1]].get(h, codec.k + codec.m - 1) is not None
+    assert mgr.rpc_get_block(h) == data
+    mgr.block_incref(h)
+    mgr.clock_advance(mgr.gc_delay_ms + 11_000)
+    assert mgr.resync_all() == 0 and mgr.rpc_get_block(h) == data

@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -12,6 +14,7 @@
 
 extern "C" gec_codec *stub_codec_create(int k, int m);
 extern "C" void stub_codec_destroy(gec_codec *c);
+extern "C" unsigned long long stub_reconstruct_calls(void);
 
 #define CHECK(cond)                                                                               \
 	do {                                                                                      \
@@ -60,15 +63,15 @@ static void run(int k, int m, const char *dir_root)
 		ptrs.push_back(blocks[b].data());
 		lens.push_back(blocks[b].size());
 	}
-	CHECK(gbm_rpc_put_blocks(mg, blocks.size(), hashes.data(), ptrs.data(), lens.data()) == GBM_OK);
+	CHECK(gbm_rpc_put_blocks(mg, blocks.size(), hashes.data(), ptrs.data(), lens.data(), nullptr, nullptr) == GBM_OK);
 	std::vector<uint8_t> out(1 << 20);
 	size_t got = 0;
 	for (size_t b = 0; b < blocks.size(); ++b) {
-		CHECK(gbm_rpc_get_block(mg, hashes.data() + 32 * b, out.data(), out.size(), &got) == GBM_OK);
+		CHECK(gbm_rpc_get_block(mg, hashes.data() + 32 * b, nullptr, out.data(), out.size(), &got) == GBM_OK);
 		CHECK(got == blocks[b].size() && std::memcmp(out.data(), blocks[b].data(), got) == 0);
 		CHECK(gbm_block_incref(mg, hashes.data() + 32 * b) == GBM_OK);
 	}
-	CHECK(gbm_rpc_get_block(mg, hashes.data(), out.data(), 100, &got) == GBM_E_BUFFER_TOO_SMALL && got == 3073);
+	CHECK(gbm_rpc_get_block(mg, hashes.data(), nullptr, out.data(), 100, &got) == GBM_E_BUFFER_TOO_SMALL && got == 3073);
 
 	// m nodes down (data shards first): still readable through a decode; one more: MissingBlock
 	const uint8_t *h = hashes.data() + 32 * 2;
@@ -76,12 +79,12 @@ static void run(int k, int m, const char *dir_root)
 	CHECK(gbm_storage_nodes_of(mg, h, who.data()) == GBM_OK);
 	for (int j = 0; j < m; ++j)
 		CHECK(gbm_node_set_down(mg, who[j], 1) == GBM_OK);
-	CHECK(gbm_rpc_get_block(mg, h, out.data(), out.size(), &got) == GBM_OK && got == 500000);
+	CHECK(gbm_rpc_get_block(mg, h, nullptr, out.data(), out.size(), &got) == GBM_OK && got == 500000);
 	CHECK(std::memcmp(out.data(), blocks[2].data(), got) == 0);
 	CHECK(gbm_node_set_down(mg, who[m], 1) == GBM_OK);
-	CHECK(gbm_rpc_get_block(mg, h, out.data(), out.size(), &got) == GBM_E_MISSING_BLOCK);
+	CHECK(gbm_rpc_get_block(mg, h, nullptr, out.data(), out.size(), &got) == GBM_E_MISSING_BLOCK);
 	// write quorum
-	CHECK(gbm_rpc_put_block(mg, h, blocks[2].data(), blocks[2].size()) == GBM_E_QUORUM);
+	CHECK(gbm_rpc_put_block(mg, h, blocks[2].data(), blocks[2].size(), 0, nullptr) == GBM_E_QUORUM);
 	for (int j = 0; j <= m; ++j)
 		gbm_node_set_down(mg, who[j], 0);
 
@@ -92,7 +95,7 @@ static void run(int k, int m, const char *dir_root)
 		CHECK(gbm_node_delete_shard(mg, who[k], h, k) == GBM_OK);
 		lost = 2;
 	}
-	CHECK(gbm_rpc_get_block(mg, h, out.data(), out.size(), &got) == GBM_OK);
+	CHECK(gbm_rpc_get_block(mg, h, nullptr, out.data(), out.size(), &got) == GBM_OK);
 	CHECK(std::memcmp(out.data(), blocks[2].data(), got) == 0);
 	uint64_t met[6];
 	CHECK(gbm_metrics(mg, met) == GBM_OK && met[2] == 1 && met[3] >= 2);
@@ -112,24 +115,27 @@ static void run(int k, int m, const char *dir_root)
 	CHECK(bad[2] == 1 && bad[0] == 0 && bad[1] == 0 && bad[3] == 0);
 
 	// wrong content under a valid name -> CorruptData
-	CHECK(gbm_rpc_put_block(mg, hashes.data(), blocks[1].data(), blocks[1].size()) == GBM_OK);
-	CHECK(gbm_rpc_get_block(mg, hashes.data(), out.data(), out.size(), &got) == GBM_E_CORRUPT_DATA);
+	CHECK(gbm_rpc_put_block(mg, hashes.data(), blocks[1].data(), blocks[1].size(), 0, nullptr) == GBM_OK);
+	CHECK(gbm_rpc_get_block(mg, hashes.data(), nullptr, out.data(), out.size(), &got) == GBM_E_CORRUPT_DATA);
 
 	// compression (zstd frame + checksum), if libzstd is there
 	if (gbm_set_compression_level(mg, 1, 1) == GBM_OK) {
 		std::vector<uint8_t> z = pattern(800000, 9);
 		uint8_t hz[32];
 		gbm_blake2sum(z.data(), z.size(), hz);
-		CHECK(gbm_rpc_put_block(mg, hz, z.data(), z.size()) == GBM_OK);
-		CHECK(gbm_rpc_get_block(mg, hz, out.data(), out.size(), &got) == GBM_OK && got == z.size());
+		CHECK(gbm_rpc_put_block(mg, hz, z.data(), z.size(), 0, nullptr) == GBM_OK);
+		CHECK(gbm_rpc_get_block(mg, hz, nullptr, out.data(), out.size(), &got) == GBM_OK && got == z.size());
 		CHECK(std::memcmp(out.data(), z.data(), got) == 0);
 		gbm_set_compression_level(mg, 0, 0);
 	}
 
-	// rc -> 0: resync deletes every shard
+	// rc -> 0: nothing is deleted before BLOCK_GC_DELAY has passed, everything after it
 	CHECK(gbm_block_decref(mg, hashes.data() + 32 * 3) == GBM_OK);
+	CHECK(gbm_resync_all(mg, &changed) == GBM_OK && changed == 0);
+	CHECK(gbm_rpc_get_block(mg, hashes.data() + 32 * 3, nullptr, out.data(), out.size(), &got) == GBM_OK);
+	CHECK(gbm_clock_advance(mg, GBM_BLOCK_GC_DELAY_MS + 11000) == GBM_OK);
 	CHECK(gbm_resync_all(mg, &changed) == GBM_OK && changed >= n);
-	CHECK(gbm_rpc_get_block(mg, hashes.data() + 32 * 3, out.data(), out.size(), &got) == GBM_E_MISSING_BLOCK);
+	CHECK(gbm_rpc_get_block(mg, hashes.data() + 32 * 3, nullptr, out.data(), out.size(), &got) == GBM_E_MISSING_BLOCK);
 
 	gbm_destroy(mg);
 	stub_codec_destroy(codec);
@@ -159,7 +165,7 @@ static void run_batcher(int k, int m)
 		th.emplace_back([&, t] {
 			for (int j = 0; j < PER; ++j) {
 				const int i = t * PER + j;
-				rcs[i] = gbm_batcher_put_block(bt, hashes.data() + 32 * i, blocks[i].data(), blocks[i].size());
+				rcs[i] = gbm_batcher_put_block(bt, hashes.data() + 32 * i, blocks[i].data(), blocks[i].size(), 0, nullptr);
 			}
 		});
 	std::vector<int> reader_ok(2, 1);
@@ -169,7 +175,7 @@ static void run_batcher(int k, int m)
 			for (int round = 0; round < 40; ++round)
 				for (int i = r; i < T * PER; i += 7) {
 					size_t got = 0;
-					int rc = gbm_rpc_get_block(mg, hashes.data() + 32 * i, out.data(), out.size(), &got);
+					int rc = gbm_rpc_get_block(mg, hashes.data() + 32 * i, nullptr, out.data(), out.size(), &got);
 					if (rc == GBM_OK && (got != blocks[i].size() || std::memcmp(out.data(), blocks[i].data(), got)))
 						reader_ok[r] = 0;  // a block is either not there yet or exactly right
 					else if (rc != GBM_OK && rc != GBM_E_MISSING_BLOCK)
@@ -183,7 +189,7 @@ static void run_batcher(int k, int m)
 	for (int i = 0; i < T * PER; ++i) {
 		CHECK(rcs[i] == GBM_OK);
 		size_t got = 0;
-		CHECK(gbm_rpc_get_block(mg, hashes.data() + 32 * i, out.data(), out.size(), &got) == GBM_OK);
+		CHECK(gbm_rpc_get_block(mg, hashes.data() + 32 * i, nullptr, out.data(), out.size(), &got) == GBM_OK);
 		CHECK(got == blocks[i].size() && std::memcmp(out.data(), blocks[i].data(), got) == 0);
 	}
 	uint64_t st[3];
@@ -199,7 +205,7 @@ static void run_batcher(int k, int m)
 		std::vector<std::thread> th2;
 		std::vector<int> rc2(T, -999);
 		for (int t = 0; t < T; ++t)
-			th2.emplace_back([&, t] { rc2[t] = gbm_batcher_put_block(bt, hashes.data() + 32 * t, blocks[t].data(), blocks[t].size()); });
+			th2.emplace_back([&, t] { rc2[t] = gbm_batcher_put_block(bt, hashes.data() + 32 * t, blocks[t].data(), blocks[t].size(), 0, nullptr); });
 		for (auto &x : th2)
 			x.join();
 		for (int t = 0; t < T; ++t)
@@ -210,14 +216,14 @@ static void run_batcher(int k, int m)
 	std::vector<uint8_t> big(300 * 1024, 7);
 	uint8_t bigh[32];
 	gbm_blake2sum(big.data(), big.size(), bigh);
-	CHECK(gbm_batcher_put_block(bt, bigh, big.data(), big.size()) == GBM_E_INVALID_ARG);
+	CHECK(gbm_batcher_put_block(bt, bigh, big.data(), big.size(), 0, nullptr) == GBM_E_INVALID_ARG);
 	CHECK(gbm_batcher_set_ram_buffer_max(bt, 256u << 20) == GBM_OK);
 	// a quorum failure is reported to the caller whose block it was
 	std::vector<int> who(k + m);
 	CHECK(gbm_storage_nodes_of(mg, hashes.data(), who.data()) == GBM_OK);
 	for (int j = 0; j < m; ++j)
 		gbm_node_set_down(mg, who[j], 1);
-	CHECK(gbm_batcher_put_block(bt, hashes.data(), blocks[0].data(), blocks[0].size()) == GBM_E_QUORUM);
+	CHECK(gbm_batcher_put_block(bt, hashes.data(), blocks[0].data(), blocks[0].size(), 0, nullptr) == GBM_E_QUORUM);
 	gbm_batcher_destroy(bt);
 	gbm_destroy(mg);
 	stub_codec_destroy(codec);
@@ -225,8 +231,245 @@ static void run_batcher(int k, int m)
 	       (unsigned long long)st[1], (unsigned long long)st[0], (unsigned long long)st[2]);
 }
 
+struct Sink {
+	std::vector<uint8_t> got;
+	size_t calls = 0, max_chunk = 0, stop_after = 0;
+};
+static int sink_fn(void *ctx, const uint8_t *chunk, size_t len)
+{
+	Sink *s = (Sink *)ctx;
+	s->got.insert(s->got.end(), chunk, chunk + len);
+	s->max_chunk = std::max(s->max_chunk, len);
+	return ++s->calls == s->stop_after ? 1 : 0;
+}
+
+// Round-2 scenarios: the reference's put/get surface (prevent_compression, order_tag, raw / streaming gets),
+// refcount GC semantics, the time-ordered resync queue with back-off, batched rebuilds, layout change offload.
+static void run_round2(int k, int m)
+{
+	gec_codec *codec = stub_codec_create(k, m);
+	const int n = k + m, nnodes = n + 3;
+	gbm_manager *mg = nullptr;
+	CHECK(gbm_create(codec, nnodes, nullptr, /*write_quorum=*/k, &mg) == GBM_OK);  // tolerate m absent nodes on write
+	CHECK(gbm_set_threads(mg, 4) == GBM_OK);
+	std::vector<uint8_t> out(1 << 20);
+	size_t got = 0;
+	int changed = -1;
+	uint64_t st[8];
+
+	// (1) a put that reached its quorum with a node down, and nobody has incref'ed the block yet: resync must
+	//     REPAIR the straggler, never delete the block
+	{
+		std::vector<uint8_t> d = pattern(300000, 5);
+		uint8_t h[32];
+		gbm_blake2sum(d.data(), d.size(), h);
+		std::vector<int> who(n);
+		CHECK(gbm_storage_nodes_of(mg, h, who.data()) == GBM_OK);
+		CHECK(gbm_node_set_down(mg, who[n - 1], 1) == GBM_OK);
+		CHECK(gbm_rpc_put_block(mg, h, d.data(), d.size(), 0, nullptr) == GBM_OK);
+		uint64_t rc[3];
+		CHECK(gbm_block_rc(mg, h, rc) == GBM_OK && rc[1] == 2 && rc[0] == 0);  // Deletable{now + GC delay}: protected
+		CHECK(gbm_node_set_down(mg, who[n - 1], 0) == GBM_OK);
+		CHECK(gbm_resync_all(mg, &changed) == GBM_OK && changed == 1);   // the one missing shard was rebuilt
+		CHECK(gbm_node_has_shard(mg, who[n - 1], h, n - 1));
+		CHECK(gbm_rpc_get_block(mg, h, nullptr, out.data(), out.size(), &got) == GBM_OK && got == d.size());
+		CHECK(std::memcmp(out.data(), d.data(), got) == 0);
+		// incref within the delay makes it Present; decref -> Deletable again; incref again cancels the GC
+		CHECK(gbm_block_incref(mg, h) == GBM_OK && gbm_block_rc(mg, h, rc) == GBM_OK && rc[1] == 1 && rc[0] == 1);
+		CHECK(gbm_block_decref(mg, h) == GBM_OK && gbm_block_rc(mg, h, rc) == GBM_OK && rc[1] == 2);
+		CHECK(gbm_block_incref(mg, h) == GBM_OK);
+		CHECK(gbm_clock_advance(mg, GBM_BLOCK_GC_DELAY_MS + 11000) == GBM_OK);
+		CHECK(gbm_resync_all(mg, &changed) == GBM_OK && changed == 0);
+		CHECK(gbm_rpc_get_block(mg, h, nullptr, out.data(), out.size(), &got) == GBM_OK);
+		CHECK(gbm_block_decref(mg, h) == GBM_OK);
+		CHECK(gbm_resync_all(mg, &changed) == GBM_OK && changed == 0);   // inside the GC delay
+		CHECK(gbm_clock_advance(mg, GBM_BLOCK_GC_DELAY_MS + 11000) == GBM_OK);
+		CHECK(gbm_resync_all(mg, &changed) == GBM_OK && changed == n);
+		CHECK(gbm_rpc_get_block(mg, h, nullptr, out.data(), out.size(), &got) == GBM_E_MISSING_BLOCK);
+		CHECK(gbm_block_rc(mg, h, rc) == GBM_OK && rc[1] == 0);               // clear_deleted_block_rc
+	}
+
+	// (2) prevent_compression (SSE-C blocks, put.rs:576) + raw / streaming gets
+	if (gbm_set_compression_level(mg, 1, 1) == GBM_OK) {
+		std::vector<uint8_t> d = pattern(700000, 77);
+		uint8_t h[32], hdr[GBM_SHARD_HEADER_SIZE];
+		gbm_blake2sum(d.data(), d.size(), h);
+		std::vector<int> who(n);
+		CHECK(gbm_storage_nodes_of(mg, h, who.data()) == GBM_OK);
+		CHECK(gbm_rpc_put_block(mg, h, d.data(), d.size(), /*prevent_compression=*/1, nullptr) == GBM_OK);
+		for (int j = 0; j < n; ++j) {
+			CHECK(gbm_node_shard_header(mg, who[j], h, j, hdr) == GBM_OK);
+			CHECK(hdr[8] == 0);  // compressed flag of every shard header
+		}
+		gbm_data_block_header dh;
+		CHECK(gbm_rpc_get_raw_block(mg, h, nullptr, &dh, out.data(), out.size(), &got) == GBM_OK);
+		CHECK(dh.kind == GBM_HEADER_PLAIN && got == d.size() && std::memcmp(out.data(), d.data(), got) == 0);
+		// same block without the flag: stored Compressed, raw get returns the zstd frame, get returns the block
+		CHECK(gbm_rpc_put_block(mg, h, d.data(), d.size(), 0, nullptr) == GBM_OK);
+		CHECK(gbm_node_shard_header(mg, who[0], h, 0, hdr) == GBM_OK && hdr[8] == 1);
+		CHECK(gbm_rpc_get_raw_block(mg, h, nullptr, &dh, out.data(), out.size(), &got) == GBM_OK);
+		CHECK(dh.kind == GBM_HEADER_COMPRESSED && got < d.size() && out[0] == 0x28 && out[1] == 0xb5);  // zstd magic
+		CHECK(gbm_rpc_get_block(mg, h, nullptr, out.data(), out.size(), &got) == GBM_OK && got == d.size());
+		CHECK(std::memcmp(out.data(), d.data(), got) == 0);
+		Sink s1;
+		CHECK(gbm_rpc_get_block_streaming(mg, h, nullptr, 10000, sink_fn, &s1) == GBM_OK);
+		CHECK(s1.got == d && s1.max_chunk == 10000 && s1.calls == (d.size() + 9999) / 10000);
+		Sink s2;
+		CHECK(gbm_rpc_get_raw_block_streaming(mg, h, nullptr, &dh, 0, sink_fn, &s2) == GBM_OK);
+		CHECK(dh.kind == GBM_HEADER_COMPRESSED && s2.got.size() < d.size() && s2.max_chunk <= 65536);
+		Sink s3;
+		s3.stop_after = 2;
+		CHECK(gbm_rpc_get_block_streaming(mg, h, nullptr, 4096, sink_fn, &s3) == GBM_E_ABORTED && s3.calls == 2);
+		uint8_t nope[32] = {1, 2, 3};
+		CHECK(gbm_rpc_get_block_streaming(mg, nope, nullptr, 0, sink_fn, &s3) == GBM_E_MISSING_BLOCK);
+		gbm_set_compression_level(mg, 0, 0);
+	}
+
+	// (3) order tags: a batch handed over in reverse order reaches the nodes in stream order
+	{
+		const int NB = 12;
+		std::vector<std::vector<uint8_t>> blocks(NB);
+		std::vector<uint8_t> hashes(NB * 32);
+		std::vector<const uint8_t *> ptrs(NB);
+		std::vector<size_t> lens(NB);
+		std::vector<gbm_order_tag> tags(NB);
+		for (int i = 0; i < NB; ++i) {
+			blocks[i] = pattern(20000 + 100 * i, 300 + i);
+			gbm_blake2sum(blocks[i].data(), blocks[i].size(), hashes.data() + 32 * i);
+			ptrs[i] = blocks[i].data();
+			lens[i] = blocks[i].size();
+			tags[i] = gbm_order_tag{42, (uint64_t)(NB - i)};
+		}
+		CHECK(gbm_rpc_put_blocks(mg, NB, hashes.data(), ptrs.data(), lens.data(), nullptr, tags.data()) == GBM_OK);
+		for (int node = 0; node < nnodes; ++node)
+			CHECK(gbm_node_order_violations(mg, node) == 0);
+		gbm_order_tag gt{7, 1};
+		CHECK(gbm_rpc_get_block(mg, hashes.data(), &gt, out.data(), out.size(), &got) == GBM_OK && got == lens[0]);
+	}
+
+	// (4) resync as the survey wrote it: 200 blocks written while one node is down; the node comes back; ONE pass of
+	//     the queue rebuilds every absent shard with at most one device call per erasure pattern (<= k+m)
+	{
+		const int NB = 200;
+		std::vector<std::vector<uint8_t>> blocks(NB);
+		std::vector<uint8_t> hashes(NB * 32);
+		std::vector<const uint8_t *> ptrs(NB);
+		std::vector<size_t> lens(NB);
+		for (int i = 0; i < NB; ++i) {
+			blocks[i] = pattern(30000, 900 + i);  // equal shard length: groups differ by pattern only
+			std::memcpy(blocks[i].data(), &i, sizeof(i));  // (two salts can give the same pattern)
+			gbm_blake2sum(blocks[i].data(), blocks[i].size(), hashes.data() + 32 * i);
+			ptrs[i] = blocks[i].data();
+			lens[i] = blocks[i].size();
+		}
+		const int dead = 2;
+		CHECK(gbm_node_set_down(mg, dead, 1) == GBM_OK);
+		CHECK(gbm_rpc_put_blocks(mg, NB, hashes.data(), ptrs.data(), lens.data(), nullptr, nullptr) == GBM_OK);
+		int affected = 0;
+		std::vector<int> who(n);
+		for (int i = 0; i < NB; ++i) {
+			CHECK(gbm_block_incref(mg, hashes.data() + 32 * i) == GBM_OK);
+			CHECK(gbm_storage_nodes_of(mg, hashes.data() + 32 * i, who.data()) == GBM_OK);
+			for (int j = 0; j < n; ++j)
+				affected += who[j] == dead;
+		}
+		CHECK(affected > 0 && (int)gbm_resync_queue_len(mg) >= affected);
+		// while the node is still down the rebuild cannot be delivered: error, back-off
+		int rr = gbm_resync_run(mg, 0, st);
+		if (!(rr != GBM_OK && st[2] == (uint64_t)affected && st[4] == 0))
+			fprintf(stderr, "resync_run rc=%d affected=%d st=%llu %llu %llu %llu %llu %llu %llu %llu\n", rr, affected, (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2], (unsigned long long)st[3], (unsigned long long)st[4], (unsigned long long)st[5], (unsigned long long)st[6], (unsigned long long)st[7]);
+		CHECK(rr != GBM_OK && st[2] == (uint64_t)affected && st[4] == 0);
+		CHECK((int)gbm_resync_errors_len(mg) == affected);
+		CHECK(gbm_node_set_down(mg, dead, 0) == GBM_OK);
+		CHECK(gbm_resync_run(mg, 0, st) == GBM_OK && st[0] == 0 && st[3] == 0);  // nothing due: the retries are 60 s away
+		CHECK(gbm_clock_advance(mg, GBM_RESYNC_RETRY_DELAY_MS - 2000) == GBM_OK);
+		CHECK(gbm_resync_run(mg, 0, st) == GBM_OK && st[0] == 0);
+		CHECK(gbm_clock_advance(mg, 3000) == GBM_OK);
+		const unsigned long long calls0 = stub_reconstruct_calls();
+		CHECK(gbm_resync_run(mg, 0, st) == GBM_OK);
+		CHECK(st[0] == (uint64_t)affected && st[1] == (uint64_t)affected && st[2] == 0 && st[4] == (uint64_t)affected);
+		CHECK(st[7] >= 1 && st[7] <= (uint64_t)n);                                  // <= #patterns device calls
+		CHECK(stub_reconstruct_calls() - calls0 == st[7]);
+		CHECK(gbm_resync_errors_len(mg) == 0);
+		for (int i = 0; i < NB; ++i) {
+			CHECK(gbm_storage_nodes_of(mg, hashes.data() + 32 * i, who.data()) == GBM_OK);
+			for (int j = 0; j < n; ++j)
+				CHECK(gbm_node_has_shard(mg, who[j], hashes.data() + 32 * i, j));
+		}
+		std::vector<uint8_t> bad(NB);
+		CHECK(gbm_scrub(mg, NB, hashes.data(), bad.data()) == GBM_OK);
+		for (uint8_t x : bad)
+			CHECK(x == 0);
+
+		// back-off doubles: a block that cannot be repaired (m+1 shards gone) errs at 60 s, 120 s, 240 s ...
+		const uint8_t *hb = hashes.data();
+		CHECK(gbm_storage_nodes_of(mg, hb, who.data()) == GBM_OK);
+		for (int j = 0; j <= m; ++j)
+			CHECK(gbm_node_delete_shard(mg, who[j], hb, j) == GBM_OK);
+		CHECK(gbm_put_to_resync(mg, hb, 0) == GBM_OK);
+		CHECK(gbm_resync_run(mg, 0, st) == GBM_E_MISSING_BLOCK && st[2] == 1);
+		CHECK(gbm_clock_advance(mg, GBM_RESYNC_RETRY_DELAY_MS + 10) == GBM_OK);
+		CHECK(gbm_resync_run(mg, 0, st) == GBM_E_MISSING_BLOCK && st[0] == 1 && st[2] == 1);   // 2nd error -> next try 120 s later
+		CHECK(gbm_clock_advance(mg, GBM_RESYNC_RETRY_DELAY_MS + 10) == GBM_OK);
+		CHECK(gbm_resync_run(mg, 0, st) == GBM_OK && st[0] == 0);
+		CHECK(gbm_put_to_resync(mg, hb, 0) == GBM_OK);                                         // an early entry is pushed back, not run
+		CHECK(gbm_resync_run(mg, 0, st) == GBM_OK && st[0] == 0 && st[3] == 1);
+		CHECK(gbm_clock_advance(mg, GBM_RESYNC_RETRY_DELAY_MS) == GBM_OK);
+		CHECK(gbm_resync_run(mg, 0, st) == GBM_E_MISSING_BLOCK && st[0] == 1);
+
+		// (5) layout change: shards move; reads still succeed through the old version; resync offloads every shard to
+		//     its new owner and deletes it where it no longer belongs
+		const uint8_t *h1 = hashes.data() + 32;
+		std::vector<int> who_old(n), who_new(n);
+		CHECK(gbm_storage_nodes_of(mg, h1, who_old.data()) == GBM_OK);
+		CHECK(gbm_layout_update(mg) == 1);
+		CHECK(gbm_storage_nodes_of(mg, h1, who_new.data()) == GBM_OK);
+		CHECK(who_old != who_new);
+		CHECK(gbm_rpc_get_block(mg, h1, nullptr, out.data(), out.size(), &got) == GBM_OK && got == lens[1]);
+		CHECK(std::memcmp(out.data(), blocks[1].data(), got) == 0);
+		CHECK(gbm_resync_block(mg, h1, &changed) == GBM_OK && changed >= 1);
+		for (int j = 0; j < n; ++j) {
+			CHECK(gbm_node_has_shard(mg, who_new[j], h1, j));
+			if (who_old[j] != who_new[j])
+				CHECK(!gbm_node_has_shard(mg, who_old[j], h1, j));
+		}
+		for (int i = 2; i < NB; ++i)
+			CHECK(gbm_put_to_resync(mg, hashes.data() + 32 * i, 0) == GBM_OK);
+		CHECK(gbm_resync_run(mg, 0, st) == GBM_OK && st[6] > 0 && st[7] == 0);  // pure offload: no device work
+		CHECK(gbm_layout_trim(mg) == GBM_OK);
+		for (int i = 1; i < NB; ++i) {
+			CHECK(gbm_rpc_get_block(mg, hashes.data() + 32 * i, nullptr, out.data(), out.size(), &got) == GBM_OK);
+			CHECK(got == lens[i] && std::memcmp(out.data(), blocks[i].data(), got) == 0);
+		}
+	}
+
+	// (6) the background worker picks up what becomes due
+	{
+		std::vector<uint8_t> d = pattern(50000, 4242);
+		uint8_t h[32];
+		gbm_blake2sum(d.data(), d.size(), h);
+		CHECK(gbm_rpc_put_block(mg, h, d.data(), d.size(), 0, nullptr) == GBM_OK);
+		CHECK(gbm_block_incref(mg, h) == GBM_OK);
+		std::vector<int> who(n);
+		CHECK(gbm_storage_nodes_of(mg, h, who.data()) == GBM_OK);
+		CHECK(gbm_node_delete_shard(mg, who[0], h, 0) == GBM_OK);
+		CHECK(gbm_resync_worker_start(mg) == GBM_OK);
+		CHECK(gbm_put_to_resync(mg, h, 0) == GBM_OK);
+		for (int spin = 0; spin < 2000 && !gbm_node_has_shard(mg, who[0], h, 0); ++spin)
+			std::this_thread::sleep_for(std::chrono::milliseconds(2));
+		CHECK(gbm_node_has_shard(mg, who[0], h, 0));
+		CHECK(gbm_resync_worker_stop(mg) == GBM_OK);
+	}
+
+	gbm_destroy(mg);
+	stub_codec_destroy(codec);
+	printf("round-2 scenarios RS(%d,%d): OK\n", k, m);
+}
+
 int main(int argc, char **argv)
 {
+	run_round2(3, 1);
+	run_round2(10, 4);
 	run(3, 1, nullptr);
 	run(10, 4, nullptr);
 	if (argc > 1)

@@ -3,6 +3,7 @@
 // (oracle/rs_oracle.c).  It exists so that the C++ BlockManager host logic can
 // run on a box without a GPU and under ASan/UBSan.  Never linked into a product
 // library: the real libgarage_ec has no CPU path.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -53,9 +54,17 @@ int gec_encode_hash_batch(const gec_codec *c, size_t nb, const uint8_t *const *b
 	return GEC_OK;
 }
 
+// pinned host memory does not exist without a device: plain heap
+void *gec_host_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+void gec_host_free(void *p) { std::free(p); }
+
+static std::atomic<unsigned long long> g_reconstruct_calls{0};
+unsigned long long stub_reconstruct_calls(void) { return g_reconstruct_calls.load(); }
+
 int gec_reconstruct_batch(const gec_codec *c, size_t nb, const uint8_t *const *shards, uint8_t *const *out, size_t S,
 			  int data_only)
 {
+	++g_reconstruct_calls;
 	const int k = c->k, n = c->k + c->m;
 	for (size_t b = 0; b < nb; ++b) {
 		std::vector<std::vector<uint8_t>> buf(n, std::vector<uint8_t>(S));

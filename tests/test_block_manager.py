@@ -76,3 +76,7 @@ def test_compressed_put_get_and_corruption():
         mgr.rpc_get_block(h)
     with pytest.raises(CorruptData):
         DataBlock.compressed(b"not a zstd frame").verify(h)
+
+
+def test_put_with_node_down_is_repaired_not_deleted(codec):
+    C.scenario_put_with_node_down_is_repaired_not_deleted(codec)

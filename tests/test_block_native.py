@@ -139,8 +139,10 @@ def test_native_corruption_resync_scrub(codec, tmp_path):
     mgr.rpc_put_block(hashes[0], evil)
     with pytest.raises(bn.CorruptData):
         mgr.rpc_get_block(hashes[0])
-    # rc -> 0: resync deletes every shard
+    # rc -> 0: nothing is deleted inside BLOCK_GC_DELAY, every shard after it
     mgr.block_decref(hashes[5])
+    assert mgr.resync_all() == 0 and mgr.rpc_get_block(hashes[5]) == blocks[5]
+    mgr.clock_advance(bn.GBM_BLOCK_GC_DELAY_MS + 11_000)
     assert mgr.resync_all() >= codec.k + codec.m
     with pytest.raises(bn.MissingBlock):
         mgr.rpc_get_block(hashes[5])
@@ -192,11 +194,145 @@ def test_compressed_blocks_native_and_python(tmp_path):
     for j in (0, 1, 2, 11):
         native.node_delete_shard(who[j], ha, j)
     assert native.rpc_get_block(ha) == a
-    # prevent_compression / random data: falls back to what zstd produces (still a frame)
+    # random data: falls back to what zstd produces (still a frame)
     rnd = bytes(np.random.default_rng(1).integers(0, 256, 100_000, dtype=np.uint8))
     hr = bn.blake2sum(rnd)
     native.rpc_put_block(hr, rnd)
     assert pym.rpc_get_block(hr) == rnd
+
+
+@pytest.mark.gpu
+def test_prevent_compression_order_tag_raw_and_streaming_gets():
+    """The reference's put/get surface (src/block/manager.rs:243-274,344-408): an "encrypted" (SSE-C) block is
+    put with prevent_compression=True under compression level 1 (put.rs:576) and every shard header says
+    Plain; rpc_get_raw_block returns the DataBlock as stored; the streaming forms deliver it in order."""
+    codec = g.ReedSolomon(10, 4)
+    mgr = bn.NativeBlockManager(codec, 16, compression_level=1)
+    data = pattern_block(1 << 20, 12)                       # very compressible
+    h = bn.blake2sum(data)
+    who = mgr.storage_nodes_of(h)
+    mgr.rpc_put_block(h, data, prevent_compression=True, order_tag=(99, 1))
+    S = g.shard_len(10, len(data))
+    for j, node in enumerate(who):
+        hdr = mgr.node_shard_header(node, h, j)
+        assert hdr[:4] == b"GECS" and hdr[7] == j and hdr[8] == 0, "compressed flag must be 0 in every shard header"
+        assert int.from_bytes(hdr[12:20], "little") == len(data) and int.from_bytes(hdr[20:24], "little") == S
+    hd, raw = mgr.rpc_get_raw_block(h)
+    assert not hd.is_compressed() and raw == data
+    mgr.rpc_put_block(h, data)                              # the same block without the flag: stored Compressed
+    hd, raw = mgr.rpc_get_raw_block(h, order_tag=(99, 2))
+    assert hd.is_compressed() and len(raw) < len(data) // 4 and raw[:4] == bytes.fromhex("28b52ffd")
+    assert mgr.node_shard_header(who[3], h, 3)[8] == 1
+    assert mgr.rpc_get_block(h, order_tag=(99, 3)) == data
+    chunks = mgr.rpc_get_block_streaming(h, chunk_bytes=100_000)
+    assert b"".join(chunks) == data and max(map(len, chunks)) == 100_000 and len(chunks) == 11
+    hd2, rchunks = mgr.rpc_get_block_streaming(h, raw=True)
+    assert hd2.is_compressed() and b"".join(rchunks) == raw
+    with pytest.raises(bn.MissingBlock):
+        mgr.rpc_get_block_streaming(bytes(32))
+    # a batch handed over in reverse stream order reaches every node in order
+    blocks = [pattern_block(300_000 + 4096 * i, 500 + i) for i in range(10)]
+    hashes = [bn.blake2sum(b) for b in blocks]
+    mgr.rpc_put_blocks(list(zip(hashes, blocks)), prevent_compression=[i % 2 == 0 for i in range(10)],
+                       order_tags=[(7, 10 - i) for i in range(10)])
+    assert all(mgr.node_order_violations(node) == 0 for node in range(16))
+    assert mgr.rpc_get_blocks(hashes, 400_000) == blocks
+    assert [mgr.node_shard_header(mgr.storage_nodes_of(hashes[i])[0], hashes[i], 0)[8] for i in range(10)] == [0, 1] * 5
+
+
+@pytest.mark.gpu
+def test_put_with_node_down_is_repaired_never_deleted():
+    """put reaches its quorum with a node down, no incref yet, resync runs: the straggler is
+    rebuilt; the block is only deleted after a decref AND BLOCK_GC_DELAY."""
+    codec = g.ReedSolomon(10, 4)
+    mgr = bn.NativeBlockManager(codec, 16)
+    data = pattern_block(400_000, 41)
+    h = bn.blake2sum(data)
+    who = mgr.storage_nodes_of(h)
+    mgr.node_set_down(who[0], True)
+    mgr.rpc_put_block(h, data)
+    assert mgr.block_rc(h)[1] == "Deletable"                 # protected for BLOCK_GC_DELAY
+    mgr.node_set_down(who[0], False)
+    assert mgr.resync_all() == 1 and mgr.node_has_shard(who[0], h, 0)
+    assert mgr.rpc_get_block(h) == data
+    mgr.block_incref(h)
+    mgr.clock_advance(bn.GBM_BLOCK_GC_DELAY_MS + 11_000)
+    assert mgr.resync_all() == 0 and mgr.rpc_get_block(h) == data
+    mgr.block_decref(h)
+    assert mgr.resync_all() == 0 and mgr.rpc_get_block(h) == data      # inside the GC delay
+    mgr.block_incref(h)                                                  # re-upload of identical content
+    mgr.clock_advance(bn.GBM_BLOCK_GC_DELAY_MS + 11_000)
+    assert mgr.resync_all() == 0 and mgr.rpc_get_block(h) == data
+    mgr.block_decref(h)
+    mgr.clock_advance(bn.GBM_BLOCK_GC_DELAY_MS + 11_000)
+    assert mgr.resync_all() == 14
+    with pytest.raises(bn.MissingBlock):
+        mgr.rpc_get_block(h)
+    assert mgr.block_rc(h)[1] == "Absent"
+
+
+@pytest.mark.gpu
+def test_resync_queue_batches_rebuilds_by_erasure_pattern():
+    """Row f3 as the survey wrote it: 1000 blocks are written while one node is dead; the node comes back
+    empty; ONE pass over the time-ordered queue gathers k shards per block and rebuilds every absent shard
+    with at most one device call -- and one matrix inversion -- per erasure pattern (<= k+m), with error
+    back-off while the node is still away."""
+    codec = g.ReedSolomon(10, 4)
+    mgr = bn.NativeBlockManager(codec, 17)
+    NB, L = 1000, 65536
+    rng = np.random.default_rng(5)
+    blocks = [rng.integers(0, 256, L, dtype=np.uint8).tobytes() for _ in range(NB)]
+    hashes = codec.blake2sum_batch(blocks)
+    dead = 4
+    mgr.node_set_down(dead, True)
+    mgr.rpc_put_blocks(list(zip(hashes, blocks)))
+    for h in hashes:
+        mgr.block_incref(h)
+    affected = [h for h in hashes if dead in mgr.storage_nodes_of(h)]
+    patterns = {mgr.storage_nodes_of(h).index(dead) for h in affected}
+    assert 400 < len(affected) < NB and len(patterns) == 14
+    st = mgr.resync_run(check=False)                          # node still away: every rebuild fails to land
+    assert st["rc"] != 0 and st["errors"] == len(affected) and st["rebuilt"] == 0
+    assert mgr.resync_errors_len() == len(affected)
+    mgr.node_set_down(dead, False)
+    assert mgr.resync_run()["taken"] == 0                     # inside the 60 s back-off
+    mgr.clock_advance(bn.GBM_RESYNC_RETRY_DELAY_MS + 5)
+    _, inv0 = codec.cache_stats()
+    st = mgr.resync_run()
+    _, inv1 = codec.cache_stats()
+    assert st["taken"] == st["ok"] == st["rebuilt"] == len(affected) and st["errors"] == 0
+    assert 1 <= st["device_calls"] <= len(patterns)
+    assert inv1 - inv0 <= len(patterns)                       # one decode matrix per pattern, LRU-cached
+    assert mgr.resync_errors_len() == 0
+    assert all(mgr.node_has_shard(dead, h, mgr.storage_nodes_of(h).index(dead)) for h in affected)
+    assert mgr.scrub(hashes) == []                            # every stripe RS-consistent on the device
+    assert mgr.rpc_get_blocks(hashes[:50], L) == blocks[:50]
+
+
+@pytest.mark.gpu
+def test_layout_change_offloads_shards_to_their_new_owners():
+    codec = g.ReedSolomon(10, 4)
+    mgr = bn.NativeBlockManager(codec, 20)
+    blocks = [pattern_block(200_000, 700 + i) for i in range(40)]
+    hashes = [bn.blake2sum(b) for b in blocks]
+    mgr.rpc_put_blocks(list(zip(hashes, blocks)))
+    for h in hashes:
+        mgr.block_incref(h)
+    old = [mgr.storage_nodes_of(h) for h in hashes]
+    assert mgr.layout_update() == 1
+    new = [mgr.storage_nodes_of(h) for h in hashes]
+    assert old != new
+    assert mgr.rpc_get_blocks(hashes, 200_000) == blocks      # reads fall back to the previous layout version
+    for h in hashes:
+        mgr.put_to_resync(h)
+    st = mgr.resync_run()
+    assert st["ok"] == 40 and st["offloaded"] > 0 and st["device_calls"] == 0
+    for h, o, n_ in zip(hashes, old, new):
+        for j in range(14):
+            assert mgr.node_has_shard(n_[j], h, j)
+            assert o[j] == n_[j] or not mgr.node_has_shard(o[j], h, j)
+    mgr.layout_trim()
+    assert mgr.rpc_get_blocks(hashes, 200_000) == blocks
 
 
 @pytest.mark.gpu

@@ -35,3 +35,7 @@ def test_scrub_finds_silent_corruption(codec):
 
 def test_geometry_is_a_function_of_the_block(codec):
     C.scenario_geometry_is_a_function_of_the_block(codec)
+
+
+def test_put_with_node_down_is_repaired_not_deleted(codec):
+    C.scenario_put_with_node_down_is_repaired_not_deleted(codec)
