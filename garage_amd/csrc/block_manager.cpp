@@ -25,6 +25,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -804,14 +805,19 @@ struct Geometry {
 
 struct Gathered {
 	std::vector<Bytes> shard;  // n entries; empty = not in hand
+	std::vector<std::array<uint8_t, 32>> sum;  // the checksum each shard's header promises
+	std::vector<int> node;                     // where each shard came from
 	ShardHeader meta;
 	bool have_meta = false;
 	int count = 0;
 	size_t next = 0;  // next candidate (version-major, shard index minor) to try
 	bool mixed = false;
+	bool settled = false;  // a geometry has been chosen; later candidates must match it
 	struct Group {
 		ShardHeader meta;
 		std::vector<Bytes> shard;
+		std::vector<std::array<uint8_t, 32>> sum;
+		std::vector<int> node;
 		int count = 0;
 	};
 	std::map<Geometry, Group> groups;
@@ -837,28 +843,36 @@ struct Gathered {
 // ONE batch; a shard whose checksum or header does not match is treated as missing, renamed *.corrupted and
 // queued for resync (read_block_from's behaviour, manager.rs:577-609), and the next node is tried in the
 // following round.
-int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, int want, std::vector<Gathered> &gs)
+int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, int want, std::vector<Gathered> &gs,
+		bool verify = true, const std::vector<uint8_t> *only = nullptr)
 {
+	// verify == false: shards are accepted on their header alone; the caller checks the checksums in the same
+	// device trip that decodes (gec_decode_verify_batch) and comes back for more (`only` = blocks to continue)
 	const int n = mg->n;
 	const int vcur = mg->layout_cur.load(), vold = mg->layout_oldest.load();
 	const size_t ncand = (size_t)(vcur - vold + 1) * n;
-	gs.assign(hs.size(), Gathered());
+	if (!only)
+		gs.assign(hs.size(), Gathered());
 	struct Cand {
 		size_t b;
 		int j, node;
 		Shard s;
 	};
+	auto have = [&](const Gathered &g, int j) { return g.settled ? !g.shard[j].empty() : g.have_idx(j); };
+	auto in_hand = [&](const Gathered &g) { return g.settled ? g.count : g.best(); };
 	for (;;) {
 		std::vector<std::vector<Cand>> per(hs.size());
 		mg->pool->parallel_for(hs.size(), [&](size_t b) {
+			if (only && !(*only)[b])
+				return;
 			Gathered &g = gs[b];
 			int pending = 0;
 			std::vector<int> who;
 			int who_v = -1;
-			while (g.next < ncand && g.best() + pending < want) {
+			while (g.next < ncand && in_hand(g) + pending < want) {
 				const size_t c = g.next++;
 				const int v = vcur - (int)(c / n), j = (int)(c % n);
-				if (g.have_idx(j))
+				if (have(g, j))
 					continue;
 				bool dup = false;
 				for (const Cand &pc : per[b])
@@ -883,6 +897,11 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 					mg->put_to_resync(hs[b], 0);
 					continue;
 				}
+				if (g.settled && (hd.compressed != g.meta.compressed || hd.orig_len != g.meta.orig_len ||
+						  hd.shard_len != g.meta.shard_len)) {
+					g.mixed = true;  // a stale shard of another geometry: resync will overwrite it
+					continue;
+				}
 				per[b].push_back(Cand{b, j, who[j], std::move(rs.shard)});
 				++pending;
 			}
@@ -893,23 +912,35 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 				cands.push_back(&c);
 		if (cands.empty())
 			break;
-		std::vector<const uint8_t *> ptrs(cands.size());
-		std::vector<size_t> lens(cands.size());
-		for (size_t i = 0; i < cands.size(); ++i) {
-			ptrs[i] = cands[i]->s.data.data();
-			lens[i] = cands[i]->s.hd.shard_len;
-		}
 		std::vector<uint8_t> sums;
-		int rc = hash_many(mg, ptrs, lens, sums);
-		if (rc)
-			return rc;
+		if (verify) {
+			std::vector<const uint8_t *> ptrs(cands.size());
+			std::vector<size_t> lens(cands.size());
+			for (size_t i = 0; i < cands.size(); ++i) {
+				ptrs[i] = cands[i]->s.data.data();
+				lens[i] = cands[i]->s.hd.shard_len;
+			}
+			int rc = hash_many(mg, ptrs, lens, sums);
+			if (rc)
+				return rc;
+		}
 		for (size_t i = 0; i < cands.size(); ++i) {
 			Cand &c = *cands[i];
 			Gathered &g = gs[c.b];
-			if (std::memcmp(sums.data() + 32 * i, c.s.hd.checksum, 32) != 0) {
+			if (verify && std::memcmp(sums.data() + 32 * i, c.s.hd.checksum, 32) != 0) {
 				mg->metrics[2]++;
 				mg->nodes[c.node]->mark_corrupted(hs[c.b], c.j);
 				mg->put_to_resync(hs[c.b], 0);
+				continue;
+			}
+			mg->metrics[1] += c.s.hd.shard_len;
+			std::array<uint8_t, 32> want_sum;
+			std::memcpy(want_sum.data(), c.s.hd.checksum, 32);
+			if (g.settled) {
+				g.shard[c.j] = std::move(c.s.data);
+				g.sum[c.j] = want_sum;
+				g.node[c.j] = c.node;
+				g.count++;
 				continue;
 			}
 			Geometry geo;
@@ -919,10 +950,13 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 			Gathered::Group &grp = g.groups[geo];
 			if (grp.shard.empty()) {
 				grp.shard.assign(n, Bytes());
+				grp.sum.assign(n, {});
+				grp.node.assign(n, -1);
 				grp.meta = c.s.hd;
 			}
-			mg->metrics[1] += c.s.hd.shard_len;
 			grp.shard[c.j] = std::move(c.s.data);
+			grp.sum[c.j] = want_sum;
+			grp.node[c.j] = c.node;
 			grp.count++;
 		}
 	}
@@ -930,23 +964,31 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 	// stale leftovers that resync will overwrite
 	for (size_t b = 0; b < hs.size(); ++b) {
 		Gathered &g = gs[b];
+		if (g.settled || (only && !(*only)[b]))
+			continue;
 		Gathered::Group *bestg = nullptr;
 		for (auto &kv : g.groups)
 			if (!bestg || kv.second.count > bestg->count)
 				bestg = &kv.second;
 		if (bestg) {
 			g.shard = std::move(bestg->shard);
+			g.sum = std::move(bestg->sum);
+			g.node = std::move(bestg->node);
 			g.meta = bestg->meta;
 			g.have_meta = true;
 			g.count = bestg->count;
 			g.mixed = g.groups.size() > 1;
-			if (g.mixed)
-				mg->put_to_resync(hs[b], 0);
 		} else {
 			g.shard.assign(n, Bytes());
+			g.sum.assign(n, {});
+			g.node.assign(n, -1);
 		}
+		g.settled = true;
 		g.groups.clear();
 	}
+	for (size_t b = 0; b < hs.size(); ++b)
+		if (gs[b].mixed && (!only || (*only)[b]))
+			mg->put_to_resync(hs[b], 0);
 	return GBM_OK;
 }
 
@@ -1113,58 +1155,123 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 	return result;
 }
 
-// gather + decode: on return, for every block with rcs[b] == GBM_OK, payload[b] holds orig_len bytes of the
-// stored DataBlock (plain bytes or one zstd frame) as k shard-sized pieces in g[b].shard[0..k-1].
-int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs)
+// gather + verify + decode, in rounds of ONE device trip each (gec_decode_verify_batch: shard checksums, rebuild
+// of missing data shards and the block's own blake2sum from a single upload).  A shard whose checksum does not
+// match its header is treated the way read_block_from treats a corrupt file (manager.rs:577-609): renamed
+// *.corrupted, queued for resync, and the read carries on with the next node.
+// On return, for every block with rcs[b] == GBM_OK, g[b].shard[0..k-1] hold the stored DataBlock (plain bytes or
+// one zstd frame, orig_len bytes) and block_sums[32*b..] its blake2sum (when want_block_sums).
+int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs,
+		 bool want_block_sums, std::vector<uint8_t> &block_sums)
 {
 	const int k = mg->k, n = mg->n;
 	const size_t nb = hs.size();
-	int grc = gather_many(mg, hs, tags, k, g);  // shard checksums verified in batches (GPU when large)
+	block_sums.assign(want_block_sums ? nb * 32 : 0, 0);
+	int grc = gather_many(mg, hs, tags, k, g, /*verify=*/false);
 	if (grc)
 		return grc;
-	// blocks that need a decode, grouped by shard length (one device call per group)
-	std::map<size_t, std::vector<size_t>> need;
-	for (size_t b = 0; b < nb; ++b) {
-		if (!g[b].have_meta || g[b].count < k) {
-			rcs[b] = GBM_E_MISSING_BLOCK;
-			continue;
-		}
-		rcs[b] = GBM_OK;
-		if (g[b].meta.orig_len > (uint64_t)k * g[b].meta.shard_len) {
-			rcs[b] = GBM_E_CORRUPT_DATA;
-			continue;
-		}
-		for (int j = 0; j < k; ++j)
-			if (g[b].shard[j].empty()) {
-				need[g[b].meta.shard_len].push_back(b);
-				break;
+	std::vector<uint8_t> todo(nb, 1);
+	for (int round = 0; round <= n; ++round) {
+		std::map<size_t, std::vector<size_t>> by_s;
+		for (size_t b = 0; b < nb; ++b) {
+			if (!todo[b])
+				continue;
+			if (!g[b].have_meta || g[b].count < k) {
+				rcs[b] = GBM_E_MISSING_BLOCK;
+				todo[b] = 0;
+				continue;
 			}
-	}
-	for (auto &kv : need) {
-		const size_t S = kv.first;
-		const std::vector<size_t> &ids = kv.second;
-		std::vector<const uint8_t *> sp(ids.size() * n, nullptr);
-		std::vector<uint8_t *> op(ids.size() * n, nullptr);
-		try {
-			for (size_t i = 0; i < ids.size(); ++i) {
-				Gathered &gb = g[ids[i]];
-				for (int j = 0; j < n; ++j) {
-					if (!gb.shard[j].empty()) {
-						sp[i * n + j] = gb.shard[j].data();
-					} else if (j < k) {
-						gb.shard[j] = mg->bufs->get(S);
-						op[i * n + j] = gb.shard[j].mut();
+			if (g[b].meta.orig_len > (uint64_t)k * g[b].meta.shard_len) {
+				rcs[b] = GBM_E_CORRUPT_DATA;
+				todo[b] = 0;
+				continue;
+			}
+			by_s[g[b].meta.shard_len].push_back(b);
+		}
+		if (by_s.empty())
+			break;
+		std::vector<uint8_t> again(nb, 0);
+		bool any_again = false;
+		for (auto &kv : by_s) {
+			const size_t S = kv.first;
+			const std::vector<size_t> &ids = kv.second;
+			std::vector<const uint8_t *> sp(ids.size() * n, nullptr);
+			std::vector<uint8_t *> op(ids.size() * n, nullptr);
+			std::vector<size_t> lens(ids.size());
+			std::vector<uint8_t> ssums(ids.size() * (size_t)n * 32), bsums(want_block_sums ? ids.size() * 32 : 0);
+			std::vector<std::vector<Bytes>> fresh(ids.size(), std::vector<Bytes>(k));
+			size_t nrebuild = 0;
+			try {
+				for (size_t i = 0; i < ids.size(); ++i) {
+					Gathered &gb = g[ids[i]];
+					lens[i] = gb.meta.orig_len;
+					for (int j = 0; j < n; ++j) {
+						if (!gb.shard[j].empty()) {
+							sp[i * n + j] = gb.shard[j].data();
+						} else if (j < k) {
+							fresh[i][j] = mg->bufs->get(S);
+							op[i * n + j] = fresh[i][j].mut();
+							++nrebuild;
+						}
 					}
 				}
+			} catch (const std::bad_alloc &) {
+				return fail(GBM_E_IO, "out of (pinned) host memory");
 			}
-		} catch (const std::bad_alloc &) {
-			return fail(GBM_E_IO, "out of (pinned) host memory");
+			int rc = gec_decode_verify_batch(mg->codec, ids.size(), sp.data(), S, lens.data(), op.data(), ssums.data(),
+							 want_block_sums ? bsums.data() : nullptr);
+			if (rc)
+				return ec_fail(rc, "gec_decode_verify_batch");
+			mg->gpu_hashed += ids.size() * (size_t)k + (want_block_sums ? ids.size() : 0);
+			for (size_t i = 0; i < ids.size(); ++i) {
+				const size_t b = ids[i];
+				Gathered &gb = g[b];
+				// the shards that were read: the first k present, in index order
+				int seen = 0;
+				bool bad = false;
+				for (int j = 0; j < n && seen < k; ++j) {
+					if (gb.shard[j].empty())
+						continue;
+					++seen;
+					if (std::memcmp(ssums.data() + (i * n + j) * 32, gb.sum[j].data(), 32) != 0) {
+						mg->metrics[2]++;
+						if (gb.node[j] >= 0)
+							mg->nodes[gb.node[j]]->mark_corrupted(hs[b], j);
+						mg->put_to_resync(hs[b], 0);
+						gb.shard[j] = Bytes();
+						gb.count--;
+						bad = true;
+					}
+				}
+				if (bad) {
+					again[b] = 1;
+					any_again = true;
+					continue;
+				}
+				bool rebuilt_any = false;
+				for (int j = 0; j < k; ++j)
+					if (!fresh[i][j].empty()) {
+						gb.shard[j] = fresh[i][j];
+						rebuilt_any = true;
+					}
+				if (rebuilt_any)
+					mg->metrics[3]++;
+				if (want_block_sums)
+					std::memcpy(block_sums.data() + 32 * b, bsums.data() + 32 * i, 32);
+				rcs[b] = GBM_OK;
+				todo[b] = 0;
+			}
+			(void)nrebuild;
 		}
-		int rc = gec_reconstruct_batch(mg->codec, ids.size(), sp.data(), op.data(), S, /*data_only=*/1);
-		if (rc)
-			return ec_fail(rc, "gec_reconstruct_batch");
-		mg->metrics[3] += ids.size();
+		if (!any_again)
+			break;
+		grc = gather_many(mg, hs, tags, k, g, /*verify=*/false, &again);  // the next nodes, for the blocks that lost a shard
+		if (grc)
+			return grc;
 	}
+	for (size_t b = 0; b < nb; ++b)
+		if (todo[b])
+			rcs[b] = GBM_E_MISSING_BLOCK;
 	return GBM_OK;
 }
 
@@ -1190,14 +1297,15 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 	for (size_t b = 0; b < nb; ++b)
 		hs[b].assign((const char *)hashes + 32 * b, 32);
 	std::vector<Gathered> g;
-	int frc = fetch_blocks(mg, hs, tags, g, rcs);
+	std::vector<uint8_t> block_sums;
+	const bool verify = mg->verify_block_hash.load();
+	int frc = fetch_blocks(mg, hs, tags, g, rcs, verify, block_sums);
 	if (frc)
 		return frc;
 	// assemble (parallel), then check every Plain block's content against its name (DataBlock::verify,
 	// block.rs:69-77) -- all block hashes in one batch.  Plain blocks are assembled straight into the
 	// caller's buffer and hashed from there (on CORRUPT_DATA its contents are unspecified); compressed
 	// blocks go through an intermediate for the zstd frame, whose checksum is their verify.
-	std::vector<uint8_t> want_hash(nb, 0);
 	mg->pool->parallel_for(nb, [&](size_t b) {
 		len_out[b] = 0;
 		if (rcs[b] != GBM_OK)
@@ -1207,6 +1315,12 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 		if (headers)
 			headers[b].kind = z ? GBM_HEADER_COMPRESSED : GBM_HEADER_PLAIN;
 		len_out[b] = L;
+		// DataBlock::verify (block.rs:69-83): Plain = content against its name -- the block's blake2sum came back
+		// from the same device trip that decoded it; Compressed = the zstd frame (with its checksum) decodes
+		if (!z && verify && std::memcmp(block_sums.data() + 32 * b, hashes + 32 * b, 32) != 0) {
+			rcs[b] = GBM_E_CORRUPT_DATA;
+			return;
+		}
 		if (z && !raw) {
 			std::vector<uint8_t> frame(L), plain;
 			assemble(g[b], k, frame.data());
@@ -1229,31 +1343,8 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 			return;
 		}
 		assemble(g[b], k, out[b]);
-		if (!z && mg->verify_block_hash.load())
-			want_hash[b] = 1;
-		else
-			mg->metrics[5]++;
-	});
-	std::vector<const uint8_t *> ptrs;
-	std::vector<size_t> lens, idx;
-	for (size_t b = 0; b < nb; ++b)
-		if (want_hash[b]) {
-			ptrs.push_back(out[b]);
-			lens.push_back(len_out[b]);
-			idx.push_back(b);
-		}
-	std::vector<uint8_t> sums;
-	int hrc = hash_many(mg, ptrs, lens, sums);
-	if (hrc)
-		return hrc;
-	for (size_t i = 0; i < idx.size(); ++i) {
-		const size_t b = idx[i];
-		if (std::memcmp(sums.data() + 32 * i, hashes + 32 * b, 32) != 0) {
-			rcs[b] = GBM_E_CORRUPT_DATA;
-			continue;
-		}
 		mg->metrics[5]++;
-	}
+	});
 	return GBM_OK;
 }
 

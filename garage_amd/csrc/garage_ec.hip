@@ -191,10 +191,12 @@ unsigned copy_pool_threads()
 // without the pageable -> pinned staging copy (which costs a third of the PCIe-inclusive rate).
 class PinnedRanges {
 public:
-	void add(const void *p, size_t n, bool owned)
+	// dev_delta: what to add to a host address inside the range to get the address the GPU must use
+	// (0 for hipHostMalloc; hipHostRegister may map the pages at a different device address)
+	void add(const void *p, size_t n, bool owned, intptr_t dev_delta = 0)
 	{
 		std::lock_guard<std::mutex> g(mu_);
-		ranges_[reinterpret_cast<uintptr_t>(p)] = {n, owned};
+		ranges_[reinterpret_cast<uintptr_t>(p)] = {n, owned, dev_delta};
 	}
 	// returns true and whether the library allocated it
 	bool remove(const void *p, bool &owned)
@@ -207,7 +209,7 @@ public:
 		ranges_.erase(it);
 		return true;
 	}
-	bool contains(const void *p, size_t n) const
+	bool contains(const void *p, size_t n, intptr_t *dev_delta = nullptr) const
 	{
 		if (!p)
 			return false;
@@ -219,13 +221,26 @@ public:
 		if (it == ranges_.begin())
 			return false;
 		--it;
-		return a >= it->first && a + n <= it->first + it->second.len;
+		if (!(a >= it->first && a + n <= it->first + it->second.len))
+			return false;
+		if (dev_delta)
+			*dev_delta = it->second.dev_delta;
+		return true;
+	}
+	// the address a kernel uses for host address p (p must lie in a registered range)
+	template <class T>
+	T *dev(T *p) const
+	{
+		intptr_t d = 0;
+		contains(p, 1, &d);
+		return reinterpret_cast<T *>(reinterpret_cast<intptr_t>(p) + d);
 	}
 
 private:
 	struct R {
 		size_t len;
 		bool owned;
+		intptr_t dev_delta;
 	};
 	mutable std::mutex mu_;
 	std::map<uintptr_t, R> ranges_;
@@ -247,6 +262,39 @@ struct Staging {
 	size_t cap = 0;
 	uint32_t *d_bad = nullptr, *h_bad = nullptr;
 	size_t bad_cap = 0;
+	// copy tables of the zero-copy path (pinned, read by the copy_table kernel straight from host memory)
+	gec::CopyEntry *h_tab = nullptr;
+	size_t tab_cap = 0, tab_used = 0;
+	// whole-batch device buffer of the read path (gec_decode_verify_batch): grow-only
+	uint8_t *d_big = nullptr;
+	size_t big_cap = 0;
+
+	int ensure_big(size_t bytes)
+	{
+		if (bytes <= big_cap)
+			return GEC_OK;
+		if (d_big)
+			(void)hipFree(d_big);
+		d_big = nullptr;
+		big_cap = 0;
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_big), bytes));
+		big_cap = bytes;
+		return GEC_OK;
+	}
+
+	int ensure_tab(size_t entries)
+	{
+		tab_used = 0;
+		if (entries <= tab_cap)
+			return GEC_OK;
+		if (h_tab)
+			(void)hipHostFree(h_tab);
+		h_tab = nullptr;
+		tab_cap = 0;
+		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_tab), entries * sizeof(gec::CopyEntry), hipHostMallocDefault));
+		tab_cap = entries;
+		return GEC_OK;
+	}
 
 	int ensure(size_t bytes, size_t nbad)
 	{
@@ -291,6 +339,10 @@ struct Staging {
 			(void)hipHostFree(h_bad);
 		if (d_bad)
 			(void)hipFree(d_bad);
+		if (h_tab)
+			(void)hipHostFree(h_tab);
+		if (d_big)
+			(void)hipFree(d_big);
 		if (stream)
 			(void)hipStreamDestroy(stream);
 		if (stream2)
@@ -809,6 +861,33 @@ int reconstruct_dev(const gec_codec *c, size_t nblocks, uint8_t *d_base, size_t 
 	return launch_apply(c, d_base, stride, d_base, stride, nullptr, byte_off, byte_len, nblocks, in_off.data(),
 			    out_off.data(), (int)plan->missing.size(), plan->rows.v.data(), gec::MODE_STORE, stream);
 }
+
+// Appends `n` entries to the slot's table and launches ONE copy_table kernel over them.  Entries must have
+// 16-byte aligned src and dst (callers check with copyable()).
+int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipStream_t stream)
+{
+	if (ents.empty())
+		return GEC_OK;
+	if (st.tab_used + ents.size() > st.tab_cap)
+		return fail(GEC_E_INVALID_ARG, "copy table overflow");
+	gec::CopyEntry *tab = st.h_tab + st.tab_used;
+	uint64_t maxb = 0;
+	for (size_t i = 0; i < ents.size(); ++i) {
+		tab[i] = ents[i];
+		maxb = std::max<uint64_t>(maxb, ents[i].bytes);
+	}
+	st.tab_used += ents.size();
+	const unsigned gx = (unsigned)((maxb >> 4) / 1024 + 1);
+	// grid.y <= 65535: split long tables
+	for (size_t e0 = 0; e0 < ents.size(); e0 += 65535) {
+		const unsigned gy = (unsigned)std::min<size_t>(65535, ents.size() - e0);
+		hipLaunchKernelGGL(gec::copy_table, dim3(gx, gy), dim3(256), 0, stream, tab + e0);
+		HIP_TRY(hipGetLastError());
+	}
+	return GEC_OK;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Encode + the blake2sum of all k+m shards of every stripe (d_stripes: shard j of block b at b*stride + j*S),
 // everything enqueued behind whatever `stream` already holds.  The checksums of the k data shards do not depend
@@ -1432,8 +1511,11 @@ int gec_host_register(void *p, size_t bytes)
 {
 	if (!p || bytes == 0)
 		return fail(GEC_E_INVALID_ARG, "NULL / empty range");
-	HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable));
-	pinned().add(p, bytes, false);
+	HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+	void *dptr = p;
+	if (hipHostGetDevicePointer(&dptr, p, 0) != hipSuccess || !dptr)
+		dptr = p;
+	pinned().add(p, bytes, false, reinterpret_cast<intptr_t>(dptr) - reinterpret_cast<intptr_t>(p));
 	return GEC_OK;
 }
 
@@ -1486,15 +1568,16 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 	std::vector<size_t> min_len(nchunks, k * S);
 	for (size_t b = 0; b < nblocks; ++b) {
 		const size_t ci = b / ch;
-		if (in_pinned[ci] && !pinned().contains(blocks[b], block_len[b]))
+		if (in_pinned[ci] && !(aligned16(blocks[b]) && pinned().contains(blocks[b], block_len[b])))
 			in_pinned[ci] = 0;
-		if (out_pinned[ci] && !pinned().contains(parity[b], m * S))
+		if (out_pinned[ci] && !(aligned16(parity[b]) && pinned().contains(parity[b], m * S)))
 			out_pinned[ci] = 0;
 		min_len[ci] = std::min(min_len[ci], block_len[b]);
 	}
 	return run_pipeline(
 		c, nchunks, ch * stripe + (shard_sums ? ch * n * 32 : 0), 0,
 		[&](size_t ci, Staging &st) {  // host: user blocks -> pinned, zero-padded to k*S
+			(void)st.ensure_tab(2 * ch);  // a failure shows up as "copy table overflow" when the table is used
 			if (in_pinned[ci])
 				return;
 			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
@@ -1512,19 +1595,15 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 				// every block straight from the caller's memory
 				if (min_len[ci] < k * S)
 					HIP_TRY(hipMemset2DAsync(st.d_buf + min_len[ci], stripe, 0, k * S - min_len[ci], nb, st.stream));
-				// equally spaced, equally long blocks (one big pinned arena): ONE strided copy
-				const size_t len0 = block_len[b0];
-				bool strided = nb > 1 && blocks[b0 + 1] > blocks[b0];
-				const size_t pitch = nb > 1 ? (size_t)(blocks[b0 + 1] - blocks[b0]) : 0;
-				for (size_t i = 0; i < nb && strided; ++i)
-					strided = block_len[b0 + i] == len0 && blocks[b0 + i] == blocks[b0] + i * pitch;
-				if (strided && pitch >= len0 && len0 > 0) {
-					HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, blocks[b0], pitch, len0, nb, hipMemcpyHostToDevice, st.stream));
-				} else {
-					for (size_t i = 0; i < nb; ++i)
-						if (block_len[b0 + i])
-							HIP_TRY(hipMemcpyAsync(st.d_buf + i * stripe, blocks[b0 + i], block_len[b0 + i], hipMemcpyHostToDevice, st.stream));
-				}
+				// ONE copy_table launch: the kernel reads every block straight from the caller's pinned memory
+				std::vector<gec::CopyEntry> ents;
+				ents.reserve(nb);
+				for (size_t i = 0; i < nb; ++i)
+					if (block_len[b0 + i])
+						ents.push_back({pinned().dev(blocks[b0 + i]), st.d_buf + i * stripe, block_len[b0 + i]});
+				int rct = launch_copy_table(st, ents, st.stream);
+				if (rct)
+					return rct;
 			} else {
 				HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, st.h_buf, stripe, k * S, nb, hipMemcpyHostToDevice, st.stream));
 			}
@@ -1533,16 +1612,13 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 			if (rc)
 				return rc;
 			if (out_pinned[ci]) {
-				bool strided = nb > 1 && parity[b0 + 1] > parity[b0];
-				const size_t pitch = nb > 1 ? (size_t)(parity[b0 + 1] - parity[b0]) : 0;
-				for (size_t i = 0; i < nb && strided; ++i)
-					strided = parity[b0 + i] == parity[b0] + i * pitch;
-				if (strided && pitch >= m * S) {
-					HIP_TRY(hipMemcpy2DAsync(parity[b0], pitch, st.d_buf + k * S, stripe, m * S, nb, hipMemcpyDeviceToHost, st.stream));
-				} else {
-					for (size_t i = 0; i < nb; ++i)
-						HIP_TRY(hipMemcpyAsync(parity[b0 + i], st.d_buf + i * stripe + k * S, m * S, hipMemcpyDeviceToHost, st.stream));
-				}
+				std::vector<gec::CopyEntry> ents;
+				ents.reserve(nb);
+				for (size_t i = 0; i < nb; ++i)
+					ents.push_back({st.d_buf + i * stripe + k * S, pinned().dev(parity[b0 + i]), m * S});
+				int rct = launch_copy_table(st, ents, st.stream);
+				if (rct)
+					return rct;
 			} else {
 				HIP_TRY(hipMemcpy2DAsync(st.h_buf + k * S, stripe, st.d_buf + k * S, stripe, m * S, nb, hipMemcpyDeviceToHost, st.stream));
 			}
@@ -1623,7 +1699,125 @@ int gec_blake2sum_batch(const gec_codec *c, size_t n, const uint8_t *const *msgs
 	for (size_t i = 0; i < n; ++i)
 		if (!msgs[i] && lens[i])
 			return fail(GEC_E_INVALID_ARG, "NULL message pointer");
-	// greedy chunks of <= kChunkBytes of (16-byte aligned) message slots
+	size_t longest = 0;
+	bool all_pinned = true;
+	for (size_t i = 0; i < n; ++i) {
+		longest = std::max(longest, lens[i]);
+		if (all_pinned && lens[i] && !(aligned16(msgs[i]) && pinned().contains(msgs[i], lens[i])))
+			all_pinned = false;
+	}
+	// (a) every message in pinned, 16-byte aligned caller memory: NO copy at all -- ONE launch whose lanes
+	//     stream their messages straight from host memory over PCIe; only the (offset, length) table and the
+	//     32-byte results go through a staging slot.
+	// (b) long messages (a BLAKE2b chain costs ~4000 cycles per 128-byte block however many messages run
+	//     beside it: 14 ms per MiB): everything is first moved into ONE device buffer through two pinned
+	//     staging pieces, then hashed by ONE launch -- chunked launches would pay the chain once per chunk.
+	if (all_pinned || longest >= (256u << 10)) {
+		DeviceGuard dg(c->device);
+		if (!dg.ok)
+			return fail(GEC_E_DEVICE, "hipSetDevice failed");
+		constexpr size_t kPiece = 32ull << 20;
+		std::vector<uint64_t> off(n);
+		size_t dev_bytes = 0;
+		for (size_t i = 0; i < n; ++i) {
+			off[i] = dev_bytes;
+			dev_bytes += (lens[i] + 15) / 16 * 16;
+		}
+		if (!all_pinned && dev_bytes > (8ull << 30)) {
+			// more than a device buffer should hold at once: halves (each still one launch)
+			const size_t h = n / 2;
+			int rc = gec_blake2sum_batch(c, h, msgs, lens, out);
+			return rc ? rc : gec_blake2sum_batch(c, n - h, msgs + h, lens + h, out + 32 * h);
+		}
+		StagingLease l0(c);
+		const size_t meta = n * 16, res = n * 32;
+		const size_t meta_off = all_pinned ? 0 : 2 * kPiece;  // h_buf of slot 0: [piece A][piece B][off][len][out]
+		int rc = l0.st.ensure(meta_off + meta + res + 64, 0);
+		if (rc)
+			return rc;
+		Staging &st = l0.st;
+		uint8_t *d_msgs = nullptr;
+		if (!all_pinned)
+			HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_msgs), std::max<size_t>(dev_bytes, 16)));
+		uint64_t *h_off = reinterpret_cast<uint64_t *>(st.h_buf + meta_off);
+		uint64_t *h_len = h_off + n;
+		uint8_t *h_out = st.h_buf + meta_off + meta;
+		for (size_t i = 0; i < n; ++i) {
+			h_off[i] = all_pinned ? reinterpret_cast<uint64_t>(pinned().dev(msgs[i])) : off[i];
+			h_len[i] = lens[i];
+		}
+		auto cleanup = [&](int code) {
+			if (d_msgs) {
+				(void)hipStreamSynchronize(st.stream);
+				(void)hipFree(d_msgs);
+			}
+			return code;
+		};
+		if (!all_pinned) {
+			// two staging pieces, filled by the copy pool while the other one is on the bus
+			CopyPool &pool = c->copy_pool();
+			hipEvent_t done[2] = {st.ev_fork, st.ev_join};
+			bool used[2] = {false, false};
+			size_t piece = 0;
+			for (size_t i = 0; i < n;) {
+				// messages (or parts of a long one) that fit the piece
+				uint8_t *hp = st.h_buf + (piece & 1) * kPiece;
+				if (used[piece & 1]) {
+					hipError_t e = hipEventSynchronize(done[piece & 1]);
+					if (e != hipSuccess)
+						return cleanup(fail(GEC_E_DEVICE, std::string("hipEventSynchronize: ") + hipGetErrorString(e)));
+				}
+				const size_t d0 = off[i];
+				size_t j = i, bytes = 0;
+				while (j < n && bytes + (lens[j] + 15) / 16 * 16 <= kPiece) {
+					bytes += (lens[j] + 15) / 16 * 16;
+					++j;
+				}
+				if (j == i) {  // one message longer than a piece: stream it through in piece-sized parts
+					for (size_t o = 0; o < lens[i]; o += kPiece) {
+						hp = st.h_buf + (piece & 1) * kPiece;
+						if (used[piece & 1] && hipEventSynchronize(done[piece & 1]) != hipSuccess)
+							return cleanup(fail(GEC_E_DEVICE, "hipEventSynchronize failed"));
+						const size_t nbytes = std::min(kPiece, lens[i] - o);
+						const size_t parts = (nbytes + (1 << 20) - 1) >> 20;
+						pool.parallel_for(parts, [&](size_t q) {
+							const size_t a = q << 20, b = std::min(nbytes, a + (1 << 20));
+							std::memcpy(hp + a, msgs[i] + o + a, b - a);
+						});
+						hipError_t e = hipMemcpyAsync(d_msgs + off[i] + o, hp, nbytes, hipMemcpyHostToDevice, st.stream);
+						if (e == hipSuccess)
+							e = hipEventRecord(done[piece & 1], st.stream);
+						if (e != hipSuccess)
+							return cleanup(fail(GEC_E_DEVICE, std::string("H2D: ") + hipGetErrorString(e)));
+						used[piece & 1] = true;
+						++piece;
+					}
+					++i;
+					continue;
+				}
+				pool.parallel_for(j - i, [&](size_t q) { std::memcpy(hp + (off[i + q] - d0), msgs[i + q], lens[i + q]); });
+				hipError_t e = hipMemcpyAsync(d_msgs + d0, hp, bytes, hipMemcpyHostToDevice, st.stream);
+				if (e == hipSuccess)
+					e = hipEventRecord(done[piece & 1], st.stream);
+				if (e != hipSuccess)
+					return cleanup(fail(GEC_E_DEVICE, std::string("H2D: ") + hipGetErrorString(e)));
+				used[piece & 1] = true;
+				++piece;
+				i = j;
+			}
+		}
+		// the (offset, length) table and the results live in pinned host memory the kernel reads / writes directly
+		rc = blake2_dev(n, all_pinned ? nullptr : d_msgs, h_off, h_len, 0, 0, h_out, st.stream);
+		if (rc)
+			return cleanup(rc);
+		hipError_t e = hipStreamSynchronize(st.stream);
+		if (e != hipSuccess)
+			return cleanup(fail(GEC_E_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)));
+		std::memcpy(out, h_out, res);
+		return cleanup(GEC_OK);
+	}
+	// (c) many short messages in pageable memory: greedy chunks of <= 4*kChunkBytes of (16-byte aligned) message
+	//     slots through the two-slot pipeline (hashing of chunk i overlaps the upload of chunk i+1)
 	struct Chunk {
 		size_t first, count, bytes;
 	};
@@ -1673,6 +1867,258 @@ int gec_blake2sum_batch(const gec_codec *c, size_t n, const uint8_t *const *msgs
 			const Chunk &ck = chunks[ci];
 			std::memcpy(out + 32 * ck.first, st.h_buf + out_off, 32 * ck.count);
 		});
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The read path in ONE trip (twin of gec_encode_hash_batch): upload the k shards each block is read from,
+// checksum every uploaded shard, rebuild missing data shards, checksum the assembled block.
+int gec_decode_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, size_t S,
+			    const size_t *block_len, uint8_t *const *rebuilt, uint8_t *shard_sums, uint8_t *block_sums)
+{
+	if (!c)
+		return fail(GEC_E_INVALID_ARG, "NULL codec");
+	if (nblocks == 0)
+		return GEC_OK;
+	if (!shards || !shard_sums || (block_sums && !block_len))
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (S == 0)
+		return fail(GEC_E_EMPTY_SHARD, "shard length is 0");
+	if (S % 64)
+		return fail(GEC_E_INCORRECT_SHARD_SIZE, "S must be a multiple of 64");
+	const size_t k = c->k, n = c->k + c->m;
+	// more than one device buffer should hold: halves
+	const size_t kMaxBytes = 6ull << 30;
+	if (nblocks > 1 && nblocks * n * S > kMaxBytes) {
+		const size_t h = nblocks / 2;
+		int rc = gec_decode_verify_batch(c, h, shards, S, block_len, rebuilt, shard_sums, block_sums);
+		if (rc)
+			return rc;
+		return gec_decode_verify_batch(c, nblocks - h, shards + h * n, S, block_len ? block_len + h : nullptr,
+					       rebuilt ? rebuilt + h * n : nullptr, shard_sums + h * n * 32,
+					       block_sums ? block_sums + h * 32 : nullptr);
+	}
+	// -- per block: which shards are read (the crate's rule: the first k present), which data shards are rebuilt;
+	//    blocks are laid out on the device bucket by bucket (one erasure pattern each), a block's stripe holding
+	//    its k data slots followed by one slot per parity shard it is decoded from
+	struct Bucket {
+		std::shared_ptr<const Plan> plan;
+		std::vector<size_t> ids;
+		size_t base = 0, stripe = 0, npar = 0;
+	};
+	std::map<std::string, Bucket> buckets;
+	for (size_t b = 0; b < nblocks; ++b) {
+		std::string key(n, 0);
+		size_t np = 0;
+		for (size_t j = 0; j < n; ++j) {
+			key[j] = shards[b * n + j] ? 1 : 0;
+			np += key[j];
+		}
+		if (np < k)
+			return fail(GEC_E_TOO_FEW_PRESENT, "fewer than k shards present");
+		if (block_len && block_len[b] > k * S)
+			return fail(GEC_E_INCORRECT_SHARD_SIZE, "block longer than k*S");
+		buckets[key].ids.push_back(b);
+	}
+	size_t dev_bytes = 0, nup = 0, nreb = 0;
+	for (auto &kv : buckets) {
+		Bucket &bk = kv.second;
+		int rc = get_plan(c, reinterpret_cast<const uint8_t *>(kv.first.data()), true, bk.plan);
+		if (rc)
+			return rc;
+		bk.npar = bk.plan->missing.size();  // as many parity inputs as data shards to rebuild
+		bk.stripe = (k + bk.npar) * S;
+		bk.base = dev_bytes;
+		dev_bytes += bk.ids.size() * bk.stripe;
+		nup += bk.ids.size() * k;
+		nreb += bk.ids.size() * bk.npar;
+		for (size_t b : bk.ids)
+			for (int j : bk.plan->missing)
+				if (!rebuilt || !rebuilt[b * n + j])
+					return fail(GEC_E_INVALID_ARG, "NULL output for a missing data shard");
+	}
+	DeviceGuard dg(c->device);
+	if (!dg.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	StagingLease lease(c);
+	Staging &st = lease.st;
+	constexpr size_t kPiece = 32ull << 20;
+	// host staging: [piece A][piece B][shard off | shard len | block off | block len][shard sums][block sums][rebuilt]
+	const size_t tab_off = 2 * kPiece;
+	const size_t tab_bytes = (nup * 2 + nblocks * 2) * 8;
+	const size_t ssum_off = tab_off + tab_bytes, bsum_off = ssum_off + nup * 32;
+	const size_t reb_off = (bsum_off + nblocks * 32 + 63) / 64 * 64;
+	int rc = st.ensure(reb_off + nreb * S + 64, 0);
+	if (rc)
+		return rc;
+	rc = st.ensure_big(std::max<size_t>(dev_bytes, 64));
+	if (rc)
+		return rc;
+	rc = st.ensure_tab(nup + nreb);
+	if (rc)
+		return rc;
+	uint64_t *h_soff = reinterpret_cast<uint64_t *>(st.h_buf + tab_off), *h_slen = h_soff + nup;
+	uint64_t *h_boff = h_slen + nup, *h_blen = h_boff + nblocks;
+	// -- upload list, in device order
+	struct Up {
+		const uint8_t *src;
+		size_t dst;  // byte offset in d_big
+		size_t idx;  // (b*n + j): where the shard's checksum goes
+	};
+	std::vector<Up> ups;
+	ups.reserve(nup);
+	bool all_pinned = true;
+	for (auto &kv : buckets) {
+		Bucket &bk = kv.second;
+		for (size_t i = 0; i < bk.ids.size(); ++i) {
+			const size_t b = bk.ids[i];
+			size_t q = 0;  // parity input slot
+			for (size_t t = 0; t < k; ++t) {
+				const int j = bk.plan->valid[t];
+				const size_t slot = (size_t)j < k ? (size_t)j : k + q++;
+				const uint8_t *p = shards[b * n + j];
+				ups.push_back({p, bk.base + i * bk.stripe + slot * S, b * n + j});
+				if (all_pinned && !(aligned16(p) && pinned().contains(p, S)))
+					all_pinned = false;
+			}
+		}
+	}
+	std::sort(ups.begin(), ups.end(), [](const Up &a, const Up &b) { return a.dst < b.dst; });
+	for (size_t i = 0; i < ups.size(); ++i) {
+		h_soff[i] = ups[i].dst;
+		h_slen[i] = S;
+	}
+	size_t bi = 0;
+	std::vector<size_t> block_order(nblocks);
+	for (auto &kv : buckets)
+		for (size_t i = 0; i < kv.second.ids.size(); ++i) {
+			h_boff[bi] = kv.second.base + i * kv.second.stripe;
+			h_blen[bi] = block_len ? block_len[kv.second.ids[i]] : 0;
+			block_order[bi++] = kv.second.ids[i];
+		}
+	auto hip_fail = [&](hipError_t e, const char *what) { return fail(GEC_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); };
+	if (all_pinned) {
+		std::vector<gec::CopyEntry> ents;
+		ents.reserve(ups.size());
+		for (size_t i = 0; i < ups.size();) {  // merge neighbours (the data shards of a block are slices of one buffer)
+			size_t run = 1;
+			while (i + run < ups.size() && ups[i + run].src == ups[i].src + run * S && ups[i + run].dst == ups[i].dst + run * S)
+				++run;
+			ents.push_back({pinned().dev(ups[i].src), st.d_big + ups[i].dst, run * S});
+			i += run;
+		}
+		rc = launch_copy_table(st, ents, st.stream);
+		if (rc)
+			return rc;
+	} else {
+		// pageable shards: the pieces are images of dense device ranges, filled by the copy pool while the other is on the bus
+		CopyPool &pool = c->copy_pool();
+		hipEvent_t done[2] = {st.ev_fork, st.ev_join};
+		bool used[2] = {false, false};
+		size_t piece = 0;
+		for (size_t i = 0; i < ups.size();) {
+			uint8_t *hp = st.h_buf + (piece & 1) * kPiece;
+			if (used[piece & 1]) {
+				hipError_t e = hipEventSynchronize(done[piece & 1]);
+				if (e != hipSuccess)
+					return hip_fail(e, "hipEventSynchronize");
+			}
+			const size_t d0 = ups[i].dst;
+			size_t j = i;
+			while (j < ups.size() && ups[j].dst + S - d0 <= kPiece)
+				++j;
+			if (j == i)
+				return fail(GEC_E_INVALID_ARG, "shard larger than a staging piece");
+			const size_t bytes = ups[j - 1].dst + S - d0;
+			pool.parallel_for(j - i, [&](size_t q) { std::memcpy(hp + (ups[i + q].dst - d0), ups[i + q].src, S); });
+			hipError_t e = hipMemcpyAsync(st.d_big + d0, hp, bytes, hipMemcpyHostToDevice, st.stream);
+			if (e == hipSuccess)
+				e = hipEventRecord(done[piece & 1], st.stream);
+			if (e != hipSuccess)
+				return hip_fail(e, "H2D");
+			used[piece & 1] = true;
+			++piece;
+			i = j;
+		}
+	}
+	// -- everything is on the device.  Shard checksums on the partner stream (they depend on nothing else); on the
+	//    main stream: decode per bucket, then the block checksums, then the rebuilt shards go home.
+	hipEvent_t ev_up = nullptr, ev_sh = nullptr;
+	HIP_TRY(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
+	HIP_TRY(hipEventCreateWithFlags(&ev_sh, hipEventDisableTiming));
+	auto finish = [&](int code) {
+		(void)hipStreamSynchronize(st.stream);
+		(void)hipStreamSynchronize(st.stream2);
+		(void)hipEventDestroy(ev_up);
+		(void)hipEventDestroy(ev_sh);
+		return code;
+	};
+	hipError_t e = hipEventRecord(ev_up, st.stream);
+	if (e == hipSuccess)
+		e = hipStreamWaitEvent(st.stream2, ev_up, 0);
+	if (e != hipSuccess)
+		return finish(hip_fail(e, "fork"));
+	rc = blake2_dev(nup, st.d_big, h_soff, h_slen, 0, 0, st.h_buf + ssum_off, st.stream2);
+	if (rc)
+		return finish(rc);
+	e = hipEventRecord(ev_sh, st.stream2);
+	if (e != hipSuccess)
+		return finish(hip_fail(e, "hipEventRecord"));
+	std::vector<gec::CopyEntry> outs;
+	size_t rq = 0;
+	for (auto &kv : buckets) {
+		Bucket &bk = kv.second;
+		if (bk.npar == 0)
+			continue;
+		std::vector<size_t> in_off(k), out_off(bk.npar);
+		size_t q = 0;
+		for (size_t t = 0; t < k; ++t) {
+			const int j = bk.plan->valid[t];
+			in_off[t] = ((size_t)j < k ? (size_t)j : k + q++) * S;
+		}
+		for (size_t r = 0; r < bk.npar; ++r)
+			out_off[r] = (size_t)bk.plan->missing[r] * S;  // rebuilt in place, in the block's data area
+		rc = launch_apply(c, st.d_big + bk.base, bk.stripe, st.d_big + bk.base, bk.stripe, nullptr, 0, S, bk.ids.size(),
+				  in_off.data(), out_off.data(), (int)bk.npar, bk.plan->rows.v.data(), gec::MODE_STORE, st.stream);
+		if (rc)
+			return finish(rc);
+		for (size_t i = 0; i < bk.ids.size(); ++i)
+			for (size_t r = 0; r < bk.npar; ++r) {
+				uint8_t *dst = rebuilt[bk.ids[i] * n + bk.plan->missing[r]];
+				const bool direct = aligned16(dst) && pinned().contains(dst, S);
+				outs.push_back({st.d_big + bk.base + i * bk.stripe + out_off[r], direct ? pinned().dev(dst) : st.h_buf + reb_off + rq * S, S});
+				++rq;
+			}
+	}
+	if (block_sums) {
+		rc = blake2_dev(nblocks, st.d_big, h_boff, h_blen, 0, 0, st.h_buf + bsum_off, st.stream);
+		if (rc)
+			return finish(rc);
+	}
+	rc = launch_copy_table(st, outs, st.stream);
+	if (rc)
+		return finish(rc);
+	e = hipStreamWaitEvent(st.stream, ev_sh, 0);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(st.stream);
+	if (e != hipSuccess)
+		return finish(hip_fail(e, "hipStreamSynchronize"));
+	// -- results: checksums to where the caller indexes them, rebuilt shards that could not be written directly
+	for (size_t i = 0; i < ups.size(); ++i)
+		std::memcpy(shard_sums + 32 * ups[i].idx, st.h_buf + ssum_off + 32 * i, 32);
+	if (block_sums)
+		for (size_t i = 0; i < nblocks; ++i)
+			std::memcpy(block_sums + 32 * block_order[i], st.h_buf + bsum_off + 32 * i, 32);
+	rq = 0;
+	for (auto &kv : buckets) {
+		Bucket &bk = kv.second;
+		for (size_t i = 0; i < bk.ids.size(); ++i)
+			for (size_t r = 0; r < bk.npar; ++r, ++rq) {
+				uint8_t *dst = rebuilt[bk.ids[i] * n + bk.plan->missing[r]];
+				if (!(aligned16(dst) && pinned().contains(dst, S)))
+					std::memcpy(dst, st.h_buf + reb_off + rq * S, S);
+			}
+	}
+	return finish(GEC_OK);
 }
 
 int gec_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, size_t S, uint8_t *ok)
@@ -1794,15 +2240,16 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 		for (size_t i = 0; i < ids.size(); ++i) {
 			const size_t ci = i / ch;
 			for (size_t t = 0; t < k && in_pinned[ci]; ++t)
-				if (!pinned().contains(shards[ids[i] * n + plan->valid[t]], S))
+				if (!(aligned16(shards[ids[i] * n + plan->valid[t]]) && pinned().contains(shards[ids[i] * n + plan->valid[t]], S)))
 					in_pinned[ci] = 0;
 			for (size_t r = 0; r < nmiss && out_pinned[ci]; ++r)
-				if (!pinned().contains(out[ids[i] * n + plan->missing[r]], S))
+				if (!(aligned16(out[ids[i] * n + plan->missing[r]]) && pinned().contains(out[ids[i] * n + plan->missing[r]], S)))
 					out_pinned[ci] = 0;
 		}
 		rc = run_pipeline(
 			c, nchunks, ch * stripe, 0,
 			[&](size_t ci, Staging &st) {
+				(void)st.ensure_tab(ch * (k + nmiss));
 				if (in_pinned[ci])
 					return;
 				const size_t i0 = ci * ch, nb = std::min(ch, ids.size() - i0);
@@ -1814,16 +2261,21 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 			[&](size_t ci, Staging &st) -> int {
 				const size_t i0 = ci * ch, nb = std::min(ch, ids.size() - i0);
 				if (in_pinned[ci]) {
+					std::vector<gec::CopyEntry> ents;
+					ents.reserve(nb * 3);
 					for (size_t i = 0; i < nb; ++i) {
 						const uint8_t *const *sh = shards + ids[i0 + i] * n;
-						for (size_t t = 0; t < k;) {
+						for (size_t t = 0; t < k;) {  // adjacent shards (slices of one block buffer): one entry
 							size_t run = 1;
 							while (t + run < k && sh[plan->valid[t + run]] == sh[plan->valid[t]] + run * S)
 								++run;
-							HIP_TRY(hipMemcpyAsync(st.d_buf + i * stripe + t * S, sh[plan->valid[t]], run * S, hipMemcpyHostToDevice, st.stream));
+							ents.push_back({pinned().dev(sh[plan->valid[t]]), st.d_buf + i * stripe + t * S, run * S});
 							t += run;
 						}
 					}
+					int rct = launch_copy_table(st, ents, st.stream);
+					if (rct)
+						return rct;
 				} else {
 					HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, st.h_buf, stripe, k * S, nb, hipMemcpyHostToDevice, st.stream));
 				}
@@ -1832,16 +2284,16 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 				if (r2)
 					return r2;
 				if (out_pinned[ci]) {
+					std::vector<gec::CopyEntry> ents;
+					ents.reserve(nb * nmiss);
 					for (size_t i = 0; i < nb; ++i) {
 						uint8_t *const *o = out + ids[i0 + i] * n;
-						for (size_t r = 0; r < nmiss;) {
-							size_t run = 1;
-							while (r + run < nmiss && o[plan->missing[r + run]] == o[plan->missing[r]] + run * S)
-								++run;
-							HIP_TRY(hipMemcpyAsync(o[plan->missing[r]], st.d_buf + i * stripe + (k + r) * S, run * S, hipMemcpyDeviceToHost, st.stream));
-							r += run;
-						}
+						for (size_t r = 0; r < nmiss; ++r)
+							ents.push_back({st.d_buf + i * stripe + (k + r) * S, pinned().dev(o[plan->missing[r]]), S});
 					}
+					int rct = launch_copy_table(st, ents, st.stream);
+					if (rct)
+						return rct;
 				} else {
 					HIP_TRY(hipMemcpy2DAsync(st.h_buf + k * S, stripe, st.d_buf + k * S, stripe, nmiss * S, nb, hipMemcpyDeviceToHost, st.stream));
 				}

@@ -372,6 +372,46 @@ __global__ void clear_flags(uint32_t *p, uint32_t n)
 }
 
 // ---------------------------------------------------------------------------
+// copy_table: a batch of independent byte-range copies in ONE launch -- entry e moves `bytes` bytes from src to
+// dst; either side may be PINNED HOST memory, which the kernel reads / writes directly over PCIe.  This is how
+// caller buffers registered with gec_host_alloc / gec_host_register reach the device stripes and how parity
+// gets back: tools/pcie_probe measures 55 GB/s for such a kernel, against 36-47 GB/s for the same pieces as
+// individual hipMemcpyAsync calls (per-copy engine overhead) and 57 GB/s for one huge DMA.
+// src and dst of every entry are 16-byte aligned (the host checks); the last <16 bytes go byte-wise.
+// blockIdx.y = entry, blockIdx.x = 16 KiB tile of the entry (the grid covers the largest entry).
+// ---------------------------------------------------------------------------
+struct CopyEntry {
+	const uint8_t *src;
+	uint8_t *dst;
+	uint64_t bytes;
+};
+
+__global__ __launch_bounds__(256) void copy_table(const CopyEntry *__restrict__ tab)
+{
+	const CopyEntry e = tab[blockIdx.y];
+	const uint64_t nvec = e.bytes >> 4;
+	const uint64_t base = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+	if ((uint64_t)blockIdx.x * 1024 >= nvec + 1)  // whole tile past the end (tail handled by the tile that holds nvec)
+		return;
+	const u32x4 *s = reinterpret_cast<const u32x4 *>(e.src);
+	u32x4 *d = reinterpret_cast<u32x4 *>(e.dst);
+	u32x4 v[4];
+#pragma unroll
+	for (int j = 0; j < 4; ++j)
+		if (base + j * 256 < nvec)
+			v[j] = __builtin_nontemporal_load(s + base + j * 256);
+#pragma unroll
+	for (int j = 0; j < 4; ++j)
+		if (base + j * 256 < nvec)
+			__builtin_nontemporal_store(v[j], d + base + j * 256);
+	// ragged tail: one thread of the tile that contains vector index nvec
+	const uint64_t tail = e.bytes & 15;
+	if (tail && nvec / 1024 == blockIdx.x && threadIdx.x == 0)
+		for (uint64_t b = 0; b < tail; ++b)
+			e.dst[(nvec << 4) + b] = e.src[(nvec << 4) + b];
+}
+
+// ---------------------------------------------------------------------------
 // Striped decode, step 3 (gec_group_allgather_decode): after every rank rebuilt its byte
 // range of each missing shard inside the gathered buffer, the ranges are exchanged with a
 // second all-gather.  range_pack gathers THIS rank's ranges into a dense send buffer

@@ -300,6 +300,24 @@ int gec_encode_hash_batch(const gec_codec *c, size_t nblocks,
 			  const uint8_t *const *blocks, const size_t *block_len,
 			  size_t S, uint8_t *const *parity, uint8_t *shard_sums);
 
+/* The read path in ONE trip to the device -- the twin of gec_encode_hash_batch, for what
+ * rpc_get_raw_block_internal does after gathering (src/block/manager.rs:292-334) plus the verify that
+ * read_block_from does on the serving node (:577-609):
+ *   - shards[b*n + j] (S bytes each, NULL = not in hand; >= k per block, else GEC_E_TOO_FEW_PRESENT): the first
+ *     k present shards of every block are uploaded (the crate's rule);
+ *   - shard_sums[(b*n + j)*32] receives the blake2sum of every shard that was uploaded (entries of the others
+ *     are left untouched) -- the caller compares them with the checksums in the shard headers;
+ *   - missing DATA shards are rebuilt into rebuilt[b*n + j] (S bytes; must be non-NULL exactly for those);
+ *   - block_sums (may be NULL): blake2sum of the first block_len[b] bytes of block b's data area, i.e. of the
+ *     block itself (DataBlock::verify's content-against-name check, src/block/block.rs:69-77).
+ * Every checksum kernel runs ONCE over the whole batch (a BLAKE2b chain costs the same however many messages
+ * run beside it), the shard checksums beside the decode on a second stream.  Buffers inside pinned ranges
+ * (gec_host_alloc / gec_host_register) are read and written by copy kernels directly; others are staged. */
+int gec_decode_verify_batch(const gec_codec *c, size_t nblocks,
+			    const uint8_t *const *shards, size_t S,
+			    const size_t *block_len, uint8_t *const *rebuilt,
+			    uint8_t *shard_sums, uint8_t *block_sums);
+
 /* Device-resident form: stripes already in HBM (shard j of block b at d_stripes + b*stride + j*S), parity
  * written in place, d_sums (16-byte aligned device memory, nblocks*(k+m)*32 bytes) receives the checksums.
  * Asynchronous: everything is ordered behind / ahead of the work on `hip_stream`; internally the checksums

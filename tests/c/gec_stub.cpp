@@ -88,6 +88,45 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nb, const uint8_t *const *s
 	return GEC_OK;
 }
 
+// read path in one trip: checksums of the first k present shards, rebuild of missing data shards, block checksum
+int gec_decode_verify_batch(const gec_codec *c, size_t nb, const uint8_t *const *shards, size_t S, const size_t *block_len,
+			    uint8_t *const *rebuilt, uint8_t *shard_sums, uint8_t *block_sums)
+{
+	const int k = c->k, n = c->k + c->m;
+	for (size_t b = 0; b < nb; ++b) {
+		std::vector<std::vector<uint8_t>> buf(n, std::vector<uint8_t>(S));
+		std::vector<uint8_t *> ptr(n);
+		std::vector<uint8_t> present(n, 0);
+		int seen = 0;
+		for (int j = 0; j < n; ++j) {
+			ptr[j] = buf[j].data();
+			if (shards[b * n + j] && seen < k) {  // the crate's rule: only the first k present shards are read
+				present[j] = 1;
+				++seen;
+				std::memcpy(buf[j].data(), shards[b * n + j], S);
+				gbm_blake2sum(shards[b * n + j], S, shard_sums + (b * n + j) * 32);
+			}
+		}
+		if (seen < k)
+			return GEC_E_TOO_FEW_PRESENT;
+		if (rso_reconstruct(k, c->m, S, ptr.data(), present.data(), 1) != RSO_OK)
+			return GEC_E_INVALID_ARG;
+		for (int j = 0; j < k; ++j)
+			if (!shards[b * n + j]) {
+				if (!rebuilt || !rebuilt[b * n + j])
+					return GEC_E_INVALID_ARG;
+				std::memcpy(rebuilt[b * n + j], buf[j].data(), S);
+			}
+		if (block_sums) {
+			std::vector<uint8_t> blk;
+			for (int j = 0; j < k; ++j)
+				blk.insert(blk.end(), buf[j].begin(), buf[j].end());
+			gbm_blake2sum(blk.data(), block_len[b], block_sums + 32 * b);
+		}
+	}
+	return GEC_OK;
+}
+
 int gec_verify_batch(const gec_codec *c, size_t nb, const uint8_t *const *shards, size_t S, uint8_t *ok)
 {
 	const int n = c->k + c->m;

@@ -141,3 +141,36 @@ print("OK")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_host_blake2sum_zero_copy_and_single_launch_paths(rs):
+    """gec_blake2sum_batch has three ways in: (a) every message in pinned memory -> one launch reading host memory
+    directly; (b) long messages in pageable memory -> everything staged into one device buffer, one launch; (c) many
+    short pageable messages -> chunked pipeline.  Same digests from all of them."""
+    import ctypes
+
+    from garage_amd._lib import check, lib
+    from garage_amd.codec import host_alloc, host_free
+
+    lens = [1 << 20, (1 << 20) + 13, 3 << 20, 40 << 20, 0, 5, 65536, 999_999]
+    rng = np.random.default_rng(77)
+    msgs = [rng.integers(0, 256, n, dtype=np.uint8) for n in lens]
+    want = [ref(m.tobytes()) for m in msgs]
+    assert rs.blake2sum_batch([m.tobytes() for m in msgs]) == want            # (b): longest >= 256 KiB, pageable
+    pinned = [host_alloc(max(n, 16)) for n in lens]                           # (a)
+    for p_, m in zip(pinned, msgs):
+        p_[:len(m)] = m
+    n = len(lens)
+    ptrs = (ctypes.c_void_p * n)(*[p_.ctypes.data for p_ in pinned])
+    clens = (ctypes.c_size_t * n)(*lens)
+    out = np.zeros((n, 32), dtype=np.uint8)
+    check(lib.gec_blake2sum_batch(rs._h, n, ptrs, clens, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), "pinned blake2")
+    assert [out[i].tobytes() for i in range(n)] == want
+    # a slice in the middle of a pinned buffer, 16-byte aligned, and one that is not (falls back to staging)
+    for off in (4096, 4099):
+        p1 = (ctypes.c_void_p * 1)(pinned[3].ctypes.data + off)
+        l1 = (ctypes.c_size_t * 1)(1 << 20)
+        check(lib.gec_blake2sum_batch(rs._h, 1, p1, l1, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), "slice")
+        assert out[0].tobytes() == ref(msgs[3][off:off + (1 << 20)].tobytes())
+    for p_ in pinned:
+        host_free(p_)

@@ -750,3 +750,68 @@ def test_host_api_pinned_buffers_match_pageable(coracle, rs104):
     for a in outs + rec:
         host_free(a)
     host_free(arena)
+
+
+# ------------------------------------------------ the read path in one trip (gec_decode_verify_batch)
+@pytest.mark.parametrize("pin", [False, True], ids=["pageable", "pinned"])
+def test_decode_verify_batch_one_trip(coracle, rs104, pin):
+    """Per block: some shards in hand (different erasure patterns in one batch, more than k in hand for some),
+    -> checksums of exactly the first k present shards (vs hashlib), missing data shards rebuilt (vs the oracle's
+    encode of the original data), blake2sum of the block itself (vs hashlib), for ragged block lengths."""
+    import ctypes
+    import hashlib
+
+    from garage_amd.codec import host_alloc, host_free
+
+    lib = _lib.lib
+    k, m, n = 10, 4, 14
+    S = 8192
+    lens = [k * S, k * S - 1, 70_000, 1, 0, k * S, 33_333, k * S - 4096]
+    nb = len(lens)
+    rng = np.random.default_rng(21)
+    data = np.zeros((nb, k, S), dtype=np.uint8)
+    for b in range(nb):
+        data[b].reshape(-1)[:lens[b]] = rng.integers(0, 256, lens[b], dtype=np.uint8)
+    par = coracle.encode_batch(k, m, data, coracle.AVX2)
+    full = np.concatenate([data, par], axis=1)
+    # in hand, per block (None = all): patterns with 0..4 data shards missing, surplus parity, parity-only losses
+    lost = [(), (0,), (0, 3, 7, 9), (2, 11), (9, 10, 11, 12), (1, 2, 3), (13,), (0, 1, 2, 3)]
+    alloc = (lambda sz: host_alloc(sz)) if pin else (lambda sz: np.empty(sz, dtype=np.uint8))
+    bufs, sp, op, fresh = [], (ctypes.c_void_p * (nb * n))(), (ctypes.c_void_p * (nb * n))(), {}
+    for b in range(nb):
+        for j in range(n):
+            if j in lost[b]:
+                sp[b * n + j] = None
+                if j < k:
+                    fresh[(b, j)] = alloc(S)
+                    op[b * n + j] = fresh[(b, j)].ctypes.data
+            else:
+                a = alloc(S)
+                a[:] = full[b, j]
+                bufs.append(a)
+                sp[b * n + j] = a.ctypes.data
+    clens = (ctypes.c_size_t * nb)(*lens)
+    ssums = np.zeros((nb, n, 32), dtype=np.uint8)
+    bsums = np.zeros((nb, 32), dtype=np.uint8)
+    u8 = ctypes.POINTER(ctypes.c_uint8)
+    _lib.check(lib.gec_decode_verify_batch(rs104._h, nb, sp, S, clens, op, ssums.ctypes.data_as(u8), bsums.ctypes.data_as(u8)),
+               "gec_decode_verify_batch")
+    h32 = lambda x: hashlib.blake2b(x, digest_size=64).digest()[:32]  # noqa: E731
+    for b in range(nb):
+        present = [j for j in range(n) if j not in lost[b]][:k]          # the shards that were read
+        for j in range(n):
+            if j in present:
+                assert ssums[b, j].tobytes() == h32(full[b, j].tobytes()), (b, j)
+            else:
+                assert not ssums[b, j].any(), (b, j)                       # untouched
+        for j in lost[b]:
+            if j < k:
+                assert np.array_equal(fresh[(b, j)], full[b, j]), (b, j)
+        assert bsums[b].tobytes() == h32(data[b].reshape(-1)[:lens[b]].tobytes()), b
+    # too few shards in hand in one block: the whole call is refused, like ReedSolomon::reconstruct
+    for j in range(5):
+        sp[3 * n + j] = None
+    assert lib.gec_decode_verify_batch(rs104._h, nb, sp, S, clens, op, ssums.ctypes.data_as(u8), None) == _lib.GEC_E_TOO_FEW_PRESENT
+    if pin:
+        for a in bufs + list(fresh.values()):
+            host_free(a)
