@@ -42,7 +42,7 @@ SYMBOLS = [
     "gec_group_unique_id", "gec_group_create", "gec_group_create_with_transport", "gec_group_destroy",
     "gec_group_rank", "gec_group_size", "gec_group_slots", "gec_group_allgather_decode",
     "gec_launch_geometry",
-    "gec_encode_hash_batch_dev", "gec_decode_verify_batch", "gec_host_alloc", "gec_host_free", "gec_host_register", "gec_host_unregister", "gec_host_is_pinned",
+    "gec_encode_hash_batch_dev", "gec_decode_verify_batch", "gec_shardsum_batch", "gec_shardsum_batch_dev", "gec_host_alloc", "gec_host_free", "gec_host_register", "gec_host_unregister", "gec_host_is_pinned",
 ]
 GEC_GROUP_ID_BYTES = 128
 # int (*gec_allgather_fn)(void *ctx, const void *d_send, void *d_recv, size_t bytes, void *hip_stream)
@@ -113,6 +113,8 @@ def _load() -> ctypes.CDLL:
     lib.gec_reconstruct_scattered_dev.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), sz, u8p, ci, sz, sz, vp]
     lib.gec_blake2sum_batch_dev.argtypes = [vp, sz, vp, sz, sz, vp, vp]
     lib.gec_blake2sum_batch.argtypes = [vp, sz, pp, ctypes.POINTER(sz), u8p]
+    lib.gec_shardsum_batch.argtypes = [vp, sz, pp, ctypes.POINTER(sz), u8p]
+    lib.gec_shardsum_batch_dev.argtypes = [vp, sz, vp, sz, sz, vp, vp]
     lib.gec_encode_hash_batch.argtypes = [vp, sz, pp, ctypes.POINTER(sz), sz, pp, u8p]
     lib.gec_encode_hash_batch_dev.argtypes = [vp, sz, vp, sz, sz, vp, vp]
     lib.gec_decode_verify_batch.argtypes = [vp, sz, pp, sz, ctypes.POINTER(sz), pp, u8p, u8p]

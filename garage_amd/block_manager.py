@@ -32,7 +32,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-from .codec import shard_len
+from .codec import shard_len, shardsum
 from .partition import block_hash
 
 INLINE_THRESHOLD = 3072  # src/block/manager.rs:46
@@ -140,10 +140,10 @@ class ShardHeader:
     compressed: bool
     orig_len: int      # length of the (possibly compressed) block payload
     shard_len: int
-    checksum: bytes    # blake2sum of the shard payload (32 bytes)
+    checksum: bytes    # shardsum of the shard payload (32 bytes, BLAKE2b tree mode)
 
     MAGIC = b"GECS"
-    VERSION = 1
+    VERSION = 2        # version 2: checksum = shardsum (BLAKE2b tree mode, include/garage_ec.h); 1 was plain blake2sum
     SIZE = 64
     _FMT = "<4sBBBBB3xQII32s"
 
@@ -314,7 +314,7 @@ class BlockManager:
                 ok, errors = 0, []
                 for j, node in enumerate(who):
                     payload = shards[j].tobytes()
-                    hdr = ShardHeader(self.k, self.m, j, blk.header.is_compressed(), len(blk.elem), S, block_hash(payload))
+                    hdr = ShardHeader(self.k, self.m, j, blk.header.is_compressed(), len(blk.elem), S, shardsum(payload))
                     try:
                         self.stores[node].put(hash_, j, hdr.pack() + payload)
                         ok += 1
@@ -358,7 +358,7 @@ class BlockManager:
                 hdr = ShardHeader.unpack(raw)
                 payload = raw[ShardHeader.SIZE:]
                 if hdr.idx != j or hdr.k != self.k or hdr.m != self.m or len(payload) != hdr.shard_len \
-                        or block_hash(payload) != hdr.checksum:
+                        or shardsum(payload) != hdr.checksum:
                     raise ValueError("shard checksum/geometry mismatch")
             except ValueError:
                 self.metrics["corruption_counter"] += 1
@@ -450,7 +450,7 @@ class BlockManager:
             if j in got:
                 continue
             payload = np.asarray(row[j]).tobytes()
-            hdr = ShardHeader(self.k, self.m, j, meta.compressed, meta.orig_len, meta.shard_len, block_hash(payload))
+            hdr = ShardHeader(self.k, self.m, j, meta.compressed, meta.orig_len, meta.shard_len, shardsum(payload))
             try:
                 self.stores[node].put(hash_, j, hdr.pack() + payload)
                 fixed += 1

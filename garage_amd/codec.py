@@ -235,6 +235,30 @@ class ReedSolomon:
         check(lib.gec_blake2sum_batch(self._h, n, ptrs, lens, _u8p(out)), "gec_blake2sum_batch")
         return [out[i].tobytes() for i in range(n)]
 
+    def shardsum_batch(self, msgs: Sequence[bytes]) -> list[bytes]:
+        """The shard checksum (BLAKE2b tree mode, `shardsum`) of every message, on the GPU."""
+        n = len(msgs)
+        if n == 0:
+            return []
+        bufs = [np.frombuffer(bytes(x), dtype=np.uint8) if len(x) else np.zeros(1, dtype=np.uint8) for x in msgs]
+        ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in bufs])
+        lens = (ctypes.c_size_t * n)(*[len(x) for x in msgs])
+        out = np.empty((n, 32), dtype=np.uint8)
+        check(lib.gec_shardsum_batch(self._h, n, ptrs, lens, _u8p(out)), "gec_shardsum_batch")
+        return [out[i].tobytes() for i in range(n)]
+
+    def shardsum_dev(self, t):
+        """t: (n, len) uint8 CUDA tensor, rows 16-byte aligned -> (n, 32) uint8 tensor of shard checksums."""
+        import torch
+
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.dim() == 2 and t.is_contiguous()):
+            raise TypeError("expected a contiguous 2-D uint8 CUDA tensor")
+        n, ln = t.shape
+        out = torch.empty((n, 32), dtype=torch.uint8, device=t.device)
+        check(lib.gec_shardsum_batch_dev(self._h, n, t.data_ptr(), ln, ln, out.data_ptr(), _stream_handle(self.device)),
+              "gec_shardsum_batch_dev")
+        return out
+
     def blake2sum_dev(self, t):
         """t: (n, len) uint8 CUDA tensor, rows 16-byte aligned -> (n, 32) uint8 tensor."""
         import torch
@@ -319,6 +343,22 @@ class ReedSolomon:
 
     def reconstruct_data(self, shards):
         return self.reconstruct(shards, data_only=True)
+
+
+SHARDSUM_LEAF = 4096
+
+
+def shardsum(data: bytes) -> bytes:
+    """The shard checksum, restated with hashlib (test oracle and host mirror): BLAKE2b tree mode, 4 KiB leaves,
+    unlimited fanout, depth 2, 64-byte inner digests, root truncated to 32 bytes (include/garage_ec.h)."""
+    import hashlib
+
+    n = max(1, -(-len(data) // SHARDSUM_LEAF))
+    leaves = b"".join(
+        hashlib.blake2b(data[i * SHARDSUM_LEAF:(i + 1) * SHARDSUM_LEAF], digest_size=64, fanout=0, depth=2, leaf_size=SHARDSUM_LEAF,
+                        node_offset=i, node_depth=0, inner_size=64, last_node=(i == n - 1)).digest() for i in range(n))
+    return hashlib.blake2b(leaves, digest_size=64, fanout=0, depth=2, leaf_size=SHARDSUM_LEAF, node_offset=0, node_depth=1,
+                           inner_size=64, last_node=True).digest()[:32]
 
 
 def host_alloc(nbytes: int) -> np.ndarray:

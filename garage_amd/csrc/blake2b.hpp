@@ -108,13 +108,14 @@ __device__ __forceinline__ uint64_t b2_add(uint64_t a, uint64_t b)
 	GEC_B2_G(v3, v4, v9, v14, m[s14], m[s15]);
 
 template <bool ADD32>
-__device__ __forceinline__ void b2_compress(uint64_t (&h)[8], const uint64_t (&m)[16], uint64_t t, bool last)
+__device__ __forceinline__ void b2_compress(uint64_t (&h)[8], const uint64_t (&m)[16], uint64_t t, bool last, bool last_node = false)
 {
 	const uint64_t IV0 = 0x6a09e667f3bcc908ULL, IV1 = 0xbb67ae8584caa73bULL, IV2 = 0x3c6ef372fe94f82bULL,
 		       IV3 = 0xa54ff53a5f1d36f1ULL, IV4 = 0x510e527fade682d1ULL, IV5 = 0x9b05688c2b3e6c1fULL,
 		       IV6 = 0x1f83d9abfb41bd6bULL, IV7 = 0x5be0cd19137e2179ULL;
 	uint64_t v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
-	uint64_t v8 = IV0, v9 = IV1, v10 = IV2, v11 = IV3, v12 = IV4 ^ t, v13 = IV5, v14 = last ? ~IV6 : IV6, v15 = IV7;
+	uint64_t v8 = IV0, v9 = IV1, v10 = IV2, v11 = IV3, v12 = IV4 ^ t, v13 = IV5, v14 = last ? ~IV6 : IV6,
+		 v15 = (last && last_node) ? ~IV7 : IV7;  // f1: "last node" of a tree level (RFC 7693 / BLAKE2 spec 2.10)
 	// sigma permutations are compile-time, so m[] stays in registers
 	GEC_B2_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
 	GEC_B2_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
@@ -410,6 +411,113 @@ __global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
 	}
 	if (live)
 		reinterpret_cast<uint64_t *>(b2_out_ptr(a, i))[q] = ha;  // h[0..3] = first 32 bytes
+}
+
+// ---------------------------------------------------------------------------
+// Shard checksums: BLAKE2b in TREE mode (BLAKE2 specification section 2.10; the parameter block of RFC 7693
+// section 2.5), two levels: leaves of GEC_SHARDSUM_LEAF = 4096 bytes, unlimited fanout, 64-byte inner digests,
+// the root's 64-byte digest truncated to 32 bytes like Garage's blake2sum.  Python's hashlib reproduces it
+// (blake2b(..., fanout=0, depth=2, leaf_size=4096, node_offset=i, node_depth=0|1, inner_size=64, last_node=..)).
+//
+// Why not plain BLAKE2b over the shard: a BLAKE2b message is one serial chain, and a lone wave issues one VALU
+// instruction per ~5 cycles (profiles/r02_valu_probe.txt) -- 14336 shards of 105 KB are 820-block chains that take
+// 1.4 ms however the kernel is written, with three quarters of the chip's issue slots idle.  The shard checksum is
+// this project's own format (Garage has no shards), so it is free to use the standard's own answer to that:
+// 26 independent 32-block leaves per shard = 373k messages, enough waves per SIMD to fill the VALUs, and a
+// 13-block root per shard.  Block names stay plain blake2sum (gec_blake2sum_batch): they are Garage's.
+// ---------------------------------------------------------------------------
+constexpr uint32_t SHARDSUM_LEAF = 4096;
+constexpr uint64_t SHARDSUM_P0 = 64ull /*digest*/ | (0ull << 8) /*key*/ | (0ull << 16) /*fanout: unlimited*/ | (2ull << 24) /*depth*/ |
+				 ((uint64_t)SHARDSUM_LEAF << 32);
+constexpr uint64_t SHARDSUM_P2_LEAF = 0ull /*node_depth*/ | (64ull << 8) /*inner_length*/;
+constexpr uint64_t SHARDSUM_P2_ROOT = 1ull | (64ull << 8);
+
+// One lane per LEAF: lane i hashes leaf (i % nleaf) of shard (i / nleaf); shards addressed like messages of
+// Blake2Args (flat / grouped / offset table, uniform or per-shard lengths).  leafdig: [shard][leaf][64].
+__global__ __launch_bounds__(64) void shardsum_leaves(const Blake2Args a, uint32_t nleaf_max, uint8_t *__restrict__ leafdig)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t s = (uint32_t)(i / nleaf_max), l = (uint32_t)(i % nleaf_max);
+	if (s >= a.n)
+		return;
+	const uint64_t slen = a.len ? a.len[s] : a.uniform_len;
+	const uint32_t nleaf = slen ? (uint32_t)((slen + SHARDSUM_LEAF - 1) / SHARDSUM_LEAF) : 1;
+	if (l >= nleaf)
+		return;
+	const uint8_t *p = b2_msg_ptr(a, s) + (uint64_t)l * SHARDSUM_LEAF;
+	const uint64_t len = slen > (uint64_t)l * SHARDSUM_LEAF ? (slen - (uint64_t)l * SHARDSUM_LEAF < SHARDSUM_LEAF ? slen - (uint64_t)l * SHARDSUM_LEAF : SHARDSUM_LEAF) : 0;
+	uint64_t h[8] = {0x6a09e667f3bcc908ULL ^ SHARDSUM_P0, 0xbb67ae8584caa73bULL ^ (uint64_t)l /*node_offset*/,
+			 0x3c6ef372fe94f82bULL ^ SHARDSUM_P2_LEAF, 0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL,
+			 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+	const bool last_node = l + 1 == nleaf;
+	uint64_t m[16];
+	uint64_t done = 0;
+	while (len - done > 128) {
+		const u64x2 *q = reinterpret_cast<const u64x2 *>(p + done);
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			u64x2 w = __builtin_nontemporal_load(q + j);
+			m[2 * j] = w.x;
+			m[2 * j + 1] = w.y;
+		}
+		done += 128;
+		b2_compress<false>(h, m, done, false);
+	}
+	const uint64_t rem = len - done;
+#pragma unroll
+	for (int j = 0; j < 16; ++j) {
+		uint64_t w = 0;
+		if ((uint64_t)(8 * j + 8) <= rem) {
+			w = *reinterpret_cast<const uint64_t *>(p + done + 8 * j);
+		} else if ((uint64_t)(8 * j) < rem) {
+			for (uint64_t b = 0; b < rem - 8 * j; ++b)
+				w |= (uint64_t)p[done + 8 * j + b] << (8 * b);
+		}
+		m[j] = w;
+	}
+	b2_compress<false>(h, m, len, true, last_node);
+	u64x2 *o = reinterpret_cast<u64x2 *>(leafdig + ((uint64_t)s * nleaf_max + l) * 64);
+	o[0] = u64x2{h[0], h[1]};
+	o[1] = u64x2{h[2], h[3]};
+	o[2] = u64x2{h[4], h[5]};
+	o[3] = u64x2{h[6], h[7]};
+}
+
+// One lane per shard: the root over that shard's leaf digests (nleaf * 64 bytes, always whole blocks of 128 bytes
+// except possibly the last 64).  Output placement like b2_out_ptr.
+__global__ __launch_bounds__(64) void shardsum_roots(const Blake2Args a, uint32_t nleaf_max, const uint8_t *__restrict__ leafdig)
+{
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= a.n)
+		return;
+	const uint64_t slen = a.len ? a.len[s] : a.uniform_len;
+	const uint32_t nleaf = slen ? (uint32_t)((slen + SHARDSUM_LEAF - 1) / SHARDSUM_LEAF) : 1;
+	const uint64_t len = (uint64_t)nleaf * 64;
+	const uint8_t *p = leafdig + (uint64_t)s * nleaf_max * 64;
+	uint64_t h[8] = {0x6a09e667f3bcc908ULL ^ SHARDSUM_P0, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL ^ SHARDSUM_P2_ROOT,
+			 0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL,
+			 0x5be0cd19137e2179ULL};
+	uint64_t m[16];
+	uint64_t done = 0;
+	while (len - done > 128) {
+		const u64x2 *q = reinterpret_cast<const u64x2 *>(p + done);
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			u64x2 w = q[j];
+			m[2 * j] = w.x;
+			m[2 * j + 1] = w.y;
+		}
+		done += 128;
+		b2_compress<false>(h, m, done, false);
+	}
+	const uint64_t rem = len - done;  // 64 or 128
+#pragma unroll
+	for (int j = 0; j < 16; ++j)
+		m[j] = (uint64_t)(8 * j) < rem ? *reinterpret_cast<const uint64_t *>(p + done + 8 * j) : 0;
+	b2_compress<false>(h, m, len, true, true);
+	u64x2 *o = reinterpret_cast<u64x2 *>(b2_out_ptr(a, s));
+	o[0] = u64x2{h[0], h[1]};
+	o[1] = u64x2{h[2], h[3]};
 }
 
 }  // namespace gec

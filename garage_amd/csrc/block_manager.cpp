@@ -70,7 +70,7 @@ const uint8_t B2_SIGMA[12][16] = {
 
 inline uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
 
-void b2_compress(uint64_t h[8], const uint8_t block[128], uint64_t t, bool last)
+void b2_compress(uint64_t h[8], const uint8_t block[128], uint64_t t, bool last, bool last_node = false)
 {
 	uint64_t m[16], v[16];
 	std::memcpy(m, block, 128);  // little-endian host
@@ -81,6 +81,8 @@ void b2_compress(uint64_t h[8], const uint8_t block[128], uint64_t t, bool last)
 	v[12] ^= t;  // t fits 64 bits here
 	if (last)
 		v[14] = ~v[14];
+	if (last && last_node)
+		v[15] = ~v[15];  // f1, tree mode
 #define B2_G(a, b, c, d, x, y)                  \
 	v[a] = v[a] + v[b] + (x);               \
 	v[d] = rotr64(v[d] ^ v[a], 32);         \
@@ -106,12 +108,15 @@ void b2_compress(uint64_t h[8], const uint8_t block[128], uint64_t t, bool last)
 		h[i] ^= v[i] ^ v[i + 8];
 }
 
-void blake2sum(const uint8_t *data, size_t len, uint8_t out[32])
+// BLAKE2b-512 with an explicit parameter block (words 0..2) and the tree-mode "last node" flag; full digest out
+void blake2b_params(const uint8_t *data, size_t len, uint64_t p0, uint64_t p1, uint64_t p2, bool last_node, uint8_t out[64])
 {
 	uint64_t h[8];
 	for (int i = 0; i < 8; ++i)
 		h[i] = B2_IV[i];
-	h[0] ^= 0x01010000ULL ^ 64;  // digest length 64, no key, fanout 1, depth 1
+	h[0] ^= p0;
+	h[1] ^= p1;
+	h[2] ^= p2;
 	size_t off = 0;
 	while (len - off > 128) {
 		b2_compress(h, data + off, off + 128, false);
@@ -120,8 +125,32 @@ void blake2sum(const uint8_t *data, size_t len, uint8_t out[32])
 	uint8_t last[128] = {0};
 	if (len > off)  // data may be NULL for the empty message
 		std::memcpy(last, data + off, len - off);
-	b2_compress(h, last, len, true);
-	std::memcpy(out, h, 32);
+	b2_compress(h, last, len, true, last_node);
+	std::memcpy(out, h, 64);
+}
+
+void blake2sum(const uint8_t *data, size_t len, uint8_t out[32])
+{
+	uint8_t full[64];
+	blake2b_params(data, len, 0x01010000ULL ^ 64 /* digest length 64, no key, fanout 1, depth 1 */, 0, 0, false, full);
+	std::memcpy(out, full, 32);
+}
+
+// The shard checksum: BLAKE2b tree mode, GEC_SHARDSUM_LEAF-byte leaves, unlimited fanout, depth 2, 64-byte inner
+// digests, root truncated to 32 bytes (include/garage_ec.h has the definition and the reason).  CPU restatement for the
+// few shards the manager checksums itself (a repair, a small read); batches go to gec_shardsum_batch.
+void shardsum(const uint8_t *data, size_t len, uint8_t out[32])
+{
+	const uint64_t P0 = 64ull | (2ull << 24) | ((uint64_t)GEC_SHARDSUM_LEAF << 32);
+	const size_t nleaf = len ? (len + GEC_SHARDSUM_LEAF - 1) / GEC_SHARDSUM_LEAF : 1;
+	std::vector<uint8_t> digs(nleaf * 64);
+	for (size_t i = 0; i < nleaf; ++i) {
+		const size_t lo = i * GEC_SHARDSUM_LEAF, n = len > lo ? std::min<size_t>(GEC_SHARDSUM_LEAF, len - lo) : 0;
+		blake2b_params(n ? data + lo : nullptr, n, P0, i, 64ull << 8, i + 1 == nleaf, digs.data() + 64 * i);
+	}
+	uint8_t full[64];
+	blake2b_params(digs.data(), digs.size(), P0, 0, 1ull | (64ull << 8), true, full);
+	std::memcpy(out, full, 32);
 }
 
 // --------------------------------------------------------------------- zstd
@@ -248,7 +277,7 @@ struct ShardHeader {
 	{
 		std::memset(out, 0, GBM_SHARD_HEADER_SIZE);
 		std::memcpy(out, "GECS", 4);
-		out[4] = 1;
+		out[4] = 2;  // version 2: the checksum is the tree-mode shardsum (version 1 was plain blake2sum)
 		out[5] = k;
 		out[6] = m;
 		out[7] = idx;
@@ -259,7 +288,7 @@ struct ShardHeader {
 	}
 	bool unpack(const uint8_t *in, size_t n)
 	{
-		if (n < GBM_SHARD_HEADER_SIZE || std::memcmp(in, "GECS", 4) != 0 || in[4] != 1)
+		if (n < GBM_SHARD_HEADER_SIZE || std::memcmp(in, "GECS", 4) != 0 || in[4] != 2)
 			return false;
 		k = in[5];
 		m = in[6];
@@ -763,9 +792,8 @@ int ec_fail(int rc, const char *what)
 // "a few MiB" in practice; 1 GiB is far above any of it and still a harmless allocation bound
 constexpr size_t kMaxDecompressed = 1ull << 30;
 
-// blake2sum of many buffers: on the GPU (gec_blake2sum_batch) once the batch is big
-// enough to beat the CPU pool through PCIe + the kernel's ~1.5 ms chain latency, else on the pool's
-// threads.  SURVEY.md section 8 row f4.
+// shard checksums of many buffers: on the GPU (gec_shardsum_batch) once the batch is big enough to beat the
+// CPU pool through PCIe, else on the pool's threads.  SURVEY.md section 8 row f4.
 constexpr size_t kGpuHashMinMessages = 64;
 constexpr size_t kGpuHashMinBytes = 8u << 20;
 
@@ -777,13 +805,13 @@ int hash_many(gbm_manager *mg, const std::vector<const uint8_t *> &ptrs, const s
 	for (size_t l : lens)
 		total += l;
 	if (ptrs.size() >= kGpuHashMinMessages && total >= kGpuHashMinBytes) {
-		int rc = gec_blake2sum_batch(mg->codec, ptrs.size(), ptrs.data(), lens.data(), sums.data());
+		int rc = gec_shardsum_batch(mg->codec, ptrs.size(), ptrs.data(), lens.data(), sums.data());
 		if (rc)
-			return ec_fail(rc, "gec_blake2sum_batch");
+			return ec_fail(rc, "gec_shardsum_batch");
 		mg->gpu_hashed += ptrs.size();
 		return GBM_OK;
 	}
-	mg->pool->parallel_for(ptrs.size(), [&](size_t i) { blake2sum(ptrs[i], lens[i], sums.data() + 32 * i); });
+	mg->pool->parallel_for(ptrs.size(), [&](size_t i) { shardsum(ptrs[i], lens[i], sums.data() + 32 * i); });
 	return GBM_OK;
 }
 
@@ -1007,7 +1035,7 @@ bool send_shard(gbm_manager *mg, int node, const Hash &h, int idx, const Bytes &
 	if (checksum)
 		std::memcpy(hd.checksum, checksum, 32);
 	else
-		blake2sum(payload.data(), S, hd.checksum);
+		shardsum(payload.data(), S, hd.checksum);
 	rq.shard.data = payload;
 	ShardResp rs;
 	return mg->nodes[node]->handle(rq, rs) && rs.ok;
@@ -1462,7 +1490,7 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 				if (!mg->nodes[s.node]->handle(rq, rs) || !rs.ok)
 					continue;
 				uint8_t sum[32];
-				blake2sum(rs.shard.data.data(), rs.shard.data.n, sum);
+				shardsum(rs.shard.data.data(), rs.shard.data.n, sum);
 				if (rs.shard.data.n != rs.shard.hd.shard_len || std::memcmp(sum, rs.shard.hd.checksum, 32) != 0) {
 					mg->metrics[2]++;
 					mg->nodes[s.node]->mark_corrupted(t.h, s.idx);
@@ -1600,6 +1628,8 @@ const char *gbm_last_error(void) { return g_err.c_str(); }
 
 void gbm_blake2sum(const uint8_t *data, size_t len, uint8_t out[32]) { blake2sum(data, len, out); }
 
+void gbm_shardsum(const uint8_t *data, size_t len, uint8_t out[32]) { shardsum(data, len, out); }
+
 int gbm_create(const gec_codec *codec, int nnodes, const char *const *node_dirs, int write_quorum, gbm_manager **out)
 {
 	if (!codec || !out)
@@ -1715,8 +1745,42 @@ int gbm_layout_trim(gbm_manager *m)
 int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data, const size_t *len,
 		       const uint8_t *prevent_compression, const gbm_order_tag *order_tags)
 {
+	// Large untagged batches go through in slices on two threads, so that one slice's host work (the copy into the
+	// shard buffers, the fan-out) runs while the other slice is on the device.  Tagged batches keep their order.
+	constexpr size_t kSlice = 128;
 	try {
-		return put_blocks_impl(mg, nb, hashes, data, len, prevent_compression, order_tags, nullptr);
+		if (!mg || order_tags || nb < 2 * kSlice)
+			return put_blocks_impl(mg, nb, hashes, data, len, prevent_compression, order_tags, nullptr);
+		std::atomic<size_t> next{0};
+		std::mutex mu;
+		int result = GBM_OK;
+		std::string err;
+		auto run = [&] {
+			for (;;) {
+				const size_t b0 = next.fetch_add(kSlice);
+				if (b0 >= nb)
+					return;
+				const size_t cnt = std::min(kSlice, nb - b0);
+				int rc;
+				try {
+					rc = put_blocks_impl(mg, cnt, hashes + 32 * b0, data + b0, len + b0,
+							     prevent_compression ? prevent_compression + b0 : nullptr, nullptr, nullptr);
+				} catch (const std::exception &e) {
+					rc = fail(GBM_E_IO, std::string("rpc_put_blocks: ") + e.what());
+				}
+				if (rc) {
+					std::lock_guard<std::mutex> g(mu);
+					result = rc;
+					err = g_err;  // the error text is thread-local: carry it to the caller's thread
+				}
+			}
+		};
+		std::thread other(run);
+		run();
+		other.join();
+		if (result)
+			return fail(result, err);
+		return GBM_OK;
 	} catch (const std::exception &e) {
 		return fail(GBM_E_IO, std::string("rpc_put_blocks: ") + e.what());
 	}
@@ -2134,7 +2198,7 @@ int gbm_node_corrupt_shard(gbm_manager *m, int node, const uint8_t hash[32], int
 		return fail(GBM_E_IO, "out of memory");
 	}
 	if (fix_checksum)
-		blake2sum(s.data.data(), s.data.n, s.hd.checksum);
+		shardsum(s.data.data(), s.data.n, s.hd.checksum);
 	return m->nodes[node]->put(h, idx, s) ? GBM_OK : fail(GBM_E_IO, "rewrite failed");
 }
 
@@ -2192,20 +2256,24 @@ struct gbm_batcher {
 	std::mutex mu;
 	std::condition_variable cv_work, cv_done, cv_ram;
 	std::deque<Item *> queue;
-	bool stop = false;
+	bool stop = false, forming = false;
 	uint64_t batches = 0, blocks = 0, max_batch = 0;
-	std::thread worker;
+	// two workers: while one batch is on the device the next one forms and starts (the device trip has a latency
+	// floor -- the checksum chain -- that a single worker would pay serially)
+	std::vector<std::thread> workers;
 
 	void run()
 	{
 		std::unique_lock<std::mutex> lk(mu);
 		for (;;) {
-			cv_work.wait(lk, [&] { return stop || !queue.empty(); });
+			// one worker forms a batch at a time; the other one is either on the device or waits its turn
+			cv_work.wait(lk, [&] { return stop || (!queue.empty() && !forming); });
 			if (queue.empty()) {
 				if (stop)
 					return;
 				continue;
 			}
+			forming = true;
 			// linger a little so concurrent callers land in the same batch
 			// system_clock: libstdc++ maps it to pthread_cond_timedwait, which ThreadSanitizer
 			// understands (steady_clock -> pthread_cond_clockwait is not intercepted by gcc 11's
@@ -2219,6 +2287,8 @@ struct gbm_batcher {
 				batch.push_back(queue.front());
 				queue.pop_front();
 			}
+			forming = false;
+			cv_work.notify_all();
 			lk.unlock();
 			const size_t nb = batch.size();
 			std::vector<uint8_t> hashes(nb * 32), pc(nb);
@@ -2269,7 +2339,8 @@ int gbm_batcher_create(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, 
 	b->mg = m;
 	b->max_blocks = max_blocks;
 	b->max_wait_us = max_wait_us;
-	b->worker = std::thread([b] { b->run(); });
+	for (int i = 0; i < 2; ++i)
+		b->workers.emplace_back([b] { b->run(); });
 	*out = b;
 	return GBM_OK;
 }
@@ -2284,7 +2355,8 @@ void gbm_batcher_destroy(gbm_batcher *b)
 	}
 	b->cv_work.notify_all();
 	b->cv_ram.notify_all();
-	b->worker.join();
+	for (auto &t : b->workers)
+		t.join();
 	delete b;
 }
 
@@ -2313,7 +2385,7 @@ int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t 
 		return fail(GBM_E_INVALID_ARG, "batcher is shutting down");
 	b->ram_in_use_kb += need_kb;
 	b->queue.push_back(&it);
-	b->cv_work.notify_one();
+	b->cv_work.notify_all();
 	b->cv_done.wait(lk, [&] { return it.done; });
 	if (it.rc == GBM_E_QUORUM)
 		return fail(it.rc, "Could not reach quorum");

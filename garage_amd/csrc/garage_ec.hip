@@ -376,6 +376,15 @@ struct gec_codec {
 	// One copy pool per codec = per device: a process that drives several GPUs (one codec each)
 	// must not funnel all their staging copies through one set of threads.  Created on the
 	// first host-pointer call; device-API-only users never start the threads.
+	// leaf-digest scratch of the tree-mode shard checksums, one per stream that ever hashed (work on one
+	// stream is ordered, so reuse on the same stream is safe; grow-only)
+	struct LeafScratch {
+		uint8_t *p = nullptr;
+		size_t cap = 0;
+	};
+	mutable std::mutex leaf_mu;
+	mutable std::map<hipStream_t, LeafScratch> leaf_scratch;
+
 	mutable std::once_flag copy_once;
 	mutable std::unique_ptr<CopyPool> copy_threads;
 	CopyPool &copy_pool() const
@@ -804,13 +813,32 @@ int verify_dev(const gec_codec *c, size_t nblocks, const uint8_t *d_stripes, siz
 			    in_off.data(), out_off.data(), m, c->enc.row(k), gec::MODE_COMPARE, stream);
 }
 
-// one lane per message, one wave per workgroup so that few messages still spread
-// over many SIMDs (the kernel is VALU-bound, occupancy per SIMD does not matter)
-// group != 0: message i lives at d_base + (i / group)*group_stride + (i % group)*stride and its checksum goes to
-// d_out + 32*((i / group)*out_group + i % group) -- e.g. only the data (or only the parity) shards of every stripe.
-int blake2_dev(size_t n, const uint8_t *d_base, const uint64_t *d_off, const uint64_t *d_len, size_t stride,
+int leaf_scratch(const gec_codec *c, hipStream_t stream, size_t bytes, uint8_t **out)
+{
+	std::lock_guard<std::mutex> g(c->leaf_mu);
+	gec_codec::LeafScratch &ls = c->leaf_scratch[stream];
+	if (bytes > ls.cap) {
+		if (ls.p) {
+			HIP_TRY(hipStreamSynchronize(stream));  // earlier launches on this stream may still read the old one
+			(void)hipFree(ls.p);
+			ls.p = nullptr;
+			ls.cap = 0;
+		}
+		const size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 20);
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ls.p), want));
+		ls.cap = want;
+	}
+	*out = ls.p;
+	return GEC_OK;
+}
+
+// blake2sum of n messages.  group != 0: message i lives at d_base + (i / group)*group_stride + (i % group)*stride and
+// its checksum goes to d_out + 32*((i / group)*out_group + i % group) -- e.g. only the data (or only the parity)
+// shards of every stripe.  tree: the shard checksum (BLAKE2b tree mode, blake2b.hpp) instead of the plain hash;
+// max_len = the longest message (sizes the leaf grid).
+int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64_t *d_off, const uint64_t *d_len, size_t stride,
 	       size_t len, uint8_t *d_out, hipStream_t stream, uint32_t group = 0, size_t group_stride = 0,
-	       uint32_t out_group = 0)
+	       uint32_t out_group = 0, bool tree = false, size_t max_len = 0)
 {
 	if (n == 0)
 		return GEC_OK;
@@ -827,6 +855,22 @@ int blake2_dev(size_t n, const uint8_t *d_base, const uint64_t *d_off, const uin
 	a.group = group;
 	a.group_stride = group_stride;
 	a.out_group = out_group;
+	if (tree) {
+		const size_t longest = d_len ? max_len : len;
+		const uint32_t nleaf = (uint32_t)std::max<size_t>(1, (longest + gec::SHARDSUM_LEAF - 1) / gec::SHARDSUM_LEAF);
+		const uint64_t lanes = (uint64_t)n * nleaf;
+		if ((lanes + 63) / 64 > 0x7fffffffull)
+			return fail(GEC_E_INVALID_ARG, "too many leaves for one call");
+		uint8_t *scratch = nullptr;
+		int rc = leaf_scratch(c, stream, lanes * 64, &scratch);
+		if (rc)
+			return rc;
+		hipLaunchKernelGGL(gec::shardsum_leaves, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, stream, a, nleaf, scratch);
+		HIP_TRY(hipGetLastError());
+		hipLaunchKernelGGL(gec::shardsum_roots, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a, nleaf, scratch);
+		HIP_TRY(hipGetLastError());
+		return GEC_OK;
+	}
 	// one lane per message is the faster kernel once there are enough messages to put a
 	// wave on every SIMD (1024 SIMDs x 64 lanes); below that the quad kernel (4 lanes per
 	// message, ~4x shorter chain) wins.  GEC_BLAKE2_KERNEL=lane|quad forces one (A/B).
@@ -898,19 +942,24 @@ int encode_hash_dev(const gec_codec *c, size_t nblocks, uint8_t *d_stripes, size
 		    hipStream_t stream, Staging &aux)
 {
 	const size_t k = c->k, m = c->m, n = k + m;
-	HIP_TRY(hipEventRecord(aux.ev_fork, stream));
-	HIP_TRY(hipStreamWaitEvent(aux.stream2, aux.ev_fork, 0));
-	int rc = blake2_dev(nblocks * k, d_stripes, nullptr, nullptr, S, S, d_sums, aux.stream2, (uint32_t)k, stride, (uint32_t)n);
+	static const bool fork = [] { const char *e = getenv("GEC_HASH_FORK"); return !e || atoi(e) != 0; }();  // A/B switch
+	if (fork) {
+		HIP_TRY(hipEventRecord(aux.ev_fork, stream));
+		HIP_TRY(hipStreamWaitEvent(aux.stream2, aux.ev_fork, 0));
+	}
+	int rc = blake2_dev(c, nblocks * k, d_stripes, nullptr, nullptr, S, S, d_sums, fork ? aux.stream2 : stream, (uint32_t)k, stride, (uint32_t)n, true);
 	if (rc)
 		return rc;
-	HIP_TRY(hipEventRecord(aux.ev_join, aux.stream2));
+	if (fork)
+		HIP_TRY(hipEventRecord(aux.ev_join, aux.stream2));
 	rc = encode_dev(c, nblocks, d_stripes, stride, S, d_stripes + k * S, stride, stream);
 	if (rc)
 		return rc;
-	rc = blake2_dev(nblocks * m, d_stripes + k * S, nullptr, nullptr, S, S, d_sums + 32 * k, stream, (uint32_t)m, stride, (uint32_t)n);
+	rc = blake2_dev(c, nblocks * m, d_stripes + k * S, nullptr, nullptr, S, S, d_sums + 32 * k, stream, (uint32_t)m, stride, (uint32_t)n, true);
 	if (rc)
 		return rc;
-	HIP_TRY(hipStreamWaitEvent(stream, aux.ev_join, 0));
+	if (fork)
+		HIP_TRY(hipStreamWaitEvent(stream, aux.ev_join, 0));
 	return GEC_OK;
 }
 
@@ -1148,6 +1197,9 @@ void gec_codec_destroy(gec_codec *c)
 		DeviceGuard g(c->device);
 		for (auto &s : c->pool)
 			s.release();
+		for (auto &kv : c->leaf_scratch)
+			if (kv.second.p)
+				(void)hipFree(kv.second.p);
 		if (c->d_logexp)
 			(void)hipFree(c->d_logexp);
 	}
@@ -1558,7 +1610,13 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 	const size_t stripe = n * S;
 	// the hash kernel's serial chain costs ~3.5 ms per launch whatever the batch, so
 	// chunks are 8x larger when checksums are requested
-	const size_t ch = chunk_blocks(stripe, nblocks, shard_sums ? 8 * kChunkBytes : kChunkBytes);
+	// caller memory that is pinned end to end needs no host staging, so the only reasons to chunk are the size of
+	// the device buffer and the overlap of copy-in / kernels / copy-out between the two slots: 128 MiB chunks
+	bool all_pinned = true;
+	for (size_t b = 0; b < nblocks && all_pinned; ++b)
+		all_pinned = aligned16(blocks[b]) && aligned16(parity[b]) && pinned().contains(blocks[b], block_len[b]) &&
+			     pinned().contains(parity[b], m * S);
+	const size_t ch = chunk_blocks(stripe, nblocks, (shard_sums || all_pinned) ? 8 * kChunkBytes : kChunkBytes);
 	const size_t sums_off = ch * stripe;  // checksum area behind the stripes of a slot
 	const size_t nchunks = (nblocks + ch - 1) / ch;
 	CopyPool &pool = c->copy_pool();
@@ -1672,8 +1730,8 @@ int gec_encode_hash_batch_dev(const gec_codec *c, size_t nblocks, void *d_stripe
 			       static_cast<hipStream_t>(hip_stream), aux.st);
 }
 
-int gec_blake2sum_batch_dev(const gec_codec *c, size_t n, const void *d_base, size_t stride, size_t len, void *d_out,
-			    void *hip_stream)
+static int hash_batch_dev_impl(const gec_codec *c, size_t n, const void *d_base, size_t stride, size_t len, void *d_out,
+			       void *hip_stream, int tree)
 {
 	if (!c || (n && (!d_base || !d_out)))
 		return fail(GEC_E_INVALID_ARG, "NULL argument");
@@ -1684,11 +1742,23 @@ int gec_blake2sum_batch_dev(const gec_codec *c, size_t n, const void *d_base, si
 	DeviceGuard g(c->device);
 	if (!g.ok)
 		return fail(GEC_E_DEVICE, "hipSetDevice failed");
-	return blake2_dev(n, static_cast<const uint8_t *>(d_base), nullptr, nullptr, stride, len,
-			  static_cast<uint8_t *>(d_out), static_cast<hipStream_t>(hip_stream));
+	return blake2_dev(c, n, static_cast<const uint8_t *>(d_base), nullptr, nullptr, stride, len,
+			  static_cast<uint8_t *>(d_out), static_cast<hipStream_t>(hip_stream), 0, 0, 0, tree != 0, len);
 }
 
-int gec_blake2sum_batch(const gec_codec *c, size_t n, const uint8_t *const *msgs, const size_t *lens, uint8_t *out)
+int gec_blake2sum_batch_dev(const gec_codec *c, size_t n, const void *d_base, size_t stride, size_t len, void *d_out,
+			    void *hip_stream)
+{
+	return hash_batch_dev_impl(c, n, d_base, stride, len, d_out, hip_stream, 0);
+}
+
+int gec_shardsum_batch_dev(const gec_codec *c, size_t n, const void *d_base, size_t stride, size_t len, void *d_out,
+			   void *hip_stream)
+{
+	return hash_batch_dev_impl(c, n, d_base, stride, len, d_out, hip_stream, 1);
+}
+
+static int hash_batch_impl(const gec_codec *c, size_t n, const uint8_t *const *msgs, const size_t *lens, uint8_t *out, bool tree)
 {
 	if (!c)
 		return fail(GEC_E_INVALID_ARG, "NULL codec");
@@ -1712,7 +1782,7 @@ int gec_blake2sum_batch(const gec_codec *c, size_t n, const uint8_t *const *msgs
 	// (b) long messages (a BLAKE2b chain costs ~4000 cycles per 128-byte block however many messages run
 	//     beside it: 14 ms per MiB): everything is first moved into ONE device buffer through two pinned
 	//     staging pieces, then hashed by ONE launch -- chunked launches would pay the chain once per chunk.
-	if (all_pinned || longest >= (256u << 10)) {
+	if (all_pinned || longest >= (256u << 10) || tree) {
 		DeviceGuard dg(c->device);
 		if (!dg.ok)
 			return fail(GEC_E_DEVICE, "hipSetDevice failed");
@@ -1726,8 +1796,8 @@ int gec_blake2sum_batch(const gec_codec *c, size_t n, const uint8_t *const *msgs
 		if (!all_pinned && dev_bytes > (8ull << 30)) {
 			// more than a device buffer should hold at once: halves (each still one launch)
 			const size_t h = n / 2;
-			int rc = gec_blake2sum_batch(c, h, msgs, lens, out);
-			return rc ? rc : gec_blake2sum_batch(c, n - h, msgs + h, lens + h, out + 32 * h);
+			int rc = hash_batch_impl(c, h, msgs, lens, out, tree);
+			return rc ? rc : hash_batch_impl(c, n - h, msgs + h, lens + h, out + 32 * h, tree);
 		}
 		StagingLease l0(c);
 		const size_t meta = n * 16, res = n * 32;
@@ -1807,7 +1877,7 @@ int gec_blake2sum_batch(const gec_codec *c, size_t n, const uint8_t *const *msgs
 			}
 		}
 		// the (offset, length) table and the results live in pinned host memory the kernel reads / writes directly
-		rc = blake2_dev(n, all_pinned ? nullptr : d_msgs, h_off, h_len, 0, 0, h_out, st.stream);
+		rc = blake2_dev(c, n, all_pinned ? nullptr : d_msgs, h_off, h_len, 0, 0, h_out, st.stream, 0, 0, 0, tree, longest);
 		if (rc)
 			return cleanup(rc);
 		hipError_t e = hipStreamSynchronize(st.stream);
@@ -1857,7 +1927,7 @@ int gec_blake2sum_batch(const gec_codec *c, size_t n, const uint8_t *const *msgs
 			HIP_TRY(hipMemcpyAsync(st.d_buf, st.h_buf, ck.bytes, hipMemcpyHostToDevice, st.stream));
 			HIP_TRY(hipMemcpyAsync(st.d_buf + meta_off, st.h_buf + meta_off, 16 * ck.count, hipMemcpyHostToDevice, st.stream));
 			const uint64_t *d_off = reinterpret_cast<const uint64_t *>(st.d_buf + meta_off);
-			int rc = blake2_dev(ck.count, st.d_buf, d_off, d_off + ck.count, 0, 0, st.d_buf + out_off, st.stream);
+			int rc = blake2_dev(c, ck.count, st.d_buf, d_off, d_off + ck.count, 0, 0, st.d_buf + out_off, st.stream);
 			if (rc)
 				return rc;
 			HIP_TRY(hipMemcpyAsync(st.h_buf + out_off, st.d_buf + out_off, 32 * ck.count, hipMemcpyDeviceToHost, st.stream));
@@ -1867,6 +1937,16 @@ int gec_blake2sum_batch(const gec_codec *c, size_t n, const uint8_t *const *msgs
 			const Chunk &ck = chunks[ci];
 			std::memcpy(out + 32 * ck.first, st.h_buf + out_off, 32 * ck.count);
 		});
+}
+
+int gec_blake2sum_batch(const gec_codec *c, size_t n, const uint8_t *const *msgs, const size_t *lens, uint8_t *out)
+{
+	return hash_batch_impl(c, n, msgs, lens, out, false);
+}
+
+int gec_shardsum_batch(const gec_codec *c, size_t n, const uint8_t *const *msgs, const size_t *lens, uint8_t *out)
+{
+	return hash_batch_impl(c, n, msgs, lens, out, true);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2057,7 +2137,7 @@ int gec_decode_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *c
 		e = hipStreamWaitEvent(st.stream2, ev_up, 0);
 	if (e != hipSuccess)
 		return finish(hip_fail(e, "fork"));
-	rc = blake2_dev(nup, st.d_big, h_soff, h_slen, 0, 0, st.h_buf + ssum_off, st.stream2);
+	rc = blake2_dev(c, nup, st.d_big, h_soff, h_slen, 0, 0, st.h_buf + ssum_off, st.stream2, 0, 0, 0, true, S);
 	if (rc)
 		return finish(rc);
 	e = hipEventRecord(ev_sh, st.stream2);
@@ -2090,7 +2170,7 @@ int gec_decode_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *c
 			}
 	}
 	if (block_sums) {
-		rc = blake2_dev(nblocks, st.d_big, h_boff, h_blen, 0, 0, st.h_buf + bsum_off, st.stream);
+		rc = blake2_dev(c, nblocks, st.d_big, h_boff, h_blen, 0, 0, st.h_buf + bsum_off, st.stream);
 		if (rc)
 			return finish(rc);
 	}
@@ -2226,7 +2306,14 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 		if (nmiss == 0)
 			continue;
 		const size_t stripe = (k + nmiss) * S;
-		const size_t ch = chunk_blocks(stripe, ids.size(), kChunkBytes);
+		bool all_pinned = true;
+		for (size_t i = 0; i < ids.size() && all_pinned; ++i) {
+			for (size_t t = 0; t < k && all_pinned; ++t)
+				all_pinned = aligned16(shards[ids[i] * n + plan->valid[t]]) && pinned().contains(shards[ids[i] * n + plan->valid[t]], S);
+			for (size_t r = 0; r < nmiss && all_pinned; ++r)
+				all_pinned = aligned16(out[ids[i] * n + plan->missing[r]]) && pinned().contains(out[ids[i] * n + plan->missing[r]], S);
+		}
+		const size_t ch = chunk_blocks(stripe, ids.size(), all_pinned ? 8 * kChunkBytes : kChunkBytes);
 		std::vector<size_t> in_off(k), out_off(nmiss);
 		for (size_t t = 0; t < k; ++t)
 			in_off[t] = t * S;

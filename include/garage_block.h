@@ -71,6 +71,8 @@ const char *gbm_last_error(void);
 
 /* Garage's content hash: blake2b-512 truncated to 32 bytes (NOT blake2b-256). */
 void gbm_blake2sum(const uint8_t *data, size_t len, uint8_t out[32]);
+/* The checksum every shard header carries: BLAKE2b tree mode ("shardsum", include/garage_ec.h), CPU restatement. */
+void gbm_shardsum(const uint8_t *data, size_t len, uint8_t out[32]);
 
 /* node_dirs == NULL: in-memory nodes; otherwise nnodes directory roots using
  * Garage's naming <root>/<h0>/<h1>/<hex>.s<idx> (src/block/layout.rs:286-291).

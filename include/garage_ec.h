@@ -32,7 +32,8 @@
  *   GEC_COPY_THREADS=n          staging-copy threads per codec for the host-pointer calls (default 7)
  *   GEC_RCCL_LIB=path           RCCL to dlopen for gec_group_* (default librccl.so.1)
  *   GEC_ROWS16=0                A/B: 9..16 output rows as 8-row passes instead of one 16-row pass
- *   GEC_BLAKE2_KERNEL=lane|quad A/B: force one of the two blake2 kernels
+ *   GEC_BLAKE2_KERNEL=lane|quad A/B: force one of the two (plain) blake2 kernels
+ *   GEC_HASH_FORK=0             A/B: encode+checksum on one stream instead of data-shard checksums beside the encode
  *   GEC_MAX_COLS_PER_LAUNCH=n   test hook: exercise the multi-launch split on small inputs
  */
 #ifndef GARAGE_EC_H
@@ -293,7 +294,29 @@ int gec_blake2sum_batch(const gec_codec *c, size_t n,
 			const uint8_t *const *msgs, const size_t *lens,
 			uint8_t *out);
 
-/* gec_encode_batch + the blake2sum of all k+m shards of every block, computed on
+/* SHARD CHECKSUMS ("shardsum").  Shards are this project's own storage format (Garage has none), and their
+ * checksum is BLAKE2b in its standard TREE mode (BLAKE2 specification section 2.10, parameter block of RFC 7693
+ * section 2.5): leaves of GEC_SHARDSUM_LEAF bytes, unlimited fanout, depth 2, 64-byte inner digests, the root's
+ * 64-byte digest truncated to 32 bytes like blake2sum.  Python's hashlib reproduces it:
+ *   leaf i = blake2b(shard[i*4096:(i+1)*4096], digest_size=64, fanout=0, depth=2, leaf_size=4096, node_offset=i,
+ *                    node_depth=0, inner_size=64, last_node=(i == nleaves-1)).digest()
+ *   sum    = blake2b(b"".join(leaves), digest_size=64, fanout=0, depth=2, leaf_size=4096, node_offset=0,
+ *                    node_depth=1, inner_size=64, last_node=True).digest()[:32]
+ * Why a tree: one BLAKE2b message is one serial dependency chain, and on MI355X a lone wave issues one VALU
+ * instruction per ~5 cycles -- the 14336 shards of a 1024-block batch take 1.4 ms as plain BLAKE2b however the
+ * kernel is written (profiles/r02_valu_probe.txt), 5x the RS encode beside them.  26 independent leaves per
+ * shard fill the machine.  Block NAMES remain plain blake2sum: they are Garage's (src/util/data.rs:130-138). */
+#define GEC_SHARDSUM_LEAF 4096
+/* n shards of `len` bytes, shard i at d_base + i*stride; d_out receives 32 bytes each.  Async. */
+int gec_shardsum_batch_dev(const gec_codec *c, size_t n, const void *d_base,
+			   size_t stride, size_t len, void *d_out,
+			   void *hip_stream);
+/* Host buffers of arbitrary lengths (16-byte aligned pinned buffers are read in place); out = n*32 bytes. */
+int gec_shardsum_batch(const gec_codec *c, size_t n,
+		       const uint8_t *const *msgs, const size_t *lens,
+		       uint8_t *out);
+
+/* gec_encode_batch + the shardsum of all k+m shards of every block, computed on
  * the device while the stripe is resident: shard_sums[(b*(k+m) + j)*32 ..] is the
  * checksum of shard j of block b (data shards as zero-extended to S bytes). */
 int gec_encode_hash_batch(const gec_codec *c, size_t nblocks,
@@ -305,7 +328,7 @@ int gec_encode_hash_batch(const gec_codec *c, size_t nblocks,
  * read_block_from does on the serving node (:577-609):
  *   - shards[b*n + j] (S bytes each, NULL = not in hand; >= k per block, else GEC_E_TOO_FEW_PRESENT): the first
  *     k present shards of every block are uploaded (the crate's rule);
- *   - shard_sums[(b*n + j)*32] receives the blake2sum of every shard that was uploaded (entries of the others
+ *   - shard_sums[(b*n + j)*32] receives the shardsum of every shard that was uploaded (entries of the others
  *     are left untouched) -- the caller compares them with the checksums in the shard headers;
  *   - missing DATA shards are rebuilt into rebuilt[b*n + j] (S bytes; must be non-NULL exactly for those);
  *   - block_sums (may be NULL): blake2sum of the first block_len[b] bytes of block b's data area, i.e. of the

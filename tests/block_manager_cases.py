@@ -6,6 +6,7 @@ import pytest
 
 from garage_amd.block_manager import (BlockManager, CorruptData, DataBlock, DataBlockHeader, DirShardStore,
                                       MemoryShardStore, MissingBlock, Quorum, ShardHeader)
+from garage_amd.codec import shardsum
 from garage_amd.partition import block_hash
 
 
@@ -43,7 +44,7 @@ def scenario_put_get_roundtrip(codec, tmp_path):
         rawshard = stores[node].get(h, j)
         hdr = ShardHeader.unpack(rawshard)
         assert (hdr.k, hdr.m, hdr.idx, hdr.orig_len) == (codec.k, codec.m, j, 65536)
-        assert block_hash(rawshard[ShardHeader.SIZE:]) == hdr.checksum
+        assert shardsum(rawshard[ShardHeader.SIZE:]) == hdr.checksum
     hx = h.hex()
     assert (tmp_path / f"node{who[0]}" / hx[:2] / hx[2:4] / f"{hx}.s0").exists()
 
@@ -132,7 +133,7 @@ def scenario_scrub_finds_silent_corruption(codec):
     raw = bytearray(stores[who[j]].get(h, j))
     raw[ShardHeader.SIZE + 77] ^= 1
     hdr = ShardHeader.unpack(bytes(raw))
-    hdr.checksum = block_hash(bytes(raw[ShardHeader.SIZE:]))
+    hdr.checksum = shardsum(bytes(raw[ShardHeader.SIZE:]))
     stores[who[j]].put(h, j, hdr.pack() + bytes(raw[ShardHeader.SIZE:]))
     assert mgr.scrub(hashes) == [h]
     # wrong content under a valid name is caught by the block hash on read of a plain block
@@ -176,7 +177,7 @@ def scenario_geometry_is_a_function_of_the_block(codec):
 
     assert ShardHeader.unpack(alone[0]).shard_len == garage_amd.shard_len(codec.k, len(small))
     mgr.block_incref(hs)
-    hdr = ShardHeader(codec.k, codec.m, 0, False, 1000, 64, block_hash(bytes(64)))
+    hdr = ShardHeader(codec.k, codec.m, 0, False, 1000, 64, shardsum(bytes(64)))
     stores[who[0]].put(hs, 0, hdr.pack() + bytes(64))     # stale shard of another geometry
     assert mgr.rpc_get_block(hs) == small                  # majority geometry wins
     assert mgr.resync_all() >= 1                           # and resync overwrites the stray shard

@@ -159,7 +159,7 @@ int main(int argc, char **argv)
 			sp[j] = j < 10 ? b2 + j * S2 : p2 + (j - 10) * S2;
 			sl[j] = S2;
 		}
-		CHECK(gec_blake2sum_batch(c, 14, sp, sl, direct) == GEC_OK);
+		CHECK(gec_shardsum_batch(c, 14, sp, sl, direct) == GEC_OK);   /* shard checksums are BLAKE2b tree mode */
 		CHECK(memcmp(shard_sums, direct, sizeof direct) == 0);
 		free(b2);
 		free(p2);

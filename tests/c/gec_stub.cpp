@@ -49,7 +49,7 @@ int gec_encode_hash_batch(const gec_codec *c, size_t nb, const uint8_t *const *b
 		if (rso_encode(k, m, S, d.data(), p.data(), RSO_SCALAR) != RSO_OK)
 			return GEC_E_INVALID_ARG;
 		for (int j = 0; j < k + m; ++j)
-			gbm_blake2sum(j < k ? d[j] : p[j - k], S, sums + (b * (k + m) + j) * 32);
+			gbm_shardsum(j < k ? d[j] : p[j - k], S, sums + (b * (k + m) + j) * 32);
 	}
 	return GEC_OK;
 }
@@ -104,7 +104,7 @@ int gec_decode_verify_batch(const gec_codec *c, size_t nb, const uint8_t *const 
 				present[j] = 1;
 				++seen;
 				std::memcpy(buf[j].data(), shards[b * n + j], S);
-				gbm_blake2sum(shards[b * n + j], S, shard_sums + (b * n + j) * 32);
+				gbm_shardsum(shards[b * n + j], S, shard_sums + (b * n + j) * 32);
 			}
 		}
 		if (seen < k)
@@ -136,6 +136,13 @@ int gec_verify_batch(const gec_codec *c, size_t nb, const uint8_t *const *shards
 			return GEC_E_INVALID_ARG;
 		ok[b] = (uint8_t)good;
 	}
+	return GEC_OK;
+}
+
+int gec_shardsum_batch(const gec_codec *, size_t n, const uint8_t *const *msgs, const size_t *lens, uint8_t *out)
+{
+	for (size_t i = 0; i < n; ++i)
+		gbm_shardsum(msgs[i], lens[i], out + 32 * i);
 	return GEC_OK;
 }
 

@@ -32,6 +32,15 @@ def test_blake2sum_is_blake2b512_truncated(n):
     assert bn.blake2sum(d) != hashlib.blake2b(d, digest_size=32).digest(), "NOT blake2b-256 (src/util/data.rs:130-138)"
 
 
+@pytest.mark.parametrize("n", [0, 1, 64, 4095, 4096, 4097, 8192, 104896, 209728, (1 << 20) + 3])
+def test_shardsum_is_blake2b_tree_mode(n):
+    """The shard checksum restated three times -- C++ (libgarage_block), hashlib with BLAKE2's tree parameters
+    (garage_amd.codec.shardsum), and (GPU tests) the device kernels -- must agree; it is NOT the plain hash."""
+    d = bytes(pattern_block(n, salt=n + 1)) if n else b""
+    assert bn.shardsum(d) == g.shardsum(d)
+    assert bn.shardsum(d) != bn.blake2sum(d)
+
+
 def test_create_rejects_null_codec():
     h = ctypes.c_void_p()
     assert bn.lib.gbm_create(None, 14, None, 0, ctypes.byref(h)) == bn.GBM_E_INVALID_ARG
@@ -71,7 +80,7 @@ def test_native_put_get_roundtrip(codec, tmp_path):
     raw = p.read_bytes()
     hdr = ShardHeader.unpack(raw)
     assert (hdr.k, hdr.m, hdr.idx, hdr.orig_len) == (codec.k, codec.m, 0, 65536)
-    assert bn.blake2sum(raw[64:]) == hdr.checksum
+    assert bn.shardsum(raw[64:]) == hdr.checksum == g.shardsum(raw[64:])
     assert mgr.metrics["blocks_put"] == 4 and mgr.metrics["blocks_get"] == 4
 
 

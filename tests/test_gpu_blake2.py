@@ -59,7 +59,8 @@ def test_uniform_device_api_shard_shape(rs):
 @pytest.mark.parametrize("k,m,S,nb", [(10, 4, 104896, 24), (3, 1, 64, 70), (20, 8, 4160, 5), (10, 4, 128, 1), (10, 4, 192, 3)])
 def test_encode_hash_dev_fork_join(coracle, k, m, S, nb):
     """gec_encode_hash_batch_dev: the checksums of the data shards are computed on a second stream beside
-    the RS kernel, the parity checksums behind it; parity vs the oracle, every checksum vs hashlib --
+    the RS kernel, the parity checksums behind it; parity vs the oracle, every checksum vs the hashlib restatement
+    of the shard checksum (BLAKE2b tree mode, garage_amd.codec.shardsum) --
     repeated back to back so that a missing stream dependency would show as a stale checksum."""
     rs = g.ReedSolomon(k, m)
     for rep in range(3):
@@ -73,7 +74,7 @@ def test_encode_hash_dev_fork_join(coracle, k, m, S, nb):
         got = sums.cpu().numpy()
         for b in range(nb):
             for j in range(k + m):
-                assert got[b, j].tobytes() == ref(full[b, j].tobytes()), (rep, b, j)
+                assert got[b, j].tobytes() == g.shardsum(full[b, j].tobytes()), (rep, b, j)
 
 
 def test_blake2_quad_and_lane_kernels_agree_on_tails(rs):
@@ -111,7 +112,7 @@ def test_encode_hash_batch_sums_every_shard(coracle, rs):
         assert np.array_equal(pars[b], want_par)
         for j in range(k + m):
             payload = shards[j] if j < k else want_par[j - k]
-            assert sums[b, j].tobytes() == ref(payload.tobytes()), (b, j)
+            assert sums[b, j].tobytes() == g.shardsum(payload.tobytes()), (b, j)
 
 
 @pytest.mark.parametrize("kernel", ["lane", "quad"])
@@ -172,5 +173,40 @@ def test_host_blake2sum_zero_copy_and_single_launch_paths(rs):
         l1 = (ctypes.c_size_t * 1)(1 << 20)
         check(lib.gec_blake2sum_batch(rs._h, 1, p1, l1, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), "slice")
         assert out[0].tobytes() == ref(msgs[3][off:off + (1 << 20)].tobytes())
+    for p_ in pinned:
+        host_free(p_)
+
+
+
+def test_shardsum_tree_mode_against_hashlib(rs):
+    """The shard checksum (BLAKE2b tree mode: 4 KiB leaves, unlimited fanout, depth 2, inner 64) on the device vs
+    hashlib with the same tree parameters: lengths around the leaf boundary, one / many leaves, ragged batches
+    through the host API, uniform shard-shaped batches through the device API, pinned zero-copy input."""
+    import ctypes
+
+    from garage_amd._lib import check, lib
+    from garage_amd.codec import host_alloc, host_free
+
+    lens = [0, 1, 63, 64, 127, 128, 129, 4095, 4096, 4097, 8191, 8192, 8193, 12288, 104896, 209728, 1 << 20, (1 << 20) + 5]
+    msgs = [bytes(O.splitmix64_bytes(300 + i, n)) for i, n in enumerate(lens)]
+    assert rs.shardsum_batch(msgs) == [g.shardsum(x) for x in msgs]
+    assert rs.shardsum_batch([b"abc"])[0] != ref(b"abc"), "the shard checksum is not the plain hash"
+    for S in (64, 4096, 4160, 104896):
+        n = 97
+        data = O.splitmix64_bytes(77 + S, n * S).reshape(n, S)
+        out = rs.shardsum_dev(torch.from_numpy(data).to("cuda:0"))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for i in range(n):
+            assert got[i].tobytes() == g.shardsum(data[i].tobytes()), (S, i)
+    pinned = [host_alloc(max(len(x), 16)) for x in msgs]
+    for p_, x in zip(pinned, msgs):
+        p_[:len(x)] = np.frombuffer(x, dtype=np.uint8)
+    n = len(msgs)
+    ptrs = (ctypes.c_void_p * n)(*[p_.ctypes.data for p_ in pinned])
+    clens = (ctypes.c_size_t * n)(*lens)
+    out = np.zeros((n, 32), dtype=np.uint8)
+    check(lib.gec_shardsum_batch(rs._h, n, ptrs, clens, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), "pinned shardsum")
+    assert [out[i].tobytes() for i in range(n)] == [g.shardsum(x) for x in msgs]
     for p_ in pinned:
         host_free(p_)
