@@ -72,14 +72,16 @@ __device__ __forceinline__ uint64_t b2_rotr(uint64_t x)
 	return b2_mk64(__builtin_amdgcn_alignbit(lo, hi, N - 32), __builtin_amdgcn_alignbit(hi, lo, N - 32));
 }
 
-// 64-bit add: ADD32 = false keeps hipcc's own choice, v_lshl_add_u64 (one instruction), which is what
-// both kernels use.  ADD32 = true spells it as add + add-with-carry on the halves; measured 1.44x SLOWER
-// in round 1 (the carry travels through VCC, which serialises the four independent G chains), kept as the
-// A/B switch of tools/blake2_bench.py.
-template <bool ADD32>
+// ADD32 selects how a 64-bit add is spelled (GEC_B2_ADD=0|1 is the A/B switch, tools/shardsum_bench.py):
+//   0  v_lshl_add_u64, hipcc's own choice and the default;
+//   1  v_add_co_u32 + v_addc_co_u32: 1.4x SLOWER, alone on a SIMD and with six waves per SIMD alike.
+// (A third spelling -- carry out of bit 31 computed with v_bitop3_b32 and folded in with v_add3_u32, four
+// full-rate instructions -- was tried in round 2 and measured 1.5x slower than v_lshl_add_u64 as well:
+// profiles/r02_shardsum.txt.  The 64-bit add is not the bottleneck it looks like on paper.)
+template <int ADD32>
 __device__ __forceinline__ uint64_t b2_add(uint64_t a, uint64_t b)
 {
-	if (!ADD32)
+	if (ADD32 == 0)
 		return a + b;
 	uint32_t lo, hi;
 	const uint32_t carry = __builtin_uadd_overflow((uint32_t)a, (uint32_t)b, &lo);
@@ -107,7 +109,7 @@ __device__ __forceinline__ uint64_t b2_add(uint64_t a, uint64_t b)
 	GEC_B2_G(v2, v7, v8, v13, m[s12], m[s13]);                                         \
 	GEC_B2_G(v3, v4, v9, v14, m[s14], m[s15]);
 
-template <bool ADD32>
+template <int ADD32>
 __device__ __forceinline__ void b2_compress(uint64_t (&h)[8], const uint64_t (&m)[16], uint64_t t, bool last, bool last_node = false)
 {
 	const uint64_t IV0 = 0x6a09e667f3bcc908ULL, IV1 = 0xbb67ae8584caa73bULL, IV2 = 0x3c6ef372fe94f82bULL,
@@ -143,7 +145,7 @@ typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 
 // Messages must start on 16-byte boundaries (shards do: 64-byte geometry; the host
 // API stages each message into a 16-byte aligned slot).
-template <bool ADD32>
+template <int ADD32>
 __global__ __launch_bounds__(64) void blake2b_batch(const Blake2Args a)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -434,6 +436,7 @@ constexpr uint64_t SHARDSUM_P2_ROOT = 1ull | (64ull << 8);
 
 // One lane per LEAF: lane i hashes leaf (i % nleaf) of shard (i / nleaf); shards addressed like messages of
 // Blake2Args (flat / grouped / offset table, uniform or per-shard lengths).  leafdig: [shard][leaf][64].
+template <int ADD32>
 __global__ __launch_bounds__(64) void shardsum_leaves(const Blake2Args a, uint32_t nleaf_max, uint8_t *__restrict__ leafdig)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(64) void shardsum_leaves(const Blake2Args a, uint32
 			m[2 * j + 1] = w.y;
 		}
 		done += 128;
-		b2_compress<false>(h, m, done, false);
+		b2_compress<ADD32>(h, m, done, false);
 	}
 	const uint64_t rem = len - done;
 #pragma unroll
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(64) void shardsum_leaves(const Blake2Args a, uint32
 		}
 		m[j] = w;
 	}
-	b2_compress<false>(h, m, len, true, last_node);
+	b2_compress<ADD32>(h, m, len, true, last_node);
 	u64x2 *o = reinterpret_cast<u64x2 *>(leafdig + ((uint64_t)s * nleaf_max + l) * 64);
 	o[0] = u64x2{h[0], h[1]};
 	o[1] = u64x2{h[2], h[3]};
@@ -508,13 +511,13 @@ __global__ __launch_bounds__(64) void shardsum_roots(const Blake2Args a, uint32_
 			m[2 * j + 1] = w.y;
 		}
 		done += 128;
-		b2_compress<false>(h, m, done, false);
+		b2_compress<0>(h, m, done, false);
 	}
 	const uint64_t rem = len - done;  // 64 or 128
 #pragma unroll
 	for (int j = 0; j < 16; ++j)
 		m[j] = (uint64_t)(8 * j) < rem ? *reinterpret_cast<const uint64_t *>(p + done + 8 * j) : 0;
-	b2_compress<false>(h, m, len, true, true);
+	b2_compress<0>(h, m, len, true, true);
 	u64x2 *o = reinterpret_cast<u64x2 *>(b2_out_ptr(a, s));
 	o[0] = u64x2{h[0], h[1]};
 	o[1] = u64x2{h[2], h[3]};

@@ -865,7 +865,12 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 		int rc = leaf_scratch(c, stream, lanes * 64, &scratch);
 		if (rc)
 			return rc;
-		hipLaunchKernelGGL(gec::shardsum_leaves, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, stream, a, nleaf, scratch);
+		static const int addmode = [] { const char *e = getenv("GEC_B2_ADD"); return e ? atoi(e) : 0; }();  // A/B, see blake2b.hpp
+		const dim3 lgrid((unsigned)((lanes + 63) / 64));
+		if (addmode == 0)
+			hipLaunchKernelGGL(gec::shardsum_leaves<0>, lgrid, dim3(64), 0, stream, a, nleaf, scratch);
+		else
+			hipLaunchKernelGGL(gec::shardsum_leaves<1>, lgrid, dim3(64), 0, stream, a, nleaf, scratch);
 		HIP_TRY(hipGetLastError());
 		hipLaunchKernelGGL(gec::shardsum_roots, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a, nleaf, scratch);
 		HIP_TRY(hipGetLastError());
@@ -882,7 +887,13 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 	if (quad)
 		hipLaunchKernelGGL(gec::blake2b_batch_quad, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, stream, a);
 	else
-		hipLaunchKernelGGL(gec::blake2b_batch<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a);
+		{
+		static const int addmode = [] { const char *e = getenv("GEC_B2_ADD"); return e ? atoi(e) : 0; }();
+		if (addmode == 0)
+			hipLaunchKernelGGL(gec::blake2b_batch<0>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a);
+		else
+			hipLaunchKernelGGL(gec::blake2b_batch<1>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a);
+	}
 	HIP_TRY(hipGetLastError());
 	return GEC_OK;
 }
