@@ -41,6 +41,7 @@ SYMBOLS = [
     "gec_encode_hash_batch", "gec_set_kernel_variant", "gec_get_kernel_variant",
     "gec_group_unique_id", "gec_group_create", "gec_group_create_with_transport", "gec_group_destroy",
     "gec_group_rank", "gec_group_size", "gec_group_slots", "gec_group_allgather_decode",
+    "gec_group_create_with_transport2", "gec_group_alltoall_decode", "gec_group_bytes_exchanged",
     "gec_launch_geometry",
     "gec_encode_hash_batch_dev", "gec_decode_verify_batch", "gec_shardsum_batch", "gec_shardsum_batch_dev", "gec_host_alloc", "gec_host_free", "gec_host_register", "gec_host_unregister", "gec_host_is_pinned",
 ]
@@ -138,6 +139,10 @@ def _load() -> ctypes.CDLL:
     lib.gec_group_slots.argtypes = [vp]
     lib.gec_group_slots.restype = sz
     lib.gec_group_allgather_decode.argtypes = [vp, sz, vp, sz, u8p, ci, ci, vp, vp]
+    lib.gec_group_create_with_transport2.argtypes = [vp, ci, ci, vp, vp, vp, pp]
+    lib.gec_group_alltoall_decode.argtypes = [vp, sz, vp, sz, u8p, ci, ci, vp, vp]
+    lib.gec_group_bytes_exchanged.argtypes = [vp]
+    lib.gec_group_bytes_exchanged.restype = ctypes.c_uint64
     return lib
 
 

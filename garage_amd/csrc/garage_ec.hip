@@ -258,6 +258,7 @@ struct Staging {
 	// fork/join partner of `stream`: the blake2 of the data shards runs here, beside the RS kernel
 	hipStream_t stream2 = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipEvent_t ev_in = nullptr, ev_out = nullptr;  // "this slot's copy-in / copy-out kernel is done" (PipeChain)
 	uint8_t *h_buf = nullptr, *d_buf = nullptr;
 	size_t cap = 0;
 	uint32_t *d_bad = nullptr, *h_bad = nullptr;
@@ -304,6 +305,8 @@ struct Staging {
 			HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
 			HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
 			HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
 		}
 		if (bytes > cap) {
 			if (h_buf)
@@ -351,6 +354,10 @@ struct Staging {
 			(void)hipEventDestroy(ev_fork);
 		if (ev_join)
 			(void)hipEventDestroy(ev_join);
+		if (ev_in)
+			(void)hipEventDestroy(ev_in);
+		if (ev_out)
+			(void)hipEventDestroy(ev_out);
 		*this = Staging();
 	}
 };
@@ -403,6 +410,10 @@ struct Rccl {
 	decltype(&ncclCommInitRank) CommInitRank = nullptr;
 	decltype(&ncclCommDestroy) CommDestroy = nullptr;
 	decltype(&ncclAllGather) AllGather = nullptr;
+	decltype(&ncclSend) Send = nullptr;
+	decltype(&ncclRecv) Recv = nullptr;
+	decltype(&ncclGroupStart) GroupStart = nullptr;
+	decltype(&ncclGroupEnd) GroupEnd = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
 	std::string error;
 };
@@ -429,7 +440,12 @@ const Rccl &rccl()
 		x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.handle, "ncclCommDestroy"));
 		x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.handle, "ncclAllGather"));
 		x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.handle, "ncclGetErrorString"));
-		if (!x.GetUniqueId || !x.CommInitRank || !x.CommDestroy || !x.AllGather || !x.GetErrorString) {
+		x.Send = reinterpret_cast<decltype(x.Send)>(dlsym(x.handle, "ncclSend"));
+		x.Recv = reinterpret_cast<decltype(x.Recv)>(dlsym(x.handle, "ncclRecv"));
+		x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(x.handle, "ncclGroupStart"));
+		x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(x.handle, "ncclGroupEnd"));
+		if (!x.GetUniqueId || !x.CommInitRank || !x.CommDestroy || !x.AllGather || !x.GetErrorString || !x.Send || !x.Recv ||
+		    !x.GroupStart || !x.GroupEnd) {
 			x.error = "RCCL library lacks a required symbol";
 			x.handle = nullptr;
 		}
@@ -443,8 +459,13 @@ struct gec_group {
 	const gec_codec *c = nullptr;
 	int rank = 0, nranks = 1;
 	gec_allgather_fn all_gather = nullptr;
+	gec_alltoall_fn all_to_all = nullptr;
 	void *ctx = nullptr;
 	ncclComm_t comm = nullptr;  // RCCL transport only
+	// all-to-all exchange scratch
+	uint8_t *d_a2a_send = nullptr, *d_a2a_recv = nullptr;
+	size_t a2a_cap = 0;
+	uint64_t bytes_exchanged = 0;  // bytes this rank RECEIVED from other ranks in the last decode call
 	// scratch for the exchange of the rebuilt ranges (step 3)
 	uint8_t *d_send = nullptr, *d_recv = nullptr;
 	size_t send_cap = 0, recv_cap = 0;
@@ -458,6 +479,26 @@ int rccl_all_gather(void *ctx, const void *d_send, void *d_recv, size_t bytes, v
 	ncclResult_t r = rccl().AllGather(d_send, d_recv, bytes, ncclUint8, g->comm, static_cast<hipStream_t>(hip_stream));
 	if (r != ncclSuccess)
 		return fail(GEC_E_DEVICE, std::string("ncclAllGather: ") + rccl().GetErrorString(r));
+	return GEC_OK;
+}
+
+// all-to-all over RCCL: one grouped ncclSend/ncclRecv pair per peer (xGMI is a full mesh: every pair has its own link)
+int rccl_all_to_all(void *ctx, const void *d_send, void *d_recv, size_t bytes, void *hip_stream)
+{
+	gec_group *g = static_cast<gec_group *>(ctx);
+	const Rccl &R = rccl();
+	hipStream_t s = static_cast<hipStream_t>(hip_stream);
+	ncclResult_t r = R.GroupStart();
+	for (int q = 0; q < g->nranks && r == ncclSuccess; ++q) {
+		r = R.Send(static_cast<const uint8_t *>(d_send) + (size_t)q * bytes, bytes, ncclUint8, q, g->comm, s);
+		if (r == ncclSuccess)
+			r = R.Recv(static_cast<uint8_t *>(d_recv) + (size_t)q * bytes, bytes, ncclUint8, q, g->comm, s);
+	}
+	ncclResult_t e = R.GroupEnd();
+	if (r == ncclSuccess)
+		r = e;
+	if (r != ncclSuccess)
+		return fail(GEC_E_DEVICE, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(r));
 	return GEC_OK;
 }
 
@@ -1011,10 +1052,48 @@ size_t chunk_blocks(size_t bytes_per_block, size_t nblocks, size_t target)
 
 constexpr size_t kChunkBytes = 16ull << 20;  // staging chunk: small enough to overlap, big enough to fill the GPU
 
-// Host-pointer calls run their chunks through two staging slots, each with its own
-// stream: while chunk i is on the PCIe bus / in the kernel, the host drains chunk
-// i-1 and fills chunk i+1.  fill/drain run on the calling thread (+ copy pool),
-// enqueue only queues asynchronous work on st.stream.
+// chunk size when the caller's memory is pinned end to end (no host staging to bound): GEC_PINNED_CHUNK_MB, default 128
+size_t pinned_chunk_bytes()
+{
+	static const size_t v = [] {
+		const char *e = getenv("GEC_PINNED_CHUNK_MB");
+		const size_t mb = e ? strtoull(e, nullptr, 0) : 128;  // sweep on MI355X: 16..64 MiB 33-37 GiB/s, 128 MiB 45, 256 MiB 39
+		return std::max<size_t>(mb, 1) << 20;
+	}();
+	return v;
+}
+
+// Host-pointer calls run their chunks through three staging slots, each with its own stream: while
+// chunk i is on the PCIe bus / in the kernel, the host drains chunk i-2 and fills chunk i+1.  fill/drain
+// run on the calling thread (+ copy pool), enqueue only queues asynchronous work on st.stream.
+// Copy KERNELS (pinned callers) additionally chain through PipeChain so that the copies of one direction
+// run one after the other: left alone, the slots phase-lock -- all copy-ins at once, then all copy-outs --
+// and the link idles in one direction at a time.
+struct PipeChain {
+	hipEvent_t last_in = nullptr, last_out = nullptr;
+	// call before / after launching a copy on `stream`; `mine` = the slot's event for that direction
+	int before(hipEvent_t last, hipStream_t stream)
+	{
+		if (last)
+			HIP_TRY(hipStreamWaitEvent(stream, last, 0));
+		return GEC_OK;
+	}
+	int after_in(Staging &st)
+	{
+		HIP_TRY(hipEventRecord(st.ev_in, st.stream));
+		last_in = st.ev_in;
+		return GEC_OK;
+	}
+	int after_out(Staging &st)
+	{
+		HIP_TRY(hipEventRecord(st.ev_out, st.stream));
+		last_out = st.ev_out;
+		return GEC_OK;
+	}
+};
+
+constexpr size_t kSlots = 3;
+
 template <class Fill, class Enqueue, class Drain>
 int run_pipeline(const gec_codec *c, size_t nchunks, size_t slot_bytes, size_t nbad, Fill fill, Enqueue enqueue,
 		 Drain drain)
@@ -1022,29 +1101,36 @@ int run_pipeline(const gec_codec *c, size_t nchunks, size_t slot_bytes, size_t n
 	DeviceGuard g(c->device);
 	if (!g.ok)
 		return fail(GEC_E_DEVICE, "hipSetDevice failed");
-	StagingLease lease0(c), lease1(c);
-	Staging *slot[2] = {&lease0.st, &lease1.st};
-	for (size_t i = 0; i < std::min<size_t>(nchunks, 2); ++i) {
+	StagingLease lease0(c), lease1(c), lease2(c);
+	Staging *slot[kSlots] = {&lease0.st, &lease1.st, &lease2.st};
+	for (size_t i = 0; i < std::min<size_t>(nchunks, kSlots); ++i) {
 		int rc = slot[i]->ensure(slot_bytes, nbad);
 		if (rc)
 			return rc;
 	}
 	int rc = GEC_OK;
-	for (size_t ci = 0; ci <= nchunks && rc == GEC_OK; ++ci) {
-		if (ci < nchunks) {
-			Staging &st = *slot[ci % 2];
-			fill(ci, st);
-			rc = enqueue(ci, st);
+	auto finish = [&](size_t ci) {
+		Staging &st = *slot[ci % kSlots];
+		hipError_t e = hipStreamSynchronize(st.stream);
+		if (e != hipSuccess)
+			rc = fail(GEC_E_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+		else
+			drain(ci, st);
+	};
+	size_t drained = 0;
+	for (size_t ci = 0; ci < nchunks && rc == GEC_OK; ++ci) {
+		if (ci >= kSlots) {  // the slot is still busy with chunk ci - kSlots
+			finish(ci - kSlots);
+			++drained;
+			if (rc != GEC_OK)
+				break;
 		}
-		if (ci >= 1 && rc == GEC_OK) {
-			Staging &st = *slot[(ci - 1) % 2];
-			hipError_t e = hipStreamSynchronize(st.stream);
-			if (e != hipSuccess)
-				rc = fail(GEC_E_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
-			else
-				drain(ci - 1, st);
-		}
+		Staging &st = *slot[ci % kSlots];
+		fill(ci, st);
+		rc = enqueue(ci, st);
 	}
+	for (; drained < nchunks && rc == GEC_OK; ++drained)
+		finish(drained);
 	if (rc != GEC_OK)  // leave no work in flight on pooled buffers
 		for (Staging *st : slot)
 			if (st->stream)
@@ -1412,13 +1498,14 @@ int gec_group_create(const gec_codec *c, int rank, int nranks, const uint8_t id[
 	if (r != ncclSuccess)
 		return fail(GEC_E_DEVICE, std::string("ncclCommInitRank: ") + R.GetErrorString(r));
 	g->all_gather = rccl_all_gather;
+	g->all_to_all = rccl_all_to_all;
 	g->ctx = g.get();
 	*out = g.release();
 	return GEC_OK;
 }
 
-int gec_group_create_with_transport(const gec_codec *c, int rank, int nranks, gec_allgather_fn all_gather, void *ctx,
-				    gec_group **out)
+int gec_group_create_with_transport2(const gec_codec *c, int rank, int nranks, gec_allgather_fn all_gather,
+				     gec_alltoall_fn all_to_all, void *ctx, gec_group **out)
 {
 	std::unique_ptr<gec_group> g;
 	int rc = group_new(c, rank, nranks, out, g);
@@ -1427,9 +1514,16 @@ int gec_group_create_with_transport(const gec_codec *c, int rank, int nranks, ge
 	if (!all_gather)
 		return fail(GEC_E_INVALID_ARG, "NULL all_gather");
 	g->all_gather = all_gather;
+	g->all_to_all = all_to_all;
 	g->ctx = ctx;
 	*out = g.release();
 	return GEC_OK;
+}
+
+int gec_group_create_with_transport(const gec_codec *c, int rank, int nranks, gec_allgather_fn all_gather, void *ctx,
+				    gec_group **out)
+{
+	return gec_group_create_with_transport2(c, rank, nranks, all_gather, nullptr, ctx, out);
 }
 
 void gec_group_destroy(gec_group *g)
@@ -1442,6 +1536,10 @@ void gec_group_destroy(gec_group *g)
 			(void)hipFree(g->d_send);
 		if (g->d_recv)
 			(void)hipFree(g->d_recv);
+		if (g->d_a2a_send)
+			(void)hipFree(g->d_a2a_send);
+		if (g->d_a2a_recv)
+			(void)hipFree(g->d_a2a_recv);
 		if (g->comm)
 			(void)rccl().CommDestroy(g->comm);
 	}
@@ -1480,6 +1578,7 @@ int gec_group_allgather_decode(gec_group *g, size_t nobjects, const void *d_loca
 		return rc;
 	// (1) the exchange step: every rank's slot buffer to everybody
 	const size_t per_rank = nobjects * slots * S;
+	g->bytes_exchanged = per_rank * (N - 1);
 	rc = g->all_gather(g->ctx, d_local_slots, d_gathered, per_rank, hip_stream);
 	if (rc)
 		return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
@@ -1540,6 +1639,7 @@ int gec_group_allgather_decode(gec_group *g, size_t nobjects, const void *d_loca
 		hipLaunchKernelGGL(gec::range_pack, dim3(grid_for(nmiss * nobjects * my_cols)), dim3(256), 0, stream, ra);
 		HIP_TRY(hipGetLastError());
 	}
+	g->bytes_exchanged += send_bytes * (N - 1);
 	rc = g->all_gather(g->ctx, g->d_send, g->d_recv, send_bytes, hip_stream);
 	if (rc)
 		return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
@@ -1597,6 +1697,142 @@ int gec_host_unregister(void *p)
 
 int gec_host_is_pinned(const void *p, size_t bytes) { return pinned().contains(p, bytes) ? 1 : 0; }
 
+uint64_t gec_group_bytes_exchanged(const gec_group *g) { return g ? g->bytes_exchanged : 0; }
+
+int gec_group_alltoall_decode(gec_group *g, size_t nobjects, const void *d_local_slots, size_t S, const uint8_t *present,
+			      int data_only, int complete, void *d_rebuilt, void *hip_stream)
+{
+	if (!g || !present || !d_rebuilt)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (!g->all_to_all)
+		return fail(GEC_E_INVALID_ARG, "this group's transport has no all-to-all");
+	if (nobjects == 0)
+		return GEC_OK;
+	const gec_codec *c = g->c;
+	const size_t k = c->k, N = (size_t)g->nranks, slots = gec_group_slots(g);
+	int rc = check_dev_layout(d_local_slots, slots * S, S, slots * S);
+	if (rc)
+		return rc;
+	if (reinterpret_cast<uintptr_t>(d_rebuilt) % 16)
+		return fail(GEC_E_INVALID_ARG, "d_rebuilt must be 16-byte aligned");
+	if (nobjects > 0xffffffffull || S / 16 > 0xffffffffull)
+		return fail(GEC_E_INVALID_ARG, "batch too large for one call");
+	hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+	DeviceGuard dg(c->device);
+	if (!dg.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	std::shared_ptr<const Plan> plan;  // before the exchange: a bad pattern fails on every rank alike, no rank hangs
+	rc = get_plan(c, present, data_only != 0, plan);
+	if (rc)
+		return rc;
+	g->bytes_exchanged = 0;
+	const size_t nmiss = plan->missing.size();
+	if (nmiss == 0)
+		return GEC_OK;
+	// which of the k shards the decode reads live on which rank: shard v on rank v % N, local slot v / N;
+	// vs index = position among that rank's valid shards
+	std::vector<std::vector<int>> valid_of(N);
+	for (size_t t = 0; t < k; ++t)
+		valid_of[plan->valid[t] % N].push_back(plan->valid[t]);
+	size_t nvs_max = 0;
+	for (auto &v : valid_of)
+		nvs_max = std::max(nvs_max, v.size());
+	const size_t cols = S / 16;
+	auto range_lo = [&](size_t r) { return cols * r / N; };
+	size_t max_cols = 0;
+	for (size_t r = 0; r < N; ++r)
+		max_cols = std::max(max_cols, range_lo(r + 1) - range_lo(r));
+	const size_t my_cols = range_lo(g->rank + 1) - range_lo(g->rank);
+	const size_t per_peer = nvs_max * nobjects * max_cols * 16;
+	const size_t packed_bytes = nmiss * nobjects * max_cols * 16;
+	// scratch: [send N*per_peer][recv N*per_peer]; the rebuilt ranges reuse the group's d_send / d_recv
+	if (N * per_peer > g->a2a_cap || packed_bytes > g->send_cap || packed_bytes * N > g->recv_cap) {
+		HIP_TRY(hipStreamSynchronize(stream));
+		for (uint8_t **p : {&g->d_a2a_send, &g->d_a2a_recv, &g->d_send, &g->d_recv})
+			if (*p) {
+				(void)hipFree(*p);
+				*p = nullptr;
+			}
+		g->a2a_cap = g->send_cap = g->recv_cap = 0;
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_a2a_send), N * per_peer));
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_a2a_recv), N * per_peer));
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_send), packed_bytes));
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_recv), packed_bytes * N));
+		HIP_TRY(hipMemsetAsync(g->d_a2a_send, 0, N * per_peer, stream));  // pad columns / unused vs slots: defined bytes on the wire
+		HIP_TRY(hipMemsetAsync(g->d_send, 0, packed_bytes, stream));
+		g->a2a_cap = N * per_peer;
+		g->send_cap = packed_bytes;
+		g->recv_cap = packed_bytes * N;
+	}
+	auto grid_for = [](size_t items) { return (unsigned)std::max<size_t>(1, std::min<size_t>((items + 255) / 256, 1u << 16)); };
+	// (1) pack: for every peer, that peer's byte range of my valid shards
+	const std::vector<int> &mine = valid_of[g->rank];
+	if (!mine.empty()) {
+		gec::A2aArgs pa;
+		std::memset(&pa, 0, sizeof(pa));
+		pa.local = static_cast<const uint8_t *>(d_local_slots);
+		pa.send = g->d_a2a_send;
+		pa.obj_stride = slots * S;
+		pa.nobj = (uint32_t)nobjects;
+		pa.nvs = (uint32_t)mine.size();
+		pa.nvs_max = (uint32_t)nvs_max;
+		pa.cols = (uint32_t)cols;
+		pa.max_cols = (uint32_t)max_cols;
+		pa.world = (uint32_t)N;
+		for (size_t i = 0; i < mine.size(); ++i)
+			pa.slot_of[i] = (uint32_t)(mine[i] / N);
+		hipLaunchKernelGGL(gec::a2a_pack, dim3(grid_for(N * mine.size() * nobjects * max_cols)), dim3(256), 0, stream, pa);
+		HIP_TRY(hipGetLastError());
+	}
+	// (2) the exchange step: 1/N of the all-gather's bytes
+	g->bytes_exchanged = per_peer * (N - 1);
+	rc = g->all_to_all(g->ctx, g->d_a2a_send, g->d_a2a_recv, per_peer, hip_stream);
+	if (rc)
+		return rc > 0 ? fail(GEC_E_DEVICE, "all_to_all transport failed") : rc;
+	// (3) my byte range of every missing shard, from the received ranges: input shard valid[t] sits at
+	//     recv[(owner*nvs_max + vs)*nobj + obj][max_cols]; output i at d_send[(i*nobj + obj)][max_cols]
+	if (my_cols) {
+		std::vector<size_t> in_off(k), out_off(nmiss);
+		for (size_t t = 0; t < k; ++t) {
+			const int v = plan->valid[t];
+			const size_t owner = v % N;
+			const size_t vs = std::find(valid_of[owner].begin(), valid_of[owner].end(), v) - valid_of[owner].begin();
+			in_off[t] = (owner * nvs_max + vs) * nobjects * max_cols * 16;
+		}
+		for (size_t i = 0; i < nmiss; ++i)
+			out_off[i] = i * nobjects * max_cols * 16;
+		rc = launch_apply(c, g->d_a2a_recv, max_cols * 16, g->d_send, max_cols * 16, nullptr, 0, my_cols * 16, nobjects,
+				  in_off.data(), out_off.data(), (int)nmiss, plan->rows.v.data(), gec::MODE_STORE, stream);
+		if (rc)
+			return rc;
+	}
+	// (4) the rebuilt ranges: mine only, or everybody's after a (small) all-gather
+	gec::RebuiltArgs ua;
+	std::memset(&ua, 0, sizeof(ua));
+	ua.rebuilt = static_cast<uint8_t *>(d_rebuilt);
+	ua.nobj = (uint32_t)nobjects;
+	ua.nmiss = (uint32_t)nmiss;
+	ua.cols = (uint32_t)cols;
+	ua.max_cols = (uint32_t)max_cols;
+	ua.world = (uint32_t)N;
+	if (complete && N > 1) {
+		g->bytes_exchanged += packed_bytes * (N - 1);
+		rc = g->all_gather(g->ctx, g->d_send, g->d_recv, packed_bytes, hip_stream);
+		if (rc)
+			return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+		ua.packed = g->d_recv;
+		ua.first_rank = 0;
+		ua.nranks_in = (uint32_t)N;
+	} else {
+		ua.packed = g->d_send;
+		ua.first_rank = (uint32_t)g->rank;
+		ua.nranks_in = 1;
+	}
+	hipLaunchKernelGGL(gec::rebuilt_unpack, dim3(grid_for((size_t)ua.nranks_in * nmiss * nobjects * max_cols)), dim3(256), 0, stream, ua);
+	HIP_TRY(hipGetLastError());
+	return GEC_OK;
+}
+
 // -------------------------------------------------------- host-pointer API
 static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *const *blocks, const size_t *block_len,
 			     size_t S, uint8_t *const *parity, uint8_t *shard_sums)
@@ -1627,7 +1863,7 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 	for (size_t b = 0; b < nblocks && all_pinned; ++b)
 		all_pinned = aligned16(blocks[b]) && aligned16(parity[b]) && pinned().contains(blocks[b], block_len[b]) &&
 			     pinned().contains(parity[b], m * S);
-	const size_t ch = chunk_blocks(stripe, nblocks, (shard_sums || all_pinned) ? 8 * kChunkBytes : kChunkBytes);
+	const size_t ch = chunk_blocks(stripe, nblocks, shard_sums ? 8 * kChunkBytes : all_pinned ? pinned_chunk_bytes() : kChunkBytes);
 	const size_t sums_off = ch * stripe;  // checksum area behind the stripes of a slot
 	const size_t nchunks = (nblocks + ch - 1) / ch;
 	CopyPool &pool = c->copy_pool();
@@ -1635,6 +1871,7 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 	// Then the DMA engines read / write the caller's memory directly and the staging copy is skipped.
 	std::vector<uint8_t> in_pinned(nchunks, 1), out_pinned(nchunks, 1);
 	std::vector<size_t> min_len(nchunks, k * S);
+	PipeChain chain;
 	for (size_t b = 0; b < nblocks; ++b) {
 		const size_t ci = b / ch;
 		if (in_pinned[ci] && !(aligned16(blocks[b]) && pinned().contains(blocks[b], block_len[b])))
@@ -1670,7 +1907,11 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 				for (size_t i = 0; i < nb; ++i)
 					if (block_len[b0 + i])
 						ents.push_back({pinned().dev(blocks[b0 + i]), st.d_buf + i * stripe, block_len[b0 + i]});
-				int rct = launch_copy_table(st, ents, st.stream);
+				int rct = chain.before(chain.last_in, st.stream);
+				if (!rct)
+					rct = launch_copy_table(st, ents, st.stream);
+				if (!rct)
+					rct = chain.after_in(st);
 				if (rct)
 					return rct;
 			} else {
@@ -1685,7 +1926,11 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 				ents.reserve(nb);
 				for (size_t i = 0; i < nb; ++i)
 					ents.push_back({st.d_buf + i * stripe + k * S, pinned().dev(parity[b0 + i]), m * S});
-				int rct = launch_copy_table(st, ents, st.stream);
+				int rct = chain.before(chain.last_out, st.stream);
+				if (!rct)
+					rct = launch_copy_table(st, ents, st.stream);
+				if (!rct)
+					rct = chain.after_out(st);
 				if (rct)
 					return rct;
 			} else {
@@ -2324,7 +2569,7 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 			for (size_t r = 0; r < nmiss && all_pinned; ++r)
 				all_pinned = aligned16(out[ids[i] * n + plan->missing[r]]) && pinned().contains(out[ids[i] * n + plan->missing[r]], S);
 		}
-		const size_t ch = chunk_blocks(stripe, ids.size(), all_pinned ? 8 * kChunkBytes : kChunkBytes);
+		const size_t ch = chunk_blocks(stripe, ids.size(), all_pinned ? pinned_chunk_bytes() : kChunkBytes);
 		std::vector<size_t> in_off(k), out_off(nmiss);
 		for (size_t t = 0; t < k; ++t)
 			in_off[t] = t * S;
@@ -2335,6 +2580,7 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 		// are merged into one copy
 		const size_t nchunks = (ids.size() + ch - 1) / ch;
 		std::vector<uint8_t> in_pinned(nchunks, 1), out_pinned(nchunks, 1);
+		PipeChain chain;
 		for (size_t i = 0; i < ids.size(); ++i) {
 			const size_t ci = i / ch;
 			for (size_t t = 0; t < k && in_pinned[ci]; ++t)
@@ -2371,7 +2617,11 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 							t += run;
 						}
 					}
-					int rct = launch_copy_table(st, ents, st.stream);
+					int rct = chain.before(chain.last_in, st.stream);
+					if (!rct)
+						rct = launch_copy_table(st, ents, st.stream);
+					if (!rct)
+						rct = chain.after_in(st);
 					if (rct)
 						return rct;
 				} else {
@@ -2389,7 +2639,11 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 						for (size_t r = 0; r < nmiss; ++r)
 							ents.push_back({st.d_buf + i * stripe + (k + r) * S, pinned().dev(o[plan->missing[r]]), S});
 					}
-					int rct = launch_copy_table(st, ents, st.stream);
+					int rct = chain.before(chain.last_out, st.stream);
+					if (!rct)
+						rct = launch_copy_table(st, ents, st.stream);
+					if (!rct)
+						rct = chain.after_out(st);
 					if (rct)
 						return rct;
 				} else {

@@ -471,6 +471,64 @@ __global__ __launch_bounds__(256) void range_unpack(const RangeArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Striped decode, all-to-all exchange (gec_group_alltoall_decode): rank r only needs ITS byte range of the k
+// shards the decode reads, so instead of gathering every survivor slot everywhere each rank packs, for every
+// peer, that peer's range of its own valid shards -- 1/N of the all-gather's traffic per link.
+//   a2a_pack:   send[peer][vs][obj][max_cols]  <-  local[obj][slot(vs)][range of peer]      (vs = index in `slots_used`)
+//   rebuilt_unpack: d_rebuilt[i][obj][S]       <-  recv[rank][i][obj][max_cols]              (i = missing shard)
+// Pure 16-byte copies.
+// ---------------------------------------------------------------------------
+struct A2aArgs {
+	const uint8_t *local;  // [obj][slots][S]
+	uint8_t *send;         // [peer][nvs_max][obj][max_cols]
+	uint64_t obj_stride;   // slots*S
+	uint32_t nobj, nvs, nvs_max;
+	uint32_t cols, max_cols, world;
+	uint32_t slot_of[KMAX];  // local slot of valid shard vs
+};
+
+__global__ __launch_bounds__(256) void a2a_pack(const A2aArgs a)
+{
+	const uint64_t per_peer = (uint64_t)a.nvs * a.nobj * a.max_cols;
+	const uint64_t total = per_peer * a.world;
+	for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t peer = (uint32_t)(q / per_peer);
+		const uint64_t w = q % per_peer;
+		const uint32_t c = (uint32_t)(w % a.max_cols);
+		const uint32_t lo = range_lo(a.cols, peer, a.world), n = range_lo(a.cols, peer + 1, a.world) - lo;
+		if (c >= n)
+			continue;
+		const uint64_t vo = w / a.max_cols;  // vs*nobj + obj
+		const uint32_t obj = (uint32_t)(vo % a.nobj), vs = (uint32_t)(vo / a.nobj);
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(a.local + obj * a.obj_stride) + (uint64_t)a.slot_of[vs] * a.cols + lo + c;
+		reinterpret_cast<u32x4 *>(a.send)[((uint64_t)peer * a.nvs_max * a.nobj + vo) * a.max_cols + c] = *src;
+	}
+}
+
+struct RebuiltArgs {
+	const uint8_t *packed;  // [rank][nmiss][obj][max_cols] (or just this rank's [nmiss][obj][max_cols] with world_in == 1)
+	uint8_t *rebuilt;       // [nmiss][obj][S]
+	uint32_t nobj, nmiss, cols, max_cols, world;
+	uint32_t first_rank, nranks_in;  // ranks whose ranges `packed` holds: first_rank .. first_rank + nranks_in - 1
+};
+
+__global__ __launch_bounds__(256) void rebuilt_unpack(const RebuiltArgs a)
+{
+	const uint64_t per_rank = (uint64_t)a.nmiss * a.nobj * a.max_cols;
+	const uint64_t total = per_rank * a.nranks_in;
+	for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t r = a.first_rank + (uint32_t)(q / per_rank);
+		const uint64_t w = q % per_rank;
+		const uint32_t c = (uint32_t)(w % a.max_cols);
+		const uint32_t lo = range_lo(a.cols, r, a.world), n = range_lo(a.cols, r + 1, a.world) - lo;
+		if (c >= n)
+			continue;
+		const uint64_t io = w / a.max_cols;  // i*nobj + obj
+		reinterpret_cast<u32x4 *>(a.rebuilt)[io * a.cols + lo + c] = reinterpret_cast<const u32x4 *>(a.packed)[q];
+	}
+}
+
+// ---------------------------------------------------------------------------
 // Baseline kernel (variant 1): the literal north_star formulation -- per-byte
 // log/antilog lookups in LDS, one GF multiply per (byte, row).  Kept only as the
 // measured "before" of DESIGN.md; same results, ~an order of magnitude more LDS

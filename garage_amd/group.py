@@ -28,9 +28,15 @@ class Group:
         self.rank, self.nranks = rank, nranks
         h = ctypes.c_void_p()
         if transport is not None:
-            fn, ctx = transport
-            check(lib.gec_group_create_with_transport(codec._h, rank, nranks, fn, ctx, ctypes.byref(h)),
-                  "gec_group_create_with_transport")
+            # (all_gather_fn, ctx) or (all_gather_fn, all_to_all_fn, ctx)
+            if len(transport) == 3:
+                fn, a2a, ctx = transport
+                check(lib.gec_group_create_with_transport2(codec._h, rank, nranks, fn, a2a, ctx, ctypes.byref(h)),
+                      "gec_group_create_with_transport2")
+            else:
+                fn, ctx = transport
+                check(lib.gec_group_create_with_transport(codec._h, rank, nranks, fn, ctx, ctypes.byref(h)),
+                      "gec_group_create_with_transport")
         else:
             if unique_id is None or len(unique_id) != _lib.GEC_GROUP_ID_BYTES:
                 raise GecError(_lib.GEC_E_INVALID_ARG, "unique_id", f"must be {_lib.GEC_GROUP_ID_BYTES} bytes")
@@ -85,6 +91,32 @@ class Group:
                                              int(bool(complete)), out.data_ptr(), _stream_handle(self.codec.device)),
               "gec_group_allgather_decode")
         return out
+
+    def alltoall_decode(self, local_slots, present: Sequence[int], data_only: bool = False, complete: bool = True, out=None):
+        """All-to-all exchange (gec_group_alltoall_decode): every rank receives only its byte range of the k shards
+        the decode reads.  Returns the rebuilt shards (nmiss, nobjects, S), nmiss = missing (data_only: missing data)
+        shards in ascending index order; with complete=False only this rank's byte range of them is valid."""
+        import torch
+
+        if not (isinstance(local_slots, torch.Tensor) and local_slots.is_cuda and local_slots.dtype == torch.uint8
+                and local_slots.dim() == 3 and local_slots.shape[1] == self.slots):
+            raise TypeError(f"local_slots must be a uint8 CUDA tensor (nobjects, {self.slots}, S)")
+        local_slots = local_slots.contiguous()
+        nobj, slots, S = local_slots.shape
+        pres = np.ascontiguousarray(np.asarray(present, dtype=np.uint8))
+        if pres.size != self.codec.n:
+            raise GecError(_lib.GEC_E_INVALID_INDEX, "present", "must have k+m entries")
+        nmiss = sum(1 for j in range(self.codec.n) if not pres[j] and not (data_only and j >= self.codec.k))
+        if out is None:
+            out = torch.zeros((nmiss, nobj, S), dtype=torch.uint8, device=local_slots.device)
+        check(lib.gec_group_alltoall_decode(self._h, nobj, local_slots.data_ptr(), S, _u8p(pres), int(bool(data_only)),
+                                            int(bool(complete)), out.data_ptr(), _stream_handle(self.codec.device)),
+              "gec_group_alltoall_decode")
+        return out
+
+    def bytes_exchanged(self) -> int:
+        """bytes this rank received from other ranks in the last decode call"""
+        return int(lib.gec_group_bytes_exchanged(self._h))
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -121,6 +121,64 @@ def striped_reconstruct(codec, local_slots: torch.Tensor, present: Sequence[int]
     return gathered
 
 
+def striped_reconstruct_alltoall(codec, local_slots: torch.Tensor, present: Sequence[int], layout: StripeLayout,
+                                 group: Optional[dist.ProcessGroup] = None, data_only: bool = False,
+                                 complete: bool = True) -> torch.Tensor:
+    """The all-to-all form of the exchange (gec_group_alltoall_decode in the C ABI): every rank receives only ITS
+    byte range of the k shards the decode reads -- (world-1)/world^2 of k*S per object instead of the whole
+    survivor set -- rebuilds its range of the missing shards, and (``complete``) the rebuilt ranges are
+    all-gathered.  Returns the rebuilt shards only, shape (nmiss, nobjects, S), in ascending index order of the
+    missing (``data_only``: missing data) shards; survivors stay where they are."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world != layout.world:
+        raise ValueError(f"layout is for {layout.world} ranks, group has {world}")
+    nobj, slots, S = local_slots.shape
+    if slots != layout.slots or S % 64 or len(present) != layout.n:
+        raise ValueError("bad local_slots / present")
+    n, k = layout.n, layout.k
+    valid = [j for j in range(n) if present[j]][:k]
+    if len(valid) < k:
+        raise ValueError("fewer than k shards present")
+    wanted = [j for j in range(n) if not present[j] and not (data_only and j >= k)]
+    dev = local_slots.device
+    if not wanted:
+        return torch.zeros((0, nobj, S), dtype=torch.uint8, device=dev)
+    valid_of = [[v for v in valid if layout.owner(v) == r] for r in range(world)]
+    nvs_max = max(len(v) for v in valid_of)
+    ranges = [layout.byte_range(r, S) for r in range(world)]
+    pitch = -(-max(ln for _, ln in ranges) // 64) * 64          # column pitch of the exchanged ranges
+    send = torch.zeros((world, nvs_max, nobj, pitch), dtype=torch.uint8, device=dev)
+    for peer, (off, ln) in enumerate(ranges):
+        for vs, v in enumerate(valid_of[rank]):
+            send[peer, vs, :, :ln] = local_slots[:, layout.slot(v), off:off + ln]
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)   # (1) the exchange step
+    # (2) my byte range of every shard the decode can produce, into an area behind the received ranges
+    others = [j for j in range(n) if j not in valid]
+    buf = torch.cat([recv.view(-1), torch.zeros(len(others) * nobj * pitch, dtype=torch.uint8, device=dev)])
+    shard_off = [0] * n
+    for r in range(world):
+        for vs, v in enumerate(valid_of[r]):
+            shard_off[v] = (r * nvs_max + vs) * nobj * pitch
+    for i, j in enumerate(others):
+        shard_off[j] = recv.numel() + i * nobj * pitch
+    off, ln = ranges[rank]
+    if ln:
+        codec.reconstruct_scattered_dev(buf, nobj, pitch, shard_off, pitch, [j in valid for j in range(n)],
+                                        data_only=False, byte_range=(0, ln))
+    mine = torch.stack([buf[shard_off[j]: shard_off[j] + nobj * pitch].view(nobj, pitch) for j in wanted])
+    rebuilt = torch.zeros((len(wanted), nobj, S), dtype=torch.uint8, device=dev)
+    if complete and world > 1:                                  # (3) exchange the rebuilt ranges
+        parts = torch.empty((world,) + tuple(mine.shape), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(parts.view(-1), mine.contiguous().view(-1), group=group)
+        for r, (roff, rln) in enumerate(ranges):
+            rebuilt[:, :, roff:roff + rln] = parts[r][:, :, :rln]
+    else:
+        rebuilt[:, :, off:off + ln] = mine[:, :, :ln]
+    return rebuilt
+
+
 def scatter_stripes(stripes: torch.Tensor, layout: StripeLayout, rank: int) -> torch.Tensor:
     """Test/bench helper: the slot buffer rank `rank` would hold for full stripes
     (nobjects, n, S)."""

@@ -275,6 +275,30 @@ int gec_group_allgather_decode(gec_group *g, size_t nobjects,
 			       const uint8_t *present, int data_only, int complete,
 			       void *d_gathered, void *hip_stream);
 
+/* All-to-all variant of the exchange.  After the all-gather every rank holds EVERY survivor slot (7/8 of them
+ * arrive over xGMI), although it only reads its own 1/N byte range of the k shards the decode uses.  Here each
+ * rank sends every peer just that peer's range of its own valid shards (grouped ncclSend/ncclRecv over the xGMI
+ * full mesh, or the caller's gec_alltoall_fn), rebuilds its range of the missing shards, and -- with
+ * complete != 0 -- the rebuilt ranges are all-gathered as before.  Bytes received per rank:
+ * k*S*nobjects*(N-1)/N^2 instead of slots*S*nobjects*(N-1): 11x less at BASELINE config 5 (N = 8, RS(20,8)).
+ * The result is NOT the gathered stripe buffer (survivors stay where they are): d_rebuilt receives the missing
+ * shards only, [nmiss][nobjects][S] in ascending shard-index order of the missing (data_only: missing data) shards,
+ * complete on every rank (complete != 0) or valid in this rank's byte range only.
+ * all-gather stays the default exchange of the project brief (gec_group_allgather_decode). */
+typedef int (*gec_alltoall_fn)(void *ctx, const void *d_send, void *d_recv,
+			       size_t bytes_per_peer, void *hip_stream);
+/* like gec_group_create_with_transport, with an all-to-all as well: rank r's `bytes_per_peer` at
+ * d_send + q*bytes_per_peer must arrive at rank q's d_recv + r*bytes_per_peer (all_to_all may be NULL). */
+int gec_group_create_with_transport2(const gec_codec *c, int rank, int nranks,
+				     gec_allgather_fn all_gather, gec_alltoall_fn all_to_all,
+				     void *ctx, gec_group **out);
+int gec_group_alltoall_decode(gec_group *g, size_t nobjects,
+			      const void *d_local_slots, size_t S,
+			      const uint8_t *present, int data_only, int complete,
+			      void *d_rebuilt, void *hip_stream);
+/* bytes this rank received from other ranks during the last *_decode call on the group (both exchanges) */
+uint64_t gec_group_bytes_exchanged(const gec_group *g);
+
 /* ------------------------------------------------------- blake2sum on the GPU
  * SURVEY.md section 8 row f4.  Garage's content hash `blake2sum` = blake2b-512
  * truncated to 32 bytes (src/util/data.rs:130-138); today it is a CPU pass in

@@ -83,4 +83,28 @@ int lb_all_gather(void *ctx, const void *d_send, void *d_recv, size_t bytes, voi
 
 void *lb_all_gather_ptr(void) { return reinterpret_cast<void *>(&lb_all_gather); }
 
+// matches gec_alltoall_fn: rank r's piece q goes to rank q's slot r
+int lb_all_to_all(void *ctx, const void *d_send, void *d_recv, size_t bytes, void *hip_stream)
+{
+	Loopback::RankCtx *rc = static_cast<Loopback::RankCtx *>(ctx);
+	Loopback *lb = rc->lb;
+	hipStream_t s = static_cast<hipStream_t>(hip_stream);
+	if (hipStreamSynchronize(s) != hipSuccess)
+		return 1;
+	lb->send[rc->rank] = d_send;
+	lb->barrier();
+	int err = 0;
+	for (int q = 0; q < lb->n; ++q)
+		if (hipMemcpyAsync(static_cast<char *>(d_recv) + (size_t)q * bytes,
+				   static_cast<const char *>(lb->send[q]) + (size_t)rc->rank * bytes, bytes,
+				   hipMemcpyDeviceToDevice, s) != hipSuccess)
+			err = 1;
+	if (hipStreamSynchronize(s) != hipSuccess)
+		err = 1;
+	lb->barrier();
+	return err;
+}
+
+void *lb_all_to_all_ptr(void) { return reinterpret_cast<void *>(&lb_all_to_all); }
+
 }  // extern "C"

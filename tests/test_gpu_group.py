@@ -196,3 +196,119 @@ def test_group_argument_errors(loopback):
         grp.allgather_decode(local[:, :13], [1] * 14)                           # wrong slot count
     grp.close()
     loopback.lb_destroy(handle)
+
+
+# ------------------------------------------------------------- all-to-all exchange (gec_group_alltoall_decode)
+def _run_logical_ranks_a2a(lb, rs, world, broken, present, data_only, complete):
+    """-> per-rank (rebuilt (nmiss, nobj, S) numpy array, bytes received)"""
+    layout = StripeLayout(rs.k, rs.m, world)
+    handle = lb.lb_create(world)
+    lb.lb_all_to_all_ptr.restype = ctypes.c_void_p
+    outs, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(DEV)):
+                grp = g.Group(rs, r, world, transport=(lb.lb_all_gather_ptr(), lb.lb_all_to_all_ptr(), lb.lb_rank_ctx(handle, r)))
+                local = scatter_stripes(broken, layout, r)
+                local[:, [layout.slot(j) for j in layout.shards_of(r) if not present[j]]] = 0xB0 + r
+                out = grp.alltoall_decode(local, present, data_only=data_only, complete=complete)
+                torch.cuda.current_stream().synchronize()
+                outs[r] = (out.cpu().numpy(), grp.bytes_exchanged())
+                grp.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, e))
+
+    ts = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ts), "a logical rank hung"
+    lb.lb_destroy(handle)
+    assert not errs, errs
+    return outs, layout
+
+
+@pytest.mark.parametrize("k,m,world,S,lost", [
+    (10, 4, 2, 4160, (0, 3, 7, 9)),
+    (10, 4, 3, 1984, (4, 12)),                              # world divides neither k+m nor the columns
+    (20, 8, 8, 4096 + 64, (0, 1, 5, 9, 13, 19, 21, 27)),   # config 5's shape, short shards
+    (3, 1, 8, 64, (2,)),                                    # most ranks own an EMPTY byte range
+    (10, 4, 1, 640, (1, 13)),
+])
+@pytest.mark.parametrize("data_only", [False, True])
+def test_group_alltoall_decode_logical_ranks(coracle, loopback, k, m, world, S, lost, data_only):
+    """The all-to-all exchange gives every rank the same rebuilt shards as the all-gather path (= the oracle's
+    stripes), while receiving 1/N-th of the survivor bytes."""
+    nobj = 5
+    full = _stripes(coracle, k, m, S, nobj, 1900 + world)
+    present = [j not in lost for j in range(k + m)]
+    broken = torch.from_numpy(full).to(DEV)
+    rs = g.ReedSolomon(k, m)
+    want = [j for j in lost if not (data_only and j >= k)]
+    outs, layout = _run_logical_ranks_a2a(loopback, rs, world, broken, present, data_only, True)
+    for r in range(world):
+        reb, nbytes = outs[r]
+        assert reb.shape == (len(want), nobj, S)
+        for i, j in enumerate(want):
+            assert np.array_equal(reb[i], full[:, j]), f"rank {r} shard {j}"
+    if world > 1 and want:
+        ag, _ = _run_logical_ranks(loopback, rs, world, broken, present, data_only=data_only, complete=True)
+        # bytes over the wire: all-to-all receives ~1/world of what the all-gather moves for the survivors
+        slots = layout.slots
+        assert outs[0][1] < nobj * slots * S * (world - 1)
+    # complete=0: only the rank's own byte range of every wanted shard
+    outs, layout = _run_logical_ranks_a2a(loopback, rs, world, broken, present, data_only, False)
+    for r in range(world):
+        off, ln = layout.byte_range(r, S)
+        for i, j in enumerate(want):
+            assert np.array_equal(outs[r][0][i][:, off:off + ln], full[:, j, off:off + ln]), f"rank {r} shard {j}"
+
+
+def test_group_alltoall_full_size_config5_and_traffic(loopback):
+    """BASELINE config 5 geometry at full shard size: same rebuilt shards as the encode produced, and the
+    traffic claim of the header: 11x fewer bytes received per rank than the all-gather."""
+    k, m, world, nobj = 20, 8, 8, 4
+    S = g.shard_len(k, 4 << 20)
+    rs = g.ReedSolomon(k, m)
+    st = torch.randint(0, 256, (nobj, k + m, S), dtype=torch.uint8, device=DEV)
+    rs.encode_dev(st)
+    lost = (0, 1, 5, 9, 13, 19, 21, 27)
+    present = [j not in lost for j in range(k + m)]
+    outs, layout = _run_logical_ranks_a2a(loopback, rs, world, st, present, False, True)
+    full = st.cpu().numpy()
+    for r in (0, 3, 7):
+        for i, j in enumerate(lost):
+            assert np.array_equal(outs[r][0][i], full[:, j])
+    ag, _ = _run_logical_ranks(loopback, rs, world, st, present, data_only=False, complete=True)
+    a2a_bytes = outs[0][1]
+    ag_bytes = nobj * layout.slots * S * (world - 1) + len(lost) * nobj * (S // 8) * (world - 1)
+    assert a2a_bytes * 3 < ag_bytes, (a2a_bytes, ag_bytes)
+
+
+def test_group_without_alltoall_transport_is_refused(loopback):
+    rs = g.ReedSolomon(10, 4)
+    handle = loopback.lb_create(1)
+    grp = g.Group(rs, 0, 1, transport=(loopback.lb_all_gather_ptr(), loopback.lb_rank_ctx(handle, 0)))
+    with pytest.raises(g.GecError):
+        grp.alltoall_decode(torch.zeros((1, 14, 64), dtype=torch.uint8, device=DEV), [0] + [1] * 13)
+    grp.close()
+    loopback.lb_destroy(handle)
+
+
+def test_group_rccl_world1_alltoall(coracle):
+    """The library's own RCCL all-to-all (grouped ncclSend / ncclRecv) at world size 1."""
+    k, m, S, nobj = 10, 4, 4160, 3
+    full = _stripes(coracle, k, m, S, nobj, 59)
+    lost = (0, 3, 7, 9)
+    present = [j not in lost for j in range(k + m)]
+    broken = torch.from_numpy(full).to(DEV)
+    broken[:, list(lost)] = 0
+    rs = g.ReedSolomon(k, m)
+    grp = g.Group(rs, 0, 1, g.Group.unique_id())
+    out = grp.alltoall_decode(scatter_stripes(broken, StripeLayout(k, m, 1), 0), present)
+    torch.cuda.synchronize()
+    for i, j in enumerate(lost):
+        assert np.array_equal(out[i].cpu().numpy(), full[:, j])
+    grp.close()

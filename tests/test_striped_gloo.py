@@ -12,7 +12,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from garage_amd.partition import block_hash, gpu_of_hash, partition
-from garage_amd.striped import StripeLayout, gather_stripes, scatter_stripes, striped_reconstruct
+from garage_amd.striped import (StripeLayout, gather_stripes, scatter_stripes, striped_reconstruct,
+                                striped_reconstruct_alltoall)
 from oracle import rs_oracle as O
 
 
@@ -55,6 +56,61 @@ def _worker(rank, world, port, k, m, S, nobj, lost, data_only, complete, q):
         import traceback
 
         q.put((rank, False, traceback.format_exc()))
+
+
+def _worker_a2a(rank, world, port, k, m, S, nobj, lost, data_only, complete, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tests.oracle_codec import OracleCodec
+
+        layout = StripeLayout(k, m, world)
+        data = O.splitmix64_bytes(78, nobj * k * S).reshape(nobj, k, S)
+        full = np.concatenate([data, np.stack([O.encode(k, m, d) for d in data])], axis=1)
+        present = [j not in lost for j in range(k + m)]
+        broken = full.copy()
+        broken[:, list(lost)] = 0xEE
+        mine = scatter_stripes(torch.from_numpy(broken), layout, rank)
+        reb = striped_reconstruct_alltoall(OracleCodec(k, m), mine, present, layout, data_only=data_only, complete=complete).numpy()
+        wanted = [j for j in lost if not (data_only and j >= k)]
+        ok = reb.shape == (len(wanted), nobj, S)
+        off, ln = layout.byte_range(rank, S)
+        for i, j in enumerate(wanted):
+            if complete:
+                ok = ok and np.array_equal(reb[i], full[:, j])
+            else:
+                ok = ok and np.array_equal(reb[i][:, off:off + ln], full[:, j, off:off + ln])
+        q.put((rank, bool(ok), ""))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, False, traceback.format_exc()))
+
+
+def _run_a2a(world, **kw):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_a2a, args=(r, world, port, kw["k"], kw["m"], kw["S"], kw["nobj"], kw["lost"],
+                                                   kw.get("data_only", False), kw.get("complete", True), q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    for rank, ok, err in res:
+        assert ok, f"rank {rank} failed: {err}"
+
+
+@pytest.mark.timeout(180)
+def test_striped_alltoall_world2_and_world3():
+    """The all-to-all exchange (each rank receives only its byte range of the k valid shards) over gloo."""
+    _run_a2a(2, k=20, m=8, S=1088, nobj=3, lost=(0, 1, 5, 9, 13, 19, 21, 27))
+    _run_a2a(3, k=10, m=4, S=832, nobj=2, lost=(1, 4, 13))             # ragged ranges, padded slots, surplus survivors
+    _run_a2a(2, k=10, m=4, S=192, nobj=2, lost=(0, 3, 7, 11), complete=False)
+    _run_a2a(2, k=10, m=4, S=192, nobj=2, lost=(2, 12), data_only=True)
 
 
 def _run(world, **kw):

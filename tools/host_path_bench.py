@@ -87,9 +87,9 @@ def pcie_inclusive_rates(nb: int = 512, reps: int = 5) -> dict:
     return out
 
 
-def block_manager_rates(nb: int = 512, threads: int = 16) -> dict:
+def block_manager_rates(nb: int = 512, threads: int = 48) -> dict:
     """libgarage_block (C++ BlockManager mirror) on 16 in-memory nodes: coalesced put, get, get with
-    4 nodes down (every block needs a decode), and concurrent single-block puts through the batcher."""
+    4 nodes down (every block needs a decode), and concurrent single-block puts through the batcher (48 callers = 16 PutObject requests x PUT_BLOCKS_MAX_PARALLEL = 3, src/api/s3/put.rs:42)."""
     import garage_amd as g
     from garage_amd import block_native as bn
 
