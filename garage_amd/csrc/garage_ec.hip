@@ -752,8 +752,11 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 		const int cr = mw == 4 ? gec::RMAX16 : gec::RMAX;  // coefficient bytes per input shard
 		uint8_t *flat = &a.coef[0][0];
 		for (int r = 0; r < cr; ++r) {
-			if (r < rows)
+			if (r < rows) {
+				if (out_base_off[r0 + r] / 16 > 0xffffffffull)  // same limit as the input offsets: 64 GiB per stripe
+					return fail(GEC_E_INVALID_ARG, "stripe too large");
 				a.out_off[r] = (uint32_t)(out_base_off[r0 + r] / 16);
+			}
 			for (int t = 0; t < k; ++t)
 				flat[(size_t)t * cr + r] = r < rows ? coef[(size_t)(r0 + r) * k + t] : 0;
 		}

@@ -815,3 +815,21 @@ def test_decode_verify_batch_one_trip(coracle, rs104, pin):
     if pin:
         for a in bufs + list(fresh.values()):
             host_free(a)
+
+
+def test_scattered_offsets_beyond_64gib_are_refused(rs104):
+    """shard offsets are carried as 32-bit counts of 16-byte units; an offset of 64 GiB or more --
+    input OR output side -- must be refused, not silently truncated (no memory is touched: the check precedes
+    the launch)."""
+    import ctypes
+
+    lib = _lib.lib
+    buf = torch.zeros(14 * 64, dtype=torch.uint8, device=DEV)
+    present = np.array([0] + [1] * 13, dtype=np.uint8)
+    for bad_idx in (0, 5):                       # 0 = the missing shard (an OUTPUT offset), 5 = an input
+        offs = [j * 64 for j in range(14)]
+        offs[bad_idx] = 1 << 36
+        coffs = (ctypes.c_size_t * 14)(*offs)
+        rc = lib.gec_reconstruct_scattered_dev(rs104._h, 1, buf.data_ptr(), 14 * 64, coffs, 64,
+                                               present.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), 0, 0, 64, None)
+        assert rc == _lib.GEC_E_INVALID_ARG, (bad_idx, rc)

@@ -32,10 +32,13 @@ rows = list(csv.DictReader(open(os.path.join(G, "prof_final", "d_kernel_stats.cs
 tr = list(csv.DictReader(open(os.path.join(G, "prof_final", "d_kernel_trace.csv"))))
 ds = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
             for r in tr if "gf_apply_nibble<1, 0" in r["Kernel_Name"])
-enc = [x for _, x in ds[100:1100]]
+# the 1000 timed launches are the last 1000 encode launches before the verify (MODE_COMPARE) launch that follows the timed region
+vstart = min(int(r["Start_Timestamp"]) for r in tr if "gf_apply_nibble<1, 2" in r["Kernel_Name"])
+before = [x for st_, x in ds if st_ < vstart]
+enc = before[-1000:]
 with open(os.path.join(P, f"{tag}_bench_default_kernel_stats.txt"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py     (defaults: --steps 1000 --warmup 100)\n")
-    f.write(f"# {tag} FINAL kernel (flattened, XCD-aware tiles, bitop3 XOR), MI355X.  gf_apply_nibble<1,0,10,1,true,256> = 100 warm-up + 1000 timed encode + 501 reconstruct launches\n")
+    f.write(f"# {tag} FINAL kernel (flattened, XCD-aware tiles, bitop3 XOR), MI355X.  gf_apply_nibble<1,0,10,1,true,256> = cold burst + pre-conditioning + 100 warm-up + 1000 timed encode + 501 reconstruct launches\n")
     f.write(f"# bench.py printed in this profiled run: value {d['value']} GiB/s, ms_per_step {d['ms_per_step']}, roofline.kernel_ms {d['roofline']['kernel_ms']} (HIP events over the 1000 timed steps), frac {d['roofline']['frac']}\n")
     f.write(f"# rocprofv3, the 1000 timed encode launches alone: avg {sum(enc)/len(enc)/1e3:.1f} us, min {min(enc)/1e3:.1f}, max {max(enc)/1e3:.1f}  -> agrees with kernel_ms\n")
     f.write(f"# un-profiled run right after, same box: value {d2['value']} GiB/s, frac {d2['roofline']['frac']}, decode {d2['decode']['value']} GiB/s, cpu_baseline {d2['cpu_baseline']['value']} GiB/s on {d2['cpu_baseline']['cores']} threads\n")
@@ -52,9 +55,37 @@ write = per_dispatch(os.path.join(G, "prof_final_write", "w_counter_collection.c
 vfetch = per_dispatch(os.path.join(G, "prof_final_fetch", "f_counter_collection.csv"), "gf_apply_nibble<1, 2, 10", "FETCH_SIZE")
 rd, wr = 2 * fetch * 1024, write * 1024
 algo = 1503789056
-json.dump({"_comment": "HBM bytes per launch from rocprofv3 PMC passes (profiles/%s_pmc_hbm_traffic.txt): 2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes, per the gfx950 correction in MI355X_MICROARCH.md. bench.py reports this as roofline.traffic for the matching workload." % tag,
-           "rs10_4_encode_1MiB_x1024": {"traffic_bytes": int(round(rd + wr)), "algorithmic_bytes": algo, "round": int(tag[1:])}},
-          open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+sqp0 = os.path.join(G, "prof_final_sq", "sq_counter_collection.csv")
+sec = None
+if os.path.exists(sqp0):
+    # the kernel's secondary bounds next to the HBM one (hard part 1), per launch:
+    lds0 = per_dispatch(sqp0, K, "SQ_LDS_IDX_ACTIVE")          # LDS-array cycles, summed over the 256 CUs
+    conf0 = per_dispatch(sqp0, K, "SQ_LDS_BANK_CONFLICT")
+    valu0 = per_dispatch(sqp0, K, "SQ_ACTIVE_INST_VALU")       # quad-cycles, summed over all waves
+    wave0 = per_dispatch(sqp0, K, "SQ_WAVE_CYCLES")
+    wait0 = per_dispatch(sqp0, K, "SQ_WAIT_ANY")
+    try:
+        gui = per_dispatch(sqp0, K, "GRBM_GUI_ACTIVE")         # shader-clock cycles the dispatch kept the GPU busy
+    except ZeroDivisionError:
+        gui = 0.0
+    sec = {
+        "_comment": "per launch of gf_apply_nibble<1,0,10,1,true,256> on config 2, rocprofv3 SQ pass of round %s (profiles/%s_pmc_sq.txt); "
+                    "cycles = GRBM_GUI_ACTIVE (shader clocks the dispatch was resident)" % (tag[1:], tag),
+        "gpu_cycles": round(gui),
+        "lds_array_cycles_per_cu": round(lds0 / 256),
+        "lds_busy_frac": round(lds0 / 256 / gui, 3) if gui else None,
+        "lds_bank_conflict_frac": round(conf0 / lds0, 4),
+        "valu_issue_cycles_per_simd": round(valu0 * 4 / 1024),
+        "valu_busy_frac": round(valu0 * 4 / 1024 / gui, 3) if gui else None,
+        "waves_parked_on_waitcnt_frac": round(wait0 / wave0, 3),
+        "statement": "HBM is the binding resource: the LDS array and the VALUs are busy for the stated fraction of the launch's cycles",
+    }
+rec = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (profiles/%s_pmc_hbm_traffic.txt): 2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes, per the gfx950 correction in MI355X_MICROARCH.md. bench.py reports this as roofline.traffic (a STATIC figure, labelled so) for the matching workload." % tag,
+       "rs10_4_encode_1MiB_x1024": {"traffic_bytes": int(round(rd + wr)), "algorithmic_bytes": algo, "round": int(tag[1:]),
+                                     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round %s, profiles/%s_pmc_hbm_traffic.txt" % (tag[1:], tag)}}
+if sec:
+    rec["rs10_4_secondary_bounds"] = sec
+json.dump(rec, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 summ = lambda *dirs: subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), *dirs], capture_output=True, text=True).stdout
 with open(os.path.join(P, f"{tag}_pmc_hbm_traffic.txt"), "w") as f:
     f.write(f"# rocprofv3 --pmc <counter> --kernel-trace --output-format csv, one counter group per pass ({tag} FINAL kernel, MI355X)\n")
