@@ -65,7 +65,7 @@ if os.path.exists(sqp0):
     wave0 = per_dispatch(sqp0, K, "SQ_WAVE_CYCLES")
     wait0 = per_dispatch(sqp0, K, "SQ_WAIT_ANY")
     try:
-        gui = per_dispatch(sqp0, K, "GRBM_GUI_ACTIVE")         # shader-clock cycles the dispatch kept the GPU busy
+        gui = per_dispatch(sqp0, K, "GRBM_GUI_ACTIVE") / 8     # shader-clock cycles of the dispatch (the counter has one instance per XCD)
     except ZeroDivisionError:
         gui = 0.0
     sec = {
@@ -78,7 +78,7 @@ if os.path.exists(sqp0):
         "valu_issue_cycles_per_simd": round(valu0 * 4 / 1024),
         "valu_busy_frac": round(valu0 * 4 / 1024 / gui, 3) if gui else None,
         "waves_parked_on_waitcnt_frac": round(wait0 / wave0, 3),
-        "statement": "HBM is the binding resource: the LDS array and the VALUs are busy for the stated fraction of the launch's cycles",
+        "statement": "HBM is the binding resource; next would be VALU issue (busy this fraction of the launch's cycles on every SIMD), then the LDS array",
     }
 rec = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (profiles/%s_pmc_hbm_traffic.txt): 2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes, per the gfx950 correction in MI355X_MICROARCH.md. bench.py reports this as roofline.traffic (a STATIC figure, labelled so) for the matching workload." % tag,
        "rs10_4_encode_1MiB_x1024": {"traffic_bytes": int(round(rd + wr)), "algorithmic_bytes": algo, "round": int(tag[1:]),
