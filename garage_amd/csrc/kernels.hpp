@@ -179,6 +179,14 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 	// single dynamic LDS object (no static __shared__ in front of it, so the base
 	// stays 16-byte aligned): [tables k*TBL][exp 512][log 256][coef k*CR]
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+#ifndef GEC_NO_SETPRIO
+	// When the shard-checksum kernels run beside this one (gec_encode_hash_batch_dev forks the data shards'
+	// checksums onto a second stream) they are pure VALU work with many waves per SIMD: at equal priority this
+	// kernel's few VALU bursts queue behind them and its HBM streams stall (0.25 ms alone -> 0.92 ms beside the
+	// hash, profiles/r02_shardsum_kernel_stats.txt).  Raised priority lets the HBM-bound kernel through; alone
+	// on the chip it changes nothing.
+	__builtin_amdgcn_s_setprio(3);
+#endif
 	const uint32_t tid = threadIdx.x;
 	const uint32_t k = a.k;
 	const uint32_t rows = a.rows;
