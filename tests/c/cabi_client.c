@@ -83,6 +83,65 @@ static void *worker(void *arg)
 				return NULL;
 		free(tmp);
 	}
+	/* round-2 entry points from the same threads: pinned buffers (copy kernels instead of staging), encode +
+	 * shard checksums, the read path in one trip (checksums of the shards read, rebuilt data shards, the block's
+	 * own blake2sum) -- every result cross-checked against the other entry points */
+	{
+		uint8_t *pblk[NB], *ppar[NB], sums[NB * 64 * 32], sums2[NB * 64 * 32], bsum[NB * 32], bsum2[NB * 32];
+		for (int b = 0; b < NB; b++) {
+			pblk[b] = (uint8_t *)gec_host_alloc(k * S);
+			ppar[b] = (uint8_t *)gec_host_alloc(m * S);
+			if (!pblk[b] || !ppar[b] || !gec_host_is_pinned(pblk[b], k * S))
+				return NULL;
+			memcpy(pblk[b], blk[b], k * S);
+		}
+		for (int rep = 0; rep < 3; rep++) {
+			if (gec_encode_hash_batch(j->c, NB, (const uint8_t *const *)pblk, len, S, ppar, sums) != GEC_OK)
+				return NULL;
+			const uint8_t *sh[NB * 64];
+			uint8_t *out[NB * 64];
+			const uint8_t *flat[NB * 64];
+			size_t flen[NB * 64];
+			uint8_t *tmp = (uint8_t *)gec_host_alloc((size_t)NB * S);
+			const int lost = (j->id + rep) % k;
+			for (int b = 0; b < NB; b++) {
+				if (memcmp(ppar[b], par[b], m * S))
+					return NULL; /* pinned path == staged path */
+				for (int s = 0; s < n; s++) {
+					sh[b * n + s] = s < k ? pblk[b] + s * S : ppar[b] + (s - k) * S;
+					flat[b * n + s] = sh[b * n + s];
+					flen[b * n + s] = S;
+					out[b * n + s] = NULL;
+				}
+				sh[b * n + lost] = NULL;
+				out[b * n + lost] = tmp + (size_t)b * S;
+			}
+			memset(sums2, 0, sizeof sums2);
+			if (gec_decode_verify_batch(j->c, NB, sh, S, len, out, sums2, bsum) != GEC_OK)
+				return NULL;
+			const uint8_t *bp[NB];
+			for (int b = 0; b < NB; b++)
+				bp[b] = pblk[b];
+			if (gec_blake2sum_batch(j->c, NB, bp, len, bsum2) != GEC_OK || memcmp(bsum, bsum2, NB * 32))
+				return NULL;
+			uint8_t direct[NB * 64 * 32];
+			if (gec_shardsum_batch(j->c, (size_t)NB * n, flat, flen, direct) != GEC_OK || memcmp(direct, sums, (size_t)NB * n * 32))
+				return NULL;
+			for (int b = 0; b < NB; b++) {
+				if (memcmp(tmp + (size_t)b * S, pblk[b] + lost * S, S))
+					return NULL;
+				/* the k shards that were read: every data shard but `lost`, plus parity shard k */
+				for (int s = 0; s <= k; s++)
+					if (s != lost && memcmp(sums2 + (b * n + s) * 32, sums + (b * n + s) * 32, 32))
+						return NULL;
+			}
+			gec_host_free(tmp);
+		}
+		for (int b = 0; b < NB; b++) {
+			gec_host_free(pblk[b]);
+			gec_host_free(ppar[b]);
+		}
+	}
 	j->ok = 1;
 	return NULL;
 }
