@@ -407,6 +407,7 @@ def run_procs(args) -> None:
     # ---- BASELINE config 5 beside it when there is more than one GPU (or on request): the path's one
     # real exchange step.  Guarded by a watchdog so that a collective that hangs cannot take the
     # headline line with it.
+    striped_failed = False
     dry = os.environ.get("GARAGE_DRYRUN_ONE_GPU") == "1"  # gloo stand-in on one device: no RCCL to measure
     if (world > 1 and not args.no_striped and not dry) or args.striped:
         box = {}
@@ -423,7 +424,8 @@ def run_procs(args) -> None:
         try:
             res = striped_decode_bench(args, R, distrib, box)
         except Exception as e:  # noqa: BLE001 -- reported in the line, the headline number stands
-            res = {"error": f"{type(e).__name__}: {e}"[:400]}
+            res = {"error": f"{type(e).__name__}: {e}"[:400], **box}
+            striped_failed = True
         done.set()
         if rank == 0:
             out["striped_decode"] = res
@@ -434,6 +436,11 @@ def run_procs(args) -> None:
         if world == 1 and not args.no_host_path:
             out.update(host_path_objects())
         print(json.dumps(out), flush=True)
+    if striped_failed:
+        # a rank that fell out of the striped decode may have left its peers inside a collective: the line is out,
+        # do not wait for them in the process group's teardown
+        sys.stdout.flush()
+        os._exit(0)
     distrib.shutdown(R)
 
 
@@ -709,7 +716,7 @@ def main() -> None:
     ap.add_argument("--no-striped", action="store_true", help="N>1: skip the BASELINE config 5 striped_decode object")
     ap.add_argument("--striped", action="store_true", help="N=1: also run the striped_decode object (RCCL with one rank)")
     ap.add_argument("--striped-objects", type=int, default=256)
-    ap.add_argument("--striped-timeout", type=float, default=240.0,
+    ap.add_argument("--striped-timeout", type=float, default=150.0,
                     help="watchdog for the striped_decode object: after this many seconds the line is printed without it")
     ap.add_argument("--precondition-ms", type=float, default=200.0,
                     help="untimed device pre-conditioning before the W warm-up steps: the same encode launches for this "

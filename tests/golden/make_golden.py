@@ -57,6 +57,30 @@ def case(co, name, cfg, k, m, L, nb, lost):
     }
 
 
+SHARDSUM_LEAF = 4096
+
+
+def shardsum_hashlib(data: bytes) -> bytes:
+    """The shard checksum written out with hashlib only (BLAKE2b tree mode; include/garage_ec.h)."""
+    n = max(1, -(-len(data) // SHARDSUM_LEAF))
+    leaves = b"".join(
+        hashlib.blake2b(data[i * SHARDSUM_LEAF:(i + 1) * SHARDSUM_LEAF], digest_size=64, fanout=0, depth=2, leaf_size=SHARDSUM_LEAF,
+                        node_offset=i, node_depth=0, inner_size=64, last_node=(i == n - 1)).digest() for i in range(n))
+    return hashlib.blake2b(leaves, digest_size=64, fanout=0, depth=2, leaf_size=SHARDSUM_LEAF, node_offset=0, node_depth=1,
+                           inner_size=64, last_node=True).digest()[:32]
+
+
+def checksum_cases():
+    """Known answers for the two hashes of row f4: Garage's blake2sum (plain) and the shard checksum (tree mode), on
+    SplitMix64 messages -- generated with hashlib, the RFC 7693 reference implementation in CPython."""
+    out = []
+    for i, n in enumerate([0, 1, 3, 64, 127, 128, 129, 4095, 4096, 4097, 8192, 12289, 104896, 209728, (1 << 20) + 3]):
+        msg = bytes(O.splitmix64_bytes(SEED + 100 + i, n))
+        out.append({"len": n, "seed": SEED + 100 + i, "blake2sum": hashlib.blake2b(msg, digest_size=64).digest()[:32].hex(),
+                    "shardsum": shardsum_hashlib(msg).hex()})
+    return out
+
+
 def main():
     co = O.COracle()
     cases = [
@@ -69,7 +93,8 @@ def main():
         case(co, "config2_full_batch_rs10_4_1MiB_x1024", 7, 10, 4, 1 << 20, 1024, (0, 3, 7, 9)),
     ]
     with open(os.path.join(HERE, "rs_golden.json"), "w") as f:
-        json.dump({"generator": "tests/golden/make_golden.py (CPU oracle)", "cases": cases}, f, indent=1)
+        json.dump({"generator": "tests/golden/make_golden.py (CPU oracle; checksums: hashlib)", "cases": cases,
+                   "checksums": checksum_cases()}, f, indent=1)
     print("wrote", len(cases), "cases")
 
 

@@ -12,7 +12,9 @@ import pytest
 from oracle import rs_oracle as O
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = json.load(open(os.path.join(HERE, "golden", "rs_golden.json")))["cases"]
+_GOLDEN = json.load(open(os.path.join(HERE, "golden", "rs_golden.json")))
+CASES = _GOLDEN["cases"]
+CHECKSUMS = _GOLDEN["checksums"]
 
 
 def sha(a) -> str:
@@ -67,3 +69,30 @@ def test_gpu_matches_golden(c):
     # same through the host-pointer API (what the Rust shim calls)
     pars = rs.encode_blocks([bytes(data[b].reshape(-1)[: c["block_len"]]) for b in range(c["nblocks"])], c["shard_len"])
     assert sha(np.stack(pars)) == c["parity_sha256"]
+
+
+def _msg(c):
+    return bytes(O.splitmix64_bytes(c["seed"], c["len"]))
+
+
+def test_checksum_restatements_reproduce_golden():
+    """blake2sum and the tree-mode shard checksum: the hashlib restatement the GPU tests use as their oracle
+    (garage_amd.codec.shardsum) and the C++ one inside libgarage_block against the committed known answers."""
+    import garage_amd as g
+    from garage_amd import block_native as bn
+
+    assert hashlib.blake2b(b"abc", digest_size=64).hexdigest()[:64] == "ba80a53f981c4d0d6a2797b69f12f6e94c212f14685ac4b74b12bb6fdbffa2d1"  # RFC 7693 A
+    for c in CHECKSUMS:
+        m = _msg(c)
+        assert hashlib.blake2b(m, digest_size=64).digest()[:32].hex() == c["blake2sum"] == bn.blake2sum(m).hex(), c["len"]
+        assert g.shardsum(m).hex() == c["shardsum"] == bn.shardsum(m).hex(), c["len"]
+
+
+@pytest.mark.gpu
+def test_gpu_checksums_match_golden():
+    import garage_amd as g
+
+    rs = g.ReedSolomon(10, 4)
+    msgs = [_msg(c) for c in CHECKSUMS]
+    assert [x.hex() for x in rs.blake2sum_batch(msgs)] == [c["blake2sum"] for c in CHECKSUMS]
+    assert [x.hex() for x in rs.shardsum_batch(msgs)] == [c["shardsum"] for c in CHECKSUMS]
