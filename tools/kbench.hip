@@ -364,6 +364,12 @@ int main(int argc, char **argv)
 		NIB(4, 4, 1, true, 256, 0, 0, "nib16 kc4 cpt1 nt t256");
 	} else {
 		NIB(2, 5, 1, true, 512, 0, 0, "nib8 kc5  cpt1 nt t512 (default)");
+		NIB(2, 5, 1, true, 256, 0, 0, "nib8 kc5  cpt1 nt t256");
+		NIB(2, 4, 1, true, 256, 0, 0, "nib8 kc4  cpt1 nt t256");
+		NIB(2, 5, 1, true, 320, 0, 0, "nib8 kc5  cpt1 nt t320");
+		NIBW(2, 5, 1, true, 256, 6, 0, "nib8 kc5  cpt1 nt t256 w6");
+		NIBW(2, 5, 1, true, 256, 8, 0, "nib8 kc5  cpt1 nt t256 w8");
+		NIB(2, 5, 1, true, 512, 0, 0, "nib8 kc5  cpt1 nt t512 (again)");
 		NIB(2, 5, 1, true, 384, 0, 0, "nib8 kc5  cpt1 nt t384");
 		NIB(2, 5, 1, true, 448, 0, 0, "nib8 kc5  cpt1 nt t448");
 		NIB(2, 5, 1, true, 640, 0, 0, "nib8 kc5  cpt1 nt t640");
