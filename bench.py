@@ -352,6 +352,7 @@ def run_procs(args) -> None:
     elapsed = distrib.max_over_ranks(R, t1 - t0)      # MAX over ranks
     blocks_all = distrib.sum_over_ranks(R, nb)        # units all ranks processed
     per_rank = distrib.gather_ints(R, nb)
+    kern_ns_all = distrib.gather_ints(R, int(round(kern_ms * 1e6)))   # every GPU's own average launch duration
     rccl = distrib.count_ranks(R)                     # an all-reduce of ones on the device: RCCL saw this many ranks
 
     # correctness gates, after and outside the timed region: the kernel's own compare mode over the
@@ -394,6 +395,10 @@ def run_procs(args) -> None:
         out = base_line(args, world, elapsed, blocks_all, per_rank, nb, S,
                         "one process per GPU (torch.distributed.run)" + (", self-launched" if os.environ.get("GARAGE_BENCH_SELF_LAUNCHED") else ""))
         out["roofline"] = roofline_obj(args, nb, S, kern_ms, cold_ms)
+        if world > 1:  # the fraction of the HBM roofline on every GPU, not only rank 0's
+            out["kernel_ms_per_gpu"] = [round(x / 1e6, 4) for x in kern_ns_all]
+            out["roofline_frac_per_gpu"] = [round(algo_bytes(per_rank[i], S) / (kern_ns_all[i] / 1e9) / 1e9 / HBM_PEAK_GBS, 4)
+                                            if kern_ns_all[i] else None for i in range(world)]
         out["parity_checked_blocks"] = checked_all
         out["parity_check"] = ("gec_verify_batch_dev over every block of every rank + CPU oracle byte-for-byte on "
                                f"{checked_all} strided blocks, after the timed region")

@@ -1189,17 +1189,36 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 // *.corrupted, queued for resync, and the read carries on with the next node.
 // On return, for every block with rcs[b] == GBM_OK, g[b].shard[0..k-1] hold the stored DataBlock (plain bytes or
 // one zstd frame, orig_len bytes) and block_sums[32*b..] its blake2sum (when want_block_sums).
+// `overlap` (optional) runs on a helper thread while the first device trip is in flight -- the caller assembles the
+// blocks that need no decode into its output buffers meanwhile; `changed[b]` is set for every block whose shard set
+// changed after that point (a shard failed its checksum and was replaced, or a data shard was rebuilt).
 int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs,
-		 bool want_block_sums, std::vector<uint8_t> &block_sums)
+		 bool want_block_sums, std::vector<uint8_t> &block_sums, const std::function<void()> &overlap = nullptr,
+		 std::vector<uint8_t> *changed = nullptr)
 {
 	const int k = mg->k, n = mg->n;
 	const size_t nb = hs.size();
 	block_sums.assign(want_block_sums ? nb * 32 : 0, 0);
+	if (changed)
+		changed->assign(nb, 0);
 	int grc = gather_many(mg, hs, tags, k, g, /*verify=*/false);
 	if (grc)
 		return grc;
+	std::thread helper;
+	struct Joiner {
+		std::thread &t;
+		~Joiner()
+		{
+			if (t.joinable())
+				t.join();
+		}
+	} joiner{helper};
+	if (overlap)
+		helper = std::thread(overlap);
 	std::vector<uint8_t> todo(nb, 1);
 	for (int round = 0; round <= n; ++round) {
+		if (round == 1 && helper.joinable())
+			helper.join();
 		std::map<size_t, std::vector<size_t>> by_s;
 		for (size_t b = 0; b < nb; ++b) {
 			if (!todo[b])
@@ -1248,6 +1267,8 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 			}
 			int rc = gec_decode_verify_batch(mg->codec, ids.size(), sp.data(), S, lens.data(), op.data(), ssums.data(),
 							 want_block_sums ? bsums.data() : nullptr);
+			if (helper.joinable())
+				helper.join();  // the overlapped host work reads g: it must be done before the results below change it
 			if (rc)
 				return ec_fail(rc, "gec_decode_verify_batch");
 			mg->gpu_hashed += ids.size() * (size_t)k + (want_block_sums ? ids.size() : 0);
@@ -1274,6 +1295,8 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 				if (bad) {
 					again[b] = 1;
 					any_again = true;
+					if (changed)
+						(*changed)[b] = 1;
 					continue;
 				}
 				bool rebuilt_any = false;
@@ -1282,8 +1305,11 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 						gb.shard[j] = fresh[i][j];
 						rebuilt_any = true;
 					}
-				if (rebuilt_any)
+				if (rebuilt_any) {
 					mg->metrics[3]++;
+					if (changed)
+						(*changed)[b] = 1;
+				}
 				if (want_block_sums)
 					std::memcpy(block_sums.data() + 32 * b, bsums.data() + 32 * i, 32);
 				rcs[b] = GBM_OK;
@@ -1293,6 +1319,8 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 		}
 		if (!any_again)
 			break;
+		if (helper.joinable())
+			helper.join();
 		grc = gather_many(mg, hs, tags, k, g, /*verify=*/false, &again);  // the next nodes, for the blocks that lost a shard
 		if (grc)
 			return grc;
@@ -1325,9 +1353,25 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 	for (size_t b = 0; b < nb; ++b)
 		hs[b].assign((const char *)hashes + 32 * b, 32);
 	std::vector<Gathered> g;
-	std::vector<uint8_t> block_sums;
+	std::vector<uint8_t> block_sums, changed, early(nb, 0);
 	const bool verify = mg->verify_block_hash.load();
-	int frc = fetch_blocks(mg, hs, tags, g, rcs, verify, block_sums);
+	// While the device checks the shards, the host already copies the blocks that need no decode (all k data shards in
+	// hand, stored Plain) into the caller's buffers: a block that then fails a checksum is reported as such (its buffer
+	// contents are unspecified on error) or is assembled again from the replaced shards.
+	auto assemble_early = [&] {
+		mg->pool->parallel_for(nb, [&](size_t b) {
+			const Gathered &gb = g[b];
+			if (!gb.have_meta || gb.count < k || gb.meta.compressed || gb.meta.orig_len > (uint64_t)k * gb.meta.shard_len ||
+			    cap[b] < gb.meta.orig_len)
+				return;
+			for (int j = 0; j < k; ++j)
+				if (gb.shard[j].empty())
+					return;
+			assemble(gb, k, out[b]);
+			early[b] = 1;
+		});
+	};
+	int frc = fetch_blocks(mg, hs, tags, g, rcs, verify, block_sums, assemble_early, &changed);
 	if (frc)
 		return frc;
 	// assemble (parallel), then check every Plain block's content against its name (DataBlock::verify,
@@ -1370,7 +1414,8 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 			rcs[b] = GBM_E_BUFFER_TOO_SMALL;
 			return;
 		}
-		assemble(g[b], k, out[b]);
+		if (!(early[b] && !changed[b]))
+			assemble(g[b], k, out[b]);
 		mg->metrics[5]++;
 	});
 	return GBM_OK;

@@ -74,6 +74,7 @@ def test_gpu_procs_mode_two_ranks_on_one_gpu(launcher):
     per = d["config"]["blocks_per_rank"]
     assert len(per) == 2 and sum(per) == 128 == d["config"]["blocks_total"]
     assert d["parity_checked_blocks"] >= 32 and d["roofline"]["frac"] > 0 and "decode" in d
+    assert len(d["roofline_frac_per_gpu"]) == 2 and all(0 < f < 1 for f in d["roofline_frac_per_gpu"])
 
 
 @pytest.mark.gpu
