@@ -517,6 +517,8 @@ def run_threads(args) -> None:
                     + (" (DRY RUN: all on device 0)" if dry else ""))
     out["roofline"] = roofline_obj(args, res[0]["nb"], S, res[0]["kern_ms"], res[0]["cold"])
     out["kernel_ms_per_gpu"] = [round(r["kern_ms"], 4) for r in res]
+    out["roofline_frac_per_gpu"] = [round(algo_bytes(r["nb"], S) / (r["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if r["kern_ms"] else None
+                                    for r in res]
     out["parity_checked_blocks"] = sum(r["checked"] for r in res)
     out["rccl_ranks"] = None
     out["collective_backend"] = "none (single process; the encode path has no collective)"
