@@ -25,7 +25,7 @@ SYMBOLS = [
     "gbm_block_incref", "gbm_block_decref", "gbm_block_rc",
     "gbm_put_to_resync", "gbm_resync_run", "gbm_resync_block", "gbm_resync_all", "gbm_resync_queue_len",
     "gbm_resync_errors_len", "gbm_resync_worker_start", "gbm_resync_worker_stop",
-    "gbm_scrub", "gbm_node_set_down", "gbm_node_has_shard", "gbm_node_delete_shard",
+    "gbm_scrub", "gbm_scrub_all", "gbm_scrub_state", "gbm_repair_all", "gbm_node_set_down", "gbm_node_has_shard", "gbm_node_delete_shard",
     "gbm_node_corrupt_shard", "gbm_node_shard_header", "gbm_node_order_violations", "gbm_metrics", "gbm_gpu_hashed",
     "gbm_batcher_create", "gbm_batcher_destroy", "gbm_batcher_put_block", "gbm_batcher_set_ram_buffer_max", "gbm_batcher_stats",
 ]
@@ -116,6 +116,9 @@ def _load():
     lib.gbm_resync_queue_len.argtypes = [vp]
     lib.gbm_resync_queue_len.restype = sz
     lib.gbm_scrub.argtypes = [vp, sz, ctypes.c_char_p, u8p]
+    lib.gbm_scrub_all.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint64)]
+    lib.gbm_scrub_state.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.gbm_repair_all.argtypes = [vp, ctypes.POINTER(sz)]
     lib.gbm_node_set_down.argtypes = [vp, ci, ci]
     lib.gbm_node_has_shard.argtypes = [vp, ci, ctypes.c_char_p, ci]
     lib.gbm_node_delete_shard.argtypes = [vp, ci, ctypes.c_char_p, ci]
@@ -345,6 +348,22 @@ class NativeBlockManager:
         bad = (ctypes.c_uint8 * n)()
         _check(lib.gbm_scrub(self._h, n, b"".join(hashes), bad), "scrub")
         return [h for h, b in zip(hashes, bad) if b]
+
+    def scrub_all(self, batch_blocks: int = 0) -> dict:
+        """ScrubWorker over everything stored: {scrubbed, corruptions, device_calls, located}."""
+        st = (ctypes.c_uint64 * 4)()
+        _check(lib.gbm_scrub_all(self._h, batch_blocks, st), "scrub_all")
+        return dict(zip(("scrubbed", "corruptions", "device_calls", "located"), [int(x) for x in st]))
+
+    def scrub_state(self) -> tuple[int, int]:
+        out = (ctypes.c_uint64 * 2)()
+        _check(lib.gbm_scrub_state(self._h, out), "scrub_state")
+        return int(out[0]), int(out[1])
+
+    def repair_all(self) -> int:
+        n = ctypes.c_size_t()
+        _check(lib.gbm_repair_all(self._h, ctypes.byref(n)), "repair_all")
+        return int(n.value)
 
     # fault injection -------------------------------------------------------------
     def node_set_down(self, node: int, down: bool) -> None:

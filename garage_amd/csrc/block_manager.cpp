@@ -19,6 +19,7 @@
 //    are striped / locked, nodes lock internally.
 #include "../../include/garage_block.h"
 
+#include <dirent.h>
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -515,6 +516,8 @@ struct Node {
 	virtual bool has(const Hash &h, int idx) = 0;
 	virtual bool del(const Hash &h, int idx) = 0;
 	virtual void mark_corrupted(const Hash &h, int idx) { del(h, idx); }
+	// every hash this node holds a shard of (BlockStoreIterator, src/block/repair.rs:196-233,634-752)
+	virtual void list(std::set<Hash> &out) = 0;
 
 	// the node's endpoint (StreamingEndpointHandler<BlockRpc>::handle, src/block/manager.rs:692-707);
 	// false = could not be contacted
@@ -603,6 +606,14 @@ struct MemoryNode : Node {
 		std::lock_guard<std::mutex> g(st.mu);
 		return st.files.erase(shard_key(h, idx)) != 0;
 	}
+	void list(std::set<Hash> &out) override
+	{
+		for (Stripe &st : stripes) {
+			std::lock_guard<std::mutex> g(st.mu);
+			for (auto &kv : st.files)
+				out.insert(kv.first.substr(0, 32));
+		}
+	}
 };
 
 // <root>/<h0>/<h1>/<hex>.s<idx>, tmp file + rename (write_block_inner, manager.rs:720-805);
@@ -689,6 +700,33 @@ struct DirNode : Node {
 		std::string p = path(h, idx);
 		std::rename(p.c_str(), (p + ".corrupted").c_str());
 	}
+	void list(std::set<Hash> &out) override
+	{
+		// <root>/<h0>/<h1>/<64 hex digits>.s<idx>
+		auto each = [](const std::string &d, const std::function<void(const std::string &)> &fn) {
+			if (DIR *dp = ::opendir(d.c_str())) {
+				while (struct dirent *e = ::readdir(dp))
+					if (e->d_name[0] != '.')
+						fn(e->d_name);
+				::closedir(dp);
+			}
+		};
+		each(root, [&](const std::string &a) {
+			each(root + "/" + a, [&](const std::string &b) {
+				each(root + "/" + a + "/" + b, [&](const std::string &f) {
+					const size_t dot = f.find(".s");
+					if (dot != 64 || f.find_first_not_of("0123456789", dot + 2) != std::string::npos || f.size() == dot + 2)
+						return;
+					Hash h(32, 0);
+					for (int i = 0; i < 32; ++i) {
+						auto nib = [](char c) { return c >= 'a' ? c - 'a' + 10 : c - '0'; };
+						h[i] = (char)((nib(f[2 * i]) << 4) | nib(f[2 * i + 1]));
+					}
+					out.insert(h);
+				});
+			});
+		});
+	}
 };
 
 // RcEntry (src/block/rc.rs:122-240)
@@ -745,6 +783,8 @@ struct gbm_manager {
 	std::atomic<uint64_t> clock_skew_ms{0};
 	uint64_t now() const { return real_now_ms() + clock_skew_ms.load(); }
 
+	// ScrubWorkerPersisted (src/block/repair.rs:169-194)
+	std::atomic<uint64_t> scrub_corruptions{0}, scrub_last_complete_ms{0};
 	std::atomic<uint64_t> metrics[6] = {};
 	std::atomic<uint64_t> gpu_hashed{0};
 	std::atomic<bool> compress{false};    // Config.compression_level (src/util/config.rs:52-58); Garage's default is Some(1)
@@ -2198,6 +2238,152 @@ int gbm_scrub(gbm_manager *mg, size_t nb, const uint8_t *hashes, uint8_t *bad_ou
 	} catch (const std::exception &e) {
 		return fail(GBM_E_IO, std::string("scrub: ") + e.what());
 	}
+	return GBM_OK;
+}
+
+// RepairWorker (src/block/repair.rs:30-150): phase 1 queues every hash of the refcount table, phase 2 every hash that
+// is actually stored somewhere ("blocks we are storing but don't actually need").
+int gbm_repair_all(gbm_manager *mg, size_t *queued)
+{
+	if (!mg)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	std::set<Hash> all;
+	for (auto &st : mg->rc) {
+		std::lock_guard<std::mutex> g(st.mu);
+		for (auto &kv : st.map)
+			all.insert(kv.first);
+	}
+	for (auto &nd : mg->nodes)
+		if (!nd->down.load())
+			nd->list(all);
+	for (const Hash &h : all)
+		mg->put_to_resync(h, 0);
+	if (queued)
+		*queued = all.size();
+	return GBM_OK;
+}
+
+// Which single shard of an RS-inconsistent stripe is the wrong one?  For every candidate j the stripe is re-derived
+// from the first k of the OTHER shards; the candidate is the culprit iff all the others then agree with what is
+// stored (needs m >= 2).  One gec_reconstruct_batch call: the n candidates are n "blocks" with n erasure patterns.
+static int locate_bad_shard(gbm_manager *mg, const Gathered &g)
+{
+	const int n = mg->n, k = mg->k;
+	if (mg->m < 2)
+		return -1;
+	const size_t S = g.meta.shard_len;
+	std::vector<const uint8_t *> sp((size_t)n * n, nullptr);
+	std::vector<uint8_t *> op((size_t)n * n, nullptr);
+	std::vector<std::vector<Bytes>> outb(n, std::vector<Bytes>(n));
+	for (int c = 0; c < n; ++c) {
+		// candidate c erased; of the rest the first k are read, the others are rebuilt and compared
+		int used = 0;
+		for (int j = 0; j < n; ++j) {
+			if (j == c)
+				continue;
+			if (used < k) {
+				sp[(size_t)c * n + j] = g.shard[j].data();
+				++used;
+			} else {
+				outb[c][j] = mg->bufs->get(S);
+				op[(size_t)c * n + j] = outb[c][j].mut();
+			}
+		}
+	}
+	if (gec_reconstruct_batch(mg->codec, n, sp.data(), op.data(), S, 0) != GEC_OK)
+		return -1;
+	int culprit = -1;
+	for (int c = 0; c < n; ++c) {
+		bool agree = true;
+		for (int j = 0; j < n && agree; ++j)
+			if (!outb[c][j].empty())
+				agree = std::memcmp(outb[c][j].data(), g.shard[j].data(), S) == 0;
+		if (agree) {
+			if (culprit >= 0)
+				return -1;  // ambiguous: more than one shard is wrong
+			culprit = c;
+		}
+	}
+	return culprit;
+}
+
+// ScrubWorker (src/block/repair.rs:234-500): walk everything that is stored, batch by batch, verify on the device;
+// a corrupt block is counted and queued for resync.  Where the reference can only say "this file no longer matches
+// its name", the code can say WHICH shard of an inconsistent stripe is wrong (if only one is): that shard is set
+// aside as *.corrupted, and resync rebuilds it.
+// stats (may be NULL): [0] blocks scrubbed, [1] corruptions detected, [2] device verify calls, [3] shards located and set aside
+int gbm_scrub_all(gbm_manager *mg, size_t batch_blocks, uint64_t stats[4])
+{
+	if (!mg)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	if (batch_blocks == 0)
+		batch_blocks = 1024;
+	uint64_t st[4] = {0, 0, 0, 0};
+	try {
+		std::set<Hash> all;
+		for (auto &nd : mg->nodes)
+			if (!nd->down.load())
+				nd->list(all);
+		std::vector<Hash> hs(all.begin(), all.end());
+		for (size_t b0 = 0; b0 < hs.size(); b0 += batch_blocks) {
+			const size_t nb = std::min(batch_blocks, hs.size() - b0);
+			std::vector<Hash> batch(hs.begin() + b0, hs.begin() + b0 + nb);
+			std::vector<Gathered> g;
+			int grc = gather_many(mg, batch, nullptr, mg->n, g);  // checksum failures are handled in there (renamed + queued)
+			if (grc)
+				return grc;
+			std::map<size_t, std::vector<size_t>> by_len;
+			for (size_t b = 0; b < nb; ++b) {
+				++st[0];
+				if (g[b].count == mg->n)
+					by_len[g[b].meta.shard_len].push_back(b);
+				else if (mg->get_rc(batch[b]).is_nonzero()) {
+					++st[1];  // a needed block that is not fully readable
+					mg->put_to_resync(batch[b], 0);
+				}
+			}
+			for (auto &kv : by_len) {
+				const std::vector<size_t> &ids = kv.second;
+				std::vector<const uint8_t *> sp(ids.size() * mg->n);
+				for (size_t i = 0; i < ids.size(); ++i)
+					for (int j = 0; j < mg->n; ++j)
+						sp[i * mg->n + j] = g[ids[i]].shard[j].data();
+				std::vector<uint8_t> ok(ids.size());
+				int rc = gec_verify_batch(mg->codec, ids.size(), sp.data(), kv.first, ok.data());
+				++st[2];
+				if (rc)
+					return ec_fail(rc, "gec_verify_batch");
+				for (size_t i = 0; i < ids.size(); ++i) {
+					if (ok[i])
+						continue;
+					++st[1];
+					mg->metrics[2]++;
+					const Gathered &gb = g[ids[i]];
+					const int bad = locate_bad_shard(mg, gb);
+					if (bad >= 0 && gb.node[bad] >= 0) {
+						mg->nodes[gb.node[bad]]->mark_corrupted(batch[ids[i]], bad);
+						++st[3];
+					}
+					mg->put_to_resync(batch[ids[i]], 0);
+				}
+			}
+		}
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("scrub_all: ") + e.what());
+	}
+	mg->scrub_corruptions += st[1];
+	mg->scrub_last_complete_ms = mg->now();
+	if (stats)
+		std::copy(st, st + 4, stats);
+	return GBM_OK;
+}
+
+int gbm_scrub_state(const gbm_manager *m, uint64_t out[2])
+{
+	if (!m || !out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	out[0] = m->scrub_corruptions.load();
+	out[1] = m->scrub_last_complete_ms.load();
 	return GBM_OK;
 }
 

@@ -210,6 +210,18 @@ int gbm_resync_worker_stop(gbm_manager *m);
  * not fully readable. */
 int gbm_scrub(gbm_manager *m, size_t n, const uint8_t *hashes, uint8_t *bad_out);
 
+/* RepairWorker (src/block/repair.rs:30-150): queue every hash of the refcount table and every hash that is stored on
+ * some node for resync, now.  *queued = distinct hashes. */
+int gbm_repair_all(gbm_manager *m, size_t *queued);
+/* ScrubWorker (src/block/repair.rs:234-500): verify EVERYTHING that is stored, batch_blocks (0 = 1024) stripes per device
+ * call; corrupt blocks are counted (corruptions_detected) and queued for resync.  For an RS-inconsistent stripe
+ * whose checksums all match (bit rot before checksumming) the one wrong shard is located by leave-one-out decodes
+ * (m >= 2), set aside as *.corrupted, and rebuilt by the resync that follows.
+ * stats (may be NULL): [0] blocks scrubbed, [1] corruptions detected, [2] device verify calls, [3] shards located. */
+int gbm_scrub_all(gbm_manager *m, size_t batch_blocks, uint64_t stats[4]);
+/* out[0] = corruptions_detected so far, out[1] = time_last_complete_scrub (ms; ScrubWorkerPersisted, :169-194) */
+int gbm_scrub_state(const gbm_manager *m, uint64_t out[2]);
+
 /* Fault injection / inspection for tests. */
 int gbm_node_set_down(gbm_manager *m, int node, int down);
 int gbm_node_has_shard(gbm_manager *m, int node, const uint8_t hash[32], int idx);

@@ -379,3 +379,37 @@ def test_batcher_coalesces_concurrent_puts():
     with pytest.raises(bn.Quorum):
         bt.put_block(hashes[0][0], blocks[0][0])
     bt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("on_disk", [False, True], ids=["memory", "directories"])
+def test_scrub_all_locates_and_repairs_silent_corruption(tmp_path, on_disk):
+    """ScrubWorker over everything stored (BlockStoreIterator = directory walk / memory stripes), device verify in
+    batches.  A parity shard AND (in another block) a data shard rot *before* their checksums are taken: every
+    checksum still matches, only the RS verify sees it; leave-one-out decodes say which shard it is; it is set aside
+    and the resync that follows rebuilds it.  RepairWorker queues everything known."""
+    codec = g.ReedSolomon(10, 4)
+    dirs = [str(tmp_path / f"node{i}") for i in range(16)] if on_disk else None
+    mgr = bn.NativeBlockManager(codec, 16, dirs)
+    blocks = [pattern_block(300_000 + 64 * i, 1200 + i) for i in range(40)]
+    hashes = [bn.blake2sum(b) for b in blocks]
+    mgr.rpc_put_blocks(list(zip(hashes, blocks)))
+    for h in hashes:
+        mgr.block_incref(h)
+    st = mgr.scrub_all(batch_blocks=16)
+    assert st == {"scrubbed": 40, "corruptions": 0, "device_calls": st["device_calls"], "located": 0} and st["device_calls"] >= 3
+    who7, who9 = mgr.storage_nodes_of(hashes[7]), mgr.storage_nodes_of(hashes[9])
+    mgr.node_corrupt_shard(who7[12], hashes[7], 12, 4242, 0x80, fix_checksum=True)      # a parity shard
+    mgr.node_corrupt_shard(who9[3], hashes[9], 3, 17, 0x01, fix_checksum=True)          # a data shard
+    assert mgr.scrub(hashes) == [hashes[7], hashes[9]]
+    st = mgr.scrub_all()
+    assert st["corruptions"] == 2 and st["located"] == 2
+    assert not mgr.node_has_shard(who7[12], hashes[7], 12) and not mgr.node_has_shard(who9[3], hashes[9], 3)
+    if on_disk:
+        hx = hashes[9].hex()
+        assert (tmp_path / f"node{who9[3]}" / hx[:2] / hx[2:4] / f"{hx}.s3.corrupted").exists()
+    assert mgr.resync_run()["rebuilt"] == 2
+    assert mgr.scrub_all()["corruptions"] == 0 and mgr.scrub_state()[0] == 2
+    assert mgr.rpc_get_blocks(hashes, 400_000) == blocks
+    assert mgr.repair_all() == 40 and mgr.resync_queue_len() >= 40
+    assert mgr.resync_run()["ok"] == 40
