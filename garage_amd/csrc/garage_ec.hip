@@ -798,6 +798,8 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 			const unsigned grid = (unsigned)(((la.total_cols + tile_cols - 1) / tile_cols + 7) / 8 * 8);
 			if (mw == 1 && mode == gec::MODE_STORE)
 				launch_nibble<1, gec::MODE_STORE, kThreadsMW1>(la, c->d_logexp, geo.kc, grid, lds, stream);
+			else if (mw == 1 && rows == 4)  // all four row slots real: stored rows prefetched behind the data loads
+				launch_nibble<1, gec::MODE_COMPARE_PF, kThreadsMW1>(la, c->d_logexp, geo.kc, grid, lds, stream);
 			else if (mw == 1)
 				launch_nibble<1, gec::MODE_COMPARE, kThreadsMW1>(la, c->d_logexp, geo.kc, grid, lds, stream);
 			else if (mw == 2 && mode == gec::MODE_STORE)
@@ -1890,18 +1892,11 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 			if (in_pinned[ci])
 				return;
 			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
-			// a call with few blocks would leave the copy threads idle: cut every block into 256 KiB pieces
-			// (one 1 MiB block: 95 -> ~70 us per call)
-			constexpr size_t kCopyPiece = 256u << 10;
-			const size_t ppb = (k * S + kCopyPiece - 1) / kCopyPiece;  // pieces per block
-			pool.parallel_for(nb * ppb, [&](size_t q) {
-				const size_t i = q / ppb, lo = (q % ppb) * kCopyPiece, hi = std::min(k * S, lo + kCopyPiece);
+			pool.parallel_for(nb, [&](size_t i) {
 				uint8_t *dst = st.h_buf + i * stripe;
 				const size_t len = block_len[b0 + i];
-				if (lo < len)
-					std::memcpy(dst + lo, blocks[b0 + i] + lo, std::min(hi, len) - lo);
-				if (hi > len)
-					std::memset(dst + std::max(lo, len), 0, hi - std::max(lo, len));
+				std::memcpy(dst, blocks[b0 + i], len);
+				std::memset(dst + len, 0, k * S - len);
 			});
 		},
 		[&](size_t ci, Staging &st) -> int {  // device: only data shards go H2D, only parity (+sums) comes back

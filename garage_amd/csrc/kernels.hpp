@@ -40,6 +40,12 @@ constexpr int RMAX16 = 16;   // ... with 16-byte entries (MW = 4): k <= K16MAX o
 constexpr int K16MAX = 120;  // 16 coefficient bytes per input shard must fit ApplyArgs.coef, the tables 64 KiB of LDS
 constexpr int BLOCK = 256;   // threads per workgroup of the baseline kernel
 constexpr int MODE_STORE = 0, MODE_COMPARE = 2;  // write the rows / compare them with what is stored
+// compare, with the stored rows requested up front behind the data loads (instead of at the end of the tile, where
+// their latency is exposed: verify is a pure read stream).  Only where every one of the 4 row slots is a real row
+// (rows == 4, 4-byte table entries): RS(10,4) verify 250 -> 232 us = 75 -> 81 % of peak; with fewer rows the
+// index-clamped duplicate loads cost more than they hide (RS(3,1): -6 %), with 8-byte entries the 32 extra VGPRs
+// cost occupancy (RS(20,8): -7 %).  tools/verify_bench.py.
+constexpr int MODE_COMPARE_PF = 3;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -250,6 +256,20 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 			d[j][c] = ld16<NT>(srcp[c] + off);
 	}
 
+	// -- compare mode: the stored rows are requested NOW, behind the data loads, instead of at the end of the tile
+	//    where their latency would be exposed (verify is a pure read stream: nothing else is left to hide it)
+	constexpr int NOLD = MODE == MODE_COMPARE_PF ? 4 * MW : 1;
+	u32x4 oldv[CPT][NOLD];
+	if (MODE == MODE_COMPARE_PF) {
+#pragma unroll
+		for (int r = 0; r < NOLD; ++r) {
+			const uint32_t ooff = a.out_off[(uint32_t)r < rows ? r : rows - 1];
+#pragma unroll
+			for (int c = 0; c < CPT; ++c)
+				oldv[c][r] = ld16<NT>(reinterpret_cast<const u32x4 *>(dstp[c]) + ooff);
+		}
+	}
+
 	// -- prologue 1: pin log/antilog + coefficients in LDS
 	reinterpret_cast<uint32_t *>(lexp)[le_idx] = le_word;
 	reinterpret_cast<uint32_t *>(lcoef)[coef_idx] = coef_word;
@@ -343,14 +363,18 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 				continue;
 			u32x4 v = {P[r][0], P[r][1], P[r][2], P[r][3]};
 			u32x4 *o = dstp[c] + a.out_off[r];
-			if (MODE == MODE_COMPARE) {
-				u32x4 old = ld16<NT>(o);
+			if (MODE == MODE_COMPARE || MODE == MODE_COMPARE_PF) {
+				u32x4 old;
+				if constexpr (MODE == MODE_COMPARE_PF)
+					old = oldv[c][r < NOLD ? r : 0];
+				else
+					old = ld16<NT>(o);
 				diff |= (v.x ^ old.x) | (v.y ^ old.y) | (v.z ^ old.z) | (v.w ^ old.w);
 			} else {
 				st16<NT>(v, o);
 			}
 		}
-		if (MODE == MODE_COMPARE && diff)
+		if ((MODE == MODE_COMPARE || MODE == MODE_COMPARE_PF) && diff)
 			a.bad[bb[c]] = 1u;
 	}
 }
