@@ -1925,33 +1925,54 @@ static int stream_out(const uint8_t *p, size_t len, size_t chunk_bytes, gbm_chun
 	return GBM_OK;
 }
 
+// one block into a buffer this function owns (the streaming forms do not know the size up front)
+static int get_block_owned(gbm_manager *mg, const uint8_t hash[32], const gbm_order_tag *tag, bool raw,
+			   gbm_data_block_header *hdr, std::vector<uint8_t> &out)
+{
+	const int k = mg->k;
+	std::vector<Hash> hs(1, Hash((const char *)hash, 32));
+	std::vector<Gathered> g;
+	std::vector<uint8_t> block_sums;
+	int rc1 = GBM_OK;
+	const bool verify = mg->verify_block_hash.load();
+	int frc = fetch_blocks(mg, hs, tag, g, &rc1, verify, block_sums);
+	if (frc)
+		return frc;
+	if (rc1 != GBM_OK)
+		return one_block_rc(rc1);
+	const size_t L = g[0].meta.orig_len;
+	const bool z = g[0].meta.compressed != 0;
+	if (hdr)
+		hdr->kind = z ? GBM_HEADER_COMPRESSED : GBM_HEADER_PLAIN;
+	if (!z && verify && std::memcmp(block_sums.data(), hash, 32) != 0)
+		return one_block_rc(GBM_E_CORRUPT_DATA);
+	std::vector<uint8_t> stored(L);
+	assemble(g[0], k, stored.data());
+	if (z && !raw) {
+		if (!zstd().decode(stored.data(), L, kMaxDecompressed, out))
+			return one_block_rc(GBM_E_CORRUPT_DATA);
+	} else {
+		out.swap(stored);
+	}
+	mg->metrics[5]++;
+	return GBM_OK;
+}
+
 static int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, gbm_data_block_header *hdr,
 			 size_t chunk_bytes, gbm_chunk_fn sink, void *ctx, bool raw)
 {
 	if (!m || !hash || !sink)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
-	// the shards have to be complete before any byte can be trusted (checksums, decode), so the block is
-	// gathered first and then handed out in order; the size is learnt from a first, zero-capacity call
-	size_t len = 0, cap = 0;
-	int rc1 = GBM_OK;
-	uint8_t *none[1] = {nullptr};
-	gbm_data_block_header h0;
-	int rc = get_blocks_impl(m, 1, hash, order_tag, none, &cap, &len, &rc1, raw, &h0);
+	// the shards have to be complete before any byte can be trusted (checksums, decode), so the block is gathered
+	// first and then handed out in order
+	std::vector<uint8_t> buf;
+	gbm_data_block_header h0{};
+	int rc = get_block_owned(m, hash, order_tag, raw, &h0, buf);
 	if (rc)
 		return rc;
-	if (rc1 != GBM_OK && rc1 != GBM_E_BUFFER_TOO_SMALL)
-		return one_block_rc(rc1);
-	std::vector<uint8_t> buf(len);
-	uint8_t *o[1] = {buf.data()};
-	cap = len;
-	rc = get_blocks_impl(m, 1, hash, order_tag, o, &cap, &len, &rc1, raw, &h0);
-	if (rc)
-		return rc;
-	if (rc1 != GBM_OK)
-		return one_block_rc(rc1);
 	if (hdr)
 		*hdr = h0;
-	return stream_out(buf.data(), len, chunk_bytes, sink, ctx);
+	return stream_out(buf.data(), buf.size(), chunk_bytes, sink, ctx);
 }
 
 int gbm_rpc_get_block_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, size_t chunk_bytes,

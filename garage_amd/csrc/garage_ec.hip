@@ -2280,11 +2280,16 @@ int gec_decode_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *c
 	DeviceGuard dg(c->device);
 	if (!dg.ok)
 		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	bool all_pinned = true;
+	for (size_t b = 0; b < nblocks && all_pinned; ++b)
+		for (size_t j = 0; j < n && all_pinned; ++j)
+			if (shards[b * n + j])
+				all_pinned = aligned16(shards[b * n + j]) && pinned().contains(shards[b * n + j], S);
 	StagingLease lease(c);
 	Staging &st = lease.st;
 	constexpr size_t kPiece = 32ull << 20;
-	// host staging: [piece A][piece B][shard off | shard len | block off | block len][shard sums][block sums][rebuilt]
-	const size_t tab_off = 2 * kPiece;
+	// host staging: [piece A][piece B] (pageable shards only) [shard off | shard len | block off | block len][shard sums][block sums][rebuilt]
+	const size_t tab_off = all_pinned ? 0 : 2 * kPiece;
 	const size_t tab_bytes = (nup * 2 + nblocks * 2) * 8;
 	const size_t ssum_off = tab_off + tab_bytes, bsum_off = ssum_off + nup * 32;
 	const size_t reb_off = (bsum_off + nblocks * 32 + 63) / 64 * 64;
@@ -2307,7 +2312,6 @@ int gec_decode_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *c
 	};
 	std::vector<Up> ups;
 	ups.reserve(nup);
-	bool all_pinned = true;
 	for (auto &kv : buckets) {
 		Bucket &bk = kv.second;
 		for (size_t i = 0; i < bk.ids.size(); ++i) {
@@ -2318,8 +2322,6 @@ int gec_decode_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *c
 				const size_t slot = (size_t)j < k ? (size_t)j : k + q++;
 				const uint8_t *p = shards[b * n + j];
 				ups.push_back({p, bk.base + i * bk.stripe + slot * S, b * n + j});
-				if (all_pinned && !(aligned16(p) && pinned().contains(p, S)))
-					all_pinned = false;
 			}
 		}
 	}
