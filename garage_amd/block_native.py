@@ -27,6 +27,7 @@ SYMBOLS = [
     "gbm_resync_errors_len", "gbm_resync_worker_start", "gbm_resync_worker_stop",
     "gbm_scrub", "gbm_scrub_all", "gbm_scrub_state", "gbm_repair_all", "gbm_node_set_down", "gbm_node_has_shard", "gbm_node_delete_shard",
     "gbm_node_corrupt_shard", "gbm_node_shard_header", "gbm_node_order_violations", "gbm_metrics", "gbm_gpu_hashed",
+    "gbm_set_read_hedge", "gbm_hedged_reads", "gbm_node_set_latency",
     "gbm_batcher_create", "gbm_batcher_destroy", "gbm_batcher_put_block", "gbm_batcher_set_ram_buffer_max", "gbm_batcher_stats",
 ]
 
@@ -111,6 +112,10 @@ def _load():
     lib.gbm_node_shard_header.argtypes = [vp, ci, ctypes.c_char_p, ci, ctypes.c_char_p]
     lib.gbm_node_order_violations.argtypes = [vp, ci]
     lib.gbm_node_order_violations.restype = ctypes.c_uint64
+    lib.gbm_set_read_hedge.argtypes = [vp, ctypes.c_uint64]
+    lib.gbm_hedged_reads.argtypes = [vp]
+    lib.gbm_hedged_reads.restype = ctypes.c_uint64
+    lib.gbm_node_set_latency.argtypes = [vp, ci, ctypes.c_uint64]
     lib.gbm_resync_block.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ci)]
     lib.gbm_resync_all.argtypes = [vp, ctypes.POINTER(ci)]
     lib.gbm_resync_queue_len.argtypes = [vp]
@@ -342,6 +347,18 @@ class NativeBlockManager:
 
     def node_order_violations(self, node: int) -> int:
         return int(lib.gbm_node_order_violations(self._h, node))
+
+    def set_read_hedge(self, hedge_us: int) -> None:
+        """0 = ask the first k holders and go further only on failure; >0 = ask the next holders too when some
+        have not answered after hedge_us."""
+        _check(lib.gbm_set_read_hedge(self._h, hedge_us), "set_read_hedge")
+
+    @property
+    def hedged_reads(self) -> int:
+        return int(lib.gbm_hedged_reads(self._h))
+
+    def node_set_latency(self, node: int, latency_us: int) -> None:
+        _check(lib.gbm_node_set_latency(self._h, node, latency_us), "node_set_latency")
 
     def scrub(self, hashes: Sequence[bytes]) -> list[bytes]:
         n = len(hashes)

@@ -405,6 +405,57 @@ private:
 	bool stop_ = false;
 };
 
+// Fire-and-forget tasks for requests that may be abandoned (hedged reads): a task owns everything it touches
+// through shared_ptrs, so nobody has to wait for a slow one.
+class Async {
+public:
+	explicit Async(unsigned n)
+	{
+		for (unsigned i = 0; i < n; ++i)
+			workers_.emplace_back([this] { run(); });
+	}
+	~Async()
+	{
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			stop_ = true;
+		}
+		cv_.notify_all();
+		for (auto &t : workers_)
+			t.join();
+	}
+	void submit(std::function<void()> fn)
+	{
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			q_.push_back(std::move(fn));
+		}
+		cv_.notify_one();
+	}
+
+private:
+	void run()
+	{
+		for (;;) {
+			std::function<void()> fn;
+			{
+				std::unique_lock<std::mutex> g(mu_);
+				cv_.wait(g, [&] { return stop_ || !q_.empty(); });
+				if (q_.empty())
+					return;  // stop_ and drained
+				fn = std::move(q_.front());
+				q_.pop_front();
+			}
+			fn();
+		}
+	}
+	std::vector<std::thread> workers_;
+	std::mutex mu_;
+	std::condition_variable cv_;
+	std::deque<std::function<void()>> q_;
+	bool stop_ = false;
+};
+
 // ------------------------------------------------------------------ buffers
 // Bytes = shared, immutable-after-fill byte range; slices alias their parent (std::shared_ptr aliasing
 // constructor), so a data shard is a view into its block's buffer and lives as long as any node keeps it.
@@ -509,6 +560,7 @@ struct ShardResp {
 struct Node {
 	std::atomic<bool> down{false};  // flipped by gbm_node_set_down while other threads are talking to the node
 	std::atomic<uint64_t> order_violations{0};
+	std::atomic<uint64_t> latency_us{0};  // test hook: every request to this node takes this long
 	std::shared_ptr<BufPool> bufs;
 	virtual ~Node() = default;
 	virtual bool put(const Hash &h, int idx, const Shard &s) = 0;
@@ -525,6 +577,8 @@ struct Node {
 	{
 		if (down.load(std::memory_order_acquire))
 			return false;
+		if (const uint64_t us = latency_us.load(std::memory_order_relaxed))
+			std::this_thread::sleep_for(std::chrono::microseconds(us));
 		switch (rq.kind) {
 		case RpcKind::PutShard:
 			note_order(rq.tag);
@@ -791,6 +845,18 @@ struct gbm_manager {
 	std::atomic<int> compression_level{1};
 	std::atomic<bool> verify_block_hash{true};
 
+	// hedged reads: 0 = the k requests of a read are issued and awaited in order
+	std::atomic<uint64_t> hedge_us{0}, hedged_reads{0};
+	std::mutex async_mu;
+	std::shared_ptr<Async> async;  // created when hedging is first switched on
+	std::shared_ptr<Async> async_pool()
+	{
+		std::lock_guard<std::mutex> g(async_mu);
+		if (!async)
+			async = std::make_shared<Async>(32);
+		return async;
+	}
+
 	// storage nodes of a hash in layout version v: a deterministic stand-in for
 	// ClusterLayout::storage_nodes_of (partition = top bits of the hash, src/rpc/layout/version.rs:101-118)
 	void nodes_of(const Hash &h, int version, std::vector<int> &who) const
@@ -928,52 +994,173 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 	};
 	auto have = [&](const Gathered &g, int j) { return g.settled ? !g.shard[j].empty() : g.have_idx(j); };
 	auto in_hand = [&](const Gathered &g) { return g.settled ? g.count : g.best(); };
+	// header checks every fetched shard passes before it becomes a candidate; called by one thread per block
+	auto accept = [&](std::vector<Cand> &mine, size_t b, int j, int node, Shard &&sh) -> bool {
+		Gathered &g = gs[b];
+		const ShardHeader &hd = sh.hd;
+		const bool ok = hd.idx == j && hd.k == mg->k && hd.m == mg->m && sh.data.n == hd.shard_len && hd.shard_len > 0 &&
+				hd.shard_len % 64 == 0;
+		if (!ok) {
+			mg->metrics[2]++;
+			mg->nodes[node]->mark_corrupted(hs[b], j);
+			mg->put_to_resync(hs[b], 0);
+			return false;
+		}
+		if (g.settled &&
+		    (hd.compressed != g.meta.compressed || hd.orig_len != g.meta.orig_len || hd.shard_len != g.meta.shard_len)) {
+			g.mixed = true;  // a stale shard of another geometry: resync will overwrite it
+			return false;
+		}
+		mine.push_back(Cand{b, j, node, std::move(sh)});
+		return true;
+	};
+	// next (version, shard index) candidate of block b that is not in hand and not already asked for this round
+	// (`taken(j)`: shard j is already covered this round; a j whose request failed is asked again from the holder
+	// in the next older layout version)
+	auto next_candidate = [&](size_t b, const std::function<bool(int)> &taken, std::vector<int> &who, int &who_v,
+				  int &j_out) -> bool {
+		Gathered &g = gs[b];
+		while (g.next < ncand) {
+			const size_t c = g.next++;
+			const int v = vcur - (int)(c / n), j = (int)(c % n);
+			if (have(g, j) || taken(j))
+				continue;
+			if (v != who_v) {
+				mg->nodes_of(hs[b], v, who);
+				who_v = v;
+			}
+			j_out = j;
+			return true;
+		}
+		return false;
+	};
+	const uint64_t hedge_us = mg->hedge_us.load();
 	for (;;) {
 		std::vector<std::vector<Cand>> per(hs.size());
-		mg->pool->parallel_for(hs.size(), [&](size_t b) {
-			if (only && !(*only)[b])
-				return;
-			Gathered &g = gs[b];
-			int pending = 0;
-			std::vector<int> who;
-			int who_v = -1;
-			while (g.next < ncand && in_hand(g) + pending < want) {
-				const size_t c = g.next++;
-				const int v = vcur - (int)(c / n), j = (int)(c % n);
-				if (have(g, j))
-					continue;
-				bool dup = false;
-				for (const Cand &pc : per[b])
-					dup = dup || pc.j == j;
-				if (dup)
-					continue;
-				if (v != who_v) {
-					mg->nodes_of(hs[b], v, who);
-					who_v = v;
+		if (hedge_us == 0) {
+			mg->pool->parallel_for(hs.size(), [&](size_t b) {
+				if (only && !(*only)[b])
+					return;
+				Gathered &g = gs[b];
+				int pending = 0, who_v = -1, j = 0;
+				std::vector<int> who;
+				auto taken = [&](int jj) {
+					for (const Cand &pc : per[b])
+						if (pc.j == jj)
+							return true;
+					return false;
+				};
+				while (in_hand(g) + pending < want && next_candidate(b, taken, who, who_v, j)) {
+					ShardRpc rq{RpcKind::GetShard, &hs[b], j, Shard(), tags ? &tags[b] : nullptr};
+					ShardResp rs;
+					if (!mg->nodes[who[j]]->handle(rq, rs) || !rs.ok)
+						continue;
+					if (accept(per[b], b, j, who[j], std::move(rs.shard)))
+						++pending;
 				}
-				ShardRpc rq{RpcKind::GetShard, &hs[b], j, Shard(), tags ? &tags[b] : nullptr};
+			});
+		} else {
+			// Hedged round: every request of the round is in flight at once; when some have not answered
+			// after hedge_us, the next candidates (the parity holders, then older layout versions) are
+			// asked as well, and a block moves on as soon as it has its shards from whoever answered
+			// first.  Requests that lose the race are abandoned, not cancelled: they own their state.
+			struct Flight {
+				size_t b;
+				int j, node;
+				Hash h;
+				gbm_order_tag tag;
+				bool has_tag, answered = false, done = false;
 				ShardResp rs;
-				Node &nd = *mg->nodes[who[j]];
-				if (!nd.handle(rq, rs) || !rs.ok)
-					continue;
-				const ShardHeader &hd = rs.shard.hd;
-				const bool ok = hd.idx == j && hd.k == mg->k && hd.m == mg->m && rs.shard.data.n == hd.shard_len &&
-						hd.shard_len > 0 && hd.shard_len % 64 == 0;
-				if (!ok) {
-					mg->metrics[2]++;
-					nd.mark_corrupted(hs[b], j);
-					mg->put_to_resync(hs[b], 0);
-					continue;
+			};
+			struct Round {
+				std::mutex mu;
+				std::condition_variable cv;
+				std::vector<int> need, ok, outstanding;
+				size_t unsatisfied = 0;
+				std::atomic<bool> over{false};  // the round has what it needs: requests not yet started are dropped
+				bool satisfied(size_t b) const { return ok[b] >= need[b] || outstanding[b] == 0; }
+			};
+			auto rd = std::make_shared<Round>();
+			rd->need.assign(hs.size(), 0);
+			rd->ok.assign(hs.size(), 0);
+			rd->outstanding.assign(hs.size(), 0);
+			std::vector<std::shared_ptr<Flight>> flights;
+			std::vector<std::vector<size_t>> flights_of(hs.size());
+			std::vector<std::vector<int>> who(hs.size());
+			std::vector<int> who_v(hs.size(), -1);
+			std::shared_ptr<Async> async = mg->async_pool();
+			// caller holds rd->mu
+			auto launch = [&](size_t b, int count) -> int {
+				int launched = 0, j = 0;
+				auto taken = [&](int jj) {  // in flight, or answered with a shard
+					for (size_t fi : flights_of[b]) {
+						const Flight &f = *flights[fi];
+						if (f.j == jj && (!f.done || (f.answered && f.rs.ok)))
+							return true;
+					}
+					return false;
+				};
+				while (launched < count && next_candidate(b, taken, who[b], who_v[b], j)) {
+					flights_of[b].push_back(flights.size());
+					auto f = std::make_shared<Flight>();
+					f->b = b;
+					f->j = j;
+					f->node = who[b][j];
+					f->h = hs[b];
+					f->has_tag = tags != nullptr;
+					if (tags)
+						f->tag = tags[b];
+					flights.push_back(f);
+					const bool was = rd->satisfied(b);
+					rd->outstanding[b]++;
+					if (was && !rd->satisfied(b))
+						rd->unsatisfied++;
+					Node *nd = mg->nodes[f->node].get();
+					async->submit([rd, f, nd] {
+						ShardRpc rq{RpcKind::GetShard, &f->h, f->j, Shard(), f->has_tag ? &f->tag : nullptr};
+						ShardResp rs;
+						const bool answered = !rd->over.load() && nd->handle(rq, rs);
+						{
+							std::lock_guard<std::mutex> g(rd->mu);
+							f->rs = std::move(rs);
+							f->answered = answered;
+							f->done = true;
+							const bool was = rd->satisfied(f->b);
+							rd->outstanding[f->b]--;
+							if (answered && f->rs.ok)
+								rd->ok[f->b]++;
+							if (!was && rd->satisfied(f->b))
+								rd->unsatisfied--;
+						}
+						rd->cv.notify_all();
+					});
+					++launched;
 				}
-				if (g.settled && (hd.compressed != g.meta.compressed || hd.orig_len != g.meta.orig_len ||
-						  hd.shard_len != g.meta.shard_len)) {
-					g.mixed = true;  // a stale shard of another geometry: resync will overwrite it
+				return launched;
+			};
+			std::unique_lock<std::mutex> lk(rd->mu);
+			for (size_t b = 0; b < hs.size(); ++b) {
+				if (only && !(*only)[b])
 					continue;
-				}
-				per[b].push_back(Cand{b, j, who[j], std::move(rs.shard)});
-				++pending;
+				rd->need[b] = std::max(0, want - in_hand(gs[b]));
+				launch(b, rd->need[b]);
 			}
-		});
+			// (system_clock: pthread_cond_timedwait, which ThreadSanitizer understands; gcc 11's does not know
+			// the pthread_cond_clockwait a steady_clock deadline turns into)
+			const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(hedge_us);
+			if (!rd->cv.wait_until(lk, deadline, [&] { return rd->unsatisfied == 0; })) {
+				uint64_t hedges = 0;
+				for (size_t b = 0; b < hs.size(); ++b)
+					if (!rd->satisfied(b))
+						hedges += launch(b, rd->need[b] - rd->ok[b]);
+				mg->hedged_reads += hedges;
+				rd->cv.wait(lk, [&] { return rd->unsatisfied == 0; });
+			}
+			rd->over = true;
+			for (auto &f : flights)
+				if (f->done && f->answered && f->rs.ok)
+					accept(per[f->b], f->b, f->j, f->node, std::move(f->rs.shard));
+		}
 		std::vector<Cand *> cands;
 		for (auto &v : per)
 			for (Cand &c : v)
@@ -1751,6 +1938,7 @@ void gbm_destroy(gbm_manager *m)
 	if (!m)
 		return;
 	gbm_resync_worker_stop(m);
+	m->async.reset();  // drains: abandoned hedged requests still point at the nodes
 	delete m;
 }
 
@@ -1777,6 +1965,24 @@ int gbm_set_verify_block_hash(gbm_manager *m, int enabled)
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
 	m->verify_block_hash = enabled != 0;
+	return GBM_OK;
+}
+
+int gbm_set_read_hedge(gbm_manager *m, uint64_t hedge_us)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	m->hedge_us = hedge_us;
+	return GBM_OK;
+}
+
+uint64_t gbm_hedged_reads(const gbm_manager *m) { return m ? m->hedged_reads.load() : 0; }
+
+int gbm_node_set_latency(gbm_manager *m, int node, uint64_t latency_us)
+{
+	if (!m || node < 0 || node >= (int)m->nodes.size())
+		return fail(GBM_E_INVALID_ARG, "bad node");
+	m->nodes[node]->latency_us = latency_us;
 	return GBM_OK;
 }
 

@@ -965,6 +965,74 @@ int reconstruct_dev(const gec_codec *c, size_t nblocks, uint8_t *d_base, size_t 
 
 // Appends `n` entries to the slot's table and launches ONE copy_table kernel over them.  Entries must have
 // 16-byte aligned src and dst (callers check with copyable()).
+// GEC_ZERO_COPY=0: caller memory that is pinned still goes through the HBM staging pipeline (A/B switch)
+bool zero_copy_enabled()
+{
+	static const bool on = [] {
+		const char *e = std::getenv("GEC_ZERO_COPY");
+		return !(e && e[0] == '0');
+	}();
+	return on;
+}
+
+// out[b][r] = XOR_t coef[r][t] * in[b][t] over shards that stay in the caller's pinned memory (gf_apply_ptrs):
+// in[b*k + t] / valid[b*k + t] name the k input shards of block b and how many of their S bytes exist,
+// out[b*nout + r] the output rows.  The tables are written into the staging slot's pinned table area, which the
+// kernel reads directly.  k <= PTR_KMAX.
+int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uint8_t *const *in, const uint32_t *valid,
+		      uint8_t *const *out, int nout, size_t S, const uint8_t *coef /* nout x k */, hipStream_t stream)
+{
+	const size_t k = c->k;
+	if (nblocks == 0 || nout == 0)
+		return GEC_OK;
+	if (k > (size_t)gec::PTR_KMAX || S / 16 > 0xffffffffull)
+		return fail(GEC_E_INVALID_ARG, "shape not supported by the pointer-table kernel");
+	const size_t in_bytes = nblocks * k * 8, valid_bytes = (nblocks * k * 4 + 7) / 8 * 8, out_bytes = nblocks * (size_t)nout * 8;
+	const size_t need = (st.tab_used * sizeof(gec::CopyEntry) + in_bytes + valid_bytes + out_bytes) / sizeof(gec::CopyEntry) + 2;
+	if (need > st.tab_cap)
+		return fail(GEC_E_INVALID_ARG, "pointer table overflow");
+	uint8_t *base = reinterpret_cast<uint8_t *>(st.h_tab + st.tab_used);
+	const uint8_t **t_in = reinterpret_cast<const uint8_t **>(base);
+	uint32_t *t_valid = reinterpret_cast<uint32_t *>(base + in_bytes);
+	uint8_t **t_out = reinterpret_cast<uint8_t **>(base + in_bytes + valid_bytes);
+	st.tab_used = need;
+	std::memcpy(t_in, in, in_bytes);
+	std::memcpy(t_valid, valid, nblocks * k * 4);
+	gec::PtrApplyArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.cols = (uint32_t)(S / 16);
+	a.k = (uint32_t)k;
+	const unsigned gx = (a.cols + 255) / 256;
+	int rows = 0;
+	size_t out_done = 0;  // entries of t_out consumed by earlier row groups
+	for (int r0 = 0; r0 < nout; r0 += rows) {
+		rows = std::min(gec::RMAX, nout - r0);
+		a.rows = (uint32_t)rows;
+		for (int r = 0; r < gec::RMAX; ++r)
+			for (size_t t = 0; t < k; ++t)
+				a.coef[t][r] = r < rows ? coef[(size_t)(r0 + r) * k + t] : 0;
+		uint8_t **grp = t_out + out_done;  // [nblocks][rows] for this group
+		for (size_t b = 0; b < nblocks; ++b)
+			for (int r = 0; r < rows; ++r)
+				grp[b * rows + r] = out[b * nout + r0 + r];
+		out_done += nblocks * rows;
+		const int mw = rows <= 4 ? 1 : 2;
+		const size_t lds = k * 32 * 4 * mw + 768 + k * gec::RMAX;
+		for (size_t b0 = 0; b0 < nblocks; b0 += 65535) {
+			const unsigned gy = (unsigned)std::min<size_t>(65535, nblocks - b0);
+			a.in = t_in + b0 * k;
+			a.in_valid = t_valid + b0 * k;
+			a.out = grp + b0 * rows;
+			if (mw == 1)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
+			else
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
+			HIP_TRY(hipGetLastError());
+		}
+	}
+	return GEC_OK;
+}
+
 int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipStream_t stream)
 {
 	if (ents.empty())
@@ -1868,6 +1936,38 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 	for (size_t b = 0; b < nblocks && all_pinned; ++b)
 		all_pinned = aligned16(blocks[b]) && aligned16(parity[b]) && pinned().contains(blocks[b], block_len[b]) &&
 			     pinned().contains(parity[b], m * S);
+	if (all_pinned && !shard_sums && k <= (size_t)gec::PTR_KMAX && zero_copy_enabled()) {
+		// every buffer is device-addressable: ONE kernel reads the data shards and writes the parity in place
+		// over the link; nothing is staged in HBM (with checksums requested the shards are needed in HBM anyway)
+		DeviceGuard dg(c->device);
+		if (!dg.ok)
+			return fail(GEC_E_DEVICE, "hipSetDevice failed");
+		StagingLease lease(c);
+		Staging &st = lease.st;
+		int rc = st.ensure(64, 0);
+		if (!rc)
+			rc = st.ensure_tab((nblocks * (k * 12 + m * 8) + 64) / sizeof(gec::CopyEntry) + 4);
+		if (rc)
+			return rc;
+		std::vector<const uint8_t *> in(nblocks * k);
+		std::vector<uint32_t> valid(nblocks * k);
+		std::vector<uint8_t *> out(nblocks * m);
+		for (size_t b = 0; b < nblocks; ++b) {
+			const uint8_t *p = pinned().dev(blocks[b]);
+			uint8_t *q = pinned().dev(parity[b]);
+			for (size_t t = 0; t < k; ++t) {
+				in[b * k + t] = p + t * S;
+				valid[b * k + t] = (uint32_t)(block_len[b] > t * S ? std::min(S, block_len[b] - t * S) : 0);
+			}
+			for (size_t r = 0; r < m; ++r)
+				out[b * m + r] = q + r * S;
+		}
+		rc = launch_apply_ptrs(c, st, nblocks, in.data(), valid.data(), out.data(), (int)m, S, c->enc.row(k), st.stream);
+		if (rc)
+			return rc;
+		HIP_TRY(hipStreamSynchronize(st.stream));
+		return GEC_OK;
+	}
 	const size_t ch = chunk_blocks(stripe, nblocks, shard_sums ? 8 * kChunkBytes : all_pinned ? pinned_chunk_bytes() : kChunkBytes);
 	const size_t sums_off = ch * stripe;  // checksum area behind the stripes of a slot
 	const size_t nchunks = (nblocks + ch - 1) / ch;
@@ -2544,13 +2644,20 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 			buckets[key].push_back(b);
 	}
 	CopyPool &pool = c->copy_pool();
+	// one decode plan per bucket, cut down to the rows the caller wants
+	struct Work {
+		const std::vector<size_t> *ids;
+		std::shared_ptr<const Plan> plan;
+		bool all_pinned;
+	};
+	std::vector<Work> work;
+	bool every_pinned = true;
+	size_t tab_bytes = 0;
 	for (auto &kv : buckets) {
 		const std::vector<size_t> &ids = kv.second;
 		std::string pres(kv.first);
 		for (auto &ch : pres)
 			ch = ch == 1 ? 1 : 0;
-		// compact staging: only the k shards the decode reads go H2D (slots 0..k-1 of the
-		// staging stripe), only the rebuilt shards come back (slots k..k+nmiss-1)
 		std::shared_ptr<const Plan> full;
 		int rc = get_plan(c, reinterpret_cast<const uint8_t *>(pres.data()), false, full);
 		if (rc)
@@ -2564,18 +2671,63 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 		for (size_t r = 0, w = 0; r < full->missing.size(); ++r)
 			if (kv.first[full->missing[r]] == 0)
 				std::memcpy(&sub->rows.at((int)w++, 0), full->rows.row((int)r), k);
-		std::shared_ptr<const Plan> plan = sub;
-		const size_t nmiss = plan->missing.size();
+		const size_t nmiss = sub->missing.size();
 		if (nmiss == 0)
 			continue;
-		const size_t stripe = (k + nmiss) * S;
 		bool all_pinned = true;
 		for (size_t i = 0; i < ids.size() && all_pinned; ++i) {
 			for (size_t t = 0; t < k && all_pinned; ++t)
-				all_pinned = aligned16(shards[ids[i] * n + plan->valid[t]]) && pinned().contains(shards[ids[i] * n + plan->valid[t]], S);
+				all_pinned = aligned16(shards[ids[i] * n + sub->valid[t]]) && pinned().contains(shards[ids[i] * n + sub->valid[t]], S);
 			for (size_t r = 0; r < nmiss && all_pinned; ++r)
-				all_pinned = aligned16(out[ids[i] * n + plan->missing[r]]) && pinned().contains(out[ids[i] * n + plan->missing[r]], S);
+				all_pinned = aligned16(out[ids[i] * n + sub->missing[r]]) && pinned().contains(out[ids[i] * n + sub->missing[r]], S);
 		}
+		every_pinned = every_pinned && all_pinned;
+		tab_bytes += ids.size() * (k * 12 + nmiss * 8) + 64;
+		work.push_back({&ids, sub, all_pinned});
+	}
+	if (!work.empty() && every_pinned && k <= (size_t)gec::PTR_KMAX && zero_copy_enabled()) {
+		// every shard and every output is device-addressable: one gf_apply_ptrs launch per erasure pattern reads
+		// the k shards the decode uses and writes the rebuilt ones straight over the link
+		DeviceGuard dg(c->device);
+		if (!dg.ok)
+			return fail(GEC_E_DEVICE, "hipSetDevice failed");
+		StagingLease lease(c);
+		Staging &st = lease.st;
+		int rc = st.ensure(64, 0);
+		if (!rc)
+			rc = st.ensure_tab(tab_bytes / sizeof(gec::CopyEntry) + 4 * work.size() + 4);
+		if (rc)
+			return rc;
+		for (const Work &w : work) {
+			const std::vector<size_t> &ids = *w.ids;
+			const size_t nmiss = w.plan->missing.size();
+			std::vector<const uint8_t *> in(ids.size() * k);
+			std::vector<uint32_t> valid(ids.size() * k, (uint32_t)S);
+			std::vector<uint8_t *> outp(ids.size() * nmiss);
+			for (size_t i = 0; i < ids.size(); ++i) {
+				for (size_t t = 0; t < k; ++t)
+					in[i * k + t] = pinned().dev(shards[ids[i] * n + w.plan->valid[t]]);
+				for (size_t r = 0; r < nmiss; ++r)
+					outp[i * nmiss + r] = pinned().dev(out[ids[i] * n + w.plan->missing[r]]);
+			}
+			rc = launch_apply_ptrs(c, st, ids.size(), in.data(), valid.data(), outp.data(), (int)nmiss, S,
+					       w.plan->rows.v.data(), st.stream);
+			if (rc)
+				break;
+		}
+		const hipError_t e = hipStreamSynchronize(st.stream);  // also on error: launches already queued read the tables
+		if (rc)
+			return rc;
+		HIP_TRY(e);
+		return GEC_OK;
+	}
+	for (const Work &wk : work) {
+		const std::vector<size_t> &ids = *wk.ids;
+		std::shared_ptr<const Plan> plan = wk.plan;
+		const size_t nmiss = plan->missing.size();
+		const size_t stripe = (k + nmiss) * S;
+		const bool all_pinned = wk.all_pinned;
+		int rc = GEC_OK;
 		const size_t ch = chunk_blocks(stripe, ids.size(), all_pinned ? pinned_chunk_bytes() : kChunkBytes);
 		std::vector<size_t> in_off(k), out_off(nmiss);
 		for (size_t t = 0; t < k; ++t)

@@ -391,6 +391,139 @@ __global__ __launch_bounds__(TPB, MINW) void gf_apply_nibble_w(const ApplyArgs a
 	gf_apply_nibble_body<MW, MODE, KC, CPT, NT, TPB>(a, le);
 }
 
+// ---------------------------------------------------------------------------
+// gf_apply_ptrs: the same product for shards that stay in the CALLER's memory -- pinned host buffers the device
+// addresses over PCIe (gec_host_alloc / gec_host_register).  Shards are named by pointer tables instead of
+// base + stride, each input shard carries the number of its bytes that exist (a block's last data shard is
+// short; the rest of it reads as zero), and every output row has its own pointer.  One launch replaces
+// copy-in kernel + apply + copy-out kernel and nothing is staged in HBM; the link, not the kernel, is the bound
+// (tools/pcie_probe: 53 GB/s for this access shape on a Gen5 x16 link), so the kernel is the plain one-column-
+// per-lane form of gf_apply_nibble: same LDS tables, same lookups, KC loads in flight per lane.
+// blockIdx.y = block, blockIdx.x = tile of 256 columns.  The tables themselves live in pinned host memory too:
+// they are wave-uniform, i.e. a few scalar loads per workgroup.
+// ---------------------------------------------------------------------------
+constexpr int PTR_KMAX = 128;  // coef[PTR_KMAX][RMAX] keeps the kernel argument block at 1 KiB
+
+struct PtrApplyArgs {
+	const uint8_t *const *in;  // [nblocks][k]: 16-byte aligned shard pointers
+	const uint32_t *in_valid;  // [nblocks][k]: bytes of the shard that exist (<= 16*cols)
+	uint8_t *const *out;       // [nblocks][rows]
+	uint32_t cols;             // 16-byte columns per shard
+	uint32_t k, rows;
+	uint8_t coef[PTR_KMAX][RMAX];
+};
+
+__device__ __forceinline__ u32x4 ld16_valid(const uint8_t *shard, uint32_t col, uint32_t valid)
+{
+	const uint32_t off = col << 4;
+	if (off + 16 <= valid)
+		return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(shard) + col);
+	uint32_t w[4] = {0, 0, 0, 0};
+	for (uint32_t i = off; i < valid; ++i)  // the one column per block that straddles the end of the data
+		w[(i - off) >> 2] |= (uint32_t)shard[i] << (8 * (i & 3));
+	return u32x4{w[0], w[1], w[2], w[3]};
+}
+
+template <int MW, int KC>
+__global__ __launch_bounds__(256) void gf_apply_ptrs(const PtrApplyArgs a, const LogExp *__restrict__ le)
+{
+	constexpr int ENT = 4 * MW, TBL = 32 * ENT;
+	static_assert(MW == 1 || MW == 2, "rows go out in groups of at most 8");
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const uint32_t tid = threadIdx.x, k = a.k, rows = a.rows, b = blockIdx.y;
+	uint8_t *lexp = lds + k * TBL, *llog = lexp + 512, *lcoef = llog + 256;
+	const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds;
+	const uint32_t col_raw = blockIdx.x * 256 + tid;
+	const bool live = col_raw < a.cols;
+	const uint32_t col = live ? col_raw : 0;  // dead lanes shadow column 0 (loads only)
+	const uint8_t *const *inp = a.in + (size_t)b * k;
+	const uint32_t *valid = a.in_valid + (size_t)b * k;
+
+	// first batch of shard loads goes out before the tables are built: PCIe latency hides behind the expansion
+	u32x4 d[KC];
+#pragma unroll
+	for (int j = 0; j < KC; ++j) {
+		const uint32_t t = (uint32_t)j < k ? j : k - 1;
+		d[j] = ld16_valid(inp[t], col, valid[t]);
+	}
+	if (tid < 192)
+		reinterpret_cast<uint32_t *>(lexp)[tid] = reinterpret_cast<const uint32_t *>(le)[tid];
+	for (uint32_t i = tid; i < k * (RMAX / 4); i += 256)
+		reinterpret_cast<uint32_t *>(lcoef)[i] = reinterpret_cast<const uint32_t *>(&a.coef[0][0])[i];
+	__syncthreads();
+	for (uint32_t idx = tid; idx < k * 32; idx += 256) {
+		const uint32_t t = idx >> 5, e = idx & 31;
+		const uint32_t x = e < 16 ? e : (e - 16) << 4;
+		uint32_t w[MW] = {};
+		if (x) {
+			const uint32_t lx = llog[x];
+#pragma unroll
+			for (int r = 0; r < 4 * MW; ++r) {
+				const uint32_t c = lcoef[t * RMAX + r];  // rows beyond `rows` are 0
+				const uint32_t p = c ? lexp[llog[c] + lx] : 0;
+				w[r >> 2] |= p << (8 * (r & 3));
+			}
+		}
+		uint32_t *tdst = reinterpret_cast<uint32_t *>(lds + t * TBL + e * ENT);
+#pragma unroll
+		for (int h = 0; h < MW; ++h)
+			tdst[h] = w[h];
+	}
+	__syncthreads();
+
+	uint32_t acc[4][4][MW];
+#pragma unroll
+	for (int w = 0; w < 4; ++w)
+#pragma unroll
+		for (int j = 0; j < 4; ++j)
+#pragma unroll
+			for (int h = 0; h < MW; ++h)
+				acc[w][j][h] = 0;
+	for (uint32_t t0 = 0; t0 < k; t0 += KC) {
+		if (t0 > 0) {
+#pragma unroll
+			for (int j = 0; j < KC; ++j) {
+				const uint32_t t = t0 + j < k ? t0 + j : k - 1;
+				d[j] = ld16_valid(inp[t], col, valid[t]);
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < KC; ++j) {
+			if (t0 + j >= k)
+				break;
+			const uint32_t tb = __builtin_amdgcn_readfirstlane(lds_base + (t0 + j) * TBL);
+			const uint32_t xs[4] = {d[j].x, d[j].y, d[j].z, d[j].w};
+#pragma unroll
+			for (int w = 0; w < 4; ++w) {
+				const uint32_t x = xs[w];
+				const uint32_t lo = (MW == 1) ? ((x << 2) & 0x3C3C3C3Cu) : ((x << 3) & 0x78787878u);
+				const uint32_t hi = (MW == 1) ? ((x >> 2) & 0x3C3C3C3Cu) : ((x >> 1) & 0x78787878u);
+				lut_acc<MW, 0>(tb, lo, hi, acc[w][0]);
+				lut_acc<MW, 1>(tb, lo, hi, acc[w][1]);
+				lut_acc<MW, 2>(tb, lo, hi, acc[w][2]);
+				lut_acc<MW, 3>(tb, lo, hi, acc[w][3]);
+			}
+		}
+	}
+	uint32_t P[4 * MW][4];
+#pragma unroll
+	for (int h = 0; h < MW; ++h)
+#pragma unroll
+		for (int w = 0; w < 4; ++w)
+			transpose4x4(acc[w][0][h], acc[w][1][h], acc[w][2][h], acc[w][3][h], P[4 * h + 0][w], P[4 * h + 1][w],
+				     P[4 * h + 2][w], P[4 * h + 3][w]);
+	if (!live)
+		return;
+	uint8_t *const *outp = a.out + (size_t)b * rows;
+#pragma unroll
+	for (int r = 0; r < 4 * MW; ++r) {
+		if (r >= (int)rows)
+			continue;
+		const u32x4 v = {P[r][0], P[r][1], P[r][2], P[r][3]};
+		__builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(outp[r]) + col);
+	}
+}
+
 // Clears the per-block mismatch flags ahead of a MODE_COMPARE launch.  A kernel rather
 // than hipMemsetAsync: inside a captured hipGraph (ROCm 7.0/7.2) the memset node did not
 // order the compare kernel behind the preceding encode kernel, so verify could race with

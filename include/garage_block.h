@@ -236,6 +236,18 @@ int gbm_node_shard_header(gbm_manager *m, int node, const uint8_t hash[32], int 
 /* PutShard deliveries to this node whose order tag was lower than one it had already seen for the same stream */
 uint64_t gbm_node_order_violations(gbm_manager *m, int node);
 
+/* Hedged reads (the template is try_call_many_inner,
+ * /root/reference/src/rpc/rpc_helper.rs:323-411: launch exactly quorum requests in request_order, start another on
+ * each failure, stop at quorum successes).  hedge_us == 0 (default): a read asks the holders of the first k shard
+ * indices and only goes further when one of them fails.  hedge_us > 0: all requests of a round are in flight at
+ * once, and when some have not answered after hedge_us the next holders in the order (parity, then older layout
+ * versions) are asked too; the block is decoded from whichever k shards arrive first ("first k present" makes the
+ * result independent of who wins), the losers are abandoned.  gbm_hedged_reads = extra requests sent so far. */
+int gbm_set_read_hedge(gbm_manager *m, uint64_t hedge_us);
+uint64_t gbm_hedged_reads(const gbm_manager *m);
+/* Test hook: every request to this node takes latency_us longer (a slow disk / a far zone). */
+int gbm_node_set_latency(gbm_manager *m, int node, uint64_t latency_us);
+
 /* out[0..5] = bytes_written, bytes_read, corruption_counter, ec_reconstructs,
  * blocks_put, blocks_get */
 int gbm_metrics(const gbm_manager *m, uint64_t out[6]);

@@ -486,8 +486,93 @@ static void run_round2(int k, int m)
 	printf("round-2 scenarios RS(%d,%d): OK\n", k, m);
 }
 
+// Hedged reads: a slow data-shard holder must not set the latency of the read.
+static void run_hedged(int k, int m)
+{
+	using clk = std::chrono::steady_clock;
+	gec_codec *codec = stub_codec_create(k, m);
+	const int n = k + m;
+	gbm_manager *mg = nullptr;
+	CHECK(gbm_create(codec, n + 2, nullptr, 0, &mg) == GBM_OK);
+	CHECK(gbm_set_threads(mg, 4) == GBM_OK);
+	const size_t nb = 24;
+	std::vector<std::vector<uint8_t>> blocks(nb);
+	std::vector<uint8_t> hashes(nb * 32);
+	std::vector<const uint8_t *> ptrs(nb);
+	std::vector<size_t> lens(nb);
+	for (size_t b = 0; b < nb; ++b) {
+		blocks[b] = pattern(100000 + 977 * b, 300 + (unsigned)b);
+		std::memcpy(blocks[b].data(), &b, sizeof b);
+		gbm_blake2sum(blocks[b].data(), blocks[b].size(), &hashes[32 * b]);
+		ptrs[b] = blocks[b].data();
+		lens[b] = blocks[b].size();
+	}
+	CHECK(gbm_rpc_put_blocks(mg, nb, hashes.data(), ptrs.data(), lens.data(), nullptr, nullptr) == GBM_OK);
+	// the holder of data shard 0 of block 0 answers after 300 ms
+	std::vector<int> who(n);
+	CHECK(gbm_storage_nodes_of(mg, &hashes[0], who.data()) == GBM_OK);
+	const int slow = who[0];
+	CHECK(gbm_node_set_latency(mg, slow, 300000) == GBM_OK);
+	std::vector<std::vector<uint8_t>> outs(nb);
+	std::vector<uint8_t *> outp(nb);
+	std::vector<size_t> caps(nb), got(nb);
+	std::vector<int> rcs(nb);
+	for (size_t b = 0; b < nb; ++b) {
+		outs[b].resize(lens[b]);
+		outp[b] = outs[b].data();
+		caps[b] = lens[b];
+	}
+	auto read_all = [&]() -> double {
+		const auto t0 = clk::now();
+		CHECK(gbm_rpc_get_blocks(mg, nb, hashes.data(), nullptr, outp.data(), caps.data(), got.data(), rcs.data()) == GBM_OK);
+		const std::chrono::duration<double, std::milli> dt = clk::now() - t0;
+		const double ms = dt.count();
+		for (size_t b = 0; b < nb; ++b)
+			CHECK(rcs[b] == GBM_OK && got[b] == lens[b] && std::memcmp(outp[b], ptrs[b], lens[b]) == 0);
+		return ms;
+	};
+	// unhedged: somebody waits for the slow node
+	const double t_plain = read_all();
+	CHECK(t_plain >= 290.0);
+	CHECK(gbm_hedged_reads(mg) == 0);
+	// hedged at 20 ms: parity holders are asked instead, the slow request is abandoned, same bytes
+	CHECK(gbm_set_read_hedge(mg, 20000) == GBM_OK);
+	const double t_hedged = read_all();
+	CHECK(gbm_hedged_reads(mg) >= 1);
+	CHECK(t_hedged < 0.6 * t_plain);  // (relative: the sanitizer builds run this too)
+	// single-block form, streaming form
+	size_t g1 = 0;
+	const auto t0 = clk::now();
+	CHECK(gbm_rpc_get_block(mg, &hashes[0], nullptr, outp[0], caps[0], &g1) == GBM_OK && g1 == lens[0]);
+	CHECK(std::memcmp(outp[0], ptrs[0], g1) == 0);
+	const std::chrono::duration<double, std::milli> dt1 = clk::now() - t0;
+	CHECK(dt1.count() < 290.0);
+	// hedging with every spare needed: m nodes down as well -> the read has to wait for the slow node and still succeeds
+	int downed = 0;
+	for (int j = n - 1; j >= 0 && downed < m; --j)
+		if (who[j] != slow) {
+			CHECK(gbm_node_set_down(mg, who[j], 1) == GBM_OK);
+			++downed;
+		}
+	CHECK(gbm_rpc_get_block(mg, &hashes[0], nullptr, outp[0], caps[0], &g1) == GBM_OK && g1 == lens[0]);
+	CHECK(std::memcmp(outp[0], ptrs[0], g1) == 0);
+	// no latency, hedging on: nothing is hedged
+	CHECK(gbm_node_set_latency(mg, slow, 0) == GBM_OK);
+	for (int j = 0; j < n; ++j)
+		CHECK(gbm_node_set_down(mg, who[j], 0) == GBM_OK);
+	CHECK(gbm_set_read_hedge(mg, 2000000) == GBM_OK);
+	const uint64_t before = gbm_hedged_reads(mg);
+	read_all();
+	CHECK(gbm_hedged_reads(mg) == before);
+	gbm_destroy(mg);  // drains the abandoned requests
+	stub_codec_destroy(codec);
+	printf("hedged reads RS(%d,%d): plain %.0f ms, hedged %.0f ms: OK\n", k, m, t_plain, t_hedged);
+}
+
 int main(int argc, char **argv)
 {
+	run_hedged(3, 1);
+	run_hedged(10, 4);
 	run_round2(3, 1);
 	run_round2(10, 4);
 	run(3, 1, nullptr);

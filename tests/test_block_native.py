@@ -413,3 +413,34 @@ def test_scrub_all_locates_and_repairs_silent_corruption(tmp_path, on_disk):
     assert mgr.rpc_get_blocks(hashes, 400_000) == blocks
     assert mgr.repair_all() == 40 and mgr.resync_queue_len() >= 40
     assert mgr.resync_run()["ok"] == 40
+
+
+@pytest.mark.gpu
+def test_hedged_read_decodes_around_a_slow_node(codec):
+    """with a hedge delay, a read whose data-shard holder is slow asks the parity
+    holders too and decodes from whichever k shards arrive first -- same bytes, without waiting for the slow node."""
+    import time
+
+    mgr = _mgr(codec)
+    blocks = [pattern_block(200_000 + 4099 * i, 900 + i) + bytes([i]) for i in range(32)]
+    hashes = [bn.blake2sum(b) for b in blocks]
+    mgr.rpc_put_blocks(list(zip(hashes, blocks)))
+    who = mgr.storage_nodes_of(hashes[0])
+    mgr.node_set_latency(who[0], 400_000)
+    t0 = time.perf_counter()
+    assert mgr.rpc_get_block(hashes[0]) == blocks[0]
+    assert time.perf_counter() - t0 >= 0.39 and mgr.hedged_reads == 0
+    rec0 = mgr.metrics["ec_reconstructs"]
+    mgr.set_read_hedge(10_000)
+    t0 = time.perf_counter()
+    assert mgr.rpc_get_block(hashes[0]) == blocks[0]
+    assert time.perf_counter() - t0 < 0.35
+    assert mgr.hedged_reads >= 1 and mgr.metrics["ec_reconstructs"] == rec0 + 1
+    t0 = time.perf_counter()
+    assert mgr.rpc_get_blocks(hashes, 1 << 19) == blocks
+    assert time.perf_counter() - t0 < 0.39
+    # hedging never lowers the bar: with m other holders down the slow shard is needed and is waited for
+    down = [w for w in who[1:]][-codec.m:]
+    for w in down:
+        mgr.node_set_down(w, True)
+    assert mgr.rpc_get_block(hashes[0]) == blocks[0]

@@ -752,6 +752,64 @@ def test_host_api_pinned_buffers_match_pageable(coracle, rs104):
     host_free(arena)
 
 
+@pytest.mark.parametrize("k,m", [(3, 1), (20, 8), (10, 12), (128, 3)], ids=["rs3_1", "rs20_8", "rs10_12", "rs128_3"])
+def test_zero_copy_encode_shapes(coracle, k, m):
+    """gf_apply_ptrs (encode straight out of / into pinned caller memory): 4- and 8-byte table entries, more
+    than 8 parity rows (two row groups), the largest k it takes; ragged lengths incl. blocks that end inside a
+    16-byte column and blocks with empty trailing shards; junk behind every block must read as zero."""
+    import ctypes
+
+    from garage_amd.codec import host_alloc, host_free
+
+    lib = _lib.lib
+    rs = g.ReedSolomon(k, m)
+    lens = [200_000, 199_999, 1, 4096 * k + 5, 64 * k, 123_457]
+    nb = len(lens)
+    S = g.shard_len(k, max(lens))
+    rng = np.random.default_rng(k * 100 + m)
+    padded = np.zeros((nb, k * S), dtype=np.uint8)
+    blocks = [host_alloc(k * S) for _ in range(nb)]
+    outs = [host_alloc(m * S) for _ in range(nb)]
+    for b in range(nb):
+        padded[b, :lens[b]] = rng.integers(0, 256, lens[b], dtype=np.uint8)
+        blocks[b][:] = 0x5A
+        blocks[b][:lens[b]] = padded[b, :lens[b]]
+        outs[b][:] = 0xEE
+    want = coracle.encode_batch(k, m, padded.reshape(nb, k, S), coracle.AVX2, threads=4)
+    clens = (ctypes.c_size_t * nb)(*lens)
+    ptrs = (ctypes.c_void_p * nb)(*[x.ctypes.data for x in blocks])
+    optrs = (ctypes.c_void_p * nb)(*[o.ctypes.data for o in outs])
+    _lib.check(lib.gec_encode_batch(rs._h, nb, ptrs, clens, S, optrs), "zero-copy encode")
+    for b in range(nb):
+        assert np.array_equal(outs[b].reshape(m, S), want[b]), f"block {b} (len {lens[b]})"
+        assert np.all(blocks[b][lens[b]:] == 0x5A)   # the caller's memory is only read
+    # reconstruct, a different erasure pattern per block (one launch per pattern), rebuilt shards into pinned memory
+    n = k + m
+    for b in range(nb):
+        blocks[b][:] = padded[b]
+    rec = [host_alloc(m * S) for _ in range(nb)]
+    sp = (ctypes.c_void_p * (nb * n))()
+    op = (ctypes.c_void_p * (nb * n))()
+    lost_of = []
+    for b in range(nb):
+        nl = 1 + b % m
+        lost = sorted(int(x) for x in rng.choice(n, size=nl, replace=False))
+        lost_of.append(lost)
+        for j in range(n):
+            if j in lost:
+                sp[b * n + j] = None
+                op[b * n + j] = rec[b].ctypes.data + lost.index(j) * S
+            else:
+                sp[b * n + j] = blocks[b].ctypes.data + j * S if j < k else outs[b].ctypes.data + (j - k) * S
+    _lib.check(lib.gec_reconstruct_batch(rs._h, nb, sp, op, S, 0), "zero-copy reconstruct")
+    for b in range(nb):
+        for i, j in enumerate(lost_of[b]):
+            ref = padded[b, j * S:(j + 1) * S] if j < k else want[b, j - k]
+            assert np.array_equal(rec[b][i * S:(i + 1) * S], ref), (b, j)
+    for a in blocks + outs + rec:
+        host_free(a)
+
+
 # ------------------------------------------------ the read path in one trip (gec_decode_verify_batch)
 @pytest.mark.parametrize("pin", [False, True], ids=["pageable", "pinned"])
 def test_decode_verify_batch_one_trip(coracle, rs104, pin):
