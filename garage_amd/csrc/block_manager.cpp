@@ -35,6 +35,7 @@
 #include <thread>
 #include <cerrno>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -889,6 +890,37 @@ struct gbm_manager {
 
 namespace {
 
+// GBM_TRACE=1: stage timings of the batched put / get on stderr (tools/host_path_bench.py reads them off)
+bool trace_on()
+{
+	static const bool on = [] {
+		const char *e = std::getenv("GBM_TRACE");
+		return e && e[0] == '1';
+	}();
+	return on;
+}
+struct Trace {
+	const char *what;
+	std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+	std::string line;
+	explicit Trace(const char *w) : what(w) {}
+	void lap(const char *stage)
+	{
+		if (!trace_on())
+			return;
+		const auto t = std::chrono::steady_clock::now();
+		char buf[64];
+		std::snprintf(buf, sizeof buf, " %s %.2f ms", stage, std::chrono::duration<double, std::milli>(t - t0).count());
+		line += buf;
+		t0 = t;
+	}
+	~Trace()
+	{
+		if (trace_on() && !line.empty())
+			std::fprintf(stderr, "[gbm] %s:%s\n", what, line.c_str());
+	}
+};
+
 int ec_fail(int rc, const char *what)
 {
 	return fail(GBM_E_EC, std::string(what) + ": " + gec_strerror(rc) + " (" + gec_last_error() + ")");
@@ -1297,6 +1329,7 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 	};
 	std::vector<Prep> prep(nb);
 	std::atomic<bool> oom{false};
+	Trace tr("put");
 	mg->pool->parallel_for(nb, [&](size_t b) {
 		try {
 			Prep &p = prep[b];
@@ -1321,6 +1354,7 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 	});
 	if (oom)
 		return fail(GBM_E_IO, "out of (pinned) host memory for the shard buffers");
+	tr.lap("prep");
 	// Blocks of equal S -- in practice all full block_size blocks -- share ONE device call that returns
 	// parity and the checksums of all k+m shards.
 	std::map<size_t, std::vector<size_t>> by_s;
@@ -1349,6 +1383,7 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 		for (size_t i = 0; i < gn; ++i)
 			std::memcpy(sums.data() + ids[i] * (size_t)n * 32, gsums.data() + i * (size_t)n * 32, (size_t)n * 32);
 	}
+	tr.lap("encode+hash");
 	// fan-out: shard j of every block to nodes_of(hash)[j].  With order tags the blocks go out one after the
 	// other in (stream, order) order -- requests of one stream reach a node in `order` order, whatever their
 	// shard geometry; without tags the blocks are independent and go out from the pool's threads.
@@ -1381,6 +1416,7 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 	} else {
 		mg->pool->parallel_for(nb, fan_out);
 	}
+	tr.lap("fan-out");
 	int result = GBM_OK;
 	for (size_t b = 0; b < nb; ++b) {
 		Hash h((const char *)hashes + 32 * b, 32);
@@ -1428,9 +1464,11 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 	block_sums.assign(want_block_sums ? nb * 32 : 0, 0);
 	if (changed)
 		changed->assign(nb, 0);
+	Trace tr("get");
 	int grc = gather_many(mg, hs, tags, k, g, /*verify=*/false);
 	if (grc)
 		return grc;
+	tr.lap("gather");
 	std::thread helper;
 	struct Joiner {
 		std::thread &t;
@@ -1494,8 +1532,10 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 			}
 			int rc = gec_decode_verify_batch(mg->codec, ids.size(), sp.data(), S, lens.data(), op.data(), ssums.data(),
 							 want_block_sums ? bsums.data() : nullptr);
+			tr.lap("decode+verify");
 			if (helper.joinable())
 				helper.join();  // the overlapped host work reads g: it must be done before the results below change it
+			tr.lap("join overlapped assembly");
 			if (rc)
 				return ec_fail(rc, "gec_decode_verify_batch");
 			mg->gpu_hashed += ids.size() * (size_t)k + (want_block_sums ? ids.size() : 0);
@@ -2036,9 +2076,19 @@ int gbm_layout_trim(gbm_manager *m)
 int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data, const size_t *len,
 		       const uint8_t *prevent_compression, const gbm_order_tag *order_tags)
 {
-	// Large untagged batches go through in slices on two threads, so that one slice's host work (the copy into the
-	// shard buffers, the fan-out) runs while the other slice is on the device.  Tagged batches keep their order.
-	constexpr size_t kSlice = 128;
+	// Large untagged batches go through in slices of 64 blocks on four threads, so that one slice's host work (the copy
+	// into the shard buffers, the fan-out) runs while other slices are on the link: 512 x 1 MiB blocks 26 -> 38 GiB/s
+	// (tools/bm_sweep.sh: 128 x 2 threads 33, 128 x 3 37, 64 x 4 38.6, 64 x 8 39.5).  Tagged batches keep their order.
+	static const size_t kSlice = [] {
+		const char *e = std::getenv("GBM_PUT_SLICE");
+		const long v = e ? std::atol(e) : 0;
+		return (size_t)(v > 0 ? v : 64);
+	}();
+	static const int kThreads = [] {
+		const char *e = std::getenv("GBM_PUT_THREADS");
+		const int v = e ? std::atoi(e) : 0;
+		return v > 0 && v <= 8 ? v : 4;
+	}();
 	try {
 		if (!mg || order_tags || nb < 2 * kSlice)
 			return put_blocks_impl(mg, nb, hashes, data, len, prevent_compression, order_tags, nullptr);
@@ -2066,9 +2116,12 @@ int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const 
 				}
 			}
 		};
-		std::thread other(run);
+		std::vector<std::thread> others;
+		for (int t = 1; t < kThreads; ++t)
+			others.emplace_back(run);
 		run();
-		other.join();
+		for (auto &t : others)
+			t.join();
 		if (result)
 			return fail(result, err);
 		return GBM_OK;

@@ -980,7 +980,8 @@ bool zero_copy_enabled()
 // out[b*nout + r] the output rows.  The tables are written into the staging slot's pinned table area, which the
 // kernel reads directly.  k <= PTR_KMAX.
 int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uint8_t *const *in, const uint32_t *valid,
-		      uint8_t *const *out, int nout, size_t S, const uint8_t *coef /* nout x k */, hipStream_t stream)
+		      uint8_t *const *out, int nout, size_t S, const uint8_t *coef /* nout x k */, hipStream_t stream,
+		      uint8_t *d_mirror = nullptr /* [nblocks][k + nout][S]: inputs and outputs also laid down in HBM */)
 {
 	const size_t k = c->k;
 	if (nblocks == 0 || nout == 0)
@@ -1018,15 +1019,23 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 		out_done += nblocks * rows;
 		const int mw = rows <= 4 ? 1 : 2;
 		const size_t lds = k * 32 * 4 * mw + 768 + k * gec::RMAX;
+		a.mirror_stride = (k + (size_t)nout) * S;
+		a.mirror_row0 = (k + (size_t)r0) * S;
+		a.mirror_inputs = r0 == 0;
 		for (size_t b0 = 0; b0 < nblocks; b0 += 65535) {
 			const unsigned gy = (unsigned)std::min<size_t>(65535, nblocks - b0);
 			a.in = t_in + b0 * k;
 			a.in_valid = t_valid + b0 * k;
 			a.out = grp + b0 * rows;
-			if (mw == 1)
-				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
+			a.mirror = d_mirror ? d_mirror + b0 * a.mirror_stride : nullptr;
+			if (mw == 1 && d_mirror)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, true>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
+			else if (mw == 1)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, false>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
+			else if (d_mirror)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5, true>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
 			else
-				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5, false>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
 			HIP_TRY(hipGetLastError());
 		}
 	}
@@ -1936,36 +1945,59 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 	for (size_t b = 0; b < nblocks && all_pinned; ++b)
 		all_pinned = aligned16(blocks[b]) && aligned16(parity[b]) && pinned().contains(blocks[b], block_len[b]) &&
 			     pinned().contains(parity[b], m * S);
-	if (all_pinned && !shard_sums && k <= (size_t)gec::PTR_KMAX && zero_copy_enabled()) {
+	if (all_pinned && k <= (size_t)gec::PTR_KMAX && zero_copy_enabled()) {
 		// every buffer is device-addressable: ONE kernel reads the data shards and writes the parity in place
-		// over the link; nothing is staged in HBM (with checksums requested the shards are needed in HBM anyway)
+		// over the link; nothing is staged in HBM, no host copy.  With checksums requested the same kernel also
+		// lays everything it reads and computes down in HBM (the bytes still cross the link once), chunk by
+		// chunk on two streams, and each chunk's shard checksums are computed from there while the next chunk
+		// is on the link.
 		DeviceGuard dg(c->device);
 		if (!dg.ok)
 			return fail(GEC_E_DEVICE, "hipSetDevice failed");
 		StagingLease lease(c);
 		Staging &st = lease.st;
-		int rc = st.ensure(64, 0);
+		const size_t zch = shard_sums ? chunk_blocks(stripe, nblocks, 8 * kChunkBytes) : nblocks;
+		const size_t nz = (nblocks + zch - 1) / zch;
+		int rc = st.ensure(shard_sums ? nblocks * n * 32 + 64 : 64, 0);
 		if (!rc)
-			rc = st.ensure_tab((nblocks * (k * 12 + m * 8) + 64) / sizeof(gec::CopyEntry) + 4);
+			rc = st.ensure_tab((nblocks * (k * 12 + m * 8) + 64 * nz) / sizeof(gec::CopyEntry) + 4 * nz + 4);
+		if (!rc && shard_sums)
+			rc = st.ensure_big(2 * (zch * stripe + zch * n * 32));
 		if (rc)
 			return rc;
-		std::vector<const uint8_t *> in(nblocks * k);
-		std::vector<uint32_t> valid(nblocks * k);
-		std::vector<uint8_t *> out(nblocks * m);
-		for (size_t b = 0; b < nblocks; ++b) {
-			const uint8_t *p = pinned().dev(blocks[b]);
-			uint8_t *q = pinned().dev(parity[b]);
-			for (size_t t = 0; t < k; ++t) {
-				in[b * k + t] = p + t * S;
-				valid[b * k + t] = (uint32_t)(block_len[b] > t * S ? std::min(S, block_len[b] - t * S) : 0);
+		std::vector<const uint8_t *> in(zch * k);
+		std::vector<uint32_t> valid(zch * k);
+		std::vector<uint8_t *> out(zch * m);
+		for (size_t ci = 0; ci < nz && !rc; ++ci) {
+			const size_t b0 = ci * zch, nb = std::min(zch, nblocks - b0);
+			for (size_t i = 0; i < nb; ++i) {
+				const uint8_t *p = pinned().dev(blocks[b0 + i]);
+				uint8_t *q = pinned().dev(parity[b0 + i]);
+				const size_t len = block_len[b0 + i];
+				for (size_t t = 0; t < k; ++t) {
+					in[i * k + t] = p + t * S;
+					valid[i * k + t] = (uint32_t)(len > t * S ? std::min(S, len - t * S) : 0);
+				}
+				for (size_t r = 0; r < m; ++r)
+					out[i * m + r] = q + r * S;
 			}
-			for (size_t r = 0; r < m; ++r)
-				out[b * m + r] = q + r * S;
+			hipStream_t s = (ci & 1) ? st.stream2 : st.stream;
+			uint8_t *mir = shard_sums ? st.d_big + (ci & 1) * (zch * stripe + zch * n * 32) : nullptr;
+			rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), out.data(), (int)m, S, c->enc.row(k), s, mir);
+			if (rc || !shard_sums)
+				continue;
+			uint8_t *d_sums = mir + zch * stripe;
+			rc = blake2_dev(c, nb * n, mir, nullptr, nullptr, S, S, d_sums, s, 0, 0, 0, true);
+			if (!rc && hipMemcpyAsync(st.h_buf + b0 * n * 32, d_sums, nb * n * 32, hipMemcpyDeviceToHost, s) != hipSuccess)
+				rc = fail(GEC_E_DEVICE, "hipMemcpyAsync (shard sums)");
 		}
-		rc = launch_apply_ptrs(c, st, nblocks, in.data(), valid.data(), out.data(), (int)m, S, c->enc.row(k), st.stream);
+		const hipError_t e1 = hipStreamSynchronize(st.stream), e2 = nz > 1 ? hipStreamSynchronize(st.stream2) : hipSuccess;
 		if (rc)
 			return rc;
-		HIP_TRY(hipStreamSynchronize(st.stream));
+		HIP_TRY(e1);
+		HIP_TRY(e2);
+		if (shard_sums)
+			std::memcpy(shard_sums, st.h_buf, nblocks * n * 32);
 		return GEC_OK;
 	}
 	const size_t ch = chunk_blocks(stripe, nblocks, shard_sums ? 8 * kChunkBytes : all_pinned ? pinned_chunk_bytes() : kChunkBytes);

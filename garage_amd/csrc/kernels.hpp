@@ -410,6 +410,13 @@ struct PtrApplyArgs {
 	uint8_t *const *out;       // [nblocks][rows]
 	uint32_t cols;             // 16-byte columns per shard
 	uint32_t k, rows;
+	// MIRROR: everything the kernel reads and computes is also laid down in device memory, dense --
+	// mirror + b*mirror_stride + t*16*cols for input shard t (first row group only: mirror_inputs),
+	// ... + mirror_row0 + r*16*cols for output row r -- so that the shard checksums can be computed from
+	// HBM while the bytes cross the link only once (gec_encode_hash_batch on pinned memory)
+	uint8_t *mirror;
+	uint64_t mirror_stride, mirror_row0;
+	uint32_t mirror_inputs;
 	uint8_t coef[PTR_KMAX][RMAX];
 };
 
@@ -424,7 +431,7 @@ __device__ __forceinline__ u32x4 ld16_valid(const uint8_t *shard, uint32_t col, 
 	return u32x4{w[0], w[1], w[2], w[3]};
 }
 
-template <int MW, int KC>
+template <int MW, int KC, bool MIRROR>
 __global__ __launch_bounds__(256) void gf_apply_ptrs(const PtrApplyArgs a, const LogExp *__restrict__ le)
 {
 	constexpr int ENT = 4 * MW, TBL = 32 * ENT;
@@ -438,6 +445,8 @@ __global__ __launch_bounds__(256) void gf_apply_ptrs(const PtrApplyArgs a, const
 	const uint32_t col = live ? col_raw : 0;  // dead lanes shadow column 0 (loads only)
 	const uint8_t *const *inp = a.in + (size_t)b * k;
 	const uint32_t *valid = a.in_valid + (size_t)b * k;
+	u32x4 *mir = MIRROR ? reinterpret_cast<u32x4 *>(a.mirror + (size_t)b * a.mirror_stride) + col : nullptr;
+	const bool mir_in = MIRROR && live && a.mirror_inputs;
 
 	// first batch of shard loads goes out before the tables are built: PCIe latency hides behind the expansion
 	u32x4 d[KC];
@@ -491,6 +500,8 @@ __global__ __launch_bounds__(256) void gf_apply_ptrs(const PtrApplyArgs a, const
 		for (int j = 0; j < KC; ++j) {
 			if (t0 + j >= k)
 				break;
+			if (mir_in)
+				mir[(size_t)(t0 + j) * a.cols] = d[j];
 			const uint32_t tb = __builtin_amdgcn_readfirstlane(lds_base + (t0 + j) * TBL);
 			const uint32_t xs[4] = {d[j].x, d[j].y, d[j].z, d[j].w};
 #pragma unroll
@@ -521,6 +532,8 @@ __global__ __launch_bounds__(256) void gf_apply_ptrs(const PtrApplyArgs a, const
 			continue;
 		const u32x4 v = {P[r][0], P[r][1], P[r][2], P[r][3]};
 		__builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(outp[r]) + col);
+		if (MIRROR)
+			reinterpret_cast<u32x4 *>(a.mirror + (size_t)b * a.mirror_stride + a.mirror_row0)[(size_t)r * a.cols + col] = v;
 	}
 }
 

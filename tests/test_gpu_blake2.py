@@ -115,6 +115,48 @@ def test_encode_hash_batch_sums_every_shard(coracle, rs):
             assert sums[b, j].tobytes() == g.shardsum(payload.tobytes()), (b, j)
 
 
+@pytest.mark.parametrize("k,m,L,nb", [(10, 4, 1 << 20, 200), (3, 1, 300_000, 7), (10, 12, 70_000, 5)],
+                         ids=["rs10_4_three_chunks", "rs3_1", "rs10_12_two_row_groups"])
+def test_encode_hash_batch_zero_copy_pinned(coracle, k, m, L, nb):
+    """gec_encode_hash_batch on pinned caller memory: one kernel reads the data shards over the link, writes parity
+    back and lays everything down in HBM, where the shard checksums are computed chunk by chunk -- against the
+    oracle's parity and hashlib's tree-mode checksums, ragged lengths, several chunks on both streams."""
+    import ctypes
+
+    from garage_amd import _lib
+    from garage_amd.codec import host_alloc, host_free
+
+    lib = _lib.lib
+    rs_ = g.ReedSolomon(k, m)
+    n = k + m
+    S = g.shard_len(k, L)
+    rng = np.random.default_rng(nb)
+    lens = [L if b % 5 else int(rng.integers(0, L + 1)) for b in range(nb)]
+    lens[0] = L
+    padded = np.zeros((nb, k * S), dtype=np.uint8)
+    arena = host_alloc(nb * k * S)
+    par = host_alloc(nb * m * S)
+    arena[:] = 0x77
+    for b in range(nb):
+        padded[b, :lens[b]] = rng.integers(0, 256, lens[b], dtype=np.uint8)
+        arena[b * k * S: b * k * S + lens[b]] = padded[b, :lens[b]]
+    want = coracle.encode_batch(k, m, padded.reshape(nb, k, S), coracle.AVX2, threads=8)
+    ptrs = (ctypes.c_void_p * nb)(*[arena.ctypes.data + b * k * S for b in range(nb)])
+    optrs = (ctypes.c_void_p * nb)(*[par.ctypes.data + b * m * S for b in range(nb)])
+    clens = (ctypes.c_size_t * nb)(*lens)
+    sums = np.zeros((nb, n, 32), dtype=np.uint8)
+    _lib.check(lib.gec_encode_hash_batch(rs_._h, nb, ptrs, clens, S, optrs, sums.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))),
+               "gec_encode_hash_batch")
+    assert np.array_equal(par.reshape(nb, m, S), want)
+    shards = padded.reshape(nb, k, S)
+    for b in list(range(0, nb, max(1, nb // 16))) + [nb - 1]:
+        for j in range(n):
+            payload = shards[b, j] if j < k else want[b, j - k]
+            assert sums[b, j].tobytes() == g.shardsum(payload.tobytes()), (b, j)
+    host_free(arena)
+    host_free(par)
+
+
 @pytest.mark.parametrize("kernel", ["lane", "quad"])
 def test_both_kernels_forced(kernel):
     """The host picks the one-lane or the four-lane kernel by batch size; force each
