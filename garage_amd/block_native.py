@@ -186,7 +186,7 @@ class NativeBlockManager:
             _check(lib.gbm_set_data_fsync(self._h, 1), "gbm_set_data_fsync")
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:   # (lib is None while the interpreter shuts down)
             lib.gbm_destroy(self._h)
             self._h = None
 

@@ -28,6 +28,14 @@ struct Blake2Args {
 	uint32_t group;        // messages per group (e.g. the m parity shards of one stripe); 0 = flat
 	uint64_t group_stride;
 	uint32_t out_group;
+	// Segmented hashing (blake2b_batch_quad only): this launch compresses blocks [seg_begin_blk, seg_end_blk) of
+	// every message, picking the chaining value up from `state` (8 words per message) when it does not start at
+	// block 0 and leaving it there when the message goes on beyond seg_end_blk; a message whose last block falls
+	// inside the range is finished (digest written) by this launch, messages that ended earlier are skipped.
+	// The whole-message form is seg_begin_blk = 0, seg_end_blk = ~0.  This is how a block's checksum chain --
+	// serial, ~14 ms per MiB whatever runs beside it -- starts while the rest of the block is still on the link.
+	uint64_t *state = nullptr;
+	uint64_t seg_begin_blk = 0, seg_end_blk = ~0ull;
 };
 
 __device__ __forceinline__ const uint8_t *b2_msg_ptr(const Blake2Args &a, uint32_t i)
@@ -377,15 +385,20 @@ __global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
 		       : q == 2 ? 0x1f83d9abfb41bd6bULL : 0x5be0cd19137e2179ULL);
 	typedef __attribute__((address_space(3))) u64x2 lds_u64x2_w;
 	const uint64_t nblk = len ? (len + 127) / 128 : 1;  // the empty message still has one (all-zero, final) block
+	const uint64_t b0 = a.seg_begin_blk, b1 = nblk < a.seg_end_blk ? nblk : a.seg_end_blk;
+	if (b0 > 0 && b0 < b1) {  // resume
+		ha = a.state[8ull * ii + q];
+		hb = a.state[8ull * ii + 4 + q];
+	}
 	u64x2 w0, w1;
-	b2q_fetch(p, 0, len, q, w0, w1);
+	b2q_fetch(p, b0 * 128, len, q, w0, w1);
 	{
 		lds_u64x2_w *s = reinterpret_cast<lds_u64x2_w *>(slot0 + 32 * q);
 		s[0] = w0;
 		s[1] = w1;
 	}
-	if (nblk > 1)
-		b2q_fetch(p, 128, len, q, w0, w1);
+	if (b0 + 1 < b1)
+		b2q_fetch(p, (b0 + 1) * 128, len, q, w0, w1);
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -393,13 +406,13 @@ __global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
 	uint64_t x = *reinterpret_cast<lds_u64_t *>(slot0 + __builtin_amdgcn_ubfe(SCH.w[0][0], q7, 7));
 	uint64_t y = *reinterpret_cast<lds_u64_t *>(slot0 + __builtin_amdgcn_ubfe(SCH.w[0][1], q7, 7));
 	uint32_t cur = slot0, nxt = slot0 + slot_xor;
-	for (uint64_t blk = 0; blk < nblk; ++blk) {
-		if (blk + 1 < nblk) {  // block blk+1 has arrived (requested one iteration ago): stage it
+	for (uint64_t blk = b0; blk < b1; ++blk) {
+		if (blk + 1 < b1) {  // block blk+1 has arrived (requested one iteration ago): stage it
 			lds_u64x2_w *s = reinterpret_cast<lds_u64x2_w *>(nxt + 32 * q);
 			s[0] = w0;
 			s[1] = w1;
 		}
-		if (blk + 2 < nblk)    // block blk+2: on its way from HBM while block blk is compressed
+		if (blk + 2 < b1)    // block blk+2: on its way from HBM while block blk is compressed
 			b2q_fetch(p, (blk + 2) * 128, len, q, w0, w1);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
@@ -411,8 +424,14 @@ __global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
 		cur = nxt;
 		nxt = tmp;
 	}
-	if (live)
+	if (!live || b0 >= b1)
+		return;
+	if (b1 == nblk) {
 		reinterpret_cast<uint64_t *>(b2_out_ptr(a, i))[q] = ha;  // h[0..3] = first 32 bytes
+	} else {
+		a.state[8ull * i + q] = ha;
+		a.state[8ull * i + 4 + q] = hb;
+	}
 }
 
 // ---------------------------------------------------------------------------

@@ -269,6 +269,37 @@ struct Staging {
 	// whole-batch device buffer of the read path (gec_decode_verify_batch): grow-only
 	uint8_t *d_big = nullptr;
 	size_t big_cap = 0;
+	// the read path's upload stages: "stage s is on the device" events, and a third stream so that the shard
+	// checksums do not queue behind the block checksums' serial chains
+	static constexpr int kMaxSeg = 16;
+	hipStream_t stream3 = nullptr;
+	hipEvent_t ev_seg[kMaxSeg] = {};
+	// CU-masked pair for the staged upload: the copy kernels' host reads sit in the memory pipeline of the CUs they
+	// run on for microseconds each, and a checksum chain sharing such a CU crawls (7x slower, measured); so the
+	// upload gets a few CUs of its own (the link needs very little in flight) and the chains the rest.
+	hipStream_t stream_up = nullptr, stream_chain = nullptr;
+
+	int ensure_segments(int num_cu)
+	{
+		if (stream3)
+			return GEC_OK;
+		for (int i = 0; i < kMaxSeg; ++i)
+			HIP_TRY(hipEventCreateWithFlags(&ev_seg[i], hipEventDisableTiming));
+		static const int up_cus = [] {
+			const char *e = std::getenv("GEC_UPLOAD_CUS");  // 0 = no CU masks (A/B)
+			return e ? std::atoi(e) : 16;
+		}();
+		if (up_cus > 0 && up_cus < num_cu) {
+			const int words = (num_cu + 31) / 32;
+			std::vector<uint32_t> up(words, 0), rest(words, 0);
+			for (int i = 0; i < num_cu; ++i)
+				(i < up_cus ? up : rest)[i / 32] |= 1u << (i % 32);
+			HIP_TRY(hipExtStreamCreateWithCUMask(&stream_up, (uint32_t)words, up.data()));
+			HIP_TRY(hipExtStreamCreateWithCUMask(&stream_chain, (uint32_t)words, rest.data()));
+		}
+		HIP_TRY(hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking));
+		return GEC_OK;
+	}
 
 	int ensure_big(size_t bytes)
 	{
@@ -358,6 +389,15 @@ struct Staging {
 			(void)hipEventDestroy(ev_in);
 		if (ev_out)
 			(void)hipEventDestroy(ev_out);
+		for (hipEvent_t e : ev_seg)
+			if (e)
+				(void)hipEventDestroy(e);
+		if (stream3)
+			(void)hipStreamDestroy(stream3);
+		if (stream_up)
+			(void)hipStreamDestroy(stream_up);
+		if (stream_chain)
+			(void)hipStreamDestroy(stream_chain);
 		*this = Staging();
 	}
 };
@@ -884,13 +924,17 @@ int leaf_scratch(const gec_codec *c, hipStream_t stream, size_t bytes, uint8_t *
 // max_len = the longest message (sizes the leaf grid).
 int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64_t *d_off, const uint64_t *d_len, size_t stride,
 	       size_t len, uint8_t *d_out, hipStream_t stream, uint32_t group = 0, size_t group_stride = 0,
-	       uint32_t out_group = 0, bool tree = false, size_t max_len = 0)
+	       uint32_t out_group = 0, bool tree = false, size_t max_len = 0, uint64_t *d_state = nullptr,
+	       uint64_t seg_begin_blk = 0, uint64_t seg_end_blk = ~0ull)
 {
 	if (n == 0)
 		return GEC_OK;
 	if (n > 0xffffffffull)
 		return fail(GEC_E_INVALID_ARG, "too many messages for one call");
 	gec::Blake2Args a;
+	a.state = d_state;
+	a.seg_begin_blk = seg_begin_blk;
+	a.seg_end_blk = seg_end_blk;
 	a.base = d_base;
 	a.off = d_off;
 	a.len = d_len;
@@ -929,7 +973,7 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 		const char *e = getenv("GEC_BLAKE2_KERNEL");
 		return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'q' ? 2 : 0));
 	}();
-	const bool quad = forced ? forced == 2 : n < 40000;
+	const bool quad = d_state ? true : forced ? forced == 2 : n < 40000;  // segments: the quad kernel only
 	if (quad)
 		hipLaunchKernelGGL(gec::blake2b_batch_quad, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, stream, a);
 	else
@@ -1963,8 +2007,15 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 			rc = st.ensure_tab((nblocks * (k * 12 + m * 8) + 64 * nz) / sizeof(gec::CopyEntry) + 4 * nz + 4);
 		if (!rc && shard_sums)
 			rc = st.ensure_big(2 * (zch * stripe + zch * n * 32));
+		if (!rc && shard_sums)
+			rc = st.ensure_segments(c->num_cu);
 		if (rc)
 			return rc;
+		// with checksums: the link kernel on a few CUs of its own, the checksum kernels on the rest (a kernel whose
+		// loads share a CU with microsecond-long host reads crawls, see Staging::stream_up); chunk ci+2 reuses the
+		// mirror of chunk ci, so its link kernel waits for that chunk's checksums
+		hipStream_t up = shard_sums && st.stream_up ? st.stream_up : st.stream;
+		hipStream_t chain = shard_sums && st.stream_chain ? st.stream_chain : st.stream2;
 		std::vector<const uint8_t *> in(zch * k);
 		std::vector<uint32_t> valid(zch * k);
 		std::vector<uint8_t *> out(zch * m);
@@ -1981,17 +2032,28 @@ static int encode_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *
 				for (size_t r = 0; r < m; ++r)
 					out[i * m + r] = q + r * S;
 			}
-			hipStream_t s = (ci & 1) ? st.stream2 : st.stream;
 			uint8_t *mir = shard_sums ? st.d_big + (ci & 1) * (zch * stripe + zch * n * 32) : nullptr;
-			rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), out.data(), (int)m, S, c->enc.row(k), s, mir);
+			if (shard_sums && ci >= 2 && hipStreamWaitEvent(up, st.ev_seg[2 + (ci & 1)], 0) != hipSuccess)
+				rc = fail(GEC_E_DEVICE, "hipStreamWaitEvent");
+			if (!rc)
+				rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), out.data(), (int)m, S, c->enc.row(k), up, mir);
 			if (rc || !shard_sums)
 				continue;
 			uint8_t *d_sums = mir + zch * stripe;
-			rc = blake2_dev(c, nb * n, mir, nullptr, nullptr, S, S, d_sums, s, 0, 0, 0, true);
-			if (!rc && hipMemcpyAsync(st.h_buf + b0 * n * 32, d_sums, nb * n * 32, hipMemcpyDeviceToHost, s) != hipSuccess)
+			hipError_t e = hipEventRecord(st.ev_seg[ci & 1], up);
+			if (e == hipSuccess)
+				e = hipStreamWaitEvent(chain, st.ev_seg[ci & 1], 0);
+			if (e != hipSuccess) {
+				rc = fail(GEC_E_DEVICE, "chunk event");
+				continue;
+			}
+			rc = blake2_dev(c, nb * n, mir, nullptr, nullptr, S, S, d_sums, chain, 0, 0, 0, true);
+			if (!rc && hipMemcpyAsync(st.h_buf + b0 * n * 32, d_sums, nb * n * 32, hipMemcpyDeviceToHost, chain) != hipSuccess)
 				rc = fail(GEC_E_DEVICE, "hipMemcpyAsync (shard sums)");
+			if (!rc && hipEventRecord(st.ev_seg[2 + (ci & 1)], chain) != hipSuccess)
+				rc = fail(GEC_E_DEVICE, "hipEventRecord");
 		}
-		const hipError_t e1 = hipStreamSynchronize(st.stream), e2 = nz > 1 ? hipStreamSynchronize(st.stream2) : hipSuccess;
+		const hipError_t e1 = hipStreamSynchronize(up), e2 = shard_sums ? hipStreamSynchronize(chain) : hipSuccess;
 		if (rc)
 			return rc;
 		HIP_TRY(e1);
@@ -2428,19 +2490,52 @@ int gec_decode_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *c
 	int rc = st.ensure(reb_off + nreb * S + 64, 0);
 	if (rc)
 		return rc;
-	rc = st.ensure_big(std::max<size_t>(dev_bytes, 64));
+	const size_t state_off = (dev_bytes + 63) / 64 * 64;  // chaining values of the segmented block checksums
+	rc = st.ensure_big(state_off + nblocks * 64 + 64);
 	if (rc)
 		return rc;
 	rc = st.ensure_tab(nup + nreb);
 	if (rc)
 		return rc;
+	rc = st.ensure_segments(c->num_cu);
+	if (rc)
+		return rc;
 	uint64_t *h_soff = reinterpret_cast<uint64_t *>(st.h_buf + tab_off), *h_slen = h_soff + nup;
 	uint64_t *h_boff = h_slen + nup, *h_blen = h_boff + nblocks;
+	// -- block table: the blocks that need no decode first -- their checksum chains start while the upload is
+	//    still running (below); the others are hashed after their decode
+	size_t bi = 0, nh = 0, longest = 0;
+	std::vector<size_t> block_order(nblocks);
+	for (int pass = 0; pass < 2; ++pass) {
+		for (auto &kv : buckets) {
+			if ((kv.second.npar == 0) != (pass == 0))
+				continue;
+			for (size_t i = 0; i < kv.second.ids.size(); ++i) {
+				h_boff[bi] = kv.second.base + i * kv.second.stripe;
+				h_blen[bi] = block_len ? block_len[kv.second.ids[i]] : 0;
+				longest = std::max<size_t>(longest, h_blen[bi]);
+				block_order[bi++] = kv.second.ids[i];
+			}
+		}
+		if (pass == 0)
+			nh = bi;
+	}
+	// Upload stages: stage s carries data slots [k*s/nseg, k*(s+1)/nseg) of the blocks that need no decode (stage 0
+	// also everything of the blocks that do).  One stage unless every shard is pinned (the staged path uploads
+	// dense device ranges block by block) and the chains are long enough to be worth hiding: a BLAKE2b chain runs
+	// at ~14 ms per MiB, the link moves the MiB of 512 such blocks in 10 ms.
+	static const int seg_max = [] {
+		const char *e = std::getenv("GEC_VERIFY_SEGMENTS");  // A/B: 1 = upload everything, then hash
+		const int v = e ? std::atoi(e) : Staging::kMaxSeg;
+		return std::max(1, std::min(v, (int)Staging::kMaxSeg));
+	}();
+	const size_t nseg = (all_pinned && block_sums && nh > 0 && longest >= (256u << 10)) ? std::min<size_t>(k, (size_t)seg_max) : 1;
 	// -- upload list, in device order
 	struct Up {
 		const uint8_t *src;
 		size_t dst;  // byte offset in d_big
 		size_t idx;  // (b*n + j): where the shard's checksum goes
+		size_t stage;
 	};
 	std::vector<Up> ups;
 	ups.reserve(nup);
@@ -2453,7 +2548,12 @@ int gec_decode_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *c
 				const int j = bk.plan->valid[t];
 				const size_t slot = (size_t)j < k ? (size_t)j : k + q++;
 				const uint8_t *p = shards[b * n + j];
-				ups.push_back({p, bk.base + i * bk.stripe + slot * S, b * n + j});
+				// stage of data slot j: the s with k*s/nseg <= j < k*(s+1)/nseg
+				size_t stage = 0;
+				if (bk.npar == 0 && nseg > 1)
+					while (k * (stage + 1) / nseg <= slot)
+						++stage;
+				ups.push_back({p, bk.base + i * bk.stripe + slot * S, b * n + j, stage});
 			}
 		}
 	}
@@ -2462,28 +2562,55 @@ int gec_decode_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *c
 		h_soff[i] = ups[i].dst;
 		h_slen[i] = S;
 	}
-	size_t bi = 0;
-	std::vector<size_t> block_order(nblocks);
-	for (auto &kv : buckets)
-		for (size_t i = 0; i < kv.second.ids.size(); ++i) {
-			h_boff[bi] = kv.second.base + i * kv.second.stripe;
-			h_blen[bi] = block_len ? block_len[kv.second.ids[i]] : 0;
-			block_order[bi++] = kv.second.ids[i];
-		}
 	auto hip_fail = [&](hipError_t e, const char *what) { return fail(GEC_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); };
+	hipEvent_t ev_up = nullptr, ev_sh = nullptr;
+	HIP_TRY(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
+	HIP_TRY(hipEventCreateWithFlags(&ev_sh, hipEventDisableTiming));
+	// staged upload: its own (CU-masked) stream pair when there is one
+	hipStream_t up_stream = nseg > 1 && st.stream_up ? st.stream_up : st.stream;
+	hipStream_t chain_stream = nseg > 1 && st.stream_chain ? st.stream_chain : st.stream2;
+	auto finish = [&](int code) {
+		(void)hipStreamSynchronize(up_stream);
+		(void)hipStreamSynchronize(chain_stream);
+		(void)hipStreamSynchronize(st.stream);
+		(void)hipStreamSynchronize(st.stream2);
+		(void)hipStreamSynchronize(st.stream3);
+		(void)hipEventDestroy(ev_up);
+		(void)hipEventDestroy(ev_sh);
+		return code;
+	};
+	bool healthy_hashed = false;
 	if (all_pinned) {
-		std::vector<gec::CopyEntry> ents;
-		ents.reserve(ups.size());
+		std::vector<std::vector<gec::CopyEntry>> ents(nseg);
 		for (size_t i = 0; i < ups.size();) {  // merge neighbours (the data shards of a block are slices of one buffer)
 			size_t run = 1;
-			while (i + run < ups.size() && ups[i + run].src == ups[i].src + run * S && ups[i + run].dst == ups[i].dst + run * S)
+			while (i + run < ups.size() && ups[i + run].stage == ups[i].stage && ups[i + run].src == ups[i].src + run * S &&
+			       ups[i + run].dst == ups[i].dst + run * S)
 				++run;
-			ents.push_back({pinned().dev(ups[i].src), st.d_big + ups[i].dst, run * S});
+			ents[ups[i].stage].push_back({pinned().dev(ups[i].src), st.d_big + ups[i].dst, run * S});
 			i += run;
 		}
-		rc = launch_copy_table(st, ents, st.stream);
-		if (rc)
-			return rc;
+		for (size_t sg = 0; sg < nseg; ++sg) {
+			rc = launch_copy_table(st, ents[sg], up_stream);
+			if (rc)
+				return finish(rc);
+			if (nseg == 1)
+				break;
+			// the chains of the no-decode blocks advance over what has arrived: whole 128-byte blocks below the
+			// end of this stage's last slot (the final stage finishes every message)
+			hipError_t es = hipEventRecord(st.ev_seg[sg], up_stream);
+			if (es == hipSuccess)
+				es = hipStreamWaitEvent(chain_stream, st.ev_seg[sg], 0);
+			if (es != hipSuccess)
+				return finish(hip_fail(es, "stage event"));
+			const uint64_t blk0 = (k * sg / nseg) * S / 128;
+			const uint64_t blk1 = sg + 1 == nseg ? ~0ull : (k * (sg + 1) / nseg) * S / 128;
+			rc = blake2_dev(c, nh, st.d_big, h_boff, h_blen, 0, 0, st.h_buf + bsum_off, chain_stream, 0, 0, 0, false, 0,
+					reinterpret_cast<uint64_t *>(st.d_big + state_off), blk0, blk1);
+			if (rc)
+				return finish(rc);
+		}
+		healthy_hashed = nseg > 1;
 	} else {
 		// pageable shards: the pieces are images of dense device ranges, filled by the copy pool while the other is on the bus
 		CopyPool &pool = c->copy_pool();
@@ -2495,47 +2622,39 @@ int gec_decode_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *c
 			if (used[piece & 1]) {
 				hipError_t e = hipEventSynchronize(done[piece & 1]);
 				if (e != hipSuccess)
-					return hip_fail(e, "hipEventSynchronize");
+					return finish(hip_fail(e, "hipEventSynchronize"));
 			}
 			const size_t d0 = ups[i].dst;
 			size_t j = i;
 			while (j < ups.size() && ups[j].dst + S - d0 <= kPiece)
 				++j;
 			if (j == i)
-				return fail(GEC_E_INVALID_ARG, "shard larger than a staging piece");
+				return finish(fail(GEC_E_INVALID_ARG, "shard larger than a staging piece"));
 			const size_t bytes = ups[j - 1].dst + S - d0;
 			pool.parallel_for(j - i, [&](size_t q) { std::memcpy(hp + (ups[i + q].dst - d0), ups[i + q].src, S); });
 			hipError_t e = hipMemcpyAsync(st.d_big + d0, hp, bytes, hipMemcpyHostToDevice, st.stream);
 			if (e == hipSuccess)
 				e = hipEventRecord(done[piece & 1], st.stream);
 			if (e != hipSuccess)
-				return hip_fail(e, "H2D");
+				return finish(hip_fail(e, "H2D"));
 			used[piece & 1] = true;
 			++piece;
 			i = j;
 		}
 	}
-	// -- everything is on the device.  Shard checksums on the partner stream (they depend on nothing else); on the
-	//    main stream: decode per bucket, then the block checksums, then the rebuilt shards go home.
-	hipEvent_t ev_up = nullptr, ev_sh = nullptr;
-	HIP_TRY(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
-	HIP_TRY(hipEventCreateWithFlags(&ev_sh, hipEventDisableTiming));
-	auto finish = [&](int code) {
-		(void)hipStreamSynchronize(st.stream);
-		(void)hipStreamSynchronize(st.stream2);
-		(void)hipEventDestroy(ev_up);
-		(void)hipEventDestroy(ev_sh);
-		return code;
-	};
-	hipError_t e = hipEventRecord(ev_up, st.stream);
+	// -- everything is on the device.  Shard checksums on their own stream (they depend on nothing else); on the
+	//    main stream: decode per bucket, then the checksums of the blocks not hashed yet, then the rebuilt shards go home.
+	hipError_t e = hipEventRecord(ev_up, up_stream);
 	if (e == hipSuccess)
-		e = hipStreamWaitEvent(st.stream2, ev_up, 0);
+		e = hipStreamWaitEvent(st.stream3, ev_up, 0);
+	if (e == hipSuccess && up_stream != st.stream)
+		e = hipStreamWaitEvent(st.stream, ev_up, 0);
 	if (e != hipSuccess)
 		return finish(hip_fail(e, "fork"));
-	rc = blake2_dev(c, nup, st.d_big, h_soff, h_slen, 0, 0, st.h_buf + ssum_off, st.stream2, 0, 0, 0, true, S);
+	rc = blake2_dev(c, nup, st.d_big, h_soff, h_slen, 0, 0, st.h_buf + ssum_off, st.stream3, 0, 0, 0, true, S);
 	if (rc)
 		return finish(rc);
-	e = hipEventRecord(ev_sh, st.stream2);
+	e = hipEventRecord(ev_sh, st.stream3);
 	if (e != hipSuccess)
 		return finish(hip_fail(e, "hipEventRecord"));
 	std::vector<gec::CopyEntry> outs;
@@ -2565,13 +2684,21 @@ int gec_decode_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *c
 			}
 	}
 	if (block_sums) {
-		rc = blake2_dev(c, nblocks, st.d_big, h_boff, h_blen, 0, 0, st.h_buf + bsum_off, st.stream);
+		const size_t first = healthy_hashed ? nh : 0;  // [0, nh) went through the segments above
+		rc = blake2_dev(c, nblocks - first, st.d_big, h_boff + first, h_blen + first, 0, 0, st.h_buf + bsum_off + 32 * first, st.stream);
 		if (rc)
 			return finish(rc);
 	}
 	rc = launch_copy_table(st, outs, st.stream);
 	if (rc)
 		return finish(rc);
+	if (healthy_hashed) {
+		e = hipEventRecord(st.ev_join, chain_stream);
+		if (e == hipSuccess)
+			e = hipStreamWaitEvent(st.stream, st.ev_join, 0);
+		if (e != hipSuccess)
+			return finish(hip_fail(e, "join"));
+	}
 	e = hipStreamWaitEvent(st.stream, ev_sh, 0);
 	if (e == hipSuccess)
 		e = hipStreamSynchronize(st.stream);

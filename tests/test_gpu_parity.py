@@ -811,8 +811,9 @@ def test_zero_copy_encode_shapes(coracle, k, m):
 
 
 # ------------------------------------------------ the read path in one trip (gec_decode_verify_batch)
+@pytest.mark.parametrize("S,healthy", [(8192, False), (104896, False), (104896, True)], ids=["S8192", "S104896", "S104896_no_decode"])
 @pytest.mark.parametrize("pin", [False, True], ids=["pageable", "pinned"])
-def test_decode_verify_batch_one_trip(coracle, rs104, pin):
+def test_decode_verify_batch_one_trip(coracle, rs104, pin, S, healthy):
     """Per block: some shards in hand (different erasure patterns in one batch, more than k in hand for some),
     -> checksums of exactly the first k present shards (vs hashlib), missing data shards rebuilt (vs the oracle's
     encode of the original data), blake2sum of the block itself (vs hashlib), for ragged block lengths."""
@@ -823,8 +824,12 @@ def test_decode_verify_batch_one_trip(coracle, rs104, pin):
 
     lib = _lib.lib
     k, m, n = 10, 4, 14
-    S = 8192
+    # (with 1 MiB-class blocks in pinned memory the checksum chains of the blocks that need no decode run in
+    # segments behind the upload stages: lengths that end in the first, a middle and the last stage, on and next to
+    # 128-byte and shard boundaries)
     lens = [k * S, k * S - 1, 70_000, 1, 0, k * S, 33_333, k * S - 4096]
+    if healthy:
+        lens += [5 * S, 5 * S + 1, 5 * S - 1, 128, 127, 3 * S + 64, 9 * S, 9 * S + 129]
     nb = len(lens)
     rng = np.random.default_rng(21)
     data = np.zeros((nb, k, S), dtype=np.uint8)
@@ -834,6 +839,8 @@ def test_decode_verify_batch_one_trip(coracle, rs104, pin):
     full = np.concatenate([data, par], axis=1)
     # in hand, per block (None = all): patterns with 0..4 data shards missing, surplus parity, parity-only losses
     lost = [(), (0,), (0, 3, 7, 9), (2, 11), (9, 10, 11, 12), (1, 2, 3), (13,), (0, 1, 2, 3)]
+    if healthy:
+        lost = [(), (10,), (11, 13), (), (12,), (), (13,), (10, 11, 12, 13)] + [()] * 8
     alloc = (lambda sz: host_alloc(sz)) if pin else (lambda sz: np.empty(sz, dtype=np.uint8))
     bufs, sp, op, fresh = [], (ctypes.c_void_p * (nb * n))(), (ctypes.c_void_p * (nb * n))(), {}
     for b in range(nb):
