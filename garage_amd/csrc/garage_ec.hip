@@ -1025,7 +1025,8 @@ bool zero_copy_enabled()
 // kernel reads directly.  k <= PTR_KMAX.
 int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uint8_t *const *in, const uint32_t *valid,
 		      uint8_t *const *out, int nout, size_t S, const uint8_t *coef /* nout x k */, hipStream_t stream,
-		      uint8_t *d_mirror = nullptr /* [nblocks][k + nout][S]: inputs and outputs also laid down in HBM */)
+		      uint8_t *d_mirror = nullptr /* [nblocks][k + nout][S]: inputs and outputs also laid down in HBM */,
+		      uint32_t *bad = nullptr /* compare with what out[] holds instead of storing: bad[b] = 1 on mismatch */)
 {
 	const size_t k = c->k;
 	if (nblocks == 0 || nout == 0)
@@ -1072,7 +1073,12 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 			a.in_valid = t_valid + b0 * k;
 			a.out = grp + b0 * rows;
 			a.mirror = d_mirror ? d_mirror + b0 * a.mirror_stride : nullptr;
-			if (mw == 1 && d_mirror)
+			a.bad = bad ? bad + b0 : nullptr;
+			if (bad && mw == 1)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, false, true>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
+			else if (bad)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5, false, true>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
+			else if (mw == 1 && d_mirror)
 				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, true>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
 			else if (mw == 1)
 				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, false>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
@@ -2740,6 +2746,42 @@ int gec_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *s
 		if (!shards[i])
 			return fail(GEC_E_TOO_FEW_SHARDS, "verify needs all k+m shards");
 	const size_t stripe = n * S;
+	bool all_pinned = (size_t)c->k <= (size_t)gec::PTR_KMAX && zero_copy_enabled();
+	for (size_t i = 0; i < nblocks * n && all_pinned; ++i)
+		all_pinned = aligned16(shards[i]) && pinned().contains(shards[i], S);
+	if (all_pinned) {
+		// scrub of shards that sit in pinned memory: one kernel reads all k+m shards over the link and leaves the
+		// per-block verdicts in pinned memory; nothing is staged
+		const size_t k = c->k, m = c->m;
+		DeviceGuard dg(c->device);
+		if (!dg.ok)
+			return fail(GEC_E_DEVICE, "hipSetDevice failed");
+		StagingLease lease(c);
+		Staging &st = lease.st;
+		int rc = st.ensure(64, nblocks);
+		if (!rc)
+			rc = st.ensure_tab((nblocks * (k * 12 + m * 8) + 64) / sizeof(gec::CopyEntry) + 8);
+		if (rc)
+			return rc;
+		std::vector<const uint8_t *> in(nblocks * k);
+		std::vector<uint32_t> valid(nblocks * k, (uint32_t)S);
+		std::vector<uint8_t *> par(nblocks * m);
+		for (size_t b = 0; b < nblocks; ++b) {
+			for (size_t t = 0; t < k; ++t)
+				in[b * k + t] = pinned().dev(shards[b * n + t]);
+			for (size_t r = 0; r < m; ++r)
+				par[b * m + r] = const_cast<uint8_t *>(pinned().dev(shards[b * n + k + r]));
+		}
+		std::memset(st.h_bad, 0, nblocks * sizeof(uint32_t));
+		rc = launch_apply_ptrs(c, st, nblocks, in.data(), valid.data(), par.data(), (int)m, S, c->enc.row((int)k), st.stream, nullptr, st.h_bad);
+		const hipError_t e = hipStreamSynchronize(st.stream);
+		if (rc)
+			return rc;
+		HIP_TRY(e);
+		for (size_t b = 0; b < nblocks; ++b)
+			ok[b] = st.h_bad[b] ? 0 : 1;
+		return GEC_OK;
+	}
 	const size_t ch = chunk_blocks(stripe, nblocks, kChunkBytes);
 	CopyPool &pool = c->copy_pool();
 	return run_pipeline(

@@ -417,6 +417,9 @@ struct PtrApplyArgs {
 	uint8_t *mirror;
 	uint64_t mirror_stride, mirror_row0;
 	uint32_t mirror_inputs;
+	// COMPARE: the rows are compared with what out[b][r] holds instead of being stored; bad[b] = 1 on a mismatch
+	// (bad may itself be pinned host memory: the flags need no copy back)
+	uint32_t *bad;
 	uint8_t coef[PTR_KMAX][RMAX];
 };
 
@@ -431,7 +434,7 @@ __device__ __forceinline__ u32x4 ld16_valid(const uint8_t *shard, uint32_t col, 
 	return u32x4{w[0], w[1], w[2], w[3]};
 }
 
-template <int MW, int KC, bool MIRROR>
+template <int MW, int KC, bool MIRROR, bool COMPARE = false>
 __global__ __launch_bounds__(256) void gf_apply_ptrs(const PtrApplyArgs a, const LogExp *__restrict__ le)
 {
 	constexpr int ENT = 4 * MW, TBL = 32 * ENT;
@@ -526,6 +529,19 @@ __global__ __launch_bounds__(256) void gf_apply_ptrs(const PtrApplyArgs a, const
 	if (!live)
 		return;
 	uint8_t *const *outp = a.out + (size_t)b * rows;
+	if (COMPARE) {
+		uint32_t diff = 0;
+#pragma unroll
+		for (int r = 0; r < 4 * MW; ++r) {
+			if (r >= (int)rows)
+				continue;
+			const u32x4 old = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(outp[r]) + col);
+			diff |= (P[r][0] ^ old.x) | (P[r][1] ^ old.y) | (P[r][2] ^ old.z) | (P[r][3] ^ old.w);
+		}
+		if (diff)
+			a.bad[b] = 1u;
+		return;
+	}
 #pragma unroll
 	for (int r = 0; r < 4 * MW; ++r) {
 		if (r >= (int)rows)

@@ -882,6 +882,97 @@ def test_decode_verify_batch_one_trip(coracle, rs104, pin, S, healthy):
             host_free(a)
 
 
+@pytest.mark.parametrize("k,m,L", [(20, 8, 2 << 20), (3, 1, 1 << 20), (17, 3, 700_001)], ids=["rs20_8", "rs3_1", "rs17_3"])
+def test_decode_verify_segmented_chains_other_shapes(k, m, L):
+    """The staged upload + segmented block checksum with more data shards than stages (k = 20 > 16), with fewer
+    (k = 3), and with stage boundaries that are not multiples of 128 bytes: block and shard checksums vs hashlib."""
+    import ctypes
+    import hashlib
+
+    from garage_amd.codec import host_alloc, host_free
+
+    lib = _lib.lib
+    rs = g.ReedSolomon(k, m)
+    n = k + m
+    S = g.shard_len(k, L)
+    lens = [L, L - 1, L // 2, L // 2 + 129, 7 * S + 5 if k > 7 else S + 5, 300_000, L]
+    nb = len(lens)
+    rng = np.random.default_rng(k)
+    bufs = [host_alloc(k * S) for _ in range(nb)]
+    sp = (ctypes.c_void_p * (nb * n))()
+    op = (ctypes.c_void_p * (nb * n))()
+    for b in range(nb):
+        bufs[b][:] = 0
+        bufs[b][:lens[b]] = rng.integers(0, 256, lens[b], dtype=np.uint8)
+        for j in range(k):
+            sp[b * n + j] = bufs[b].ctypes.data + j * S
+    clens = (ctypes.c_size_t * nb)(*lens)
+    ssums = np.zeros((nb, n, 32), dtype=np.uint8)
+    bsums = np.zeros((nb, 32), dtype=np.uint8)
+    u8 = ctypes.POINTER(ctypes.c_uint8)
+    _lib.check(lib.gec_decode_verify_batch(rs._h, nb, sp, S, clens, op, ssums.ctypes.data_as(u8), bsums.ctypes.data_as(u8)),
+               "gec_decode_verify_batch")
+    for b in range(nb):
+        assert bsums[b].tobytes() == hashlib.blake2b(bufs[b][:lens[b]].tobytes(), digest_size=64).digest()[:32], b
+        for j in (0, k // 2, k - 1):
+            assert ssums[b, j].tobytes() == g.shardsum(bufs[b][j * S:(j + 1) * S].tobytes()), (b, j)
+    for a in bufs:
+        host_free(a)
+
+
+@pytest.mark.parametrize("k,m", [(10, 4), (20, 8), (6, 10)], ids=["rs10_4", "rs20_8", "rs6_10_two_row_groups"])
+def test_zero_copy_verify_flags_the_right_blocks(coracle, k, m):
+    """gec_verify_batch on pinned shards (the scrub path without staging): one flipped bit in a data shard, in a
+    parity shard of the first and of the last row group, in the last column -- exactly those blocks are reported,
+    and the pageable (staged) call agrees."""
+    import ctypes
+
+    from garage_amd.codec import host_alloc, host_free
+
+    lib = _lib.lib
+    rs = g.ReedSolomon(k, m)
+    n, S, nb = k + m, 4160, 40
+    rng = np.random.default_rng(m)
+    data = rng.integers(0, 256, (nb, k, S), dtype=np.uint8)
+    par = coracle.encode_batch(k, m, data, coracle.AVX2, threads=4)
+    arena = host_alloc(nb * n * S)
+    st = arena.reshape(nb, n, S)
+    st[:, :k] = data
+    st[:, k:] = par
+    bad = {3: (0, 0), 7: (k - 1, S - 1), 11: (k, 17), 19: (n - 1, S - 1), 39: (k + m // 2, 4159)}
+    for b, (j, off) in bad.items():
+        st[b, j, off] ^= 0x10
+    ptrs = (ctypes.c_void_p * (nb * n))(*[arena.ctypes.data + (b * n + j) * S for b in range(nb) for j in range(n)])
+    ok = np.full(nb, 7, dtype=np.uint8)
+    _lib.check(lib.gec_verify_batch(rs._h, nb, ptrs, S, ok.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), "gec_verify_batch")
+    assert [b for b in range(nb) if not ok[b]] == sorted(bad) and set(ok.tolist()) == {0, 1}
+    assert rs.verify(np.array(st)).tolist() == ok.astype(bool).tolist()      # pageable copy: staged path
+    host_free(arena)
+
+
+def test_zero_copy_encode_more_blocks_than_one_grid(coracle):
+    """gf_apply_ptrs puts the block index in gridDim.y (<= 65535): 70 000 tiny pinned blocks take two launches."""
+    import ctypes
+
+    from garage_amd.codec import host_alloc, host_free
+
+    lib = _lib.lib
+    k, m, S, nb = 4, 2, 64, 70_000
+    rs = g.ReedSolomon(k, m)
+    arena = host_alloc(nb * k * S)
+    par = host_alloc(nb * m * S)
+    arena[:] = np.random.default_rng(5).integers(0, 256, arena.size, dtype=np.uint8)
+    par[:] = 0
+    ptrs = (ctypes.c_void_p * nb)(*[arena.ctypes.data + b * k * S for b in range(nb)])
+    optrs = (ctypes.c_void_p * nb)(*[par.ctypes.data + b * m * S for b in range(nb)])
+    clens = (ctypes.c_size_t * nb)(*[k * S] * nb)
+    _lib.check(lib.gec_encode_batch(rs._h, nb, ptrs, clens, S, optrs), "zero-copy encode")
+    want = coracle.encode_batch(k, m, arena.reshape(nb, k, S), coracle.AVX2, threads=8)
+    assert np.array_equal(par.reshape(nb, m, S), want)
+    host_free(arena)
+    host_free(par)
+
+
 def test_scattered_offsets_beyond_64gib_are_refused(rs104):
     """shard offsets are carried as 32-bit counts of 16-byte units; an offset of 64 GiB or more --
     input OR output side -- must be refused, not silently truncated (no memory is touched: the check precedes
