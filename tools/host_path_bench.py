@@ -76,6 +76,22 @@ def pcie_inclusive_rates(nb: int = 512, reps: int = 5) -> dict:
         best, _ = _best(dec, reps)
         assert np.array_equal(rec[0][:S], blocks[0][:S]) and np.array_equal(rec[-1][S:], blocks[-1][3 * S:4 * S])
         out[f"reconstruct_data_2_lost_{kind}_GiBps"] = round(nb * L / best / 2**30, 2)
+        # encode + the checksums of all k+m shards in the same trip (what the BlockManager's put calls)
+        sums = np.zeros((nb, n, 32), dtype=np.uint8)
+        u8 = ctypes.POINTER(ctypes.c_uint8)
+        eh = lambda: check(lib.gec_encode_hash_batch(rs._h, nb, ptrs, lens, S, optrs, sums.ctypes.data_as(u8)), "gec_encode_hash_batch")  # noqa: E731
+        eh()
+        best, _ = _best(eh, reps)
+        out[f"encode_hash_{kind}_GiBps"] = round(nb * L / best / 2**30, 2)
+        # verify (scrub): all k+m shards cross the link, payload rate
+        vp = (ctypes.c_void_p * (nb * n))(*[blocks[b].ctypes.data + j * S if j < K else outs[b].ctypes.data + (j - K) * S
+                                            for b in range(nb) for j in range(n)])
+        okf = np.zeros(nb, dtype=np.uint8)
+        ver = lambda: check(lib.gec_verify_batch(rs._h, nb, vp, S, okf.ctypes.data_as(u8)), "gec_verify_batch")  # noqa: E731
+        ver()
+        best, _ = _best(ver, reps)
+        assert okf.all()
+        out[f"verify_{kind}_GiBps"] = round(nb * L / best / 2**30, 2)
         for a in blocks + outs + rec:
             free(a)
 

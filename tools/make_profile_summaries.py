@@ -33,12 +33,12 @@ tr = list(csv.DictReader(open(os.path.join(G, "prof_final", "d_kernel_trace.csv"
 ds = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
             for r in tr if "gf_apply_nibble<1, 0" in r["Kernel_Name"])
 # the 1000 timed launches are the last 1000 encode launches before the verify (MODE_COMPARE) launch that follows the timed region
-vstart = min(int(r["Start_Timestamp"]) for r in tr if "gf_apply_nibble<1, 2" in r["Kernel_Name"])
+vstart = min(int(r["Start_Timestamp"]) for r in tr if "gf_apply_nibble<1, 2" in r["Kernel_Name"] or "gf_apply_nibble<1, 3" in r["Kernel_Name"])
 before = [x for st_, x in ds if st_ < vstart]
 enc = before[-1000:]
 with open(os.path.join(P, f"{tag}_bench_default_kernel_stats.txt"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py     (defaults: --steps 1000 --warmup 100)\n")
-    f.write(f"# {tag} FINAL kernel (flattened, XCD-aware tiles, bitop3 XOR), MI355X.  gf_apply_nibble<1,0,10,1,true,256> = cold burst + pre-conditioning + 100 warm-up + 1000 timed encode + 501 reconstruct launches\n")
+    f.write(f"# {tag} FINAL kernel (flattened, XCD-aware tiles, bitop3 XOR, s_setprio; verify = <1,3,...> stored rows prefetched), MI355X.  gf_apply_nibble<1,0,10,1,true,256> = cold burst + pre-conditioning + 100 warm-up + 1000 timed encode + 501 reconstruct launches\n")
     f.write(f"# bench.py printed in this profiled run: value {d['value']} GiB/s, ms_per_step {d['ms_per_step']}, roofline.kernel_ms {d['roofline']['kernel_ms']} (HIP events over the 1000 timed steps), frac {d['roofline']['frac']}\n")
     f.write(f"# rocprofv3, the 1000 timed encode launches alone: avg {sum(enc)/len(enc)/1e3:.1f} us, min {min(enc)/1e3:.1f}, max {max(enc)/1e3:.1f}  -> agrees with kernel_ms\n")
     f.write(f"# un-profiled run right after, same box: value {d2['value']} GiB/s, frac {d2['roofline']['frac']}, decode {d2['decode']['value']} GiB/s, cpu_baseline {d2['cpu_baseline']['value']} GiB/s on {d2['cpu_baseline']['cores']} threads\n")
@@ -52,7 +52,7 @@ with open(os.path.join(P, f"{tag}_bench_default_kernel_stats.txt"), "w") as f:
 K = "gf_apply_nibble<1, 0, 10"
 fetch = per_dispatch(os.path.join(G, "prof_final_fetch", "f_counter_collection.csv"), K, "FETCH_SIZE")
 write = per_dispatch(os.path.join(G, "prof_final_write", "w_counter_collection.csv"), K, "WRITE_SIZE")
-vfetch = per_dispatch(os.path.join(G, "prof_final_fetch", "f_counter_collection.csv"), "gf_apply_nibble<1, 2, 10", "FETCH_SIZE")
+vfetch = per_dispatch(os.path.join(G, "prof_final_fetch", "f_counter_collection.csv"), "gf_apply_nibble<1, 3, 10", "FETCH_SIZE")
 rd, wr = 2 * fetch * 1024, write * 1024
 algo = 1503789056
 sqp0 = os.path.join(G, "prof_final_sq", "sq_counter_collection.csv")
