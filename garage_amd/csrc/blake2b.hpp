@@ -228,8 +228,8 @@ constexpr int B2Q_SLOT = 144;  // LDS bytes per message block: 128 + pad (bank s
 template <int CTRL>
 __device__ __forceinline__ uint64_t b2_quad_perm(uint64_t x)
 {
-	const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)x, CTRL, 0xf, 0xf, false);
-	const int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(x >> 32), CTRL, 0xf, 0xf, false);
+	const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)x, CTRL, 0xf, 0xf, true);
+	const int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(x >> 32), CTRL, 0xf, 0xf, true);
 	return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 

@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 : > gpurun_out/get_ab.txt
-for cus in 1 2 4 8 16; do
+for cus in 0 4 8 16 32 64; do
 GEC_UPLOAD_CUS=$cus timeout 300 python - >> gpurun_out/get_ab.txt 2>&1 <<PY
 import sys, time, numpy as np
 sys.path.insert(0, '.')
