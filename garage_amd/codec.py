@@ -295,6 +295,20 @@ class ReedSolomon:
         check(lib.gec_verify_batch(self._h, nb, ptrs, S, _u8p(ok)), "gec_verify_batch")
         return ok.astype(bool)
 
+    def verify_hash(self, stripes: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        """The scrub check in one trip (gec_verify_hash_batch): stripes (nblocks, k+m, S) host array (pinned or not)
+        -> (ok bool (nblocks,), shard checksums uint8 (nblocks, k+m, 32))."""
+        st = stripes if stripes.flags["C_CONTIGUOUS"] and stripes.dtype == np.uint8 else np.ascontiguousarray(stripes, dtype=np.uint8)
+        if st.ndim != 3 or st.shape[1] != self.n:
+            raise GecError(_lib.GEC_E_TOO_FEW_SHARDS, "verify_hash", f"expected (nblocks, {self.n}, S)")
+        nb, _, S = st.shape
+        base = st.ctypes.data
+        ptrs = (ctypes.c_void_p * (nb * self.n))(*[base + i * S for i in range(nb * self.n)])
+        ok = np.zeros(nb, dtype=np.uint8)
+        sums = np.zeros((nb, self.n, 32), dtype=np.uint8)
+        check(lib.gec_verify_hash_batch(self._h, nb, ptrs, S, _u8p(ok), _u8p(sums)), "gec_verify_hash_batch")
+        return ok.astype(bool), sums
+
     def reconstruct(self, shards: Sequence[Sequence[Optional[np.ndarray]]], data_only: bool = False):
         """shards[b][j] is a uint8 array of S bytes or None (missing).  Returns a
         list of lists with the missing entries filled (`reconstruct` /

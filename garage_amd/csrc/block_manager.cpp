@@ -1761,7 +1761,9 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 {
 	const int k = mg->k, n = mg->n;
 	const uint64_t now = mg->now();
+	Trace tr("resync");
 	mg->pool->parallel_for(tasks.size(), [&](size_t i) { scan_block(mg, tasks[i]); });
+	tr.lap("presence scan");
 	std::vector<size_t> rebuild;
 	std::atomic<uint64_t> deleted{0}, offloaded{0};
 	mg->pool->parallel_for(tasks.size(), [&](size_t i) {
@@ -1834,6 +1836,7 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 	});
 	st.deleted += deleted.load();
 	st.offloaded += offloaded.load();
+	tr.lap("delete / offload");
 	for (size_t i = 0; i < tasks.size(); ++i)
 		if (!tasks[i].want.empty())
 			rebuild.push_back(i);
@@ -1844,6 +1847,7 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 			hs.push_back(tasks[i].h);
 		std::vector<Gathered> gs;
 		int grc = gather_many(mg, hs, nullptr, k, gs);
+		tr.lap("gather k + checksums");
 		for (size_t q = 0; q < rebuild.size(); ++q) {
 			ResyncTask &t = tasks[rebuild[q]];
 			if (grc) {
@@ -1892,21 +1896,32 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 			std::vector<uint8_t *> op(ids.size() * n, nullptr);
 			std::vector<std::vector<Bytes>> outb(ids.size(), std::vector<Bytes>(n));
 			bool oom = false;
+			// one pinned slab for the group's rebuilt shards (a first-time allocation per shard costs more than
+			// the decode), sliced per shard: the nodes keep the slices, the slab lives as long as any of them
+			size_t nwant = 0;
+			for (size_t q = 0; q < ids.size(); ++q)
+				nwant += tasks[ids[q]].want.size();
+			Bytes slab;
+			try {
+				slab = mg->bufs->get(nwant * S);
+			} catch (const std::bad_alloc &) {
+				oom = true;
+			}
+			size_t slot = 0;
 			for (size_t q = 0; q < ids.size() && !oom; ++q) {
 				ResyncTask &t = tasks[ids[q]];
 				for (int j = 0; j < n; ++j)
 					if (!t.g.shard[j].empty())
 						sp[q * n + j] = t.g.shard[j].data();
-				try {
-					for (int j : t.want) {
-						outb[q][j] = mg->bufs->get(S);
-						op[q * n + j] = outb[q][j].mut();
-					}
-				} catch (const std::bad_alloc &) {
-					oom = true;
+				for (int j : t.want) {
+					outb[q][j] = slab.slice(slot * S, S);
+					op[q * n + j] = outb[q][j].mut();
+					++slot;
 				}
 			}
+			tr.lap("group setup");
 			int rc = oom ? GEC_E_NOMEM : gec_reconstruct_batch(mg->codec, ids.size(), sp.data(), op.data(), S, 0);
+			tr.lap("reconstruct");
 			++st.device_calls;
 			if (rc) {
 				ec_fail(rc, "gec_reconstruct_batch");
@@ -1928,6 +1943,7 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 				}
 			});
 			st.rebuilt += rebuilt.load();
+			tr.lap("PutShard");
 		}
 	}
 }
@@ -2609,18 +2625,24 @@ int gbm_scrub_all(gbm_manager *mg, size_t batch_blocks, uint64_t stats[4])
 			const size_t nb = std::min(batch_blocks, hs.size() - b0);
 			std::vector<Hash> batch(hs.begin() + b0, hs.begin() + b0 + nb);
 			std::vector<Gathered> g;
-			int grc = gather_many(mg, batch, nullptr, mg->n, g);  // checksum failures are handled in there (renamed + queued)
+			// shards are accepted on their headers; their checksums come back from the same device trip that checks
+			// the stripe against the code (every byte crosses the link once)
+			int grc = gather_many(mg, batch, nullptr, mg->n, g, /*verify=*/false);
 			if (grc)
 				return grc;
 			std::map<size_t, std::vector<size_t>> by_len;
+			auto unreadable = [&](size_t b) {
+				if (mg->get_rc(batch[b]).is_nonzero()) {
+					++st[1];  // a needed block that is not fully readable
+					mg->put_to_resync(batch[b], 0);
+				}
+			};
 			for (size_t b = 0; b < nb; ++b) {
 				++st[0];
 				if (g[b].count == mg->n)
 					by_len[g[b].meta.shard_len].push_back(b);
-				else if (mg->get_rc(batch[b]).is_nonzero()) {
-					++st[1];  // a needed block that is not fully readable
-					mg->put_to_resync(batch[b], 0);
-				}
+				else
+					unreadable(b);
 			}
 			for (auto &kv : by_len) {
 				const std::vector<size_t> &ids = kv.second;
@@ -2628,12 +2650,30 @@ int gbm_scrub_all(gbm_manager *mg, size_t batch_blocks, uint64_t stats[4])
 				for (size_t i = 0; i < ids.size(); ++i)
 					for (int j = 0; j < mg->n; ++j)
 						sp[i * mg->n + j] = g[ids[i]].shard[j].data();
-				std::vector<uint8_t> ok(ids.size());
-				int rc = gec_verify_batch(mg->codec, ids.size(), sp.data(), kv.first, ok.data());
+				std::vector<uint8_t> ok(ids.size()), sums(ids.size() * (size_t)mg->n * 32);
+				int rc = gec_verify_hash_batch(mg->codec, ids.size(), sp.data(), kv.first, ok.data(), sums.data());
 				++st[2];
 				if (rc)
-					return ec_fail(rc, "gec_verify_batch");
+					return ec_fail(rc, "gec_verify_hash_batch");
+				mg->gpu_hashed += ids.size() * (size_t)mg->n;
 				for (size_t i = 0; i < ids.size(); ++i) {
+					// a shard that does not match the checksum in its own header: read_block_from's corrupt-file
+					// case (manager.rs:577-609) -- set aside, queued; the stripe's verdict follows from it
+					bool sum_bad = false;
+					for (int j = 0; j < mg->n; ++j) {
+						const Gathered &gb = g[ids[i]];
+						if (std::memcmp(sums.data() + (i * mg->n + j) * 32, gb.sum[j].data(), 32) != 0) {
+							mg->metrics[2]++;
+							if (gb.node[j] >= 0)
+								mg->nodes[gb.node[j]]->mark_corrupted(batch[ids[i]], j);
+							mg->put_to_resync(batch[ids[i]], 0);
+							sum_bad = true;
+						}
+					}
+					if (sum_bad) {
+						unreadable(ids[i]);
+						continue;
+					}
 					if (ok[i])
 						continue;
 					++st[1];

@@ -1074,7 +1074,11 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 			a.out = grp + b0 * rows;
 			a.mirror = d_mirror ? d_mirror + b0 * a.mirror_stride : nullptr;
 			a.bad = bad ? bad + b0 : nullptr;
-			if (bad && mw == 1)
+			if (bad && d_mirror && mw == 1)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, true, true>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
+			else if (bad && d_mirror)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5, true, true>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
+			else if (bad && mw == 1)
 				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, false, true>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
 			else if (bad)
 				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5, false, true>), dim3(gx, gy), dim3(256), lds, stream, a, c->d_logexp);
@@ -2243,6 +2247,68 @@ static int hash_batch_impl(const gec_codec *c, size_t n, const uint8_t *const *m
 	// (b) long messages (a BLAKE2b chain costs ~4000 cycles per 128-byte block however many messages run
 	//     beside it: 14 ms per MiB): everything is first moved into ONE device buffer through two pinned
 	//     staging pieces, then hashed by ONE launch -- chunked launches would pay the chain once per chunk.
+	if (all_pinned && tree && zero_copy_enabled() && n > 1) {
+		// Shard checksums of pinned messages: lanes that each stream a 4 KiB leaf out of host memory read the link in
+		// 16-byte pieces (22 GiB/s); a copy kernel moves the same bytes coalesced at the link's rate, so the messages
+		// go to HBM chunk by chunk (copy_table on the upload stream's CUs) and are hashed there beside the next
+		// chunk's transfer.
+		DeviceGuard dg(c->device);
+		if (!dg.ok)
+			return fail(GEC_E_DEVICE, "hipSetDevice failed");
+		StagingLease lease(c);
+		Staging &st = lease.st;
+		const size_t kChunk = 8 * kChunkBytes;
+		const size_t buf_bytes = std::max(kChunk, (longest + 15) / 16 * 16);
+		int rc = st.ensure(n * 48 + 64, 0);  // [off][len][out]
+		if (!rc)
+			rc = st.ensure_tab(n + 8);
+		if (!rc)
+			rc = st.ensure_big(2 * buf_bytes);
+		if (!rc)
+			rc = st.ensure_segments(c->num_cu);
+		if (rc)
+			return rc;
+		hipStream_t up = st.stream_up ? st.stream_up : st.stream;
+		hipStream_t chain = st.stream_chain ? st.stream_chain : st.stream2;
+		uint64_t *h_off = reinterpret_cast<uint64_t *>(st.h_buf), *h_len = h_off + n;
+		uint8_t *h_out = st.h_buf + n * 16;
+		size_t ci = 0;
+		for (size_t i = 0; i < n && !rc; ++ci) {
+			uint8_t *buf = st.d_big + (ci & 1) * buf_bytes;
+			std::vector<gec::CopyEntry> ents;
+			size_t j = i, bytes = 0, chunk_longest = 0;
+			while (j < n && (j == i || bytes + (lens[j] + 15) / 16 * 16 <= buf_bytes)) {
+				h_off[j] = bytes;
+				h_len[j] = lens[j];
+				if (lens[j])
+					ents.push_back({pinned().dev(msgs[j]), buf + bytes, lens[j]});
+				chunk_longest = std::max(chunk_longest, lens[j]);
+				bytes += (lens[j] + 15) / 16 * 16;
+				++j;
+			}
+			if (ci >= 2 && hipStreamWaitEvent(up, st.ev_seg[2 + (ci & 1)], 0) != hipSuccess)
+				rc = fail(GEC_E_DEVICE, "hipStreamWaitEvent");
+			if (!rc)
+				rc = launch_copy_table(st, ents, up);
+			hipError_t e = rc ? hipSuccess : hipEventRecord(st.ev_seg[ci & 1], up);
+			if (!rc && e == hipSuccess)
+				e = hipStreamWaitEvent(chain, st.ev_seg[ci & 1], 0);
+			if (!rc && e != hipSuccess)
+				rc = fail(GEC_E_DEVICE, "chunk event");
+			if (!rc)
+				rc = blake2_dev(c, j - i, buf, h_off + i, h_len + i, 0, 0, h_out + 32 * i, chain, 0, 0, 0, true, chunk_longest);
+			if (!rc && hipEventRecord(st.ev_seg[2 + (ci & 1)], chain) != hipSuccess)
+				rc = fail(GEC_E_DEVICE, "hipEventRecord");
+			i = j;
+		}
+		const hipError_t e1 = hipStreamSynchronize(up), e2 = hipStreamSynchronize(chain);
+		if (rc)
+			return rc;
+		HIP_TRY(e1);
+		HIP_TRY(e2);
+		std::memcpy(out, h_out, n * 32);
+		return GEC_OK;
+	}
 	if (all_pinned || longest >= (256u << 10) || tree) {
 		DeviceGuard dg(c->device);
 		if (!dg.ok)
@@ -2806,6 +2872,100 @@ int gec_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *s
 			for (size_t i = 0; i < nb; ++i)
 				ok[b0 + i] = st.h_bad[i] ? 0 : 1;
 		});
+}
+
+int gec_verify_hash_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, size_t S, uint8_t *ok,
+			  uint8_t *shard_sums)
+{
+	if (!c)
+		return fail(GEC_E_INVALID_ARG, "NULL codec");
+	if (nblocks == 0)
+		return GEC_OK;
+	if (!shards || !ok || !shard_sums)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (S == 0)
+		return fail(GEC_E_EMPTY_SHARD, "shard length is 0");
+	if (S % 64)
+		return fail(GEC_E_INCORRECT_SHARD_SIZE, "S must be a multiple of 64");
+	const size_t k = c->k, m = c->m, n = k + m;
+	for (size_t i = 0; i < nblocks * n; ++i)
+		if (!shards[i])
+			return fail(GEC_E_TOO_FEW_SHARDS, "verify needs all k+m shards");
+	bool all_pinned = k <= (size_t)gec::PTR_KMAX && zero_copy_enabled();
+	for (size_t i = 0; i < nblocks * n && all_pinned; ++i)
+		all_pinned = aligned16(shards[i]) && pinned().contains(shards[i], S);
+	if (!all_pinned) {
+		// pageable shards: two staged trips (the scrub of shards a caller keeps in ordinary memory is not a hot path)
+		int rc = gec_verify_batch(c, nblocks, shards, S, ok);
+		if (rc)
+			return rc;
+		std::vector<size_t> lens(nblocks * n, S);
+		return gec_shardsum_batch(c, nblocks * n, shards, lens.data(), shard_sums);
+	}
+	// one trip: the compare form of gf_apply_ptrs reads all k+m shards of a chunk over the link, leaves the verdicts in
+	// pinned memory and everything it read in HBM, where the chunk's shard checksums are computed while the next
+	// chunk is on the link (same stream pair as gec_encode_hash_batch)
+	DeviceGuard dg(c->device);
+	if (!dg.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	StagingLease lease(c);
+	Staging &st = lease.st;
+	const size_t stripe = n * S;
+	const size_t zch = chunk_blocks(stripe, nblocks, 8 * kChunkBytes);
+	const size_t nz = (nblocks + zch - 1) / zch;
+	int rc = st.ensure(nblocks * n * 32 + 64, nblocks);
+	if (!rc)
+		rc = st.ensure_tab((nblocks * (k * 12 + m * 8) + 64 * nz) / sizeof(gec::CopyEntry) + 4 * nz + 4);
+	if (!rc)
+		rc = st.ensure_big(2 * (zch * stripe + zch * n * 32));
+	if (!rc)
+		rc = st.ensure_segments(c->num_cu);
+	if (rc)
+		return rc;
+	hipStream_t up = st.stream_up ? st.stream_up : st.stream;
+	hipStream_t chain = st.stream_chain ? st.stream_chain : st.stream2;
+	std::memset(st.h_bad, 0, nblocks * sizeof(uint32_t));
+	std::vector<const uint8_t *> in(zch * k);
+	std::vector<uint32_t> valid(zch * k, (uint32_t)S);
+	std::vector<uint8_t *> par(zch * m);
+	for (size_t ci = 0; ci < nz && !rc; ++ci) {
+		const size_t b0 = ci * zch, nb = std::min(zch, nblocks - b0);
+		for (size_t i = 0; i < nb; ++i) {
+			for (size_t t = 0; t < k; ++t)
+				in[i * k + t] = pinned().dev(shards[(b0 + i) * n + t]);
+			for (size_t r = 0; r < m; ++r)
+				par[i * m + r] = const_cast<uint8_t *>(pinned().dev(shards[(b0 + i) * n + k + r]));
+		}
+		uint8_t *mir = st.d_big + (ci & 1) * (zch * stripe + zch * n * 32);
+		if (ci >= 2 && hipStreamWaitEvent(up, st.ev_seg[2 + (ci & 1)], 0) != hipSuccess)
+			rc = fail(GEC_E_DEVICE, "hipStreamWaitEvent");
+		if (!rc)
+			rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), par.data(), (int)m, S, c->enc.row((int)k), up, mir, st.h_bad + b0);
+		if (rc)
+			continue;
+		uint8_t *d_sums = mir + zch * stripe;
+		hipError_t e = hipEventRecord(st.ev_seg[ci & 1], up);
+		if (e == hipSuccess)
+			e = hipStreamWaitEvent(chain, st.ev_seg[ci & 1], 0);
+		if (e != hipSuccess) {
+			rc = fail(GEC_E_DEVICE, "chunk event");
+			continue;
+		}
+		rc = blake2_dev(c, nb * n, mir, nullptr, nullptr, S, S, d_sums, chain, 0, 0, 0, true);
+		if (!rc && hipMemcpyAsync(st.h_buf + b0 * n * 32, d_sums, nb * n * 32, hipMemcpyDeviceToHost, chain) != hipSuccess)
+			rc = fail(GEC_E_DEVICE, "hipMemcpyAsync (shard sums)");
+		if (!rc && hipEventRecord(st.ev_seg[2 + (ci & 1)], chain) != hipSuccess)
+			rc = fail(GEC_E_DEVICE, "hipEventRecord");
+	}
+	const hipError_t e1 = hipStreamSynchronize(up), e2 = hipStreamSynchronize(chain);
+	if (rc)
+		return rc;
+	HIP_TRY(e1);
+	HIP_TRY(e2);
+	std::memcpy(shard_sums, st.h_buf, nblocks * n * 32);
+	for (size_t b = 0; b < nblocks; ++b)
+		ok[b] = st.h_bad[b] ? 0 : 1;
+	return GEC_OK;
 }
 
 int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, uint8_t *const *out,

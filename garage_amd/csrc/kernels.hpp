@@ -537,6 +537,8 @@ __global__ __launch_bounds__(256) void gf_apply_ptrs(const PtrApplyArgs a, const
 				continue;
 			const u32x4 old = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(outp[r]) + col);
 			diff |= (P[r][0] ^ old.x) | (P[r][1] ^ old.y) | (P[r][2] ^ old.z) | (P[r][3] ^ old.w);
+			if (MIRROR)  // the STORED row: what the shard checksum is computed over
+				reinterpret_cast<u32x4 *>(a.mirror + (size_t)b * a.mirror_stride + a.mirror_row0)[(size_t)r * a.cols + col] = old;
 		}
 		if (diff)
 			a.bad[b] = 1u;

@@ -158,6 +158,16 @@ int gec_encode_batch(const gec_codec *c, size_t nblocks,
 int gec_verify_batch(const gec_codec *c, size_t nblocks,
 		     const uint8_t *const *shards, size_t S, uint8_t *ok);
 
+/* The scrub worker's whole check in ONE trip (src/block/repair.rs:450-458 reads a block and compares its hash
+ * with its name; a stripe has k+m shards to check and a code to check them against): ok[b] as gec_verify_batch,
+ * and shard_sums[32*(b*(k+m) + j)] = the shard checksum (gec_shardsum_batch) of every shard, for the caller to
+ * compare with the shard headers.  With all shards in pinned memory every byte crosses the link once: the
+ * compare form of the pointer-table kernel reads the shards, leaves verdicts in pinned memory and the shards in
+ * device memory, where the checksums are computed chunk by chunk beside the next chunk's transfer. */
+int gec_verify_hash_batch(const gec_codec *c, size_t nblocks,
+			  const uint8_t *const *shards, size_t S, uint8_t *ok,
+			  uint8_t *shard_sums);
+
 /* == ReedSolomon::reconstruct / reconstruct_data [EXT], batched; sits where
  * rpc_get_raw_block_internal returns the first whole block it finds
  * (src/block/manager.rs:292-334) and where resync_block fetches an absent

@@ -139,6 +139,15 @@ int gec_verify_batch(const gec_codec *c, size_t nb, const uint8_t *const *shards
 	return GEC_OK;
 }
 
+int gec_verify_hash_batch(const gec_codec *c, size_t nb, const uint8_t *const *shards, size_t S, uint8_t *ok, uint8_t *sums)
+{
+	const int n = c->k + c->m;
+	int rc = gec_verify_batch(c, nb, shards, S, ok);
+	for (size_t i = 0; !rc && i < nb * (size_t)n; ++i)
+		gbm_shardsum(shards[i], S, sums + 32 * i);
+	return rc;
+}
+
 int gec_shardsum_batch(const gec_codec *, size_t n, const uint8_t *const *msgs, const size_t *lens, uint8_t *out)
 {
 	for (size_t i = 0; i < n; ++i)

@@ -950,6 +950,35 @@ def test_zero_copy_verify_flags_the_right_blocks(coracle, k, m):
     host_free(arena)
 
 
+@pytest.mark.parametrize("pin", [False, True], ids=["pageable", "pinned"])
+@pytest.mark.parametrize("k,m,S,nb", [(10, 4, 104896, 200), (6, 10, 4160, 30)], ids=["rs10_4_three_chunks", "rs6_10"])
+def test_verify_hash_batch_scrub_in_one_trip(coracle, k, m, S, nb, pin):
+    """gec_verify_hash_batch: stripe verdicts (vs which stripes were corrupted) and the checksum of every one of the
+    k+m stored shards (vs hashlib's tree mode), corrupted shards included: the checksum is of what is stored."""
+    from garage_amd.codec import host_alloc, host_free
+
+    rs = g.ReedSolomon(k, m)
+    n = k + m
+    rng = np.random.default_rng(S + nb)
+    data = rng.integers(0, 256, (nb, k, S), dtype=np.uint8)
+    par = coracle.encode_batch(k, m, data, coracle.AVX2, threads=8)
+    arena = host_alloc(nb * n * S) if pin else np.empty(nb * n * S, dtype=np.uint8)
+    st = arena.reshape(nb, n, S)
+    st[:, :k] = data
+    st[:, k:] = par
+    bad = {1: (0, 5), nb // 2: (n - 1, S - 1), nb - 1: (k, 0), nb - 2: (k - 1, S // 2)}
+    for b, (j, off) in bad.items():
+        st[b, j, off] ^= 0x80
+    ok, sums = rs.verify_hash(st)
+    assert [b for b in range(nb) if not ok[b]] == sorted(bad)
+    check_b = sorted(set(list(bad) + list(range(0, nb, max(1, nb // 8)))))
+    for b in check_b:
+        for j in range(n):
+            assert sums[b, j].tobytes() == g.shardsum(st[b, j].tobytes()), (b, j)
+    if pin:
+        host_free(arena)
+
+
 def test_zero_copy_encode_more_blocks_than_one_grid(coracle):
     """gf_apply_ptrs puts the block index in gridDim.y (<= 65535): 70 000 tiny pinned blocks take two launches."""
     import ctypes

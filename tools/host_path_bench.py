@@ -168,6 +168,70 @@ def block_manager_rates(nb: int = 512, threads: int = 48) -> dict:
     return res
 
 
+def maintenance_rates(nb: int = 512, root: str = "") -> dict:
+    """Rows f2 / f3 of SURVEY.md section 8 as rates: scrub of everything stored (gbm_scrub_all: every stripe's k+m shards
+    through gec_verify_batch) and the resync of one node's worth of lost shards (gbm_resync_run: presence scan, gather k,
+    one gec_reconstruct_batch per erasure pattern, PutShard).  Memory nodes, and directory nodes under `root` (tmpfs on
+    the GPU box: the file format and the directory walk, not a disk)."""
+    import shutil
+    import tempfile
+
+    import garage_amd as g
+    from garage_amd import block_native as bn
+
+    codec = g.ReedSolomon(K, M)
+    rng = np.random.default_rng(5)
+    blocks = [rng.integers(0, 256, L, dtype=np.uint8).tobytes() for _ in range(nb)]
+    hashes = codec.blake2sum_batch(blocks)
+    items = list(zip(hashes, blocks))
+    gib = nb * L / 2**30
+    res = {"what": "libgarage_block maintenance paths, RS(10,4), 1 MiB blocks, 16 nodes, payload GiB/s of the blocks concerned", "nblocks": nb}
+    for kind in ("memory", "directories"):
+        tmp = None
+        if kind == "directories":
+            tmp = tempfile.mkdtemp(prefix="gbm_bench_", dir=root or ("/dev/shm" if os.path.isdir("/dev/shm") else None))
+            mgr = bn.NativeBlockManager(codec, 16, [os.path.join(tmp, f"n{i}") for i in range(16)])
+        else:
+            mgr = bn.NativeBlockManager(codec, 16)
+        try:
+            t_put, _ = _best(lambda: mgr.rpc_put_blocks(items), 2)
+            outs = [np.empty(L, dtype=np.uint8) for _ in range(nb)]
+            t_get, _ = _best(lambda: mgr.rpc_get_blocks(hashes, L, out=outs), 2)
+            assert outs[7].tobytes() == blocks[7]
+            st = {}
+            t_scrub, _ = _best(lambda: st.update(mgr.scrub_all(256)), 2)
+            assert st["scrubbed"] == nb and st["corruptions"] == 0
+            # lose everything node 3 holds, queue every block, one resync pass rebuilds it
+            lost = 0
+            for h in hashes:
+                who = mgr.storage_nodes_of(h)
+                if 3 in who:
+                    mgr.node_delete_shard(3, h, who.index(3))
+                    lost += 1
+                mgr.put_to_resync(h, 0)
+            t0 = time.perf_counter()
+            rs_ = mgr.resync_run(0)
+            t_resync = time.perf_counter() - t0
+            assert mgr.scrub_all(256)["corruptions"] == 0 and all(mgr.node_has_shard(3, h, mgr.storage_nodes_of(h).index(3))
+                                                                  for h in hashes[:50] if 3 in mgr.storage_nodes_of(h))
+            res[kind] = {
+                "rpc_put_blocks_GiBps": round(gib / t_put, 2),
+                "rpc_get_blocks_GiBps": round(gib / t_get, 2),
+                "scrub_all_GiBps": round(gib / t_scrub, 2),
+                "resync_one_lost_node": {"blocks_queued": nb, "shards_rebuilt": lost, "seconds": round(t_resync, 4),
+                                         "GiBps_of_blocks_repaired": round(lost * L / 2**30 / t_resync, 2),
+                                         "device_calls": rs_.get("device_calls", rs_.get("batches"))},
+            }
+        finally:
+            mgr.close()
+            if tmp:
+                shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
 if __name__ == "__main__":
     nb = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-    print(json.dumps({"pcie_inclusive": pcie_inclusive_rates(nb), "block_manager": block_manager_rates(nb)}))
+    if len(sys.argv) > 2 and sys.argv[2] == "maintenance":
+        print(json.dumps({"maintenance": maintenance_rates(nb)}))
+    else:
+        print(json.dumps({"pcie_inclusive": pcie_inclusive_rates(nb), "block_manager": block_manager_rates(nb)}))
