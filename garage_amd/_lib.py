@@ -35,7 +35,7 @@ SYMBOLS = [
     "gec_shard_len", "gec_build_matrix", "gec_build_matrix_ex", "gec_build_decode_matrix",
     "gec_codec_create", "gec_codec_create_ex", "gec_codec_destroy", "gec_codec_k", "gec_codec_m",
     "gec_codec_device", "gec_parity_matrix", "gec_codec_cache_stats",
-    "gec_encode_batch", "gec_verify_batch", "gec_verify_hash_batch", "gec_reconstruct_batch",
+    "gec_encode_batch", "gec_verify_batch", "gec_verify_hash_batch", "gec_reconstruct_batch", "gec_reconstruct_hash_batch",
     "gec_encode_batch_dev", "gec_verify_batch_dev", "gec_reconstruct_batch_dev",
     "gec_reconstruct_range_dev", "gec_reconstruct_scattered_dev", "gec_blake2sum_batch_dev", "gec_blake2sum_batch",
     "gec_encode_hash_batch", "gec_set_kernel_variant", "gec_get_kernel_variant",
@@ -108,6 +108,7 @@ def _load() -> ctypes.CDLL:
     lib.gec_verify_batch.argtypes = [vp, sz, pp, sz, u8p]
     lib.gec_verify_hash_batch.argtypes = [vp, sz, pp, sz, u8p, u8p]
     lib.gec_reconstruct_batch.argtypes = [vp, sz, pp, pp, sz, ci]
+    lib.gec_reconstruct_hash_batch.argtypes = [vp, sz, pp, pp, sz, ci, u8p, u8p]
     lib.gec_encode_batch_dev.argtypes = [vp, sz, vp, sz, sz, vp, sz, vp]
     lib.gec_verify_batch_dev.argtypes = [vp, sz, vp, sz, sz, vp, vp]
     lib.gec_reconstruct_batch_dev.argtypes = [vp, sz, vp, sz, sz, u8p, ci, vp]

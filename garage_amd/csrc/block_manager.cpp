@@ -1840,14 +1840,19 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 	for (size_t i = 0; i < tasks.size(); ++i)
 		if (!tasks[i].want.empty())
 			rebuild.push_back(i);
-	if (!rebuild.empty()) {
-		// "fetching absent but needed block": gather exactly k shards per block (checksums verified in one batch)
+	// "fetching absent but needed block" (resync.rs:485-499): gather exactly k shards per block, rebuild what is wanted,
+	// PutShard.  First pass: shards are accepted on their headers and ONE device trip per group both rebuilds and
+	// returns the checksums of what it read (compared with the headers) and of what it wrote (stamped into the new
+	// headers) -- gec_reconstruct_hash_batch.  A block that turns out to have read a corrupt shard (set aside,
+	// queued) goes through a second pass whose gather verifies checksums first and moves on to the next holder.
+	auto rebuild_pass = [&](const std::vector<size_t> &rebuild, bool verify_in_gather) -> std::vector<size_t> {
+		std::vector<size_t> again;
 		std::vector<Hash> hs;
 		for (size_t i : rebuild)
 			hs.push_back(tasks[i].h);
 		std::vector<Gathered> gs;
-		int grc = gather_many(mg, hs, nullptr, k, gs);
-		tr.lap("gather k + checksums");
+		int grc = gather_many(mg, hs, nullptr, k, gs, verify_in_gather);
+		tr.lap(verify_in_gather ? "gather k + checksums" : "gather k");
 		for (size_t q = 0; q < rebuild.size(); ++q) {
 			ResyncTask &t = tasks[rebuild[q]];
 			if (grc) {
@@ -1875,26 +1880,21 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 					if (t.reachable[j] && t.g.shard[j].empty() && std::find(t.want.begin(), t.want.end(), j) == t.want.end())
 						t.want.push_back(j);
 		}
-		// group by (shard length, which shards are in hand, which are wanted): ONE device call per group, and
-		// inside it one decode plan (gec_reconstruct_batch buckets by exactly this key)
-		std::map<std::tuple<size_t, std::string, std::string>, std::vector<size_t>> groups;
-		for (size_t i : rebuild) {
-			ResyncTask &t = tasks[i];
-			if (t.want.empty())
-				continue;
-			std::string pres(n, 0), want(n, 0);
-			for (int j = 0; j < n; ++j)
-				pres[j] = t.g.shard[j].empty() ? 0 : 1;
-			for (int j : t.want)
-				want[j] = 1;
-			groups[{t.g.meta.shard_len, pres, want}].push_back(i);
-		}
+		// ONE device call per shard length: inside it gec_reconstruct_hash_batch buckets the blocks by (which shards
+		// are in hand, which are wanted) -- one decode plan and one kernel launch per such erasure pattern, the patterns'
+		// chunks pipelined through the link without a host round trip in between (one call per pattern: 14 calls,
+		// 20 ms for a lost node's 449 shards; one call: see tools/host_path_bench.py maintenance)
+		std::map<size_t, std::vector<size_t>> groups;
+		for (size_t i : rebuild)
+			if (!tasks[i].want.empty())
+				groups[tasks[i].g.meta.shard_len].push_back(i);
 		for (auto &kv : groups) {
-			const size_t S = std::get<0>(kv.first);
+			const size_t S = kv.first;
 			const std::vector<size_t> &ids = kv.second;
 			std::vector<const uint8_t *> sp(ids.size() * n, nullptr);
 			std::vector<uint8_t *> op(ids.size() * n, nullptr);
 			std::vector<std::vector<Bytes>> outb(ids.size(), std::vector<Bytes>(n));
+			std::vector<uint8_t> in_sums(ids.size() * (size_t)n * 32), out_sums(ids.size() * (size_t)n * 32);
 			bool oom = false;
 			// one pinned slab for the group's rebuilt shards (a first-time allocation per shard costs more than
 			// the decode), sliced per shard: the nodes keep the slices, the slab lives as long as any of them
@@ -1920,21 +1920,49 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 				}
 			}
 			tr.lap("group setup");
-			int rc = oom ? GEC_E_NOMEM : gec_reconstruct_batch(mg->codec, ids.size(), sp.data(), op.data(), S, 0);
-			tr.lap("reconstruct");
+			int rc = oom ? GEC_E_NOMEM
+				     : gec_reconstruct_hash_batch(mg->codec, ids.size(), sp.data(), op.data(), S, 0, in_sums.data(), out_sums.data());
+			tr.lap("reconstruct + checksums");
 			++st.device_calls;
 			if (rc) {
-				ec_fail(rc, "gec_reconstruct_batch");
+				ec_fail(rc, "gec_reconstruct_hash_batch");
 				for (size_t i : ids)
 					tasks[i].error = g_err;
 				continue;
 			}
+			mg->gpu_hashed += ids.size() * (size_t)k + nwant;
+			std::vector<uint8_t> good(ids.size(), 1);
+			if (!verify_in_gather) {
+				// what was read: the first k shards in hand, in index order
+				for (size_t q = 0; q < ids.size(); ++q) {
+					ResyncTask &t = tasks[ids[q]];
+					int seen = 0;
+					for (int j = 0; j < n && seen < k; ++j) {
+						if (t.g.shard[j].empty())
+							continue;
+						++seen;
+						if (std::memcmp(in_sums.data() + (q * n + j) * 32, t.g.sum[j].data(), 32) != 0) {
+							mg->metrics[2]++;
+							if (t.g.node[j] >= 0)
+								mg->nodes[t.g.node[j]]->mark_corrupted(t.h, j);
+							good[q] = 0;
+						}
+					}
+					if (!good[q]) {
+						t.want.clear();  // decided again by the second pass
+						again.push_back(ids[q]);
+					}
+				}
+			}
 			mg->metrics[3] += ids.size();
 			std::atomic<uint64_t> rebuilt{0};
 			mg->pool->parallel_for(ids.size(), [&](size_t q) {
+				if (!good[q])
+					return;
 				ResyncTask &t = tasks[ids[q]];
 				for (int j : t.want) {
-					if (send_shard(mg, t.who[j], t.h, j, outb[q][j], S, t.g.meta.orig_len, t.g.meta.compressed != 0, nullptr, nullptr)) {
+					if (send_shard(mg, t.who[j], t.h, j, outb[q][j], S, t.g.meta.orig_len, t.g.meta.compressed != 0,
+						       out_sums.data() + (q * n + j) * 32, nullptr)) {
 						++t.changed;
 						++rebuilt;
 					} else {
@@ -1944,6 +1972,24 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 			});
 			st.rebuilt += rebuilt.load();
 			tr.lap("PutShard");
+		}
+		return again;
+	};
+	if (!rebuild.empty()) {
+		std::vector<size_t> again = rebuild_pass(rebuild, false);
+		if (!again.empty()) {
+			// the presence of the shards that were set aside has changed: scan those blocks again
+			for (size_t i : again) {
+				ResyncTask &t = tasks[i];
+				for (int j = 0; j < n; ++j)
+					if (t.reachable[j]) {
+						ShardRpc rq{RpcKind::NeedShardQuery, &t.h, j, Shard(), nullptr};
+						ShardResp rs;
+						if (mg->nodes[t.who[j]]->handle(rq, rs) && rs.needed)
+							t.want.push_back(j);
+					}
+			}
+			(void)rebuild_pass(again, true);
 		}
 	}
 }

@@ -2968,8 +2968,10 @@ int gec_verify_hash_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 	return GEC_OK;
 }
 
-int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, uint8_t *const *out,
-			  size_t S, int data_only)
+// in_sums / out_sums (both or neither): the shard checksums of the k shards READ per block and of the shards WRITTEN,
+// at 32*(b*n + j), from the same trip (gec_reconstruct_hash_batch)
+static int reconstruct_batch_impl(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, uint8_t *const *out,
+				  size_t S, int data_only, uint8_t *in_sums, uint8_t *out_sums)
 {
 	if (!c)
 		return fail(GEC_E_INVALID_ARG, "NULL codec");
@@ -3054,33 +3056,121 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 			return fail(GEC_E_DEVICE, "hipSetDevice failed");
 		StagingLease lease(c);
 		Staging &st = lease.st;
-		int rc = st.ensure(64, 0);
-		if (!rc)
-			rc = st.ensure_tab(tab_bytes / sizeof(gec::CopyEntry) + 4 * work.size() + 4);
-		if (rc)
-			return rc;
+		const bool sums = in_sums != nullptr;
+		// with checksums: chunks of every pattern run through the two mirror halves in turn (chunk q+2 waits for
+		// the checksums of chunk q), link kernels on the upload CUs, checksum kernels on the rest
+		size_t sum_bytes = 0, max_ids = 0, nchunks_total = 0;
+		const size_t zch_cap = chunk_blocks(n * S, nblocks, 8 * kChunkBytes);
 		for (const Work &w : work) {
-			const std::vector<size_t> &ids = *w.ids;
-			const size_t nmiss = w.plan->missing.size();
-			std::vector<const uint8_t *> in(ids.size() * k);
-			std::vector<uint32_t> valid(ids.size() * k, (uint32_t)S);
-			std::vector<uint8_t *> outp(ids.size() * nmiss);
-			for (size_t i = 0; i < ids.size(); ++i) {
-				for (size_t t = 0; t < k; ++t)
-					in[i * k + t] = pinned().dev(shards[ids[i] * n + w.plan->valid[t]]);
-				for (size_t r = 0; r < nmiss; ++r)
-					outp[i * nmiss + r] = pinned().dev(out[ids[i] * n + w.plan->missing[r]]);
-			}
-			rc = launch_apply_ptrs(c, st, ids.size(), in.data(), valid.data(), outp.data(), (int)nmiss, S,
-					       w.plan->rows.v.data(), st.stream);
-			if (rc)
-				break;
+			sum_bytes += w.ids->size() * (k + w.plan->missing.size()) * 32;
+			max_ids = std::max(max_ids, w.ids->size());
+			nchunks_total += (w.ids->size() + zch_cap - 1) / zch_cap;
 		}
-		const hipError_t e = hipStreamSynchronize(st.stream);  // also on error: launches already queued read the tables
+		const size_t zch = std::min(zch_cap, std::max<size_t>(max_ids, 1));
+		const size_t half = zch * n * S + zch * n * 32;
+		int rc = st.ensure(sums ? sum_bytes + 64 : 64, 0);
+		if (!rc)
+			rc = st.ensure_tab(tab_bytes / sizeof(gec::CopyEntry) + 4 * (work.size() + nchunks_total) + 4);
+		if (!rc && sums)
+			rc = st.ensure_big(2 * half);
+		if (!rc && sums)
+			rc = st.ensure_segments(c->num_cu);
 		if (rc)
 			return rc;
-		HIP_TRY(e);
+		hipStream_t up = sums && st.stream_up ? st.stream_up : st.stream;
+		hipStream_t chain = sums && st.stream_chain ? st.stream_chain : st.stream2;
+		size_t q = 0, sum_off = 0;  // running chunk number, running offset into the pinned checksum area
+		std::vector<size_t> sum_base(work.size());
+		for (size_t wi = 0; wi < work.size() && !rc; ++wi) {
+			const Work &w = work[wi];
+			const std::vector<size_t> &ids = *w.ids;
+			const size_t nmiss = w.plan->missing.size(), per = k + nmiss;
+			sum_base[wi] = sum_off;
+			std::vector<const uint8_t *> in(std::min(zch, ids.size()) * k);
+			std::vector<uint32_t> valid(in.size(), (uint32_t)S);
+			std::vector<uint8_t *> outp(std::min(zch, ids.size()) * nmiss);
+			for (size_t i0 = 0; i0 < ids.size() && !rc; i0 += sums ? zch : ids.size(), ++q) {
+				const size_t nb = sums ? std::min(zch, ids.size() - i0) : ids.size();
+				if (!sums) {
+					in.resize(nb * k);
+					valid.assign(nb * k, (uint32_t)S);
+					outp.resize(nb * nmiss);
+				}
+				for (size_t i = 0; i < nb; ++i) {
+					for (size_t t = 0; t < k; ++t)
+						in[i * k + t] = pinned().dev(shards[ids[i0 + i] * n + w.plan->valid[t]]);
+					for (size_t r = 0; r < nmiss; ++r)
+						outp[i * nmiss + r] = pinned().dev(out[ids[i0 + i] * n + w.plan->missing[r]]);
+				}
+				uint8_t *mir = sums ? st.d_big + (q & 1) * half : nullptr;
+				if (sums && q >= 2 && hipStreamWaitEvent(up, st.ev_seg[2 + (q & 1)], 0) != hipSuccess)
+					rc = fail(GEC_E_DEVICE, "hipStreamWaitEvent");
+				if (!rc)
+					rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), outp.data(), (int)nmiss, S, w.plan->rows.v.data(), up, mir);
+				if (rc || !sums)
+					continue;
+				uint8_t *d_sums = mir + zch * n * S;
+				hipError_t e = hipEventRecord(st.ev_seg[q & 1], up);
+				if (e == hipSuccess)
+					e = hipStreamWaitEvent(chain, st.ev_seg[q & 1], 0);
+				if (e != hipSuccess) {
+					rc = fail(GEC_E_DEVICE, "chunk event");
+					continue;
+				}
+				rc = blake2_dev(c, nb * per, mir, nullptr, nullptr, S, S, d_sums, chain, 0, 0, 0, true);
+				if (!rc && hipMemcpyAsync(st.h_buf + sum_off, d_sums, nb * per * 32, hipMemcpyDeviceToHost, chain) != hipSuccess)
+					rc = fail(GEC_E_DEVICE, "hipMemcpyAsync (shard sums)");
+				if (!rc && hipEventRecord(st.ev_seg[2 + (q & 1)], chain) != hipSuccess)
+					rc = fail(GEC_E_DEVICE, "hipEventRecord");
+				sum_off += nb * per * 32;
+			}
+		}
+		const hipError_t e1 = hipStreamSynchronize(up), e2 = sums ? hipStreamSynchronize(chain) : hipSuccess;  // also on error: queued launches read the tables
+		if (rc)
+			return rc;
+		HIP_TRY(e1);
+		HIP_TRY(e2);
+		if (sums)
+			for (size_t wi = 0; wi < work.size(); ++wi) {
+				const Work &w = work[wi];
+				const size_t nmiss = w.plan->missing.size(), per = k + nmiss;
+				for (size_t i = 0; i < w.ids->size(); ++i) {
+					const uint8_t *src = st.h_buf + sum_base[wi] + i * per * 32;
+					const size_t b = (*w.ids)[i];
+					for (size_t t = 0; t < k; ++t)
+						std::memcpy(in_sums + 32 * (b * n + w.plan->valid[t]), src + 32 * t, 32);
+					for (size_t r = 0; r < nmiss; ++r)
+						std::memcpy(out_sums + 32 * (b * n + w.plan->missing[r]), src + 32 * (k + r), 32);
+				}
+			}
 		return GEC_OK;
+	}
+	if (in_sums) {
+		// buffers the device cannot address: the staged reconstruct, then the checksums of what was read and written in
+		// a second trip
+		int rc = reconstruct_batch_impl(c, nblocks, shards, out, S, data_only, nullptr, nullptr);
+		if (rc)
+			return rc;
+		std::vector<const uint8_t *> msgs;
+		std::vector<size_t> lens, where;
+		std::vector<uint8_t *> dst;
+		for (const Work &w : work)
+			for (size_t b : *w.ids) {
+				for (size_t t = 0; t < k; ++t) {
+					msgs.push_back(shards[b * n + w.plan->valid[t]]);
+					dst.push_back(in_sums + 32 * (b * n + w.plan->valid[t]));
+				}
+				for (int j : w.plan->missing) {
+					msgs.push_back(out[b * n + j]);
+					dst.push_back(out_sums + 32 * (b * n + j));
+				}
+			}
+		lens.assign(msgs.size(), S);
+		std::vector<uint8_t> tmp(msgs.size() * 32);
+		rc = gec_shardsum_batch(c, msgs.size(), msgs.data(), lens.data(), tmp.data());
+		for (size_t i = 0; !rc && i < msgs.size(); ++i)
+			std::memcpy(dst[i], tmp.data() + 32 * i, 32);
+		return rc;
 	}
 	for (const Work &wk : work) {
 		const std::vector<size_t> &ids = *wk.ids;
@@ -3184,6 +3274,20 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *con
 			return rc;
 	}
 	return GEC_OK;
+}
+
+int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, uint8_t *const *out, size_t S,
+			  int data_only)
+{
+	return reconstruct_batch_impl(c, nblocks, shards, out, S, data_only, nullptr, nullptr);
+}
+
+int gec_reconstruct_hash_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, uint8_t *const *out, size_t S,
+			       int data_only, uint8_t *in_sums, uint8_t *out_sums)
+{
+	if (!in_sums || !out_sums)
+		return fail(GEC_E_INVALID_ARG, "NULL checksum output");
+	return reconstruct_batch_impl(c, nblocks, shards, out, S, data_only, in_sums, out_sums);
 }
 
 }  // extern "C"

@@ -182,6 +182,17 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks,
 			  const uint8_t *const *shards, uint8_t *const *out,
 			  size_t S, int data_only);
 
+/* gec_reconstruct_batch plus, from the same trip, the shard checksums (gec_shardsum_batch) of the k shards that
+ * were READ for every block (in_sums[32*(b*n + j)] for the first k present shards j; other entries untouched) and
+ * of the shards that were WRITTEN (out_sums[32*(b*n + j)]).  The resync worker's rebuild
+ * (src/block/resync.rs:485-499, "fetching absent but needed block") in one pass over the link: the caller
+ * compares in_sums with the shard headers it read and stamps out_sums into the headers it writes.  Pinned
+ * buffers: one pointer-table kernel per erasure pattern that also mirrors what it reads and writes into device
+ * memory, where the checksums are computed beside the next chunk's transfer. */
+int gec_reconstruct_hash_batch(const gec_codec *c, size_t nblocks,
+			       const uint8_t *const *shards, uint8_t *const *out,
+			       size_t S, int data_only, uint8_t *in_sums, uint8_t *out_sums);
+
 /* --------------------------------------------- device-resident entry points
  * Used by bench.py (no PCIe in the timed region) and by callers that already
  * hold blocks in HBM.  All device pointers must be 16-byte aligned, strides

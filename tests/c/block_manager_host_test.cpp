@@ -309,6 +309,29 @@ static void run_round2(int k, int m)
 		CHECK(gbm_block_rc(mg, h, rc) == GBM_OK && rc[1] == 0);               // clear_deleted_block_rc
 	}
 
+	if (m >= 2)  // (with one parity shard the corrupt shard alone uses up the code's tolerance)
+	// (1b) the rebuild reads a shard that does not match its checksum: it is set aside and the block goes through the
+	//      second pass (checksums verified in the gather, next holder asked) -- both shards are back after ONE resync
+	{
+		std::vector<uint8_t> d = pattern(400000, 9);
+		uint8_t h[32];
+		gbm_blake2sum(d.data(), d.size(), h);
+		std::vector<int> who(n);
+		CHECK(gbm_storage_nodes_of(mg, h, who.data()) == GBM_OK);
+		CHECK(gbm_rpc_put_block(mg, h, d.data(), d.size(), 0, nullptr) == GBM_OK);
+		CHECK(gbm_block_incref(mg, h) == GBM_OK);
+		CHECK(gbm_node_delete_shard(mg, who[n - 1], h, n - 1) == GBM_OK);
+		CHECK(gbm_node_corrupt_shard(mg, who[0], h, 0, 1234, 0x40, /*fix_checksum=*/0) == GBM_OK);
+		CHECK(gbm_resync_block(mg, h, &changed) == GBM_OK && changed == 2);
+		for (int j = 0; j < n; ++j)
+			CHECK(gbm_node_has_shard(mg, who[j], h, j));
+		CHECK(gbm_rpc_get_block(mg, h, nullptr, out.data(), out.size(), &got) == GBM_OK && got == d.size());
+		CHECK(std::memcmp(out.data(), d.data(), got) == 0);
+		uint8_t bad = 9;
+		CHECK(gbm_scrub(mg, 1, h, &bad) == GBM_OK && bad == 0);
+		CHECK(gbm_block_decref(mg, h) == GBM_OK);
+	}
+
 	// (2) prevent_compression (SSE-C blocks, put.rs:576) + raw / streaming gets
 	if (gbm_set_compression_level(mg, 1, 1) == GBM_OK) {
 		std::vector<uint8_t> d = pattern(700000, 77);

@@ -88,6 +88,27 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nb, const uint8_t *const *s
 	return GEC_OK;
 }
 
+int gec_reconstruct_hash_batch(const gec_codec *c, size_t nb, const uint8_t *const *shards, uint8_t *const *out, size_t S,
+			       int data_only, uint8_t *in_sums, uint8_t *out_sums)
+{
+	int rc = gec_reconstruct_batch(c, nb, shards, out, S, data_only);
+	if (rc)
+		return rc;
+	const int k = c->k, n = c->k + c->m;
+	for (size_t b = 0; b < nb; ++b) {
+		int seen = 0;
+		for (int j = 0; j < n; ++j) {
+			if (shards[b * n + j]) {
+				if (seen++ < k)
+					gbm_shardsum(shards[b * n + j], S, in_sums + 32 * (b * n + j));
+			} else if (out[b * n + j] && !(data_only && j >= k)) {
+				gbm_shardsum(out[b * n + j], S, out_sums + 32 * (b * n + j));
+			}
+		}
+	}
+	return GEC_OK;
+}
+
 // read path in one trip: checksums of the first k present shards, rebuild of missing data shards, block checksum
 int gec_decode_verify_batch(const gec_codec *c, size_t nb, const uint8_t *const *shards, size_t S, const size_t *block_len,
 			    uint8_t *const *rebuilt, uint8_t *shard_sums, uint8_t *block_sums)

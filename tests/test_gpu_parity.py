@@ -979,6 +979,58 @@ def test_verify_hash_batch_scrub_in_one_trip(coracle, k, m, S, nb, pin):
         host_free(arena)
 
 
+@pytest.mark.parametrize("pin", [False, True], ids=["pageable", "pinned"])
+def test_reconstruct_hash_batch_rebuild_and_checksums_in_one_trip(coracle, rs104, pin):
+    """gec_reconstruct_hash_batch: per block a different erasure pattern and a different set of wanted shards (NULL
+    output = not wanted) -> rebuilt shards vs the oracle, checksums of exactly the first k present shards and of
+    exactly the written shards vs hashlib's tree mode, everything else untouched; 150 blocks = several chunks."""
+    import ctypes
+
+    from garage_amd.codec import host_alloc, host_free
+
+    lib = _lib.lib
+    k, m, n, S, nb = 10, 4, 14, 104896, 150
+    rng = np.random.default_rng(77)
+    data = rng.integers(0, 256, (nb, k, S), dtype=np.uint8)
+    par = coracle.encode_batch(k, m, data, coracle.AVX2, threads=8)
+    arena = host_alloc(nb * n * S) if pin else np.empty(nb * n * S, dtype=np.uint8)
+    full = arena.reshape(nb, n, S)
+    full[:, :k] = data
+    full[:, k:] = par
+    outbuf = host_alloc(nb * m * S) if pin else np.empty(nb * m * S, dtype=np.uint8)
+    outbuf[:] = 0
+    sp = (ctypes.c_void_p * (nb * n))()
+    op = (ctypes.c_void_p * (nb * n))()
+    lost, wanted = [], []
+    for b in range(nb):
+        pat = b % 6
+        ls = [(3,), (0, 13), (1, 2, 11, 12), (9,), (10, 11), (0, 5, 7, 9)][pat]
+        ws = [j for i, j in enumerate(ls) if not (pat == 2 and i == 1)]      # pattern 2: shard 2 is missing but not wanted
+        lost.append(ls)
+        wanted.append(ws)
+        for j in range(n):
+            sp[b * n + j] = None if j in ls else arena.ctypes.data + (b * n + j) * S
+        for i, j in enumerate(ws):
+            op[b * n + j] = outbuf.ctypes.data + (b * m + i) * S
+    u8 = ctypes.POINTER(ctypes.c_uint8)
+    ins = np.zeros((nb, n, 32), dtype=np.uint8)
+    outs = np.zeros((nb, n, 32), dtype=np.uint8)
+    _lib.check(lib.gec_reconstruct_hash_batch(rs104._h, nb, sp, op, S, 0, ins.ctypes.data_as(u8), outs.ctypes.data_as(u8)),
+               "gec_reconstruct_hash_batch")
+    ob = outbuf.reshape(nb, m, S)
+    for b in range(nb):
+        for i, j in enumerate(wanted[b]):
+            assert np.array_equal(ob[b, i], full[b, j]), (b, j)
+        if b % 7 == 0 or b >= nb - 6:
+            read = [j for j in range(n) if j not in lost[b]][:k]
+            for j in range(n):
+                assert ins[b, j].tobytes() == (g.shardsum(full[b, j].tobytes()) if j in read else bytes(32)), (b, j, "in")
+                assert outs[b, j].tobytes() == (g.shardsum(full[b, j].tobytes()) if j in wanted[b] else bytes(32)), (b, j, "out")
+    if pin:
+        host_free(arena)
+        host_free(outbuf)
+
+
 def test_zero_copy_encode_more_blocks_than_one_grid(coracle):
     """gf_apply_ptrs puts the block index in gridDim.y (<= 65535): 70 000 tiny pinned blocks take two launches."""
     import ctypes
