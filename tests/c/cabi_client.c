@@ -188,6 +188,39 @@ int main(int argc, char **argv)
 	const uint8_t *sh2[4] = {blk, NULL, NULL, par};
 	uint8_t *outp[4] = {NULL, NULL, NULL, NULL};
 	CHECK(gec_reconstruct_batch(c, 1, sh2, outp, S, 0) == GEC_E_TOO_FEW_PRESENT);
+	{
+		/* scrub in one trip and rebuild in one trip, from ordinary and from pinned memory: the checksums they
+		 * return are gec_shardsum_batch's */
+		uint8_t want[4 * 32], sums[4 * 32], ins[4 * 32], outs[4 * 32];
+		const size_t lens4[4] = {S, S, S, S};
+		CHECK(gec_shardsum_batch(c, 4, sh, lens4, want) == GEC_OK);
+		for (int pinned = 0; pinned < 2; pinned++) {
+			uint8_t *arena = pinned ? (uint8_t *)gec_host_alloc(5 * S) : (uint8_t *)malloc(5 * S);
+			CHECK(arena != NULL);
+			memcpy(arena, blk, 3 * S);
+			memcpy(arena + 3 * S, par, S);
+			const uint8_t *shp[4] = {arena, arena + S, arena + 2 * S, arena + 3 * S};
+			memset(sums, 0, sizeof sums);
+			CHECK(gec_verify_hash_batch(c, 1, shp, S, &ok, sums) == GEC_OK && ok == 1 && memcmp(sums, want, sizeof want) == 0);
+			arena[S + 9] ^= 4;
+			CHECK(gec_verify_hash_batch(c, 1, shp, S, &ok, sums) == GEC_OK && ok == 0);
+			CHECK(memcmp(sums, want, 32) == 0 && memcmp(sums + 32, want + 32, 32) != 0);
+			/* shard 1 lost: rebuilt into the spare slot, checksums of shards 0, 2, 3 read and of shard 1 written */
+			const uint8_t *sh3[4] = {arena, NULL, arena + 2 * S, arena + 3 * S};
+			uint8_t *out3[4] = {NULL, arena + 4 * S, NULL, NULL};
+			memset(ins, 0, sizeof ins);
+			memset(outs, 0, sizeof outs);
+			CHECK(gec_reconstruct_hash_batch(c, 1, sh3, out3, S, 0, ins, outs) == GEC_OK);
+			CHECK(memcmp(arena + 4 * S, blk + S, S) == 0);
+			CHECK(memcmp(ins, want, 32) == 0 && memcmp(ins + 64, want + 64, 64) == 0 && memcmp(outs + 32, want + 32, 32) == 0);
+			for (int i = 0; i < 32; i++)
+				CHECK(ins[32 + i] == 0 && outs[i] == 0);
+			if (pinned)
+				gec_host_free(arena);
+			else
+				free(arena);
+		}
+	}
 	gec_codec_destroy(c);
 
 	/* ---- blake2sum on the device: RFC 7693 "abc" (blake2b-512, first 32 bytes = Garage's blake2sum),
