@@ -663,6 +663,12 @@ def host_path_objects() -> dict:
         out["block_manager"] = block_manager_rates()
     except Exception as e:  # noqa: BLE001 -- secondary numbers must never cost the headline line
         out.setdefault("pcie_inclusive", {"error": f"{type(e).__name__}: {e}"[:300]})
+    try:
+        from tools.host_path_bench import maintenance_rates
+
+        out["block_manager"]["maintenance"] = maintenance_rates(256)   # scrub / resync of the mirror
+    except Exception as e:  # noqa: BLE001
+        out.setdefault("block_manager", {})["maintenance"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
 
 

@@ -194,9 +194,9 @@ def maintenance_rates(nb: int = 512, root: str = "") -> dict:
         else:
             mgr = bn.NativeBlockManager(codec, 16)
         try:
-            t_put, _ = _best(lambda: mgr.rpc_put_blocks(items), 2)
+            t_put, _ = _best(lambda: mgr.rpc_put_blocks(items), 4)   # (the first two size the pinned buffer pool)
             outs = [np.empty(L, dtype=np.uint8) for _ in range(nb)]
-            t_get, _ = _best(lambda: mgr.rpc_get_blocks(hashes, L, out=outs), 2)
+            t_get, _ = _best(lambda: mgr.rpc_get_blocks(hashes, L, out=outs), 3)
             assert outs[7].tobytes() == blocks[7]
             st = {}
             t_scrub, _ = _best(lambda: st.update(mgr.scrub_all(256)), 2)
@@ -215,8 +215,8 @@ def maintenance_rates(nb: int = 512, root: str = "") -> dict:
             assert mgr.scrub_all(256)["corruptions"] == 0 and all(mgr.node_has_shard(3, h, mgr.storage_nodes_of(h).index(3))
                                                                   for h in hashes[:50] if 3 in mgr.storage_nodes_of(h))
             res[kind] = {
-                "rpc_put_blocks_GiBps": round(gib / t_put, 2),
-                "rpc_get_blocks_GiBps": round(gib / t_get, 2),
+                **({"rpc_put_blocks_GiBps": round(gib / t_put, 2), "rpc_get_blocks_GiBps": round(gib / t_get, 2)}
+                   if kind == "directories" else {}),   # memory nodes: block_manager_rates' numbers
                 "scrub_all_GiBps": round(gib / t_scrub, 2),
                 "resync_one_lost_node": {"blocks_queued": nb, "shards_rebuilt": lost, "seconds": round(t_resync, 4),
                                          "GiBps_of_blocks_repaired": round(lost * L / 2**30 / t_resync, 2),
