@@ -292,14 +292,21 @@ __device__ __forceinline__ uint64_t b2_pin(uint64_t v)
 		b = b2_rotr<63>(b ^ c);           \
 	}
 
-// Compresses the block staged in slot `cur`.  ax/y come in holding (a + x) and y of round 0's column
+// Compresses the block staged in the current slot.  ax/y come in holding (a + x) and y of round 0's column
 // step (x, y gathered by the caller or by the previous call) and leave holding those of the NEXT
-// block's, whose words are read from slot `nxt` (garbage after the last block: never used).  The state
+// block's, whose words are read from the other slot (garbage after the last block: never used).  The state
 // words a live inside ax: h_a is recovered at the end as ax - (next x).
-__device__ __forceinline__ void b2q_compress(uint64_t &ha, uint64_t &hb, uint32_t cur, uint32_t nxt, uint32_t q7, uint32_t q,
-					     uint64_t t, bool last, uint64_t &x, uint64_t &y)
+// wa[r][i]: LDS byte address, in slot 0, of the message word lane q needs at round r (column x, column y,
+// diagonal x, diagonal y) -- computed once per kernel; the two slots are a compile-time distance apart, so which
+// slot a read goes to is an immediate offset on the ds_read (ODD = the current block sits in slot 1): no address
+// arithmetic is left in the compression loop.
+constexpr uint32_t B2Q_SLOT1 = 16 * B2Q_SLOT;
+
+template <bool ODD>
+__device__ __forceinline__ void b2q_compress(uint64_t &ha, uint64_t &hb, const uint32_t (&wa)[10][4], uint32_t q, uint64_t t,
+					     bool last, uint64_t &x, uint64_t &y)
 {
-	constexpr B2QSchedule SCH = b2q_schedule();
+	constexpr uint32_t CUR = ODD ? B2Q_SLOT1 : 0, NXT = ODD ? 0 : B2Q_SLOT1;
 	const uint64_t IVq = q == 0 ? 0x6a09e667f3bcc908ULL : q == 1 ? 0xbb67ae8584caa73bULL
 			   : q == 2 ? 0x3c6ef372fe94f82bULL : 0xa54ff53a5f1d36f1ULL;
 	const uint64_t IVq4 = q == 0 ? 0x510e527fade682d1ULL : q == 1 ? 0x9b05688c2b3e6c1fULL
@@ -310,20 +317,20 @@ __device__ __forceinline__ void b2q_compress(uint64_t &ha, uint64_t &hb, uint32_
 		d ^= t;
 	if (q == 2 && last)
 		d = ~d;
-#define GEC_B2Q_WORD(slot, packed) (*reinterpret_cast<lds_u64_t *>((slot) + __builtin_amdgcn_ubfe((packed), q7, 7)))
+#define GEC_B2Q_WORD(off, r, i) (*reinterpret_cast<lds_u64_t *>(wa[(r) % 10][i] + (off)))
 #pragma unroll
 	for (int r = 0; r < 12; ++r) {
 		// column step; the diagonal step's words are gathered first, a whole step ahead of their use
-		const uint64_t dx = GEC_B2Q_WORD(cur, SCH.w[r][2]);
-		const uint64_t dy = GEC_B2Q_WORD(cur, SCH.w[r][3]);
+		const uint64_t dx = GEC_B2Q_WORD(CUR, r, 2);
+		const uint64_t dy = GEC_B2Q_WORD(CUR, r, 3);
 		__builtin_amdgcn_sched_barrier(0);  // keep the gathers up here: hipcc otherwise sinks them next to their use
 		GEC_B2Q_STEP(ax, b, c, d, y, dx)
 		b = b2_quad_perm<0x39>(b);
 		c = b2_quad_perm<0x4E>(c);
 		d = b2_quad_perm<0x93>(d);
 		// diagonal step; the next column step's words (next round, or next block) are gathered first
-		x = r < 11 ? GEC_B2Q_WORD(cur, SCH.w[r < 11 ? r + 1 : 0][0]) : GEC_B2Q_WORD(nxt, SCH.w[0][0]);
-		y = r < 11 ? GEC_B2Q_WORD(cur, SCH.w[r < 11 ? r + 1 : 0][1]) : GEC_B2Q_WORD(nxt, SCH.w[0][1]);
+		x = r < 11 ? GEC_B2Q_WORD(CUR, r + 1, 0) : GEC_B2Q_WORD(NXT, 0, 0);
+		y = r < 11 ? GEC_B2Q_WORD(CUR, r + 1, 1) : GEC_B2Q_WORD(NXT, 0, 1);
 		__builtin_amdgcn_sched_barrier(0);
 		GEC_B2Q_STEP(ax, b, c, d, dy, x)
 		b = b2_quad_perm<0x93>(b);
@@ -365,6 +372,42 @@ __device__ __forceinline__ void b2q_fetch(const uint8_t *p, uint64_t off, uint64
 	w1 = u64x2{w[2], w[3]};
 }
 
+// One block of the chain: stage block blk+1 (requested one step ago) into the other slot, request block blk+2,
+// compress block blk out of the current slot.  ODD: the current slot is slot 1.
+struct B2QLane {
+	const uint8_t *pq;   // message + 32*q: this lane's quarter of block 0
+	uint64_t len, nblk, b1;
+	uint32_t q, stage;   // stage = LDS address of this lane's quarter in slot 0
+	u64x2 w0, w1;
+	uint64_t ha, hb, x, y;
+};
+
+template <bool ODD>
+__device__ __forceinline__ void b2q_block(B2QLane &L, const uint32_t (&wa)[10][4], uint64_t blk)
+{
+	typedef __attribute__((address_space(3))) u64x2 lds_u64x2_w;
+	if (blk + 1 < L.b1) {  // block blk+1 has arrived: stage it
+		lds_u64x2_w *s = reinterpret_cast<lds_u64x2_w *>(L.stage + (ODD ? 0 : B2Q_SLOT1));
+		s[0] = L.w0;
+		s[1] = L.w1;
+	}
+	if (blk + 2 < L.b1) {  // block blk+2: on its way from HBM while block blk is compressed
+		if (blk + 3 < L.nblk) {  // not the message's last block: whole, no bounds to check
+			const u64x2 *g = reinterpret_cast<const u64x2 *>(L.pq + (blk + 2) * 128);
+			L.w0 = __builtin_nontemporal_load(g);
+			L.w1 = __builtin_nontemporal_load(g + 1);
+		} else {
+			b2q_fetch(L.pq - 32 * L.q, (blk + 2) * 128, L.len, L.q, L.w0, L.w1);
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	const bool last = blk + 1 == L.nblk;
+	b2q_compress<ODD>(L.ha, L.hb, wa, L.q, last ? L.len : (blk + 1) * 128, last, L.x, L.y);
+	__builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t lds[2 * 16 * B2Q_SLOT];
@@ -377,60 +420,59 @@ __global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
 	const uint8_t *p = b2_msg_ptr(a, ii);
 	const uint64_t len = a.len ? a.len[ii] : a.uniform_len;
 	const uint32_t slot0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)(lds + (lane >> 2) * B2Q_SLOT);
-	const uint32_t slot_xor = 16 * B2Q_SLOT;  // slot1 = slot0 + 16*B2Q_SLOT (add/sub alternate below)
 	const uint32_t q7 = q * 7;
-	uint64_t ha = (q == 0 ? 0x6a09e667f3bcc908ULL ^ 0x01010040ULL : q == 1 ? 0xbb67ae8584caa73bULL
-		       : q == 2 ? 0x3c6ef372fe94f82bULL : 0xa54ff53a5f1d36f1ULL);
-	uint64_t hb = (q == 0 ? 0x510e527fade682d1ULL : q == 1 ? 0x9b05688c2b3e6c1fULL
-		       : q == 2 ? 0x1f83d9abfb41bd6bULL : 0x5be0cd19137e2179ULL);
+	B2QLane L;
+	L.ha = (q == 0 ? 0x6a09e667f3bcc908ULL ^ 0x01010040ULL : q == 1 ? 0xbb67ae8584caa73bULL
+		: q == 2 ? 0x3c6ef372fe94f82bULL : 0xa54ff53a5f1d36f1ULL);
+	L.hb = (q == 0 ? 0x510e527fade682d1ULL : q == 1 ? 0x9b05688c2b3e6c1fULL
+		: q == 2 ? 0x1f83d9abfb41bd6bULL : 0x5be0cd19137e2179ULL);
 	typedef __attribute__((address_space(3))) u64x2 lds_u64x2_w;
 	const uint64_t nblk = len ? (len + 127) / 128 : 1;  // the empty message still has one (all-zero, final) block
 	const uint64_t b0 = a.seg_begin_blk, b1 = nblk < a.seg_end_blk ? nblk : a.seg_end_blk;
 	if (b0 > 0 && b0 < b1) {  // resume
-		ha = a.state[8ull * ii + q];
-		hb = a.state[8ull * ii + 4 + q];
+		L.ha = a.state[8ull * ii + q];
+		L.hb = a.state[8ull * ii + 4 + q];
 	}
-	u64x2 w0, w1;
-	b2q_fetch(p, b0 * 128, len, q, w0, w1);
+	L.pq = p + 32 * q;
+	L.len = len;
+	L.nblk = nblk;
+	L.b1 = b1;
+	L.q = q;
+	L.stage = slot0 + 32 * q;
+	// the message-word addresses of this lane for every round (rounds 10 and 11 repeat 0 and 1)
+	constexpr B2QSchedule SCH = b2q_schedule();
+	uint32_t wa[10][4];
+#pragma unroll
+	for (int r = 0; r < 10; ++r)
+#pragma unroll
+		for (int w = 0; w < 4; ++w)
+			wa[r][w] = slot0 + __builtin_amdgcn_ubfe(SCH.w[r][w], q7, 7);
+	b2q_fetch(p, b0 * 128, len, q, L.w0, L.w1);
 	{
-		lds_u64x2_w *s = reinterpret_cast<lds_u64x2_w *>(slot0 + 32 * q);
-		s[0] = w0;
-		s[1] = w1;
+		lds_u64x2_w *s = reinterpret_cast<lds_u64x2_w *>(L.stage);
+		s[0] = L.w0;
+		s[1] = L.w1;
 	}
 	if (b0 + 1 < b1)
-		b2q_fetch(p, (b0 + 1) * 128, len, q, w0, w1);
+		b2q_fetch(p, (b0 + 1) * 128, len, q, L.w0, L.w1);
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-	constexpr B2QSchedule SCH = b2q_schedule();
-	uint64_t x = *reinterpret_cast<lds_u64_t *>(slot0 + __builtin_amdgcn_ubfe(SCH.w[0][0], q7, 7));
-	uint64_t y = *reinterpret_cast<lds_u64_t *>(slot0 + __builtin_amdgcn_ubfe(SCH.w[0][1], q7, 7));
-	uint32_t cur = slot0, nxt = slot0 + slot_xor;
-	for (uint64_t blk = b0; blk < b1; ++blk) {
-		if (blk + 1 < b1) {  // block blk+1 has arrived (requested one iteration ago): stage it
-			lds_u64x2_w *s = reinterpret_cast<lds_u64x2_w *>(nxt + 32 * q);
-			s[0] = w0;
-			s[1] = w1;
-		}
-		if (blk + 2 < b1)    // block blk+2: on its way from HBM while block blk is compressed
-			b2q_fetch(p, (blk + 2) * 128, len, q, w0, w1);
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		const bool last = blk + 1 == nblk;
-		b2q_compress(ha, hb, cur, nxt, q7, q, last ? len : (blk + 1) * 128, last, x, y);
-		__builtin_amdgcn_wave_barrier();
-		const uint32_t tmp = cur;
-		cur = nxt;
-		nxt = tmp;
+	L.x = *reinterpret_cast<lds_u64_t *>(wa[0][0]);
+	L.y = *reinterpret_cast<lds_u64_t *>(wa[0][1]);
+	// two blocks per trip: which slot is current is then a compile-time fact of each half
+	for (uint64_t blk = b0; blk < b1; blk += 2) {
+		b2q_block<false>(L, wa, blk);
+		if (blk + 1 < b1)
+			b2q_block<true>(L, wa, blk + 1);
 	}
 	if (!live || b0 >= b1)
 		return;
 	if (b1 == nblk) {
-		reinterpret_cast<uint64_t *>(b2_out_ptr(a, i))[q] = ha;  // h[0..3] = first 32 bytes
+		reinterpret_cast<uint64_t *>(b2_out_ptr(a, i))[q] = L.ha;  // h[0..3] = first 32 bytes
 	} else {
-		a.state[8ull * i + q] = ha;
-		a.state[8ull * i + 4 + q] = hb;
+		a.state[8ull * i + q] = L.ha;
+		a.state[8ull * i + 4 + q] = L.hb;
 	}
 }
 
