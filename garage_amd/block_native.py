@@ -27,7 +27,7 @@ SYMBOLS = [
     "gbm_resync_errors_len", "gbm_resync_worker_start", "gbm_resync_worker_stop",
     "gbm_scrub", "gbm_scrub_all", "gbm_scrub_state", "gbm_repair_all", "gbm_node_set_down", "gbm_node_has_shard", "gbm_node_delete_shard",
     "gbm_node_corrupt_shard", "gbm_node_shard_header", "gbm_node_order_violations", "gbm_metrics", "gbm_gpu_hashed",
-    "gbm_set_read_hedge", "gbm_hedged_reads", "gbm_node_set_latency",
+    "gbm_set_read_hedge", "gbm_hedged_reads", "gbm_node_set_latency", "gbm_set_host_block_hash_max",
     "gbm_batcher_create", "gbm_batcher_destroy", "gbm_batcher_put_block", "gbm_batcher_set_ram_buffer_max", "gbm_batcher_stats",
 ]
 
@@ -116,6 +116,7 @@ def _load():
     lib.gbm_hedged_reads.argtypes = [vp]
     lib.gbm_hedged_reads.restype = ctypes.c_uint64
     lib.gbm_node_set_latency.argtypes = [vp, ci, ctypes.c_uint64]
+    lib.gbm_set_host_block_hash_max.argtypes = [vp, sz]
     lib.gbm_resync_block.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ci)]
     lib.gbm_resync_all.argtypes = [vp, ctypes.POINTER(ci)]
     lib.gbm_resync_queue_len.argtypes = [vp]
@@ -347,6 +348,10 @@ class NativeBlockManager:
 
     def node_order_violations(self, node: int) -> int:
         return int(lib.gbm_node_order_violations(self._h, node))
+
+    def set_host_block_hash_max(self, nblocks: int) -> None:
+        """Gets of up to this many blocks verify the block hash on the host pool (0 = always on the device)."""
+        _check(lib.gbm_set_host_block_hash_max(self._h, nblocks), "set_host_block_hash_max")
 
     def set_read_hedge(self, hedge_us: int) -> None:
         """0 = ask the first k holders and go further only on failure; >0 = ask the next holders too when some

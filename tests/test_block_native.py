@@ -147,7 +147,12 @@ def test_native_corruption_resync_scrub(codec, tmp_path):
     evil = pattern_block(200_000, 99)
     mgr.rpc_put_block(hashes[0], evil)
     with pytest.raises(bn.CorruptData):
+        mgr.rpc_get_block(hashes[0])          # (small request: the block hash is checked on the host pool)
+    mgr.set_host_block_hash_max(0)            # ... and on the device, in the decode's trip
+    with pytest.raises(bn.CorruptData):
         mgr.rpc_get_block(hashes[0])
+    assert mgr.rpc_get_block(hashes[2]) == blocks[2]
+    mgr.set_host_block_hash_max(128)
     # rc -> 0: nothing is deleted inside BLOCK_GC_DELAY, every shard after it
     mgr.block_decref(hashes[5])
     assert mgr.resync_all() == 0 and mgr.rpc_get_block(hashes[5]) == blocks[5]
@@ -372,7 +377,9 @@ def test_batcher_coalesces_concurrent_puts():
     [x.join() for x in th]
     assert not errors, errors
     st = bt.stats()
-    assert st["blocks"] == T * PER and st["batches"] < T * PER // 2 and 2 <= st["max_batch"] <= 32, st
+    # (how many batches depends on how the callers' gets interleave -- they take ~1 ms since the block hash of small
+    # requests moved to the host pool -- but 16 callers must coalesce)
+    assert st["blocks"] == T * PER and st["batches"] <= T * PER * 3 // 4 and 4 <= st["max_batch"] <= 32, st
     who = mgr.storage_nodes_of(hashes[0][0])
     for j in range(3):
         mgr.node_set_down(who[j], True)
