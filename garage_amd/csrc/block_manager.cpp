@@ -23,6 +23,7 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -32,6 +33,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <future>
 #include <thread>
 #include <cerrno>
 #include <cstdio>
@@ -689,28 +691,51 @@ struct DirNode : Node {
 			if (i == p.size() || p[i] == '/')
 				::mkdir(p.substr(0, i).c_str(), 0755);
 	}
+	// raw descriptors, one writev / two preads per shard: a shard file is written and read whole, stdio's buffer
+	// would only add a copy (7168 files per 512-block batch: the syscall count is what the node's rate is made of)
 	bool put(const Hash &h, int idx, const Shard &s) override
 	{
-		mkdirs(dir(h));
 		static std::atomic<uint64_t> seq{0};  // unique per writer: two threads may store the same shard
+		const std::string d = dir(h);
 		std::string p = path(h, idx), tmp = p + ".tmp" + std::to_string(::getpid()) + "_" + std::to_string(seq++);
-		FILE *f = std::fopen(tmp.c_str(), "wb");
-		if (!f)
+		int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+		if (fd < 0 && errno == ENOENT) {  // first shard of this prefix
+			mkdirs(d);
+			fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+		}
+		if (fd < 0)
 			return false;
 		uint8_t hdr[GBM_SHARD_HEADER_SIZE];
 		s.hd.pack(hdr);
-		bool ok = std::fwrite(hdr, 1, sizeof(hdr), f) == sizeof(hdr) &&
-			  std::fwrite(s.data.data(), 1, s.data.n, f) == s.data.n;
+		struct iovec iov[2] = {{hdr, sizeof(hdr)}, {const_cast<uint8_t *>(s.data.data()), s.data.n}};
+		size_t left = sizeof(hdr) + s.data.n;
+		bool ok = true;
+		int cur = 0;
+		while (left && ok) {  // (short writes: continue where the kernel stopped)
+			const ssize_t w = ::writev(fd, iov + cur, 2 - cur);
+			if (w < 0) {
+				ok = errno == EINTR;
+				continue;
+			}
+			left -= (size_t)w;
+			size_t adv = (size_t)w;
+			while (cur < 2 && adv >= iov[cur].iov_len)
+				adv -= iov[cur++].iov_len;
+			if (cur < 2) {
+				iov[cur].iov_base = (uint8_t *)iov[cur].iov_base + adv;
+				iov[cur].iov_len -= adv;
+			}
+		}
 		const bool sync = fsync_data.load();
 		if (ok && sync)  // file first, then (after the rename) its directory: manager.rs:775-800
-			ok = std::fflush(f) == 0 && ::fsync(::fileno(f)) == 0;
-		ok = (std::fclose(f) == 0) && ok;
+			ok = ::fsync(fd) == 0;
+		ok = (::close(fd) == 0) && ok;
 		if (ok)
 			ok = std::rename(tmp.c_str(), p.c_str()) == 0;
 		if (!ok)
 			std::remove(tmp.c_str());
 		if (ok && sync) {
-			int dfd = ::open(dir(h).c_str(), O_RDONLY | O_DIRECTORY);
+			int dfd = ::open(d.c_str(), O_RDONLY | O_DIRECTORY);
 			if (dfd >= 0) {
 				ok = ::fsync(dfd) == 0;
 				::close(dfd);
@@ -720,16 +745,28 @@ struct DirNode : Node {
 		}
 		return ok;
 	}
+	static bool read_all(int fd, uint8_t *dst, size_t len, off_t off)
+	{
+		while (len) {
+			const ssize_t r = ::pread(fd, dst, len, off);
+			if (r < 0 && errno == EINTR)
+				continue;
+			if (r <= 0)
+				return false;
+			dst += r;
+			len -= (size_t)r;
+			off += r;
+		}
+		return true;
+	}
 	bool get(const Hash &h, int idx, Shard &s) override
 	{
-		FILE *f = std::fopen(path(h, idx).c_str(), "rb");
-		if (!f)
+		const int fd = ::open(path(h, idx).c_str(), O_RDONLY | O_CLOEXEC);
+		if (fd < 0)
 			return false;
-		std::fseek(f, 0, SEEK_END);
-		const long n = std::ftell(f);
-		std::fseek(f, 0, SEEK_SET);
+		struct stat stt;
 		uint8_t hdr[GBM_SHARD_HEADER_SIZE];
-		bool ok = n >= (long)sizeof(hdr) && std::fread(hdr, 1, sizeof(hdr), f) == sizeof(hdr);
+		bool ok = ::fstat(fd, &stt) == 0 && stt.st_size >= (off_t)sizeof(hdr) && read_all(fd, hdr, sizeof(hdr), 0);
 		// a file whose header does not parse is handed up as an invalid shard (shard_len != size) so that
 		// the reader treats it like a checksum failure: *.corrupted + resync
 		if (ok && !s.hd.unpack(hdr, sizeof(hdr))) {
@@ -737,11 +774,11 @@ struct DirNode : Node {
 			s.hd.idx = 0xff;
 		}
 		if (ok) {
-			const size_t len = (size_t)n - sizeof(hdr);
+			const size_t len = (size_t)stt.st_size - sizeof(hdr);
 			s.data = bufs->get(len);
-			ok = std::fread(s.data.mut(), 1, len, f) == len;
+			ok = read_all(fd, s.data.mut(), len, sizeof(hdr));
 		}
-		std::fclose(f);
+		::close(fd);
 		return ok;
 	}
 	bool has(const Hash &h, int idx) override
@@ -2613,6 +2650,19 @@ int gbm_scrub(gbm_manager *mg, size_t nb, const uint8_t *hashes, uint8_t *bad_ou
 
 // RepairWorker (src/block/repair.rs:30-150): phase 1 queues every hash of the refcount table, phase 2 every hash that
 // is actually stored somewhere ("blocks we are storing but don't actually need").
+// every hash any reachable node holds a shard of: the nodes are walked side by side (a directory node's walk is one
+// opendir per prefix directory -- 16 nodes x hundreds of directories, tens of milliseconds when done one after the other)
+static void list_all_nodes(gbm_manager *mg, std::set<Hash> &all)
+{
+	std::vector<std::set<Hash>> per(mg->nodes.size());
+	mg->pool->parallel_for(mg->nodes.size(), [&](size_t i) {
+		if (!mg->nodes[i]->down.load())
+			mg->nodes[i]->list(per[i]);
+	});
+	for (auto &s : per)
+		all.insert(s.begin(), s.end());
+}
+
 int gbm_repair_all(gbm_manager *mg, size_t *queued)
 {
 	if (!mg)
@@ -2623,9 +2673,7 @@ int gbm_repair_all(gbm_manager *mg, size_t *queued)
 		for (auto &kv : st.map)
 			all.insert(kv.first);
 	}
-	for (auto &nd : mg->nodes)
-		if (!nd->down.load())
-			nd->list(all);
+	list_all_nodes(mg, all);
 	for (const Hash &h : all)
 		mg->put_to_resync(h, 0);
 	if (queued)
@@ -2691,19 +2739,49 @@ int gbm_scrub_all(gbm_manager *mg, size_t batch_blocks, uint64_t stats[4])
 	uint64_t st[4] = {0, 0, 0, 0};
 	try {
 		std::set<Hash> all;
-		for (auto &nd : mg->nodes)
-			if (!nd->down.load())
-				nd->list(all);
+		Trace tr("scrub");
+		list_all_nodes(mg, all);
+		tr.lap("list");
 		std::vector<Hash> hs(all.begin(), all.end());
-		for (size_t b0 = 0; b0 < hs.size(); b0 += batch_blocks) {
-			const size_t nb = std::min(batch_blocks, hs.size() - b0);
-			std::vector<Hash> batch(hs.begin() + b0, hs.begin() + b0 + nb);
+		// the next batch's shards are read from the nodes while the current batch is on the device
+		struct Batch {
+			std::vector<Hash> batch;
 			std::vector<Gathered> g;
+			int rc = GBM_OK;
+			std::string err;
+		};
+		auto read_batch = [&](size_t b0) {
+			Batch bt;
+			const size_t nb = std::min(batch_blocks, hs.size() - b0);
+			bt.batch.assign(hs.begin() + b0, hs.begin() + b0 + nb);
 			// shards are accepted on their headers; their checksums come back from the same device trip that checks
 			// the stripe against the code (every byte crosses the link once)
-			int grc = gather_many(mg, batch, nullptr, mg->n, g, /*verify=*/false);
-			if (grc)
-				return grc;
+			try {
+				bt.rc = gather_many(mg, bt.batch, nullptr, mg->n, bt.g, /*verify=*/false);
+				if (bt.rc)
+					bt.err = g_err;  // thread-local: carried to the caller's thread
+			} catch (const std::exception &e) {
+				bt.rc = GBM_E_IO;
+				bt.err = e.what();
+			}
+			return bt;
+		};
+		std::future<Batch> next;
+		if (!hs.empty())
+			next = std::async(std::launch::async, read_batch, (size_t)0);
+		for (size_t b0 = 0; b0 < hs.size(); b0 += batch_blocks) {
+			Batch cur = next.get();
+			tr.lap("wait for the batch's shards");
+			if (b0 + batch_blocks < hs.size())
+				next = std::async(std::launch::async, read_batch, b0 + batch_blocks);
+			if (cur.rc) {
+				if (next.valid())
+					next.wait();
+				return fail(cur.rc, cur.err);
+			}
+			const size_t nb = cur.batch.size();
+			std::vector<Hash> &batch = cur.batch;
+			std::vector<Gathered> &g = cur.g;
 			std::map<size_t, std::vector<size_t>> by_len;
 			auto unreadable = [&](size_t b) {
 				if (mg->get_rc(batch[b]).is_nonzero()) {
@@ -2727,6 +2805,7 @@ int gbm_scrub_all(gbm_manager *mg, size_t batch_blocks, uint64_t stats[4])
 				std::vector<uint8_t> ok(ids.size()), sums(ids.size() * (size_t)mg->n * 32);
 				int rc = gec_verify_hash_batch(mg->codec, ids.size(), sp.data(), kv.first, ok.data(), sums.data());
 				++st[2];
+				tr.lap("verify + checksums");
 				if (rc)
 					return ec_fail(rc, "gec_verify_hash_batch");
 				mg->gpu_hashed += ids.size() * (size_t)mg->n;
