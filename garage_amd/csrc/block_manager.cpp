@@ -1195,11 +1195,11 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 							f->rs = std::move(rs);
 							f->answered = answered;
 							f->done = true;
-							const bool was = rd->satisfied(f->b);
+							const bool was_sat = rd->satisfied(f->b);
 							rd->outstanding[f->b]--;
 							if (answered && f->rs.ok)
 								rd->ok[f->b]++;
-							if (!was && rd->satisfied(f->b))
+							if (!was_sat && rd->satisfied(f->b))
 								rd->unsatisfied--;
 						}
 						rd->cv.notify_all();
@@ -1897,16 +1897,16 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 	// returns the checksums of what it read (compared with the headers) and of what it wrote (stamped into the new
 	// headers) -- gec_reconstruct_hash_batch.  A block that turns out to have read a corrupt shard (set aside,
 	// queued) goes through a second pass whose gather verifies checksums first and moves on to the next holder.
-	auto rebuild_pass = [&](const std::vector<size_t> &rebuild, bool verify_in_gather) -> std::vector<size_t> {
+	auto rebuild_pass = [&](const std::vector<size_t> &todo, bool verify_in_gather) -> std::vector<size_t> {
 		std::vector<size_t> again;
 		std::vector<Hash> hs;
-		for (size_t i : rebuild)
+		for (size_t i : todo)
 			hs.push_back(tasks[i].h);
 		std::vector<Gathered> gs;
 		int grc = gather_many(mg, hs, nullptr, k, gs, verify_in_gather);
 		tr.lap(verify_in_gather ? "gather k + checksums" : "gather k");
-		for (size_t q = 0; q < rebuild.size(); ++q) {
-			ResyncTask &t = tasks[rebuild[q]];
+		for (size_t q = 0; q < todo.size(); ++q) {
+			ResyncTask &t = tasks[todo[q]];
 			if (grc) {
 				t.error = std::string("gather: ") + g_err;
 				t.want.clear();
@@ -1937,7 +1937,7 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 		// chunks pipelined through the link without a host round trip in between (one call per pattern: 14 calls,
 		// 20 ms for a lost node's 449 shards; one call: see tools/host_path_bench.py maintenance)
 		std::map<size_t, std::vector<size_t>> groups;
-		for (size_t i : rebuild)
+		for (size_t i : todo)
 			if (!tasks[i].want.empty())
 				groups[tasks[i].g.meta.shard_len].push_back(i);
 		for (auto &kv : groups) {
