@@ -1443,14 +1443,37 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 		oks[b] = ok;
 	};
 	if (tags) {
+		// order is a per-node property (requests of one stream reach a NODE in `order` order): the nodes are served
+		// side by side, each one walking the blocks in (stream, order) order and taking the shards that are its own
 		std::vector<size_t> order(nb);
 		for (size_t i = 0; i < nb; ++i)
 			order[i] = i;
 		std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
 			return std::tie(tags[x].stream_id, tags[x].order) < std::tie(tags[y].stream_id, tags[y].order);
 		});
-		for (size_t b : order)
-			fan_out(b);
+		std::vector<std::vector<int>> who(nb);
+		for (size_t b = 0; b < nb; ++b)
+			mg->nodes_of(Hash((const char *)hashes + 32 * b, 32), who[b]);
+		std::vector<std::atomic<int>> okc(nb);
+		for (auto &x : okc)
+			x = 0;
+		mg->pool->parallel_for(mg->nodes.size(), [&](size_t node) {
+			for (size_t b : order) {
+				const size_t S = prep[b].S;
+				for (int j = 0; j < n; ++j) {
+					if (who[b][j] != (int)node)
+						continue;
+					const Hash h((const char *)hashes + 32 * b, 32);
+					const Bytes payload = j < k ? prep[b].block.slice((size_t)j * S, S) : prep[b].parity.slice((size_t)(j - k) * S, S);
+					if (send_shard(mg, (int)node, h, j, payload, S, prep[b].plen, prep[b].z, sums.data() + (b * n + j) * 32, &tags[b])) {
+						++okc[b];
+						mg->metrics[0] += S;
+					}
+				}
+			}
+		});
+		for (size_t b = 0; b < nb; ++b)
+			oks[b] = okc[b].load();
 	} else {
 		mg->pool->parallel_for(nb, fan_out);
 	}
