@@ -35,6 +35,10 @@
  *   GEC_BLAKE2_KERNEL=lane|quad A/B: force one of the two (plain) blake2 kernels
  *   GEC_HASH_FORK=0             A/B: encode+checksum on one stream instead of data-shard checksums beside the encode
  *   GEC_MAX_COLS_PER_LAUNCH=n   test hook: exercise the multi-launch split on small inputs
+ *   GEC_ZERO_COPY=0             A/B: pinned caller memory through the device staging pipeline instead of in place
+ *   GEC_UPLOAD_CUS=n            CUs reserved for kernels that read / write host memory (default 16; 0 = no CU masks)
+ *   GEC_VERIFY_SEGMENTS=n       A/B: upload stages of gec_decode_verify_batch (default min(k, 16); 1 = upload, then hash)
+ *   GEC_PINNED_CHUNK_MB=n       chunk size of the staged path for pinned memory (default 128)
  */
 #ifndef GARAGE_EC_H
 #define GARAGE_EC_H
@@ -381,8 +385,12 @@ int gec_encode_hash_batch(const gec_codec *c, size_t nblocks,
  *   - block_sums (may be NULL): blake2sum of the first block_len[b] bytes of block b's data area, i.e. of the
  *     block itself (DataBlock::verify's content-against-name check, src/block/block.rs:69-77).
  * Every checksum kernel runs ONCE over the whole batch (a BLAKE2b chain costs the same however many messages
- * run beside it), the shard checksums beside the decode on a second stream.  Buffers inside pinned ranges
- * (gec_host_alloc / gec_host_register) are read and written by copy kernels directly; others are staged. */
+ * run beside it), the shard checksums beside the decode on their own stream.  Buffers inside pinned ranges
+ * (gec_host_alloc / gec_host_register) are read and written by copy kernels directly, in k stages (data slot s of
+ * every block), and the block checksums of blocks that need no decode advance behind the stages: their chains -- the
+ * longest thing in the call, ~13 ms per MiB of block -- start while the blocks are still arriving.  Other buffers are
+ * staged through pinned pieces.  (One block's chain on a host core takes ~1 ms per MiB: for a handful of blocks pass
+ * block_sums = NULL and hash on the host, as libgarage_block does below 128 blocks.) */
 int gec_decode_verify_batch(const gec_codec *c, size_t nblocks,
 			    const uint8_t *const *shards, size_t S,
 			    const size_t *block_len, uint8_t *const *rebuilt,
