@@ -510,13 +510,20 @@ static void run_round2(int k, int m)
 }
 
 // Hedged reads: a slow data-shard holder must not set the latency of the read.
-static void run_hedged(int k, int m)
+static void run_hedged(int k, int m, const char *dir_root = nullptr)
 {
 	using clk = std::chrono::steady_clock;
 	gec_codec *codec = stub_codec_create(k, m);
 	const int n = k + m;
 	gbm_manager *mg = nullptr;
-	CHECK(gbm_create(codec, n + 2, nullptr, 0, &mg) == GBM_OK);
+	std::vector<std::string> dirs;
+	std::vector<const char *> dirp;
+	if (dir_root)
+		for (int i = 0; i < n + 2; ++i) {
+			dirs.push_back(std::string(dir_root) + "/hedged" + std::to_string(k) + "_" + std::to_string(m) + "/node" + std::to_string(i));
+			dirp.push_back(dirs.back().c_str());
+		}
+	CHECK(gbm_create(codec, n + 2, dir_root ? dirp.data() : nullptr, 0, &mg) == GBM_OK);
 	CHECK(gbm_set_threads(mg, 4) == GBM_OK);
 	const size_t nb = 24;
 	std::vector<std::vector<uint8_t>> blocks(nb);
@@ -600,8 +607,10 @@ int main(int argc, char **argv)
 	run_round2(10, 4);
 	run(3, 1, nullptr);
 	run(10, 4, nullptr);
-	if (argc > 1)
+	if (argc > 1) {
 		run(10, 4, argv[1]);
+		run_hedged(10, 4, argv[1]);  // the same races between first answers and abandoned requests, over files
+	}
 	run_batcher(10, 4);
 	printf("block_manager_host_test: all scenarios OK\n");
 	return 0;
