@@ -189,7 +189,9 @@ def maintenance_rates(nb: int = 512, root: str = "") -> dict:
     for kind in ("memory", "directories"):
         tmp = None
         if kind == "directories":
-            tmp = tempfile.mkdtemp(prefix="gbm_bench_", dir=root or ("/dev/shm" if os.path.isdir("/dev/shm") else None))
+            need = 3 * nb * (K + M) * (g.shard_len(K, L) + 64)   # the shard files, with room for the .tmp copies
+            shm = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > need else None
+            tmp = tempfile.mkdtemp(prefix="gbm_bench_", dir=root or shm)
             mgr = bn.NativeBlockManager(codec, 16, [os.path.join(tmp, f"n{i}") for i in range(16)])
         else:
             mgr = bn.NativeBlockManager(codec, 16)
@@ -222,6 +224,8 @@ def maintenance_rates(nb: int = 512, root: str = "") -> dict:
                                          "GiBps_of_blocks_repaired": round(lost * L / 2**30 / t_resync, 2),
                                          "device_calls": rs_.get("device_calls", rs_.get("batches"))},
             }
+        except Exception as e:  # noqa: BLE001 -- one kind of node failing (a full tmpfs) must not cost the other's numbers
+            res[kind] = {"error": f"{type(e).__name__}: {e}"[:300]}
         finally:
             mgr.close()
             if tmp:
