@@ -3066,7 +3066,12 @@ int gbm_batcher_create(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, 
 	b->mg = m;
 	b->max_blocks = max_blocks;
 	b->max_wait_us = max_wait_us;
-	for (int i = 0; i < 2; ++i)
+	static const int nworkers = [] {
+		const char *e = std::getenv("GBM_BATCHER_WORKERS");
+		const int v = e ? std::atoi(e) : 0;
+		return v >= 1 && v <= 16 ? v : 2;
+	}();
+	for (int i = 0; i < nworkers; ++i)
 		b->workers.emplace_back([b] { b->run(); });
 	*out = b;
 	return GBM_OK;
