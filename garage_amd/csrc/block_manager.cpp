@@ -3005,9 +3005,19 @@ struct gbm_batcher {
 			// system_clock: libstdc++ maps it to pthread_cond_timedwait, which ThreadSanitizer
 			// understands (steady_clock -> pthread_cond_clockwait is not intercepted by gcc 11's
 			// TSan and floods the report with false "double lock" findings)
+			// The linger ends early once arrivals stop: callers come in bursts (the <= 3 parallel puts of a PutObject,
+			// or everybody at once when a batch completes), and waiting out the full linger after the burst is pure
+			// latency -- 3 callers: 0.80 -> 0.55 ms per put.
 			const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(max_wait_us);
-			while (!stop && queue.size() < max_blocks &&
-			       cv_work.wait_until(lk, deadline) != std::cv_status::timeout) {
+			const auto gap = std::chrono::microseconds(std::max(20u, max_wait_us / 6));
+			size_t seen = queue.size();
+			while (!stop && queue.size() < max_blocks) {
+				const auto now = std::chrono::system_clock::now();
+				if (now >= deadline)
+					break;
+				if (cv_work.wait_until(lk, std::min(deadline, now + gap)) == std::cv_status::timeout && queue.size() == seen)
+					break;  // nobody arrived during the gap
+				seen = queue.size();
 			}
 			std::vector<Item *> batch;
 			while (!queue.empty() && batch.size() < max_blocks) {
