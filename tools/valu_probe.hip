@@ -21,8 +21,10 @@ constexpr int ITER = 2000;
 
 // KIND: which instruction; DEP: true = every instruction consumes the previous result
 template <int KIND, bool DEP>
-__global__ __launch_bounds__(64) void probe(uint64_t *out, uint64_t seed)
+__global__ __launch_bounds__(64) void probe(uint64_t *out, uint64_t seed, uint32_t active_lanes)
 {
+	if (threadIdx.x >= active_lanes)  // the rest of the wave runs with a partial EXEC mask
+		return;
 	uint64_t a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, b = seed | 1;
 	uint32_t x0 = (uint32_t)a0, x1 = (uint32_t)a1, x2 = (uint32_t)a2, x3 = (uint32_t)a3, y = (uint32_t)b, sel = 0x02010003;
 	const uint64_t t0 = __builtin_amdgcn_s_memtime();
@@ -93,16 +95,16 @@ __global__ __launch_bounds__(64) void probe(uint64_t *out, uint64_t seed)
 }
 
 template <int KIND>
-void run(const char *name, int per_iter_dep, int per_iter_ind, uint64_t *d_out)
+void run(const char *name, int per_iter_dep, int per_iter_ind, uint64_t *d_out, uint32_t active = 64)
 {
 	uint64_t h[2];
 	double res[2];
 	for (int dep = 0; dep < 2; ++dep) {
 		for (int rep = 0; rep < 2; ++rep) {
 			if (dep)
-				probe<KIND, true><<<1024, 64>>>(d_out, 12345);
+				probe<KIND, true><<<1024, 64>>>(d_out, 12345, active);
 			else
-				probe<KIND, false><<<1024, 64>>>(d_out, 12345);
+				probe<KIND, false><<<1024, 64>>>(d_out, 12345, active);
 			CK(hipDeviceSynchronize());
 		}
 		CK(hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost));
@@ -125,5 +127,12 @@ int main()
 	run<4>("v_perm_b32", 8, 32, d_out);
 	run<5>("v_mov_b32_dpp quad_perm", 8, 32, d_out);
 	run<6>("v_pk_mov_b32", 8, 32, d_out);
+	// does the VALU skip the quarter-wave passes whose lanes are all inactive?  (the quad kernel keeps 16 messages per
+	// wave busy in 64 lanes; 4 messages in 16 lanes would be 4x faster per message if it did)
+	run<2>("v_xor_b32, lanes 0-31 active", 8, 32, d_out, 32);
+	run<2>("v_xor_b32, lanes 0-15 active", 8, 32, d_out, 16);
+	run<2>("v_xor_b32, lanes 0-3 active", 8, 32, d_out, 4);
+	run<0>("v_lshl_add_u64, lanes 0-15 active", 8, 32, d_out, 16);
+	run<5>("v_mov_b32_dpp quad_perm, lanes 0-15 active", 8, 32, d_out, 16);
 	return 0;
 }
