@@ -271,7 +271,10 @@ typedef __attribute__((address_space(3))) const uint64_t lds_u64_t;
 // back to (b + x) + a and both adds wait for the freshly rotated b again.
 __device__ __forceinline__ uint64_t b2_pin(uint64_t v)
 {
+#ifdef GEC_B2Q_PIN  // A/B: since a lone wave is issue-bound, the s_nop the hazard recognizer puts behind every inline asm
+		    // (its result could be a dst_sel write) costs more than the longer dependency chain: 1449 vs 1404 ns
 	asm("" : "+v"(v));
+#endif
 	return v;
 }
 
@@ -318,25 +321,41 @@ __device__ __forceinline__ void b2q_compress(uint64_t &ha, uint64_t &hb, const u
 	if (q == 2 && last)
 		d = ~d;
 #define GEC_B2Q_WORD(off, r, i) (*reinterpret_cast<lds_u64_t *>(wa[(r) % 10][i] + (off)))
+	// The four message words of a round are gathered together, one whole round before they are used (a lone wave pays
+	// an issue slot for every s_waitcnt: LDS returns in order, so ONE wait per round -- "all but the four reads just
+	// issued" -- covers the round's four words, where gathering them pairwise a step ahead cost a wait per use).
+	// w[0..3] = (column x, column y, diagonal x, diagonal y); x and y arrive holding round 0's column words.
+	uint64_t cx = x, cy = y, dx = GEC_B2Q_WORD(CUR, 0, 2), dy = GEC_B2Q_WORD(CUR, 0, 3);
 #pragma unroll
 	for (int r = 0; r < 12; ++r) {
-		// column step; the diagonal step's words are gathered first, a whole step ahead of their use
-		const uint64_t dx = GEC_B2Q_WORD(CUR, r, 2);
-		const uint64_t dy = GEC_B2Q_WORD(CUR, r, 3);
+		// next round's words (or, in the last round, the next block's round-0 column words: the diagonal ones are
+		// read by the next call)
+		uint64_t ncx, ncy, ndx = 0, ndy = 0;
+		if (r < 11) {
+			ncx = GEC_B2Q_WORD(CUR, r + 1, 0);
+			ncy = GEC_B2Q_WORD(CUR, r + 1, 1);
+			ndx = GEC_B2Q_WORD(CUR, r + 1, 2);
+			ndy = GEC_B2Q_WORD(CUR, r + 1, 3);
+		} else {
+			ncx = GEC_B2Q_WORD(NXT, 0, 0);
+			ncy = GEC_B2Q_WORD(NXT, 0, 1);
+		}
 		__builtin_amdgcn_sched_barrier(0);  // keep the gathers up here: hipcc otherwise sinks them next to their use
-		GEC_B2Q_STEP(ax, b, c, d, y, dx)
+		GEC_B2Q_STEP(ax, b, c, d, cy, dx)
 		b = b2_quad_perm<0x39>(b);
 		c = b2_quad_perm<0x4E>(c);
 		d = b2_quad_perm<0x93>(d);
-		// diagonal step; the next column step's words (next round, or next block) are gathered first
-		x = r < 11 ? GEC_B2Q_WORD(CUR, r + 1, 0) : GEC_B2Q_WORD(NXT, 0, 0);
-		y = r < 11 ? GEC_B2Q_WORD(CUR, r + 1, 1) : GEC_B2Q_WORD(NXT, 0, 1);
-		__builtin_amdgcn_sched_barrier(0);
-		GEC_B2Q_STEP(ax, b, c, d, dy, x)
+		GEC_B2Q_STEP(ax, b, c, d, dy, ncx)
 		b = b2_quad_perm<0x93>(b);
 		c = b2_quad_perm<0x4E>(c);
 		d = b2_quad_perm<0x39>(d);
+		cx = ncx;
+		cy = ncy;
+		dx = ndx;
+		dy = ndy;
 	}
+	x = cx;
+	y = cy;
 #undef GEC_B2Q_WORD
 	const uint64_t a = ax - x;  // undo the look-ahead add of the (not yet started) next step
 	ha ^= a ^ c;
@@ -408,6 +427,23 @@ __device__ __forceinline__ void b2q_block(B2QLane &L, const uint32_t (&wa)[10][4
 	__builtin_amdgcn_wave_barrier();
 }
 
+template <bool ODD>
+__device__ __forceinline__ void b2q_block_fast(B2QLane &L, const uint32_t (&wa)[10][4], uint64_t blk)
+{
+	typedef __attribute__((address_space(3))) u64x2 lds_u64x2_w;
+	lds_u64x2_w *s = reinterpret_cast<lds_u64x2_w *>(L.stage + (ODD ? 0 : B2Q_SLOT1));
+	s[0] = L.w0;
+	s[1] = L.w1;
+	const u64x2 *g = reinterpret_cast<const u64x2 *>(L.pq + (blk + 2) * 128);
+	L.w0 = __builtin_nontemporal_load(g);
+	L.w1 = __builtin_nontemporal_load(g + 1);
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	b2q_compress<ODD>(L.ha, L.hb, wa, L.q, (blk + 1) * 128, false, L.x, L.y);
+	__builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t lds[2 * 16 * B2Q_SLOT];
@@ -445,8 +481,10 @@ __global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
 #pragma unroll
 	for (int r = 0; r < 10; ++r)
 #pragma unroll
-		for (int w = 0; w < 4; ++w)
+		for (int w = 0; w < 4; ++w) {
 			wa[r][w] = slot0 + __builtin_amdgcn_ubfe(SCH.w[r][w], q7, 7);
+			asm("" : "+v"(wa[r][w]));  // opaque: otherwise the sums are re-formed inside the loop (19 v_add_u32 per block)
+		}
 	b2q_fetch(p, b0 * 128, len, q, L.w0, L.w1);
 	{
 		lds_u64x2_w *s = reinterpret_cast<lds_u64x2_w *>(L.stage);
@@ -460,8 +498,20 @@ __global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	L.x = *reinterpret_cast<lds_u64_t *>(wa[0][0]);
 	L.y = *reinterpret_cast<lds_u64_t *>(wa[0][1]);
-	// two blocks per trip: which slot is current is then a compile-time fact of each half
-	for (uint64_t blk = b0; blk < b1; blk += 2) {
+	// two blocks per trip: which slot is current is then a compile-time fact of each half.  First the blocks with
+	// nothing to decide -- two whole successors inside this segment, not the message's last block: stage, request,
+	// compress, no per-block conditions (a lone wave pays an issue slot for every compare, select and branch) --
+	// then the general form for the last few.
+	uint64_t blk = b0;
+	{
+		const uint64_t lim_a = b1 >= 2 ? b1 - 2 : 0, lim_b = nblk >= 3 ? nblk - 3 : 0;
+		const uint64_t fast_until = lim_a < lim_b ? lim_a : lim_b;  // blocks below it are "fast"
+		for (; blk + 1 < fast_until; blk += 2) {
+			b2q_block_fast<false>(L, wa, blk);
+			b2q_block_fast<true>(L, wa, blk + 1);
+		}
+	}
+	for (; blk < b1; blk += 2) {
 		b2q_block<false>(L, wa, blk);
 		if (blk + 1 < b1)
 			b2q_block<true>(L, wa, blk + 1);
