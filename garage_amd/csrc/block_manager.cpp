@@ -882,7 +882,7 @@ struct gbm_manager {
 	std::atomic<bool> compress{false};    // Config.compression_level (src/util/config.rs:52-58); Garage's default is Some(1)
 	std::atomic<int> compression_level{1};
 	std::atomic<bool> verify_block_hash{true};
-	std::atomic<size_t> cpu_block_hash_max{128};  // gets of up to this many blocks hash them on the host (gbm_set_threads rescales)
+	std::atomic<size_t> cpu_block_hash_max{96};  // gets of up to this many blocks hash them on the host (gbm_set_threads rescales)
 
 	// hedged reads: 0 = the k requests of a read are issued and awaited in order
 	std::atomic<uint64_t> hedge_us{0}, hedged_reads{0};
@@ -1683,7 +1683,7 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 	std::vector<Gathered> g;
 	std::vector<uint8_t> block_sums, changed, early(nb, 0);
 	const bool verify = mg->verify_block_hash.load();
-	// Where the block's own checksum is computed.  It is one serial BLAKE2b chain per block: ~13 ms per MiB on the
+	// Where the block's own checksum is computed.  It is one serial BLAKE2b chain per block: ~11 ms per MiB on the
 	// device however many blocks run beside it, ~1 ms per MiB on a host core.  Small requests -- a GetObject reads
 	// its blocks a few at a time -- are hashed by the pool from the assembled bytes; big batches on the device,
 	// behind the upload (gec_decode_verify_batch).
@@ -2124,7 +2124,7 @@ int gbm_set_threads(gbm_manager *m, int nthreads)
 	if (!m || nthreads < 1 || nthreads > 256)
 		return fail(GBM_E_INVALID_ARG, "need 1 <= nthreads <= 256");
 	m->pool->resize((unsigned)nthreads - 1);  // the calling thread works too
-	m->cpu_block_hash_max = 8 * (size_t)nthreads;
+	m->cpu_block_hash_max = 6 * (size_t)nthreads;
 	return GBM_OK;
 }
 

@@ -98,8 +98,8 @@ int gbm_set_data_fsync(gbm_manager *m, int enabled);
  * that is what replaces the serving node's verify of read_block_from (:577-609); this switch
  * only controls the additional end-to-end pass over the assembled block. */
 int gbm_set_verify_block_hash(gbm_manager *m, int enabled);
-/* A block's own checksum is one serial BLAKE2b chain: ~13 ms per MiB on the device however many blocks run beside
- * it, ~1 ms per MiB on a host core.  Gets of up to `nblocks` blocks (default 8 per pool thread = 128) verify it on the
+/* A block's own checksum is one serial BLAKE2b chain: ~11 ms per MiB on the device however many blocks run beside
+ * it, ~1 ms per MiB on a host core.  Gets of up to `nblocks` blocks (default 6 per pool thread = 96) verify it on the
  * host pool from the assembled bytes; larger batches on the device, behind the upload.  0 = always on the device. */
 int gbm_set_host_block_hash_max(gbm_manager *m, size_t nblocks);
 

@@ -152,7 +152,7 @@ def test_native_corruption_resync_scrub(codec, tmp_path):
     with pytest.raises(bn.CorruptData):
         mgr.rpc_get_block(hashes[0])
     assert mgr.rpc_get_block(hashes[2]) == blocks[2]
-    mgr.set_host_block_hash_max(128)
+    mgr.set_host_block_hash_max(96)
     # rc -> 0: nothing is deleted inside BLOCK_GC_DELAY, every shard after it
     mgr.block_decref(hashes[5])
     assert mgr.resync_all() == 0 and mgr.rpc_get_block(hashes[5]) == blocks[5]
