@@ -1515,7 +1515,7 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 // one zstd frame, orig_len bytes) and block_sums[32*b..] its blake2sum (when want_block_sums).
 // `overlap` (optional) runs on a helper thread while the first device trip is in flight -- the caller assembles the
 // blocks that need no decode into its output buffers meanwhile; `changed[b]` is set for every block whose shard set
-// changed after that point (a shard failed its checksum and was replaced, or a data shard was rebuilt).
+// changed after that point (bit 0: a shard failed its checksum and was replaced, bit 1: a data shard was rebuilt).
 int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs,
 		 bool want_block_sums, std::vector<uint8_t> &block_sums, const std::function<void()> &overlap = nullptr,
 		 std::vector<uint8_t> *changed = nullptr)
@@ -1624,7 +1624,7 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 					again[b] = 1;
 					any_again = true;
 					if (changed)
-						(*changed)[b] = 1;
+						(*changed)[b] |= 1;  // a shard in hand was replaced
 					continue;
 				}
 				bool rebuilt_any = false;
@@ -1636,7 +1636,7 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 				if (rebuilt_any) {
 					mg->metrics[3]++;
 					if (changed)
-						(*changed)[b] = 1;
+						(*changed)[b] |= 2;  // missing data shards were filled in
 				}
 				if (want_block_sums)
 					std::memcpy(block_sums.data() + 32 * b, bsums.data() + 32 * i, 32);
@@ -1691,16 +1691,21 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 	// While the device checks the shards, the host already copies the blocks that need no decode (all k data shards in
 	// hand, stored Plain) into the caller's buffers: a block that then fails a checksum is reported as such (its buffer
 	// contents are unspecified on error) or is assembled again from the replaced shards.
+	// (a block with data shards to rebuild gets the shards it has; the rebuilt ones follow after the trip)
+	std::vector<std::vector<uint8_t>> missing_early(nb);  // data shard indices that were not in hand at that point
 	auto assemble_early = [&] {
 		mg->pool->parallel_for(nb, [&](size_t b) {
 			const Gathered &gb = g[b];
 			if (!gb.have_meta || gb.count < k || gb.meta.compressed || gb.meta.orig_len > (uint64_t)k * gb.meta.shard_len ||
 			    cap[b] < gb.meta.orig_len)
 				return;
-			for (int j = 0; j < k; ++j)
+			const size_t L = gb.meta.orig_len, S = gb.meta.shard_len;
+			for (int j = 0; j < k && (size_t)j * S < L; ++j) {
 				if (gb.shard[j].empty())
-					return;
-			assemble(gb, k, out[b]);
+					missing_early[b].push_back((uint8_t)j);
+				else
+					std::memcpy(out[b] + (size_t)j * S, gb.shard[j].data(), std::min(S, L - (size_t)j * S));
+			}
 			early[b] = 1;
 		});
 	};
@@ -1748,8 +1753,13 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 			rcs[b] = GBM_E_BUFFER_TOO_SMALL;
 			return;
 		}
-		if (!(early[b] && !changed[b]))
+		if (early[b] && !(changed[b] & 1)) {
+			const size_t S = g[b].meta.shard_len;
+			for (uint8_t j : missing_early[b])  // rebuilt since
+				std::memcpy(out[b] + (size_t)j * S, g[b].shard[j].data(), std::min(S, L - (size_t)j * S));
+		} else {
 			assemble(g[b], k, out[b]);
+		}
 		if (!z && cpu_hash) {
 			uint8_t sum[32];
 			blake2sum(out[b], L, sum);
