@@ -21,6 +21,12 @@
  * resolved at run time.  The manager is thread-safe: per-hash striped locks like
  * mutation_lock (src/block/manager.rs:679-689), nodes lock internally, and the bulk
  * work (copies, fan-out, gathers) runs on an internal thread pool.
+ *
+ * Environment (all optional, read once per process; none changes results):
+ *   GBM_TRACE=1              stage timings of the batched put / get / resync / scrub on stderr
+ *   GBM_PUT_SLICE=n          blocks per slice of a large untagged put (default 64)
+ *   GBM_PUT_THREADS=n        slices in flight (default 4)
+ *   GBM_BATCHER_WORKERS=n    batches the coalescing batcher keeps in flight (default 2)
  */
 #ifndef GARAGE_BLOCK_H
 #define GARAGE_BLOCK_H
