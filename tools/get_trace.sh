@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/get_trace
 export TMPDIR=/tmp
-GEC_UPLOAD_CUS=8 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/get_trace -- python tools/get_trace.py 512 > gpurun_out/get_trace/run.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/get_trace -- python tools/get_trace.py 512 > gpurun_out/get_trace/run.log 2>&1
 f=$(find gpurun_out/get_trace -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
