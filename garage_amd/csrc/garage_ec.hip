@@ -294,8 +294,15 @@ struct Staging {
 			std::vector<uint32_t> up(words, 0), rest(words, 0);
 			for (int i = 0; i < num_cu; ++i)
 				(i < up_cus ? up : rest)[i / 32] |= 1u << (i % 32);
-			HIP_TRY(hipExtStreamCreateWithCUMask(&stream_up, (uint32_t)words, up.data()));
-			HIP_TRY(hipExtStreamCreateWithCUMask(&stream_chain, (uint32_t)words, rest.data()));
+			// (a runtime or partition mode without CU masks is not an error: the paths then share all CUs, slower)
+			if (hipExtStreamCreateWithCUMask(&stream_up, (uint32_t)words, up.data()) != hipSuccess)
+				stream_up = nullptr;
+			if (!stream_up || hipExtStreamCreateWithCUMask(&stream_chain, (uint32_t)words, rest.data()) != hipSuccess) {
+				if (stream_up)
+					(void)hipStreamDestroy(stream_up);
+				stream_up = stream_chain = nullptr;
+				(void)hipGetLastError();
+			}
 		}
 		HIP_TRY(hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking));
 		return GEC_OK;
