@@ -1,8 +1,10 @@
 """ctypes binding of libgarage_ec.so (include/garage_ec.h).
 
 The library is the product; this module only declares prototypes.  There is no
-fallback of any kind: if the shared object is missing, import fails loudly with
-the command that builds it.
+Python fallback of any kind: if the shared object is missing, import fails loudly
+with the command that builds it.  (The library itself has two backends, chosen
+per codec: GEC_BACKEND_HIP -- the gfx950 kernels -- and GEC_BACKEND_CPU, its own
+host-core data path for nodes without a GPU.)
 """
 from __future__ import annotations
 
@@ -27,14 +29,17 @@ GEC_E_DEVICE = -100
 GEC_E_NOMEM = -101
 GEC_E_INVALID_ARG = -102
 GEC_MATRIX_VANDERMONDE, GEC_MATRIX_CAUCHY = 0, 1
+GEC_BACKEND_CPU, GEC_BACKEND_HIP, GEC_BACKEND_AUTO = 0, 1, 2
+GEC_CLASS_FOREGROUND, GEC_CLASS_BACKGROUND = 0, 1
 
 # every symbol include/garage_ec.h declares (tests/test_cabi_symbols.py checks
 # this list against the header and against the built library)
 SYMBOLS = [
-    "gec_version", "gec_device_count", "gec_strerror", "gec_last_error",
+    "gec_version", "gec_device_count", "gec_strerror", "gec_last_error", "gec_env_table", "gec_cpu_isa",
     "gec_shard_len", "gec_build_matrix", "gec_build_matrix_ex", "gec_build_decode_matrix",
     "gec_codec_create", "gec_codec_create_ex", "gec_codec_destroy", "gec_codec_k", "gec_codec_m",
     "gec_codec_device", "gec_parity_matrix", "gec_codec_cache_stats",
+    "gec_codec_background", "gec_codec_class", "gec_codec_backend", "gec_qos_yields",
     "gec_encode_batch", "gec_verify_batch", "gec_verify_hash_batch", "gec_reconstruct_batch", "gec_reconstruct_hash_batch",
     "gec_encode_batch_dev", "gec_verify_batch_dev", "gec_reconstruct_batch_dev",
     "gec_reconstruct_range_dev", "gec_reconstruct_scattered_dev", "gec_blake2sum_batch_dev", "gec_blake2sum_batch",
@@ -63,7 +68,7 @@ def _load() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: libgarage_ec has not been built. Run "
             "`make -C garage_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
-            "There is no CPU fallback for the erasure-coding data path."
+            "Nothing in Python stands in for it."
         )
     # One HIP runtime per process: PyTorch's ROCm wheel bundles its own
     # libamdhip64.so (SONAME libamdhip64.so.7).  If libgarage_ec were loaded first it
@@ -95,12 +100,17 @@ def _load() -> ctypes.CDLL:
     lib.gec_shard_len.argtypes = [ci, sz]
     lib.gec_build_matrix.argtypes = [ci, ci, u8p]
     lib.gec_build_matrix_ex.argtypes = [ci, ci, ci, u8p]
-    lib.gec_codec_create_ex.argtypes = [ci, ci, ci, ci, pp]
+    lib.gec_codec_create_ex.argtypes = [ci, ci, ci, ci, ci, pp]
+    lib.gec_codec_background.argtypes = [vp, pp]
+    lib.gec_env_table.restype = ctypes.c_char_p
+    lib.gec_cpu_isa.restype = ctypes.c_char_p
+    lib.gec_qos_yields.argtypes = [ci]
+    lib.gec_qos_yields.restype = ctypes.c_uint64
     lib.gec_build_decode_matrix.argtypes = [ci, ci, u8p, ctypes.POINTER(ctypes.c_int32), u8p]
-    lib.gec_codec_create.argtypes = [ci, ci, ci, pp]
+    lib.gec_codec_create.argtypes = [ci, ci, ci, ci, pp]
     lib.gec_codec_destroy.argtypes = [vp]
     lib.gec_codec_destroy.restype = None
-    for f in ("gec_codec_k", "gec_codec_m", "gec_codec_device"):
+    for f in ("gec_codec_k", "gec_codec_m", "gec_codec_device", "gec_codec_class", "gec_codec_backend"):
         getattr(lib, f).argtypes = [vp]
     lib.gec_parity_matrix.argtypes = [vp, u8p]
     lib.gec_codec_cache_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]

@@ -29,6 +29,7 @@ SYMBOLS = [
     "gbm_node_corrupt_shard", "gbm_node_shard_header", "gbm_node_order_violations", "gbm_metrics", "gbm_gpu_hashed",
     "gbm_set_read_hedge", "gbm_hedged_reads", "gbm_node_set_latency", "gbm_set_host_block_hash_max",
     "gbm_batcher_create", "gbm_batcher_destroy", "gbm_batcher_put_block", "gbm_batcher_set_ram_buffer_max", "gbm_batcher_stats",
+    "gbm_env_table", "gbm_set_tranquility", "gbm_tranquilized_ms", "gbm_background_codec",
 ]
 
 
@@ -138,6 +139,12 @@ def _load():
     lib.gbm_batcher_set_ram_buffer_max.argtypes = [vp, ctypes.c_size_t]
     lib.gbm_gpu_hashed.argtypes = [vp]
     lib.gbm_gpu_hashed.restype = ctypes.c_uint64
+    lib.gbm_env_table.restype = ctypes.c_char_p
+    lib.gbm_set_tranquility.argtypes = [vp, ci, ci]
+    lib.gbm_tranquilized_ms.argtypes = [vp]
+    lib.gbm_tranquilized_ms.restype = ctypes.c_uint64
+    lib.gbm_background_codec.argtypes = [vp]
+    lib.gbm_background_codec.restype = vp
     return lib
 
 

@@ -22,6 +22,7 @@ def shard_len(k: int, block_len: int) -> int:
 
 
 MATRIX_KINDS = {"vandermonde": _lib.GEC_MATRIX_VANDERMONDE, "cauchy": _lib.GEC_MATRIX_CAUCHY}
+BACKENDS = {"cpu": _lib.GEC_BACKEND_CPU, "hip": _lib.GEC_BACKEND_HIP, "auto": _lib.GEC_BACKEND_AUTO}
 
 
 def build_matrix(k: int, m: int, matrix: str = "vandermonde") -> np.ndarray:
@@ -54,20 +55,37 @@ def _stream_handle(device_index: int) -> int:
 
 
 class ReedSolomon:
-    """`ReedSolomon::new(data_shards, parity_shards)` bound to one GPU."""
+    """`ReedSolomon::new(data_shards, parity_shards)` bound to one GPU (backend="hip", the default) or to the
+    host cores (backend="cpu": the library's own CPU data path, host-pointer methods only); "auto" picks the
+    GPU when there is one."""
 
-    def __init__(self, data_shards: int, parity_shards: int, device: int = 0, matrix: str = "vandermonde"):
+    def __init__(self, data_shards: int, parity_shards: int, device: int = 0, matrix: str = "vandermonde",
+                 backend: str = "hip", _handle=None):
         """matrix="vandermonde" is the crate-compatible default; "cauchy" is the extra family
         of include/garage_ec.h (not interchangeable with the default)."""
         h = ctypes.c_void_p()
-        check(lib.gec_codec_create_ex(data_shards, parity_shards, device, MATRIX_KINDS[matrix], ctypes.byref(h)),
-              "gec_codec_create_ex")
+        if _handle is not None:
+            h = _handle
+        else:
+            check(lib.gec_codec_create_ex(data_shards, parity_shards, BACKENDS[backend], device, MATRIX_KINDS[matrix],
+                                          ctypes.byref(h)), "gec_codec_create_ex")
         self.matrix = matrix
         self._h = h
         self.k = data_shards
         self.m = parity_shards
         self.n = data_shards + parity_shards
-        self.device = device
+        self.backend = {v: k for k, v in BACKENDS.items()}[int(lib.gec_codec_backend(h))]
+        self.device = int(lib.gec_codec_device(h))
+
+    def background(self) -> "ReedSolomon":
+        """gec_codec_background: a sibling codec whose work is classed BACKGROUND (scrub, resync)."""
+        h = ctypes.c_void_p()
+        check(lib.gec_codec_background(self._h, ctypes.byref(h)), "gec_codec_background")
+        return ReedSolomon(self.k, self.m, self.device, self.matrix, self.backend, _handle=h)
+
+    @property
+    def qos_class(self) -> int:
+        return int(lib.gec_codec_class(self._h))
 
     def close(self) -> None:
         h, self._h = getattr(self, "_h", None), None

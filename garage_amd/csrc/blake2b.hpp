@@ -15,28 +15,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "kernel_args.hpp"
+
 namespace gec {
 
-struct Blake2Args {
-	const uint8_t *base;
-	const uint64_t *off;   // per-message byte offset from base (NULL: computed, below)
-	const uint64_t *len;   // per-message length (NULL: uniform_len)
-	uint64_t stride;       // message i at base + i*stride, or with group != 0:
-	uint64_t uniform_len;  //   base + (i / group)*group_stride + (i % group)*stride
-	uint8_t *out;          // 32 bytes per message, at out + 32*i, or with group != 0:
-	uint32_t n;            //   out + 32*((i / group)*out_group + i % group)
-	uint32_t group;        // messages per group (e.g. the m parity shards of one stripe); 0 = flat
-	uint64_t group_stride;
-	uint32_t out_group;
-	// Segmented hashing (blake2b_batch_quad only): this launch compresses blocks [seg_begin_blk, seg_end_blk) of
-	// every message, picking the chaining value up from `state` (8 words per message) when it does not start at
-	// block 0 and leaving it there when the message goes on beyond seg_end_blk; a message whose last block falls
-	// inside the range is finished (digest written) by this launch, messages that ended earlier are skipped.
-	// The whole-message form is seg_begin_blk = 0, seg_end_blk = ~0.  This is how a block's checksum chain --
-	// serial, ~14 ms per MiB whatever runs beside it -- starts while the rest of the block is still on the link.
-	uint64_t *state = nullptr;
-	uint64_t seg_begin_blk = 0, seg_end_blk = ~0ull;
-};
 
 __device__ __forceinline__ const uint8_t *b2_msg_ptr(const Blake2Args &a, uint32_t i)
 {
@@ -539,11 +521,6 @@ __global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
 // 26 independent 32-block leaves per shard = 373k messages, enough waves per SIMD to fill the VALUs, and a
 // 13-block root per shard.  Block names stay plain blake2sum (gec_blake2sum_batch): they are Garage's.
 // ---------------------------------------------------------------------------
-constexpr uint32_t SHARDSUM_LEAF = 4096;
-constexpr uint64_t SHARDSUM_P0 = 64ull /*digest*/ | (0ull << 8) /*key*/ | (0ull << 16) /*fanout: unlimited*/ | (2ull << 24) /*depth*/ |
-				 ((uint64_t)SHARDSUM_LEAF << 32);
-constexpr uint64_t SHARDSUM_P2_LEAF = 0ull /*node_depth*/ | (64ull << 8) /*inner_length*/;
-constexpr uint64_t SHARDSUM_P2_ROOT = 1ull | (64ull << 8);
 
 // One lane per LEAF: lane i hashes leaf (i % nleaf) of shard (i / nleaf); shards addressed like messages of
 // Blake2Args (flat / grouped / offset table, uniform or per-shard lengths).  leafdig: [shard][leaf][64].

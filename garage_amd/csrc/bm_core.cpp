@@ -1,0 +1,464 @@
+// bm_core.cpp -- errors, zstd, the environment table, the manager's life cycle and settings, fault-injection hooks
+// for tests, metrics.
+#include "bm_internal.hpp"
+
+#include <dlfcn.h>
+
+namespace gbmimpl {
+
+namespace {
+thread_local std::string g_err;
+}
+
+int fail(int code, const std::string &msg)
+{
+	g_err = msg;
+	return code;
+}
+
+const std::string &last_error() { return g_err; }
+
+int ec_fail(int rc, const char *what)
+{
+	return fail(GBM_E_EC, std::string(what) + ": " + gec_strerror(rc) + " (" + gec_last_error() + ")");
+}
+
+// ------------------------------------------------------------------ environment: the one table of GBM_* switches
+// (all optional, read once per process, none changes results; gbm_env_table() returns it as text)
+namespace {
+struct EnvRow {
+	const char *name, *def, *doc;
+};
+const EnvRow kEnvRows[] = {
+	{"GBM_TRACE", "0", "1 = stage timings of the batched put / get / resync / scrub on stderr"},
+	{"GBM_PUT_SLICE", "64", "blocks per slice of a large untagged put"},
+	{"GBM_PUT_THREADS", "4", "put slices in flight"},
+	{"GBM_GET_SLICE", "0", "blocks per slice of a large get (0 = one device trip for the whole request)"},
+	{"GBM_GET_THREADS", "2", "get slices in flight"},
+	{"GBM_BATCHER_WORKERS", "2", "batches the coalescing batcher keeps in flight"},
+};
+long env_long(const char *name, long def)
+{
+	const char *e = std::getenv(name);
+	return e && *e ? std::atol(e) : def;
+}
+}  // namespace
+
+const Env &env()
+{
+	static const Env e = [] {
+		Env v;
+		v.trace = env_long("GBM_TRACE", 0) == 1;
+		const long sl = env_long("GBM_PUT_SLICE", 0);
+		v.put_slice = (size_t)(sl > 0 ? sl : 64);
+		const long pt = env_long("GBM_PUT_THREADS", 0);
+		v.put_threads = (int)(pt > 0 && pt <= 8 ? pt : 4);
+		const long bw = env_long("GBM_BATCHER_WORKERS", 0);
+		v.batcher_workers = (int)(bw >= 1 && bw <= 16 ? bw : 2);
+		const long gs = env_long("GBM_GET_SLICE", 0);
+		v.get_slice = (size_t)(gs > 0 ? gs : 0);
+		const long gt = env_long("GBM_GET_THREADS", 0);
+		v.get_threads = (int)(gt > 0 && gt <= 8 ? gt : 2);
+		return v;
+	}();
+	return e;
+}
+
+const char *env_table_text()
+{
+	static const std::string text = [] {
+		std::string s;
+		for (const EnvRow &r : kEnvRows)
+			s += std::string(r.name) + "\t" + r.def + "\t" + r.doc + "\n";
+		return s;
+	}();
+	return text.c_str();
+}
+
+void Trace::lap(const char *stage)
+{
+	if (!env().trace)
+		return;
+	const auto t = std::chrono::steady_clock::now();
+	char buf[64];
+	std::snprintf(buf, sizeof buf, " %s %.2f ms", stage, std::chrono::duration<double, std::milli>(t - t0).count());
+	line += buf;
+	t0 = t;
+}
+
+Trace::~Trace()
+{
+	if (env().trace && !line.empty())
+		std::fprintf(stderr, "[gbm] %s:%s\n", what, line.c_str());
+}
+
+Zstd::Zstd()
+{
+	void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+	if (!h)
+		return;
+#define GBM_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(h, name))
+	GBM_SYM(createCCtx, "ZSTD_createCCtx");
+	GBM_SYM(freeCCtx, "ZSTD_freeCCtx");
+	GBM_SYM(setParameter, "ZSTD_CCtx_setParameter");
+	GBM_SYM(compress2, "ZSTD_compress2");
+	GBM_SYM(compressBound, "ZSTD_compressBound");
+	GBM_SYM(decompress, "ZSTD_decompress");
+	GBM_SYM(getFrameContentSize, "ZSTD_getFrameContentSize");
+	GBM_SYM(isError, "ZSTD_isError");
+#undef GBM_SYM
+	ok = createCCtx && freeCCtx && setParameter && compress2 && compressBound && decompress &&
+	     getFrameContentSize && isError;
+}
+// false on any error: the caller then stores the block Plain (block.rs:88-93)
+bool Zstd::encode(const uint8_t *data, size_t len, int level, std::vector<uint8_t> &out) const
+{
+	if (!ok)
+		return false;
+	void *c = createCCtx();
+	if (!c)
+		return false;
+	bool good = !isError(setParameter(c, 100 /* ZSTD_c_compressionLevel */, level)) &&
+		    !isError(setParameter(c, 201 /* ZSTD_c_checksumFlag */, 1));
+	if (good) {
+		out.resize(compressBound(len));
+		size_t n = compress2(c, out.data(), out.size(), data, len);
+		good = !isError(n);
+		if (good)
+			out.resize(n);
+	}
+	freeCCtx(c);
+	return good;
+}
+// verifies the frame checksum; false = corrupt.  `max_out` bounds the allocation: a damaged or
+// forged frame header must not be able to ask for terabytes (Garage blocks are <= block_size, and a
+// zstd frame cannot expand by more than ~2^17 per byte; the caller passes a generous multiple of
+// block_size).  Frames without a content-size field (streaming encoders write those) are decoded
+// into a buffer that grows up to the same bound.
+bool Zstd::decode(const uint8_t *data, size_t len, size_t max_out, std::vector<uint8_t> &out) const
+{
+	if (!ok)
+		return false;
+	const unsigned long long sz = getFrameContentSize(data, len);
+	const unsigned long long UNKNOWN = 0ULL - 1, ERROR_ = 0ULL - 2;
+	if (sz == ERROR_)
+		return false;
+	try {
+		if (sz != UNKNOWN) {
+			if (sz > max_out)
+				return false;
+			out.resize((size_t)sz);
+			uint8_t dummy;
+			size_t n = decompress(sz ? out.data() : &dummy, (size_t)sz, data, len);
+			return !isError(n) && n == sz;
+		}
+		size_t cap = std::min<size_t>(std::max<size_t>(4 * len, 1 << 16), max_out);
+		for (;;) {
+			out.resize(cap);
+			size_t n = decompress(out.data(), cap, data, len);
+			if (!isError(n)) {
+				out.resize(n);
+				return true;
+			}
+			if (cap >= max_out)
+				return false;  // corrupt, or larger than any block can be
+			cap = std::min(cap * 4, max_out);
+		}
+	} catch (const std::bad_alloc &) {
+		return false;
+	}
+}
+const Zstd &zstd()
+{
+	static const Zstd z;
+	return z;
+}
+
+uint64_t real_now_ms()
+{
+	return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+
+// shard checksums of many buffers: on the GPU (gec_shardsum_batch) once the batch is big enough to beat the
+// CPU pool through PCIe, else on the pool's threads.  SURVEY.md section 8 row f4.
+constexpr size_t kGpuHashMinMessages = 64;
+constexpr size_t kGpuHashMinBytes = 8u << 20;
+
+int hash_many(gbm_manager *mg, const std::vector<const uint8_t *> &ptrs, const std::vector<size_t> &lens,
+	      std::vector<uint8_t> &sums)
+{
+	sums.resize(ptrs.size() * 32);
+	size_t total = 0;
+	for (size_t l : lens)
+		total += l;
+	// (on a CPU codec the library's own threads hash: no link to amortise, any batch may go)
+	if (ptrs.size() >= kGpuHashMinMessages && total >= kGpuHashMinBytes) {
+		int rc = gec_shardsum_batch(mg->codec, ptrs.size(), ptrs.data(), lens.data(), sums.data());
+		if (rc)
+			return ec_fail(rc, "gec_shardsum_batch");
+		mg->gpu_hashed += ptrs.size();
+		return GBM_OK;
+	}
+	mg->pool->parallel_for(ptrs.size(), [&](size_t i) { shardsum(ptrs[i], lens[i], sums.data() + 32 * i); });
+	return GBM_OK;
+}
+
+}  // namespace gbmimpl
+
+using namespace gbmimpl;
+
+extern "C" {
+
+const char *gbm_last_error(void) { return last_error().c_str(); }
+
+const char *gbm_env_table(void) { return env_table_text(); }
+
+void gbm_blake2sum(const uint8_t *data, size_t len, uint8_t out[32]) { blake2sum(data, len, out); }
+
+void gbm_shardsum(const uint8_t *data, size_t len, uint8_t out[32]) { shardsum(data, len, out); }
+
+int gbm_create(const gec_codec *codec, int nnodes, const char *const *node_dirs, int write_quorum, gbm_manager **out)
+{
+	if (!codec || !out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	*out = nullptr;
+	const int k = gec_codec_k(codec), m = gec_codec_m(codec);
+	if (nnodes < k + m)
+		return fail(GBM_E_INVALID_ARG, "RS(k,m) needs at least k+m storage nodes (replication_factor == k+m)");
+	if (k + m > 255)
+		return fail(GBM_E_INVALID_ARG, "shard index must fit a byte");
+	auto mg = std::make_unique<gbm_manager>();
+	mg->codec = codec;
+	mg->k = k;
+	mg->m = m;
+	mg->n = k + m;
+	mg->write_quorum = write_quorum > 0 ? write_quorum : k + (m + 1) / 2;
+	if (mg->write_quorum < k || mg->write_quorum > mg->n)
+		return fail(GBM_E_INVALID_ARG, "write quorum must be in [k, k+m]");
+	for (int i = 0; i < nnodes; ++i) {
+		mg->nodes.push_back(node_dirs ? make_dir_node(node_dirs[i]) : make_memory_node());
+		mg->nodes.back()->bufs = mg->bufs;
+	}
+	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+	mg->pool.reset(new Pool(std::min(15u, hw - 1)));
+	// maintenance gets a background-class sibling of the codec (its own staging slots, low-priority streams on a
+	// subset of the CUs, small chunks that yield to the request path); without one it shares the request path's codec
+	if (gec_codec_background(codec, &mg->bg_codec_owned) != GEC_OK)
+		mg->bg_codec_owned = nullptr;
+	*out = mg.release();
+	return GBM_OK;
+}
+
+void gbm_destroy(gbm_manager *m)
+{
+	if (!m)
+		return;
+	gbm_resync_worker_stop(m);
+	m->async.reset();  // drains: abandoned hedged requests still point at the nodes
+	if (m->bg_codec_owned)
+		gec_codec_destroy(m->bg_codec_owned);
+	delete m;
+}
+
+int gbm_set_threads(gbm_manager *m, int nthreads)
+{
+	if (!m || nthreads < 1 || nthreads > 256)
+		return fail(GBM_E_INVALID_ARG, "need 1 <= nthreads <= 256");
+	m->pool->resize((unsigned)nthreads - 1);  // the calling thread works too
+	m->cpu_block_hash_max = 6 * (size_t)nthreads;
+	return GBM_OK;
+}
+
+int gbm_set_host_block_hash_max(gbm_manager *m, size_t nblocks)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	m->cpu_block_hash_max = nblocks;
+	return GBM_OK;
+}
+
+int gbm_set_data_fsync(gbm_manager *m, int enabled)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	for (auto &nd : m->nodes)
+		nd->set_fsync(enabled != 0);
+	return GBM_OK;
+}
+
+int gbm_set_verify_block_hash(gbm_manager *m, int enabled)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	m->verify_block_hash = enabled != 0;
+	return GBM_OK;
+}
+
+int gbm_set_tranquility(gbm_manager *m, int scrub_tranquility, int resync_tranquility)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	if (scrub_tranquility >= 0)
+		m->scrub_tranquility = (uint32_t)scrub_tranquility;
+	if (resync_tranquility >= 0)
+		m->resync_tranquility = (uint32_t)resync_tranquility;
+	return GBM_OK;
+}
+
+uint64_t gbm_tranquilized_ms(const gbm_manager *m) { return m ? m->tranquilized_ms.load() : 0; }
+
+const gec_codec *gbm_background_codec(const gbm_manager *m) { return m ? m->bg_codec() : nullptr; }
+
+int gbm_set_read_hedge(gbm_manager *m, uint64_t hedge_us)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	m->hedge_us = hedge_us;
+	return GBM_OK;
+}
+
+uint64_t gbm_hedged_reads(const gbm_manager *m) { return m ? m->hedged_reads.load() : 0; }
+
+int gbm_node_set_latency(gbm_manager *m, int node, uint64_t latency_us)
+{
+	if (!m || node < 0 || node >= (int)m->nodes.size())
+		return fail(GBM_E_INVALID_ARG, "bad node");
+	m->nodes[node]->latency_us = latency_us;
+	return GBM_OK;
+}
+
+int gbm_set_timing(gbm_manager *m, int64_t gc_delay_ms, int64_t resync_retry_delay_ms, int64_t incref_check_delay_ms)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	if (gc_delay_ms >= 0)
+		m->gc_delay_ms = (uint64_t)gc_delay_ms;
+	if (resync_retry_delay_ms >= 0)
+		m->retry_delay_ms = (uint64_t)resync_retry_delay_ms;
+	if (incref_check_delay_ms >= 0)
+		m->incref_delay_ms = (uint64_t)incref_check_delay_ms;
+	return GBM_OK;
+}
+
+int gbm_clock_advance(gbm_manager *m, uint64_t ms)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	m->clock_skew_ms += ms;
+	m->rs_cv.notify_all();
+	return GBM_OK;
+}
+
+int gbm_storage_nodes_of(const gbm_manager *m, const uint8_t hash[32], int *nodes_out)
+{
+	if (!m || !hash || !nodes_out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	std::vector<int> who;
+	m->nodes_of(Hash((const char *)hash, 32), who);
+	std::copy(who.begin(), who.end(), nodes_out);
+	return GBM_OK;
+}
+
+int gbm_layout_update(gbm_manager *m)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	return ++m->layout_cur;
+}
+
+int gbm_layout_trim(gbm_manager *m)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	m->layout_oldest = m->layout_cur.load();
+	return GBM_OK;
+}
+
+int gbm_node_set_down(gbm_manager *m, int node, int down)
+{
+	if (!m || node < 0 || node >= (int)m->nodes.size())
+		return fail(GBM_E_INVALID_ARG, "bad node index");
+	m->nodes[node]->down = down != 0;
+	return GBM_OK;
+}
+
+int gbm_node_has_shard(gbm_manager *m, int node, const uint8_t hash[32], int idx)
+{
+	if (!m || node < 0 || node >= (int)m->nodes.size())
+		return 0;
+	return m->nodes[node]->has(Hash((const char *)hash, 32), idx) ? 1 : 0;
+}
+
+int gbm_node_delete_shard(gbm_manager *m, int node, const uint8_t hash[32], int idx)
+{
+	if (!m || node < 0 || node >= (int)m->nodes.size())
+		return fail(GBM_E_INVALID_ARG, "bad node index");
+	m->nodes[node]->del(Hash((const char *)hash, 32), idx);
+	return GBM_OK;
+}
+
+int gbm_node_corrupt_shard(gbm_manager *m, int node, const uint8_t hash[32], int idx, size_t offset, uint8_t mask,
+			   int fix_checksum)
+{
+	if (!m || node < 0 || node >= (int)m->nodes.size())
+		return fail(GBM_E_INVALID_ARG, "bad node index");
+	Hash h((const char *)hash, 32);
+	Shard s;
+	if (!m->nodes[node]->get(h, idx, s) || s.data.n <= offset)
+		return fail(GBM_E_IO, "no such shard / offset");
+	try {
+		// shard buffers are shared (a data shard is a slice of its block's buffer): corrupt a private copy
+		Bytes copy = m->bufs->get(s.data.n);
+		std::memcpy(copy.mut(), s.data.data(), s.data.n);
+		copy.mut()[offset] ^= mask;
+		s.data = copy;
+	} catch (const std::bad_alloc &) {
+		return fail(GBM_E_IO, "out of memory");
+	}
+	if (fix_checksum)
+		shardsum(s.data.data(), s.data.n, s.hd.checksum);
+	return m->nodes[node]->put(h, idx, s) ? GBM_OK : fail(GBM_E_IO, "rewrite failed");
+}
+
+int gbm_node_shard_header(gbm_manager *m, int node, const uint8_t hash[32], int idx, uint8_t out[GBM_SHARD_HEADER_SIZE])
+{
+	if (!m || node < 0 || node >= (int)m->nodes.size() || !hash || !out)
+		return fail(GBM_E_INVALID_ARG, "bad argument");
+	Shard s;
+	if (!m->nodes[node]->get(Hash((const char *)hash, 32), idx, s))
+		return fail(GBM_E_IO, "no such shard");
+	s.hd.pack(out);
+	return GBM_OK;
+}
+
+uint64_t gbm_node_order_violations(gbm_manager *m, int node)
+{
+	if (!m || node < 0 || node >= (int)m->nodes.size())
+		return 0;
+	return m->nodes[node]->order_violations.load();
+}
+
+int gbm_set_compression_level(gbm_manager *m, int enabled, int level)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	if (enabled && !zstd().ok)
+		return fail(GBM_E_IO, "libzstd.so.1 not available");
+	m->compression_level = level;
+	m->compress = enabled != 0;
+	return GBM_OK;
+}
+
+uint64_t gbm_gpu_hashed(const gbm_manager *m) { return m ? m->gpu_hashed.load() : 0; }
+
+int gbm_metrics(const gbm_manager *m, uint64_t out[6])
+{
+	if (!m || !out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	for (int i = 0; i < 6; ++i)
+		out[i] = m->metrics[i].load();
+	return GBM_OK;
+}
+
+
+}  // extern "C"

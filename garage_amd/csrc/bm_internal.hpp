@@ -1,0 +1,652 @@
+// bm_internal.hpp -- what the translation units of libgarage_block share.
+//
+// Layout of the library (include/garage_block.h is the contract; reference anchors are cited there):
+//   bm_core.cpp     errors, zstd, the environment table, manager life cycle and settings, test hooks, metrics
+//   bm_node.cpp     the storage nodes behind ShardRpc: memory- and directory-backed (shard files, two-phase replace)
+//   bm_rw.cpp       rpc_put_block(s) / rpc_get_block(s): gather, fan-out, the one-trip device calls, assembly
+//   bm_resync.cpp   refcounts (RcEntry), the resync queue and its worker, resync_block(s)
+//   bm_scrub.cpp    ScrubWorker / RepairWorker: gbm_scrub, gbm_scrub_all, gbm_repair_all
+//   bm_batcher.cpp  the coalescing queue in front of the FFI (PUT_BLOCKS_MAX_PARALLEL callers -> device batches)
+// Pure host code: every shard byte and every large checksum batch is computed by libgarage_ec (include/garage_ec.h).
+#pragma once
+
+#include "../../include/garage_block.h"
+
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <future>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <set>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "blake2b_host.hpp"
+
+namespace gbmimpl {
+
+// sets the calling thread's gbm_last_error() text and returns `code`
+int fail(int code, const std::string &msg);
+const std::string &last_error();
+int ec_fail(int rc, const char *what);
+
+using b2host::blake2sum;
+using b2host::shardsum;
+
+// ------------------------------------------------------------------ environment (bm_core.cpp holds the one table)
+struct Env {
+	bool trace;               // GBM_TRACE
+	size_t put_slice;         // GBM_PUT_SLICE
+	int put_threads;          // GBM_PUT_THREADS
+	int batcher_workers;      // GBM_BATCHER_WORKERS
+	size_t get_slice;         // GBM_GET_SLICE
+	int get_threads;          // GBM_GET_THREADS
+};
+const Env &env();
+const char *env_table_text();
+
+// --------------------------------------------------------------------- zstd
+// DataBlock::from_buffer / zstd_encode (src/block/block.rs:85-106): one frame, level
+// from the config, content checksum ON.  This image ships libzstd.so.1 but no headers,
+// so the handful of entry points are resolved at run time.
+struct Zstd {
+	bool ok = false;
+	// false on any error: the caller then stores the block Plain (block.rs:88-93)
+	bool encode(const uint8_t *data, size_t len, int level, std::vector<uint8_t> &out) const;
+	// verifies the frame checksum; false = corrupt.  `max_out` bounds the allocation.
+	bool decode(const uint8_t *data, size_t len, size_t max_out, std::vector<uint8_t> &out) const;
+	Zstd();
+
+private:
+	void *(*createCCtx)() = nullptr;
+	size_t (*freeCCtx)(void *) = nullptr;
+	size_t (*setParameter)(void *, int, int) = nullptr;
+	size_t (*compress2)(void *, void *, size_t, const void *, size_t) = nullptr;
+	size_t (*compressBound)(size_t) = nullptr;
+	size_t (*decompress)(void *, size_t, const void *, size_t) = nullptr;
+	unsigned long long (*getFrameContentSize)(const void *, size_t) = nullptr;
+	unsigned (*isError)(size_t) = nullptr;
+};
+const Zstd &zstd();
+
+using Hash = std::string;  // 32 raw bytes
+
+inline std::string hex(const Hash &h)
+{
+	static const char *d = "0123456789abcdef";
+	std::string s;
+	for (unsigned char c : h) {
+		s.push_back(d[c >> 4]);
+		s.push_back(d[c & 15]);
+	}
+	return s;
+}
+
+// ------------------------------------------------------------- shard header
+// Same 64-byte layout as garage_amd/block_manager.py::ShardHeader ("<4sBBBBB3xQII32s").
+// version 2: the checksum is the tree-mode shardsum.  version 1 (round 1's format) carried plain blake2sum: such a
+// shard is still readable -- verified with blake2sum on the host and rewritten as version 2 the first time it is
+// read.  Any other version is a format this build does not know: the shard is left alone (never renamed or deleted)
+// and reported as unreadable.
+struct ShardHeader {
+	uint8_t version = 2;
+	uint8_t k = 0, m = 0, idx = 0, compressed = 0;
+	uint64_t orig_len = 0;
+	uint32_t shard_len = 0;
+	uint8_t checksum[32] = {0};
+
+	enum Parse { OK = 0, GARBAGE = 1, UNKNOWN_VERSION = 2 };
+
+	void pack(uint8_t out[GBM_SHARD_HEADER_SIZE]) const
+	{
+		std::memset(out, 0, GBM_SHARD_HEADER_SIZE);
+		std::memcpy(out, "GECS", 4);
+		out[4] = version;
+		out[5] = k;
+		out[6] = m;
+		out[7] = idx;
+		out[8] = compressed;
+		std::memcpy(out + 12, &orig_len, 8);
+		std::memcpy(out + 20, &shard_len, 4);
+		std::memcpy(out + 28, checksum, 32);
+	}
+	Parse unpack(const uint8_t *in, size_t n)
+	{
+		if (n < GBM_SHARD_HEADER_SIZE || std::memcmp(in, "GECS", 4) != 0)
+			return GARBAGE;
+		version = in[4];
+		if (version != 1 && version != 2)
+			return UNKNOWN_VERSION;
+		k = in[5];
+		m = in[6];
+		idx = in[7];
+		compressed = in[8];
+		std::memcpy(&orig_len, in + 12, 8);
+		std::memcpy(&shard_len, in + 20, 4);
+		std::memcpy(checksum, in + 28, 32);
+		return OK;
+	}
+	bool same_geometry(const ShardHeader &o) const
+	{
+		return compressed == o.compressed && orig_len == o.orig_len && shard_len == o.shard_len;
+	}
+};
+
+uint64_t real_now_ms();
+
+// ------------------------------------------------------------------ thread pool
+// fork-join: fn(i) for i in [0, n) on the workers and the calling thread.  Several callers may use it at
+// once (they queue on call_mu_); work items must not call parallel_for themselves.
+class Pool {
+public:
+	explicit Pool(unsigned n) { resize(n); }
+	~Pool() { stop_all(); }
+	void resize(unsigned n)
+	{
+		std::lock_guard<std::mutex> call(call_mu_);
+		stop_all();
+		stop_ = false;
+		for (unsigned i = 0; i < n; ++i)
+			workers_.emplace_back([this] { run(); });
+	}
+	void parallel_for(size_t n, const std::function<void(size_t)> &fn)
+	{
+		if (n == 0)
+			return;
+		if (n == 1) {
+			fn(0);
+			return;
+		}
+		std::unique_lock<std::mutex> call_lock(call_mu_);
+		if (workers_.empty()) {
+			call_lock.unlock();
+			for (size_t i = 0; i < n; ++i)
+				fn(i);
+			return;
+		}
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			fn_ = &fn;
+			n_ = n;
+			next_ = 0;
+			pending_ = n;
+			++epoch_;
+		}
+		cv_.notify_all();
+		work();
+		std::unique_lock<std::mutex> g(mu_);
+		done_cv_.wait(g, [this] { return pending_ == 0; });
+		fn_ = nullptr;
+	}
+
+private:
+	void stop_all()
+	{
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			stop_ = true;
+		}
+		cv_.notify_all();
+		for (auto &t : workers_)
+			t.join();
+		workers_.clear();
+	}
+	void work()
+	{
+		for (;;) {
+			size_t i;
+			const std::function<void(size_t)> *fn;
+			{
+				std::lock_guard<std::mutex> g(mu_);
+				if (!fn_ || next_ >= n_)
+					return;
+				i = next_++;
+				fn = fn_;
+			}
+			(*fn)(i);
+			std::lock_guard<std::mutex> g(mu_);
+			if (--pending_ == 0)
+				done_cv_.notify_all();
+		}
+	}
+	void run()
+	{
+		uint64_t seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> g(mu_);
+				cv_.wait(g, [&] { return stop_ || epoch_ != seen; });
+				if (stop_)
+					return;
+				seen = epoch_;
+			}
+			work();
+		}
+	}
+	std::vector<std::thread> workers_;
+	std::mutex mu_, call_mu_;
+	std::condition_variable cv_, done_cv_;
+	const std::function<void(size_t)> *fn_ = nullptr;
+	size_t n_ = 0, next_ = 0, pending_ = 0;
+	uint64_t epoch_ = 0;
+	bool stop_ = false;
+};
+
+// Fire-and-forget tasks for requests that may be abandoned (hedged reads): a task owns everything it touches
+// through shared_ptrs, so nobody has to wait for a slow one.
+class Async {
+public:
+	explicit Async(unsigned n)
+	{
+		for (unsigned i = 0; i < n; ++i)
+			workers_.emplace_back([this] { run(); });
+	}
+	~Async()
+	{
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			stop_ = true;
+		}
+		cv_.notify_all();
+		for (auto &t : workers_)
+			t.join();
+	}
+	void submit(std::function<void()> fn)
+	{
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			q_.push_back(std::move(fn));
+		}
+		cv_.notify_one();
+	}
+
+private:
+	void run()
+	{
+		for (;;) {
+			std::function<void()> fn;
+			{
+				std::unique_lock<std::mutex> g(mu_);
+				cv_.wait(g, [&] { return stop_ || !q_.empty(); });
+				if (q_.empty())
+					return;  // stop_ and drained
+				fn = std::move(q_.front());
+				q_.pop_front();
+			}
+			fn();
+		}
+	}
+	std::vector<std::thread> workers_;
+	std::mutex mu_;
+	std::condition_variable cv_;
+	std::deque<std::function<void()>> q_;
+	bool stop_ = false;
+};
+
+// ------------------------------------------------------------------ buffers
+// Bytes = shared, immutable-after-fill byte range; slices alias their parent (std::shared_ptr aliasing
+// constructor), so a data shard is a view into its block's buffer and lives as long as any node keeps it.
+struct Bytes {
+	std::shared_ptr<uint8_t> p;
+	size_t n = 0;
+	const uint8_t *data() const { return p.get(); }
+	uint8_t *mut() const { return p.get(); }
+	bool empty() const { return !p; }
+	Bytes slice(size_t off, size_t len) const
+	{
+		Bytes b;
+		b.p = std::shared_ptr<uint8_t>(p, p.get() + off);
+		b.n = len;
+		return b;
+	}
+};
+
+// Pool of pinned host buffers (gec_host_alloc): hipHostMalloc costs ~0.1 ms per MiB, so buffers are recycled
+// by size.  On a host without a device gec_host_alloc hands out page-aligned ordinary memory (include/garage_ec.h).
+class BufPool : public std::enable_shared_from_this<BufPool> {
+public:
+	static constexpr size_t kRetainMax = 2ull << 30;  // bytes kept for reuse; beyond that buffers are freed
+	~BufPool()
+	{
+		for (auto &kv : free_)
+			for (uint8_t *p : kv.second)
+				gec_host_free(p);
+	}
+	Bytes get(size_t n)
+	{
+		const size_t cap = std::max<size_t>((n + 4095) / 4096 * 4096, 4096);
+		uint8_t *raw = nullptr;
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			auto it = free_.find(cap);
+			if (it != free_.end() && !it->second.empty()) {
+				raw = it->second.back();
+				it->second.pop_back();
+				retained_ -= cap;
+			}
+		}
+		if (!raw)
+			raw = static_cast<uint8_t *>(gec_host_alloc(cap));
+		if (!raw)
+			throw std::bad_alloc();
+		std::weak_ptr<BufPool> self = shared_from_this();
+		Bytes b;
+		b.n = n;
+		b.p = std::shared_ptr<uint8_t>(raw, [self, cap](uint8_t *q) {
+			if (auto sp = self.lock())
+				sp->put_back(q, cap);
+			else
+				gec_host_free(q);
+		});
+		return b;
+	}
+
+private:
+	void put_back(uint8_t *q, size_t cap)
+	{
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			if (retained_ + cap <= kRetainMax) {
+				free_[cap].push_back(q);
+				retained_ += cap;
+				return;
+			}
+		}
+		gec_host_free(q);
+	}
+	std::mutex mu_;
+	std::map<size_t, std::vector<uint8_t *>> free_;
+	size_t retained_ = 0;
+};
+
+// ------------------------------------------------------------------ ShardRpc
+// What the manager and a storage node say to each other: the per-shard analogue of BlockRpc
+// (src/block/manager.rs:54-73).  PutShard carries the shard header (the DataBlockHeader plus the EC
+// geometry and the shard's checksum) and the payload; GetShard is answered with a PutShard.
+// A PutShard that would REPLACE a shard of a different geometry (the same block put again with another
+// compression setting) is parked beside it and only takes its place on CommitShard, which the manager sends once
+// the new stripe has reached its write quorum (AbortShard otherwise): a put that fails half way can no longer
+// leave a block with too few shards of either geometry.
+struct Shard {
+	ShardHeader hd;
+	Bytes data;  // shard_len bytes
+};
+
+enum class RpcKind { PutShard, GetShard, NeedShardQuery, DeleteShard, CommitShard, AbortShard };
+
+struct ShardRpc {
+	RpcKind kind;
+	const Hash *hash;
+	int idx;
+	Shard shard;                        // PutShard
+	const gbm_order_tag *tag = nullptr; // PutShard / GetShard
+};
+
+struct ShardResp {
+	bool ok = false;      // PutShard stored / GetShard found / DeleteShard had something to delete
+	bool needed = false;  // NeedShardReply
+	bool pending = false; // PutShard: parked beside a shard of another geometry, waiting for CommitShard
+	Shard shard;          // answer to GetShard
+};
+
+struct Node {
+	std::atomic<bool> down{false};  // flipped by gbm_node_set_down while other threads are talking to the node
+	std::atomic<uint64_t> order_violations{0};
+	std::atomic<uint64_t> latency_us{0};  // test hook: every request to this node takes this long
+	std::shared_ptr<BufPool> bufs;
+	virtual ~Node() = default;
+	// stores the shard; *pending = it was parked because a shard of another geometry is in place
+	virtual bool put(const Hash &h, int idx, const Shard &s, bool *pending = nullptr) = 0;
+	virtual bool get(const Hash &h, int idx, Shard &s) = 0;  // false: absent / unreadable
+	virtual bool has(const Hash &h, int idx) = 0;
+	virtual bool del(const Hash &h, int idx) = 0;
+	virtual bool commit(const Hash &h, int idx) = 0;  // a parked shard takes the place of the one in place
+	virtual bool abort(const Hash &h, int idx) = 0;   // a parked shard is dropped
+	virtual void mark_corrupted(const Hash &h, int idx) { del(h, idx); }
+	virtual void set_fsync(bool) {}
+	// every hash this node holds a shard of (BlockStoreIterator, src/block/repair.rs:196-233,634-752)
+	virtual void list(std::set<Hash> &out) = 0;
+
+	// the node's endpoint (StreamingEndpointHandler<BlockRpc>::handle, src/block/manager.rs:692-707);
+	// false = could not be contacted
+	bool handle(const ShardRpc &rq, ShardResp &rs);
+
+private:
+	void note_order(const gbm_order_tag *tag);
+	std::mutex order_mu_;
+	std::map<uint64_t, uint64_t> last_order_;
+};
+
+std::unique_ptr<Node> make_memory_node();
+std::unique_ptr<Node> make_dir_node(const std::string &root);
+
+// RcEntry (src/block/rc.rs:122-240)
+struct RcEntry {
+	enum Kind : uint8_t { Absent = 0, Present = 1, Deletable = 2 } kind = Absent;
+	uint64_t v = 0;  // Present: count; Deletable: at_time (ms)
+	bool is_zero() const { return kind != Present; }
+	bool is_nonzero() const { return kind == Present; }
+	bool is_deletable(uint64_t now) const { return kind == Absent || (kind == Deletable && now > v); }
+	bool is_needed(uint64_t now) const { return !is_deletable(now); }
+};
+
+// ErrorCounter (src/block/resync.rs:604-648)
+struct ErrorCounter {
+	uint64_t errors = 0, last_try = 0;
+	uint64_t delay_ms(uint64_t base) const
+	{
+		return base << std::min<uint64_t>(errors - 1, GBM_RESYNC_RETRY_MAX_BACKOFF_POWER);
+	}
+	uint64_t next_try(uint64_t base) const { return last_try + delay_ms(base); }
+};
+
+}  // namespace gbmimpl
+
+struct gbm_manager {
+	using Hash = gbmimpl::Hash;
+	using Node = gbmimpl::Node;
+	using BufPool = gbmimpl::BufPool;
+	using Pool = gbmimpl::Pool;
+	using Async = gbmimpl::Async;
+	using RcEntry = gbmimpl::RcEntry;
+	using ErrorCounter = gbmimpl::ErrorCounter;
+
+	const gec_codec *codec = nullptr;  // the request path's codec (borrowed)
+	// Maintenance (scrub, resync rebuilds) runs on a BACKGROUND-class sibling of `codec` (gec_codec_background): its
+	// device work yields to the request path's.  Owned; NULL when the sibling could not be created (then == codec).
+	gec_codec *bg_codec_owned = nullptr;
+	const gec_codec *bg_codec() const { return bg_codec_owned ? bg_codec_owned : codec; }
+	// Tranquilizer (src/util/tranquilizer.rs:38-69): after each maintenance batch that took t, sleep tranquility * t
+	// (resync.rs:46,568 reads its value from the persisted worker config; scrub has its own, repair.rs:386-390)
+	std::atomic<uint32_t> scrub_tranquility{0}, resync_tranquility{0};
+	std::atomic<uint64_t> tranquilized_ms{0};
+	int k = 0, m = 0, n = 0, write_quorum = 0;
+	std::vector<std::unique_ptr<Node>> nodes;
+	std::shared_ptr<BufPool> bufs = std::make_shared<BufPool>();
+	std::unique_ptr<Pool> pool;
+
+	// cluster layout versions (src/rpc/layout/): reads consult [current .. oldest]
+	std::atomic<int> layout_cur{0}, layout_oldest{0};
+
+	// refcounts, striped like mutation_lock (manager.rs:679-689)
+	static constexpr int kRcStripes = 256;
+	struct RcStripe {
+		std::mutex mu;
+		std::unordered_map<Hash, RcEntry> map;
+	};
+	RcStripe rc[kRcStripes];
+	RcStripe &rc_of(const Hash &h) { return rc[(((unsigned char)h[0] << 8) | (unsigned char)h[1]) % kRcStripes]; }
+	// mutation_lock (manager.rs:679-689): whoever changes which shards of a hash exist -- a put's "this block is
+	// protected from now on" stamp, resync's delete branch -- does so under the hash's lock, and resync re-reads
+	// the refcount under it right before it deletes (delete_if_unneeded, manager.rs:619-623,821-830)
+	std::mutex mutation_lock[kRcStripes];
+	std::mutex &lock_mutate(const Hash &h) { return mutation_lock[(((unsigned char)h[0] << 8) | (unsigned char)h[1]) % kRcStripes]; }
+
+	// resync.queue / resync.errors (resync.rs:170-253)
+	mutable std::mutex rs_mu;
+	std::condition_variable rs_cv;
+	std::set<std::pair<uint64_t, Hash>> rs_queue;
+	std::unordered_map<Hash, ErrorCounter> rs_errors;
+	std::thread rs_worker;
+	bool rs_worker_stop = false;
+
+	std::atomic<uint64_t> gc_delay_ms{GBM_BLOCK_GC_DELAY_MS}, retry_delay_ms{GBM_RESYNC_RETRY_DELAY_MS},
+		incref_delay_ms{2 * 300000ull};  // 2 * rpc_timeout, DEFAULT_TIMEOUT = 300 s (rpc_helper.rs:33)
+	std::atomic<uint64_t> clock_skew_ms{0};
+	uint64_t now() const { return gbmimpl::real_now_ms() + clock_skew_ms.load(); }
+
+	// ScrubWorkerPersisted (src/block/repair.rs:169-194)
+	std::atomic<uint64_t> scrub_corruptions{0}, scrub_last_complete_ms{0};
+	std::atomic<uint64_t> metrics[6] = {};
+	std::atomic<uint64_t> gpu_hashed{0};
+	std::atomic<bool> compress{false};    // Config.compression_level (src/util/config.rs:52-58); Garage's default is Some(1)
+	std::atomic<int> compression_level{1};
+	std::atomic<bool> verify_block_hash{true};
+	std::atomic<size_t> cpu_block_hash_max{96};  // gets of up to this many blocks hash them on the host (gbm_set_threads rescales)
+
+	// hedged reads: 0 = the k requests of a read are issued and awaited in order
+	std::atomic<uint64_t> hedge_us{0}, hedged_reads{0};
+	std::mutex async_mu;
+	std::shared_ptr<Async> async;  // created when hedging is first switched on
+	std::shared_ptr<Async> async_pool()
+	{
+		std::lock_guard<std::mutex> g(async_mu);
+		if (!async)
+			async = std::make_shared<Async>(32);
+		return async;
+	}
+
+	// storage nodes of a hash in layout version v: a deterministic stand-in for
+	// ClusterLayout::storage_nodes_of (partition = top bits of the hash, src/rpc/layout/version.rs:101-118)
+	void nodes_of(const Hash &h, int version, std::vector<int> &who) const
+	{
+		const size_t N = nodes.size();
+		const size_t start = ((unsigned char)h[0] * 31u + (unsigned char)h[1] + (size_t)version * (N / 2 + 1)) % N;
+		who.resize(n);
+		for (int j = 0; j < n; ++j)
+			who[j] = (int)((start + j) % N);
+	}
+	void nodes_of(const Hash &h, std::vector<int> &who) const { nodes_of(h, layout_cur.load(), who); }
+
+	RcEntry get_rc(const Hash &h)
+	{
+		RcStripe &s = rc_of(h);
+		std::lock_guard<std::mutex> g(s.mu);
+		auto it = s.map.find(h);
+		return it == s.map.end() ? RcEntry() : it->second;
+	}
+	void put_to_resync_at(const Hash &h, uint64_t when)
+	{
+		{
+			std::lock_guard<std::mutex> g(rs_mu);
+			rs_queue.insert({when, h});
+		}
+		rs_cv.notify_all();
+	}
+	void put_to_resync(const Hash &h, uint64_t delay) { put_to_resync_at(h, now() + delay); }
+};
+
+namespace gbmimpl {
+
+// GBM_TRACE=1: stage timings of the batched put / get on stderr (tools/host_path_bench.py reads them off)
+struct Trace {
+	const char *what;
+	std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+	std::string line;
+	explicit Trace(const char *w) : what(w) {}
+	void lap(const char *stage);
+	~Trace();
+};
+
+// largest block a Garage node will ever hold decompresses to: block_size is configurable, 1 MiB by default and
+// "a few MiB" in practice; 1 GiB is far above any of it and still a harmless allocation bound
+constexpr size_t kMaxDecompressed = 1ull << 30;
+
+// shard checksums of many buffers: on the GPU (gec_shardsum_batch) once the batch is big enough to beat the
+// CPU pool through PCIe, else on the pool's threads.  SURVEY.md section 8 row f4.
+int hash_many(gbm_manager *mg, const std::vector<const uint8_t *> &ptrs, const std::vector<size_t> &lens, std::vector<uint8_t> &sums);
+
+// Shards of one block are only usable together when they were cut from the same
+// payload with the same geometry.  A block can legitimately have shards of two
+// geometries on disk at once -- e.g. it was first stored Plain and a later put with
+// compression enabled reached only some nodes before failing its quorum -- so shards
+// are grouped by geometry and the largest consistent group is used (find_block makes
+// the same kind of choice between <hash> and <hash>.zst, manager.rs:627-662).
+struct Geometry {
+	uint8_t compressed = 0;
+	uint64_t orig_len = 0;
+	uint32_t shard_len = 0;
+	bool operator<(const Geometry &o) const
+	{
+		return std::tie(compressed, orig_len, shard_len) < std::tie(o.compressed, o.orig_len, o.shard_len);
+	}
+};
+
+struct Gathered {
+	std::vector<Bytes> shard;  // n entries; empty = not in hand
+	std::vector<std::array<uint8_t, 32>> sum;  // the checksum each shard's header promises
+	std::vector<int> node;                     // where each shard came from
+	ShardHeader meta;
+	bool have_meta = false;
+	int count = 0;
+	size_t next = 0;  // next candidate (version-major, shard index minor) to try
+	bool mixed = false;
+	bool settled = false;  // a geometry has been chosen; later candidates must match it
+	struct Group {
+		ShardHeader meta;
+		std::vector<Bytes> shard;
+		std::vector<std::array<uint8_t, 32>> sum;
+		std::vector<int> node;
+		int count = 0;
+	};
+	std::map<Geometry, Group> groups;
+	int best() const
+	{
+		int c = 0;
+		for (auto &kv : groups)
+			c = std::max(c, kv.second.count);
+		return c;
+	}
+	bool have_idx(int j) const
+	{
+		for (auto &kv : groups)
+			if (!kv.second.shard[j].empty())
+				return true;
+		return false;
+	}
+};
+
+// Fetch shards until every block has `want` valid ones of one geometry in hand (or ran out of nodes) -- bm_rw.cpp
+int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, int want, std::vector<Gathered> &gs,
+		bool verify = true, const std::vector<uint8_t> *only = nullptr);
+// PutShard to one node; false = the node could not be contacted or refused
+bool send_shard(gbm_manager *mg, int node, const Hash &h, int idx, const Bytes &payload, size_t S, uint64_t orig_len, bool compressed,
+		const uint8_t *checksum, const gbm_order_tag *tag, bool *pending = nullptr);
+// order gate of the batcher: batches that carry order tags hand their shards to the nodes in the order they were formed
+struct FanoutGate {
+	std::function<void()> before, after;
+};
+int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data, const size_t *len,
+		    const uint8_t *prevent_compression, const gbm_order_tag *tags, int *rcs, const FanoutGate *gate = nullptr);
+int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs,
+		 bool want_block_sums, std::vector<uint8_t> &block_sums, const std::function<void()> &overlap = nullptr,
+		 std::vector<uint8_t> *changed = nullptr);
+void assemble(const Gathered &g, int k, uint8_t *dst);
+int one_block_rc(int rc1);
+// every hash any reachable node holds a shard of (bm_scrub.cpp)
+void list_all_nodes(gbm_manager *mg, std::set<Hash> &all);
+
+}  // namespace gbmimpl

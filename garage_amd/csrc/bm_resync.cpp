@@ -1,0 +1,554 @@
+// bm_resync.cpp -- refcounts (RcEntry, src/block/rc.rs), the resync queue with its ErrorCounter back-off and
+// background worker (src/block/resync.rs:170-337,513-648), and resync_block for a whole pass of blocks at once
+// (:354-503) with the device work of all of them batched on the manager's BACKGROUND-class codec.
+#include "bm_internal.hpp"
+
+namespace gbmimpl {
+namespace {
+
+// ------------------------------------------------------------------ resync
+struct ResyncStats {
+	uint64_t taken = 0, ok = 0, errors = 0, skipped = 0, rebuilt = 0, deleted = 0, offloaded = 0, device_calls = 0;
+};
+
+// What one block needs, decided from the refcount and a presence scan (NeedShardQuery to every node that
+// could hold a shard: no payload moves).
+struct ResyncTask {
+	Hash h;
+	std::vector<int> who;              // current layout
+	std::vector<uint8_t> present_cur;  // shard j present on its current node
+	std::vector<uint8_t> reachable;    // current node of shard j is up
+	struct Stray {
+		int version, idx, node;
+	};
+	std::vector<Stray> strays;         // shards sitting on nodes of older layout versions
+	bool exists = false;
+	RcEntry rc;
+	std::string error;
+	int changed = 0;
+	// rebuild
+	std::vector<int> want;             // absent on a reachable current node, not recoverable by offload
+	Gathered g;
+};
+
+void scan_block(gbm_manager *mg, ResyncTask &t)
+{
+	const int n = mg->n;
+	const int vcur = mg->layout_cur.load(), vold = mg->layout_oldest.load();
+	mg->nodes_of(t.h, vcur, t.who);
+	t.present_cur.assign(n, 0);
+	t.reachable.assign(n, 0);
+	for (int j = 0; j < n; ++j) {
+		ShardRpc rq{RpcKind::NeedShardQuery, &t.h, j, Shard(), nullptr};
+		ShardResp rs;
+		if (mg->nodes[t.who[j]]->handle(rq, rs)) {
+			t.reachable[j] = 1;
+			t.present_cur[j] = rs.needed ? 0 : 1;
+			t.exists = t.exists || !rs.needed;
+		}
+	}
+	std::vector<int> who;
+	for (int v = vcur - 1; v >= vold; --v) {
+		mg->nodes_of(t.h, v, who);
+		for (int j = 0; j < n; ++j) {
+			if (who[j] == t.who[j])
+				continue;
+			ShardRpc rq{RpcKind::NeedShardQuery, &t.h, j, Shard(), nullptr};
+			ShardResp rs;
+			if (mg->nodes[who[j]]->handle(rq, rs) && !rs.needed) {
+				t.strays.push_back({v, j, who[j]});
+				t.exists = true;
+			}
+		}
+	}
+	t.rc = mg->get_rc(t.h);
+}
+
+// resync_block for a set of blocks (src/block/resync.rs:354-503), with the device work of all of them batched.
+void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats &st)
+{
+	const int k = mg->k, n = mg->n;
+	const uint64_t now = mg->now();
+	Trace tr("resync");
+	mg->pool->parallel_for(tasks.size(), [&](size_t i) { scan_block(mg, tasks[i]); });
+	tr.lap("presence scan");
+	std::vector<size_t> rebuild;
+	std::atomic<uint64_t> deleted{0}, offloaded{0};
+	mg->pool->parallel_for(tasks.size(), [&](size_t i) {
+		ResyncTask &t = tasks[i];
+		if (t.exists && t.rc.is_deletable(now)) {
+			// "offloading and deleting" -- with one refcount for the whole (in-process) cluster a deletable
+			// block is needed by nobody, so NeedShardQuery has no taker and the offload set is empty.
+			// The refcount read by the presence scan may be stale by now (the scan of a 1024-block pass takes a
+			// while): it is read AGAIN under the hash's mutation lock, and the shards are deleted under that lock
+			// (delete_if_unneeded re-checks under lock_mutate, manager.rs:619-623,821-830).  A put of the same hash
+			// stamps its protection under the same lock before it writes its first shard (put_blocks_impl).
+			std::lock_guard<std::mutex> ml(mg->lock_mutate(t.h));
+			t.rc = mg->get_rc(t.h);
+			if (!t.rc.is_deletable(mg->now()))
+				return;  // referenced, or put, in the meantime: nothing to delete; stragglers are queued by the put
+			for (int j = 0; j < n; ++j)
+				if (t.present_cur[j]) {
+					ShardRpc rq{RpcKind::DeleteShard, &t.h, j, Shard(), nullptr};
+					ShardResp rs;
+					if (mg->nodes[t.who[j]]->handle(rq, rs) && rs.ok)
+						++t.changed;
+				}
+			for (auto &s : t.strays) {
+				ShardRpc rq{RpcKind::DeleteShard, &t.h, s.idx, Shard(), nullptr};
+				ShardResp rs;
+				if (mg->nodes[s.node]->handle(rq, rs) && rs.ok)
+					++t.changed;
+			}
+			deleted += t.changed;
+			// clear_deleted_block_rc
+			gbm_manager::RcStripe &rs = mg->rc_of(t.h);
+			std::lock_guard<std::mutex> g(rs.mu);
+			auto it = rs.map.find(t.h);
+			if (it != rs.map.end() && it->second.kind == RcEntry::Deletable && now > it->second.v)
+				rs.map.erase(it);
+			return;
+		}
+		if (!t.rc.is_needed(now))
+			return;  // nothing stored, nothing needed
+		// needed.  First the offload branch: a shard that a layout change left on its old node is sent to the
+		// owner that lacks it (PutShard), then deleted where it no longer belongs.
+		for (auto &s : t.strays) {
+			if (!t.present_cur[s.idx] && t.reachable[s.idx]) {
+				ShardRpc rq{RpcKind::GetShard, &t.h, s.idx, Shard(), nullptr};
+				ShardResp rs;
+				if (!mg->nodes[s.node]->handle(rq, rs) || !rs.ok)
+					continue;
+				uint8_t sum[32];
+				shardsum(rs.shard.data.data(), rs.shard.data.n, sum);
+				if (rs.shard.data.n != rs.shard.hd.shard_len || std::memcmp(sum, rs.shard.hd.checksum, 32) != 0) {
+					mg->metrics[2]++;
+					mg->nodes[s.node]->mark_corrupted(t.h, s.idx);
+					continue;
+				}
+				ShardRpc pq{RpcKind::PutShard, &t.h, s.idx, rs.shard, nullptr};
+				ShardResp ps;
+				if (!mg->nodes[t.who[s.idx]]->handle(pq, ps) || !ps.ok) {
+					t.error = "offload: PutShard to the new owner failed";
+					continue;
+				}
+				t.present_cur[s.idx] = 1;
+				++t.changed;
+				++offloaded;
+			}
+			if (t.present_cur[s.idx]) {  // the owner has it: the stray copy is unneeded
+				ShardRpc rq{RpcKind::DeleteShard, &t.h, s.idx, Shard(), nullptr};
+				ShardResp rs;
+				(void)mg->nodes[s.node]->handle(rq, rs);
+			}
+		}
+		for (int j = 0; j < n; ++j)
+			if (!t.present_cur[j]) {
+				if (t.reachable[j])
+					t.want.push_back(j);
+				else
+					t.error = "storage node of shard " + std::to_string(j) + " could not be contacted";
+			}
+	});
+	st.deleted += deleted.load();
+	st.offloaded += offloaded.load();
+	tr.lap("delete / offload");
+	for (size_t i = 0; i < tasks.size(); ++i)
+		if (!tasks[i].want.empty())
+			rebuild.push_back(i);
+	// "fetching absent but needed block" (resync.rs:485-499): gather exactly k shards per block, rebuild what is wanted,
+	// PutShard.  First pass: shards are accepted on their headers and ONE device trip per group both rebuilds and
+	// returns the checksums of what it read (compared with the headers) and of what it wrote (stamped into the new
+	// headers) -- gec_reconstruct_hash_batch.  A block that turns out to have read a corrupt shard (set aside,
+	// queued) goes through a second pass whose gather verifies checksums first and moves on to the next holder.
+	auto rebuild_pass = [&](const std::vector<size_t> &todo, bool verify_in_gather) -> std::vector<size_t> {
+		std::vector<size_t> again;
+		std::vector<Hash> hs;
+		for (size_t i : todo)
+			hs.push_back(tasks[i].h);
+		std::vector<Gathered> gs;
+		int grc = gather_many(mg, hs, nullptr, k, gs, verify_in_gather);
+		tr.lap(verify_in_gather ? "gather k + checksums" : "gather k");
+		for (size_t q = 0; q < todo.size(); ++q) {
+			ResyncTask &t = tasks[todo[q]];
+			if (grc) {
+				t.error = std::string("gather: ") + last_error();
+				t.want.clear();
+				continue;
+			}
+			t.g = std::move(gs[q]);
+			if (!t.g.have_meta || t.g.count < k) {
+				t.error = "Missing block: fewer than k shards reachable";
+				t.want.clear();
+				continue;
+			}
+			// the read may have found corrupt shards (renamed away): those are absent now as well
+			for (int j = 0; j < n; ++j)
+				if (t.reachable[j] && t.g.shard[j].empty() && std::find(t.want.begin(), t.want.end(), j) == t.want.end()) {
+					ShardRpc rq{RpcKind::NeedShardQuery, &t.h, j, Shard(), nullptr};
+					ShardResp rs;
+					if (mg->nodes[t.who[j]]->handle(rq, rs) && rs.needed)
+						t.want.push_back(j);
+				}
+			// shards of a minority geometry are stale: overwrite them
+			if (t.g.mixed)
+				for (int j = 0; j < n; ++j)
+					if (t.reachable[j] && t.g.shard[j].empty() && std::find(t.want.begin(), t.want.end(), j) == t.want.end())
+						t.want.push_back(j);
+		}
+		// ONE device call per shard length: inside it gec_reconstruct_hash_batch buckets the blocks by (which shards
+		// are in hand, which are wanted) -- one decode plan and one kernel launch per such erasure pattern, the patterns'
+		// chunks pipelined through the link without a host round trip in between (one call per pattern: 14 calls,
+		// 20 ms for a lost node's 449 shards; one call: see tools/host_path_bench.py maintenance)
+		std::map<size_t, std::vector<size_t>> groups;
+		for (size_t i : todo)
+			if (!tasks[i].want.empty())
+				groups[tasks[i].g.meta.shard_len].push_back(i);
+		for (auto &kv : groups) {
+			const size_t S = kv.first;
+			const std::vector<size_t> &ids = kv.second;
+			std::vector<const uint8_t *> sp(ids.size() * n, nullptr);
+			std::vector<uint8_t *> op(ids.size() * n, nullptr);
+			std::vector<std::vector<Bytes>> outb(ids.size(), std::vector<Bytes>(n));
+			std::vector<uint8_t> in_sums(ids.size() * (size_t)n * 32), out_sums(ids.size() * (size_t)n * 32);
+			bool oom = false;
+			// one pinned slab for the group's rebuilt shards (a first-time allocation per shard costs more than
+			// the decode), sliced per shard: the nodes keep the slices, the slab lives as long as any of them
+			size_t nwant = 0;
+			for (size_t q = 0; q < ids.size(); ++q)
+				nwant += tasks[ids[q]].want.size();
+			Bytes slab;
+			try {
+				slab = mg->bufs->get(nwant * S);
+			} catch (const std::bad_alloc &) {
+				oom = true;
+			}
+			size_t slot = 0;
+			for (size_t q = 0; q < ids.size() && !oom; ++q) {
+				ResyncTask &t = tasks[ids[q]];
+				for (int j = 0; j < n; ++j)
+					if (!t.g.shard[j].empty())
+						sp[q * n + j] = t.g.shard[j].data();
+				for (int j : t.want) {
+					outb[q][j] = slab.slice(slot * S, S);
+					op[q * n + j] = outb[q][j].mut();
+					++slot;
+				}
+			}
+			tr.lap("group setup");
+			const auto t_dev = std::chrono::steady_clock::now();
+			int rc = oom ? GEC_E_NOMEM
+				     : gec_reconstruct_hash_batch(mg->bg_codec(), ids.size(), sp.data(), op.data(), S, 0, in_sums.data(), out_sums.data());
+			tr.lap("reconstruct + checksums");
+			if (const uint32_t tranq = mg->resync_tranquility.load()) {  // Tranquilizer::tranquilize (tranquilizer.rs:38-69)
+				const auto spent = std::chrono::steady_clock::now() - t_dev;
+				std::this_thread::sleep_for(spent * tranq);
+				mg->tranquilized_ms += (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(spent * tranq).count();
+			}
+			++st.device_calls;
+			if (rc) {
+				ec_fail(rc, "gec_reconstruct_hash_batch");
+				for (size_t i : ids)
+					tasks[i].error = last_error();
+				continue;
+			}
+			mg->gpu_hashed += ids.size() * (size_t)k + nwant;
+			std::vector<uint8_t> good(ids.size(), 1);
+			if (!verify_in_gather) {
+				// what was read: the first k shards in hand, in index order
+				for (size_t q = 0; q < ids.size(); ++q) {
+					ResyncTask &t = tasks[ids[q]];
+					int seen = 0;
+					for (int j = 0; j < n && seen < k; ++j) {
+						if (t.g.shard[j].empty())
+							continue;
+						++seen;
+						if (std::memcmp(in_sums.data() + (q * n + j) * 32, t.g.sum[j].data(), 32) != 0) {
+							mg->metrics[2]++;
+							if (t.g.node[j] >= 0)
+								mg->nodes[t.g.node[j]]->mark_corrupted(t.h, j);
+							good[q] = 0;
+						}
+					}
+					if (!good[q]) {
+						t.want.clear();  // decided again by the second pass
+						again.push_back(ids[q]);
+					}
+				}
+			}
+			mg->metrics[3] += ids.size();
+			std::atomic<uint64_t> rebuilt{0};
+			mg->pool->parallel_for(ids.size(), [&](size_t q) {
+				if (!good[q])
+					return;
+				ResyncTask &t = tasks[ids[q]];
+				for (int j : t.want) {
+					if (send_shard(mg, t.who[j], t.h, j, outb[q][j], S, t.g.meta.orig_len, t.g.meta.compressed != 0,
+						       out_sums.data() + (q * n + j) * 32, nullptr)) {
+						++t.changed;
+						++rebuilt;
+					} else {
+						t.error = "PutShard of a rebuilt shard failed";
+					}
+				}
+			});
+			st.rebuilt += rebuilt.load();
+			tr.lap("PutShard");
+		}
+		return again;
+	};
+	if (!rebuild.empty()) {
+		std::vector<size_t> again = rebuild_pass(rebuild, false);
+		if (!again.empty()) {
+			// the presence of the shards that were set aside has changed: scan those blocks again
+			for (size_t i : again) {
+				ResyncTask &t = tasks[i];
+				for (int j = 0; j < n; ++j)
+					if (t.reachable[j]) {
+						ShardRpc rq{RpcKind::NeedShardQuery, &t.h, j, Shard(), nullptr};
+						ShardResp rs;
+						if (mg->nodes[t.who[j]]->handle(rq, rs) && rs.needed)
+							t.want.push_back(j);
+					}
+			}
+			(void)rebuild_pass(again, true);
+		}
+	}
+}
+
+}  // namespace
+}  // namespace gbmimpl
+
+using namespace gbmimpl;
+
+extern "C" {
+
+int gbm_block_incref(gbm_manager *m, const uint8_t hash[32])
+{
+	if (!m || !hash)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	Hash h((const char *)hash, 32);
+	bool was_zero;
+	{
+		gbm_manager::RcStripe &s = m->rc_of(h);
+		std::lock_guard<std::mutex> lk(s.mu);
+		RcEntry &e = s.map[h];
+		was_zero = e.is_zero();
+		e.v = e.kind == RcEntry::Present ? e.v + 1 : 1;
+		e.kind = RcEntry::Present;
+	}
+	// "there is normally a node that is responsible for sending us the data of the block.  However that
+	// operation may fail, so in all cases we add the block here to the todo list" (manager.rs:452-475)
+	if (was_zero)
+		m->put_to_resync(h, m->incref_delay_ms.load());
+	return GBM_OK;
+}
+
+int gbm_block_decref(gbm_manager *m, const uint8_t hash[32])
+{
+	if (!m || !hash)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	Hash h((const char *)hash, 32);
+	bool deletable = false;
+	{
+		gbm_manager::RcStripe &s = m->rc_of(h);
+		std::lock_guard<std::mutex> lk(s.mu);
+		auto it = s.map.find(h);
+		if (it != s.map.end() && it->second.kind == RcEntry::Present) {
+			if (it->second.v > 1) {
+				--it->second.v;
+			} else {
+				it->second.kind = RcEntry::Deletable;
+				it->second.v = m->now() + m->gc_delay_ms.load();
+				deletable = true;
+			}
+		}  // Deletable / Absent stay what they are (RcEntry::decrement)
+	}
+	if (deletable)  // handled in the resync loop after the GC delay has passed (manager.rs:478-500)
+		m->put_to_resync(h, m->gc_delay_ms.load() + 10000);
+	return GBM_OK;
+}
+
+int gbm_block_rc(gbm_manager *m, const uint8_t hash[32], uint64_t out[3])
+{
+	if (!m || !hash || !out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	RcEntry e = m->get_rc(Hash((const char *)hash, 32));
+	out[0] = e.kind == RcEntry::Present ? e.v : 0;
+	out[1] = e.kind;
+	out[2] = e.kind == RcEntry::Deletable ? e.v : 0;
+	return GBM_OK;
+}
+
+int gbm_put_to_resync(gbm_manager *m, const uint8_t hash[32], uint64_t delay_ms)
+{
+	if (!m || !hash)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	m->put_to_resync(Hash((const char *)hash, 32), delay_ms);
+	return GBM_OK;
+}
+
+// One pass of resync_iter over everything that is due (resync.rs:255-337).
+int gbm_resync_run(gbm_manager *mg, size_t max_blocks, uint64_t stats[8])
+{
+	if (!mg)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	ResyncStats st;
+	std::vector<ResyncTask> tasks;
+	std::vector<std::pair<uint64_t, Hash>> taken;
+	const uint64_t now = mg->now(), base = mg->retry_delay_ms.load();
+	{
+		std::lock_guard<std::mutex> g(mg->rs_mu);
+		std::set<Hash> seen;
+		for (auto it = mg->rs_queue.begin(); it != mg->rs_queue.end() && it->first <= now;) {
+			if (max_blocks && taken.size() >= max_blocks)
+				break;
+			const Hash &h = it->second;
+			auto ec = mg->rs_errors.find(h);
+			if (ec != mg->rs_errors.end() && now < ec->second.next_try(base)) {
+				// still inside the back-off: keep the entry, at the time it may be retried
+				mg->rs_queue.insert({ec->second.next_try(base), h});
+				it = mg->rs_queue.erase(it);
+				++st.skipped;
+				continue;
+			}
+			if (seen.insert(h).second)
+				taken.push_back(*it);
+			it = mg->rs_queue.erase(it);
+		}
+	}
+	st.taken = taken.size();
+	tasks.resize(taken.size());
+	for (size_t i = 0; i < taken.size(); ++i)
+		tasks[i].h = taken[i].second;
+	int result = GBM_OK;
+	try {
+		resync_blocks(mg, tasks, st);
+	} catch (const std::exception &e) {
+		for (auto &t : tasks)
+			if (t.error.empty())
+				t.error = e.what();
+	}
+	{
+		std::lock_guard<std::mutex> g(mg->rs_mu);
+		for (auto &t : tasks) {
+			if (t.error.empty()) {
+				mg->rs_errors.erase(t.h);
+				++st.ok;
+				continue;
+			}
+			++st.errors;
+			result = fail(t.error.rfind("Missing block", 0) == 0 ? GBM_E_MISSING_BLOCK : GBM_E_IO, t.error);
+			ErrorCounter &ec = mg->rs_errors[t.h];
+			ec.errors += 1;
+			ec.last_try = now + 1;
+			mg->rs_queue.insert({ec.next_try(base), t.h});
+		}
+	}
+	if (stats) {
+		const uint64_t v[8] = {st.taken, st.ok, st.errors, st.skipped, st.rebuilt, st.deleted, st.offloaded, st.device_calls};
+		std::copy(v, v + 8, stats);
+	}
+	return result;
+}
+
+int gbm_resync_block(gbm_manager *mg, const uint8_t hash[32], int *changed)
+{
+	if (!mg || !hash)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	std::vector<ResyncTask> tasks(1);
+	tasks[0].h.assign((const char *)hash, 32);
+	ResyncStats st;
+	try {
+		resync_blocks(mg, tasks, st);
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("resync_block: ") + e.what());
+	}
+	if (changed)
+		*changed = tasks[0].changed;
+	if (!tasks[0].error.empty())
+		return fail(tasks[0].error.rfind("Missing block", 0) == 0 ? GBM_E_MISSING_BLOCK : GBM_E_IO, tasks[0].error);
+	return GBM_OK;
+}
+
+int gbm_resync_all(gbm_manager *mg, int *changed)
+{
+	if (!mg)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	int total = 0, result = GBM_OK;
+	for (int round = 0; round < 64; ++round) {
+		uint64_t st[8];
+		int rc = gbm_resync_run(mg, 0, st);
+		if (rc)
+			result = rc;
+		total += (int)(st[4] + st[5] + st[6]);
+		if (st[0] == 0)
+			break;
+	}
+	if (changed)
+		*changed = total;
+	return result;
+}
+
+size_t gbm_resync_queue_len(const gbm_manager *m)
+{
+	if (!m)
+		return 0;
+	std::lock_guard<std::mutex> lk(m->rs_mu);
+	return m->rs_queue.size();
+}
+
+size_t gbm_resync_errors_len(const gbm_manager *m)
+{
+	if (!m)
+		return 0;
+	std::lock_guard<std::mutex> lk(m->rs_mu);
+	return m->rs_errors.size();
+}
+
+int gbm_resync_worker_start(gbm_manager *m)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	std::lock_guard<std::mutex> g(m->rs_mu);
+	if (m->rs_worker.joinable())
+		return GBM_OK;
+	m->rs_worker_stop = false;
+	m->rs_worker = std::thread([m] {
+		std::unique_lock<std::mutex> lk(m->rs_mu);
+		while (!m->rs_worker_stop) {
+			const uint64_t now = m->now();
+			if (!m->rs_queue.empty() && m->rs_queue.begin()->first <= now) {
+				lk.unlock();
+				(void)gbm_resync_run(m, 1024, nullptr);
+				lk.lock();
+				continue;
+			}
+			// idle until the first entry is due, something is queued, or 10 s pass (resync.rs:325-336)
+			uint64_t wait_ms = 10000;
+			if (!m->rs_queue.empty())
+				wait_ms = std::min<uint64_t>(wait_ms, m->rs_queue.begin()->first - now);
+			m->rs_cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(std::max<uint64_t>(wait_ms, 1)));
+		}
+	});
+	return GBM_OK;
+}
+
+int gbm_resync_worker_stop(gbm_manager *m)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	std::thread t;
+	{
+		std::lock_guard<std::mutex> g(m->rs_mu);
+		if (!m->rs_worker.joinable())
+			return GBM_OK;
+		m->rs_worker_stop = true;
+		t = std::move(m->rs_worker);
+	}
+	m->rs_cv.notify_all();
+	t.join();
+	return GBM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,990 @@
+// bm_rw.cpp -- the request path: rpc_put_block(s) (encode + checksums in ONE device trip, per-node fan-out, write
+// quorum) and rpc_get_block(s) (gather k shards, ONE decode + verify trip, assembly), plus their C entry points.
+#include "bm_internal.hpp"
+
+namespace gbmimpl {
+
+// Fetch shards until every block has `want` valid ones of one geometry in hand (or ran out of nodes): shard
+// index order within the current layout version, then older versions (block_read_nodes_of interleaves
+// versions the same way, rpc_helper.rs:570-619).  The checksums of each round's candidates are verified in
+// ONE batch; a shard whose checksum or header does not match is treated as missing, renamed *.corrupted and
+// queued for resync (read_block_from's behaviour, manager.rs:577-609), and the next node is tried in the
+// following round.
+int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, int want, std::vector<Gathered> &gs,
+		bool verify, const std::vector<uint8_t> *only)
+{
+	// verify == false: shards are accepted on their header alone; the caller checks the checksums in the same
+	// device trip that decodes (gec_decode_verify_batch) and comes back for more (`only` = blocks to continue)
+	const int n = mg->n;
+	const int vcur = mg->layout_cur.load(), vold = mg->layout_oldest.load();
+	const size_t ncand = (size_t)(vcur - vold + 1) * n;
+	if (!only)
+		gs.assign(hs.size(), Gathered());
+	struct Cand {
+		size_t b;
+		int j, node;
+		Shard s;
+	};
+	auto have = [&](const Gathered &g, int j) { return g.settled ? !g.shard[j].empty() : g.have_idx(j); };
+	auto in_hand = [&](const Gathered &g) { return g.settled ? g.count : g.best(); };
+	// header checks every fetched shard passes before it becomes a candidate; called by one thread per block
+	auto accept = [&](std::vector<Cand> &mine, size_t b, int j, int node, Shard &&sh) -> bool {
+		Gathered &g = gs[b];
+		ShardHeader &hd = sh.hd;
+		if (hd.version != 1 && hd.version != 2)
+			return false;  // a shard format this build does not know: unreadable for us, but left alone (never renamed)
+		bool ok = hd.idx == j && hd.k == mg->k && hd.m == mg->m && sh.data.n == hd.shard_len && hd.shard_len > 0 &&
+			  hd.shard_len % 64 == 0;
+		if (ok && hd.version == 1) {
+			// round 1's format: the checksum is plain blake2sum.  Verified here, on the host (there are at most a
+			// cluster's worth of such shards and each is read this way once), then carried -- and rewritten on its
+			// node -- as version 2, so that everything downstream sees one format.
+			uint8_t sum[32];
+			blake2sum(sh.data.data(), hd.shard_len, sum);
+			ok = std::memcmp(sum, hd.checksum, 32) == 0;
+			if (ok) {
+				hd.version = 2;
+				shardsum(sh.data.data(), hd.shard_len, hd.checksum);
+				ShardRpc up{RpcKind::PutShard, &hs[b], j, sh, nullptr};
+				ShardResp ur;
+				(void)mg->nodes[node]->handle(up, ur);
+			}
+		}
+		if (!ok) {
+			mg->metrics[2]++;
+			mg->nodes[node]->mark_corrupted(hs[b], j);
+			mg->put_to_resync(hs[b], 0);
+			return false;
+		}
+		if (g.settled &&
+		    (hd.compressed != g.meta.compressed || hd.orig_len != g.meta.orig_len || hd.shard_len != g.meta.shard_len)) {
+			g.mixed = true;  // a stale shard of another geometry: resync will overwrite it
+			return false;
+		}
+		mine.push_back(Cand{b, j, node, std::move(sh)});
+		return true;
+	};
+	// next (version, shard index) candidate of block b that is not in hand and not already asked for this round
+	// (`taken(j)`: shard j is already covered this round; a j whose request failed is asked again from the holder
+	// in the next older layout version)
+	auto next_candidate = [&](size_t b, const std::function<bool(int)> &taken, std::vector<int> &who, int &who_v,
+				  int &j_out) -> bool {
+		Gathered &g = gs[b];
+		while (g.next < ncand) {
+			const size_t c = g.next++;
+			const int v = vcur - (int)(c / n), j = (int)(c % n);
+			if (have(g, j) || taken(j))
+				continue;
+			if (v != who_v) {
+				mg->nodes_of(hs[b], v, who);
+				who_v = v;
+			}
+			j_out = j;
+			return true;
+		}
+		return false;
+	};
+	const uint64_t hedge_us = mg->hedge_us.load();
+	for (;;) {
+		std::vector<std::vector<Cand>> per(hs.size());
+		if (hedge_us == 0) {
+			mg->pool->parallel_for(hs.size(), [&](size_t b) {
+				if (only && !(*only)[b])
+					return;
+				Gathered &g = gs[b];
+				int pending = 0, who_v = -1, j = 0;
+				std::vector<int> who;
+				auto taken = [&](int jj) {
+					for (const Cand &pc : per[b])
+						if (pc.j == jj)
+							return true;
+					return false;
+				};
+				while (in_hand(g) + pending < want && next_candidate(b, taken, who, who_v, j)) {
+					ShardRpc rq{RpcKind::GetShard, &hs[b], j, Shard(), tags ? &tags[b] : nullptr};
+					ShardResp rs;
+					if (!mg->nodes[who[j]]->handle(rq, rs) || !rs.ok)
+						continue;
+					if (accept(per[b], b, j, who[j], std::move(rs.shard)))
+						++pending;
+				}
+			});
+		} else {
+			// Hedged round: every request of the round is in flight at once; when some have not answered
+			// after hedge_us, the next candidates (the parity holders, then older layout versions) are
+			// asked as well, and a block moves on as soon as it has its shards from whoever answered
+			// first.  Requests that lose the race are abandoned, not cancelled: they own their state.
+			struct Flight {
+				size_t b;
+				int j, node;
+				Hash h;
+				gbm_order_tag tag;
+				bool has_tag, answered = false, done = false;
+				ShardResp rs;
+			};
+			struct Round {
+				std::mutex mu;
+				std::condition_variable cv;
+				std::vector<int> need, ok, outstanding;
+				size_t unsatisfied = 0;
+				std::atomic<bool> over{false};  // the round has what it needs: requests not yet started are dropped
+				bool satisfied(size_t b) const { return ok[b] >= need[b] || outstanding[b] == 0; }
+			};
+			auto rd = std::make_shared<Round>();
+			rd->need.assign(hs.size(), 0);
+			rd->ok.assign(hs.size(), 0);
+			rd->outstanding.assign(hs.size(), 0);
+			std::vector<std::shared_ptr<Flight>> flights;
+			std::vector<std::vector<size_t>> flights_of(hs.size());
+			std::vector<std::vector<int>> who(hs.size());
+			std::vector<int> who_v(hs.size(), -1);
+			std::shared_ptr<Async> async = mg->async_pool();
+			// caller holds rd->mu
+			auto launch = [&](size_t b, int count) -> int {
+				int launched = 0, j = 0;
+				auto taken = [&](int jj) {  // in flight, or answered with a shard
+					for (size_t fi : flights_of[b]) {
+						const Flight &f = *flights[fi];
+						if (f.j == jj && (!f.done || (f.answered && f.rs.ok)))
+							return true;
+					}
+					return false;
+				};
+				while (launched < count && next_candidate(b, taken, who[b], who_v[b], j)) {
+					flights_of[b].push_back(flights.size());
+					auto f = std::make_shared<Flight>();
+					f->b = b;
+					f->j = j;
+					f->node = who[b][j];
+					f->h = hs[b];
+					f->has_tag = tags != nullptr;
+					if (tags)
+						f->tag = tags[b];
+					flights.push_back(f);
+					const bool was = rd->satisfied(b);
+					rd->outstanding[b]++;
+					if (was && !rd->satisfied(b))
+						rd->unsatisfied++;
+					Node *nd = mg->nodes[f->node].get();
+					async->submit([rd, f, nd] {
+						ShardRpc rq{RpcKind::GetShard, &f->h, f->j, Shard(), f->has_tag ? &f->tag : nullptr};
+						ShardResp rs;
+						const bool answered = !rd->over.load() && nd->handle(rq, rs);
+						{
+							std::lock_guard<std::mutex> g(rd->mu);
+							f->rs = std::move(rs);
+							f->answered = answered;
+							f->done = true;
+							const bool was_sat = rd->satisfied(f->b);
+							rd->outstanding[f->b]--;
+							if (answered && f->rs.ok)
+								rd->ok[f->b]++;
+							if (!was_sat && rd->satisfied(f->b))
+								rd->unsatisfied--;
+						}
+						rd->cv.notify_all();
+					});
+					++launched;
+				}
+				return launched;
+			};
+			std::unique_lock<std::mutex> lk(rd->mu);
+			for (size_t b = 0; b < hs.size(); ++b) {
+				if (only && !(*only)[b])
+					continue;
+				rd->need[b] = std::max(0, want - in_hand(gs[b]));
+				launch(b, rd->need[b]);
+			}
+			// (system_clock: pthread_cond_timedwait, which ThreadSanitizer understands; gcc 11's does not know
+			// the pthread_cond_clockwait a steady_clock deadline turns into)
+			const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(hedge_us);
+			if (!rd->cv.wait_until(lk, deadline, [&] { return rd->unsatisfied == 0; })) {
+				uint64_t hedges = 0;
+				for (size_t b = 0; b < hs.size(); ++b)
+					if (!rd->satisfied(b))
+						hedges += launch(b, rd->need[b] - rd->ok[b]);
+				mg->hedged_reads += hedges;
+				rd->cv.wait(lk, [&] { return rd->unsatisfied == 0; });
+			}
+			rd->over = true;
+			for (auto &f : flights)
+				if (f->done && f->answered && f->rs.ok)
+					accept(per[f->b], f->b, f->j, f->node, std::move(f->rs.shard));
+		}
+		std::vector<Cand *> cands;
+		for (auto &v : per)
+			for (Cand &c : v)
+				cands.push_back(&c);
+		if (cands.empty())
+			break;
+		std::vector<uint8_t> sums;
+		if (verify) {
+			std::vector<const uint8_t *> ptrs(cands.size());
+			std::vector<size_t> lens(cands.size());
+			for (size_t i = 0; i < cands.size(); ++i) {
+				ptrs[i] = cands[i]->s.data.data();
+				lens[i] = cands[i]->s.hd.shard_len;
+			}
+			int rc = hash_many(mg, ptrs, lens, sums);
+			if (rc)
+				return rc;
+		}
+		for (size_t i = 0; i < cands.size(); ++i) {
+			Cand &c = *cands[i];
+			Gathered &g = gs[c.b];
+			if (verify && std::memcmp(sums.data() + 32 * i, c.s.hd.checksum, 32) != 0) {
+				mg->metrics[2]++;
+				mg->nodes[c.node]->mark_corrupted(hs[c.b], c.j);
+				mg->put_to_resync(hs[c.b], 0);
+				continue;
+			}
+			mg->metrics[1] += c.s.hd.shard_len;
+			std::array<uint8_t, 32> want_sum;
+			std::memcpy(want_sum.data(), c.s.hd.checksum, 32);
+			if (g.settled) {
+				g.shard[c.j] = std::move(c.s.data);
+				g.sum[c.j] = want_sum;
+				g.node[c.j] = c.node;
+				g.count++;
+				continue;
+			}
+			Geometry geo;
+			geo.compressed = c.s.hd.compressed;
+			geo.orig_len = c.s.hd.orig_len;
+			geo.shard_len = c.s.hd.shard_len;
+			Gathered::Group &grp = g.groups[geo];
+			if (grp.shard.empty()) {
+				grp.shard.assign(n, Bytes());
+				grp.sum.assign(n, {});
+				grp.node.assign(n, -1);
+				grp.meta = c.s.hd;
+			}
+			grp.shard[c.j] = std::move(c.s.data);
+			grp.sum[c.j] = want_sum;
+			grp.node[c.j] = c.node;
+			grp.count++;
+		}
+	}
+	// settle on the largest consistent group; the stragglers of other geometries are
+	// stale leftovers that resync will overwrite
+	for (size_t b = 0; b < hs.size(); ++b) {
+		Gathered &g = gs[b];
+		if (g.settled || (only && !(*only)[b]))
+			continue;
+		Gathered::Group *bestg = nullptr;
+		for (auto &kv : g.groups)
+			if (!bestg || kv.second.count > bestg->count)
+				bestg = &kv.second;
+		if (bestg) {
+			g.shard = std::move(bestg->shard);
+			g.sum = std::move(bestg->sum);
+			g.node = std::move(bestg->node);
+			g.meta = bestg->meta;
+			g.have_meta = true;
+			g.count = bestg->count;
+			g.mixed = g.groups.size() > 1;
+		} else {
+			g.shard.assign(n, Bytes());
+			g.sum.assign(n, {});
+			g.node.assign(n, -1);
+		}
+		g.settled = true;
+		g.groups.clear();
+	}
+	for (size_t b = 0; b < hs.size(); ++b)
+		if (gs[b].mixed && (!only || (*only)[b]))
+			mg->put_to_resync(hs[b], 0);
+	return GBM_OK;
+}
+
+// PutShard to one node; false = the node could not be contacted or refused
+bool send_shard(gbm_manager *mg, int node, const Hash &h, int idx, const Bytes &payload, size_t S, uint64_t orig_len,
+		bool compressed, const uint8_t *checksum, const gbm_order_tag *tag, bool *pending)
+{
+	ShardRpc rq{RpcKind::PutShard, &h, idx, Shard(), tag};
+	ShardHeader &hd = rq.shard.hd;
+	hd.k = (uint8_t)mg->k;
+	hd.m = (uint8_t)mg->m;
+	hd.idx = (uint8_t)idx;
+	hd.compressed = compressed ? 1 : 0;
+	hd.orig_len = orig_len;
+	hd.shard_len = (uint32_t)S;
+	if (checksum)
+		std::memcpy(hd.checksum, checksum, 32);
+	else
+		shardsum(payload.data(), S, hd.checksum);
+	rq.shard.data = payload;
+	ShardResp rs;
+	const bool ok = mg->nodes[node]->handle(rq, rs) && rs.ok;
+	if (pending)
+		*pending = ok && rs.pending;
+	return ok;
+}
+
+// rcs (optional): per-block result, GBM_OK or GBM_E_QUORUM; the return value is the last failure.  The device
+// work of the whole batch happens before anything is sent to a node, so a device error (GBM_E_EC) fails
+// every block of the batch and leaves no partial state behind.  (gbm_rpc_put_blocks cuts a big untagged request into
+// slices that are independent puts: a device error in one slice does not undo the others.)
+// Whatever the outcome, every entry of rcs is set: a whole-batch failure marks every block.
+int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data, const size_t *len,
+		    const uint8_t *prevent_compression, const gbm_order_tag *tags, int *rcs, const FanoutGate *gate)
+{
+	auto fail_all = [&](int code, const std::string &msg) {
+		if (rcs)
+			std::fill(rcs, rcs + nb, code);
+		return fail(code, msg);
+	};
+	if (!mg || (nb && (!hashes || !data || !len)))
+		return fail_all(GBM_E_INVALID_ARG, "NULL argument");
+	if (nb == 0)
+		return GBM_OK;
+	for (size_t b = 0; b < nb; ++b)
+		if (!data[b] && len[b])
+			return fail_all(GBM_E_INVALID_ARG, "NULL block pointer");
+	if (rcs)
+		std::fill(rcs, rcs + nb, GBM_OK);
+	const int k = mg->k, m = mg->m, n = mg->n;
+	const bool compress = mg->compress.load();
+	const int level = mg->compression_level.load();
+	// -- DataBlock::from_buffer (zstd when a level is configured and the caller did not forbid it, Plain on any
+	//    encoder error), then ONE copy of the payload into a zero-padded k*S buffer whose slices are the k data
+	//    shards.  Shard geometry is a pure function of the block: S = gec_shard_len(k, payload length) --
+	//    never the batch maximum: a later put of the same block must produce compatible shards.
+	struct Prep {
+		Bytes block, parity;
+		size_t plen = 0, S = 0;
+		bool z = false;
+	};
+	std::vector<Prep> prep(nb);
+	std::atomic<bool> oom{false};
+	Trace tr("put");
+	mg->pool->parallel_for(nb, [&](size_t b) {
+		try {
+			Prep &p = prep[b];
+			std::vector<uint8_t> zbuf;
+			const uint8_t *src = data[b];
+			p.plen = len[b];
+			if (compress && !(prevent_compression && prevent_compression[b]) &&
+			    zstd().encode(data[b], len[b], level, zbuf)) {
+				src = zbuf.data();
+				p.plen = zbuf.size();
+				p.z = true;
+			}
+			p.S = gec_shard_len(k, p.plen);
+			p.block = mg->bufs->get((size_t)k * p.S);
+			if (p.plen)
+				std::memcpy(p.block.mut(), src, p.plen);
+			std::memset(p.block.mut() + p.plen, 0, (size_t)k * p.S - p.plen);
+			p.parity = mg->bufs->get((size_t)m * p.S);
+		} catch (const std::bad_alloc &) {
+			oom = true;
+		}
+	});
+	if (oom)
+		return fail_all(GBM_E_IO, "out of (pinned) host memory for the shard buffers");
+	tr.lap("prep");
+	// Blocks of equal S -- in practice all full block_size blocks -- share ONE device call that returns
+	// parity and the checksums of all k+m shards.
+	std::map<size_t, std::vector<size_t>> by_s;
+	for (size_t b = 0; b < nb; ++b)
+		by_s[prep[b].S].push_back(b);
+	std::vector<uint8_t> sums(nb * (size_t)n * 32);
+	for (auto &kv : by_s) {
+		const size_t S = kv.first;
+		const std::vector<size_t> &ids = kv.second;
+		const size_t gn = ids.size();
+		std::vector<uint8_t *> pp(gn);
+		std::vector<const uint8_t *> gd(gn);
+		std::vector<size_t> gl(gn, (size_t)k * S);  // the buffers are already padded: whole data area
+		std::vector<uint8_t> gsums(gn * (size_t)n * 32);
+		for (size_t i = 0; i < gn; ++i) {
+			pp[i] = prep[ids[i]].parity.mut();
+			gd[i] = prep[ids[i]].block.data();
+		}
+		int rc = gec_encode_hash_batch(mg->codec, gn, gd.data(), gl.data(), S, pp.data(), gsums.data());
+		if (rc) {  // nothing has been sent to any node yet: the whole batch fails
+			if (rcs)
+				std::fill(rcs, rcs + nb, GBM_E_EC);
+			return ec_fail(rc, "gec_encode_hash_batch");
+		}
+		mg->gpu_hashed += gn * (size_t)n;
+		for (size_t i = 0; i < gn; ++i)
+			std::memcpy(sums.data() + ids[i] * (size_t)n * 32, gsums.data() + i * (size_t)n * 32, (size_t)n * 32);
+	}
+	tr.lap("encode+hash");
+	// From here on shards of these blocks start to exist.  A block that nobody references yet (PutObject runs the
+	// put and the block_ref incref concurrently, src/api/s3/put.rs:545-581) is protected for BLOCK_GC_DELAY exactly
+	// like one whose count just dropped to zero -- and it is protected BEFORE its first shard is written, under the
+	// hash's mutation lock: resync's delete branch re-reads the refcount under the same lock right before it
+	// deletes, so it either finishes before this stamp (and the shards written below are new) or sees it.
+	for (size_t b = 0; b < nb; ++b) {
+		Hash h((const char *)hashes + 32 * b, 32);
+		std::lock_guard<std::mutex> ml(mg->lock_mutate(h));
+		gbm_manager::RcStripe &st = mg->rc_of(h);
+		std::lock_guard<std::mutex> g(st.mu);
+		RcEntry &e = st.map[h];
+		if (e.kind != RcEntry::Present) {
+			e.kind = RcEntry::Deletable;
+			e.v = std::max(e.v, mg->now() + mg->gc_delay_ms.load());
+		}
+	}
+	// fan-out: shard j of every block to nodes_of(hash)[j].  With order tags the blocks go out one after the
+	// other in (stream, order) order -- requests of one stream reach a node in `order` order, whatever their
+	// shard geometry; without tags the blocks are independent and go out from the pool's threads.
+	std::vector<int> oks(nb, 0);
+	// shards that a node parked beside a shard of another geometry (ShardResp::pending): committed once the block has
+	// its quorum, dropped otherwise
+	std::mutex parked_mu;
+	std::vector<std::tuple<size_t, int, int>> parked;  // (block, shard idx, node)
+	auto note_parked = [&](size_t b, int j, int node) {
+		std::lock_guard<std::mutex> g(parked_mu);
+		parked.emplace_back(b, j, node);
+	};
+	if (gate && gate->before)
+		gate->before();
+	auto fan_out = [&](size_t b) {
+		Hash h((const char *)hashes + 32 * b, 32);
+		std::vector<int> who;
+		mg->nodes_of(h, who);
+		const size_t S = prep[b].S;
+		int ok = 0;
+		for (int j = 0; j < n; ++j) {
+			const Bytes payload = j < k ? prep[b].block.slice((size_t)j * S, S) : prep[b].parity.slice((size_t)(j - k) * S, S);
+			bool pend = false;
+			if (send_shard(mg, who[j], h, j, payload, S, prep[b].plen, prep[b].z, sums.data() + (b * n + j) * 32,
+				       tags ? &tags[b] : nullptr, &pend)) {
+				++ok;
+				mg->metrics[0] += S;
+				if (pend)
+					note_parked(b, j, who[j]);
+			}
+		}
+		oks[b] = ok;
+	};
+	if (tags) {
+		// order is a per-node property (requests of one stream reach a NODE in `order` order): the nodes are served
+		// side by side, each one walking the blocks in (stream, order) order and taking the shards that are its own
+		std::vector<size_t> order(nb);
+		for (size_t i = 0; i < nb; ++i)
+			order[i] = i;
+		std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+			return std::tie(tags[x].stream_id, tags[x].order) < std::tie(tags[y].stream_id, tags[y].order);
+		});
+		std::vector<std::vector<int>> who(nb);
+		for (size_t b = 0; b < nb; ++b)
+			mg->nodes_of(Hash((const char *)hashes + 32 * b, 32), who[b]);
+		std::vector<std::atomic<int>> okc(nb);
+		for (auto &x : okc)
+			x = 0;
+		mg->pool->parallel_for(mg->nodes.size(), [&](size_t node) {
+			for (size_t b : order) {
+				const size_t S = prep[b].S;
+				for (int j = 0; j < n; ++j) {
+					if (who[b][j] != (int)node)
+						continue;
+					const Hash h((const char *)hashes + 32 * b, 32);
+					const Bytes payload = j < k ? prep[b].block.slice((size_t)j * S, S) : prep[b].parity.slice((size_t)(j - k) * S, S);
+					bool pend = false;
+					if (send_shard(mg, (int)node, h, j, payload, S, prep[b].plen, prep[b].z, sums.data() + (b * n + j) * 32, &tags[b], &pend)) {
+						++okc[b];
+						mg->metrics[0] += S;
+						if (pend)
+							note_parked(b, j, (int)node);
+					}
+				}
+			}
+		});
+		for (size_t b = 0; b < nb; ++b)
+			oks[b] = okc[b].load();
+	} else {
+		mg->pool->parallel_for(nb, fan_out);
+	}
+	if (gate && gate->after)
+		gate->after();
+	tr.lap("fan-out");
+	for (auto &pk : parked) {  // rare: the block existed with another geometry
+		const size_t b = std::get<0>(pk);
+		const Hash h((const char *)hashes + 32 * b, 32);
+		ShardRpc rq{oks[b] >= mg->write_quorum ? RpcKind::CommitShard : RpcKind::AbortShard, &h, std::get<1>(pk), Shard(), nullptr};
+		ShardResp rs;
+		(void)mg->nodes[std::get<2>(pk)]->handle(rq, rs);
+	}
+	int result = GBM_OK;
+	for (size_t b = 0; b < nb; ++b) {
+		Hash h((const char *)hashes + 32 * b, 32);
+		mg->metrics[4]++;
+		if (oks[b] < mg->write_quorum) {
+			result = fail(GBM_E_QUORUM, "Could not reach quorum of " + std::to_string(mg->write_quorum) + ". " +
+							    std::to_string(oks[b]) + " of " + std::to_string(n) + " request succeeded");
+			if (rcs)
+				rcs[b] = GBM_E_QUORUM;
+			continue;
+		}
+		if (oks[b] < n)
+			mg->put_to_resync(h, 0);  // stragglers: resync rebuilds what is absent (it only REBUILDS while the block is needed)
+	}
+	return result;
+}
+
+// gather + verify + decode, in rounds of ONE device trip each (gec_decode_verify_batch: shard checksums, rebuild
+// of missing data shards and the block's own blake2sum from a single upload).  A shard whose checksum does not
+// match its header is treated the way read_block_from treats a corrupt file (manager.rs:577-609): renamed
+// *.corrupted, queued for resync, and the read carries on with the next node.
+// On return, for every block with rcs[b] == GBM_OK, g[b].shard[0..k-1] hold the stored DataBlock (plain bytes or
+// one zstd frame, orig_len bytes) and block_sums[32*b..] its blake2sum (when want_block_sums).
+// `overlap` (optional) runs on a helper thread while the first device trip is in flight -- the caller assembles the
+// blocks that need no decode into its output buffers meanwhile; `changed[b]` is set for every block whose shard set
+// changed after that point (bit 0: a shard failed its checksum and was replaced, bit 1: a data shard was rebuilt).
+int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs,
+		 bool want_block_sums, std::vector<uint8_t> &block_sums, const std::function<void()> &overlap,
+		 std::vector<uint8_t> *changed)
+{
+	const int k = mg->k, n = mg->n;
+	const size_t nb = hs.size();
+	block_sums.assign(want_block_sums ? nb * 32 : 0, 0);
+	if (changed)
+		changed->assign(nb, 0);
+	Trace tr("get");
+	int grc = gather_many(mg, hs, tags, k, g, /*verify=*/false);
+	if (grc)
+		return grc;
+	tr.lap("gather");
+	std::thread helper;
+	struct Joiner {
+		std::thread &t;
+		~Joiner()
+		{
+			if (t.joinable())
+				t.join();
+		}
+	} joiner{helper};
+	if (overlap)
+		helper = std::thread(overlap);
+	std::vector<uint8_t> todo(nb, 1);
+	for (int round = 0; round <= n; ++round) {
+		if (round == 1 && helper.joinable())
+			helper.join();
+		std::map<size_t, std::vector<size_t>> by_s;
+		for (size_t b = 0; b < nb; ++b) {
+			if (!todo[b])
+				continue;
+			if (!g[b].have_meta || g[b].count < k) {
+				rcs[b] = GBM_E_MISSING_BLOCK;
+				todo[b] = 0;
+				continue;
+			}
+			if (g[b].meta.orig_len > (uint64_t)k * g[b].meta.shard_len) {
+				rcs[b] = GBM_E_CORRUPT_DATA;
+				todo[b] = 0;
+				continue;
+			}
+			by_s[g[b].meta.shard_len].push_back(b);
+		}
+		if (by_s.empty())
+			break;
+		std::vector<uint8_t> again(nb, 0);
+		bool any_again = false;
+		for (auto &kv : by_s) {
+			const size_t S = kv.first;
+			const std::vector<size_t> &ids = kv.second;
+			std::vector<const uint8_t *> sp(ids.size() * n, nullptr);
+			std::vector<uint8_t *> op(ids.size() * n, nullptr);
+			std::vector<size_t> lens(ids.size());
+			std::vector<uint8_t> ssums(ids.size() * (size_t)n * 32), bsums(want_block_sums ? ids.size() * 32 : 0);
+			std::vector<std::vector<Bytes>> fresh(ids.size(), std::vector<Bytes>(k));
+			size_t nrebuild = 0;
+			try {
+				for (size_t i = 0; i < ids.size(); ++i) {
+					Gathered &gb = g[ids[i]];
+					lens[i] = gb.meta.orig_len;
+					for (int j = 0; j < n; ++j) {
+						if (!gb.shard[j].empty()) {
+							sp[i * n + j] = gb.shard[j].data();
+						} else if (j < k) {
+							fresh[i][j] = mg->bufs->get(S);
+							op[i * n + j] = fresh[i][j].mut();
+							++nrebuild;
+						}
+					}
+				}
+			} catch (const std::bad_alloc &) {
+				return fail(GBM_E_IO, "out of (pinned) host memory");
+			}
+			int rc = gec_decode_verify_batch(mg->codec, ids.size(), sp.data(), S, lens.data(), op.data(), ssums.data(),
+							 want_block_sums ? bsums.data() : nullptr);
+			tr.lap("decode+verify");
+			if (helper.joinable())
+				helper.join();  // the overlapped host work reads g: it must be done before the results below change it
+			tr.lap("join overlapped assembly");
+			if (rc)
+				return ec_fail(rc, "gec_decode_verify_batch");
+			mg->gpu_hashed += ids.size() * (size_t)k + (want_block_sums ? ids.size() : 0);
+			for (size_t i = 0; i < ids.size(); ++i) {
+				const size_t b = ids[i];
+				Gathered &gb = g[b];
+				// the shards that were read: the first k present, in index order
+				int seen = 0;
+				bool bad = false;
+				for (int j = 0; j < n && seen < k; ++j) {
+					if (gb.shard[j].empty())
+						continue;
+					++seen;
+					if (std::memcmp(ssums.data() + (i * n + j) * 32, gb.sum[j].data(), 32) != 0) {
+						mg->metrics[2]++;
+						if (gb.node[j] >= 0)
+							mg->nodes[gb.node[j]]->mark_corrupted(hs[b], j);
+						mg->put_to_resync(hs[b], 0);
+						gb.shard[j] = Bytes();
+						gb.count--;
+						bad = true;
+					}
+				}
+				if (bad) {
+					again[b] = 1;
+					any_again = true;
+					if (changed)
+						(*changed)[b] |= 1;  // a shard in hand was replaced
+					continue;
+				}
+				bool rebuilt_any = false;
+				for (int j = 0; j < k; ++j)
+					if (!fresh[i][j].empty()) {
+						gb.shard[j] = fresh[i][j];
+						rebuilt_any = true;
+					}
+				if (rebuilt_any) {
+					mg->metrics[3]++;
+					if (changed)
+						(*changed)[b] |= 2;  // missing data shards were filled in
+				}
+				if (want_block_sums)
+					std::memcpy(block_sums.data() + 32 * b, bsums.data() + 32 * i, 32);
+				rcs[b] = GBM_OK;
+				todo[b] = 0;
+			}
+			(void)nrebuild;
+		}
+		if (!any_again)
+			break;
+		if (helper.joinable())
+			helper.join();
+		grc = gather_many(mg, hs, tags, k, g, /*verify=*/false, &again);  // the next nodes, for the blocks that lost a shard
+		if (grc)
+			return grc;
+	}
+	for (size_t b = 0; b < nb; ++b)
+		if (todo[b])
+			rcs[b] = GBM_E_MISSING_BLOCK;
+	return GBM_OK;
+}
+
+void assemble(const Gathered &g, int k, uint8_t *dst)
+{
+	const size_t L = g.meta.orig_len, S = g.meta.shard_len;
+	for (int j = 0; j < k; ++j) {
+		const size_t lo = (size_t)j * S;
+		if (lo >= L)
+			break;
+		std::memcpy(dst + lo, g.shard[j].data(), std::min(S, L - lo));
+	}
+}
+
+// raw == true: rpc_get_raw_block (stored bytes + header); false: rpc_get_block (plain bytes).
+int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
+		    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers)
+{
+	if (!mg || (nb && (!hashes || !out || !cap || !len_out || !rcs)))
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	const int k = mg->k;
+	std::vector<Hash> hs(nb);
+	for (size_t b = 0; b < nb; ++b)
+		hs[b].assign((const char *)hashes + 32 * b, 32);
+	std::vector<Gathered> g;
+	std::vector<uint8_t> block_sums, changed, early(nb, 0);
+	const bool verify = mg->verify_block_hash.load();
+	// Where the block's own checksum is computed.  It is one serial BLAKE2b chain per block: ~11 ms per MiB on the
+	// device however many blocks run beside it, ~1 ms per MiB on a host core.  Small requests -- a GetObject reads
+	// its blocks a few at a time -- are hashed by the pool from the assembled bytes; big batches on the device,
+	// behind the upload (gec_decode_verify_batch).
+	const bool cpu_hash = verify && nb <= mg->cpu_block_hash_max.load();
+	// While the device checks the shards, the host already copies the blocks that need no decode (all k data shards in
+	// hand, stored Plain) into the caller's buffers: a block that then fails a checksum is reported as such (its buffer
+	// contents are unspecified on error) or is assembled again from the replaced shards.
+	// (a block with data shards to rebuild gets the shards it has; the rebuilt ones follow after the trip)
+	std::vector<std::vector<uint8_t>> missing_early(nb);  // data shard indices that were not in hand at that point
+	auto assemble_early = [&] {
+		mg->pool->parallel_for(nb, [&](size_t b) {
+			const Gathered &gb = g[b];
+			if (!gb.have_meta || gb.count < k || gb.meta.compressed || gb.meta.orig_len > (uint64_t)k * gb.meta.shard_len ||
+			    cap[b] < gb.meta.orig_len)
+				return;
+			const size_t L = gb.meta.orig_len, S = gb.meta.shard_len;
+			for (int j = 0; j < k && (size_t)j * S < L; ++j) {
+				if (gb.shard[j].empty())
+					missing_early[b].push_back((uint8_t)j);
+				else
+					std::memcpy(out[b] + (size_t)j * S, gb.shard[j].data(), std::min(S, L - (size_t)j * S));
+			}
+			early[b] = 1;
+		});
+	};
+	int frc = fetch_blocks(mg, hs, tags, g, rcs, verify && !cpu_hash, block_sums, assemble_early, &changed);
+	if (frc)
+		return frc;
+	// assemble (parallel), then check every Plain block's content against its name (DataBlock::verify,
+	// block.rs:69-77) -- all block hashes in one batch.  Plain blocks are assembled straight into the
+	// caller's buffer and hashed from there (on CORRUPT_DATA its contents are unspecified); compressed
+	// blocks go through an intermediate for the zstd frame, whose checksum is their verify.
+	mg->pool->parallel_for(nb, [&](size_t b) {
+		len_out[b] = 0;
+		if (rcs[b] != GBM_OK)
+			return;
+		const size_t L = g[b].meta.orig_len;
+		const bool z = g[b].meta.compressed != 0;
+		if (headers)
+			headers[b].kind = z ? GBM_HEADER_COMPRESSED : GBM_HEADER_PLAIN;
+		len_out[b] = L;
+		// DataBlock::verify (block.rs:69-83): Plain = content against its name -- the block's blake2sum came back
+		// from the same device trip that decoded it (or is computed below, cpu_hash); Compressed = the zstd frame
+		// (with its checksum) decodes
+		if (!z && verify && !cpu_hash && std::memcmp(block_sums.data() + 32 * b, hashes + 32 * b, 32) != 0) {
+			rcs[b] = GBM_E_CORRUPT_DATA;
+			return;
+		}
+		if (z && !raw) {
+			std::vector<uint8_t> frame(L), plain;
+			assemble(g[b], k, frame.data());
+			if (!zstd().decode(frame.data(), L, kMaxDecompressed, plain)) {
+				rcs[b] = GBM_E_CORRUPT_DATA;
+				return;
+			}
+			len_out[b] = plain.size();
+			if (cap[b] < plain.size()) {
+				rcs[b] = GBM_E_BUFFER_TOO_SMALL;
+				return;
+			}
+			if (!plain.empty())
+				std::memcpy(out[b], plain.data(), plain.size());
+			mg->metrics[5]++;
+			return;
+		}
+		if (cap[b] < L) {
+			rcs[b] = GBM_E_BUFFER_TOO_SMALL;
+			return;
+		}
+		if (early[b] && !(changed[b] & 1)) {
+			const size_t S = g[b].meta.shard_len;
+			for (uint8_t j : missing_early[b])  // rebuilt since
+				std::memcpy(out[b] + (size_t)j * S, g[b].shard[j].data(), std::min(S, L - (size_t)j * S));
+		} else {
+			assemble(g[b], k, out[b]);
+		}
+		if (!z && cpu_hash) {
+			uint8_t sum[32];
+			blake2sum(out[b], L, sum);
+			if (std::memcmp(sum, hashes + 32 * b, 32) != 0) {
+				rcs[b] = GBM_E_CORRUPT_DATA;
+				return;
+			}
+		}
+		mg->metrics[5]++;
+	});
+	return GBM_OK;
+}
+
+int one_block_rc(int rc1)
+{
+	switch (rc1) {
+	case GBM_E_MISSING_BLOCK: return fail(rc1, "Missing block: no node returned a valid block");
+	case GBM_E_CORRUPT_DATA: return fail(rc1, "Corrupt data: does not match hash");
+	case GBM_E_BUFFER_TOO_SMALL: return fail(rc1, "output buffer too small");
+	default: return rc1;
+	}
+}
+
+}  // namespace gbmimpl
+
+using namespace gbmimpl;
+
+extern "C" {
+
+int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data, const size_t *len,
+		       const uint8_t *prevent_compression, const gbm_order_tag *order_tags)
+{
+	// Large untagged batches go through in slices of 64 blocks on four threads, so that one slice's host work (the copy
+	// into the shard buffers, the fan-out) runs while other slices are on the link: 512 x 1 MiB blocks 26 -> 38 GiB/s
+	// (tools/bm_sweep.sh: 128 x 2 threads 33, 128 x 3 37, 64 x 4 38.6, 64 x 8 39.5).  Tagged batches keep their order.
+	const size_t kSlice = env().put_slice;
+	const int kThreads = env().put_threads;
+	try {
+		if (!mg || order_tags || nb < 2 * kSlice)
+			return put_blocks_impl(mg, nb, hashes, data, len, prevent_compression, order_tags, nullptr);
+		std::atomic<size_t> next{0};
+		std::mutex mu;
+		int result = GBM_OK;
+		std::string err;
+		auto run = [&] {
+			for (;;) {
+				const size_t b0 = next.fetch_add(kSlice);
+				if (b0 >= nb)
+					return;
+				const size_t cnt = std::min(kSlice, nb - b0);
+				int rc;
+				try {
+					rc = put_blocks_impl(mg, cnt, hashes + 32 * b0, data + b0, len + b0,
+							     prevent_compression ? prevent_compression + b0 : nullptr, nullptr, nullptr);
+				} catch (const std::exception &e) {
+					rc = fail(GBM_E_IO, std::string("rpc_put_blocks: ") + e.what());
+				}
+				if (rc) {
+					std::lock_guard<std::mutex> g(mu);
+					result = rc;
+					err = last_error();  // the error text is thread-local: carry it to the caller's thread
+				}
+			}
+		};
+		std::vector<std::thread> others;
+		for (int t = 1; t < kThreads; ++t)
+			others.emplace_back(run);
+		run();
+		for (auto &t : others)
+			t.join();
+		if (result)
+			return fail(result, err);
+		return GBM_OK;
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("rpc_put_blocks: ") + e.what());
+	}
+}
+
+int gbm_rpc_put_block(gbm_manager *m, const uint8_t hash[32], const uint8_t *data, size_t len, int prevent_compression,
+		      const gbm_order_tag *order_tag)
+{
+	const uint8_t *d[1] = {data};
+	const uint8_t pc = prevent_compression ? 1 : 0;
+	return gbm_rpc_put_blocks(m, 1, hash, d, &len, &pc, order_tag);
+}
+
+int gbm_rpc_get_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *order_tags, uint8_t *const *out,
+		       const size_t *cap, size_t *len_out, int *rcs)
+{
+	try {
+		return get_blocks_impl(mg, nb, hashes, order_tags, out, cap, len_out, rcs, false, nullptr);
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("rpc_get_blocks: ") + e.what());
+	}
+}
+
+int gbm_rpc_get_block(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, uint8_t *out, size_t cap,
+		      size_t *len_out)
+{
+	if (!len_out)
+		return fail(GBM_E_INVALID_ARG, "NULL len_out");
+	uint8_t *o[1] = {out};
+	int rc1 = GBM_OK;
+	int rc = gbm_rpc_get_blocks(m, 1, hash, order_tag, o, &cap, len_out, &rc1);
+	return rc ? rc : one_block_rc(rc1);
+}
+
+int gbm_rpc_get_raw_block(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag,
+			  gbm_data_block_header *header_out, uint8_t *out, size_t cap, size_t *len_out)
+{
+	if (!len_out || !header_out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	uint8_t *o[1] = {out};
+	int rc1 = GBM_OK;
+	int rc;
+	try {
+		rc = get_blocks_impl(m, 1, hash, order_tag, o, &cap, len_out, &rc1, true, header_out);
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("rpc_get_raw_block: ") + e.what());
+	}
+	return rc ? rc : one_block_rc(rc1);
+}
+
+static int stream_out(const uint8_t *p, size_t len, size_t chunk_bytes, gbm_chunk_fn sink, void *ctx)
+{
+	const size_t ch = chunk_bytes ? chunk_bytes : 65536;
+	for (size_t off = 0; off < len; off += ch)
+		if (sink(ctx, p + off, std::min(ch, len - off)) != 0)
+			return fail(GBM_E_ABORTED, "the stream's consumer stopped");
+	return GBM_OK;
+}
+
+// one block into a buffer this function owns (the streaming forms do not know the size up front)
+static int get_block_owned(gbm_manager *mg, const uint8_t hash[32], const gbm_order_tag *tag, bool raw,
+			   gbm_data_block_header *hdr, std::vector<uint8_t> &out)
+{
+	const int k = mg->k;
+	std::vector<Hash> hs(1, Hash((const char *)hash, 32));
+	std::vector<Gathered> g;
+	std::vector<uint8_t> block_sums;
+	int rc1 = GBM_OK;
+	const bool verify = mg->verify_block_hash.load();
+	int frc = fetch_blocks(mg, hs, tag, g, &rc1, /*want_block_sums=*/false, block_sums);  // one block: hashed on the host, below
+	if (frc)
+		return frc;
+	if (rc1 != GBM_OK)
+		return one_block_rc(rc1);
+	const size_t L = g[0].meta.orig_len;
+	const bool z = g[0].meta.compressed != 0;
+	if (hdr)
+		hdr->kind = z ? GBM_HEADER_COMPRESSED : GBM_HEADER_PLAIN;
+	std::vector<uint8_t> stored(L);
+	assemble(g[0], k, stored.data());
+	if (!z && verify) {
+		uint8_t sum[32];
+		blake2sum(stored.data(), L, sum);
+		if (std::memcmp(sum, hash, 32) != 0)
+			return one_block_rc(GBM_E_CORRUPT_DATA);
+	}
+	if (z && !raw) {
+		if (!zstd().decode(stored.data(), L, kMaxDecompressed, out))
+			return one_block_rc(GBM_E_CORRUPT_DATA);
+	} else {
+		out.swap(stored);
+	}
+	mg->metrics[5]++;
+	return GBM_OK;
+}
+
+static int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, gbm_data_block_header *hdr,
+			 size_t chunk_bytes, gbm_chunk_fn sink, void *ctx, bool raw)
+{
+	if (!m || !hash || !sink)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	// the shards have to be complete before any byte can be trusted (checksums, decode), so the block is gathered
+	// first and then handed out in order
+	std::vector<uint8_t> buf;
+	gbm_data_block_header h0{};
+	int rc = get_block_owned(m, hash, order_tag, raw, &h0, buf);
+	if (rc)
+		return rc;
+	if (hdr)
+		*hdr = h0;
+	return stream_out(buf.data(), buf.size(), chunk_bytes, sink, ctx);
+}
+
+int gbm_rpc_get_block_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, size_t chunk_bytes,
+				gbm_chunk_fn sink, void *ctx)
+{
+	try {
+		return get_streaming(m, hash, order_tag, nullptr, chunk_bytes, sink, ctx, false);
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("rpc_get_block_streaming: ") + e.what());
+	}
+}
+
+int gbm_rpc_get_raw_block_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag,
+				    gbm_data_block_header *header_out, size_t chunk_bytes, gbm_chunk_fn sink, void *ctx)
+{
+	if (!header_out)
+		return fail(GBM_E_INVALID_ARG, "NULL header_out");
+	try {
+		return get_streaming(m, hash, order_tag, header_out, chunk_bytes, sink, ctx, true);
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("rpc_get_raw_block_streaming: ") + e.what());
+	}
+}
+
+}  // extern "C"

@@ -1,0 +1,567 @@
+// ec_cpu.cpp -- GEC_BACKEND_CPU: libgarage_ec's own data path on the host cores, behind the same host-pointer entry
+// points as the HIP backend and with identical results.
+//
+// Why it exists (SURVEY.md Appendix B's `backend` argument, BASELINE config 1): a Garage node that has no GPU, or has
+// lost it, must still be able to read and repair its erasure-coded blocks; and the insertion point of the codec is a
+// blocking call on a tokio blocking-pool thread either way (src/block/block.rs:85-96), so the caller does not care
+// which backend answers.  It is not the product's fast path and it is never used behind a HIP codec's back (the one
+// opt-in exception: GEC_SMALL_CALL_BLOCKS, ec_hip_host.cpp).  Nothing here includes, links or calls anything under
+// oracle/ -- the oracle checks this backend exactly like it checks the kernels (tests/test_cpu_backend.py).
+//
+// The arithmetic: out[r] = XOR_t coef[r][t] * in[t] over GF(2^8)/0x11D, the same product the kernels compute
+// [EXT reed-solomon-erasure core.rs code_some_slices].  Three kernels, picked once per process (GEC_CPU_ISA):
+//   avx512+gfni  one VGF2P8AFFINEQB per (64 data bytes, coefficient): multiplication by a constant c is linear over
+//                GF(2), i.e. an 8x8 bit matrix per coefficient.  (GF2P8MULB itself is useless here: it is hard-wired
+//                to the AES polynomial 0x11B; the affine form takes ANY matrix, so 0x11D is free.)
+//   avx2         split-nibble: two VPSHUFB lookups in 16-entry product tables per (32 data bytes, coefficient) -- the
+//                CPU twin of the kernels' LDS nibble tables, and what the crate's simd-accel feature does [EXT];
+//   scalar       one lookup in a 256-entry product row per (byte, coefficient) -- the crate's default MUL_TABLE form.
+// Up to 8 output rows are accumulated in registers per pass over the inputs (each input byte is loaded once per
+// pass); a call is cut into (block, 16 KiB column chunk) work items spread over the codec's threads, so even one
+// 1 MiB block keeps several cores busy.
+#include "ec_internal.hpp"
+
+#include <immintrin.h>
+
+#include <algorithm>
+#include <map>
+
+#include "blake2b_host.hpp"
+#include "ec_env.hpp"
+
+namespace gecimpl {
+namespace {
+
+enum Isa { ISA_SCALAR = 0, ISA_AVX2 = 1, ISA_GFNI512 = 2 };
+
+Isa detect_isa()
+{
+	__builtin_cpu_init();
+	const bool avx2 = __builtin_cpu_supports("avx2");
+	const bool gfni512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("gfni");
+	const std::string &want = env().cpu_isa;
+	if (want == "scalar")
+		return ISA_SCALAR;
+	if (want == "avx2")
+		return avx2 ? ISA_AVX2 : ISA_SCALAR;
+	if (want == "gfni")
+		return gfni512 ? ISA_GFNI512 : (avx2 ? ISA_AVX2 : ISA_SCALAR);
+	return gfni512 ? ISA_GFNI512 : (avx2 ? ISA_AVX2 : ISA_SCALAR);
+}
+
+Isa isa()
+{
+	static const Isa v = detect_isa();
+	return v;
+}
+
+constexpr int kRowsPerPass = 8;
+constexpr size_t kChunk = 16384;  // bytes of every shard per work item
+
+// 256 x 256 product table of the scalar kernel (64 KiB, built on first use)
+const uint8_t (*mul_table())[256]
+{
+	static const std::vector<uint8_t> tab = [] {
+		std::vector<uint8_t> t(65536);
+		const gec::Field &f = gec::field();
+		for (int a = 0; a < 256; ++a)
+			for (int b = 0; b < 256; ++b)
+				t[(size_t)a * 256 + b] = f.mul((uint8_t)a, (uint8_t)b);
+		return t;
+	}();
+	return reinterpret_cast<const uint8_t(*)[256]>(tab.data());
+}
+
+// The 8x8 bit matrix of "multiply by c", in VGF2P8AFFINEQB's layout: result bit i of every byte is the parity of
+// (matrix byte [7 - i] AND source byte), so matrix byte 7-i holds row i: bit j set iff bit i of c * 2^j is set.
+uint64_t gfni_matrix(uint8_t c)
+{
+	const gec::Field &f = gec::field();
+	uint8_t row[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	for (int j = 0; j < 8; ++j) {
+		const uint8_t p = f.mul(c, (uint8_t)(1u << j));
+		for (int i = 0; i < 8; ++i)
+			if ((p >> i) & 1)
+				row[i] |= (uint8_t)(1u << j);
+	}
+	uint64_t m = 0;
+	for (int i = 0; i < 8; ++i)
+		m |= (uint64_t)row[i] << (8 * (7 - i));
+	return m;
+}
+
+// A coefficient matrix (rows x k) expanded for the active kernel, in passes of up to 8 rows.
+struct Program {
+	int k = 0, rows = 0;
+	std::vector<uint8_t> coef;      // rows x k (scalar kernel, and the source of the other two)
+	std::vector<uint64_t> affine;   // [pass][t][r in pass]: GFNI bit matrices
+	std::vector<uint8_t> nibbles;   // [pass][t][r in pass][lo 16 | hi 16]: split-nibble tables
+
+	Program(const uint8_t *c, int nrows, int kk) : k(kk), rows(nrows), coef(c, c + (size_t)nrows * kk)
+	{
+		const gec::Field &f = gec::field();
+		const int npass = (rows + kRowsPerPass - 1) / kRowsPerPass;
+		if (isa() == ISA_GFNI512) {
+			affine.resize((size_t)npass * k * kRowsPerPass, 0);
+			for (int r = 0; r < rows; ++r)
+				for (int t = 0; t < k; ++t)
+					affine[((size_t)(r / kRowsPerPass) * k + t) * kRowsPerPass + r % kRowsPerPass] = gfni_matrix(coef[(size_t)r * k + t]);
+		} else if (isa() == ISA_AVX2) {
+			nibbles.resize((size_t)npass * k * kRowsPerPass * 32, 0);
+			for (int r = 0; r < rows; ++r)
+				for (int t = 0; t < k; ++t) {
+					uint8_t *e = &nibbles[(((size_t)(r / kRowsPerPass) * k + t) * kRowsPerPass + r % kRowsPerPass) * 32];
+					const uint8_t cc = coef[(size_t)r * k + t];
+					for (int x = 0; x < 16; ++x) {
+						e[x] = f.mul(cc, (uint8_t)x);
+						e[16 + x] = f.mul(cc, (uint8_t)(x << 4));
+					}
+				}
+		}
+	}
+};
+
+// ---- kernels: out[r][0..len) = XOR_t coef[r][t] * in[t][0..len) for the R rows of one pass.
+// `active` lists the inputs that have bytes in this range (a zero input contributes nothing).
+
+template <int R>
+__attribute__((target("avx512f,avx512bw,gfni"))) void pass_gfni(const uint8_t *const *in, const int *active, int nactive,
+								 const uint64_t *mat /* [t][8] of this pass */, uint8_t *const *out, size_t len)
+{
+	size_t pos = 0;
+	for (; pos + 128 <= len; pos += 128) {  // two vectors per trip: every broadcast matrix is used twice
+		__m512i a0[R], a1[R];
+		for (int r = 0; r < R; ++r)
+			a0[r] = a1[r] = _mm512_setzero_si512();
+		for (int q = 0; q < nactive; ++q) {
+			const int t = active[q];
+			const __m512i x0 = _mm512_loadu_si512(in[t] + pos), x1 = _mm512_loadu_si512(in[t] + pos + 64);
+			for (int r = 0; r < R; ++r) {
+				const __m512i m = _mm512_set1_epi64((long long)mat[(size_t)t * kRowsPerPass + r]);
+				a0[r] = _mm512_xor_si512(a0[r], _mm512_gf2p8affine_epi64_epi8(x0, m, 0));
+				a1[r] = _mm512_xor_si512(a1[r], _mm512_gf2p8affine_epi64_epi8(x1, m, 0));
+			}
+		}
+		for (int r = 0; r < R; ++r) {
+			_mm512_storeu_si512(out[r] + pos, a0[r]);
+			_mm512_storeu_si512(out[r] + pos + 64, a1[r]);
+		}
+	}
+	for (; pos < len; pos += 64) {  // last vectors, the final one masked
+		const size_t left = len - pos;
+		const __mmask64 mk = left >= 64 ? ~0ull : ((1ull << left) - 1);
+		__m512i a[R];
+		for (int r = 0; r < R; ++r)
+			a[r] = _mm512_setzero_si512();
+		for (int q = 0; q < nactive; ++q) {
+			const int t = active[q];
+			const __m512i x = _mm512_maskz_loadu_epi8(mk, in[t] + pos);
+			for (int r = 0; r < R; ++r)
+				a[r] = _mm512_xor_si512(a[r], _mm512_gf2p8affine_epi64_epi8(x, _mm512_set1_epi64((long long)mat[(size_t)t * kRowsPerPass + r]), 0));
+		}
+		for (int r = 0; r < R; ++r)
+			_mm512_mask_storeu_epi8(out[r] + pos, mk, a[r]);
+	}
+}
+
+void scalar_range(const uint8_t *const *in, const int *active, int nactive, const uint8_t *coef, int k, int row0, int R,
+		  uint8_t *const *out, size_t pos, size_t len)
+{
+	const uint8_t(*MUL)[256] = mul_table();
+	for (int r = 0; r < R; ++r) {
+		uint8_t *o = out[r];
+		std::memset(o + pos, 0, len - pos);
+		for (int q = 0; q < nactive; ++q) {
+			const int t = active[q];
+			const uint8_t *row = MUL[coef[(size_t)(row0 + r) * k + t]];
+			const uint8_t *src = in[t];
+			for (size_t i = pos; i < len; ++i)
+				o[i] ^= row[src[i]];
+		}
+	}
+}
+
+template <int R>
+__attribute__((target("avx2"))) void pass_avx2(const uint8_t *const *in, const int *active, int nactive,
+						const uint8_t *tab /* [t][8][32] of this pass */, uint8_t *const *out, size_t len,
+						const uint8_t *coef, int k, int row0)
+{
+	const __m256i low = _mm256_set1_epi8(0x0f);
+	size_t pos = 0;
+	for (; pos + 32 <= len; pos += 32) {
+		__m256i a[R];
+		for (int r = 0; r < R; ++r)
+			a[r] = _mm256_setzero_si256();
+		for (int q = 0; q < nactive; ++q) {
+			const int t = active[q];
+			const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(in[t] + pos));
+			const __m256i xl = _mm256_and_si256(x, low), xh = _mm256_and_si256(_mm256_srli_epi64(x, 4), low);
+			for (int r = 0; r < R; ++r) {
+				const uint8_t *e = tab + ((size_t)t * kRowsPerPass + r) * 32;
+				const __m256i lo = _mm256_broadcastsi128_si256(_mm_loadu_si128(reinterpret_cast<const __m128i *>(e)));
+				const __m256i hi = _mm256_broadcastsi128_si256(_mm_loadu_si128(reinterpret_cast<const __m128i *>(e + 16)));
+				a[r] = _mm256_xor_si256(a[r], _mm256_xor_si256(_mm256_shuffle_epi8(lo, xl), _mm256_shuffle_epi8(hi, xh)));
+			}
+		}
+		for (int r = 0; r < R; ++r)
+			_mm256_storeu_si256(reinterpret_cast<__m256i *>(out[r] + pos), a[r]);
+	}
+	if (pos < len)
+		scalar_range(in, active, nactive, coef, k, row0, R, out, pos, len);
+}
+
+template <int R>
+void run_pass(const Program &p, int pass, const uint8_t *const *in, const int *active, int nactive, uint8_t *const *out, size_t len)
+{
+	switch (isa()) {
+	case ISA_GFNI512:
+		pass_gfni<R>(in, active, nactive, p.affine.data() + (size_t)pass * p.k * kRowsPerPass, out, len);
+		break;
+	case ISA_AVX2:
+		pass_avx2<R>(in, active, nactive, p.nibbles.data() + (size_t)pass * p.k * kRowsPerPass * 32, out, len, p.coef.data(), p.k,
+			     pass * kRowsPerPass);
+		break;
+	default:
+		scalar_range(in, active, nactive, p.coef.data(), p.k, pass * kRowsPerPass, R, out, 0, len);
+	}
+}
+
+// out[r][0..len) for all rows of the program; in[t] are pointers to the first byte of this column range,
+// avail[t] = how many of its `len` bytes exist (the rest reads as zero: a block's last data shard is short).
+void apply_range(const Program &p, const uint8_t *const *in, const size_t *avail, uint8_t *const *out, size_t len)
+{
+	const int k = p.k;
+	// one input may straddle the end of the data: it is padded into a private buffer (at most one per block)
+	thread_local std::vector<uint8_t> pad;
+	std::vector<const uint8_t *> src(in, in + k);
+	std::vector<int> active;
+	active.reserve(k);
+	size_t npad = 0;
+	for (int t = 0; t < k; ++t)
+		if (avail[t] > 0 && avail[t] < len)
+			++npad;
+	if (pad.size() < npad * len)
+		pad.resize(npad * len);
+	npad = 0;
+	for (int t = 0; t < k; ++t) {
+		if (avail[t] == 0)
+			continue;
+		if (avail[t] < len) {
+			uint8_t *q = pad.data() + npad++ * len;
+			std::memcpy(q, in[t], avail[t]);
+			std::memset(q + avail[t], 0, len - avail[t]);
+			src[t] = q;
+		}
+		active.push_back(t);
+	}
+	const int npass = (p.rows + kRowsPerPass - 1) / kRowsPerPass;
+	for (int pass = 0; pass < npass; ++pass) {
+		const int R = std::min(kRowsPerPass, p.rows - pass * kRowsPerPass);
+		uint8_t *const *o = out + (size_t)pass * kRowsPerPass;
+		const int na = (int)active.size();
+		switch (R) {
+		case 1: run_pass<1>(p, pass, src.data(), active.data(), na, o, len); break;
+		case 2: run_pass<2>(p, pass, src.data(), active.data(), na, o, len); break;
+		case 3: run_pass<3>(p, pass, src.data(), active.data(), na, o, len); break;
+		case 4: run_pass<4>(p, pass, src.data(), active.data(), na, o, len); break;
+		case 5: run_pass<5>(p, pass, src.data(), active.data(), na, o, len); break;
+		case 6: run_pass<6>(p, pass, src.data(), active.data(), na, o, len); break;
+		case 7: run_pass<7>(p, pass, src.data(), active.data(), na, o, len); break;
+		default: run_pass<8>(p, pass, src.data(), active.data(), na, o, len); break;
+		}
+	}
+}
+
+struct CpuBackend : Backend {
+	const gec_codec *c = nullptr;
+	std::unique_ptr<ForkJoinPool> pool;
+
+	// One unit of the product: block `b` of a bucket, all rows, every column chunk.
+	struct Job {
+		const Program *prog;
+		const uint8_t *const *in;  // k shard pointers (whole shards)
+		const size_t *valid;       // k: bytes of each shard that exist (<= S)
+		uint8_t *const *out;       // rows output pointers (whole shards)
+	};
+
+	// runs every (job, chunk) on the pool
+	void run_jobs(const std::vector<Job> &jobs, size_t S) const
+	{
+		const size_t nch = (S + kChunk - 1) / kChunk;
+		pool->parallel_for(jobs.size() * nch, [&](size_t item) {
+			const Job &j = jobs[item / nch];
+			const size_t off = (item % nch) * kChunk, len = std::min(kChunk, S - off);
+			const int k = j.prog->k, rows = j.prog->rows;
+			std::vector<const uint8_t *> in(k);
+			std::vector<size_t> avail(k);
+			std::vector<uint8_t *> out(rows);
+			for (int t = 0; t < k; ++t) {
+				in[t] = j.in[t] + off;
+				avail[t] = j.valid[t] > off ? std::min(len, j.valid[t] - off) : 0;
+			}
+			for (int r = 0; r < rows; ++r)
+				out[r] = j.out[r] + off;
+			apply_range(*j.prog, in.data(), avail.data(), out.data(), len);
+		});
+	}
+
+	int encode_batch(size_t nblocks, const uint8_t *const *blocks, const size_t *block_len, size_t S, uint8_t *const *parity,
+			 uint8_t *shard_sums) override
+	{
+		const size_t k = c->k, m = c->m, n = k + m;
+		const Program prog(c->enc.row((int)k), (int)m, (int)k);
+		std::vector<const uint8_t *> in(nblocks * k);
+		std::vector<size_t> valid(nblocks * k);
+		std::vector<uint8_t *> out(nblocks * m);
+		std::vector<Job> jobs(nblocks);
+		for (size_t b = 0; b < nblocks; ++b) {
+			for (size_t t = 0; t < k; ++t) {
+				in[b * k + t] = blocks[b] + t * S;  // never dereferenced beyond valid[]
+				valid[b * k + t] = block_len[b] > t * S ? std::min(S, block_len[b] - t * S) : 0;
+			}
+			for (size_t r = 0; r < m; ++r)
+				out[b * m + r] = parity[b] + r * S;
+			jobs[b] = Job{&prog, &in[b * k], &valid[b * k], &out[b * m]};
+		}
+		run_jobs(jobs, S);
+		if (!shard_sums)
+			return GEC_OK;
+		// the checksum of every shard, data shards as zero-extended to S bytes
+		pool->parallel_for(nblocks * n, [&](size_t q) {
+			const size_t b = q / n, j = q % n;
+			uint8_t *dst = shard_sums + 32 * q;
+			if (j >= k) {
+				b2host::shardsum(parity[b] + (j - k) * S, S, dst);
+				return;
+			}
+			const size_t have = valid[b * k + j];
+			if (have == S) {
+				b2host::shardsum(blocks[b] + j * S, S, dst);
+			} else {
+				std::vector<uint8_t> tmp(S, 0);
+				if (have)
+					std::memcpy(tmp.data(), blocks[b] + j * S, have);
+				b2host::shardsum(tmp.data(), S, dst);
+			}
+		});
+		return GEC_OK;
+	}
+
+	int verify_batch(size_t nblocks, const uint8_t *const *shards, size_t S, uint8_t *ok) override
+	{
+		const size_t k = c->k, m = c->m, n = k + m;
+		const Program prog(c->enc.row((int)k), (int)m, (int)k);
+		const size_t nch = (S + kChunk - 1) / kChunk;
+		std::fill(ok, ok + nblocks, (uint8_t)1);
+		pool->parallel_for(nblocks * nch, [&](size_t item) {
+			const size_t b = item / nch, off = (item % nch) * kChunk, len = std::min(kChunk, S - off);
+			thread_local std::vector<uint8_t> tmp;
+			if (tmp.size() < m * kChunk)
+				tmp.resize(m * kChunk);
+			std::vector<const uint8_t *> in(k);
+			std::vector<size_t> avail(k, len);
+			std::vector<uint8_t *> out(m);
+			for (size_t t = 0; t < k; ++t)
+				in[t] = shards[b * n + t] + off;
+			for (size_t r = 0; r < m; ++r)
+				out[r] = tmp.data() + r * kChunk;
+			apply_range(prog, in.data(), avail.data(), out.data(), len);
+			for (size_t r = 0; r < m; ++r)
+				if (std::memcmp(out[r], shards[b * n + k + r] + off, len) != 0) {
+					__atomic_store_n(&ok[b], (uint8_t)0, __ATOMIC_RELAXED);
+					break;
+				}
+		});
+		return GEC_OK;
+	}
+
+	int verify_hash_batch(size_t nblocks, const uint8_t *const *shards, size_t S, uint8_t *ok, uint8_t *shard_sums) override
+	{
+		int rc = verify_batch(nblocks, shards, S, ok);
+		if (rc)
+			return rc;
+		const size_t n = (size_t)c->k + c->m;
+		pool->parallel_for(nblocks * n, [&](size_t q) { b2host::shardsum(shards[q], S, shard_sums + 32 * q); });
+		return GEC_OK;
+	}
+
+	int reconstruct_batch(size_t nblocks, const uint8_t *const *shards, uint8_t *const *out, size_t S, int data_only, uint8_t *in_sums,
+			      uint8_t *out_sums) override
+	{
+		const size_t k = c->k, n = (size_t)c->k + c->m;
+		// bucket blocks by erasure pattern AND by which of the missing shards the caller wants back (out entry
+		// non-NULL; with data_only parity is never wanted): one decode plan and one program per bucket, only the
+		// wanted rows computed.  key[j]: 1 present, 0 missing + wanted, 2 missing + unwanted
+		std::map<std::string, std::vector<size_t>> buckets;
+		for (size_t b = 0; b < nblocks; ++b) {
+			std::string key(n, 0);
+			size_t nwanted = 0;
+			for (size_t j = 0; j < n; ++j) {
+				if (shards[b * n + j])
+					key[j] = 1;
+				else if ((data_only && j >= k) || !out[b * n + j])
+					key[j] = 2;
+				else
+					++nwanted;
+			}
+			if (nwanted)
+				buckets[key].push_back(b);
+		}
+		struct Work {
+			std::shared_ptr<const Plan> plan;
+			std::vector<int> wanted;  // shard indices, ascending
+			std::unique_ptr<Program> prog;
+			const std::vector<size_t> *ids;
+		};
+		std::vector<Work> work;
+		size_t njobs = 0;
+		for (auto &kv : buckets) {
+			std::string pres(kv.first);
+			for (auto &ch : pres)
+				ch = ch == 1 ? 1 : 0;
+			Work w;
+			int rc = get_plan(c, reinterpret_cast<const uint8_t *>(pres.data()), false, w.plan);
+			if (rc)
+				return rc;
+			std::vector<uint8_t> rows;
+			for (size_t r = 0; r < w.plan->missing.size(); ++r)
+				if (kv.first[w.plan->missing[r]] == 0) {
+					w.wanted.push_back(w.plan->missing[r]);
+					rows.insert(rows.end(), w.plan->rows.row((int)r), w.plan->rows.row((int)r) + k);
+				}
+			if (w.wanted.empty())
+				continue;
+			w.prog.reset(new Program(rows.data(), (int)w.wanted.size(), (int)k));
+			w.ids = &kv.second;
+			njobs += kv.second.size();
+			work.push_back(std::move(w));
+		}
+		std::vector<const uint8_t *> in;
+		std::vector<uint8_t *> outp;
+		std::vector<Job> jobs;
+		in.reserve(njobs * k);
+		jobs.reserve(njobs);
+		size_t nout = 0;
+		for (const Work &w : work)
+			nout += w.ids->size() * w.wanted.size();
+		outp.reserve(nout);
+		const std::vector<size_t> full(k, S);
+		for (const Work &w : work)
+			for (size_t b : *w.ids) {
+				const size_t i0 = in.size(), o0 = outp.size();
+				for (size_t t = 0; t < k; ++t)
+					in.push_back(shards[b * n + w.plan->valid[t]]);
+				for (int j : w.wanted)
+					outp.push_back(out[b * n + j]);
+				jobs.push_back(Job{w.prog.get(), in.data() + i0, full.data(), outp.data() + o0});
+			}
+		run_jobs(jobs, S);
+		if (!in_sums)
+			return GEC_OK;
+		// the checksums of the k shards that were read and of the shards that were written
+		struct Sum {
+			const uint8_t *p;
+			uint8_t *dst;
+		};
+		std::vector<Sum> sums;
+		for (const Work &w : work)
+			for (size_t b : *w.ids) {
+				for (size_t t = 0; t < k; ++t)
+					sums.push_back({shards[b * n + w.plan->valid[t]], in_sums + 32 * (b * n + w.plan->valid[t])});
+				for (int j : w.wanted)
+					sums.push_back({out[b * n + j], out_sums + 32 * (b * n + j)});
+			}
+		pool->parallel_for(sums.size(), [&](size_t i) { b2host::shardsum(sums[i].p, S, sums[i].dst); });
+		return GEC_OK;
+	}
+
+	int decode_verify_batch(size_t nblocks, const uint8_t *const *shards, size_t S, const size_t *block_len, uint8_t *const *rebuilt,
+				uint8_t *shard_sums, uint8_t *block_sums) override
+	{
+		const size_t k = c->k, n = (size_t)c->k + c->m;
+		// the first k present shards of every block are "read" (the crate's rule); missing data shards are rebuilt
+		// through gec_reconstruct_batch's machinery with only those k marked present
+		std::vector<const uint8_t *> used(nblocks * n, nullptr);
+		std::vector<uint8_t *> want(nblocks * n, nullptr);
+		bool any_missing = false;
+		for (size_t b = 0; b < nblocks; ++b) {
+			size_t seen = 0;
+			for (size_t j = 0; j < n && seen < k; ++j)
+				if (shards[b * n + j]) {
+					used[b * n + j] = shards[b * n + j];
+					++seen;
+				}
+			for (size_t j = 0; j < k; ++j)
+				if (!shards[b * n + j]) {
+					want[b * n + j] = rebuilt[b * n + j];
+					any_missing = true;
+				}
+		}
+		if (any_missing) {
+			int rc = reconstruct_batch(nblocks, used.data(), want.data(), S, /*data_only=*/1, nullptr, nullptr);
+			if (rc)
+				return rc;
+		}
+		// checksums: every shard that was read, and (optionally) the block itself from its k data shards
+		pool->parallel_for(nblocks * (n + 1), [&](size_t q) {
+			const size_t b = q / (n + 1), j = q % (n + 1);
+			if (j < n) {
+				if (used[b * n + j])
+					b2host::shardsum(used[b * n + j], S, shard_sums + 32 * (b * n + j));
+				return;
+			}
+			if (!block_sums)
+				return;
+			b2host::State st;
+			size_t left = block_len[b];
+			for (size_t t = 0; t < k && left; ++t) {
+				const uint8_t *p = shards[b * n + t] ? shards[b * n + t] : rebuilt[b * n + t];
+				const size_t take = std::min(S, left);
+				st.update(p, take);
+				left -= take;
+			}
+			uint8_t full[64];
+			st.final(full);
+			std::memcpy(block_sums + 32 * b, full, 32);
+		});
+		return GEC_OK;
+	}
+
+	int hash_batch(size_t nmsg, const uint8_t *const *msgs, const size_t *lens, uint8_t *out, bool tree) override
+	{
+		pool->parallel_for(nmsg, [&](size_t i) {
+			if (tree)
+				b2host::shardsum(msgs[i], lens[i], out + 32 * i);
+			else
+				b2host::blake2sum(msgs[i], lens[i], out + 32 * i);
+		});
+		return GEC_OK;
+	}
+};
+
+}  // namespace
+
+int make_cpu_backend(gec_codec *c, std::unique_ptr<Backend> &out)
+{
+	std::unique_ptr<CpuBackend> be(new (std::nothrow) CpuBackend());
+	if (!be)
+		return fail(GEC_E_NOMEM, "alloc backend");
+	be->c = c;
+	// a background codec keeps to a quarter of the threads: repair must not take the cores the request path needs
+	const int threads = c->qos_class == GEC_CLASS_BACKGROUND ? std::max(1, env().cpu_threads / 4) : env().cpu_threads;
+	be->pool.reset(new ForkJoinPool((unsigned)std::max(0, threads - 1)));  // the calling thread works too
+	(void)mul_table();
+	out = std::move(be);
+	return GEC_OK;
+}
+
+}  // namespace gecimpl
+
+extern "C" const char *gec_cpu_isa(void)
+{
+	switch (gecimpl::isa()) {
+	case gecimpl::ISA_GFNI512: return "avx512+gfni";
+	case gecimpl::ISA_AVX2: return "avx2";
+	default: return "scalar";
+	}
+}

@@ -1,0 +1,96 @@
+// ec_env.cpp -- the one table of libgarage_ec's environment switches (see ec_env.hpp).
+#include "ec_env.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+namespace gecimpl {
+namespace {
+
+struct Row {
+	const char *name, *def, *doc;
+};
+
+// Keep in step with the parser below and with the table in include/garage_ec.h / INTEGRATION.md
+// (tests/test_cabi_host.py checks that every GEC_* name in the sources appears here).
+const Row kRows[] = {
+	{"GEC_CPU_THREADS", "min(cores, 16)", "threads a CPU codec spreads one call over (1 = the calling thread only)"},
+	{"GEC_CPU_ISA", "auto", "CPU backend kernel: auto | gfni (AVX-512 + GFNI) | avx2 (split-nibble vpshufb) | scalar"},
+	{"GEC_SMALL_CALL_BLOCKS", "0", "a HIP codec answers pageable host-pointer encode / reconstruct calls of up to this many blocks on the host cores (0 = never)"},
+	{"GEC_COPY_THREADS", "7", "staging-copy threads per HIP codec for pageable caller memory (0 = copy on the calling thread)"},
+	{"GEC_ZERO_COPY", "1", "A/B: 0 = pinned caller memory goes through the device staging pipeline instead of being read in place"},
+	{"GEC_UPLOAD_CUS", "16", "CUs reserved for kernels that read / write host memory (0 = no CU masks)"},
+	{"GEC_VERIFY_SEGMENTS", "min(k, 16)", "A/B: upload stages of gec_decode_verify_batch (1 = upload, then hash)"},
+	{"GEC_PINNED_CHUNK_MB", "128", "chunk size of the staged path for pinned memory"},
+	{"GEC_HASH_FORK", "1", "A/B: 0 = encode + checksums on one stream instead of the data-shard checksums beside the encode"},
+	{"GEC_DEGRADED_GROUPS", "4", "gec_decode_verify_batch: blocks that need a decode are uploaded, decoded and hashed in this many groups, ordered by their first missing data shard (1 = one group after the whole upload)"},
+	{"GEC_BG_CUS", "64", "CUs a background-class codec's kernels may occupy (0 = no mask; link kernels stay on GEC_UPLOAD_CUS)"},
+	{"GEC_BG_CHUNK_MB", "32", "chunk size of a background-class codec's host-pointer trips (a foreground call waits for at most one)"},
+	{"GEC_BG_YIELD_US", "2000", "a background chunk waits up to this long for foreground calls on the same device to drain (0 = never waits)"},
+	{"GEC_ROWS16", "1", "A/B: 0 = 9..16 output rows as 8-row passes instead of one 16-row pass"},
+	{"GEC_BLAKE2_KERNEL", "auto", "A/B: lane | quad forces one of the two plain-blake2 kernels"},
+	{"GEC_B2_ADD", "0", "A/B: 1 = 64-bit adds of the blake2 kernels spelled as 32-bit add / addc"},
+	{"GEC_MAX_COLS_PER_LAUNCH", "0", "test hook: cap on the 16-byte columns one launch covers, to exercise the multi-launch split on small inputs"},
+	{"GEC_RCCL_LIB", "librccl.so.1", "RCCL to dlopen for gec_group_*"},
+};
+
+const char *get(const char *name) { return std::getenv(name); }
+
+long get_long(const char *name, long def)
+{
+	const char *e = get(name);
+	return e && *e ? std::strtol(e, nullptr, 0) : def;
+}
+
+}  // namespace
+
+const Env &env()
+{
+	static const Env e = [] {
+		Env v;
+		const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+		v.cpu_threads = (int)std::min<long>(std::max<long>(get_long("GEC_CPU_THREADS", std::min(hw, 16u)), 1), 256);
+		v.cpu_isa = get("GEC_CPU_ISA") ? get("GEC_CPU_ISA") : "auto";
+		v.small_call_blocks = (size_t)std::max<long>(get_long("GEC_SMALL_CALL_BLOCKS", 0), 0);
+		v.copy_threads = get("GEC_COPY_THREADS") ? (unsigned)std::min<unsigned long>(std::strtoul(get("GEC_COPY_THREADS"), nullptr, 0), 64ul)
+							 : std::min(7u, hw - 1);
+		v.zero_copy = !(get("GEC_ZERO_COPY") && get("GEC_ZERO_COPY")[0] == '0');
+		v.upload_cus = (int)get_long("GEC_UPLOAD_CUS", 16);
+		v.verify_segments = (int)get_long("GEC_VERIFY_SEGMENTS", 0);
+		v.pinned_chunk_mb = (size_t)std::max<long>(get_long("GEC_PINNED_CHUNK_MB", 128), 1);
+		v.hash_fork = get_long("GEC_HASH_FORK", 1) != 0;
+		v.degraded_groups = (int)std::min<long>(std::max<long>(get_long("GEC_DEGRADED_GROUPS", 4), 1), 12);
+		v.bg_cus = (int)get_long("GEC_BG_CUS", 64);
+		v.bg_chunk_mb = (size_t)std::max<long>(get_long("GEC_BG_CHUNK_MB", 32), 1);
+		v.bg_yield_us = (unsigned)std::max<long>(get_long("GEC_BG_YIELD_US", 2000), 0);
+		v.rows16 = (int)get_long("GEC_ROWS16", 1);
+		const char *bk = get("GEC_BLAKE2_KERNEL");
+		v.blake2_kernel = !bk ? 0 : (bk[0] == 'l' ? 1 : (bk[0] == 'q' ? 2 : 0));
+		v.b2_add = (int)get_long("GEC_B2_ADD", 0);
+		v.max_cols_per_launch = get("GEC_MAX_COLS_PER_LAUNCH") ? std::strtoull(get("GEC_MAX_COLS_PER_LAUNCH"), nullptr, 0) : 0ull;
+		v.rccl_lib = get("GEC_RCCL_LIB") ? get("GEC_RCCL_LIB") : "";
+		return v;
+	}();
+	return e;
+}
+
+const char *env_table_text()
+{
+	static const std::string text = [] {
+		std::string s;
+		for (const Row &r : kRows) {
+			s += r.name;
+			s += "\t";
+			s += r.def;
+			s += "\t";
+			s += r.doc;
+			s += "\n";
+		}
+		return s;
+	}();
+	return text.c_str();
+}
+
+}  // namespace gecimpl

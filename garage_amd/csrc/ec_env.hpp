@@ -1,0 +1,44 @@
+// ec_env.hpp -- every environment switch of libgarage_ec, in one place.  All are optional, read once per process,
+// and none changes results: they select between equivalent paths (A/B measurements), size pools, or name a library.
+// ec_env.cpp holds the table (name, default, meaning) that gec_env_table() prints; include/garage_ec.h and
+// INTEGRATION.md quote it.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+namespace gecimpl {
+
+struct Env {
+	// ---- both backends
+	int cpu_threads;        // GEC_CPU_THREADS: worker threads of a CPU codec (0 = the calling thread only)
+	std::string cpu_isa;    // GEC_CPU_ISA: auto | gfni | avx2 | scalar
+	size_t small_call_blocks;  // GEC_SMALL_CALL_BLOCKS: a HIP codec answers pageable host-pointer calls of up to this many blocks on the host cores
+	// ---- HIP backend: host-pointer paths
+	unsigned copy_threads;  // GEC_COPY_THREADS
+	bool zero_copy;         // GEC_ZERO_COPY
+	int upload_cus;         // GEC_UPLOAD_CUS
+	int verify_segments;    // GEC_VERIFY_SEGMENTS (0 = the built-in maximum)
+	size_t pinned_chunk_mb; // GEC_PINNED_CHUNK_MB
+	bool hash_fork;         // GEC_HASH_FORK
+	int degraded_groups;    // GEC_DEGRADED_GROUPS
+	// ---- HIP backend: background class
+	int bg_cus;             // GEC_BG_CUS
+	size_t bg_chunk_mb;     // GEC_BG_CHUNK_MB
+	unsigned bg_yield_us;   // GEC_BG_YIELD_US
+	// ---- HIP backend: kernels (A/B)
+	int rows16;             // GEC_ROWS16
+	int blake2_kernel;      // GEC_BLAKE2_KERNEL: 0 auto, 1 lane, 2 quad
+	int b2_add;             // GEC_B2_ADD
+	uint64_t max_cols_per_launch;  // GEC_MAX_COLS_PER_LAUNCH (0 = no cap)
+	// ---- multi-GPU
+	std::string rccl_lib;   // GEC_RCCL_LIB ("" = librccl.so.1, then librccl.so)
+};
+
+const Env &env();
+
+// the table as text: one "NAME  default  meaning" line per switch
+const char *env_table_text();
+
+}  // namespace gecimpl

@@ -1,0 +1,474 @@
+// ec_hip_group.cpp -- gec_group_*: decode of an object whose shards are striped over several GPUs (BASELINE config 5),
+// the path's one real exchange step: all-gather (or all-to-all) of the survivors over RCCL / a caller transport, every
+// rank rebuilds its byte range of the missing shards, the rebuilt ranges are exchanged.  Host code only; the pack /
+// unpack kernels are launched through ec_hip_launch.hip.
+#include "ec_hip.hpp"
+
+#include <rccl/rccl.h>  // types only: RCCL itself is resolved with dlopen
+
+#include <dlfcn.h>
+
+#include <algorithm>
+
+using namespace gecimpl;
+
+// RCCL entry points, resolved on first use (the library must load on hosts without RCCL,
+// and inside a PyTorch process it must bind to the RCCL torch already loaded).
+namespace {
+struct Rccl {
+	void *handle = nullptr;
+	decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+	decltype(&ncclCommInitRank) CommInitRank = nullptr;
+	decltype(&ncclCommDestroy) CommDestroy = nullptr;
+	decltype(&ncclAllGather) AllGather = nullptr;
+	decltype(&ncclSend) Send = nullptr;
+	decltype(&ncclRecv) Recv = nullptr;
+	decltype(&ncclGroupStart) GroupStart = nullptr;
+	decltype(&ncclGroupEnd) GroupEnd = nullptr;
+	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	std::string error;
+};
+
+const Rccl &rccl()
+{
+	static const Rccl r = [] {
+		Rccl x;
+		std::vector<std::string> names;
+		if (!env().rccl_lib.empty())
+			names.push_back(env().rccl_lib);
+		names.insert(names.end(), {"librccl.so.1", "librccl.so"});
+		for (const std::string &n : names) {
+			x.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
+			if (x.handle)
+				break;
+			const char *de = dlerror();
+			x.error += n + ": " + (de ? de : "?") + "; ";
+		}
+		if (!x.handle)
+			return x;
+		x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(x.handle, "ncclGetUniqueId"));
+		x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(x.handle, "ncclCommInitRank"));
+		x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.handle, "ncclCommDestroy"));
+		x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.handle, "ncclAllGather"));
+		x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.handle, "ncclGetErrorString"));
+		x.Send = reinterpret_cast<decltype(x.Send)>(dlsym(x.handle, "ncclSend"));
+		x.Recv = reinterpret_cast<decltype(x.Recv)>(dlsym(x.handle, "ncclRecv"));
+		x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(x.handle, "ncclGroupStart"));
+		x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(x.handle, "ncclGroupEnd"));
+		if (!x.GetUniqueId || !x.CommInitRank || !x.CommDestroy || !x.AllGather || !x.GetErrorString || !x.Send || !x.Recv ||
+		    !x.GroupStart || !x.GroupEnd) {
+			x.error = "RCCL library lacks a required symbol";
+			x.handle = nullptr;
+		}
+		return x;
+	}();
+	return r;
+}
+}  // namespace
+
+struct gec_group {
+	const gec_codec *c = nullptr;
+	int rank = 0, nranks = 1;
+	gec_allgather_fn all_gather = nullptr;
+	gec_alltoall_fn all_to_all = nullptr;
+	void *ctx = nullptr;
+	ncclComm_t comm = nullptr;  // RCCL transport only
+	// all-to-all exchange scratch
+	uint8_t *d_a2a_send = nullptr, *d_a2a_recv = nullptr;
+	size_t a2a_cap = 0;
+	uint64_t bytes_exchanged = 0;  // bytes this rank RECEIVED from other ranks in the last decode call
+	// scratch for the exchange of the rebuilt ranges (step 3)
+	uint8_t *d_send = nullptr, *d_recv = nullptr;
+	size_t send_cap = 0, recv_cap = 0;
+};
+
+namespace {
+
+int rccl_all_gather(void *ctx, const void *d_send, void *d_recv, size_t bytes, void *hip_stream)
+{
+	gec_group *g = static_cast<gec_group *>(ctx);
+	ncclResult_t r = rccl().AllGather(d_send, d_recv, bytes, ncclUint8, g->comm, static_cast<hipStream_t>(hip_stream));
+	if (r != ncclSuccess)
+		return fail(GEC_E_DEVICE, std::string("ncclAllGather: ") + rccl().GetErrorString(r));
+	return GEC_OK;
+}
+
+// all-to-all over RCCL: one grouped ncclSend/ncclRecv pair per peer (xGMI is a full mesh: every pair has its own link)
+int rccl_all_to_all(void *ctx, const void *d_send, void *d_recv, size_t bytes, void *hip_stream)
+{
+	gec_group *g = static_cast<gec_group *>(ctx);
+	const Rccl &R = rccl();
+	hipStream_t s = static_cast<hipStream_t>(hip_stream);
+	ncclResult_t r = R.GroupStart();
+	for (int q = 0; q < g->nranks && r == ncclSuccess; ++q) {
+		r = R.Send(static_cast<const uint8_t *>(d_send) + (size_t)q * bytes, bytes, ncclUint8, q, g->comm, s);
+		if (r == ncclSuccess)
+			r = R.Recv(static_cast<uint8_t *>(d_recv) + (size_t)q * bytes, bytes, ncclUint8, q, g->comm, s);
+	}
+	ncclResult_t e = R.GroupEnd();
+	if (r == ncclSuccess)
+		r = e;
+	if (r != ncclSuccess)
+		return fail(GEC_E_DEVICE, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(r));
+	return GEC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gec_group_unique_id(uint8_t id[GEC_GROUP_ID_BYTES])
+{
+	static_assert(sizeof(ncclUniqueId) == GEC_GROUP_ID_BYTES, "GEC_GROUP_ID_BYTES must equal sizeof(ncclUniqueId)");
+	if (!id)
+		return fail(GEC_E_INVALID_ARG, "NULL id");
+	const Rccl &R = rccl();
+	if (!R.handle)
+		return fail(GEC_E_DEVICE, "RCCL is not available: " + R.error);
+	ncclUniqueId u;
+	ncclResult_t r = R.GetUniqueId(&u);
+	if (r != ncclSuccess)
+		return fail(GEC_E_DEVICE, std::string("ncclGetUniqueId: ") + R.GetErrorString(r));
+	std::memcpy(id, &u, sizeof(u));
+	return GEC_OK;
+}
+
+static int check_dev_layout(const void *p, size_t stride, size_t S, size_t need)
+{
+	if (S == 0)
+		return fail(GEC_E_EMPTY_SHARD, "shard length is 0");
+	if (S % 64 != 0)
+		return fail(GEC_E_INCORRECT_SHARD_SIZE, "S must be a multiple of 64");
+	if (!p)
+		return fail(GEC_E_INVALID_ARG, "NULL device pointer");
+	if (reinterpret_cast<uintptr_t>(p) % 16 != 0 || stride % 16 != 0)
+		return fail(GEC_E_INVALID_ARG, "device pointer/stride must be 16-byte aligned");
+	if (stride < need)
+		return fail(GEC_E_INCORRECT_SHARD_SIZE, "stride smaller than the shards it must hold");
+	return GEC_OK;
+}
+
+static int group_new(const gec_codec *c, int rank, int nranks, gec_group **out, std::unique_ptr<gec_group> &g)
+{
+	if (!out)
+		return fail(GEC_E_INVALID_ARG, "NULL out");
+	*out = nullptr;
+	if (!c)
+		return fail(GEC_E_INVALID_ARG, "NULL codec");
+	if (c->backend != GEC_BACKEND_HIP)
+		return fail(GEC_E_DEVICE, "a striped-object group needs a GEC_BACKEND_HIP codec (the exchange moves device memory)");
+	if (nranks < 1 || rank < 0 || rank >= nranks)
+		return fail(GEC_E_INVALID_ARG, "need 0 <= rank < nranks");
+	g.reset(new (std::nothrow) gec_group());
+	if (!g)
+		return fail(GEC_E_NOMEM, "alloc group");
+	g->c = c;
+	g->rank = rank;
+	g->nranks = nranks;
+	return GEC_OK;
+}
+
+int gec_group_create(const gec_codec *c, int rank, int nranks, const uint8_t id[GEC_GROUP_ID_BYTES], gec_group **out)
+{
+	std::unique_ptr<gec_group> g;
+	int rc = group_new(c, rank, nranks, out, g);
+	if (rc)
+		return rc;
+	if (!id)
+		return fail(GEC_E_INVALID_ARG, "NULL id");
+	const Rccl &R = rccl();
+	if (!R.handle)
+		return fail(GEC_E_DEVICE, "RCCL is not available: " + R.error);
+	DeviceGuard dg(c->device);
+	if (!dg.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	ncclUniqueId u;
+	std::memcpy(&u, id, sizeof(u));
+	ncclResult_t r = R.CommInitRank(&g->comm, nranks, u, rank);
+	if (r != ncclSuccess)
+		return fail(GEC_E_DEVICE, std::string("ncclCommInitRank: ") + R.GetErrorString(r));
+	g->all_gather = rccl_all_gather;
+	g->all_to_all = rccl_all_to_all;
+	g->ctx = g.get();
+	*out = g.release();
+	return GEC_OK;
+}
+
+int gec_group_create_with_transport2(const gec_codec *c, int rank, int nranks, gec_allgather_fn all_gather,
+				     gec_alltoall_fn all_to_all, void *ctx, gec_group **out)
+{
+	std::unique_ptr<gec_group> g;
+	int rc = group_new(c, rank, nranks, out, g);
+	if (rc)
+		return rc;
+	if (!all_gather)
+		return fail(GEC_E_INVALID_ARG, "NULL all_gather");
+	g->all_gather = all_gather;
+	g->all_to_all = all_to_all;
+	g->ctx = ctx;
+	*out = g.release();
+	return GEC_OK;
+}
+
+int gec_group_create_with_transport(const gec_codec *c, int rank, int nranks, gec_allgather_fn all_gather, void *ctx,
+				    gec_group **out)
+{
+	return gec_group_create_with_transport2(c, rank, nranks, all_gather, nullptr, ctx, out);
+}
+
+void gec_group_destroy(gec_group *g)
+{
+	if (!g)
+		return;
+	{
+		DeviceGuard dg(g->c->device);
+		if (g->d_send)
+			(void)hipFree(g->d_send);
+		if (g->d_recv)
+			(void)hipFree(g->d_recv);
+		if (g->d_a2a_send)
+			(void)hipFree(g->d_a2a_send);
+		if (g->d_a2a_recv)
+			(void)hipFree(g->d_a2a_recv);
+		if (g->comm)
+			(void)rccl().CommDestroy(g->comm);
+	}
+	delete g;
+}
+
+int gec_group_rank(const gec_group *g) { return g ? g->rank : -1; }
+int gec_group_size(const gec_group *g) { return g ? g->nranks : 0; }
+size_t gec_group_slots(const gec_group *g)
+{
+	return g ? ((size_t)(g->c->k + g->c->m) + g->nranks - 1) / g->nranks : 0;
+}
+
+int gec_group_allgather_decode(gec_group *g, size_t nobjects, const void *d_local_slots, size_t S,
+			       const uint8_t *present, int data_only, int complete, void *d_gathered, void *hip_stream)
+{
+	if (!g || !present)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (nobjects == 0)
+		return GEC_OK;
+	const gec_codec *c = g->c;
+	const size_t n = (size_t)c->k + c->m, N = (size_t)g->nranks, slots = gec_group_slots(g);
+	int rc = check_dev_layout(d_local_slots, slots * S, S, slots * S);
+	if (rc)
+		return rc;
+	rc = check_dev_layout(d_gathered, slots * S, S, slots * S);
+	if (rc)
+		return rc;
+	hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+	DeviceGuard dg(c->device);
+	if (!dg.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	std::shared_ptr<const Plan> plan;  // before the exchange: a bad pattern fails on every rank alike, no rank hangs
+	rc = get_plan(c, present, data_only != 0, plan);
+	if (rc)
+		return rc;
+	// (1) the exchange step: every rank's slot buffer to everybody
+	const size_t per_rank = nobjects * slots * S;
+	g->bytes_exchanged = per_rank * (N - 1);
+	rc = g->all_gather(g->ctx, d_local_slots, d_gathered, per_rank, hip_stream);
+	if (rc)
+		return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+	if (plan->missing.empty())
+		return GEC_OK;
+	// (2) my byte range of every missing shard, in place in the gathered buffer
+	std::vector<size_t> shard_off(n);
+	for (size_t j = 0; j < n; ++j)
+		shard_off[j] = (j % N) * per_rank + (j / N) * S;
+	const size_t cols = S / 16;
+	auto range_lo = [&](size_t r) { return cols * r / N; };
+	const size_t lo = range_lo(g->rank), my_cols = range_lo(g->rank + 1) - lo;
+	if (my_cols) {
+		rc = reconstruct_dev(c, nobjects, static_cast<uint8_t *>(d_gathered), slots * S, shard_off.data(), present,
+				     data_only != 0, lo * 16, my_cols * 16, stream);
+		if (rc)
+			return rc;
+	}
+	if (!complete || N == 1)
+		return GEC_OK;
+	// (3) exchange the rebuilt ranges (ranges differ by at most one column: pad to the longest)
+	size_t max_cols = 0;
+	for (size_t r = 0; r < N; ++r)
+		max_cols = std::max(max_cols, range_lo(r + 1) - range_lo(r));
+	const size_t nmiss = plan->missing.size();
+	const size_t send_bytes = nmiss * nobjects * max_cols * 16;
+	if (nobjects > 0xffffffffull || cols > 0xffffffffull)
+		return fail(GEC_E_INVALID_ARG, "batch too large for one call");
+	if (send_bytes > g->send_cap || send_bytes * N > g->recv_cap) {
+		HIP_TRY(hipStreamSynchronize(stream));  // earlier calls may still use the old buffers
+		if (g->d_send)
+			(void)hipFree(g->d_send);
+		if (g->d_recv)
+			(void)hipFree(g->d_recv);
+		g->d_send = g->d_recv = nullptr;
+		g->send_cap = g->recv_cap = 0;
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_send), send_bytes));
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_recv), send_bytes * N));
+		HIP_TRY(hipMemsetAsync(g->d_send, 0, send_bytes, stream));  // pad columns: defined bytes on the wire
+		g->send_cap = send_bytes;
+		g->recv_cap = send_bytes * N;
+	}
+	gec::RangeArgs ra;
+	std::memset(&ra, 0, sizeof(ra));
+	ra.gathered = static_cast<uint8_t *>(d_gathered);
+	ra.obj_stride = slots * S;
+	ra.nobj = (uint32_t)nobjects;
+	ra.nmiss = (uint32_t)nmiss;
+	ra.cols = (uint32_t)cols;
+	ra.max_cols = (uint32_t)max_cols;
+	ra.world = (uint32_t)N;
+	ra.rank = (uint32_t)g->rank;
+	for (size_t i = 0; i < nmiss; ++i)
+		ra.shard_off[i] = shard_off[plan->missing[i]];
+	if (my_cols) {
+		ra.packed = g->d_send;
+		rc = launch_range_pack(ra, nmiss * nobjects * my_cols, stream);
+		if (rc)
+			return rc;
+	}
+	g->bytes_exchanged += send_bytes * (N - 1);
+	rc = g->all_gather(g->ctx, g->d_send, g->d_recv, send_bytes, hip_stream);
+	if (rc)
+		return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+	ra.packed = g->d_recv;
+	return launch_range_unpack(ra, send_bytes / 16 * N, stream);
+}
+
+uint64_t gec_group_bytes_exchanged(const gec_group *g) { return g ? g->bytes_exchanged : 0; }
+
+int gec_group_alltoall_decode(gec_group *g, size_t nobjects, const void *d_local_slots, size_t S, const uint8_t *present,
+			      int data_only, int complete, void *d_rebuilt, void *hip_stream)
+{
+	if (!g || !present || !d_rebuilt)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (!g->all_to_all)
+		return fail(GEC_E_INVALID_ARG, "this group's transport has no all-to-all");
+	if (nobjects == 0)
+		return GEC_OK;
+	const gec_codec *c = g->c;
+	const size_t k = c->k, N = (size_t)g->nranks, slots = gec_group_slots(g);
+	int rc = check_dev_layout(d_local_slots, slots * S, S, slots * S);
+	if (rc)
+		return rc;
+	if (reinterpret_cast<uintptr_t>(d_rebuilt) % 16)
+		return fail(GEC_E_INVALID_ARG, "d_rebuilt must be 16-byte aligned");
+	if (nobjects > 0xffffffffull || S / 16 > 0xffffffffull)
+		return fail(GEC_E_INVALID_ARG, "batch too large for one call");
+	hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+	DeviceGuard dg(c->device);
+	if (!dg.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	std::shared_ptr<const Plan> plan;  // before the exchange: a bad pattern fails on every rank alike, no rank hangs
+	rc = get_plan(c, present, data_only != 0, plan);
+	if (rc)
+		return rc;
+	g->bytes_exchanged = 0;
+	const size_t nmiss = plan->missing.size();
+	if (nmiss == 0)
+		return GEC_OK;
+	// which of the k shards the decode reads live on which rank: shard v on rank v % N, local slot v / N;
+	// vs index = position among that rank's valid shards
+	std::vector<std::vector<int>> valid_of(N);
+	for (size_t t = 0; t < k; ++t)
+		valid_of[plan->valid[t] % N].push_back(plan->valid[t]);
+	size_t nvs_max = 0;
+	for (auto &v : valid_of)
+		nvs_max = std::max(nvs_max, v.size());
+	const size_t cols = S / 16;
+	auto range_lo = [&](size_t r) { return cols * r / N; };
+	size_t max_cols = 0;
+	for (size_t r = 0; r < N; ++r)
+		max_cols = std::max(max_cols, range_lo(r + 1) - range_lo(r));
+	const size_t my_cols = range_lo(g->rank + 1) - range_lo(g->rank);
+	const size_t per_peer = nvs_max * nobjects * max_cols * 16;
+	const size_t packed_bytes = nmiss * nobjects * max_cols * 16;
+	// scratch: [send N*per_peer][recv N*per_peer]; the rebuilt ranges reuse the group's d_send / d_recv
+	if (N * per_peer > g->a2a_cap || packed_bytes > g->send_cap || packed_bytes * N > g->recv_cap) {
+		HIP_TRY(hipStreamSynchronize(stream));
+		for (uint8_t **p : {&g->d_a2a_send, &g->d_a2a_recv, &g->d_send, &g->d_recv})
+			if (*p) {
+				(void)hipFree(*p);
+				*p = nullptr;
+			}
+		g->a2a_cap = g->send_cap = g->recv_cap = 0;
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_a2a_send), N * per_peer));
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_a2a_recv), N * per_peer));
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_send), packed_bytes));
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_recv), packed_bytes * N));
+		HIP_TRY(hipMemsetAsync(g->d_a2a_send, 0, N * per_peer, stream));  // pad columns / unused vs slots: defined bytes on the wire
+		HIP_TRY(hipMemsetAsync(g->d_send, 0, packed_bytes, stream));
+		g->a2a_cap = N * per_peer;
+		g->send_cap = packed_bytes;
+		g->recv_cap = packed_bytes * N;
+	}
+	// (1) pack: for every peer, that peer's byte range of my valid shards
+	const std::vector<int> &mine = valid_of[g->rank];
+	if (!mine.empty()) {
+		gec::A2aArgs pa;
+		std::memset(&pa, 0, sizeof(pa));
+		pa.local = static_cast<const uint8_t *>(d_local_slots);
+		pa.send = g->d_a2a_send;
+		pa.obj_stride = slots * S;
+		pa.nobj = (uint32_t)nobjects;
+		pa.nvs = (uint32_t)mine.size();
+		pa.nvs_max = (uint32_t)nvs_max;
+		pa.cols = (uint32_t)cols;
+		pa.max_cols = (uint32_t)max_cols;
+		pa.world = (uint32_t)N;
+		for (size_t i = 0; i < mine.size(); ++i)
+			pa.slot_of[i] = (uint32_t)(mine[i] / N);
+		rc = launch_a2a_pack(pa, N * mine.size() * nobjects * max_cols, stream);
+		if (rc)
+			return rc;
+	}
+	// (2) the exchange step: 1/N of the all-gather's bytes
+	g->bytes_exchanged = per_peer * (N - 1);
+	rc = g->all_to_all(g->ctx, g->d_a2a_send, g->d_a2a_recv, per_peer, hip_stream);
+	if (rc)
+		return rc > 0 ? fail(GEC_E_DEVICE, "all_to_all transport failed") : rc;
+	// (3) my byte range of every missing shard, from the received ranges: input shard valid[t] sits at
+	//     recv[(owner*nvs_max + vs)*nobj + obj][max_cols]; output i at d_send[(i*nobj + obj)][max_cols]
+	if (my_cols) {
+		std::vector<size_t> in_off(k), out_off(nmiss);
+		for (size_t t = 0; t < k; ++t) {
+			const int v = plan->valid[t];
+			const size_t owner = v % N;
+			const size_t vs = std::find(valid_of[owner].begin(), valid_of[owner].end(), v) - valid_of[owner].begin();
+			in_off[t] = (owner * nvs_max + vs) * nobjects * max_cols * 16;
+		}
+		for (size_t i = 0; i < nmiss; ++i)
+			out_off[i] = i * nobjects * max_cols * 16;
+		rc = launch_apply(c, g->d_a2a_recv, max_cols * 16, g->d_send, max_cols * 16, nullptr, 0, my_cols * 16, nobjects,
+				  in_off.data(), out_off.data(), (int)nmiss, plan->rows.v.data(), gec::MODE_STORE, stream);
+		if (rc)
+			return rc;
+	}
+	// (4) the rebuilt ranges: mine only, or everybody's after a (small) all-gather
+	gec::RebuiltArgs ua;
+	std::memset(&ua, 0, sizeof(ua));
+	ua.rebuilt = static_cast<uint8_t *>(d_rebuilt);
+	ua.nobj = (uint32_t)nobjects;
+	ua.nmiss = (uint32_t)nmiss;
+	ua.cols = (uint32_t)cols;
+	ua.max_cols = (uint32_t)max_cols;
+	ua.world = (uint32_t)N;
+	if (complete && N > 1) {
+		g->bytes_exchanged += packed_bytes * (N - 1);
+		rc = g->all_gather(g->ctx, g->d_send, g->d_recv, packed_bytes, hip_stream);
+		if (rc)
+			return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+		ua.packed = g->d_recv;
+		ua.first_rank = 0;
+		ua.nranks_in = (uint32_t)N;
+	} else {
+		ua.packed = g->d_send;
+		ua.first_rank = (uint32_t)g->rank;
+		ua.nranks_in = 1;
+	}
+	return launch_rebuilt_unpack(ua, (size_t)ua.nranks_in * nmiss * nobjects * max_cols, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,1178 @@
+// ec_hip_host.cpp -- the host-pointer entry points of the HIP backend: how caller memory (ordinary or pinned) gets
+// to the kernels and back.  Pageable buffers go through the staging slots' pinned pieces (run_pipeline); pinned
+// caller memory is read and written in place by pointer-table kernels (zero copy), optionally mirrored into HBM for
+// the checksums of the same trip.  Argument checking happened in ec_api.cpp.  Host code only.
+#include "ec_hip.hpp"
+
+#include <algorithm>
+
+namespace gecimpl {
+
+// gec_encode_batch (shard_sums == NULL) / gec_encode_hash_batch
+int HipBackend::encode_batch(size_t nblocks, const uint8_t *const *blocks, const size_t *block_len, size_t S, uint8_t *const *parity,
+			     uint8_t *shard_sums)
+{
+	const size_t k = c->k, m = c->m, n = k + m;
+	const size_t stripe = n * S;
+	ForegroundScope fg(c);
+	// the hash kernel's serial chain costs ~3.5 ms per launch whatever the batch, so
+	// chunks are 8x larger when checksums are requested
+	// caller memory that is pinned end to end needs no host staging, so the only reasons to chunk are the size of
+	// the device buffer and the overlap of copy-in / kernels / copy-out between the two slots: 128 MiB chunks
+	bool all_pinned = true;
+	for (size_t b = 0; b < nblocks && all_pinned; ++b)
+		all_pinned = aligned16(blocks[b]) && aligned16(parity[b]) && pinned().contains(blocks[b], block_len[b]) &&
+			     pinned().contains(parity[b], m * S);
+	// a handful of blocks in ordinary memory: a host core is done before a staged device trip has started
+	// (one 1 MiB block: 57 us on one AVX2 core against 94 us; profiles/r02_host_api_latency.txt).  Off by default.
+	if (!all_pinned && !shard_sums && nblocks <= env().small_call_blocks)
+		if (Backend *cpu = small_call_helper())
+			return cpu->encode_batch(nblocks, blocks, block_len, S, parity, nullptr);
+	if (all_pinned && k <= (size_t)gec::PTR_KMAX && env().zero_copy) {
+		// every buffer is device-addressable: ONE kernel reads the data shards and writes the parity in place
+		// over the link; nothing is staged in HBM, no host copy.  With checksums requested the same kernel also
+		// lays everything it reads and computes down in HBM (the bytes still cross the link once), chunk by
+		// chunk on two streams, and each chunk's shard checksums are computed from there while the next chunk
+		// is on the link.
+		DeviceGuard dg(c->device);
+		if (!dg.ok)
+			return fail(GEC_E_DEVICE, "hipSetDevice failed");
+		StagingLease lease(c);
+		Staging &st = lease.st;
+		const size_t zch = shard_sums || c->qos_class == GEC_CLASS_BACKGROUND ? chunk_blocks(stripe, nblocks, trip_chunk_bytes(c)) : nblocks;
+		const size_t nz = (nblocks + zch - 1) / zch;
+		int rc = st.ensure(shard_sums ? nblocks * n * 32 + 64 : 64, 0);
+		if (!rc)
+			rc = st.ensure_tab((nblocks * (k * 12 + m * 8) + 64 * nz) / sizeof(gec::CopyEntry) + 4 * nz + 4);
+		if (!rc && shard_sums)
+			rc = st.ensure_big(2 * (zch * stripe + zch * n * 32));
+		if (!rc && shard_sums)
+			rc = st.ensure_segments(num_cu);
+		if (rc)
+			return rc;
+		// with checksums: the link kernel on a few CUs of its own, the checksum kernels on the rest (a kernel whose
+		// loads share a CU with microsecond-long host reads crawls, see Staging::stream_up); chunk ci+2 reuses the
+		// mirror of chunk ci, so its link kernel waits for that chunk's checksums
+		hipStream_t up = shard_sums && st.stream_up ? st.stream_up : st.stream;
+		hipStream_t chain = shard_sums && st.stream_chain ? st.stream_chain : st.stream2;
+		std::vector<const uint8_t *> in(zch * k);
+		std::vector<uint32_t> valid(zch * k);
+		std::vector<uint8_t *> out(zch * m);
+		for (size_t ci = 0; ci < nz && !rc; ++ci) {
+			const size_t b0 = ci * zch, nb = std::min(zch, nblocks - b0);
+			background_yield(c);
+			for (size_t i = 0; i < nb; ++i) {
+				const uint8_t *p = pinned().dev(blocks[b0 + i]);
+				uint8_t *q = pinned().dev(parity[b0 + i]);
+				const size_t len = block_len[b0 + i];
+				for (size_t t = 0; t < k; ++t) {
+					in[i * k + t] = p + t * S;
+					valid[i * k + t] = (uint32_t)(len > t * S ? std::min(S, len - t * S) : 0);
+				}
+				for (size_t r = 0; r < m; ++r)
+					out[i * m + r] = q + r * S;
+			}
+			uint8_t *mir = shard_sums ? st.d_big + (ci & 1) * (zch * stripe + zch * n * 32) : nullptr;
+			if (shard_sums && ci >= 2 && hipStreamWaitEvent(up, st.ev_seg[2 + (ci & 1)], 0) != hipSuccess)
+				rc = fail(GEC_E_DEVICE, "hipStreamWaitEvent");
+			if (!rc)
+				rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), out.data(), (int)m, S, c->enc.row(k), up, mir);
+			if (rc || !shard_sums)
+				continue;
+			uint8_t *d_sums = mir + zch * stripe;
+			hipError_t e = hipEventRecord(st.ev_seg[ci & 1], up);
+			if (e == hipSuccess)
+				e = hipStreamWaitEvent(chain, st.ev_seg[ci & 1], 0);
+			if (e != hipSuccess) {
+				rc = fail(GEC_E_DEVICE, "chunk event");
+				continue;
+			}
+			rc = blake2_dev(c, nb * n, mir, nullptr, nullptr, S, S, d_sums, chain, 0, 0, 0, true);
+			if (!rc && hipMemcpyAsync(st.h_buf + b0 * n * 32, d_sums, nb * n * 32, hipMemcpyDeviceToHost, chain) != hipSuccess)
+				rc = fail(GEC_E_DEVICE, "hipMemcpyAsync (shard sums)");
+			if (!rc && hipEventRecord(st.ev_seg[2 + (ci & 1)], chain) != hipSuccess)
+				rc = fail(GEC_E_DEVICE, "hipEventRecord");
+		}
+		const hipError_t e1 = hipStreamSynchronize(up), e2 = shard_sums ? hipStreamSynchronize(chain) : hipSuccess;
+		if (rc)
+			return rc;
+		HIP_TRY(e1);
+		HIP_TRY(e2);
+		if (shard_sums)
+			std::memcpy(shard_sums, st.h_buf, nblocks * n * 32);
+		return GEC_OK;
+	}
+	const size_t ch = chunk_blocks(stripe, nblocks, shard_sums ? trip_chunk_bytes(c) : all_pinned ? pinned_chunk_bytes(c) : kChunkBytes);
+	const size_t sums_off = ch * stripe;  // checksum area behind the stripes of a slot
+	const size_t nchunks = (nblocks + ch - 1) / ch;
+	ForkJoinPool &pool = copy_pool();
+	// per chunk: are all its blocks / all its parity buffers in pinned memory the caller registered?
+	// Then the DMA engines read / write the caller's memory directly and the staging copy is skipped.
+	std::vector<uint8_t> in_pinned(nchunks, 1), out_pinned(nchunks, 1);
+	std::vector<size_t> min_len(nchunks, k * S);
+	PipeChain chain;
+	for (size_t b = 0; b < nblocks; ++b) {
+		const size_t ci = b / ch;
+		if (in_pinned[ci] && !(aligned16(blocks[b]) && pinned().contains(blocks[b], block_len[b])))
+			in_pinned[ci] = 0;
+		if (out_pinned[ci] && !(aligned16(parity[b]) && pinned().contains(parity[b], m * S)))
+			out_pinned[ci] = 0;
+		min_len[ci] = std::min(min_len[ci], block_len[b]);
+	}
+	return run_pipeline(
+		c, nchunks, ch * stripe + (shard_sums ? ch * n * 32 : 0), 0,
+		[&](size_t ci, Staging &st) {  // host: user blocks -> pinned, zero-padded to k*S
+			(void)st.ensure_tab(2 * ch);  // a failure shows up as "copy table overflow" when the table is used
+			if (in_pinned[ci])
+				return;
+			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
+			pool.parallel_for(nb, [&](size_t i) {
+				uint8_t *dst = st.h_buf + i * stripe;
+				const size_t len = block_len[b0 + i];
+				std::memcpy(dst, blocks[b0 + i], len);
+				std::memset(dst + len, 0, k * S - len);
+			});
+		},
+		[&](size_t ci, Staging &st) -> int {  // device: only data shards go H2D, only parity (+sums) comes back
+			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
+			if (in_pinned[ci]) {
+				// zero padding behind the shortest block of the chunk first (stream order), then
+				// every block straight from the caller's memory
+				if (min_len[ci] < k * S)
+					HIP_TRY(hipMemset2DAsync(st.d_buf + min_len[ci], stripe, 0, k * S - min_len[ci], nb, st.stream));
+				// ONE copy_table launch: the kernel reads every block straight from the caller's pinned memory
+				std::vector<gec::CopyEntry> ents;
+				ents.reserve(nb);
+				for (size_t i = 0; i < nb; ++i)
+					if (block_len[b0 + i])
+						ents.push_back({pinned().dev(blocks[b0 + i]), st.d_buf + i * stripe, block_len[b0 + i]});
+				int rct = chain.before(chain.last_in, st.stream);
+				if (!rct)
+					rct = launch_copy_table(st, ents, st.stream);
+				if (!rct)
+					rct = chain.after_in(st);
+				if (rct)
+					return rct;
+			} else {
+				HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, st.h_buf, stripe, k * S, nb, hipMemcpyHostToDevice, st.stream));
+			}
+			int rc = shard_sums ? encode_hash_dev(c, nb, st.d_buf, stripe, S, st.d_buf + sums_off, st.stream, st)
+					    : encode_dev(c, nb, st.d_buf, stripe, S, st.d_buf + k * S, stripe, st.stream);
+			if (rc)
+				return rc;
+			if (out_pinned[ci]) {
+				std::vector<gec::CopyEntry> ents;
+				ents.reserve(nb);
+				for (size_t i = 0; i < nb; ++i)
+					ents.push_back({st.d_buf + i * stripe + k * S, pinned().dev(parity[b0 + i]), m * S});
+				int rct = chain.before(chain.last_out, st.stream);
+				if (!rct)
+					rct = launch_copy_table(st, ents, st.stream);
+				if (!rct)
+					rct = chain.after_out(st);
+				if (rct)
+					return rct;
+			} else {
+				HIP_TRY(hipMemcpy2DAsync(st.h_buf + k * S, stripe, st.d_buf + k * S, stripe, m * S, nb, hipMemcpyDeviceToHost, st.stream));
+			}
+			if (shard_sums)
+				HIP_TRY(hipMemcpyAsync(st.h_buf + sums_off, st.d_buf + sums_off, nb * n * 32, hipMemcpyDeviceToHost, st.stream));
+			return GEC_OK;
+		},
+		[&](size_t ci, Staging &st) {  // host: parity (+sums) -> user buffers
+			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
+			if (!out_pinned[ci])
+				pool.parallel_for(nb, [&](size_t i) { std::memcpy(parity[b0 + i], st.h_buf + i * stripe + k * S, m * S); });
+			if (shard_sums)
+				std::memcpy(shard_sums + b0 * n * 32, st.h_buf + sums_off, nb * n * 32);
+		});
+}
+
+// gec_blake2sum_batch (tree == false) / gec_shardsum_batch
+int HipBackend::hash_batch(size_t n, const uint8_t *const *msgs, const size_t *lens, uint8_t *out, bool tree)
+{
+	ForegroundScope fg(c);
+	size_t longest = 0;
+	bool all_pinned = true;
+	for (size_t i = 0; i < n; ++i) {
+		longest = std::max(longest, lens[i]);
+		if (all_pinned && lens[i] && !(aligned16(msgs[i]) && pinned().contains(msgs[i], lens[i])))
+			all_pinned = false;
+	}
+	// (a) every message in pinned, 16-byte aligned caller memory: NO copy at all -- ONE launch whose lanes
+	//     stream their messages straight from host memory over PCIe; only the (offset, length) table and the
+	//     32-byte results go through a staging slot.
+	// (b) long messages (a BLAKE2b chain costs ~4000 cycles per 128-byte block however many messages run
+	//     beside it: 14 ms per MiB): everything is first moved into ONE device buffer through two pinned
+	//     staging pieces, then hashed by ONE launch -- chunked launches would pay the chain once per chunk.
+	if (all_pinned && tree && env().zero_copy && n > 1) {
+		// Shard checksums of pinned messages: lanes that each stream a 4 KiB leaf out of host memory read the link in
+		// 16-byte pieces (22 GiB/s); a copy kernel moves the same bytes coalesced at the link's rate, so the messages
+		// go to HBM chunk by chunk (copy_table on the upload stream's CUs) and are hashed there beside the next
+		// chunk's transfer.
+		DeviceGuard dg(c->device);
+		if (!dg.ok)
+			return fail(GEC_E_DEVICE, "hipSetDevice failed");
+		StagingLease lease(c);
+		Staging &st = lease.st;
+		const size_t kChunk = trip_chunk_bytes(c);
+		const size_t buf_bytes = std::max(kChunk, (longest + 15) / 16 * 16);
+		int rc = st.ensure(n * 48 + 64, 0);  // [off][len][out]
+		if (!rc)
+			rc = st.ensure_tab(n + 8);
+		if (!rc)
+			rc = st.ensure_big(2 * buf_bytes);
+		if (!rc)
+			rc = st.ensure_segments(num_cu);
+		if (rc)
+			return rc;
+		hipStream_t up = st.stream_up ? st.stream_up : st.stream;
+		hipStream_t chain = st.stream_chain ? st.stream_chain : st.stream2;
+		uint64_t *h_off = reinterpret_cast<uint64_t *>(st.h_buf), *h_len = h_off + n;
+		uint8_t *h_out = st.h_buf + n * 16;
+		size_t ci = 0;
+		for (size_t i = 0; i < n && !rc; ++ci) {
+			background_yield(c);
+			uint8_t *buf = st.d_big + (ci & 1) * buf_bytes;
+			std::vector<gec::CopyEntry> ents;
+			size_t j = i, bytes = 0, chunk_longest = 0;
+			while (j < n && (j == i || bytes + (lens[j] + 15) / 16 * 16 <= buf_bytes)) {
+				h_off[j] = bytes;
+				h_len[j] = lens[j];
+				if (lens[j])
+					ents.push_back({pinned().dev(msgs[j]), buf + bytes, lens[j]});
+				chunk_longest = std::max(chunk_longest, lens[j]);
+				bytes += (lens[j] + 15) / 16 * 16;
+				++j;
+			}
+			if (ci >= 2 && hipStreamWaitEvent(up, st.ev_seg[2 + (ci & 1)], 0) != hipSuccess)
+				rc = fail(GEC_E_DEVICE, "hipStreamWaitEvent");
+			if (!rc)
+				rc = launch_copy_table(st, ents, up);
+			hipError_t e = rc ? hipSuccess : hipEventRecord(st.ev_seg[ci & 1], up);
+			if (!rc && e == hipSuccess)
+				e = hipStreamWaitEvent(chain, st.ev_seg[ci & 1], 0);
+			if (!rc && e != hipSuccess)
+				rc = fail(GEC_E_DEVICE, "chunk event");
+			if (!rc)
+				rc = blake2_dev(c, j - i, buf, h_off + i, h_len + i, 0, 0, h_out + 32 * i, chain, 0, 0, 0, true, chunk_longest);
+			if (!rc && hipEventRecord(st.ev_seg[2 + (ci & 1)], chain) != hipSuccess)
+				rc = fail(GEC_E_DEVICE, "hipEventRecord");
+			i = j;
+		}
+		const hipError_t e1 = hipStreamSynchronize(up), e2 = hipStreamSynchronize(chain);
+		if (rc)
+			return rc;
+		HIP_TRY(e1);
+		HIP_TRY(e2);
+		std::memcpy(out, h_out, n * 32);
+		return GEC_OK;
+	}
+	if (all_pinned || longest >= (256u << 10) || tree) {
+		DeviceGuard dg(c->device);
+		if (!dg.ok)
+			return fail(GEC_E_DEVICE, "hipSetDevice failed");
+		constexpr size_t kPiece = 32ull << 20;
+		std::vector<uint64_t> off(n);
+		size_t dev_bytes = 0;
+		for (size_t i = 0; i < n; ++i) {
+			off[i] = dev_bytes;
+			dev_bytes += (lens[i] + 15) / 16 * 16;
+		}
+		if (!all_pinned && dev_bytes > (8ull << 30)) {
+			// more than a device buffer should hold at once: halves (each still one launch)
+			const size_t h = n / 2;
+			int rc = hash_batch(h, msgs, lens, out, tree);
+			return rc ? rc : hash_batch(n - h, msgs + h, lens + h, out + 32 * h, tree);
+		}
+		StagingLease l0(c);
+		const size_t meta = n * 16, res = n * 32;
+		const size_t meta_off = all_pinned ? 0 : 2 * kPiece;  // h_buf of slot 0: [piece A][piece B][off][len][out]
+		int rc = l0.st.ensure(meta_off + meta + res + 64, 0);
+		if (rc)
+			return rc;
+		Staging &st = l0.st;
+		uint8_t *d_msgs = nullptr;
+		if (!all_pinned)
+			HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_msgs), std::max<size_t>(dev_bytes, 16)));
+		uint64_t *h_off = reinterpret_cast<uint64_t *>(st.h_buf + meta_off);
+		uint64_t *h_len = h_off + n;
+		uint8_t *h_out = st.h_buf + meta_off + meta;
+		for (size_t i = 0; i < n; ++i) {
+			h_off[i] = all_pinned ? reinterpret_cast<uint64_t>(pinned().dev(msgs[i])) : off[i];
+			h_len[i] = lens[i];
+		}
+		auto cleanup = [&](int code) {
+			if (d_msgs) {
+				(void)hipStreamSynchronize(st.stream);
+				(void)hipFree(d_msgs);
+			}
+			return code;
+		};
+		if (!all_pinned) {
+			// two staging pieces, filled by the copy pool while the other one is on the bus
+			ForkJoinPool &pool = copy_pool();
+			hipEvent_t done[2] = {st.ev_fork, st.ev_join};
+			bool used[2] = {false, false};
+			size_t piece = 0;
+			for (size_t i = 0; i < n;) {
+				// messages (or parts of a long one) that fit the piece
+				uint8_t *hp = st.h_buf + (piece & 1) * kPiece;
+				if (used[piece & 1]) {
+					hipError_t e = hipEventSynchronize(done[piece & 1]);
+					if (e != hipSuccess)
+						return cleanup(fail(GEC_E_DEVICE, std::string("hipEventSynchronize: ") + hipGetErrorString(e)));
+				}
+				const size_t d0 = off[i];
+				size_t j = i, bytes = 0;
+				while (j < n && bytes + (lens[j] + 15) / 16 * 16 <= kPiece) {
+					bytes += (lens[j] + 15) / 16 * 16;
+					++j;
+				}
+				if (j == i) {  // one message longer than a piece: stream it through in piece-sized parts
+					for (size_t o = 0; o < lens[i]; o += kPiece) {
+						hp = st.h_buf + (piece & 1) * kPiece;
+						if (used[piece & 1] && hipEventSynchronize(done[piece & 1]) != hipSuccess)
+							return cleanup(fail(GEC_E_DEVICE, "hipEventSynchronize failed"));
+						const size_t nbytes = std::min(kPiece, lens[i] - o);
+						const size_t parts = (nbytes + (1 << 20) - 1) >> 20;
+						pool.parallel_for(parts, [&](size_t q) {
+							const size_t a = q << 20, b = std::min(nbytes, a + (1 << 20));
+							std::memcpy(hp + a, msgs[i] + o + a, b - a);
+						});
+						hipError_t e = hipMemcpyAsync(d_msgs + off[i] + o, hp, nbytes, hipMemcpyHostToDevice, st.stream);
+						if (e == hipSuccess)
+							e = hipEventRecord(done[piece & 1], st.stream);
+						if (e != hipSuccess)
+							return cleanup(fail(GEC_E_DEVICE, std::string("H2D: ") + hipGetErrorString(e)));
+						used[piece & 1] = true;
+						++piece;
+					}
+					++i;
+					continue;
+				}
+				pool.parallel_for(j - i, [&](size_t q) { std::memcpy(hp + (off[i + q] - d0), msgs[i + q], lens[i + q]); });
+				hipError_t e = hipMemcpyAsync(d_msgs + d0, hp, bytes, hipMemcpyHostToDevice, st.stream);
+				if (e == hipSuccess)
+					e = hipEventRecord(done[piece & 1], st.stream);
+				if (e != hipSuccess)
+					return cleanup(fail(GEC_E_DEVICE, std::string("H2D: ") + hipGetErrorString(e)));
+				used[piece & 1] = true;
+				++piece;
+				i = j;
+			}
+		}
+		// the (offset, length) table and the results live in pinned host memory the kernel reads / writes directly
+		rc = blake2_dev(c, n, all_pinned ? nullptr : d_msgs, h_off, h_len, 0, 0, h_out, st.stream, 0, 0, 0, tree, longest);
+		if (rc)
+			return cleanup(rc);
+		hipError_t e = hipStreamSynchronize(st.stream);
+		if (e != hipSuccess)
+			return cleanup(fail(GEC_E_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)));
+		std::memcpy(out, h_out, res);
+		return cleanup(GEC_OK);
+	}
+	// (c) many short messages in pageable memory: greedy chunks of <= 4*kChunkBytes of (16-byte aligned) message
+	//     slots through the two-slot pipeline (hashing of chunk i overlaps the upload of chunk i+1)
+	struct Chunk {
+		size_t first, count, bytes;
+	};
+	std::vector<Chunk> chunks;
+	std::vector<uint64_t> slot_off(n);
+	size_t max_bytes = 0, max_count = 0;
+	for (size_t i = 0; i < n;) {
+		Chunk ck{i, 0, 0};
+		while (i < n && (ck.count == 0 || ck.bytes + lens[i] <= 4 * kChunkBytes)) {
+			slot_off[i] = ck.bytes;
+			ck.bytes += (lens[i] + 15) / 16 * 16;
+			++ck.count;
+			++i;
+		}
+		chunks.push_back(ck);
+		max_bytes = std::max(max_bytes, ck.bytes);
+		max_count = std::max(max_count, ck.count);
+	}
+	// slot layout: [messages][off u64 x count][len u64 x count][out 32 x count]
+	const size_t meta_off = (max_bytes + 63) / 64 * 64;
+	const size_t out_off = meta_off + 16 * max_count;
+	ForkJoinPool &pool = copy_pool();
+	return run_pipeline(
+		c, chunks.size(), out_off + 32 * max_count, 0,
+		[&](size_t ci, Staging &st) {
+			const Chunk &ck = chunks[ci];
+			uint64_t *offs = reinterpret_cast<uint64_t *>(st.h_buf + meta_off);
+			uint64_t *ls = offs + ck.count;
+			pool.parallel_for(ck.count, [&](size_t i) {
+				std::memcpy(st.h_buf + slot_off[ck.first + i], msgs[ck.first + i], lens[ck.first + i]);
+				offs[i] = slot_off[ck.first + i];
+				ls[i] = lens[ck.first + i];
+			});
+		},
+		[&](size_t ci, Staging &st) -> int {
+			const Chunk &ck = chunks[ci];
+			HIP_TRY(hipMemcpyAsync(st.d_buf, st.h_buf, ck.bytes, hipMemcpyHostToDevice, st.stream));
+			HIP_TRY(hipMemcpyAsync(st.d_buf + meta_off, st.h_buf + meta_off, 16 * ck.count, hipMemcpyHostToDevice, st.stream));
+			const uint64_t *d_off = reinterpret_cast<const uint64_t *>(st.d_buf + meta_off);
+			int rc = blake2_dev(c, ck.count, st.d_buf, d_off, d_off + ck.count, 0, 0, st.d_buf + out_off, st.stream);
+			if (rc)
+				return rc;
+			HIP_TRY(hipMemcpyAsync(st.h_buf + out_off, st.d_buf + out_off, 32 * ck.count, hipMemcpyDeviceToHost, st.stream));
+			return GEC_OK;
+		},
+		[&](size_t ci, Staging &st) {
+			const Chunk &ck = chunks[ci];
+			std::memcpy(out + 32 * ck.first, st.h_buf + out_off, 32 * ck.count);
+		});
+}
+
+int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards, size_t S, const size_t *block_len,
+				    uint8_t *const *rebuilt, uint8_t *shard_sums, uint8_t *block_sums)
+{
+	const size_t k = c->k, n = c->k + c->m;
+	ForegroundScope fg(c);
+	// more than one device buffer should hold: halves
+	const size_t kMaxBytes = 6ull << 30;
+	if (nblocks > 1 && nblocks * n * S > kMaxBytes) {
+		const size_t h = nblocks / 2;
+		int rc = decode_verify_batch(h, shards, S, block_len, rebuilt, shard_sums, block_sums);
+		if (rc)
+			return rc;
+		return decode_verify_batch(nblocks - h, shards + h * n, S, block_len ? block_len + h : nullptr,
+					   rebuilt ? rebuilt + h * n : nullptr, shard_sums + h * n * 32,
+					   block_sums ? block_sums + h * 32 : nullptr);
+	}
+	// -- per block: which shards are read (the crate's rule: the first k present), which data shards are rebuilt;
+	//    blocks are laid out on the device bucket by bucket (one erasure pattern each), a block's stripe holding
+	//    its k data slots followed by one slot per parity shard it is decoded from
+	struct Bucket {
+		std::shared_ptr<const Plan> plan;
+		std::vector<size_t> ids;
+		size_t base = 0, stripe = 0, npar = 0;
+	};
+	std::map<std::string, Bucket> buckets;
+	for (size_t b = 0; b < nblocks; ++b) {
+		std::string key(n, 0);
+		size_t np = 0;
+		for (size_t j = 0; j < n; ++j) {
+			key[j] = shards[b * n + j] ? 1 : 0;
+			np += key[j];
+		}
+		if (np < k)
+			return fail(GEC_E_TOO_FEW_PRESENT, "fewer than k shards present");
+		if (block_len && block_len[b] > k * S)
+			return fail(GEC_E_INCORRECT_SHARD_SIZE, "block longer than k*S");
+		buckets[key].ids.push_back(b);
+	}
+	size_t dev_bytes = 0, nup = 0, nreb = 0;
+	for (auto &kv : buckets) {
+		Bucket &bk = kv.second;
+		int rc = get_plan(c, reinterpret_cast<const uint8_t *>(kv.first.data()), true, bk.plan);
+		if (rc)
+			return rc;
+		bk.npar = bk.plan->missing.size();  // as many parity inputs as data shards to rebuild
+		bk.stripe = (k + bk.npar) * S;
+		bk.base = dev_bytes;
+		dev_bytes += bk.ids.size() * bk.stripe;
+		nup += bk.ids.size() * k;
+		nreb += bk.ids.size() * bk.npar;
+		for (size_t b : bk.ids)
+			for (int j : bk.plan->missing)
+				if (!rebuilt || !rebuilt[b * n + j])
+					return fail(GEC_E_INVALID_ARG, "NULL output for a missing data shard");
+	}
+	DeviceGuard dg(c->device);
+	if (!dg.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	bool all_pinned = true;
+	for (size_t b = 0; b < nblocks && all_pinned; ++b)
+		for (size_t j = 0; j < n && all_pinned; ++j)
+			if (shards[b * n + j])
+				all_pinned = aligned16(shards[b * n + j]) && pinned().contains(shards[b * n + j], S);
+	StagingLease lease(c);
+	Staging &st = lease.st;
+	constexpr size_t kPiece = 32ull << 20;
+	// host staging: [piece A][piece B] (pageable shards only) [shard off | shard len | block off | block len][shard sums][block sums][rebuilt]
+	const size_t tab_off = all_pinned ? 0 : 2 * kPiece;
+	const size_t tab_bytes = (nup * 2 + nblocks * 2) * 8;
+	const size_t ssum_off = tab_off + tab_bytes, bsum_off = ssum_off + nup * 32;
+	const size_t reb_off = (bsum_off + nblocks * 32 + 63) / 64 * 64;
+	int rc = st.ensure(reb_off + nreb * S + 64, 0);
+	if (rc)
+		return rc;
+	const size_t state_off = (dev_bytes + 63) / 64 * 64;  // chaining values of the segmented block checksums
+	rc = st.ensure_big(state_off + nblocks * 64 + 64);
+	if (rc)
+		return rc;
+	rc = st.ensure_tab(nup + nreb);
+	if (rc)
+		return rc;
+	rc = st.ensure_segments(num_cu);
+	if (rc)
+		return rc;
+	uint64_t *h_soff = reinterpret_cast<uint64_t *>(st.h_buf + tab_off), *h_slen = h_soff + nup;
+	uint64_t *h_boff = h_slen + nup, *h_blen = h_boff + nblocks;
+	// -- block table: the blocks that need no decode first -- their checksum chains start while the upload is
+	//    still running (below); the others are hashed after their decode
+	size_t bi = 0, nh = 0, longest = 0;
+	std::vector<size_t> block_order(nblocks);
+	for (int pass = 0; pass < 2; ++pass) {
+		for (auto &kv : buckets) {
+			if ((kv.second.npar == 0) != (pass == 0))
+				continue;
+			for (size_t i = 0; i < kv.second.ids.size(); ++i) {
+				h_boff[bi] = kv.second.base + i * kv.second.stripe;
+				h_blen[bi] = block_len ? block_len[kv.second.ids[i]] : 0;
+				longest = std::max<size_t>(longest, h_blen[bi]);
+				block_order[bi++] = kv.second.ids[i];
+			}
+		}
+		if (pass == 0)
+			nh = bi;
+	}
+	// Upload stages: stage s carries data slots [k*s/nseg, k*(s+1)/nseg) of the blocks that need no decode (stage 0
+	// also everything of the blocks that do).  One stage unless every shard is pinned (the staged path uploads
+	// dense device ranges block by block) and the chains are long enough to be worth hiding: a BLAKE2b chain runs
+	// at ~14 ms per MiB, the link moves the MiB of 512 such blocks in 10 ms.
+	// GEC_VERIFY_SEGMENTS (A/B): 1 = upload everything, then hash
+	const int seg_max = env().verify_segments > 0 ? std::min(env().verify_segments, (int)Staging::kMaxSeg) : (int)Staging::kMaxSeg;
+	const size_t nseg = (all_pinned && block_sums && nh > 0 && longest >= (256u << 10)) ? std::min<size_t>(k, (size_t)seg_max) : 1;
+	// -- upload list, in device order
+	struct Up {
+		const uint8_t *src;
+		size_t dst;  // byte offset in d_big
+		size_t idx;  // (b*n + j): where the shard's checksum goes
+		size_t stage;
+	};
+	std::vector<Up> ups;
+	ups.reserve(nup);
+	for (auto &kv : buckets) {
+		Bucket &bk = kv.second;
+		for (size_t i = 0; i < bk.ids.size(); ++i) {
+			const size_t b = bk.ids[i];
+			size_t q = 0;  // parity input slot
+			for (size_t t = 0; t < k; ++t) {
+				const int j = bk.plan->valid[t];
+				const size_t slot = (size_t)j < k ? (size_t)j : k + q++;
+				const uint8_t *p = shards[b * n + j];
+				// stage of data slot j: the s with k*s/nseg <= j < k*(s+1)/nseg
+				size_t stage = 0;
+				if (bk.npar == 0 && nseg > 1)
+					while (k * (stage + 1) / nseg <= slot)
+						++stage;
+				ups.push_back({p, bk.base + i * bk.stripe + slot * S, b * n + j, stage});
+			}
+		}
+	}
+	std::sort(ups.begin(), ups.end(), [](const Up &a, const Up &b) { return a.dst < b.dst; });
+	for (size_t i = 0; i < ups.size(); ++i) {
+		h_soff[i] = ups[i].dst;
+		h_slen[i] = S;
+	}
+	auto hip_fail = [&](hipError_t e, const char *what) { return fail(GEC_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); };
+	hipEvent_t ev_up = nullptr, ev_sh = nullptr;
+	HIP_TRY(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
+	HIP_TRY(hipEventCreateWithFlags(&ev_sh, hipEventDisableTiming));
+	// staged upload: its own (CU-masked) stream pair when there is one
+	hipStream_t up_stream = nseg > 1 && st.stream_up ? st.stream_up : st.stream;
+	hipStream_t chain_stream = nseg > 1 && st.stream_chain ? st.stream_chain : st.stream2;
+	auto finish = [&](int code) {
+		(void)hipStreamSynchronize(up_stream);
+		(void)hipStreamSynchronize(chain_stream);
+		(void)hipStreamSynchronize(st.stream);
+		(void)hipStreamSynchronize(st.stream2);
+		(void)hipStreamSynchronize(st.stream3);
+		(void)hipEventDestroy(ev_up);
+		(void)hipEventDestroy(ev_sh);
+		return code;
+	};
+	bool healthy_hashed = false;
+	if (all_pinned) {
+		std::vector<std::vector<gec::CopyEntry>> ents(nseg);
+		for (size_t i = 0; i < ups.size();) {  // merge neighbours (the data shards of a block are slices of one buffer)
+			size_t run = 1;
+			while (i + run < ups.size() && ups[i + run].stage == ups[i].stage && ups[i + run].src == ups[i].src + run * S &&
+			       ups[i + run].dst == ups[i].dst + run * S)
+				++run;
+			ents[ups[i].stage].push_back({pinned().dev(ups[i].src), st.d_big + ups[i].dst, run * S});
+			i += run;
+		}
+		for (size_t sg = 0; sg < nseg; ++sg) {
+			rc = launch_copy_table(st, ents[sg], up_stream);
+			if (rc)
+				return finish(rc);
+			if (nseg == 1)
+				break;
+			// the chains of the no-decode blocks advance over what has arrived: whole 128-byte blocks below the
+			// end of this stage's last slot (the final stage finishes every message)
+			hipError_t es = hipEventRecord(st.ev_seg[sg], up_stream);
+			if (es == hipSuccess)
+				es = hipStreamWaitEvent(chain_stream, st.ev_seg[sg], 0);
+			if (es != hipSuccess)
+				return finish(hip_fail(es, "stage event"));
+			const uint64_t blk0 = (k * sg / nseg) * S / 128;
+			const uint64_t blk1 = sg + 1 == nseg ? ~0ull : (k * (sg + 1) / nseg) * S / 128;
+			rc = blake2_dev(c, nh, st.d_big, h_boff, h_blen, 0, 0, st.h_buf + bsum_off, chain_stream, 0, 0, 0, false, 0,
+					reinterpret_cast<uint64_t *>(st.d_big + state_off), blk0, blk1);
+			if (rc)
+				return finish(rc);
+		}
+		healthy_hashed = nseg > 1;
+	} else {
+		// pageable shards: the pieces are images of dense device ranges, filled by the copy pool while the other is on the bus
+		ForkJoinPool &pool = copy_pool();
+		hipEvent_t done[2] = {st.ev_fork, st.ev_join};
+		bool used[2] = {false, false};
+		size_t piece = 0;
+		for (size_t i = 0; i < ups.size();) {
+			uint8_t *hp = st.h_buf + (piece & 1) * kPiece;
+			if (used[piece & 1]) {
+				hipError_t e = hipEventSynchronize(done[piece & 1]);
+				if (e != hipSuccess)
+					return finish(hip_fail(e, "hipEventSynchronize"));
+			}
+			const size_t d0 = ups[i].dst;
+			size_t j = i;
+			while (j < ups.size() && ups[j].dst + S - d0 <= kPiece)
+				++j;
+			if (j == i)
+				return finish(fail(GEC_E_INVALID_ARG, "shard larger than a staging piece"));
+			const size_t bytes = ups[j - 1].dst + S - d0;
+			pool.parallel_for(j - i, [&](size_t q) { std::memcpy(hp + (ups[i + q].dst - d0), ups[i + q].src, S); });
+			hipError_t e = hipMemcpyAsync(st.d_big + d0, hp, bytes, hipMemcpyHostToDevice, st.stream);
+			if (e == hipSuccess)
+				e = hipEventRecord(done[piece & 1], st.stream);
+			if (e != hipSuccess)
+				return finish(hip_fail(e, "H2D"));
+			used[piece & 1] = true;
+			++piece;
+			i = j;
+		}
+	}
+	// -- everything is on the device.  Shard checksums on their own stream (they depend on nothing else); on the
+	//    main stream: decode per bucket, then the checksums of the blocks not hashed yet, then the rebuilt shards go home.
+	hipError_t e = hipEventRecord(ev_up, up_stream);
+	if (e == hipSuccess)
+		e = hipStreamWaitEvent(st.stream3, ev_up, 0);
+	if (e == hipSuccess && up_stream != st.stream)
+		e = hipStreamWaitEvent(st.stream, ev_up, 0);
+	if (e != hipSuccess)
+		return finish(hip_fail(e, "fork"));
+	rc = blake2_dev(c, nup, st.d_big, h_soff, h_slen, 0, 0, st.h_buf + ssum_off, st.stream3, 0, 0, 0, true, S);
+	if (rc)
+		return finish(rc);
+	e = hipEventRecord(ev_sh, st.stream3);
+	if (e != hipSuccess)
+		return finish(hip_fail(e, "hipEventRecord"));
+	std::vector<gec::CopyEntry> outs;
+	size_t rq = 0;
+	for (auto &kv : buckets) {
+		Bucket &bk = kv.second;
+		if (bk.npar == 0)
+			continue;
+		std::vector<size_t> in_off(k), out_off(bk.npar);
+		size_t q = 0;
+		for (size_t t = 0; t < k; ++t) {
+			const int j = bk.plan->valid[t];
+			in_off[t] = ((size_t)j < k ? (size_t)j : k + q++) * S;
+		}
+		for (size_t r = 0; r < bk.npar; ++r)
+			out_off[r] = (size_t)bk.plan->missing[r] * S;  // rebuilt in place, in the block's data area
+		rc = launch_apply(c, st.d_big + bk.base, bk.stripe, st.d_big + bk.base, bk.stripe, nullptr, 0, S, bk.ids.size(),
+				  in_off.data(), out_off.data(), (int)bk.npar, bk.plan->rows.v.data(), gec::MODE_STORE, st.stream);
+		if (rc)
+			return finish(rc);
+		for (size_t i = 0; i < bk.ids.size(); ++i)
+			for (size_t r = 0; r < bk.npar; ++r) {
+				uint8_t *dst = rebuilt[bk.ids[i] * n + bk.plan->missing[r]];
+				const bool direct = aligned16(dst) && pinned().contains(dst, S);
+				outs.push_back({st.d_big + bk.base + i * bk.stripe + out_off[r], direct ? pinned().dev(dst) : st.h_buf + reb_off + rq * S, S});
+				++rq;
+			}
+	}
+	if (block_sums) {
+		const size_t first = healthy_hashed ? nh : 0;  // [0, nh) went through the segments above
+		rc = blake2_dev(c, nblocks - first, st.d_big, h_boff + first, h_blen + first, 0, 0, st.h_buf + bsum_off + 32 * first, st.stream);
+		if (rc)
+			return finish(rc);
+	}
+	rc = launch_copy_table(st, outs, st.stream);
+	if (rc)
+		return finish(rc);
+	if (healthy_hashed) {
+		e = hipEventRecord(st.ev_join, chain_stream);
+		if (e == hipSuccess)
+			e = hipStreamWaitEvent(st.stream, st.ev_join, 0);
+		if (e != hipSuccess)
+			return finish(hip_fail(e, "join"));
+	}
+	e = hipStreamWaitEvent(st.stream, ev_sh, 0);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(st.stream);
+	if (e != hipSuccess)
+		return finish(hip_fail(e, "hipStreamSynchronize"));
+	// -- results: checksums to where the caller indexes them, rebuilt shards that could not be written directly
+	for (size_t i = 0; i < ups.size(); ++i)
+		std::memcpy(shard_sums + 32 * ups[i].idx, st.h_buf + ssum_off + 32 * i, 32);
+	if (block_sums)
+		for (size_t i = 0; i < nblocks; ++i)
+			std::memcpy(block_sums + 32 * block_order[i], st.h_buf + bsum_off + 32 * i, 32);
+	rq = 0;
+	for (auto &kv : buckets) {
+		Bucket &bk = kv.second;
+		for (size_t i = 0; i < bk.ids.size(); ++i)
+			for (size_t r = 0; r < bk.npar; ++r, ++rq) {
+				uint8_t *dst = rebuilt[bk.ids[i] * n + bk.plan->missing[r]];
+				if (!(aligned16(dst) && pinned().contains(dst, S)))
+					std::memcpy(dst, st.h_buf + reb_off + rq * S, S);
+			}
+	}
+	return finish(GEC_OK);
+}
+
+int HipBackend::verify_batch(size_t nblocks, const uint8_t *const *shards, size_t S, uint8_t *ok)
+{
+	const size_t n = c->k + c->m;
+	const size_t stripe = n * S;
+	ForegroundScope fg(c);
+	bool all_pinned = (size_t)c->k <= (size_t)gec::PTR_KMAX && env().zero_copy;
+	for (size_t i = 0; i < nblocks * n && all_pinned; ++i)
+		all_pinned = aligned16(shards[i]) && pinned().contains(shards[i], S);
+	if (all_pinned) {
+		// scrub of shards that sit in pinned memory: one kernel reads all k+m shards over the link and leaves the
+		// per-block verdicts in pinned memory; nothing is staged
+		const size_t k = c->k, m = c->m;
+		DeviceGuard dg(c->device);
+		if (!dg.ok)
+			return fail(GEC_E_DEVICE, "hipSetDevice failed");
+		StagingLease lease(c);
+		Staging &st = lease.st;
+		int rc = st.ensure(64, nblocks);
+		if (!rc)
+			rc = st.ensure_tab((nblocks * (k * 12 + m * 8) + 64) / sizeof(gec::CopyEntry) + 8);
+		if (rc)
+			return rc;
+		std::vector<const uint8_t *> in(nblocks * k);
+		std::vector<uint32_t> valid(nblocks * k, (uint32_t)S);
+		std::vector<uint8_t *> par(nblocks * m);
+		for (size_t b = 0; b < nblocks; ++b) {
+			for (size_t t = 0; t < k; ++t)
+				in[b * k + t] = pinned().dev(shards[b * n + t]);
+			for (size_t r = 0; r < m; ++r)
+				par[b * m + r] = const_cast<uint8_t *>(pinned().dev(shards[b * n + k + r]));
+		}
+		std::memset(st.h_bad, 0, nblocks * sizeof(uint32_t));
+		rc = launch_apply_ptrs(c, st, nblocks, in.data(), valid.data(), par.data(), (int)m, S, c->enc.row((int)k), st.stream, nullptr, st.h_bad);
+		const hipError_t e = hipStreamSynchronize(st.stream);
+		if (rc)
+			return rc;
+		HIP_TRY(e);
+		for (size_t b = 0; b < nblocks; ++b)
+			ok[b] = st.h_bad[b] ? 0 : 1;
+		return GEC_OK;
+	}
+	const size_t ch = chunk_blocks(stripe, nblocks, kChunkBytes);
+	ForkJoinPool &pool = copy_pool();
+	return run_pipeline(
+		c, (nblocks + ch - 1) / ch, ch * stripe, ch,
+		[&](size_t ci, Staging &st) {
+			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
+			pool.parallel_for(nb * n, [&](size_t q) {
+				std::memcpy(st.h_buf + (q / n) * stripe + (q % n) * S, shards[(b0 + q / n) * n + q % n], S);
+			});
+		},
+		[&](size_t ci, Staging &st) -> int {
+			const size_t nb = std::min(ch, nblocks - ci * ch);
+			HIP_TRY(hipMemcpyAsync(st.d_buf, st.h_buf, nb * stripe, hipMemcpyHostToDevice, st.stream));
+			int rc = verify_dev(c, nb, st.d_buf, stripe, S, st.d_bad, st.stream);
+			if (rc)
+				return rc;
+			HIP_TRY(hipMemcpyAsync(st.h_bad, st.d_bad, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st.stream));
+			return GEC_OK;
+		},
+		[&](size_t ci, Staging &st) {
+			const size_t b0 = ci * ch, nb = std::min(ch, nblocks - b0);
+			for (size_t i = 0; i < nb; ++i)
+				ok[b0 + i] = st.h_bad[i] ? 0 : 1;
+		});
+}
+
+int HipBackend::verify_hash_batch(size_t nblocks, const uint8_t *const *shards, size_t S, uint8_t *ok, uint8_t *shard_sums)
+{
+	const size_t k = c->k, m = c->m, n = k + m;
+	ForegroundScope fg(c);
+	bool all_pinned = k <= (size_t)gec::PTR_KMAX && env().zero_copy;
+	for (size_t i = 0; i < nblocks * n && all_pinned; ++i)
+		all_pinned = aligned16(shards[i]) && pinned().contains(shards[i], S);
+	if (!all_pinned) {
+		// pageable shards: two staged trips (the scrub of shards a caller keeps in ordinary memory is not a hot path)
+		int rc = verify_batch(nblocks, shards, S, ok);
+		if (rc)
+			return rc;
+		std::vector<size_t> lens(nblocks * n, S);
+		return hash_batch(nblocks * n, shards, lens.data(), shard_sums, true);
+	}
+	// one trip: the compare form of gf_apply_ptrs reads all k+m shards of a chunk over the link, leaves the verdicts in
+	// pinned memory and everything it read in HBM, where the chunk's shard checksums are computed while the next
+	// chunk is on the link (same stream pair as gec_encode_hash_batch)
+	DeviceGuard dg(c->device);
+	if (!dg.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	StagingLease lease(c);
+	Staging &st = lease.st;
+	const size_t stripe = n * S;
+	const size_t zch = chunk_blocks(stripe, nblocks, trip_chunk_bytes(c));
+	const size_t nz = (nblocks + zch - 1) / zch;
+	int rc = st.ensure(nblocks * n * 32 + 64, nblocks);
+	if (!rc)
+		rc = st.ensure_tab((nblocks * (k * 12 + m * 8) + 64 * nz) / sizeof(gec::CopyEntry) + 4 * nz + 4);
+	if (!rc)
+		rc = st.ensure_big(2 * (zch * stripe + zch * n * 32));
+	if (!rc)
+		rc = st.ensure_segments(num_cu);
+	if (rc)
+		return rc;
+	hipStream_t up = st.stream_up ? st.stream_up : st.stream;
+	hipStream_t chain = st.stream_chain ? st.stream_chain : st.stream2;
+	std::memset(st.h_bad, 0, nblocks * sizeof(uint32_t));
+	std::vector<const uint8_t *> in(zch * k);
+	std::vector<uint32_t> valid(zch * k, (uint32_t)S);
+	std::vector<uint8_t *> par(zch * m);
+	for (size_t ci = 0; ci < nz && !rc; ++ci) {
+		const size_t b0 = ci * zch, nb = std::min(zch, nblocks - b0);
+		background_yield(c);
+		for (size_t i = 0; i < nb; ++i) {
+			for (size_t t = 0; t < k; ++t)
+				in[i * k + t] = pinned().dev(shards[(b0 + i) * n + t]);
+			for (size_t r = 0; r < m; ++r)
+				par[i * m + r] = const_cast<uint8_t *>(pinned().dev(shards[(b0 + i) * n + k + r]));
+		}
+		uint8_t *mir = st.d_big + (ci & 1) * (zch * stripe + zch * n * 32);
+		if (ci >= 2 && hipStreamWaitEvent(up, st.ev_seg[2 + (ci & 1)], 0) != hipSuccess)
+			rc = fail(GEC_E_DEVICE, "hipStreamWaitEvent");
+		if (!rc)
+			rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), par.data(), (int)m, S, c->enc.row((int)k), up, mir, st.h_bad + b0);
+		if (rc)
+			continue;
+		uint8_t *d_sums = mir + zch * stripe;
+		hipError_t e = hipEventRecord(st.ev_seg[ci & 1], up);
+		if (e == hipSuccess)
+			e = hipStreamWaitEvent(chain, st.ev_seg[ci & 1], 0);
+		if (e != hipSuccess) {
+			rc = fail(GEC_E_DEVICE, "chunk event");
+			continue;
+		}
+		rc = blake2_dev(c, nb * n, mir, nullptr, nullptr, S, S, d_sums, chain, 0, 0, 0, true);
+		if (!rc && hipMemcpyAsync(st.h_buf + b0 * n * 32, d_sums, nb * n * 32, hipMemcpyDeviceToHost, chain) != hipSuccess)
+			rc = fail(GEC_E_DEVICE, "hipMemcpyAsync (shard sums)");
+		if (!rc && hipEventRecord(st.ev_seg[2 + (ci & 1)], chain) != hipSuccess)
+			rc = fail(GEC_E_DEVICE, "hipEventRecord");
+	}
+	const hipError_t e1 = hipStreamSynchronize(up), e2 = hipStreamSynchronize(chain);
+	if (rc)
+		return rc;
+	HIP_TRY(e1);
+	HIP_TRY(e2);
+	std::memcpy(shard_sums, st.h_buf, nblocks * n * 32);
+	for (size_t b = 0; b < nblocks; ++b)
+		ok[b] = st.h_bad[b] ? 0 : 1;
+	return GEC_OK;
+}
+
+int HipBackend::reconstruct_batch(size_t nblocks, const uint8_t *const *shards, uint8_t *const *out, size_t S, int data_only,
+				  uint8_t *in_sums, uint8_t *out_sums)
+{
+	const size_t k = c->k, n = c->k + c->m;
+	ForegroundScope fg(c);
+	// bucket blocks by erasure pattern AND by which of the missing shards the caller wants back
+	// (out entry non-NULL; with data_only parity is never wanted): one decode plan per bucket, one
+	// launch per chunk, only the wanted rows computed.  key[j]: 1 present, 0 missing+wanted, 2 missing+unwanted
+	std::map<std::string, std::vector<size_t>> buckets;
+	for (size_t b = 0; b < nblocks; ++b) {
+		std::string key(n, 0);
+		size_t npresent = 0, nwanted = 0;
+		for (size_t j = 0; j < n; ++j) {
+			if (shards[b * n + j]) {
+				key[j] = 1;
+				++npresent;
+			} else if ((data_only && j >= k) || !out[b * n + j]) {
+				key[j] = 2;
+			} else {
+				++nwanted;
+			}
+		}
+		if (npresent < k)
+			return fail(GEC_E_TOO_FEW_PRESENT, "fewer than k shards present");
+		if (nwanted)
+			buckets[key].push_back(b);
+	}
+	ForkJoinPool &pool = copy_pool();
+	// one decode plan per bucket, cut down to the rows the caller wants
+	struct Work {
+		const std::vector<size_t> *ids;
+		std::shared_ptr<const Plan> plan;
+		bool all_pinned;
+	};
+	std::vector<Work> work;
+	bool every_pinned = true;
+	size_t tab_bytes = 0;
+	for (auto &kv : buckets) {
+		const std::vector<size_t> &ids = kv.second;
+		std::string pres(kv.first);
+		for (auto &ch : pres)
+			ch = ch == 1 ? 1 : 0;
+		std::shared_ptr<const Plan> full;
+		int rc = get_plan(c, reinterpret_cast<const uint8_t *>(pres.data()), false, full);
+		if (rc)
+			return rc;
+		auto sub = std::make_shared<Plan>();
+		sub->valid = full->valid;
+		for (size_t r = 0; r < full->missing.size(); ++r)
+			if (kv.first[full->missing[r]] == 0)
+				sub->missing.push_back(full->missing[r]);
+		sub->rows = gec::Matrix((int)sub->missing.size(), (int)k);
+		for (size_t r = 0, w = 0; r < full->missing.size(); ++r)
+			if (kv.first[full->missing[r]] == 0)
+				std::memcpy(&sub->rows.at((int)w++, 0), full->rows.row((int)r), k);
+		const size_t nmiss = sub->missing.size();
+		if (nmiss == 0)
+			continue;
+		bool all_pinned = true;
+		for (size_t i = 0; i < ids.size() && all_pinned; ++i) {
+			for (size_t t = 0; t < k && all_pinned; ++t)
+				all_pinned = aligned16(shards[ids[i] * n + sub->valid[t]]) && pinned().contains(shards[ids[i] * n + sub->valid[t]], S);
+			for (size_t r = 0; r < nmiss && all_pinned; ++r)
+				all_pinned = aligned16(out[ids[i] * n + sub->missing[r]]) && pinned().contains(out[ids[i] * n + sub->missing[r]], S);
+		}
+		every_pinned = every_pinned && all_pinned;
+		tab_bytes += ids.size() * (k * 12 + nmiss * 8) + 64;
+		work.push_back({&ids, sub, all_pinned});
+	}
+	if (!work.empty() && every_pinned && k <= (size_t)gec::PTR_KMAX && env().zero_copy) {
+		// every shard and every output is device-addressable: one gf_apply_ptrs launch per erasure pattern reads
+		// the k shards the decode uses and writes the rebuilt ones straight over the link
+		DeviceGuard dg(c->device);
+		if (!dg.ok)
+			return fail(GEC_E_DEVICE, "hipSetDevice failed");
+		StagingLease lease(c);
+		Staging &st = lease.st;
+		const bool sums = in_sums != nullptr;
+		// with checksums: chunks of every pattern run through the two mirror halves in turn (chunk q+2 waits for
+		// the checksums of chunk q), link kernels on the upload CUs, checksum kernels on the rest
+		size_t sum_bytes = 0, max_ids = 0, nchunks_total = 0;
+		const size_t zch_cap = chunk_blocks(n * S, nblocks, trip_chunk_bytes(c));
+		for (const Work &w : work) {
+			sum_bytes += w.ids->size() * (k + w.plan->missing.size()) * 32;
+			max_ids = std::max(max_ids, w.ids->size());
+			nchunks_total += (w.ids->size() + zch_cap - 1) / zch_cap;
+		}
+		const size_t zch = std::min(zch_cap, std::max<size_t>(max_ids, 1));
+		const size_t half = zch * n * S + zch * n * 32;
+		int rc = st.ensure(sums ? sum_bytes + 64 : 64, 0);
+		if (!rc)
+			rc = st.ensure_tab(tab_bytes / sizeof(gec::CopyEntry) + 4 * (work.size() + nchunks_total) + 4);
+		if (!rc && sums)
+			rc = st.ensure_big(2 * half);
+		if (!rc && sums)
+			rc = st.ensure_segments(num_cu);
+		if (rc)
+			return rc;
+		hipStream_t up = sums && st.stream_up ? st.stream_up : st.stream;
+		hipStream_t chain = sums && st.stream_chain ? st.stream_chain : st.stream2;
+		size_t q = 0, sum_off = 0;  // running chunk number, running offset into the pinned checksum area
+		std::vector<size_t> sum_base(work.size());
+		for (size_t wi = 0; wi < work.size() && !rc; ++wi) {
+			const Work &w = work[wi];
+			const std::vector<size_t> &ids = *w.ids;
+			const size_t nmiss = w.plan->missing.size(), per = k + nmiss;
+			sum_base[wi] = sum_off;
+			std::vector<const uint8_t *> in(std::min(zch, ids.size()) * k);
+			std::vector<uint32_t> valid(in.size(), (uint32_t)S);
+			std::vector<uint8_t *> outp(std::min(zch, ids.size()) * nmiss);
+			for (size_t i0 = 0; i0 < ids.size() && !rc; i0 += sums ? zch : ids.size(), ++q) {
+				const size_t nb = sums ? std::min(zch, ids.size() - i0) : ids.size();
+				if (!sums) {
+					in.resize(nb * k);
+					valid.assign(nb * k, (uint32_t)S);
+					outp.resize(nb * nmiss);
+				}
+				for (size_t i = 0; i < nb; ++i) {
+					for (size_t t = 0; t < k; ++t)
+						in[i * k + t] = pinned().dev(shards[ids[i0 + i] * n + w.plan->valid[t]]);
+					for (size_t r = 0; r < nmiss; ++r)
+						outp[i * nmiss + r] = pinned().dev(out[ids[i0 + i] * n + w.plan->missing[r]]);
+				}
+				uint8_t *mir = sums ? st.d_big + (q & 1) * half : nullptr;
+				if (sums && q >= 2 && hipStreamWaitEvent(up, st.ev_seg[2 + (q & 1)], 0) != hipSuccess)
+					rc = fail(GEC_E_DEVICE, "hipStreamWaitEvent");
+				if (!rc)
+					rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), outp.data(), (int)nmiss, S, w.plan->rows.v.data(), up, mir);
+				if (rc || !sums)
+					continue;
+				uint8_t *d_sums = mir + zch * n * S;
+				hipError_t e = hipEventRecord(st.ev_seg[q & 1], up);
+				if (e == hipSuccess)
+					e = hipStreamWaitEvent(chain, st.ev_seg[q & 1], 0);
+				if (e != hipSuccess) {
+					rc = fail(GEC_E_DEVICE, "chunk event");
+					continue;
+				}
+				rc = blake2_dev(c, nb * per, mir, nullptr, nullptr, S, S, d_sums, chain, 0, 0, 0, true);
+				if (!rc && hipMemcpyAsync(st.h_buf + sum_off, d_sums, nb * per * 32, hipMemcpyDeviceToHost, chain) != hipSuccess)
+					rc = fail(GEC_E_DEVICE, "hipMemcpyAsync (shard sums)");
+				if (!rc && hipEventRecord(st.ev_seg[2 + (q & 1)], chain) != hipSuccess)
+					rc = fail(GEC_E_DEVICE, "hipEventRecord");
+				sum_off += nb * per * 32;
+			}
+		}
+		const hipError_t e1 = hipStreamSynchronize(up), e2 = sums ? hipStreamSynchronize(chain) : hipSuccess;  // also on error: queued launches read the tables
+		if (rc)
+			return rc;
+		HIP_TRY(e1);
+		HIP_TRY(e2);
+		if (sums)
+			for (size_t wi = 0; wi < work.size(); ++wi) {
+				const Work &w = work[wi];
+				const size_t nmiss = w.plan->missing.size(), per = k + nmiss;
+				for (size_t i = 0; i < w.ids->size(); ++i) {
+					const uint8_t *src = st.h_buf + sum_base[wi] + i * per * 32;
+					const size_t b = (*w.ids)[i];
+					for (size_t t = 0; t < k; ++t)
+						std::memcpy(in_sums + 32 * (b * n + w.plan->valid[t]), src + 32 * t, 32);
+					for (size_t r = 0; r < nmiss; ++r)
+						std::memcpy(out_sums + 32 * (b * n + w.plan->missing[r]), src + 32 * (k + r), 32);
+				}
+			}
+		return GEC_OK;
+	}
+	if (in_sums) {
+		// buffers the device cannot address: the staged reconstruct, then the checksums of what was read and written in
+		// a second trip
+		int rc = reconstruct_batch(nblocks, shards, out, S, data_only, nullptr, nullptr);
+		if (rc)
+			return rc;
+		std::vector<const uint8_t *> msgs;
+		std::vector<size_t> lens, where;
+		std::vector<uint8_t *> dst;
+		for (const Work &w : work)
+			for (size_t b : *w.ids) {
+				for (size_t t = 0; t < k; ++t) {
+					msgs.push_back(shards[b * n + w.plan->valid[t]]);
+					dst.push_back(in_sums + 32 * (b * n + w.plan->valid[t]));
+				}
+				for (int j : w.plan->missing) {
+					msgs.push_back(out[b * n + j]);
+					dst.push_back(out_sums + 32 * (b * n + j));
+				}
+			}
+		lens.assign(msgs.size(), S);
+		std::vector<uint8_t> tmp(msgs.size() * 32);
+		rc = hash_batch(msgs.size(), msgs.data(), lens.data(), tmp.data(), true);
+		for (size_t i = 0; !rc && i < msgs.size(); ++i)
+			std::memcpy(dst[i], tmp.data() + 32 * i, 32);
+		return rc;
+	}
+	for (const Work &wk : work) {
+		const std::vector<size_t> &ids = *wk.ids;
+		std::shared_ptr<const Plan> plan = wk.plan;
+		const size_t nmiss = plan->missing.size();
+		const size_t stripe = (k + nmiss) * S;
+		const bool all_pinned = wk.all_pinned;
+		int rc = GEC_OK;
+		const size_t ch = chunk_blocks(stripe, ids.size(), all_pinned ? pinned_chunk_bytes(c) : kChunkBytes);
+		std::vector<size_t> in_off(k), out_off(nmiss);
+		for (size_t t = 0; t < k; ++t)
+			in_off[t] = t * S;
+		for (size_t r = 0; r < nmiss; ++r)
+			out_off[r] = (k + r) * S;
+		// chunks whose input shards (resp. output buffers) all lie in registered pinned memory go by
+		// DMA straight from / to the caller's memory; adjacent shards (slices of one block buffer)
+		// are merged into one copy
+		const size_t nchunks = (ids.size() + ch - 1) / ch;
+		std::vector<uint8_t> in_pinned(nchunks, 1), out_pinned(nchunks, 1);
+		PipeChain chain;
+		for (size_t i = 0; i < ids.size(); ++i) {
+			const size_t ci = i / ch;
+			for (size_t t = 0; t < k && in_pinned[ci]; ++t)
+				if (!(aligned16(shards[ids[i] * n + plan->valid[t]]) && pinned().contains(shards[ids[i] * n + plan->valid[t]], S)))
+					in_pinned[ci] = 0;
+			for (size_t r = 0; r < nmiss && out_pinned[ci]; ++r)
+				if (!(aligned16(out[ids[i] * n + plan->missing[r]]) && pinned().contains(out[ids[i] * n + plan->missing[r]], S)))
+					out_pinned[ci] = 0;
+		}
+		rc = run_pipeline(
+			c, nchunks, ch * stripe, 0,
+			[&](size_t ci, Staging &st) {
+				(void)st.ensure_tab(ch * (k + nmiss));
+				if (in_pinned[ci])
+					return;
+				const size_t i0 = ci * ch, nb = std::min(ch, ids.size() - i0);
+				pool.parallel_for(nb * k, [&](size_t q) {
+					const size_t i = q / k, t = q % k;
+					std::memcpy(st.h_buf + i * stripe + t * S, shards[ids[i0 + i] * n + plan->valid[t]], S);
+				});
+			},
+			[&](size_t ci, Staging &st) -> int {
+				const size_t i0 = ci * ch, nb = std::min(ch, ids.size() - i0);
+				if (in_pinned[ci]) {
+					std::vector<gec::CopyEntry> ents;
+					ents.reserve(nb * 3);
+					for (size_t i = 0; i < nb; ++i) {
+						const uint8_t *const *sh = shards + ids[i0 + i] * n;
+						for (size_t t = 0; t < k;) {  // adjacent shards (slices of one block buffer): one entry
+							size_t run = 1;
+							while (t + run < k && sh[plan->valid[t + run]] == sh[plan->valid[t]] + run * S)
+								++run;
+							ents.push_back({pinned().dev(sh[plan->valid[t]]), st.d_buf + i * stripe + t * S, run * S});
+							t += run;
+						}
+					}
+					int rct = chain.before(chain.last_in, st.stream);
+					if (!rct)
+						rct = launch_copy_table(st, ents, st.stream);
+					if (!rct)
+						rct = chain.after_in(st);
+					if (rct)
+						return rct;
+				} else {
+					HIP_TRY(hipMemcpy2DAsync(st.d_buf, stripe, st.h_buf, stripe, k * S, nb, hipMemcpyHostToDevice, st.stream));
+				}
+				int r2 = launch_apply(c, st.d_buf, stripe, st.d_buf, stripe, nullptr, 0, S, nb, in_off.data(),
+						      out_off.data(), (int)nmiss, plan->rows.v.data(), gec::MODE_STORE, st.stream);
+				if (r2)
+					return r2;
+				if (out_pinned[ci]) {
+					std::vector<gec::CopyEntry> ents;
+					ents.reserve(nb * nmiss);
+					for (size_t i = 0; i < nb; ++i) {
+						uint8_t *const *o = out + ids[i0 + i] * n;
+						for (size_t r = 0; r < nmiss; ++r)
+							ents.push_back({st.d_buf + i * stripe + (k + r) * S, pinned().dev(o[plan->missing[r]]), S});
+					}
+					int rct = chain.before(chain.last_out, st.stream);
+					if (!rct)
+						rct = launch_copy_table(st, ents, st.stream);
+					if (!rct)
+						rct = chain.after_out(st);
+					if (rct)
+						return rct;
+				} else {
+					HIP_TRY(hipMemcpy2DAsync(st.h_buf + k * S, stripe, st.d_buf + k * S, stripe, nmiss * S, nb, hipMemcpyDeviceToHost, st.stream));
+				}
+				return GEC_OK;
+			},
+			[&](size_t ci, Staging &st) {
+				if (out_pinned[ci])
+					return;
+				const size_t i0 = ci * ch, nb = std::min(ch, ids.size() - i0);
+				pool.parallel_for(nb * nmiss, [&](size_t q) {
+					const size_t i = q / nmiss, r = q % nmiss;
+					std::memcpy(out[ids[i0 + i] * n + plan->missing[r]], st.h_buf + i * stripe + (k + r) * S, S);
+				});
+			});
+		if (rc)
+			return rc;
+	}
+	return GEC_OK;
+}
+
+}  // namespace gecimpl

@@ -1,0 +1,503 @@
+// ec_hip_launch.hip -- the one translation unit of libgarage_ec with device code: launch geometry and every kernel
+// launch.  Everything else in the HIP backend reaches the kernels through the launch_* / blake2_dev functions
+// declared in ec_hip.hpp.
+#include "ec_hip.hpp"
+
+#include <algorithm>
+
+#include "kernels.hpp"
+#include "blake2b.hpp"
+
+namespace gecimpl {
+
+namespace {
+
+std::atomic<int> g_variant{0};
+
+// Launch geometry of the default kernel, tuned on MI355X with tools/kbench
+// (profiles/r01_kbench_*.txt): one tile per workgroup, 1 column per thread.
+//   4-byte table entries (rows <= 4): 256 threads, up to 10 shards loaded per batch
+//     (RS(10,4): all 10 loads go out before the table expansion; 72-74% of 8 TB/s)
+//   8-byte table entries (rows <= 8): 512 threads, up to 6 per batch (register budget)
+constexpr int kCPT = 1;
+constexpr int kThreadsMW1 = 256;
+constexpr int kThreadsMW2 = 512;
+constexpr int kThreadsMW4 = 512;  // 16-byte entries: 64 accumulator VGPRs per lane, 4 shards per batch (512 beats 256 by 2-5 %)
+
+// Test hook: GEC_MAX_COLS_PER_LAUNCH caps the columns one launch may cover, so the
+// multi-launch split (normally only beyond 2^32 columns = 64 GiB per shard slot) can be
+// exercised on small inputs.
+uint64_t launch_cols_limit() { return env().max_cols_per_launch; }
+
+// Loads per batch (tools/kbench sweeps, profiles/r01_kbench_kc_sweep.txt): k itself when small;
+// with 4-byte entries one batch of 10 / 12 / 16 for k <= 16, beyond that batches of 10 whenever
+// the duplicate (index-clamped, cache-hit) loads of the last batch stay within a quarter of k --
+// fewer, larger batches win even with some waste; otherwise the candidate that wastes the fewest
+// (ties: the larger).
+int choose_kc(int k, int mw)
+{
+	if (k <= 6)
+		return k;
+	if (mw == 2 && k <= 10)  // one batch, in the 256-thread geometry (threads_for): +3-4 % on RS(8,8) / RS(10,8)
+		return 10;
+	if (mw == 1) {
+		// up to 16 shards: ONE batch (all loads in flight before the table expansion) beats two
+		// by 2-3 % even at 150 VGPRs / 3 waves per SIMD; 20 in one batch is too many (-10 %)
+		if (k <= 10)
+			return 10;
+		if (k <= 12)
+			return 12;
+		if (k <= 16)
+			return 16;
+		const int w10 = (k + 9) / 10 * 10 - k;
+		if (w10 * 4 <= k)
+			return 10;
+	}
+	int best = 0, waste = 1 << 30;
+	for (int kc : {6, 5, 4}) {
+		int w = (k + kc - 1) / kc * kc - k;
+		if (w < waste) {
+			waste = w;
+			best = kc;
+		}
+	}
+	return best;
+}
+
+// Workgroup size that goes with (table width, loads per batch).
+int threads_for(int mw, int kc)
+{
+	if (mw == 1)
+		return kThreadsMW1;
+	if (mw == 2)
+		return kc == 10 ? 256 : kThreadsMW2;  // 10 loads in flight per lane need the 256-thread register budget
+	return kThreadsMW4;
+}
+
+// Everything the host decides about one launch of the default kernel, in one place (also what
+// gec_launch_geometry reports, so the invariants -- LDS within 64 KiB, coefficients within the
+// argument block -- are testable without a GPU).
+struct Geometry {
+	int rows;     // output rows this launch takes (<= rows_left)
+	int mw;       // dwords per table entry: 1, 2 or 4
+	int kc;       // loads per batch
+	int threads;  // workgroup size
+	size_t lds;   // dynamic LDS bytes: tables + log/antilog image + coefficient rows
+};
+
+Geometry pick_geometry(int k, int rows_left, bool rows16_allowed)
+{
+	Geometry g;
+	g.rows = std::min(gec::RMAX, rows_left);
+	// More than 8 rows left: 16-byte table entries take up to 16 of them in ONE pass over the
+	// data (instead of one pass per 8 rows), as long as k*16 coefficient bytes fit the argument
+	// block and k*512 bytes of tables fit 64 KiB of LDS.
+	if (rows_left > gec::RMAX && k <= gec::K16MAX && rows16_allowed)
+		g.rows = std::min(gec::RMAX16, rows_left);
+	// 8-byte table entries need k*256 bytes of LDS; beyond the 64 KiB a workgroup gets without
+	// opting in (k > ~245) fall back to groups of 4 rows (4-byte entries)
+	if (g.rows > 4 && g.rows <= gec::RMAX && (size_t)k * 256 + 768 + (size_t)k * gec::RMAX > 65536)
+		g.rows = 4;
+	g.mw = g.rows <= 4 ? 1 : g.rows <= gec::RMAX ? 2 : 4;
+	g.kc = g.mw == 4 ? std::min(k, 4) : choose_kc(k, g.mw);  // 16-byte entries: 64 accumulator VGPRs, 4 shards in flight
+	g.threads = threads_for(g.mw, g.kc);
+	const int cr = g.mw == 4 ? gec::RMAX16 : gec::RMAX;
+	g.lds = (size_t)k * 32 * 4 * g.mw + 768 + (size_t)k * cr;
+	return g;
+}
+
+template <int MW, int MODE, int TPB>
+void launch_nibble(const gec::ApplyArgs &a, const gec::LogExp *le, int kc, unsigned grid, size_t lds, hipStream_t s)
+{
+	if constexpr (MW == 2) {
+		if (kc == 10) {
+			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 10, kCPT, true, 256>), dim3(grid), dim3(256), lds, s, a, le);
+			return;
+		}
+	}
+	if constexpr (MW == 1) {
+		if (kc == 10) {
+			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 10, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, a, le);
+			return;
+		}
+		if (kc == 12) {
+			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 12, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, a, le);
+			return;
+		}
+		if (kc == 16) {
+			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 16, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, a, le);
+			return;
+		}
+	}
+#define GEC_CASE(KC)                                                                                              \
+	case KC:                                                                                                  \
+		hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, KC, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, \
+				   a, le);                                                                        \
+		break;
+	if constexpr (MW == 4) {
+		switch (kc) {
+			GEC_CASE(1)
+			GEC_CASE(2)
+			GEC_CASE(3)
+			GEC_CASE(4)
+		}
+	} else {
+		switch (kc) {
+			GEC_CASE(1)
+			GEC_CASE(2)
+			GEC_CASE(3)
+			GEC_CASE(4)
+			GEC_CASE(5)
+			GEC_CASE(6)
+		}
+	}
+#undef GEC_CASE
+}
+
+}  // namespace
+
+// out[r] = XOR_t coef[r][t] * in[t] for r < nout: shard t of block b is read at
+// in + b*in_stride + in_base_off[t], row r written at out + b*out_stride +
+// out_base_off[r]; only bytes [byte_off, byte_off+byte_len) of every shard are
+// touched.  Rows go out in groups of RMAX per launch.
+int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_t *out, size_t out_stride,
+		 uint32_t *bad, size_t byte_off, size_t byte_len, size_t nblocks, const size_t *in_base_off,
+		 const size_t *out_base_off, int nout, const uint8_t *coef /* nout x k */, int mode,
+		 hipStream_t stream)
+{
+	const int k = c->k;
+	const HipBackend &hb = hip_of(c);
+	if (nblocks == 0 || nout == 0 || byte_len == 0)
+		return GEC_OK;
+	if (nblocks > 0xffffffffull || (byte_len / 16) > 0x7fffffffull)
+		return fail(GEC_E_INVALID_ARG, "batch too large for one call");
+	gec::ApplyArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.in = in;
+	a.out = out;
+	a.bad = bad;
+	a.in_stride = in_stride;
+	a.out_stride = out_stride;
+	a.col0 = (uint32_t)(byte_off / 16);
+	a.cols = (uint32_t)(byte_len / 16);
+	a.nblocks = (uint32_t)nblocks;
+	a.k = (uint32_t)k;
+	for (int t = 0; t < k; ++t) {
+		if (in_base_off[t] / 16 > 0xffffffffull)
+			return fail(GEC_E_INVALID_ARG, "stripe too large");
+		a.in_off[t] = (uint32_t)(in_base_off[t] / 16);
+	}
+	const int variant = g_variant.load(std::memory_order_relaxed);
+	int rows = 0;
+	for (int r0 = 0; r0 < nout; r0 += rows) {
+		const Geometry geo = pick_geometry(k, nout - r0, variant == 0 && env().rows16 != 0);
+		rows = variant == 1 ? std::min(gec::RMAX, nout - r0) : geo.rows;  // the baseline kernel takes up to 8 rows
+		a.rows = (uint32_t)rows;
+		const int mw = variant == 1 ? 2 : geo.mw;
+		const int cr = mw == 4 ? gec::RMAX16 : gec::RMAX;  // coefficient bytes per input shard
+		uint8_t *flat = &a.coef[0][0];
+		for (int r = 0; r < cr; ++r) {
+			if (r < rows) {
+				if (out_base_off[r0 + r] / 16 > 0xffffffffull)  // same limit as the input offsets: 64 GiB per stripe
+					return fail(GEC_E_INVALID_ARG, "stripe too large");
+				a.out_off[r] = (uint32_t)(out_base_off[r0 + r] / 16);
+			}
+			for (int t = 0; t < k; ++t)
+				flat[(size_t)t * cr + r] = r < rows ? coef[(size_t)(r0 + r) * k + t] : 0;
+		}
+		if (variant == 1) {
+			// measured baseline: persistent grid-stride log/antilog kernel, one tile = 256
+			// columns of one block
+			a.tiles_per_block = (a.cols + gec::BLOCK - 1) / gec::BLOCK;
+			const uint64_t ntiles = (uint64_t)a.nblocks * a.tiles_per_block;
+			if (ntiles > 0xffffffffull)
+				return fail(GEC_E_INVALID_ARG, "batch too large for the baseline kernel");
+			const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)hb.num_cu * 8);
+			if (mode == gec::MODE_STORE)
+				hipLaunchKernelGGL((gec::gf_apply_logexp<gec::MODE_STORE>), dim3(grid), dim3(gec::BLOCK), 0, stream, a, hb.d_logexp);
+			else
+				hipLaunchKernelGGL((gec::gf_apply_logexp<gec::MODE_COMPARE>), dim3(grid), dim3(gec::BLOCK), 0, stream, a, hb.d_logexp);
+			HIP_TRY(hipGetLastError());
+			continue;
+		}
+		// The (block, column) space is flattened: a launch covers a range of whole blocks
+		// whose columns fit 32 bits and whose tiles fit HIP's grid limit (grid*block < 2^32).
+		const int threads = geo.threads;
+		const uint64_t tile_cols = (uint64_t)threads * kCPT;
+		uint64_t max_cols = std::min<uint64_t>(0xfffff000ull, (0xffffffffull / threads - 8) * tile_cols);
+		if (launch_cols_limit())
+			max_cols = std::min<uint64_t>(max_cols, launch_cols_limit());
+		if (a.cols > max_cols)
+			return fail(GEC_E_INVALID_ARG, "shard too large for one launch");
+		const uint64_t blocks_per_launch = std::max<uint64_t>(1, max_cols / a.cols);
+		const size_t lds = geo.lds;
+		gec::ApplyArgs la = a;
+		for (uint64_t b0 = 0; b0 < nblocks; b0 += blocks_per_launch) {
+			const uint64_t nb = std::min<uint64_t>(blocks_per_launch, nblocks - b0);
+			la.in = in + b0 * in_stride;
+			la.out = out + b0 * out_stride;
+			la.bad = bad ? bad + b0 : nullptr;
+			la.nblocks = (uint32_t)nb;
+			la.total_cols = (uint32_t)(nb * a.cols);
+			// multiple of 8: the kernel hands each XCD a contiguous range of tiles
+			const unsigned grid = (unsigned)(((la.total_cols + tile_cols - 1) / tile_cols + 7) / 8 * 8);
+			if (mw == 1 && mode == gec::MODE_STORE)
+				launch_nibble<1, gec::MODE_STORE, kThreadsMW1>(la, hb.d_logexp, geo.kc, grid, lds, stream);
+			else if (mw == 1 && rows == 4)  // all four row slots real: stored rows prefetched behind the data loads
+				launch_nibble<1, gec::MODE_COMPARE_PF, kThreadsMW1>(la, hb.d_logexp, geo.kc, grid, lds, stream);
+			else if (mw == 1)
+				launch_nibble<1, gec::MODE_COMPARE, kThreadsMW1>(la, hb.d_logexp, geo.kc, grid, lds, stream);
+			else if (mw == 2 && mode == gec::MODE_STORE)
+				launch_nibble<2, gec::MODE_STORE, kThreadsMW2>(la, hb.d_logexp, geo.kc, grid, lds, stream);
+			else if (mw == 2)
+				launch_nibble<2, gec::MODE_COMPARE, kThreadsMW2>(la, hb.d_logexp, geo.kc, grid, lds, stream);
+			else if (mode == gec::MODE_STORE)
+				launch_nibble<4, gec::MODE_STORE, kThreadsMW4>(la, hb.d_logexp, geo.kc, grid, lds, stream);
+			else
+				launch_nibble<4, gec::MODE_COMPARE, kThreadsMW4>(la, hb.d_logexp, geo.kc, grid, lds, stream);
+			HIP_TRY(hipGetLastError());
+		}
+	}
+	return GEC_OK;
+}
+
+// blake2sum of n messages.  group != 0: message i lives at d_base + (i / group)*group_stride + (i % group)*stride and
+// its checksum goes to d_out + 32*((i / group)*out_group + i % group) -- e.g. only the data (or only the parity)
+// shards of every stripe.  tree: the shard checksum (BLAKE2b tree mode, blake2b.hpp) instead of the plain hash;
+// max_len = the longest message (sizes the leaf grid).
+int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64_t *d_off, const uint64_t *d_len, size_t stride,
+	       size_t len, uint8_t *d_out, hipStream_t stream, uint32_t group, size_t group_stride, uint32_t out_group, bool tree,
+	       size_t max_len, uint64_t *d_state, uint64_t seg_begin_blk, uint64_t seg_end_blk)
+{
+	if (n == 0)
+		return GEC_OK;
+	if (n > 0xffffffffull)
+		return fail(GEC_E_INVALID_ARG, "too many messages for one call");
+	gec::Blake2Args a;
+	a.state = d_state;
+	a.seg_begin_blk = seg_begin_blk;
+	a.seg_end_blk = seg_end_blk;
+	a.base = d_base;
+	a.off = d_off;
+	a.len = d_len;
+	a.stride = stride;
+	a.uniform_len = len;
+	a.out = d_out;
+	a.n = (uint32_t)n;
+	a.group = group;
+	a.group_stride = group_stride;
+	a.out_group = out_group;
+	if (tree) {
+		const size_t longest = d_len ? max_len : len;
+		const uint32_t nleaf = (uint32_t)std::max<size_t>(1, (longest + gec::SHARDSUM_LEAF - 1) / gec::SHARDSUM_LEAF);
+		const uint64_t lanes = (uint64_t)n * nleaf;
+		if ((lanes + 63) / 64 > 0x7fffffffull)
+			return fail(GEC_E_INVALID_ARG, "too many leaves for one call");
+		uint8_t *scratch = nullptr;
+		int rc = leaf_scratch(c, stream, lanes * 64, &scratch);
+		if (rc)
+			return rc;
+		const int addmode = env().b2_add;  // A/B, see blake2b.hpp
+		const dim3 lgrid((unsigned)((lanes + 63) / 64));
+		if (addmode == 0)
+			hipLaunchKernelGGL(gec::shardsum_leaves<0>, lgrid, dim3(64), 0, stream, a, nleaf, scratch);
+		else
+			hipLaunchKernelGGL(gec::shardsum_leaves<1>, lgrid, dim3(64), 0, stream, a, nleaf, scratch);
+		HIP_TRY(hipGetLastError());
+		hipLaunchKernelGGL(gec::shardsum_roots, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a, nleaf, scratch);
+		HIP_TRY(hipGetLastError());
+		return GEC_OK;
+	}
+	// one lane per message is the faster kernel once there are enough messages to put a
+	// wave on every SIMD (1024 SIMDs x 64 lanes); below that the quad kernel (4 lanes per
+	// message, ~4x shorter chain) wins.  GEC_BLAKE2_KERNEL=lane|quad forces one (A/B).
+	const int forced = env().blake2_kernel;
+	const bool quad = d_state ? true : forced ? forced == 2 : n < 40000;  // segments: the quad kernel only
+	if (quad)
+		hipLaunchKernelGGL(gec::blake2b_batch_quad, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, stream, a);
+	else
+		{
+		const int addmode = env().b2_add;
+		if (addmode == 0)
+			hipLaunchKernelGGL(gec::blake2b_batch<0>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a);
+		else
+			hipLaunchKernelGGL(gec::blake2b_batch<1>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a);
+	}
+	HIP_TRY(hipGetLastError());
+	return GEC_OK;
+}
+
+// out[b][r] = XOR_t coef[r][t] * in[b][t] over shards that stay in the caller's pinned memory (gf_apply_ptrs):
+// in[b*k + t] / valid[b*k + t] name the k input shards of block b and how many of their S bytes exist,
+// out[b*nout + r] the output rows.  The tables are written into the staging slot's pinned table area, which the
+// kernel reads directly.  k <= PTR_KMAX.
+int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uint8_t *const *in, const uint32_t *valid,
+		      uint8_t *const *out, int nout, size_t S, const uint8_t *coef /* nout x k */, hipStream_t stream, uint8_t *d_mirror,
+		      uint32_t *bad)
+{
+	const size_t k = c->k;
+	const HipBackend &hb = hip_of(c);
+	if (nblocks == 0 || nout == 0)
+		return GEC_OK;
+	if (k > (size_t)gec::PTR_KMAX || S / 16 > 0xffffffffull)
+		return fail(GEC_E_INVALID_ARG, "shape not supported by the pointer-table kernel");
+	const size_t in_bytes = nblocks * k * 8, valid_bytes = (nblocks * k * 4 + 7) / 8 * 8, out_bytes = nblocks * (size_t)nout * 8;
+	const size_t need = (st.tab_used * sizeof(gec::CopyEntry) + in_bytes + valid_bytes + out_bytes) / sizeof(gec::CopyEntry) + 2;
+	if (need > st.tab_cap)
+		return fail(GEC_E_INVALID_ARG, "pointer table overflow");
+	uint8_t *base = reinterpret_cast<uint8_t *>(st.h_tab + st.tab_used);
+	const uint8_t **t_in = reinterpret_cast<const uint8_t **>(base);
+	uint32_t *t_valid = reinterpret_cast<uint32_t *>(base + in_bytes);
+	uint8_t **t_out = reinterpret_cast<uint8_t **>(base + in_bytes + valid_bytes);
+	st.tab_used = need;
+	std::memcpy(t_in, in, in_bytes);
+	std::memcpy(t_valid, valid, nblocks * k * 4);
+	gec::PtrApplyArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.cols = (uint32_t)(S / 16);
+	a.k = (uint32_t)k;
+	const unsigned gx = (a.cols + 255) / 256;
+	int rows = 0;
+	size_t out_done = 0;  // entries of t_out consumed by earlier row groups
+	for (int r0 = 0; r0 < nout; r0 += rows) {
+		rows = std::min(gec::RMAX, nout - r0);
+		a.rows = (uint32_t)rows;
+		for (int r = 0; r < gec::RMAX; ++r)
+			for (size_t t = 0; t < k; ++t)
+				a.coef[t][r] = r < rows ? coef[(size_t)(r0 + r) * k + t] : 0;
+		uint8_t **grp = t_out + out_done;  // [nblocks][rows] for this group
+		for (size_t b = 0; b < nblocks; ++b)
+			for (int r = 0; r < rows; ++r)
+				grp[b * rows + r] = out[b * nout + r0 + r];
+		out_done += nblocks * rows;
+		const int mw = rows <= 4 ? 1 : 2;
+		const size_t lds = k * 32 * 4 * mw + 768 + k * gec::RMAX;
+		a.mirror_stride = (k + (size_t)nout) * S;
+		a.mirror_row0 = (k + (size_t)r0) * S;
+		a.mirror_inputs = r0 == 0;
+		for (size_t b0 = 0; b0 < nblocks; b0 += 65535) {
+			const unsigned gy = (unsigned)std::min<size_t>(65535, nblocks - b0);
+			a.in = t_in + b0 * k;
+			a.in_valid = t_valid + b0 * k;
+			a.out = grp + b0 * rows;
+			a.mirror = d_mirror ? d_mirror + b0 * a.mirror_stride : nullptr;
+			a.bad = bad ? bad + b0 : nullptr;
+			if (bad && d_mirror && mw == 1)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, true, true>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
+			else if (bad && d_mirror)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5, true, true>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
+			else if (bad && mw == 1)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, false, true>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
+			else if (bad)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5, false, true>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
+			else if (mw == 1 && d_mirror)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, true>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
+			else if (mw == 1)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, false>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
+			else if (d_mirror)
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5, true>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
+			else
+				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5, false>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
+			HIP_TRY(hipGetLastError());
+		}
+	}
+	return GEC_OK;
+}
+
+int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipStream_t stream)
+{
+	if (ents.empty())
+		return GEC_OK;
+	if (st.tab_used + ents.size() > st.tab_cap)
+		return fail(GEC_E_INVALID_ARG, "copy table overflow");
+	gec::CopyEntry *tab = st.h_tab + st.tab_used;
+	uint64_t maxb = 0;
+	for (size_t i = 0; i < ents.size(); ++i) {
+		tab[i] = ents[i];
+		maxb = std::max<uint64_t>(maxb, ents[i].bytes);
+	}
+	st.tab_used += ents.size();
+	const unsigned gx = (unsigned)((maxb >> 4) / 1024 + 1);
+	// grid.y <= 65535: split long tables
+	for (size_t e0 = 0; e0 < ents.size(); e0 += 65535) {
+		const unsigned gy = (unsigned)std::min<size_t>(65535, ents.size() - e0);
+		hipLaunchKernelGGL(gec::copy_table, dim3(gx, gy), dim3(256), 0, stream, tab + e0);
+		HIP_TRY(hipGetLastError());
+	}
+	return GEC_OK;
+}
+
+int launch_clear_flags(uint32_t *d_bad, size_t n, hipStream_t stream)
+{
+	hipLaunchKernelGGL(gec::clear_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_bad, (uint32_t)n);
+	HIP_TRY(hipGetLastError());
+	return GEC_OK;
+}
+
+namespace {
+unsigned copy_grid(size_t items) { return (unsigned)std::max<size_t>(1, std::min<size_t>((items + 255) / 256, 1u << 16)); }
+}
+
+int launch_range_pack(const gec::RangeArgs &a, size_t items, hipStream_t stream)
+{
+	hipLaunchKernelGGL(gec::range_pack, dim3(copy_grid(items)), dim3(256), 0, stream, a);
+	HIP_TRY(hipGetLastError());
+	return GEC_OK;
+}
+
+int launch_range_unpack(const gec::RangeArgs &a, size_t items, hipStream_t stream)
+{
+	hipLaunchKernelGGL(gec::range_unpack, dim3(copy_grid(items)), dim3(256), 0, stream, a);
+	HIP_TRY(hipGetLastError());
+	return GEC_OK;
+}
+
+int launch_a2a_pack(const gec::A2aArgs &a, size_t items, hipStream_t stream)
+{
+	hipLaunchKernelGGL(gec::a2a_pack, dim3(copy_grid(items)), dim3(256), 0, stream, a);
+	HIP_TRY(hipGetLastError());
+	return GEC_OK;
+}
+
+int launch_rebuilt_unpack(const gec::RebuiltArgs &a, size_t items, hipStream_t stream)
+{
+	hipLaunchKernelGGL(gec::rebuilt_unpack, dim3(copy_grid(items)), dim3(256), 0, stream, a);
+	HIP_TRY(hipGetLastError());
+	return GEC_OK;
+}
+
+}  // namespace gecimpl
+
+using namespace gecimpl;
+
+extern "C" {
+
+int gec_launch_geometry(int k, int rows_left, int *rows, int *entry_bytes, int *loads_per_batch, int *threads, size_t *lds_bytes)
+{
+	if (k < 1 || k > GEC_MAX_SHARDS - 1 || rows_left < 1)
+		return fail(GEC_E_INVALID_ARG, "need 1 <= k <= 255 and rows_left >= 1");
+	const Geometry g = pick_geometry(k, rows_left, env().rows16 != 0);
+	if (rows)
+		*rows = g.rows;
+	if (entry_bytes)
+		*entry_bytes = 4 * g.mw;
+	if (loads_per_batch)
+		*loads_per_batch = g.kc;
+	if (threads)
+		*threads = g.threads;
+	if (lds_bytes)
+		*lds_bytes = g.lds;
+	return GEC_OK;
+}
+
+int gec_set_kernel_variant(int variant)
+{
+	if (variant < 0 || variant > 1)
+		return fail(GEC_E_INVALID_ARG, "unknown kernel variant");
+	g_variant.store(variant);
+	return GEC_OK;
+}
+
+int gec_get_kernel_variant(void) { return g_variant.load(); }
+
+}  // extern "C"

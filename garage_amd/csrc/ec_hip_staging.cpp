@@ -1,0 +1,387 @@
+// ec_hip_staging.cpp -- the HIP backend's host-side resources: staging slots (streams, events, pinned + device
+// buffers), the registry of pinned caller memory (gec_host_*), the quality-of-service gate between foreground and
+// background codecs.  Host code only.
+#include "ec_hip.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+
+namespace gecimpl {
+
+// ------------------------------------------------------------------ pinned caller memory
+void PinnedRanges::add(const void *p, size_t n, bool owned, intptr_t dev_delta, bool plain)
+{
+	std::lock_guard<std::mutex> g(mu_);
+	ranges_[reinterpret_cast<uintptr_t>(p)] = {n, owned, plain, dev_delta};
+}
+
+bool PinnedRanges::remove(const void *p, bool &owned, bool &plain)
+{
+	std::lock_guard<std::mutex> g(mu_);
+	auto it = ranges_.find(reinterpret_cast<uintptr_t>(p));
+	if (it == ranges_.end())
+		return false;
+	owned = it->second.owned;
+	plain = it->second.plain;
+	ranges_.erase(it);
+	return true;
+}
+
+bool PinnedRanges::contains(const void *p, size_t n, intptr_t *dev_delta) const
+{
+	if (!p)
+		return false;
+	const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+	std::lock_guard<std::mutex> g(mu_);
+	if (ranges_.empty())
+		return false;
+	auto it = ranges_.upper_bound(a);
+	if (it == ranges_.begin())
+		return false;
+	--it;
+	if (it->second.plain || !(a >= it->first && a + n <= it->first + it->second.len))
+		return false;
+	if (dev_delta)
+		*dev_delta = it->second.dev_delta;
+	return true;
+}
+
+PinnedRanges &pinned()
+{
+	static PinnedRanges r;
+	return r;
+}
+
+// ------------------------------------------------------------------ staging slots
+// Every stream of a slot is created here, so that the codec's class decides priority and CU mask in one place: a
+// background codec's streams are confined to qos.compute_cus CUs (the LAST ones of the chip -- the link kernels'
+// GEC_UPLOAD_CUS are the first) or, where the runtime has no CU masks, at least run at the lowest priority.
+int Staging::make_stream(hipStream_t *s)
+{
+	if (qos.background && qos.compute_cus > 0 && qos.num_cu > qos.compute_cus) {
+		const int words = (qos.num_cu + 31) / 32;
+		std::vector<uint32_t> mask(words, 0);
+		for (int i = qos.num_cu - qos.compute_cus; i < qos.num_cu; ++i)
+			mask[i / 32] |= 1u << (i % 32);
+		if (hipExtStreamCreateWithCUMask(s, (uint32_t)words, mask.data()) == hipSuccess)
+			return GEC_OK;
+		(void)hipGetLastError();  // no CU masks in this runtime / partition mode: priority alone
+		*s = nullptr;
+	}
+	if (qos.background) {
+		if (hipStreamCreateWithPriority(s, hipStreamNonBlocking, qos.stream_priority) == hipSuccess)
+			return GEC_OK;
+		(void)hipGetLastError();
+	}
+	HIP_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+	return GEC_OK;
+}
+
+int Staging::ensure_groups(int ngroups)
+{
+	for (int i = 0; i < std::min(ngroups, (int)kMaxGroups); ++i) {
+		if (!stream_grp[i])
+			if (int rc = make_stream(&stream_grp[i]))
+				return rc;
+		if (!ev_grp[i])
+			HIP_TRY(hipEventCreateWithFlags(&ev_grp[i], hipEventDisableTiming));
+	}
+	return GEC_OK;
+}
+
+int Staging::ensure_segments(int num_cu)
+{
+	if (stream3)
+		return GEC_OK;
+	for (int i = 0; i < kMaxSeg; ++i)
+		HIP_TRY(hipEventCreateWithFlags(&ev_seg[i], hipEventDisableTiming));
+	const int up_cus = env().upload_cus;  // 0 = no CU masks (A/B)
+	if (up_cus > 0 && up_cus < num_cu) {
+		const int words = (num_cu + 31) / 32;
+		std::vector<uint32_t> up(words, 0), rest(words, 0);
+		// the checksum side of a background codec keeps to its own CUs, like every other stream of it (make_stream)
+		const int rest_lo = qos.background && qos.compute_cus > 0 ? std::max(up_cus, num_cu - qos.compute_cus) : up_cus;
+		for (int i = 0; i < num_cu; ++i) {
+			if (i < up_cus)
+				up[i / 32] |= 1u << (i % 32);
+			else if (i >= rest_lo)
+				rest[i / 32] |= 1u << (i % 32);
+		}
+		// (a runtime or partition mode without CU masks is not an error: the paths then share all CUs, slower)
+		if (hipExtStreamCreateWithCUMask(&stream_up, (uint32_t)words, up.data()) != hipSuccess)
+			stream_up = nullptr;
+		if (!stream_up || hipExtStreamCreateWithCUMask(&stream_chain, (uint32_t)words, rest.data()) != hipSuccess) {
+			if (stream_up)
+				(void)hipStreamDestroy(stream_up);
+			stream_up = stream_chain = nullptr;
+			(void)hipGetLastError();
+		}
+	}
+	return make_stream(&stream3);
+}
+
+int Staging::ensure_big(size_t bytes)
+{
+	if (bytes <= big_cap)
+		return GEC_OK;
+	if (d_big)
+		(void)hipFree(d_big);
+	d_big = nullptr;
+	big_cap = 0;
+	HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_big), bytes));
+	big_cap = bytes;
+	return GEC_OK;
+}
+
+int Staging::ensure_tab(size_t entries)
+{
+	tab_used = 0;
+	if (entries <= tab_cap)
+		return GEC_OK;
+	if (h_tab)
+		(void)hipHostFree(h_tab);
+	h_tab = nullptr;
+	tab_cap = 0;
+	HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_tab), entries * sizeof(gec::CopyEntry), hipHostMallocDefault));
+	tab_cap = entries;
+	return GEC_OK;
+}
+
+int Staging::ensure(size_t bytes, size_t nbad)
+{
+	if (!stream)
+		if (int rc = make_stream(&stream))
+			return rc;
+	if (!stream2) {
+		if (int rc = make_stream(&stream2))
+			return rc;
+		HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+	}
+	if (bytes > cap) {
+		if (h_buf)
+			(void)hipHostFree(h_buf);
+		if (d_buf)
+			(void)hipFree(d_buf);
+		h_buf = d_buf = nullptr;
+		cap = 0;
+		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_buf), bytes, hipHostMallocDefault));
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_buf), bytes));
+		cap = bytes;
+	}
+	if (nbad > bad_cap) {
+		if (h_bad)
+			(void)hipHostFree(h_bad);
+		if (d_bad)
+			(void)hipFree(d_bad);
+		h_bad = d_bad = nullptr;
+		bad_cap = 0;
+		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_bad), nbad * sizeof(uint32_t), hipHostMallocDefault));
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_bad), nbad * sizeof(uint32_t)));
+		bad_cap = nbad;
+	}
+	return GEC_OK;
+}
+void Staging::release()
+{
+	if (h_buf)
+		(void)hipHostFree(h_buf);
+	if (d_buf)
+		(void)hipFree(d_buf);
+	if (h_bad)
+		(void)hipHostFree(h_bad);
+	if (d_bad)
+		(void)hipFree(d_bad);
+	if (h_tab)
+		(void)hipHostFree(h_tab);
+	if (d_big)
+		(void)hipFree(d_big);
+	if (stream)
+		(void)hipStreamDestroy(stream);
+	if (stream2)
+		(void)hipStreamDestroy(stream2);
+	if (ev_fork)
+		(void)hipEventDestroy(ev_fork);
+	if (ev_join)
+		(void)hipEventDestroy(ev_join);
+	if (ev_in)
+		(void)hipEventDestroy(ev_in);
+	if (ev_out)
+		(void)hipEventDestroy(ev_out);
+	for (hipEvent_t e : ev_seg)
+		if (e)
+			(void)hipEventDestroy(e);
+	if (stream3)
+		(void)hipStreamDestroy(stream3);
+	if (stream_up)
+		(void)hipStreamDestroy(stream_up);
+	if (stream_chain)
+		(void)hipStreamDestroy(stream_chain);
+	for (hipStream_t s : stream_grp)
+		if (s)
+			(void)hipStreamDestroy(s);
+	for (hipEvent_t e : ev_grp)
+		if (e)
+			(void)hipEventDestroy(e);
+	const QosPolicy keep = qos;
+	*this = Staging();
+	qos = keep;
+}
+
+
+StagingLease::StagingLease(const gec_codec *cc) : c(cc)
+{
+	HipBackend &hb = hip_of(c);
+	{
+		std::lock_guard<std::mutex> g(hb.pool_mu);
+		if (!hb.pool.empty()) {
+			st = hb.pool.back();
+			hb.pool.pop_back();
+		}
+	}
+	st.qos = hb.qos;
+}
+
+StagingLease::~StagingLease()
+{
+	HipBackend &hb = hip_of(c);
+	std::lock_guard<std::mutex> g(hb.pool_mu);
+	hb.pool.push_back(st);
+}
+
+// ------------------------------------------------------------------ foreground / background
+QosGate &QosGate::of(int device)
+{
+	static QosGate gates[64];
+	return gates[(unsigned)device % 64];
+}
+
+void QosGate::leave()
+{
+	if (fg_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+		std::lock_guard<std::mutex> g(mu_);
+		cv_.notify_all();
+	}
+}
+
+uint64_t QosGate::yield_to_foreground(unsigned max_wait_us)
+{
+	if (max_wait_us == 0 || fg_.load(std::memory_order_acquire) == 0)
+		return 0;
+	const auto t0 = std::chrono::steady_clock::now();
+	std::unique_lock<std::mutex> lk(mu_);
+	yields_.fetch_add(1);
+	cv_.wait_for(lk, std::chrono::microseconds(max_wait_us), [&] { return fg_.load(std::memory_order_acquire) == 0; });
+	return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+}
+
+ForegroundScope::ForegroundScope(const gec_codec *c)
+{
+	if (c->qos_class == GEC_CLASS_FOREGROUND) {
+		gate = &QosGate::of(c->device);
+		gate->enter();
+	}
+}
+
+ForegroundScope::~ForegroundScope()
+{
+	if (gate)
+		gate->leave();
+}
+
+void background_yield(const gec_codec *c)
+{
+	if (c->qos_class == GEC_CLASS_BACKGROUND)
+		(void)QosGate::of(c->device).yield_to_foreground(env().bg_yield_us);
+}
+
+size_t trip_chunk_bytes(const gec_codec *c)
+{
+	return c->qos_class == GEC_CLASS_BACKGROUND ? (env().bg_chunk_mb << 20) : 8 * kChunkBytes;
+}
+
+// sweep on MI355X: 16..64 MiB 33-37 GiB/s, 128 MiB 45, 256 MiB 39
+size_t pinned_chunk_bytes(const gec_codec *c)
+{
+	return c->qos_class == GEC_CLASS_BACKGROUND ? std::min(env().bg_chunk_mb, env().pinned_chunk_mb) << 20 : env().pinned_chunk_mb << 20;
+}
+
+}  // namespace gecimpl
+
+using namespace gecimpl;
+
+extern "C" {
+
+// ------------------------------------------------------------ pinned host memory
+void *gec_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	// portable: usable by every device's DMA engines (one process may drive several codecs)
+	if (hip_device_count() == 0) {
+		// a host without a (working) device: page-aligned heap memory, so that callers that draw their buffers from
+		// here -- libgarage_block's pool -- keep working over a GEC_BACKEND_CPU codec.  Not device-addressable.
+		const size_t n = (std::max<size_t>(bytes, 1) + 4095) / 4096 * 4096;
+		p = std::aligned_alloc(4096, n);
+		if (!p) {
+			fail(GEC_E_NOMEM, "aligned_alloc failed");
+			return nullptr;
+		}
+		pinned().add(p, n, true, 0, /*plain=*/true);
+		return p;
+	}
+	hipError_t e = hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocPortable);
+	if (e != hipSuccess) {
+		fail(e == hipErrorOutOfMemory ? GEC_E_NOMEM : GEC_E_DEVICE, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+		return nullptr;
+	}
+	pinned().add(p, std::max<size_t>(bytes, 1), true);
+	return p;
+}
+
+void gec_host_free(void *p)
+{
+	bool owned = false, plain = false;
+	if (p && pinned().remove(p, owned, plain) && owned) {
+		if (plain)
+			std::free(p);
+		else
+			(void)hipHostFree(p);
+	}
+}
+
+int gec_host_register(void *p, size_t bytes)
+{
+	if (!p || bytes == 0)
+		return fail(GEC_E_INVALID_ARG, "NULL / empty range");
+	HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+	void *dptr = p;
+	if (hipHostGetDevicePointer(&dptr, p, 0) != hipSuccess || !dptr)
+		dptr = p;
+	pinned().add(p, bytes, false, reinterpret_cast<intptr_t>(dptr) - reinterpret_cast<intptr_t>(p));
+	return GEC_OK;
+}
+
+int gec_host_unregister(void *p)
+{
+	bool owned = false, plain = false;
+	if (!p || !pinned().remove(p, owned, plain))
+		return fail(GEC_E_INVALID_ARG, "not a registered range");
+	if (owned) {  // it came from gec_host_alloc: treat like gec_host_free
+		if (plain)
+			std::free(p);
+		else
+			(void)hipHostFree(p);
+		return GEC_OK;
+	}
+	HIP_TRY(hipHostUnregister(p));
+	return GEC_OK;
+}
+
+int gec_host_is_pinned(const void *p, size_t bytes) { return pinned().contains(p, bytes) ? 1 : 0; }
+
+uint64_t gec_qos_yields(int device) { return QosGate::of(device).yields(); }
+
+}  // extern "C"

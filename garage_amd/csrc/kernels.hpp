@@ -32,49 +32,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "kernel_args.hpp"  // argument structs and limits shared with the host-only translation units
+
 namespace gec {
 
-constexpr int KMAX = 256;    // input shards per launch (k + m <= 256 => k <= 255)
-constexpr int RMAX = 8;      // output rows per launch with 4- and 8-byte table entries
-constexpr int RMAX16 = 16;   // ... with 16-byte entries (MW = 4): k <= K16MAX only
-constexpr int K16MAX = 120;  // 16 coefficient bytes per input shard must fit ApplyArgs.coef, the tables 64 KiB of LDS
-constexpr int BLOCK = 256;   // threads per workgroup of the baseline kernel
-constexpr int MODE_STORE = 0, MODE_COMPARE = 2;  // write the rows / compare them with what is stored
-// compare, with the stored rows requested up front behind the data loads (instead of at the end of the tile, where
-// their latency is exposed: verify is a pure read stream).  Only where every one of the 4 row slots is a real row
-// (rows == 4, 4-byte table entries): RS(10,4) verify 250 -> 232 us = 75 -> 81 % of peak; with fewer rows the
-// index-clamped duplicate loads cost more than they hide (RS(3,1): -6 %), with 8-byte entries the 32 extra VGPRs
-// cost occupancy (RS(20,8): -7 %).  tools/verify_bench.py.
-constexpr int MODE_COMPARE_PF = 3;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-struct ApplyArgs {
-	const uint8_t *in;   // input stripes base
-	uint8_t *out;        // output base (may alias `in`: rows never overlap inputs)
-	uint32_t *bad;       // MODE_COMPARE: bad[b] |= 1 on mismatch
-	uint64_t in_stride;  // bytes between consecutive blocks
-	uint64_t out_stride;
-	uint32_t col0;       // first 16-byte column of every shard to process
-	uint32_t cols;       // number of 16-byte columns to process
-	uint32_t nblocks;
-	uint32_t tiles_per_block;  // baseline kernel only
-	uint32_t total_cols;       // nblocks * cols (< 2^32: the host splits larger batches by blocks)
-	uint32_t k;          // inputs  (<= KMAX)
-	uint32_t rows;       // outputs (<= RMAX)
-	uint32_t in_off[KMAX];   // shard offsets inside a block, in 16-byte units
-	uint32_t out_off[RMAX16];
-	// coef[t][r] = mat[r][t]: one 8-byte row per input shard.  The 16-row kernel (MW = 4) reads the
-	// same bytes as a flat [k][16] array (k <= K16MAX).
-	uint8_t coef[KMAX][RMAX];
-};
-
-// exp[512] | log[256], filled by the host from gec::Field (768 bytes).
-struct LogExp {
-	uint8_t exp[512];
-	uint8_t log[256];
-};
 
 __device__ __forceinline__ void transpose4x4(uint32_t a0, uint32_t a1, uint32_t a2,
 					     uint32_t a3, uint32_t &p0, uint32_t &p1,
@@ -402,26 +367,6 @@ __global__ __launch_bounds__(TPB, MINW) void gf_apply_nibble_w(const ApplyArgs a
 // blockIdx.y = block, blockIdx.x = tile of 256 columns.  The tables themselves live in pinned host memory too:
 // they are wave-uniform, i.e. a few scalar loads per workgroup.
 // ---------------------------------------------------------------------------
-constexpr int PTR_KMAX = 128;  // coef[PTR_KMAX][RMAX] keeps the kernel argument block at 1 KiB
-
-struct PtrApplyArgs {
-	const uint8_t *const *in;  // [nblocks][k]: 16-byte aligned shard pointers
-	const uint32_t *in_valid;  // [nblocks][k]: bytes of the shard that exist (<= 16*cols)
-	uint8_t *const *out;       // [nblocks][rows]
-	uint32_t cols;             // 16-byte columns per shard
-	uint32_t k, rows;
-	// MIRROR: everything the kernel reads and computes is also laid down in device memory, dense --
-	// mirror + b*mirror_stride + t*16*cols for input shard t (first row group only: mirror_inputs),
-	// ... + mirror_row0 + r*16*cols for output row r -- so that the shard checksums can be computed from
-	// HBM while the bytes cross the link only once (gec_encode_hash_batch on pinned memory)
-	uint8_t *mirror;
-	uint64_t mirror_stride, mirror_row0;
-	uint32_t mirror_inputs;
-	// COMPARE: the rows are compared with what out[b][r] holds instead of being stored; bad[b] = 1 on a mismatch
-	// (bad may itself be pinned host memory: the flags need no copy back)
-	uint32_t *bad;
-	uint8_t coef[PTR_KMAX][RMAX];
-};
 
 __device__ __forceinline__ u32x4 ld16_valid(const uint8_t *shard, uint32_t col, uint32_t valid)
 {
@@ -576,11 +521,6 @@ __global__ void clear_flags(uint32_t *p, uint32_t n)
 // src and dst of every entry are 16-byte aligned (the host checks); the last <16 bytes go byte-wise.
 // blockIdx.y = entry, blockIdx.x = 16 KiB tile of the entry (the grid covers the largest entry).
 // ---------------------------------------------------------------------------
-struct CopyEntry {
-	const uint8_t *src;
-	uint8_t *dst;
-	uint64_t bytes;
-};
 
 __global__ __launch_bounds__(256) void copy_table(const CopyEntry *__restrict__ tab)
 {
@@ -617,16 +557,6 @@ __global__ __launch_bounds__(256) void copy_table(const CopyEntry *__restrict__ 
 // length by at most one column, max_cols is the longest.  Pure 16-byte copies, HBM-bound,
 // a few percent of the decode's traffic.
 // ---------------------------------------------------------------------------
-struct RangeArgs {
-	uint8_t *gathered;     // [rank][object][slot][S]
-	uint8_t *packed;       // pack: send buffer, unpack: receive buffer
-	uint64_t obj_stride;   // slots*S, bytes between consecutive objects of one rank
-	uint32_t nobj, nmiss;
-	uint32_t cols;         // S / 16
-	uint32_t max_cols;
-	uint32_t world, rank;
-	uint64_t shard_off[KMAX];  // missing shard i of object 0, byte offset in `gathered`
-};
 
 __device__ __forceinline__ uint32_t range_lo(uint32_t cols, uint32_t r, uint32_t world)
 {
@@ -674,14 +604,6 @@ __global__ __launch_bounds__(256) void range_unpack(const RangeArgs a)
 //   rebuilt_unpack: d_rebuilt[i][obj][S]       <-  recv[rank][i][obj][max_cols]              (i = missing shard)
 // Pure 16-byte copies.
 // ---------------------------------------------------------------------------
-struct A2aArgs {
-	const uint8_t *local;  // [obj][slots][S]
-	uint8_t *send;         // [peer][nvs_max][obj][max_cols]
-	uint64_t obj_stride;   // slots*S
-	uint32_t nobj, nvs, nvs_max;
-	uint32_t cols, max_cols, world;
-	uint32_t slot_of[KMAX];  // local slot of valid shard vs
-};
 
 __global__ __launch_bounds__(256) void a2a_pack(const A2aArgs a)
 {
@@ -701,12 +623,6 @@ __global__ __launch_bounds__(256) void a2a_pack(const A2aArgs a)
 	}
 }
 
-struct RebuiltArgs {
-	const uint8_t *packed;  // [rank][nmiss][obj][max_cols] (or just this rank's [nmiss][obj][max_cols] with world_in == 1)
-	uint8_t *rebuilt;       // [nmiss][obj][S]
-	uint32_t nobj, nmiss, cols, max_cols, world;
-	uint32_t first_rank, nranks_in;  // ranks whose ranges `packed` holds: first_rank .. first_rank + nranks_in - 1
-};
 
 __global__ __launch_bounds__(256) void rebuilt_unpack(const RebuiltArgs a)
 {

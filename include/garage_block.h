@@ -18,15 +18,23 @@
  * the reference tests multi-node logic on loopback (src/net/test.rs:15-118);
  * the network and the metadata tables are out of scope.  zstd (DataBlock::
  * from_buffer, src/block/block.rs:85-106) goes through the system's libzstd.so.1,
- * resolved at run time.  The manager is thread-safe: per-hash striped locks like
- * mutation_lock (src/block/manager.rs:679-689), nodes lock internally, and the bulk
- * work (copies, fan-out, gathers) runs on an internal thread pool.
+ * resolved at run time.  The manager is thread-safe: refcounts are striped, a per-hash
+ * mutation lock like mutation_lock (src/block/manager.rs:679-689) orders a put's "protected
+ * from now on" stamp against resync's delete branch (which re-reads the refcount under it,
+ * delete_if_unneeded :619-623), nodes lock internally, and the bulk work (copies, fan-out,
+ * gathers) runs on an internal thread pool.
  *
- * Environment (all optional, read once per process; none changes results):
- *   GBM_TRACE=1              stage timings of the batched put / get / resync / scrub on stderr
- *   GBM_PUT_SLICE=n          blocks per slice of a large untagged put (default 64)
- *   GBM_PUT_THREADS=n        slices in flight (default 4)
- *   GBM_BATCHER_WORKERS=n    batches the coalescing batcher keeps in flight (default 2)
+ * The codec may be a GEC_BACKEND_HIP or a GEC_BACKEND_CPU one (create it with GEC_BACKEND_AUTO
+ * and a node that has lost its GPU keeps reading and repairing its blocks on the host cores:
+ * BASELINE config 1, "CPU path via BlockManager").
+ *
+ * Foreground and background: puts and gets run on the codec given to gbm_create; gbm_scrub*,
+ * gbm_resync_* rebuilds run on a BACKGROUND-class sibling of it (gec_codec_background) that the
+ * manager creates, with a tranquility knob like the reference's workers (gbm_set_tranquility).
+ *
+ * Environment: every switch is optional, read once per process, and none changes results; the one
+ * table of the GBM_* switches is in garage_amd/csrc/bm_core.cpp, gbm_env_table() returns it as text
+ * and INTEGRATION.md section 6 prints it.
  */
 #ifndef GARAGE_BLOCK_H
 #define GARAGE_BLOCK_H
@@ -74,6 +82,8 @@ typedef struct {
 } gbm_data_block_header;
 
 const char *gbm_last_error(void);
+/* Every GBM_* environment switch: "NAME<tab>default<tab>meaning" lines (static storage). */
+const char *gbm_env_table(void);
 
 /* Garage's content hash: blake2b-512 truncated to 32 bytes (NOT blake2b-256). */
 void gbm_blake2sum(const uint8_t *data, size_t len, uint8_t out[32]);
@@ -108,6 +118,16 @@ int gbm_set_verify_block_hash(gbm_manager *m, int enabled);
  * it, ~1 ms per MiB on a host core.  Gets of up to `nblocks` blocks (default 6 per pool thread = 96) verify it on the
  * host pool from the assembled bytes; larger batches on the device, behind the upload.  0 = always on the device. */
 int gbm_set_host_block_hash_max(gbm_manager *m, size_t nblocks);
+
+/* Tranquilizer (src/util/tranquilizer.rs:38-69; resync.rs:46,568 and the scrub worker's own, repair.rs:386-390):
+ * after every maintenance batch that kept the device busy for t, the worker sleeps tranquility * t.  0 (default) =
+ * no pause; a negative argument keeps the current value.  On top of that, maintenance always runs on a
+ * BACKGROUND-class codec whose device work yields to the request path's (include/garage_ec.h). */
+int gbm_set_tranquility(gbm_manager *m, int scrub_tranquility, int resync_tranquility);
+uint64_t gbm_tranquilized_ms(const gbm_manager *m);   /* total time slept by the tranquilizer */
+/* The codec maintenance runs on (the manager's own BACKGROUND-class sibling of the codec it was given, or that
+ * codec itself when no sibling could be created).  Borrowed. */
+const gec_codec *gbm_background_codec(const gbm_manager *m);
 
 /* Worker threads of the manager's internal pool (copies, fan-out, gathers); default min(16, cores). */
 int gbm_set_threads(gbm_manager *m, int nthreads);
@@ -167,9 +187,11 @@ int gbm_rpc_get_raw_block_streaming(gbm_manager *m, const uint8_t hash[32], cons
 /* Garage keeps <= 3 block puts in flight per PutObject (PUT_BLOCKS_MAX_PARALLEL,
  * src/api/s3/put.rs:42,486-511) across many concurrent requests.  gbm_batcher_put_block is
  * thread-safe and blocks its caller (like `rpc_put_block(..).await`) until the batch that contains
- * the block has been encoded and fanned out; one worker thread turns everything queued within
- * max_wait_us (or max_blocks) into ONE device call.  Returns that block's own
- * result (GBM_OK / GBM_E_QUORUM / a device error). */
+ * the block has been encoded and fanned out; a worker thread turns everything queued within
+ * max_wait_us (or max_blocks) into ONE device call, GBM_BATCHER_WORKERS (default 2) such batches in flight at a
+ * time.  Batches that carry order tags hand their shards to the nodes in the order the batches were formed, so
+ * blocks of one OrderTag stream reach every node in `order` order even when they land in different batches.
+ * Returns that block's own result (GBM_OK / GBM_E_QUORUM / a device error). */
 typedef struct gbm_batcher gbm_batcher;
 int gbm_batcher_create(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, gbm_batcher **out);
 void gbm_batcher_destroy(gbm_batcher *b);

@@ -19,26 +19,22 @@
  *  - a codec is immutable after creation and may be shared by any number of
  *    threads (Rust: Send + Sync); every entry point is blocking w.r.t. host
  *    buffers; *_dev entry points are asynchronous on the given HIP stream;
- *  - all shard data is computed on the GPU by hand-written HIP kernels; there
- *    is NO CPU fallback: without a usable device gec_codec_create fails with
- *    GEC_E_DEVICE.
+ *  - a codec has a backend: GEC_BACKEND_HIP computes every shard byte on the
+ *    GPU with hand-written gfx950 kernels and is the product; GEC_BACKEND_CPU is the library's own
+ *    host-core data path (AVX-512 + GFNI / AVX2 / scalar, chosen at run time) behind the same
+ *    host-pointer entry points -- what a node runs on when it has no GPU, or has lost it, so that it
+ *    can still read and repair its own erasure-coded blocks (BASELINE config 1's "CPU path via
+ *    BlockManager").  Both produce identical bytes.  The *_dev and gec_group_* entry points need a
+ *    HIP codec.
  *
  * Shard geometry: a block of L bytes is cut into k
  * data shards of S = round_up(ceil(L/k), 64) bytes, shard i = block bytes
  * [i*S, (i+1)*S) zero-extended, so data shards are zero-copy slices of the
  * (padded) block buffer and every shard starts on a 64-byte line.
  *
- * Environment (all optional, read once per process; none changes results):
- *   GEC_COPY_THREADS=n          staging-copy threads per codec for the host-pointer calls (default 7)
- *   GEC_RCCL_LIB=path           RCCL to dlopen for gec_group_* (default librccl.so.1)
- *   GEC_ROWS16=0                A/B: 9..16 output rows as 8-row passes instead of one 16-row pass
- *   GEC_BLAKE2_KERNEL=lane|quad A/B: force one of the two (plain) blake2 kernels
- *   GEC_HASH_FORK=0             A/B: encode+checksum on one stream instead of data-shard checksums beside the encode
- *   GEC_MAX_COLS_PER_LAUNCH=n   test hook: exercise the multi-launch split on small inputs
- *   GEC_ZERO_COPY=0             A/B: pinned caller memory through the device staging pipeline instead of in place
- *   GEC_UPLOAD_CUS=n            CUs reserved for kernels that read / write host memory (default 16; 0 = no CU masks)
- *   GEC_VERIFY_SEGMENTS=n       A/B: upload stages of gec_decode_verify_batch (default min(k, 16); 1 = upload, then hash)
- *   GEC_PINNED_CHUNK_MB=n       chunk size of the staged path for pinned memory (default 128)
+ * Environment: every switch is optional, read once per process, and none changes results.  The one
+ * table (name, default, meaning) lives in garage_amd/csrc/ec_env.cpp; gec_env_table() returns it as
+ * text and INTEGRATION.md section 6 prints it.
  */
 #ifndef GARAGE_EC_H
 #define GARAGE_EC_H
@@ -50,7 +46,7 @@
 extern "C" {
 #endif
 
-#define GEC_VERSION 0x00020000u /* major.minor.patch = 0.2.0 */
+#define GEC_VERSION 0x00030000u /* major.minor.patch = 0.3.0 (0.3: backend argument of gec_codec_create) */
 #define GEC_MAX_SHARDS 256      /* GF(2^8): k + m <= 256 [EXT] */
 
 typedef struct gec_codec gec_codec; /* opaque */
@@ -77,8 +73,12 @@ enum {
 
 /* ------------------------------------------------------------- library */
 uint32_t gec_version(void);
-/* Number of usable HIP devices (0 => every gec_codec_create fails). */
+/* Number of usable HIP devices (0 => only GEC_BACKEND_CPU codecs can be created). */
 int gec_device_count(void);
+/* Every GEC_* environment switch: "NAME<tab>default<tab>meaning" lines (static storage). */
+const char *gec_env_table(void);
+/* The kernel a GEC_BACKEND_CPU codec runs on this host: "avx512+gfni", "avx2" or "scalar" (static storage). */
+const char *gec_cpu_isa(void);
 const char *gec_strerror(int code);
 /* Thread-local detail string of the last failing call on this thread. */
 const char *gec_last_error(void);
@@ -106,19 +106,43 @@ int gec_build_decode_matrix(int k, int m, const uint8_t *present,
 			    int32_t *valid_out, uint8_t *out_k_by_k);
 
 /* --------------------------------------------------------------- codec */
+/* Who moves the bytes.  HIP: `device` names the GPU; without a usable one creation fails with GEC_E_DEVICE.
+ * CPU: the host cores (`device` is ignored) -- the same host-pointer entry points, the same bytes; the *_dev
+ * and gec_group_* entry points answer GEC_E_DEVICE.  AUTO: HIP when gec_device_count() > 0, else CPU -- what
+ * a Garage node uses so that losing its GPU degrades its throughput, not its ability to read and repair
+ * (the codec call sits in spawn_blocking either way, src/block/block.rs:85-96). */
+enum { GEC_BACKEND_CPU = 0, GEC_BACKEND_HIP = 1, GEC_BACKEND_AUTO = 2 };
 /* == ReedSolomon::new(data_shards, parity_shards) [EXT]; belongs in
  * BlockManager::new (src/block/manager.rs:122-192) next to the
  * compression_level / data_fsync fields, built from new Config keys.
- * Argument errors are reported before the device is touched. */
-int gec_codec_create(int k, int m, int device, gec_codec **out);
+ * Argument errors are reported before any device is touched.  (SURVEY.md Appendix B's signature.) */
+int gec_codec_create(int k, int m, int backend, int device, gec_codec **out);
 /* Same with an explicit matrix family (gec_codec_create == GEC_MATRIX_VANDERMONDE). */
-int gec_codec_create_ex(int k, int m, int device, int matrix, gec_codec **out);
+int gec_codec_create_ex(int k, int m, int backend, int device, int matrix, gec_codec **out);
+
+/* Foreground and background work.  Garage keeps repair off the request path with a bounded worker pool and a
+ * Tranquilizer (src/block/resync.rs:43-46,513-599, src/util/tranquilizer.rs:38-69); on a device the same split
+ * needs the codec's cooperation.  gec_codec_background returns a sibling of `c` -- same code, same backend and
+ * device, its own staging slots and copy threads -- whose work is classed BACKGROUND:
+ *   - its streams run at the device's lowest priority and on a subset of the CUs (GEC_BG_CUS), so a long
+ *     checksum kernel of a scrub never holds the whole chip when a PutObject's encode arrives;
+ *   - its host-pointer trips go in small chunks (GEC_BG_CHUNK_MB) and, before each chunk, wait (up to
+ *     GEC_BG_YIELD_US) for the foreground calls in flight on the same device to finish: a foreground call
+ *     finds the link, the copy threads and the CUs busy with at most one background chunk;
+ *   - it keeps to two staging-copy threads.
+ * libgarage_block runs gbm_scrub_all / gbm_resync_run on such a sibling.  Results are identical. */
+enum { GEC_CLASS_FOREGROUND = 0, GEC_CLASS_BACKGROUND = 1 };
+int gec_codec_background(const gec_codec *c, gec_codec **out);
+int gec_codec_class(const gec_codec *c);   /* GEC_CLASS_* */
+int gec_codec_backend(const gec_codec *c); /* GEC_BACKEND_CPU or GEC_BACKEND_HIP (AUTO is resolved at creation) */
+/* times a background chunk found foreground work in flight on `device` and waited (process-wide counter) */
+uint64_t gec_qos_yields(int device);
 /* Must not run concurrently with any other call on the same codec, and only after
  * work enqueued by *_dev calls on caller streams has completed. */
 void gec_codec_destroy(gec_codec *c);
 int gec_codec_k(const gec_codec *c);
 int gec_codec_m(const gec_codec *c);
-int gec_codec_device(const gec_codec *c);
+int gec_codec_device(const gec_codec *c); /* -1 for a CPU codec */
 /* m x k parity rows of this codec (test introspection). */
 int gec_parity_matrix(const gec_codec *c, uint8_t *out_m_by_k);
 /* Number of decode matrices currently cached / total inversions performed
@@ -139,6 +163,8 @@ int gec_codec_cache_stats(const gec_codec *c, uint64_t *cached,
  * shim would draw the block buffers PutObject fills (src/api/s3/put.rs:440-456) and the parity
  * buffers from a pool allocated with gec_host_alloc, or register its existing arena once.
  * Process-wide, thread-safe, usable with every device's codec. */
+/* (On a host without a usable device gec_host_alloc hands out page-aligned ordinary memory, so that callers
+ * that draw their buffers from it keep working over a GEC_BACKEND_CPU codec; gec_host_is_pinned says 0.) */
 void *gec_host_alloc(size_t bytes);   /* NULL on failure (gec_last_error) */
 void gec_host_free(void *p);
 int gec_host_register(void *p, size_t bytes);   /* pin caller-owned memory (hipHostRegister) */

@@ -91,7 +91,7 @@ static void *worker(void *arg)
 		for (int b = 0; b < NB; b++) {
 			pblk[b] = (uint8_t *)gec_host_alloc(k * S);
 			ppar[b] = (uint8_t *)gec_host_alloc(m * S);
-			if (!pblk[b] || !ppar[b] || !gec_host_is_pinned(pblk[b], k * S))
+			if (!pblk[b] || !ppar[b] || (gec_device_count() > 0 && !gec_host_is_pinned(pblk[b], k * S)))
 				return NULL;
 			memcpy(pblk[b], blk[b], k * S);
 		}
@@ -148,7 +148,9 @@ static void *worker(void *arg)
 
 int main(int argc, char **argv)
 {
-	(void)argv;
+	/* mode: none = host logic only; "gpu" = every section on a GEC_BACKEND_HIP codec; "cpu" = the same sections on a
+	 * GEC_BACKEND_CPU codec (the library's own host-core data path: runs on a box without a GPU) */
+	const int backend = (argc > 1 && strcmp(argv[1], "cpu") == 0) ? GEC_BACKEND_CPU : GEC_BACKEND_HIP;
 	/* ---- host logic, no GPU needed ---- */
 	CHECK(gec_version() == GEC_VERSION);
 	CHECK(gec_shard_len(10, 1 << 20) == 104896 && gec_shard_len(3, 65536) == 21888);
@@ -159,18 +161,30 @@ int main(int argc, char **argv)
 	CHECK(gec_build_matrix(0, 4, mat) == GEC_E_TOO_FEW_DATA);
 	CHECK(gec_build_matrix(250, 7, mat) == GEC_E_TOO_MANY_SHARDS);
 	gec_codec *c = NULL;
-	CHECK(gec_codec_create(10, 0, 0, &c) == GEC_E_TOO_FEW_PARITY && c == NULL);
+	CHECK(gec_codec_create(10, 0, GEC_BACKEND_HIP, 0, &c) == GEC_E_TOO_FEW_PARITY && c == NULL);
+	CHECK(gec_codec_create(10, 4, 7, 0, &c) == GEC_E_INVALID_ARG && c == NULL); /* unknown backend */
 	if (gec_device_count() == 0) {
-		CHECK(gec_codec_create(10, 4, 0, &c) == GEC_E_DEVICE && c == NULL);
-		CHECK(strstr(gec_last_error(), "no CPU fallback") != NULL);
-		printf("cabi_client: host-logic checks OK (no GPU: codec creation refused as designed)\n");
-		return argc > 1 ? 2 : 0;
+		/* no GPU: a HIP codec is refused, AUTO falls back to the host cores */
+		CHECK(gec_codec_create(10, 4, GEC_BACKEND_HIP, 0, &c) == GEC_E_DEVICE && c == NULL);
+		CHECK(strstr(gec_last_error(), "GEC_BACKEND_CPU") != NULL);
+		CHECK(gec_codec_create(10, 4, GEC_BACKEND_AUTO, 0, &c) == GEC_OK && gec_codec_backend(c) == GEC_BACKEND_CPU);
+		CHECK(gec_codec_device(c) == -1);
+		uint8_t dummy[64];
+		CHECK(gec_encode_batch_dev(c, 1, dummy, 640, 64, dummy, 256, NULL) == GEC_E_INVALID_ARG ||
+		      gec_encode_batch_dev(c, 1, dummy, 640, 64, dummy, 256, NULL) == GEC_E_DEVICE); /* no device entry points */
+		gec_codec_destroy(c);
+		c = NULL;
+		if (backend == GEC_BACKEND_HIP) {
+			printf("cabi_client: host-logic checks OK (no GPU: HIP codec refused, AUTO -> CPU)\n");
+			return argc > 1 ? 2 : 0;
+		}
 	}
 	if (argc < 2)
 		return 0;
+	printf("cabi_client: backend %s (cpu kernel: %s)\n", backend == GEC_BACKEND_CPU ? "cpu" : "hip", gec_cpu_isa());
 
 	/* ---- RS(3,1): parity must be the XOR of the three data shards ---- */
-	CHECK(gec_codec_create(3, 1, 0, &c) == GEC_OK);
+	CHECK(gec_codec_create(3, 1, backend, 0, &c) == GEC_OK);
 	const size_t L = 65536, S = gec_shard_len(3, L);
 	uint8_t *blk = (uint8_t *)calloc(3 * S, 1), *par = (uint8_t *)malloc(S);
 	fill(blk, L, 7);
@@ -225,7 +239,7 @@ int main(int argc, char **argv)
 
 	/* ---- blake2sum on the device: RFC 7693 "abc" (blake2b-512, first 32 bytes = Garage's blake2sum),
 	 *      the empty message, and encode + shard checksums in one call ---- */
-	CHECK(gec_codec_create(10, 4, 0, &c) == GEC_OK);
+	CHECK(gec_codec_create(10, 4, backend, 0, &c) == GEC_OK);
 	{
 		static const uint8_t abc_want[32] = {0xba, 0x80, 0xa5, 0x3f, 0x98, 0x1c, 0x4d, 0x0d, 0x6a, 0x27, 0x97,
 						     0xb6, 0x9f, 0x12, 0xf6, 0xe9, 0x4c, 0x21, 0x2f, 0x14, 0x68, 0x5a,
@@ -260,7 +274,7 @@ int main(int argc, char **argv)
 	gec_codec_destroy(c);
 
 	/* ---- 4 threads sharing one RS(10,4) codec (Send + Sync on the Rust side) ---- */
-	CHECK(gec_codec_create(10, 4, 0, &c) == GEC_OK);
+	CHECK(gec_codec_create(10, 4, backend, 0, &c) == GEC_OK);
 	pthread_t th[4];
 	struct job jobs[4];
 	for (int i = 0; i < 4; i++) {
@@ -274,6 +288,6 @@ int main(int argc, char **argv)
 		CHECK(jobs[i].ok);
 	}
 	gec_codec_destroy(c);
-	printf("cabi_client: GPU checks OK\n");
+	printf("cabi_client: %s checks OK\n", backend == GEC_BACKEND_CPU ? "CPU" : "GPU");
 	return 0;
 }

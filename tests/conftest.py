@@ -18,7 +18,7 @@ def pytest_configure(config):
             os.path.join(ROOT, "oracle", "librs_oracle.so")]
     if not all(os.path.exists(p) for p in need):
         for d in (os.path.join(ROOT, "garage_amd", "csrc"), os.path.join(ROOT, "oracle")):
-            r = subprocess.run(["make", "-C", d], capture_output=True, text=True)
+            r = subprocess.run(["make", "-j8", "-C", d], capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"make -C {d} failed:\n{r.stdout}\n{r.stderr}")
 

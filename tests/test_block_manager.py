@@ -1,8 +1,13 @@
-"""Host logic of the EC BlockManager mirror on CPU (arithmetic by the oracle stub)."""
+"""The (frozen) Python BlockManager mirror over libgarage_ec's own CPU backend: BASELINE config 1 -- RS(3,1) /
+RS(10,4) "CPU path via BlockManager (plumbing, no GPU)" -- with product code end to end (no oracle in the path)."""
 import pytest
 
+import garage_amd as g
 from tests import block_manager_cases as C
-from tests.oracle_codec import OracleCodec
+
+
+def OracleCodec(k, m):  # historic name in this file: the codec is the PRODUCT's CPU backend now
+    return g.ReedSolomon(k, m, backend="cpu")
 
 
 @pytest.fixture(params=[(3, 1), (10, 4)], ids=["rs3_1", "rs10_4"])

@@ -1,6 +1,7 @@
 """libgarage_block.so (C++ BlockManager mirror, include/garage_block.h).
-CPU: symbols, blake2sum against hashlib, argument errors.  GPU: the put/get/
-failure/resync/scrub scenarios with the real codec underneath."""
+Symbols, blake2sum against hashlib, argument errors; then the put / get / failure / resync / scrub scenarios twice:
+over libgarage_ec's CPU backend (backend "cpu": runs anywhere -- BASELINE config 1, "CPU path via BlockManager") and
+over the HIP backend (backend "hip": marked gpu)."""
 import ctypes
 import hashlib
 import os
@@ -46,10 +47,15 @@ def test_create_rejects_null_codec():
     assert bn.lib.gbm_create(None, 14, None, 0, ctypes.byref(h)) == bn.GBM_E_INVALID_ARG
 
 
-# ----------------------------------------------------------------- GPU scenarios
+# ----------------------------------------------------------------- scenarios, on both backends
+@pytest.fixture(params=["cpu", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request):
+    return request.param
+
+
 @pytest.fixture(params=[(3, 1), (10, 4)], ids=["rs3_1", "rs10_4"])
-def codec(request):
-    return g.ReedSolomon(*request.param)
+def codec(request, backend):
+    return g.ReedSolomon(*request.param, backend=backend)
 
 
 def _mgr(codec, tmp_path=None, extra=2):
@@ -58,7 +64,6 @@ def _mgr(codec, tmp_path=None, extra=2):
     return bn.NativeBlockManager(codec, n, dirs)
 
 
-@pytest.mark.gpu
 def test_native_put_get_roundtrip(codec, tmp_path):
     mgr = _mgr(codec, tmp_path)
     for size in (3073, 65536, 500_000, 1 << 20):
@@ -84,7 +89,6 @@ def test_native_put_get_roundtrip(codec, tmp_path):
     assert mgr.metrics["blocks_put"] == 4 and mgr.metrics["blocks_get"] == 4
 
 
-@pytest.mark.gpu
 def test_native_survives_m_failures_and_quorum(codec):
     mgr = _mgr(codec)
     data = pattern_block(300_000, 7)
@@ -117,7 +121,6 @@ def test_native_survives_m_failures_and_quorum(codec):
     assert "Could not reach quorum" in str(ei.value)
 
 
-@pytest.mark.gpu
 def test_native_corruption_resync_scrub(codec, tmp_path):
     mgr = _mgr(codec, tmp_path)
     blocks = [pattern_block(200_000, s) for s in range(6)]
@@ -162,13 +165,12 @@ def test_native_corruption_resync_scrub(codec, tmp_path):
         mgr.rpc_get_block(hashes[5])
 
 
-@pytest.mark.gpu
-def test_native_and_python_mirrors_interoperate(tmp_path):
+def test_native_and_python_mirrors_interoperate(tmp_path, backend):
     """Same placement, same shard files: a block written by the C++ manager is
     readable by the Python mirror over the same directories and vice versa."""
     from garage_amd.block_manager import BlockManager, DirShardStore
 
-    codec = g.ReedSolomon(10, 4)
+    codec = g.ReedSolomon(10, 4, backend=backend)
     dirs = [str(tmp_path / f"node{i}") for i in range(16)]
     native = bn.NativeBlockManager(codec, 16, dirs)
     pym = BlockManager(codec, [DirShardStore(d) for d in dirs])
@@ -181,14 +183,13 @@ def test_native_and_python_mirrors_interoperate(tmp_path):
     assert native.rpc_get_block(hb) == b
 
 
-@pytest.mark.gpu
-def test_compressed_blocks_native_and_python(tmp_path):
+def test_compressed_blocks_native_and_python(tmp_path, backend):
     """compression_level = Some(1) (Garage's default): blocks are zstd frames with the
     content checksum on before they are cut into shards; both mirrors read each
     other's compressed blocks; a corrupted compressed payload is CorruptData."""
     from garage_amd.block_manager import BlockManager, DataBlockHeader, DirShardStore
 
-    codec = g.ReedSolomon(10, 4)
+    codec = g.ReedSolomon(10, 4, backend=backend)
     dirs = [str(tmp_path / f"node{i}") for i in range(14)]
     native = bn.NativeBlockManager(codec, 14, dirs, compression_level=1)
     pym = BlockManager(codec, [DirShardStore(d) for d in dirs], compression_level=1)
@@ -215,12 +216,11 @@ def test_compressed_blocks_native_and_python(tmp_path):
     assert pym.rpc_get_block(hr) == rnd
 
 
-@pytest.mark.gpu
-def test_prevent_compression_order_tag_raw_and_streaming_gets():
+def test_prevent_compression_order_tag_raw_and_streaming_gets(backend):
     """The reference's put/get surface (src/block/manager.rs:243-274,344-408): an "encrypted" (SSE-C) block is
     put with prevent_compression=True under compression level 1 (put.rs:576) and every shard header says
     Plain; rpc_get_raw_block returns the DataBlock as stored; the streaming forms deliver it in order."""
-    codec = g.ReedSolomon(10, 4)
+    codec = g.ReedSolomon(10, 4, backend=backend)
     mgr = bn.NativeBlockManager(codec, 16, compression_level=1)
     data = pattern_block(1 << 20, 12)                       # very compressible
     h = bn.blake2sum(data)
@@ -254,11 +254,10 @@ def test_prevent_compression_order_tag_raw_and_streaming_gets():
     assert [mgr.node_shard_header(mgr.storage_nodes_of(hashes[i])[0], hashes[i], 0)[8] for i in range(10)] == [0, 1] * 5
 
 
-@pytest.mark.gpu
-def test_put_with_node_down_is_repaired_never_deleted():
+def test_put_with_node_down_is_repaired_never_deleted(backend):
     """put reaches its quorum with a node down, no incref yet, resync runs: the straggler is
     rebuilt; the block is only deleted after a decref AND BLOCK_GC_DELAY."""
-    codec = g.ReedSolomon(10, 4)
+    codec = g.ReedSolomon(10, 4, backend=backend)
     mgr = bn.NativeBlockManager(codec, 16)
     data = pattern_block(400_000, 41)
     h = bn.blake2sum(data)
@@ -285,13 +284,12 @@ def test_put_with_node_down_is_repaired_never_deleted():
     assert mgr.block_rc(h)[1] == "Absent"
 
 
-@pytest.mark.gpu
-def test_resync_queue_batches_rebuilds_by_erasure_pattern():
+def test_resync_queue_batches_rebuilds_by_erasure_pattern(backend):
     """Row f3 as the survey wrote it: 1000 blocks are written while one node is dead; the node comes back
     empty; ONE pass over the time-ordered queue gathers k shards per block and rebuilds every absent shard
     with at most one device call -- and one matrix inversion -- per erasure pattern (<= k+m), with error
     back-off while the node is still away."""
-    codec = g.ReedSolomon(10, 4)
+    codec = g.ReedSolomon(10, 4, backend=backend)
     mgr = bn.NativeBlockManager(codec, 17)
     NB, L = 1000, 65536
     rng = np.random.default_rng(5)
@@ -323,9 +321,8 @@ def test_resync_queue_batches_rebuilds_by_erasure_pattern():
     assert mgr.rpc_get_blocks(hashes[:50], L) == blocks[:50]
 
 
-@pytest.mark.gpu
-def test_layout_change_offloads_shards_to_their_new_owners():
-    codec = g.ReedSolomon(10, 4)
+def test_layout_change_offloads_shards_to_their_new_owners(backend):
+    codec = g.ReedSolomon(10, 4, backend=backend)
     mgr = bn.NativeBlockManager(codec, 20)
     blocks = [pattern_block(200_000, 700 + i) for i in range(40)]
     hashes = [bn.blake2sum(b) for b in blocks]
@@ -349,14 +346,13 @@ def test_layout_change_offloads_shards_to_their_new_owners():
     assert mgr.rpc_get_blocks(hashes, 200_000) == blocks
 
 
-@pytest.mark.gpu
-def test_batcher_coalesces_concurrent_puts():
+def test_batcher_coalesces_concurrent_puts(backend):
     """16 caller threads (think: 16 PutObject requests) each put 6 blocks through the
     batcher; every call blocks until ITS block is stored; the worker coalesces them into
     far fewer device batches; everything reads back; a quorum failure reaches its caller."""
     import threading
 
-    codec = g.ReedSolomon(10, 4)
+    codec = g.ReedSolomon(10, 4, backend=backend)
     mgr = bn.NativeBlockManager(codec, 16)
     bt = bn.Batcher(mgr, max_blocks=32, max_wait_us=2000)
     T, PER = 16, 6
@@ -388,14 +384,13 @@ def test_batcher_coalesces_concurrent_puts():
     bt.close()
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("on_disk", [False, True], ids=["memory", "directories"])
-def test_scrub_all_locates_and_repairs_silent_corruption(tmp_path, on_disk):
+def test_scrub_all_locates_and_repairs_silent_corruption(tmp_path, on_disk, backend):
     """ScrubWorker over everything stored (BlockStoreIterator = directory walk / memory stripes), device verify in
     batches.  A parity shard AND (in another block) a data shard rot *before* their checksums are taken: every
     checksum still matches, only the RS verify sees it; leave-one-out decodes say which shard it is; it is set aside
     and the resync that follows rebuilds it.  RepairWorker queues everything known."""
-    codec = g.ReedSolomon(10, 4)
+    codec = g.ReedSolomon(10, 4, backend=backend)
     dirs = [str(tmp_path / f"node{i}") for i in range(16)] if on_disk else None
     mgr = bn.NativeBlockManager(codec, 16, dirs)
     blocks = [pattern_block(300_000 + 64 * i, 1200 + i) for i in range(40)]
@@ -422,7 +417,6 @@ def test_scrub_all_locates_and_repairs_silent_corruption(tmp_path, on_disk):
     assert mgr.resync_run()["ok"] == 40
 
 
-@pytest.mark.gpu
 def test_hedged_read_decodes_around_a_slow_node(codec):
     """with a hedge delay, a read whose data-shard holder is slow asks the parity
     holders too and decodes from whichever k shards arrive first -- same bytes, without waiting for the slow node."""

@@ -21,6 +21,15 @@ def test_c_client_host_logic():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_c_client_cpu_backend_and_threads():
+    """The same sections on a GEC_BACKEND_CPU codec: RS(3,1) parity == XOR, verify, one-trip scrub / rebuild with their
+    checksums, blake2sum KATs, 4 threads on one codec -- on a box without a GPU."""
+    _build()
+    r = subprocess.run([EXE, "cpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "CPU checks OK" in r.stdout
+
+
 @pytest.mark.gpu
 def test_c_client_gpu_and_threads():
     _build()

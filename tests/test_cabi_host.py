@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_version_and_strerror():
-    assert _lib.lib.gec_version() == 0x00020000
+    assert _lib.lib.gec_version() == 0x00030000
     assert _lib.lib.gec_strerror(0) == b"ok"
     assert b"present" in _lib.lib.gec_strerror(_lib.GEC_E_TOO_FEW_PRESENT)
     assert _lib.lib.gec_device_count() >= 0
@@ -84,13 +84,48 @@ def test_error_codes_mirror_the_crate():
     assert ei.value.code == _lib.GEC_E_TOO_FEW_PRESENT
 
 
-def test_no_cpu_fallback_without_gpu():
+def test_backends_without_a_gpu():
+    """SURVEY.md Appendix B's `backend` argument: without a device a HIP codec is refused (and says what would
+    work), AUTO resolves to the host cores, a CPU codec has no device-resident entry points."""
     if _lib.lib.gec_device_count() > 0:
         pytest.skip("a GPU is present")
     with pytest.raises(g.GecError) as ei:
-        g.ReedSolomon(10, 4)
+        g.ReedSolomon(10, 4)  # backend="hip" is the default
     assert ei.value.code == _lib.GEC_E_DEVICE
-    assert "no CPU fallback" in str(ei.value)
+    assert "GEC_BACKEND_CPU" in str(ei.value)
+    rs = g.ReedSolomon(10, 4, backend="auto")
+    assert rs.backend == "cpu" and rs.device == -1
+    h = ctypes.c_void_p()
+    assert _lib.lib.gec_codec_create(10, 4, 7, 0, ctypes.byref(h)) == _lib.GEC_E_INVALID_ARG
+    # no *_dev, no groups on a CPU codec
+    buf = np.zeros(14 * 64 + 64, dtype=np.uint8)
+    base = (buf.ctypes.data + 15) // 16 * 16
+    assert _lib.lib.gec_encode_batch_dev(rs._h, 1, base, 14 * 64, 64, base + 640, 14 * 64, None) == _lib.GEC_E_DEVICE
+    fn = _lib.ALLGATHER_FN(lambda *a: 0)
+    assert _lib.lib.gec_group_create_with_transport(rs._h, 0, 1, fn, None, ctypes.byref(h)) == _lib.GEC_E_DEVICE
+    # a background sibling keeps code and backend
+    bg = rs.background()
+    assert bg.backend == "cpu" and bg.qos_class == _lib.GEC_CLASS_BACKGROUND and rs.qos_class == _lib.GEC_CLASS_FOREGROUND
+    assert np.array_equal(bg.parity_matrix(), rs.parity_matrix())
+
+
+def test_env_tables_name_every_switch_the_sources_read():
+    """One table per library (gec_env_table / gbm_env_table); every GEC_* / GBM_* name that appears in a getenv of the
+    product sources is in it, and nothing reads the environment outside the two table files."""
+    from garage_amd import block_native as bn
+
+    gec = {ln.split("\t")[0] for ln in _lib.lib.gec_env_table().decode().splitlines()}
+    gbm = {ln.split("\t")[0] for ln in bn.lib.gbm_env_table().decode().splitlines()}
+    assert "GEC_UPLOAD_CUS" in gec and "GEC_CPU_ISA" in gec and "GBM_TRACE" in gbm
+    csrc = os.path.join(ROOT, "garage_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".cpp", ".hip", ".hpp")):
+            continue
+        txt = open(os.path.join(csrc, f)).read()
+        if "getenv" in txt:
+            assert f in ("ec_env.cpp", "bm_core.cpp"), f"{f} reads the environment outside the tables"
+        for name in set(re.findall(r'"(GEC_[A-Z0-9_]+|GBM_[A-Z0-9_]+)"', txt)):
+            assert name in gec or name in gbm, f"{name} ({f}) is not in the environment tables"
 
 
 def test_group_entry_points_reject_bad_arguments_without_a_gpu():
@@ -143,12 +178,22 @@ def test_launch_geometry_invariants_for_every_k_and_row_count():
 
 
 def test_product_never_imports_oracle():
-    pkg = os.path.join(ROOT, "garage_amd")
-    for dp, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
-                txt = open(os.path.join(dp, f)).read()
-                assert "rs_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+    """Nothing under garage_amd/ (the CPU backend ec_cpu.cpp included) or include/ names the oracle, and neither
+    shared library links it."""
+    import subprocess
+
+    for top in ("garage_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".map")) or f == "Makefile":
+                    txt = open(os.path.join(dp, f)).read()
+                    assert "rs_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+                    for line in txt.splitlines():  # no source includes, links or opens anything under oracle/
+                        if "oracle" in line and not line.lstrip().startswith(("//", "*", "#", '"""')):
+                            assert not re.search(r'#include|dlopen|-l|\.so|open\(', line), f"{f}: {line}"
+    for so in ("libgarage_ec.so", "libgarage_block.so"):
+        out = subprocess.run(["ldd", os.path.join(ROOT, "garage_amd", so)], capture_output=True, text=True).stdout
+        assert "rs_oracle" not in out
 
 
 # ------------------------------------------------- Cauchy family (extra mode)

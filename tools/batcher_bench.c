@@ -52,7 +52,7 @@ int main(int argc, char **argv)
 	const int N = T * P;
 	gec_codec *c;
 	gbm_manager *m;
-	if (gec_codec_create(10, 4, 0, &c) != GEC_OK || gbm_create(c, 16, NULL, 0, &m) != GBM_OK) {
+	if (gec_codec_create(10, 4, GEC_BACKEND_AUTO, 0, &c) != GEC_OK || gbm_create(c, 16, NULL, 0, &m) != GBM_OK) {
 		fprintf(stderr, "setup failed: %s / %s\n", gec_last_error(), gbm_last_error());
 		return 2;
 	}
