@@ -92,10 +92,26 @@ def secondary_bounds():
         return None
 
 
-def cpu_baseline(S: int):
+def host_description() -> dict:
+    """What the CPU figures were measured on: lscpu model / sockets / threads, nproc, the OpenMP environment."""
+    info = {"nproc": os.cpu_count(), "omp_env": {k: v for k, v in os.environ.items() if k.startswith(("OMP_", "GOMP_", "KMP_"))}}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for line in out.splitlines():
+            key, _, val = line.partition(":")
+            key, val = key.strip(), val.strip()
+            if key in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core", "NUMA node(s)", "CPU(s)"):
+                info["lscpu_" + key.lower().replace("(s)", "s").replace(" ", "_")] = val
+    except (OSError, subprocess.SubprocessError):
+        pass
+    return info
+
+
+def cpu_baseline(S: int, quick: bool = False):
     """Oracle C restatement (split-nibble AVX2 when available, OpenMP over blocks,
     buffers first-touched by the threads that encode them) on a bounded sample of
-    the same workload; thread count swept and the best reported with its count."""
+    the same workload; thread count swept and the best reported with its count.
+    quick: the two largest thread counts only, 3 repetitions (the in-process cross-check)."""
     from oracle import rs_oracle as O
 
     co = O.COracle()
@@ -104,15 +120,18 @@ def cpu_baseline(S: int):
     t0 = time.perf_counter()
     best = None
     sweep = {}
-    for thr in sorted({t for t in (maxthr, maxthr // 2, maxthr // 4, 32, 16) if 1 <= t <= maxthr}, reverse=True):
+    counts = sorted({t for t in (maxthr, maxthr // 2, maxthr // 4, 32, 16) if 1 <= t <= maxthr}, reverse=True)
+    for thr in (counts[:2] if quick else counts):
         nb = 2048  # 3 GB of stripes: well past the host's L3 (2 x 256 MB on the EPYC 9575F box)
-        sec = co.bench_encode(K, M, S, nb, 5, variant, thr)
+        sec = co.bench_encode(K, M, S, nb, 3 if quick else 5, variant, thr)
         rate = nb * BLOCK_LEN / sec / 2**30
         sweep[str(thr)] = round(rate, 2)
         if best is None or rate > best[0]:
             best = (rate, thr, nb)
         if time.perf_counter() - t0 > 20:
             break
+    if quick:
+        return {"value": round(best[0], 2), "unit": "GiB/s", "cores": best[1], "threads_sweep_GiBps": sweep}
     scalar1 = 16 * BLOCK_LEN / co.bench_encode(K, M, S, 16, 3, co.SCALAR, 1) / 2**30
     simd1 = 64 * BLOCK_LEN / co.bench_encode(K, M, S, 64, 5, variant, 1) / 2**30
     return {
@@ -128,6 +147,81 @@ def cpu_baseline(S: int):
         "one_thread_scalar_GiBps": round(scalar1, 3),
         "one_thread_simd_GiBps": round(simd1, 3),
     }
+
+
+def cpu_backend_rate(S: int, nb: int = 512) -> dict:
+    """The PRODUCT's own CPU backend (GEC_BACKEND_CPU, garage_amd/csrc/ec_cpu.cpp) on the same sample, through the C
+    ABI (gec_encode_batch on a CPU codec): what a node without a GPU falls back to.  Reported beside cpu_baseline, never
+    as it (the baseline is the oracle's restatement of the crate)."""
+    import ctypes
+
+    import numpy as np
+
+    import garage_amd as g
+    from garage_amd._lib import check, lib
+
+    rs = g.ReedSolomon(K, M, backend="cpu")
+    rng = np.random.default_rng(3)
+    blocks = [rng.integers(0, 256, K * S, dtype=np.uint8) for _ in range(nb)]
+    outs = [np.empty(M * S, dtype=np.uint8) for _ in range(nb)]
+    ptrs = (ctypes.c_void_p * nb)(*[b.ctypes.data for b in blocks])
+    optrs = (ctypes.c_void_p * nb)(*[o.ctypes.data for o in outs])
+    lens = (ctypes.c_size_t * nb)(*[BLOCK_LEN] * nb)
+    best = None
+    for _ in range(5):
+        t0 = time.perf_counter()
+        check(lib.gec_encode_batch(rs._h, nb, ptrs, lens, S, optrs), "gec_encode_batch")
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": round(nb * BLOCK_LEN / best / 2**30, 2), "unit": "GiB/s", "kernel": lib.gec_cpu_isa().decode(),
+            "threads": int(os.environ.get("GEC_CPU_THREADS", "0")) or min(os.cpu_count() or 1, 16),
+            "sample": f"{nb} blocks x 1 MiB RS(10,4) gec_encode_batch on a GEC_BACKEND_CPU codec, best of 5"}
+
+
+def cpu_baseline_only() -> None:
+    """`bench.py --cpu-baseline-only`: the CPU figures in a process of their own -- nothing of HIP or torch is loaded
+    while the oracle is timed (the in-process figure of round 2 fell from 388 to 259 GiB/s at 64 threads and from 333
+    to 21 at 128 with an unchanged oracle: whatever else the bench process had running took part)."""
+    S = (BLOCK_LEN + K - 1) // K
+    S = (S + 63) // 64 * 64
+    out = cpu_baseline(S)
+    out["host"] = host_description()
+    out["process"] = "fresh subprocess, before any HIP / torch initialisation; OMP_PROC_BIND=close OMP_PLACES=cores"
+    try:
+        out["cpu_backend"] = cpu_backend_rate(S)   # loads libgarage_ec (and torch, as plumbing) only AFTER the oracle was timed
+    except Exception as e:  # noqa: BLE001
+        out["cpu_backend"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_subprocess():
+    """Runs cpu_baseline_only() in a fresh interpreter with an explicit OpenMP placement; None on failure."""
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores")
+    env.pop("OMP_NUM_THREADS", None)
+    env.setdefault("GEC_CPU_THREADS", str(min(os.cpu_count() or 1, 64)))
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], env=env, capture_output=True, text=True,
+                           timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # noqa: BLE001 -- a reported baseline must never cost the headline line
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def cpu_baseline_object(args, S: int):
+    """cpu_baseline of the line: the subprocess figure (taken before this process touched the GPU), with the
+    in-process figure -- same oracle, same sample, measured now, HIP runtime and torch loaded -- beside it."""
+    out = getattr(args, "cpu_pre", None)
+    if not out or "error" in out:
+        base = cpu_baseline(S)
+        base["process"] = "in-process (the subprocess measurement failed: " + str((out or {}).get("error")) + ")"
+        return base
+    try:
+        out["in_process"] = cpu_baseline(S, quick=True)
+        out["in_process"]["process"] = "the bench process itself, after the GPU work (HIP runtime, torch and the codec's threads loaded)"
+    except Exception as e:  # noqa: BLE001
+        out["in_process"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
 
 
 def oracle_check_sample(st, nb: int, S: int) -> int:
@@ -409,6 +503,29 @@ def run_procs(args) -> None:
     del job
     torch.cuda.empty_cache()
 
+    # ---- every GPU fed from host memory at once (N>1: the question one host with N x16 links has to answer)
+    if (world > 1 and not args.no_host_fed) or args.host_fed:
+        try:
+            rs_h = g.ReedSolomon(K, M, device=R.local_rank)
+            reps = max(2, min(8, args.steps // 100 or 2))
+            sec = host_fed_section(rs_h, args.host_blocks, reps, barrier, seed=100 + rank)
+            per = []
+            cols = {}
+            for kind in ("pinned", "pageable"):
+                cols[kind] = {"t0": distrib.gather_ints(R, int(sec[kind]["t0"] * 1e6)), "t1": distrib.gather_ints(R, int(sec[kind]["t1"] * 1e6)),
+                              "rate": distrib.gather_ints(R, int(sec[kind]["GiBps"] * 1000)),
+                              "exact": distrib.gather_ints(R, int(sec[kind]["bit_exact"])), "checked": distrib.gather_ints(R, sec[kind]["checked"])}
+            if rank == 0:
+                for q in range(world):
+                    per.append({kind: {"t0": cols[kind]["t0"][q] / 1e6, "t1": cols[kind]["t1"][q] / 1e6, "GiBps": cols[kind]["rate"][q] / 1000,
+                                       "bit_exact": bool(cols[kind]["exact"][q]), "checked": cols[kind]["checked"][q]}
+                                for kind in ("pinned", "pageable")})
+                out["host_fed"] = host_fed_object(per, args.host_blocks, reps)
+            del rs_h
+        except Exception as e:  # noqa: BLE001 -- a secondary object must never cost the headline line
+            if rank == 0:
+                out["host_fed"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+
     # ---- BASELINE config 5 beside it when there is more than one GPU (or on request): the path's one
     # real exchange step.  Guarded by a watchdog so that a collective that hangs cannot take the
     # headline line with it.
@@ -437,7 +554,7 @@ def run_procs(args) -> None:
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S)
+            out["cpu_baseline"] = cpu_baseline_object(args, S)
         if world == 1 and not args.no_host_path:
             out.update(host_path_objects())
         print(json.dumps(out), flush=True)
@@ -471,6 +588,7 @@ def run_threads(args) -> None:
     res = [None] * world
     err = []
     bar = threading.Barrier(world)
+    hf_reps = max(2, min(8, args.steps // 100 or 2))
 
     def worker(t: int):
         try:
@@ -499,8 +617,13 @@ def run_threads(args) -> None:
                 checked = 0 if args.no_oracle_check else oracle_check_sample(job.st, nb, S)
             if not ok:
                 raise AssertionError("verify failed on bench output")
+            hf = None
+            if (world > 1 and not args.no_host_fed) or args.host_fed:
+                # N host threads, N codecs, N links at once: how a single Garage daemon would feed the node's GPUs
+                job.st = None
+                hf = host_fed_section(job.rs, args.host_blocks, hf_reps, bar.wait, seed=100 + t)
             res[t] = {"t0": t0, "t1": t1, "nb": nb, "kern_ms": ev0.elapsed_time(ev1) / args.steps, "cold": cold,
-                      "checked": checked}
+                      "checked": checked, "host_fed": hf}
         except BaseException as e:  # noqa: BLE001
             err.append(f"thread {t}: {type(e).__name__}: {e}")
             bar.abort()
@@ -522,9 +645,112 @@ def run_threads(args) -> None:
     out["parity_checked_blocks"] = sum(r["checked"] for r in res)
     out["rccl_ranks"] = None
     out["collective_backend"] = "none (single process; the encode path has no collective)"
+    if all(r["host_fed"] for r in res):
+        out["host_fed"] = host_fed_object([r["host_fed"] for r in res], args.host_blocks, hf_reps)
+    # the path's one collective, from this one process: a gec_group over the N devices (N threads, N codecs), an
+    # oracle-checked striped decode through it -- `rccl_ranks` is what RCCL connected
+    if (world > 1 and not args.no_striped) or args.striped:
+        try:
+            grp = threads_group_check(world, dry)
+            out["striped_decode"] = grp
+            out["rccl_ranks"] = grp.get("rccl_ranks")
+            out["collective_backend"] = grp.get("transport")
+        except Exception as e:  # noqa: BLE001
+            out["striped_decode"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(S)
+        out["cpu_baseline"] = cpu_baseline_object(args, S)
     print(json.dumps(out), flush=True)
+
+
+def threads_group_check(world: int, dry: bool) -> dict:
+    """One process, `world` threads, one RS(20,8) codec and one gec_group rank per device: create the group over RCCL
+    (ncclCommInitRank from every thread with rank 0's unique id), decode 8 oracle-encoded 4 MiB objects striped over
+    the ranks through both exchanges, compare every rebuilt shard on every rank with the oracle's stripes.
+    dry (GARAGE_DRYRUN_ONE_GPU=1: every codec on device 0, where RCCL refuses a second rank): the same flow over the
+    loopback gec_allgather_fn of tests/c (test transport, plumbing only)."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    import garage_amd as g
+    from garage_amd.striped import StripeLayout, gather_stripes, scatter_stripes
+    from oracle import rs_oracle as O
+
+    k, m, L, nobj = 20, 8, 4 << 20, 8
+    S = g.shard_len(k, L)
+    layout = StripeLayout(k, m, world)
+    lost = (0, 1, 5, 9, 13, 19, 21, 27)
+    present = [j not in lost for j in range(k + m)]
+    data = np.zeros((nobj, k * S), dtype=np.uint8)
+    data[:, :L] = O.splitmix64_bytes(0x6761726167650005, nobj * L).reshape(nobj, L)
+    data = data.reshape(nobj, k, S)
+    co = O.COracle()
+    full_np = np.concatenate([data, co.encode_batch(k, m, data, co.AVX2 if co.has_avx2() else co.SCALAR, threads=4)], axis=1)
+    lb = handle = None
+    if dry:
+        so = os.path.join(ROOT, "tests", "c", "libgec_loopback.so")
+        if not os.path.exists(so):
+            return {"skipped": "dry run on one device and tests/c/libgec_loopback.so is not built (RCCL refuses two ranks on one device)"}
+        lb = ctypes.CDLL(so)
+        lb.lb_create.restype = ctypes.c_void_p
+        lb.lb_create.argtypes = [ctypes.c_int]
+        lb.lb_destroy.argtypes = [ctypes.c_void_p]
+        lb.lb_rank_ctx.restype = ctypes.c_void_p
+        lb.lb_rank_ctx.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lb.lb_all_gather_ptr.restype = ctypes.c_void_p
+        lb.lb_all_to_all_ptr.restype = ctypes.c_void_p
+        handle = lb.lb_create(world)
+    uid = None if dry else g.Group.unique_id()
+    oks, errs, times = [None] * world, [], [None] * world
+    bar = threading.Barrier(world)
+
+    def rank_main(r: int):
+        try:
+            d = 0 if dry else r
+            torch.cuda.set_device(d)
+            dev = torch.device("cuda", d)
+            with torch.cuda.stream(torch.cuda.Stream(dev)):
+                rs = g.ReedSolomon(k, m, device=d)
+                if dry:
+                    grp = g.Group(rs, r, world, transport=(lb.lb_all_gather_ptr(), lb.lb_all_to_all_ptr(), lb.lb_rank_ctx(handle, r)))
+                else:
+                    grp = g.Group(rs, r, world, uid)
+                full = torch.from_numpy(full_np).to(dev)
+                broken = full.clone()
+                broken[:, list(lost)] = 0xEE
+                mine = scatter_stripes(broken, layout, r)
+                got = gather_stripes(grp.allgather_decode(mine, present), layout)
+                torch.cuda.current_stream().synchronize()
+                ok = bool(torch.equal(got, full))
+                reb = grp.alltoall_decode(mine, present)
+                torch.cuda.current_stream().synchronize()
+                ok = ok and all(bool(torch.equal(reb[i], full[:, j])) for i, j in enumerate(sorted(lost)))
+                bar.wait()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    grp.allgather_decode(mine, present)
+                torch.cuda.current_stream().synchronize()
+                times[r] = (time.perf_counter() - t0) / 5
+                oks[r] = ok
+                grp.close()
+        except BaseException as e:  # noqa: BLE001
+            errs.append(f"rank {r}: {type(e).__name__}: {e}")
+            bar.abort()
+
+    ts = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    [x.start() for x in ts]
+    [x.join(timeout=120) for x in ts]
+    hung = any(x.is_alive() for x in ts)
+    if lb is not None and not hung:
+        lb.lb_destroy(handle)
+    if errs or hung:
+        return {"error": ("a rank hung; " if hung else "") + "; ".join(errs)[:400]}
+    return {"rccl_ranks": None if dry else world, "ranks": world,
+            "transport": "loopback test transport (DRY RUN on one device)" if dry else f"RCCL: gec_group_create over {world} devices from one process",
+            "bit_exact": all(oks), "bit_exact_objects": nobj, "bit_exact_against": "stripes encoded by the CPU oracle; both exchanges, every rank",
+            "allgather_decode_ms": round(max(times) * 1e3, 3),
+            "config": {"workload": f"BASELINE config 5 check: RS(20,8), {nobj} x 4 MiB objects striped over {world} ranks, 8 erasures", "shard_len": S}}
 
 
 # ------------------------------------------------------------------ BASELINE config 5
@@ -573,13 +799,20 @@ def striped_decode_bench(args, R, distrib, progress=None) -> dict:
             return grp.alltoall_decode(local, present, out=out)
         return striped_reconstruct_alltoall(rs, local, present, layout)
 
-    # -- bit-exact check: same seeded objects on every rank
+    # -- bit-exact check: same seeded objects on every rank; the stripes they must decode to are encoded by the CPU
+    #    ORACLE on the host (8 x 4 MiB: milliseconds), never by the kernel under test
+    import numpy as np
+
+    from oracle import rs_oracle as O
+
     ncheck = 8
-    gen = torch.Generator(device=R.device)
-    gen.manual_seed(0x6761726167650005)
-    full = torch.zeros((ncheck, k + m, S), dtype=torch.uint8, device=R.device)
-    full[:, :k].reshape(ncheck, k * S)[:, :L] = torch.randint(0, 256, (ncheck, L), dtype=torch.uint8, device=R.device, generator=gen)
-    rs.encode_dev(full)
+    payload = O.splitmix64_bytes(0x6761726167650005, ncheck * L).reshape(ncheck, L)
+    data = np.zeros((ncheck, k * S), dtype=np.uint8)
+    data[:, :L] = payload
+    data = data.reshape(ncheck, k, S)
+    co = O.COracle()
+    parity = co.encode_batch(k, m, data, co.AVX2 if co.has_avx2() else co.SCALAR, threads=4)
+    full = torch.from_numpy(np.concatenate([data, parity], axis=1)).to(R.device)
     broken = full.clone()
     broken[:, list(lost)] = 0xEE
     mine = scatter_stripes(broken, layout, R.rank)
@@ -626,6 +859,7 @@ def striped_decode_bench(args, R, distrib, progress=None) -> dict:
         "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "bit_exact": ok_all, "bit_exact_objects": ncheck,
+        "bit_exact_against": "stripes encoded by the CPU oracle (oracle/rs_oracle.c) on the host; every rebuilt shard compared on every rank",
         "rccl_ranks": (grp.nranks if grp is not None else dist.get_world_size()),
         "config": {"workload": f"BASELINE config 5: RS(20,8), {nobj} x 4 MiB objects striped over the ranks, 8 erasures",
                    "k": k, "m": m, "shard_len": S, "slots_per_rank": layout.slots,
@@ -647,8 +881,91 @@ def striped_decode_bench(args, R, distrib, progress=None) -> dict:
     if own_pg:
         dist.destroy_process_group()
     if not (ok_all and ok_a2a_all):
-        res["error"] = "striped decode result differs from the locally encoded stripes"
+        res["error"] = "striped decode result differs from the oracle's stripes"
     return res
+
+
+# ------------------------------------------------- every GPU fed from host memory at once
+HOST_TRAFFIC_MODEL = {
+    # host-memory bytes moved per payload byte, RS(10,4) encode + all 14 shard checksums through gec_encode_hash_batch
+    "pinned": 1.0 * (10 * 104896 / 1048576) + 0.4 * (10 * 104896 / 1048576),   # the kernel reads k*S, writes m*S in place over the link
+    "pageable": (1.0 + 1.0 + 1.0 + 0.4 + 0.4 + 0.4) * (10 * 104896 / 1048576),  # memcpy in (r+w), DMA read, DMA write, memcpy out (r+w)
+}
+
+
+def host_fed_section(rs, nb: int, reps: int, barrier, seed: int) -> dict:
+    """One GPU's share of the host-fed measurement: `nb` 1 MiB blocks pushed through gec_encode_hash_batch (encode +
+    the checksum of every shard, what rpc_put_block needs) `reps` times, first from pinned caller memory (read in
+    place over the link), then from ordinary pageable memory (staged), between barriers so that every GPU of the node
+    pulls on the host's memory system at the same time.  Parity and checksums of a strided sample are compared with
+    the CPU oracle / hashlib afterwards."""
+    import ctypes
+
+    import numpy as np
+
+    import garage_amd as g
+    from garage_amd._lib import check, lib
+    from oracle import rs_oracle as O
+
+    S = g.shard_len(K, BLOCK_LEN)
+    n = K + M
+    rng = np.random.default_rng(seed)
+    res = {}
+    for kind in ("pinned", "pageable"):
+        alloc = (lambda nbytes: g.host_alloc(nbytes)) if kind == "pinned" else (lambda nbytes: np.empty(nbytes, dtype=np.uint8))
+        blocks = [alloc(K * S) for _ in range(nb)]
+        outs = [alloc(M * S) for _ in range(nb)]
+        for b in blocks:
+            b[:BLOCK_LEN] = rng.integers(0, 256, BLOCK_LEN, dtype=np.uint8)
+            b[BLOCK_LEN:] = 0
+        lens = (ctypes.c_size_t * nb)(*[BLOCK_LEN] * nb)
+        ptrs = (ctypes.c_void_p * nb)(*[b.ctypes.data for b in blocks])
+        optrs = (ctypes.c_void_p * nb)(*[o.ctypes.data for o in outs])
+        sums = np.zeros((nb, n, 32), dtype=np.uint8)
+        sp = sums.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+        run = lambda: check(lib.gec_encode_hash_batch(rs._h, nb, ptrs, lens, S, optrs, sp), "gec_encode_hash_batch")  # noqa: E731
+        run()
+        run()
+        barrier()
+        t0 = time.time()   # wall clock: comparable across the ranks of one node
+        for _ in range(reps):
+            run()
+        t1 = time.time()
+        barrier()
+        # the oracle's word on a strided sample of what the last call left in the caller's buffers
+        co = O.COracle()
+        idx = sorted(set(np.linspace(0, nb - 1, min(8, nb)).astype(int).tolist()))
+        data = np.stack([np.asarray(blocks[i]).reshape(K, S) for i in idx])
+        want = co.encode_batch(K, M, data, co.AVX2 if co.has_avx2() else co.SCALAR, threads=2)
+        got = np.stack([np.asarray(outs[i]).reshape(M, S) for i in idx])
+        exact = bool(np.array_equal(got, want))
+        for q, i in enumerate(idx[:2]):
+            for j in (0, K - 1, K, n - 1):
+                sh = data[q, j] if j < K else want[q, j - K]
+                exact = exact and sums[i, j].tobytes() == g.shardsum(sh.tobytes())
+        res[kind] = {"t0": t0, "t1": t1, "GiBps": nb * reps * BLOCK_LEN / (t1 - t0) / 2**30, "bit_exact": exact, "checked": len(idx)}
+        if kind == "pinned":
+            for a in blocks + outs:
+                g.host_free(a)
+        del blocks, outs
+    return res
+
+
+def host_fed_object(per_gpu: list, nb: int, reps: int) -> dict:
+    """per_gpu: host_fed_section results, one per GPU -> the `host_fed` object of the line."""
+    out = {"what": "every GPU fed from host memory at once: gec_encode_hash_batch (RS(10,4) encode + 14 shard checksums per block), "
+                   "1 MiB blocks, payload GiB/s -- PCIe-inclusive, never the `value`",
+           "blocks_per_gpu_and_call": nb, "calls": reps, "n_gpus": len(per_gpu)}
+    for kind in ("pinned", "pageable"):
+        rates = [r[kind]["GiBps"] for r in per_gpu]
+        span = max(r[kind]["t1"] for r in per_gpu) - min(r[kind]["t0"] for r in per_gpu)
+        agg = len(per_gpu) * nb * reps * BLOCK_LEN / span / 2**30
+        out[kind] = {"per_gpu_GiBps": [round(x, 2) for x in rates], "aggregate_GiBps": round(agg, 2),
+                     "host_memory_traffic_GBps_model": round(agg * 2**30 / 1e9 * HOST_TRAFFIC_MODEL[kind], 1),
+                     "host_bytes_per_payload_byte_model": round(HOST_TRAFFIC_MODEL[kind], 2),
+                     "bit_exact_vs_oracle": all(r[kind]["bit_exact"] for r in per_gpu),
+                     "blocks_checked": sum(r[kind]["checked"] for r in per_gpu)}
+    return out
 
 
 # ------------------------------------------------- the path above the kernel (N=1, rank 0)
@@ -740,9 +1057,23 @@ def main() -> None:
     ap.add_argument("--collective", choices=["torch", "cabi"], default="cabi",
                     help="striped decode: who drives RCCL -- libgarage_ec's gec_group_* C ABI (default) or torch.distributed")
     ap.add_argument("--launch-check", action="store_true", help="exercise only the launch plumbing (no GPU needed)")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="print only the cpu_baseline object (what the default run executes in a fresh subprocess before it touches the GPU)")
+    ap.add_argument("--no-host-fed", action="store_true",
+                    help="N>1: skip the host_fed object (every GPU fed from host memory through gec_encode_hash_batch at once)")
+    ap.add_argument("--host-fed", action="store_true", help="N=1: also run the host_fed object")
+    ap.add_argument("--host-blocks", type=int, default=256, help="host_fed: 1 MiB blocks per GPU and call")
     args = ap.parse_args()
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
+    if args.cpu_baseline_only:
+        cpu_baseline_only()
+        return
+    # the CPU baseline first, in a process of its own, before anything of HIP / torch is loaded here (N=1, rank 0)
+    args.cpu_pre = None
+    if (args.gpus == 1 and not args.no_cpu_baseline and not args.launch_check and args.op == "encode"
+            and int(os.environ.get("RANK", "0")) == 0):
+        args.cpu_pre = cpu_baseline_subprocess()
 
     if args.mode == "procs" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))

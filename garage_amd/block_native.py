@@ -30,6 +30,7 @@ SYMBOLS = [
     "gbm_set_read_hedge", "gbm_hedged_reads", "gbm_node_set_latency", "gbm_set_host_block_hash_max",
     "gbm_batcher_create", "gbm_batcher_destroy", "gbm_batcher_put_block", "gbm_batcher_set_ram_buffer_max", "gbm_batcher_stats",
     "gbm_env_table", "gbm_set_tranquility", "gbm_tranquilized_ms", "gbm_background_codec",
+    "gbm_batcher_submit", "gbm_batcher_wait", "gbm_set_maintenance_class",
 ]
 
 
@@ -145,6 +146,9 @@ def _load():
     lib.gbm_tranquilized_ms.restype = ctypes.c_uint64
     lib.gbm_background_codec.argtypes = [vp]
     lib.gbm_background_codec.restype = vp
+    lib.gbm_batcher_submit.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, sz, ci, tagp, pp]
+    lib.gbm_batcher_wait.argtypes = [vp]
+    lib.gbm_set_maintenance_class.argtypes = [vp, ci]
     return lib
 
 

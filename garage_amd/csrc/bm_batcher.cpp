@@ -178,12 +178,26 @@ void gbm_batcher_destroy(gbm_batcher *b)
 	delete b;
 }
 
-int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t *data, size_t len, int prevent_compression,
-			  const gbm_order_tag *order_tag)
-{
-	if (!b || !hash || (!data && len))
-		return fail(GBM_E_INVALID_ARG, "NULL argument");
+// The asynchronous pair: submit queues the block and returns at once (it only waits for RAM permits), wait blocks until
+// the batch that took the block has been fanned out.  This is the shape of `rpc_put_block(..)` as a future: a request
+// creates its futures in block order and keeps <= 3 of them pending (put.rs:486-511), so the blocks of one stream enter
+// the queue in `order` order -- which, with the fan-out turnstile, is what makes the OrderTag guarantee hold.
+struct gbm_put_ticket {
+	gbm_batcher *b;
 	gbm_batcher::Item it;
+};
+
+int gbm_batcher_submit(gbm_batcher *b, const uint8_t hash[32], const uint8_t *data, size_t len, int prevent_compression,
+		       const gbm_order_tag *order_tag, gbm_put_ticket **ticket_out)
+{
+	if (!b || !hash || (!data && len) || !ticket_out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	*ticket_out = nullptr;
+	std::unique_ptr<gbm_put_ticket> tk(new (std::nothrow) gbm_put_ticket());
+	if (!tk)
+		return fail(GBM_E_IO, "out of memory");
+	tk->b = b;
+	gbm_batcher::Item &it = tk->it;
 	it.hash = hash;
 	it.data = data;
 	it.len = len;
@@ -204,12 +218,34 @@ int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t 
 	b->ram_in_use_kb += need_kb;
 	b->queue.push_back(&it);
 	b->cv_work.notify_all();
-	b->cv_done.wait(lk, [&] { return it.done; });
-	if (it.rc == GBM_E_QUORUM)
-		return fail(it.rc, "Could not reach quorum");
-	if (it.rc != GBM_OK)
-		return fail(it.rc, "device batch failed");
+	*ticket_out = tk.release();
 	return GBM_OK;
+}
+
+int gbm_batcher_wait(gbm_put_ticket *ticket)
+{
+	if (!ticket)
+		return fail(GBM_E_INVALID_ARG, "NULL ticket");
+	std::unique_ptr<gbm_put_ticket> tk(ticket);
+	int rc;
+	{
+		std::unique_lock<std::mutex> lk(tk->b->mu);
+		tk->b->cv_done.wait(lk, [&] { return tk->it.done; });
+		rc = tk->it.rc;
+	}
+	if (rc == GBM_E_QUORUM)
+		return fail(rc, "Could not reach quorum");
+	if (rc != GBM_OK)
+		return fail(rc, "device batch failed");
+	return GBM_OK;
+}
+
+int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t *data, size_t len, int prevent_compression,
+			  const gbm_order_tag *order_tag)
+{
+	gbm_put_ticket *tk = nullptr;
+	int rc = gbm_batcher_submit(b, hash, data, len, prevent_compression, order_tag, &tk);
+	return rc ? rc : gbm_batcher_wait(tk);
 }
 
 int gbm_batcher_set_ram_buffer_max(gbm_batcher *b, size_t bytes)

@@ -307,6 +307,14 @@ int gbm_set_tranquility(gbm_manager *m, int scrub_tranquility, int resync_tranqu
 
 uint64_t gbm_tranquilized_ms(const gbm_manager *m) { return m ? m->tranquilized_ms.load() : 0; }
 
+int gbm_set_maintenance_class(gbm_manager *m, int background)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	m->maintenance_on_bg = background != 0;
+	return GBM_OK;
+}
+
 const gec_codec *gbm_background_codec(const gbm_manager *m) { return m ? m->bg_codec() : nullptr; }
 
 int gbm_set_read_hedge(gbm_manager *m, uint64_t hedge_us)

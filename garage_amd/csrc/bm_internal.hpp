@@ -468,7 +468,8 @@ struct gbm_manager {
 	// Maintenance (scrub, resync rebuilds) runs on a BACKGROUND-class sibling of `codec` (gec_codec_background): its
 	// device work yields to the request path's.  Owned; NULL when the sibling could not be created (then == codec).
 	gec_codec *bg_codec_owned = nullptr;
-	const gec_codec *bg_codec() const { return bg_codec_owned ? bg_codec_owned : codec; }
+	std::atomic<bool> maintenance_on_bg{true};  // gbm_set_maintenance_class (A/B: what the class buys)
+	const gec_codec *bg_codec() const { return bg_codec_owned && maintenance_on_bg.load() ? bg_codec_owned : codec; }
 	// Tranquilizer (src/util/tranquilizer.rs:38-69): after each maintenance batch that took t, sleep tranquility * t
 	// (resync.rs:46,568 reads its value from the persisted worker config; scrub has its own, repair.rs:386-390)
 	std::atomic<uint32_t> scrub_tranquility{0}, resync_tranquility{0};

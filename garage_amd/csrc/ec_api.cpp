@@ -63,34 +63,48 @@ void ForkJoinPool::parallel_for(size_t n, const std::function<void(size_t)> &fn)
 		std::lock_guard<std::mutex> g(mu_);
 		fn_ = &fn;
 		n_ = n;
-		next_ = 0;
+		// items are handed out in runs: an item may be as small as a 16 KiB column range (~10 us), and a lock per
+		// item would serialise the threads on the lock
+		grab_ = std::max<size_t>(1, n / (4 * (workers_.size() + 1)));
+		next_.store(0, std::memory_order_relaxed);
 		pending_ = n;
 		++epoch_;
 	}
 	cv_.notify_all();
 	work();
 	std::unique_lock<std::mutex> g(mu_);
-	done_cv_.wait(g, [this] { return pending_ == 0; });
+	done_cv_.wait(g, [this] { return pending_ == 0 && active_ == 0; });
 	fn_ = nullptr;
 }
 
 void ForkJoinPool::work()
 {
-	for (;;) {
-		size_t i;
-		const std::function<void(size_t)> *fn;
-		{
-			std::lock_guard<std::mutex> g(mu_);
-			if (!fn_ || next_ >= n_)
-				return;
-			i = next_++;
-			fn = fn_;
-		}
-		(*fn)(i);
+	const std::function<void(size_t)> *fn;
+	size_t n, grab;
+	{
 		std::lock_guard<std::mutex> g(mu_);
-		if (--pending_ == 0)
-			done_cv_.notify_all();
+		if (!fn_)
+			return;
+		fn = fn_;
+		n = n_;
+		grab = grab_;
+		++active_;  // parallel_for does not return (and fn stays alive) while a registered thread is in here
 	}
+	size_t done = 0;
+	for (;;) {
+		const size_t i0 = next_.fetch_add(grab, std::memory_order_relaxed);
+		if (i0 >= n)
+			break;
+		const size_t i1 = std::min(n, i0 + grab);
+		for (size_t i = i0; i < i1; ++i)
+			(*fn)(i);
+		done += i1 - i0;
+	}
+	std::lock_guard<std::mutex> g(mu_);
+	pending_ -= done;
+	--active_;
+	if (pending_ == 0 && active_ == 0)
+		done_cv_.notify_all();
 }
 
 void ForkJoinPool::run()

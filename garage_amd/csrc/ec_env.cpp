@@ -25,7 +25,6 @@ const Row kRows[] = {
 	{"GEC_VERIFY_SEGMENTS", "min(k, 16)", "A/B: upload stages of gec_decode_verify_batch (1 = upload, then hash)"},
 	{"GEC_PINNED_CHUNK_MB", "128", "chunk size of the staged path for pinned memory"},
 	{"GEC_HASH_FORK", "1", "A/B: 0 = encode + checksums on one stream instead of the data-shard checksums beside the encode"},
-	{"GEC_DEGRADED_GROUPS", "4", "gec_decode_verify_batch: blocks that need a decode are uploaded, decoded and hashed in this many groups, ordered by their first missing data shard (1 = one group after the whole upload)"},
 	{"GEC_BG_CUS", "64", "CUs a background-class codec's kernels may occupy (0 = no mask; link kernels stay on GEC_UPLOAD_CUS)"},
 	{"GEC_BG_CHUNK_MB", "32", "chunk size of a background-class codec's host-pointer trips (a foreground call waits for at most one)"},
 	{"GEC_BG_YIELD_US", "2000", "a background chunk waits up to this long for foreground calls on the same device to drain (0 = never waits)"},
@@ -61,7 +60,6 @@ const Env &env()
 		v.verify_segments = (int)get_long("GEC_VERIFY_SEGMENTS", 0);
 		v.pinned_chunk_mb = (size_t)std::max<long>(get_long("GEC_PINNED_CHUNK_MB", 128), 1);
 		v.hash_fork = get_long("GEC_HASH_FORK", 1) != 0;
-		v.degraded_groups = (int)std::min<long>(std::max<long>(get_long("GEC_DEGRADED_GROUPS", 4), 1), 12);
 		v.bg_cus = (int)get_long("GEC_BG_CUS", 64);
 		v.bg_chunk_mb = (size_t)std::max<long>(get_long("GEC_BG_CHUNK_MB", 32), 1);
 		v.bg_yield_us = (unsigned)std::max<long>(get_long("GEC_BG_YIELD_US", 2000), 0);

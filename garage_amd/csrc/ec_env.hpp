@@ -22,7 +22,6 @@ struct Env {
 	int verify_segments;    // GEC_VERIFY_SEGMENTS (0 = the built-in maximum)
 	size_t pinned_chunk_mb; // GEC_PINNED_CHUNK_MB
 	bool hash_fork;         // GEC_HASH_FORK
-	int degraded_groups;    // GEC_DEGRADED_GROUPS
 	// ---- HIP backend: background class
 	int bg_cus;             // GEC_BG_CUS
 	size_t bg_chunk_mb;     // GEC_BG_CHUNK_MB

@@ -109,14 +109,13 @@ struct Staging {
 	// run on for microseconds each, and a checksum chain sharing such a CU crawls (7x slower, measured); so the
 	// upload gets a few CUs of its own (the link needs very little in flight) and the chains the rest.
 	hipStream_t stream_up = nullptr, stream_chain = nullptr;
-	// streams for the groups of the degraded read path (decode + block checksum chain per group of blocks)
-	static constexpr int kMaxGroups = 12;
-	hipStream_t stream_grp[kMaxGroups] = {};
-	hipEvent_t ev_grp[kMaxGroups] = {};
+	// ... and a few more for kernels that WRITE host memory while uploads are still running (the rebuilt shards of
+	// the read path on their way home): sixteen CUs read host memory at the link's rate but cannot also write it
+	hipStream_t stream_down = nullptr;
+	hipEvent_t ev_dec[kMaxSeg] = {};  // "the decodes of stage s are done"
 	QosPolicy qos;  // set by the lease from the codec's class before anything is created
 
 	int ensure_segments(int num_cu);
-	int ensure_groups(int ngroups);
 	int ensure_big(size_t bytes);
 	int ensure_tab(size_t entries);
 	int ensure(size_t bytes, size_t nbad);

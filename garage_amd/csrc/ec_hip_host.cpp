@@ -448,6 +448,8 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 		std::shared_ptr<const Plan> plan;
 		std::vector<size_t> ids;
 		size_t base = 0, stripe = 0, npar = 0;
+		size_t j0 = 0;  // first missing data slot (k: none)
+		std::vector<size_t> rq;  // staging slot of every rebuilt shard that cannot be written to its buffer directly
 	};
 	std::map<std::string, Bucket> buckets;
 	for (size_t b = 0; b < nblocks; ++b) {
@@ -470,6 +472,7 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 		if (rc)
 			return rc;
 		bk.npar = bk.plan->missing.size();  // as many parity inputs as data shards to rebuild
+		bk.j0 = bk.npar ? (size_t)bk.plan->missing[0] : k;
 		bk.stripe = (k + bk.npar) * S;
 		bk.base = dev_bytes;
 		dev_bytes += bk.ids.size() * bk.stripe;
@@ -511,9 +514,8 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 		return rc;
 	uint64_t *h_soff = reinterpret_cast<uint64_t *>(st.h_buf + tab_off), *h_slen = h_soff + nup;
 	uint64_t *h_boff = h_slen + nup, *h_blen = h_boff + nblocks;
-	// -- block table: the blocks that need no decode first -- their checksum chains start while the upload is
-	//    still running (below); the others are hashed after their decode
-	size_t bi = 0, nh = 0, longest = 0;
+	// -- block table (the blocks that need no decode first)
+	size_t bi = 0, longest = 0;
 	std::vector<size_t> block_order(nblocks);
 	for (int pass = 0; pass < 2; ++pass) {
 		for (auto &kv : buckets) {
@@ -526,16 +528,31 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 				block_order[bi++] = kv.second.ids[i];
 			}
 		}
-		if (pass == 0)
-			nh = bi;
 	}
-	// Upload stages: stage s carries data slots [k*s/nseg, k*(s+1)/nseg) of the blocks that need no decode (stage 0
-	// also everything of the blocks that do).  One stage unless every shard is pinned (the staged path uploads
-	// dense device ranges block by block) and the chains are long enough to be worth hiding: a BLAKE2b chain runs
-	// at ~14 ms per MiB, the link moves the MiB of 512 such blocks in 10 ms.
-	// GEC_VERIFY_SEGMENTS (A/B): 1 = upload everything, then hash
+	// Upload stages.  A block's own checksum is one serial BLAKE2b chain -- ~10.6 ms per MiB whatever runs beside it,
+	// as long as the link needs for 512 such blocks -- so the chains must run WHILE the blocks arrive.  Data slot s
+	// belongs to stage(s) = the st with k*st/nseg <= s < k*(st+1)/nseg, and after every stage ONE segment launch
+	// advances the chain of every block of the batch over the 128-byte blocks of that stage's slots, in lock step.
+	// What a stage uploads is decided per block by its first missing data slot j0 (j0 = k for a block that needs no
+	// decode):
+	//   - data slot s < j0 travels in stage(s): it is there when the chains reach it;
+	//   - everything else the block is decoded from -- its data slots beyond j0, its parity inputs -- travels in
+	//     stage(j0): when the chains reach slot j0 the block is complete on the device, its decode (one launch per
+	//     erasure pattern, on the chain stream, right before the segment) has filled slot j0 and every later
+	//     missing slot, and the rebuilt shards start for home on a third stream while later stages still arrive.
+	// This is earliest-deadline-first for "slot s must be hashable at chain step s": a batch where EVERY block has
+	// lost data shards (a node of each stripe down) finishes a chain step after the last byte arrived, like a
+	// healthy one, instead of upload + decode + a whole chain (24.7 -> see profiles/r03_get_degraded.txt).
+	// One stage unless every shard is pinned (the staged path uploads dense device ranges block by block) and the
+	// chains are long enough to be worth hiding.  GEC_VERIFY_SEGMENTS (A/B): 1 = upload everything, then hash.
 	const int seg_max = env().verify_segments > 0 ? std::min(env().verify_segments, (int)Staging::kMaxSeg) : (int)Staging::kMaxSeg;
-	const size_t nseg = (all_pinned && block_sums && nh > 0 && longest >= (256u << 10)) ? std::min<size_t>(k, (size_t)seg_max) : 1;
+	const size_t nseg = (all_pinned && block_sums && longest >= (256u << 10)) ? std::min<size_t>(k, (size_t)seg_max) : 1;
+	auto stage_of_slot = [&](size_t slot) {
+		size_t sg = 0;
+		while (sg + 1 < nseg && k * (sg + 1) / nseg <= slot)
+			++sg;
+		return sg;
+	};
 	// -- upload list, in device order
 	struct Up {
 		const uint8_t *src;
@@ -554,11 +571,7 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 				const int j = bk.plan->valid[t];
 				const size_t slot = (size_t)j < k ? (size_t)j : k + q++;
 				const uint8_t *p = shards[b * n + j];
-				// stage of data slot j: the s with k*s/nseg <= j < k*(s+1)/nseg
-				size_t stage = 0;
-				if (bk.npar == 0 && nseg > 1)
-					while (k * (stage + 1) / nseg <= slot)
-						++stage;
+				const size_t stage = nseg == 1 ? 0 : stage_of_slot(std::min<size_t>(slot, bk.j0));  // parity inputs: slot >= k > j0
 				ups.push_back({p, bk.base + i * bk.stripe + slot * S, b * n + j, stage});
 			}
 		}
@@ -581,11 +594,38 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 		(void)hipStreamSynchronize(st.stream);
 		(void)hipStreamSynchronize(st.stream2);
 		(void)hipStreamSynchronize(st.stream3);
+		if (st.stream_down)
+			(void)hipStreamSynchronize(st.stream_down);
 		(void)hipEventDestroy(ev_up);
 		(void)hipEventDestroy(ev_sh);
 		return code;
 	};
-	bool healthy_hashed = false;
+	// decode of one erasure pattern, in place in the bucket's stripes; the rebuilt shards' way home is appended to `outs`
+	size_t rq = 0;
+	auto decode_bucket = [&](Bucket &bk, hipStream_t s, std::vector<gec::CopyEntry> &outs) -> int {
+		std::vector<size_t> in_off(k), out_off(bk.npar);
+		size_t q = 0;
+		for (size_t t = 0; t < k; ++t) {
+			const int j = bk.plan->valid[t];
+			in_off[t] = ((size_t)j < k ? (size_t)j : k + q++) * S;
+		}
+		for (size_t r = 0; r < bk.npar; ++r)
+			out_off[r] = (size_t)bk.plan->missing[r] * S;  // rebuilt in place, in the block's data area
+		int drc = launch_apply(c, st.d_big + bk.base, bk.stripe, st.d_big + bk.base, bk.stripe, nullptr, 0, S, bk.ids.size(),
+				       in_off.data(), out_off.data(), (int)bk.npar, bk.plan->rows.v.data(), gec::MODE_STORE, s);
+		if (drc)
+			return drc;
+		for (size_t i = 0; i < bk.ids.size(); ++i)
+			for (size_t r = 0; r < bk.npar; ++r) {
+				uint8_t *dst = rebuilt[bk.ids[i] * n + bk.plan->missing[r]];
+				const bool direct = aligned16(dst) && pinned().contains(dst, S);
+				outs.push_back({st.d_big + bk.base + i * bk.stripe + out_off[r], direct ? pinned().dev(dst) : st.h_buf + reb_off + rq * S, S});
+				bk.rq.push_back(rq++);
+			}
+		return GEC_OK;
+	};
+	const bool staged = all_pinned && nseg > 1;
+	hipStream_t down_stream = staged && st.stream_down ? st.stream_down : st.stream;
 	if (all_pinned) {
 		std::vector<std::vector<gec::CopyEntry>> ents(nseg);
 		for (size_t i = 0; i < ups.size();) {  // merge neighbours (the data shards of a block are slices of one buffer)
@@ -600,23 +640,41 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 			rc = launch_copy_table(st, ents[sg], up_stream);
 			if (rc)
 				return finish(rc);
-			if (nseg == 1)
+			if (!staged)
 				break;
-			// the chains of the no-decode blocks advance over what has arrived: whole 128-byte blocks below the
-			// end of this stage's last slot (the final stage finishes every message)
 			hipError_t es = hipEventRecord(st.ev_seg[sg], up_stream);
 			if (es == hipSuccess)
 				es = hipStreamWaitEvent(chain_stream, st.ev_seg[sg], 0);
 			if (es != hipSuccess)
 				return finish(hip_fail(es, "stage event"));
+			// the blocks whose first missing slot lies in this stage are complete now: decode them, send the rebuilt
+			// shards home on the down stream (beside the stages still to come: the link is full duplex)
+			std::vector<gec::CopyEntry> outs;
+			for (auto &kv : buckets)
+				if (kv.second.npar && stage_of_slot(kv.second.j0) == sg) {
+					rc = decode_bucket(kv.second, chain_stream, outs);
+					if (rc)
+						return finish(rc);
+				}
+			if (!outs.empty()) {
+				es = hipEventRecord(st.ev_dec[sg], chain_stream);
+				if (es == hipSuccess)
+					es = hipStreamWaitEvent(down_stream, st.ev_dec[sg], 0);
+				if (es != hipSuccess)
+					return finish(hip_fail(es, "decode event"));
+				rc = launch_copy_table(st, outs, down_stream);
+				if (rc)
+					return finish(rc);
+			}
+			// every chain advances over what is on the device now: whole 128-byte blocks below the end of this stage's
+			// last slot (the final stage finishes every message)
 			const uint64_t blk0 = (k * sg / nseg) * S / 128;
 			const uint64_t blk1 = sg + 1 == nseg ? ~0ull : (k * (sg + 1) / nseg) * S / 128;
-			rc = blake2_dev(c, nh, st.d_big, h_boff, h_blen, 0, 0, st.h_buf + bsum_off, chain_stream, 0, 0, 0, false, 0,
+			rc = blake2_dev(c, nblocks, st.d_big, h_boff, h_blen, 0, 0, st.h_buf + bsum_off, chain_stream, 0, 0, 0, false, 0,
 					reinterpret_cast<uint64_t *>(st.d_big + state_off), blk0, blk1);
 			if (rc)
 				return finish(rc);
 		}
-		healthy_hashed = nseg > 1;
 	} else {
 		// pageable shards: the pieces are images of dense device ranges, filled by the copy pool while the other is on the bus
 		ForkJoinPool &pool = copy_pool();
@@ -663,45 +721,32 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 	e = hipEventRecord(ev_sh, st.stream3);
 	if (e != hipSuccess)
 		return finish(hip_fail(e, "hipEventRecord"));
-	std::vector<gec::CopyEntry> outs;
-	size_t rq = 0;
-	for (auto &kv : buckets) {
-		Bucket &bk = kv.second;
-		if (bk.npar == 0)
-			continue;
-		std::vector<size_t> in_off(k), out_off(bk.npar);
-		size_t q = 0;
-		for (size_t t = 0; t < k; ++t) {
-			const int j = bk.plan->valid[t];
-			in_off[t] = ((size_t)j < k ? (size_t)j : k + q++) * S;
-		}
-		for (size_t r = 0; r < bk.npar; ++r)
-			out_off[r] = (size_t)bk.plan->missing[r] * S;  // rebuilt in place, in the block's data area
-		rc = launch_apply(c, st.d_big + bk.base, bk.stripe, st.d_big + bk.base, bk.stripe, nullptr, 0, S, bk.ids.size(),
-				  in_off.data(), out_off.data(), (int)bk.npar, bk.plan->rows.v.data(), gec::MODE_STORE, st.stream);
-		if (rc)
-			return finish(rc);
-		for (size_t i = 0; i < bk.ids.size(); ++i)
-			for (size_t r = 0; r < bk.npar; ++r) {
-				uint8_t *dst = rebuilt[bk.ids[i] * n + bk.plan->missing[r]];
-				const bool direct = aligned16(dst) && pinned().contains(dst, S);
-				outs.push_back({st.d_big + bk.base + i * bk.stripe + out_off[r], direct ? pinned().dev(dst) : st.h_buf + reb_off + rq * S, S});
-				++rq;
+	if (!staged) {
+		// one stage: decode per bucket, then the block checksums, then the rebuilt shards go home, all on the main stream
+		std::vector<gec::CopyEntry> outs;
+		for (auto &kv : buckets)
+			if (kv.second.npar) {
+				rc = decode_bucket(kv.second, st.stream, outs);
+				if (rc)
+					return finish(rc);
 			}
-	}
-	if (block_sums) {
-		const size_t first = healthy_hashed ? nh : 0;  // [0, nh) went through the segments above
-		rc = blake2_dev(c, nblocks - first, st.d_big, h_boff + first, h_blen + first, 0, 0, st.h_buf + bsum_off + 32 * first, st.stream);
+		if (block_sums) {
+			rc = blake2_dev(c, nblocks, st.d_big, h_boff, h_blen, 0, 0, st.h_buf + bsum_off, st.stream);
+			if (rc)
+				return finish(rc);
+		}
+		rc = launch_copy_table(st, outs, st.stream);
 		if (rc)
 			return finish(rc);
-	}
-	rc = launch_copy_table(st, outs, st.stream);
-	if (rc)
-		return finish(rc);
-	if (healthy_hashed) {
+	} else {
 		e = hipEventRecord(st.ev_join, chain_stream);
 		if (e == hipSuccess)
 			e = hipStreamWaitEvent(st.stream, st.ev_join, 0);
+		if (e == hipSuccess && down_stream != st.stream) {
+			e = hipEventRecord(st.ev_out, down_stream);
+			if (e == hipSuccess)
+				e = hipStreamWaitEvent(st.stream, st.ev_out, 0);
+		}
 		if (e != hipSuccess)
 			return finish(hip_fail(e, "join"));
 	}
@@ -716,14 +761,14 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 	if (block_sums)
 		for (size_t i = 0; i < nblocks; ++i)
 			std::memcpy(block_sums + 32 * block_order[i], st.h_buf + bsum_off + 32 * i, 32);
-	rq = 0;
 	for (auto &kv : buckets) {
 		Bucket &bk = kv.second;
+		size_t w = 0;
 		for (size_t i = 0; i < bk.ids.size(); ++i)
-			for (size_t r = 0; r < bk.npar; ++r, ++rq) {
+			for (size_t r = 0; r < bk.npar; ++r, ++w) {
 				uint8_t *dst = rebuilt[bk.ids[i] * n + bk.plan->missing[r]];
 				if (!(aligned16(dst) && pinned().contains(dst, S)))
-					std::memcpy(dst, st.h_buf + reb_off + rq * S, S);
+					std::memcpy(dst, st.h_buf + reb_off + bk.rq[w] * S, S);
 			}
 	}
 	return finish(GEC_OK);
@@ -905,6 +950,16 @@ int HipBackend::reconstruct_batch(size_t nblocks, const uint8_t *const *shards, 
 		if (nwanted)
 			buckets[key].push_back(b);
 	}
+	// a handful of blocks in ordinary memory: the host cores are done before a staged device trip has started
+	// (GEC_SMALL_CALL_BLOCKS, off by default)
+	if (!in_sums && nblocks <= env().small_call_blocks) {
+		bool any_pinned = false;
+		for (size_t i = 0; i < nblocks * n && !any_pinned; ++i)
+			any_pinned = shards[i] && pinned().contains(shards[i], S);
+		if (!any_pinned)
+			if (Backend *cpu = small_call_helper())
+				return cpu->reconstruct_batch(nblocks, shards, out, S, data_only, nullptr, nullptr);
+	}
 	ForkJoinPool &pool = copy_pool();
 	// one decode plan per bucket, cut down to the rows the caller wants
 	struct Work {
@@ -988,8 +1043,10 @@ int HipBackend::reconstruct_batch(size_t nblocks, const uint8_t *const *shards, 
 			std::vector<const uint8_t *> in(std::min(zch, ids.size()) * k);
 			std::vector<uint32_t> valid(in.size(), (uint32_t)S);
 			std::vector<uint8_t *> outp(std::min(zch, ids.size()) * nmiss);
-			for (size_t i0 = 0; i0 < ids.size() && !rc; i0 += sums ? zch : ids.size(), ++q) {
-				const size_t nb = sums ? std::min(zch, ids.size() - i0) : ids.size();
+			const bool chunked = sums || c->qos_class == GEC_CLASS_BACKGROUND;  // a background codec always goes in chunks
+			for (size_t i0 = 0; i0 < ids.size() && !rc; i0 += chunked ? zch : ids.size(), ++q) {
+				const size_t nb = chunked ? std::min(zch, ids.size() - i0) : ids.size();
+				background_yield(c);
 				if (!sums) {
 					in.resize(nb * k);
 					valid.assign(nb * k, (uint32_t)S);

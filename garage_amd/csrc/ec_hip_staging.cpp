@@ -78,33 +78,28 @@ int Staging::make_stream(hipStream_t *s)
 	return GEC_OK;
 }
 
-int Staging::ensure_groups(int ngroups)
-{
-	for (int i = 0; i < std::min(ngroups, (int)kMaxGroups); ++i) {
-		if (!stream_grp[i])
-			if (int rc = make_stream(&stream_grp[i]))
-				return rc;
-		if (!ev_grp[i])
-			HIP_TRY(hipEventCreateWithFlags(&ev_grp[i], hipEventDisableTiming));
-	}
-	return GEC_OK;
-}
-
 int Staging::ensure_segments(int num_cu)
 {
 	if (stream3)
 		return GEC_OK;
-	for (int i = 0; i < kMaxSeg; ++i)
+	for (int i = 0; i < kMaxSeg; ++i) {
 		HIP_TRY(hipEventCreateWithFlags(&ev_seg[i], hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&ev_dec[i], hipEventDisableTiming));
+	}
 	const int up_cus = env().upload_cus;  // 0 = no CU masks (A/B)
 	if (up_cus > 0 && up_cus < num_cu) {
 		const int words = (num_cu + 31) / 32;
-		std::vector<uint32_t> up(words, 0), rest(words, 0);
-		// the checksum side of a background codec keeps to its own CUs, like every other stream of it (make_stream)
-		const int rest_lo = qos.background && qos.compute_cus > 0 ? std::max(up_cus, num_cu - qos.compute_cus) : up_cus;
+		std::vector<uint32_t> up(words, 0), down(words, 0), rest(words, 0);
+		// CUs [0, up_cus): kernels that read host memory; [up_cus, 2*up_cus): kernels that write it; the rest: the
+		// checksum chains.  The checksum side of a background codec keeps to its own CUs, like every other stream of
+		// it (make_stream).
+		const int down_hi = 2 * up_cus < num_cu ? 2 * up_cus : up_cus;
+		const int rest_lo = qos.background && qos.compute_cus > 0 ? std::max(down_hi, num_cu - qos.compute_cus) : down_hi;
 		for (int i = 0; i < num_cu; ++i) {
 			if (i < up_cus)
 				up[i / 32] |= 1u << (i % 32);
+			else if (i < down_hi)
+				down[i / 32] |= 1u << (i % 32);
 			else if (i >= rest_lo)
 				rest[i / 32] |= 1u << (i % 32);
 		}
@@ -115,6 +110,10 @@ int Staging::ensure_segments(int num_cu)
 			if (stream_up)
 				(void)hipStreamDestroy(stream_up);
 			stream_up = stream_chain = nullptr;
+			(void)hipGetLastError();
+		}
+		if (stream_up && down_hi > up_cus && hipExtStreamCreateWithCUMask(&stream_down, (uint32_t)words, down.data()) != hipSuccess) {
+			stream_down = nullptr;
 			(void)hipGetLastError();
 		}
 	}
@@ -220,10 +219,9 @@ void Staging::release()
 		(void)hipStreamDestroy(stream_up);
 	if (stream_chain)
 		(void)hipStreamDestroy(stream_chain);
-	for (hipStream_t s : stream_grp)
-		if (s)
-			(void)hipStreamDestroy(s);
-	for (hipEvent_t e : ev_grp)
+	if (stream_down)
+		(void)hipStreamDestroy(stream_down);
+	for (hipEvent_t e : ev_dec)
 		if (e)
 			(void)hipEventDestroy(e);
 	const QosPolicy keep = qos;

@@ -61,7 +61,8 @@ private:
 	std::mutex mu_, call_mu_;
 	std::condition_variable cv_, done_cv_;
 	const std::function<void(size_t)> *fn_ = nullptr;
-	size_t n_ = 0, next_ = 0, pending_ = 0;
+	size_t n_ = 0, grab_ = 1, pending_ = 0, active_ = 0;
+	std::atomic<size_t> next_{0};
 	uint64_t epoch_ = 0;
 	bool stop_ = false;
 };

@@ -128,6 +128,9 @@ uint64_t gbm_tranquilized_ms(const gbm_manager *m);   /* total time slept by the
 /* The codec maintenance runs on (the manager's own BACKGROUND-class sibling of the codec it was given, or that
  * codec itself when no sibling could be created).  Borrowed. */
 const gec_codec *gbm_background_codec(const gbm_manager *m);
+/* A/B switch for measurements (tools/qos_bench): background = 0 runs maintenance on the request path's own codec,
+ * the way it did before the classes existed.  Default 1. */
+int gbm_set_maintenance_class(gbm_manager *m, int background);
 
 /* Worker threads of the manager's internal pool (copies, fan-out, gathers); default min(16, cores). */
 int gbm_set_threads(gbm_manager *m, int nthreads);
@@ -197,6 +200,15 @@ int gbm_batcher_create(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, 
 void gbm_batcher_destroy(gbm_batcher *b);
 int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t *data, size_t len,
 			  int prevent_compression, const gbm_order_tag *order_tag);
+/* The same as a future: gbm_batcher_submit queues the block and returns at once (it only waits for RAM permits);
+ * gbm_batcher_wait blocks until the block's batch has been fanned out, returns the block's result and frees the
+ * ticket (every ticket must be waited for exactly once, before gbm_batcher_destroy; `hash` and `data` must stay
+ * valid until then).  A request that submits its blocks in `order` order and keeps <= 3 tickets pending is
+ * put_block_and_meta's `buffered(PUT_BLOCKS_MAX_PARALLEL)` (src/api/s3/put.rs:486-511). */
+typedef struct gbm_put_ticket gbm_put_ticket;
+int gbm_batcher_submit(gbm_batcher *b, const uint8_t hash[32], const uint8_t *data, size_t len, int prevent_compression,
+		       const gbm_order_tag *order_tag, gbm_put_ticket **ticket_out);
+int gbm_batcher_wait(gbm_put_ticket *ticket);
 /* Config.block_ram_buffer_max (src/util/config.rs:74-76,276-278; default 256 MiB): bytes of blocks that
  * may be on their way to the storage nodes at once.  gbm_batcher_put_block takes len/1024 permits before it
  * queues the block and returns them when its batch has been fanned out (buffer_kb_semaphore,

@@ -1,0 +1,229 @@
+// put_get_callers.cpp -- SURVEY.md section 8 row a10 as a native test: the callers of the block path, the way the
+// S3 layer drives them, through the C API of libgarage_block:
+//
+//   PutObject   put_block_and_meta keeps at most PUT_BLOCKS_MAX_PARALLEL = 3 block puts of one request in flight
+//               (/root/reference/src/api/s3/put.rs:42,486-511), every block tagged OrderTag(stream of the request, index);
+//               many requests run at once.  Here: R request threads, each submitting its blocks in order through
+//               gbm_batcher_submit and keeping <= 3 tickets pending (gbm_batcher_wait = `.await` on the oldest).
+//   GetObject   the blocks of an object are fetched with a 2-deep prefetch (src/api/s3/get.rs:429, `.buffered(2)`),
+//               tagged the same way.  Here: G reader threads with 2 slots each, reading objects that were put
+//               earlier while the writers are still writing theirs.
+//
+// Checked: every put is acknowledged; the batcher coalesced (fewer device batches than blocks, some batch > 1 block);
+// no node ever saw a stream's PutShards out of `order` (gbm_node_order_violations == 0 everywhere) although blocks of
+// one stream land in different batches on different workers; with a RAM budget of two blocks (block_ram_buffer_max,
+// src/block/manager.rs:380-384) no batch ever holds more than two blocks and everything still completes; every
+// byte of every object reads back.
+//
+// Two builds (tests/c/Makefile): `put_get_callers_tsan` links the host-only product sources (CPU backend) under
+// ThreadSanitizer; `put_get_callers` links the real libraries -- GEC_BACKEND_AUTO picks the GPU on a GPU box.
+// usage: put_get_callers [requests] [blocks_per_object] [block_bytes] [readers]
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/garage_block.h"
+
+#define CHECK(cond)                                                                                              \
+	do {                                                                                                     \
+		if (!(cond)) {                                                                                   \
+			fprintf(stderr, "FAIL %s:%d: %s (gbm: %s)\n", __FILE__, __LINE__, #cond, gbm_last_error()); \
+			exit(1);                                                                                 \
+		}                                                                                                \
+	} while (0)
+
+namespace {
+
+constexpr int K = 10, M = 4, NNODES = 16;
+constexpr int PUT_BLOCKS_MAX_PARALLEL = 3;  // put.rs:42
+constexpr int GET_PREFETCH = 2;             // get.rs:429
+
+struct Object {
+	uint64_t stream_id;
+	std::vector<std::vector<uint8_t>> blocks;
+	std::vector<uint8_t> hashes;  // 32 bytes per block
+};
+
+void fill_block(std::vector<uint8_t> &b, uint64_t seed)
+{
+	uint64_t x = seed * 0x9E3779B97F4A7C15ull + 0x6761726167650010ull;
+	for (size_t i = 0; i + 8 <= b.size(); i += 8) {
+		x ^= x << 13;
+		x ^= x >> 7;
+		x ^= x << 17;
+		std::memcpy(&b[i], &x, 8);
+	}
+}
+
+Object make_object(uint64_t stream_id, int nblocks, size_t block_bytes, bool short_last = true)
+{
+	Object o;
+	o.stream_id = stream_id;
+	o.blocks.resize(nblocks);
+	o.hashes.resize((size_t)nblocks * 32);
+	for (int i = 0; i < nblocks; ++i) {
+		// the last block of an object is short, like a real upload's
+		o.blocks[i].assign(short_last && i + 1 == nblocks ? block_bytes / 2 + 7 : block_bytes, 0);
+		fill_block(o.blocks[i], stream_id * 1000 + i);
+		gbm_blake2sum(o.blocks[i].data(), o.blocks[i].size(), &o.hashes[(size_t)i * 32]);
+	}
+	return o;
+}
+
+// PutObject: the request submits its blocks in order and keeps at most PUT_BLOCKS_MAX_PARALLEL of them pending --
+// `buffered(PUT_BLOCKS_MAX_PARALLEL)` over futures created in block order (put.rs:486-511)
+void put_object(gbm_batcher *bt, const Object &o, std::atomic<uint64_t> &put_ns, std::atomic<uint64_t> &nput)
+{
+	struct Pending {
+		gbm_put_ticket *tk;
+		std::chrono::steady_clock::time_point t0;
+	};
+	std::vector<Pending> pending;
+	std::vector<gbm_order_tag> tags(o.blocks.size());
+	auto finish_oldest = [&] {
+		CHECK(gbm_batcher_wait(pending.front().tk) == GBM_OK);
+		put_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - pending.front().t0).count();
+		++nput;
+		pending.erase(pending.begin());
+	};
+	for (size_t i = 0; i < o.blocks.size(); ++i) {
+		if (pending.size() == (size_t)PUT_BLOCKS_MAX_PARALLEL)
+			finish_oldest();
+		tags[i] = gbm_order_tag{o.stream_id, (uint64_t)i};
+		Pending p{nullptr, std::chrono::steady_clock::now()};
+		CHECK(gbm_batcher_submit(bt, &o.hashes[i * 32], o.blocks[i].data(), o.blocks[i].size(), 0, &tags[i], &p.tk) == GBM_OK);
+		pending.push_back(p);
+	}
+	while (!pending.empty())
+		finish_oldest();
+}
+
+// GetObject: GET_PREFETCH slots fetch the object's blocks; every byte is compared
+void get_object(gbm_manager *mg, const Object &o, uint64_t read_stream, std::atomic<uint64_t> &nget)
+{
+	std::atomic<int> next{0};
+	std::vector<std::thread> slots;
+	for (int s = 0; s < GET_PREFETCH; ++s)
+		slots.emplace_back([&] {
+			std::vector<uint8_t> buf;
+			for (;;) {
+				const int i = next.fetch_add(1);
+				if (i >= (int)o.blocks.size())
+					return;
+				buf.assign(o.blocks[i].size() + 64, 0xEE);
+				size_t len = 0;
+				const gbm_order_tag tag{read_stream, (uint64_t)i};
+				CHECK(gbm_rpc_get_block(mg, &o.hashes[(size_t)i * 32], &tag, buf.data(), buf.size(), &len) == GBM_OK);
+				CHECK(len == o.blocks[i].size() && std::memcmp(buf.data(), o.blocks[i].data(), len) == 0);
+				++nget;
+			}
+		});
+	for (auto &t : slots)
+		t.join();
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+	const int requests = argc > 1 ? atoi(argv[1]) : 8;
+	const int per_object = argc > 2 ? atoi(argv[2]) : 9;
+	const size_t block_bytes = argc > 3 ? (size_t)atol(argv[3]) : 65536;
+	const int readers = argc > 4 ? atoi(argv[4]) : 3;
+
+	gec_codec *codec = nullptr;
+	CHECK(gec_codec_create(K, M, GEC_BACKEND_AUTO, 0, &codec) == GEC_OK);
+	gbm_manager *mg = nullptr;
+	CHECK(gbm_create(codec, NNODES, nullptr, 0, &mg) == GBM_OK);
+	gbm_batcher *bt = nullptr;
+	CHECK(gbm_batcher_create(mg, 64, 300, &bt) == GBM_OK);
+
+	// objects the readers fetch while the writers are busy: put first, through the same batcher
+	std::vector<Object> old_objs, new_objs;
+	for (int r = 0; r < readers; ++r)
+		old_objs.push_back(make_object(1000 + r, per_object, block_bytes));
+	for (int r = 0; r < requests; ++r)
+		new_objs.push_back(make_object(1 + r, per_object, block_bytes));
+	std::atomic<uint64_t> put_ns{0}, nput{0}, nget{0};
+	{
+		std::vector<std::thread> th;
+		for (const Object &o : old_objs)
+			th.emplace_back([&] { put_object(bt, o, put_ns, nput); });
+		for (auto &t : th)
+			t.join();
+	}
+	uint64_t st0[3];
+	CHECK(gbm_batcher_stats(bt, st0) == GBM_OK);
+
+	// ---- the mixed phase: R PutObjects and G GetObjects at once
+	put_ns = 0;
+	nput = 0;
+	const auto t0 = std::chrono::steady_clock::now();
+	{
+		std::vector<std::thread> th;
+		for (const Object &o : new_objs)
+			th.emplace_back([&] { put_object(bt, o, put_ns, nput); });
+		for (int r = 0; r < readers; ++r)
+			th.emplace_back([&, r] {
+				for (int pass = 0; pass < 3; ++pass)
+					get_object(mg, old_objs[r], 5000 + r * 10 + pass, nget);
+			});
+		for (auto &t : th)
+			t.join();
+	}
+	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	uint64_t st1[3];
+	CHECK(gbm_batcher_stats(bt, st1) == GBM_OK);
+	const uint64_t batches = st1[0] - st0[0], blocks = st1[1] - st0[1];
+	const double mean_put_ms = blocks ? put_ns.load() / 1e6 / (double)blocks : 0.0;
+	CHECK(blocks == (uint64_t)requests * per_object && nput.load() == blocks);
+	CHECK(nget.load() == (uint64_t)readers * 3 * per_object);
+	// coalescing: concurrent requests share device batches
+	if (requests >= 4)
+		CHECK(batches < blocks && st1[2] >= 2);
+	// OrderTag: no node saw a stream's blocks out of order, although they crossed batches and batcher workers
+	for (int nd = 0; nd < NNODES; ++nd)
+		CHECK(gbm_node_order_violations(mg, nd) == 0);
+	// every byte of what the writers put reads back (after the fact, whole objects)
+	for (const Object &o : new_objs)
+		get_object(mg, o, 9000 + o.stream_id, nget);
+
+	// ---- RAM permits: a budget of two blocks -- the queue can never hold more than two blocks, so no batch can
+	gbm_batcher_destroy(bt);
+	CHECK(gbm_batcher_create(mg, 64, 300, &bt) == GBM_OK);
+	CHECK(gbm_batcher_set_ram_buffer_max(bt, 2 * block_bytes) == GBM_OK);
+	std::vector<Object> tight;
+	for (int r = 0; r < 4; ++r)
+		tight.push_back(make_object(2000 + r, 4, block_bytes, /*short_last=*/false));
+	{
+		std::vector<std::thread> th;
+		for (const Object &o : tight)
+			th.emplace_back([&] { put_object(bt, o, put_ns, nput); });
+		for (auto &t : th)
+			t.join();
+	}
+	uint64_t st2[3];
+	CHECK(gbm_batcher_stats(bt, st2) == GBM_OK);
+	CHECK(st2[1] == 16 && st2[2] <= 2);
+	for (const Object &o : tight)
+		get_object(mg, o, 9500 + o.stream_id, nget);
+	for (int nd = 0; nd < NNODES; ++nd)
+		CHECK(gbm_node_order_violations(mg, nd) == 0);
+
+	const double mib = (double)blocks * (double)block_bytes / (1 << 20);
+	printf("put_get_callers: backend %s, %d PutObjects x %d blocks of %zu bytes (<=%d in flight each) beside %d GetObjects (prefetch %d): "
+	       "%llu blocks in %llu device batches (largest %llu), mean put %.3f ms, %.2f GiB/s put; 0 order violations; all bytes round-trip: OK\n",
+	       gec_codec_backend(codec) == GEC_BACKEND_CPU ? "cpu" : "hip", requests, per_object, block_bytes, PUT_BLOCKS_MAX_PARALLEL, readers,
+	       GET_PREFETCH, (unsigned long long)blocks, (unsigned long long)batches, (unsigned long long)st1[2],
+	       mean_put_ms, mib / 1024.0 / secs);
+	gbm_batcher_destroy(bt);
+	gbm_destroy(mg);
+	gec_codec_destroy(codec);
+	return 0;
+}

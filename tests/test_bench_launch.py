@@ -75,6 +75,13 @@ def test_gpu_procs_mode_two_ranks_on_one_gpu(launcher):
     assert len(per) == 2 and sum(per) == 128 == d["config"]["blocks_total"]
     assert d["parity_checked_blocks"] >= 32 and d["roofline"]["frac"] > 0 and "decode" in d
     assert len(d["roofline_frac_per_gpu"]) == 2 and all(0 < f < 1 for f in d["roofline_frac_per_gpu"])
+    # every GPU fed from host memory at once (both ranks push their blocks through gec_encode_hash_batch), oracle-checked
+    hf = d["host_fed"]
+    assert hf["n_gpus"] == 2
+    for kind in ("pinned", "pageable"):
+        assert len(hf[kind]["per_gpu_GiBps"]) == 2 and hf[kind]["aggregate_GiBps"] > 0
+        assert hf[kind]["bit_exact_vs_oracle"] is True and hf[kind]["blocks_checked"] >= 4
+        assert hf[kind]["host_memory_traffic_GBps_model"] > hf[kind]["aggregate_GiBps"]
 
 
 @pytest.mark.gpu
@@ -84,6 +91,22 @@ def test_gpu_threads_mode_two_codecs_on_one_gpu():
     per = d["config"]["blocks_per_rank"]
     assert len(per) == 2 and sum(per) == 128 and len(d["kernel_ms_per_gpu"]) == 2
     assert d["parity_checked_blocks"] >= 32
+    # two host threads, two codecs: the host-fed path, pinned and pageable, oracle-checked
+    hf = d["host_fed"]
+    for kind in ("pinned", "pageable"):
+        assert len(hf[kind]["per_gpu_GiBps"]) == 2 and hf[kind]["bit_exact_vs_oracle"] is True
+    # a one-process gec_group over the (logical) ranks: the striped decode against the ORACLE's stripes, both exchanges
+    sd = d["striped_decode"]
+    assert sd.get("bit_exact") is True and sd["ranks"] == 2 and "oracle" in sd["bit_exact_against"], sd
+
+
+@pytest.mark.gpu
+def test_gpu_striped_decode_is_checked_against_the_oracle():
+    """--op striped-decode at world 1 (RCCL with one rank): the rebuilt shards are compared with stripes the CPU oracle
+    encoded, not with the GPU's own encode."""
+    d = _run([sys.executable, BENCH, "--op", "striped-decode", "--steps", "100", "--striped-objects", "32"])
+    assert d["bit_exact"] is True and "oracle" in d["bit_exact_against"]
+    assert d["exchange"]["alltoall"]["bit_exact"] is True
 
 
 @pytest.mark.gpu

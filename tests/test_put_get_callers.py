@@ -1,0 +1,59 @@
+"""SURVEY.md section 8 row a10 -- the callers of the block path, replayed natively (tests/c/put_get_callers.cpp):
+R PutObject requests, each submitting its blocks in order with <= PUT_BLOCKS_MAX_PARALLEL = 3 in flight and an
+OrderTag per block (/root/reference/src/api/s3/put.rs:42,486-511), beside GetObject readers with a 2-deep prefetch
+(src/api/s3/get.rs:429), through gbm_batcher_submit / gbm_batcher_wait and gbm_rpc_get_block.  The harness asserts
+coalescing (gbm_batcher_stats), zero gbm_node_order_violations, RAM-permit back-pressure and that every byte round-trips;
+here it runs (1) under ThreadSanitizer over the product's CPU backend, (2) against the real libraries on the CPU
+backend, (3) on the GPU with 1 MiB blocks."""
+import os
+import re
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CDIR = os.path.join(HERE, "c")
+
+
+def _make(target):
+    r = subprocess.run(["make", "-C", CDIR, target], capture_output=True, text=True)
+    if r.returncode != 0 and "fsanitize" in (r.stdout + r.stderr) and "cannot find" in (r.stdout + r.stderr):
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def _check(out: str, backend: str):
+    assert "all bytes round-trip: OK" in out and "0 order violations" in out, out
+    assert f"backend {backend}" in out, out
+    m = re.search(r"(\d+) blocks in (\d+) device batches \(largest (\d+)\)", out)
+    assert m, out
+    blocks, batches, largest = map(int, m.groups())
+    assert batches < blocks and largest >= 2, out   # concurrent requests shared device batches
+
+
+def test_callers_under_tsan_on_the_cpu_backend():
+    _make("put_get_callers_tsan")
+    r = subprocess.run([os.path.join(CDIR, "put_get_callers_tsan"), "8", "9", "65536", "3"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, GEC_CPU_THREADS="4"))
+    if "FATAL: ThreadSanitizer: unexpected memory mapping" in r.stderr:
+        pytest.skip("TSan cannot run in this container (ASLR/memory layout)")
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
+    _check(r.stdout, "cpu")
+
+
+def test_callers_on_the_real_libraries_cpu_backend():
+    _make("put_get_callers")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="")   # GEC_BACKEND_AUTO -> the host cores
+    r = subprocess.run([os.path.join(CDIR, "put_get_callers"), "12", "8", "262144", "3"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _check(r.stdout, "cpu")
+
+
+@pytest.mark.gpu
+def test_callers_on_the_gpu_one_mib_blocks():
+    """16 PutObjects x 12 blocks of 1 MiB (48 puts in flight: the batcher's design load) beside 4 GetObjects."""
+    _make("put_get_callers")
+    r = subprocess.run([os.path.join(CDIR, "put_get_callers"), "16", "12", "1048576", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _check(r.stdout, "hip")
+    print(r.stdout)
