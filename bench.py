@@ -829,6 +829,7 @@ def striped_decode_bench(args, R, distrib, progress=None) -> dict:
     progress["stage"] = "bit-exact checks done"
 
     # -- timing: contents do not affect it
+    gen = torch.Generator(device=R.device)
     gen.manual_seed(0x6761726167650005 + 1 + R.rank)
     local = torch.randint(0, 256, (nobj, layout.slots, S), dtype=torch.uint8, device=R.device, generator=gen)
     steps = max(5, min(50, args.steps // 20))
@@ -905,6 +906,7 @@ def host_fed_section(rs, nb: int, reps: int, barrier, seed: int) -> dict:
 
     import garage_amd as g
     from garage_amd._lib import check, lib
+    from garage_amd.codec import host_alloc, host_free
     from oracle import rs_oracle as O
 
     S = g.shard_len(K, BLOCK_LEN)
@@ -912,7 +914,7 @@ def host_fed_section(rs, nb: int, reps: int, barrier, seed: int) -> dict:
     rng = np.random.default_rng(seed)
     res = {}
     for kind in ("pinned", "pageable"):
-        alloc = (lambda nbytes: g.host_alloc(nbytes)) if kind == "pinned" else (lambda nbytes: np.empty(nbytes, dtype=np.uint8))
+        alloc = (lambda nbytes: host_alloc(nbytes)) if kind == "pinned" else (lambda nbytes: np.empty(nbytes, dtype=np.uint8))
         blocks = [alloc(K * S) for _ in range(nb)]
         outs = [alloc(M * S) for _ in range(nb)]
         for b in blocks:
@@ -946,7 +948,7 @@ def host_fed_section(rs, nb: int, reps: int, barrier, seed: int) -> dict:
         res[kind] = {"t0": t0, "t1": t1, "GiBps": nb * reps * BLOCK_LEN / (t1 - t0) / 2**30, "bit_exact": exact, "checked": len(idx)}
         if kind == "pinned":
             for a in blocks + outs:
-                g.host_free(a)
+                host_free(a)
         del blocks, outs
     return res
 

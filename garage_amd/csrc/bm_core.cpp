@@ -33,8 +33,6 @@ const EnvRow kEnvRows[] = {
 	{"GBM_TRACE", "0", "1 = stage timings of the batched put / get / resync / scrub on stderr"},
 	{"GBM_PUT_SLICE", "64", "blocks per slice of a large untagged put"},
 	{"GBM_PUT_THREADS", "4", "put slices in flight"},
-	{"GBM_GET_SLICE", "0", "blocks per slice of a large get (0 = one device trip for the whole request)"},
-	{"GBM_GET_THREADS", "2", "get slices in flight"},
 	{"GBM_BATCHER_WORKERS", "2", "batches the coalescing batcher keeps in flight"},
 };
 long env_long(const char *name, long def)
@@ -55,10 +53,6 @@ const Env &env()
 		v.put_threads = (int)(pt > 0 && pt <= 8 ? pt : 4);
 		const long bw = env_long("GBM_BATCHER_WORKERS", 0);
 		v.batcher_workers = (int)(bw >= 1 && bw <= 16 ? bw : 2);
-		const long gs = env_long("GBM_GET_SLICE", 0);
-		v.get_slice = (size_t)(gs > 0 ? gs : 0);
-		const long gt = env_long("GBM_GET_THREADS", 0);
-		v.get_threads = (int)(gt > 0 && gt <= 8 ? gt : 2);
 		return v;
 	}();
 	return e;

@@ -52,8 +52,6 @@ struct Env {
 	size_t put_slice;         // GBM_PUT_SLICE
 	int put_threads;          // GBM_PUT_THREADS
 	int batcher_workers;      // GBM_BATCHER_WORKERS
-	size_t get_slice;         // GBM_GET_SLICE
-	int get_threads;          // GBM_GET_THREADS
 };
 const Env &env();
 const char *env_table_text();

@@ -231,11 +231,14 @@ void run_pass(const Program &p, int pass, const uint8_t *const *in, const int *a
 void apply_range(const Program &p, const uint8_t *const *in, const size_t *avail, uint8_t *const *out, size_t len)
 {
 	const int k = p.k;
-	// one input may straddle the end of the data: it is padded into a private buffer (at most one per block)
+	// one input may straddle the end of the data: it is padded into a private buffer (at most one per block).
+	// All scratch is per thread and only ever grows: a work item is ~10 us of arithmetic, and five heap allocations per
+	// item put every thread of the pool on the allocator's locks.
 	thread_local std::vector<uint8_t> pad;
-	std::vector<const uint8_t *> src(in, in + k);
-	std::vector<int> active;
-	active.reserve(k);
+	thread_local std::vector<const uint8_t *> src;
+	thread_local std::vector<int> active;
+	src.assign(in, in + k);
+	active.clear();
 	size_t npad = 0;
 	for (int t = 0; t < k; ++t)
 		if (avail[t] > 0 && avail[t] < len)
@@ -292,9 +295,12 @@ struct CpuBackend : Backend {
 			const Job &j = jobs[item / nch];
 			const size_t off = (item % nch) * kChunk, len = std::min(kChunk, S - off);
 			const int k = j.prog->k, rows = j.prog->rows;
-			std::vector<const uint8_t *> in(k);
-			std::vector<size_t> avail(k);
-			std::vector<uint8_t *> out(rows);
+			thread_local std::vector<const uint8_t *> in;
+			thread_local std::vector<size_t> avail;
+			thread_local std::vector<uint8_t *> out;
+			in.resize(k);
+			avail.resize(k);
+			out.resize(rows);
 			for (int t = 0; t < k; ++t) {
 				in[t] = j.in[t] + off;
 				avail[t] = j.valid[t] > off ? std::min(len, j.valid[t] - off) : 0;
@@ -356,11 +362,14 @@ struct CpuBackend : Backend {
 		pool->parallel_for(nblocks * nch, [&](size_t item) {
 			const size_t b = item / nch, off = (item % nch) * kChunk, len = std::min(kChunk, S - off);
 			thread_local std::vector<uint8_t> tmp;
+			thread_local std::vector<const uint8_t *> in;
+			thread_local std::vector<size_t> avail;
+			thread_local std::vector<uint8_t *> out;
 			if (tmp.size() < m * kChunk)
 				tmp.resize(m * kChunk);
-			std::vector<const uint8_t *> in(k);
-			std::vector<size_t> avail(k, len);
-			std::vector<uint8_t *> out(m);
+			in.resize(k);
+			avail.assign(k, len);
+			out.resize(m);
 			for (size_t t = 0; t < k; ++t)
 				in[t] = shards[b * n + t] + off;
 			for (size_t r = 0; r < m; ++r)

@@ -17,7 +17,7 @@ struct Row {
 // (tests/test_cabi_host.py checks that every GEC_* name in the sources appears here).
 const Row kRows[] = {
 	{"GEC_CPU_THREADS", "min(cores, 16)", "threads a CPU codec spreads one call over (1 = the calling thread only)"},
-	{"GEC_CPU_ISA", "auto", "CPU backend kernel: auto | gfni (AVX-512 + GFNI) | avx2 (split-nibble vpshufb) | scalar"},
+	{"GEC_CPU_ISA", "auto", "CPU backend kernel: auto, gfni (AVX-512 + GFNI), avx2 (split-nibble vpshufb) or scalar"},
 	{"GEC_SMALL_CALL_BLOCKS", "0", "a HIP codec answers pageable host-pointer encode / reconstruct calls of up to this many blocks on the host cores (0 = never)"},
 	{"GEC_COPY_THREADS", "7", "staging-copy threads per HIP codec for pageable caller memory (0 = copy on the calling thread)"},
 	{"GEC_ZERO_COPY", "1", "A/B: 0 = pinned caller memory goes through the device staging pipeline instead of being read in place"},
@@ -29,7 +29,7 @@ const Row kRows[] = {
 	{"GEC_BG_CHUNK_MB", "32", "chunk size of a background-class codec's host-pointer trips (a foreground call waits for at most one)"},
 	{"GEC_BG_YIELD_US", "2000", "a background chunk waits up to this long for foreground calls on the same device to drain (0 = never waits)"},
 	{"GEC_ROWS16", "1", "A/B: 0 = 9..16 output rows as 8-row passes instead of one 16-row pass"},
-	{"GEC_BLAKE2_KERNEL", "auto", "A/B: lane | quad forces one of the two plain-blake2 kernels"},
+	{"GEC_BLAKE2_KERNEL", "auto", "A/B: lane or quad forces one of the two plain-blake2 kernels"},
 	{"GEC_B2_ADD", "0", "A/B: 1 = 64-bit adds of the blake2 kernels spelled as 32-bit add / addc"},
 	{"GEC_MAX_COLS_PER_LAUNCH", "0", "test hook: cap on the 16-byte columns one launch covers, to exercise the multi-launch split on small inputs"},
 	{"GEC_RCCL_LIB", "librccl.so.1", "RCCL to dlopen for gec_group_*"},

@@ -80,6 +80,7 @@ struct QosPolicy {
 	bool background = false;
 	int stream_priority = 0;   // hipStreamCreateWithPriority value (background: the device's lowest)
 	int compute_cus = 0;       // > 0: the codec's streams are confined to this many CUs (of num_cu)
+	int compute_cus_plan = 0;  // GEC_BG_CUS as every codec of the process sees it: the CUs set aside for the background class
 	int num_cu = 0;
 };
 

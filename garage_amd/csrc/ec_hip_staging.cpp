@@ -88,20 +88,40 @@ int Staging::ensure_segments(int num_cu)
 	}
 	const int up_cus = env().upload_cus;  // 0 = no CU masks (A/B)
 	if (up_cus > 0 && up_cus < num_cu) {
+		// The chip is partitioned once, the same way for every codec of the process (CuPlan), so that the classes
+		// never share a CU:
+		//   [0, U)            foreground kernels that READ host memory   (the link needs very little in flight)
+		//   [U, 2U)           foreground kernels that WRITE host memory  (sixteen CUs cannot do both at link rate)
+		//   [2U, 2U + U/2)    background kernels that touch host memory, either way
+		//   [2U + U/2, N - B) foreground checksum kernels
+		//   [N - B, N)        everything else a background codec launches (B = GEC_BG_CUS)
+		// A kernel whose loads share a CU with microsecond-long host accesses crawls, and a foreground kernel is only
+		// done when its slowest workgroup is: a scrub's long checksum launch on the CUs a PutObject's small one lands on
+		// was what its p99 was made of (profiles/r03_qos.txt).  Without a usable partition (tiny device, B = 0) the
+		// background class falls back to sharing the foreground's CUs at the lowest stream priority.
 		const int words = (num_cu + 31) / 32;
-		std::vector<uint32_t> up(words, 0), down(words, 0), rest(words, 0);
-		// CUs [0, up_cus): kernels that read host memory; [up_cus, 2*up_cus): kernels that write it; the rest: the
-		// checksum chains.  The checksum side of a background codec keeps to its own CUs, like every other stream of
-		// it (make_stream).
-		const int down_hi = 2 * up_cus < num_cu ? 2 * up_cus : up_cus;
-		const int rest_lo = qos.background && qos.compute_cus > 0 ? std::max(down_hi, num_cu - qos.compute_cus) : down_hi;
-		for (int i = 0; i < num_cu; ++i) {
-			if (i < up_cus)
-				up[i / 32] |= 1u << (i % 32);
-			else if (i < down_hi)
-				down[i / 32] |= 1u << (i % 32);
-			else if (i >= rest_lo)
-				rest[i / 32] |= 1u << (i % 32);
+		const int U = up_cus, B = qos.compute_cus_plan;
+		const bool split = B > 0 && 2 * U + U / 2 + B + 16 <= num_cu && U >= 2;
+		auto mask = [&](int lo, int hi) {
+			std::vector<uint32_t> m(words, 0);
+			for (int i = lo; i < hi && i < num_cu; ++i)
+				m[i / 32] |= 1u << (i % 32);
+			return m;
+		};
+		std::vector<uint32_t> up, down, rest;
+		if (split && qos.background) {
+			up = mask(2 * U, 2 * U + U / 2);
+			rest = mask(num_cu - B, num_cu);
+		} else if (split) {
+			up = mask(0, U);
+			down = mask(U, 2 * U);
+			rest = mask(2 * U + U / 2, num_cu - B);
+		} else {
+			const int down_hi = 2 * U < num_cu ? 2 * U : U;
+			up = mask(0, U);
+			if (down_hi > U)
+				down = mask(U, down_hi);
+			rest = mask(down_hi, num_cu);
 		}
 		// (a runtime or partition mode without CU masks is not an error: the paths then share all CUs, slower)
 		if (hipExtStreamCreateWithCUMask(&stream_up, (uint32_t)words, up.data()) != hipSuccess)
@@ -112,7 +132,7 @@ int Staging::ensure_segments(int num_cu)
 			stream_up = stream_chain = nullptr;
 			(void)hipGetLastError();
 		}
-		if (stream_up && down_hi > up_cus && hipExtStreamCreateWithCUMask(&stream_down, (uint32_t)words, down.data()) != hipSuccess) {
+		if (stream_up && !down.empty() && hipExtStreamCreateWithCUMask(&stream_down, (uint32_t)words, down.data()) != hipSuccess) {
 			stream_down = nullptr;
 			(void)hipGetLastError();
 		}

@@ -1,0 +1,65 @@
+"""Foreground and background on one device (the reference keeps repair off the request path with a
+bounded worker pool and a Tranquilizer, /root/reference/src/block/resync.rs:43-46,513-599, src/util/tranquilizer.rs:38-69).
+tools/qos_bench puts a PutObject's three closed-loop callers beside a continuous gbm_scrub_all; with maintenance on the
+manager's BACKGROUND-class codec the puts keep their latency, without it they do not.  profiles/r03_qos.txt has the
+numbers (p99 1.04x solo with the class, 4.5x without; 48 callers: 1.30x / 6.9x); the bounds asserted here are loose."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import garage_amd as g
+from garage_amd import _lib
+from garage_amd import block_native as bn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_background_codec_is_a_sibling_with_the_same_code():
+    rs = g.ReedSolomon(10, 4, backend="cpu")
+    bg = rs.background()
+    assert bg.qos_class == _lib.GEC_CLASS_BACKGROUND and rs.qos_class == _lib.GEC_CLASS_FOREGROUND
+    assert bg.backend == rs.backend and (bg.parity_matrix() == rs.parity_matrix()).all()
+    mgr = bn.NativeBlockManager(rs, 16)
+    h = bn.lib.gbm_background_codec(mgr._h)
+    assert h and _lib.lib.gec_codec_class(h) == _lib.GEC_CLASS_BACKGROUND   # maintenance runs on a sibling the manager owns
+    assert bn.lib.gbm_set_tranquility(mgr._h, 2, 1) == 0 and bn.lib.gbm_tranquilized_ms(mgr._h) == 0
+    mgr.close()
+
+
+def test_tranquility_pauses_the_scrub():
+    """gbm_set_tranquility(scrub = 3): after a batch that kept the codec busy for t the worker sleeps 3 t."""
+    import time
+
+    rs = g.ReedSolomon(3, 1, backend="cpu")
+    mgr = bn.NativeBlockManager(rs, 6)
+    blocks = [bytes([i]) * 200_000 for i in range(40)]
+    mgr.rpc_put_blocks([(bn.blake2sum(b), b) for b in blocks])
+    t0 = time.perf_counter()
+    mgr.scrub_all()
+    plain = time.perf_counter() - t0
+    assert bn.lib.gbm_set_tranquility(mgr._h, 3, -1) == 0
+    t0 = time.perf_counter()
+    mgr.scrub_all()
+    slow = time.perf_counter() - t0
+    assert bn.lib.gbm_tranquilized_ms(mgr._h) > 0 and slow > plain
+    mgr.close()
+
+
+@pytest.mark.gpu
+def test_puts_keep_their_latency_beside_a_scrub_on_the_background_class():
+    exe = os.path.join(ROOT, "tools", "qos_bench")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "qos_bench"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([exe, "3", "1.5", "256"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout)
+    m_with = re.search(r"with the class:\s+put p99 ([0-9.]+)x solo, scrub at (\d+) % of its solo rate", r.stdout)
+    m_without = re.search(r"without the class:\s+put p99 ([0-9.]+)x solo", r.stdout)
+    assert m_with and m_without, r.stdout
+    with_x, scrub_pct, without_x = float(m_with.group(1)), int(m_with.group(2)), float(m_without.group(1))
+    assert "0 corruptions" in r.stdout and "backend hip" in r.stdout
+    assert with_x <= 1.6, r.stdout            # measured 1.04
+    assert scrub_pct >= 40, r.stdout          # measured 90
+    assert with_x < without_x, r.stdout       # measured 1.04 vs 4.5
