@@ -107,6 +107,29 @@ def host_description() -> dict:
     return info
 
 
+def physical_cores() -> int:
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        vals = {}
+        for line in out.splitlines():
+            key, _, val = line.partition(":")
+            vals[key.strip()] = val.strip()
+        return int(vals["Socket(s)"]) * int(vals["Core(s) per socket"])
+    except (OSError, KeyError, ValueError, subprocess.SubprocessError):
+        return 0
+
+
+def cpu_threads_probe(nthreads: int) -> None:
+    """`bench.py --cpu-threads-probe N`: the oracle's encode rate at exactly N threads under this process's OpenMP
+    environment (cpu_baseline_only runs it with different wait policies to name what starves the all-CPUs point)."""
+    from oracle import rs_oracle as O
+
+    co = O.COracle()
+    S = ((BLOCK_LEN + K - 1) // K + 63) // 64 * 64
+    sec = co.bench_encode(K, M, S, 2048, 3, co.AVX2 if co.has_avx2() else co.SCALAR, nthreads)
+    print(json.dumps({"threads": nthreads, "GiBps": round(2048 * BLOCK_LEN / sec / 2**30, 2)}), flush=True)
+
+
 def cpu_baseline(S: int, quick: bool = False):
     """Oracle C restatement (split-nibble AVX2 when available, OpenMP over blocks,
     buffers first-touched by the threads that encode them) on a bounded sample of
@@ -120,7 +143,12 @@ def cpu_baseline(S: int, quick: bool = False):
     t0 = time.perf_counter()
     best = None
     sweep = {}
-    counts = sorted({t for t in (maxthr, maxthr // 2, maxthr // 4, 32, 16) if 1 <= t <= maxthr}, reverse=True)
+    # thread counts: the physical cores first (the best point on every box seen so far), then every logical CPU (SMT
+    # siblings included: on these boxes that point collapses, see cpu_baseline_only), then fractions
+    phys = physical_cores() or maxthr
+    phys = min(phys, maxthr)
+    counts = [phys] + [t for t in (maxthr, phys // 2, phys // 4, 32, 16) if 1 <= t <= maxthr and t != phys]
+    counts = list(dict.fromkeys(counts))
     for thr in (counts[:2] if quick else counts):
         nb = 2048  # 3 GB of stripes: well past the host's L3 (2 x 256 MB on the EPYC 9575F box)
         sec = co.bench_encode(K, M, S, nb, 3 if quick else 5, variant, thr)
@@ -162,10 +190,10 @@ def cpu_backend_rate(S: int, nb: int = 512) -> dict:
 
     rs = g.ReedSolomon(K, M, backend="cpu")
     rng = np.random.default_rng(3)
-    blocks = [rng.integers(0, 256, K * S, dtype=np.uint8) for _ in range(nb)]
-    outs = [np.empty(M * S, dtype=np.uint8) for _ in range(nb)]
-    ptrs = (ctypes.c_void_p * nb)(*[b.ctypes.data for b in blocks])
-    optrs = (ctypes.c_void_p * nb)(*[o.ctypes.data for o in outs])
+    big = rng.integers(0, 256, nb * K * S, dtype=np.uint8)      # one arena for the blocks, one for the parity
+    outb = np.zeros(nb * M * S, dtype=np.uint8)
+    ptrs = (ctypes.c_void_p * nb)(*[big.ctypes.data + b * K * S for b in range(nb)])
+    optrs = (ctypes.c_void_p * nb)(*[outb.ctypes.data + b * M * S for b in range(nb)])
     lens = (ctypes.c_size_t * nb)(*[BLOCK_LEN] * nb)
     best = None
     for _ in range(5):
@@ -187,8 +215,32 @@ def cpu_baseline_only() -> None:
     out = cpu_baseline(S)
     out["host"] = host_description()
     out["process"] = "fresh subprocess, before any HIP / torch initialisation; OMP_PROC_BIND=close OMP_PLACES=cores"
+    # The point with one thread per LOGICAL CPU collapsed by 16x in round 2's line (and does here whenever it is run):
+    # with every CPU of the box inside a libgomp team that spin-waits at its barriers, anything else that becomes
+    # runnable (the gpurun agent, the driver's rocm-smi sampler, kernel threads) preempts one team member and the
+    # others spin for it.  Shown by running that one point again with a passive wait policy and with one CPU left free.
+    allcpus = out["host_threads_available"]
+    rate_all = out["threads_sweep_GiBps"].get(str(allcpus))
+    if rate_all is not None and rate_all < 0.5 * out["value"]:
+        probe = {}
+        for name, env_add, n in (("passive_wait", {"OMP_WAIT_POLICY": "passive"}, allcpus),
+                                 ("two_cpus_left_free", {}, max(1, allcpus - 2))):
+            try:
+                env = dict(os.environ, **env_add)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-threads-probe", str(n)], env=env, capture_output=True,
+                                   text=True, timeout=120)
+                probe[name] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            except Exception as e:  # noqa: BLE001
+                probe[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        out["all_logical_cpus_point"] = {"threads": allcpus, "GiBps_active_wait": rate_all, **probe,
+                                         "reading": "every logical CPU inside a spin-waiting OpenMP team: any other runnable thread on the box "
+                                                    "preempts a team member and the rest spin at the barrier; not a property of the encode loop"}
+    # the product's own CPU backend, in a process of ITS own: libgomp has bound this process's main thread to the first
+    # place (OMP_PROC_BIND=close), and threads created from it -- the CPU codec's pool -- would inherit that one core
     try:
-        out["cpu_backend"] = cpu_backend_rate(S)   # loads libgarage_ec (and torch, as plumbing) only AFTER the oracle was timed
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("OMP_", "GOMP_"))}
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-backend-only"], env=env, capture_output=True, text=True, timeout=240)
+        out["cpu_backend"] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     except Exception as e:  # noqa: BLE001
         out["cpu_backend"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     print(json.dumps(out), flush=True)
@@ -1061,6 +1113,8 @@ def main() -> None:
     ap.add_argument("--launch-check", action="store_true", help="exercise only the launch plumbing (no GPU needed)")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="print only the cpu_baseline object (what the default run executes in a fresh subprocess before it touches the GPU)")
+    ap.add_argument("--cpu-threads-probe", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-backend-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-host-fed", action="store_true",
                     help="N>1: skip the host_fed object (every GPU fed from host memory through gec_encode_hash_batch at once)")
     ap.add_argument("--host-fed", action="store_true", help="N=1: also run the host_fed object")
@@ -1068,6 +1122,12 @@ def main() -> None:
     args = ap.parse_args()
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
+    if args.cpu_threads_probe:
+        cpu_threads_probe(args.cpu_threads_probe)
+        return
+    if args.cpu_backend_only:
+        print(json.dumps(cpu_backend_rate(((BLOCK_LEN + K - 1) // K + 63) // 64 * 64)), flush=True)
+        return
     if args.cpu_baseline_only:
         cpu_baseline_only()
         return

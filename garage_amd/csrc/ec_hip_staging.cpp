@@ -53,6 +53,10 @@ PinnedRanges &pinned()
 	return r;
 }
 
+namespace {
+std::atomic<int> g_cu_masks{-1};  // gec_cu_masks_active: -1 not tried yet, 0 refused by the runtime, 1 masks, 2 masks + class partition
+}
+
 // ------------------------------------------------------------------ staging slots
 // Every stream of a slot is created here, so that the codec's class decides priority and CU mask in one place: a
 // background codec's streams are confined to qos.compute_cus CUs (the LAST ones of the chip -- the link kernels'
@@ -132,6 +136,7 @@ int Staging::ensure_segments(int num_cu)
 			stream_up = stream_chain = nullptr;
 			(void)hipGetLastError();
 		}
+		g_cu_masks.store(stream_up ? (split ? 2 : 1) : 0);
 		if (stream_up && !down.empty() && hipExtStreamCreateWithCUMask(&stream_down, (uint32_t)words, down.data()) != hipSuccess) {
 			stream_down = nullptr;
 			(void)hipGetLastError();
@@ -401,5 +406,7 @@ int gec_host_unregister(void *p)
 int gec_host_is_pinned(const void *p, size_t bytes) { return pinned().contains(p, bytes) ? 1 : 0; }
 
 uint64_t gec_qos_yields(int device) { return QosGate::of(device).yields(); }
+
+int gec_cu_masks_active(void) { return g_cu_masks.load(); }
 
 }  // extern "C"

@@ -137,6 +137,11 @@ int gec_codec_class(const gec_codec *c);   /* GEC_CLASS_* */
 int gec_codec_backend(const gec_codec *c); /* GEC_BACKEND_CPU or GEC_BACKEND_HIP (AUTO is resolved at creation) */
 /* times a background chunk found foreground work in flight on `device` and waited (process-wide counter) */
 uint64_t gec_qos_yields(int device);
+/* Whether this process's staging slots run on CU-masked streams (hipExtStreamCreateWithCUMask): -1 = no host-pointer
+ * path that wants them has run yet, 0 = the runtime / partition mode refused them (everything shares the CUs; a
+ * background codec then only has its low stream priority, its small chunks and its yields), 1 = masks for the link
+ * kernels, 2 = masks and the foreground / background partition (GEC_BG_CUS > 0). */
+int gec_cu_masks_active(void);
 /* Must not run concurrently with any other call on the same codec, and only after
  * work enqueued by *_dev calls on caller streams has completed. */
 void gec_codec_destroy(gec_codec *c);
