@@ -920,6 +920,75 @@ def test_decode_verify_segmented_chains_other_shapes(k, m, L):
         host_free(a)
 
 
+@pytest.mark.parametrize("k,m,L", [(10, 4, 1 << 20), (20, 8, 2 << 20), (3, 1, 600_000), (17, 3, 900_001)],
+                         ids=["rs10_4", "rs20_8_more_slots_than_stages", "rs3_1", "rs17_3"])
+def test_decode_verify_degraded_batch_staged_by_first_missing_slot(coracle, k, m, L):
+    """Round 3's read path: with pinned shards and block checksums requested, every block's chain advances behind the
+    upload stages and a block is decoded in the stage of its FIRST missing data slot j0.  One batch with every j0 from
+    0 to k-1 (plus further losses up to m, surplus shards in hand, healthy blocks in between) and block lengths that end
+    before, inside and after the rebuilt slots: rebuilt shards vs the oracle's stripes, shard checksums of exactly the
+    first k shards in hand and the block's own blake2sum vs hashlib."""
+    import ctypes
+    import hashlib
+
+    from garage_amd.codec import host_alloc, host_free
+
+    lib = _lib.lib
+    rs = g.ReedSolomon(k, m)
+    n = k + m
+    S = g.shard_len(k, L)
+    rng = np.random.default_rng(1000 + k)
+    lost, lens = [], []
+    for j0 in range(k):
+        extra = rng.choice([j for j in range(n) if j > j0], size=int(rng.integers(0, m)), replace=False).tolist()
+        lost.append(tuple(sorted([j0] + extra)))
+        lens.append([L, L - 1, j0 * S + 1, max(1, j0 * S), min(L, (j0 + 1) * S + 77), L][j0 % 6])
+        if j0 % 3 == 1:                        # a healthy block in between, some with a parity shard lost
+            lost.append(() if j0 % 2 else (k,))
+            lens.append(L - 129 * j0)
+    nb = len(lens)
+    data = np.zeros((nb, k, S), dtype=np.uint8)
+    for b in range(nb):
+        data[b].reshape(-1)[:lens[b]] = rng.integers(0, 256, lens[b], dtype=np.uint8)
+    full = np.concatenate([data, coracle.encode_batch(k, m, data, coracle.AVX2, threads=4)], axis=1)
+    bufs, sp, op, fresh = [], (ctypes.c_void_p * (nb * n))(), (ctypes.c_void_p * (nb * n))(), {}
+    for b in range(nb):
+        for j in range(n):
+            if j in lost[b]:
+                if j < k:
+                    fresh[(b, j)] = host_alloc(S)
+                    fresh[(b, j)][:] = 0x5A
+                    op[b * n + j] = fresh[(b, j)].ctypes.data
+            else:
+                a = host_alloc(S)
+                a[:] = full[b, j]
+                bufs.append(a)
+                sp[b * n + j] = a.ctypes.data
+    clens = (ctypes.c_size_t * nb)(*lens)
+    ssums = np.zeros((nb, n, 32), dtype=np.uint8)
+    bsums = np.zeros((nb, 32), dtype=np.uint8)
+    u8 = ctypes.POINTER(ctypes.c_uint8)
+    for rep in range(2):                       # twice: the second call reuses the slot's streams, events and buffers
+        ssums[:] = 0
+        bsums[:] = 0
+        _lib.check(lib.gec_decode_verify_batch(rs._h, nb, sp, S, clens, op, ssums.ctypes.data_as(u8), bsums.ctypes.data_as(u8)),
+                   "gec_decode_verify_batch")
+        for b in range(nb):
+            present = [j for j in range(n) if j not in lost[b]][:k]
+            for j in range(n):
+                if j in present:
+                    assert ssums[b, j].tobytes() == g.shardsum(full[b, j].tobytes()), (rep, b, j)
+                else:
+                    assert not ssums[b, j].any(), (rep, b, j)
+            for j in lost[b]:
+                if j < k:
+                    assert np.array_equal(fresh[(b, j)], full[b, j]), (rep, b, j, lost[b])
+            want = hashlib.blake2b(data[b].reshape(-1)[:lens[b]].tobytes(), digest_size=64).digest()[:32]
+            assert bsums[b].tobytes() == want, (rep, b, lost[b], lens[b])
+    for a in bufs + list(fresh.values()):
+        host_free(a)
+
+
 @pytest.mark.parametrize("k,m", [(10, 4), (20, 8), (6, 10)], ids=["rs10_4", "rs20_8", "rs6_10_two_row_groups"])
 def test_zero_copy_verify_flags_the_right_blocks(coracle, k, m):
     """gec_verify_batch on pinned shards (the scrub path without staging): one flipped bit in a data shard, in a

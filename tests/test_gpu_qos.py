@@ -65,3 +65,109 @@ def test_puts_keep_their_latency_beside_a_scrub_on_the_background_class():
     assert with_x < without_x, r.stdout       # measured 1.04 vs 4.5
     if masks == 2:                            # with the CU partition: 1.04 (profiles/r03_qos.txt); where the runtime refuses CU
         assert with_x <= 2.0, r.stdout        # masks the classes share every CU and only priority / chunks / yields are left
+
+
+_BG_SCRIPT = r"""
+import sys, ctypes, numpy as np
+sys.path.insert(0, %r)
+import garage_amd as g
+from garage_amd._lib import lib, check
+from garage_amd.codec import host_alloc
+from oracle import rs_oracle as O
+co = O.COracle()
+k, m, n = 10, 4, 14
+fg = g.ReedSolomon(k, m)
+bg = fg.background()
+assert bg.qos_class == 1 and bg.backend == "hip"
+S, nb = 26240, 48                       # 48 stripes of 359 KiB: 17 chunks of 1 MiB for the background codec
+data = O.splitmix64_bytes(5, nb * k * S).reshape(nb, k, S)
+want = co.encode_batch(k, m, data, co.AVX2)
+full = np.concatenate([data, want], axis=1)
+u8 = ctypes.POINTER(ctypes.c_uint8)
+for pinned in (True, False):
+    alloc = host_alloc if pinned else (lambda sz: np.empty(sz, dtype=np.uint8))
+    blocks = [alloc(k * S) for _ in range(nb)]
+    pars = {c: [alloc(m * S) for _ in range(nb)] for c in ("fg", "bg")}
+    for b in range(nb):
+        blocks[b][:] = data[b].reshape(-1)
+    lens = (ctypes.c_size_t * nb)(*[k * S] * nb)
+    bp = (ctypes.c_void_p * nb)(*[x.ctypes.data for x in blocks])
+    sums = {}
+    for name, rs in (("fg", fg), ("bg", bg)):
+        pp = (ctypes.c_void_p * nb)(*[x.ctypes.data for x in pars[name]])
+        s = np.zeros((nb, n, 32), dtype=np.uint8)
+        check(lib.gec_encode_hash_batch(rs._h, nb, bp, lens, S, pp, s.ctypes.data_as(u8)), "encode_hash")
+        sums[name] = s
+        assert all(np.array_equal(np.asarray(pars[name][b]).reshape(m, S), want[b]) for b in range(nb)), (name, pinned)
+    assert np.array_equal(sums["fg"], sums["bg"])
+    assert sums["bg"][3, 11].tobytes() == g.shardsum(full[3, 11].tobytes())
+    # scrub in one trip and rebuild in one trip on the background codec
+    shards = [alloc(S) for _ in range(nb * n)]
+    for b in range(nb):
+        for j in range(n):
+            shards[b * n + j][:] = full[b, j]
+    shards[5 * n + 2][100] ^= 1
+    sp = (ctypes.c_void_p * (nb * n))(*[x.ctypes.data for x in shards])
+    ok = np.zeros(nb, dtype=np.uint8); s2 = np.zeros((nb, n, 32), dtype=np.uint8)
+    check(lib.gec_verify_hash_batch(bg._h, nb, sp, S, ok.ctypes.data_as(u8), s2.ctypes.data_as(u8)), "verify_hash")
+    assert ok.tolist() == [1] * 5 + [0] + [1] * (nb - 6), ok.tolist()
+    assert s2[7, 0].tobytes() == g.shardsum(full[7, 0].tobytes())
+    shards[5 * n + 2][100] ^= 1
+    outs = {}
+    op = (ctypes.c_void_p * (nb * n))()
+    for b in range(nb):
+        for j in ((b %% n), ((b + 3) %% n)):
+            sp[b * n + j] = None
+            outs[(b, j)] = alloc(S)
+            op[b * n + j] = outs[(b, j)].ctypes.data
+    ins = np.zeros((nb, n, 32), dtype=np.uint8); osum = np.zeros((nb, n, 32), dtype=np.uint8)
+    check(lib.gec_reconstruct_hash_batch(bg._h, nb, sp, op, S, 0, ins.ctypes.data_as(u8), osum.ctypes.data_as(u8)), "reconstruct_hash")
+    for (b, j), buf in outs.items():
+        assert np.array_equal(np.asarray(buf), full[b, j]), (b, j, pinned)
+        assert osum[b, j].tobytes() == g.shardsum(full[b, j].tobytes())
+print("ok", lib.gec_cu_masks_active())
+"""
+
+
+@pytest.mark.gpu
+def test_background_codec_computes_the_same_bytes_in_small_chunks():
+    """A BACKGROUND-class codec only changes WHEN and WHERE the work runs: with 1 MiB chunks (GEC_BG_CHUNK_MB=1: many
+    chunks, many yields) encode + checksums, scrub-in-one-trip and rebuild-in-one-trip return what the foreground codec
+    and the oracle do, from pinned and from pageable memory."""
+    import sys
+
+    env = dict(os.environ, GEC_BG_CHUNK_MB="1", GEC_BG_YIELD_US="200")
+    r = subprocess.run([sys.executable, "-c", _BG_SCRIPT % ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+_SMALL_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import garage_amd as g
+from oracle import rs_oracle as O
+co = O.COracle()
+rs = g.ReedSolomon(10, 4)
+S = g.shard_len(10, 1 << 20)
+data = O.splitmix64_bytes(9, 2 * 10 * S).reshape(2, 10, S)
+want = co.encode_batch(10, 4, data, co.AVX2)
+par = np.stack(rs.encode_blocks([data[b].tobytes() for b in range(2)], S))       # 2 pageable blocks: answered on the host cores
+assert np.array_equal(par, want)
+st = np.concatenate([data, want], axis=1)
+rec = rs.reconstruct([[None if j in (0, 12) else st[b, j] for j in range(14)] for b in range(2)])
+assert all(np.array_equal(rec[b][j], st[b, j]) for b in range(2) for j in (0, 12))
+big = O.splitmix64_bytes(10, 8 * 10 * S).reshape(8, 10, S)                      # 8 blocks: the device, as always
+assert np.array_equal(np.stack(rs.encode_blocks([big[b].tobytes() for b in range(8)], S)), co.encode_batch(10, 4, big, co.AVX2))
+print("ok")
+"""
+
+
+@pytest.mark.gpu
+def test_small_pageable_calls_can_be_answered_on_the_host_cores():
+    """GEC_SMALL_CALL_BLOCKS=2: a HIP codec hands pageable encode / reconstruct calls of up to two blocks to the library's
+    CPU backend (one 1 MiB block: 94 us through the staged device path, less on one core); same bytes either way."""
+    import sys
+
+    r = subprocess.run([sys.executable, "-c", _SMALL_SCRIPT % ROOT], capture_output=True, text=True,
+                       env=dict(os.environ, GEC_SMALL_CALL_BLOCKS="2"), timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]
