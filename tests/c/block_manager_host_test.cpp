@@ -608,6 +608,58 @@ static void run_hedged(int k, int m, const char *dir_root = nullptr)
 	printf("hedged reads RS(%d,%d): plain %.0f ms, hedged %.0f ms: OK\n", k, m, t_plain, t_hedged);
 }
 
+// Round-2 advisor item: resync's delete branch against a concurrent put of the same hash.  The block is deletable (its
+// protection ran out); one thread runs the resync pass that wants to delete it, another puts it again.  Whatever the
+// interleaving, a put that returned OK leaves a readable block.
+static void run_put_vs_resync_delete(int k, int m)
+{
+	gec_codec *codec = stub_codec_create(k, m);
+	gbm_manager *mg = nullptr;
+	CHECK(gbm_create(codec, k + m + 2, nullptr, 0, &mg) == GBM_OK);
+	CHECK(gbm_set_timing(mg, 1000, -1, -1) == GBM_OK);
+	const int NB = 10;
+	std::vector<std::vector<uint8_t>> blocks(NB);
+	std::vector<uint8_t> hashes(NB * 32);
+	std::vector<const uint8_t *> ptr(NB);
+	std::vector<size_t> len(NB);
+	for (int i = 0; i < NB; ++i) {
+		blocks[i] = pattern(30000 + 1111 * i, 7000 + i);
+		gbm_blake2sum(blocks[i].data(), blocks[i].size(), hashes.data() + 32 * i);
+		ptr[i] = blocks[i].data();
+		len[i] = blocks[i].size();
+	}
+	for (int round = 0; round < 8; ++round) {
+		CHECK(gbm_rpc_put_blocks(mg, NB, hashes.data(), ptr.data(), len.data(), nullptr, nullptr) == GBM_OK);
+		CHECK(gbm_clock_advance(mg, 5000) == GBM_OK);  // every stamp is in the past now
+		for (int i = 0; i < NB; ++i)
+			CHECK(gbm_put_to_resync(mg, hashes.data() + 32 * i, 0) == GBM_OK);
+		int put_rc = GBM_OK;
+		std::thread putter([&] {
+			for (int i = 0; i < NB; ++i) {
+				int rc = gbm_rpc_put_block(mg, hashes.data() + 32 * i, blocks[i].data(), blocks[i].size(), 0, nullptr);
+				if (rc != GBM_OK)
+					put_rc = rc;
+			}
+		});
+		std::thread resyncer([&] {
+			int changed = 0;
+			(void)gbm_resync_all(mg, &changed);
+		});
+		putter.join();
+		resyncer.join();
+		CHECK(put_rc == GBM_OK);
+		std::vector<uint8_t> out(100000);
+		for (int i = 0; i < NB; ++i) {
+			size_t got = 0;
+			CHECK(gbm_rpc_get_block(mg, hashes.data() + 32 * i, nullptr, out.data(), out.size(), &got) == GBM_OK);
+			CHECK(got == blocks[i].size() && std::memcmp(out.data(), blocks[i].data(), got) == 0);
+		}
+	}
+	gbm_destroy(mg);
+	stub_codec_destroy(codec);
+	printf("put vs resync delete RS(%d,%d): OK\n", k, m);
+}
+
 int main(int argc, char **argv)
 {
 	run_hedged(3, 1);
@@ -621,6 +673,7 @@ int main(int argc, char **argv)
 		run_hedged(10, 4, argv[1]);  // the same races between first answers and abandoned requests, over files
 	}
 	run_batcher(10, 4);
+	run_put_vs_resync_delete(10, 4);
 	printf("block_manager_host_test: all scenarios OK\n");
 	return 0;
 }

@@ -445,3 +445,111 @@ def test_hedged_read_decodes_around_a_slow_node(codec):
     for w in down:
         mgr.node_set_down(w, True)
     assert mgr.rpc_get_block(hashes[0]) == blocks[0]
+
+
+# ----------------------------------------------------------------- round-2 advisor items
+def test_v1_shard_headers_are_read_and_rewritten_unknown_versions_are_left_alone(tmp_path, backend):
+    """Header version 1 (round 1's format: plain blake2sum checksum) is still readable -- verified on the host, rewritten
+    as version 2 the first time it is read; a version this build does not know is never renamed or deleted."""
+    import hashlib
+    import struct
+
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    mgr = _mgr(codec, tmp_path)
+    data = pattern_block(500_000, salt=77)
+    h = bn.blake2sum(data)
+    mgr.rpc_put_block(h, data)
+    who = mgr.storage_nodes_of(h)
+    hx = h.hex()
+
+    def shard_file(j):
+        return tmp_path / f"node{who[j]}" / hx[:2] / hx[2:4] / f"{hx}.s{j}"
+
+    # shard 0 becomes a version-1 file: same payload, checksum = plain blake2sum
+    raw = bytearray(shard_file(0).read_bytes())
+    assert raw[:4] == b"GECS" and raw[4] == 2
+    raw[4] = 1
+    raw[28:60] = hashlib.blake2b(bytes(raw[64:]), digest_size=64).digest()[:32]
+    shard_file(0).write_bytes(bytes(raw))
+    # shard 1 claims a version from the future
+    raw1 = bytearray(shard_file(1).read_bytes())
+    raw1[4] = 9
+    shard_file(1).write_bytes(bytes(raw1))
+    assert mgr.rpc_get_block(h) == data                  # shard 0 is used (after its v1 check), shard 1 is skipped: 13 >= k
+    again = shard_file(0).read_bytes()
+    assert again[4] == 2 and again[28:60] == bn.shardsum(again[64:])      # upgraded in place
+    assert shard_file(1).exists() and shard_file(1).read_bytes()[4] == 9  # untouched: not *.corrupted, not deleted
+    assert not list((tmp_path / f"node{who[1]}" / hx[:2] / hx[2:4]).glob("*.corrupted"))
+    # a v1 file whose payload does not match its blake2sum IS corrupt
+    raw[70] ^= 1
+    shard_file(0).write_bytes(bytes(raw))
+    assert mgr.rpc_get_block(h) == data
+    assert not shard_file(0).exists()                    # renamed *.corrupted, queued for resync
+    mgr.close()
+
+
+def test_a_reput_with_another_geometry_replaces_shards_only_at_quorum(backend):
+    """The same block put again with a different compression setting cuts shards of another geometry.  A node parks such
+    a shard beside the one in place; the manager commits it once the new stripe has its write quorum and drops it
+    otherwise -- a put that fails half way must not leave 7 shards of each kind."""
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    mgr = _mgr(codec)
+    data = bytes(pattern_block(600_000, salt=5))
+    h = bn.blake2sum(data)
+    mgr.rpc_put_block(h, data)                                       # Plain
+    assert not mgr.rpc_get_raw_block(h)[0].is_compressed()
+    who = mgr.storage_nodes_of(h)
+    assert bn.lib.gbm_set_compression_level(mgr._h, 1, 1) == 0
+    for node in who[:7]:                                             # 7 of the 14 holders unreachable: quorum (12) fails
+        mgr.node_set_down(node, True)
+    with pytest.raises(bn.Quorum):
+        mgr.rpc_put_block(h, data)                                   # Compressed this time
+    for node in who[:7]:
+        mgr.node_set_down(node, False)
+    hdr, stored = mgr.rpc_get_raw_block(h)
+    assert not hdr.is_compressed() and stored == data                # all 14 Plain shards are still in place
+    assert mgr.rpc_get_block(h) == data
+    mgr.rpc_put_block(h, data)                                       # now it reaches everybody: committed
+    hdr, stored = mgr.rpc_get_raw_block(h)
+    assert hdr.is_compressed() and len(stored) < len(data) and mgr.rpc_get_block(h) == data
+    mgr.close()
+
+
+def test_resync_never_deletes_what_a_concurrent_put_acknowledges(backend):
+    """A block that is deletable (its protection ran out) is put again while resync is deciding to delete it: whatever the
+    interleaving, a put that returned OK leaves a readable block (the delete branch re-reads the refcount under the hash's
+    mutation lock; the put stamps its protection under that lock before it writes its first shard)."""
+    import threading
+
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    mgr = _mgr(codec)
+    mgr.set_timing(gc_delay_ms=1000)
+    blocks = [bytes(pattern_block(70_000, salt=900 + i)) for i in range(12)]
+    hashes = [bn.blake2sum(b) for b in blocks]
+    for rnd in range(6):
+        mgr.rpc_put_blocks(list(zip(hashes, blocks)))
+        mgr.clock_advance(5000)                                       # every stamp is in the past: all deletable
+        for h in hashes:
+            mgr.put_to_resync(h, 0)
+        errs = []
+
+        def putter():
+            try:
+                for h, b in zip(hashes, blocks):
+                    mgr.rpc_put_block(h, b)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        def resyncer():
+            try:
+                mgr.resync_all()
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        ts = [threading.Thread(target=putter), threading.Thread(target=resyncer)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+        for h, b in zip(hashes, blocks):
+            assert mgr.rpc_get_block(h) == b, f"round {rnd}: an acknowledged put lost its shards"
+    mgr.close()
