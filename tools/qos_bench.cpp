@@ -130,8 +130,8 @@ int main(int argc, char **argv)
 	auto report = [&](const char *name, const PutStats *ps, const ScrubStats *ss) {
 		printf("%-34s", name);
 		if (ps)
-			printf(" put p50 %6.3f ms  p99 %6.3f ms  %6.2f GiB/s (%zu puts)", pct(ps->lat_ms, 0.5), pct(ps->lat_ms, 0.99),
-			       ps->lat_ms.size() / 1024.0 / ps->secs, ps->lat_ms.size());
+			printf(" put p50 %6.3f ms  p90 %6.3f  p99 %6.3f ms  max %6.3f  %6.2f GiB/s (%zu puts)", pct(ps->lat_ms, 0.5), pct(ps->lat_ms, 0.9),
+			       pct(ps->lat_ms, 0.99), pct(ps->lat_ms, 1.0), ps->lat_ms.size() / 1024.0 / ps->secs, ps->lat_ms.size());
 		if (ss)
 			printf("  scrub %6.2f GiB/s of blocks (%llu blocks, %llu corruptions)", ss->blocks / 1024.0 / ss->secs,
 			       (unsigned long long)ss->blocks, (unsigned long long)ss->corruptions);
