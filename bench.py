@@ -202,6 +202,7 @@ def cpu_backend_rate(S: int, nb: int = 512) -> dict:
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     return {"value": round(nb * BLOCK_LEN / best / 2**30, 2), "unit": "GiB/s", "kernel": lib.gec_cpu_isa().decode(),
+            "cpus_allowed": len(os.sched_getaffinity(0)),
             "threads": int(os.environ.get("GEC_CPU_THREADS", "0")) or min(os.cpu_count() or 1, 16),
             "sample": f"{nb} blocks x 1 MiB RS(10,4) gec_encode_batch on a GEC_BACKEND_CPU codec, best of 5"}
 
@@ -235,14 +236,6 @@ def cpu_baseline_only() -> None:
         out["all_logical_cpus_point"] = {"threads": allcpus, "GiBps_active_wait": rate_all, **probe,
                                          "reading": "every logical CPU inside a spin-waiting OpenMP team: any other runnable thread on the box "
                                                     "preempts a team member and the rest spin at the barrier; not a property of the encode loop"}
-    # the product's own CPU backend, in a process of ITS own: libgomp has bound this process's main thread to the first
-    # place (OMP_PROC_BIND=close), and threads created from it -- the CPU codec's pool -- would inherit that one core
-    try:
-        env = {k: v for k, v in os.environ.items() if not k.startswith(("OMP_", "GOMP_"))}
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-backend-only"], env=env, capture_output=True, text=True, timeout=240)
-        out["cpu_backend"] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    except Exception as e:  # noqa: BLE001
-        out["cpu_backend"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     print(json.dumps(out), flush=True)
 
 
@@ -255,9 +248,19 @@ def cpu_baseline_subprocess():
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], env=env, capture_output=True, text=True,
                            timeout=300)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-        return json.loads(line)
+        out = json.loads(line)
     except Exception as e:  # noqa: BLE001 -- a reported baseline must never cost the headline line
         return {"error": f"{type(e).__name__}: {e}"[:300]}
+    # The product's own CPU backend, in a process of ITS own started from here: libgomp binds the main thread of the
+    # oracle's process to the first place (OMP_PROC_BIND=close), and both the threads created from it and the
+    # processes forked from it inherit that one-core affinity mask -- a CPU codec's pool measured there runs on one core.
+    try:
+        env = {k: v for k, v in env.items() if not k.startswith(("OMP_", "GOMP_"))}
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-backend-only"], env=env, capture_output=True, text=True, timeout=240)
+        out["cpu_backend"] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as e:  # noqa: BLE001
+        out["cpu_backend"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
 
 
 def cpu_baseline_object(args, S: int):

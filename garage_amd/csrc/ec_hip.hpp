@@ -114,6 +114,7 @@ struct Staging {
 	// the read path on their way home): sixteen CUs read host memory at the link's rate but cannot also write it
 	hipStream_t stream_down = nullptr;
 	hipEvent_t ev_dec[kMaxSeg] = {};  // "the decodes of stage s are done"
+	int cus_up = 0, cus_chain = 0, cus_down = 0;  // CUs of the three masked streams (0 = that stream has no mask)
 	QosPolicy qos;  // set by the lease from the codec's class before anything is created
 
 	int ensure_segments(int num_cu);
@@ -121,6 +122,8 @@ struct Staging {
 	int ensure_tab(size_t entries);
 	int ensure(size_t bytes, size_t nbad);
 	void release();
+	// how many CUs kernels launched on `s` (a stream of this slot) may run on
+	int cus_of(hipStream_t s) const;
 
 private:
 	int make_stream(hipStream_t *s);

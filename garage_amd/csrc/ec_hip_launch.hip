@@ -4,6 +4,8 @@
 #include "ec_hip.hpp"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 #include "kernels.hpp"
 #include "blake2b.hpp"
@@ -327,6 +329,41 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 	return GEC_OK;
 }
 
+// Grid of a tile-walking kernel (gf_apply_ptrs, copy_table) on a CU-masked stream: no more workgroups than the
+// stream's CUs hold at once; each walks tiles blockIdx.x, + gridDim.x, ...  A launch with more workgroups than fit
+// occupies its queue's dispatcher until the last one is placed -- and kernels of other streams served by the same
+// dispatcher wait for as long, whatever CUs THEY are confined to.  That is how a scrub's 600 us link kernel (800
+// workgroups onto 8 CUs) made a PutObject's 140 us checksum kernel take 660 us in some process runs and not in others
+// (which queues share a dispatcher is decided when they are created): tools/dispatch_probe, profiles/r03_qos.txt.
+// GEC_RESIDENT_GRID=0 restores one workgroup per tile (A/B).
+namespace {
+unsigned resident_grid(const Staging &st, hipStream_t stream, const void *kernel, size_t lds, uint32_t tiles)
+{
+	if (!env().resident_grid)
+		return tiles;
+	static std::mutex mu;
+	static std::map<std::pair<const void *, size_t>, int> occ_of;
+	int occ = 0;
+	{
+		std::lock_guard<std::mutex> g(mu);
+		auto it = occ_of.find({kernel, lds});
+		if (it == occ_of.end()) {
+			int v = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, 256, lds) != hipSuccess || v < 1) {
+				(void)hipGetLastError();
+				v = 0;  // unknown: one workgroup per tile
+			}
+			it = occ_of.emplace(std::make_pair(kernel, lds), v).first;
+		}
+		occ = it->second;
+	}
+	if (occ < 1)
+		return tiles;
+	const uint64_t fit = (uint64_t)st.cus_of(stream) * (uint64_t)occ;
+	return (unsigned)std::min<uint64_t>(tiles, std::max<uint64_t>(fit, 1));
+}
+}  // namespace
+
 // out[b][r] = XOR_t coef[r][t] * in[b][t] over shards that stay in the caller's pinned memory (gf_apply_ptrs):
 // in[b*k + t] / valid[b*k + t] name the k input shards of block b and how many of their S bytes exist,
 // out[b*nout + r] the output rows.  The tables are written into the staging slot's pinned table area, which the
@@ -357,6 +394,13 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 	a.cols = (uint32_t)(S / 16);
 	a.k = (uint32_t)k;
 	const unsigned gx = (a.cols + 255) / 256;
+	if ((uint64_t)gx * nblocks > 0xffffffffull)
+		return fail(GEC_E_INVALID_ARG, "too many tiles for one launch");
+	a.tiles_x = gx;
+	a.tiles_total = (uint32_t)(gx * nblocks);
+	a.in = t_in;
+	a.in_valid = t_valid;
+	a.bad = bad;
 	int rows = 0;
 	size_t out_done = 0;  // entries of t_out consumed by earlier row groups
 	for (int r0 = 0; r0 < nout; r0 += rows) {
@@ -375,31 +419,21 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 		a.mirror_stride = (k + (size_t)nout) * S;
 		a.mirror_row0 = (k + (size_t)r0) * S;
 		a.mirror_inputs = r0 == 0;
-		for (size_t b0 = 0; b0 < nblocks; b0 += 65535) {
-			const unsigned gy = (unsigned)std::min<size_t>(65535, nblocks - b0);
-			a.in = t_in + b0 * k;
-			a.in_valid = t_valid + b0 * k;
-			a.out = grp + b0 * rows;
-			a.mirror = d_mirror ? d_mirror + b0 * a.mirror_stride : nullptr;
-			a.bad = bad ? bad + b0 : nullptr;
-			if (bad && d_mirror && mw == 1)
-				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, true, true>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
-			else if (bad && d_mirror)
-				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5, true, true>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
-			else if (bad && mw == 1)
-				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, false, true>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
-			else if (bad)
-				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5, false, true>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
-			else if (mw == 1 && d_mirror)
-				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, true>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
-			else if (mw == 1)
-				hipLaunchKernelGGL((gec::gf_apply_ptrs<1, 5, false>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
-			else if (d_mirror)
-				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5, true>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
-			else
-				hipLaunchKernelGGL((gec::gf_apply_ptrs<2, 5, false>), dim3(gx, gy), dim3(256), lds, stream, a, hb.d_logexp);
-			HIP_TRY(hipGetLastError());
-		}
+		a.out = grp;
+		a.mirror = d_mirror;
+		using Kern = void (*)(const gec::PtrApplyArgs, const gec::LogExp *);
+		Kern kern;
+		if (bad && d_mirror)
+			kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, true, true> : (Kern)gec::gf_apply_ptrs<2, 5, true, true>;
+		else if (bad)
+			kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, false, true> : (Kern)gec::gf_apply_ptrs<2, 5, false, true>;
+		else if (d_mirror)
+			kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, true> : (Kern)gec::gf_apply_ptrs<2, 5, true>;
+		else
+			kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, false> : (Kern)gec::gf_apply_ptrs<2, 5, false>;
+		const unsigned grid = resident_grid(st, stream, reinterpret_cast<const void *>(kern), lds, a.tiles_total);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, hb.d_logexp);
+		HIP_TRY(hipGetLastError());
 	}
 	return GEC_OK;
 }
@@ -417,13 +451,13 @@ int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipS
 		maxb = std::max<uint64_t>(maxb, ents[i].bytes);
 	}
 	st.tab_used += ents.size();
-	const unsigned gx = (unsigned)((maxb >> 4) / 1024 + 1);
-	// grid.y <= 65535: split long tables
-	for (size_t e0 = 0; e0 < ents.size(); e0 += 65535) {
-		const unsigned gy = (unsigned)std::min<size_t>(65535, ents.size() - e0);
-		hipLaunchKernelGGL(gec::copy_table, dim3(gx, gy), dim3(256), 0, stream, tab + e0);
-		HIP_TRY(hipGetLastError());
-	}
+	const uint64_t gx = (maxb >> 4) / 1024 + 1;
+	if (gx * ents.size() > 0xffffffffull)
+		return fail(GEC_E_INVALID_ARG, "too many tiles for one launch");
+	const uint32_t total = (uint32_t)(gx * ents.size());
+	const unsigned grid = resident_grid(st, stream, reinterpret_cast<const void *>(gec::copy_table), 0, total);
+	hipLaunchKernelGGL(gec::copy_table, dim3(grid), dim3(256), 0, stream, tab, (uint32_t)gx, total);
+	HIP_TRY(hipGetLastError());
 	return GEC_OK;
 }
 

@@ -137,12 +137,36 @@ int Staging::ensure_segments(int num_cu)
 			(void)hipGetLastError();
 		}
 		g_cu_masks.store(stream_up ? (split ? 2 : 1) : 0);
+		auto bits = [](const std::vector<uint32_t> &m) {
+			int n = 0;
+			for (uint32_t w : m)
+				n += __builtin_popcount(w);
+			return n;
+		};
+		if (stream_up) {
+			cus_up = bits(up);
+			cus_chain = bits(rest);
+		}
 		if (stream_up && !down.empty() && hipExtStreamCreateWithCUMask(&stream_down, (uint32_t)words, down.data()) != hipSuccess) {
 			stream_down = nullptr;
 			(void)hipGetLastError();
 		}
+		if (stream_down)
+			cus_down = bits(down);
 	}
 	return make_stream(&stream3);
+}
+
+int Staging::cus_of(hipStream_t s) const
+{
+	if (s && s == stream_up)
+		return cus_up;
+	if (s && s == stream_chain)
+		return cus_chain;
+	if (s && s == stream_down)
+		return cus_down;
+	const int all = qos.num_cu > 0 ? qos.num_cu : 256;
+	return qos.background && qos.compute_cus > 0 && qos.compute_cus < all ? qos.compute_cus : all;
 }
 
 int Staging::ensure_big(size_t bytes)

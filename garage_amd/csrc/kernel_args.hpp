@@ -56,6 +56,7 @@ struct PtrApplyArgs {
 	uint8_t *const *out;       // [nblocks][rows]
 	uint32_t cols;             // 16-byte columns per shard
 	uint32_t k, rows;
+	uint32_t tiles_x, tiles_total;  // 256-column tiles per shard; tiles_x * (blocks of this launch)
 	// MIRROR: everything the kernel reads and computes is also laid down in device memory, dense --
 	// mirror + b*mirror_stride + t*16*cols for input shard t (first row group only: mirror_inputs),
 	// ... + mirror_row0 + r*16*cols for output row r -- so that the shard checksums can be computed from

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(TPB, MINW) void gf_apply_nibble_w(const ApplyArgs a
 // copy-in kernel + apply + copy-out kernel and nothing is staged in HBM; the link, not the kernel, is the bound
 // (tools/pcie_probe: 53 GB/s for this access shape on a Gen5 x16 link), so the kernel is the plain one-column-
 // per-lane form of gf_apply_nibble: same LDS tables, same lookups, KC loads in flight per lane.
-// blockIdx.y = block, blockIdx.x = tile of 256 columns.  The tables themselves live in pinned host memory too:
+// Tile = (block, 256 columns of its shards), see the kernel.  The tables themselves live in pinned host memory too:
 // they are wave-uniform, i.e. a few scalar loads per workgroup.
 // ---------------------------------------------------------------------------
 
@@ -385,16 +385,21 @@ __global__ __launch_bounds__(256) void gf_apply_ptrs(const PtrApplyArgs a, const
 	constexpr int ENT = 4 * MW, TBL = 32 * ENT;
 	static_assert(MW == 1 || MW == 2, "rows go out in groups of at most 8");
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const uint32_t tid = threadIdx.x, k = a.k, rows = a.rows, b = blockIdx.y;
+	const uint32_t tid = threadIdx.x, k = a.k, rows = a.rows;
 	uint8_t *lexp = lds + k * TBL, *llog = lexp + 512, *lcoef = llog + 256;
 	const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds;
-	const uint32_t col_raw = blockIdx.x * 256 + tid;
-	const bool live = col_raw < a.cols;
-	const uint32_t col = live ? col_raw : 0;  // dead lanes shadow column 0 (loads only)
+	// The grid is 1-D and may be SHORTER than the tile list (a.tiles_total = tiles_x * nblocks; tile = block * tiles_x
+	// + 256-column tile of the shard): a workgroup then walks tiles blockIdx.x, + gridDim.x, ...  The host sizes the
+	// grid to what the stream's CU partition holds at once (ec_hip_launch.hip, resident_grid): a launch with more
+	// workgroups than fit keeps its queue's dispatcher busy until the last one is placed, and kernels of OTHER streams
+	// that share that dispatcher wait for as long (tools/dispatch_probe, profiles/r03_qos.txt).
+	uint32_t tile = blockIdx.x;
+	uint32_t b = tile / a.tiles_x;
+	uint32_t col_raw = (tile - b * a.tiles_x) * 256 + tid;
+	bool live = col_raw < a.cols;
+	uint32_t col = live ? col_raw : 0;  // dead lanes shadow column 0 (loads only)
 	const uint8_t *const *inp = a.in + (size_t)b * k;
 	const uint32_t *valid = a.in_valid + (size_t)b * k;
-	u32x4 *mir = MIRROR ? reinterpret_cast<u32x4 *>(a.mirror + (size_t)b * a.mirror_stride) + col : nullptr;
-	const bool mir_in = MIRROR && live && a.mirror_inputs;
 
 	// first batch of shard loads goes out before the tables are built: PCIe latency hides behind the expansion
 	u32x4 d[KC];
@@ -428,75 +433,104 @@ __global__ __launch_bounds__(256) void gf_apply_ptrs(const PtrApplyArgs a, const
 	}
 	__syncthreads();
 
-	uint32_t acc[4][4][MW];
-#pragma unroll
-	for (int w = 0; w < 4; ++w)
-#pragma unroll
-		for (int j = 0; j < 4; ++j)
-#pragma unroll
-			for (int h = 0; h < MW; ++h)
-				acc[w][j][h] = 0;
-	for (uint32_t t0 = 0; t0 < k; t0 += KC) {
-		if (t0 > 0) {
-#pragma unroll
-			for (int j = 0; j < KC; ++j) {
-				const uint32_t t = t0 + j < k ? t0 + j : k - 1;
-				d[j] = ld16_valid(inp[t], col, valid[t]);
-			}
-		}
-#pragma unroll
-		for (int j = 0; j < KC; ++j) {
-			if (t0 + j >= k)
-				break;
-			if (mir_in)
-				mir[(size_t)(t0 + j) * a.cols] = d[j];
-			const uint32_t tb = __builtin_amdgcn_readfirstlane(lds_base + (t0 + j) * TBL);
-			const uint32_t xs[4] = {d[j].x, d[j].y, d[j].z, d[j].w};
-#pragma unroll
-			for (int w = 0; w < 4; ++w) {
-				const uint32_t x = xs[w];
-				const uint32_t lo = (MW == 1) ? ((x << 2) & 0x3C3C3C3Cu) : ((x << 3) & 0x78787878u);
-				const uint32_t hi = (MW == 1) ? ((x >> 2) & 0x3C3C3C3Cu) : ((x >> 1) & 0x78787878u);
-				lut_acc<MW, 0>(tb, lo, hi, acc[w][0]);
-				lut_acc<MW, 1>(tb, lo, hi, acc[w][1]);
-				lut_acc<MW, 2>(tb, lo, hi, acc[w][2]);
-				lut_acc<MW, 3>(tb, lo, hi, acc[w][3]);
-			}
-		}
-	}
-	uint32_t P[4 * MW][4];
-#pragma unroll
-	for (int h = 0; h < MW; ++h)
+	for (;;) {  // one tile per turn; no barrier in here (the tables are read-only from now on)
+		u32x4 *mir = MIRROR ? reinterpret_cast<u32x4 *>(a.mirror + (size_t)b * a.mirror_stride) + col : nullptr;
+		const bool mir_in = MIRROR && live && a.mirror_inputs;
+		uint32_t acc[4][4][MW];
 #pragma unroll
 		for (int w = 0; w < 4; ++w)
-			transpose4x4(acc[w][0][h], acc[w][1][h], acc[w][2][h], acc[w][3][h], P[4 * h + 0][w], P[4 * h + 1][w],
-				     P[4 * h + 2][w], P[4 * h + 3][w]);
-	if (!live)
-		return;
-	uint8_t *const *outp = a.out + (size_t)b * rows;
-	if (COMPARE) {
-		uint32_t diff = 0;
 #pragma unroll
-		for (int r = 0; r < 4 * MW; ++r) {
-			if (r >= (int)rows)
-				continue;
-			const u32x4 old = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(outp[r]) + col);
-			diff |= (P[r][0] ^ old.x) | (P[r][1] ^ old.y) | (P[r][2] ^ old.z) | (P[r][3] ^ old.w);
-			if (MIRROR)  // the STORED row: what the shard checksum is computed over
-				reinterpret_cast<u32x4 *>(a.mirror + (size_t)b * a.mirror_stride + a.mirror_row0)[(size_t)r * a.cols + col] = old;
+			for (int j = 0; j < 4; ++j)
+#pragma unroll
+				for (int h = 0; h < MW; ++h)
+					acc[w][j][h] = 0;
+		for (uint32_t t0 = 0; t0 < k; t0 += KC) {
+			if (t0 > 0) {
+#pragma unroll
+				for (int j = 0; j < KC; ++j) {
+					const uint32_t t = t0 + j < k ? t0 + j : k - 1;
+					d[j] = ld16_valid(inp[t], col, valid[t]);
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < KC; ++j) {
+				if (t0 + j >= k)
+					break;
+				if (mir_in)
+					mir[(size_t)(t0 + j) * a.cols] = d[j];
+				const uint32_t tb = __builtin_amdgcn_readfirstlane(lds_base + (t0 + j) * TBL);
+				const uint32_t xs[4] = {d[j].x, d[j].y, d[j].z, d[j].w};
+#pragma unroll
+				for (int w = 0; w < 4; ++w) {
+					const uint32_t x = xs[w];
+					const uint32_t lo = (MW == 1) ? ((x << 2) & 0x3C3C3C3Cu) : ((x << 3) & 0x78787878u);
+					const uint32_t hi = (MW == 1) ? ((x >> 2) & 0x3C3C3C3Cu) : ((x >> 1) & 0x78787878u);
+					lut_acc<MW, 0>(tb, lo, hi, acc[w][0]);
+					lut_acc<MW, 1>(tb, lo, hi, acc[w][1]);
+					lut_acc<MW, 2>(tb, lo, hi, acc[w][2]);
+					lut_acc<MW, 3>(tb, lo, hi, acc[w][3]);
+				}
+			}
 		}
-		if (diff)
-			a.bad[b] = 1u;
-		return;
-	}
+		// the next tile's first loads go out before this tile's rows are stored
+		const uint32_t next = tile + gridDim.x;
+		const bool more = next < a.tiles_total;
+		const uint32_t nb = more ? next / a.tiles_x : b;
+		const uint32_t ncol_raw = more ? (next - nb * a.tiles_x) * 256 + tid : col_raw;
+		const bool nlive = ncol_raw < a.cols;
+		const uint32_t ncol = nlive ? ncol_raw : 0;
+		const uint8_t *const *ninp = a.in + (size_t)nb * k;
+		const uint32_t *nvalid = a.in_valid + (size_t)nb * k;
+		if (more) {
 #pragma unroll
-	for (int r = 0; r < 4 * MW; ++r) {
-		if (r >= (int)rows)
-			continue;
-		const u32x4 v = {P[r][0], P[r][1], P[r][2], P[r][3]};
-		__builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(outp[r]) + col);
-		if (MIRROR)
-			reinterpret_cast<u32x4 *>(a.mirror + (size_t)b * a.mirror_stride + a.mirror_row0)[(size_t)r * a.cols + col] = v;
+			for (int j = 0; j < KC; ++j) {
+				const uint32_t t = (uint32_t)j < k ? j : k - 1;
+				d[j] = ld16_valid(ninp[t], ncol, nvalid[t]);
+			}
+		}
+		if (live) {
+			uint32_t P[4 * MW][4];
+#pragma unroll
+			for (int h = 0; h < MW; ++h)
+#pragma unroll
+				for (int w = 0; w < 4; ++w)
+					transpose4x4(acc[w][0][h], acc[w][1][h], acc[w][2][h], acc[w][3][h], P[4 * h + 0][w], P[4 * h + 1][w],
+						     P[4 * h + 2][w], P[4 * h + 3][w]);
+			uint8_t *const *outp = a.out + (size_t)b * rows;
+			if (COMPARE) {
+				uint32_t diff = 0;
+#pragma unroll
+				for (int r = 0; r < 4 * MW; ++r) {
+					if (r >= (int)rows)
+						continue;
+					const u32x4 old = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(outp[r]) + col);
+					diff |= (P[r][0] ^ old.x) | (P[r][1] ^ old.y) | (P[r][2] ^ old.z) | (P[r][3] ^ old.w);
+					if (MIRROR)  // the STORED row: what the shard checksum is computed over
+						reinterpret_cast<u32x4 *>(a.mirror + (size_t)b * a.mirror_stride + a.mirror_row0)[(size_t)r * a.cols + col] = old;
+				}
+				if (diff)
+					a.bad[b] = 1u;
+			} else {
+#pragma unroll
+				for (int r = 0; r < 4 * MW; ++r) {
+					if (r >= (int)rows)
+						continue;
+					const u32x4 v = {P[r][0], P[r][1], P[r][2], P[r][3]};
+					__builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(outp[r]) + col);
+					if (MIRROR)
+						reinterpret_cast<u32x4 *>(a.mirror + (size_t)b * a.mirror_stride + a.mirror_row0)[(size_t)r * a.cols + col] = v;
+				}
+			}
+		}
+		if (!more)
+			break;
+		tile = next;
+		b = nb;
+		col_raw = ncol_raw;
+		live = nlive;
+		col = ncol;
+		inp = ninp;
+		valid = nvalid;
 	}
 }
 
@@ -519,32 +553,36 @@ __global__ void clear_flags(uint32_t *p, uint32_t n)
 // gets back: tools/pcie_probe measures 55 GB/s for such a kernel, against 36-47 GB/s for the same pieces as
 // individual hipMemcpyAsync calls (per-copy engine overhead) and 57 GB/s for one huge DMA.
 // src and dst of every entry are 16-byte aligned (the host checks); the last <16 bytes go byte-wise.
-// blockIdx.y = entry, blockIdx.x = 16 KiB tile of the entry (the grid covers the largest entry).
+// Tile = (entry, 16 KiB tile of the entry); the tile list covers the largest entry for every entry.
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void copy_table(const CopyEntry *__restrict__ tab)
+__global__ __launch_bounds__(256) void copy_table(const CopyEntry *__restrict__ tab, uint32_t tiles_x, uint32_t tiles_total)
 {
-	const CopyEntry e = tab[blockIdx.y];
-	const uint64_t nvec = e.bytes >> 4;
-	const uint64_t base = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
-	if ((uint64_t)blockIdx.x * 1024 >= nvec + 1)  // whole tile past the end (tail handled by the tile that holds nvec)
-		return;
-	const u32x4 *s = reinterpret_cast<const u32x4 *>(e.src);
-	u32x4 *d = reinterpret_cast<u32x4 *>(e.dst);
-	u32x4 v[4];
+	// 1-D grid, possibly shorter than the tile list (see gf_apply_ptrs): tile = entry * tiles_x + 16 KiB tile of the entry
+	for (uint32_t tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
+		const uint32_t ent = tile / tiles_x, tx = tile - ent * tiles_x;
+		const CopyEntry e = tab[ent];
+		const uint64_t nvec = e.bytes >> 4;
+		const uint64_t base = (uint64_t)tx * 1024 + threadIdx.x;
+		if ((uint64_t)tx * 1024 >= nvec + 1)  // whole tile past the end (tail handled by the tile that holds nvec)
+			continue;
+		const u32x4 *s = reinterpret_cast<const u32x4 *>(e.src);
+		u32x4 *d = reinterpret_cast<u32x4 *>(e.dst);
+		u32x4 v[4];
 #pragma unroll
-	for (int j = 0; j < 4; ++j)
-		if (base + j * 256 < nvec)
-			v[j] = __builtin_nontemporal_load(s + base + j * 256);
+		for (int j = 0; j < 4; ++j)
+			if (base + j * 256 < nvec)
+				v[j] = __builtin_nontemporal_load(s + base + j * 256);
 #pragma unroll
-	for (int j = 0; j < 4; ++j)
-		if (base + j * 256 < nvec)
-			__builtin_nontemporal_store(v[j], d + base + j * 256);
-	// ragged tail: one thread of the tile that contains vector index nvec
-	const uint64_t tail = e.bytes & 15;
-	if (tail && nvec / 1024 == blockIdx.x && threadIdx.x == 0)
-		for (uint64_t b = 0; b < tail; ++b)
-			e.dst[(nvec << 4) + b] = e.src[(nvec << 4) + b];
+		for (int j = 0; j < 4; ++j)
+			if (base + j * 256 < nvec)
+				__builtin_nontemporal_store(v[j], d + base + j * 256);
+		// ragged tail: one thread of the tile that contains vector index nvec
+		const uint64_t tail = e.bytes & 15;
+		if (tail && nvec / 1024 == tx && threadIdx.x == 0)
+			for (uint64_t q = 0; q < tail; ++q)
+				e.dst[(nvec << 4) + q] = e.src[(nvec << 4) + q];
+	}
 }
 
 // ---------------------------------------------------------------------------
