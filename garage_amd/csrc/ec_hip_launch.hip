@@ -4,8 +4,6 @@
 #include "ec_hip.hpp"
 
 #include <algorithm>
-#include <map>
-#include <mutex>
 
 #include "kernels.hpp"
 #include "blake2b.hpp"
@@ -337,30 +335,15 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 // (which queues share a dispatcher is decided when they are created): tools/dispatch_probe, profiles/r03_qos.txt.
 // GEC_RESIDENT_GRID=0 restores one workgroup per tile (A/B).
 namespace {
-unsigned resident_grid(const Staging &st, hipStream_t stream, const void *kernel, size_t lds, uint32_t tiles)
+unsigned resident_grid(const Staging &st, hipStream_t stream, uint32_t tiles)
 {
 	if (!env().resident_grid)
 		return tiles;
-	static std::mutex mu;
-	static std::map<std::pair<const void *, size_t>, int> occ_of;
-	int occ = 0;
-	{
-		std::lock_guard<std::mutex> g(mu);
-		auto it = occ_of.find({kernel, lds});
-		if (it == occ_of.end()) {
-			int v = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, 256, lds) != hipSuccess || v < 1) {
-				(void)hipGetLastError();
-				v = 0;  // unknown: one workgroup per tile
-			}
-			it = occ_of.emplace(std::make_pair(kernel, lds), v).first;
-		}
-		occ = it->second;
-	}
-	if (occ < 1)
-		return tiles;
-	const uint64_t fit = (uint64_t)st.cus_of(stream) * (uint64_t)occ;
-	return (unsigned)std::min<uint64_t>(tiles, std::max<uint64_t>(fit, 1));
+	// gec::RESIDENT_WGS workgroups per CU is what the kernels' __launch_bounds__ guarantees room for (the occupancy
+	// query of the runtime does not count scalar registers and promised 8 for a kernel that fits 7 times: the
+	// workgroups that did not fit started when the others were done, and held the dispatcher until then)
+	const uint64_t fit = (uint64_t)std::max(st.cus_of(stream), 1) * (uint64_t)gec::RESIDENT_WGS;
+	return (unsigned)std::min<uint64_t>(tiles, fit);
 }
 }  // namespace
 
@@ -431,7 +414,7 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 			kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, true> : (Kern)gec::gf_apply_ptrs<2, 5, true>;
 		else
 			kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, false> : (Kern)gec::gf_apply_ptrs<2, 5, false>;
-		const unsigned grid = resident_grid(st, stream, reinterpret_cast<const void *>(kern), lds, a.tiles_total);
+		const unsigned grid = resident_grid(st, stream, a.tiles_total);
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, hb.d_logexp);
 		HIP_TRY(hipGetLastError());
 	}
@@ -455,7 +438,7 @@ int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipS
 	if (gx * ents.size() > 0xffffffffull)
 		return fail(GEC_E_INVALID_ARG, "too many tiles for one launch");
 	const uint32_t total = (uint32_t)(gx * ents.size());
-	const unsigned grid = resident_grid(st, stream, reinterpret_cast<const void *>(gec::copy_table), 0, total);
+	const unsigned grid = resident_grid(st, stream, total);
 	hipLaunchKernelGGL(gec::copy_table, dim3(grid), dim3(256), 0, stream, tab, (uint32_t)gx, total);
 	HIP_TRY(hipGetLastError());
 	return GEC_OK;

@@ -50,6 +50,11 @@ struct LogExp {
 
 constexpr int PTR_KMAX = 128;  // coef[PTR_KMAX][RMAX] keeps the kernel argument block at 1 KiB
 
+// Workgroups (of 256 lanes = 4 waves, one per SIMD) of a tile-walking kernel that are resident on one CU at once:
+// promised by the kernels' __launch_bounds__(256, RESIDENT_WGS) (second argument = waves per SIMD the register
+// allocation must leave room for) and used by the host to size grids that FIT (ec_hip_launch.hip, resident_grid).
+constexpr int RESIDENT_WGS = 6;
+
 struct PtrApplyArgs {
 	const uint8_t *const *in;  // [nblocks][k]: 16-byte aligned shard pointers
 	const uint32_t *in_valid;  // [nblocks][k]: bytes of the shard that exist (<= 16*cols)

@@ -380,7 +380,7 @@ __device__ __forceinline__ u32x4 ld16_valid(const uint8_t *shard, uint32_t col, 
 }
 
 template <int MW, int KC, bool MIRROR, bool COMPARE = false>
-__global__ __launch_bounds__(256) void gf_apply_ptrs(const PtrApplyArgs a, const LogExp *__restrict__ le)
+__global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrApplyArgs a, const LogExp *__restrict__ le)
 {
 	constexpr int ENT = 4 * MW, TBL = 32 * ENT;
 	static_assert(MW == 1 || MW == 2, "rows go out in groups of at most 8");
@@ -556,7 +556,7 @@ __global__ void clear_flags(uint32_t *p, uint32_t n)
 // Tile = (entry, 16 KiB tile of the entry); the tile list covers the largest entry for every entry.
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void copy_table(const CopyEntry *__restrict__ tab, uint32_t tiles_x, uint32_t tiles_total)
+__global__ __launch_bounds__(256, RESIDENT_WGS) void copy_table(const CopyEntry *__restrict__ tab, uint32_t tiles_x, uint32_t tiles_total)
 {
 	// 1-D grid, possibly shorter than the tile list (see gf_apply_ptrs): tile = entry * tiles_x + 16 KiB tile of the entry
 	for (uint32_t tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
