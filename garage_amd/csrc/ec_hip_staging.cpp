@@ -339,6 +339,10 @@ ForegroundScope::~ForegroundScope()
 		gate->leave();
 }
 
+// Called by a background codec's chunk loops before every chunk: the chunk waits (at most GEC_BG_YIELD_US) for the
+// foreground calls in flight to drain, so that a PutObject's encode finds the link and the copy threads free within
+// one background chunk.  (Pausing the background class in proportion to the foreground's load was tried and dropped:
+// under a saturating PutObject load it slowed the scrub and left the puts where they were, profiles/r03_qos.txt.)
 void background_yield(const gec_codec *c)
 {
 	if (c->qos_class == GEC_CLASS_BACKGROUND)
