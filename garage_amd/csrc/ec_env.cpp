@@ -28,7 +28,7 @@ const Row kRows[] = {
 	{"GEC_BG_CUS", "64", "CUs a background-class codec's kernels may occupy (0 = no mask; link kernels stay on GEC_UPLOAD_CUS)"},
 	{"GEC_BG_CHUNK_MB", "32", "chunk size of a background-class codec's host-pointer trips (a foreground call waits for at most one)"},
 	{"GEC_BG_YIELD_US", "2000", "a background chunk waits up to this long for foreground calls on the same device to drain (0 = never waits)"},
-	{"GEC_DOWN_XCD", "-1", "experiment: 0..7 = kernels that write host memory run on CUs of that XCD only, which the checksum kernels then avoid"},
+	{"GEC_HOME_RATE_GBPS", "25", "the read path sends rebuilt shards home no faster than this while checksum chains run (0 = unpaced, one workgroup per tile): a link saturated with writes backs up into the fabric and every other kernel's loads wait"},
 	{"GEC_RESIDENT_GRID", "1", "link kernels launched as a grid that fits the stream's CUs and walks the tiles, instead of one workgroup per tile: 0 = never, 1 = background codecs, 2 = every codec"},
 	{"GEC_ROWS16", "1", "A/B: 0 = 9..16 output rows as 8-row passes instead of one 16-row pass"},
 	{"GEC_BLAKE2_KERNEL", "auto", "A/B: lane or quad forces one of the two plain-blake2 kernels"},
@@ -65,7 +65,7 @@ const Env &env()
 		v.bg_cus = (int)get_long("GEC_BG_CUS", 64);
 		v.bg_chunk_mb = (size_t)std::max<long>(get_long("GEC_BG_CHUNK_MB", 32), 1);
 		v.bg_yield_us = (unsigned)std::max<long>(get_long("GEC_BG_YIELD_US", 2000), 0);
-		v.down_xcd = (int)get_long("GEC_DOWN_XCD", -1);
+		v.home_rate_gbps = (unsigned)std::max<long>(get_long("GEC_HOME_RATE_GBPS", 25), 0);
 		v.resident_grid = (int)get_long("GEC_RESIDENT_GRID", 1);
 		v.rows16 = (int)get_long("GEC_ROWS16", 1);
 		const char *bk = get("GEC_BLAKE2_KERNEL");

@@ -19,7 +19,7 @@ struct Env {
 	unsigned copy_threads;  // GEC_COPY_THREADS
 	bool zero_copy;         // GEC_ZERO_COPY
 	int upload_cus;         // GEC_UPLOAD_CUS
-	int down_xcd;           // GEC_DOWN_XCD
+	unsigned home_rate_gbps; // GEC_HOME_RATE_GBPS
 	int resident_grid;      // GEC_RESIDENT_GRID
 	int verify_segments;    // GEC_VERIFY_SEGMENTS (0 = the built-in maximum)
 	size_t pinned_chunk_mb; // GEC_PINNED_CHUNK_MB

@@ -331,7 +331,8 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 
 // Appends the entries to the slot's table and launches ONE copy_table kernel over them.  Entries must have
 // 16-byte aligned src and dst.
-int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipStream_t stream);
+// max_wgs > 0: a grid of at most that many workgroups walking the tiles; pace_ns > 0: each starts a tile every pace_ns
+int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipStream_t stream, unsigned max_wgs = 0, unsigned pace_ns = 0);
 
 int launch_clear_flags(uint32_t *d_bad, size_t n, hipStream_t stream);
 

@@ -662,7 +662,11 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 					es = hipStreamWaitEvent(down_stream, st.ev_dec[sg], 0);
 				if (es != hipSuccess)
 					return finish(hip_fail(es, "decode event"));
-				rc = launch_copy_table(st, outs, down_stream);
+				// paced: the copies have a chain segment's time (~1 ms) to finish in, and at the link's full write rate
+				// they stop the chains for exactly as long as they take (segments 1.07 -> 1.2-1.7 ms: the fabric's queues
+				// towards the link fill up and every load behind them waits) -- at half the rate the chains do not notice
+				const unsigned home_wgs = 16, rate = env().home_rate_gbps;
+				rc = launch_copy_table(st, outs, down_stream, rate ? home_wgs : 0, rate ? home_wgs * 16384u / rate : 0);
 				if (rc)
 					return finish(rc);
 			}

@@ -426,7 +426,7 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 	return GEC_OK;
 }
 
-int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipStream_t stream)
+int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipStream_t stream, unsigned max_wgs, unsigned pace_ns)
 {
 	if (ents.empty())
 		return GEC_OK;
@@ -443,8 +443,10 @@ int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipS
 	if (gx * ents.size() > 0xffffffffull)
 		return fail(GEC_E_INVALID_ARG, "too many tiles for one launch");
 	const uint32_t total = (uint32_t)(gx * ents.size());
-	const unsigned grid = resident_grid(st, stream, total);
-	hipLaunchKernelGGL(gec::copy_table, dim3(grid), dim3(256), 0, stream, tab, (uint32_t)gx, total);
+	unsigned grid = resident_grid(st, stream, total);
+	if (max_wgs > 0)
+		grid = std::min(grid, max_wgs);
+	hipLaunchKernelGGL(gec::copy_table, dim3(grid), dim3(256), 0, stream, tab, (uint32_t)gx, total, max_wgs > 0 ? pace_ns / 10 : 0u);
 	HIP_TRY(hipGetLastError());
 	return GEC_OK;
 }

@@ -120,16 +120,6 @@ int Staging::ensure_segments(int num_cu)
 			up = mask(0, U);
 			down = mask(U, 2 * U);
 			rest = mask(2 * U + U / 2, num_cu - B);
-			// experiment (GEC_DOWN_XCD = x): the kernels that WRITE host memory on CUs of one XCD only (mask bit i is
-			// a CU of XCD i % 8), and that XCD's CUs taken out of the checksum kernels' mask
-			const int x = env().down_xcd;
-			if (x >= 0 && x < 8 && num_cu == 256) {
-				down.assign(words, 0);
-				for (int j = 5; j < 5 + U; ++j)
-					down[(x + 8 * j) / 32] |= 1u << ((x + 8 * j) % 32);
-				for (int i = x; i < num_cu; i += 8)
-					rest[i / 32] &= ~(1u << (i % 32));
-			}
 		} else {
 			const int down_hi = 2 * U < num_cu ? 2 * U : U;
 			up = mask(0, U);

@@ -556,10 +556,19 @@ __global__ void clear_flags(uint32_t *p, uint32_t n)
 // Tile = (entry, 16 KiB tile of the entry); the tile list covers the largest entry for every entry.
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256, RESIDENT_WGS) void copy_table(const CopyEntry *__restrict__ tab, uint32_t tiles_x, uint32_t tiles_total)
+__global__ __launch_bounds__(256, RESIDENT_WGS) void copy_table(const CopyEntry *__restrict__ tab, uint32_t tiles_x, uint32_t tiles_total,
+								  uint32_t pace_ticks)
 {
-	// 1-D grid, possibly shorter than the tile list (see gf_apply_ptrs): tile = entry * tiles_x + 16 KiB tile of the entry
-	for (uint32_t tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
+	// 1-D grid, possibly shorter than the tile list (see gf_apply_ptrs): tile = entry * tiles_x + 16 KiB tile of the entry.
+	// pace_ticks > 0: a workgroup starts its i-th tile no earlier than i * pace_ticks (10 ns each) after its first -- a
+	// copy that has the whole trip to finish in (rebuilt shards going home beside the checksum chains) must not fill the
+	// fabric's queues towards the link: loads of every other kernel wait behind them (profiles/r03_get_degraded.txt).
+	const uint64_t t0 = pace_ticks ? wall_clock64() : 0;
+	uint32_t turn = 0;
+	for (uint32_t tile = blockIdx.x; tile < tiles_total; tile += gridDim.x, ++turn) {
+		if (pace_ticks)
+			while (wall_clock64() - t0 < (uint64_t)turn * pace_ticks)
+				__builtin_amdgcn_s_sleep(16);
 		const uint32_t ent = tile / tiles_x, tx = tile - ent * tiles_x;
 		const CopyEntry e = tab[ent];
 		const uint64_t nvec = e.bytes >> 4;
