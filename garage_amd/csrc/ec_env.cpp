@@ -29,7 +29,7 @@ const Row kRows[] = {
 	{"GEC_BG_CHUNK_MB", "32", "chunk size of a background-class codec's host-pointer trips (a foreground call waits for at most one)"},
 	{"GEC_BG_YIELD_US", "2000", "a background chunk waits up to this long for foreground calls on the same device to drain (0 = never waits)"},
 	{"GEC_HOME_RATE_GBPS", "25", "the read path sends rebuilt shards home no faster than this while checksum chains run (0 = unpaced, one workgroup per tile): a link saturated with writes backs up into the fabric and every other kernel's loads wait"},
-	{"GEC_RESIDENT_GRID", "1", "link kernels launched as a grid that fits the stream's CUs and walks the tiles, instead of one workgroup per tile: 0 = never, 1 = background codecs, 2 = every codec"},
+	{"GEC_RESIDENT_GRID", "1", "A/B: 0 = link kernels launch one workgroup per tile instead of a grid that fits the stream's CUs and walks the tiles"},
 	{"GEC_ROWS16", "1", "A/B: 0 = 9..16 output rows as 8-row passes instead of one 16-row pass"},
 	{"GEC_BLAKE2_KERNEL", "auto", "A/B: lane or quad forces one of the two plain-blake2 kernels"},
 	{"GEC_B2_ADD", "0", "A/B: 1 = 64-bit adds of the blake2 kernels spelled as 32-bit add / addc"},

@@ -333,16 +333,15 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 // dispatcher wait for as long, whatever CUs THEY are confined to.  That is how a scrub's 600 us link kernel (800
 // workgroups onto 8 CUs) made a PutObject's 140 us checksum kernel take 660 us in some process runs and not in others
 // (which queues share a dispatcher is decided when they are created): tools/dispatch_probe, profiles/r03_qos.txt.
-// GEC_RESIDENT_GRID: 0 = one workgroup per tile everywhere, 2 = walked tiles for every codec (A/B).
+// GEC_RESIDENT_GRID=0: one workgroup per tile (A/B).
 namespace {
 unsigned resident_grid(const Staging &st, hipStream_t stream, uint32_t tiles)
 {
-	// Background codecs only, by default: theirs are the kernels that must not stand in a PutObject's way.  For the
-	// request path itself one workgroup per tile is the faster form (pageable reconstruct 48 -> 33 GiB/s with walked
-	// tiles: a fresh workgroup's loads go out while its predecessor's stores drain) and its kernels only ever delay
-	// one another.
-	const int mode = env().resident_grid;
-	if (mode == 0 || (mode == 1 && !st.qos.background))
+	// Every codec: a background codec's kernels must not stand in a PutObject's way, and the request path's own
+	// kernels are meant to overlap too -- the read path's upload stages beside its checksum segments: with one
+	// workgroup per tile, a get whose upload queue happened to share a dispatcher with its chain queue ran every
+	// segment BEHIND the next stage's upload (17.7 instead of 15.8 ms for the same 512 blocks, process by process).
+	if (env().resident_grid == 0)
 		return tiles;
 	// gec::RESIDENT_WGS workgroups per CU is what the kernels' __launch_bounds__ guarantees room for (the occupancy
 	// query of the runtime does not count scalar registers and promised 8 for a kernel that fits 7 times: the

@@ -129,9 +129,10 @@ int gec_codec_create_ex(int k, int m, int backend, int device, int matrix, gec_c
  *   - its host-pointer trips go in small chunks (GEC_BG_CHUNK_MB) and, before each chunk, wait (up to
  *     GEC_BG_YIELD_US) for the foreground calls in flight on the same device to finish: a foreground call
  *     finds the link, the copy threads and the CUs busy with at most one background chunk;
- *   - its link kernels are launched with no more workgroups than its CUs hold at once (each walks a list of
- *     tiles): a launch with more keeps its queue's dispatcher busy until the last workgroup is placed, and kernels
- *     of foreground streams that share that dispatcher would wait for as long (tools/dispatch_probe);
+ *   - its link kernels -- like every codec's -- are launched with no more workgroups than its CUs hold at once
+ *     (each walks a list of tiles): a launch with more keeps its queue's dispatcher busy until the last workgroup
+ *     is placed, and kernels of foreground streams that share that dispatcher would wait for as long
+ *     (tools/dispatch_probe);
  *   - it keeps to two staging-copy threads.
  * libgarage_block runs gbm_scrub_all / gbm_resync_run on such a sibling.  Results are identical. */
 enum { GEC_CLASS_FOREGROUND = 0, GEC_CLASS_BACKGROUND = 1 };
