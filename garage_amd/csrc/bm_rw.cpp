@@ -728,9 +728,11 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 			early[b] = 1;
 		});
 	};
+	Trace tr("get (whole call)");
 	int frc = fetch_blocks(mg, hs, tags, g, rcs, verify && !cpu_hash, block_sums, assemble_early, &changed);
 	if (frc)
 		return frc;
+	tr.lap("fetch");
 	// assemble (parallel), then check every Plain block's content against its name (DataBlock::verify,
 	// block.rs:69-77) -- all block hashes in one batch.  Plain blocks are assembled straight into the
 	// caller's buffer and hashed from there (on CORRUPT_DATA its contents are unspecified); compressed
@@ -789,6 +791,9 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 		}
 		mg->metrics[5]++;
 	});
+	tr.lap("finish");
+	g.clear();
+	tr.lap("release");
 	return GBM_OK;
 }
 

@@ -171,3 +171,33 @@ def test_small_pageable_calls_can_be_answered_on_the_host_cores():
     r = subprocess.run([sys.executable, "-c", _SMALL_SCRIPT % ROOT], capture_output=True, text=True,
                        env=dict(os.environ, GEC_SMALL_CALL_BLOCKS="2"), timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_cu_mask_ranges_of_the_partition_are_disjoint_physical_cus():
+    """What Staging::ensure_segments relies on: contiguous mask-bit ranges select disjoint physical CUs, evenly over the
+    XCDs (tools/cu_mask_probe reads XCC_ID / HW_ID under each mask)."""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "cu_mask_probe"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(ROOT, "tools", "cu_mask_probe")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout)
+    if "device: 256 CUs" not in r.stdout:
+        pytest.skip("partition layout is checked for the 256-CU device")
+    assert "DISJOINT, covers the device" in r.stdout, r.stdout
+    first = [ln for ln in r.stdout.splitlines() if ln.startswith("bits [0,16)")][0]
+    assert all(f"xcc{x}:2" in first for x in range(8)), first
+
+
+@pytest.mark.gpu
+def test_a_grid_that_fits_its_cu_mask_does_not_hold_up_other_streams():
+    """tools/dispatch_probe: with a resident grid on stream A no other stream's tiny kernel waits anywhere near A's
+    duration (with 40x as many workgroups as fit, the streams that share A's dispatcher wait ~0.85 ms)."""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "dispatch_probe"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(ROOT, "tools", "dispatch_probe"), "9"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout)
+    sect = r.stdout.split("A = resident grid")[1]
+    waits = [float(x) for x in re.findall(r"tiny kernel done after median\s+([0-9.]+) us", sect)]
+    assert len(waits) >= 8 and max(waits) < 300.0, sect

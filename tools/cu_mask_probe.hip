@@ -33,7 +33,7 @@ __global__ void where(uint32_t *out)
 	}
 }
 
-static void run(const char *name, int ncu, const std::vector<int> &bits)
+static std::set<uint32_t> run(const char *name, int ncu, const std::vector<int> &bits)
 {
 	const int words = (ncu + 31) / 32;
 	std::vector<uint32_t> m(words, 0);
@@ -49,10 +49,12 @@ static void run(const char *name, int ncu, const std::vector<int> &bits)
 	std::vector<uint32_t> h(2 * nwg);
 	CHECK(hipMemcpy(h.data(), d, nwg * 8, hipMemcpyDeviceToHost));
 	std::map<uint32_t, std::set<uint32_t>> per_xcc;
+	std::set<uint32_t> all;
 	for (int i = 0; i < nwg; ++i) {
 		const uint32_t xcc = h[2 * i] & 0xf, hw = h[2 * i + 1];
 		const uint32_t cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 0x1, se = (hw >> 13) & 0x7;
 		per_xcc[xcc].insert(se * 100 + sh * 50 + cu);
+		all.insert(xcc * 1000 + se * 100 + sh * 50 + cu);
 	}
 	printf("%-34s %3zu bits ->", name, bits.size());
 	size_t total = 0;
@@ -63,6 +65,7 @@ static void run(const char *name, int ncu, const std::vector<int> &bits)
 	printf("   (%zu distinct CUs)\n", total);
 	CHECK(hipFree(d));
 	CHECK(hipStreamDestroy(s));
+	return all;
 }
 
 int main()
@@ -83,11 +86,21 @@ int main()
 			v.push_back(x + 8 * j);
 		return v;
 	};
-	run("bits [0,16)", ncu, range(0, 16));
-	run("bits [16,32)", ncu, range(16, 32));
-	run("bits [32,40)", ncu, range(32, 40));
-	run("bits [40,192)", ncu, range(40, 192));
-	run("bits [192,256)", ncu, range(192, ncu));
+	// the staging slots' partition (ec_hip_staging.cpp, defaults): pairwise disjoint physical CUs, together the whole chip
+	std::vector<std::set<uint32_t>> part;
+	part.push_back(run("bits [0,16)", ncu, range(0, 16)));
+	part.push_back(run("bits [16,32)", ncu, range(16, 32)));
+	part.push_back(run("bits [32,40)", ncu, range(32, 40)));
+	part.push_back(run("bits [40,192)", ncu, range(40, 192)));
+	part.push_back(run("bits [192,256)", ncu, range(192, ncu)));
+	std::set<uint32_t> uni;
+	size_t sum = 0;
+	for (auto &s : part) {
+		uni.insert(s.begin(), s.end());
+		sum += s.size();
+	}
+	printf("partition: %zu CUs in the five ranges, %zu distinct -> %s\n", sum, uni.size(),
+	       sum == uni.size() && (int)sum == ncu ? "DISJOINT, covers the device" : "OVERLAP or gap");
 	run("bits 7+8j, j in [0,32)", ncu, stride8(7, 0, 32));
 	run("bits 7+8j, j in [5,21)", ncu, stride8(7, 5, 21));
 	run("bits 0+8j, j in [0,32)", ncu, stride8(0, 0, 32));
