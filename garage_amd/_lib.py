@@ -39,7 +39,7 @@ SYMBOLS = [
     "gec_shard_len", "gec_build_matrix", "gec_build_matrix_ex", "gec_build_decode_matrix",
     "gec_codec_create", "gec_codec_create_ex", "gec_codec_destroy", "gec_codec_k", "gec_codec_m",
     "gec_codec_device", "gec_parity_matrix", "gec_codec_cache_stats",
-    "gec_codec_background", "gec_codec_class", "gec_codec_backend", "gec_qos_yields", "gec_cu_masks_active", "gec_stream_placement",
+    "gec_codec_background", "gec_codec_class", "gec_codec_backend", "gec_qos_yields", "gec_cu_masks_active",
     "gec_encode_batch", "gec_verify_batch", "gec_verify_hash_batch", "gec_reconstruct_batch", "gec_reconstruct_hash_batch",
     "gec_encode_batch_dev", "gec_verify_batch_dev", "gec_reconstruct_batch_dev",
     "gec_reconstruct_range_dev", "gec_reconstruct_scattered_dev", "gec_blake2sum_batch_dev", "gec_blake2sum_batch",

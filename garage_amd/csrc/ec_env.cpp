@@ -29,7 +29,6 @@ const Row kRows[] = {
 	{"GEC_BG_CHUNK_MB", "32", "chunk size of a background-class codec's host-pointer trips (a foreground call waits for at most one)"},
 	{"GEC_BG_YIELD_US", "2000", "a background chunk waits up to this long for foreground calls on the same device to drain (0 = never waits)"},
 	{"GEC_HOME_RATE_GBPS", "25", "the read path sends rebuilt shards home no faster than this while checksum chains run (0 = unpaced, one workgroup per tile): a link saturated with writes backs up into the fabric and every other kernel's loads wait"},
-	{"GEC_PLACE_STREAMS", "1", "0 = take the streams as the runtime hands them out instead of probing which ones share a dispatcher (A/B)"},
 	{"GEC_RESIDENT_GRID", "1", "A/B: 0 = link kernels launch one workgroup per tile instead of a grid that fits the stream's CUs and walks the tiles"},
 	{"GEC_ROWS16", "1", "A/B: 0 = 9..16 output rows as 8-row passes instead of one 16-row pass"},
 	{"GEC_BLAKE2_KERNEL", "auto", "A/B: lane or quad forces one of the two plain-blake2 kernels"},
@@ -67,7 +66,6 @@ const Env &env()
 		v.bg_chunk_mb = (size_t)std::max<long>(get_long("GEC_BG_CHUNK_MB", 32), 1);
 		v.bg_yield_us = (unsigned)std::max<long>(get_long("GEC_BG_YIELD_US", 2000), 0);
 		v.home_rate_gbps = (unsigned)std::max<long>(get_long("GEC_HOME_RATE_GBPS", 25), 0);
-		v.place_streams = get_long("GEC_PLACE_STREAMS", 1) != 0;
 		v.resident_grid = (int)get_long("GEC_RESIDENT_GRID", 1);
 		v.rows16 = (int)get_long("GEC_ROWS16", 1);
 		const char *bk = get("GEC_BLAKE2_KERNEL");

@@ -20,7 +20,6 @@ struct Env {
 	bool zero_copy;         // GEC_ZERO_COPY
 	int upload_cus;         // GEC_UPLOAD_CUS
 	unsigned home_rate_gbps; // GEC_HOME_RATE_GBPS
-	bool place_streams;     // GEC_PLACE_STREAMS
 	int resident_grid;      // GEC_RESIDENT_GRID
 	int verify_segments;    // GEC_VERIFY_SEGMENTS (0 = the built-in maximum)
 	size_t pinned_chunk_mb; // GEC_PINNED_CHUNK_MB

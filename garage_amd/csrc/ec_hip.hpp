@@ -82,7 +82,6 @@ struct QosPolicy {
 	int compute_cus = 0;       // > 0: the codec's streams are confined to this many CUs (of num_cu)
 	int compute_cus_plan = 0;  // GEC_BG_CUS as every codec of the process sees it: the CUs set aside for the background class
 	int num_cu = 0;
-	int device = 0;
 };
 
 // Staging resources for the host-pointer entry points (one per in-flight call).
@@ -116,8 +115,6 @@ struct Staging {
 	hipStream_t stream_down = nullptr;
 	hipEvent_t ev_dec[kMaxSeg] = {};  // "the decodes of stage s are done"
 	int cus_up = 0, cus_chain = 0, cus_down = 0;  // CUs of the three masked streams (0 = that stream has no mask)
-	std::vector<uint32_t> mask_up, mask_chain;    // their CU masks (place_streams may have to create a stream again)
-	bool registered = false;                      // in the placement registry (ec_hip_staging.cpp)
 	QosPolicy qos;  // set by the lease from the codec's class before anything is created
 
 	int ensure_segments(int num_cu);
@@ -130,7 +127,6 @@ struct Staging {
 
 private:
 	int make_stream(hipStream_t *s);
-	void place_streams();
 };
 
 // Per-device count of foreground host-pointer calls in flight: a background codec's chunk loop looks at it
@@ -339,7 +335,6 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipStream_t stream, unsigned max_wgs = 0, unsigned pace_ns = 0);
 
 int launch_clear_flags(uint32_t *d_bad, size_t n, hipStream_t stream);
-int launch_spin(hipStream_t stream, uint64_t ns);  // one wave busy for ns, no memory traffic
 
 // blake2sum of n messages.  group != 0: message i lives at d_base + (i / group)*group_stride + (i % group)*stride and
 // its checksum goes to d_out + 32*((i / group)*out_group + i % group) -- e.g. only the data (or only the parity)

@@ -450,13 +450,6 @@ int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipS
 	return GEC_OK;
 }
 
-int launch_spin(hipStream_t stream, uint64_t ns)
-{
-	hipLaunchKernelGGL(gec::spin_ticks, dim3(1), dim3(64), 0, stream, ns / 10);
-	HIP_TRY(hipGetLastError());
-	return GEC_OK;
-}
-
 int launch_clear_flags(uint32_t *d_bad, size_t n, hipStream_t stream)
 {
 	hipLaunchKernelGGL(gec::clear_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_bad, (uint32_t)n);

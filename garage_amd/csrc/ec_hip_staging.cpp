@@ -146,8 +146,6 @@ int Staging::ensure_segments(int num_cu)
 		if (stream_up) {
 			cus_up = bits(up);
 			cus_chain = bits(rest);
-			mask_up = up;
-			mask_chain = rest;
 		}
 		if (stream_up && !down.empty() && hipExtStreamCreateWithCUMask(&stream_down, (uint32_t)words, down.data()) != hipSuccess) {
 			stream_down = nullptr;
@@ -155,120 +153,9 @@ int Staging::ensure_segments(int num_cu)
 		}
 		if (stream_down)
 			cus_down = bits(down);
-		if (stream_up && split && env().place_streams)
-			place_streams();
 	}
 	return make_stream(&stream3);
 }
-
-// ------------------------------------------------------------------ which streams share a dispatcher
-// A launch on one queue costs ~36 us more while a kernel of another queue ON THE SAME DISPATCHER is running (four
-// pipes; tools/dispatch_probe, profiles/r03_dispatch_probe.txt) -- five launches per PutObject, a dozen per degraded
-// read.  Which queues share one is fixed when they are created and HIP neither says nor lets one choose, so the slots
-// measure it: the stream that carries the latency-critical launches of the request path (stream_chain: checksum
-// kernels, chain segments, decodes) is timed against the streams whose kernels run for long beside it -- its own
-// slot's link streams and every background codec's streams -- and created again (the colliding one is kept until the
-// replacement exists, so that the replacement gets another queue) until it shares a dispatcher with none of them; a
-// background slot's streams are placed the same way against every foreground slot's stream_chain.  A handful of
-// 0.2 ms probes per slot, once.  GEC_PLACE_STREAMS=0 takes the streams as they come (A/B).
-namespace {
-struct PlacementRegistry {
-	std::mutex mu;  // one placement at a time: the probes time launches
-	std::vector<hipStream_t> fg_critical, bg_long;
-};
-PlacementRegistry &placement(int device)
-{
-	static PlacementRegistry r[64];  // streams of different devices share nothing
-	return r[(unsigned)device % 64];
-}
-std::atomic<uint64_t> g_replaced{0}, g_unplaced{0};
-
-double launch_latency_us(hipStream_t s)
-{
-	const auto t0 = std::chrono::steady_clock::now();
-	if (launch_spin(s, 1000) != GEC_OK || hipStreamSynchronize(s) != hipSuccess)
-		return -1;
-	return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-}
-
-// does a launch on `b` wait while a kernel runs on `a`?
-bool share_a_dispatcher(hipStream_t a, hipStream_t b)
-{
-	constexpr int kReps = 5;
-	double base[kReps], busy[kReps];
-	(void)launch_latency_us(a);  // code object, queue doorbells: warm
-	(void)launch_latency_us(b);
-	for (int r = 0; r < kReps; ++r)
-		base[r] = launch_latency_us(b);
-	for (int r = 0; r < kReps; ++r) {
-		if (launch_spin(a, 250000) != GEC_OK)
-			return false;
-		const auto t0 = std::chrono::steady_clock::now();
-		while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 40) {
-		}
-		busy[r] = launch_latency_us(b);
-		(void)hipStreamSynchronize(a);
-	}
-	std::sort(base, base + kReps);
-	std::sort(busy, busy + kReps);
-	if (base[0] < 0 || busy[0] < 0)
-		return false;
-	return busy[kReps / 2] > base[kReps / 2] + 15.0;  // measured: +36 us
-}
-
-// `*s` (CU mask `mask`) is created again until it shares a dispatcher with none of `others`; false if five tries did not get there
-bool place(hipStream_t *s, const std::vector<uint32_t> &mask, const std::vector<hipStream_t> &others)
-{
-	std::vector<hipStream_t> rejected;
-	bool ok = false;
-	for (int attempt = 0; attempt < 5; ++attempt) {
-		bool clash = false;
-		for (hipStream_t o : others)
-			if (o && o != *s && share_a_dispatcher(o, *s)) {
-				clash = true;
-				break;
-			}
-		if (!clash) {
-			ok = true;
-			break;
-		}
-		hipStream_t fresh = nullptr;
-		if (hipExtStreamCreateWithCUMask(&fresh, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-			(void)hipGetLastError();
-			break;
-		}
-		rejected.push_back(*s);
-		*s = fresh;
-		g_replaced.fetch_add(1);
-	}
-	for (hipStream_t r : rejected)
-		(void)hipStreamDestroy(r);
-	if (!ok)
-		g_unplaced.fetch_add(1);
-	return ok;
-}
-}  // namespace
-
-void Staging::place_streams()
-{
-	PlacementRegistry &reg = placement(qos.device);
-	std::lock_guard<std::mutex> g(reg.mu);
-	if (!qos.background) {
-		std::vector<hipStream_t> others = reg.bg_long;
-		others.push_back(stream_up);
-		if (stream_down)
-			others.push_back(stream_down);
-		(void)place(&stream_chain, mask_chain, others);
-		reg.fg_critical.push_back(stream_chain);
-	} else {
-		(void)place(&stream_up, mask_up, reg.fg_critical);
-		(void)place(&stream_chain, mask_chain, reg.fg_critical);
-		reg.bg_long.push_back(stream_up);
-		reg.bg_long.push_back(stream_chain);
-	}
-	registered = true;
-}
-
 
 int Staging::cus_of(hipStream_t s) const
 {
@@ -348,12 +235,6 @@ int Staging::ensure(size_t bytes, size_t nbad)
 }
 void Staging::release()
 {
-	if (registered) {
-		PlacementRegistry &reg = placement(qos.device);
-		std::lock_guard<std::mutex> g(reg.mu);
-		for (auto *v : {&reg.fg_critical, &reg.bg_long})
-			v->erase(std::remove_if(v->begin(), v->end(), [&](hipStream_t s) { return s == stream_up || s == stream_chain; }), v->end());
-	}
 	if (h_buf)
 		(void)hipHostFree(h_buf);
 	if (d_buf)
@@ -555,11 +436,5 @@ int gec_host_is_pinned(const void *p, size_t bytes) { return pinned().contains(p
 uint64_t gec_qos_yields(int device) { return QosGate::of(device).yields(); }
 
 int gec_cu_masks_active(void) { return g_cu_masks.load(); }
-
-void gec_stream_placement(uint64_t out[2])
-{
-	out[0] = g_replaced.load();
-	out[1] = g_unplaced.load();
-}
 
 }  // extern "C"

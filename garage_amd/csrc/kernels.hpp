@@ -534,15 +534,6 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrAppl
 	}
 }
 
-// Occupies one wave for `ticks` x 10 ns and touches no memory: what the stream placement probe (ec_hip_staging.cpp,
-// place_streams) runs on one stream while it times a launch on another.
-__global__ __launch_bounds__(64) void spin_ticks(uint64_t ticks)
-{
-	const uint64_t t0 = wall_clock64();
-	while (wall_clock64() - t0 < ticks)
-		__builtin_amdgcn_s_sleep(8);
-}
-
 // Clears the per-block mismatch flags ahead of a MODE_COMPARE launch.  A kernel rather
 // than hipMemsetAsync: inside a captured hipGraph (ROCm 7.0/7.2) the memset node did not
 // order the compare kernel behind the preceding encode kernel, so verify could race with

@@ -146,9 +146,6 @@ uint64_t gec_qos_yields(int device);
  * background codec then only has its low stream priority, its small chunks and its yields), 1 = masks for the link
  * kernels, 2 = masks and the foreground / background partition (GEC_BG_CUS > 0). */
 int gec_cu_masks_active(void);
-/* Stream placement (GEC_PLACE_STREAMS): out[0] = streams created again because they shared a dispatcher with a stream
- * whose kernels run for long beside theirs, out[1] = streams for which five tries did not find a free one. */
-void gec_stream_placement(uint64_t out[2]);
 /* Must not run concurrently with any other call on the same codec, and only after
  * work enqueued by *_dev calls on caller streams has completed. */
 void gec_codec_destroy(gec_codec *c);

@@ -31,6 +31,5 @@ int gec_host_unregister(void *) { return gecimpl::fail(GEC_E_DEVICE, "no device"
 int gec_host_is_pinned(const void *, size_t) { return 0; }
 uint64_t gec_qos_yields(int) { return 0; }
 int gec_cu_masks_active(void) { return -1; }
-void gec_stream_placement(uint64_t out[2]) { out[0] = out[1] = 0; }
 
 }  // extern "C"

@@ -194,11 +194,6 @@ int main(int argc, char **argv)
 	const double p99_solo = pct(solo_put.lat_ms, 0.99), scrub_solo = solo_scrub.blocks / 1024.0 / solo_scrub.secs;
 	printf("CU masks: %d (2 = link / checksum masks and the foreground-background partition, 1 = masks without the partition, 0 = refused by "
 	       "this runtime: the classes then share every CU, -1 = not used)\n", gec_cu_masks_active());
-	{
-		uint64_t pl[2];
-		gec_stream_placement(pl);
-		printf("stream placement: %llu streams created again, %llu left sharing a dispatcher\n", (unsigned long long)pl[0], (unsigned long long)pl[1]);
-	}
 	printf("with the class:    put p99 %.2fx solo, scrub at %.0f %% of its solo rate (%llu chunk waits for foreground work)\n",
 	       pct(mixed_bg_put.lat_ms, 0.99) / p99_solo, 100.0 * (mixed_bg_scrub.blocks / 1024.0 / mixed_bg_scrub.secs) / scrub_solo,
 	       (unsigned long long)(y1 - y0));
