@@ -20,6 +20,9 @@ shard is missing.  Every shard byte is produced by the codec passed in
 Nodes are in-process objects (the way the reference tests multi-node logic with
 several NetApp instances on loopback, src/net/test.rs:15-118); the network and
 the metadata tables are out of scope.
+
+FROZEN (round 3): the product mirror is the C++ one (garage_amd/csrc/bm_*.cpp, include/garage_block.h); this module
+stays for the scenarios both mirrors share in the tests and for on-disk interop checks, and takes no new features.
 """
 from __future__ import annotations
 
