@@ -207,13 +207,69 @@ def cpu_backend_rate(S: int, nb: int = 512) -> dict:
             "sample": f"{nb} blocks x 1 MiB RS(10,4) gec_encode_batch on a GEC_BACKEND_CPU codec, best of 5"}
 
 
+def _proc_snapshot():
+    """(jiffies per field of the aggregate `cpu` line of /proc/stat, {pid: (comm, utime + stime)}) -- who else runs."""
+    fields = ("user", "nice", "system", "idle", "iowait", "irq", "softirq", "steal")
+    cpu = {}
+    try:
+        with open("/proc/stat") as f:
+            parts = f.readline().split()
+        cpu = {k: int(v) for k, v in zip(fields, parts[1:1 + len(fields)])}
+    except (OSError, ValueError):
+        pass
+    procs = {}
+    try:
+        for pid in os.listdir("/proc"):
+            if not pid.isdigit():
+                continue
+            try:
+                with open(f"/proc/{pid}/stat") as f:
+                    s = f.read()
+                comm = s[s.index("(") + 1:s.rindex(")")]
+                rest = s[s.rindex(")") + 2:].split()
+                procs[int(pid)] = (comm, int(rest[11]) + int(rest[12]))
+            except (OSError, ValueError, IndexError):
+                continue
+    except OSError:
+        pass
+    return cpu, procs
+
+
+def host_load_during(before, after, wall_s: float) -> dict:
+    """What the box did besides the oracle while it was timed: CPU seconds by kind (steal = taken by the hypervisor from
+    this VM's vCPUs) and the other processes that used the most CPU -- the threads a collapsed team was waiting for."""
+    hz = os.sysconf("SC_CLK_TCK") if hasattr(os, "sysconf") else 100
+    cpu0, p0 = before
+    cpu1, p1 = after
+    me = os.getpid()
+    out = {"wall_s": round(wall_s, 2)}
+    if cpu0 and cpu1:
+        out["cpu_seconds"] = {k: round((cpu1[k] - cpu0[k]) / hz, 2) for k in cpu1 if k in cpu0 and k in ("user", "system", "idle", "steal")}
+    others = []
+    for pid, (comm, t1) in p1.items():
+        if pid == me:
+            continue
+        dt = (t1 - p0.get(pid, (comm, 0))[1]) / hz
+        if dt >= 0.2:
+            others.append((dt, comm, pid))
+    others.sort(reverse=True)
+    out["other_processes_cpu_s"] = [{"comm": c, "pid": p, "cpu_s": round(d, 2)} for d, c, p in others[:5]]
+    try:
+        out["loadavg_after"] = open("/proc/loadavg").read().split()[:3]
+    except OSError:
+        pass
+    return out
+
+
 def cpu_baseline_only() -> None:
     """`bench.py --cpu-baseline-only`: the CPU figures in a process of their own -- nothing of HIP or torch is loaded
     while the oracle is timed (the in-process figure of round 2 fell from 388 to 259 GiB/s at 64 threads and from 333
     to 21 at 128 with an unchanged oracle: whatever else the bench process had running took part)."""
     S = (BLOCK_LEN + K - 1) // K
     S = (S + 63) // 64 * 64
+    snap0, t0 = _proc_snapshot(), time.time()
     out = cpu_baseline(S)
+    out["host_load_during_sweep"] = host_load_during(snap0, _proc_snapshot(), time.time() - t0)
     out["host"] = host_description()
     out["process"] = "fresh subprocess, before any HIP / torch initialisation; OMP_PROC_BIND=close OMP_PLACES=cores"
     # The point with one thread per LOGICAL CPU collapsed by 16x in round 2's line (and does here whenever it is run):
