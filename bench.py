@@ -168,7 +168,7 @@ def cpu_baseline(S: int, quick: bool = False):
         "cores": best[1],
         "kind": "port",
         "sample": f"{best[2]} blocks x 1 MiB RS(10,4) encode, median of 5 reps, "
-                  f"{'avx2 split-nibble' if variant else 'scalar'} + OpenMP static schedule with NUMA first-touch; "
+                  f"{'avx2 split-nibble' if variant else 'scalar'} + OpenMP, every thread on the blocks it first-touched (NUMA) and then on what others have left; "
                   "C restatement of reed-solomon-erasure (not the Rust crate)",
         "threads_sweep_GiBps": sweep,
         "host_threads_available": maxthr,

@@ -528,6 +528,14 @@ static int cmp_double(const void *a, const void *b)
 	return x < y ? -1 : x > y;
 }
 
+/* the contiguous share of thread t of T under schedule(static) without a chunk size */
+static void range_of(long n, int T, int t, long *lo, long *hi)
+{
+	const long q = n / T, r = n % T;
+	*lo = t * q + (t < r ? t : r);
+	*hi = *lo + q + (t < r ? 1 : 0);
+}
+
 double rso_bench_encode(int k, int m, size_t S, size_t nblocks, int reps,
 			int variant, int threads, uint64_t seed, uint8_t *checksum)
 {
@@ -538,10 +546,12 @@ double rso_bench_encode(int k, int m, size_t S, size_t nblocks, int reps,
 	uint8_t *buf = (uint8_t *)malloc(stride * nblocks);
 	uint8_t *M = (uint8_t *)malloc((size_t)n * k);
 	double *t = (double *)malloc(sizeof(double) * reps);
-	if (!buf || !M || !t || rso_build_matrix(k, m, M)) {
+	long *cursor = (long *)malloc(sizeof(long) * 8 * 1024); /* one cache line per thread */
+	if (!buf || !M || !t || !cursor || threads > 1024 || rso_build_matrix(k, m, M)) {
 		free(buf);
 		free(M);
 		free(t);
+		free(cursor);
 		return -1.0;
 	}
 #ifdef _OPENMP
@@ -550,7 +560,7 @@ double rso_bench_encode(int k, int m, size_t S, size_t nblocks, int reps,
 #else
 	threads = 1;
 #endif
-	/* first touch by the thread that will encode the block */
+	/* first touch by the thread that will encode the block (schedule(static) = the contiguous ranges of range_of) */
 #pragma omp parallel for schedule(static) num_threads(threads)
 	for (long b = 0; b < (long)nblocks; b++) {
 		uint64_t *p = (uint64_t *)(buf + (size_t)b * stride);
@@ -565,19 +575,41 @@ double rso_bench_encode(int k, int m, size_t S, size_t nblocks, int reps,
 	}
 	for (int r = -1; r < reps; r++) { /* r == -1: warm-up */
 		double t0 = now_s();
-#pragma omp parallel for schedule(static) num_threads(threads)
-		for (long b = 0; b < (long)nblocks; b++) {
-			const uint8_t *in[256];
-			uint8_t *out[256];
-			const uint8_t *rows[256];
-			uint8_t *base = buf + (size_t)b * stride;
-			for (int i = 0; i < k; i++)
-				in[i] = base + (size_t)i * S;
-			for (int j = 0; j < m; j++) {
-				out[j] = base + (size_t)(k + j) * S;
-				rows[j] = M + (size_t)(k + j) * k;
+		/* Every thread encodes the blocks it first-touched (its static range), then takes what is left of the others'
+		 * ranges, nearest first: a team member that loses its CPU for a while -- a vCPU the hypervisor hands to someone
+		 * else, any other runnable thread -- no longer holds the whole team at the closing barrier for the length of
+		 * its share (profiles/r03_cpu_baseline.txt: 128 threads 22 instead of 350 GiB/s on one box). */
+#pragma omp parallel num_threads(threads)
+		{
+#ifdef _OPENMP
+			const int tid = omp_get_thread_num(), T = omp_get_num_threads();
+#else
+			const int tid = 0, T = 1;
+#endif
+			long lo, hi;
+			range_of((long)nblocks, T, tid, &lo, &hi);
+			cursor[(size_t)tid * 8] = lo;
+#pragma omp barrier
+			for (int v = 0; v < T; v++) {
+				const int vic = (tid + v) % T;
+				range_of((long)nblocks, T, vic, &lo, &hi);
+				for (;;) {
+					const long b = __atomic_fetch_add(&cursor[(size_t)vic * 8], 1, __ATOMIC_RELAXED);
+					if (b >= hi)
+						break;
+					const uint8_t *in[256];
+					uint8_t *out[256];
+					const uint8_t *rows[256];
+					uint8_t *base = buf + (size_t)b * stride;
+					for (int i = 0; i < k; i++)
+						in[i] = base + (size_t)i * S;
+					for (int j = 0; j < m; j++) {
+						out[j] = base + (size_t)(k + j) * S;
+						rows[j] = M + (size_t)(k + j) * k;
+					}
+					code_some(k, m, rows, in, out, S, variant);
+				}
 			}
-			code_some(k, m, rows, in, out, S, variant);
 		}
 		if (r >= 0)
 			t[r] = now_s() - t0;
@@ -593,5 +625,6 @@ double rso_bench_encode(int k, int m, size_t S, size_t nblocks, int reps,
 	free(buf);
 	free(M);
 	free(t);
+	free(cursor);
 	return med;
 }
