@@ -15,3 +15,22 @@ bm = d["block_manager"]; pc = d["pcie_inclusive"]
 print(d["value"], d["roofline"]["frac"], {k.replace("rpc_","").replace("_GiBps",""): v for k, v in bm.items() if k.endswith("GiBps")}, {k.replace("_GiBps",""): v for k, v in pc.items() if k.endswith("GiBps")})
 print({k: v for k, v in d["cpu_baseline"].items() if k in ("value", "cores", "cpu_backend")})
 PY
+# rocprofv3 --kernel-trace --stats of the host-pointer paths (the walked-tile link kernels, checksum kernels), summarised
+cd /tmp && export TMPDIR=/tmp
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/final/prof_host
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final/prof_host -o h -- python $GRAFT_REPO_ROOT/tools/host_path_bench.py 512 > $GRAFT_REPO_ROOT/gpurun_out/final/prof_host.json 2> $GRAFT_REPO_ROOT/gpurun_out/final/prof_host.err
+cd $GRAFT_REPO_ROOT
+python - <<'PY'
+import csv, glob
+f = glob.glob("gpurun_out/final/prof_host/**/*kernel_stats.csv", recursive=True)
+out = open("gpurun_out/final/host_path_kernel_stats.txt", "w")
+if f:
+    rows = list(csv.DictReader(open(f[0])))
+    out.write("%6s %10s %10s %10s %6s  kernel\n" % ("calls", "avg_us", "min_us", "max_us", "%"))
+    for r in rows[:16]:
+        out.write("%6s %10.1f %10.1f %10.1f %6.2f  %s\n" % (r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
+                                                     float(r["Percentage"]), r["Name"][:110]))
+out.close()
+print(open("gpurun_out/final/host_path_kernel_stats.txt").read())
+PY
+find gpurun_out/final/prof_host -name "*.csv" -size +1M -delete
