@@ -765,6 +765,9 @@ def run_threads(args) -> None:
     out["roofline_frac_per_gpu"] = [round(algo_bytes(r["nb"], S) / (r["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if r["kern_ms"] else None
                                     for r in res]
     out["parity_checked_blocks"] = sum(r["checked"] for r in res)
+    out["parity_check"] = ("CPU oracle byte-for-byte on "
+                           + ("every block" if out["parity_checked_blocks"] == sum(r["nb"] for r in res) else f"{out['parity_checked_blocks']} strided blocks")
+                           + " of every GPU's timed batch, after the timed region; gec_verify_batch_dev over every block beside it")
     out["rccl_ranks"] = None
     out["collective_backend"] = "none (single process; the encode path has no collective)"
     if all(r["host_fed"] for r in res):
