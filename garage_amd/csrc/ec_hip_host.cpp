@@ -79,7 +79,6 @@ int HipBackend::encode_batch(size_t nblocks, const uint8_t *const *blocks, const
 				rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), out.data(), (int)m, S, c->enc.row(k), up, mir);
 			if (rc || !shard_sums)
 				continue;
-			uint8_t *d_sums = mir + zch * stripe;
 			hipError_t e = hipEventRecord(st.ev_seg[ci & 1], up);
 			if (e == hipSuccess)
 				e = hipStreamWaitEvent(chain, st.ev_seg[ci & 1], 0);
@@ -87,9 +86,8 @@ int HipBackend::encode_batch(size_t nblocks, const uint8_t *const *blocks, const
 				rc = fail(GEC_E_DEVICE, "chunk event");
 				continue;
 			}
-			rc = blake2_dev(c, nb * n, mir, nullptr, nullptr, S, S, d_sums, chain, 0, 0, 0, true);
-			if (!rc && hipMemcpyAsync(st.h_buf + b0 * n * 32, d_sums, nb * n * 32, hipMemcpyDeviceToHost, chain) != hipSuccess)
-				rc = fail(GEC_E_DEVICE, "hipMemcpyAsync (shard sums)");
+			// the checksums land in the slot's pinned area straight from the kernel (no copy to launch behind it)
+			rc = blake2_dev(c, nb * n, mir, nullptr, nullptr, S, S, st.h_buf + b0 * n * 32, chain, 0, 0, 0, true);
 			if (!rc && hipEventRecord(st.ev_seg[2 + (ci & 1)], chain) != hipSuccess)
 				rc = fail(GEC_E_DEVICE, "hipEventRecord");
 		}
@@ -902,7 +900,6 @@ int HipBackend::verify_hash_batch(size_t nblocks, const uint8_t *const *shards, 
 			rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), par.data(), (int)m, S, c->enc.row((int)k), up, mir, st.h_bad + b0);
 		if (rc)
 			continue;
-		uint8_t *d_sums = mir + zch * stripe;
 		hipError_t e = hipEventRecord(st.ev_seg[ci & 1], up);
 		if (e == hipSuccess)
 			e = hipStreamWaitEvent(chain, st.ev_seg[ci & 1], 0);
@@ -910,9 +907,7 @@ int HipBackend::verify_hash_batch(size_t nblocks, const uint8_t *const *shards, 
 			rc = fail(GEC_E_DEVICE, "chunk event");
 			continue;
 		}
-		rc = blake2_dev(c, nb * n, mir, nullptr, nullptr, S, S, d_sums, chain, 0, 0, 0, true);
-		if (!rc && hipMemcpyAsync(st.h_buf + b0 * n * 32, d_sums, nb * n * 32, hipMemcpyDeviceToHost, chain) != hipSuccess)
-			rc = fail(GEC_E_DEVICE, "hipMemcpyAsync (shard sums)");
+		rc = blake2_dev(c, nb * n, mir, nullptr, nullptr, S, S, st.h_buf + b0 * n * 32, chain, 0, 0, 0, true);
 		if (!rc && hipEventRecord(st.ev_seg[2 + (ci & 1)], chain) != hipSuccess)
 			rc = fail(GEC_E_DEVICE, "hipEventRecord");
 	}
@@ -1069,7 +1064,6 @@ int HipBackend::reconstruct_batch(size_t nblocks, const uint8_t *const *shards, 
 					rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), outp.data(), (int)nmiss, S, w.plan->rows.v.data(), up, mir);
 				if (rc || !sums)
 					continue;
-				uint8_t *d_sums = mir + zch * n * S;
 				hipError_t e = hipEventRecord(st.ev_seg[q & 1], up);
 				if (e == hipSuccess)
 					e = hipStreamWaitEvent(chain, st.ev_seg[q & 1], 0);
@@ -1077,9 +1071,7 @@ int HipBackend::reconstruct_batch(size_t nblocks, const uint8_t *const *shards, 
 					rc = fail(GEC_E_DEVICE, "chunk event");
 					continue;
 				}
-				rc = blake2_dev(c, nb * per, mir, nullptr, nullptr, S, S, d_sums, chain, 0, 0, 0, true);
-				if (!rc && hipMemcpyAsync(st.h_buf + sum_off, d_sums, nb * per * 32, hipMemcpyDeviceToHost, chain) != hipSuccess)
-					rc = fail(GEC_E_DEVICE, "hipMemcpyAsync (shard sums)");
+				rc = blake2_dev(c, nb * per, mir, nullptr, nullptr, S, S, st.h_buf + sum_off, chain, 0, 0, 0, true);
 				if (!rc && hipEventRecord(st.ev_seg[2 + (q & 1)], chain) != hipSuccess)
 					rc = fail(GEC_E_DEVICE, "hipEventRecord");
 				sum_off += nb * per * 32;
