@@ -19,6 +19,7 @@ struct Env {
 	unsigned copy_threads;  // GEC_COPY_THREADS
 	bool zero_copy;         // GEC_ZERO_COPY
 	int upload_cus;         // GEC_UPLOAD_CUS
+	unsigned bg_link_wait_us; // GEC_BG_LINK_WAIT_US
 	unsigned home_rate_gbps; // GEC_HOME_RATE_GBPS
 	int resident_grid;      // GEC_RESIDENT_GRID
 	int verify_segments;    // GEC_VERIFY_SEGMENTS (0 = the built-in maximum)

@@ -82,6 +82,7 @@ struct QosPolicy {
 	int compute_cus = 0;       // > 0: the codec's streams are confined to this many CUs (of num_cu)
 	int compute_cus_plan = 0;  // GEC_BG_CUS as every codec of the process sees it: the CUs set aside for the background class
 	int num_cu = 0;
+	int device = 0;
 };
 
 // Staging resources for the host-pointer entry points (one per in-flight call).
@@ -333,8 +334,12 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 // 16-byte aligned src and dst.
 // max_wgs > 0: a grid of at most that many workgroups walking the tiles; pace_ns > 0: each starts a tile every pace_ns
 int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipStream_t stream, unsigned max_wgs = 0, unsigned pace_ns = 0);
+// what a link kernel launched from this slot does with the device's link_busy count
+void link_role_of(const Staging &st, unsigned pace_ns, uint32_t **busy, uint32_t *role, uint32_t *wait_ticks);
 
 int launch_clear_flags(uint32_t *d_bad, size_t n, hipStream_t stream);
+// the device's count of running foreground link workgroups (kernel_args.hpp, PtrApplyArgs::link_busy); NULL if it could not be allocated
+uint32_t *link_busy_counter(int device);
 
 // blake2sum of n messages.  group != 0: message i lives at d_base + (i / group)*group_stride + (i % group)*stride and
 // its checksum goes to d_out + 32*((i / group)*out_group + i % group) -- e.g. only the data (or only the parity)

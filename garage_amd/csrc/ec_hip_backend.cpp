@@ -170,6 +170,7 @@ int make_hip_backend(gec_codec *c, int device, std::unique_ptr<Backend> &out)
 	HIP_TRY(hipGetDeviceProperties(&prop, device));
 	hb->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	hb->qos.num_cu = hb->num_cu;
+	hb->qos.device = device;
 	hb->qos.compute_cus_plan = env().bg_cus > 0 && env().bg_cus < hb->num_cu ? env().bg_cus : 0;
 	if (c->qos_class == GEC_CLASS_BACKGROUND) {
 		// low-priority streams (the hardware scheduler hands free CUs to the foreground queues first) and a CU mask

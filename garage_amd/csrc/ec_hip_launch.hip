@@ -388,6 +388,7 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 	a.in = t_in;
 	a.in_valid = t_valid;
 	a.bad = bad;
+	link_role_of(st, 0, &a.link_busy, &a.link_role, &a.link_wait_ticks);
 	int rows = 0;
 	size_t out_done = 0;  // entries of t_out consumed by earlier row groups
 	for (int r0 = 0; r0 < nout; r0 += rows) {
@@ -445,7 +446,10 @@ int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipS
 	unsigned grid = resident_grid(st, stream, total);
 	if (max_wgs > 0)
 		grid = std::min(grid, max_wgs);
-	hipLaunchKernelGGL(gec::copy_table, dim3(grid), dim3(256), 0, stream, tab, (uint32_t)gx, total, max_wgs > 0 ? pace_ns / 10 : 0u);
+	const unsigned pace = max_wgs > 0 ? pace_ns : 0;
+	uint32_t *busy = nullptr, role = 0, wait_ticks = 0;
+	link_role_of(st, pace, &busy, &role, &wait_ticks);
+	hipLaunchKernelGGL(gec::copy_table, dim3(grid), dim3(256), 0, stream, tab, (uint32_t)gx, total, pace / 10, busy, role, wait_ticks);
 	HIP_TRY(hipGetLastError());
 	return GEC_OK;
 }

@@ -2,6 +2,7 @@
 // buffers), the registry of pinned caller memory (gec_host_*), the quality-of-service gate between foreground and
 // background codecs.  Host code only.
 #include "ec_hip.hpp"
+#include "kernel_args.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -297,6 +298,43 @@ StagingLease::~StagingLease()
 	HipBackend &hb = hip_of(c);
 	std::lock_guard<std::mutex> g(hb.pool_mu);
 	hb.pool.push_back(st);
+}
+
+// ------------------------------------------------------------------ who has the link
+uint32_t *link_busy_counter(int device)
+{
+	static std::mutex mu;
+	static uint32_t *ctr[64] = {};
+	static bool tried[64] = {};
+	const unsigned d = (unsigned)device % 64;
+	std::lock_guard<std::mutex> g(mu);
+	if (!tried[d]) {
+		tried[d] = true;
+		void *p = nullptr;
+		if (hipMalloc(&p, 256) == hipSuccess && hipMemset(p, 0, 256) == hipSuccess)
+			ctr[d] = static_cast<uint32_t *>(p);
+		else
+			(void)hipGetLastError();
+	}
+	return ctr[d];
+}
+
+// Foreground link kernels announce themselves, background ones give way (GEC_BG_LINK_WAIT_US per workgroup and launch);
+// a paced copy (rebuilt shards on their way home) is in no hurry and does neither.
+void link_role_of(const Staging &st, unsigned pace_ns, uint32_t **busy, uint32_t *role, uint32_t *wait_ticks)
+{
+	*busy = nullptr;
+	*role = gec::LINK_NONE;
+	*wait_ticks = 0;
+	const unsigned wait_us = env().bg_link_wait_us;
+	if (wait_us == 0 || pace_ns != 0)
+		return;
+	uint32_t *c = link_busy_counter(st.qos.device);
+	if (!c)
+		return;
+	*busy = c;
+	*role = st.qos.background ? gec::LINK_YIELD : gec::LINK_SIGNAL;
+	*wait_ticks = wait_us * 100u;
 }
 
 // ------------------------------------------------------------------ foreground / background

@@ -55,6 +55,8 @@ constexpr int PTR_KMAX = 128;  // coef[PTR_KMAX][RMAX] keeps the kernel argument
 // allocation must leave room for) and used by the host to size grids that FIT (ec_hip_launch.hip, resident_grid).
 constexpr int RESIDENT_WGS = 6;
 
+enum : uint32_t { LINK_NONE = 0, LINK_SIGNAL = 1, LINK_YIELD = 2 };
+
 struct PtrApplyArgs {
 	const uint8_t *const *in;  // [nblocks][k]: 16-byte aligned shard pointers
 	const uint32_t *in_valid;  // [nblocks][k]: bytes of the shard that exist (<= 16*cols)
@@ -62,6 +64,12 @@ struct PtrApplyArgs {
 	uint32_t cols;             // 16-byte columns per shard
 	uint32_t k, rows;
 	uint32_t tiles_x, tiles_total;  // 256-column tiles per shard; tiles_x * (blocks of this launch)
+	// The link is the one thing the two classes cannot be given halves of.  link_busy counts the workgroups of
+	// FOREGROUND link kernels that are running on the device (LINK_SIGNAL: +1 on entry, -1 on exit); a BACKGROUND link
+	// kernel (LINK_YIELD) looks at it before every tile and sleeps while it is non-zero -- for at most
+	// link_wait_ticks (10 ns each) per workgroup and launch, so that it always finishes.
+	uint32_t *link_busy;
+	uint32_t link_role, link_wait_ticks;
 	// MIRROR: everything the kernel reads and computes is also laid down in device memory, dense --
 	// mirror + b*mirror_stride + t*16*cols for input shard t (first row group only: mirror_inputs),
 	// ... + mirror_row0 + r*16*cols for output row r -- so that the shard checksums can be computed from

@@ -379,6 +379,31 @@ __device__ __forceinline__ u32x4 ld16_valid(const uint8_t *shard, uint32_t col, 
 	return u32x4{w[0], w[1], w[2], w[3]};
 }
 
+// see PtrApplyArgs::link_busy
+__device__ __forceinline__ void link_enter(uint32_t *busy, uint32_t role)
+{
+	if (role == LINK_SIGNAL && threadIdx.x == 0)
+		__hip_atomic_fetch_add(busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void link_leave(uint32_t *busy, uint32_t role)
+{
+	if (role == LINK_SIGNAL && threadIdx.x == 0)
+		__hip_atomic_fetch_sub(busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// returns what is left of the wait budget
+__device__ __forceinline__ uint32_t link_yield(const uint32_t *busy, uint32_t role, uint32_t budget_ticks)
+{
+	if (role != LINK_YIELD || budget_ticks == 0)
+		return budget_ticks;
+	const uint64_t t0 = wall_clock64();
+	uint64_t waited = 0;
+	while (__hip_atomic_load(busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 && waited < budget_ticks) {
+		__builtin_amdgcn_s_sleep(64);
+		waited = wall_clock64() - t0;
+	}
+	return waited >= budget_ticks ? 0u : budget_ticks - (uint32_t)waited;
+}
+
 template <int MW, int KC, bool MIRROR, bool COMPARE = false>
 __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrApplyArgs a, const LogExp *__restrict__ le)
 {
@@ -393,6 +418,8 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrAppl
 	// grid to what the stream's CU partition holds at once (ec_hip_launch.hip, resident_grid): a launch with more
 	// workgroups than fit keeps its queue's dispatcher busy until the last one is placed, and kernels of OTHER streams
 	// that share that dispatcher wait for as long (tools/dispatch_probe, profiles/r03_qos.txt).
+	link_enter(a.link_busy, a.link_role);
+	uint32_t wait_left = link_yield(a.link_busy, a.link_role, a.link_wait_ticks);
 	uint32_t tile = blockIdx.x;
 	uint32_t b = tile / a.tiles_x;
 	uint32_t col_raw = (tile - b * a.tiles_x) * 256 + tid;
@@ -481,6 +508,8 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrAppl
 		const uint32_t ncol = nlive ? ncol_raw : 0;
 		const uint8_t *const *ninp = a.in + (size_t)nb * k;
 		const uint32_t *nvalid = a.in_valid + (size_t)nb * k;
+		if (more)
+			wait_left = link_yield(a.link_busy, a.link_role, wait_left);
 		if (more) {
 #pragma unroll
 			for (int j = 0; j < KC; ++j) {
@@ -532,6 +561,7 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrAppl
 		inp = ninp;
 		valid = nvalid;
 	}
+	link_leave(a.link_busy, a.link_role);
 }
 
 // Clears the per-block mismatch flags ahead of a MODE_COMPARE launch.  A kernel rather
@@ -557,8 +587,11 @@ __global__ void clear_flags(uint32_t *p, uint32_t n)
 // ---------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256, RESIDENT_WGS) void copy_table(const CopyEntry *__restrict__ tab, uint32_t tiles_x, uint32_t tiles_total,
-								  uint32_t pace_ticks)
+								  uint32_t pace_ticks, uint32_t *link_busy, uint32_t link_role,
+								  uint32_t link_wait_ticks)
 {
+	link_enter(link_busy, link_role);
+	uint32_t wait_left = link_wait_ticks;
 	// 1-D grid, possibly shorter than the tile list (see gf_apply_ptrs): tile = entry * tiles_x + 16 KiB tile of the entry.
 	// pace_ticks > 0: a workgroup starts its i-th tile no earlier than i * pace_ticks (10 ns each) after its first -- a
 	// copy that has the whole trip to finish in (rebuilt shards going home beside the checksum chains) must not fill the
@@ -569,6 +602,7 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void copy_table(const CopyEntry 
 		if (pace_ticks)
 			while (wall_clock64() - t0 < (uint64_t)turn * pace_ticks)
 				__builtin_amdgcn_s_sleep(16);
+		wait_left = link_yield(link_busy, link_role, wait_left);
 		const uint32_t ent = tile / tiles_x, tx = tile - ent * tiles_x;
 		const CopyEntry e = tab[ent];
 		const uint64_t nvec = e.bytes >> 4;
@@ -592,6 +626,7 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void copy_table(const CopyEntry 
 			for (uint64_t q = 0; q < tail; ++q)
 				e.dst[(nvec << 4) + q] = e.src[(nvec << 4) + q];
 	}
+	link_leave(link_busy, link_role);
 }
 
 // ---------------------------------------------------------------------------
