@@ -133,6 +133,10 @@ int gec_codec_create_ex(int k, int m, int backend, int device, int matrix, gec_c
  *     (each walks a list of tiles): a launch with more keeps its queue's dispatcher busy until the last workgroup
  *     is placed, and kernels of foreground streams that share that dispatcher would wait for as long
  *     (tools/dispatch_probe);
+ *   - its link kernels give way on the device: foreground link kernels count their running workgroups in a word of
+ *     device memory, and a background link kernel's workgroups sleep before every tile while that count is non-zero
+ *     (at most GEC_BG_LINK_WAIT_US per workgroup and launch): the link is the one resource the classes cannot be
+ *     given halves of;
  *   - it keeps to two staging-copy threads.
  * libgarage_block runs gbm_scrub_all / gbm_resync_run on such a sibling.  Results are identical. */
 enum { GEC_CLASS_FOREGROUND = 0, GEC_CLASS_BACKGROUND = 1 };
