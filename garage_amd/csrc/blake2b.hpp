@@ -289,7 +289,7 @@ constexpr uint32_t B2Q_SLOT1 = 16 * B2Q_SLOT;
 
 template <bool ODD>
 __device__ __forceinline__ void b2q_compress(uint64_t &ha, uint64_t &hb, const uint32_t (&wa)[10][4], uint32_t q, uint64_t t,
-					     bool last, uint64_t &x, uint64_t &y)
+					     bool last, uint64_t &x, uint64_t &y, bool last_node = false)
 {
 	constexpr uint32_t CUR = ODD ? B2Q_SLOT1 : 0, NXT = ODD ? 0 : B2Q_SLOT1;
 	const uint64_t IVq = q == 0 ? 0x6a09e667f3bcc908ULL : q == 1 ? 0xbb67ae8584caa73bULL
@@ -301,6 +301,8 @@ __device__ __forceinline__ void b2q_compress(uint64_t &ha, uint64_t &hb, const u
 	if (q == 0)
 		d ^= t;
 	if (q == 2 && last)
+		d = ~d;
+	if (q == 3 && last && last_node)  // tree mode: f1 on the final block of the last node of a level
 		d = ~d;
 #define GEC_B2Q_WORD(off, r, i) (*reinterpret_cast<lds_u64_t *>(wa[(r) % 10][i] + (off)))
 	// The four message words of a round are gathered together, one whole round before they are used (a lone wave pays
@@ -381,6 +383,7 @@ struct B2QLane {
 	uint32_t q, stage;   // stage = LDS address of this lane's quarter in slot 0
 	u64x2 w0, w1;
 	uint64_t ha, hb, x, y;
+	bool last_node = false;  // tree-mode leaves only (blake2b_batch_quad<true>)
 };
 
 template <bool ODD>
@@ -405,7 +408,7 @@ __device__ __forceinline__ void b2q_block(B2QLane &L, const uint32_t (&wa)[10][4
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	const bool last = blk + 1 == L.nblk;
-	b2q_compress<ODD>(L.ha, L.hb, wa, L.q, last ? L.len : (blk + 1) * 128, last, L.x, L.y);
+	b2q_compress<ODD>(L.ha, L.hb, wa, L.q, last ? L.len : (blk + 1) * 128, last, L.x, L.y, L.last_node);
 	__builtin_amdgcn_wave_barrier();
 }
 
@@ -426,28 +429,76 @@ __device__ __forceinline__ void b2q_block_fast(B2QLane &L, const uint32_t (&wa)[
 	__builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
+// LEAF: the messages are the 4 KiB leaves of the shard checksums' tree (below): message i is leaf i % nleaf_max of shard
+// i / nleaf_max, hashed with the leaf parameter block, and all 64 bytes of its digest go to leafdig[i].  For batches too
+// small to give the one-lane-per-leaf kernel a wave per SIMD -- a PutObject's three blocks are 1092 leaves, 17 waves, 139 us
+// of one wave's issue latency however idle the chip is -- four lanes per leaf finish in a third of the time.
+// TREE = B2Q_ROOT: the messages are the shards' roots -- message s is the nleaf(s) * 64 bytes of leaf digests of shard s, hashed
+// with the root parameter block, its first 32 bytes stored like a plain digest (shardsum_roots with four lanes per shard).
+enum : int { B2Q_PLAIN = 0, B2Q_LEAF = 1, B2Q_ROOT = 2 };
+template <int TREE = B2Q_PLAIN>
+__global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a, uint32_t nleaf_max = 0, uint8_t *__restrict__ leafdig = nullptr)
 {
+	constexpr bool LEAF = TREE == B2Q_LEAF, ROOT = TREE == B2Q_ROOT;
 	__shared__ __attribute__((aligned(16))) uint8_t lds[2 * 16 * B2Q_SLOT];
 	__builtin_amdgcn_s_setprio(3);
 	const uint32_t lane = threadIdx.x;
 	const uint32_t q = lane & 3;
 	const uint32_t i = blockIdx.x * 16 + (lane >> 2);
-	const bool live = i < a.n;
-	const uint32_t ii = live ? i : a.n - 1;  // dead quads shadow the last message (no stores)
-	const uint8_t *p = b2_msg_ptr(a, ii);
-	const uint64_t len = a.len ? a.len[ii] : a.uniform_len;
+	bool live;
+	uint32_t ii;
+	const uint8_t *p;
+	uint64_t len;
+	uint32_t leaf = 0;
+	bool last_node = false;
+	if (LEAF) {
+		const uint64_t total = (uint64_t)a.n * nleaf_max;
+		const uint64_t iq = (uint64_t)i < total ? i : total - 1;  // dead quads shadow the last leaf slot (no stores)
+		const uint32_t s = (uint32_t)(iq / nleaf_max);
+		leaf = (uint32_t)(iq % nleaf_max);
+		const uint64_t slen = a.len ? a.len[s] : a.uniform_len;
+		const uint32_t nleaf = slen ? (uint32_t)((slen + SHARDSUM_LEAF - 1) / SHARDSUM_LEAF) : 1;
+		live = (uint64_t)i < total && leaf < nleaf;
+		if (leaf >= nleaf)
+			leaf = nleaf - 1;  // a slot beyond this shard's leaves: shadow its last leaf
+		ii = s;
+		p = b2_msg_ptr(a, s) + (uint64_t)leaf * SHARDSUM_LEAF;
+		const uint64_t lo = (uint64_t)leaf * SHARDSUM_LEAF;
+		len = slen > lo ? (slen - lo < SHARDSUM_LEAF ? slen - lo : SHARDSUM_LEAF) : 0;
+		last_node = leaf + 1 == nleaf;
+	} else if (ROOT) {
+		live = i < a.n;
+		ii = live ? i : a.n - 1;
+		const uint64_t slen = a.len ? a.len[ii] : a.uniform_len;
+		const uint32_t nleaf = slen ? (uint32_t)((slen + SHARDSUM_LEAF - 1) / SHARDSUM_LEAF) : 1;
+		p = leafdig + (uint64_t)ii * nleaf_max * 64;
+		len = (uint64_t)nleaf * 64;
+		last_node = true;
+	} else {
+		live = i < a.n;
+		ii = live ? i : a.n - 1;  // dead quads shadow the last message (no stores)
+		p = b2_msg_ptr(a, ii);
+		len = a.len ? a.len[ii] : a.uniform_len;
+	}
 	const uint32_t slot0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)(lds + (lane >> 2) * B2Q_SLOT);
 	const uint32_t q7 = q * 7;
 	B2QLane L;
-	L.ha = (q == 0 ? 0x6a09e667f3bcc908ULL ^ 0x01010040ULL : q == 1 ? 0xbb67ae8584caa73bULL
-		: q == 2 ? 0x3c6ef372fe94f82bULL : 0xa54ff53a5f1d36f1ULL);
+	if (LEAF)  // the leaf parameter block: like shardsum_leaves
+		L.ha = (q == 0 ? 0x6a09e667f3bcc908ULL ^ SHARDSUM_P0 : q == 1 ? 0xbb67ae8584caa73bULL ^ (uint64_t)leaf /*node_offset*/
+			: q == 2 ? 0x3c6ef372fe94f82bULL ^ SHARDSUM_P2_LEAF : 0xa54ff53a5f1d36f1ULL);
+	else if (ROOT)
+		L.ha = (q == 0 ? 0x6a09e667f3bcc908ULL ^ SHARDSUM_P0 : q == 1 ? 0xbb67ae8584caa73bULL
+			: q == 2 ? 0x3c6ef372fe94f82bULL ^ SHARDSUM_P2_ROOT : 0xa54ff53a5f1d36f1ULL);
+	else
+		L.ha = (q == 0 ? 0x6a09e667f3bcc908ULL ^ 0x01010040ULL : q == 1 ? 0xbb67ae8584caa73bULL
+			: q == 2 ? 0x3c6ef372fe94f82bULL : 0xa54ff53a5f1d36f1ULL);
 	L.hb = (q == 0 ? 0x510e527fade682d1ULL : q == 1 ? 0x9b05688c2b3e6c1fULL
 		: q == 2 ? 0x1f83d9abfb41bd6bULL : 0x5be0cd19137e2179ULL);
+	L.last_node = (LEAF || ROOT) && last_node;
 	typedef __attribute__((address_space(3))) u64x2 lds_u64x2_w;
 	const uint64_t nblk = len ? (len + 127) / 128 : 1;  // the empty message still has one (all-zero, final) block
-	const uint64_t b0 = a.seg_begin_blk, b1 = nblk < a.seg_end_blk ? nblk : a.seg_end_blk;
-	if (b0 > 0 && b0 < b1) {  // resume
+	const uint64_t b0 = TREE ? 0 : a.seg_begin_blk, b1 = TREE ? nblk : (nblk < a.seg_end_blk ? nblk : a.seg_end_blk);
+	if (!TREE && b0 > 0 && b0 < b1) {  // resume
 		L.ha = a.state[8ull * ii + q];
 		L.hb = a.state[8ull * ii + 4 + q];
 	}
@@ -500,7 +551,11 @@ __global__ __launch_bounds__(64) void blake2b_batch_quad(const Blake2Args a)
 	}
 	if (!live || b0 >= b1)
 		return;
-	if (b1 == nblk) {
+	if (LEAF) {
+		uint64_t *o = reinterpret_cast<uint64_t *>(leafdig + 64ull * i);  // i = shard * nleaf_max + leaf
+		o[q] = L.ha;
+		o[4 + q] = L.hb;
+	} else if (b1 == nblk) {
 		reinterpret_cast<uint64_t *>(b2_out_ptr(a, i))[q] = L.ha;  // h[0..3] = first 32 bytes
 	} else {
 		a.state[8ull * i + q] = L.ha;

@@ -299,12 +299,20 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 			return rc;
 		const int addmode = env().b2_add;  // A/B, see blake2b.hpp
 		const dim3 lgrid((unsigned)((lanes + 63) / 64));
-		if (addmode == 0)
+		// few leaves (a PutObject's blocks, a GetObject's): four lanes per leaf, like the plain hash below
+		const int forced_leaf = env().blake2_kernel;
+		const bool quad_tree = forced_leaf ? forced_leaf == 2 : lanes < 40000;
+		if (quad_tree)
+			hipLaunchKernelGGL(gec::blake2b_batch_quad<gec::B2Q_LEAF>, dim3((unsigned)((lanes + 15) / 16)), dim3(64), 0, stream, a, nleaf, scratch);
+		else if (addmode == 0)
 			hipLaunchKernelGGL(gec::shardsum_leaves<0>, lgrid, dim3(64), 0, stream, a, nleaf, scratch);
 		else
 			hipLaunchKernelGGL(gec::shardsum_leaves<1>, lgrid, dim3(64), 0, stream, a, nleaf, scratch);
 		HIP_TRY(hipGetLastError());
-		hipLaunchKernelGGL(gec::shardsum_roots, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a, nleaf, scratch);
+		if (quad_tree)
+			hipLaunchKernelGGL(gec::blake2b_batch_quad<gec::B2Q_ROOT>, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, stream, a, nleaf, scratch);
+		else
+			hipLaunchKernelGGL(gec::shardsum_roots, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a, nleaf, scratch);
 		HIP_TRY(hipGetLastError());
 		return GEC_OK;
 	}
@@ -314,7 +322,7 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 	const int forced = env().blake2_kernel;
 	const bool quad = d_state ? true : forced ? forced == 2 : n < 40000;  // segments: the quad kernel only
 	if (quad)
-		hipLaunchKernelGGL(gec::blake2b_batch_quad, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, stream, a);
+		hipLaunchKernelGGL(gec::blake2b_batch_quad<gec::B2Q_PLAIN>, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, stream, a, 0u, static_cast<uint8_t *>(nullptr));
 	else
 		{
 		const int addmode = env().b2_add;

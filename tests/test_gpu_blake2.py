@@ -93,6 +93,10 @@ lens = list(range(0, 300)) + [383, 384, 385, 4095, 4096, 4097, 104896]
 msgs = [bytes((i * 7 + j) & 255 for j in range(n)) for i, n in enumerate(lens)]
 want = [hashlib.blake2b(x, digest_size=64).digest()[:32] for x in msgs]
 assert rs.blake2sum_batch(msgs) == want
+# the shard checksum's leaves and roots have the same two forms (four lanes per leaf / root below 40000 leaves)
+tl = [0, 1, 63, 64, 65, 127, 128, 129, 4095, 4096, 4097, 8191, 8192, 8193, 12288, 12289, 104896, 209728, (1 << 20) + 5]
+tm = [bytes((i * 11 + j * 3) & 255 for j in range(n)) for i, n in enumerate(tl)]
+assert rs.shardsum_batch(tm) == [g.shardsum(x) for x in tm]
 print("ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for kern in ("quad", "lane"):
