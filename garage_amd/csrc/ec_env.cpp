@@ -32,7 +32,7 @@ const Row kRows[] = {
 	{"GEC_HOME_RATE_GBPS", "25", "the read path sends rebuilt shards home no faster than this while checksum chains run (0 = unpaced, one workgroup per tile): a link saturated with writes backs up into the fabric and every other kernel's loads wait"},
 	{"GEC_RESIDENT_GRID", "1", "A/B: 0 = link kernels launch one workgroup per tile instead of a grid that fits the stream's CUs and walks the tiles"},
 	{"GEC_ROWS16", "1", "A/B: 0 = 9..16 output rows as 8-row passes instead of one 16-row pass"},
-	{"GEC_BLAKE2_KERNEL", "auto", "A/B: lane or quad forces one of the two plain-blake2 kernels"},
+	{"GEC_BLAKE2_KERNEL", "auto", "A/B: lane or quad forces one of the two forms of the blake2 kernels (plain hashes, and the leaves / roots of the shard checksums)"},
 	{"GEC_B2_ADD", "0", "A/B: 1 = 64-bit adds of the blake2 kernels spelled as 32-bit add / addc"},
 	{"GEC_MAX_COLS_PER_LAUNCH", "0", "test hook: cap on the 16-byte columns one launch covers, to exercise the multi-launch split on small inputs"},
 	{"GEC_RCCL_LIB", "librccl.so.1", "RCCL to dlopen for gec_group_*"},
