@@ -8,13 +8,16 @@
 // (gec_codec_background: low-priority CU-masked streams, small chunks that yield to foreground calls); both with
 // maintenance on the request path's own codec (gbm_set_maintenance_class(m, 0): round 2's behaviour).
 // Reports put p50 / p99 / rate and the scrub rate of each phase.
-// usage: qos_bench [callers=3] [seconds=3] [scrub_blocks=512] [tranquility=0]
+// usage: qos_bench [callers=3] [seconds=3] [scrub_blocks=512] [tranquility=0] [get_blocks=0]
+// get_blocks = G > 0: the callers are readers instead -- each keeps fetching G of its blocks with one gbm_rpc_get_blocks (a
+// GetObject with its prefetch), block-hash check on -- and the latencies reported are those of the gets.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -43,6 +46,7 @@ int main(int argc, char **argv)
 	const double seconds = argc > 2 ? atof(argv[2]) : 3.0;
 	const size_t nscrub = argc > 3 ? (size_t)atol(argv[3]) : 512;
 	const int tranq = argc > 4 ? atoi(argv[4]) : 0;
+	const int get_blocks = argc > 5 ? atoi(argv[5]) : 0;
 	gec_codec *c = nullptr;
 	gbm_manager *ma = nullptr, *mb = nullptr;
 	if (gec_codec_create(10, 4, GEC_BACKEND_AUTO, 0, &c) != GEC_OK || gbm_create(c, 16, NULL, 0, &ma) != GBM_OK ||
@@ -82,7 +86,52 @@ int main(int argc, char **argv)
 	if (gbm_batcher_create(ma, 128, 300, &bt) != GBM_OK)
 		return 2;
 	std::atomic<bool> stop{false};
-	auto run_puts = [&](PutStats &ps) {
+	const char *op = get_blocks > 0 ? "get" : "put";
+	if (get_blocks > 0) {  // readers: their blocks have to be there first
+		if (get_blocks > RING)
+			return 2;
+		std::vector<const uint8_t *> d(data.size());
+		std::vector<size_t> l(data.size(), L);
+		for (size_t i = 0; i < data.size(); ++i)
+			d[i] = data[i].data();
+		if (gbm_rpc_put_blocks(ma, data.size(), hashes.data(), d.data(), l.data(), NULL, NULL) != GBM_OK) {
+			fprintf(stderr, "preload failed: %s\n", gbm_last_error());
+			return 2;
+		}
+	}
+	auto run_gets = [&](PutStats &ps) {
+		std::vector<std::vector<double>> lat(callers);
+		std::vector<std::thread> th;
+		const auto t0 = Clock::now();
+		for (int t = 0; t < callers; ++t)
+			th.emplace_back([&, t] {
+				std::vector<std::vector<uint8_t>> out(get_blocks, std::vector<uint8_t>(L));
+				std::vector<uint8_t *> op_(get_blocks);
+				std::vector<size_t> cap(get_blocks, L), len(get_blocks);
+				std::vector<int> rcs(get_blocks);
+				for (int i = 0; i < get_blocks; ++i)
+					op_[i] = out[i].data();
+				for (size_t j = 0; !stop.load(); ++j) {
+					const size_t i0 = (size_t)t * RING + (j % (RING / get_blocks)) * get_blocks;
+					const auto a = Clock::now();
+					if (gbm_rpc_get_blocks(ma, get_blocks, &hashes[32 * i0], NULL, op_.data(), cap.data(), len.data(), rcs.data()) != GBM_OK ||
+					    rcs[0] != GBM_OK || len[0] != L) {
+						fprintf(stderr, "get failed: %s\n", gbm_last_error());
+						exit(1);
+					}
+					const double ms = std::chrono::duration<double, std::milli>(Clock::now() - a).count();
+					for (int i = 0; i < get_blocks; ++i)
+						lat[t].push_back(ms);  // one entry per block: the rate column counts blocks
+				}
+			});
+		for (auto &x : th)
+			x.join();
+		ps.secs = std::chrono::duration<double>(Clock::now() - t0).count();
+		for (auto &v : lat)
+			ps.lat_ms.insert(ps.lat_ms.end(), v.begin(), v.end());
+		std::sort(ps.lat_ms.begin(), ps.lat_ms.end());
+	};
+	auto run_puts_only = [&](PutStats &ps) {
 		std::vector<std::vector<double>> lat(callers);
 		std::vector<std::thread> th;
 		const auto t0 = Clock::now();
@@ -104,6 +153,12 @@ int main(int argc, char **argv)
 		for (auto &v : lat)
 			ps.lat_ms.insert(ps.lat_ms.end(), v.begin(), v.end());
 		std::sort(ps.lat_ms.begin(), ps.lat_ms.end());
+	};
+	auto run_puts = [&](PutStats &ps) {
+		if (get_blocks > 0)
+			run_gets(ps);
+		else
+			run_puts_only(ps);
 	};
 	struct ScrubStats {
 		uint64_t blocks = 0, corruptions = 0;
@@ -130,7 +185,7 @@ int main(int argc, char **argv)
 	auto report = [&](const char *name, const PutStats *ps, const ScrubStats *ss) {
 		printf("%-34s", name);
 		if (ps)
-			printf(" put p50 %6.3f ms  p90 %6.3f  p99 %6.3f ms  max %6.3f  %6.2f GiB/s (%zu puts)", pct(ps->lat_ms, 0.5), pct(ps->lat_ms, 0.9),
+			printf(" %s p50 %6.3f ms  p90 %6.3f  p99 %6.3f ms  max %6.3f  %6.2f GiB/s (%zu blocks)", op, pct(ps->lat_ms, 0.5), pct(ps->lat_ms, 0.9),
 			       pct(ps->lat_ms, 0.99), pct(ps->lat_ms, 1.0), ps->lat_ms.size() / 1024.0 / ps->secs, ps->lat_ms.size());
 		if (ss)
 			printf("  scrub %6.2f GiB/s of blocks (%llu blocks, %llu corruptions)", ss->blocks / 1024.0 / ss->secs,
@@ -152,8 +207,9 @@ int main(int argc, char **argv)
 		s.join();
 		stopper.join();
 	}
-	printf("qos_bench: backend %s, %d closed-loop callers, %.1f s per phase, scrub over %zu blocks, scrub tranquility %d\n",
-	       gec_codec_backend(c) == GEC_BACKEND_CPU ? "cpu" : "hip", callers, seconds, nscrub, tranq);
+	printf("qos_bench: backend %s, %d closed-loop callers (%s%s), %.1f s per phase, scrub over %zu blocks, scrub tranquility %d\n",
+	       gec_codec_backend(c) == GEC_BACKEND_CPU ? "cpu" : "hip", callers, get_blocks > 0 ? "gets of " : "puts through the batcher",
+	       get_blocks > 0 ? (std::to_string(get_blocks) + " blocks").c_str() : "", seconds, nscrub, tranq);
 	PutStats solo_put, mixed_bg_put, mixed_fg_put;
 	ScrubStats solo_scrub, mixed_bg_scrub, mixed_fg_scrub;
 	{
@@ -161,7 +217,7 @@ int main(int argc, char **argv)
 		std::thread stopper(sleep_then_stop);
 		run_puts(solo_put);
 		stopper.join();
-		report("puts alone", &solo_put, nullptr);
+		report(get_blocks > 0 ? "gets alone" : "puts alone", &solo_put, nullptr);
 	}
 	{
 		stop = false;
@@ -178,7 +234,7 @@ int main(int argc, char **argv)
 		run_puts(mixed_bg_put);
 		s.join();
 		stopper.join();
-		report("puts + scrub, background class", &mixed_bg_put, &mixed_bg_scrub);
+		report(get_blocks > 0 ? "gets + scrub, background class" : "puts + scrub, background class", &mixed_bg_put, &mixed_bg_scrub);
 	}
 	const uint64_t y1 = gec_qos_yields(0);
 	gbm_set_maintenance_class(mb, 0);
@@ -189,15 +245,15 @@ int main(int argc, char **argv)
 		run_puts(mixed_fg_put);
 		s.join();
 		stopper.join();
-		report("puts + scrub, no class (round 2)", &mixed_fg_put, &mixed_fg_scrub);
+		report(get_blocks > 0 ? "gets + scrub, no class (round 2)" : "puts + scrub, no class (round 2)", &mixed_fg_put, &mixed_fg_scrub);
 	}
 	const double p99_solo = pct(solo_put.lat_ms, 0.99), scrub_solo = solo_scrub.blocks / 1024.0 / solo_scrub.secs;
 	printf("CU masks: %d (2 = link / checksum masks and the foreground-background partition, 1 = masks without the partition, 0 = refused by "
 	       "this runtime: the classes then share every CU, -1 = not used)\n", gec_cu_masks_active());
-	printf("with the class:    put p99 %.2fx solo, scrub at %.0f %% of its solo rate (%llu chunk waits for foreground work)\n",
+	printf("with the class:    %s p99 %.2fx solo, scrub at %.0f %% of its solo rate (%llu chunk waits for foreground work)\n", op,
 	       pct(mixed_bg_put.lat_ms, 0.99) / p99_solo, 100.0 * (mixed_bg_scrub.blocks / 1024.0 / mixed_bg_scrub.secs) / scrub_solo,
 	       (unsigned long long)(y1 - y0));
-	printf("without the class: put p99 %.2fx solo, scrub at %.0f %% of its solo rate\n", pct(mixed_fg_put.lat_ms, 0.99) / p99_solo,
+	printf("without the class: %s p99 %.2fx solo, scrub at %.0f %% of its solo rate\n", op, pct(mixed_fg_put.lat_ms, 0.99) / p99_solo,
 	       100.0 * (mixed_fg_scrub.blocks / 1024.0 / mixed_fg_scrub.secs) / scrub_solo);
 	gbm_batcher_destroy(bt);
 	gbm_destroy(ma);
