@@ -30,7 +30,7 @@ SYMBOLS = [
     "gbm_set_read_hedge", "gbm_hedged_reads", "gbm_node_set_latency", "gbm_set_host_block_hash_max",
     "gbm_batcher_create", "gbm_batcher_destroy", "gbm_batcher_put_block", "gbm_batcher_set_ram_buffer_max", "gbm_batcher_stats",
     "gbm_env_table", "gbm_set_tranquility", "gbm_tranquilized_ms", "gbm_background_codec",
-    "gbm_batcher_submit", "gbm_batcher_wait", "gbm_set_maintenance_class",
+    "gbm_batcher_submit", "gbm_batcher_wait", "gbm_set_maintenance_class", "gbm_batcher_get_block", "gbm_batcher_get_stats",
 ]
 
 
@@ -148,6 +148,8 @@ def _load():
     lib.gbm_background_codec.restype = vp
     lib.gbm_batcher_submit.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, sz, ci, tagp, pp]
     lib.gbm_batcher_wait.argtypes = [vp]
+    lib.gbm_batcher_get_block.argtypes = [vp, ctypes.c_char_p, vp, sz, ctypes.POINTER(ctypes.c_size_t)]
+    lib.gbm_batcher_get_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.gbm_set_maintenance_class.argtypes = [vp, ci]
     return lib
 
@@ -448,4 +450,16 @@ class Batcher:
     def stats(self) -> dict:
         out = (ctypes.c_uint64 * 3)()
         _check(lib.gbm_batcher_stats(self._h, out), "gbm_batcher_stats")
+        return {"batches": int(out[0]), "blocks": int(out[1]), "max_batch": int(out[2])}
+
+    def get_block(self, hash_: bytes, max_len: int) -> bytes:
+        """The read side: blocks until the batch of concurrent gets containing this one has been fetched and checked."""
+        buf = ctypes.create_string_buffer(max(max_len, 1))
+        n = ctypes.c_size_t()
+        _check(lib.gbm_batcher_get_block(self._h, hash_, buf, max_len, ctypes.byref(n)), "batcher.get_block")
+        return buf.raw[: n.value]
+
+    def get_stats(self) -> dict:
+        out = (ctypes.c_uint64 * 3)()
+        _check(lib.gbm_batcher_get_stats(self._h, out), "gbm_batcher_get_stats")
         return {"batches": int(out[0]), "blocks": int(out[1]), "max_batch": int(out[2])}

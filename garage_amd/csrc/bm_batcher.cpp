@@ -43,6 +43,85 @@ struct gbm_batcher {
 	// floor -- the checksum chain -- that a single worker would pay serially)
 	std::vector<std::thread> workers;
 
+	// ---- the read side: GetObject's readers (a few blocks ahead each, src/api/s3/get.rs:429) coalesced the same way.
+	// Sixteen readers fetching eight blocks each through gbm_rpc_get_blocks make sixteen device trips that queue up
+	// behind one another and behind the host pool (4.3 GiB/s, 26 ms per get); through here they make a few.
+	struct GetItem {
+		const uint8_t *hash;
+		uint8_t *out;
+		size_t cap, len = 0;
+		int rc = GBM_OK;
+		bool done = false;
+	};
+	std::mutex gmu;
+	std::condition_variable gcv_work, gcv_done;
+	std::deque<GetItem *> gqueue;
+	bool gforming = false;
+	uint64_t gbatches = 0, gblocks = 0, gmax_batch = 0;
+	std::vector<std::thread> gworkers;
+
+	void run_gets()
+	{
+		std::unique_lock<std::mutex> lk(gmu);
+		for (;;) {
+			gcv_work.wait(lk, [&] { return stop_gets || (!gqueue.empty() && !gforming); });
+			if (gqueue.empty()) {
+				if (stop_gets)
+					return;
+				continue;
+			}
+			gforming = true;
+			const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(max_wait_us);
+			const auto gap = std::chrono::microseconds(std::max(20u, max_wait_us / 6));
+			size_t seen = gqueue.size();
+			while (!stop_gets && gqueue.size() < max_blocks) {  // the put side's linger: it ends once arrivals stop
+				const auto now = std::chrono::system_clock::now();
+				if (now >= deadline)
+					break;
+				if (gcv_work.wait_until(lk, std::min(deadline, now + gap)) == std::cv_status::timeout && gqueue.size() == seen)
+					break;
+				seen = gqueue.size();
+			}
+			std::vector<GetItem *> batch;
+			while (!gqueue.empty() && batch.size() < max_blocks) {
+				batch.push_back(gqueue.front());
+				gqueue.pop_front();
+			}
+			gforming = false;
+			gcv_work.notify_all();
+			lk.unlock();
+			const size_t nb = batch.size();
+			std::vector<uint8_t> hashes(nb * 32);
+			std::vector<uint8_t *> outs(nb);
+			std::vector<size_t> caps(nb), lens(nb, 0);
+			std::vector<int> rcs(nb, GBM_E_MISSING_BLOCK);
+			for (size_t i = 0; i < nb; ++i) {
+				std::memcpy(hashes.data() + 32 * i, batch[i]->hash, 32);
+				outs[i] = batch[i]->out;
+				caps[i] = batch[i]->cap;
+			}
+			int rc;
+			try {
+				rc = get_blocks_impl(mg, nb, hashes.data(), nullptr, outs.data(), caps.data(), lens.data(), rcs.data(), false, nullptr);
+			} catch (const std::exception &) {
+				rc = GBM_E_IO;
+			}
+			if (rc != GBM_OK)  // the whole call failed (a device error, out of memory): nobody of this batch has a block
+				std::fill(rcs.begin(), rcs.end(), rc);
+			lk.lock();
+			for (size_t i = 0; i < nb; ++i) {
+				batch[i]->rc = rcs[i];
+				batch[i]->len = lens[i];
+				batch[i]->done = true;
+			}
+			++gbatches;
+			gblocks += nb;
+			gmax_batch = std::max<uint64_t>(gmax_batch, nb);
+			gcv_done.notify_all();
+		}
+	}
+	bool stop_gets = false;
+
 	void run()
 	{
 		std::unique_lock<std::mutex> lk(mu);
@@ -159,6 +238,8 @@ int gbm_batcher_create(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, 
 	const int nworkers = env().batcher_workers;
 	for (int i = 0; i < nworkers; ++i)
 		b->workers.emplace_back([b] { b->run(); });
+	for (int i = 0; i < nworkers; ++i)
+		b->gworkers.emplace_back([b] { b->run_gets(); });
 	*out = b;
 	return GBM_OK;
 }
@@ -173,7 +254,14 @@ void gbm_batcher_destroy(gbm_batcher *b)
 	}
 	b->cv_work.notify_all();
 	b->cv_ram.notify_all();
+	{
+		std::lock_guard<std::mutex> g(b->gmu);
+		b->stop_gets = true;
+	}
+	b->gcv_work.notify_all();
 	for (auto &t : b->workers)
+		t.join();
+	for (auto &t : b->gworkers)
 		t.join();
 	delete b;
 }
@@ -246,6 +334,39 @@ int gbm_batcher_put_block(gbm_batcher *b, const uint8_t hash[32], const uint8_t 
 	gbm_put_ticket *tk = nullptr;
 	int rc = gbm_batcher_submit(b, hash, data, len, prevent_compression, order_tag, &tk);
 	return rc ? rc : gbm_batcher_wait(tk);
+}
+
+int gbm_batcher_get_block(gbm_batcher *b, const uint8_t hash[32], uint8_t *out, size_t cap, size_t *len_out)
+{
+	if (!b || !hash || (!out && cap) || !len_out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	gbm_batcher::GetItem it;
+	it.hash = hash;
+	it.out = out;
+	it.cap = cap;
+	{
+		std::unique_lock<std::mutex> lk(b->gmu);
+		if (b->stop_gets)
+			return fail(GBM_E_INVALID_ARG, "batcher is shutting down");
+		b->gqueue.push_back(&it);
+		b->gcv_work.notify_all();
+		b->gcv_done.wait(lk, [&] { return it.done; });
+	}
+	*len_out = it.len;
+	if (it.rc != GBM_OK)
+		return one_block_rc(it.rc);
+	return GBM_OK;
+}
+
+int gbm_batcher_get_stats(gbm_batcher *b, uint64_t out[3])
+{
+	if (!b || !out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	std::lock_guard<std::mutex> g(b->gmu);
+	out[0] = b->gbatches;
+	out[1] = b->gblocks;
+	out[2] = b->gmax_batch;
+	return GBM_OK;
 }
 
 int gbm_batcher_set_ram_buffer_max(gbm_batcher *b, size_t bytes)

@@ -638,6 +638,9 @@ bool send_shard(gbm_manager *mg, int node, const Hash &h, int idx, const Bytes &
 struct FanoutGate {
 	std::function<void()> before, after;
 };
+// raw == true: rpc_get_raw_block (stored bytes + header); false: rpc_get_block (plain bytes).  bm_rw.cpp
+int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
+		    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers);
 int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data, const size_t *len,
 		    const uint8_t *prevent_compression, const gbm_order_tag *tags, int *rcs, const FanoutGate *gate = nullptr);
 int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs,

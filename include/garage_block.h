@@ -216,6 +216,13 @@ int gbm_batcher_wait(gbm_put_ticket *ticket);
 int gbm_batcher_set_ram_buffer_max(gbm_batcher *b, size_t bytes);
 /* out = { device batches issued, blocks put, largest batch } */
 int gbm_batcher_stats(gbm_batcher *b, uint64_t out[3]);
+/* The read side of the same queue: GetObject's readers fetch a few blocks ahead each (src/api/s3/get.rs:429), many
+ * requests at a time.  gbm_batcher_get_block is gbm_rpc_get_block for ONE block (same result codes, plain bytes in
+ * `out`), thread-safe and blocking; whatever readers queue up within max_wait_us (or max_blocks) is fetched, checked
+ * and decoded as one batch -- one gather round, one device trip -- instead of one trip per reader. */
+int gbm_batcher_get_block(gbm_batcher *b, const uint8_t hash[32], uint8_t *out, size_t cap, size_t *len_out);
+/* out = { get batches issued, blocks fetched, largest batch } */
+int gbm_batcher_get_stats(gbm_batcher *b, uint64_t out[3]);
 
 /* ------------------------------------------------------------- refcounts */
 /* block_incref: RcEntry::increment; when the count was zero a presence check is queued

@@ -105,7 +105,8 @@ void put_object(gbm_batcher *bt, const Object &o, std::atomic<uint64_t> &put_ns,
 }
 
 // GetObject: GET_PREFETCH slots fetch the object's blocks; every byte is compared
-void get_object(gbm_manager *mg, const Object &o, uint64_t read_stream, std::atomic<uint64_t> &nget)
+// (through the batcher's read side when `bt` is given: concurrent GetObjects share gather rounds and device trips)
+void get_object(gbm_manager *mg, const Object &o, uint64_t read_stream, std::atomic<uint64_t> &nget, gbm_batcher *bt = nullptr)
 {
 	std::atomic<int> next{0};
 	std::vector<std::thread> slots;
@@ -119,7 +120,10 @@ void get_object(gbm_manager *mg, const Object &o, uint64_t read_stream, std::ato
 				buf.assign(o.blocks[i].size() + 64, 0xEE);
 				size_t len = 0;
 				const gbm_order_tag tag{read_stream, (uint64_t)i};
-				CHECK(gbm_rpc_get_block(mg, &o.hashes[(size_t)i * 32], &tag, buf.data(), buf.size(), &len) == GBM_OK);
+				if (bt)
+					CHECK(gbm_batcher_get_block(bt, &o.hashes[(size_t)i * 32], buf.data(), buf.size(), &len) == GBM_OK);
+				else
+					CHECK(gbm_rpc_get_block(mg, &o.hashes[(size_t)i * 32], &tag, buf.data(), buf.size(), &len) == GBM_OK);
 				CHECK(len == o.blocks[i].size() && std::memcmp(buf.data(), o.blocks[i].data(), len) == 0);
 				++nget;
 			}
@@ -172,7 +176,7 @@ int main(int argc, char **argv)
 		for (int r = 0; r < readers; ++r)
 			th.emplace_back([&, r] {
 				for (int pass = 0; pass < 3; ++pass)
-					get_object(mg, old_objs[r], 5000 + r * 10 + pass, nget);
+					get_object(mg, old_objs[r], 5000 + r * 10 + pass, nget, bt);
 			});
 		for (auto &t : th)
 			t.join();
@@ -187,6 +191,18 @@ int main(int argc, char **argv)
 	// coalescing: concurrent requests share device batches
 	if (requests >= 4)
 		CHECK(batches < blocks && st1[2] >= 2);
+	uint64_t gst[3];
+	CHECK(gbm_batcher_get_stats(bt, gst) == GBM_OK);
+	CHECK(gst[1] == (uint64_t)readers * 3 * per_object && gst[0] <= gst[1]);
+	if (readers >= 3)  // six prefetch slots re-submit together whenever a batch completes
+		CHECK(gst[2] >= 2);
+	{  // the read side reports a missing block and a short buffer like gbm_rpc_get_block does
+		uint8_t nohash[32], small[8];
+		std::memset(nohash, 0x5A, sizeof nohash);
+		size_t len = 0;
+		CHECK(gbm_batcher_get_block(bt, nohash, small, sizeof small, &len) == GBM_E_MISSING_BLOCK);
+		CHECK(gbm_batcher_get_block(bt, &new_objs[0].hashes[0], small, sizeof small, &len) == GBM_E_BUFFER_TOO_SMALL);
+	}
 	// OrderTag: no node saw a stream's blocks out of order, although they crossed batches and batcher workers
 	for (int nd = 0; nd < NNODES; ++nd)
 		CHECK(gbm_node_order_violations(mg, nd) == 0);
@@ -218,10 +234,11 @@ int main(int argc, char **argv)
 
 	const double mib = (double)blocks * (double)block_bytes / (1 << 20);
 	printf("put_get_callers: backend %s, %d PutObjects x %d blocks of %zu bytes (<=%d in flight each) beside %d GetObjects (prefetch %d): "
-	       "%llu blocks in %llu device batches (largest %llu), mean put %.3f ms, %.2f GiB/s put; 0 order violations; all bytes round-trip: OK\n",
+	       "%llu blocks in %llu device batches (largest %llu), mean put %.3f ms, %.2f GiB/s put; %llu blocks read in %llu batches (largest %llu); "
+	       "0 order violations; all bytes round-trip: OK\n",
 	       gec_codec_backend(codec) == GEC_BACKEND_CPU ? "cpu" : "hip", requests, per_object, block_bytes, PUT_BLOCKS_MAX_PARALLEL, readers,
 	       GET_PREFETCH, (unsigned long long)blocks, (unsigned long long)batches, (unsigned long long)st1[2],
-	       mean_put_ms, mib / 1024.0 / secs);
+	       mean_put_ms, mib / 1024.0 / secs, (unsigned long long)gst[1], (unsigned long long)gst[0], (unsigned long long)gst[2]);
 	gbm_batcher_destroy(bt);
 	gbm_destroy(mg);
 	gec_codec_destroy(codec);

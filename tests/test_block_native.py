@@ -553,3 +553,39 @@ def test_resync_never_deletes_what_a_concurrent_put_acknowledges(backend):
         for h, b in zip(hashes, blocks):
             assert mgr.rpc_get_block(h) == b, f"round {rnd}: an acknowledged put lost its shards"
     mgr.close()
+
+
+def test_batcher_read_side_coalesces_concurrent_gets(backend):
+    """gbm_batcher_get_block: many readers, one block each at a time (GetObject's prefetch slots) -> shared batches; the
+    bytes, a missing block and a short buffer come back like from rpc_get_block."""
+    import threading
+
+    codec = g.ReedSolomon(4, 2, backend=backend)
+    mgr = bn.NativeBlockManager(codec, 8)
+    bt = bn.Batcher(mgr, max_blocks=64, max_wait_us=2000)
+    rng = np.random.default_rng(11)
+    blocks = [rng.integers(0, 256, 20000 + 997 * i, dtype=np.uint8).tobytes() for i in range(24)]
+    hashes = [bn.blake2sum(b) for b in blocks]
+    mgr.rpc_put_blocks(list(zip(hashes, blocks)))
+    got = [None] * len(blocks)
+
+    def reader(t):
+        for i in range(t, len(blocks), 6):
+            got[i] = bt.get_block(hashes[i], 1 << 16)
+
+    th = [threading.Thread(target=reader, args=(t,)) for t in range(6)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert got == blocks
+    st = bt.get_stats()
+    assert st["blocks"] == len(blocks) and st["batches"] <= st["blocks"] and st["max_batch"] >= 2
+    with pytest.raises(bn.BlockError) as e:
+        bt.get_block(b"\x5a" * 32, 100)
+    assert e.value.code == bn.GBM_E_MISSING_BLOCK
+    with pytest.raises(bn.BlockError) as e:
+        bt.get_block(hashes[0], 8)
+    assert e.value.code == bn.GBM_E_BUFFER_TOO_SMALL
+    bt.close()
+    mgr.close()

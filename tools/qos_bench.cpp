@@ -8,9 +8,11 @@
 // (gec_codec_background: low-priority CU-masked streams, small chunks that yield to foreground calls); both with
 // maintenance on the request path's own codec (gbm_set_maintenance_class(m, 0): round 2's behaviour).
 // Reports put p50 / p99 / rate and the scrub rate of each phase.
-// usage: qos_bench [callers=3] [seconds=3] [scrub_blocks=512] [tranquility=0] [get_blocks=0]
+// usage: qos_bench [callers=3] [seconds=3] [scrub_blocks=512] [tranquility=0] [get_blocks=0] [gets_via_batcher=0]
 // get_blocks = G > 0: the callers are readers instead -- each keeps fetching G of its blocks with one gbm_rpc_get_blocks (a
-// GetObject with its prefetch), block-hash check on -- and the latencies reported are those of the gets.
+// GetObject with its prefetch), block-hash check on -- and the latencies reported are those of the gets;
+// gets_via_batcher = 1 (with get_blocks = 1): every reader fetches one block at a time through gbm_batcher_get_block, the
+// read side of the coalescing queue (48 callers = 16 GetObjects with three blocks in flight each).
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -47,6 +49,7 @@ int main(int argc, char **argv)
 	const size_t nscrub = argc > 3 ? (size_t)atol(argv[3]) : 512;
 	const int tranq = argc > 4 ? atoi(argv[4]) : 0;
 	const int get_blocks = argc > 5 ? atoi(argv[5]) : 0;
+	const bool gets_via_batcher = argc > 6 && atoi(argv[6]) != 0 && get_blocks == 1;
 	gec_codec *c = nullptr;
 	gbm_manager *ma = nullptr, *mb = nullptr;
 	if (gec_codec_create(10, 4, GEC_BACKEND_AUTO, 0, &c) != GEC_OK || gbm_create(c, 16, NULL, 0, &ma) != GBM_OK ||
@@ -114,8 +117,14 @@ int main(int argc, char **argv)
 				for (size_t j = 0; !stop.load(); ++j) {
 					const size_t i0 = (size_t)t * RING + (j % (RING / get_blocks)) * get_blocks;
 					const auto a = Clock::now();
-					if (gbm_rpc_get_blocks(ma, get_blocks, &hashes[32 * i0], NULL, op_.data(), cap.data(), len.data(), rcs.data()) != GBM_OK ||
-					    rcs[0] != GBM_OK || len[0] != L) {
+					int grc;
+					if (gets_via_batcher) {
+						grc = gbm_batcher_get_block(bt, &hashes[32 * i0], op_[0], L, &len[0]);
+						rcs[0] = grc;
+					} else {
+						grc = gbm_rpc_get_blocks(ma, get_blocks, &hashes[32 * i0], NULL, op_.data(), cap.data(), len.data(), rcs.data());
+					}
+					if (grc != GBM_OK || rcs[0] != GBM_OK || len[0] != L) {
 						fprintf(stderr, "get failed: %s\n", gbm_last_error());
 						exit(1);
 					}
