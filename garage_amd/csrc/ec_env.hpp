@@ -18,6 +18,7 @@ struct Env {
 	// ---- HIP backend: host-pointer paths
 	unsigned copy_threads;  // GEC_COPY_THREADS
 	bool zero_copy;         // GEC_ZERO_COPY
+	unsigned max_calls;     // GEC_MAX_CALLS
 	int upload_cus;         // GEC_UPLOAD_CUS
 	unsigned bg_link_wait_us; // GEC_BG_LINK_WAIT_US
 	unsigned home_rate_gbps; // GEC_HOME_RATE_GBPS

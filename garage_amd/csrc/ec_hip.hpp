@@ -159,6 +159,11 @@ struct HipBackend : Backend {
 
 	mutable std::mutex pool_mu;
 	mutable std::vector<Staging> pool;
+	// host-pointer calls in flight on this codec (GEC_MAX_CALLS): every call owns one to three staging slots, every slot
+	// three or four device queues, and past a few dozen queues the device spends its time switching between them
+	mutable std::mutex calls_mu;
+	mutable std::condition_variable calls_cv;
+	mutable unsigned calls_in_flight = 0;
 
 	// leaf-digest scratch of the tree-mode shard checksums, one per stream that ever hashed (work on one
 	// stream is ordered, so reuse on the same stream is safe; grow-only)
@@ -213,8 +218,12 @@ struct StagingLease {
 };
 
 // RAII: a foreground host-pointer call is in flight on this codec's device (no-op for a background codec)
+// What every host-pointer entry point of the HIP backend holds for its duration: a call permit of its codec (at most
+// GEC_MAX_CALLS at a time; a call made from inside another one of the same thread rides on the outer permit) and, for a
+// foreground codec, a count in the device's QosGate.
 struct ForegroundScope {
 	QosGate *gate = nullptr;
+	const HipBackend *permit_of = nullptr;
 	explicit ForegroundScope(const gec_codec *c);
 	~ForegroundScope();
 };

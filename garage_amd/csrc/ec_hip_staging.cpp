@@ -363,8 +363,20 @@ uint64_t QosGate::yield_to_foreground(unsigned max_wait_us)
 	return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
 }
 
+namespace {
+thread_local int t_call_depth = 0;
+}
+
 ForegroundScope::ForegroundScope(const gec_codec *c)
 {
+	const unsigned cap = env().max_calls;
+	if (cap > 0 && t_call_depth++ == 0) {
+		const HipBackend &hb = hip_of(c);
+		std::unique_lock<std::mutex> lk(hb.calls_mu);
+		hb.calls_cv.wait(lk, [&] { return hb.calls_in_flight < cap; });
+		++hb.calls_in_flight;
+		permit_of = &hb;
+	}
 	if (c->qos_class == GEC_CLASS_FOREGROUND) {
 		gate = &QosGate::of(c->device);
 		gate->enter();
@@ -375,6 +387,15 @@ ForegroundScope::~ForegroundScope()
 {
 	if (gate)
 		gate->leave();
+	if (env().max_calls > 0)
+		--t_call_depth;
+	if (permit_of) {
+		{
+			std::lock_guard<std::mutex> g(permit_of->calls_mu);
+			--permit_of->calls_in_flight;
+		}
+		permit_of->calls_cv.notify_one();
+	}
 }
 
 // Called by a background codec's chunk loops before every chunk: the chunk waits (at most GEC_BG_YIELD_US) for the
