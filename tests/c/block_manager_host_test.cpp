@@ -222,6 +222,35 @@ static void run_batcher(int k, int m)
 	uint64_t st[3];
 	CHECK(gbm_batcher_stats(bt, st) == GBM_OK);
 	CHECK(st[1] == (uint64_t)T * PER && st[0] < st[1] && st[2] >= 2 && st[2] <= 16);
+	// the read side of the queue: T readers, one block at a time each; every byte right, gets coalesced, errors per block
+	{
+		std::vector<std::thread> rd;
+		std::vector<int> ok(T, 1);
+		for (int t = 0; t < T; ++t)
+			rd.emplace_back([&, t] {
+				std::vector<uint8_t> o(200000);
+				for (int j = 0; j < PER; ++j) {
+					const int i = t * PER + j;
+					size_t got = 0;
+					if (gbm_batcher_get_block(bt, hashes.data() + 32 * i, o.data(), o.size(), &got) != GBM_OK || got != blocks[i].size() ||
+					    std::memcmp(o.data(), blocks[i].data(), got))
+						ok[t] = 0;
+				}
+			});
+		for (auto &x : rd)
+			x.join();
+		for (int t = 0; t < T; ++t)
+			CHECK(ok[t]);
+		uint64_t gst[3];
+		CHECK(gbm_batcher_get_stats(bt, gst) == GBM_OK);
+		CHECK(gst[1] == (uint64_t)T * PER && gst[0] < gst[1] && gst[2] >= 2 && gst[2] <= 16);
+		uint8_t nohash[32], small[16];
+		std::memset(nohash, 0x3C, sizeof nohash);
+		size_t got = 0;
+		CHECK(gbm_batcher_get_block(bt, nohash, small, sizeof small, &got) == GBM_E_MISSING_BLOCK);
+		CHECK(gbm_batcher_get_block(bt, hashes.data(), small, sizeof small, &got) == GBM_E_BUFFER_TOO_SMALL && got == blocks[0].size());
+		CHECK(gbm_batcher_get_block(nullptr, hashes.data(), small, sizeof small, &got) == GBM_E_INVALID_ARG);
+	}
 	// block_ram_buffer_max: with a budget of ~2 blocks the 8 callers still all get through (they wait for
 	// permits), batches can no longer exceed the budget, and an oversized block is refused, not queued
 	CHECK(gbm_batcher_set_ram_buffer_max(nullptr, 1 << 20) == GBM_E_INVALID_ARG);
