@@ -299,6 +299,7 @@ class COracle:
         t = self.lib.rso_bench_encode(k, m, S, nblocks, reps, variant, threads, seed, ctypes.byref(cs))
         if t <= 0:
             raise ValueError("rso_bench_encode failed")
+        self.last_bench_checksum = int(cs.value)  # XOR over a sample of the parity bytes: the same for any thread count
         return float(t)
 
     def invert(self, mat: np.ndarray) -> np.ndarray:

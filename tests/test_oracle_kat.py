@@ -231,3 +231,15 @@ def test_bench_helper_runs(coracle):
     for variant in (coracle.SCALAR, coracle.AVX2):
         t = coracle.bench_encode(10, 4, 4096, 8, 3, variant, 2)
         assert 0 < t < 5
+
+
+def test_bench_loop_encodes_every_block_once_whatever_the_thread_count():
+    """rso_bench_encode's timed loop lets threads take blocks from one another's ranges: the parity it leaves (sampled
+    into a checksum byte) must not depend on how many threads shared the work, nor on the SIMD variant."""
+    co = O.COracle()
+    sums = set()
+    for threads in (1, 2, 3, 8):
+        for variant in ([co.SCALAR, co.AVX2] if co.has_avx2() else [co.SCALAR]):
+            co.bench_encode(10, 4, 4160, 37, 2, variant, threads, seed=9)
+            sums.add(co.last_bench_checksum)
+    assert len(sums) == 1, sums
