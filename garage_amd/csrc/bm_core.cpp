@@ -34,6 +34,7 @@ const EnvRow kEnvRows[] = {
 	{"GBM_PUT_SLICE", "64", "blocks per slice of a large untagged put"},
 	{"GBM_PUT_THREADS", "4", "put slices in flight"},
 	{"GBM_BATCHER_WORKERS", "2", "batches the coalescing batcher keeps in flight"},
+	{"GBM_CPU_BLAKE2", "auto", "the manager's own BLAKE2b (block hashes of small gets, shard checks): auto = eight messages at a time with AVX-512, scalar = one at a time (A/B)"},
 };
 long env_long(const char *name, long def)
 {
@@ -53,10 +54,17 @@ const Env &env()
 		v.put_threads = (int)(pt > 0 && pt <= 8 ? pt : 4);
 		const long bw = env_long("GBM_BATCHER_WORKERS", 0);
 		v.batcher_workers = (int)(bw >= 1 && bw <= 16 ? bw : 2);
+		const char *b2 = std::getenv("GBM_CPU_BLAKE2");
+		if (b2 && b2[0] == 's')
+			b2host::mb_mode().store(0);
 		return v;
 	}();
 	return e;
 }
+
+namespace {
+const bool kEnvReadAtLoad = (env(), true);  // GBM_CPU_BLAKE2 acts on header-only code: in force from the first hash on
+}  // namespace
 
 const char *env_table_text()
 {
@@ -193,7 +201,11 @@ int hash_many(gbm_manager *mg, const std::vector<const uint8_t *> &ptrs, const s
 		mg->gpu_hashed += ptrs.size();
 		return GBM_OK;
 	}
-	mg->pool->parallel_for(ptrs.size(), [&](size_t i) { shardsum(ptrs[i], lens[i], sums.data() + 32 * i); });
+	constexpr size_t kPerTask = 16;  // shards per pool task: their leaves go through the cores' vector lanes eight at a time
+	mg->pool->parallel_for((ptrs.size() + kPerTask - 1) / kPerTask, [&](size_t g) {
+		const size_t i0 = g * kPerTask, cnt = std::min(kPerTask, ptrs.size() - i0);
+		b2host::shardsum_many(ptrs.data() + i0, lens.data() + i0, cnt, sums.data() + 32 * i0);
+	});
 	return GBM_OK;
 }
 

@@ -34,7 +34,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "blake2b_host.hpp"
+#include "blake2b_mb.hpp"
 
 namespace gbmimpl {
 
@@ -44,7 +44,8 @@ const std::string &last_error();
 int ec_fail(int rc, const char *what);
 
 using b2host::blake2sum;
-using b2host::shardsum;
+// one shard: its leaves are independent chains, eight at a time where the core can (blake2b_mb.hpp)
+inline void shardsum(const uint8_t *data, size_t len, uint8_t out[32]) { b2host::shardsum_many(&data, &len, 1, out); }
 
 // ------------------------------------------------------------------ environment (bm_core.cpp holds the one table)
 struct Env {

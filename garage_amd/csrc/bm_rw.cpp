@@ -737,6 +737,7 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 	// block.rs:69-77) -- all block hashes in one batch.  Plain blocks are assembled straight into the
 	// caller's buffer and hashed from there (on CORRUPT_DATA its contents are unspecified); compressed
 	// blocks go through an intermediate for the zstd frame, whose checksum is their verify.
+	std::vector<uint8_t> hash_here(nb, 0);
 	mg->pool->parallel_for(nb, [&](size_t b) {
 		len_out[b] = 0;
 		if (rcs[b] != GBM_OK)
@@ -782,15 +783,35 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 			assemble(g[b], k, out[b]);
 		}
 		if (!z && cpu_hash) {
-			uint8_t sum[32];
-			blake2sum(out[b], L, sum);
-			if (std::memcmp(sum, hashes + 32 * b, 32) != 0) {
-				rcs[b] = GBM_E_CORRUPT_DATA;
-				return;
-			}
+			hash_here[b] = 1;  // checked below, eight blocks per core at a time
+			return;
 		}
 		mg->metrics[5]++;
 	});
+	if (cpu_hash) {
+		std::vector<size_t> idx;
+		for (size_t b = 0; b < nb; ++b)
+			if (hash_here[b])
+				idx.push_back(b);
+		mg->pool->parallel_for((idx.size() + 7) / 8, [&](size_t grp) {
+			const size_t i0 = grp * 8, cnt = std::min<size_t>(8, idx.size() - i0);
+			const uint8_t *ptr[8];
+			size_t len[8];
+			uint8_t sums[8 * 32];
+			for (size_t i = 0; i < cnt; ++i) {
+				ptr[i] = out[idx[i0 + i]];
+				len[i] = len_out[idx[i0 + i]];
+			}
+			b2host::blake2sum_many(ptr, len, cnt, sums);
+			for (size_t i = 0; i < cnt; ++i) {
+				const size_t b = idx[i0 + i];
+				if (std::memcmp(sums + 32 * i, hashes + 32 * b, 32) != 0)
+					rcs[b] = GBM_E_CORRUPT_DATA;
+				else
+					mg->metrics[5]++;
+			}
+		});
+	}
 	tr.lap("finish");
 	g.clear();
 	tr.lap("release");

@@ -26,7 +26,7 @@
 #include <algorithm>
 #include <map>
 
-#include "blake2b_host.hpp"
+#include "blake2b_mb.hpp"
 #include "ec_env.hpp"
 
 namespace gecimpl {
@@ -311,6 +311,28 @@ struct CpuBackend : Backend {
 		});
 	}
 
+	// shard checksums of many S-byte shards, eight chains at a time per core (blake2b_mb.hpp), kShardTask shards per pool task
+	struct ShardRef {
+		const uint8_t *p;
+		uint8_t *dst;
+	};
+	void shardsums(const std::vector<ShardRef> &list, size_t S)
+	{
+		constexpr size_t kShardTask = 16;
+		pool->parallel_for((list.size() + kShardTask - 1) / kShardTask, [&](size_t g) {
+			const size_t i0 = g * kShardTask, cnt = std::min(kShardTask, list.size() - i0);
+			const uint8_t *ptr[kShardTask];
+			uint8_t *dst[kShardTask];
+			size_t len[kShardTask];
+			for (size_t i = 0; i < cnt; ++i) {
+				ptr[i] = list[i0 + i].p;
+				dst[i] = list[i0 + i].dst;
+				len[i] = S;
+			}
+			b2host::shardsum_many(ptr, len, cnt, nullptr, dst);
+		});
+	}
+
 	int encode_batch(size_t nblocks, const uint8_t *const *blocks, const size_t *block_len, size_t S, uint8_t *const *parity,
 			 uint8_t *shard_sums) override
 	{
@@ -333,23 +355,27 @@ struct CpuBackend : Backend {
 		if (!shard_sums)
 			return GEC_OK;
 		// the checksum of every shard, data shards as zero-extended to S bytes
-		pool->parallel_for(nblocks * n, [&](size_t q) {
+		std::vector<ShardRef> list(nblocks * n);
+		std::vector<std::vector<uint8_t>> padded;  // the one short data shard of a block, zero-extended
+		padded.reserve(nblocks);
+		for (size_t q = 0; q < nblocks * n; ++q) {
 			const size_t b = q / n, j = q % n;
 			uint8_t *dst = shard_sums + 32 * q;
 			if (j >= k) {
-				b2host::shardsum(parity[b] + (j - k) * S, S, dst);
-				return;
+				list[q] = {parity[b] + (j - k) * S, dst};
+				continue;
 			}
 			const size_t have = valid[b * k + j];
 			if (have == S) {
-				b2host::shardsum(blocks[b] + j * S, S, dst);
+				list[q] = {blocks[b] + j * S, dst};
 			} else {
-				std::vector<uint8_t> tmp(S, 0);
+				padded.emplace_back(S, 0);
 				if (have)
-					std::memcpy(tmp.data(), blocks[b] + j * S, have);
-				b2host::shardsum(tmp.data(), S, dst);
+					std::memcpy(padded.back().data(), blocks[b] + j * S, have);
+				list[q] = {padded.back().data(), dst};
 			}
-		});
+		}
+		shardsums(list, S);
 		return GEC_OK;
 	}
 
@@ -390,7 +416,10 @@ struct CpuBackend : Backend {
 		if (rc)
 			return rc;
 		const size_t n = (size_t)c->k + c->m;
-		pool->parallel_for(nblocks * n, [&](size_t q) { b2host::shardsum(shards[q], S, shard_sums + 32 * q); });
+		std::vector<ShardRef> list(nblocks * n);
+		for (size_t q = 0; q < nblocks * n; ++q)
+			list[q] = {shards[q], shard_sums + 32 * q};
+		shardsums(list, S);
 		return GEC_OK;
 	}
 
@@ -468,11 +497,7 @@ struct CpuBackend : Backend {
 		if (!in_sums)
 			return GEC_OK;
 		// the checksums of the k shards that were read and of the shards that were written
-		struct Sum {
-			const uint8_t *p;
-			uint8_t *dst;
-		};
-		std::vector<Sum> sums;
+		std::vector<ShardRef> sums;
 		for (const Work &w : work)
 			for (size_t b : *w.ids) {
 				for (size_t t = 0; t < k; ++t)
@@ -480,7 +505,7 @@ struct CpuBackend : Backend {
 				for (int j : w.wanted)
 					sums.push_back({out[b * n + j], out_sums + 32 * (b * n + j)});
 			}
-		pool->parallel_for(sums.size(), [&](size_t i) { b2host::shardsum(sums[i].p, S, sums[i].dst); });
+		shardsums(sums, S);
 		return GEC_OK;
 	}
 
@@ -512,37 +537,44 @@ struct CpuBackend : Backend {
 				return rc;
 		}
 		// checksums: every shard that was read, and (optionally) the block itself from its k data shards
-		pool->parallel_for(nblocks * (n + 1), [&](size_t q) {
-			const size_t b = q / (n + 1), j = q % (n + 1);
-			if (j < n) {
+		std::vector<ShardRef> list;
+		list.reserve(nblocks * n);
+		for (size_t b = 0; b < nblocks; ++b)
+			for (size_t j = 0; j < n; ++j)
 				if (used[b * n + j])
-					b2host::shardsum(used[b * n + j], S, shard_sums + 32 * (b * n + j));
-				return;
-			}
-			if (!block_sums)
-				return;
-			b2host::State st;
-			size_t left = block_len[b];
-			for (size_t t = 0; t < k && left; ++t) {
-				const uint8_t *p = shards[b * n + t] ? shards[b * n + t] : rebuilt[b * n + t];
-				const size_t take = std::min(S, left);
-				st.update(p, take);
-				left -= take;
-			}
-			uint8_t full[64];
-			st.final(full);
-			std::memcpy(block_sums + 32 * b, full, 32);
-		});
+					list.push_back({used[b * n + j], shard_sums + 32 * (b * n + j)});
+		shardsums(list, S);
+		if (block_sums) {
+			// a block is one chain over its k data shards (read or rebuilt): eight blocks at a time per core
+			std::vector<const uint8_t *> piece(nblocks * k);
+			for (size_t b = 0; b < nblocks; ++b)
+				for (size_t t = 0; t < k; ++t)
+					piece[b * k + t] = shards[b * n + t] ? shards[b * n + t] : rebuilt[b * n + t];
+			pool->parallel_for((nblocks + 7) / 8, [&](size_t g) {
+				const size_t b0 = g * 8, cnt = std::min<size_t>(8, nblocks - b0);
+				b2host::Job jobs[8];
+				for (size_t i = 0; i < cnt; ++i) {
+					jobs[i].pieces = &piece[(b0 + i) * k];
+					jobs[i].piece_len = S;
+					jobs[i].len = block_len[b0 + i];
+					jobs[i].out = block_sums + 32 * (b0 + i);
+				}
+				b2host::run_jobs(jobs, cnt);
+			});
+		}
 		return GEC_OK;
 	}
 
 	int hash_batch(size_t nmsg, const uint8_t *const *msgs, const size_t *lens, uint8_t *out, bool tree) override
 	{
-		pool->parallel_for(nmsg, [&](size_t i) {
+		// eight chains at a time per core: tasks of 8 (plain) / 16 (tree: the leaves are the chains) messages
+		const size_t per = tree ? 16 : 8;
+		pool->parallel_for((nmsg + per - 1) / per, [&](size_t g) {
+			const size_t i0 = g * per, cnt = std::min(per, nmsg - i0);
 			if (tree)
-				b2host::shardsum(msgs[i], lens[i], out + 32 * i);
+				b2host::shardsum_many(msgs + i0, lens + i0, cnt, out + 32 * i0);
 			else
-				b2host::blake2sum(msgs[i], lens[i], out + 32 * i);
+				b2host::blake2sum_many(msgs + i0, lens + i0, cnt, out + 32 * i0);
 		});
 		return GEC_OK;
 	}

@@ -1,5 +1,6 @@
 // ec_env.cpp -- the one table of libgarage_ec's environment switches (see ec_env.hpp).
 #include "ec_env.hpp"
+#include "blake2b_mb.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -18,6 +19,7 @@ struct Row {
 const Row kRows[] = {
 	{"GEC_CPU_THREADS", "min(cores, 16)", "threads a CPU codec spreads one call over (1 = the calling thread only)"},
 	{"GEC_CPU_ISA", "auto", "CPU backend kernel: auto, gfni (AVX-512 + GFNI), avx2 (split-nibble vpshufb) or scalar"},
+	{"GEC_CPU_BLAKE2", "auto", "host-side BLAKE2b (CPU backend, libgarage_block's own hashes): auto = eight messages at a time with AVX-512, scalar = one at a time (A/B)"},
 	{"GEC_SMALL_CALL_BLOCKS", "0", "a HIP codec answers pageable host-pointer encode / reconstruct calls of up to this many blocks on the host cores (0 = never)"},
 	{"GEC_MAX_CALLS", "4", "host-pointer calls in flight per HIP codec; further callers wait (0 = no limit: every concurrent call gets staging slots and device queues of its own)"},
 	{"GEC_COPY_THREADS", "7", "staging-copy threads per HIP codec for pageable caller memory (0 = copy on the calling thread)"},
@@ -56,6 +58,8 @@ const Env &env()
 		const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
 		v.cpu_threads = (int)std::min<long>(std::max<long>(get_long("GEC_CPU_THREADS", std::min(hw, 16u)), 1), 256);
 		v.cpu_isa = get("GEC_CPU_ISA") ? get("GEC_CPU_ISA") : "auto";
+		if (get("GEC_CPU_BLAKE2") && get("GEC_CPU_BLAKE2")[0] == 's')
+			b2host::mb_mode().store(0);
 		v.small_call_blocks = (size_t)std::max<long>(get_long("GEC_SMALL_CALL_BLOCKS", 0), 0);
 		v.max_calls = (unsigned)std::max<long>(get_long("GEC_MAX_CALLS", 4), 0);
 		v.copy_threads = get("GEC_COPY_THREADS") ? (unsigned)std::min<unsigned long>(std::strtoul(get("GEC_COPY_THREADS"), nullptr, 0), 64ul)
@@ -100,3 +104,8 @@ const char *env_table_text()
 }
 
 }  // namespace gecimpl
+
+namespace {
+// the switches that act on header-only code shared with libgarage_block (blake2b_mb.hpp) take effect when the library is loaded
+const bool kEnvReadAtLoad = (gecimpl::env(), true);
+}  // namespace

@@ -400,3 +400,33 @@ def test_baseline_config1_encode_and_reconstruct_one_erasure(coracle):
         rec = rs.reconstruct([[None if j == lost else st[b, j] for j in range(k + m)] for b in range(nb)])
         for b in range(nb):
             assert np.array_equal(rec[b][lost], st[b, lost])
+
+
+def test_host_blake2b_eight_at_a_time_and_one_at_a_time_agree_with_hashlib():
+    """blake2b_mb.hpp: the AVX-512 form (eight chains per core) and the scalar fallback, through the CPU codec's
+    gec_blake2sum_batch / gec_shardsum_batch and libgarage_block's gbm_shardsum, on ragged batches."""
+    import subprocess
+    import sys
+
+    code = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+import numpy as np
+import garage_amd as g
+from garage_amd import block_native as bn
+rs = g.ReedSolomon(10, 4, backend="cpu")
+lens = list(range(0, 140)) + [255, 256, 257, 4095, 4096, 4097, 8191, 8192, 8193, 12288, 104896, 104897, 209728, (1 << 20) + 5]
+msgs = [bytes((i * 7 + j * 13) & 255 for j in range(n)) for i, n in enumerate(lens)]
+assert rs.blake2sum_batch(msgs) == [hashlib.blake2b(x, digest_size=64).digest()[:32] for x in msgs]
+assert rs.shardsum_batch(msgs) == [g.shardsum(x) for x in msgs]
+for x in msgs[::7]:
+    assert bn.shardsum(x) == g.shardsum(x) and bn.blake2sum(x) == hashlib.blake2b(x, digest_size=64).digest()[:32]
+# 1..17 equal messages (every group size), and the block checksum over k shard buffers (decode_verify on the CPU codec)
+for n in range(1, 18):
+    same = [msgs[-3]] * n
+    assert rs.shardsum_batch(same) == [g.shardsum(msgs[-3])] * n
+print("ok")
+""" % ROOT
+    for mode in ("auto", "scalar"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GEC_CPU_BLAKE2=mode, GBM_CPU_BLAKE2=mode, GEC_CPU_THREADS="3"))
+        assert r.returncode == 0 and "ok" in r.stdout, (mode, r.stdout, r.stderr[-2000:])
