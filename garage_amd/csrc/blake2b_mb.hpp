@@ -295,12 +295,14 @@ inline void shardsum_many(const uint8_t *const *msgs, const size_t *lens, size_t
 {
 	const uint64_t P0 = 64ull | (2ull << 24) | ((uint64_t)kShardsumLeaf << 32);
 	constexpr size_t kShardsPerRound = 16;  // leaf digests of a round stay in L1 / L2 for the roots
-	std::vector<Job> jobs;
-	std::vector<uint8_t> dig;
+	// scratch per thread, grown once: sixty-four pool threads allocating and freeing these per task met in malloc
+	thread_local std::vector<Job> jobs, roots;
+	thread_local std::vector<uint8_t> dig;
+	thread_local std::vector<size_t> first;
 	for (size_t s0 = 0; s0 < n; s0 += kShardsPerRound) {
 		const size_t ns = std::min(kShardsPerRound, n - s0);
 		size_t nleaf_total = 0;
-		std::vector<size_t> first(ns + 1, 0);
+		first.assign(ns + 1, 0);
 		for (size_t s = 0; s < ns; ++s) {
 			const size_t len = lens[s0 + s];
 			nleaf_total += len ? (len + kShardsumLeaf - 1) / kShardsumLeaf : 1;
@@ -324,7 +326,7 @@ inline void shardsum_many(const uint8_t *const *msgs, const size_t *lens, size_t
 			}
 		}
 		run_jobs(jobs.data(), jobs.size());
-		std::vector<Job> roots(ns);
+		roots.assign(ns, Job());
 		for (size_t s = 0; s < ns; ++s) {
 			Job &j = roots[s];
 			j.p = dig.data() + 64 * first[s];
