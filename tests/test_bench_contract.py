@@ -61,6 +61,6 @@ def test_bench_source_still_emits_every_field():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for key in list(TOP) + ["vs_baseline"] + list(ROOFLINE) + ["traffic", "secondary", "cold_burst_frac", "traffic_source"] + list(CPU) + [
             "parity_checked_blocks", "rccl_ranks", "blocks_per_rank", "striped_decode", "exchange", "host_fed", "in_process",
-            "cpu_backend", "process", "bit_exact_against", "host_load_during_sweep", "checked"]:
+            "cpu_backend", "process", "bit_exact_against", "host_load_during_sweep", "checked", "encode_plus_14_checksums_GiBps"]:
         assert re.search(rf'"{key}"\s*:', src) or f'["{key}"]' in src, key
     assert "max_over_ranks" in src and "barrier()" in src and "torch.cuda.synchronize()" in src
