@@ -17,7 +17,7 @@ GBM_E_INVALID_ARG, GBM_E_EC, GBM_E_IO, GBM_E_BUFFER_TOO_SMALL, GBM_E_ABORTED = -
 GBM_BLOCK_GC_DELAY_MS, GBM_RESYNC_RETRY_DELAY_MS = 600_000, 60_000
 
 SYMBOLS = [
-    "gbm_last_error", "gbm_blake2sum", "gbm_shardsum", "gbm_create", "gbm_destroy", "gbm_set_compression_level", "gbm_set_data_fsync",
+    "gbm_last_error", "gbm_blake2sum", "gbm_shardsum", "gbm_blake2sum_batch", "gbm_create", "gbm_destroy", "gbm_set_compression_level", "gbm_set_data_fsync",
     "gbm_set_verify_block_hash", "gbm_set_threads", "gbm_set_timing", "gbm_clock_advance",
     "gbm_storage_nodes_of", "gbm_layout_update", "gbm_layout_trim",
     "gbm_rpc_put_block", "gbm_rpc_put_blocks", "gbm_rpc_get_block", "gbm_rpc_get_blocks",
@@ -81,6 +81,8 @@ def _load():
     lib.gbm_blake2sum.restype = None
     lib.gbm_shardsum.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p]
     lib.gbm_shardsum.restype = None
+    lib.gbm_blake2sum_batch.argtypes = [sz, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p]
+    lib.gbm_blake2sum_batch.restype = None
     lib.gbm_create.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), ci, pp]
     lib.gbm_destroy.argtypes = [vp]
     lib.gbm_destroy.restype = None
@@ -169,6 +171,16 @@ def blake2sum(data: bytes) -> bytes:
     out = ctypes.create_string_buffer(32)
     lib.gbm_blake2sum(data, len(data), out)
     return out.raw
+
+
+def blake2sum_batch(blocks) -> list:
+    """Content hashes of several blocks on one host core (eight at a time in AVX-512 lanes where there are any)."""
+    n = len(blocks)
+    ptrs = (ctypes.c_char_p * n)(*blocks)
+    lens = (ctypes.c_size_t * n)(*[len(b) for b in blocks])
+    out = ctypes.create_string_buffer(32 * n)
+    lib.gbm_blake2sum_batch(n, ptrs, lens, out)
+    return [out.raw[32 * i:32 * i + 32] for i in range(n)]
 
 
 def shardsum(data: bytes) -> bytes:

@@ -223,6 +223,12 @@ void gbm_blake2sum(const uint8_t *data, size_t len, uint8_t out[32]) { blake2sum
 
 void gbm_shardsum(const uint8_t *data, size_t len, uint8_t out[32]) { shardsum(data, len, out); }
 
+void gbm_blake2sum_batch(size_t n, const uint8_t *const *data, const size_t *len, uint8_t *out)
+{
+	if (n && data && len && out)
+		b2host::blake2sum_many(data, len, n, out);
+}
+
 int gbm_create(const gec_codec *codec, int nnodes, const char *const *node_dirs, int write_quorum, gbm_manager **out)
 {
 	if (!codec || !out)

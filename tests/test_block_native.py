@@ -31,6 +31,8 @@ def test_blake2sum_is_blake2b512_truncated(n):
     d = bytes(pattern_block(n, salt=n)) if n else b""
     assert bn.blake2sum(d) == hashlib.blake2b(d, digest_size=64).digest()[:32]
     assert bn.blake2sum(d) != hashlib.blake2b(d, digest_size=32).digest(), "NOT blake2b-256 (src/util/data.rs:130-138)"
+    blocks = [bytes((i * 5 + j) & 255 for j in range(n)) for i, n in enumerate([0, 1, 127, 128, 129, 4096, 70001, 3] * 2 + [9])]
+    assert bn.blake2sum_batch(blocks) == [hashlib.blake2b(b, digest_size=64).digest()[:32] for b in blocks]
 
 
 @pytest.mark.parametrize("n", [0, 1, 64, 4095, 4096, 4097, 8192, 104896, 209728, (1 << 20) + 3])
