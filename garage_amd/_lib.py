@@ -32,10 +32,10 @@ GEC_MATRIX_VANDERMONDE, GEC_MATRIX_CAUCHY = 0, 1
 GEC_BACKEND_CPU, GEC_BACKEND_HIP, GEC_BACKEND_AUTO = 0, 1, 2
 GEC_CLASS_FOREGROUND, GEC_CLASS_BACKGROUND = 0, 1
 
-# every symbol include/garage_ec.h declares (tests/test_cabi_symbols.py checks
+# every symbol include/garage_ec.h declares (tests/test_cabi_host.py::test_every_declared_symbol_is_exported checks
 # this list against the header and against the built library)
 SYMBOLS = [
-    "gec_version", "gec_device_count", "gec_strerror", "gec_last_error", "gec_env_table", "gec_cpu_isa",
+    "gec_version", "gec_device_count", "gec_device_of_hash", "gec_strerror", "gec_last_error", "gec_env_table", "gec_cpu_isa",
     "gec_shard_len", "gec_build_matrix", "gec_build_matrix_ex", "gec_build_decode_matrix",
     "gec_codec_create", "gec_codec_create_ex", "gec_codec_destroy", "gec_codec_k", "gec_codec_m",
     "gec_codec_device", "gec_parity_matrix", "gec_codec_cache_stats",
@@ -93,6 +93,8 @@ def _load() -> ctypes.CDLL:
     pp = ctypes.POINTER(ctypes.c_void_p)
     lib.gec_version.restype = ctypes.c_uint32
     lib.gec_device_count.restype = ci
+    lib.gec_device_of_hash.argtypes = [ctypes.c_char_p, ci]
+    lib.gec_device_of_hash.restype = ci
     lib.gec_strerror.restype = ctypes.c_char_p
     lib.gec_strerror.argtypes = [ci]
     lib.gec_last_error.restype = ctypes.c_char_p

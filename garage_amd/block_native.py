@@ -31,6 +31,8 @@ SYMBOLS = [
     "gbm_batcher_create", "gbm_batcher_destroy", "gbm_batcher_put_block", "gbm_batcher_set_ram_buffer_max", "gbm_batcher_stats",
     "gbm_env_table", "gbm_set_tranquility", "gbm_tranquilized_ms", "gbm_background_codec",
     "gbm_batcher_submit", "gbm_batcher_wait", "gbm_set_maintenance_class", "gbm_batcher_get_block", "gbm_batcher_get_stats",
+    "gbm_create_multi", "gbm_device_count", "gbm_device_of_hash", "gbm_device_codec", "gbm_device_background_codec",
+    "gbm_device_metrics", "gbm_batcher_device_stats",
 ]
 
 
@@ -153,6 +155,14 @@ def _load():
     lib.gbm_batcher_get_block.argtypes = [vp, ctypes.c_char_p, vp, sz, ctypes.POINTER(ctypes.c_size_t)]
     lib.gbm_batcher_get_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.gbm_set_maintenance_class.argtypes = [vp, ci]
+    lib.gbm_create_multi.argtypes = [pp, ci, ci, ctypes.POINTER(ctypes.c_char_p), ci, pp]
+    lib.gbm_device_count.argtypes = [vp]
+    lib.gbm_device_of_hash.argtypes = [vp, ctypes.c_char_p]
+    for f in ("gbm_device_codec", "gbm_device_background_codec"):
+        getattr(lib, f).argtypes = [vp, ci]
+        getattr(lib, f).restype = vp
+    lib.gbm_device_metrics.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_uint64)]
+    lib.gbm_batcher_device_stats.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     return lib
 
 
@@ -191,20 +201,26 @@ def shardsum(data: bytes) -> bytes:
 
 
 class NativeBlockManager:
-    """garage_block::BlockManager mirror (C++), `codec` is a garage_amd.ReedSolomon."""
+    """garage_block::BlockManager mirror (C++), `codec` is a garage_amd.ReedSolomon -- or a list of them, one per
+    device: the manager then routes every block to the device gec_device_of_hash(hash, ndev) names (gbm_create_multi)."""
 
     METRICS = ("bytes_written", "bytes_read", "corruption_counter", "ec_reconstructs", "blocks_put", "blocks_get")
 
     def __init__(self, codec, nnodes: int, node_dirs: Optional[Sequence[str]] = None, write_quorum: int = 0,
                  compression_level: Optional[int] = None, data_fsync: bool = False):
-        self.codec = codec  # keep the borrowed codec alive
+        self.codecs = list(codec) if isinstance(codec, (list, tuple)) else None  # keep the borrowed codecs alive
+        self.codec = codec = self.codecs[0] if self.codecs else codec
         self.k, self.m, self.n, self.nnodes = codec.k, codec.m, codec.k + codec.m, nnodes
         dirs = None
         if node_dirs is not None:
             assert len(node_dirs) == nnodes
             dirs = (ctypes.c_char_p * nnodes)(*[d.encode() for d in node_dirs])
         h = ctypes.c_void_p()
-        _check(lib.gbm_create(codec._h, nnodes, dirs, write_quorum, ctypes.byref(h)), "gbm_create")
+        if self.codecs is not None:
+            arr = (ctypes.c_void_p * len(self.codecs))(*[c._h.value if isinstance(c._h, ctypes.c_void_p) else c._h for c in self.codecs])
+            _check(lib.gbm_create_multi(arr, len(self.codecs), nnodes, dirs, write_quorum, ctypes.byref(h)), "gbm_create_multi")
+        else:
+            _check(lib.gbm_create(codec._h, nnodes, dirs, write_quorum, ctypes.byref(h)), "gbm_create")
         self._h = h
         if compression_level is not None:
             _check(lib.gbm_set_compression_level(self._h, 1, compression_level), "gbm_set_compression_level")
@@ -434,6 +450,19 @@ class NativeBlockManager:
         _check(lib.gbm_metrics(self._h, out), "gbm_metrics")
         return dict(zip(self.METRICS, [int(x) for x in out]))
 
+    # several devices -------------------------------------------------------------
+    @property
+    def device_count(self) -> int:
+        return int(lib.gbm_device_count(self._h))
+
+    def device_of_hash(self, hash_: bytes) -> int:
+        return int(lib.gbm_device_of_hash(self._h, hash_))
+
+    def device_metrics(self, dev: int) -> dict:
+        out = (ctypes.c_uint64 * 6)()
+        _check(lib.gbm_device_metrics(self._h, dev, out), "gbm_device_metrics")
+        return dict(zip(self.METRICS, [int(x) for x in out]))
+
 
 class Batcher:
     """gbm_batcher: thread-safe put_block() calls coalesced into device batches."""
@@ -459,6 +488,17 @@ class Batcher:
         _check(lib.gbm_batcher_put_block(self._h, hash_, data, len(data), int(bool(prevent_compression)),
                                          NativeBlockManager._tag(order_tag)), "batcher.put_block")
 
+    def submit(self, hash_: bytes, data: bytes, prevent_compression: bool = False, order_tag=None):
+        """rpc_put_block as a future: queues the block and returns a ticket at once; `wait(ticket)` blocks until the
+        block's batch has been fanned out.  `hash_` and `data` must stay alive until then (the ticket keeps them)."""
+        tk = ctypes.c_void_p()
+        _check(lib.gbm_batcher_submit(self._h, hash_, data, len(data), int(bool(prevent_compression)),
+                                      NativeBlockManager._tag(order_tag), ctypes.byref(tk)), "batcher.submit")
+        return (tk, hash_, data)
+
+    def wait(self, ticket) -> None:
+        _check(lib.gbm_batcher_wait(ticket[0]), "batcher.wait")
+
     def stats(self) -> dict:
         out = (ctypes.c_uint64 * 3)()
         _check(lib.gbm_batcher_stats(self._h, out), "gbm_batcher_stats")
@@ -475,3 +515,10 @@ class Batcher:
         out = (ctypes.c_uint64 * 3)()
         _check(lib.gbm_batcher_get_stats(self._h, out), "gbm_batcher_get_stats")
         return {"batches": int(out[0]), "blocks": int(out[1]), "max_batch": int(out[2])}
+
+    def device_stats(self, dev: int) -> dict:
+        """One device's queue of a multi-device manager's batcher: {"put": {...}, "get": {...}}."""
+        p, g = (ctypes.c_uint64 * 3)(), (ctypes.c_uint64 * 3)()
+        _check(lib.gbm_batcher_device_stats(self._h, dev, p, g), "gbm_batcher_device_stats")
+        f = lambda o: {"batches": int(o[0]), "blocks": int(o[1]), "max_batch": int(o[2])}  # noqa: E731
+        return {"put": f(p), "get": f(g)}

@@ -1,6 +1,6 @@
 // bm_batcher.cpp -- the coalescing queue in front of the FFI: many callers with <= 3 puts in flight each
 // (PUT_BLOCKS_MAX_PARALLEL, src/api/s3/put.rs:42,486-511) -> a few device batches, with RAM permits
-// (buffer_kb_semaphore, src/block/manager.rs:380-384).
+// (buffer_kb_semaphore, src/block/manager.rs:380-384); one such queue per device of a multi-device manager.
 #include "bm_internal.hpp"
 
 using namespace gbmimpl;
@@ -15,6 +15,24 @@ using namespace gbmimpl;
 // take a ticket when they are formed and hand their shards to the nodes in ticket order (their device trips still
 // overlap), so the OrderTag guarantee -- requests of one stream reach a node in `order` order -- holds across
 // batches as well as inside one.
+//
+// How a batch is cut (round 4).  A batch goes through three stages -- the copy into the shard buffers (host pool), the
+// device trip (link-bound), the fan-out (host pool) -- and with two workers the stages of consecutive batches can
+// overlap, IF the callers are not all in the same batch: a closed loop of 48 callers that land in one batch wait for
+// it together, come back together and form the next one together, and the second worker never has anything to do
+// (round 3: 960 puts in 22 batches, 21.6 GiB/s where a bulk put of the same blocks reaches 43).  So
+//   - a worker that forms a batch while other workers are idle takes only its share of what is queued
+//     (GBM_BATCHER_SPLIT_MIN blocks or more: a PutObject's three still go as one batch), and the next idle worker
+//     takes the rest at once;
+//   - one batch per device is on the link at a time (`dev_mu`): two trips that share the link only lengthen each
+//     other and finish together, which is how the callers get back into lock step.
+// The same holds for the read side (gather / device trip / assembly).
+//
+// Several devices (gbm_create_multi): the batcher the caller holds is a front with one complete queue -- workers, RAM
+// budget share, statistics -- per device; a block goes to the queue of gec_device_of_hash(hash), and no lock is
+// shared between the queues.  The exception is by necessity: an OrderTag stream's blocks are encoded on different
+// devices, so tagged blocks take a sequence number from the front when they are submitted and reach the nodes one
+// block at a time behind their stream's previous block (`StreamSeq`).
 struct gbm_batcher {
 	struct Item {
 		const uint8_t *hash, *data;
@@ -22,7 +40,10 @@ struct gbm_batcher {
 		uint8_t prevent_compression = 0;
 		bool has_tag = false;
 		gbm_order_tag tag{0, 0};
+		uint64_t seq = 0, prev_seq = 0;  // multi-device fronts: submission sequence, and the stream's previous block's
+		bool delivered = false;          // (its fan-out is over: the stream's next block may go)
 		int rc = GBM_OK;
+		std::string err;  // the worker's error text (thread-local there), re-published on the caller's thread
 		bool done = false;
 	};
 	gbm_manager *mg = nullptr;
@@ -35,13 +56,63 @@ struct gbm_batcher {
 	std::condition_variable cv_work, cv_done, cv_ram;
 	std::deque<Item *> queue;
 	bool stop = false, forming = false;
+	int busy = 0;  // workers with a batch in hand
 	uint64_t batches = 0, blocks = 0, max_batch = 0;
 	// fan-out turnstile of the tagged batches
 	uint64_t next_ticket = 0, serving = 0;
 	std::condition_variable cv_turn;
+	std::mutex dev_mu, gdev_mu;  // one put batch / one get batch of this device on the link at a time
 	// two workers: while one batch is on the device the next one forms and starts (the device trip has a latency
 	// floor -- the checksum chain -- that a single worker would pay serially)
 	std::vector<std::thread> workers;
+
+	// ---- several devices
+	std::vector<gbm_batcher *> lanes;  // non-empty: this is a front, it only routes
+	gbm_batcher *front = nullptr;      // a lane's front
+	// Tagged blocks of a multi-device front.  A block's `seq` is taken when it is queued (under its lane's lock, so a
+	// lane's queue is in seq order) and a block waits for exactly one thing: its stream's previous block.  The block with
+	// the smallest undelivered seq is always first in its batch's order, its batch is the oldest of its lane, and its
+	// predecessor has a smaller seq -- so it can always go: no cycle.
+	struct StreamSeq {
+		std::mutex mu;
+		std::condition_variable cv;
+		uint64_t next = 1;
+		struct St {
+			uint64_t last_submitted = 0, delivered = 0;
+		};
+		std::unordered_map<uint64_t, St> streams;
+		void submit(Item &it)
+		{
+			std::lock_guard<std::mutex> g(mu);
+			St &st = streams[it.tag.stream_id];
+			it.seq = next++;
+			it.prev_seq = st.last_submitted;
+			st.last_submitted = it.seq;
+		}
+		void wait_turn(const Item &it)
+		{
+			std::unique_lock<std::mutex> g(mu);
+			cv.wait(g, [&] {
+				auto f = streams.find(it.tag.stream_id);
+				return f == streams.end() || f->second.delivered >= it.prev_seq;
+			});
+		}
+		void deliver(Item &it)
+		{
+			{
+				std::lock_guard<std::mutex> g(mu);
+				auto f = streams.find(it.tag.stream_id);
+				if (f != streams.end()) {
+					f->second.delivered = std::max(f->second.delivered, it.seq);
+					if (f->second.last_submitted == it.seq)
+						streams.erase(f);  // nothing of this stream is pending any more
+				}
+				it.delivered = true;
+			}
+			cv.notify_all();
+		}
+	} sseq;
+	bool sequenced() const { return front && front->lanes.size() > 1; }
 
 	// ---- the read side: GetObject's readers (a few blocks ahead each, src/api/s3/get.rs:429) coalesced the same way.
 	// Sixteen readers fetching eight blocks each through gbm_rpc_get_blocks make sixteen device trips that queue up
@@ -51,14 +122,51 @@ struct gbm_batcher {
 		uint8_t *out;
 		size_t cap, len = 0;
 		int rc = GBM_OK;
+		std::string err;
 		bool done = false;
 	};
 	std::mutex gmu;
 	std::condition_variable gcv_work, gcv_done;
 	std::deque<GetItem *> gqueue;
-	bool gforming = false;
+	bool gforming = false, stop_gets = false;
+	int gbusy = 0;
 	uint64_t gbatches = 0, gblocks = 0, gmax_batch = 0;
 	std::vector<std::thread> gworkers;
+
+	// Forms one batch out of `q` (the caller holds `lk`, `forming_flag` is this side's): lingers a little so concurrent
+	// callers land in the same batch -- the linger ends early once arrivals stop: callers come in bursts (the <= 3
+	// parallel puts of a PutObject, or everybody at once when a batch completes), and waiting out the full linger after
+	// the burst is pure latency (3 callers: 0.80 -> 0.55 ms per put) -- then takes its share of what is queued.
+	// (system_clock: libstdc++ maps it to pthread_cond_timedwait, which ThreadSanitizer understands; steady_clock ->
+	// pthread_cond_clockwait is not intercepted by gcc 11's TSan and floods the report with false "double lock" findings)
+	template <class T>
+	std::vector<T *> form(std::unique_lock<std::mutex> &lk, std::condition_variable &cv, std::deque<T *> &q, const bool &stopping,
+			      int busy_now, size_t nworkers)
+	{
+		const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(max_wait_us);
+		const auto gap = std::chrono::microseconds(std::max(20u, max_wait_us / 6));
+		size_t seen = q.size();
+		while (!stopping && q.size() < max_blocks) {
+			const auto now = std::chrono::system_clock::now();
+			if (now >= deadline)
+				break;
+			if (cv.wait_until(lk, std::min(deadline, now + gap)) == std::cv_status::timeout && q.size() == seen)
+				break;  // nobody arrived during the gap
+			seen = q.size();
+		}
+		size_t take = std::min(q.size(), max_blocks);
+		const size_t idle = nworkers > (size_t)busy_now ? nworkers - (size_t)busy_now : 1;  // this worker included
+		const size_t split_min = env().batcher_split_min;
+		if (split_min && idle > 1 && q.size() >= split_min)
+			take = std::min(take, (q.size() + idle - 1) / idle);
+		std::vector<T *> batch;
+		batch.reserve(take);
+		while (batch.size() < take) {
+			batch.push_back(q.front());
+			q.pop_front();
+		}
+		return batch;
+	}
 
 	void run_gets()
 	{
@@ -71,62 +179,77 @@ struct gbm_batcher {
 				continue;
 			}
 			gforming = true;
-			const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(max_wait_us);
-			const auto gap = std::chrono::microseconds(std::max(20u, max_wait_us / 6));
-			size_t seen = gqueue.size();
-			while (!stop_gets && gqueue.size() < max_blocks) {  // the put side's linger: it ends once arrivals stop
-				const auto now = std::chrono::system_clock::now();
-				if (now >= deadline)
-					break;
-				if (gcv_work.wait_until(lk, std::min(deadline, now + gap)) == std::cv_status::timeout && gqueue.size() == seen)
-					break;
-				seen = gqueue.size();
-			}
-			std::vector<GetItem *> batch;
-			while (!gqueue.empty() && batch.size() < max_blocks) {
-				batch.push_back(gqueue.front());
-				gqueue.pop_front();
-			}
+			std::vector<GetItem *> batch = form(lk, gcv_work, gqueue, stop_gets, gbusy, gworkers.size());
 			gforming = false;
+			++gbusy;
 			gcv_work.notify_all();
 			lk.unlock();
 			const size_t nb = batch.size();
-			std::vector<uint8_t> hashes(nb * 32);
-			std::vector<uint8_t *> outs(nb);
-			std::vector<size_t> caps(nb), lens(nb, 0);
-			std::vector<int> rcs(nb, GBM_E_MISSING_BLOCK);
-			for (size_t i = 0; i < nb; ++i) {
-				std::memcpy(hashes.data() + 32 * i, batch[i]->hash, 32);
-				outs[i] = batch[i]->out;
-				caps[i] = batch[i]->cap;
+			std::vector<int> rcs;
+			std::vector<size_t> lens;
+			std::vector<std::string> errs(nb);
+			FanoutGate gate;
+			if (env().batcher_device_turn) {
+				gate.device_enter = [&] { gdev_mu.lock(); };
+				gate.device_exit = [&] { gdev_mu.unlock(); };
 			}
-			int rc;
 			try {
-				rc = get_blocks_impl(mg, nb, hashes.data(), nullptr, outs.data(), caps.data(), lens.data(), rcs.data(), false, nullptr);
-			} catch (const std::exception &) {
-				rc = GBM_E_IO;
+				std::vector<uint8_t> hashes(nb * 32);
+				std::vector<uint8_t *> outs(nb);
+				std::vector<size_t> caps(nb);
+				lens.assign(nb, 0);
+				rcs.assign(nb, GBM_E_MISSING_BLOCK);
+				for (size_t i = 0; i < nb; ++i) {
+					std::memcpy(hashes.data() + 32 * i, batch[i]->hash, 32);
+					outs[i] = batch[i]->out;
+					caps[i] = batch[i]->cap;
+				}
+				auto fetch = [&](size_t i0, size_t cnt) {
+					int rc;
+					try {
+						rc = get_blocks_impl(mg, cnt, hashes.data() + 32 * i0, nullptr, outs.data() + i0, caps.data() + i0,
+								     lens.data() + i0, rcs.data() + i0, false, nullptr, &gate);
+					} catch (const std::exception &e) {
+						rc = fail(GBM_E_IO, std::string("batched get: ") + e.what());
+					}
+					if (rc != GBM_OK)  // the whole call failed (a device error, out of memory)
+						for (size_t i = i0; i < i0 + cnt; ++i) {
+							rcs[i] = rc;
+							errs[i] = last_error();
+						}
+					return rc;
+				};
+				// a call that fails as a whole (out of pinned memory, a device error) fails every block it carries: the
+				// blocks are then fetched one by one, so that one reader's trouble is not every reader's
+				if (fetch(0, nb) != GBM_OK && nb > 1)
+					for (size_t i = 0; i < nb; ++i)
+						(void)fetch(i, 1);
+			} catch (const std::exception &e) {  // the vectors above
+				rcs.assign(nb, GBM_E_IO);
+				lens.assign(nb, 0);
+				for (auto &s : errs)
+					s = e.what();
 			}
-			if (rc != GBM_OK)  // the whole call failed (a device error, out of memory): nobody of this batch has a block
-				std::fill(rcs.begin(), rcs.end(), rc);
 			lk.lock();
 			for (size_t i = 0; i < nb; ++i) {
 				batch[i]->rc = rcs[i];
 				batch[i]->len = lens[i];
+				batch[i]->err = std::move(errs[i]);
 				batch[i]->done = true;
 			}
+			--gbusy;
 			++gbatches;
 			gblocks += nb;
 			gmax_batch = std::max<uint64_t>(gmax_batch, nb);
 			gcv_done.notify_all();
 		}
 	}
-	bool stop_gets = false;
 
 	void run()
 	{
 		std::unique_lock<std::mutex> lk(mu);
 		for (;;) {
-			// one worker forms a batch at a time; the other one is either on the device or waits its turn
+			// one worker forms a batch at a time; the others are on the device, or wait their turn
 			cv_work.wait(lk, [&] { return stop || (!queue.empty() && !forming); });
 			if (queue.empty()) {
 				if (stop)
@@ -134,88 +257,110 @@ struct gbm_batcher {
 				continue;
 			}
 			forming = true;
-			// linger a little so concurrent callers land in the same batch
-			// system_clock: libstdc++ maps it to pthread_cond_timedwait, which ThreadSanitizer
-			// understands (steady_clock -> pthread_cond_clockwait is not intercepted by gcc 11's
-			// TSan and floods the report with false "double lock" findings)
-			// The linger ends early once arrivals stop: callers come in bursts (the <= 3 parallel puts of a PutObject,
-			// or everybody at once when a batch completes), and waiting out the full linger after the burst is pure
-			// latency -- 3 callers: 0.80 -> 0.55 ms per put.
-			const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(max_wait_us);
-			const auto gap = std::chrono::microseconds(std::max(20u, max_wait_us / 6));
-			size_t seen = queue.size();
-			while (!stop && queue.size() < max_blocks) {
-				const auto now = std::chrono::system_clock::now();
-				if (now >= deadline)
-					break;
-				if (cv_work.wait_until(lk, std::min(deadline, now + gap)) == std::cv_status::timeout && queue.size() == seen)
-					break;  // nobody arrived during the gap
-				seen = queue.size();
-			}
-			std::vector<Item *> batch;
-			while (!queue.empty() && batch.size() < max_blocks) {
-				batch.push_back(queue.front());
-				queue.pop_front();
-			}
+			std::vector<Item *> batch = form(lk, cv_work, queue, stop, busy, workers.size());
 			bool any_tag = false;
 			for (Item *it : batch)
 				any_tag = any_tag || it->has_tag;
-			const uint64_t ticket = any_tag ? next_ticket++ : 0;  // taken in formation order, under the lock
+			const bool seq = any_tag && sequenced();
+			// (single device) taken in formation order, under the lock
+			const uint64_t ticket = any_tag && !seq ? next_ticket++ : 0;
 			forming = false;
+			++busy;
 			cv_work.notify_all();
 			lk.unlock();
 			const size_t nb = batch.size();
-			std::vector<uint8_t> hashes(nb * 32), pc(nb);
-			std::vector<const uint8_t *> data(nb);
-			std::vector<size_t> lens(nb);
-			std::vector<gbm_order_tag> tags(nb);
-			std::vector<int> rcs(nb, GBM_OK);
-			static const uint8_t kEmpty = 0;  // a zero-length block may come with a NULL pointer
-			for (size_t i = 0; i < nb; ++i) {
-				std::memcpy(hashes.data() + 32 * i, batch[i]->hash, 32);
-				data[i] = batch[i]->data ? batch[i]->data : &kEmpty;
-				lens[i] = batch[i]->len;
-				pc[i] = batch[i]->prevent_compression;
-				// untagged blocks sort after tagged ones of the same batch; their relative order is free
-				tags[i] = batch[i]->has_tag ? batch[i]->tag : gbm_order_tag{~0ull, i};
-			}
-			FanoutGate gate;
+			std::vector<int> rcs;
+			std::string err;
 			bool passed = false;
-			gate.before = [&] {
-				std::unique_lock<std::mutex> g(mu);
-				cv_turn.wait(g, [&] { return serving == ticket; });
-			};
-			gate.after = [&] {
-				std::lock_guard<std::mutex> g(mu);
-				++serving;
-				passed = true;
-				cv_turn.notify_all();
-			};
-			int rc;
 			try {
-				rc = put_blocks_impl(mg, nb, hashes.data(), data.data(), lens.data(), pc.data(), any_tag ? tags.data() : nullptr,
-						     rcs.data(), any_tag ? &gate : nullptr);
-			} catch (const std::exception &) {
-				rc = GBM_E_IO;
-				std::fill(rcs.begin(), rcs.end(), GBM_E_IO);
+				std::vector<uint8_t> hashes(nb * 32), pc(nb);
+				std::vector<const uint8_t *> data(nb);
+				std::vector<size_t> lens(nb), order;
+				std::vector<gbm_order_tag> tags(nb);
+				rcs.assign(nb, GBM_OK);
+				static const uint8_t kEmpty = 0;  // a zero-length block may come with a NULL pointer
+				for (size_t i = 0; i < nb; ++i) {
+					std::memcpy(hashes.data() + 32 * i, batch[i]->hash, 32);
+					data[i] = batch[i]->data ? batch[i]->data : &kEmpty;
+					lens[i] = batch[i]->len;
+					pc[i] = batch[i]->prevent_compression;
+					// untagged blocks sort after tagged ones of the same batch; their relative order is free
+					tags[i] = batch[i]->has_tag ? batch[i]->tag : gbm_order_tag{~0ull, i};
+				}
+				FanoutGate gate;
+				if (env().batcher_device_turn) {
+					gate.device_enter = [&] { dev_mu.lock(); };
+					gate.device_exit = [&] { dev_mu.unlock(); };
+				}
+				if (seq) {
+					// tagged blocks in submission order (the queue's), untagged ones behind them
+					for (size_t i = 0; i < nb; ++i)
+						if (batch[i]->has_tag)
+							order.push_back(i);
+					for (size_t i = 0; i < nb; ++i)
+						if (!batch[i]->has_tag)
+							order.push_back(i);
+					gate.block_order = &order;
+					gate.before_block = [&](size_t b) {
+						if (batch[b]->has_tag)
+							front->sseq.wait_turn(*batch[b]);
+					};
+					gate.after_block = [&](size_t b) {
+						if (batch[b]->has_tag)
+							front->sseq.deliver(*batch[b]);
+					};
+				} else if (any_tag) {
+					gate.before = [&] {
+						std::unique_lock<std::mutex> g(mu);
+						cv_turn.wait(g, [&] { return serving == ticket; });
+					};
+					gate.after = [&] {
+						std::lock_guard<std::mutex> g(mu);
+						++serving;
+						passed = true;
+						cv_turn.notify_all();
+					};
+				}
+				int rc;
+				try {
+					rc = put_blocks_impl(mg, nb, hashes.data(), data.data(), lens.data(), pc.data(), any_tag ? tags.data() : nullptr,
+							     rcs.data(), &gate);
+				} catch (const std::exception &e) {
+					rc = fail(GBM_E_IO, std::string("batched put: ") + e.what());
+					std::fill(rcs.begin(), rcs.end(), GBM_E_IO);
+				}
+				if (rc != GBM_OK)
+					err = last_error();
+				// per-block results are in rcs; put_blocks_impl marks every block on a whole-batch failure, and should it
+				// ever return one without doing so, no caller of this batch is told its block was stored
+				if (rc != GBM_OK && rc != GBM_E_QUORUM)
+					for (int &r : rcs)
+						if (r == GBM_OK)
+							r = rc;
+			} catch (const std::exception &e) {  // the vectors above
+				rcs.assign(nb, GBM_E_IO);
+				err = e.what();
 			}
-			// per-block results are in rcs; put_blocks_impl marks every block on a whole-batch failure, and should it
-			// ever return one without doing so, no caller of this batch is told its block was stored
-			if (rc != GBM_OK && rc != GBM_E_QUORUM)
-				for (int &r : rcs)
-					if (r == GBM_OK)
-						r = rc;
+			if (seq)  // a put that failed before (or during) its fan-out: the streams must still move on
+				for (Item *it : batch)
+					if (it->has_tag && !it->delivered) {
+						front->sseq.wait_turn(*it);
+						front->sseq.deliver(*it);
+					}
 			lk.lock();
-			if (any_tag && !passed) {  // the put failed before its fan-out: the turnstile must still move on
+			if (any_tag && !seq && !passed) {  // the put failed before its fan-out: the turnstile must still move on
 				cv_turn.wait(lk, [&] { return serving == ticket; });
 				++serving;
 				cv_turn.notify_all();
 			}
 			for (size_t i = 0; i < nb; ++i) {
 				batch[i]->rc = rcs[i];
+				if (rcs[i] != GBM_OK)
+					batch[i]->err = err;
 				batch[i]->done = true;
 				ram_in_use_kb -= batch[i]->len / 1024;  // the permit is dropped once all sends finished
 			}
+			--busy;
 			cv_ram.notify_all();
 			++batches;
 			blocks += nb;
@@ -225,14 +370,13 @@ struct gbm_batcher {
 	}
 };
 
-extern "C" {
+namespace {
 
-int gbm_batcher_create(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, gbm_batcher **out)
+gbm_batcher *make_lane(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, gbm_batcher *front)
 {
-	if (!m || !out || max_blocks == 0)
-		return fail(GBM_E_INVALID_ARG, "bad batcher arguments");
 	auto *b = new gbm_batcher();
 	b->mg = m;
+	b->front = front;
 	b->max_blocks = max_blocks;
 	b->max_wait_us = max_wait_us;
 	const int nworkers = env().batcher_workers;
@@ -240,14 +384,11 @@ int gbm_batcher_create(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, 
 		b->workers.emplace_back([b] { b->run(); });
 	for (int i = 0; i < nworkers; ++i)
 		b->gworkers.emplace_back([b] { b->run_gets(); });
-	*out = b;
-	return GBM_OK;
+	return b;
 }
 
-void gbm_batcher_destroy(gbm_batcher *b)
+void destroy_lane(gbm_batcher *b)
 {
-	if (!b)
-		return;
 	{
 		std::lock_guard<std::mutex> g(b->mu);
 		b->stop = true;
@@ -266,12 +407,61 @@ void gbm_batcher_destroy(gbm_batcher *b)
 	delete b;
 }
 
+// the queue that serves `hash`
+gbm_batcher *lane_for(gbm_batcher *b, const uint8_t *hash)
+{
+	return b->lanes.empty() ? b : b->lanes[(size_t)gec_device_of_hash(hash, (int)b->lanes.size())];
+}
+
+}  // namespace
+
+extern "C" {
+
+int gbm_batcher_create(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, gbm_batcher **out)
+{
+	if (!m || !out || max_blocks == 0)
+		return fail(GBM_E_INVALID_ARG, "bad batcher arguments");
+	*out = nullptr;
+	try {
+		if (!m->is_front()) {
+			*out = make_lane(m, max_blocks, max_wait_us, nullptr);
+			return GBM_OK;
+		}
+		// one queue, its workers and its share of the RAM budget per device
+		auto *f = new gbm_batcher();
+		f->mg = m;
+		f->max_blocks = max_blocks;
+		f->max_wait_us = max_wait_us;
+		for (auto &lane : m->lanes) {
+			f->lanes.push_back(make_lane(lane.get(), max_blocks, max_wait_us, f));
+			f->lanes.back()->ram_permits_kb = std::max<size_t>(1, f->ram_permits_kb / m->lanes.size());
+		}
+		*out = f;
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("gbm_batcher_create: ") + e.what());
+	}
+	return GBM_OK;
+}
+
+void gbm_batcher_destroy(gbm_batcher *b)
+{
+	if (!b)
+		return;
+	if (b->lanes.empty()) {
+		destroy_lane(b);
+		return;
+	}
+	for (gbm_batcher *l : b->lanes)
+		destroy_lane(l);
+	delete b;
+}
+
 // The asynchronous pair: submit queues the block and returns at once (it only waits for RAM permits), wait blocks until
 // the batch that took the block has been fanned out.  This is the shape of `rpc_put_block(..)` as a future: a request
 // creates its futures in block order and keeps <= 3 of them pending (put.rs:486-511), so the blocks of one stream enter
 // the queue in `order` order -- which, with the fan-out turnstile, is what makes the OrderTag guarantee hold.
 struct gbm_put_ticket {
-	gbm_batcher *b;
+	gbm_batcher *b;  // the queue that holds the item
 	gbm_batcher::Item it;
 };
 
@@ -284,6 +474,7 @@ int gbm_batcher_submit(gbm_batcher *b, const uint8_t hash[32], const uint8_t *da
 	std::unique_ptr<gbm_put_ticket> tk(new (std::nothrow) gbm_put_ticket());
 	if (!tk)
 		return fail(GBM_E_IO, "out of memory");
+	b = lane_for(b, hash);
 	tk->b = b;
 	gbm_batcher::Item &it = tk->it;
 	it.hash = hash;
@@ -304,7 +495,16 @@ int gbm_batcher_submit(gbm_batcher *b, const uint8_t hash[32], const uint8_t *da
 	if (b->stop)
 		return fail(GBM_E_INVALID_ARG, "batcher is shutting down");
 	b->ram_in_use_kb += need_kb;
-	b->queue.push_back(&it);
+	if (it.has_tag && b->sequenced())
+		b->front->sseq.submit(it);  // under the queue's lock: the queue is in sequence order
+	try {
+		b->queue.push_back(&it);
+	} catch (const std::bad_alloc &) {
+		b->ram_in_use_kb -= need_kb;
+		if (it.has_tag && b->sequenced())
+			b->front->sseq.deliver(it);  // (waits for nobody: only marks the sequence number as gone)
+		return fail(GBM_E_IO, "out of memory");
+	}
 	b->cv_work.notify_all();
 	*ticket_out = tk.release();
 	return GBM_OK;
@@ -322,9 +522,9 @@ int gbm_batcher_wait(gbm_put_ticket *ticket)
 		rc = tk->it.rc;
 	}
 	if (rc == GBM_E_QUORUM)
-		return fail(rc, "Could not reach quorum");
+		return fail(rc, tk->it.err.empty() ? "Could not reach quorum" : tk->it.err);
 	if (rc != GBM_OK)
-		return fail(rc, "device batch failed");
+		return fail(rc, tk->it.err.empty() ? "device batch failed" : tk->it.err);
 	return GBM_OK;
 }
 
@@ -340,6 +540,7 @@ int gbm_batcher_get_block(gbm_batcher *b, const uint8_t hash[32], uint8_t *out, 
 {
 	if (!b || !hash || (!out && cap) || !len_out)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	b = lane_for(b, hash);
 	gbm_batcher::GetItem it;
 	it.hash = hash;
 	it.out = out;
@@ -348,24 +549,42 @@ int gbm_batcher_get_block(gbm_batcher *b, const uint8_t hash[32], uint8_t *out, 
 		std::unique_lock<std::mutex> lk(b->gmu);
 		if (b->stop_gets)
 			return fail(GBM_E_INVALID_ARG, "batcher is shutting down");
-		b->gqueue.push_back(&it);
+		try {
+			b->gqueue.push_back(&it);
+		} catch (const std::bad_alloc &) {
+			return fail(GBM_E_IO, "out of memory");
+		}
 		b->gcv_work.notify_all();
 		b->gcv_done.wait(lk, [&] { return it.done; });
 	}
 	*len_out = it.len;
-	if (it.rc != GBM_OK)
+	if (it.rc == GBM_OK)
+		return GBM_OK;
+	if (it.rc == GBM_E_MISSING_BLOCK || it.rc == GBM_E_CORRUPT_DATA || it.rc == GBM_E_BUFFER_TOO_SMALL)
 		return one_block_rc(it.rc);
-	return GBM_OK;
+	return fail(it.rc, it.err.empty() ? "batched get failed" : it.err);  // the worker's text, on the caller's thread
+}
+
+static void sum_stats(gbm_batcher *b, bool gets, uint64_t out[3])
+{
+	out[0] = out[1] = out[2] = 0;
+	auto add = [&](gbm_batcher *q) {
+		std::lock_guard<std::mutex> g(gets ? q->gmu : q->mu);
+		out[0] += gets ? q->gbatches : q->batches;
+		out[1] += gets ? q->gblocks : q->blocks;
+		out[2] = std::max(out[2], gets ? q->gmax_batch : q->max_batch);
+	};
+	if (b->lanes.empty())
+		add(b);
+	for (gbm_batcher *l : b->lanes)
+		add(l);
 }
 
 int gbm_batcher_get_stats(gbm_batcher *b, uint64_t out[3])
 {
 	if (!b || !out)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
-	std::lock_guard<std::mutex> g(b->gmu);
-	out[0] = b->gbatches;
-	out[1] = b->gblocks;
-	out[2] = b->gmax_batch;
+	sum_stats(b, true, out);
 	return GBM_OK;
 }
 
@@ -373,9 +592,14 @@ int gbm_batcher_set_ram_buffer_max(gbm_batcher *b, size_t bytes)
 {
 	if (!b || bytes < 1024)
 		return fail(GBM_E_INVALID_ARG, "bad ram buffer size");
-	std::lock_guard<std::mutex> g(b->mu);
-	b->ram_permits_kb = bytes / 1024;
-	b->cv_ram.notify_all();
+	auto set = [](gbm_batcher *q, size_t kb) {
+		std::lock_guard<std::mutex> g(q->mu);
+		q->ram_permits_kb = std::max<size_t>(1, kb);
+		q->cv_ram.notify_all();
+	};
+	set(b, bytes / 1024);
+	for (gbm_batcher *l : b->lanes)  // the node's budget, shared out evenly: the queues share no lock
+		set(l, bytes / 1024 / b->lanes.size());
 	return GBM_OK;
 }
 
@@ -383,10 +607,19 @@ int gbm_batcher_stats(gbm_batcher *b, uint64_t out[3])
 {
 	if (!b || !out)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
-	std::lock_guard<std::mutex> g(b->mu);
-	out[0] = b->batches;
-	out[1] = b->blocks;
-	out[2] = b->max_batch;
+	sum_stats(b, false, out);
+	return GBM_OK;
+}
+
+int gbm_batcher_device_stats(gbm_batcher *b, int dev, uint64_t put_out[3], uint64_t get_out[3])
+{
+	if (!b || dev < 0 || dev >= (b->lanes.empty() ? 1 : (int)b->lanes.size()))
+		return fail(GBM_E_INVALID_ARG, "bad device index");
+	gbm_batcher *q = b->lanes.empty() ? b : b->lanes[(size_t)dev];
+	if (put_out)
+		sum_stats(q, false, put_out);
+	if (get_out)
+		sum_stats(q, true, get_out);
 	return GBM_OK;
 }
 

@@ -33,7 +33,9 @@ const EnvRow kEnvRows[] = {
 	{"GBM_TRACE", "0", "1 = stage timings of the batched put / get / resync / scrub on stderr"},
 	{"GBM_PUT_SLICE", "64", "blocks per slice of a large untagged put"},
 	{"GBM_PUT_THREADS", "4", "put slices in flight"},
-	{"GBM_BATCHER_WORKERS", "2", "batches the coalescing batcher keeps in flight"},
+	{"GBM_BATCHER_WORKERS", "2", "batches the coalescing batcher keeps in flight (per device)"},
+	{"GBM_BATCHER_SPLIT_MIN", "16", "a batcher worker that finds this many blocks queued while other workers are idle takes only its share of them (0 = never split)"},
+	{"GBM_BATCHER_DEVICE_TURN", "1", "1 = one put batch and one get batch of a device's queue on the link at a time, the others prepare / fan out meanwhile (0 = trips overlap freely)"},
 	{"GBM_CPU_BLAKE2", "auto", "the manager's own BLAKE2b (block hashes of small gets, shard checks): auto = eight messages at a time with AVX-512, scalar = one at a time (A/B)"},
 };
 long env_long(const char *name, long def)
@@ -54,6 +56,9 @@ const Env &env()
 		v.put_threads = (int)(pt > 0 && pt <= 8 ? pt : 4);
 		const long bw = env_long("GBM_BATCHER_WORKERS", 0);
 		v.batcher_workers = (int)(bw >= 1 && bw <= 16 ? bw : 2);
+		const long sm = env_long("GBM_BATCHER_SPLIT_MIN", 16);
+		v.batcher_split_min = (size_t)(sm >= 0 ? sm : 16);
+		v.batcher_device_turn = env_long("GBM_BATCHER_DEVICE_TURN", 1) != 0;
 		const char *b2 = std::getenv("GBM_CPU_BLAKE2");
 		if (b2 && b2[0] == 's')
 			b2host::mb_mode().store(0);
@@ -209,9 +214,98 @@ int hash_many(gbm_manager *mg, const std::vector<const uint8_t *> &ptrs, const s
 	return GBM_OK;
 }
 
+// fn(lane) for every lane of a front, each on a thread of its own (the calling thread takes lane 0): the lanes are
+// independent managers over different devices, so a batch call on the front is ndev batch calls side by side.
+// Returns the last non-zero result and re-publishes its (thread-local) error text on the calling thread.
+int for_lanes(gbm_manager *front, const std::function<int(gbm_manager *, size_t)> &fn)
+{
+	const size_t nl = front->lanes.size();
+	std::vector<int> rcs(nl, GBM_OK);
+	std::vector<std::string> errs(nl);
+	auto one = [&](size_t i) {
+		try {
+			rcs[i] = fn(front->lanes[i].get(), i);
+		} catch (const std::exception &e) {
+			rcs[i] = fail(GBM_E_IO, e.what());
+		}
+		if (rcs[i])
+			errs[i] = last_error();
+	};
+	std::vector<std::thread> th;
+	for (size_t i = 1; i < nl; ++i)
+		th.emplace_back(one, i);
+	one(0);
+	for (auto &t : th)
+		t.join();
+	for (size_t i = nl; i-- > 0;)
+		if (rcs[i])
+			return fail(rcs[i], errs[i]);
+	return GBM_OK;
+}
+
+namespace {
+// one complete manager over one codec; `nodes` non-empty: share these storage nodes (a lane of a front)
+int create_one(const gec_codec *codec, int nnodes, const char *const *node_dirs, int write_quorum,
+	       const std::vector<std::shared_ptr<Node>> *nodes, std::unique_ptr<gbm_manager> &out)
+{
+	const int k = gec_codec_k(codec), m = gec_codec_m(codec);
+	if (nnodes < k + m)
+		return fail(GBM_E_INVALID_ARG, "RS(k,m) needs at least k+m storage nodes (replication_factor == k+m)");
+	if (k + m > 255)
+		return fail(GBM_E_INVALID_ARG, "shard index must fit a byte");
+	auto mg = std::make_unique<gbm_manager>();
+	mg->codec = codec;
+	mg->k = k;
+	mg->m = m;
+	mg->n = k + m;
+	mg->write_quorum = write_quorum > 0 ? write_quorum : k + (m + 1) / 2;
+	if (mg->write_quorum < k || mg->write_quorum > mg->n)
+		return fail(GBM_E_INVALID_ARG, "write quorum must be in [k, k+m]");
+	if (nodes) {
+		mg->nodes = *nodes;
+	} else {
+		for (int i = 0; i < nnodes; ++i) {
+			mg->nodes.push_back(node_dirs ? make_dir_node(node_dirs[i]) : make_memory_node());
+			mg->nodes.back()->bufs = mg->bufs;
+		}
+	}
+	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+	mg->pool.reset(new Pool(std::min(15u, hw - 1)));
+	// maintenance gets a background-class sibling of the codec (its own staging slots, low-priority streams on a
+	// subset of the CUs, small chunks that yield to the request path); without one it shares the request path's codec
+	if (gec_codec_background(codec, &mg->bg_codec_owned) != GEC_OK)
+		mg->bg_codec_owned = nullptr;
+	out = std::move(mg);
+	return GBM_OK;
+}
+
+void destroy_one(gbm_manager *m)
+{
+	gbm_resync_worker_stop(m);
+	m->async.reset();  // drains: abandoned hedged requests still point at the nodes
+	if (m->bg_codec_owned)
+		gec_codec_destroy(m->bg_codec_owned);
+	m->bg_codec_owned = nullptr;
+}
+}  // namespace
+
 }  // namespace gbmimpl
 
 using namespace gbmimpl;
+
+// `expr` on the manager itself, or on every lane of a front (and on the front, whose copy of the setting only
+// answers the getters)
+#define GBM_EACH(m, var, expr)                          \
+	do {                                            \
+		{                                       \
+			gbm_manager *var = (m);         \
+			expr;                           \
+		}                                       \
+		for (auto &lane_ : (m)->lanes) {        \
+			gbm_manager *var = lane_.get(); \
+			expr;                           \
+		}                                       \
+	} while (0)
 
 extern "C" {
 
@@ -234,30 +328,54 @@ int gbm_create(const gec_codec *codec, int nnodes, const char *const *node_dirs,
 	if (!codec || !out)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
 	*out = nullptr;
-	const int k = gec_codec_k(codec), m = gec_codec_m(codec);
-	if (nnodes < k + m)
-		return fail(GBM_E_INVALID_ARG, "RS(k,m) needs at least k+m storage nodes (replication_factor == k+m)");
-	if (k + m > 255)
-		return fail(GBM_E_INVALID_ARG, "shard index must fit a byte");
-	auto mg = std::make_unique<gbm_manager>();
-	mg->codec = codec;
-	mg->k = k;
-	mg->m = m;
-	mg->n = k + m;
-	mg->write_quorum = write_quorum > 0 ? write_quorum : k + (m + 1) / 2;
-	if (mg->write_quorum < k || mg->write_quorum > mg->n)
-		return fail(GBM_E_INVALID_ARG, "write quorum must be in [k, k+m]");
-	for (int i = 0; i < nnodes; ++i) {
-		mg->nodes.push_back(node_dirs ? make_dir_node(node_dirs[i]) : make_memory_node());
-		mg->nodes.back()->bufs = mg->bufs;
-	}
-	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-	mg->pool.reset(new Pool(std::min(15u, hw - 1)));
-	// maintenance gets a background-class sibling of the codec (its own staging slots, low-priority streams on a
-	// subset of the CUs, small chunks that yield to the request path); without one it shares the request path's codec
-	if (gec_codec_background(codec, &mg->bg_codec_owned) != GEC_OK)
-		mg->bg_codec_owned = nullptr;
+	std::unique_ptr<gbm_manager> mg;
+	int rc = create_one(codec, nnodes, node_dirs, write_quorum, nullptr, mg);
+	if (rc)
+		return rc;
 	*out = mg.release();
+	return GBM_OK;
+}
+
+int gbm_create_multi(const gec_codec *const *codecs, int ndev, int nnodes, const char *const *node_dirs, int write_quorum,
+		     gbm_manager **out)
+{
+	if (!codecs || !out || ndev < 1 || ndev > 256)
+		return fail(GBM_E_INVALID_ARG, "need 1 <= ndev <= 256 codecs");
+	*out = nullptr;
+	for (int d = 0; d < ndev; ++d) {
+		if (!codecs[d])
+			return fail(GBM_E_INVALID_ARG, "NULL codec");
+		if (gec_codec_k(codecs[d]) != gec_codec_k(codecs[0]) || gec_codec_m(codecs[d]) != gec_codec_m(codecs[0]))
+			return fail(GBM_E_INVALID_ARG, "every device's codec must be the same RS(k,m)");
+		for (int e = 0; e < d; ++e)
+			if (codecs[e] == codecs[d])
+				return fail(GBM_E_INVALID_ARG, "one codec per device: the same codec was given twice");
+	}
+	try {
+		auto front = std::make_unique<gbm_manager>();
+		for (int d = 0; d < ndev; ++d) {
+			std::unique_ptr<gbm_manager> lane;
+			int rc = create_one(codecs[d], nnodes, node_dirs, write_quorum, d ? &front->nodes : nullptr, lane);
+			if (rc) {
+				for (auto &l : front->lanes)
+					destroy_one(l.get());
+				return rc;
+			}
+			lane->lane_idx = d;
+			lane->lane_cnt = ndev;
+			if (d == 0) {
+				front->nodes = lane->nodes;
+				front->k = lane->k;
+				front->m = lane->m;
+				front->n = lane->n;
+				front->write_quorum = lane->write_quorum;
+			}
+			front->lanes.push_back(std::move(lane));
+		}
+		*out = front.release();
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("gbm_create_multi: ") + e.what());
+	}
 	return GBM_OK;
 }
 
@@ -265,19 +383,60 @@ void gbm_destroy(gbm_manager *m)
 {
 	if (!m)
 		return;
-	gbm_resync_worker_stop(m);
-	m->async.reset();  // drains: abandoned hedged requests still point at the nodes
-	if (m->bg_codec_owned)
-		gec_codec_destroy(m->bg_codec_owned);
+	for (auto &l : m->lanes)
+		destroy_one(l.get());
+	if (!m->is_front())
+		destroy_one(m);
 	delete m;
+}
+
+int gbm_device_count(const gbm_manager *m) { return !m ? 0 : m->is_front() ? (int)m->lanes.size() : 1; }
+
+int gbm_device_of_hash(const gbm_manager *m, const uint8_t hash[32])
+{
+	if (!m || !hash)
+		return -1;
+	return m->is_front() ? gec_device_of_hash(hash, (int)m->lanes.size()) : 0;
+}
+
+static const gbm_manager *lane_of(const gbm_manager *m, int dev)
+{
+	if (!m || dev < 0 || dev >= gbm_device_count(m))
+		return nullptr;
+	return m->is_front() ? m->lanes[(size_t)dev].get() : m;
+}
+
+const gec_codec *gbm_device_codec(const gbm_manager *m, int dev)
+{
+	const gbm_manager *l = lane_of(m, dev);
+	return l ? l->codec : nullptr;
+}
+
+const gec_codec *gbm_device_background_codec(const gbm_manager *m, int dev)
+{
+	const gbm_manager *l = lane_of(m, dev);
+	return l ? l->bg_codec() : nullptr;
+}
+
+int gbm_device_metrics(const gbm_manager *m, int dev, uint64_t out[6])
+{
+	const gbm_manager *l = lane_of(m, dev);
+	if (!l || !out)
+		return fail(GBM_E_INVALID_ARG, "bad device index / NULL argument");
+	for (int i = 0; i < 6; ++i)
+		out[i] = l->metrics[i].load();
+	return GBM_OK;
 }
 
 int gbm_set_threads(gbm_manager *m, int nthreads)
 {
 	if (!m || nthreads < 1 || nthreads > 256)
 		return fail(GBM_E_INVALID_ARG, "need 1 <= nthreads <= 256");
-	m->pool->resize((unsigned)nthreads - 1);  // the calling thread works too
-	m->cpu_block_hash_max = 6 * (size_t)nthreads;
+	GBM_EACH(m, x, {
+		if (x->pool)
+			x->pool->resize((unsigned)nthreads - 1);  // the calling thread works too
+		x->cpu_block_hash_max = 6 * (size_t)nthreads;
+	});
 	return GBM_OK;
 }
 
@@ -285,7 +444,7 @@ int gbm_set_host_block_hash_max(gbm_manager *m, size_t nblocks)
 {
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
-	m->cpu_block_hash_max = nblocks;
+	GBM_EACH(m, x, x->cpu_block_hash_max = nblocks);
 	return GBM_OK;
 }
 
@@ -302,7 +461,7 @@ int gbm_set_verify_block_hash(gbm_manager *m, int enabled)
 {
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
-	m->verify_block_hash = enabled != 0;
+	GBM_EACH(m, x, x->verify_block_hash = enabled != 0);
 	return GBM_OK;
 }
 
@@ -310,34 +469,52 @@ int gbm_set_tranquility(gbm_manager *m, int scrub_tranquility, int resync_tranqu
 {
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
-	if (scrub_tranquility >= 0)
-		m->scrub_tranquility = (uint32_t)scrub_tranquility;
-	if (resync_tranquility >= 0)
-		m->resync_tranquility = (uint32_t)resync_tranquility;
+	GBM_EACH(m, x, {
+		if (scrub_tranquility >= 0)
+			x->scrub_tranquility = (uint32_t)scrub_tranquility;
+		if (resync_tranquility >= 0)
+			x->resync_tranquility = (uint32_t)resync_tranquility;
+	});
 	return GBM_OK;
 }
 
-uint64_t gbm_tranquilized_ms(const gbm_manager *m) { return m ? m->tranquilized_ms.load() : 0; }
+uint64_t gbm_tranquilized_ms(const gbm_manager *m)
+{
+	if (!m)
+		return 0;
+	uint64_t v = m->tranquilized_ms.load();
+	for (auto &l : m->lanes)
+		v += l->tranquilized_ms.load();
+	return v;
+}
 
 int gbm_set_maintenance_class(gbm_manager *m, int background)
 {
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
-	m->maintenance_on_bg = background != 0;
+	GBM_EACH(m, x, x->maintenance_on_bg = background != 0);
 	return GBM_OK;
 }
 
-const gec_codec *gbm_background_codec(const gbm_manager *m) { return m ? m->bg_codec() : nullptr; }
+const gec_codec *gbm_background_codec(const gbm_manager *m) { return gbm_device_background_codec(m, 0); }
 
 int gbm_set_read_hedge(gbm_manager *m, uint64_t hedge_us)
 {
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
-	m->hedge_us = hedge_us;
+	GBM_EACH(m, x, x->hedge_us = hedge_us);
 	return GBM_OK;
 }
 
-uint64_t gbm_hedged_reads(const gbm_manager *m) { return m ? m->hedged_reads.load() : 0; }
+uint64_t gbm_hedged_reads(const gbm_manager *m)
+{
+	if (!m)
+		return 0;
+	uint64_t v = m->hedged_reads.load();
+	for (auto &l : m->lanes)
+		v += l->hedged_reads.load();
+	return v;
+}
 
 int gbm_node_set_latency(gbm_manager *m, int node, uint64_t latency_us)
 {
@@ -351,12 +528,14 @@ int gbm_set_timing(gbm_manager *m, int64_t gc_delay_ms, int64_t resync_retry_del
 {
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
-	if (gc_delay_ms >= 0)
-		m->gc_delay_ms = (uint64_t)gc_delay_ms;
-	if (resync_retry_delay_ms >= 0)
-		m->retry_delay_ms = (uint64_t)resync_retry_delay_ms;
-	if (incref_check_delay_ms >= 0)
-		m->incref_delay_ms = (uint64_t)incref_check_delay_ms;
+	GBM_EACH(m, x, {
+		if (gc_delay_ms >= 0)
+			x->gc_delay_ms = (uint64_t)gc_delay_ms;
+		if (resync_retry_delay_ms >= 0)
+			x->retry_delay_ms = (uint64_t)resync_retry_delay_ms;
+		if (incref_check_delay_ms >= 0)
+			x->incref_delay_ms = (uint64_t)incref_check_delay_ms;
+	});
 	return GBM_OK;
 }
 
@@ -364,8 +543,10 @@ int gbm_clock_advance(gbm_manager *m, uint64_t ms)
 {
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
-	m->clock_skew_ms += ms;
-	m->rs_cv.notify_all();
+	GBM_EACH(m, x, {
+		x->clock_skew_ms += ms;
+		x->rs_cv.notify_all();
+	});
 	return GBM_OK;
 }
 
@@ -383,6 +564,8 @@ int gbm_layout_update(gbm_manager *m)
 {
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	for (auto &l : m->lanes)  // the layout is the cluster's, not a device's: every lane follows
+		++l->layout_cur;
 	return ++m->layout_cur;
 }
 
@@ -390,7 +573,7 @@ int gbm_layout_trim(gbm_manager *m)
 {
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
-	m->layout_oldest = m->layout_cur.load();
+	GBM_EACH(m, x, x->layout_oldest = x->layout_cur.load());
 	return GBM_OK;
 }
 
@@ -464,21 +647,33 @@ int gbm_set_compression_level(gbm_manager *m, int enabled, int level)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
 	if (enabled && !zstd().ok)
 		return fail(GBM_E_IO, "libzstd.so.1 not available");
-	m->compression_level = level;
-	m->compress = enabled != 0;
+	GBM_EACH(m, x, {
+		x->compression_level = level;
+		x->compress = enabled != 0;
+	});
 	return GBM_OK;
 }
 
-uint64_t gbm_gpu_hashed(const gbm_manager *m) { return m ? m->gpu_hashed.load() : 0; }
+uint64_t gbm_gpu_hashed(const gbm_manager *m)
+{
+	if (!m)
+		return 0;
+	uint64_t v = m->gpu_hashed.load();
+	for (auto &l : m->lanes)
+		v += l->gpu_hashed.load();
+	return v;
+}
 
 int gbm_metrics(const gbm_manager *m, uint64_t out[6])
 {
 	if (!m || !out)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
-	for (int i = 0; i < 6; ++i)
+	for (int i = 0; i < 6; ++i) {
 		out[i] = m->metrics[i].load();
+		for (auto &l : m->lanes)  // a front: the sum over its devices (gbm_device_metrics has each one's)
+			out[i] += l->metrics[i].load();
+	}
 	return GBM_OK;
 }
-
 
 }  // extern "C"

@@ -53,6 +53,8 @@ struct Env {
 	size_t put_slice;         // GBM_PUT_SLICE
 	int put_threads;          // GBM_PUT_THREADS
 	int batcher_workers;      // GBM_BATCHER_WORKERS
+	size_t batcher_split_min; // GBM_BATCHER_SPLIT_MIN
+	bool batcher_device_turn; // GBM_BATCHER_DEVICE_TURN
 };
 const Env &env();
 const char *env_table_text();
@@ -474,7 +476,28 @@ struct gbm_manager {
 	std::atomic<uint32_t> scrub_tranquility{0}, resync_tranquility{0};
 	std::atomic<uint64_t> tranquilized_ms{0};
 	int k = 0, m = 0, n = 0, write_quorum = 0;
-	std::vector<std::unique_ptr<Node>> nodes;
+	std::vector<std::shared_ptr<Node>> nodes;  // shared by the lanes of a multi-device manager
+
+	// Several devices on one node (gbm_create_multi).  The manager the caller holds is then a FRONT: it owns one complete
+	// manager per device (a "lane": that device's foreground codec, its BACKGROUND sibling, its own pinned-buffer pool, host
+	// pool, refcount stripes, mutation locks and resync queue) and routes every call by gec_device_of_hash(hash, ndev) --
+	// the same trick the reference plays with hash bytes for partitions, drives and mutation locks
+	// (src/rpc/layout/version.rs:101-104, src/block/layout.rs:278-284, src/block/manager.rs:679-689).  A hash belongs to
+	// exactly one lane, so everything keyed by hash lives in that lane alone and two devices never share a lock on the
+	// request path; only the storage nodes (which lock internally, per hash stripe) are common.
+	std::vector<std::unique_ptr<gbm_manager>> lanes;  // non-empty: this is a front (codec == NULL, no pool of its own)
+	int lane_idx = 0, lane_cnt = 1;                   // a lane owns the hashes with gec_device_of_hash(h, lane_cnt) == lane_idx
+	bool is_front() const { return !lanes.empty(); }
+	bool owns(const Hash &h) const
+	{
+		return lane_cnt == 1 || gec_device_of_hash(reinterpret_cast<const uint8_t *>(h.data()), lane_cnt) == lane_idx;
+	}
+	// the manager that serves `hash`: a lane of a front, the manager itself otherwise
+	gbm_manager *route(const uint8_t *hash)
+	{
+		return lanes.empty() ? this : lanes[(size_t)gec_device_of_hash(hash, (int)lanes.size())].get();
+	}
+	const gbm_manager *route(const uint8_t *hash) const { return const_cast<gbm_manager *>(this)->route(hash); }
 	std::shared_ptr<BufPool> bufs = std::make_shared<BufPool>();
 	std::unique_ptr<Pool> pool;
 
@@ -579,6 +602,18 @@ constexpr size_t kMaxDecompressed = 1ull << 30;
 // CPU pool through PCIe, else on the pool's threads.  SURVEY.md section 8 row f4.
 int hash_many(gbm_manager *mg, const std::vector<const uint8_t *> &ptrs, const std::vector<size_t> &lens, std::vector<uint8_t> &sums);
 
+// fn(lane, lane index) for every lane of a front, side by side on threads of their own; the last non-zero result, its
+// error text re-published on the calling thread (bm_core.cpp)
+int for_lanes(gbm_manager *front, const std::function<int(gbm_manager *, size_t)> &fn);
+// block indices [0, nb) of a batch call on a front, by owning lane, in the caller's order
+inline std::vector<std::vector<size_t>> split_by_lane(const gbm_manager *front, size_t nb, const uint8_t *hashes)
+{
+	std::vector<std::vector<size_t>> ids(front->lanes.size());
+	for (size_t b = 0; b < nb; ++b)
+		ids[(size_t)gec_device_of_hash(hashes + 32 * b, (int)front->lanes.size())].push_back(b);
+	return ids;
+}
+
 // Shards of one block are only usable together when they were cut from the same
 // payload with the same geometry.  A block can legitimately have shards of two
 // geometries on disk at once -- e.g. it was first stored Plain and a later put with
@@ -637,16 +672,41 @@ bool send_shard(gbm_manager *mg, int node, const Hash &h, int idx, const Bytes &
 		const uint8_t *checksum, const gbm_order_tag *tag, bool *pending = nullptr);
 // order gate of the batcher: batches that carry order tags hand their shards to the nodes in the order they were formed
 struct FanoutGate {
-	std::function<void()> before, after;
+	std::function<void()> before, after;  // around the whole fan-out of a batch that carries tags (one device)
+	// around the batch's device trip: the batcher lets ONE batch of a device onto the link at a time -- two trips that
+	// share it only lengthen each other, while a batch that waits its turn leaves its worker's host stages (copy into
+	// the shard buffers, fan-out) overlapping the other batch's trip
+	std::function<void()> device_enter, device_exit;
+	// several devices: blocks of one OrderTag stream are encoded on different devices, in different batches.  Tagged
+	// blocks then go out one block at a time, in `block_order` (the order the blocks were submitted in, over all
+	// devices), each one between before_block(b) -- returns once the stream's previous block has reached its nodes,
+	// whichever device had it -- and after_block(b).
+	const std::vector<size_t> *block_order = nullptr;
+	std::function<void(size_t)> before_block, after_block;
+};
+// RAII form of device_enter / device_exit
+struct DeviceTurn {
+	const FanoutGate *g;
+	explicit DeviceTurn(const FanoutGate *gate) : g(gate)
+	{
+		if (g && g->device_enter)
+			g->device_enter();
+	}
+	~DeviceTurn()
+	{
+		if (g && g->device_exit)
+			g->device_exit();
+	}
 };
 // raw == true: rpc_get_raw_block (stored bytes + header); false: rpc_get_block (plain bytes).  bm_rw.cpp
 int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
-		    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers);
+		    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers,
+		    const FanoutGate *gate = nullptr);
 int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data, const size_t *len,
 		    const uint8_t *prevent_compression, const gbm_order_tag *tags, int *rcs, const FanoutGate *gate = nullptr);
 int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs,
 		 bool want_block_sums, std::vector<uint8_t> &block_sums, const std::function<void()> &overlap = nullptr,
-		 std::vector<uint8_t> *changed = nullptr);
+		 std::vector<uint8_t> *changed = nullptr, const FanoutGate *gate = nullptr);
 void assemble(const Gathered &g, int k, uint8_t *dst);
 int one_block_rc(int rc1);
 // every hash any reachable node holds a shard of (bm_scrub.cpp)

@@ -327,6 +327,7 @@ int gbm_block_incref(gbm_manager *m, const uint8_t hash[32])
 {
 	if (!m || !hash)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	m = m->route(hash);
 	Hash h((const char *)hash, 32);
 	bool was_zero;
 	{
@@ -348,6 +349,7 @@ int gbm_block_decref(gbm_manager *m, const uint8_t hash[32])
 {
 	if (!m || !hash)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	m = m->route(hash);
 	Hash h((const char *)hash, 32);
 	bool deletable = false;
 	{
@@ -373,7 +375,7 @@ int gbm_block_rc(gbm_manager *m, const uint8_t hash[32], uint64_t out[3])
 {
 	if (!m || !hash || !out)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
-	RcEntry e = m->get_rc(Hash((const char *)hash, 32));
+	RcEntry e = m->route(hash)->get_rc(Hash((const char *)hash, 32));
 	out[0] = e.kind == RcEntry::Present ? e.v : 0;
 	out[1] = e.kind;
 	out[2] = e.kind == RcEntry::Deletable ? e.v : 0;
@@ -384,7 +386,7 @@ int gbm_put_to_resync(gbm_manager *m, const uint8_t hash[32], uint64_t delay_ms)
 {
 	if (!m || !hash)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
-	m->put_to_resync(Hash((const char *)hash, 32), delay_ms);
+	m->route(hash)->put_to_resync(Hash((const char *)hash, 32), delay_ms);
 	return GBM_OK;
 }
 
@@ -393,6 +395,19 @@ int gbm_resync_run(gbm_manager *mg, size_t max_blocks, uint64_t stats[8])
 {
 	if (!mg)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	if (mg->is_front()) {
+		// every device's queue side by side, each on its own BACKGROUND codec; max_blocks is shared out evenly
+		const size_t nl = mg->lanes.size(), share = max_blocks ? (max_blocks + nl - 1) / nl : 0;
+		std::vector<std::array<uint64_t, 8>> per(nl);
+		int rc = for_lanes(mg, [&](gbm_manager *lane, size_t i) { return gbm_resync_run(lane, share, per[i].data()); });
+		if (stats)
+			for (int j = 0; j < 8; ++j) {
+				stats[j] = 0;
+				for (auto &p : per)
+					stats[j] += p[j];
+			}
+		return rc;
+	}
 	ResyncStats st;
 	std::vector<ResyncTask> tasks;
 	std::vector<std::pair<uint64_t, Hash>> taken;
@@ -456,6 +471,7 @@ int gbm_resync_block(gbm_manager *mg, const uint8_t hash[32], int *changed)
 {
 	if (!mg || !hash)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	mg = mg->route(hash);
 	std::vector<ResyncTask> tasks(1);
 	tasks[0].h.assign((const char *)hash, 32);
 	ResyncStats st;
@@ -494,22 +510,33 @@ size_t gbm_resync_queue_len(const gbm_manager *m)
 {
 	if (!m)
 		return 0;
+	size_t total = 0;
+	for (auto &l : m->lanes)
+		total += gbm_resync_queue_len(l.get());
 	std::lock_guard<std::mutex> lk(m->rs_mu);
-	return m->rs_queue.size();
+	return total + m->rs_queue.size();
 }
 
 size_t gbm_resync_errors_len(const gbm_manager *m)
 {
 	if (!m)
 		return 0;
+	size_t total = 0;
+	for (auto &l : m->lanes)
+		total += gbm_resync_errors_len(l.get());
 	std::lock_guard<std::mutex> lk(m->rs_mu);
-	return m->rs_errors.size();
+	return total + m->rs_errors.size();
 }
 
 int gbm_resync_worker_start(gbm_manager *m)
 {
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	if (m->is_front()) {  // one ResyncWorker per device queue
+		for (auto &l : m->lanes)
+			(void)gbm_resync_worker_start(l.get());
+		return GBM_OK;
+	}
 	std::lock_guard<std::mutex> g(m->rs_mu);
 	if (m->rs_worker.joinable())
 		return GBM_OK;
@@ -538,6 +565,8 @@ int gbm_resync_worker_stop(gbm_manager *m)
 {
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	for (auto &l : m->lanes)
+		(void)gbm_resync_worker_stop(l.get());
 	std::thread t;
 	{
 		std::lock_guard<std::mutex> g(m->rs_mu);

@@ -401,7 +401,11 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 			pp[i] = prep[ids[i]].parity.mut();
 			gd[i] = prep[ids[i]].block.data();
 		}
-		int rc = gec_encode_hash_batch(mg->codec, gn, gd.data(), gl.data(), S, pp.data(), gsums.data());
+		int rc;
+		{
+			DeviceTurn turn(gate);
+			rc = gec_encode_hash_batch(mg->codec, gn, gd.data(), gl.data(), S, pp.data(), gsums.data());
+		}
 		if (rc) {  // nothing has been sent to any node yet: the whole batch fails
 			if (rcs)
 				std::fill(rcs, rcs + nb, GBM_E_EC);
@@ -461,7 +465,33 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 		}
 		oks[b] = ok;
 	};
-	if (tags) {
+	if (tags && gate && gate->block_order) {
+		// several devices share the streams: one block at a time, in submission order, each behind its stream's previous
+		// block (which another device's batch may hold)
+		for (size_t b : *gate->block_order) {
+			Hash h((const char *)hashes + 32 * b, 32);
+			std::vector<int> who;
+			mg->nodes_of(h, who);
+			const size_t S = prep[b].S;
+			std::atomic<int> okc{0};
+			if (gate->before_block)
+				gate->before_block(b);
+			mg->pool->parallel_for((size_t)n, [&](size_t jj) {
+				const int j = (int)jj;
+				const Bytes payload = j < k ? prep[b].block.slice((size_t)j * S, S) : prep[b].parity.slice((size_t)(j - k) * S, S);
+				bool pend = false;
+				if (send_shard(mg, who[j], h, j, payload, S, prep[b].plen, prep[b].z, sums.data() + (b * n + j) * 32, &tags[b], &pend)) {
+					++okc;
+					mg->metrics[0] += S;
+					if (pend)
+						note_parked(b, j, who[j]);
+				}
+			});
+			if (gate->after_block)
+				gate->after_block(b);
+			oks[b] = okc.load();
+		}
+	} else if (tags) {
 		// order is a per-node property (requests of one stream reach a NODE in `order` order): the nodes are served
 		// side by side, each one walking the blocks in (stream, order) order and taking the shards that are its own
 		std::vector<size_t> order(nb);
@@ -537,7 +567,7 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 // changed after that point (bit 0: a shard failed its checksum and was replaced, bit 1: a data shard was rebuilt).
 int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs,
 		 bool want_block_sums, std::vector<uint8_t> &block_sums, const std::function<void()> &overlap,
-		 std::vector<uint8_t> *changed)
+		 std::vector<uint8_t> *changed, const FanoutGate *gate)
 {
 	const int k = mg->k, n = mg->n;
 	const size_t nb = hs.size();
@@ -610,8 +640,12 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 			} catch (const std::bad_alloc &) {
 				return fail(GBM_E_IO, "out of (pinned) host memory");
 			}
-			int rc = gec_decode_verify_batch(mg->codec, ids.size(), sp.data(), S, lens.data(), op.data(), ssums.data(),
-							 want_block_sums ? bsums.data() : nullptr);
+			int rc;
+			{
+				DeviceTurn turn(gate);
+				rc = gec_decode_verify_batch(mg->codec, ids.size(), sp.data(), S, lens.data(), op.data(), ssums.data(),
+							     want_block_sums ? bsums.data() : nullptr);
+			}
 			tr.lap("decode+verify");
 			if (helper.joinable())
 				helper.join();  // the overlapped host work reads g: it must be done before the results below change it
@@ -691,7 +725,7 @@ void assemble(const Gathered &g, int k, uint8_t *dst)
 
 // raw == true: rpc_get_raw_block (stored bytes + header); false: rpc_get_block (plain bytes).
 int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
-		    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers)
+		    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate)
 {
 	if (!mg || (nb && (!hashes || !out || !cap || !len_out || !rcs)))
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
@@ -729,7 +763,7 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 		});
 	};
 	Trace tr("get (whole call)");
-	int frc = fetch_blocks(mg, hs, tags, g, rcs, verify && !cpu_hash, block_sums, assemble_early, &changed);
+	int frc = fetch_blocks(mg, hs, tags, g, rcs, verify && !cpu_hash, block_sums, assemble_early, &changed, gate);
 	if (frc)
 		return frc;
 	tr.lap("fetch");
@@ -842,6 +876,60 @@ int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const 
 	// (tools/bm_sweep.sh: 128 x 2 threads 33, 128 x 3 37, 64 x 4 38.6, 64 x 8 39.5).  Tagged batches keep their order.
 	const size_t kSlice = env().put_slice;
 	const int kThreads = env().put_threads;
+	if (mg && mg->is_front() && nb && hashes && data && len) {
+		// several devices: every block goes to the lane gec_device_of_hash names
+		auto sub_put = [&](gbm_manager *lane, const std::vector<size_t> &ids) {
+			const size_t cnt = ids.size();
+			if (!cnt)
+				return (int)GBM_OK;
+			std::vector<uint8_t> hh(cnt * 32), pc(cnt, 0);
+			std::vector<const uint8_t *> dd(cnt);
+			std::vector<size_t> ll(cnt);
+			std::vector<gbm_order_tag> tt(order_tags ? cnt : 0);
+			for (size_t i = 0; i < cnt; ++i) {
+				const size_t b = ids[i];
+				std::memcpy(hh.data() + 32 * i, hashes + 32 * b, 32);
+				dd[i] = data[b];
+				ll[i] = len[b];
+				if (prevent_compression)
+					pc[i] = prevent_compression[b];
+				if (order_tags)
+					tt[i] = order_tags[b];
+			}
+			return gbm_rpc_put_blocks(lane, cnt, hh.data(), dd.data(), ll.data(), pc.data(), order_tags ? tt.data() : nullptr);
+		};
+		try {
+			if (!order_tags) {
+				const auto ids = split_by_lane(mg, nb, hashes);
+				return for_lanes(mg, [&](gbm_manager *lane, size_t l) { return sub_put(lane, ids[l]); });
+			}
+			// Tagged blocks must reach every node in (stream, order) order whichever device encodes them: the batch is
+			// walked in that order and cut into runs of consecutive blocks of one device, one put per run.  (The
+			// coalescing queue, gbm_batcher_*, keeps both the order and the devices busy; this form is the simple one.)
+			std::vector<size_t> order(nb);
+			for (size_t i = 0; i < nb; ++i)
+				order[i] = i;
+			std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+				return std::tie(order_tags[x].stream_id, order_tags[x].order) < std::tie(order_tags[y].stream_id, order_tags[y].order);
+			});
+			int result = GBM_OK;
+			std::string err;
+			for (size_t i = 0; i < nb;) {
+				gbm_manager *lane = mg->route(hashes + 32 * order[i]);
+				std::vector<size_t> run;
+				for (; i < nb && mg->route(hashes + 32 * order[i]) == lane; ++i)
+					run.push_back(order[i]);
+				int rc = sub_put(lane, run);
+				if (rc) {
+					result = rc;
+					err = last_error();
+				}
+			}
+			return result ? fail(result, err) : GBM_OK;
+		} catch (const std::exception &e) {
+			return fail(GBM_E_IO, std::string("rpc_put_blocks: ") + e.what());
+		}
+	}
 	try {
 		if (!mg || order_tags || nb < 2 * kSlice)
 			return put_blocks_impl(mg, nb, hashes, data, len, prevent_compression, order_tags, nullptr);
@@ -888,6 +976,8 @@ int gbm_rpc_put_block(gbm_manager *m, const uint8_t hash[32], const uint8_t *dat
 {
 	const uint8_t *d[1] = {data};
 	const uint8_t pc = prevent_compression ? 1 : 0;
+	if (m && hash)
+		m = m->route(hash);  // one block: straight to its device's lane
 	return gbm_rpc_put_blocks(m, 1, hash, d, &len, &pc, order_tag);
 }
 
@@ -895,6 +985,35 @@ int gbm_rpc_get_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const 
 		       const size_t *cap, size_t *len_out, int *rcs)
 {
 	try {
+		if (mg && mg->is_front() && nb && hashes && out && cap && len_out && rcs) {
+			// several devices: every block is read, checked and decoded on the device that owns its hash
+			const auto ids = split_by_lane(mg, nb, hashes);
+			return for_lanes(mg, [&](gbm_manager *lane, size_t l) {
+				const size_t cnt = ids[l].size();
+				if (!cnt)
+					return (int)GBM_OK;
+				std::vector<uint8_t> hh(cnt * 32);
+				std::vector<uint8_t *> oo(cnt);
+				std::vector<size_t> cc(cnt), ll(cnt, 0);
+				std::vector<int> rr(cnt, GBM_E_MISSING_BLOCK);
+				std::vector<gbm_order_tag> tt(order_tags ? cnt : 0);
+				for (size_t i = 0; i < cnt; ++i) {
+					const size_t b = ids[l][i];
+					std::memcpy(hh.data() + 32 * i, hashes + 32 * b, 32);
+					oo[i] = out[b];
+					cc[i] = cap[b];
+					if (order_tags)
+						tt[i] = order_tags[b];
+				}
+				int rc = get_blocks_impl(lane, cnt, hh.data(), order_tags ? tt.data() : nullptr, oo.data(), cc.data(), ll.data(),
+							 rr.data(), false, nullptr);
+				for (size_t i = 0; i < cnt; ++i) {
+					len_out[ids[l][i]] = ll[i];
+					rcs[ids[l][i]] = rc ? rc : rr[i];
+				}
+				return rc;
+			});
+		}
 		return get_blocks_impl(mg, nb, hashes, order_tags, out, cap, len_out, rcs, false, nullptr);
 	} catch (const std::exception &e) {
 		return fail(GBM_E_IO, std::string("rpc_get_blocks: ") + e.what());
@@ -908,6 +1027,8 @@ int gbm_rpc_get_block(gbm_manager *m, const uint8_t hash[32], const gbm_order_ta
 		return fail(GBM_E_INVALID_ARG, "NULL len_out");
 	uint8_t *o[1] = {out};
 	int rc1 = GBM_OK;
+	if (m && hash)
+		m = m->route(hash);
 	int rc = gbm_rpc_get_blocks(m, 1, hash, order_tag, o, &cap, len_out, &rc1);
 	return rc ? rc : one_block_rc(rc1);
 }
@@ -920,6 +1041,8 @@ int gbm_rpc_get_raw_block(gbm_manager *m, const uint8_t hash[32], const gbm_orde
 	uint8_t *o[1] = {out};
 	int rc1 = GBM_OK;
 	int rc;
+	if (m && hash)
+		m = m->route(hash);
 	try {
 		rc = get_blocks_impl(m, 1, hash, order_tag, o, &cap, len_out, &rc1, true, header_out);
 	} catch (const std::exception &e) {
@@ -979,6 +1102,7 @@ static int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order
 {
 	if (!m || !hash || !sink)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	m = m->route(hash);
 	// the shards have to be complete before any byte can be trusted (checksums, decode), so the block is gathered
 	// first and then handed out in order
 	std::vector<uint8_t> buf;

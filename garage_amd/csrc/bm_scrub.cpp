@@ -17,7 +17,9 @@ void gbmimpl::list_all_nodes(gbm_manager *mg, std::set<Hash> &all)
 			mg->nodes[i]->list(per[i]);
 	});
 	for (auto &s : per)
-		all.insert(s.begin(), s.end());
+		for (const Hash &h : s)
+			if (mg->owns(h))  // a lane of a multi-device manager walks the hashes of its own device only
+				all.insert(h);
 }
 
 extern "C" {
@@ -26,6 +28,21 @@ int gbm_scrub(gbm_manager *mg, size_t nb, const uint8_t *hashes, uint8_t *bad_ou
 {
 	if (!mg || (nb && (!hashes || !bad_out)))
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	if (mg->is_front()) {
+		const auto ids = split_by_lane(mg, nb, hashes);
+		return for_lanes(mg, [&](gbm_manager *lane, size_t l) {
+			const size_t cnt = ids[l].size();
+			if (!cnt)
+				return (int)GBM_OK;
+			std::vector<uint8_t> hh(cnt * 32), bad(cnt);
+			for (size_t i = 0; i < cnt; ++i)
+				std::memcpy(hh.data() + 32 * i, hashes + 32 * ids[l][i], 32);
+			int rc = gbm_scrub(lane, cnt, hh.data(), bad.data());
+			for (size_t i = 0; i < cnt; ++i)
+				bad_out[ids[l][i]] = bad[i];
+			return rc;
+		});
+	}
 	try {
 		std::vector<Hash> hs(nb);
 		for (size_t b = 0; b < nb; ++b)
@@ -63,6 +80,16 @@ int gbm_repair_all(gbm_manager *mg, size_t *queued)
 {
 	if (!mg)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	if (mg->is_front()) {
+		std::vector<size_t> q(mg->lanes.size(), 0);
+		int rc = for_lanes(mg, [&](gbm_manager *lane, size_t l) { return gbm_repair_all(lane, &q[l]); });
+		if (queued) {
+			*queued = 0;
+			for (size_t v : q)
+				*queued += v;
+		}
+		return rc;
+	}
 	std::set<Hash> all;
 	for (auto &st : mg->rc) {
 		std::lock_guard<std::mutex> g(st.mu);
@@ -132,6 +159,20 @@ int gbm_scrub_all(gbm_manager *mg, size_t batch_blocks, uint64_t stats[4])
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
 	if (batch_blocks == 0)
 		batch_blocks = 1024;
+	if (mg->is_front()) {
+		// one ScrubWorker per device, side by side: each walks the hashes its device owns on its own BACKGROUND codec
+		std::vector<std::array<uint64_t, 4>> per(mg->lanes.size());
+		int rc = for_lanes(mg, [&](gbm_manager *lane, size_t l) { return gbm_scrub_all(lane, batch_blocks, per[l].data()); });
+		if (stats)
+			for (int j = 0; j < 4; ++j) {
+				stats[j] = 0;
+				for (auto &p : per)
+					stats[j] += p[j];
+			}
+		if (rc == GBM_OK)
+			mg->scrub_last_complete_ms = mg->lanes[0]->now();
+		return rc;
+	}
 	uint64_t st[4] = {0, 0, 0, 0};
 	try {
 		std::set<Hash> all;
@@ -258,6 +299,8 @@ int gbm_scrub_state(const gbm_manager *m, uint64_t out[2])
 	if (!m || !out)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
 	out[0] = m->scrub_corruptions.load();
+	for (auto &l : m->lanes)
+		out[0] += l->scrub_corruptions.load();
 	out[1] = m->scrub_last_complete_ms.load();
 	return GBM_OK;
 }

@@ -283,6 +283,8 @@ uint32_t gec_version(void) { return GEC_VERSION; }
 
 int gec_device_count(void) { return hip_device_count(); }
 
+int gec_device_of_hash(const uint8_t hash[32], int ndev) { return hash && ndev >= 1 ? hash[4] % ndev : -1; }
+
 const char *gec_strerror(int code)
 {
 	switch (code) {

@@ -23,11 +23,25 @@ def block_hash(data: bytes) -> bytes:
 
 
 def gpu_of_hash(hashes, n_gpus: int):
-    """hashes: (N, 32) uint8 array or a single 32-byte hash -> GPU index."""
+    """hashes: (N, 32) uint8 array or a single 32-byte hash -> GPU index.
+
+    The rule itself lives in the C ABI (`gec_device_of_hash`, include/garage_ec.h): this function
+    only calls it, so that libgarage_block's multi-device manager, bench.py and the Python side
+    cannot drift apart."""
+    from ._lib import lib
+
+    if n_gpus < 1:
+        raise ValueError("n_gpus must be >= 1")
     if isinstance(hashes, (bytes, bytearray)):
-        return hashes[4] % n_gpus
-    h = np.asarray(hashes, dtype=np.uint8)
-    return (h[..., 4].astype(np.int64)) % n_gpus
+        if len(hashes) != 32:
+            raise ValueError("a block hash is 32 bytes")
+        return lib.gec_device_of_hash(bytes(hashes), n_gpus)
+    h = np.ascontiguousarray(hashes, dtype=np.uint8)
+    if h.shape[-1] != 32:
+        raise ValueError("a block hash is 32 bytes")
+    flat = h.reshape(-1, 32)
+    out = np.fromiter((lib.gec_device_of_hash(row.tobytes(), n_gpus) for row in flat), dtype=np.int64, count=len(flat))
+    return out.reshape(h.shape[:-1])
 
 
 def partition(hashes, n_gpus: int) -> list[np.ndarray]:

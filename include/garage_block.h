@@ -103,6 +103,32 @@ int gbm_create(const gec_codec *codec, int nnodes, const char *const *node_dirs,
 	       int write_quorum, gbm_manager **out);
 void gbm_destroy(gbm_manager *m);
 
+/* ------------------------------------------------- several devices on one node */
+/* "Blocks from a batched PutObject stream are hash-partitioned across the GPUs of one node": ONE manager over `ndev`
+ * codecs (one per device; all the same RS(k,m); borrowed).  Device d gets a complete lane of its own -- foreground
+ * codec, BACKGROUND-class sibling for scrub / resync, pinned-buffer pool, host thread pool, refcount stripes, per-hash
+ * mutation locks, resync queue and worker -- and every call is routed by gec_device_of_hash(hash, ndev) (byte 4 of the
+ * hash; Garage places by hash bytes the same way: partition_of, src/rpc/layout/version.rs:101-104; drives,
+ * src/block/layout.rs:278-284; mutation locks, src/block/manager.rs:679-689).  A hash belongs to one device, so no
+ * lock is shared between devices on the request path; the storage nodes (and the cluster layout) are common.
+ *   - single-block calls (rpc_put_block, rpc_get_block*, incref / decref, resync_block ...) go straight to the lane;
+ *   - batch calls (rpc_put_blocks, rpc_get_blocks, scrub) are cut by device and the parts run side by side, one
+ *     device trip each; a put batch that carries order tags goes in (stream, order) order, one run of blocks per
+ *     device at a time (use the batcher for tagged streams);
+ *   - gbm_scrub_all / gbm_repair_all / gbm_resync_run / the resync workers: one per device, side by side, each over
+ *     the hashes its device owns;
+ *   - settings apply to every lane; counters are sums (gbm_device_metrics has each device's own);
+ *   - gbm_batcher_create on such a manager makes one coalescing queue (workers, RAM budget / ndev) per device.
+ * Any backend mix works (a node that lost one GPU can run that lane on a GEC_BACKEND_CPU codec). */
+int gbm_create_multi(const gec_codec *const *codecs, int ndev, int nnodes, const char *const *node_dirs,
+		     int write_quorum, gbm_manager **out);
+int gbm_device_count(const gbm_manager *m);                             /* 1 for a gbm_create manager */
+int gbm_device_of_hash(const gbm_manager *m, const uint8_t hash[32]);   /* the lane that serves this hash */
+const gec_codec *gbm_device_codec(const gbm_manager *m, int dev);       /* lane `dev`'s request-path codec (borrowed) */
+const gec_codec *gbm_device_background_codec(const gbm_manager *m, int dev);
+/* gbm_metrics of one device's lane */
+int gbm_device_metrics(const gbm_manager *m, int dev, uint64_t out[6]);
+
 /* Config.compression_level (src/util/config.rs:52-58): enabled=0 is "none";
  * Garage's default is level 1.  Blocks are compressed (one zstd frame, content
  * checksum on) before they are cut into shards; on any encoder error the block
@@ -197,8 +223,12 @@ int gbm_rpc_get_raw_block_streaming(gbm_manager *m, const uint8_t hash[32], cons
  * thread-safe and blocks its caller (like `rpc_put_block(..).await`) until the batch that contains
  * the block has been encoded and fanned out; a worker thread turns everything queued within
  * max_wait_us (or max_blocks) into ONE device call, GBM_BATCHER_WORKERS (default 2) such batches in flight at a
- * time.  Batches that carry order tags hand their shards to the nodes in the order the batches were formed, so
- * blocks of one OrderTag stream reach every node in `order` order even when they land in different batches.
+ * time: a worker that finds the others idle takes only its share of a long queue (GBM_BATCHER_SPLIT_MIN), and one
+ * batch at a time is on the link (GBM_BATCHER_DEVICE_TURN), so that one batch's host stages overlap the other's
+ * device trip instead of all callers moving in lock step.  Batches that carry order tags hand their shards to the
+ * nodes in the order the batches were formed, so blocks of one OrderTag stream reach every node in `order` order
+ * even when they land in different batches -- and, on a multi-device manager (one queue per device), on different
+ * devices: tagged blocks are numbered when they are submitted and each goes out behind its stream's previous one.
  * Returns that block's own result (GBM_OK / GBM_E_QUORUM / a device error). */
 typedef struct gbm_batcher gbm_batcher;
 int gbm_batcher_create(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, gbm_batcher **out);
@@ -228,6 +258,9 @@ int gbm_batcher_stats(gbm_batcher *b, uint64_t out[3]);
 int gbm_batcher_get_block(gbm_batcher *b, const uint8_t hash[32], uint8_t *out, size_t cap, size_t *len_out);
 /* out = { get batches issued, blocks fetched, largest batch } */
 int gbm_batcher_get_stats(gbm_batcher *b, uint64_t out[3]);
+/* The same two triples for ONE device's queue of a multi-device manager's batcher (either may be NULL);
+ * gbm_batcher_stats / gbm_batcher_get_stats are then the sums (largest batch: the maximum). */
+int gbm_batcher_device_stats(gbm_batcher *b, int dev, uint64_t put_out[3], uint64_t get_out[3]);
 
 /* ------------------------------------------------------------- refcounts */
 /* block_incref: RcEntry::increment; when the count was zero a presence check is queued

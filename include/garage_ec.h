@@ -75,6 +75,14 @@ enum {
 uint32_t gec_version(void);
 /* Number of usable HIP devices (0 => only GEC_BACKEND_CPU codecs can be created). */
 int gec_device_count(void);
+/* Which of a node's `ndev` devices owns a block: hash[4] % ndev on Garage's 32-byte block hash (blake2sum,
+ * src/util/data.rs:130-138).  Garage already places by hash bits at three levels -- cluster partition = bytes 0-1
+ * (partition_of, src/rpc/layout/version.rs:101-104), drive = bytes 2-3 (src/block/layout.rs:278-284), mutation
+ * lock = bytes 0-1 (src/block/manager.rs:679-689) -- so byte 4 makes the device independent of node, drive and
+ * lock stripe.  Blocks are independent units: no data-path collective.  The ONE definition of the rule:
+ * libgarage_block's multi-device manager (gbm_create_multi), garage_amd/partition.py and bench.py all call it.
+ * ndev < 1 or a NULL hash: -1. */
+int gec_device_of_hash(const uint8_t hash[32], int ndev);
 /* Every GEC_* environment switch: "NAME<tab>default<tab>meaning" lines (static storage). */
 const char *gec_env_table(void);
 /* The kernel a GEC_BACKEND_CPU codec runs on this host: "avx512+gfni", "avx2" or "scalar" (static storage). */

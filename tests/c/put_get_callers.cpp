@@ -17,7 +17,11 @@
 //
 // Two builds (tests/c/Makefile): `put_get_callers_tsan` links the host-only product sources (CPU backend) under
 // ThreadSanitizer; `put_get_callers` links the real libraries -- GEC_BACKEND_AUTO picks the GPU on a GPU box.
-// usage: put_get_callers [requests] [blocks_per_object] [block_bytes] [readers]
+// With [devices] > 1 the manager is a multi-device one (gbm_create_multi: one codec, one coalescing queue and one set of
+// workers per device, blocks routed by gec_device_of_hash; on a one-GPU box every codec sits on device 0): the same
+// assertions, plus per-device block counts that follow the hash exactly -- and the order guarantee now has to hold for
+// streams whose blocks are encoded on DIFFERENT devices.
+// usage: put_get_callers [requests] [blocks_per_object] [block_bytes] [readers] [devices]
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -140,11 +144,18 @@ int main(int argc, char **argv)
 	const int per_object = argc > 2 ? atoi(argv[2]) : 9;
 	const size_t block_bytes = argc > 3 ? (size_t)atol(argv[3]) : 65536;
 	const int readers = argc > 4 ? atoi(argv[4]) : 3;
+	const int ndev = argc > 5 ? atoi(argv[5]) : 1;
 
-	gec_codec *codec = nullptr;
-	CHECK(gec_codec_create(K, M, GEC_BACKEND_AUTO, 0, &codec) == GEC_OK);
+	std::vector<gec_codec *> codecs((size_t)ndev, nullptr);
+	for (auto &c : codecs)
+		CHECK(gec_codec_create(K, M, GEC_BACKEND_AUTO, 0, &c) == GEC_OK);
+	gec_codec *codec = codecs[0];
 	gbm_manager *mg = nullptr;
-	CHECK(gbm_create(codec, NNODES, nullptr, 0, &mg) == GBM_OK);
+	if (ndev > 1)
+		CHECK(gbm_create_multi(codecs.data(), ndev, NNODES, nullptr, 0, &mg) == GBM_OK);
+	else
+		CHECK(gbm_create(codec, NNODES, nullptr, 0, &mg) == GBM_OK);
+	CHECK(gbm_device_count(mg) == ndev);
 	gbm_batcher *bt = nullptr;
 	CHECK(gbm_batcher_create(mg, 64, 300, &bt) == GBM_OK);
 
@@ -196,6 +207,27 @@ int main(int argc, char **argv)
 	CHECK(gst[1] == (uint64_t)readers * 3 * per_object && gst[0] <= gst[1]);
 	if (readers >= 3)  // six prefetch slots re-submit together whenever a batch completes
 		CHECK(gst[2] >= 2);
+	{  // every device's queue took exactly the blocks gec_device_of_hash gives it
+		std::vector<uint64_t> want_put((size_t)ndev, 0), want_get((size_t)ndev, 0);
+		for (const Object &o : old_objs)
+			for (size_t i = 0; i < o.blocks.size(); ++i) {
+				const int d = gec_device_of_hash(&o.hashes[i * 32], ndev);
+				CHECK(d == gbm_device_of_hash(mg, &o.hashes[i * 32]));
+				want_put[(size_t)d] += 1;
+				want_get[(size_t)d] += 3;
+			}
+		for (const Object &o : new_objs)
+			for (size_t i = 0; i < o.blocks.size(); ++i)
+				want_put[(size_t)gec_device_of_hash(&o.hashes[i * 32], ndev)] += 1;
+		uint64_t sum_put = 0;
+		for (int d = 0; d < ndev; ++d) {
+			uint64_t p[3], g[3], met[6];
+			CHECK(gbm_batcher_device_stats(bt, d, p, g) == GBM_OK && gbm_device_metrics(mg, d, met) == GBM_OK);
+			CHECK(p[1] == want_put[(size_t)d] && g[1] == want_get[(size_t)d] && met[4] == want_put[(size_t)d]);
+			sum_put += p[1];
+		}
+		CHECK(sum_put == st1[1]);
+	}
 	{  // the read side reports a missing block and a short buffer like gbm_rpc_get_block does
 		uint8_t nohash[32], small[8];
 		std::memset(nohash, 0x5A, sizeof nohash);
@@ -213,7 +245,7 @@ int main(int argc, char **argv)
 	// ---- RAM permits: a budget of two blocks -- the queue can never hold more than two blocks, so no batch can
 	gbm_batcher_destroy(bt);
 	CHECK(gbm_batcher_create(mg, 64, 300, &bt) == GBM_OK);
-	CHECK(gbm_batcher_set_ram_buffer_max(bt, 2 * block_bytes) == GBM_OK);
+	CHECK(gbm_batcher_set_ram_buffer_max(bt, 2 * block_bytes * (size_t)ndev) == GBM_OK);  // (the budget is shared out per device)
 	std::vector<Object> tight;
 	for (int r = 0; r < 4; ++r)
 		tight.push_back(make_object(2000 + r, 4, block_bytes, /*short_last=*/false));
@@ -233,14 +265,15 @@ int main(int argc, char **argv)
 		CHECK(gbm_node_order_violations(mg, nd) == 0);
 
 	const double mib = (double)blocks * (double)block_bytes / (1 << 20);
-	printf("put_get_callers: backend %s, %d PutObjects x %d blocks of %zu bytes (<=%d in flight each) beside %d GetObjects (prefetch %d): "
+	printf("put_get_callers: backend %s, %d device(s), %d PutObjects x %d blocks of %zu bytes (<=%d in flight each) beside %d GetObjects (prefetch %d): "
 	       "%llu blocks in %llu device batches (largest %llu), mean put %.3f ms, %.2f GiB/s put; %llu blocks read in %llu batches (largest %llu); "
 	       "0 order violations; all bytes round-trip: OK\n",
-	       gec_codec_backend(codec) == GEC_BACKEND_CPU ? "cpu" : "hip", requests, per_object, block_bytes, PUT_BLOCKS_MAX_PARALLEL, readers,
+	       gec_codec_backend(codec) == GEC_BACKEND_CPU ? "cpu" : "hip", ndev, requests, per_object, block_bytes, PUT_BLOCKS_MAX_PARALLEL, readers,
 	       GET_PREFETCH, (unsigned long long)blocks, (unsigned long long)batches, (unsigned long long)st1[2],
 	       mean_put_ms, mib / 1024.0 / secs, (unsigned long long)gst[1], (unsigned long long)gst[0], (unsigned long long)gst[2]);
 	gbm_batcher_destroy(bt);
 	gbm_destroy(mg);
-	gec_codec_destroy(codec);
+	for (gec_codec *c : codecs)
+		gec_codec_destroy(c);
 	return 0;
 }

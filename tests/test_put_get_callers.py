@@ -4,7 +4,9 @@ OrderTag per block (/root/reference/src/api/s3/put.rs:42,486-511), beside GetObj
 (src/api/s3/get.rs:429), through gbm_batcher_submit / gbm_batcher_wait and gbm_rpc_get_block.  The harness asserts
 coalescing (gbm_batcher_stats), zero gbm_node_order_violations, RAM-permit back-pressure and that every byte round-trips;
 here it runs (1) under ThreadSanitizer over the product's CPU backend, (2) against the real libraries on the CPU
-backend, (3) on the GPU with 1 MiB blocks."""
+backend, (3) on the GPU with 1 MiB blocks -- and each of the three again over a MULTI-DEVICE manager (gbm_create_multi:
+four CPU-backend codecs as four logical devices; two HIP codecs on device 0): one queue per device, per-device block counts
+that follow gec_device_of_hash exactly, streams whose blocks cross devices still in order."""
 import os
 import re
 import subprocess
@@ -22,9 +24,9 @@ def _make(target):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
-def _check(out: str, backend: str):
+def _check(out: str, backend: str, ndev: int = 1):
     assert "all bytes round-trip: OK" in out and "0 order violations" in out, out
-    assert f"backend {backend}" in out, out
+    assert f"backend {backend}, {ndev} device(s)" in out, out
     m = re.search(r"(\d+) blocks in (\d+) device batches \(largest (\d+)\)", out)
     assert m, out
     blocks, batches, largest = map(int, m.groups())
@@ -39,6 +41,25 @@ def test_callers_under_tsan_on_the_cpu_backend():
         pytest.skip("TSan cannot run in this container (ASLR/memory layout)")
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
     _check(r.stdout, "cpu")
+
+
+def test_callers_under_tsan_multi_device_cpu_backend():
+    """a TSan run of the caller pattern over the multi manager -- four logical devices."""
+    _make("put_get_callers_tsan")
+    r = subprocess.run([os.path.join(CDIR, "put_get_callers_tsan"), "8", "9", "65536", "3", "4"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, GEC_CPU_THREADS="2"))
+    if "FATAL: ThreadSanitizer: unexpected memory mapping" in r.stderr:
+        pytest.skip("TSan cannot run in this container (ASLR/memory layout)")
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
+    _check(r.stdout, "cpu", 4)
+
+
+def test_callers_multi_device_real_libraries_cpu_backend():
+    _make("put_get_callers")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="", GEC_CPU_THREADS="2")
+    r = subprocess.run([os.path.join(CDIR, "put_get_callers"), "12", "8", "262144", "3", "4"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _check(r.stdout, "cpu", 4)
 
 
 def test_callers_on_the_real_libraries_cpu_backend():
@@ -56,4 +77,14 @@ def test_callers_on_the_gpu_one_mib_blocks():
     r = subprocess.run([os.path.join(CDIR, "put_get_callers"), "16", "12", "1048576", "4"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     _check(r.stdout, "hip")
+    print(r.stdout)
+
+
+@pytest.mark.gpu
+def test_callers_on_the_gpu_two_codecs_one_device():
+    """The multi-device manager on the one GPU a box has: two HIP codecs (two lanes, two queues) on device 0."""
+    _make("put_get_callers")
+    r = subprocess.run([os.path.join(CDIR, "put_get_callers"), "16", "12", "1048576", "4", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _check(r.stdout, "hip", 2)
     print(r.stdout)
