@@ -32,7 +32,7 @@ SYMBOLS = [
     "gbm_env_table", "gbm_set_tranquility", "gbm_tranquilized_ms", "gbm_background_codec",
     "gbm_batcher_submit", "gbm_batcher_wait", "gbm_set_maintenance_class", "gbm_batcher_get_block", "gbm_batcher_get_stats",
     "gbm_create_multi", "gbm_device_count", "gbm_device_of_hash", "gbm_device_codec", "gbm_device_background_codec",
-    "gbm_device_metrics", "gbm_batcher_device_stats",
+    "gbm_device_metrics", "gbm_batcher_device_stats", "gbm_get_verify_block_hash",
 ]
 
 
@@ -104,6 +104,7 @@ def _load():
         getattr(lib, f).argtypes = [vp, ctypes.c_char_p]
     lib.gbm_block_rc.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
     lib.gbm_set_verify_block_hash.argtypes = [vp, ci]
+    lib.gbm_get_verify_block_hash.argtypes = [vp]
     lib.gbm_set_threads.argtypes = [vp, ci]
     lib.gbm_set_timing.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
     lib.gbm_clock_advance.argtypes = [vp, ctypes.c_uint64]
@@ -370,8 +371,18 @@ class NativeBlockManager:
     def clock_advance(self, ms: int) -> None:
         _check(lib.gbm_clock_advance(self._h, ms), "clock_advance")
 
-    def set_verify_block_hash(self, enabled: bool) -> None:
-        _check(lib.gbm_set_verify_block_hash(self._h, int(enabled)), "set_verify_block_hash")
+    VERIFY_MODES = {"off": 0, "always": 1, "rebuilt": 2, "rebuilt-only": 2}
+
+    def set_verify_block_hash(self, mode) -> None:
+        """The requester's end-to-end block hash: "off" (default, the reference's read path), "rebuilt" (only blocks that
+        went through a decode), "always"; True / False mean "always" / "off".  Shard checksums are checked in every mode."""
+        if isinstance(mode, str):
+            mode = self.VERIFY_MODES[mode]
+        _check(lib.gbm_set_verify_block_hash(self._h, int(mode)), "set_verify_block_hash")
+
+    @property
+    def verify_block_hash(self) -> str:
+        return {0: "off", 1: "always", 2: "rebuilt"}[int(lib.gbm_get_verify_block_hash(self._h))]
 
     def set_threads(self, n: int) -> None:
         _check(lib.gbm_set_threads(self._h, n), "set_threads")

@@ -113,9 +113,65 @@ Zstd::Zstd()
 	GBM_SYM(decompress, "ZSTD_decompress");
 	GBM_SYM(getFrameContentSize, "ZSTD_getFrameContentSize");
 	GBM_SYM(isError, "ZSTD_isError");
+	GBM_SYM(createDStream, "ZSTD_createDStream");  // optional: without them compressed blocks are decoded in one piece
+	GBM_SYM(freeDStream, "ZSTD_freeDStream");
+	GBM_SYM(initDStream, "ZSTD_initDStream");
+	GBM_SYM(decompressStream, "ZSTD_decompressStream");
 #undef GBM_SYM
 	ok = createCCtx && freeCCtx && setParameter && compress2 && compressBound && decompress &&
 	     getFrameContentSize && isError;
+	streaming = ok && createDStream && freeDStream && initDStream && decompressStream;
+}
+
+Zstd::Stream::Stream(const Zstd &zz) : z(&zz)
+{
+	if (z->streaming && (ds = z->createDStream()) != nullptr && z->isError(z->initDStream(ds))) {
+		z->freeDStream(ds);
+		ds = nullptr;
+	}
+}
+Zstd::Stream::~Stream()
+{
+	if (ds)
+		z->freeDStream(ds);
+}
+bool Zstd::Stream::feed(const uint8_t *in, size_t len, const std::function<bool(const uint8_t *, size_t)> &emit)
+{
+	struct Buf {  // ZSTD_inBuffer / ZSTD_outBuffer
+		const void *p;
+		size_t size, pos;
+	};
+	if (!ds)
+		return false;
+	uint8_t out[1 << 16];
+	Buf ib{in, len, 0};
+	while (ib.pos < ib.size) {
+		if (frame_done)
+			return false;  // bytes behind the end of the frame: not a DataBlock
+		Buf ob{out, sizeof out, 0};
+		const size_t r = z->decompressStream(ds, &ob, &ib);
+		if (z->isError(r))
+			return false;
+		if (ob.pos && !emit(out, ob.pos))
+			return false;
+		if (r == 0)
+			frame_done = true;
+	}
+	// flush what the decoder still holds (it may have consumed all input with output pending)
+	while (!frame_done) {
+		Buf ob{out, sizeof out, 0};
+		Buf none{in, 0, 0};
+		const size_t r = z->decompressStream(ds, &ob, &none);
+		if (z->isError(r))
+			return false;
+		if (ob.pos && !emit(out, ob.pos))
+			return false;
+		if (r == 0)
+			frame_done = true;
+		if (ob.pos < sizeof out)
+			break;  // nothing more without more input
+	}
+	return true;
 }
 // false on any error: the caller then stores the block Plain (block.rs:88-93)
 bool Zstd::encode(const uint8_t *data, size_t len, int level, std::vector<uint8_t> &out) const
@@ -206,7 +262,9 @@ int hash_many(gbm_manager *mg, const std::vector<const uint8_t *> &ptrs, const s
 		mg->gpu_hashed += ptrs.size();
 		return GBM_OK;
 	}
-	constexpr size_t kPerTask = 16;  // shards per pool task: their leaves go through the cores' vector lanes eight at a time
+	// shards per pool task: their leaves go through the cores' vector lanes eight at a time -- where there are such
+	// lanes; the one-at-a-time fallback keeps one shard per task, so a small batch still spreads over the pool
+	const size_t kPerTask = b2host::mb_available() ? 16 : 1;
 	mg->pool->parallel_for((ptrs.size() + kPerTask - 1) / kPerTask, [&](size_t g) {
 		const size_t i0 = g * kPerTask, cnt = std::min(kPerTask, ptrs.size() - i0);
 		b2host::shardsum_many(ptrs.data() + i0, lens.data() + i0, cnt, sums.data() + 32 * i0);
@@ -457,13 +515,15 @@ int gbm_set_data_fsync(gbm_manager *m, int enabled)
 	return GBM_OK;
 }
 
-int gbm_set_verify_block_hash(gbm_manager *m, int enabled)
+int gbm_set_verify_block_hash(gbm_manager *m, int mode)
 {
-	if (!m)
-		return fail(GBM_E_INVALID_ARG, "NULL manager");
-	GBM_EACH(m, x, x->verify_block_hash = enabled != 0);
+	if (!m || (mode != GBM_VERIFY_OFF && mode != GBM_VERIFY_ALWAYS && mode != GBM_VERIFY_REBUILT))
+		return fail(GBM_E_INVALID_ARG, "mode must be GBM_VERIFY_OFF, GBM_VERIFY_ALWAYS or GBM_VERIFY_REBUILT");
+	GBM_EACH(m, x, x->verify_mode = mode);
 	return GBM_OK;
 }
+
+int gbm_get_verify_block_hash(const gbm_manager *m) { return m ? m->verify_mode.load() : GBM_E_INVALID_ARG; }
 
 int gbm_set_tranquility(gbm_manager *m, int scrub_tranquility, int resync_tranquility)
 {

@@ -70,6 +70,20 @@ struct Zstd {
 	// verifies the frame checksum; false = corrupt.  `max_out` bounds the allocation.
 	bool decode(const uint8_t *data, size_t len, size_t max_out, std::vector<uint8_t> &out) const;
 	Zstd();
+	// Incremental decoder of ONE frame (ZSTD_decompressStream): a compressed block is decoded shard by shard as its
+	// shards are verified, and its plain bytes leave in chunks -- the reference streams through an async zstd decoder
+	// the same way (src/block/manager.rs:344-363).  `streaming` is false when the library lacks the entry points.
+	bool streaming = false;
+	struct Stream {
+		const Zstd *z;
+		void *ds = nullptr;
+		bool frame_done = false;
+		explicit Stream(const Zstd &zz);
+		~Stream();
+		// feeds `in`; decoded bytes are appended to out (at most out_cap more bytes are accepted: kMaxDecompressed guard).
+		// false = corrupt frame
+		bool feed(const uint8_t *in, size_t len, const std::function<bool(const uint8_t *, size_t)> &emit);
+	};
 
 private:
 	void *(*createCCtx)() = nullptr;
@@ -80,6 +94,10 @@ private:
 	size_t (*decompress)(void *, size_t, const void *, size_t) = nullptr;
 	unsigned long long (*getFrameContentSize)(const void *, size_t) = nullptr;
 	unsigned (*isError)(size_t) = nullptr;
+	void *(*createDStream)() = nullptr;
+	size_t (*freeDStream)(void *) = nullptr;
+	size_t (*initDStream)(void *) = nullptr;
+	size_t (*decompressStream)(void *, void *, void *) = nullptr;
 };
 const Zstd &zstd();
 
@@ -537,7 +555,7 @@ struct gbm_manager {
 	std::atomic<uint64_t> gpu_hashed{0};
 	std::atomic<bool> compress{false};    // Config.compression_level (src/util/config.rs:52-58); Garage's default is Some(1)
 	std::atomic<int> compression_level{1};
-	std::atomic<bool> verify_block_hash{true};
+	std::atomic<int> verify_mode{GBM_VERIFY_OFF};  // the requester's end-to-end block hash (gbm_set_verify_block_hash)
 	std::atomic<size_t> cpu_block_hash_max{96};  // gets of up to this many blocks hash them on the host (gbm_set_threads rescales)
 
 	// hedged reads: 0 = the k requests of a read are issued and awaited in order
@@ -640,6 +658,7 @@ struct Gathered {
 	size_t next = 0;  // next candidate (version-major, shard index minor) to try
 	bool mixed = false;
 	bool settled = false;  // a geometry has been chosen; later candidates must match it
+	bool corrupt_seen = false;  // a shard of this block was there but failed its header / checksum check during this read
 	struct Group {
 		ShardHeader meta;
 		std::vector<Bytes> shard;
@@ -704,9 +723,11 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 		    const FanoutGate *gate = nullptr);
 int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data, const size_t *len,
 		    const uint8_t *prevent_compression, const gbm_order_tag *tags, int *rcs, const FanoutGate *gate = nullptr);
+// want_block_sums: 0 = no, 1 = the blake2sum of every block, 2 = of the blocks of every trip that rebuilds something
+// (block_sums[32*b..] is only meaningful where have_sum[b] is set)
 int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs,
-		 bool want_block_sums, std::vector<uint8_t> &block_sums, const std::function<void()> &overlap = nullptr,
-		 std::vector<uint8_t> *changed = nullptr, const FanoutGate *gate = nullptr);
+		 int want_block_sums, std::vector<uint8_t> &block_sums, const std::function<void()> &overlap = nullptr,
+		 std::vector<uint8_t> *changed = nullptr, const FanoutGate *gate = nullptr, std::vector<uint8_t> *have_sum = nullptr);
 void assemble(const Gathered &g, int k, uint8_t *dst);
 int one_block_rc(int rc1);
 // every hash any reachable node holds a shard of (bm_scrub.cpp)

@@ -54,6 +54,7 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 			mg->metrics[2]++;
 			mg->nodes[node]->mark_corrupted(hs[b], j);
 			mg->put_to_resync(hs[b], 0);
+			g.corrupt_seen = true;
 			return false;
 		}
 		if (g.settled &&
@@ -236,6 +237,7 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 				mg->metrics[2]++;
 				mg->nodes[c.node]->mark_corrupted(hs[c.b], c.j);
 				mg->put_to_resync(hs[c.b], 0);
+				g.corrupt_seen = true;
 				continue;
 			}
 			mg->metrics[1] += c.s.hd.shard_len;
@@ -566,12 +568,17 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 // blocks that need no decode into its output buffers meanwhile; `changed[b]` is set for every block whose shard set
 // changed after that point (bit 0: a shard failed its checksum and was replaced, bit 1: a data shard was rebuilt).
 int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs,
-		 bool want_block_sums, std::vector<uint8_t> &block_sums, const std::function<void()> &overlap,
-		 std::vector<uint8_t> *changed, const FanoutGate *gate)
+		 int want_block_sums, std::vector<uint8_t> &block_sums, const std::function<void()> &overlap,
+		 std::vector<uint8_t> *changed, const FanoutGate *gate, std::vector<uint8_t> *have_sum)
 {
 	const int k = mg->k, n = mg->n;
 	const size_t nb = hs.size();
 	block_sums.assign(want_block_sums ? nb * 32 : 0, 0);
+	if (have_sum)
+		have_sum->assign(nb, 0);
+	// a block that cannot be read: MissingBlock when too few shards exist, CorruptData when shards were there but
+	// failed their checks (Error::CorruptData is what the serving node's read_block_from answers, manager.rs:577-609)
+	auto unreadable = [&](size_t b) { return g[b].corrupt_seen ? GBM_E_CORRUPT_DATA : GBM_E_MISSING_BLOCK; };
 	if (changed)
 		changed->assign(nb, 0);
 	Trace tr("get");
@@ -599,7 +606,7 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 			if (!todo[b])
 				continue;
 			if (!g[b].have_meta || g[b].count < k) {
-				rcs[b] = GBM_E_MISSING_BLOCK;
+				rcs[b] = unreadable(b);
 				todo[b] = 0;
 				continue;
 			}
@@ -620,7 +627,7 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 			std::vector<const uint8_t *> sp(ids.size() * n, nullptr);
 			std::vector<uint8_t *> op(ids.size() * n, nullptr);
 			std::vector<size_t> lens(ids.size());
-			std::vector<uint8_t> ssums(ids.size() * (size_t)n * 32), bsums(want_block_sums ? ids.size() * 32 : 0);
+			std::vector<uint8_t> ssums(ids.size() * (size_t)n * 32), bsums;
 			std::vector<std::vector<Bytes>> fresh(ids.size(), std::vector<Bytes>(k));
 			size_t nrebuild = 0;
 			try {
@@ -640,11 +647,14 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 			} catch (const std::bad_alloc &) {
 				return fail(GBM_E_IO, "out of (pinned) host memory");
 			}
+			const bool trip_sums = want_block_sums == 1 || (want_block_sums == 2 && nrebuild > 0);
+			if (trip_sums)
+				bsums.assign(ids.size() * 32, 0);
 			int rc;
 			{
 				DeviceTurn turn(gate);
 				rc = gec_decode_verify_batch(mg->codec, ids.size(), sp.data(), S, lens.data(), op.data(), ssums.data(),
-							     want_block_sums ? bsums.data() : nullptr);
+							     trip_sums ? bsums.data() : nullptr);
 			}
 			tr.lap("decode+verify");
 			if (helper.joinable())
@@ -652,7 +662,7 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 			tr.lap("join overlapped assembly");
 			if (rc)
 				return ec_fail(rc, "gec_decode_verify_batch");
-			mg->gpu_hashed += ids.size() * (size_t)k + (want_block_sums ? ids.size() : 0);
+			mg->gpu_hashed += ids.size() * (size_t)k + (trip_sums ? ids.size() : 0);
 			for (size_t i = 0; i < ids.size(); ++i) {
 				const size_t b = ids[i];
 				Gathered &gb = g[b];
@@ -670,6 +680,7 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 						mg->put_to_resync(hs[b], 0);
 						gb.shard[j] = Bytes();
 						gb.count--;
+						gb.corrupt_seen = true;
 						bad = true;
 					}
 				}
@@ -691,12 +702,14 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 					if (changed)
 						(*changed)[b] |= 2;  // missing data shards were filled in
 				}
-				if (want_block_sums)
+				if (trip_sums) {
 					std::memcpy(block_sums.data() + 32 * b, bsums.data() + 32 * i, 32);
+					if (have_sum)
+						(*have_sum)[b] = 1;
+				}
 				rcs[b] = GBM_OK;
 				todo[b] = 0;
 			}
-			(void)nrebuild;
 		}
 		if (!any_again)
 			break;
@@ -708,7 +721,7 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 	}
 	for (size_t b = 0; b < nb; ++b)
 		if (todo[b])
-			rcs[b] = GBM_E_MISSING_BLOCK;
+			rcs[b] = unreadable(b);
 	return GBM_OK;
 }
 
@@ -734,8 +747,12 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 	for (size_t b = 0; b < nb; ++b)
 		hs[b].assign((const char *)hashes + 32 * b, 32);
 	std::vector<Gathered> g;
-	std::vector<uint8_t> block_sums, changed, early(nb, 0);
-	const bool verify = mg->verify_block_hash.load();
+	std::vector<uint8_t> block_sums, changed, have_sum, early(nb, 0);
+	// The requester's end-to-end check (gbm_set_verify_block_hash): every Plain block, only the blocks that went through a
+	// decode, or -- the default, the reference's read path -- none: the shard checksums of the same trip are the serving
+	// node's verify (read_block_from, manager.rs:577-609), and they are always checked.
+	const int mode = mg->verify_mode.load();
+	const bool verify = mode != GBM_VERIFY_OFF, only_rebuilt = mode == GBM_VERIFY_REBUILT;
 	// Where the block's own checksum is computed.  It is one serial BLAKE2b chain per block: ~11 ms per MiB on the
 	// device however many blocks run beside it, ~1 ms per MiB on a host core.  Small requests -- a GetObject reads
 	// its blocks a few at a time -- are hashed by the pool from the assembled bytes; big batches on the device,
@@ -763,7 +780,8 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 		});
 	};
 	Trace tr("get (whole call)");
-	int frc = fetch_blocks(mg, hs, tags, g, rcs, verify && !cpu_hash, block_sums, assemble_early, &changed, gate);
+	int frc = fetch_blocks(mg, hs, tags, g, rcs, verify && !cpu_hash ? (only_rebuilt ? 2 : 1) : 0, block_sums, assemble_early, &changed,
+			       gate, &have_sum);
 	if (frc)
 		return frc;
 	tr.lap("fetch");
@@ -784,7 +802,8 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 		// DataBlock::verify (block.rs:69-83): Plain = content against its name -- the block's blake2sum came back
 		// from the same device trip that decoded it (or is computed below, cpu_hash); Compressed = the zstd frame
 		// (with its checksum) decodes
-		if (!z && verify && !cpu_hash && std::memcmp(block_sums.data() + 32 * b, hashes + 32 * b, 32) != 0) {
+		const bool check = verify && !z && (!only_rebuilt || (changed[b] & 2));
+		if (check && !cpu_hash && have_sum[b] && std::memcmp(block_sums.data() + 32 * b, hashes + 32 * b, 32) != 0) {
 			rcs[b] = GBM_E_CORRUPT_DATA;
 			return;
 		}
@@ -816,19 +835,22 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 		} else {
 			assemble(g[b], k, out[b]);
 		}
-		if (!z && cpu_hash) {
+		if (check && (cpu_hash || !have_sum[b])) {
 			hash_here[b] = 1;  // checked below, eight blocks per core at a time
 			return;
 		}
 		mg->metrics[5]++;
 	});
-	if (cpu_hash) {
+	if (verify) {
 		std::vector<size_t> idx;
 		for (size_t b = 0; b < nb; ++b)
 			if (hash_here[b])
 				idx.push_back(b);
-		mg->pool->parallel_for((idx.size() + 7) / 8, [&](size_t grp) {
-			const size_t i0 = grp * 8, cnt = std::min<size_t>(8, idx.size() - i0);
+		// eight blocks per task where a core hashes eight chains at once (AVX-512); one block per task otherwise, so the
+		// scalar fallback keeps one message per pool thread (8 x 1 MiB: 6.7 ms either way instead of 16 ms on one core)
+		const size_t per = b2host::mb_available() ? 8 : 1;
+		mg->pool->parallel_for((idx.size() + per - 1) / per, [&](size_t grp) {
+			const size_t i0 = grp * per, cnt = std::min<size_t>(per, idx.size() - i0);
 			const uint8_t *ptr[8];
 			size_t len[8];
 			uint8_t sums[8 * 32];
@@ -1051,69 +1073,340 @@ int gbm_rpc_get_raw_block(gbm_manager *m, const uint8_t hash[32], const gbm_orde
 	return rc ? rc : one_block_rc(rc1);
 }
 
-static int stream_out(const uint8_t *p, size_t len, size_t chunk_bytes, gbm_chunk_fn sink, void *ctx)
-{
-	const size_t ch = chunk_bytes ? chunk_bytes : 65536;
-	for (size_t off = 0; off < len; off += ch)
-		if (sink(ctx, p + off, std::min(ch, len - off)) != 0)
-			return fail(GBM_E_ABORTED, "the stream's consumer stopped");
-	return GBM_OK;
-}
+// ------------------------------------------------------------------ the streaming gets
+// rpc_get_block_streaming hands the network stream through (manager.rs:344-363).  Here the "stream" is the block's data
+// shards in index order: shard i IS the bytes [i*S, (i+1)*S) of the stored DataBlock, so it can leave as soon as its own
+// checksum has matched.  The k shards in hand are checked side by side on the async pool (a shard of a 1 MiB block:
+// ~35 us on a core); the calling thread walks the shards in order and hands each one to the sink straight out of its
+// buffer the moment its verdict is in; a missing data shard is rebuilt (one small decode on the request path's codec)
+// when the walk reaches it; the end-to-end hash, when its mode asks for it, runs on a thread of its own BEHIND the walk
+// and only decides the final result.
+namespace {
 
-// one block into a buffer this function owns (the streaming forms do not know the size up front)
-static int get_block_owned(gbm_manager *mg, const uint8_t hash[32], const gbm_order_tag *tag, bool raw,
-			   gbm_data_block_header *hdr, std::vector<uint8_t> &out)
-{
-	const int k = mg->k;
-	std::vector<Hash> hs(1, Hash((const char *)hash, 32));
-	std::vector<Gathered> g;
-	std::vector<uint8_t> block_sums;
-	int rc1 = GBM_OK;
-	const bool verify = mg->verify_block_hash.load();
-	int frc = fetch_blocks(mg, hs, tag, g, &rc1, /*want_block_sums=*/false, block_sums);  // one block: hashed on the host, below
-	if (frc)
-		return frc;
-	if (rc1 != GBM_OK)
-		return one_block_rc(rc1);
-	const size_t L = g[0].meta.orig_len;
-	const bool z = g[0].meta.compressed != 0;
-	if (hdr)
-		hdr->kind = z ? GBM_HEADER_COMPRESSED : GBM_HEADER_PLAIN;
-	std::vector<uint8_t> stored(L);
-	assemble(g[0], k, stored.data());
-	if (!z && verify) {
-		uint8_t sum[32];
-		blake2sum(stored.data(), L, sum);
-		if (std::memcmp(sum, hash, 32) != 0)
-			return one_block_rc(GBM_E_CORRUPT_DATA);
-	}
-	if (z && !raw) {
-		if (!zstd().decode(stored.data(), L, kMaxDecompressed, out))
-			return one_block_rc(GBM_E_CORRUPT_DATA);
-	} else {
-		out.swap(stored);
-	}
-	mg->metrics[5]++;
-	return GBM_OK;
-}
+struct StreamChecks {  // shared with the async tasks: they own what they touch
+	std::mutex mu;
+	std::condition_variable cv;
+	std::vector<int> verdict;  // per shard index: 0 = pending, 1 = matches its header's checksum, -1 = does not
+	std::vector<Bytes> shard;
+	std::vector<std::array<uint8_t, 32>> sum;
+	std::atomic<size_t> next{0};  // next entry of the read set to check (claimed in index order)
+};
 
-static int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, gbm_data_block_header *hdr,
-			 size_t chunk_bytes, gbm_chunk_fn sink, void *ctx, bool raw)
+// the block hash behind the stream: segments are pushed in order by the walk, hashed by a thread of its own
+struct TailHash {
+	std::mutex mu;
+	std::condition_variable cv;
+	std::deque<std::pair<Bytes, std::pair<const uint8_t *, size_t>>> q;  // (owner, range)
+	bool closed = false;
+	b2host::State st;
+	std::thread th;
+	void start()
+	{
+		th = std::thread([this] {
+			for (;;) {
+				std::pair<Bytes, std::pair<const uint8_t *, size_t>> seg;
+				{
+					std::unique_lock<std::mutex> g(mu);
+					cv.wait(g, [&] { return closed || !q.empty(); });
+					if (q.empty())
+						return;
+					seg = std::move(q.front());
+					q.pop_front();
+				}
+				st.update(seg.second.first, seg.second.second);
+			}
+		});
+	}
+	void push(const Bytes &owner, const uint8_t *p, size_t n)
+	{
+		{
+			std::lock_guard<std::mutex> g(mu);
+			q.emplace_back(owner, std::make_pair(p, n));
+		}
+		cv.notify_one();
+	}
+	// waits for the hasher; the digest of everything pushed
+	void finish(uint8_t out[32])
+	{
+		{
+			std::lock_guard<std::mutex> g(mu);
+			closed = true;
+		}
+		cv.notify_one();
+		if (th.joinable())
+			th.join();
+		uint8_t full[64];
+		st.final(full);
+		std::memcpy(out, full, 32);
+	}
+	~TailHash()
+	{
+		{
+			std::lock_guard<std::mutex> g(mu);
+			closed = true;
+			q.clear();
+		}
+		cv.notify_one();
+		if (th.joinable())
+			th.join();
+	}
+};
+
+int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, gbm_data_block_header *hdr,
+		  size_t chunk_bytes, gbm_chunk_fn sink, void *ctx, bool raw)
 {
 	if (!m || !hash || !sink)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
 	m = m->route(hash);
-	// the shards have to be complete before any byte can be trusted (checksums, decode), so the block is gathered
-	// first and then handed out in order
-	std::vector<uint8_t> buf;
-	gbm_data_block_header h0{};
-	int rc = get_block_owned(m, hash, order_tag, raw, &h0, buf);
-	if (rc)
-		return rc;
+	const int k = m->k, n = m->n;
+	const size_t ch = chunk_bytes ? chunk_bytes : 65536;
+	std::vector<Hash> hs(1, Hash((const char *)hash, 32));
+	std::vector<Gathered> g;
+	Trace tr("streaming get");
+	int grc = gather_many(m, hs, order_tag, k, g, /*verify=*/false);
+	if (grc)
+		return grc;
+	tr.lap("gather");
+	if (!g[0].have_meta || g[0].count < k)
+		return one_block_rc(g[0].corrupt_seen ? GBM_E_CORRUPT_DATA : GBM_E_MISSING_BLOCK);
+	if (g[0].meta.orig_len > (uint64_t)k * g[0].meta.shard_len)
+		return one_block_rc(GBM_E_CORRUPT_DATA);
+	const size_t L = g[0].meta.orig_len, S = g[0].meta.shard_len;
+	const bool z = g[0].meta.compressed != 0;
 	if (hdr)
-		*hdr = h0;
-	return stream_out(buf.data(), buf.size(), chunk_bytes, sink, ctx);
+		hdr->kind = z ? GBM_HEADER_COMPRESSED : GBM_HEADER_PLAIN;  // reported before the first byte
+	const int mode = m->verify_mode.load();
+
+	// ---- the k shards the block is read from (the first k in hand, in index order): checked side by side
+	auto ck = std::make_shared<StreamChecks>();
+	ck->verdict.assign(n, 0);
+	ck->shard = g[0].shard;
+	ck->sum = g[0].sum;
+	std::vector<int> used;
+	bool need_decode = false;
+	for (int j = 0; j < n && (int)used.size() < k; ++j)
+		if (!g[0].shard[j].empty())
+			used.push_back(j);
+	for (int j = 0; j < k; ++j)
+		need_decode = need_decode || g[0].shard[j].empty();
+	// The checks are claimed in index order -- by a few helpers on the async pool and by the walk itself, which checks
+	// the shard it is waiting for when nobody has started on it: shard 0's verdict takes one shard's time, not the time
+	// ten checks need when they all share the cores at once.
+	auto check_one = [ck, S](int j) {
+		uint8_t sum[32];
+		shardsum(ck->shard[j].data(), S, sum);
+		const int v = std::memcmp(sum, ck->sum[j].data(), 32) == 0 ? 1 : -1;
+		{
+			std::lock_guard<std::mutex> lk(ck->mu);
+			ck->verdict[j] = v;
+		}
+		ck->cv.notify_all();
+	};
+	auto check_next = [ck, used, check_one]() -> bool {  // false: nothing left to claim
+		const size_t i = ck->next.fetch_add(1);
+		if (i >= used.size())
+			return false;
+		check_one(used[i]);
+		return true;
+	};
+	// the first shard of the read set is the walk's own, and it is checked before the helpers are even woken (on a busy
+	// or small host they would take the core): it is what the first byte waits for
+	ck->next = 1;
+	check_one(used[0]);
+	{
+		const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+		const size_t helpers = std::min<size_t>(used.size() > 1 ? used.size() - 1 : 0, std::max(1u, hw - 2));
+		std::shared_ptr<gbm_manager::Async> async = m->async_pool();
+		for (size_t i = 0; i < helpers; ++i)
+			async->submit([check_next] {
+				while (check_next()) {
+				}
+			});
+	}
+	auto wait_verdict = [&](int j) {
+		for (;;) {
+			{
+				std::lock_guard<std::mutex> lk(ck->mu);
+				if (ck->verdict[j] != 0)
+					return ck->verdict[j];
+			}
+			if (!check_next())  // everything is claimed: the verdict is on its way
+				break;
+		}
+		std::unique_lock<std::mutex> lk(ck->mu);
+		ck->cv.wait(lk, [&] { return ck->verdict[j] != 0; });
+		return ck->verdict[j];
+	};
+
+	// ---- where the bytes go: the sink (through the incremental zstd decoder for a Compressed block read as plain
+	// bytes) and, when the mode asks for it, the hash behind the stream
+	const bool want_hash = !z && (mode == GBM_VERIFY_ALWAYS || (mode == GBM_VERIFY_REBUILT && need_decode));
+	TailHash tail;
+	if (want_hash)
+		tail.start();
+	std::unique_ptr<Zstd::Stream> zs;
+	std::vector<uint8_t> zbuf, whole;  // decoder output not yet handed out / the frame, when the library cannot stream
+	size_t plain_len = 0;
+	bool aborted = false;
+	if (z && !raw && zstd().streaming) {
+		zs.reset(new Zstd::Stream(zstd()));
+		zbuf.reserve(ch);
+	}
+	auto to_sink = [&](const uint8_t *p, size_t len) {  // chunks of at most `ch` bytes
+		for (size_t off = 0; off < len && !aborted; off += ch)
+			if (sink(ctx, p + off, std::min(ch, len - off)) != 0)
+				aborted = true;
+		return !aborted;
+	};
+	// `len` stored bytes of the block, in order; `owner` keeps them alive for the hasher.  false: stop (corrupt frame / abort)
+	bool frame_bad = false;
+	auto deliver = [&](const Bytes &owner, const uint8_t *p, size_t len) {
+		if (want_hash)
+			tail.push(owner, p, len);
+		if (!z || raw)
+			return to_sink(p, len);
+		if (!zs) {  // no incremental decoder in this libzstd: the frame is collected and decoded at the end
+			whole.insert(whole.end(), p, p + len);
+			return true;
+		}
+		const bool ok = zs->feed(p, len, [&](const uint8_t *o, size_t on) {
+			plain_len += on;
+			if (plain_len > kMaxDecompressed)
+				return false;
+			while (on) {  // hand out full chunks, keep the rest
+				const size_t take = std::min(on, ch - zbuf.size());
+				zbuf.insert(zbuf.end(), o, o + take);
+				o += take;
+				on -= take;
+				if (zbuf.size() == ch) {
+					if (!to_sink(zbuf.data(), zbuf.size()))
+						return false;
+					zbuf.clear();
+				}
+			}
+			return true;
+		});
+		if (!ok && !aborted)
+			frame_bad = true;
+		return ok;
+	};
+
+	// ---- the walk
+	std::vector<Bytes> rebuilt(k);
+	bool decoded = false;
+	size_t pos = 0;  // stored bytes delivered so far
+	int bad_shard = -1;
+	for (int j = 0; j < k && pos < L && !aborted && !frame_bad; ++j) {
+		const size_t len = std::min(S, L - pos);
+		if (!g[0].shard[j].empty()) {
+			if (wait_verdict(j) < 0) {
+				bad_shard = j;
+				break;
+			}
+			if (j == 0)
+				tr.lap("first shard checked");
+			if (!deliver(g[0].shard[j], g[0].shard[j].data(), len))
+				break;
+			pos += len;
+			continue;
+		}
+		if (!decoded) {
+			// a missing data shard: every shard the decode reads must have matched first
+			for (int u : used)
+				if (wait_verdict(u) < 0) {
+					bad_shard = u;
+					break;
+				}
+			if (bad_shard >= 0)
+				break;
+			std::vector<const uint8_t *> sp(n, nullptr);
+			std::vector<uint8_t *> op(n, nullptr);
+			try {
+				for (int t = 0; t < k; ++t)
+					if (g[0].shard[t].empty()) {
+						rebuilt[t] = m->bufs->get(S);
+						op[t] = rebuilt[t].mut();
+					}
+			} catch (const std::bad_alloc &) {
+				return fail(GBM_E_IO, "out of (pinned) host memory");
+			}
+			for (int u : used)
+				sp[u] = g[0].shard[u].data();
+			int rc = gec_reconstruct_batch(m->codec, 1, sp.data(), op.data(), S, /*data_only=*/1);
+			if (rc)
+				return ec_fail(rc, "gec_reconstruct_batch");
+			m->metrics[3]++;
+			decoded = true;
+		}
+		if (!deliver(rebuilt[j], rebuilt[j].data(), len))
+			break;
+		pos += len;
+	}
+	if (bad_shard >= 0) {
+		// read_block_from's corrupt-file case (manager.rs:577-609), met mid-stream: the shard is set aside and queued, and
+		// the rest of the block comes from the batch path's gather / check / decode rounds (what was already delivered had
+		// matched its checksums and stays delivered)
+		m->metrics[2]++;
+		if (g[0].node[bad_shard] >= 0)
+			m->nodes[g[0].node[bad_shard]]->mark_corrupted(hs[0], bad_shard);
+		m->put_to_resync(hs[0], 0);
+		std::vector<Gathered> g2;
+		std::vector<uint8_t> bsums;
+		int rc1 = GBM_OK;
+		int frc = fetch_blocks(m, hs, order_tag, g2, &rc1, 0, bsums);
+		if (frc)
+			return frc;
+		if (rc1 != GBM_OK)
+			return one_block_rc(rc1 == GBM_E_MISSING_BLOCK ? GBM_E_CORRUPT_DATA : rc1);  // shards were there: they were corrupt
+		if (g2[0].meta.orig_len != L || g2[0].meta.shard_len != S || (g2[0].meta.compressed != 0) != z)
+			return one_block_rc(GBM_E_CORRUPT_DATA);  // another geometry took over mid-stream
+		for (int j = (int)(pos / S); j < k && pos < L && !aborted && !frame_bad; ++j) {
+			const size_t len = std::min(S, L - pos);
+			if (!deliver(g2[0].shard[j], g2[0].shard[j].data(), len))
+				break;
+			pos += len;
+		}
+		if (!z && mode == GBM_VERIFY_REBUILT && !want_hash && !aborted) {
+			// the replacement came out of a decode after all and no hash was running behind the stream: the block is
+			// hashed from the shards now in hand before the stream is declared good
+			b2host::State st;
+			for (int j = 0; j < k && (size_t)j * S < L; ++j)
+				st.update(g2[0].shard[j].data(), std::min(S, L - (size_t)j * S));
+			uint8_t full[64];
+			st.final(full);
+			if (std::memcmp(full, hash, 32) != 0)
+				return one_block_rc(GBM_E_CORRUPT_DATA);
+		}
+	}
+	tr.lap("last shard delivered");
+	if (aborted)
+		return fail(GBM_E_ABORTED, "the stream's consumer stopped");
+	// ---- the tail: what is left in the decoder, then the checks that can only be made once everything has gone by
+	if (z && !raw) {
+		if (!zs) {
+			std::vector<uint8_t> plain;
+			if (frame_bad || !zstd().decode(whole.data(), whole.size(), kMaxDecompressed, plain))
+				return one_block_rc(GBM_E_CORRUPT_DATA);
+			if (!to_sink(plain.data(), plain.size()))
+				return fail(GBM_E_ABORTED, "the stream's consumer stopped");
+		} else {
+			if (frame_bad || !zs->frame_done)  // a frame that does not end, or whose checksum does not match (block.rs:78-83)
+				return one_block_rc(GBM_E_CORRUPT_DATA);
+			if (!zbuf.empty() && !to_sink(zbuf.data(), zbuf.size()))
+				return fail(GBM_E_ABORTED, "the stream's consumer stopped");
+		}
+	}
+	if (want_hash) {
+		uint8_t sum[32];
+		tail.finish(sum);
+		if (std::memcmp(sum, hash, 32) != 0)
+			return one_block_rc(GBM_E_CORRUPT_DATA);
+	}
+	m->metrics[5]++;
+	return GBM_OK;
 }
+
+}  // namespace
 
 int gbm_rpc_get_block_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, size_t chunk_bytes,
 				gbm_chunk_fn sink, void *ctx)

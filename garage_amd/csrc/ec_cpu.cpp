@@ -318,12 +318,14 @@ struct CpuBackend : Backend {
 	};
 	void shardsums(const std::vector<ShardRef> &list, size_t S)
 	{
-		constexpr size_t kShardTask = 16;
+		constexpr size_t kShardTaskMax = 16;
+		// (one shard per task where a core hashes one chain at a time: the scalar fallback keeps the pool busy)
+		const size_t kShardTask = b2host::mb_available() ? kShardTaskMax : 1;
 		pool->parallel_for((list.size() + kShardTask - 1) / kShardTask, [&](size_t g) {
 			const size_t i0 = g * kShardTask, cnt = std::min(kShardTask, list.size() - i0);
-			const uint8_t *ptr[kShardTask];
-			uint8_t *dst[kShardTask];
-			size_t len[kShardTask];
+			const uint8_t *ptr[kShardTaskMax];
+			uint8_t *dst[kShardTaskMax];
+			size_t len[kShardTaskMax];
 			for (size_t i = 0; i < cnt; ++i) {
 				ptr[i] = list[i0 + i].p;
 				dst[i] = list[i0 + i].dst;
@@ -550,8 +552,9 @@ struct CpuBackend : Backend {
 			for (size_t b = 0; b < nblocks; ++b)
 				for (size_t t = 0; t < k; ++t)
 					piece[b * k + t] = shards[b * n + t] ? shards[b * n + t] : rebuilt[b * n + t];
-			pool->parallel_for((nblocks + 7) / 8, [&](size_t g) {
-				const size_t b0 = g * 8, cnt = std::min<size_t>(8, nblocks - b0);
+			const size_t per = b2host::mb_available() ? 8 : 1;
+			pool->parallel_for((nblocks + per - 1) / per, [&](size_t g) {
+				const size_t b0 = g * per, cnt = std::min<size_t>(per, nblocks - b0);
 				b2host::Job jobs[8];
 				for (size_t i = 0; i < cnt; ++i) {
 					jobs[i].pieces = &piece[(b0 + i) * k];
@@ -568,7 +571,8 @@ struct CpuBackend : Backend {
 	int hash_batch(size_t nmsg, const uint8_t *const *msgs, const size_t *lens, uint8_t *out, bool tree) override
 	{
 		// eight chains at a time per core: tasks of 8 (plain) / 16 (tree: the leaves are the chains) messages
-		const size_t per = tree ? 16 : 8;
+		// (one message per task without such lanes: GEC_CPU_BLAKE2=scalar, or a host without AVX-512)
+		const size_t per = !b2host::mb_available() ? 1 : tree ? 16 : 8;
 		pool->parallel_for((nmsg + per - 1) / per, [&](size_t g) {
 			const size_t i0 = g * per, cnt = std::min(per, nmsg - i0);
 			if (tree)

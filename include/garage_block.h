@@ -140,11 +140,21 @@ int gbm_set_compression_level(gbm_manager *m, int enabled, int level);
  * (write_block_inner, src/block/manager.rs:775-800).  No effect on in-memory nodes. */
 int gbm_set_data_fsync(gbm_manager *m, int enabled);
 
-/* After decode, check a Plain block's content against its name (DataBlock::verify,
- * src/block/block.rs:69-77).  On by default.  Every shard's own checksum is always verified --
- * that is what replaces the serving node's verify of read_block_from (:577-609); this switch
- * only controls the additional end-to-end pass over the assembled block. */
-int gbm_set_verify_block_hash(gbm_manager *m, int enabled);
+/* The END-TO-END check of a Plain block's content against its name (DataBlock::verify, src/block/block.rs:69-77) at
+ * the REQUESTER.  The reference does not have one: its only content-vs-name check is on the serving node, where the
+ * bytes come off the disk (read_block_from, src/block/manager.rs:577-609); rpc_get_raw_block_internal (:276-339) hands
+ * what arrives to the caller unchecked.  A node of an erasure-coded cluster holds a shard, so its equivalent of that check
+ * is the shard checksum -- ALWAYS verified here, in every mode, before a byte of the shard is used or delivered.  The
+ * block hash on top of that is a mode:
+ *   GBM_VERIFY_OFF      (default; the reference's read path) no end-to-end pass;
+ *   GBM_VERIFY_REBUILT  only blocks that went through a decode (a missing data shard was rebuilt) are hashed;
+ *   GBM_VERIFY_ALWAYS   every Plain block is hashed (the paranoid setting; round 3's default).
+ * When it is on, the hash runs BEHIND the data: the streaming forms deliver every chunk first and report a mismatch
+ * as the stream's final result (GBM_E_CORRUPT_DATA), the way a zstd frame checksum fails a compressed block's tail
+ * (block.rs:78-83).  Compressed blocks are checked by their frame checksum in every mode. */
+enum { GBM_VERIFY_OFF = 0, GBM_VERIFY_ALWAYS = 1, GBM_VERIFY_REBUILT = 2 };
+int gbm_set_verify_block_hash(gbm_manager *m, int mode);
+int gbm_get_verify_block_hash(const gbm_manager *m);
 /* A block's own checksum is one serial BLAKE2b chain: ~11 ms per MiB on the device however many blocks run beside
  * it, ~1 ms per MiB on a host core.  Gets of up to `nblocks` blocks (default 6 per pool thread = 96) verify it on the
  * host pool from the assembled bytes; larger batches on the device, behind the upload.  0 = always on the device. */
@@ -196,7 +206,9 @@ int gbm_rpc_put_blocks(gbm_manager *m, size_t n, const uint8_t *hashes,
 
 /* ---------------------------------------------------------------- get */
 /* rpc_get_block: gather >= k shards (each checked against its checksum), reconstruct if a data
- * shard is missing, decompress if needed.  *len_out = block length (also on GBM_E_BUFFER_TOO_SMALL). */
+ * shard is missing, decompress if needed.  *len_out = block length (also on GBM_E_BUFFER_TOO_SMALL).
+ * GBM_E_MISSING_BLOCK: fewer than k shards could be found; GBM_E_CORRUPT_DATA: fewer than k GOOD ones -- shards were
+ * there but failed their checksum (each was set aside and queued for resync) -- or the content does not match. */
 int gbm_rpc_get_block(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag,
 		      uint8_t *out, size_t cap, size_t *len_out);
 /* Batched: ONE device reconstruct for all blocks that need it.  out[i] has
@@ -208,8 +220,15 @@ int gbm_rpc_get_raw_block(gbm_manager *m, const uint8_t hash[32], const gbm_orde
 			  gbm_data_block_header *header_out, uint8_t *out, size_t cap, size_t *len_out);
 /* Streaming forms: the block is handed to `sink` in chunks of at most chunk_bytes (0 = 64 KiB), in
  * order; a non-zero return from the sink stops the stream (GBM_E_ABORTED).
- * rpc_get_block_streaming yields the plain bytes (zstd-decoded when the block is stored Compressed),
- * rpc_get_raw_block_streaming yields the stored bytes and reports the header first. */
+ * rpc_get_block_streaming yields the plain bytes (zstd-decoded, incrementally, when the block is stored Compressed),
+ * rpc_get_raw_block_streaming yields the stored bytes and reports the header first.
+ * They STREAM (rpc_get_block_streaming hands the network stream through, src/block/manager.rs:344-363): data shard i
+ * is the block's bytes [i*S, (i+1)*S), so it goes to the sink as soon as ITS checksum has matched -- the k shards are
+ * checked side by side on the manager's threads, the sink reads straight out of the shard buffers -- and a missing
+ * data shard follows as soon as its decode has landed.  Time to first byte is one shard's check, not the block's.
+ * A shard that fails its checksum mid-stream is set aside like anywhere else and the rest of the block comes from
+ * another gather; if nothing can supply it the stream ends with GBM_E_CORRUPT_DATA.  The end-to-end hash, when its
+ * mode asks for it, runs behind the stream and decides the final result (gbm_set_verify_block_hash). */
 typedef int (*gbm_chunk_fn)(void *ctx, const uint8_t *chunk, size_t len);
 int gbm_rpc_get_block_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag,
 				size_t chunk_bytes, gbm_chunk_fn sink, void *ctx);

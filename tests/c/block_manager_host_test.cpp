@@ -121,9 +121,17 @@ static void run(int k, int m, const char *dir_root)
 	CHECK(gbm_scrub(mg, blocks.size(), hashes.data(), bad.data()) == GBM_OK);
 	CHECK(bad[2] == 1 && bad[0] == 0 && bad[1] == 0 && bad[3] == 0);
 
-	// wrong content under a valid name -> CorruptData
+	// wrong content under a valid name: the requester's end-to-end check is a mode.  Off (the default: the reference's
+	// requester does not re-hash, manager.rs:276-339) hands out what the shards hold; "always" answers CorruptData.
 	CHECK(gbm_rpc_put_block(mg, hashes.data(), blocks[1].data(), blocks[1].size(), 0, nullptr) == GBM_OK);
+	CHECK(gbm_get_verify_block_hash(mg) == GBM_VERIFY_OFF);
+	CHECK(gbm_rpc_get_block(mg, hashes.data(), nullptr, out.data(), out.size(), &got) == GBM_OK && got == blocks[1].size());
+	CHECK(gbm_set_verify_block_hash(mg, GBM_VERIFY_REBUILT) == GBM_OK);  // nothing was rebuilt: not hashed either
+	CHECK(gbm_rpc_get_block(mg, hashes.data(), nullptr, out.data(), out.size(), &got) == GBM_OK);
+	CHECK(gbm_set_verify_block_hash(mg, GBM_VERIFY_ALWAYS) == GBM_OK);
 	CHECK(gbm_rpc_get_block(mg, hashes.data(), nullptr, out.data(), out.size(), &got) == GBM_E_CORRUPT_DATA);
+	CHECK(gbm_set_verify_block_hash(mg, 7) == GBM_E_INVALID_ARG);
+	CHECK(gbm_set_verify_block_hash(mg, GBM_VERIFY_OFF) == GBM_OK);
 
 	// compression (zstd frame + checksum), if libzstd is there
 	if (gbm_set_compression_level(mg, 1, 1) == GBM_OK) {
@@ -297,6 +305,123 @@ static int sink_fn(void *ctx, const uint8_t *chunk, size_t len)
 	s->got.insert(s->got.end(), chunk, chunk + len);
 	s->max_chunk = std::max(s->max_chunk, len);
 	return ++s->calls == s->stop_after ? 1 : 0;
+}
+
+// Round 4: the streaming gets stream, and the end-to-end hash is a mode.
+//   - chunks arrive in order, at most chunk_bytes each, straight out of the shard buffers;
+//   - a missing data shard is rebuilt on the way (the stream still completes, byte for byte);
+//   - a shard that fails its checksum MID-stream is set aside and the rest of the block comes from other shards;
+//   - with too few good shards left the answer is CorruptData, in every mode and through every form of get;
+//   - wrong content under a valid name: only the hash modes can tell, and the streaming form tells it at the TAIL --
+//     every chunk has been delivered by then, the way a zstd frame checksum fails at the end (block.rs:78-83).
+static void run_streaming(int k, int m)
+{
+	gec_codec *codec = stub_codec_create(k, m);
+	const int n = k + m, nnodes = n + 2;
+	gbm_manager *mg = nullptr;
+	CHECK(gbm_create(codec, nnodes, nullptr, 0, &mg) == GBM_OK);
+	CHECK(gbm_set_threads(mg, 4) == GBM_OK);
+	gbm_batcher *bt = nullptr;
+	CHECK(gbm_batcher_create(mg, 16, 200, &bt) == GBM_OK);
+	std::vector<uint8_t> out(1 << 21);
+	size_t got = 0;
+	const int modes[3] = {GBM_VERIFY_OFF, GBM_VERIFY_REBUILT, GBM_VERIFY_ALWAYS};
+	for (int mode : modes) {
+		CHECK(gbm_set_verify_block_hash(mg, mode) == GBM_OK && gbm_get_verify_block_hash(mg) == mode);
+		std::vector<uint8_t> d = pattern(900001 + 4096 * mode, 40 + mode);
+		uint8_t h[32];
+		gbm_blake2sum(d.data(), d.size(), h);
+		std::vector<int> who(n);
+		CHECK(gbm_storage_nodes_of(mg, h, who.data()) == GBM_OK);
+		CHECK(gbm_rpc_put_block(mg, h, d.data(), d.size(), 0, nullptr) == GBM_OK);
+		CHECK(gbm_block_incref(mg, h) == GBM_OK);
+		{  // healthy
+			Sink s;
+			CHECK(gbm_rpc_get_block_streaming(mg, h, nullptr, 30000, sink_fn, &s) == GBM_OK);
+			CHECK(s.got == d && s.max_chunk <= 30000 && s.calls >= (d.size() + 29999) / 30000);
+		}
+		{  // a data shard is missing: rebuilt on the way
+			CHECK(gbm_node_delete_shard(mg, who[1], h, 1) == GBM_OK);
+			Sink s;
+			gbm_data_block_header dh;
+			CHECK(gbm_rpc_get_raw_block_streaming(mg, h, nullptr, &dh, 0, sink_fn, &s) == GBM_OK);
+			CHECK(dh.kind == GBM_HEADER_PLAIN && s.got == d);
+		}
+		if (m >= 2) {  // a shard fails its checksum mid-stream (shard 1 is still missing: two shards to make up for)
+			uint64_t met0[6], met1[6];
+			CHECK(gbm_metrics(mg, met0) == GBM_OK);
+			CHECK(gbm_node_corrupt_shard(mg, who[k - 1], h, k - 1, 99, 0x21, /*fix_checksum=*/0) == GBM_OK);
+			Sink s;
+			CHECK(gbm_rpc_get_block_streaming(mg, h, nullptr, 50000, sink_fn, &s) == GBM_OK);
+			CHECK(s.got == d);
+			CHECK(gbm_metrics(mg, met1) == GBM_OK && met1[2] == met0[2] + 1);
+			CHECK(!gbm_node_has_shard(mg, who[k - 1], h, k - 1));  // set aside
+		}
+		int changed = 0;
+		CHECK(gbm_put_to_resync(mg, h, 0) == GBM_OK);
+		CHECK(gbm_resync_all(mg, &changed) == GBM_OK && changed >= (m >= 2 ? 2 : 1));  // (>=: the previous mode's block is repaired too)
+		for (int j = 0; j < n; ++j)
+			CHECK(gbm_node_has_shard(mg, who[j], h, j));
+		{  // too few GOOD shards: m nodes down and one more shard corrupt -> CorruptData, through every form of get
+			for (int j = 0; j < m; ++j)
+				CHECK(gbm_node_set_down(mg, who[n - 1 - j], 1) == GBM_OK);
+			CHECK(gbm_node_corrupt_shard(mg, who[0], h, 0, 5, 0x80, 0) == GBM_OK);
+			Sink s;
+			CHECK(gbm_rpc_get_block_streaming(mg, h, nullptr, 0, sink_fn, &s) == GBM_E_CORRUPT_DATA);
+			// (the shard was set aside; a put that cannot reach its quorum still writes it back where the nodes are up)
+			CHECK(gbm_rpc_put_block(mg, h, d.data(), d.size(), 0, nullptr) == GBM_E_QUORUM);
+			CHECK(gbm_node_corrupt_shard(mg, who[0], h, 0, 5, 0x80, 0) == GBM_OK);
+			CHECK(gbm_rpc_get_block(mg, h, nullptr, out.data(), out.size(), &got) == GBM_E_CORRUPT_DATA);
+			CHECK(gbm_rpc_put_block(mg, h, d.data(), d.size(), 0, nullptr) == GBM_E_QUORUM);
+			CHECK(gbm_node_corrupt_shard(mg, who[0], h, 0, 5, 0x80, 0) == GBM_OK);
+			CHECK(gbm_batcher_get_block(bt, h, out.data(), out.size(), &got) == GBM_E_CORRUPT_DATA);
+			for (int j = 0; j < m; ++j)
+				CHECK(gbm_node_set_down(mg, who[n - 1 - j], 0) == GBM_OK);
+			CHECK(gbm_rpc_put_block(mg, h, d.data(), d.size(), 0, nullptr) == GBM_OK);
+			CHECK(gbm_rpc_get_block(mg, h, nullptr, out.data(), out.size(), &got) == GBM_OK && got == d.size());
+			CHECK(std::memcmp(out.data(), d.data(), got) == 0);
+		}
+		{  // wrong content under a valid name (every shard checksum is right: only the block hash can tell)
+			std::vector<uint8_t> evil = pattern(d.size(), 1000 + mode);
+			CHECK(gbm_rpc_put_block(mg, h, evil.data(), evil.size(), 0, nullptr) == GBM_OK);
+			Sink s;
+			const int rc = gbm_rpc_get_block_streaming(mg, h, nullptr, 0, sink_fn, &s);
+			CHECK(rc == (mode == GBM_VERIFY_ALWAYS ? GBM_E_CORRUPT_DATA : GBM_OK));
+			CHECK(s.got == evil);  // the hash runs BEHIND the stream: everything was delivered, the tail carries the verdict
+			CHECK(gbm_batcher_get_block(bt, h, out.data(), out.size(), &got) == (mode == GBM_VERIFY_ALWAYS ? GBM_E_CORRUPT_DATA : GBM_OK));
+			// ... and with a data shard gone the block goes through a decode: "rebuilt-only" hashes it too
+			CHECK(gbm_node_delete_shard(mg, who[0], h, 0) == GBM_OK);
+			Sink s2;
+			const int rc2 = gbm_rpc_get_block_streaming(mg, h, nullptr, 0, sink_fn, &s2);
+			CHECK(rc2 == (mode == GBM_VERIFY_OFF ? GBM_OK : GBM_E_CORRUPT_DATA) && s2.got == evil);
+			CHECK(gbm_rpc_get_block(mg, h, nullptr, out.data(), out.size(), &got) == (mode == GBM_VERIFY_OFF ? GBM_OK : GBM_E_CORRUPT_DATA));
+		}
+	}
+	// a Compressed block read as plain bytes: decoded incrementally, shard by shard; a damaged frame fails the tail
+	if (gbm_set_compression_level(mg, 1, 1) == GBM_OK) {
+		CHECK(gbm_set_verify_block_hash(mg, GBM_VERIFY_OFF) == GBM_OK);
+		std::vector<uint8_t> d = pattern(1500000, 321);
+		uint8_t h[32];
+		gbm_blake2sum(d.data(), d.size(), h);
+		std::vector<int> who(n);
+		CHECK(gbm_storage_nodes_of(mg, h, who.data()) == GBM_OK);
+		CHECK(gbm_rpc_put_block(mg, h, d.data(), d.size(), 0, nullptr) == GBM_OK);
+		Sink s;
+		CHECK(gbm_rpc_get_block_streaming(mg, h, nullptr, 8192, sink_fn, &s) == GBM_OK);
+		CHECK(s.got == d && s.max_chunk == 8192);
+		CHECK(gbm_node_delete_shard(mg, who[0], h, 0) == GBM_OK);
+		Sink s2;
+		CHECK(gbm_rpc_get_block_streaming(mg, h, nullptr, 0, sink_fn, &s2) == GBM_OK && s2.got == d);
+		// silent damage inside the frame (checksum re-stamped): the zstd frame checksum is this block's verify
+		CHECK(gbm_node_corrupt_shard(mg, who[1], h, 1, 40, 0x04, /*fix_checksum=*/1) == GBM_OK);
+		Sink s3;
+		CHECK(gbm_rpc_get_block_streaming(mg, h, nullptr, 0, sink_fn, &s3) == GBM_E_CORRUPT_DATA);
+		gbm_set_compression_level(mg, 0, 0);
+	}
+	gbm_batcher_destroy(bt);
+	gbm_destroy(mg);
+	gec_codec_destroy(codec);
+	printf("streaming gets + verify modes RS(%d,%d): OK\n", k, m);
 }
 
 // Round-2 scenarios: the reference's put/get surface (prevent_compression, order_tag, raw / streaming gets),
@@ -695,6 +820,8 @@ int main(int argc, char **argv)
 	run_hedged(10, 4);
 	run_round2(3, 1);
 	run_round2(10, 4);
+	run_streaming(3, 1);
+	run_streaming(10, 4);
 	run(3, 1, nullptr);
 	run(10, 4, nullptr);
 	if (argc > 1) {

@@ -148,9 +148,12 @@ def test_native_corruption_resync_scrub(codec, tmp_path):
     # silent corruption with a re-stamped checksum: only the RS verify finds it
     mgr.node_corrupt_shard(who[codec.k], h, codec.k, 77, 1, fix_checksum=True)
     assert mgr.scrub(hashes) == [h]
-    # wrong content under a valid name -> CorruptData
+    # wrong content under a valid name: the default mode (the reference's requester does not re-hash,
+    # manager.rs:276-339) hands it out; the "always" mode answers CorruptData
     evil = pattern_block(200_000, 99)
     mgr.rpc_put_block(hashes[0], evil)
+    assert mgr.verify_block_hash == "off" and mgr.rpc_get_block(hashes[0]) == evil
+    mgr.set_verify_block_hash("always")
     with pytest.raises(bn.CorruptData):
         mgr.rpc_get_block(hashes[0])          # (small request: the block hash is checked on the host pool)
     mgr.set_host_block_hash_max(0)            # ... and on the device, in the decode's trip
@@ -591,3 +594,167 @@ def test_batcher_read_side_coalesces_concurrent_gets(backend):
     assert e.value.code == bn.GBM_E_BUFFER_TOO_SMALL
     bt.close()
     mgr.close()
+
+
+# ----------------------------------------------------------------- round 4: the gets stream; the block hash is a mode
+def _timed_stream(mgr, h, chunk_bytes=65536, raw=False):
+    """(chunks, arrival time of each chunk in seconds since the call) of a streaming get."""
+    import time
+
+    chunks, times = [], []
+    t0 = [0.0]
+
+    def sink(_ctx, p, n):
+        times.append(time.perf_counter() - t0[0])
+        chunks.append(ctypes.string_at(p, n))
+        return 0
+
+    cb = bn.CHUNK_FN(sink)
+    t0[0] = time.perf_counter()
+    if raw:
+        hdr = bn.DataBlockHeader()
+        rc = bn.lib.gbm_rpc_get_raw_block_streaming(mgr._h, h, None, ctypes.byref(hdr), chunk_bytes, cb, None)
+    else:
+        rc = bn.lib.gbm_rpc_get_block_streaming(mgr._h, h, None, chunk_bytes, cb, None)
+    return rc, chunks, times
+
+
+def _cores_really_available() -> float:
+    """How many threads this process can actually run at once (a container may show 8 CPUs and grant one)."""
+    import threading
+    import time
+
+    d = bytes(8 << 20)
+
+    def work():
+        hashlib.blake2b(d).digest()
+
+    def run(n):
+        ts = [threading.Thread(target=work) for _ in range(n)]
+        t = time.perf_counter()
+        [x.start() for x in ts]
+        [x.join() for x in ts]
+        return time.perf_counter() - t
+
+    run(1)
+    one, four = min(run(1) for _ in range(3)), min(run(4) for _ in range(3))
+    return 4 * one / four
+
+
+def test_streaming_get_first_chunk_long_before_the_last(backend):
+    """rpc_get_block_streaming hands the stream through (manager.rs:344-363): data shard 0 leaves as soon as ITS
+    checksum has matched.  A 4 MiB block, RS(10,4): the first chunk must be out in < 40 % of the time the last one
+    takes, in every mode -- the hash, when it is on, runs behind the stream."""
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    mgr = bn.NativeBlockManager(codec, 16)
+    data = bytes(np.random.default_rng(8).integers(0, 256, 4 << 20, dtype=np.uint8))
+    h = bn.blake2sum(data)
+    mgr.rpc_put_block(h, data)
+    S = g.shard_len(10, len(data))
+    # the checks of shards 1..9 run on helper threads BESIDE the walk: on a host that grants this process less than two
+    # cores' worth they take the walk's core instead, and the ratio says nothing (bytes and order are still asserted)
+    parallel = backend == "hip" or _cores_really_available() >= 2.0
+    for mode in ("off", "rebuilt", "always"):
+        mgr.set_verify_block_hash(mode)
+        best = None
+        for _ in range(5):      # (the first call also starts the manager's async pool)
+            rc, chunks, times = _timed_stream(mgr, h)
+            assert rc == 0 and b"".join(chunks) == data
+            assert max(len(c) for c in chunks) <= 65536 and len(chunks[0]) == 65536
+            if best is None or times[0] / times[-1] < best[0] / best[-1]:
+                best = times
+        if parallel:
+            assert best[0] < 0.40 * best[-1], (mode, best[0], best[-1])
+            # the first shard's chunks are out before the stream is half through
+            first_shard_chunks = -(-S // 65536)
+            assert best[first_shard_chunks - 1] < 0.5 * best[-1]
+    # degraded (data shard 3 gone): shards 0..2 still leave at once, the rebuilt one follows, bytes identical
+    who = mgr.storage_nodes_of(h)
+    mgr.node_delete_shard(who[3], h, 3)
+    for mode in ("off", "rebuilt", "always"):
+        mgr.set_verify_block_hash(mode)
+        rc, chunks, times = _timed_stream(mgr, h)
+        assert rc == 0 and b"".join(chunks) == data
+    assert mgr.metrics["ec_reconstructs"] == 3
+
+
+def test_verify_modes_and_corrupt_shards_in_every_mode(backend):
+    """Shard checksums are verified in every mode (they are the serving node's check, manager.rs:577-609): a corrupt
+    shard is detected, set aside and made up for from the others, and when too few good shards are left the answer is
+    CorruptData -- off / rebuilt / always alike, through rpc_get_block, the streaming form and the batcher.  The
+    end-to-end block hash only differs for content that is wrong under intact checksums."""
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    mgr = bn.NativeBlockManager(codec, 16)
+    bat = bn.Batcher(mgr, 8, 100)
+    k, m = 10, 4
+    for i, mode in enumerate(("off", "rebuilt", "always")):
+        mgr.set_verify_block_hash(mode)
+        assert mgr.verify_block_hash == mode
+        data = pattern_block(700_000 + 4096 * i, 31 + i)
+        h = bn.blake2sum(data)
+        mgr.rpc_put_block(h, data)
+        who = mgr.storage_nodes_of(h)
+        # one corrupt shard: detected, replaced by a decode, the caller sees the right bytes
+        c0 = mgr.metrics["corruption_counter"]
+        mgr.node_corrupt_shard(who[2], h, 2, 1000, 0x08)
+        assert mgr.rpc_get_block(h) == data
+        assert mgr.metrics["corruption_counter"] == c0 + 1 and not mgr.node_has_shard(who[2], h, 2)
+        mgr.node_corrupt_shard(who[5], h, 5, 7, 0x01)
+        assert b"".join(mgr.rpc_get_block_streaming(h)) == data       # found mid-stream
+        mgr.node_corrupt_shard(who[7], h, 7, 70, 0x10)
+        assert bat.get_block(h, len(data)) == data
+        assert mgr.metrics["corruption_counter"] == c0 + 3
+        # three shards are gone now; one more node down and another corrupt shard: k - 1 good ones -> CorruptData
+        mgr.node_set_down(who[k], True)
+        for getter in (lambda: mgr.rpc_get_block(h), lambda: mgr.rpc_get_block_streaming(h), lambda: bat.get_block(h, len(data))):
+            mgr.rpc_put_block(h, data) if False else None
+            mgr.node_set_down(who[k], False)
+            mgr.rpc_put_block(h, data)                                 # all 14 shards back
+            for j in (2, 5, 7):
+                mgr.node_delete_shard(who[j], h, j)
+            mgr.node_set_down(who[k], True)
+            mgr.node_corrupt_shard(who[0], h, 0, 3, 0x40)
+            with pytest.raises(bn.CorruptData):
+                getter()
+        mgr.node_set_down(who[k], False)
+        mgr.rpc_put_block(h, data)
+        # wrong content under a valid name, every shard checksum intact
+        evil = pattern_block(len(data), 900 + i)
+        mgr.rpc_put_block(h, evil)
+        if mode == "always":
+            with pytest.raises(bn.CorruptData):
+                mgr.rpc_get_block(h)
+            rc, chunks, _ = _timed_stream(mgr, h)
+            assert rc == bn.GBM_E_CORRUPT_DATA and b"".join(chunks) == evil   # delivered first, failed at the tail
+        else:
+            assert mgr.rpc_get_block(h) == evil
+            rc, chunks, _ = _timed_stream(mgr, h)
+            assert rc == 0 and b"".join(chunks) == evil
+        mgr.node_delete_shard(who[1], h, 1)        # now the block goes through a decode
+        if mode == "off":
+            assert mgr.rpc_get_block(h) == evil
+        else:
+            with pytest.raises(bn.CorruptData):
+                mgr.rpc_get_block(h)
+            rc, chunks, _ = _timed_stream(mgr, h)
+            assert rc == bn.GBM_E_CORRUPT_DATA and b"".join(chunks) == evil
+    bat.close()
+
+
+def test_streaming_compressed_block_is_decoded_incrementally(backend):
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    mgr = bn.NativeBlockManager(codec, 14, compression_level=1)
+    data = pattern_block(3 << 20, 5)                       # compressible
+    h = bn.blake2sum(data)
+    mgr.rpc_put_block(h, data)
+    hdr, stored = mgr.rpc_get_raw_block(h)
+    assert hdr.is_compressed() and len(stored) < len(data)
+    rc, chunks, _ = _timed_stream(mgr, h, chunk_bytes=100_000)
+    assert rc == 0 and b"".join(chunks) == data and all(len(c) == 100_000 for c in chunks[:-1])
+    rc, chunks, _ = _timed_stream(mgr, h, raw=True)
+    assert rc == 0 and b"".join(chunks) == stored
+    # silent damage inside the frame: the frame checksum fails the stream's tail (block.rs:78-83)
+    who = mgr.storage_nodes_of(h)
+    mgr.node_corrupt_shard(who[0], h, 0, 64, 0x02, fix_checksum=True)
+    rc, chunks, _ = _timed_stream(mgr, h)
+    assert rc == bn.GBM_E_CORRUPT_DATA
