@@ -24,6 +24,9 @@ struct Env {
 	unsigned home_rate_gbps; // GEC_HOME_RATE_GBPS
 	int resident_grid;      // GEC_RESIDENT_GRID
 	int verify_segments;    // GEC_VERIFY_SEGMENTS (0 = the built-in maximum)
+	int fused_small;        // GEC_FUSED_SMALL
+	size_t fused_max_leaves;  // GEC_FUSED_MAX_LEAVES
+	unsigned bg_home_rate_gbps;  // GEC_BG_HOME_RATE_GBPS
 	size_t pinned_chunk_mb; // GEC_PINNED_CHUNK_MB
 	bool hash_fork;         // GEC_HASH_FORK
 	// ---- HIP backend: background class

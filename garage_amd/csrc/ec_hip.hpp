@@ -173,6 +173,9 @@ struct HipBackend : Backend {
 	};
 	mutable std::mutex leaf_mu;
 	mutable std::map<hipStream_t, LeafScratch> leaf_scratch;
+	// per-block "tiles finished" counters of the fused small-trip kernel (fused.hpp), one array per stream like the leaf
+	// scratch: zeroed when allocated, left all zero by every launch
+	mutable std::map<hipStream_t, LeafScratch> done_counters;
 
 	// One copy pool per codec = per device: a process that drives several GPUs (one codec each)
 	// must not funnel all their staging copies through one set of threads.  Created on the
@@ -377,6 +380,18 @@ int reconstruct_dev(const gec_codec *c, size_t nblocks, uint8_t *d_base, size_t 
 int encode_hash_dev(const gec_codec *c, size_t nblocks, uint8_t *d_stripes, size_t stride, size_t S, uint8_t *d_sums, hipStream_t stream,
 		    Staging &aux);
 int leaf_scratch(const gec_codec *c, hipStream_t stream, size_t bytes, uint8_t **out);
+int done_counters(const gec_codec *c, hipStream_t stream, size_t nblocks, uint32_t **out);
+
+// ONE launch for a small trip (fused.hpp): out[b][r] = XOR_t coef_set(pat[b])[r][t] * in[b][t] over pointer tables, AND the
+// tree-mode checksum of every input shard (hash_rows: and of every output row) of every block.
+//   in / valid [nblocks][k], out [nblocks][nout] (entries may be NULL: row not wanted), coef_sets [npat][nout][k],
+//   pat [nblocks] (NULL: every block uses set 0), sums [nblocks][k + (hash_rows ? nout : 0)][32]: device-addressable
+//   (the slot's pinned area).  nout may be 0 (checksums only).  Returns GEC_E_INVALID_ARG with "fused: ..." when the
+//   shape does not fit (caller falls back to the streaming paths): see fused_fits.
+bool fused_fits(const gec_codec *c, size_t nblocks, size_t S, int nout, bool hash_rows);
+int launch_fused(const gec_codec *c, Staging &st, size_t nblocks, const uint8_t *const *in, const uint32_t *valid, uint8_t *const *out,
+		 int nout, size_t S, const uint8_t *coef_sets, size_t npat, const uint16_t *pat, bool hash_rows, uint8_t *sums,
+		 hipStream_t stream);
 
 // contiguous stripe: shard j at j*S
 inline std::vector<size_t> stripe_offsets(const gec_codec *c, size_t S)

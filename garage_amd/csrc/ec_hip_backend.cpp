@@ -54,6 +54,28 @@ int leaf_scratch(const gec_codec *c, hipStream_t stream, size_t bytes, uint8_t *
 	return GEC_OK;
 }
 
+int done_counters(const gec_codec *c, hipStream_t stream, size_t nblocks, uint32_t **out)
+{
+	HipBackend &hb = hip_of(c);
+	std::lock_guard<std::mutex> g(hb.leaf_mu);
+	HipBackend::LeafScratch &ls = hb.done_counters[stream];
+	const size_t bytes = nblocks * sizeof(uint32_t);
+	if (bytes > ls.cap) {
+		if (ls.p) {
+			HIP_TRY(hipStreamSynchronize(stream));
+			(void)hipFree(ls.p);
+			ls.p = nullptr;
+			ls.cap = 0;
+		}
+		const size_t want = std::max<size_t>(2 * bytes, 4096);
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ls.p), want));
+		HIP_TRY(hipMemset(ls.p, 0, want));
+		ls.cap = want;
+	}
+	*out = reinterpret_cast<uint32_t *>(ls.p);
+	return GEC_OK;
+}
+
 int reconstruct_dev(const gec_codec *c, size_t nblocks, uint8_t *d_base, size_t stride, const size_t *shard_off,
 		    const uint8_t *present, bool data_only, size_t byte_off, size_t byte_len, hipStream_t stream)
 {
@@ -143,6 +165,9 @@ HipBackend::~HipBackend()
 	for (auto &s : pool)
 		s.release();
 	for (auto &kv : leaf_scratch)
+		if (kv.second.p)
+			(void)hipFree(kv.second.p);
+	for (auto &kv : done_counters)
 		if (kv.second.p)
 			(void)hipFree(kv.second.p);
 	if (d_logexp)

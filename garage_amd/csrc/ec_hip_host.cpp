@@ -39,6 +39,39 @@ int HipBackend::encode_batch(size_t nblocks, const uint8_t *const *blocks, const
 			return fail(GEC_E_DEVICE, "hipSetDevice failed");
 		StagingLease lease(c);
 		Staging &st = lease.st;
+		if (shard_sums && fused_fits(c, nblocks, S, (int)m, true)) {
+			// a PutObject's few blocks: parity AND all k + m checksums from ONE launch (fused.hpp) -- the workgroup that
+			// has a tile of the stripe in hand hashes its 14 leaves out of LDS, the block's last workgroup the roots; the
+			// checksums land in the slot's pinned area straight from the kernel
+			int rc = st.ensure(nblocks * n * 32 + 64, 0);
+			if (!rc)
+				rc = st.ensure_tab((nblocks * (k * 12 + m * 8) + k * gec::RMAX + 64) / sizeof(gec::CopyEntry) + 8);
+			if (!rc)
+				rc = st.ensure_segments(num_cu);
+			if (rc)
+				return rc;
+			std::vector<const uint8_t *> in(nblocks * k);
+			std::vector<uint32_t> valid(nblocks * k);
+			std::vector<uint8_t *> out(nblocks * m);
+			for (size_t i = 0; i < nblocks; ++i) {
+				const uint8_t *p = pinned().dev(blocks[i]);
+				uint8_t *q = pinned().dev(parity[i]);
+				for (size_t t = 0; t < k; ++t) {
+					in[i * k + t] = p + t * S;
+					valid[i * k + t] = (uint32_t)(block_len[i] > t * S ? std::min(S, block_len[i] - t * S) : 0);
+				}
+				for (size_t r = 0; r < m; ++r)
+					out[i * m + r] = q + r * S;
+			}
+			hipStream_t s1 = st.stream_chain ? st.stream_chain : st.stream;
+			rc = launch_fused(c, st, nblocks, in.data(), valid.data(), out.data(), (int)m, S, c->enc.row(k), 1, nullptr, true, st.h_buf, s1);
+			const hipError_t e1 = hipStreamSynchronize(s1);
+			if (rc)
+				return rc;
+			HIP_TRY(e1);
+			std::memcpy(shard_sums, st.h_buf, nblocks * n * 32);
+			return GEC_OK;
+		}
 		const size_t zch = shard_sums || c->qos_class == GEC_CLASS_BACKGROUND ? chunk_blocks(stripe, nblocks, trip_chunk_bytes(c)) : nblocks;
 		const size_t nz = (nblocks + zch - 1) / zch;
 		int rc = st.ensure(shard_sums ? nblocks * n * 32 + 64 : 64, 0);
@@ -491,6 +524,64 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 				all_pinned = aligned16(shards[b * n + j]) && pinned().contains(shards[b * n + j], S);
 	StagingLease lease(c);
 	Staging &st = lease.st;
+	// A GetObject's few blocks, every buffer pinned, no end-to-end hash asked for: ONE launch (fused.hpp) reads the k shards
+	// of every block out of the caller's memory, returns every shard's checksum, and writes the missing data shards -- each
+	// block with the coefficient set of its own erasure pattern -- straight into the buffers they are wanted in.  Nothing
+	// is staged in HBM, nothing is copied home, however many patterns the batch has.
+	if (all_pinned && !block_sums && buckets.size() <= 0xffff) {
+		size_t max_miss = 0;
+		bool out_pinned = true;
+		for (auto &kv : buckets) {
+			max_miss = std::max(max_miss, kv.second.npar);
+			for (size_t b : kv.second.ids)
+				for (int j : kv.second.plan->missing)
+					out_pinned = out_pinned && aligned16(rebuilt[b * n + j]) && pinned().contains(rebuilt[b * n + j], S);
+		}
+		if (out_pinned && max_miss <= (size_t)gec::RMAX && fused_fits(c, nblocks, S, (int)max_miss, false)) {
+			int frc = st.ensure(nblocks * k * 32 + 64, 0);
+			if (!frc)
+				frc = st.ensure_tab((nblocks * (k * 12 + max_miss * 8 + 2) + buckets.size() * k * gec::RMAX + 64) / sizeof(gec::CopyEntry) + 8);
+			if (!frc)
+				frc = st.ensure_segments(num_cu);
+			if (frc)
+				return frc;
+			std::vector<const uint8_t *> in(nblocks * k);
+			std::vector<uint32_t> valid(nblocks * k, (uint32_t)S);
+			std::vector<uint8_t *> out(nblocks * max_miss, nullptr);
+			std::vector<uint16_t> pat(nblocks);
+			std::vector<uint8_t> sets(buckets.size() * max_miss * k, 0);
+			size_t pi = 0, i = 0;  // blocks go bucket by bucket: a workgroup rebuilds its tables only when the pattern changes
+			for (auto &kv : buckets) {
+				Bucket &bk = kv.second;
+				for (size_t r = 0; r < bk.npar; ++r)
+					std::memcpy(&sets[(pi * max_miss + r) * k], bk.plan->rows.v.data() + r * k, k);
+				for (size_t b : bk.ids) {
+					pat[i] = (uint16_t)pi;
+					for (size_t t = 0; t < k; ++t)
+						in[i * k + t] = pinned().dev(shards[b * n + bk.plan->valid[t]]);
+					for (size_t r = 0; r < bk.npar; ++r)
+						out[i * max_miss + r] = pinned().dev(rebuilt[b * n + bk.plan->missing[r]]);
+					++i;
+				}
+				++pi;
+			}
+			hipStream_t s1 = st.stream_chain ? st.stream_chain : st.stream;
+			frc = launch_fused(c, st, nblocks, in.data(), valid.data(), out.data(), (int)max_miss, S, sets.data(), buckets.size(), pat.data(),
+					   false, st.h_buf, s1);
+			const hipError_t e1 = hipStreamSynchronize(s1);
+			if (frc)
+				return frc;
+			HIP_TRY(e1);
+			i = 0;
+			for (auto &kv : buckets)
+				for (size_t b : kv.second.ids) {
+					for (size_t t = 0; t < k; ++t)
+						std::memcpy(shard_sums + 32 * (b * n + kv.second.plan->valid[t]), st.h_buf + 32 * (i * k + t), 32);
+					++i;
+				}
+			return GEC_OK;
+		}
+	}
 	constexpr size_t kPiece = 32ull << 20;
 	// host staging: [piece A][piece B] (pageable shards only) [shard off | shard len | block off | block len][shard sums][block sums][rebuilt]
 	const size_t tab_off = all_pinned ? 0 : 2 * kPiece;

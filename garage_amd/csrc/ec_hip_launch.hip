@@ -4,9 +4,13 @@
 #include "ec_hip.hpp"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <set>
 
 #include "kernels.hpp"
 #include "blake2b.hpp"
+#include "fused.hpp"
 
 namespace gecimpl {
 
@@ -302,6 +306,8 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 		// few leaves (a PutObject's blocks, a GetObject's): four lanes per leaf, like the plain hash below
 		const int forced_leaf = env().blake2_kernel;
 		const bool quad_tree = forced_leaf ? forced_leaf == 2 : lanes < 40000;
+		if (quad_tree && (lanes + 15) / 16 > 0x7fffffffull)  // (the quad kernel indexes its messages in 32 bits)
+			return fail(GEC_E_INVALID_ARG, "too many leaves for one call of the four-lane kernel");
 		if (quad_tree)
 			hipLaunchKernelGGL(gec::blake2b_batch_quad<gec::B2Q_LEAF>, dim3((unsigned)((lanes + 15) / 16)), dim3(64), 0, stream, a, nleaf, scratch);
 		else if (addmode == 0)
@@ -343,7 +349,7 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 // (which queues share a dispatcher is decided when they are created): tools/dispatch_probe, profiles/r03_qos.txt.
 // GEC_RESIDENT_GRID=0: one workgroup per tile (A/B).
 namespace {
-unsigned resident_grid(const Staging &st, hipStream_t stream, uint32_t tiles)
+unsigned resident_grid(const Staging &st, hipStream_t stream, uint32_t tiles, size_t lds_bytes = 0)
 {
 	// Every codec: a background codec's kernels must not stand in a PutObject's way, and the request path's own
 	// kernels are meant to overlap too -- the read path's upload stages beside its checksum segments: with one
@@ -354,7 +360,12 @@ unsigned resident_grid(const Staging &st, hipStream_t stream, uint32_t tiles)
 	// gec::RESIDENT_WGS workgroups per CU is what the kernels' __launch_bounds__ guarantees room for (the occupancy
 	// query of the runtime does not count scalar registers and promised 8 for a kernel that fits 7 times: the
 	// workgroups that did not fit started when the others were done, and held the dispatcher until then)
-	const uint64_t fit = (uint64_t)std::max(st.cus_of(stream), 1) * (uint64_t)gec::RESIDENT_WGS;
+	// ... unless the launch's dynamic LDS allows fewer: wide codes (k up to PTR_KMAX: ~33 KiB of tables per workgroup)
+	// fit 160 KiB of LDS only four times, and a grid sized for six would bring the hold-up back for exactly those
+	uint64_t per_cu = (uint64_t)gec::RESIDENT_WGS;
+	if (lds_bytes)
+		per_cu = std::max<uint64_t>(1, std::min<uint64_t>(per_cu, (160u << 10) / lds_bytes));
+	const uint64_t fit = (uint64_t)std::max(st.cus_of(stream), 1) * per_cu;
 	return (unsigned)std::min<uint64_t>(tiles, fit);
 }
 }  // namespace
@@ -427,10 +438,123 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 			kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, true> : (Kern)gec::gf_apply_ptrs<2, 5, true>;
 		else
 			kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, false> : (Kern)gec::gf_apply_ptrs<2, 5, false>;
-		const unsigned grid = resident_grid(st, stream, a.tiles_total);
+		const unsigned grid = resident_grid(st, stream, a.tiles_total, lds);
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, hb.d_logexp);
 		HIP_TRY(hipGetLastError());
 	}
+	return GEC_OK;
+}
+
+// ---- the fused small-trip kernel (fused.hpp)
+namespace {
+size_t fused_lds_bytes(size_t k, size_t nh, int mw)
+{
+	const size_t leaves_off = (k * 32 * 4 * mw + 768 + k * gec::RMAX + 15) & ~(size_t)15;
+	return leaves_off + nh * gec::FUSED_LEAF_PITCH + 16;
+}
+// LDS one workgroup may ask for on this device (gfx950: 160 KiB per CU, all of it available to one workgroup)
+size_t max_lds_per_workgroup(int device)
+{
+	static std::mutex mu;
+	static std::map<int, size_t> seen;
+	std::lock_guard<std::mutex> g(mu);
+	auto it = seen.find(device);
+	if (it != seen.end())
+		return it->second;
+	int v = 0;
+	if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || v <= 0)
+		v = 64 << 10;
+	(void)hipGetLastError();
+	return seen[device] = (size_t)v;
+}
+}  // namespace
+
+bool fused_fits(const gec_codec *c, size_t nblocks, size_t S, int nout, bool hash_rows)
+{
+	const size_t k = c->k, nh = k + (hash_rows ? (size_t)nout : 0);
+	if (env().fused_small == 0 || nblocks == 0 || k > (size_t)gec::PTR_KMAX || nout > gec::RMAX || nh > (size_t)gec::FUSED_MAX_LEAVES)
+		return false;
+	const size_t tiles_x = (S / 16 + 255) / 256;
+	if (S % 16 || tiles_x * nblocks > 0xffffffffull)
+		return false;
+	// small: the trip's leaves (what the one-lane-per-leaf kernels need tens of thousands of to fill the chip)
+	if (tiles_x * nblocks * nh >= env().fused_max_leaves)
+		return false;
+	return fused_lds_bytes(k, nh, nout <= 4 ? 1 : 2) <= max_lds_per_workgroup(c->device);
+}
+
+int launch_fused(const gec_codec *c, Staging &st, size_t nblocks, const uint8_t *const *in, const uint32_t *valid, uint8_t *const *out,
+		 int nout, size_t S, const uint8_t *coef_sets, size_t npat, const uint16_t *pat, bool hash_rows, uint8_t *sums,
+		 hipStream_t stream)
+{
+	const size_t k = c->k, nh = k + (hash_rows ? (size_t)nout : 0);
+	const HipBackend &hb = hip_of(c);
+	if (!fused_fits(c, nblocks, S, nout, hash_rows))
+		return fail(GEC_E_INVALID_ARG, "fused: shape does not fit the one-launch kernel");
+	if (npat == 0)
+		npat = 1;
+	// the tables ride in the slot's pinned table area, which the kernel reads directly: [in][valid][out][coef sets][pat]
+	const size_t in_bytes = nblocks * k * 8, valid_bytes = (nblocks * k * 4 + 7) / 8 * 8, out_bytes = nblocks * (size_t)nout * 8;
+	const size_t coef_bytes = (npat * k * gec::RMAX + 7) / 8 * 8, pat_bytes = pat ? (nblocks * 2 + 7) / 8 * 8 : 0;
+	const size_t need = (st.tab_used * sizeof(gec::CopyEntry) + in_bytes + valid_bytes + out_bytes + coef_bytes + pat_bytes) / sizeof(gec::CopyEntry) + 2;
+	if (need > st.tab_cap)
+		return fail(GEC_E_INVALID_ARG, "pointer table overflow");
+	uint8_t *base = reinterpret_cast<uint8_t *>(st.h_tab + st.tab_used);
+	st.tab_used = need;
+	const uint8_t **t_in = reinterpret_cast<const uint8_t **>(base);
+	uint32_t *t_valid = reinterpret_cast<uint32_t *>(base + in_bytes);
+	uint8_t **t_out = reinterpret_cast<uint8_t **>(base + in_bytes + valid_bytes);
+	uint8_t *t_coef = base + in_bytes + valid_bytes + out_bytes;
+	uint16_t *t_pat = reinterpret_cast<uint16_t *>(t_coef + coef_bytes);
+	std::memcpy(t_in, in, in_bytes);
+	std::memcpy(t_valid, valid, nblocks * k * 4);
+	if (nout)
+		std::memcpy(t_out, out, out_bytes);
+	std::memset(t_coef, 0, coef_bytes);
+	for (size_t p = 0; p < npat && nout; ++p)
+		for (size_t t = 0; t < k; ++t)
+			for (int r = 0; r < nout; ++r)
+				t_coef[(p * k + t) * gec::RMAX + r] = coef_sets[(p * (size_t)nout + r) * k + t];
+	if (pat)
+		std::memcpy(t_pat, pat, nblocks * 2);
+	gec::FusedArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.in = t_in;
+	a.in_valid = t_valid;
+	a.out = nout ? t_out : nullptr;
+	a.cols = (uint32_t)(S / 16);
+	a.k = (uint32_t)k;
+	a.rows = (uint32_t)nout;
+	a.tiles_x = (a.cols + 255) / 256;
+	a.tiles_total = (uint32_t)(a.tiles_x * nblocks);
+	a.hash_rows = hash_rows ? 1u : 0u;
+	a.coef_tab = t_coef;
+	a.pat = pat ? t_pat : nullptr;
+	a.sums = sums;
+	int rc = leaf_scratch(c, stream, nblocks * nh * a.tiles_x * 64, &a.leafdig);
+	if (!rc)
+		rc = done_counters(c, stream, nblocks, &a.done);
+	if (rc)
+		return rc;
+	link_role_of(st, 0, &a.link_busy, &a.link_role, &a.link_wait_ticks);
+	const int mw = nout <= 4 ? 1 : 2;
+	const size_t lds = fused_lds_bytes(k, nh, mw);
+	using Kern = void (*)(const gec::FusedArgs, const gec::LogExp *);
+	const Kern kern = mw == 1 ? (Kern)gec::gf_ptrs_hash<1, 5> : (Kern)gec::gf_ptrs_hash<2, 5>;
+	if (lds > (48u << 10)) {  // beyond the default limit: opt in, once per kernel and device
+		static std::mutex mu;
+		static std::set<std::pair<const void *, int>> opted;
+		std::lock_guard<std::mutex> g(mu);
+		if (opted.insert({reinterpret_cast<const void *>(kern), c->device}).second)
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+						    (int)max_lds_per_workgroup(c->device)));
+	}
+	// a grid that fits: what LDS lets a CU hold (the dispatcher hold-up of resident_grid applies here too)
+	const size_t per_cu = std::max<size_t>(1, std::min<size_t>(2, (160u << 10) / lds));
+	const uint64_t fit = (uint64_t)std::max(st.cus_of(stream), 1) * per_cu;
+	const unsigned grid = (unsigned)std::min<uint64_t>(a.tiles_total, fit);
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, hb.d_logexp);
+	HIP_TRY(hipGetLastError());
 	return GEC_OK;
 }
 

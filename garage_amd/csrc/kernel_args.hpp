@@ -9,6 +9,7 @@
 
 namespace gec {
 
+constexpr uint32_t SHARDSUM_LEAF_BYTES = 4096;  // == SHARDSUM_LEAF below (needed before it is declared)
 constexpr int KMAX = 256;    // input shards per launch (k + m <= 256 => k <= 255)
 constexpr int RMAX = 8;      // output rows per launch with 4- and 8-byte table entries
 constexpr int RMAX16 = 16;   // ... with 16-byte entries (MW = 4): k <= K16MAX only
@@ -83,6 +84,29 @@ struct PtrApplyArgs {
 	uint8_t coef[PTR_KMAX][RMAX];
 };
 
+// gf_ptrs_hash (fused.hpp): ONE launch for a small trip -- the product over pointer tables like gf_apply_ptrs, and the
+// tree-mode shard checksums of what it read (and, for a put, wrote) from the same tile while it is in LDS.
+constexpr uint32_t FUSED_LEAF_PITCH = SHARDSUM_LEAF_BYTES + 32;  // LDS bytes between the leaves of a tile (bank spread)
+constexpr int FUSED_MAX_LEAVES = 64;                             // leaves per tile: four waves x sixteen quads
+
+struct FusedArgs {
+	const uint8_t *const *in;  // [nblocks][k]
+	const uint32_t *in_valid;  // [nblocks][k]
+	uint8_t *const *out;       // [nblocks][rows]; a NULL entry: this block does not want that row
+	uint32_t cols, k, rows;
+	uint32_t tiles_x, tiles_total;  // 256-column tiles per shard (= leaves per shard); tiles_x * blocks
+	uint32_t hash_rows;        // 1: the output rows are hashed too (a put: k + rows checksums per block), 0: the inputs only
+	// per-block coefficient sets (one decode launch for several erasure patterns): block b uses set pat[b] (NULL: set 0);
+	// set p = coef_tab + p * k * RMAX bytes, [t][r] like PtrApplyArgs::coef
+	const uint8_t *coef_tab;
+	const uint16_t *pat;
+	uint8_t *leafdig;          // device scratch: [nblocks][nh][tiles_x][64], nh = k + (hash_rows ? rows : 0)
+	uint32_t *done;            // device: [nblocks] tiles finished; all zero before the launch, zero again after it
+	uint8_t *sums;             // [nblocks][nh][32] (may be pinned host memory)
+	uint32_t *link_busy;
+	uint32_t link_role, link_wait_ticks;
+};
+
 struct CopyEntry {
 	const uint8_t *src;
 	uint8_t *dst;
@@ -137,7 +161,7 @@ struct Blake2Args {
 	uint64_t seg_begin_blk = 0, seg_end_blk = ~0ull;
 };
 
-constexpr uint32_t SHARDSUM_LEAF = 4096;
+constexpr uint32_t SHARDSUM_LEAF = SHARDSUM_LEAF_BYTES;
 constexpr uint64_t SHARDSUM_P0 = 64ull /*digest*/ | (0ull << 8) /*key*/ | (0ull << 16) /*fanout: unlimited*/ | (2ull << 24) /*depth*/ |
 				 ((uint64_t)SHARDSUM_LEAF << 32);
 constexpr uint64_t SHARDSUM_P2_LEAF = 0ull /*node_depth*/ | (64ull << 8) /*inner_length*/;
