@@ -189,9 +189,10 @@ class ReedSolomon:
         covers those addresses; missing shards are rebuilt in place."""
         import torch
 
-        if not (isinstance(buf, torch.Tensor) and buf.is_cuda and buf.dtype == torch.uint8 and buf.is_contiguous()):
-            raise TypeError("buf must be a contiguous uint8 CUDA tensor")
-        if buf.device.index != self.device:
+        on_host = self.backend == "cpu"   # a CPU codec runs the same strided call on HOST memory (CPU tensors)
+        if not (isinstance(buf, torch.Tensor) and buf.is_cuda != on_host and buf.dtype == torch.uint8 and buf.is_contiguous()):
+            raise TypeError("buf must be a contiguous uint8 %s tensor" % ("CPU" if on_host else "CUDA"))
+        if not on_host and buf.device.index != self.device:
             raise GecError(_lib.GEC_E_INVALID_ARG, "buf", "tensor is on a different device than the codec")
         if len(shard_off) != self.n:
             raise GecError(_lib.GEC_E_INVALID_INDEX, "shard_off", "must have k+m entries")
@@ -204,7 +205,7 @@ class ReedSolomon:
         offs = (ctypes.c_size_t * self.n)(*[int(o) for o in shard_off])
         off, ln = (0, S) if byte_range is None else byte_range
         check(lib.gec_reconstruct_scattered_dev(self._h, nblocks, buf.data_ptr(), block_stride, offs, S, _u8p(pres),
-                                                int(bool(data_only)), off, ln, _stream_handle(self.device)),
+                                                int(bool(data_only)), off, ln, None if on_host else _stream_handle(self.device)),
               "gec_reconstruct_scattered_dev")
         return buf
 

@@ -342,4 +342,44 @@ inline void shardsum_many(const uint8_t *const *msgs, const size_t *lens, size_t
 	}
 }
 
+// The same tree in pieces, for a caller that spreads ONE shard's check over several threads (the streaming get's first
+// shard: the first byte waits for nothing else): the 64-byte digests of leaves [leaf_lo, leaf_hi) into dig[64 * leaf],
+// and the root over all nleaf of them.
+inline size_t shardsum_nleaf(size_t len) { return len ? (len + kShardsumLeaf - 1) / kShardsumLeaf : 1; }
+
+inline void shardsum_leaf_range(const uint8_t *msg, size_t len, size_t leaf_lo, size_t leaf_hi, uint8_t *dig)
+{
+	const uint64_t P0 = 64ull | (2ull << 24) | ((uint64_t)kShardsumLeaf << 32);
+	const size_t nleaf = shardsum_nleaf(len);
+	thread_local std::vector<Job> jobs;
+	jobs.assign(leaf_hi - leaf_lo, Job());
+	for (size_t l = leaf_lo; l < leaf_hi; ++l) {
+		Job &j = jobs[l - leaf_lo];
+		const size_t lo = l * kShardsumLeaf;
+		j.len = len > lo ? std::min<size_t>(kShardsumLeaf, len - lo) : 0;
+		j.p = j.len ? msg + lo : nullptr;
+		j.x0 = P0;
+		j.x1 = l;
+		j.x2 = 64ull << 8;
+		j.last_node = l + 1 == nleaf;
+		j.out = dig + 64 * l;
+		j.outlen = 64;
+	}
+	run_jobs(jobs.data(), jobs.size());
+}
+
+inline void shardsum_root(const uint8_t *dig, size_t nleaf, uint8_t out[32])
+{
+	Job j;
+	j.p = dig;
+	j.len = 64 * nleaf;
+	j.x0 = 64ull | (2ull << 24) | ((uint64_t)kShardsumLeaf << 32);
+	j.x1 = 0;
+	j.x2 = 1ull | (64ull << 8);
+	j.last_node = true;
+	j.out = out;
+	j.outlen = 32;
+	run_jobs(&j, 1);
+}
+
 }  // namespace b2host

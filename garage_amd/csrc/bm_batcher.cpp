@@ -144,7 +144,8 @@ struct gbm_batcher {
 			      int busy_now, size_t nworkers)
 	{
 		const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(max_wait_us);
-		const auto gap = std::chrono::microseconds(std::max(20u, max_wait_us / 6));
+		const unsigned gap_us = env().batcher_gap_us ? env().batcher_gap_us : std::max(20u, max_wait_us / 6);
+		const auto gap = std::chrono::microseconds(gap_us);
 		size_t seen = q.size();
 		while (!stopping && q.size() < max_blocks) {
 			const auto now = std::chrono::system_clock::now();

@@ -35,6 +35,7 @@ const EnvRow kEnvRows[] = {
 	{"GBM_PUT_THREADS", "4", "put slices in flight"},
 	{"GBM_BATCHER_WORKERS", "2", "batches the coalescing batcher keeps in flight (per device)"},
 	{"GBM_BATCHER_SPLIT_MIN", "16", "a batcher worker that finds this many blocks queued while other workers are idle takes only its share of them (0 = never split)"},
+	{"GBM_BATCHER_GAP_US", "max(20, linger / 6)", "the batcher's linger ends once nobody has arrived for this long (A/B; 0 = the default)"},
 	{"GBM_BATCHER_DEVICE_TURN", "1", "1 = one put batch and one get batch of a device's queue on the link at a time, the others prepare / fan out meanwhile (0 = trips overlap freely)"},
 	{"GBM_CPU_BLAKE2", "auto", "the manager's own BLAKE2b (block hashes of small gets, shard checks): auto = eight messages at a time with AVX-512, scalar = one at a time (A/B)"},
 };
@@ -59,6 +60,8 @@ const Env &env()
 		const long sm = env_long("GBM_BATCHER_SPLIT_MIN", 16);
 		v.batcher_split_min = (size_t)(sm >= 0 ? sm : 16);
 		v.batcher_device_turn = env_long("GBM_BATCHER_DEVICE_TURN", 1) != 0;
+		const long gp = env_long("GBM_BATCHER_GAP_US", 0);
+		v.batcher_gap_us = (unsigned)(gp > 0 && gp < 100000 ? gp : 0);
 		const char *b2 = std::getenv("GBM_CPU_BLAKE2");
 		if (b2 && b2[0] == 's')
 			b2host::mb_mode().store(0);

@@ -55,6 +55,7 @@ struct Env {
 	int batcher_workers;      // GBM_BATCHER_WORKERS
 	size_t batcher_split_min; // GBM_BATCHER_SPLIT_MIN
 	bool batcher_device_turn; // GBM_BATCHER_DEVICE_TURN
+	unsigned batcher_gap_us;  // GBM_BATCHER_GAP_US
 };
 const Env &env();
 const char *env_table_text();

@@ -360,28 +360,41 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 	std::vector<Prep> prep(nb);
 	std::atomic<bool> oom{false};
 	Trace tr("put");
+	// (zstd, when asked for, holds the compressed payload until it is copied)
+	std::vector<std::vector<uint8_t>> zbufs(nb);
 	mg->pool->parallel_for(nb, [&](size_t b) {
 		try {
 			Prep &p = prep[b];
-			std::vector<uint8_t> zbuf;
-			const uint8_t *src = data[b];
 			p.plen = len[b];
-			if (compress && !(prevent_compression && prevent_compression[b]) &&
-			    zstd().encode(data[b], len[b], level, zbuf)) {
-				src = zbuf.data();
-				p.plen = zbuf.size();
+			if (compress && !(prevent_compression && prevent_compression[b]) && zstd().encode(data[b], len[b], level, zbufs[b])) {
+				p.plen = zbufs[b].size();
 				p.z = true;
 			}
 			p.S = gec_shard_len(k, p.plen);
 			p.block = mg->bufs->get((size_t)k * p.S);
-			if (p.plen)
-				std::memcpy(p.block.mut(), src, p.plen);
-			std::memset(p.block.mut() + p.plen, 0, (size_t)k * p.S - p.plen);
 			p.parity = mg->bufs->get((size_t)m * p.S);
 		} catch (const std::bad_alloc &) {
 			oom = true;
 		}
 	});
+	if (!oom) {
+		// the ONE copy of the payload, shard by shard: a PutObject's few blocks are cut into k pieces each so that the copy
+		// of a single 1 MiB block is not one core's 80 us (it is most of what the host adds to a small put's latency)
+		const size_t pieces = nb >= 32 ? 1 : (size_t)k;
+		mg->pool->parallel_for(nb * pieces, [&](size_t i) {
+			const size_t b = i / pieces, pc = i % pieces;
+			Prep &p = prep[b];
+			const uint8_t *src = p.z ? zbufs[b].data() : data[b];
+			const size_t total = (size_t)k * p.S;
+			const size_t lo = total * pc / pieces / 64 * 64, hi = pc + 1 == pieces ? total : total * (pc + 1) / pieces / 64 * 64;
+			const size_t cp_hi = std::min(hi, p.plen);
+			if (cp_hi > lo)
+				std::memcpy(p.block.mut() + lo, src + lo, cp_hi - lo);
+			const size_t z_lo = std::max(lo, p.plen);
+			if (hi > z_lo)
+				std::memset(p.block.mut() + z_lo, 0, hi - z_lo);
+		});
+	}
 	if (oom)
 		return fail_all(GBM_E_IO, "out of (pinned) host memory for the shard buffers");
 	tr.lap("prep");
@@ -1089,7 +1102,36 @@ struct StreamChecks {  // shared with the async tasks: they own what they touch
 	std::vector<int> verdict;  // per shard index: 0 = pending, 1 = matches its header's checksum, -1 = does not
 	std::vector<Bytes> shard;
 	std::vector<std::array<uint8_t, 32>> sum;
-	std::atomic<size_t> next{0};  // next entry of the read set to check (claimed in index order)
+	// A shard's check is its checksum tree: the leaves in `groups` pieces (claimed in order, first shard first), then
+	// the root by whoever finishes the shard's last piece.
+	std::vector<int> used;                      // the read set, in index order
+	size_t S = 0, nleaf = 0, groups = 1;
+	std::vector<std::vector<uint8_t>> dig;      // per entry of `used`: nleaf leaf digests
+	std::unique_ptr<std::atomic<int>[]> left;   // per entry of `used`: pieces not yet hashed
+	std::atomic<size_t> next{0};                // next piece to claim: entry = next / groups, piece = next % groups
+
+	bool check_next()  // false: nothing left to claim
+	{
+		const size_t t = next.fetch_add(1);
+		if (t >= used.size() * groups)
+			return false;
+		const size_t e = t / groups, gi = t % groups;
+		const int j = used[e];
+		const size_t lo = nleaf * gi / groups, hi = nleaf * (gi + 1) / groups;
+		if (hi > lo)
+			b2host::shardsum_leaf_range(shard[j].data(), S, lo, hi, dig[e].data());
+		if (left[e].fetch_sub(1) == 1) {  // the shard's last piece: its root, its verdict
+			uint8_t got[32];
+			b2host::shardsum_root(dig[e].data(), nleaf, got);
+			const int v = std::memcmp(got, sum[j].data(), 32) == 0 ? 1 : -1;
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				verdict[j] = v;
+			}
+			cv.notify_all();
+		}
+		return true;
+	}
 };
 
 // the block hash behind the stream: segments are pushed in order by the walk, hashed by a thread of its own
@@ -1189,37 +1231,25 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 			used.push_back(j);
 	for (int j = 0; j < k; ++j)
 		need_decode = need_decode || g[0].shard[j].empty();
-	// The checks are claimed in index order -- by a few helpers on the async pool and by the walk itself, which checks
-	// the shard it is waiting for when nobody has started on it: shard 0's verdict takes one shard's time, not the time
-	// ten checks need when they all share the cores at once.
-	auto check_one = [ck, S](int j) {
-		uint8_t sum[32];
-		shardsum(ck->shard[j].data(), S, sum);
-		const int v = std::memcmp(sum, ck->sum[j].data(), 32) == 0 ? 1 : -1;
-		{
-			std::lock_guard<std::mutex> lk(ck->mu);
-			ck->verdict[j] = v;
-		}
-		ck->cv.notify_all();
-	};
-	auto check_next = [ck, used, check_one]() -> bool {  // false: nothing left to claim
-		const size_t i = ck->next.fetch_add(1);
-		if (i >= used.size())
-			return false;
-		check_one(used[i]);
-		return true;
-	};
-	// the first shard of the read set is the walk's own, and it is checked before the helpers are even woken (on a busy
-	// or small host they would take the core): it is what the first byte waits for
-	ck->next = 1;
-	check_one(used[0]);
+	// The checks are claimed piece by piece, the first shard's pieces first -- by a few helpers on the async pool and by
+	// the walk itself while it waits: shard 0's verdict takes a fraction of one shard's hashing time (its leaves are
+	// independent chains), the others' follow in index order as the stream advances.
+	ck->used = used;
+	ck->S = S;
+	ck->nleaf = b2host::shardsum_nleaf(S);
+	ck->groups = ck->nleaf >= 16 ? 4 : 1;
+	ck->dig.assign(used.size(), std::vector<uint8_t>(ck->nleaf * 64));
+	ck->left.reset(new std::atomic<int>[used.size()]);
+	for (size_t e = 0; e < used.size(); ++e)
+		ck->left[e] = (int)ck->groups;
 	{
 		const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
-		const size_t helpers = std::min<size_t>(used.size() > 1 ? used.size() - 1 : 0, std::max(1u, hw - 2));
+		const size_t pieces = used.size() * ck->groups;
+		const size_t helpers = std::min<size_t>(pieces > 1 ? pieces - 1 : 0, std::max(1u, hw - 2));
 		std::shared_ptr<gbm_manager::Async> async = m->async_pool();
 		for (size_t i = 0; i < helpers; ++i)
-			async->submit([check_next] {
-				while (check_next()) {
+			async->submit([ck] {
+				while (ck->check_next()) {
 				}
 			});
 	}
@@ -1230,7 +1260,7 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 				if (ck->verdict[j] != 0)
 					return ck->verdict[j];
 			}
-			if (!check_next())  // everything is claimed: the verdict is on its way
+			if (!ck->check_next())  // everything is claimed: the verdict is on its way
 				break;
 		}
 		std::unique_lock<std::mutex> lk(ck->mu);

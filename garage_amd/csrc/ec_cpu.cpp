@@ -425,6 +425,31 @@ struct CpuBackend : Backend {
 		return GEC_OK;
 	}
 
+	// The strided ("device-style") reconstruct on HOST memory: shard j of block b at base + b*block_stride + shard_off[j]
+	// (contiguous stripes when shard_off is NULL), only bytes [byte_off, byte_off + byte_len) of every shard touched,
+	// missing shards rebuilt in place.  This is what a rank of a striped-object group that runs on the host cores calls
+	// for its byte range of the gathered buffer (ec_hip_group.cpp, garage_amd/striped.py on CPU tensors); the stream
+	// argument means nothing here.
+	int reconstruct_dev(size_t nblocks, void *d_base, size_t block_stride, const size_t *shard_off, size_t S, const uint8_t *present,
+			    int data_only, size_t byte_off, size_t byte_len, void *) override
+	{
+		const size_t k = c->k, n = (size_t)c->k + c->m;
+		if (byte_len == 0)
+			return GEC_OK;
+		std::vector<const uint8_t *> sp(nblocks * n, nullptr);
+		std::vector<uint8_t *> op(nblocks * n, nullptr);
+		uint8_t *base = static_cast<uint8_t *>(d_base);
+		for (size_t b = 0; b < nblocks; ++b)
+			for (size_t j = 0; j < n; ++j) {
+				uint8_t *p = base + b * block_stride + (shard_off ? shard_off[j] : j * S) + byte_off;
+				if (present[j])
+					sp[b * n + j] = p;
+				else if (!(data_only && j >= k))
+					op[b * n + j] = p;
+			}
+		return reconstruct_batch(nblocks, sp.data(), op.data(), byte_len, data_only, nullptr, nullptr);
+	}
+
 	int reconstruct_batch(size_t nblocks, const uint8_t *const *shards, uint8_t *const *out, size_t S, int data_only, uint8_t *in_sums,
 			      uint8_t *out_sums) override
 	{

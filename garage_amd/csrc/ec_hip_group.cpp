@@ -2,6 +2,10 @@
 // the path's one real exchange step: all-gather (or all-to-all) of the survivors over RCCL / a caller transport, every
 // rank rebuilds its byte range of the missing shards, the rebuilt ranges are exchanged.  Host code only; the pack /
 // unpack kernels are launched through ec_hip_launch.hip.
+// A group over a GEC_BACKEND_CPU codec and a caller transport runs the SAME steps on host buffers (host_* below: the
+// range split, the packs and unpacks restated as loops, the rebuild on the codec's own host data path): ranks that
+// have lost their GPU stay in the group, and the CPU suite drives this file's exchange logic with N > 1 real
+// processes (tests/test_group_multiprocess.py).
 #include "ec_hip.hpp"
 
 #include <rccl/rccl.h>  // types only: RCCL itself is resolved with dlopen
@@ -66,6 +70,8 @@ const Rccl &rccl()
 }
 }  // namespace
 
+extern "C" size_t gec_group_slots(const gec_group *g);
+
 struct gec_group {
 	const gec_codec *c = nullptr;
 	int rank = 0, nranks = 1;
@@ -115,6 +121,199 @@ int rccl_all_to_all(void *ctx, const void *d_send, void *d_recv, size_t bytes, v
 
 }  // namespace
 
+
+// ---------------------------------------------------------------- the same steps on host buffers (CPU codec)
+namespace {
+
+int check_host_layout(const void *p, size_t S)
+{
+	if (S == 0)
+		return fail(GEC_E_EMPTY_SHARD, "shard length is 0");
+	if (S % 64 != 0)
+		return fail(GEC_E_INCORRECT_SHARD_SIZE, "S must be a multiple of 64");
+	if (!p)
+		return fail(GEC_E_INVALID_ARG, "NULL buffer");
+	return GEC_OK;
+}
+
+int host_scratch(uint8_t **p, size_t *cap, size_t bytes)
+{
+	if (bytes <= *cap)
+		return GEC_OK;
+	std::free(*p);
+	*p = static_cast<uint8_t *>(std::calloc(bytes ? bytes : 1, 1));  // zeroed: pad columns are defined bytes on the wire
+	*cap = *p ? bytes : 0;
+	return *p ? GEC_OK : fail(GEC_E_NOMEM, "group scratch");
+}
+
+inline size_t range_lo(size_t cols, size_t r, size_t N) { return cols * r / N; }
+
+int host_allgather_decode(gec_group *g, size_t nobjects, const uint8_t *local, size_t S, const uint8_t *present, int data_only, int complete,
+			  uint8_t *gathered)
+{
+	const gec_codec *c = g->c;
+	const size_t n = (size_t)c->k + c->m, N = (size_t)g->nranks, slots = gec_group_slots(g);
+	int rc = check_host_layout(local, S);
+	if (!rc)
+		rc = check_host_layout(gathered, S);
+	if (rc)
+		return rc;
+	std::shared_ptr<const Plan> plan;
+	rc = get_plan(c, present, data_only != 0, plan);
+	if (rc)
+		return rc;
+	// (1) every rank's slot buffer to everybody
+	const size_t per_rank = nobjects * slots * S;
+	g->bytes_exchanged = per_rank * (N - 1);
+	rc = g->all_gather(g->ctx, local, gathered, per_rank, nullptr);
+	if (rc)
+		return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+	if (plan->missing.empty())
+		return GEC_OK;
+	// (2) my byte range of every missing shard, in place in the gathered buffer, on the codec's own host data path
+	std::vector<size_t> shard_off(n);
+	for (size_t j = 0; j < n; ++j)
+		shard_off[j] = (j % N) * per_rank + (j / N) * S;
+	const size_t cols = S / 16, lo = range_lo(cols, g->rank, N), my_cols = range_lo(cols, g->rank + 1, N) - lo;
+	const size_t nmiss = plan->missing.size();
+	if (my_cols) {
+		std::vector<const uint8_t *> sp(nobjects * n, nullptr);
+		std::vector<uint8_t *> op(nobjects * n, nullptr);
+		for (size_t o = 0; o < nobjects; ++o) {
+			for (size_t j = 0; j < n; ++j)
+				if (present[j])
+					sp[o * n + j] = gathered + shard_off[j] + o * slots * S + lo * 16;
+			for (int j : plan->missing)
+				op[o * n + j] = gathered + shard_off[j] + o * slots * S + lo * 16;
+		}
+		rc = c->be->reconstruct_batch(nobjects, sp.data(), op.data(), my_cols * 16, data_only, nullptr, nullptr);
+		if (rc)
+			return rc;
+	}
+	if (!complete || N == 1)
+		return GEC_OK;
+	// (3) exchange the rebuilt ranges: [nmiss][nobj][max_cols], ranges differ by at most one column
+	size_t max_cols = 0;
+	for (size_t r = 0; r < N; ++r)
+		max_cols = std::max(max_cols, range_lo(cols, r + 1, N) - range_lo(cols, r, N));
+	const size_t send_bytes = nmiss * nobjects * max_cols * 16;
+	rc = host_scratch(&g->d_send, &g->send_cap, send_bytes);
+	if (!rc)
+		rc = host_scratch(&g->d_recv, &g->recv_cap, send_bytes * N);
+	if (rc)
+		return rc;
+	for (size_t i = 0; i < nmiss; ++i)  // range_pack
+		for (size_t o = 0; o < nobjects; ++o)
+			std::memcpy(g->d_send + (i * nobjects + o) * max_cols * 16, gathered + shard_off[plan->missing[i]] + o * slots * S + lo * 16,
+				    my_cols * 16);
+	g->bytes_exchanged += send_bytes * (N - 1);
+	rc = g->all_gather(g->ctx, g->d_send, g->d_recv, send_bytes, nullptr);
+	if (rc)
+		return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+	for (size_t r = 0; r < N; ++r) {  // range_unpack
+		if (r == (size_t)g->rank)
+			continue;
+		const size_t rlo = range_lo(cols, r, N), rn = range_lo(cols, r + 1, N) - rlo;
+		for (size_t i = 0; i < nmiss; ++i)
+			for (size_t o = 0; o < nobjects; ++o)
+				std::memcpy(gathered + shard_off[plan->missing[i]] + o * slots * S + rlo * 16,
+					    g->d_recv + ((r * nmiss + i) * nobjects + o) * max_cols * 16, rn * 16);
+	}
+	return GEC_OK;
+}
+
+int host_alltoall_decode(gec_group *g, size_t nobjects, const uint8_t *local, size_t S, const uint8_t *present, int data_only, int complete,
+			 uint8_t *rebuilt)
+{
+	const gec_codec *c = g->c;
+	const size_t k = c->k, n = (size_t)c->k + c->m, N = (size_t)g->nranks, slots = gec_group_slots(g);
+	int rc = check_host_layout(local, S);
+	if (rc)
+		return rc;
+	std::shared_ptr<const Plan> plan;
+	rc = get_plan(c, present, data_only != 0, plan);
+	if (rc)
+		return rc;
+	g->bytes_exchanged = 0;
+	const size_t nmiss = plan->missing.size();
+	if (nmiss == 0)
+		return GEC_OK;
+	std::vector<std::vector<int>> valid_of(N);
+	for (size_t t = 0; t < k; ++t)
+		valid_of[plan->valid[t] % N].push_back(plan->valid[t]);
+	size_t nvs_max = 0;
+	for (auto &v : valid_of)
+		nvs_max = std::max(nvs_max, v.size());
+	const size_t cols = S / 16;
+	size_t max_cols = 0;
+	for (size_t r = 0; r < N; ++r)
+		max_cols = std::max(max_cols, range_lo(cols, r + 1, N) - range_lo(cols, r, N));
+	const size_t my_lo = range_lo(cols, g->rank, N), my_cols = range_lo(cols, g->rank + 1, N) - my_lo;
+	const size_t per_peer = nvs_max * nobjects * max_cols * 16, packed_bytes = nmiss * nobjects * max_cols * 16;
+	size_t cap2 = g->a2a_cap;
+	rc = host_scratch(&g->d_a2a_send, &g->a2a_cap, N * per_peer);
+	if (!rc)
+		rc = host_scratch(&g->d_a2a_recv, &cap2, N * per_peer);
+	if (!rc)
+		rc = host_scratch(&g->d_send, &g->send_cap, packed_bytes);
+	if (!rc)
+		rc = host_scratch(&g->d_recv, &g->recv_cap, packed_bytes * N);
+	if (rc)
+		return rc;
+	// (1) a2a_pack: for every peer, that peer's byte range of my valid shards
+	const std::vector<int> &mine = valid_of[g->rank];
+	for (size_t peer = 0; peer < N; ++peer) {
+		const size_t plo = range_lo(cols, peer, N), pn = range_lo(cols, peer + 1, N) - plo;
+		for (size_t vs = 0; vs < mine.size(); ++vs)
+			for (size_t o = 0; o < nobjects; ++o)
+				std::memcpy(g->d_a2a_send + ((peer * nvs_max + vs) * nobjects + o) * max_cols * 16,
+					    local + o * slots * S + (size_t)(mine[vs] / N) * S + plo * 16, pn * 16);
+	}
+	// (2) the exchange step
+	g->bytes_exchanged = per_peer * (N - 1);
+	rc = g->all_to_all(g->ctx, g->d_a2a_send, g->d_a2a_recv, per_peer, nullptr);
+	if (rc)
+		return rc > 0 ? fail(GEC_E_DEVICE, "all_to_all transport failed") : rc;
+	// (3) my byte range of every missing shard from the received ranges
+	if (my_cols) {
+		std::vector<const uint8_t *> sp(nobjects * n, nullptr);
+		std::vector<uint8_t *> op(nobjects * n, nullptr);
+		for (size_t o = 0; o < nobjects; ++o) {
+			for (size_t t = 0; t < k; ++t) {
+				const int v = plan->valid[t];
+				const size_t owner = v % N;
+				const size_t vs = std::find(valid_of[owner].begin(), valid_of[owner].end(), v) - valid_of[owner].begin();
+				sp[o * n + v] = g->d_a2a_recv + ((owner * nvs_max + vs) * nobjects + o) * max_cols * 16;
+			}
+			for (size_t i = 0; i < nmiss; ++i)
+				op[o * n + plan->missing[i]] = g->d_send + (i * nobjects + o) * max_cols * 16;
+		}
+		rc = c->be->reconstruct_batch(nobjects, sp.data(), op.data(), my_cols * 16, data_only, nullptr, nullptr);
+		if (rc)
+			return rc;
+	}
+	// (4) the rebuilt ranges: mine only, or everybody's after a (small) all-gather
+	auto unpack = [&](const uint8_t *packed, size_t r) {
+		const size_t rlo = range_lo(cols, r, N), rn = range_lo(cols, r + 1, N) - rlo;
+		for (size_t i = 0; i < nmiss; ++i)
+			for (size_t o = 0; o < nobjects; ++o)
+				std::memcpy(rebuilt + (i * nobjects + o) * S + rlo * 16, packed + (i * nobjects + o) * max_cols * 16, rn * 16);
+	};
+	if (complete && N > 1) {
+		g->bytes_exchanged += packed_bytes * (N - 1);
+		rc = g->all_gather(g->ctx, g->d_send, g->d_recv, packed_bytes, nullptr);
+		if (rc)
+			return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+		for (size_t r = 0; r < N; ++r)
+			unpack(g->d_recv + r * packed_bytes, r);
+	} else {
+		unpack(g->d_send, g->rank);
+	}
+	return GEC_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int gec_group_unique_id(uint8_t id[GEC_GROUP_ID_BYTES])
@@ -155,8 +354,6 @@ static int group_new(const gec_codec *c, int rank, int nranks, gec_group **out, 
 	*out = nullptr;
 	if (!c)
 		return fail(GEC_E_INVALID_ARG, "NULL codec");
-	if (c->backend != GEC_BACKEND_HIP)
-		return fail(GEC_E_DEVICE, "a striped-object group needs a GEC_BACKEND_HIP codec (the exchange moves device memory)");
 	if (nranks < 1 || rank < 0 || rank >= nranks)
 		return fail(GEC_E_INVALID_ARG, "need 0 <= rank < nranks");
 	g.reset(new (std::nothrow) gec_group());
@@ -176,6 +373,8 @@ int gec_group_create(const gec_codec *c, int rank, int nranks, const uint8_t id[
 		return rc;
 	if (!id)
 		return fail(GEC_E_INVALID_ARG, "NULL id");
+	if (c->backend != GEC_BACKEND_HIP)
+		return fail(GEC_E_DEVICE, "an RCCL group needs a GEC_BACKEND_HIP codec (RCCL moves device memory); a CPU codec takes a caller transport");
 	const Rccl &R = rccl();
 	if (!R.handle)
 		return fail(GEC_E_DEVICE, "RCCL is not available: " + R.error);
@@ -220,6 +419,14 @@ void gec_group_destroy(gec_group *g)
 {
 	if (!g)
 		return;
+	if (g->c->backend != GEC_BACKEND_HIP) {  // host scratch
+		std::free(g->d_send);
+		std::free(g->d_recv);
+		std::free(g->d_a2a_send);
+		std::free(g->d_a2a_recv);
+		delete g;
+		return;
+	}
 	{
 		DeviceGuard dg(g->c->device);
 		if (g->d_send)
@@ -251,6 +458,9 @@ int gec_group_allgather_decode(gec_group *g, size_t nobjects, const void *d_loca
 	if (nobjects == 0)
 		return GEC_OK;
 	const gec_codec *c = g->c;
+	if (c->backend != GEC_BACKEND_HIP)  // host buffers, same steps (hip_stream is ignored)
+		return host_allgather_decode(g, nobjects, static_cast<const uint8_t *>(d_local_slots), S, present, data_only, complete,
+					     static_cast<uint8_t *>(d_gathered));
 	const size_t n = (size_t)c->k + c->m, N = (size_t)g->nranks, slots = gec_group_slots(g);
 	int rc = check_dev_layout(d_local_slots, slots * S, S, slots * S);
 	if (rc)
@@ -349,6 +559,9 @@ int gec_group_alltoall_decode(gec_group *g, size_t nobjects, const void *d_local
 	if (nobjects == 0)
 		return GEC_OK;
 	const gec_codec *c = g->c;
+	if (c->backend != GEC_BACKEND_HIP)
+		return host_alltoall_decode(g, nobjects, static_cast<const uint8_t *>(d_local_slots), S, present, data_only, complete,
+					    static_cast<uint8_t *>(d_rebuilt));
 	const size_t k = c->k, N = (size_t)g->nranks, slots = gec_group_slots(g);
 	int rc = check_dev_layout(d_local_slots, slots * S, S, slots * S);
 	if (rc)

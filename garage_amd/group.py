@@ -73,10 +73,11 @@ class Group:
         current torch stream."""
         import torch
 
-        if not (isinstance(local_slots, torch.Tensor) and local_slots.is_cuda and local_slots.dtype == torch.uint8
+        on_host = self.codec.backend == "cpu"   # a group over a CPU codec (caller transport) works on CPU tensors
+        if not (isinstance(local_slots, torch.Tensor) and local_slots.is_cuda != on_host and local_slots.dtype == torch.uint8
                 and local_slots.dim() == 3 and local_slots.shape[1] == self.slots):
-            raise TypeError(f"local_slots must be a uint8 CUDA tensor (nobjects, {self.slots}, S)")
-        if local_slots.device.index != self.codec.device:
+            raise TypeError(f"local_slots must be a uint8 {'CPU' if on_host else 'CUDA'} tensor (nobjects, {self.slots}, S)")
+        if not on_host and local_slots.device.index != self.codec.device:
             raise GecError(_lib.GEC_E_INVALID_ARG, "local_slots", "tensor is on a different device than the codec")
         local_slots = local_slots.contiguous()
         nobj, slots, S = local_slots.shape
@@ -85,10 +86,10 @@ class Group:
             raise GecError(_lib.GEC_E_INVALID_INDEX, "present", "must have k+m entries")
         if out is None:
             out = torch.empty((self.nranks, nobj, slots, S), dtype=torch.uint8, device=local_slots.device)
-        elif not (out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.numel() == self.nranks * local_slots.numel()):
-            raise TypeError("out must be a contiguous uint8 CUDA tensor of nranks*nobjects*slots*S bytes")
+        elif not (out.is_cuda != on_host and out.dtype == torch.uint8 and out.is_contiguous() and out.numel() == self.nranks * local_slots.numel()):
+            raise TypeError("out must be a contiguous uint8 tensor of nranks*nobjects*slots*S bytes, where the slots are")
         check(lib.gec_group_allgather_decode(self._h, nobj, local_slots.data_ptr(), S, _u8p(pres), int(bool(data_only)),
-                                             int(bool(complete)), out.data_ptr(), _stream_handle(self.codec.device)),
+                                             int(bool(complete)), out.data_ptr(), None if on_host else _stream_handle(self.codec.device)),
               "gec_group_allgather_decode")
         return out
 
@@ -98,9 +99,10 @@ class Group:
         shards in ascending index order; with complete=False only this rank's byte range of them is valid."""
         import torch
 
-        if not (isinstance(local_slots, torch.Tensor) and local_slots.is_cuda and local_slots.dtype == torch.uint8
+        on_host = self.codec.backend == "cpu"
+        if not (isinstance(local_slots, torch.Tensor) and local_slots.is_cuda != on_host and local_slots.dtype == torch.uint8
                 and local_slots.dim() == 3 and local_slots.shape[1] == self.slots):
-            raise TypeError(f"local_slots must be a uint8 CUDA tensor (nobjects, {self.slots}, S)")
+            raise TypeError(f"local_slots must be a uint8 {'CPU' if on_host else 'CUDA'} tensor (nobjects, {self.slots}, S)")
         local_slots = local_slots.contiguous()
         nobj, slots, S = local_slots.shape
         pres = np.ascontiguousarray(np.asarray(present, dtype=np.uint8))
@@ -109,8 +111,10 @@ class Group:
         nmiss = sum(1 for j in range(self.codec.n) if not pres[j] and not (data_only and j >= self.codec.k))
         if out is None:
             out = torch.zeros((nmiss, nobj, S), dtype=torch.uint8, device=local_slots.device)
+        if nmiss == 0:   # nothing to rebuild: no exchange either (the pattern is the same on every rank)
+            return out
         check(lib.gec_group_alltoall_decode(self._h, nobj, local_slots.data_ptr(), S, _u8p(pres), int(bool(data_only)),
-                                            int(bool(complete)), out.data_ptr(), _stream_handle(self.codec.device)),
+                                            int(bool(complete)), out.data_ptr(), None if on_host else _stream_handle(self.codec.device)),
               "gec_group_alltoall_decode")
         return out
 

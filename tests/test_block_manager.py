@@ -6,13 +6,13 @@ import garage_amd as g
 from tests import block_manager_cases as C
 
 
-def OracleCodec(k, m):  # historic name in this file: the codec is the PRODUCT's CPU backend now
+def cpu_codec(k, m):  # the PRODUCT's CPU backend
     return g.ReedSolomon(k, m, backend="cpu")
 
 
 @pytest.fixture(params=[(3, 1), (10, 4)], ids=["rs3_1", "rs10_4"])
 def codec(request):
-    return OracleCodec(*request.param)
+    return cpu_codec(*request.param)
 
 
 def test_put_get_roundtrip(codec, tmp_path):
@@ -47,7 +47,7 @@ def test_needs_enough_nodes():
     from garage_amd.block_manager import BlockManager, Error, MemoryShardStore
 
     with pytest.raises(Error):
-        BlockManager(OracleCodec(10, 4), [MemoryShardStore() for _ in range(13)])
+        BlockManager(cpu_codec(10, 4), [MemoryShardStore() for _ in range(13)])
 
 
 def test_compressed_put_get_and_corruption():
@@ -58,7 +58,7 @@ def test_compressed_put_get_and_corruption():
                                           ShardHeader)
     from garage_amd.partition import block_hash
 
-    codec = OracleCodec(3, 1)
+    codec = cpu_codec(3, 1)
     stores = [MemoryShardStore() for _ in range(5)]
     mgr = BlockManager(codec, stores, compression_level=1)
     data = C.pattern_block(300_000, 5)

@@ -1,7 +1,8 @@
-"""N>1 paths on CPU: world_size-2 (and 3) `gloo` process groups exercise the
-striped-object all-gather decode and the hash partition.  The arithmetic inside
-is the oracle (tests/oracle_codec.py) because there is no GPU here; the GPU
-version of the same flow is tests/test_gpu_striped.py."""
+"""N>1 paths on CPU: world_size-2 (and 3) `gloo` process groups exercise the striped-object decode -- the torch
+mirror's exchange logic (garage_amd/striped.py) AND the library's own (gec_group_* through the C ABI over a gloo-backed
+transport, tests/test_group_multiprocess.py) -- and the hash partition.  The arithmetic is the PRODUCT's: a
+GEC_BACKEND_CPU codec, whose strided reconstruct runs on host memory; the oracle only encodes the stripes and judges the
+result.  The GPU version of the same flow is tests/test_gpu_striped.py."""
 import os
 import socket
 
@@ -27,8 +28,9 @@ def _worker(rank, world, port, k, m, S, nobj, lost, data_only, complete, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        from tests.oracle_codec import OracleCodec
+        import garage_amd as g
 
+        codec = g.ReedSolomon(k, m, backend="cpu")
         layout = StripeLayout(k, m, world)
         data = O.splitmix64_bytes(77, nobj * k * S).reshape(nobj, k, S)
         full = np.concatenate([data, np.stack([O.encode(k, m, d) for d in data])], axis=1)
@@ -36,7 +38,7 @@ def _worker(rank, world, port, k, m, S, nobj, lost, data_only, complete, q):
         broken = full.copy()
         broken[:, list(lost)] = 0xEE
         mine = scatter_stripes(torch.from_numpy(broken), layout, rank)
-        out = striped_reconstruct(OracleCodec(k, m), mine, present, layout, data_only=data_only, complete=complete)
+        out = striped_reconstruct(codec, mine, present, layout, data_only=data_only, complete=complete)
         got = gather_stripes(out, layout).numpy()
         want = full.copy()
         if data_only:
@@ -62,8 +64,9 @@ def _worker_a2a(rank, world, port, k, m, S, nobj, lost, data_only, complete, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        from tests.oracle_codec import OracleCodec
+        import garage_amd as g
 
+        codec = g.ReedSolomon(k, m, backend="cpu")
         layout = StripeLayout(k, m, world)
         data = O.splitmix64_bytes(78, nobj * k * S).reshape(nobj, k, S)
         full = np.concatenate([data, np.stack([O.encode(k, m, d) for d in data])], axis=1)
@@ -71,7 +74,7 @@ def _worker_a2a(rank, world, port, k, m, S, nobj, lost, data_only, complete, q):
         broken = full.copy()
         broken[:, list(lost)] = 0xEE
         mine = scatter_stripes(torch.from_numpy(broken), layout, rank)
-        reb = striped_reconstruct_alltoall(OracleCodec(k, m), mine, present, layout, data_only=data_only, complete=complete).numpy()
+        reb = striped_reconstruct_alltoall(codec, mine, present, layout, data_only=data_only, complete=complete).numpy()
         wanted = [j for j in lost if not (data_only and j >= k)]
         ok = reb.shape == (len(wanted), nobj, S)
         off, ln = layout.byte_range(rank, S)
