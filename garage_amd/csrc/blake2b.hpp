@@ -287,11 +287,12 @@ __device__ __forceinline__ uint64_t b2_pin(uint64_t v)
 // arithmetic is left in the compression loop.
 constexpr uint32_t B2Q_SLOT1 = 16 * B2Q_SLOT;
 
-template <bool ODD>
-__device__ __forceinline__ void b2q_compress(uint64_t &ha, uint64_t &hb, const uint32_t (&wa)[10][4], uint32_t q, uint64_t t,
-					     bool last, uint64_t &x, uint64_t &y, bool last_node = false)
+// (b2q_compress_off: the same with the two offsets spelled out -- the fused small-trip kernel, fused.hpp, hashes messages that
+// lie in LDS whole, block i at base + 128 * i: CUR = 0 / 128, NXT = CUR + 128)
+template <uint32_t CUR, uint32_t NXT>
+__device__ __forceinline__ void b2q_compress_off(uint64_t &ha, uint64_t &hb, const uint32_t (&wa)[10][4], uint32_t q, uint64_t t,
+						 bool last, uint64_t &x, uint64_t &y, bool last_node = false)
 {
-	constexpr uint32_t CUR = ODD ? B2Q_SLOT1 : 0, NXT = ODD ? 0 : B2Q_SLOT1;
 	const uint64_t IVq = q == 0 ? 0x6a09e667f3bcc908ULL : q == 1 ? 0xbb67ae8584caa73bULL
 			   : q == 2 ? 0x3c6ef372fe94f82bULL : 0xa54ff53a5f1d36f1ULL;
 	const uint64_t IVq4 = q == 0 ? 0x510e527fade682d1ULL : q == 1 ? 0x9b05688c2b3e6c1fULL
@@ -344,6 +345,13 @@ __device__ __forceinline__ void b2q_compress(uint64_t &ha, uint64_t &hb, const u
 	const uint64_t a = ax - x;  // undo the look-ahead add of the (not yet started) next step
 	ha ^= a ^ c;
 	hb ^= b ^ d;
+}
+
+template <bool ODD>
+__device__ __forceinline__ void b2q_compress(uint64_t &ha, uint64_t &hb, const uint32_t (&wa)[10][4], uint32_t q, uint64_t t,
+					     bool last, uint64_t &x, uint64_t &y, bool last_node = false)
+{
+	b2q_compress_off<(ODD ? B2Q_SLOT1 : 0u), (ODD ? 0u : B2Q_SLOT1)>(ha, hb, wa, q, t, last, x, y, last_node);
 }
 
 // Lane q's 32-byte quarter of the 128-byte block that starts at byte `off` of a `len`-byte message,

@@ -3,6 +3,10 @@
 // (buffer_kb_semaphore, src/block/manager.rs:380-384); one such queue per device of a multi-device manager.
 #include "bm_internal.hpp"
 
+#ifdef __linux__
+#include <sys/prctl.h>
+#endif
+
 using namespace gbmimpl;
 
 // ------------------------------------------------------------------ batcher
@@ -144,7 +148,7 @@ struct gbm_batcher {
 			      int busy_now, size_t nworkers)
 	{
 		const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(max_wait_us);
-		const unsigned gap_us = env().batcher_gap_us ? env().batcher_gap_us : std::max(20u, max_wait_us / 6);
+		const unsigned gap_us = env().batcher_gap_us ? env().batcher_gap_us : std::min(100u, std::max(20u, max_wait_us / 10));
 		const auto gap = std::chrono::microseconds(gap_us);
 		size_t seen = q.size();
 		while (!stopping && q.size() < max_blocks) {
@@ -169,8 +173,17 @@ struct gbm_batcher {
 		return batch;
 	}
 
+	// The linger is a timed wait of a few tens of microseconds; a thread's default timer slack (50 us) would double it.
+	static void precise_timers()
+	{
+#ifdef __linux__
+		(void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
+#endif
+	}
+
 	void run_gets()
 	{
+		precise_timers();
 		std::unique_lock<std::mutex> lk(gmu);
 		for (;;) {
 			gcv_work.wait(lk, [&] { return stop_gets || (!gqueue.empty() && !gforming); });
@@ -248,6 +261,7 @@ struct gbm_batcher {
 
 	void run()
 	{
+		precise_timers();
 		std::unique_lock<std::mutex> lk(mu);
 		for (;;) {
 			// one worker forms a batch at a time; the others are on the device, or wait their turn

@@ -35,7 +35,7 @@ const EnvRow kEnvRows[] = {
 	{"GBM_PUT_THREADS", "4", "put slices in flight"},
 	{"GBM_BATCHER_WORKERS", "2", "batches the coalescing batcher keeps in flight (per device)"},
 	{"GBM_BATCHER_SPLIT_MIN", "16", "a batcher worker that finds this many blocks queued while other workers are idle takes only its share of them (0 = never split)"},
-	{"GBM_BATCHER_GAP_US", "max(20, linger / 6)", "the batcher's linger ends once nobody has arrived for this long (A/B; 0 = the default)"},
+	{"GBM_BATCHER_GAP_US", "clamp(linger / 10, 20, 100)", "the batcher's linger ends once nobody has arrived for this long (A/B; 0 = the default)"},
 	{"GBM_BATCHER_DEVICE_TURN", "1", "1 = one put batch and one get batch of a device's queue on the link at a time, the others prepare / fan out meanwhile (0 = trips overlap freely)"},
 	{"GBM_CPU_BLAKE2", "auto", "the manager's own BLAKE2b (block hashes of small gets, shard checks): auto = eight messages at a time with AVX-512, scalar = one at a time (A/B)"},
 };

@@ -1237,7 +1237,9 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 	ck->used = used;
 	ck->S = S;
 	ck->nleaf = b2host::shardsum_nleaf(S);
-	ck->groups = ck->nleaf >= 16 ? 4 : 1;
+	// pieces of ~100 KiB: smaller ones are over before a helper has even woken up (1 MiB blocks: a shard is one piece and the
+	// walk checks shard 0 itself, 35 us; 4 MiB blocks: four pieces per shard)
+	ck->groups = std::min<size_t>(8, std::max<size_t>(1, S / (96u << 10)));
 	ck->dig.assign(used.size(), std::vector<uint8_t>(ck->nleaf * 64));
 	ck->left.reset(new std::atomic<int>[used.size()]);
 	for (size_t e = 0; e < used.size(); ++e)

@@ -540,7 +540,8 @@ int launch_fused(const gec_codec *c, Staging &st, size_t nblocks, const uint8_t 
 	const int mw = nout <= 4 ? 1 : 2;
 	const size_t lds = fused_lds_bytes(k, nh, mw);
 	using Kern = void (*)(const gec::FusedArgs, const gec::LogExp *);
-	const Kern kern = mw == 1 ? (Kern)gec::gf_ptrs_hash<1, 5> : (Kern)gec::gf_ptrs_hash<2, 5>;
+	// k <= 10 with 4-byte entries: all of a tile's loads in ONE batch (a small trip is a few link round trips long)
+	const Kern kern = mw == 1 ? (k <= 10 ? (Kern)gec::gf_ptrs_hash<1, 10> : (Kern)gec::gf_ptrs_hash<1, 5>) : (Kern)gec::gf_ptrs_hash<2, 5>;
 	if (lds > (48u << 10)) {  // beyond the default limit: opt in, once per kernel and device
 		static std::mutex mu;
 		static std::set<std::pair<const void *, int>> opted;

@@ -27,72 +27,46 @@
 
 namespace gec {
 
-// One BLAKE2b compression of the 128-byte block at LDS byte address `blk`, four lanes per message: lane q owns column q
-// of the 4x4 state.  wo[r][i] = byte offset inside the block of the message word this lane needs at round r (column x,
-// column y, diagonal x, diagonal y).
-__device__ __forceinline__ void b2q_compress_at(uint64_t &ha, uint64_t &hb, uint32_t blk, const uint32_t (&wo)[10][4], uint32_t q,
-						uint64_t t, bool last, bool last_node)
-{
-	const uint64_t IVq = q == 0 ? 0x6a09e667f3bcc908ULL : q == 1 ? 0xbb67ae8584caa73bULL
-			   : q == 2 ? 0x3c6ef372fe94f82bULL : 0xa54ff53a5f1d36f1ULL;
-	const uint64_t IVq4 = q == 0 ? 0x510e527fade682d1ULL : q == 1 ? 0x9b05688c2b3e6c1fULL
-			    : q == 2 ? 0x1f83d9abfb41bd6bULL : 0x5be0cd19137e2179ULL;
-	uint64_t a = ha, b = hb, c = IVq, d = IVq4;
-	if (q == 0)
-		d ^= t;
-	if (q == 2 && last)
-		d = ~d;
-	if (q == 3 && last && last_node)
-		d = ~d;
-#define GEC_FW(r, i) (*reinterpret_cast<lds_u64_t *>(blk + wo[(r) % 10][i]))
-#define GEC_FG(x, y)                  \
-	{                             \
-		a = a + b + (x);      \
-		d = b2_rotr<32>(d ^ a); \
-		c = c + d;            \
-		b = b2_rotr<24>(b ^ c); \
-		a = a + b + (y);      \
-		d = b2_rotr<16>(d ^ a); \
-		c = c + d;            \
-		b = b2_rotr<63>(b ^ c); \
-	}
-	uint64_t cx = GEC_FW(0, 0), cy = GEC_FW(0, 1), dx = GEC_FW(0, 2), dy = GEC_FW(0, 3);
-#pragma unroll
-	for (int r = 0; r < 12; ++r) {
-		uint64_t ncx = 0, ncy = 0, ndx = 0, ndy = 0;
-		if (r < 11) {  // next round's words are gathered a round ahead: one wait per round
-			ncx = GEC_FW(r + 1, 0);
-			ncy = GEC_FW(r + 1, 1);
-			ndx = GEC_FW(r + 1, 2);
-			ndy = GEC_FW(r + 1, 3);
-		}
-		GEC_FG(cx, cy)
-		b = b2_quad_perm<0x39>(b);
-		c = b2_quad_perm<0x4E>(c);
-		d = b2_quad_perm<0x93>(d);
-		GEC_FG(dx, dy)
-		b = b2_quad_perm<0x93>(b);
-		c = b2_quad_perm<0x4E>(c);
-		d = b2_quad_perm<0x39>(d);
-		cx = ncx;
-		cy = ncy;
-		dx = ndx;
-		dy = ndy;
-	}
-#undef GEC_FG
-#undef GEC_FW
-	ha ^= a ^ c;
-	hb ^= b ^ d;
-}
-
-// `nblk` blocks of a message resident in LDS at `msg`; t_before = bytes of the message hashed before them; `finishes`:
-// the message (total_len bytes) ends inside this piece.
+// `nblk` blocks of a message that lies in LDS at byte address `msg`, four lanes per message (lane q owns column q of the
+// 4x4 state), with blake2b.hpp's compression: the message words of a round gathered a round ahead, the first words of the
+// NEXT block during the last round of the current one, (a + x) formed off the dependency chain.  wa[r][i] = LDS address of
+// the word this lane needs at round r of block 0; two blocks per trip (immediate offsets 0 / 128 / 256 on the ds_reads),
+// then all forty addresses move on by 256.  t_before = bytes of the message hashed before these blocks; `finishes`: the
+// message (total_len bytes) ends with them.  (The look-ahead reads up to 128 bytes past the last block: LDS, harmless.)
 __device__ __forceinline__ void b2q_hash_lds(uint64_t &ha, uint64_t &hb, uint32_t msg, uint32_t nblk, uint64_t t_before,
-					     uint64_t total_len, bool finishes, bool last_node, const uint32_t (&wo)[10][4], uint32_t q)
+					     uint64_t total_len, bool finishes, bool last_node, uint32_t q)
 {
-	for (uint32_t i = 0; i < nblk; ++i) {
+	constexpr B2QSchedule SCH = b2q_schedule();
+	const uint32_t q7 = q * 7;
+	uint32_t wa[10][4];
+#pragma unroll
+	for (int r = 0; r < 10; ++r)
+#pragma unroll
+		for (int w = 0; w < 4; ++w) {
+			wa[r][w] = msg + __builtin_amdgcn_ubfe(SCH.w[r][w], q7, 7);
+			asm("" : "+v"(wa[r][w]));  // opaque: otherwise the sums are re-formed inside the loop
+		}
+	uint64_t x = *reinterpret_cast<lds_u64_t *>(wa[0][0]), y = *reinterpret_cast<lds_u64_t *>(wa[0][1]);
+	uint32_t i = 0;
+	// pairs with nothing to decide: neither block is the message's last
+	const uint32_t plain = finishes ? (nblk ? nblk - 1 : 0) : nblk;  // blocks that are certainly not final
+	for (; i + 2 <= plain; i += 2) {
+		b2q_compress_off<0, 128>(ha, hb, wa, q, t_before + 128ull * (i + 1), false, x, y);
+		b2q_compress_off<128, 256>(ha, hb, wa, q, t_before + 128ull * (i + 2), false, x, y);
+#pragma unroll
+		for (int r = 0; r < 10; ++r)
+#pragma unroll
+			for (int w = 0; w < 4; ++w)
+				wa[r][w] += 256;
+	}
+	for (; i < nblk; ++i) {  // the last one or two
 		const bool last = finishes && i + 1 == nblk;
-		b2q_compress_at(ha, hb, msg + 128 * i, wo, q, last ? total_len : t_before + 128ull * (i + 1), last, last_node);
+		b2q_compress_off<0, 128>(ha, hb, wa, q, last ? total_len : t_before + 128ull * (i + 1), last, x, y, last_node);
+#pragma unroll
+		for (int r = 0; r < 10; ++r)
+#pragma unroll
+			for (int w = 0; w < 4; ++w)
+				wa[r][w] += 128;
 	}
 }
 
@@ -224,16 +198,6 @@ __global__ __launch_bounds__(256) void gf_ptrs_hash(const FusedArgs a, const Log
 		}
 		__syncthreads();
 		// ---- the tile's leaves, out of LDS
-		uint32_t wo[10][4];
-		{
-			constexpr B2QSchedule SCH = b2q_schedule();
-			const uint32_t q7 = q * 7;
-#pragma unroll
-			for (int r = 0; r < 10; ++r)
-#pragma unroll
-				for (int w = 0; w < 4; ++w)
-					wo[r][w] = __builtin_amdgcn_ubfe(SCH.w[r][w], q7, 7);
-		}
 		if (hashes) {
 			const uint32_t left = (a.cols - tx * 256) * 16;
 			const uint32_t len = left < SHARDSUM_LEAF ? left : SHARDSUM_LEAF;
@@ -241,7 +205,7 @@ __global__ __launch_bounds__(256) void gf_ptrs_hash(const FusedArgs a, const Log
 				    : q == 2 ? 0x3c6ef372fe94f82bULL ^ SHARDSUM_P2_LEAF : 0xa54ff53a5f1d36f1ULL;
 			uint64_t hb = q == 0 ? 0x510e527fade682d1ULL : q == 1 ? 0x9b05688c2b3e6c1fULL
 				    : q == 2 ? 0x1f83d9abfb41bd6bULL : 0x5be0cd19137e2179ULL;
-			b2q_hash_lds(ha, hb, my_msg, (len + 127) / 128, 0, len, true, tx + 1 == a.tiles_x, wo, q);
+			b2q_hash_lds(ha, hb, my_msg, (len + 127) / 128, 0, len, true, tx + 1 == a.tiles_x, q);
 			uint64_t *o = reinterpret_cast<uint64_t *>(a.leafdig + (((size_t)b * nh + hj) * a.tiles_x + tx) * 64);
 			o[q] = ha;
 			o[4 + q] = hb;
@@ -270,7 +234,7 @@ __global__ __launch_bounds__(256) void gf_ptrs_hash(const FusedArgs a, const Log
 				}
 				__syncthreads();
 				if (hashes)
-					b2q_hash_lds(ha, hb, my_msg, (bytes + 127) / 128, off, total, off + SHARDSUM_LEAF >= total, true, wo, q);
+					b2q_hash_lds(ha, hb, my_msg, (bytes + 127) / 128, off, total, off + SHARDSUM_LEAF >= total, true, q);
 				__syncthreads();
 			}
 			if (hashes)

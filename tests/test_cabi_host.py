@@ -97,12 +97,17 @@ def test_backends_without_a_gpu():
     assert rs.backend == "cpu" and rs.device == -1
     h = ctypes.c_void_p()
     assert _lib.lib.gec_codec_create(10, 4, 7, 0, ctypes.byref(h)) == _lib.GEC_E_INVALID_ARG
-    # no *_dev, no groups on a CPU codec
+    # no device-resident encode / verify / hashing on a CPU codec, and no RCCL group (RCCL moves device memory) ...
     buf = np.zeros(14 * 64 + 64, dtype=np.uint8)
     base = (buf.ctypes.data + 15) // 16 * 16
     assert _lib.lib.gec_encode_batch_dev(rs._h, 1, base, 14 * 64, 64, base + 640, 14 * 64, None) == _lib.GEC_E_DEVICE
+    ident = (ctypes.c_uint8 * _lib.GEC_GROUP_ID_BYTES)()
+    assert _lib.lib.gec_group_create(rs._h, 0, 1, ident, ctypes.byref(h)) == _lib.GEC_E_DEVICE
+    # ... but a group over a caller transport works on host buffers (round 4: a rank that lost its GPU stays in the group;
+    # tests/test_group_multiprocess.py drives it with real processes), and so does the strided reconstruct
     fn = _lib.ALLGATHER_FN(lambda *a: 0)
-    assert _lib.lib.gec_group_create_with_transport(rs._h, 0, 1, fn, None, ctypes.byref(h)) == _lib.GEC_E_DEVICE
+    assert _lib.lib.gec_group_create_with_transport(rs._h, 0, 1, fn, None, ctypes.byref(h)) == _lib.GEC_OK
+    _lib.lib.gec_group_destroy(h)
     # a background sibling keeps code and backend
     bg = rs.background()
     assert bg.backend == "cpu" and bg.qos_class == _lib.GEC_CLASS_BACKGROUND and rs.qos_class == _lib.GEC_CLASS_FOREGROUND
