@@ -84,7 +84,7 @@ def _load():
     lib.gbm_shardsum.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p]
     lib.gbm_shardsum.restype = None
     lib.gbm_blake2sum_batch.argtypes = [sz, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p]
-    lib.gbm_blake2sum_batch.restype = None
+    lib.gbm_blake2sum_batch.restype = ctypes.c_int
     lib.gbm_create.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), ci, pp]
     lib.gbm_destroy.argtypes = [vp]
     lib.gbm_destroy.restype = None
@@ -190,7 +190,7 @@ def blake2sum_batch(blocks) -> list:
     ptrs = (ctypes.c_char_p * n)(*blocks)
     lens = (ctypes.c_size_t * n)(*[len(b) for b in blocks])
     out = ctypes.create_string_buffer(32 * n)
-    lib.gbm_blake2sum_batch(n, ptrs, lens, out)
+    _check(lib.gbm_blake2sum_batch(n, ptrs, lens, out), "gbm_blake2sum_batch")
     return [out.raw[32 * i:32 * i + 32] for i in range(n)]
 
 

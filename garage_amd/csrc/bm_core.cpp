@@ -36,6 +36,7 @@ const EnvRow kEnvRows[] = {
 	{"GBM_BATCHER_WORKERS", "2", "batches the coalescing batcher keeps in flight (per device)"},
 	{"GBM_BATCHER_SPLIT_MIN", "16", "a batcher worker that finds this many blocks queued while other workers are idle takes only its share of them (0 = never split)"},
 	{"GBM_BATCHER_GAP_US", "clamp(linger / 10, 20, 100)", "the batcher's linger ends once nobody has arrived for this long (A/B; 0 = the default)"},
+	{"GBM_BATCHER_LONE_SKIP", "1", "1 = a block that arrives alone (nothing in flight, the previous batch a single block) goes without the linger (0 = always linger; A/B)"},
 	{"GBM_BATCHER_DEVICE_TURN", "1", "1 = one put batch and one get batch of a device's queue on the link at a time, the others prepare / fan out meanwhile (0 = trips overlap freely)"},
 	{"GBM_CPU_BLAKE2", "auto", "the manager's own BLAKE2b (block hashes of small gets, shard checks): auto = eight messages at a time with AVX-512, scalar = one at a time (A/B)"},
 };
@@ -60,6 +61,7 @@ const Env &env()
 		const long sm = env_long("GBM_BATCHER_SPLIT_MIN", 16);
 		v.batcher_split_min = (size_t)(sm >= 0 ? sm : 16);
 		v.batcher_device_turn = env_long("GBM_BATCHER_DEVICE_TURN", 1) != 0;
+		v.batcher_lone_skip = env_long("GBM_BATCHER_LONE_SKIP", 1) != 0;
 		const long gp = env_long("GBM_BATCHER_GAP_US", 0);
 		v.batcher_gap_us = (unsigned)(gp > 0 && gp < 100000 ? gp : 0);
 		const char *b2 = std::getenv("GBM_CPU_BLAKE2");
@@ -374,14 +376,38 @@ const char *gbm_last_error(void) { return last_error().c_str(); }
 
 const char *gbm_env_table(void) { return env_table_text(); }
 
-void gbm_blake2sum(const uint8_t *data, size_t len, uint8_t out[32]) { blake2sum(data, len, out); }
-
-void gbm_shardsum(const uint8_t *data, size_t len, uint8_t out[32]) { shardsum(data, len, out); }
-
-void gbm_blake2sum_batch(size_t n, const uint8_t *const *data, const size_t *len, uint8_t *out)
+void gbm_blake2sum(const uint8_t *data, size_t len, uint8_t out[32])
 {
-	if (n && data && len && out)
+	if (out && (data || len == 0))
+		blake2sum(data, len, out);  // (no allocation: nothing to throw)
+}
+
+void gbm_shardsum(const uint8_t *data, size_t len, uint8_t out[32])
+{
+	if (!out || (!data && len))
+		return;
+	try {
+		shardsum(data, len, out);
+	} catch (const std::exception &) {  // the eight-lane form's scratch could not grow: one leaf at a time needs none
+		b2host::shardsum(data, len, out);
+	}
+}
+
+int gbm_blake2sum_batch(size_t n, const uint8_t *const *data, const size_t *len, uint8_t *out)
+{
+	if (n == 0)
+		return GBM_OK;
+	if (!data || !len || !out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	for (size_t i = 0; i < n; ++i)
+		if (!data[i] && len[i])
+			return fail(GBM_E_INVALID_ARG, "NULL message pointer");
+	try {
 		b2host::blake2sum_many(data, len, n, out);
+	} catch (const std::exception &e) {  // nothing may unwind across the C ABI
+		return fail(GBM_E_IO, std::string("gbm_blake2sum_batch: ") + e.what());
+	}
+	return GBM_OK;
 }
 
 int gbm_create(const gec_codec *codec, int nnodes, const char *const *node_dirs, int write_quorum, gbm_manager **out)

@@ -56,6 +56,7 @@ struct Env {
 	size_t batcher_split_min; // GBM_BATCHER_SPLIT_MIN
 	bool batcher_device_turn; // GBM_BATCHER_DEVICE_TURN
 	unsigned batcher_gap_us;  // GBM_BATCHER_GAP_US
+	bool batcher_lone_skip;   // GBM_BATCHER_LONE_SKIP
 };
 const Env &env();
 const char *env_table_text();

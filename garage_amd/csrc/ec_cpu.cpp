@@ -21,7 +21,10 @@
 // 1 MiB block keeps several cores busy.
 #include "ec_internal.hpp"
 
+#if defined(__x86_64__) || defined(_M_X64)
+#define GEC_CPU_X86 1
 #include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <map>
@@ -36,9 +39,13 @@ enum Isa { ISA_SCALAR = 0, ISA_AVX2 = 1, ISA_GFNI512 = 2 };
 
 Isa detect_isa()
 {
+#ifdef GEC_CPU_X86
 	__builtin_cpu_init();
 	const bool avx2 = __builtin_cpu_supports("avx2");
 	const bool gfni512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("gfni");
+#else  // any other host: the scalar kernel (the vector kernels below are x86 intrinsics and are not even compiled)
+	const bool avx2 = false, gfni512 = false;
+#endif
 	const std::string &want = env().cpu_isa;
 	if (want == "scalar")
 		return ISA_SCALAR;
@@ -124,6 +131,7 @@ struct Program {
 // ---- kernels: out[r][0..len) = XOR_t coef[r][t] * in[t][0..len) for the R rows of one pass.
 // `active` lists the inputs that have bytes in this range (a zero input contributes nothing).
 
+#ifdef GEC_CPU_X86
 template <int R>
 __attribute__((target("avx512f,avx512bw,gfni"))) void pass_gfni(const uint8_t *const *in, const int *active, int nactive,
 								 const uint64_t *mat /* [t][8] of this pass */, uint8_t *const *out, size_t len)
@@ -209,11 +217,13 @@ __attribute__((target("avx2"))) void pass_avx2(const uint8_t *const *in, const i
 	if (pos < len)
 		scalar_range(in, active, nactive, coef, k, row0, R, out, pos, len);
 }
+#endif  // GEC_CPU_X86
 
 template <int R>
 void run_pass(const Program &p, int pass, const uint8_t *const *in, const int *active, int nactive, uint8_t *const *out, size_t len)
 {
 	switch (isa()) {
+#ifdef GEC_CPU_X86
 	case ISA_GFNI512:
 		pass_gfni<R>(in, active, nactive, p.affine.data() + (size_t)pass * p.k * kRowsPerPass, out, len);
 		break;
@@ -221,6 +231,7 @@ void run_pass(const Program &p, int pass, const uint8_t *const *in, const int *a
 		pass_avx2<R>(in, active, nactive, p.nibbles.data() + (size_t)pass * p.k * kRowsPerPass * 32, out, len, p.coef.data(), p.k,
 			     pass * kRowsPerPass);
 		break;
+#endif
 	default:
 		scalar_range(in, active, nactive, p.coef.data(), p.k, pass * kRowsPerPass, R, out, 0, len);
 	}

@@ -116,6 +116,7 @@ struct Staging {
 	hipStream_t stream_down = nullptr;
 	hipEvent_t ev_dec[kMaxSeg] = {};  // "the decodes of stage s are done"
 	int cus_up = 0, cus_chain = 0, cus_down = 0;  // CUs of the three masked streams (0 = that stream has no mask)
+	bool seg_split = false;  // the masks were made for "a background class exists on this device"
 	QosPolicy qos;  // set by the lease from the codec's class before anything is created
 
 	int ensure_segments(int num_cu);
@@ -219,6 +220,10 @@ struct StagingLease {
 	explicit StagingLease(const gec_codec *cc);
 	~StagingLease();
 };
+
+// a BACKGROUND-class codec was created on / removed from `device` (the CU partition between the classes follows)
+void background_codec_born(int device);
+void background_codec_gone(int device);
 
 // RAII: a foreground host-pointer call is in flight on this codec's device (no-op for a background codec)
 // What every host-pointer entry point of the HIP backend holds for its duration: a call permit of its codec (at most

@@ -161,6 +161,8 @@ Backend *HipBackend::small_call_helper() const
 
 HipBackend::~HipBackend()
 {
+	if (qos.background)
+		background_codec_gone(device);
 	DeviceGuard g(device);
 	for (auto &s : pool)
 		s.release();
@@ -207,6 +209,7 @@ int make_hip_backend(gec_codec *c, int device, std::unique_ptr<Backend> &out)
 		else
 			(void)hipGetLastError();
 		hb->qos.compute_cus = env().bg_cus > 0 && env().bg_cus < hb->num_cu ? env().bg_cus : 0;
+		background_codec_born(device);
 	}
 	gec::LogExp le;
 	const gec::Field &f = gec::field();

@@ -56,7 +56,22 @@ PinnedRanges &pinned()
 
 namespace {
 std::atomic<int> g_cu_masks{-1};  // gec_cu_masks_active: -1 not tried yet, 0 refused by the runtime, 1 masks, 2 masks + class partition
+// BACKGROUND-class codecs alive per device: the class partition of the CUs is only applied while there is one -- a
+// process that never scrubs or resyncs keeps the whole chip for the request path's checksum kernels
+std::atomic<int> g_bg_codecs[64];
 }
+
+void background_codec_born(int device)
+{
+	if (device >= 0 && device < 64)
+		g_bg_codecs[device].fetch_add(1);
+}
+void background_codec_gone(int device)
+{
+	if (device >= 0 && device < 64)
+		g_bg_codecs[device].fetch_sub(1);
+}
+static bool background_class_present(int device) { return device >= 0 && device < 64 && g_bg_codecs[device].load() > 0; }
 
 // ------------------------------------------------------------------ staging slots
 // Every stream of a slot is created here, so that the codec's class decides priority and CU mask in one place: a
@@ -85,12 +100,27 @@ int Staging::make_stream(hipStream_t *s)
 
 int Staging::ensure_segments(int num_cu)
 {
-	if (stream3)
+	// the masks follow the device's class situation: created for "no background class here" (the request path's checksum
+	// kernels get every CU the link kernels do not use), they are made again the first time the slot is used after a
+	// BACKGROUND codec appeared on the device (the slot is on loan to one call: nothing of it is in flight here)
+	const bool want_split = qos.background || background_class_present(qos.device);
+	if (stream3 && seg_split == want_split)
 		return GEC_OK;
-	for (int i = 0; i < kMaxSeg; ++i) {
-		HIP_TRY(hipEventCreateWithFlags(&ev_seg[i], hipEventDisableTiming));
-		HIP_TRY(hipEventCreateWithFlags(&ev_dec[i], hipEventDisableTiming));
+	if (stream3) {
+		for (hipStream_t *s : {&stream_up, &stream_chain, &stream_down})
+			if (*s) {
+				(void)hipStreamSynchronize(*s);
+				(void)hipStreamDestroy(*s);
+				*s = nullptr;
+			}
+		cus_up = cus_chain = cus_down = 0;
+	} else {
+		for (int i = 0; i < kMaxSeg; ++i) {
+			HIP_TRY(hipEventCreateWithFlags(&ev_seg[i], hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&ev_dec[i], hipEventDisableTiming));
+		}
 	}
+	seg_split = want_split;
 	const int up_cus = env().upload_cus;  // 0 = no CU masks (A/B)
 	if (up_cus > 0 && up_cus < num_cu) {
 		// The chip is partitioned once, the same way for every codec of the process (CuPlan), so that the classes
@@ -105,7 +135,7 @@ int Staging::ensure_segments(int num_cu)
 		// was what its p99 was made of (profiles/r03_qos.txt).  Without a usable partition (tiny device, B = 0) the
 		// background class falls back to sharing the foreground's CUs at the lowest stream priority.
 		const int words = (num_cu + 31) / 32;
-		const int U = up_cus, B = qos.compute_cus_plan;
+		const int U = up_cus, B = want_split ? qos.compute_cus_plan : 0;
 		const bool split = B > 0 && 2 * U + U / 2 + B + 16 <= num_cu && U >= 2;
 		auto mask = [&](int lo, int hi) {
 			std::vector<uint32_t> m(words, 0);
@@ -127,6 +157,9 @@ int Staging::ensure_segments(int num_cu)
 			if (down_hi > U)
 				down = mask(U, down_hi);
 			rest = mask(down_hi, num_cu);
+			// (no partition: a background codec's checksum kernels still keep to their own CUs, the chip's last ones)
+			if (qos.background && qos.compute_cus > 0 && qos.compute_cus < num_cu - down_hi)
+				rest = mask(num_cu - qos.compute_cus, num_cu);
 		}
 		// (a runtime or partition mode without CU masks is not an error: the paths then share all CUs, slower)
 		if (hipExtStreamCreateWithCUMask(&stream_up, (uint32_t)words, up.data()) != hipSuccess)
@@ -155,7 +188,7 @@ int Staging::ensure_segments(int num_cu)
 		if (stream_down)
 			cus_down = bits(down);
 	}
-	return make_stream(&stream3);
+	return stream3 ? GEC_OK : make_stream(&stream3);
 }
 
 int Staging::cus_of(hipStream_t s) const

@@ -92,8 +92,9 @@ void gbm_shardsum(const uint8_t *data, size_t len, uint8_t out[32]);
 /* blake2sum of n buffers on the calling thread, out[32 * i] for buffer i: the content hashes of a PutObject's blocks,
  * which the API layer computes before it calls rpc_put_block (src/api/s3/put.rs).  BLAKE2b is one serial chain per
  * message, but eight messages fit the eight lanes of an AVX-512 register: n >= 2 blocks cost about as much as one
- * (GBM_CPU_BLAKE2=scalar: one at a time). */
-void gbm_blake2sum_batch(size_t n, const uint8_t *const *data, const size_t *len, uint8_t *out);
+ * (GBM_CPU_BLAKE2=scalar: one at a time).  GBM_OK, GBM_E_INVALID_ARG (a NULL pointer with a non-zero length: nothing is
+ * written) or GBM_E_IO (out of memory). */
+int gbm_blake2sum_batch(size_t n, const uint8_t *const *data, const size_t *len, uint8_t *out);
 
 /* node_dirs == NULL: in-memory nodes; otherwise nnodes directory roots using
  * Garage's naming <root>/<h0>/<h1>/<hex>.s<idx> (src/block/layout.rs:286-291).

@@ -573,6 +573,10 @@ def test_batcher_read_side_coalesces_concurrent_gets(backend):
     hashes = [bn.blake2sum(b) for b in blocks]
     mgr.rpc_put_blocks(list(zip(hashes, blocks)))
     got = [None] * len(blocks)
+    # (a block that arrives alone goes at once, and six Python threads fetching 20 KB blocks from memory never overlap:
+    # the nodes answer after 2 ms, like disks, so that the readers do)
+    for nd in range(8):
+        mgr.node_set_latency(nd, 2000)
 
     def reader(t):
         for i in range(t, len(blocks), 6):
@@ -586,6 +590,8 @@ def test_batcher_read_side_coalesces_concurrent_gets(backend):
     assert got == blocks
     st = bt.get_stats()
     assert st["blocks"] == len(blocks) and st["batches"] <= st["blocks"] and st["max_batch"] >= 2
+    for nd in range(8):
+        mgr.node_set_latency(nd, 0)
     with pytest.raises(bn.BlockError) as e:
         bt.get_block(b"\x5a" * 32, 100)
     assert e.value.code == bn.GBM_E_MISSING_BLOCK
