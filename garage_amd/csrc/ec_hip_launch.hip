@@ -439,6 +439,11 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 		else
 			kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, false> : (Kern)gec::gf_apply_ptrs<2, 5, false>;
 		const unsigned grid = resident_grid(st, stream, a.tiles_total, lds);
+		// a background codec's rows into HOST memory are paced (GEC_BG_HOME_RATE_GBPS): `grid` resident workgroups, each
+		// writing rows * 4 KiB per tile, start a tile every grid * rows * 4096 / rate nanoseconds
+		a.pace_ticks = 0;
+		if (st.qos.background && !bad && env().bg_home_rate_gbps > 0 && nblocks && pinned().contains(out[0], S))
+			a.pace_ticks = (uint32_t)std::min<uint64_t>((uint64_t)grid * rows * 4096ull / env().bg_home_rate_gbps / 10, 1u << 24);
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, hb.d_logexp);
 		HIP_TRY(hipGetLastError());
 	}
@@ -579,7 +584,10 @@ int launch_copy_table(Staging &st, const std::vector<gec::CopyEntry> &ents, hipS
 	unsigned grid = resident_grid(st, stream, total);
 	if (max_wgs > 0)
 		grid = std::min(grid, max_wgs);
-	const unsigned pace = max_wgs > 0 ? pace_ns : 0;
+	unsigned pace = max_wgs > 0 ? pace_ns : 0;
+	// a background codec's copies INTO host memory keep to GEC_BG_HOME_RATE_GBPS like its link kernels' rows do
+	if (pace == 0 && st.qos.background && env().bg_home_rate_gbps > 0 && pinned().contains(ents[0].dst, 1))
+		pace = (unsigned)std::min<uint64_t>((uint64_t)grid * 16384ull / env().bg_home_rate_gbps, 10000000ull);
 	uint32_t *busy = nullptr, role = 0, wait_ticks = 0;
 	link_role_of(st, pace, &busy, &role, &wait_ticks);
 	hipLaunchKernelGGL(gec::copy_table, dim3(grid), dim3(256), 0, stream, tab, (uint32_t)gx, total, pace / 10, busy, role, wait_ticks);

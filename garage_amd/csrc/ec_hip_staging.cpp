@@ -360,7 +360,7 @@ void link_role_of(const Staging &st, unsigned pace_ns, uint32_t **busy, uint32_t
 	*role = gec::LINK_NONE;
 	*wait_ticks = 0;
 	const unsigned wait_us = env().bg_link_wait_us;
-	if (wait_us == 0 || pace_ns != 0)
+	if (wait_us == 0 || (pace_ns != 0 && !st.qos.background))  // (a background kernel gives way even when it is paced)
 		return;
 	uint32_t *c = link_busy_counter(st.qos.device);
 	if (!c)

@@ -71,6 +71,10 @@ struct PtrApplyArgs {
 	// link_wait_ticks (10 ns each) per workgroup and launch, so that it always finishes.
 	uint32_t *link_busy;
 	uint32_t link_role, link_wait_ticks;
+	// pace_ticks > 0 (10 ns each): a workgroup starts its i-th tile no earlier than i * pace_ticks after its first -- a
+	// BACKGROUND codec's rows on their way into host memory (resync's rebuilt shards) must not fill the fabric's queues
+	// towards the link with posted writes: every load of the request path waits behind them (GEC_BG_HOME_RATE_GBPS)
+	uint32_t pace_ticks;
 	// MIRROR: everything the kernel reads and computes is also laid down in device memory, dense --
 	// mirror + b*mirror_stride + t*16*cols for input shard t (first row group only: mirror_inputs),
 	// ... + mirror_row0 + r*16*cols for output row r -- so that the shard checksums can be computed from

@@ -460,6 +460,8 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrAppl
 	}
 	__syncthreads();
 
+	const uint64_t pace_t0 = a.pace_ticks ? wall_clock64() : 0;
+	uint32_t turn = 0;
 	for (;;) {  // one tile per turn; no barrier in here (the tables are read-only from now on)
 		u32x4 *mir = MIRROR ? reinterpret_cast<u32x4 *>(a.mirror + (size_t)b * a.mirror_stride) + col : nullptr;
 		const bool mir_in = MIRROR && live && a.mirror_inputs;
@@ -510,6 +512,11 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrAppl
 		const uint32_t *nvalid = a.in_valid + (size_t)nb * k;
 		if (more)
 			wait_left = link_yield(a.link_busy, a.link_role, wait_left);
+		if (more && a.pace_ticks) {  // (before the next tile's loads: a paced kernel's reads keep the same beat as its writes)
+			++turn;
+			while (wall_clock64() - pace_t0 < (uint64_t)turn * a.pace_ticks)
+				__builtin_amdgcn_s_sleep(16);
+		}
 		if (more) {
 #pragma unroll
 			for (int j = 0; j < KC; ++j) {

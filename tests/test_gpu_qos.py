@@ -68,6 +68,26 @@ def test_puts_keep_their_latency_beside_a_scrub_on_the_background_class():
         assert with_x <= 2.0, r.stdout        # masks the classes share every CU and only priority / chunks / yields are left
 
 
+@pytest.mark.gpu
+def test_degraded_gets_keep_their_latency_beside_a_resync_that_writes_shards_home():
+    """degraded reads (4 of 16 nodes down: every get goes through a decode whose rebuilt shards
+    travel home over the link) beside a continuous resync on the BACKGROUND class, whose own rebuilt shards are written
+    into host memory at no more than GEC_BG_HOME_RATE_GBPS.  profiles/r04_qos_get.txt has the numbers; the bounds asserted
+    here are loose: with the class the gets' p99 must not be worse than without it, and must stay within 2x of solo."""
+    exe = os.path.join(ROOT, "tools", "qos_bench")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "qos_bench"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([exe, "3", "1.5", "256", "0", "4", "0", "4", "resync"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout)
+    m_with = re.search(r"with the class:\s+get p99 ([0-9.]+)x solo, scrub at (\d+) % of its solo rate", r.stdout)
+    m_without = re.search(r"without the class:\s+get p99 ([0-9.]+)x solo", r.stdout)
+    assert m_with and m_without and "backend hip" in r.stdout and "4 of 16 nodes down" in r.stdout, r.stdout
+    with_x, maint_pct, without_x = float(m_with.group(1)), int(m_with.group(2)), float(m_without.group(1))
+    assert maint_pct >= 30, r.stdout
+    assert with_x < max(without_x, 1.6) and with_x <= 2.0, r.stdout
+
+
 _BG_SCRIPT = r"""
 import sys, ctypes, numpy as np
 sys.path.insert(0, %r)

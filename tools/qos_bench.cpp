@@ -8,7 +8,11 @@
 // (gec_codec_background: low-priority CU-masked streams, small chunks that yield to foreground calls); both with
 // maintenance on the request path's own codec (gbm_set_maintenance_class(m, 0): round 2's behaviour).
 // Reports put p50 / p99 / rate and the scrub rate of each phase.
-// usage: qos_bench [callers=3] [seconds=3] [scrub_blocks=512] [tranquility=0] [get_blocks=0] [gets_via_batcher=0]
+// usage: qos_bench [callers=3] [seconds=3] [scrub_blocks=512] [tranquility=0] [get_blocks=0] [gets_via_batcher=0] [nodes_down=0] [maintenance=scrub|resync]
+// nodes_down = D > 0 (with get_blocks): D of manager A's 16 nodes are down -- the gets are DEGRADED reads, every one of them
+// goes through a decode whose rebuilt shards travel home over the link;
+// maintenance = resync: instead of a scrub, manager B keeps losing one shard of every block and gbm_resync_run rebuilds
+// them (gather k, ONE reconstruct trip, the rebuilt shards written into host memory: the background class's WRITES).
 // get_blocks = G > 0: the callers are readers instead -- each keeps fetching G of its blocks with one gbm_rpc_get_blocks (a
 // GetObject with its prefetch), block-hash check on -- and the latencies reported are those of the gets;
 // gets_via_batcher = 1 (with get_blocks = 1): every reader fetches one block at a time through gbm_batcher_get_block, the
@@ -50,6 +54,8 @@ int main(int argc, char **argv)
 	const int tranq = argc > 4 ? atoi(argv[4]) : 0;
 	const int get_blocks = argc > 5 ? atoi(argv[5]) : 0;
 	const bool gets_via_batcher = argc > 6 && atoi(argv[6]) != 0 && get_blocks == 1;
+	const int nodes_down = argc > 7 ? atoi(argv[7]) : 0;
+	const bool resync_mode = argc > 8 && std::string(argv[8]) == "resync";
 	gec_codec *c = nullptr;
 	gbm_manager *ma = nullptr, *mb = nullptr;
 	if (gec_codec_create(10, 4, GEC_BACKEND_AUTO, 0, &c) != GEC_OK || gbm_create(c, 16, NULL, 0, &ma) != GBM_OK ||
@@ -59,6 +65,7 @@ int main(int argc, char **argv)
 	}
 	gbm_set_tranquility(mb, tranq, -1);
 	// ---- manager B: the blocks the scrub walks
+	std::vector<uint8_t> bhashes(nscrub * 32);
 	{
 		std::vector<std::vector<uint8_t>> blk(64, std::vector<uint8_t>(L));
 		std::vector<uint8_t> hashes(64 * 32);
@@ -75,6 +82,9 @@ int main(int argc, char **argv)
 				fprintf(stderr, "preload failed: %s\n", gbm_last_error());
 				return 2;
 			}
+			memcpy(&bhashes[32 * b0], hashes.data(), 32 * nb);
+			for (size_t i = 0; i < nb; ++i)
+				gbm_block_incref(mb, &hashes[32 * i]);  // needed blocks: resync REBUILDS what is missing
 		}
 	}
 	// ---- manager A: every caller rewrites its own ring of 8 blocks (memory stays bounded)
@@ -88,6 +98,7 @@ int main(int argc, char **argv)
 	gbm_batcher *bt = nullptr;
 	if (gbm_batcher_create(ma, 128, 300, &bt) != GBM_OK)
 		return 2;
+	gbm_set_verify_block_hash(ma, GBM_VERIFY_OFF);
 	std::atomic<bool> stop{false};
 	const char *op = get_blocks > 0 ? "get" : "put";
 	if (get_blocks > 0) {  // readers: their blocks have to be there first
@@ -101,7 +112,11 @@ int main(int argc, char **argv)
 			fprintf(stderr, "preload failed: %s\n", gbm_last_error());
 			return 2;
 		}
+		for (int dn = 0; dn < nodes_down; ++dn)
+			gbm_node_set_down(ma, 3 + 4 * dn, 1);
 	}
+	for (int d = 0; d < nodes_down && get_blocks > 0; ++d)  // (after the preload below would be too late to matter: done there)
+		(void)d;
 	auto run_gets = [&](PutStats &ps) {
 		std::vector<std::vector<double>> lat(callers);
 		std::vector<std::thread> th;
@@ -175,7 +190,23 @@ int main(int argc, char **argv)
 	};
 	auto run_scrub = [&](ScrubStats &ss) {
 		const auto t0 = Clock::now();
-		while (!stop.load()) {
+		for (int round = 0; resync_mode && !stop.load(); ++round) {
+			// every block loses shard (round % 14), resync rebuilds it: gather k, one reconstruct trip, rebuilt shards home
+			const int j = round % 14;
+			int who[14];
+			for (size_t b = 0; b < nscrub; ++b) {
+				gbm_storage_nodes_of(mb, &bhashes[32 * b], who);
+				gbm_node_delete_shard(mb, who[j], &bhashes[32 * b], j);
+				gbm_put_to_resync(mb, &bhashes[32 * b], 0);
+			}
+			uint64_t st[8];
+			if (gbm_resync_run(mb, 0, st) != GBM_OK) {
+				fprintf(stderr, "resync failed: %s\n", gbm_last_error());
+				exit(1);
+			}
+			ss.blocks += st[4];
+		}
+		while (!resync_mode && !stop.load()) {
 			uint64_t st[4];
 			if (gbm_scrub_all(mb, 512, st) != GBM_OK) {
 				fprintf(stderr, "scrub failed: %s\n", gbm_last_error());
@@ -216,9 +247,11 @@ int main(int argc, char **argv)
 		s.join();
 		stopper.join();
 	}
-	printf("qos_bench: backend %s, %d closed-loop callers (%s%s), %.1f s per phase, scrub over %zu blocks, scrub tranquility %d\n",
+	printf("qos_bench: backend %s, %d closed-loop callers (%s%s%s), %.1f s per phase, %s over %zu blocks, scrub tranquility %d\n",
 	       gec_codec_backend(c) == GEC_BACKEND_CPU ? "cpu" : "hip", callers, get_blocks > 0 ? "gets of " : "puts through the batcher",
-	       get_blocks > 0 ? (std::to_string(get_blocks) + " blocks").c_str() : "", seconds, nscrub, tranq);
+	       get_blocks > 0 ? (std::to_string(get_blocks) + " blocks").c_str() : "",
+	       nodes_down ? (", " + std::to_string(nodes_down) + " of 16 nodes down").c_str() : "", seconds, resync_mode ? "resync (one lost shard per block per round)" : "scrub",
+	       nscrub, tranq);
 	PutStats solo_put, mixed_bg_put, mixed_fg_put;
 	ScrubStats solo_scrub, mixed_bg_scrub, mixed_fg_scrub;
 	{
