@@ -1194,29 +1194,140 @@ struct TailHash {
 	}
 };
 
-int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, gbm_data_block_header *hdr,
-		  size_t chunk_bytes, gbm_chunk_fn sink, void *ctx, bool raw)
+// Where a stream's bytes go: the sink (through the incremental zstd decoder for a Compressed block read as plain bytes)
+// and, when the mode asks for it, the hash behind the stream.
+struct StreamOut {
+	gbm_chunk_fn sink;
+	void *ctx;
+	size_t ch;
+	bool z = false, raw = false;
+	bool aborted = false, frame_bad = false, hashing = false;
+	TailHash tail;
+	std::unique_ptr<Zstd::Stream> zs;
+	std::vector<uint8_t> zbuf, whole;  // decoder output not yet handed out / the frame, when the library cannot stream
+	size_t plain_len = 0;
+	std::vector<std::pair<Bytes, size_t>> sent;  // what has been delivered (owner, bytes): a hash that starts late catches up
+
+	StreamOut(gbm_chunk_fn s, void *c, size_t chunk) : sink(s), ctx(c), ch(chunk ? chunk : 65536) {}
+	void open(bool compressed, bool raw_)
+	{
+		z = compressed;
+		raw = raw_;
+		if (z && !raw && zstd().streaming) {
+			zs.reset(new Zstd::Stream(zstd()));
+			zbuf.reserve(ch);
+		}
+	}
+	void start_hash()  // (from the first byte: whatever went out before is hashed first)
+	{
+		if (hashing || z)
+			return;
+		hashing = true;
+		tail.start();
+		for (auto &pr : sent)
+			tail.push(pr.first, pr.first.data(), pr.second);
+	}
+	bool to_sink(const uint8_t *p, size_t len)  // chunks of at most `ch` bytes
+	{
+		for (size_t off = 0; off < len && !aborted; off += ch)
+			if (sink(ctx, p + off, std::min(ch, len - off)) != 0)
+				aborted = true;
+		return !aborted;
+	}
+	// `len` stored bytes of the block, in order, at the start of `owner`.  false: stop (corrupt frame / abort)
+	bool deliver(const Bytes &owner, size_t len)
+	{
+		const uint8_t *p = owner.data();
+		sent.emplace_back(owner, len);
+		if (hashing)
+			tail.push(owner, p, len);
+		if (!z || raw)
+			return to_sink(p, len);
+		if (!zs) {  // no incremental decoder in this libzstd: the frame is collected and decoded at the end
+			whole.insert(whole.end(), p, p + len);
+			return true;
+		}
+		const bool ok = zs->feed(p, len, [&](const uint8_t *o, size_t on) {
+			plain_len += on;
+			if (plain_len > kMaxDecompressed)
+				return false;
+			while (on) {  // hand out full chunks, keep the rest
+				const size_t take = std::min(on, ch - zbuf.size());
+				zbuf.insert(zbuf.end(), o, o + take);
+				o += take;
+				on -= take;
+				if (zbuf.size() == ch) {
+					if (!to_sink(zbuf.data(), zbuf.size()))
+						return false;
+					zbuf.clear();
+				}
+			}
+			return true;
+		});
+		if (!ok && !aborted)
+			frame_bad = true;
+		return ok;
+	}
+	// the tail: what is left in the decoder, then the checks that can only be made once everything has gone by
+	int finish(const uint8_t hash[32])
+	{
+		if (aborted)
+			return fail(GBM_E_ABORTED, "the stream's consumer stopped");
+		if (z && !raw) {
+			if (!zs) {
+				std::vector<uint8_t> plain;
+				if (frame_bad || !zstd().decode(whole.data(), whole.size(), kMaxDecompressed, plain))
+					return one_block_rc(GBM_E_CORRUPT_DATA);
+				if (!to_sink(plain.data(), plain.size()))
+					return fail(GBM_E_ABORTED, "the stream's consumer stopped");
+			} else {
+				if (frame_bad || !zs->frame_done)  // a frame that does not end, or whose checksum does not match (block.rs:78-83)
+					return one_block_rc(GBM_E_CORRUPT_DATA);
+				if (!zbuf.empty() && !to_sink(zbuf.data(), zbuf.size()))
+					return fail(GBM_E_ABORTED, "the stream's consumer stopped");
+			}
+		}
+		if (hashing) {
+			uint8_t sum[32];
+			tail.finish(sum);
+			if (std::memcmp(sum, hash, 32) != 0)
+				return one_block_rc(GBM_E_CORRUPT_DATA);
+		}
+		return GBM_OK;
+	}
+};
+
+struct StreamGeom {
+	size_t L = 0, S = 0;
+	bool z = false;
+};
+
+// The general form: gather k shards (any holders, older layout versions, parity), check them side by side, rebuild what is
+// missing, deliver from byte `skip` on (everything before it has gone out already: the fast path below hands over here
+// when a shard is not where it should be).  `geom` != NULL: the geometry the stream has been opened with.
+int stream_general(gbm_manager *m, const std::vector<Hash> &hs, const uint8_t hash[32], const gbm_order_tag *order_tag,
+		   gbm_data_block_header *hdr, bool raw, StreamOut &out, size_t skip, const StreamGeom *geom)
 {
-	if (!m || !hash || !sink)
-		return fail(GBM_E_INVALID_ARG, "NULL argument");
-	m = m->route(hash);
 	const int k = m->k, n = m->n;
-	const size_t ch = chunk_bytes ? chunk_bytes : 65536;
-	std::vector<Hash> hs(1, Hash((const char *)hash, 32));
 	std::vector<Gathered> g;
-	Trace tr("streaming get");
+	Trace tr("streaming get (general)");
 	int grc = gather_many(m, hs, order_tag, k, g, /*verify=*/false);
 	if (grc)
 		return grc;
 	tr.lap("gather");
 	if (!g[0].have_meta || g[0].count < k)
-		return one_block_rc(g[0].corrupt_seen ? GBM_E_CORRUPT_DATA : GBM_E_MISSING_BLOCK);
+		return one_block_rc(g[0].corrupt_seen || skip ? GBM_E_CORRUPT_DATA : GBM_E_MISSING_BLOCK);
 	if (g[0].meta.orig_len > (uint64_t)k * g[0].meta.shard_len)
 		return one_block_rc(GBM_E_CORRUPT_DATA);
 	const size_t L = g[0].meta.orig_len, S = g[0].meta.shard_len;
 	const bool z = g[0].meta.compressed != 0;
-	if (hdr)
-		hdr->kind = z ? GBM_HEADER_COMPRESSED : GBM_HEADER_PLAIN;  // reported before the first byte
+	if (geom && (geom->L != L || geom->S != S || geom->z != z))
+		return one_block_rc(GBM_E_CORRUPT_DATA);  // another geometry took over mid-stream
+	if (!geom) {
+		if (hdr)
+			hdr->kind = z ? GBM_HEADER_COMPRESSED : GBM_HEADER_PLAIN;  // reported before the first byte
+		out.open(z, raw);
+	}
 	const int mode = m->verify_mode.load();
 
 	// ---- the k shards the block is read from (the first k in hand, in index order): checked side by side
@@ -1269,67 +1380,20 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 		ck->cv.wait(lk, [&] { return ck->verdict[j] != 0; });
 		return ck->verdict[j];
 	};
-
-	// ---- where the bytes go: the sink (through the incremental zstd decoder for a Compressed block read as plain
-	// bytes) and, when the mode asks for it, the hash behind the stream
-	const bool want_hash = !z && (mode == GBM_VERIFY_ALWAYS || (mode == GBM_VERIFY_REBUILT && need_decode));
-	TailHash tail;
-	if (want_hash)
-		tail.start();
-	std::unique_ptr<Zstd::Stream> zs;
-	std::vector<uint8_t> zbuf, whole;  // decoder output not yet handed out / the frame, when the library cannot stream
-	size_t plain_len = 0;
-	bool aborted = false;
-	if (z && !raw && zstd().streaming) {
-		zs.reset(new Zstd::Stream(zstd()));
-		zbuf.reserve(ch);
-	}
-	auto to_sink = [&](const uint8_t *p, size_t len) {  // chunks of at most `ch` bytes
-		for (size_t off = 0; off < len && !aborted; off += ch)
-			if (sink(ctx, p + off, std::min(ch, len - off)) != 0)
-				aborted = true;
-		return !aborted;
-	};
-	// `len` stored bytes of the block, in order; `owner` keeps them alive for the hasher.  false: stop (corrupt frame / abort)
-	bool frame_bad = false;
-	auto deliver = [&](const Bytes &owner, const uint8_t *p, size_t len) {
-		if (want_hash)
-			tail.push(owner, p, len);
-		if (!z || raw)
-			return to_sink(p, len);
-		if (!zs) {  // no incremental decoder in this libzstd: the frame is collected and decoded at the end
-			whole.insert(whole.end(), p, p + len);
-			return true;
-		}
-		const bool ok = zs->feed(p, len, [&](const uint8_t *o, size_t on) {
-			plain_len += on;
-			if (plain_len > kMaxDecompressed)
-				return false;
-			while (on) {  // hand out full chunks, keep the rest
-				const size_t take = std::min(on, ch - zbuf.size());
-				zbuf.insert(zbuf.end(), o, o + take);
-				o += take;
-				on -= take;
-				if (zbuf.size() == ch) {
-					if (!to_sink(zbuf.data(), zbuf.size()))
-						return false;
-					zbuf.clear();
-				}
-			}
-			return true;
-		});
-		if (!ok && !aborted)
-			frame_bad = true;
-		return ok;
-	};
+	if (mode == GBM_VERIFY_ALWAYS || (mode == GBM_VERIFY_REBUILT && need_decode))
+		out.start_hash();
 
 	// ---- the walk
 	std::vector<Bytes> rebuilt(k);
 	bool decoded = false;
-	size_t pos = 0;  // stored bytes delivered so far
+	size_t pos = 0;  // stored bytes walked over so far (delivered, or below `skip`)
 	int bad_shard = -1;
-	for (int j = 0; j < k && pos < L && !aborted && !frame_bad; ++j) {
+	for (int j = 0; j < k && pos < L && !out.aborted && !out.frame_bad; ++j) {
 		const size_t len = std::min(S, L - pos);
+		if (pos + len <= skip) {  // went out before the hand-over
+			pos += len;
+			continue;
+		}
 		if (!g[0].shard[j].empty()) {
 			if (wait_verdict(j) < 0) {
 				bad_shard = j;
@@ -1337,7 +1401,7 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 			}
 			if (j == 0)
 				tr.lap("first shard checked");
-			if (!deliver(g[0].shard[j], g[0].shard[j].data(), len))
+			if (!out.deliver(g[0].shard[j], len))
 				break;
 			pos += len;
 			continue;
@@ -1370,7 +1434,7 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 			m->metrics[3]++;
 			decoded = true;
 		}
-		if (!deliver(rebuilt[j], rebuilt[j].data(), len))
+		if (!out.deliver(rebuilt[j], len))
 			break;
 		pos += len;
 	}
@@ -1392,50 +1456,136 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 			return one_block_rc(rc1 == GBM_E_MISSING_BLOCK ? GBM_E_CORRUPT_DATA : rc1);  // shards were there: they were corrupt
 		if (g2[0].meta.orig_len != L || g2[0].meta.shard_len != S || (g2[0].meta.compressed != 0) != z)
 			return one_block_rc(GBM_E_CORRUPT_DATA);  // another geometry took over mid-stream
-		for (int j = (int)(pos / S); j < k && pos < L && !aborted && !frame_bad; ++j) {
+		if (mode == GBM_VERIFY_REBUILT)
+			out.start_hash();  // the replacement comes out of a decode after all: the block is hashed, from its first byte
+		for (int j = (int)(pos / S); j < k && pos < L && !out.aborted && !out.frame_bad; ++j) {
 			const size_t len = std::min(S, L - pos);
-			if (!deliver(g2[0].shard[j], g2[0].shard[j].data(), len))
+			if (!out.deliver(g2[0].shard[j], len))
 				break;
 			pos += len;
 		}
-		if (!z && mode == GBM_VERIFY_REBUILT && !want_hash && !aborted) {
-			// the replacement came out of a decode after all and no hash was running behind the stream: the block is
-			// hashed from the shards now in hand before the stream is declared good
-			b2host::State st;
-			for (int j = 0; j < k && (size_t)j * S < L; ++j)
-				st.update(g2[0].shard[j].data(), std::min(S, L - (size_t)j * S));
-			uint8_t full[64];
-			st.final(full);
-			if (std::memcmp(full, hash, 32) != 0)
-				return one_block_rc(GBM_E_CORRUPT_DATA);
-		}
 	}
 	tr.lap("last shard delivered");
-	if (aborted)
-		return fail(GBM_E_ABORTED, "the stream's consumer stopped");
-	// ---- the tail: what is left in the decoder, then the checks that can only be made once everything has gone by
-	if (z && !raw) {
-		if (!zs) {
-			std::vector<uint8_t> plain;
-			if (frame_bad || !zstd().decode(whole.data(), whole.size(), kMaxDecompressed, plain))
-				return one_block_rc(GBM_E_CORRUPT_DATA);
-			if (!to_sink(plain.data(), plain.size()))
-				return fail(GBM_E_ABORTED, "the stream's consumer stopped");
-		} else {
-			if (frame_bad || !zs->frame_done)  // a frame that does not end, or whose checksum does not match (block.rs:78-83)
-				return one_block_rc(GBM_E_CORRUPT_DATA);
-			if (!zbuf.empty() && !to_sink(zbuf.data(), zbuf.size()))
-				return fail(GBM_E_ABORTED, "the stream's consumer stopped");
+	int rc = out.finish(hash);
+	if (rc == GBM_OK)
+		m->metrics[5]++;
+	return rc;
+}
+
+// The streaming get.  The fast path is the healthy block: its k data shards are asked for AT ONCE, each from the node that
+// should hold it in the current layout version; a shard is checked (header, checksum) by the task that fetched it, and
+// the walk hands shard i to the sink as soon as shards 0..i have arrived and matched -- the first byte waits for ONE
+// node's answer and one shard's checksum, not for the slowest of k nodes.  The moment a shard is not there, not
+// consistent with shard 0's geometry, or does not match, the general form takes over from the byte the walk has reached
+// (other holders, older layout versions, parity + decode, the corrupt-shard bookkeeping).
+int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, gbm_data_block_header *hdr,
+		  size_t chunk_bytes, gbm_chunk_fn sink, void *ctx, bool raw)
+{
+	if (!m || !hash || !sink)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	m = m->route(hash);
+	const int k = m->k;
+	std::vector<Hash> hs(1, Hash((const char *)hash, 32));
+	StreamOut out(sink, ctx, chunk_bytes);
+	struct Fast {
+		std::mutex mu;
+		std::condition_variable cv;
+		std::vector<int> st;  // 0 pending, 1 arrived and matches its own checksum, -1 not usable
+		std::vector<Shard> shard;
+		Hash h;
+		gbm_order_tag tag{0, 0};
+		bool has_tag = false;
+	};
+	auto fs = std::make_shared<Fast>();
+	fs->st.assign(k, 0);
+	fs->shard.resize(k);
+	fs->h = hs[0];
+	if (order_tag) {
+		fs->tag = *order_tag;
+		fs->has_tag = true;
+	}
+	std::vector<int> who;
+	m->nodes_of(hs[0], who);
+	{
+		std::shared_ptr<gbm_manager::Async> async = m->async_pool();
+		const int mk = m->k, mm = m->m;
+		auto fetch = [fs, mk, mm](Node *nd, int j) {
+			ShardRpc rq{RpcKind::GetShard, &fs->h, j, Shard(), fs->has_tag ? &fs->tag : nullptr};
+			ShardResp rs;
+			int v = -1;
+			if (nd->handle(rq, rs) && rs.ok) {
+				const ShardHeader &hd = rs.shard.hd;
+				if (hd.version == 2 && hd.idx == j && hd.k == mk && hd.m == mm && hd.shard_len > 0 && hd.shard_len % 64 == 0 &&
+				    rs.shard.data.n == hd.shard_len) {
+					uint8_t sum[32];
+					shardsum(rs.shard.data.data(), hd.shard_len, sum);
+					if (std::memcmp(sum, hd.checksum, 32) == 0)
+						v = 1;
+				}
+			}
+			{
+				std::lock_guard<std::mutex> lk(fs->mu);
+				if (v == 1)
+					fs->shard[j] = std::move(rs.shard);
+				fs->st[j] = v;
+			}
+			fs->cv.notify_all();
+		};
+		for (int j = 1; j < k; ++j) {
+			Node *nd = m->nodes[who[j]].get();
+			async->submit([fetch, nd, j] { fetch(nd, j); });
 		}
+		fetch(m->nodes[who[0]].get(), 0);  // shard 0 is the walk's own: the first byte waits for no other thread to wake up
 	}
-	if (want_hash) {
-		uint8_t sum[32];
-		tail.finish(sum);
-		if (std::memcmp(sum, hash, 32) != 0)
-			return one_block_rc(GBM_E_CORRUPT_DATA);
+	auto arrived = [&](int j) {
+		std::unique_lock<std::mutex> lk(fs->mu);
+		fs->cv.wait(lk, [&] { return fs->st[j] != 0; });
+		return fs->st[j] == 1;
+	};
+	Trace tr("streaming get");
+	StreamGeom geom;
+	size_t pos = 0;
+	bool opened = false, handover = false;
+	for (int j = 0; j < k; ++j) {
+		if (!arrived(j)) {
+			handover = true;
+			break;
+		}
+		const ShardHeader &hd = fs->shard[j].hd;
+		if (j == 0) {
+			if (hd.orig_len > (uint64_t)k * hd.shard_len) {
+				handover = true;
+				break;
+			}
+			geom.L = hd.orig_len;
+			geom.S = hd.shard_len;
+			geom.z = hd.compressed != 0;
+			if (hdr)
+				hdr->kind = geom.z ? GBM_HEADER_COMPRESSED : GBM_HEADER_PLAIN;  // reported before the first byte
+			out.open(geom.z, raw);
+			opened = true;
+			if (m->verify_mode.load() == GBM_VERIFY_ALWAYS)
+				out.start_hash();
+			tr.lap("first shard arrived and checked");
+		} else if (hd.orig_len != geom.L || hd.shard_len != geom.S || (hd.compressed != 0) != geom.z) {
+			handover = true;  // a stale shard of another geometry: the general form sorts the groups out
+			break;
+		}
+		if (pos >= geom.L)
+			break;
+		const size_t len = std::min(geom.S, geom.L - pos);
+		m->metrics[1] += hd.shard_len;
+		if (!out.deliver(fs->shard[j].data, len))
+			break;
+		pos += len;
 	}
-	m->metrics[5]++;
-	return GBM_OK;
+	if (handover)
+		return stream_general(m, hs, hash, order_tag, hdr, raw, out, pos, opened ? &geom : nullptr);
+	tr.lap("last shard delivered");
+	int rc = out.finish(hash);
+	if (rc == GBM_OK)
+		m->metrics[5]++;
+	return rc;
 }
 
 }  // namespace

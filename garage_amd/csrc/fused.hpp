@@ -90,11 +90,13 @@ __global__ __launch_bounds__(256) void gf_ptrs_hash(const FusedArgs a, const Log
 	const bool hashes = hj < nh;
 	const uint32_t my_msg = leaves_base + hj * FUSED_LEAF_PITCH;
 
-	link_enter(a.link_busy, a.link_role);
 	if (tid < 192)
 		reinterpret_cast<uint32_t *>(lexp)[tid] = reinterpret_cast<const uint32_t *>(le)[tid];
 	uint32_t cur_pat = 0xffffffffu;
 	for (uint32_t tile = blockIdx.x; tile < a.tiles_total; tile += gridDim.x) {
+		// the workgroup counts as a foreground link kernel only while it is ON the link (a tile's loads and row stores: a
+		// fifth of its time): background link kernels give way to that, not to the hashing that follows
+		link_enter(a.link_busy, a.link_role);
 		const uint32_t b = tile / a.tiles_x, tx = tile - b * a.tiles_x;
 		const uint32_t pat = a.pat ? a.pat[b] : 0;
 		const uint32_t col_raw = tx * 256 + tid;
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(256) void gf_ptrs_hash(const FusedArgs a, const Log
 			}
 		}
 		__syncthreads();
+		link_leave(a.link_busy, a.link_role);
 		// ---- the tile's leaves, out of LDS
 		if (hashes) {
 			const uint32_t left = (a.cols - tx * 256) * 16;
@@ -244,7 +247,6 @@ __global__ __launch_bounds__(256) void gf_ptrs_hash(const FusedArgs a, const Log
 		}
 		__syncthreads();  // flag and the leaves belong to the next tile from here on
 	}
-	link_leave(a.link_busy, a.link_role);
 }
 
 }  // namespace gec
