@@ -784,6 +784,10 @@ def run_threads(args) -> None:
     out["collective_backend"] = "none (single process; the encode path has no collective)"
     if all(r["host_fed"] for r in res):
         out["host_fed"] = host_fed_object([r["host_fed"] for r in res], args.host_blocks, hf_reps)
+        # ... and the same node through the PRODUCT's multi-device manager: gbm_create_multi over the N codecs, one
+        # coalescing queue per device, native callers through gbm_batcher_put_block / _get_block (tools/multi_bench), beside
+        # the raw gec_encode_hash_batch figures above
+        out["host_fed"]["block_manager_multi"] = multi_manager_rates(world, dry)
     # the path's one collective, from this one process: a gec_group over the N devices (N threads, N codecs), an
     # oracle-checked striped decode through it -- `rccl_ranks` is what RCCL connected
     if (world > 1 and not args.no_striped) or args.striped:
@@ -1088,6 +1092,26 @@ def host_fed_section(rs, nb: int, reps: int, barrier, seed: int) -> dict:
                 host_free(a)
         del blocks, outs
     return res
+
+
+def multi_manager_rates(ndev: int, dry: bool, callers_per_device: int = 48, puts: int = 20) -> dict:
+    """tools/multi_bench in a subprocess: libgarage_block's multi-device manager under native load, per device and summed."""
+    import subprocess
+
+    root = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(root, "tools", "multi_bench")
+    try:
+        if not os.path.exists(exe):
+            r = subprocess.run(["make", "-C", os.path.join(root, "tools"), "multi_bench"], capture_output=True, text=True, timeout=120)
+            if r.returncode != 0:
+                return {"error": "tools/multi_bench is not built: " + (r.stderr or r.stdout)[-200:]}
+        r = subprocess.run([exe, str(ndev), str(callers_per_device), str(puts), "1" if dry else "0"], capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        return json.loads(line[-1])
+    except Exception as e:  # noqa: BLE001 -- a secondary figure must never cost the headline line
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def host_fed_object(per_gpu: list, nb: int, reps: int) -> dict:

@@ -96,6 +96,12 @@ def test_gpu_threads_mode_two_codecs_on_one_gpu():
     assert "error" not in hf, hf
     for kind in ("pinned", "pageable"):
         assert len(hf[kind]["per_gpu_GiBps"]) == 2 and hf[kind]["bit_exact_vs_oracle"] is True
+    # ... and through the PRODUCT's multi-device manager (gbm_create_multi, one coalescing queue per device, native callers)
+    mm = hf["block_manager_multi"]
+    assert "error" not in mm, mm
+    assert mm["n_devices"] == 2 and mm["routing_follows_gec_device_of_hash"] is True and mm["every_byte_compared"] is True
+    assert len(mm["per_device"]) == 2 and all(dv["blocks_put"] > 0 and dv["blocks_get"] == dv["blocks_put"] for dv in mm["per_device"])
+    assert mm["put_GiBps"] > 0 and mm["get_GiBps"] > 0
     # a one-process gec_group over the (logical) ranks: the striped decode against the ORACLE's stripes, both exchanges
     sd = d["striped_decode"]
     assert sd.get("bit_exact") is True and sd["ranks"] == 2 and "oracle" in sd["bit_exact_against"], sd

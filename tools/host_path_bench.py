@@ -125,19 +125,25 @@ def block_manager_rates(nb: int = 512, threads: int = 48) -> dict:
     outs = [np.empty(L, dtype=np.uint8) for _ in range(nb)]
     check = lambda r: all(x == L for x in r) and all(outs[i].tobytes() == blocks[i] for i in (0, 1, nb // 2, nb - 1))  # noqa: E731
     res_ = []
-    t_get, _ = _best(lambda: res_.__setitem__(slice(None), mgr.rpc_get_blocks(hashes, L, out=outs)), 3)
-    assert check(res_)
-    mgr.set_verify_block_hash(False)
-    t_get_nv, _ = _best(lambda: res_.__setitem__(slice(None), mgr.rpc_get_blocks(hashes, L, out=outs)), 3)
-    mgr.set_verify_block_hash(True)
+    # the requester's end-to-end block hash is a mode (gbm_set_verify_block_hash): off = the reference's read path and the
+    # default; rebuilt = only blocks that went through a decode; always = round 3's behaviour
+    t_mode, t_deg_mode = {}, {}
+    for mode in ("off", "rebuilt", "always"):
+        mgr.set_verify_block_hash(mode)
+        t_mode[mode], _ = _best(lambda: res_.__setitem__(slice(None), mgr.rpc_get_blocks(hashes, L, out=outs)), 3)
+        assert check(res_)
     for node in range(4):
         mgr.node_set_down(node, True)
-    for o in outs:
-        o[:] = 0
-    t_deg, _ = _best(lambda: res_.__setitem__(slice(None), mgr.rpc_get_blocks(hashes, L, out=outs)), 3)
-    assert check(res_) and all(outs[i].tobytes() == blocks[i] for i in range(0, nb, 37))
+    for mode in ("off", "rebuilt", "always"):
+        mgr.set_verify_block_hash(mode)
+        for o in outs:
+            o[:] = 0
+        t_deg_mode[mode], _ = _best(lambda: res_.__setitem__(slice(None), mgr.rpc_get_blocks(hashes, L, out=outs)), 3)
+        assert check(res_) and all(outs[i].tobytes() == blocks[i] for i in range(0, nb, 37))
     for node in range(4):
         mgr.node_set_down(node, False)
+    mgr.set_verify_block_hash("off")
+    t_get, t_get_nv, t_deg = t_mode["always"], t_mode["off"], t_deg_mode["off"]
     bt = bn.Batcher(mgr, max_blocks=128, max_wait_us=300)
     per = max(1, nb // threads)
 
@@ -154,14 +160,18 @@ def block_manager_rates(nb: int = 512, threads: int = 48) -> dict:
     bstats = bt.stats()
     bt.close()
     native = native_batcher_rate(threads)
+    native96 = native_batcher_rate(2 * threads)
     res = {
         "what": "libgarage_block (C++ BlockManager mirror over the C ABI), RS(10,4), 1 MiB blocks, 16 in-memory nodes, payload GiB/s",
         "nblocks": nb,
         "rpc_put_blocks_GiBps": round(gib / t_put, 2),
         "rpc_put_blocks_median_GiBps": round(gib / t_put_med, 2),
-        "rpc_get_blocks_GiBps": round(gib / t_get, 2),
-        "rpc_get_blocks_without_block_hash_verify_GiBps": round(gib / t_get_nv, 2),
+        "rpc_get_blocks_GiBps": round(gib / t_get_nv, 2),   # the default mode (off), as the reference's requester reads
+        "rpc_get_blocks_by_verify_mode_GiBps": {mo: round(gib / t_mode[mo], 2) for mo in t_mode},
         "rpc_get_blocks_4_nodes_down_GiBps": round(gib / t_deg, 2),
+        "rpc_get_blocks_4_nodes_down_by_verify_mode_GiBps": {mo: round(gib / t_deg_mode[mo], 2) for mo in t_deg_mode},
+        "rpc_get_blocks_with_block_hash_always_GiBps": round(gib / t_get, 2),
+        "verify_mode_default": "off (shard checksums are always verified; the end-to-end block hash is a mode)",
         # the batcher under 48 native callers (tools/batcher_bench, C: no interpreter between the callers and the
         # library) is the figure; the same load from Python threads is kept beside it -- the GIL hand-offs between
         # 48 threads cost it a fifth
@@ -169,12 +179,58 @@ def block_manager_rates(nb: int = 512, threads: int = 48) -> dict:
         f"batcher_{threads}_threads_put_source": "tools/batcher_bench (native callers)" if "GiBps" in native else "python threads (tools/batcher_bench not built)",
         f"batcher_{threads}_python_threads_put_GiBps": round(threads * per * L / 2**30 / t_bat, 2),
         "batcher_native": native,
+        f"batcher_{2 * threads}_threads_put_GiBps": native96.get("GiBps"),
+        f"batcher_native_{2 * threads}": native96,
+        "small_trips": small_trip_rates(),
         "batcher_stats": bstats,
         "ec_reconstructs": mgr.metrics["ec_reconstructs"],
         "messages_hashed_on_gpu": mgr.gpu_hashed(),
     }
     mgr.close()
     return res
+
+
+def small_trip_rates() -> dict:
+    """tools/small_trip_bench (native): one put / a PutObject's three through the batcher, one get per verify mode (healthy and
+    degraded), streaming gets (first / last chunk), 48 readers through the batcher per mode."""
+    import re
+    import subprocess
+
+    exe = os.path.join(ROOT, "tools", "small_trip_bench")
+    if not os.path.exists(exe):
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "small_trip_bench"], capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(exe):
+            return {"error": "tools/small_trip_bench is not built"}
+    try:
+        r = subprocess.run([exe, "48", "20"], capture_output=True, text=True, timeout=300)
+    except subprocess.SubprocessError as e:
+        return {"error": f"{type(e).__name__}"}
+    out = {"source": "tools/small_trip_bench (native callers), RS(10,4), 1 MiB blocks, 16 in-memory nodes, medians"}
+    txt = r.stdout
+    m = re.findall(r"put, 1 caller through the batcher, pass \d: median ([0-9.]+) ms", txt)
+    if m:
+        out["put_one_block_ms"] = float(m[-1])
+    m = re.search(r"a PutObject's three in flight:\s+median ([0-9.]+) ms", txt)
+    if m:
+        out["put_three_blocks_ms"] = float(m.group(1))
+    for state in ("healthy", "degraded"):
+        for mo, key in (("off", "off"), ("rebuilt-only", "rebuilt"), ("always", "always")):
+            m = re.search(rf"get, one 1 MiB block, {state}\s+mode {mo}\s*: median ([0-9.]+) ms", txt)
+            if m:
+                out.setdefault(f"get_one_block_{state}_ms", {})[key] = float(m.group(1))
+    for mib in (1, 4):
+        for mo, key in (("off", "off"), ("rebuilt-only", "rebuilt"), ("always", "always")):
+            m = re.search(rf"streaming get, {mib} MiB block, mode {mo}\s*: first chunk ([0-9.]+) ms, last chunk ([0-9.]+) ms, call returns ([0-9.]+) ms", txt)
+            if m:
+                out.setdefault(f"streaming_get_{mib}MiB_ms", {})[key] = {"first_chunk": float(m.group(1)), "last_chunk": float(m.group(2)),
+                                                                             "call_returns": float(m.group(3))}
+    for mo, key in (("off", "off"), ("rebuilt-only", "rebuilt"), ("always", "always")):
+        m = re.search(rf"48 readers x 20 gets through the batcher, mode {mo}\s*: ([0-9.]+) GiB/s, median ([0-9.]+) ms, p99 ([0-9.]+) ms", txt)
+        if m:
+            out.setdefault("batcher_48_readers", {})[key] = {"GiBps": float(m.group(1)), "median_ms": float(m.group(2)), "p99_ms": float(m.group(3))}
+    if len(out) == 1:
+        out["error"] = (r.stderr or r.stdout)[-200:]
+    return out
 
 
 def native_batcher_rate(threads: int = 48, puts: int = 20) -> dict:
