@@ -31,7 +31,7 @@ const Row kRows[] = {
 	{"GEC_BG_CUS", "64", "CUs a background-class codec's kernels may occupy (0 = no mask; link kernels stay on GEC_UPLOAD_CUS)"},
 	{"GEC_BG_CHUNK_MB", "32", "chunk size of a background-class codec's host-pointer trips (a foreground call waits for at most one)"},
 	{"GEC_BG_YIELD_US", "2000", "a background chunk waits up to this long for foreground calls on the same device to drain (0 = never waits)"},
-	{"GEC_BG_LINK_WAIT_US", "2000", "a background link kernel's workgroups sleep while foreground link kernels run on the device, at most this long per launch (0 = the classes share the link as it comes)"},
+	{"GEC_BG_LINK_WAIT_US", "200", "a background link kernel's workgroups sleep while foreground link kernels run on the device, at most this long per launch (0 = the classes share the link as it comes)"},
 	{"GEC_HOME_RATE_GBPS", "25", "the read path sends rebuilt shards home no faster than this while checksum chains run (0 = unpaced, one workgroup per tile): a link saturated with writes backs up into the fabric and every other kernel's loads wait"},
 	{"GEC_RESIDENT_GRID", "1", "A/B: 0 = link kernels launch one workgroup per tile instead of a grid that fits the stream's CUs and walks the tiles"},
 	{"GEC_ROWS16", "1", "A/B: 0 = 9..16 output rows as 8-row passes instead of one 16-row pass"},
@@ -75,7 +75,7 @@ const Env &env()
 		v.bg_cus = (int)get_long("GEC_BG_CUS", 64);
 		v.bg_chunk_mb = (size_t)std::max<long>(get_long("GEC_BG_CHUNK_MB", 32), 1);
 		v.bg_yield_us = (unsigned)std::max<long>(get_long("GEC_BG_YIELD_US", 2000), 0);
-		v.bg_link_wait_us = (unsigned)std::min<long>(std::max<long>(get_long("GEC_BG_LINK_WAIT_US", 2000), 0), 1000000);
+		v.bg_link_wait_us = (unsigned)std::min<long>(std::max<long>(get_long("GEC_BG_LINK_WAIT_US", 200), 0), 1000000);
 		v.home_rate_gbps = (unsigned)std::max<long>(get_long("GEC_HOME_RATE_GBPS", 25), 0);
 		v.resident_grid = (int)get_long("GEC_RESIDENT_GRID", 1);
 		v.rows16 = (int)get_long("GEC_ROWS16", 1);

@@ -85,6 +85,12 @@ rec = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (profiles/%s_
                                      "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round %s, profiles/%s_pmc_hbm_traffic.txt" % (tag[1:], tag)}}
 if sec:
     rec["rs10_4_secondary_bounds"] = sec
+try:  # entries of other workloads (RS(20,8): profiles/r04_pmc_sq_rs20_8.txt) stay
+    old = json.load(open(os.path.join(P, "pmc_traffic.json")))
+    for key, val in old.items():
+        rec.setdefault(key, val)
+except (OSError, ValueError):
+    pass
 json.dump(rec, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 summ = lambda *dirs: subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), *dirs], capture_output=True, text=True).stdout
 with open(os.path.join(P, f"{tag}_pmc_hbm_traffic.txt"), "w") as f:
