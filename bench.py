@@ -659,6 +659,17 @@ def run_procs(args) -> None:
         except Exception as e:  # noqa: BLE001 -- a secondary object must never cost the headline line
             if rank == 0:
                 out["host_fed"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        # ... and the node's N devices through the PRODUCT's multi-device manager: ONE process (rank 0 starts it; the
+        # other ranks idle at the barrier meanwhile), gbm_create_multi over the N codecs, one coalescing queue per device,
+        # native callers (tools/multi_bench) -- "blocks from a batched PutObject stream are hash-partitioned across the
+        # GPUs of one node" as the daemon would run it, per device and summed, beside the raw per-rank figures above
+        try:
+            if rank == 0 and isinstance(out.get("host_fed"), dict):
+                out["host_fed"]["block_manager_multi"] = multi_manager_rates(world, os.environ.get("GARAGE_DRYRUN_ONE_GPU") == "1")
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                out["host_fed"]["block_manager_multi"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        barrier()
 
     # ---- BASELINE config 5 beside it when there is more than one GPU (or on request): the path's one
     # real exchange step.  Guarded by a watchdog so that a collective that hangs cannot take the

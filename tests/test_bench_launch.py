@@ -82,6 +82,10 @@ def test_gpu_procs_mode_two_ranks_on_one_gpu(launcher):
         assert len(hf[kind]["per_gpu_GiBps"]) == 2 and hf[kind]["aggregate_GiBps"] > 0
         assert hf[kind]["bit_exact_vs_oracle"] is True and hf[kind]["blocks_checked"] >= 4
         assert hf[kind]["host_memory_traffic_GBps_model"] > hf[kind]["aggregate_GiBps"]
+    # the same node through the product's multi-device manager, from one process (rank 0 runs tools/multi_bench)
+    mm = hf["block_manager_multi"]
+    assert "error" not in mm, mm
+    assert mm["n_devices"] == 2 and mm["routing_follows_gec_device_of_hash"] is True and mm["every_byte_compared"] is True
 
 
 @pytest.mark.gpu
