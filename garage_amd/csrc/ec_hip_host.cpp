@@ -691,7 +691,7 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 	};
 	// decode of one erasure pattern, in place in the bucket's stripes; the rebuilt shards' way home is appended to `outs`
 	size_t rq = 0;
-	auto decode_bucket = [&](Bucket &bk, hipStream_t s, std::vector<gec::CopyEntry> &outs) -> int {
+	auto decode_range = [&](Bucket &bk, size_t first, size_t count, hipStream_t s, std::vector<gec::CopyEntry> &outs) -> int {
 		std::vector<size_t> in_off(k), out_off(bk.npar);
 		size_t q = 0;
 		for (size_t t = 0; t < k; ++t) {
@@ -700,11 +700,12 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 		}
 		for (size_t r = 0; r < bk.npar; ++r)
 			out_off[r] = (size_t)bk.plan->missing[r] * S;  // rebuilt in place, in the block's data area
-		int drc = launch_apply(c, st.d_big + bk.base, bk.stripe, st.d_big + bk.base, bk.stripe, nullptr, 0, S, bk.ids.size(),
-				       in_off.data(), out_off.data(), (int)bk.npar, bk.plan->rows.v.data(), gec::MODE_STORE, s);
+		uint8_t *base = st.d_big + bk.base + first * bk.stripe;
+		int drc = launch_apply(c, base, bk.stripe, base, bk.stripe, nullptr, 0, S, count, in_off.data(), out_off.data(), (int)bk.npar,
+				       bk.plan->rows.v.data(), gec::MODE_STORE, s);
 		if (drc)
 			return drc;
-		for (size_t i = 0; i < bk.ids.size(); ++i)
+		for (size_t i = first; i < first + count; ++i)
 			for (size_t r = 0; r < bk.npar; ++r) {
 				uint8_t *dst = rebuilt[bk.ids[i] * n + bk.plan->missing[r]];
 				const bool direct = aligned16(dst) && pinned().contains(dst, S);
@@ -713,6 +714,108 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 			}
 		return GEC_OK;
 	};
+	auto decode_bucket = [&](Bucket &bk, hipStream_t s, std::vector<gec::CopyEntry> &outs) -> int {
+		return decode_range(bk, 0, bk.ids.size(), s, outs);
+	};
+	// A big batch without block checksums (the default read path: no end-to-end hash at the requester) has no long chains
+	// to hide, and used to do one thing after the other: upload everything (the link's 10.7 ms for 512 blocks), THEN the
+	// shard checksums, the decodes, the rebuilt shards' way home -- 17 ms with 4 of 16 nodes down.  In pieces instead:
+	// piece c+1 is on its way up while piece c is hashed and decoded and piece c-1's rebuilt shards travel down (the link
+	// is full duplex) -- three streams, one event per piece and direction.
+	if (all_pinned && !block_sums && nblocks >= 48 && env().get_pieces != 0) {
+		struct Part {
+			Bucket *bk;
+			size_t first, count;
+		};
+		const size_t npieces = std::min<size_t>({(size_t)Staging::kMaxSeg, (size_t)std::max(1, env().get_pieces), nblocks / 16});
+		const size_t per_piece = (nblocks + npieces - 1) / npieces;
+		std::vector<std::vector<Part>> pieces(1);
+		size_t in_piece = 0;
+		for (auto &kv : buckets) {
+			Bucket &bk = kv.second;
+			for (size_t f = 0; f < bk.ids.size();) {
+				if (in_piece == per_piece) {
+					pieces.emplace_back();
+					in_piece = 0;
+				}
+				const size_t cnt = std::min(bk.ids.size() - f, per_piece - in_piece);
+				pieces.back().push_back({&bk, f, cnt});
+				f += cnt;
+				in_piece += cnt;
+			}
+		}
+		hipStream_t up_s = st.stream_up ? st.stream_up : st.stream;
+		hipStream_t chain_s = st.stream_chain ? st.stream_chain : st.stream2;
+		hipStream_t down_s = st.stream_down ? st.stream_down : st.stream3;
+		size_t up_i = 0;  // ups[] is sorted by device address = bucket by bucket, block by block: a piece is a run of it
+		for (size_t pc = 0; pc < pieces.size(); ++pc) {
+			size_t lo = ~(size_t)0, hi = 0;  // device byte range of the piece
+			for (const Part &pt : pieces[pc]) {
+				lo = std::min(lo, pt.bk->base + pt.first * pt.bk->stripe);
+				hi = std::max(hi, pt.bk->base + (pt.first + pt.count) * pt.bk->stripe);
+			}
+			const size_t i0 = up_i;
+			std::vector<gec::CopyEntry> ents;
+			while (up_i < ups.size() && ups[up_i].dst < hi) {
+				size_t run = 1;
+				while (up_i + run < ups.size() && ups[up_i + run].dst < hi && ups[up_i + run].src == ups[up_i].src + run * S &&
+				       ups[up_i + run].dst == ups[up_i].dst + run * S)
+					++run;
+				ents.push_back({pinned().dev(ups[up_i].src), st.d_big + ups[up_i].dst, run * S});
+				up_i += run;
+			}
+			(void)lo;
+			rc = launch_copy_table(st, ents, up_s);
+			if (rc)
+				return finish(rc);
+			hipError_t es = hipEventRecord(st.ev_seg[pc], up_s);
+			if (es == hipSuccess)
+				es = hipStreamWaitEvent(chain_s, st.ev_seg[pc], 0);
+			if (es != hipSuccess)
+				return finish(hip_fail(es, "piece event"));
+			// the piece's shard checksums, straight into the slot's pinned area
+			rc = blake2_dev(c, up_i - i0, st.d_big, h_soff + i0, h_slen + i0, 0, 0, st.h_buf + ssum_off + 32 * i0, chain_s, 0, 0, 0, true, S);
+			if (rc)
+				return finish(rc);
+			std::vector<gec::CopyEntry> outs;
+			for (const Part &pt : pieces[pc])
+				if (pt.bk->npar) {
+					rc = decode_range(*pt.bk, pt.first, pt.count, chain_s, outs);
+					if (rc)
+						return finish(rc);
+				}
+			if (!outs.empty()) {
+				es = hipEventRecord(st.ev_dec[pc], chain_s);
+				if (es == hipSuccess)
+					es = hipStreamWaitEvent(down_s, st.ev_dec[pc], 0);
+				if (es != hipSuccess)
+					return finish(hip_fail(es, "decode event"));
+				rc = launch_copy_table(st, outs, down_s);
+				if (rc)
+					return finish(rc);
+			}
+		}
+		hipError_t e1 = hipStreamSynchronize(up_s);
+		if (e1 == hipSuccess)
+			e1 = hipStreamSynchronize(chain_s);
+		if (e1 == hipSuccess)
+			e1 = hipStreamSynchronize(down_s);
+		if (e1 != hipSuccess)
+			return finish(hip_fail(e1, "hipStreamSynchronize"));
+		for (size_t i = 0; i < ups.size(); ++i)
+			std::memcpy(shard_sums + 32 * ups[i].idx, st.h_buf + ssum_off + 32 * i, 32);
+		for (auto &kv : buckets) {
+			Bucket &bk = kv.second;
+			size_t w = 0;
+			for (size_t i = 0; i < bk.ids.size(); ++i)
+				for (size_t r = 0; r < bk.npar; ++r, ++w) {
+					uint8_t *dst = rebuilt[bk.ids[i] * n + bk.plan->missing[r]];
+					if (!(aligned16(dst) && pinned().contains(dst, S)))
+						std::memcpy(dst, st.h_buf + reb_off + bk.rq[w] * S, S);
+				}
+		}
+		return finish(GEC_OK);
+	}
 	const bool staged = all_pinned && nseg > 1;
 	hipStream_t down_stream = staged && st.stream_down ? st.stream_down : st.stream;
 	if (all_pinned) {
