@@ -345,7 +345,9 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uint8_t *const *in, const uint32_t *valid,
 		      uint8_t *const *out, int nout, size_t S, const uint8_t *coef /* nout x k */, hipStream_t stream,
 		      uint8_t *d_mirror = nullptr /* [nblocks][k + nout][S]: inputs and outputs also laid down in HBM */,
-		      uint32_t *bad = nullptr /* compare with what out[] holds instead of storing: bad[b] = 1 on mismatch */);
+		      uint32_t *bad = nullptr /* compare with what out[] holds instead of storing: bad[b] = 1 on mismatch */,
+		      size_t npat = 0, const uint16_t *pat = nullptr /* per-block coefficient sets: coef = [npat][nout][k], block b uses
+		      set pat[b], a NULL out entry = that block's set has no such row; nout <= RMAX; shards may be device memory */);
 
 // Appends the entries to the slot's table and launches ONE copy_table kernel over them.  Entries must have
 // 16-byte aligned src and dst.

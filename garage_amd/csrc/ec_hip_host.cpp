@@ -595,7 +595,7 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 	rc = st.ensure_big(state_off + nblocks * 64 + 64);
 	if (rc)
 		return rc;
-	rc = st.ensure_tab(nup + nreb);
+	rc = st.ensure_tab(nup + nreb + (nblocks * (k * 12 + gec::RMAX * 8 + 2) + buckets.size() * k * gec::RMAX + 1024) / sizeof(gec::CopyEntry) + 64);
 	if (rc)
 		return rc;
 	rc = st.ensure_segments(num_cu);
@@ -777,13 +777,62 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 			rc = blake2_dev(c, up_i - i0, st.d_big, h_soff + i0, h_slen + i0, 0, 0, st.h_buf + ssum_off + 32 * i0, chain_s, 0, 0, 0, true, S);
 			if (rc)
 				return finish(rc);
+			// the piece's decodes: ONE launch whatever mix of erasure patterns its blocks have (a coefficient set per block,
+			// the pointer-table kernel over the stripes in HBM, rebuilt in place), instead of one launch per pattern
 			std::vector<gec::CopyEntry> outs;
-			for (const Part &pt : pieces[pc])
-				if (pt.bk->npar) {
-					rc = decode_range(*pt.bk, pt.first, pt.count, chain_s, outs);
+			{
+				size_t max_miss = 0, nb_dec = 0;
+				for (const Part &pt : pieces[pc])
+					if (pt.bk->npar) {
+						max_miss = std::max(max_miss, pt.bk->npar);
+						nb_dec += pt.count;
+					}
+				if (nb_dec && max_miss <= (size_t)gec::RMAX && k <= (size_t)gec::PTR_KMAX) {
+					std::vector<const uint8_t *> in(nb_dec * k);
+					std::vector<uint32_t> valid(nb_dec * k, (uint32_t)S);
+					std::vector<uint8_t *> outp(nb_dec * max_miss, nullptr);
+					std::vector<uint16_t> pat(nb_dec);
+					std::vector<uint8_t> sets;
+					size_t bi2 = 0, pi = 0;
+					for (const Part &pt : pieces[pc]) {
+						Bucket &bk = *pt.bk;
+						if (!bk.npar)
+							continue;
+						sets.resize((pi + 1) * max_miss * k, 0);
+						for (size_t r = 0; r < bk.npar; ++r)
+							std::memcpy(&sets[(pi * max_miss + r) * k], bk.plan->rows.v.data() + r * k, k);
+						for (size_t i = pt.first; i < pt.first + pt.count; ++i, ++bi2) {
+							uint8_t *stripe0 = st.d_big + bk.base + i * bk.stripe;
+							size_t q = 0;
+							for (size_t t = 0; t < k; ++t) {
+								const int j = bk.plan->valid[t];
+								in[bi2 * k + t] = stripe0 + ((size_t)j < k ? (size_t)j : k + q++) * S;
+							}
+							pat[bi2] = (uint16_t)pi;
+							for (size_t r = 0; r < bk.npar; ++r) {
+								uint8_t *slot = stripe0 + (size_t)bk.plan->missing[r] * S;
+								outp[bi2 * max_miss + r] = slot;
+								uint8_t *dst = rebuilt[bk.ids[i] * n + bk.plan->missing[r]];
+								const bool direct = aligned16(dst) && pinned().contains(dst, S);
+								outs.push_back({slot, direct ? pinned().dev(dst) : st.h_buf + reb_off + rq * S, S});
+								bk.rq.push_back(rq++);
+							}
+						}
+						++pi;
+					}
+					rc = launch_apply_ptrs(c, st, nb_dec, in.data(), valid.data(), outp.data(), (int)max_miss, S, sets.data(), chain_s, nullptr,
+							       nullptr, pi, pat.data());
 					if (rc)
 						return finish(rc);
+				} else {
+					for (const Part &pt : pieces[pc])
+						if (pt.bk->npar) {
+							rc = decode_range(*pt.bk, pt.first, pt.count, chain_s, outs);
+							if (rc)
+								return finish(rc);
+						}
 				}
+			}
 			if (!outs.empty()) {
 				es = hipEventRecord(st.ev_dec[pc], chain_s);
 				if (es == hipSuccess)

@@ -376,7 +376,7 @@ unsigned resident_grid(const Staging &st, hipStream_t stream, uint32_t tiles, si
 // kernel reads directly.  k <= PTR_KMAX.
 int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uint8_t *const *in, const uint32_t *valid,
 		      uint8_t *const *out, int nout, size_t S, const uint8_t *coef /* nout x k */, hipStream_t stream, uint8_t *d_mirror,
-		      uint32_t *bad)
+		      uint32_t *bad, size_t npat, const uint16_t *pat)
 {
 	const size_t k = c->k;
 	const HipBackend &hb = hip_of(c);
@@ -384,8 +384,11 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 		return GEC_OK;
 	if (k > (size_t)gec::PTR_KMAX || S / 16 > 0xffffffffull)
 		return fail(GEC_E_INVALID_ARG, "shape not supported by the pointer-table kernel");
+	if (pat && (nout > gec::RMAX || npat == 0))
+		return fail(GEC_E_INVALID_ARG, "per-block coefficient sets: one row group only");
 	const size_t in_bytes = nblocks * k * 8, valid_bytes = (nblocks * k * 4 + 7) / 8 * 8, out_bytes = nblocks * (size_t)nout * 8;
-	const size_t need = (st.tab_used * sizeof(gec::CopyEntry) + in_bytes + valid_bytes + out_bytes) / sizeof(gec::CopyEntry) + 2;
+	const size_t coef_bytes = pat ? (npat * k * gec::RMAX + 7) / 8 * 8 : 0, pat_bytes = pat ? (nblocks * 2 + 7) / 8 * 8 : 0;
+	const size_t need = (st.tab_used * sizeof(gec::CopyEntry) + in_bytes + valid_bytes + out_bytes + coef_bytes + pat_bytes) / sizeof(gec::CopyEntry) + 2;
 	if (need > st.tab_cap)
 		return fail(GEC_E_INVALID_ARG, "pointer table overflow");
 	uint8_t *base = reinterpret_cast<uint8_t *>(st.h_tab + st.tab_used);
@@ -397,6 +400,18 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 	std::memcpy(t_valid, valid, nblocks * k * 4);
 	gec::PtrApplyArgs a;
 	std::memset(&a, 0, sizeof(a));
+	if (pat) {
+		uint8_t *t_coef = base + in_bytes + valid_bytes + out_bytes;
+		uint16_t *t_pat = reinterpret_cast<uint16_t *>(t_coef + coef_bytes);
+		std::memset(t_coef, 0, coef_bytes);
+		for (size_t p = 0; p < npat; ++p)
+			for (size_t t = 0; t < k; ++t)
+				for (int r = 0; r < nout; ++r)
+					t_coef[(p * k + t) * gec::RMAX + r] = coef[(p * (size_t)nout + r) * k + t];
+		std::memcpy(t_pat, pat, nblocks * 2);
+		a.coef_tab = t_coef;
+		a.pat = t_pat;
+	}
 	a.cols = (uint32_t)(S / 16);
 	a.k = (uint32_t)k;
 	const unsigned gx = (a.cols + 255) / 256;
@@ -413,7 +428,7 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 	for (int r0 = 0; r0 < nout; r0 += rows) {
 		rows = std::min(gec::RMAX, nout - r0);
 		a.rows = (uint32_t)rows;
-		for (int r = 0; r < gec::RMAX; ++r)
+		for (int r = 0; r < gec::RMAX && !pat; ++r)
 			for (size_t t = 0; t < k; ++t)
 				a.coef[t][r] = r < rows ? coef[(size_t)(r0 + r) * k + t] : 0;
 		uint8_t **grp = t_out + out_done;  // [nblocks][rows] for this group
@@ -442,7 +457,7 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 		// a background codec's rows into HOST memory are paced (GEC_BG_HOME_RATE_GBPS): `grid` resident workgroups, each
 		// writing rows * 4 KiB per tile, start a tile every grid * rows * 4096 / rate nanoseconds
 		a.pace_ticks = 0;
-		if (st.qos.background && !bad && env().bg_home_rate_gbps > 0 && nblocks && pinned().contains(out[0], S))
+		if (st.qos.background && !bad && env().bg_home_rate_gbps > 0 && nblocks && out[0] && pinned().contains(out[0], S))
 			a.pace_ticks = (uint32_t)std::min<uint64_t>((uint64_t)grid * rows * 4096ull / env().bg_home_rate_gbps / 10, 1u << 24);
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, hb.d_logexp);
 		HIP_TRY(hipGetLastError());

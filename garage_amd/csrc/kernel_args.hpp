@@ -71,6 +71,12 @@ struct PtrApplyArgs {
 	// link_wait_ticks (10 ns each) per workgroup and launch, so that it always finishes.
 	uint32_t *link_busy;
 	uint32_t link_role, link_wait_ticks;
+	// Per-block coefficient sets (one decode launch for several erasure patterns): pat != NULL -- block b uses set pat[b],
+	// set p = coef_tab + p * k * RMAX bytes laid out [t][r] like `coef` (which is then unused); a workgroup rebuilds its
+	// tables when the pattern changes between two of its tiles (the host lays blocks out pattern by pattern); a NULL
+	// out[b][r] means block b's pattern has no row r
+	const uint8_t *coef_tab;
+	const uint16_t *pat;
 	// pace_ticks > 0 (10 ns each): a workgroup starts its i-th tile no earlier than i * pace_ticks after its first -- a
 	// BACKGROUND codec's rows on their way into host memory (resync's rebuilt shards) must not fill the fabric's queues
 	// towards the link with posted writes: every load of the request path waits behind them (GEC_BG_HOME_RATE_GBPS)

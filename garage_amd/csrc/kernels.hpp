@@ -437,32 +437,46 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrAppl
 	}
 	if (tid < 192)
 		reinterpret_cast<uint32_t *>(lexp)[tid] = reinterpret_cast<const uint32_t *>(le)[tid];
-	for (uint32_t i = tid; i < k * (RMAX / 4); i += 256)
-		reinterpret_cast<uint32_t *>(lcoef)[i] = reinterpret_cast<const uint32_t *>(&a.coef[0][0])[i];
-	__syncthreads();
-	for (uint32_t idx = tid; idx < k * 32; idx += 256) {
-		const uint32_t t = idx >> 5, e = idx & 31;
-		const uint32_t x = e < 16 ? e : (e - 16) << 4;
-		uint32_t w[MW] = {};
-		if (x) {
-			const uint32_t lx = llog[x];
+	// coefficient set -> nibble product tables (the launch's one set, or the set of the block the workgroup is at)
+	auto build_tables = [&](const uint32_t *cs) {
+		for (uint32_t i = tid; i < k * (RMAX / 4); i += 256)
+			reinterpret_cast<uint32_t *>(lcoef)[i] = cs[i];
+		__syncthreads();
+		for (uint32_t idx = tid; idx < k * 32; idx += 256) {
+			const uint32_t t = idx >> 5, e = idx & 31;
+			const uint32_t x = e < 16 ? e : (e - 16) << 4;
+			uint32_t w[MW] = {};
+			if (x) {
+				const uint32_t lx = llog[x];
 #pragma unroll
-			for (int r = 0; r < 4 * MW; ++r) {
-				const uint32_t c = lcoef[t * RMAX + r];  // rows beyond `rows` are 0
-				const uint32_t p = c ? lexp[llog[c] + lx] : 0;
-				w[r >> 2] |= p << (8 * (r & 3));
+				for (int r = 0; r < 4 * MW; ++r) {
+					const uint32_t c = lcoef[t * RMAX + r];  // rows beyond `rows` are 0
+					const uint32_t p = c ? lexp[llog[c] + lx] : 0;
+					w[r >> 2] |= p << (8 * (r & 3));
+				}
 			}
-		}
-		uint32_t *tdst = reinterpret_cast<uint32_t *>(lds + t * TBL + e * ENT);
+			uint32_t *tdst = reinterpret_cast<uint32_t *>(lds + t * TBL + e * ENT);
 #pragma unroll
-		for (int h = 0; h < MW; ++h)
-			tdst[h] = w[h];
-	}
-	__syncthreads();
+			for (int h = 0; h < MW; ++h)
+				tdst[h] = w[h];
+		}
+		__syncthreads();
+	};
+	uint32_t cur_pat = a.pat ? a.pat[b] : 0;
+	__syncthreads();  // lexp / llog are in place
+	build_tables(a.pat ? reinterpret_cast<const uint32_t *>(a.coef_tab + (size_t)cur_pat * k * RMAX) : reinterpret_cast<const uint32_t *>(&a.coef[0][0]));
 
 	const uint64_t pace_t0 = a.pace_ticks ? wall_clock64() : 0;
 	uint32_t turn = 0;
-	for (;;) {  // one tile per turn; no barrier in here (the tables are read-only from now on)
+	for (;;) {  // one tile per turn; no barrier in here unless the block's coefficient set differs from the last tile's
+		if (a.pat) {
+			const uint32_t p = a.pat[b];
+			if (p != cur_pat) {  // (workgroup-uniform)
+				__syncthreads();
+				build_tables(reinterpret_cast<const uint32_t *>(a.coef_tab + (size_t)p * k * RMAX));
+				cur_pat = p;
+			}
+		}
 		u32x4 *mir = MIRROR ? reinterpret_cast<u32x4 *>(a.mirror + (size_t)b * a.mirror_stride) + col : nullptr;
 		const bool mir_in = MIRROR && live && a.mirror_inputs;
 		uint32_t acc[4][4][MW];
@@ -549,7 +563,7 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrAppl
 			} else {
 #pragma unroll
 				for (int r = 0; r < 4 * MW; ++r) {
-					if (r >= (int)rows)
+					if (r >= (int)rows || !outp[r])
 						continue;
 					const u32x4 v = {P[r][0], P[r][1], P[r][2], P[r][3]};
 					__builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(outp[r]) + col);
