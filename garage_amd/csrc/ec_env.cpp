@@ -37,7 +37,8 @@ const Row kRows[] = {
 	{"GEC_ROWS16", "1", "A/B: 0 = 9..16 output rows as 8-row passes instead of one 16-row pass"},
 	{"GEC_BLAKE2_KERNEL", "auto", "A/B: lane or quad forces one of the two forms of the blake2 kernels (plain hashes, and the leaves / roots of the shard checksums)"},
 	{"GEC_B2_ADD", "0", "A/B: 1 = 64-bit adds of the blake2 kernels spelled as 32-bit add / addc"},
-	{"GEC_GET_PIECES", "8", "a big read trip without block checksums goes in up to this many pieces, upload / checksums + decode / rebuilt shards home pipelined on three streams (0 = one piece: upload, then everything else; A/B)"},
+	{"GEC_PUT_CHUNKS", "3", "gec_encode_hash_batch on pinned memory cuts a trip of 16 or more blocks into at least this many chunks, the checksums of one beside the link kernel of the next (1 = only the size-based chunking; A/B)"},
+	{"GEC_GET_PIECES", "4", "a big read trip without block checksums goes in up to this many pieces, upload / checksums + decode / rebuilt shards home pipelined on three streams (0 = one piece: upload, then everything else; A/B)"},
 	{"GEC_FUSED_SMALL", "1", "A/B: 0 = small pinned trips (a PutObject's / GetObject's few blocks) go through the streaming paths (link kernel + leaf kernel + root kernel [+ one decode launch per erasure pattern]) instead of the one-launch kernel"},
 	{"GEC_FUSED_MAX_LEAVES", "6000", "a trip with fewer 4 KiB leaves to hash than this takes the one-launch kernel (a 1 MiB RS(10,4) put has 364; from ~16 such blocks on the streaming path is as fast: 48 callers through the batcher 27 GiB/s either way up to 12 000, 22.7 at 40 000, profiles/r04_small_trip.txt)"},
 	{"GEC_BG_HOME_RATE_GBPS", "20", "a background-class codec writes rebuilt shards into host memory (resync's rebuilds on their way home) no faster than this (0 = unpaced)"},
@@ -83,7 +84,8 @@ const Env &env()
 		const char *bk = get("GEC_BLAKE2_KERNEL");
 		v.blake2_kernel = !bk ? 0 : (bk[0] == 'l' ? 1 : (bk[0] == 'q' ? 2 : 0));
 		v.b2_add = (int)get_long("GEC_B2_ADD", 0);
-		v.get_pieces = (int)std::min<long>(std::max<long>(get_long("GEC_GET_PIECES", 8), 0), 16);
+		v.put_chunks = (int)std::min<long>(std::max<long>(get_long("GEC_PUT_CHUNKS", 3), 1), 16);
+		v.get_pieces = (int)std::min<long>(std::max<long>(get_long("GEC_GET_PIECES", 4), 0), 16);
 		v.fused_small = (int)get_long("GEC_FUSED_SMALL", 1);
 		v.fused_max_leaves = (size_t)std::max<long>(get_long("GEC_FUSED_MAX_LEAVES", 6000), 0);
 		v.bg_home_rate_gbps = (unsigned)std::max<long>(get_long("GEC_BG_HOME_RATE_GBPS", 20), 0);

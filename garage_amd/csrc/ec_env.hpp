@@ -24,6 +24,7 @@ struct Env {
 	unsigned home_rate_gbps; // GEC_HOME_RATE_GBPS
 	int resident_grid;      // GEC_RESIDENT_GRID
 	int verify_segments;    // GEC_VERIFY_SEGMENTS (0 = the built-in maximum)
+	int put_chunks;         // GEC_PUT_CHUNKS
 	int get_pieces;         // GEC_GET_PIECES
 	int fused_small;        // GEC_FUSED_SMALL
 	size_t fused_max_leaves;  // GEC_FUSED_MAX_LEAVES

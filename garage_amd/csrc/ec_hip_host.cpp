@@ -72,7 +72,12 @@ int HipBackend::encode_batch(size_t nblocks, const uint8_t *const *blocks, const
 			std::memcpy(shard_sums, st.h_buf, nblocks * n * 32);
 			return GEC_OK;
 		}
-		const size_t zch = shard_sums || c->qos_class == GEC_CLASS_BACKGROUND ? chunk_blocks(stripe, nblocks, trip_chunk_bytes(c)) : nblocks;
+		size_t zch = shard_sums || c->qos_class == GEC_CLASS_BACKGROUND ? chunk_blocks(stripe, nblocks, trip_chunk_bytes(c)) : nblocks;
+		// with checksums a trip of a few dozen blocks (a batch of the coalescing queue) goes in three chunks rather than one:
+		// the checksum kernels of chunk i run beside the link kernel of chunk i+1, and only the last third's are left over
+		// when the link falls idle (one chunk: the whole batch's, a fifth of the trip)
+		if (shard_sums && nblocks >= 16 && env().put_chunks > 1)
+			zch = std::min(zch, (nblocks + (size_t)env().put_chunks - 1) / (size_t)env().put_chunks);
 		const size_t nz = (nblocks + zch - 1) / zch;
 		int rc = st.ensure(shard_sums ? nblocks * n * 32 + 64 : 64, 0);
 		if (!rc)
