@@ -169,6 +169,10 @@ struct gbm_batcher {
 		const size_t split_min = env().batcher_split_min;
 		if (split_min && idle > 1 && q.size() >= split_min)
 			take = std::min(take, (q.size() + idle - 1) / idle);
+		else if (split_min && q.size() >= 2 * split_min)
+			// the others are busy: half of a long queue stays for the worker that frees up next -- taking it all is how a
+			// closed loop of callers falls back into one batch (one straggler's tiny batch in flight was enough)
+			take = std::min(take, (q.size() + 1) / 2);
 		std::vector<T *> batch;
 		batch.reserve(take);
 		while (batch.size() < take) {
