@@ -286,7 +286,11 @@ int gec_reconstruct_range_dev(const gec_codec *c, size_t nblocks,
  * buffer laid out [rank][object][slot][S], shard j = slot j/N of rank j%N has
  * shard_off[j] = (j%N)*nobjects*slots*S + (j/N)*S and block_stride = slots*S.
  * All offsets/strides multiples of 16; rebuilt shards are written to their own
- * (shard_off) positions. */
+ * (shard_off) positions.
+ * With a GEC_BACKEND_CPU codec the same call (and gec_reconstruct_range_dev / _batch_dev) works on HOST memory at
+ * d_base -- the strided layout is the call's shape, not a property of device memory; hip_stream is ignored and the
+ * call returns when the shards are rebuilt.  (Encode, verify and the checksums of a CPU codec go through the
+ * host-pointer entry points.) */
 int gec_reconstruct_scattered_dev(const gec_codec *c, size_t nblocks,
 				  void *d_base, size_t block_stride,
 				  const size_t *shard_off, size_t S,
@@ -328,7 +332,11 @@ int gec_group_create(const gec_codec *c, int rank, int nranks,
 /* Bring-your-own transport instead of RCCL (another fabric, or N logical ranks on
  * one device in the tests).  all_gather must deliver, for every rank q, rank q's
  * `bytes` at d_recv + q*bytes on every rank, ordered with respect to `hip_stream`
- * (it may enqueue asynchronously on it or block); 0 = success. */
+ * (it may enqueue asynchronously on it or block); 0 = success.
+ * Over a GEC_BACKEND_CPU codec such a group runs the same steps on HOST buffers (d_local_slots, d_gathered,
+ * d_rebuilt and the transport's pointers are host memory, hip_stream is NULL / ignored, the calls block): a rank
+ * that has lost its GPU stays in the group, and ranks of different backends interoperate as long as the transport
+ * moves bytes between their buffers.  (gec_group_create, RCCL, needs a HIP codec.) */
 typedef int (*gec_allgather_fn)(void *ctx, const void *d_send, void *d_recv,
 				size_t bytes, void *hip_stream);
 int gec_group_create_with_transport(const gec_codec *c, int rank, int nranks,
