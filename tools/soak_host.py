@@ -33,6 +33,8 @@ def main():
         c = rs[(k, m)]
         L = int(rng.choice([1 << 20, 65536, 300_000, 4097 * k, 1_000_003])) if k < 64 else 64 * k * int(rng.integers(1, 40))
         nb = int(rng.integers(1, 90 if L > 500_000 else 300))
+        if it % 3 == 0:          # a third of the iterations are small trips: the one-launch kernel (fused.hpp)
+            nb = int(rng.integers(1, 9))
         S = g.shard_len(k, L)
         lens = [L if rng.random() < 0.7 else int(rng.integers(0, L + 1)) for _ in range(nb)]
         arena = host_alloc(nb * n * S)
@@ -88,7 +90,35 @@ def main():
         b = int(rng.integers(nb))
         j = lost[b][0]
         assert outs[b, j].tobytes() == g.shardsum(ref[b, j].tobytes()), f"checksum of a rebuilt shard, iteration {it}"
-        nbytes += nb * n * S * 3
+        # the read path in one trip (gec_decode_verify_batch, no block checksums): a random erasure pattern per block, blocks
+        # that need no decode among them -- the one-launch kernel for small trips, pipelined pieces for big ones
+        sp2 = (ctypes.c_void_p * (nb * n))()
+        op2 = (ctypes.c_void_p * (nb * n))()
+        lost2, reb = [], {}
+        for b in range(nb):
+            ls = sorted(int(x) for x in rng.choice(n, size=int(rng.integers(0, m + 1)), replace=False)) if rng.random() < 0.7 else []
+            lost2.append(ls)
+            i = 0
+            for j in range(n):
+                sp2[b * n + j] = None if j in ls else arena.ctypes.data + (b * n + j) * S
+                if j in ls and j < k:
+                    op2[b * n + j] = out.ctypes.data + (b * m + i) * S
+                    reb[(b, j)] = (b, i)
+                    i += 1
+        out[:] = 0xAB
+        ssums = np.zeros((nb, n, 32), dtype=np.uint8)
+        blen = (ctypes.c_size_t * nb)(*[k * S] * nb)
+        _lib.check(lib.gec_decode_verify_batch(c._h, nb, sp2, S, blen, op2, ssums.ctypes.data_as(u8), None), "decode_verify")
+        for (b, j), (bb2, i) in reb.items():
+            assert np.array_equal(ob[bb2, i], ref[b, j]), f"decode_verify: rebuilt shard, iteration {it} block {b} shard {j} nb={nb} RS({k},{m})"
+        for b in set([0, nb - 1, int(rng.integers(nb))]):
+            present = [j for j in range(n) if j not in lost2[b]][:k]
+            for j in range(n):
+                if j in present:
+                    assert ssums[b, j].tobytes() == g.shardsum(ref[b, j].tobytes()), f"decode_verify: checksum, iteration {it} block {b} shard {j}"
+                else:
+                    assert not ssums[b, j].any(), f"decode_verify: checksum of a shard that was not read, iteration {it}"
+        nbytes += nb * n * S * 4
         host_free(out)
         host_free(arena)
         it += 1
