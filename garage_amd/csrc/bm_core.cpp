@@ -34,7 +34,7 @@ const EnvRow kEnvRows[] = {
 	{"GBM_PUT_SLICE", "64", "blocks per slice of a large untagged put"},
 	{"GBM_PUT_THREADS", "4", "put slices in flight"},
 	{"GBM_BATCHER_WORKERS", "2", "batches the coalescing batcher keeps in flight (per device)"},
-	{"GBM_BATCHER_SPLIT_MIN", "8", "a batcher worker that finds this many blocks queued while other workers are idle takes only its share of them (0 = never split)"},
+	{"GBM_BATCHER_SPLIT_MIN", "8", "a batcher worker that finds this many blocks queued while other workers are idle takes only its share of them, and half of a queue twice this long even when none is idle (0 = never split)"},
 	{"GBM_BATCHER_GAP_US", "clamp(linger / 10, 20, 100)", "the batcher's linger ends once nobody has arrived for this long (A/B; 0 = the default)"},
 	{"GBM_BATCHER_LONE_SKIP", "1", "1 = a block that arrives alone (nothing in flight, the previous batch a single block) goes without the linger (0 = always linger; A/B)"},
 	{"GBM_BATCHER_DEVICE_TURN", "1", "1 = one put batch and one get batch of a device's queue on the link at a time, the others prepare / fan out meanwhile (0 = trips overlap freely)"},
