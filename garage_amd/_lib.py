@@ -35,7 +35,8 @@ GEC_CLASS_FOREGROUND, GEC_CLASS_BACKGROUND = 0, 1
 # every symbol include/garage_ec.h declares (tests/test_cabi_host.py::test_every_declared_symbol_is_exported checks
 # this list against the header and against the built library)
 SYMBOLS = [
-    "gec_version", "gec_device_count", "gec_device_of_hash", "gec_strerror", "gec_last_error", "gec_env_table", "gec_cpu_isa",
+    "gec_version", "gec_device_count", "gec_device_of_hash", "gec_thread_link_release", "gec_strerror", "gec_last_error", "gec_env_table",
+    "gec_cpu_isa",
     "gec_shard_len", "gec_build_matrix", "gec_build_matrix_ex", "gec_build_decode_matrix",
     "gec_codec_create", "gec_codec_create_ex", "gec_codec_destroy", "gec_codec_k", "gec_codec_m",
     "gec_codec_device", "gec_parity_matrix", "gec_codec_cache_stats",

@@ -277,6 +277,23 @@ int create_codec(int k, int m, int backend, int device, int matrix, int qos_clas
 using namespace gecimpl;
 
 // ---------------------------------------------------------------------------
+static thread_local gec_link_release_fn t_release_fn = nullptr;
+static thread_local void *t_release_arg = nullptr;
+namespace gecimpl {
+void link_release_fire()
+{
+	if (gec_link_release_fn fn = t_release_fn) {
+		t_release_fn = nullptr;
+		fn(t_release_arg);
+	}
+}
+bool link_release_armed() { return t_release_fn != nullptr; }
+}  // namespace gecimpl
+namespace {
+struct LinkReleaseScope {
+	~LinkReleaseScope() { gecimpl::link_release_fire(); }
+};
+}  // namespace
 extern "C" {
 
 uint32_t gec_version(void) { return GEC_VERSION; }
@@ -307,6 +324,12 @@ const char *gec_strerror(int code)
 }
 
 const char *gec_last_error(void) { return g_last_error.c_str(); }
+
+void gec_thread_link_release(gec_link_release_fn fn, void *arg)
+{
+	t_release_fn = fn;
+	t_release_arg = arg;
+}
 
 const char *gec_env_table(void) { return env_table_text(); }
 
@@ -436,6 +459,7 @@ int gec_encode_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *b
 int gec_encode_hash_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *blocks, const size_t *block_len, size_t S,
 			  uint8_t *const *parity, uint8_t *shard_sums)
 {
+	LinkReleaseScope release;
 	if (!shard_sums)
 		return fail(GEC_E_INVALID_ARG, "NULL shard_sums");
 	return encode_common(c, nblocks, blocks, block_len, S, parity, shard_sums);
@@ -509,6 +533,7 @@ int gec_reconstruct_hash_batch(const gec_codec *c, size_t nblocks, const uint8_t
 int gec_decode_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, size_t S, const size_t *block_len,
 			    uint8_t *const *rebuilt, uint8_t *shard_sums, uint8_t *block_sums)
 {
+	LinkReleaseScope release;
 	if (!c)
 		return fail(GEC_E_INVALID_ARG, "NULL codec");
 	if (nblocks == 0)

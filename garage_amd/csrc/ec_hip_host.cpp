@@ -129,7 +129,9 @@ int HipBackend::encode_batch(size_t nblocks, const uint8_t *const *blocks, const
 			if (!rc && hipEventRecord(st.ev_seg[2 + (ci & 1)], chain) != hipSuccess)
 				rc = fail(GEC_E_DEVICE, "hipEventRecord");
 		}
-		const hipError_t e1 = hipStreamSynchronize(up), e2 = shard_sums ? hipStreamSynchronize(chain) : hipSuccess;
+		const hipError_t e1 = hipStreamSynchronize(up);
+		link_release_fire();  // the link is free: what is left are the last chunk's checksum kernels
+		const hipError_t e2 = shard_sums ? hipStreamSynchronize(chain) : hipSuccess;
 		if (rc)
 			return rc;
 		HIP_TRY(e1);
@@ -850,6 +852,8 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 			}
 		}
 		hipError_t e1 = hipStreamSynchronize(up_s);
+		if (nreb == 0)
+			link_release_fire();  // nothing goes home: the link is free, the last piece's checksums are what is left
 		if (e1 == hipSuccess)
 			e1 = hipStreamSynchronize(chain_s);
 		if (e1 == hipSuccess)
@@ -1000,6 +1004,8 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 		if (e != hipSuccess)
 			return finish(hip_fail(e, "join"));
 	}
+	if (link_release_armed() && nreb == 0 && hipEventSynchronize(ev_up) == hipSuccess)
+		link_release_fire();  // everything is up and nothing goes home: the link is free while the checksums run
 	e = hipStreamWaitEvent(st.stream, ev_sh, 0);
 	if (e == hipSuccess)
 		e = hipStreamSynchronize(st.stream);

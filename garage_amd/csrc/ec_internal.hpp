@@ -129,6 +129,11 @@ int make_cpu_backend(gec_codec *c, std::unique_ptr<Backend> &out);
 int make_hip_backend(gec_codec *c, int device, std::unique_ptr<Backend> &out);
 int hip_device_count();
 
+// gec_thread_link_release: calls the hook this thread armed (once; no-op when none is armed).  A backend calls it when a
+// host-pointer call's bulk transfers are over; the entry points call it again on the way out.
+void link_release_fire();
+bool link_release_armed();
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace gecimpl

@@ -83,6 +83,15 @@ int gec_device_count(void);
  * libgarage_block's multi-device manager (gbm_create_multi), garage_amd/partition.py and bench.py all call it.
  * ndev < 1 or a NULL hash: -1. */
 int gec_device_of_hash(const uint8_t hash[32], int ndev);
+/* A blocking host-pointer call keeps the host link busy only for part of its time: the kernels that read the caller's
+ * buffers and write results into them come first, checksum kernels over what is by then in HBM and a few small copies
+ * follow.  A scheduler that lets one call per device onto the link at a time (libgarage_block's coalescing queue does) can
+ * let the next one start at that point instead of at the return.  gec_thread_link_release(fn, arg) arms the CALLING
+ * THREAD's next gec_encode_hash_batch / gec_decode_verify_batch: fn(arg) is called exactly once, on that thread, when the
+ * call's bulk transfers over the link have finished -- at the latest right before the call returns (errors, calls without
+ * such a phase, CPU codecs).  fn = NULL disarms.  Results are unaffected. */
+typedef void (*gec_link_release_fn)(void *arg);
+void gec_thread_link_release(gec_link_release_fn fn, void *arg);
 /* Every GEC_* environment switch: "NAME<tab>default<tab>meaning" lines (static storage). */
 const char *gec_env_table(void);
 /* The kernel a GEC_BACKEND_CPU codec runs on this host: "avx512+gfni", "avx2" or "scalar" (static storage). */

@@ -218,3 +218,37 @@ def test_cauchy_matrix_matches_restatement_and_is_mds():
     assert not np.array_equal(g.build_matrix(10, 4, "cauchy"), g.build_matrix(10, 4))
     with pytest.raises(g.GecError):
         _lib.check(_lib.lib.gec_build_matrix_ex(10, 4, 7, M.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), "kind")
+
+
+def test_link_release_hook_fires_once_per_armed_call():
+    """gec_thread_link_release: the hook fires exactly once for the next gec_encode_hash_batch / gec_decode_verify_batch of the
+    arming thread (a CPU codec has no link phase: right before the call returns), on errors too, and never when disarmed."""
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+    fired = []
+    cb = FN(lambda arg: fired.append(arg))
+    lib.gec_thread_link_release.argtypes = [FN, ctypes.c_void_p]
+    lib.gec_thread_link_release.restype = None
+    rs = g.ReedSolomon(3, 1, backend="cpu")
+    S = 64
+    data = np.arange(3 * S, dtype=np.uint8)
+    parity = np.zeros(S, dtype=np.uint8)
+    sums = np.zeros(4 * 32, dtype=np.uint8)
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    blocks = (ctypes.c_void_p * 1)(data.ctypes.data)
+    pars = (ctypes.c_void_p * 1)(parity.ctypes.data)
+    lens = (ctypes.c_size_t * 1)(3 * S)
+
+    def encode(sums_ptr):
+        return lib.gec_encode_hash_batch(ctypes.c_void_p(rs._h.value if hasattr(rs._h, "value") else rs._h), ctypes.c_size_t(1), blocks, lens,
+                                         ctypes.c_size_t(S), pars, sums_ptr)
+
+    lib.gec_thread_link_release(cb, ctypes.c_void_p(7))
+    assert encode(sums.ctypes.data_as(u8p)) == _lib.GEC_OK and fired == [7]
+    assert encode(sums.ctypes.data_as(u8p)) == _lib.GEC_OK and fired == [7]  # one call per arming
+    lib.gec_thread_link_release(cb, ctypes.c_void_p(8))
+    assert encode(None) == _lib.GEC_E_INVALID_ARG and fired == [7, 8]  # a failing call still gives the turn back
+    lib.gec_thread_link_release(cb, ctypes.c_void_p(9))
+    lib.gec_thread_link_release(FN(), None)  # disarm
+    assert encode(sums.ctypes.data_as(u8p)) == _lib.GEC_OK and fired == [7, 8]
+    assert sums[:32].tobytes() == g.shardsum(data[:S].tobytes())
