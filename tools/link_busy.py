@@ -2,7 +2,7 @@
 """How busy is the host link?  Reads a rocprofv3 --kernel-trace CSV and reports, for the last `frac` of the trace (the steady
 state of a closed-loop run), the share of wall time during which at least one LINK kernel (gf_apply_ptrs, gf_ptrs_hash,
 copy_table: the kernels that read / write caller memory) was running, and the same for all kernels.
-usage: link_busy.py <kernel_trace.csv> [frac=0.3]"""
+usage: link_busy.py <kernel_trace.csv> [frac=0.3 | milliseconds]"""
 import csv
 import sys
 
@@ -30,7 +30,7 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     t0, t1 = min(r[0] for r in rows), max(r[1] for r in rows)
-    w0 = t1 - int((t1 - t0) * frac)
+    w0 = t1 - (int(frac * 1e6) if frac > 1 else int((t1 - t0) * frac))  # a value above 1: the last so many milliseconds
     link = [(max(s, w0), e) for s, e, n in rows if e > w0 and any(x in n for x in ("gf_apply_ptrs", "gf_ptrs_hash", "copy_table"))]
     allk = [(max(s, w0), e) for s, e, n in rows if e > w0]
     names = {}

@@ -30,6 +30,6 @@ for TURN in 1 2; do
   ( cd /tmp && GBM_BATCHER_DEVICE_TURN=$TURN timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$G/trace_turn$TURN" -- "$R/tools/batcher_bench" 48 20 128 300 > "$G/trace_turn$TURN.log" 2>&1 )
   F=$(find "$G/trace_turn$TURN" -name '*kernel_trace.csv' | head -1)
   echo "== link busy, 48 callers, turn $TURN" | tee -a "$G/link_busy.txt"
-  python tools/link_busy.py "$F" 0.12 | tee -a "$G/link_busy.txt"
+  python tools/link_busy.py "$F" 25 | tee -a "$G/link_busy.txt"
   rm -rf "$G/trace_turn$TURN"
 done
