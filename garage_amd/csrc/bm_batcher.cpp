@@ -147,7 +147,7 @@ struct gbm_batcher {
 	// pthread_cond_clockwait is not intercepted by gcc 11's TSan and floods the report with false "double lock" findings)
 	template <class T>
 	std::vector<T *> form(std::unique_lock<std::mutex> &lk, std::condition_variable &cv, std::deque<T *> &q, const bool &stopping,
-			      int busy_now, size_t nworkers, size_t &last_size)
+			      int busy_now, size_t nworkers, size_t &last_size, size_t split_min)
 	{
 		// Callers in a closed loop are not made to wait for company that never comes: when the previous batch was formed with
 		// nothing in flight it held everybody there is (one block of a lone caller, the three of a PutObject), so with nothing
@@ -169,7 +169,6 @@ struct gbm_batcher {
 		}
 		size_t take = std::min(q.size(), max_blocks);
 		const size_t idle = nworkers > (size_t)busy_now ? nworkers - (size_t)busy_now : 1;  // this worker included
-		const size_t split_min = env().batcher_split_min;
 		if (split_min && idle > 1 && q.size() >= split_min)
 			take = std::min(take, (q.size() + idle - 1) / idle);
 		else if (split_min && q.size() >= 2 * split_min)
@@ -234,7 +233,7 @@ struct gbm_batcher {
 				continue;
 			}
 			gforming = true;
-			std::vector<GetItem *> batch = form(lk, gcv_work, gqueue, stop_gets, gbusy, gworkers.size(), glast_size);
+			std::vector<GetItem *> batch = form(lk, gcv_work, gqueue, stop_gets, gbusy, gworkers.size(), glast_size, env().batcher_get_split_min);
 			gforming = false;
 			++gbusy;
 			gcv_work.notify_all();
@@ -314,7 +313,7 @@ struct gbm_batcher {
 				continue;
 			}
 			forming = true;
-			std::vector<Item *> batch = form(lk, cv_work, queue, stop, busy, workers.size(), last_size);
+			std::vector<Item *> batch = form(lk, cv_work, queue, stop, busy, workers.size(), last_size, env().batcher_split_min);
 			bool any_tag = false;
 			for (Item *it : batch)
 				any_tag = any_tag || it->has_tag;

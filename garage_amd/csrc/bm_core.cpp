@@ -35,6 +35,7 @@ const EnvRow kEnvRows[] = {
 	{"GBM_PUT_THREADS", "4", "put slices in flight"},
 	{"GBM_BATCHER_WORKERS", "2", "batches the coalescing batcher keeps in flight (per device)"},
 	{"GBM_BATCHER_SPLIT_MIN", "8", "a batcher worker that finds this many blocks queued while other workers are idle takes only its share of them, and half of a queue twice this long even when none is idle (0 = never split)"},
+	{"GBM_BATCHER_GET_SPLIT_MIN", "16", "the same rule for the queue's read side (a big read batch goes in pipelined pieces of its own: it is cut later than a put batch)"},
 	{"GBM_BATCHER_GAP_US", "clamp(linger / 10, 20, 100)", "the batcher's linger ends once nobody has arrived for this long (A/B; 0 = the default)"},
 	{"GBM_BATCHER_LONE_SKIP", "1", "1 = a block that arrives alone (nothing in flight, the previous batch a single block) goes without the linger (0 = always linger; A/B)"},
 	{"GBM_BATCHER_DEVICE_TURN", "1", "one put batch and one get batch of a device's queue on the link at a time, the others prepare / fan out meanwhile: 1 = until the codec call returns, 2 = until its bulk transfers are over (gec_thread_link_release: the next batch's upload runs beside this one's last checksum kernels), 0 = trips overlap freely"},
@@ -60,6 +61,8 @@ const Env &env()
 		v.batcher_workers = (int)(bw >= 1 && bw <= 16 ? bw : 2);
 		const long sm = env_long("GBM_BATCHER_SPLIT_MIN", 8);
 		v.batcher_split_min = (size_t)(sm >= 0 ? sm : 8);
+		const long gsm = env_long("GBM_BATCHER_GET_SPLIT_MIN", 16);
+		v.batcher_get_split_min = (size_t)(gsm >= 0 ? gsm : 16);
 		v.batcher_device_turn = (int)std::min<long>(std::max<long>(env_long("GBM_BATCHER_DEVICE_TURN", 1), 0), 2);
 		v.batcher_lone_skip = env_long("GBM_BATCHER_LONE_SKIP", 1) != 0;
 		const long gp = env_long("GBM_BATCHER_GAP_US", 0);

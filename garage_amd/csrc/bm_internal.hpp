@@ -54,6 +54,7 @@ struct Env {
 	int put_threads;          // GBM_PUT_THREADS
 	int batcher_workers;      // GBM_BATCHER_WORKERS
 	size_t batcher_split_min; // GBM_BATCHER_SPLIT_MIN
+	size_t batcher_get_split_min; // GBM_BATCHER_GET_SPLIT_MIN
 	int batcher_device_turn;  // GBM_BATCHER_DEVICE_TURN
 	unsigned batcher_gap_us;  // GBM_BATCHER_GAP_US
 	bool batcher_lone_skip;   // GBM_BATCHER_LONE_SKIP
