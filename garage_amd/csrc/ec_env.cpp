@@ -37,10 +37,12 @@ const Row kRows[] = {
 	{"GEC_ROWS16", "1", "A/B: 0 = 9..16 output rows as 8-row passes instead of one 16-row pass"},
 	{"GEC_BLAKE2_KERNEL", "auto", "A/B: lane or quad forces one of the two forms of the blake2 kernels (plain hashes, and the leaves / roots of the shard checksums)"},
 	{"GEC_B2_ADD", "0", "A/B: 1 = 64-bit adds of the blake2 kernels spelled as 32-bit add / addc"},
-	{"GEC_PUT_CHUNKS", "3", "gec_encode_hash_batch on pinned memory cuts a trip of 16 or more blocks into at least this many chunks, the checksums of one beside the link kernel of the next (1 = only the size-based chunking; A/B)"},
+	{"GEC_PUT_CHUNKS", "1", "A/B: gec_encode_hash_batch on pinned memory cuts a trip of 16 or more blocks into at least this many chunks, the checksums of one beside the link kernel of the next (1 = only the size-based chunking: one link kernel, one leaf and one root kernel -- 10-15 % faster per trip at 16-32 blocks, profiles/r04_trip_bench.txt)"},
+	{"GEC_GET_PIECES_MIN", "24", "read trips of at least this many blocks go in pieces (a piece has at least 12 blocks)"},
 	{"GEC_GET_PIECES", "4", "a big read trip without block checksums goes in up to this many pieces, upload / checksums + decode / rebuilt shards home pipelined on three streams (0 = one piece: upload, then everything else; A/B)"},
 	{"GEC_FUSED_SMALL", "1", "A/B: 0 = small pinned trips (a PutObject's / GetObject's few blocks) go through the streaming paths (link kernel + leaf kernel + root kernel [+ one decode launch per erasure pattern]) instead of the one-launch kernel"},
-	{"GEC_FUSED_MAX_LEAVES", "6000", "a trip with fewer 4 KiB leaves to hash than this takes the one-launch kernel (a 1 MiB RS(10,4) put has 364; from ~16 such blocks on the streaming path is as fast: 48 callers through the batcher 27 GiB/s either way up to 12 000, 22.7 at 40 000, profiles/r04_small_trip.txt)"},
+	{"GEC_FUSED_MAX_LEAVES", "3300", "a put trip (gec_encode_hash_batch) with fewer 4 KiB leaves to hash than this takes the one-launch kernel (a 1 MiB RS(10,4) block has 364: up to 9 such blocks; from there on the link kernel + the one-lane-per-leaf checksum kernels are faster per trip, profiles/r04_trip_bench.txt)"},
+	{"GEC_FUSED_GET_MAX_LEAVES", "4400", "the same for a read trip (gec_decode_verify_batch without block checksums: k leaves per tile, 260 per 1 MiB RS(10,4) block: up to 16 such blocks)"},
 	{"GEC_BG_HOME_RATE_GBPS", "20", "a background-class codec writes rebuilt shards into host memory (resync's rebuilds on their way home) no faster than this (0 = unpaced)"},
 	{"GEC_MAX_COLS_PER_LAUNCH", "0", "test hook: cap on the 16-byte columns one launch covers, to exercise the multi-launch split on small inputs"},
 	{"GEC_RCCL_LIB", "librccl.so.1", "RCCL to dlopen for gec_group_*"},
@@ -84,10 +86,12 @@ const Env &env()
 		const char *bk = get("GEC_BLAKE2_KERNEL");
 		v.blake2_kernel = !bk ? 0 : (bk[0] == 'l' ? 1 : (bk[0] == 'q' ? 2 : 0));
 		v.b2_add = (int)get_long("GEC_B2_ADD", 0);
-		v.put_chunks = (int)std::min<long>(std::max<long>(get_long("GEC_PUT_CHUNKS", 3), 1), 16);
+		v.put_chunks = (int)std::min<long>(std::max<long>(get_long("GEC_PUT_CHUNKS", 1), 1), 16);
+		v.get_pieces_min = (int)std::min<long>(std::max<long>(get_long("GEC_GET_PIECES_MIN", 24), 1), 1 << 20);
 		v.get_pieces = (int)std::min<long>(std::max<long>(get_long("GEC_GET_PIECES", 4), 0), 16);
 		v.fused_small = (int)get_long("GEC_FUSED_SMALL", 1);
-		v.fused_max_leaves = (size_t)std::max<long>(get_long("GEC_FUSED_MAX_LEAVES", 6000), 0);
+		v.fused_max_leaves = (size_t)std::max<long>(get_long("GEC_FUSED_MAX_LEAVES", 3300), 0);
+		v.fused_get_max_leaves = (size_t)std::max<long>(get_long("GEC_FUSED_GET_MAX_LEAVES", 4400), 0);
 		v.bg_home_rate_gbps = (unsigned)std::max<long>(get_long("GEC_BG_HOME_RATE_GBPS", 20), 0);
 		v.max_cols_per_launch = get("GEC_MAX_COLS_PER_LAUNCH") ? std::strtoull(get("GEC_MAX_COLS_PER_LAUNCH"), nullptr, 0) : 0ull;
 		v.rccl_lib = get("GEC_RCCL_LIB") ? get("GEC_RCCL_LIB") : "";

@@ -26,8 +26,10 @@ struct Env {
 	int verify_segments;    // GEC_VERIFY_SEGMENTS (0 = the built-in maximum)
 	int put_chunks;         // GEC_PUT_CHUNKS
 	int get_pieces;         // GEC_GET_PIECES
+	int get_pieces_min;  // GEC_GET_PIECES_MIN
 	int fused_small;        // GEC_FUSED_SMALL
 	size_t fused_max_leaves;  // GEC_FUSED_MAX_LEAVES
+	size_t fused_get_max_leaves;  // GEC_FUSED_GET_MAX_LEAVES
 	unsigned bg_home_rate_gbps;  // GEC_BG_HOME_RATE_GBPS
 	size_t pinned_chunk_mb; // GEC_PINNED_CHUNK_MB
 	bool hash_fork;         // GEC_HASH_FORK

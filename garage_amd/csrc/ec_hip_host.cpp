@@ -729,12 +729,12 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 	// shard checksums, the decodes, the rebuilt shards' way home -- 17 ms with 4 of 16 nodes down.  In pieces instead:
 	// piece c+1 is on its way up while piece c is hashed and decoded and piece c-1's rebuilt shards travel down (the link
 	// is full duplex) -- three streams, one event per piece and direction.
-	if (all_pinned && !block_sums && nblocks >= 48 && env().get_pieces != 0) {
+	if (all_pinned && !block_sums && nblocks >= (size_t)env().get_pieces_min && env().get_pieces != 0) {
 		struct Part {
 			Bucket *bk;
 			size_t first, count;
 		};
-		const size_t npieces = std::min<size_t>({(size_t)Staging::kMaxSeg, (size_t)std::max(1, env().get_pieces), nblocks / 16});
+		const size_t npieces = std::max<size_t>(1, std::min<size_t>({(size_t)Staging::kMaxSeg, (size_t)std::max(1, env().get_pieces), nblocks / 12}));
 		const size_t per_piece = (nblocks + npieces - 1) / npieces;
 		std::vector<std::vector<Part>> pieces(1);
 		size_t in_piece = 0;

@@ -498,7 +498,7 @@ bool fused_fits(const gec_codec *c, size_t nblocks, size_t S, int nout, bool has
 	if (S % 16 || tiles_x * nblocks > 0xffffffffull)
 		return false;
 	// small: the trip's leaves (what the one-lane-per-leaf kernels need tens of thousands of to fill the chip)
-	if (tiles_x * nblocks * nh >= env().fused_max_leaves)
+	if (tiles_x * nblocks * nh >= (hash_rows ? env().fused_max_leaves : env().fused_get_max_leaves))
 		return false;
 	return fused_lds_bytes(k, nh, nout <= 4 ? 1 : 2) <= max_lds_per_workgroup(c->device);
 }

@@ -92,14 +92,14 @@ def _get(rs, k, m, S, full, lost, with_block_sums=False):
     return ssums, out
 
 
-@pytest.mark.parametrize("k,m,L,nb", [(10, 4, 1 << 20, 1), (10, 4, 1 << 20, 24), (3, 1, 65536, 12), (20, 8, 1 << 20, 6),
-                                      (10, 4, 1 << 20, 96), (10, 4, 300_000, 130), (20, 8, 4 << 20, 50)],
-                         ids=["one_block", "24_blocks_many_patterns", "rs3_1", "rs20_8", "96_blocks_in_pieces", "130_blocks_in_pieces",
-                              "rs20_8_50_blocks_in_pieces"])
+@pytest.mark.parametrize("k,m,L,nb", [(10, 4, 1 << 20, 1), (10, 4, 1 << 20, 14), (10, 4, 1 << 20, 20), (10, 4, 1 << 20, 24),
+                                      (3, 1, 65536, 12), (20, 8, 1 << 20, 6), (10, 4, 1 << 20, 96), (10, 4, 300_000, 130), (20, 8, 4 << 20, 50)],
+                         ids=["one_block", "14_blocks_many_patterns", "20_blocks_streaming", "24_blocks_in_two_pieces", "rs3_1", "rs20_8",
+                              "96_blocks_in_pieces", "130_blocks_in_pieces", "rs20_8_50_blocks_in_pieces"])
 def test_get_in_one_launch_many_erasure_patterns(coracle, k, m, L, nb):
     """One launch serves a batch whose blocks lost DIFFERENT shards (a coefficient set per block): checksums of exactly
     the first k shards in hand, every missing data shard rebuilt, blocks that need no decode beside blocks that do.
-    (From 48 blocks on the trip is too big for the one-launch kernel and goes in PIECES instead -- upload / checksums +
+    (Past GEC_FUSED_GET_MAX_LEAVES the streaming path takes over, and from 24 blocks on the trip goes in PIECES -- upload / checksums +
     decode / rebuilt shards home pipelined on three streams, ec_hip_host.cpp: the same assertions.)"""
     rs = g.ReedSolomon(k, m)
     n, S = k + m, g.shard_len(k, L)
