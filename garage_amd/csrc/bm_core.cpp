@@ -34,7 +34,7 @@ const EnvRow kEnvRows[] = {
 	{"GBM_PUT_SLICE", "64", "blocks per slice of a large untagged put"},
 	{"GBM_PUT_THREADS", "4", "put slices in flight"},
 	{"GBM_BATCHER_WORKERS", "2", "batches the coalescing batcher keeps in flight (per device)"},
-	{"GBM_BATCHER_SPLIT_MIN", "8", "a batcher worker that finds this many blocks queued while other workers are idle takes only its share of them, and half of a queue twice this long even when none is idle (0 = never split)"},
+	{"GBM_BATCHER_SPLIT_MIN", "12", "a batcher worker that finds this many blocks queued while other workers are idle takes only its share of them, and half of a queue twice this long even when none is idle (0 = never split)"},
 	{"GBM_BATCHER_GET_SPLIT_MIN", "16", "the same rule for the queue's read side (a big read batch goes in pipelined pieces of its own: it is cut later than a put batch)"},
 	{"GBM_BATCHER_GAP_US", "clamp(linger / 10, 20, 100)", "the batcher's linger ends once nobody has arrived for this long (A/B; 0 = the default)"},
 	{"GBM_BATCHER_LONE_SKIP", "1", "1 = a block that arrives alone (nothing in flight, the previous batch a single block) goes without the linger (0 = always linger; A/B)"},
@@ -59,8 +59,8 @@ const Env &env()
 		v.put_threads = (int)(pt > 0 && pt <= 8 ? pt : 4);
 		const long bw = env_long("GBM_BATCHER_WORKERS", 0);
 		v.batcher_workers = (int)(bw >= 1 && bw <= 16 ? bw : 2);
-		const long sm = env_long("GBM_BATCHER_SPLIT_MIN", 8);
-		v.batcher_split_min = (size_t)(sm >= 0 ? sm : 8);
+		const long sm = env_long("GBM_BATCHER_SPLIT_MIN", 12);
+		v.batcher_split_min = (size_t)(sm >= 0 ? sm : 12);
 		const long gsm = env_long("GBM_BATCHER_GET_SPLIT_MIN", 16);
 		v.batcher_get_split_min = (size_t)(gsm >= 0 ? gsm : 16);
 		v.batcher_device_turn = (int)std::min<long>(std::max<long>(env_long("GBM_BATCHER_DEVICE_TURN", 1), 0), 2);
