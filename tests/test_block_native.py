@@ -364,6 +364,10 @@ def test_batcher_coalesces_concurrent_puts(backend):
     blocks = [[pattern_block(262144 + 4096 * (t * PER + j), t * 100 + j) for j in range(PER)] for t in range(T)]
     hashes = [[bn.blake2sum(b) for b in row] for row in blocks]
     errors = []
+    # (callers that never overlap have nothing to coalesce -- a block that arrives with nothing in flight goes at once -- and
+    # sixteen Python threads storing 300 KB blocks in memory nodes may well never overlap: the nodes answer after 1 ms, like disks)
+    for nd in range(16):
+        mgr.node_set_latency(nd, 1000)
 
     def worker(t):
         try:
@@ -381,6 +385,8 @@ def test_batcher_coalesces_concurrent_puts(backend):
     # (how many batches there are depends on how the callers' gets interleave and on when the linger sees arrivals
     # stop -- a timing property, tools/batcher_bench measures it -- but 16 callers released together must coalesce)
     assert st["blocks"] == T * PER and st["batches"] < T * PER and 2 <= st["max_batch"] <= 32, st
+    for nd in range(16):
+        mgr.node_set_latency(nd, 0)
     who = mgr.storage_nodes_of(hashes[0][0])
     for j in range(3):
         mgr.node_set_down(who[j], True)
