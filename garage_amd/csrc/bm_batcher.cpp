@@ -341,7 +341,7 @@ struct gbm_batcher {
 					lens[i] = batch[i]->len;
 					pc[i] = batch[i]->prevent_compression;
 					// untagged blocks sort after tagged ones of the same batch; their relative order is free
-					tags[i] = batch[i]->has_tag ? batch[i]->tag : gbm_order_tag{~0ull, i};
+					tags[i] = batch[i]->has_tag ? batch[i]->tag : gbm_order_tag{GBM_NO_STREAM, i};
 				}
 				FanoutGate gate;
 				LinkTurn turn{&dev_mu};

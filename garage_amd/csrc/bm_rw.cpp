@@ -459,6 +459,9 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 		std::lock_guard<std::mutex> g(parked_mu);
 		parked.emplace_back(b, j, node);
 	};
+	// (a tag array may hold untagged blocks -- the coalescing queue mixes requests: GBM_NO_STREAM marks them; they are
+	// ordered behind the tagged ones and reach the nodes without a tag, like a put with order_tag = None)
+	auto tag_of = [&](size_t b) -> const gbm_order_tag * { return tags && tags[b].stream_id != GBM_NO_STREAM ? &tags[b] : nullptr; };
 	if (gate && gate->before)
 		gate->before();
 	auto fan_out = [&](size_t b) {
@@ -471,7 +474,7 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 			const Bytes payload = j < k ? prep[b].block.slice((size_t)j * S, S) : prep[b].parity.slice((size_t)(j - k) * S, S);
 			bool pend = false;
 			if (send_shard(mg, who[j], h, j, payload, S, prep[b].plen, prep[b].z, sums.data() + (b * n + j) * 32,
-				       tags ? &tags[b] : nullptr, &pend)) {
+				       tag_of(b), &pend)) {
 				++ok;
 				mg->metrics[0] += S;
 				if (pend)
@@ -495,7 +498,7 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 				const int j = (int)jj;
 				const Bytes payload = j < k ? prep[b].block.slice((size_t)j * S, S) : prep[b].parity.slice((size_t)(j - k) * S, S);
 				bool pend = false;
-				if (send_shard(mg, who[j], h, j, payload, S, prep[b].plen, prep[b].z, sums.data() + (b * n + j) * 32, &tags[b], &pend)) {
+				if (send_shard(mg, who[j], h, j, payload, S, prep[b].plen, prep[b].z, sums.data() + (b * n + j) * 32, tag_of(b), &pend)) {
 					++okc;
 					mg->metrics[0] += S;
 					if (pend)
@@ -530,7 +533,7 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 					const Hash h((const char *)hashes + 32 * b, 32);
 					const Bytes payload = j < k ? prep[b].block.slice((size_t)j * S, S) : prep[b].parity.slice((size_t)(j - k) * S, S);
 					bool pend = false;
-					if (send_shard(mg, (int)node, h, j, payload, S, prep[b].plen, prep[b].z, sums.data() + (b * n + j) * 32, &tags[b], &pend)) {
+					if (send_shard(mg, (int)node, h, j, payload, S, prep[b].plen, prep[b].z, sums.data() + (b * n + j) * 32, tag_of(b), &pend)) {
 						++okc[b];
 						mg->metrics[0] += S;
 						if (pend)

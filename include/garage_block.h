@@ -69,11 +69,13 @@ enum {
 #define GBM_RESYNC_RETRY_MAX_BACKOFF_POWER 6 /* RESYNC_RETRY_DELAY_MAX_BACKOFF_POWER, :40 */
 
 /* OrderTag(stream, order) (src/net/message.rs:66-89): requests of one stream are handed to a node in
- * `order` order.  NULL = None. */
+ * `order` order.  NULL = None; in an ARRAY of tags (the batched calls) an entry whose stream_id is GBM_NO_STREAM is None
+ * too: that block goes out behind the tagged ones and reaches its nodes without a tag. */
 typedef struct {
 	uint64_t stream_id;
 	uint64_t order;
 } gbm_order_tag;
+#define GBM_NO_STREAM UINT64_MAX
 
 /* DataBlockHeader (src/block/block.rs:12-22) */
 enum { GBM_HEADER_PLAIN = 0, GBM_HEADER_COMPRESSED = 1 };
@@ -200,7 +202,7 @@ int gbm_layout_trim(gbm_manager *m);
 int gbm_rpc_put_block(gbm_manager *m, const uint8_t hash[32], const uint8_t *data, size_t len,
 		      int prevent_compression, const gbm_order_tag *order_tag);
 /* Coalesced form: ONE device encode for all n blocks (hashes = n*32 bytes).
- * prevent_compression: n flags or NULL (all 0); order_tags: n tags or NULL (all None). */
+ * prevent_compression: n flags or NULL (all 0); order_tags: n tags (GBM_NO_STREAM entries = None) or NULL (all None). */
 int gbm_rpc_put_blocks(gbm_manager *m, size_t n, const uint8_t *hashes,
 		       const uint8_t *const *data, const size_t *len,
 		       const uint8_t *prevent_compression, const gbm_order_tag *order_tags);

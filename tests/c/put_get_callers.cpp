@@ -8,6 +8,11 @@
 //   GetObject   the blocks of an object are fetched with a 2-deep prefetch (src/api/s3/get.rs:429, `.buffered(2)`),
 //               tagged the same way.  Here: G reader threads with 2 slots each, reading objects that were put
 //               earlier while the writers are still writing theirs.
+//   UploadPartCopy  the source object's blocks come through EncryptionParams::get_block = rpc_get_block_streaming with an
+//               OrderTag, two in flight and consumed in order (src/api/s3/copy.rs:520-551, `.buffered(2)`;
+//               src/api/s3/encryption.rs:269-280); each one is re-encrypted, named by the blake2sum of the NEW bytes and
+//               put with prevent_compression and NO tag while the next source block is being read (try_join!, copy.rs:606-630).
+//               Here: copier threads doing exactly that with an XOR key stream, then the copies are read back.
 //
 // Checked: every put is acknowledged; the batcher coalesced (fewer device batches than blocks, some batch > 1 block);
 // no node ever saw a stream's PutShards out of `order` (gbm_node_order_violations == 0 everywhere) although blocks of
@@ -27,6 +32,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <future>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -136,6 +143,56 @@ void get_object(gbm_manager *mg, const Object &o, uint64_t read_stream, std::ato
 		t.join();
 }
 
+
+// UploadPartCopy (copy.rs:520-630): stream the source blocks in (2 in flight, in order), re-encrypt, put under the new name
+// while the next block arrives.  Returns the destination object (what must read back).
+Object copy_object(gbm_manager *mg, gbm_batcher *bt, const Object &src, uint64_t read_stream, uint8_t key, std::atomic<uint64_t> &ncopied)
+{
+	Object dst;
+	dst.stream_id = read_stream;
+	dst.blocks.resize(src.blocks.size());
+	dst.hashes.resize(src.hashes.size());
+	auto fetch = [&](size_t i) {  // EncryptionParams::get_block: the streaming get, chunks appended as they arrive
+		std::vector<uint8_t> data;
+		data.reserve(src.blocks[i].size());
+		const gbm_order_tag tag{read_stream, (uint64_t)i};
+		auto sink = [](void *ctx, const uint8_t *chunk, size_t len) -> int {
+			auto *v = static_cast<std::vector<uint8_t> *>(ctx);
+			v->insert(v->end(), chunk, chunk + len);
+			return 0;
+		};
+		CHECK(gbm_rpc_get_block_streaming(mg, &src.hashes[i * 32], &tag, 16384, sink, &data) == GBM_OK);
+		return data;
+	};
+	std::deque<std::future<std::vector<uint8_t>>> ahead;
+	size_t next_fetch = 0;
+	auto refill = [&] {
+		while (ahead.size() < (size_t)GET_PREFETCH && next_fetch < src.blocks.size()) {
+			const size_t i = next_fetch++;
+			ahead.push_back(std::async(std::launch::async, fetch, i));
+		}
+	};
+	refill();
+	for (size_t i = 0; i < src.blocks.size(); ++i) {
+		std::vector<uint8_t> data = ahead.front().get();
+		ahead.pop_front();
+		CHECK(data == src.blocks[i]);
+		for (size_t j = 0; j < data.size(); ++j)  // "dest_encryption.encrypt_block": the bytes change, so does the name
+			data[j] ^= (uint8_t)(key + j * 31);
+		gbm_blake2sum(data.data(), data.size(), &dst.hashes[i * 32]);
+		dst.blocks[i] = std::move(data);
+		// try_join!(rpc_put_block(final_hash, final_data, is_encrypted, None), ..., defragmenter.next())
+		gbm_put_ticket *tk = nullptr;
+		CHECK(gbm_batcher_submit(bt, &dst.hashes[i * 32], dst.blocks[i].data(), dst.blocks[i].size(), /*prevent_compression=*/1, nullptr, &tk) == GBM_OK);
+		refill();
+		if (!ahead.empty())
+			ahead.front().wait();
+		CHECK(gbm_batcher_wait(tk) == GBM_OK);
+		++ncopied;
+	}
+	return dst;
+}
+
 }  // namespace
 
 int main(int argc, char **argv)
@@ -179,6 +236,9 @@ int main(int argc, char **argv)
 	// ---- the mixed phase: R PutObjects and G GetObjects at once
 	put_ns = 0;
 	nput = 0;
+	const int ncopiers = readers > 0 ? 2 : 0;
+	std::vector<Object> copies((size_t)ncopiers);
+	std::atomic<uint64_t> ncopied{0};
 	const auto t0 = std::chrono::steady_clock::now();
 	{
 		std::vector<std::thread> th;
@@ -189,6 +249,9 @@ int main(int argc, char **argv)
 				for (int pass = 0; pass < 3; ++pass)
 					get_object(mg, old_objs[r], 5000 + r * 10 + pass, nget, bt);
 			});
+		// two UploadPartCopy requests beside them (their puts are untagged and counted below)
+		for (int c = 0; c < ncopiers; ++c)
+			th.emplace_back([&, c] { copies[(size_t)c] = copy_object(mg, bt, old_objs[(size_t)c % old_objs.size()], 7000 + c, (uint8_t)(0x5C + c), ncopied); });
 		for (auto &t : th)
 			t.join();
 	}
@@ -197,7 +260,7 @@ int main(int argc, char **argv)
 	CHECK(gbm_batcher_stats(bt, st1) == GBM_OK);
 	const uint64_t batches = st1[0] - st0[0], blocks = st1[1] - st0[1];
 	const double mean_put_ms = blocks ? put_ns.load() / 1e6 / (double)blocks : 0.0;
-	CHECK(blocks == (uint64_t)requests * per_object && nput.load() == blocks);
+	CHECK(blocks == (uint64_t)(requests + ncopiers) * per_object && nput.load() + ncopied.load() == blocks);
 	CHECK(nget.load() == (uint64_t)readers * 3 * per_object);
 	// coalescing: concurrent requests share device batches
 	if (requests >= 4)
@@ -217,6 +280,9 @@ int main(int argc, char **argv)
 				want_get[(size_t)d] += 3;
 			}
 		for (const Object &o : new_objs)
+			for (size_t i = 0; i < o.blocks.size(); ++i)
+				want_put[(size_t)gec_device_of_hash(&o.hashes[i * 32], ndev)] += 1;
+		for (const Object &o : copies)
 			for (size_t i = 0; i < o.blocks.size(); ++i)
 				want_put[(size_t)gec_device_of_hash(&o.hashes[i * 32], ndev)] += 1;
 		uint64_t sum_put = 0;
@@ -241,6 +307,8 @@ int main(int argc, char **argv)
 	// every byte of what the writers put reads back (after the fact, whole objects)
 	for (const Object &o : new_objs)
 		get_object(mg, o, 9000 + o.stream_id, nget);
+	for (const Object &o : copies)  // ... and every re-encrypted copy
+		get_object(mg, o, 9200 + o.stream_id, nget);
 
 	// ---- RAM permits: a budget of two blocks -- the queue can never hold more than two blocks, so no batch can
 	gbm_batcher_destroy(bt);
@@ -265,11 +333,11 @@ int main(int argc, char **argv)
 		CHECK(gbm_node_order_violations(mg, nd) == 0);
 
 	const double mib = (double)blocks * (double)block_bytes / (1 << 20);
-	printf("put_get_callers: backend %s, %d device(s), %d PutObjects x %d blocks of %zu bytes (<=%d in flight each) beside %d GetObjects (prefetch %d): "
+	printf("put_get_callers: backend %s, %d device(s), %d PutObjects x %d blocks of %zu bytes (<=%d in flight each) beside %d GetObjects (prefetch %d) and %d UploadPartCopies: "
 	       "%llu blocks in %llu device batches (largest %llu), mean put %.3f ms, %.2f GiB/s put; %llu blocks read in %llu batches (largest %llu); "
 	       "0 order violations; all bytes round-trip: OK\n",
 	       gec_codec_backend(codec) == GEC_BACKEND_CPU ? "cpu" : "hip", ndev, requests, per_object, block_bytes, PUT_BLOCKS_MAX_PARALLEL, readers,
-	       GET_PREFETCH, (unsigned long long)blocks, (unsigned long long)batches, (unsigned long long)st1[2],
+	       GET_PREFETCH, ncopiers, (unsigned long long)blocks, (unsigned long long)batches, (unsigned long long)st1[2],
 	       mean_put_ms, mib / 1024.0 / secs, (unsigned long long)gst[1], (unsigned long long)gst[0], (unsigned long long)gst[2]);
 	gbm_batcher_destroy(bt);
 	gbm_destroy(mg);

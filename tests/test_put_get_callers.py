@@ -1,7 +1,10 @@
 """SURVEY.md section 8 row a10 -- the callers of the block path, replayed natively (tests/c/put_get_callers.cpp):
 R PutObject requests, each submitting its blocks in order with <= PUT_BLOCKS_MAX_PARALLEL = 3 in flight and an
 OrderTag per block (/root/reference/src/api/s3/put.rs:42,486-511), beside GetObject readers with a 2-deep prefetch
-(src/api/s3/get.rs:429), through gbm_batcher_submit / gbm_batcher_wait and gbm_rpc_get_block.  The harness asserts
+(src/api/s3/get.rs:429), and UploadPartCopy requests that stream their source blocks in through
+gbm_rpc_get_block_streaming (two in flight, in order), re-encrypt them and put them untagged under their new names while the
+next one is read (src/api/s3/copy.rs:520-551,606-630; src/api/s3/encryption.rs:269-280), through gbm_batcher_submit /
+gbm_batcher_wait and gbm_rpc_get_block.  The harness asserts
 coalescing (gbm_batcher_stats), zero gbm_node_order_violations, RAM-permit back-pressure and that every byte round-trips;
 here it runs (1) under ThreadSanitizer over the product's CPU backend, (2) against the real libraries on the CPU
 backend, (3) on the GPU with 1 MiB blocks -- and each of the three again over a MULTI-DEVICE manager (gbm_create_multi:
