@@ -32,7 +32,7 @@ SYMBOLS = [
     "gbm_env_table", "gbm_set_tranquility", "gbm_tranquilized_ms", "gbm_background_codec",
     "gbm_batcher_submit", "gbm_batcher_wait", "gbm_set_maintenance_class", "gbm_batcher_get_block", "gbm_batcher_get_stats",
     "gbm_create_multi", "gbm_device_count", "gbm_device_of_hash", "gbm_device_codec", "gbm_device_background_codec",
-    "gbm_device_metrics", "gbm_batcher_device_stats", "gbm_get_verify_block_hash",
+    "gbm_device_metrics", "gbm_batcher_device_stats", "gbm_get_verify_block_hash", "gbm_rpc_get_block_range_streaming",
 ]
 
 
@@ -100,6 +100,7 @@ def _load():
     lib.gbm_rpc_get_raw_block.argtypes = [vp, ctypes.c_char_p, tagp, hdrp, vp, sz, ctypes.POINTER(sz)]
     lib.gbm_rpc_get_block_streaming.argtypes = [vp, ctypes.c_char_p, tagp, sz, CHUNK_FN, vp]
     lib.gbm_rpc_get_raw_block_streaming.argtypes = [vp, ctypes.c_char_p, tagp, hdrp, sz, CHUNK_FN, vp]
+    lib.gbm_rpc_get_block_range_streaming.argtypes = [vp, ctypes.c_char_p, tagp, sz, sz, sz, sz, CHUNK_FN, vp]
     for f in ("gbm_block_incref", "gbm_block_decref"):
         getattr(lib, f).argtypes = [vp, ctypes.c_char_p]
     lib.gbm_block_rc.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
@@ -303,6 +304,20 @@ class NativeBlockManager:
                    "rpc_get_raw_block_streaming")
             return hdr, chunks
         _check(lib.gbm_rpc_get_block_streaming(self._h, hash_, self._tag(order_tag), chunk_bytes, cb, None), "rpc_get_block_streaming")
+        return chunks
+
+    def rpc_get_block_range(self, hash_: bytes, block_size: int, begin: int, end: int, order_tag=None, chunk_bytes: int = 0) -> list:
+        """Bytes [begin, end) of one block, as the chunks the sink received (body_from_blocks_range,
+        src/api/s3/get.rs:650-743): only the data shards the range touches are read when the block is stored Plain."""
+        chunks: list[bytes] = []
+
+        def sink(_ctx, p, n):
+            chunks.append(ctypes.string_at(p, n))
+            return 0
+
+        cb = CHUNK_FN(sink)
+        _check(lib.gbm_rpc_get_block_range_streaming(self._h, hash_, self._tag(order_tag), block_size, begin, end, chunk_bytes, cb, None),
+               "rpc_get_block_range_streaming")
         return chunks
 
     def rpc_get_blocks(self, hashes: Sequence[bytes], max_len: int, out: Optional[list] = None) -> list:

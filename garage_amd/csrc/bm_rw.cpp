@@ -1475,6 +1475,65 @@ int stream_general(gbm_manager *m, const std::vector<Hash> &hs, const uint8_t ha
 	return rc;
 }
 
+// The fast path's requests: data shards lo..hi asked for AT ONCE, each from the node that should hold it in the current
+// layout version; a shard is checked (header, checksum) by the task that fetched it.  Shard `lo` is fetched by the calling
+// thread itself: the first byte waits for no other thread to wake up.
+struct Fast {
+	std::mutex mu;
+	std::condition_variable cv;
+	std::vector<int> st;  // 0 pending, 1 arrived and matches its own checksum, -1 not usable
+	std::vector<Shard> shard;
+	Hash h;
+	gbm_order_tag tag{0, 0};
+	bool has_tag = false;
+	Fast(int k, const Hash &hash, const gbm_order_tag *order_tag) : st(k, 0), shard(k), h(hash)
+	{
+		if (order_tag) {
+			tag = *order_tag;
+			has_tag = true;
+		}
+	}
+	bool arrived(int j)
+	{
+		std::unique_lock<std::mutex> lk(mu);
+		cv.wait(lk, [&] { return st[j] != 0; });
+		return st[j] == 1;
+	}
+};
+
+void fast_fetch(gbm_manager *m, const std::shared_ptr<Fast> &fs, const std::vector<int> &who, int lo, int hi)
+{
+	std::shared_ptr<gbm_manager::Async> async = m->async_pool();
+	const int mk = m->k, mm = m->m;
+	auto fetch = [fs, mk, mm](Node *nd, int j) {
+		ShardRpc rq{RpcKind::GetShard, &fs->h, j, Shard(), fs->has_tag ? &fs->tag : nullptr};
+		ShardResp rs;
+		int v = -1;
+		if (nd->handle(rq, rs) && rs.ok) {
+			const ShardHeader &hd = rs.shard.hd;
+			if (hd.version == 2 && hd.idx == j && hd.k == mk && hd.m == mm && hd.shard_len > 0 && hd.shard_len % 64 == 0 &&
+			    rs.shard.data.n == hd.shard_len) {
+				uint8_t sum[32];
+				shardsum(rs.shard.data.data(), hd.shard_len, sum);
+				if (std::memcmp(sum, hd.checksum, 32) == 0)
+					v = 1;
+			}
+		}
+		{
+			std::lock_guard<std::mutex> lk(fs->mu);
+			if (v == 1)
+				fs->shard[j] = std::move(rs.shard);
+			fs->st[j] = v;
+		}
+		fs->cv.notify_all();
+	};
+	for (int j = lo + 1; j <= hi; ++j) {
+		Node *nd = m->nodes[who[j]].get();
+		async->submit([fetch, nd, j] { fetch(nd, j); });
+	}
+	fetch(m->nodes[who[lo]].get(), lo);
+}
+
 // The streaming get.  The fast path is the healthy block: its k data shards are asked for AT ONCE, each from the node that
 // should hold it in the current layout version; a shard is checked (header, checksum) by the task that fetched it, and
 // the walk hands shard i to the sink as soon as shards 0..i have arrived and matched -- the first byte waits for ONE
@@ -1490,67 +1549,16 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 	const int k = m->k;
 	std::vector<Hash> hs(1, Hash((const char *)hash, 32));
 	StreamOut out(sink, ctx, chunk_bytes);
-	struct Fast {
-		std::mutex mu;
-		std::condition_variable cv;
-		std::vector<int> st;  // 0 pending, 1 arrived and matches its own checksum, -1 not usable
-		std::vector<Shard> shard;
-		Hash h;
-		gbm_order_tag tag{0, 0};
-		bool has_tag = false;
-	};
-	auto fs = std::make_shared<Fast>();
-	fs->st.assign(k, 0);
-	fs->shard.resize(k);
-	fs->h = hs[0];
-	if (order_tag) {
-		fs->tag = *order_tag;
-		fs->has_tag = true;
-	}
+	auto fs = std::make_shared<Fast>(k, hs[0], order_tag);
 	std::vector<int> who;
 	m->nodes_of(hs[0], who);
-	{
-		std::shared_ptr<gbm_manager::Async> async = m->async_pool();
-		const int mk = m->k, mm = m->m;
-		auto fetch = [fs, mk, mm](Node *nd, int j) {
-			ShardRpc rq{RpcKind::GetShard, &fs->h, j, Shard(), fs->has_tag ? &fs->tag : nullptr};
-			ShardResp rs;
-			int v = -1;
-			if (nd->handle(rq, rs) && rs.ok) {
-				const ShardHeader &hd = rs.shard.hd;
-				if (hd.version == 2 && hd.idx == j && hd.k == mk && hd.m == mm && hd.shard_len > 0 && hd.shard_len % 64 == 0 &&
-				    rs.shard.data.n == hd.shard_len) {
-					uint8_t sum[32];
-					shardsum(rs.shard.data.data(), hd.shard_len, sum);
-					if (std::memcmp(sum, hd.checksum, 32) == 0)
-						v = 1;
-				}
-			}
-			{
-				std::lock_guard<std::mutex> lk(fs->mu);
-				if (v == 1)
-					fs->shard[j] = std::move(rs.shard);
-				fs->st[j] = v;
-			}
-			fs->cv.notify_all();
-		};
-		for (int j = 1; j < k; ++j) {
-			Node *nd = m->nodes[who[j]].get();
-			async->submit([fetch, nd, j] { fetch(nd, j); });
-		}
-		fetch(m->nodes[who[0]].get(), 0);  // shard 0 is the walk's own: the first byte waits for no other thread to wake up
-	}
-	auto arrived = [&](int j) {
-		std::unique_lock<std::mutex> lk(fs->mu);
-		fs->cv.wait(lk, [&] { return fs->st[j] != 0; });
-		return fs->st[j] == 1;
-	};
+	fast_fetch(m, fs, who, 0, k - 1);
 	Trace tr("streaming get");
 	StreamGeom geom;
 	size_t pos = 0;
 	bool opened = false, handover = false;
 	for (int j = 0; j < k; ++j) {
-		if (!arrived(j)) {
+		if (!fs->arrived(j)) {
 			handover = true;
 			break;
 		}
@@ -1591,6 +1599,95 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 	return rc;
 }
 
+// The reference's scan over a whole block's stream (body_from_blocks_range, src/api/s3/get.rs:687-723): chunks before
+// `begin` are dropped, the ones that overlap the range are cut to it, and once `end` is behind it the stream is let go.
+struct RangeSlice {
+	gbm_chunk_fn sink;
+	void *ctx;
+	size_t begin, end, off = 0;
+	bool done = false, consumer_stopped = false;
+	static int fn(void *c, const uint8_t *p, size_t n)
+	{
+		RangeSlice *r = static_cast<RangeSlice *>(c);
+		const size_t lo = r->off, hi = lo + n;
+		r->off = hi;
+		if (hi <= r->begin)
+			return 0;
+		const size_t a = std::max(lo, r->begin), b = std::min(hi, r->end);
+		if (b > a && r->sink(r->ctx, p + (a - lo), b - a) != 0) {
+			r->consumer_stopped = true;
+			return 1;
+		}
+		if (hi >= r->end) {
+			r->done = true;  // "the rest of the stream will be ignored" (get.rs:691-695)
+			return 1;
+		}
+		return 0;
+	}
+};
+
+// A byte range [begin, end) of one block.  Data shard i of a Plain block IS its bytes [i*S, (i+1)*S), so the range needs
+// only the data shards it touches: `block_size` (the VersionBlock's size the caller's version table holds) says what S
+// must be, those shards are asked for at once and each is checked against its own checksum before a byte of it goes
+// out.  Whatever does not fit that picture -- the block is stored Compressed, its stored geometry is not what
+// block_size implies, a shard is missing or does not match -- is the whole-block stream's business: it takes over
+// behind a slicing sink, from the byte the range has reached, with everything a streaming get does (other holders,
+// parity + decode, the corrupt-shard bookkeeping).
+int get_range(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, size_t block_size, size_t begin, size_t end,
+	      size_t chunk_bytes, gbm_chunk_fn sink, void *ctx)
+{
+	if (!m || !hash || !sink)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	if (begin > end)
+		return fail(GBM_E_INVALID_ARG, "range begins after its end");
+	m = m->route(hash);
+	const int k = m->k;
+	const size_t ch = chunk_bytes ? chunk_bytes : 65536;
+	size_t pos = begin;  // the next byte of the block the consumer is owed
+	auto whole_block = [&]() {
+		RangeSlice rs{sink, ctx, pos, end};
+		int rc = get_streaming(m, hash, order_tag, nullptr, chunk_bytes, RangeSlice::fn, &rs, false);
+		if (rc == GBM_E_ABORTED && rs.done && !rs.consumer_stopped)
+			return (int)GBM_OK;  // let go on purpose
+		return rc;
+	};
+	if (begin == end || block_size == 0 || begin >= block_size)
+		return begin == end ? (int)GBM_OK : whole_block();  // (a range beyond block_size: the stored block decides)
+	const size_t S = gec_shard_len(k, block_size);
+	if (S == 0)
+		return whole_block();
+	const size_t last = std::min(end, block_size) - 1;
+	const int j0 = (int)(begin / S), j1 = (int)(last / S);
+	Hash h((const char *)hash, 32);
+	auto fs = std::make_shared<Fast>(k, h, order_tag);
+	std::vector<int> who;
+	m->nodes_of(h, who);
+	Trace tr("range get");
+	fast_fetch(m, fs, who, j0, j1);
+	for (int j = j0; j <= j1; ++j) {
+		if (!fs->arrived(j))
+			return whole_block();
+		const ShardHeader &hd = fs->shard[j].hd;
+		if (hd.compressed != 0 || hd.orig_len != block_size || hd.shard_len != S)
+			return whole_block();
+		if (j == j0)
+			tr.lap("first shard arrived and checked");
+		m->metrics[1] += hd.shard_len;
+		const size_t lo = (size_t)j * S;                       // block offset of this shard's first byte
+		const size_t a = pos - lo, b = std::min(S, std::min(end, block_size) - lo);
+		const uint8_t *p = fs->shard[j].data.data();
+		for (size_t off = a; off < b; off += ch) {
+			const size_t n = std::min(ch, b - off);
+			if (sink(ctx, p + off, n) != 0)
+				return fail(GBM_E_ABORTED, "the stream's consumer stopped");
+			pos += n;
+		}
+	}
+	tr.lap("last shard delivered");
+	m->metrics[5]++;
+	return GBM_OK;
+}
+
 }  // namespace
 
 int gbm_rpc_get_block_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, size_t chunk_bytes,
@@ -1612,6 +1709,16 @@ int gbm_rpc_get_raw_block_streaming(gbm_manager *m, const uint8_t hash[32], cons
 		return get_streaming(m, hash, order_tag, header_out, chunk_bytes, sink, ctx, true);
 	} catch (const std::exception &e) {
 		return fail(GBM_E_IO, std::string("rpc_get_raw_block_streaming: ") + e.what());
+	}
+}
+
+int gbm_rpc_get_block_range_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag, size_t block_size,
+				      size_t begin, size_t end, size_t chunk_bytes, gbm_chunk_fn sink, void *ctx)
+{
+	try {
+		return get_range(m, hash, order_tag, block_size, begin, end, chunk_bytes, sink, ctx);
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("rpc_get_block_range_streaming: ") + e.what());
 	}
 }
 

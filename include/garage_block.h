@@ -239,6 +239,25 @@ int gbm_rpc_get_raw_block_streaming(gbm_manager *m, const uint8_t hash[32], cons
 				    gbm_data_block_header *header_out, size_t chunk_bytes,
 				    gbm_chunk_fn sink, void *ctx);
 
+/* A byte range of one block: the caller of a ranged GetObject (body_from_blocks_range, src/api/s3/get.rs:650-743; the
+ * range and part requests above it, :485-533, :534-600).  The reference asks for the WHOLE block's stream, drops the
+ * chunks before `begin`, cuts the ones that overlap and lets the stream go once `end` is behind it (:687-723) -- every
+ * replica holds the whole block, so that costs one node's disk read.  Here data shard i of a Plain block IS its bytes
+ * [i*S, (i+1)*S): a range needs only the data shards it touches.  `block_size` is the VersionBlock's size the caller's
+ * version table holds (it fixes S = gec_shard_len(k, block_size)); the shards the range touches are asked for at once,
+ * each is checked against its own checksum before a byte of it is used, and `sink` receives exactly the block's bytes
+ * [begin, min(end, block length)) in chunks of at most chunk_bytes (0 = 64 KiB).  A 100 KiB range of a 1 MiB RS(10,4)
+ * block reads one or two shards (~0.1 - 0.2 MiB), not ten.
+ * Whatever does not fit -- the block is stored Compressed (its bytes are a zstd frame, not the plain text), the stored
+ * geometry is not what block_size implies, a shard is missing, late or does not match -- falls to the whole-block
+ * stream behind a slicing sink, from the byte the range has reached: other holders, older layout versions, parity +
+ * decode, the corrupt-shard bookkeeping, exactly as gbm_rpc_get_block_streaming does them.  The end-to-end block hash
+ * (gbm_set_verify_block_hash) needs the whole block and is not computed for a range; a stream that is let go early
+ * is not hashed either, as dropping the reference's stream drops its tail.  begin == end delivers nothing. */
+int gbm_rpc_get_block_range_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order_tag,
+				      size_t block_size, size_t begin, size_t end, size_t chunk_bytes,
+				      gbm_chunk_fn sink, void *ctx);
+
 /* ------------------------------------------------------- coalescing queue */
 /* Garage keeps <= 3 block puts in flight per PutObject (PUT_BLOCKS_MAX_PARALLEL,
  * src/api/s3/put.rs:42,486-511) across many concurrent requests.  gbm_batcher_put_block is

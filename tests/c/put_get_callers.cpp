@@ -14,6 +14,11 @@
 //               put with prevent_compression and NO tag while the next source block is being read (try_join!, copy.rs:606-630).
 //               Here: copier threads doing exactly that with an XOR key stream, then the copies are read back.
 //
+//   ranged GetObject  body_from_blocks_range (src/api/s3/get.rs:650-743): the blocks that intersect [begin, end) with their true
+//               offsets in the object, fetched one after the other with an OrderTag, each cut to the range.  Here:
+//               gbm_rpc_get_block_range_streaming per block -- only the data shards the range touches are read -- by a
+//               thread per reader, over ranges that start and end inside blocks, while the writers are writing.
+//
 // Checked: every put is acknowledged; the batcher coalesced (fewer device batches than blocks, some batch > 1 block);
 // no node ever saw a stream's PutShards out of `order` (gbm_node_order_violations == 0 everywhere) although blocks of
 // one stream land in different batches on different workers; with a RAM budget of two blocks (block_ram_buffer_max,
@@ -27,6 +32,7 @@
 // assertions, plus per-device block counts that follow the hash exactly -- and the order guarantee now has to hold for
 // streams whose blocks are encoded on DIFFERENT devices.
 // usage: put_get_callers [requests] [blocks_per_object] [block_bytes] [readers] [devices]
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -143,6 +149,32 @@ void get_object(gbm_manager *mg, const Object &o, uint64_t read_stream, std::ato
 		t.join();
 }
 
+// A ranged GetObject (get.rs:650-743): blocks that intersect [begin, end), in order, each asked for its part of the range
+void get_object_range(gbm_manager *mg, const Object &o, uint64_t begin, uint64_t end, uint64_t read_stream, std::atomic<uint64_t> &nranges)
+{
+	std::vector<uint8_t> want, got;
+	uint64_t block_offset = 0;
+	uint64_t order = 0;
+	for (size_t i = 0; i < o.blocks.size() && block_offset < end; ++i) {
+		const uint64_t size = o.blocks[i].size();
+		if (block_offset + size > begin) {  // "keep only blocks that have an intersection with the requested range"
+			const uint64_t b = begin > block_offset ? begin - block_offset : 0;
+			const uint64_t e = std::min<uint64_t>(size, end - block_offset);
+			want.insert(want.end(), o.blocks[i].begin() + (ptrdiff_t)b, o.blocks[i].begin() + (ptrdiff_t)e);
+			const gbm_order_tag tag{read_stream, order++};
+			auto sink = [](void *ctx, const uint8_t *chunk, size_t len) -> int {
+				auto *v = static_cast<std::vector<uint8_t> *>(ctx);
+				v->insert(v->end(), chunk, chunk + len);
+				return 0;
+			};
+			// `end` is handed over unclipped for the blocks in the middle, as the reference's scan sees it
+			CHECK(gbm_rpc_get_block_range_streaming(mg, &o.hashes[i * 32], &tag, (size_t)size, (size_t)b, (size_t)(end - block_offset), 16384, sink, &got) == GBM_OK);
+		}
+		block_offset += size;
+	}
+	CHECK(got == want);
+	++nranges;
+}
 
 // UploadPartCopy (copy.rs:520-630): stream the source blocks in (2 in flight, in order), re-encrypt, put under the new name
 // while the next block arrives.  Returns the destination object (what must read back).
@@ -238,7 +270,7 @@ int main(int argc, char **argv)
 	nput = 0;
 	const int ncopiers = readers > 0 ? 2 : 0;
 	std::vector<Object> copies((size_t)ncopiers);
-	std::atomic<uint64_t> ncopied{0};
+	std::atomic<uint64_t> ncopied{0}, nranges{0};
 	const auto t0 = std::chrono::steady_clock::now();
 	{
 		std::vector<std::thread> th;
@@ -248,6 +280,20 @@ int main(int argc, char **argv)
 			th.emplace_back([&, r] {
 				for (int pass = 0; pass < 3; ++pass)
 					get_object(mg, old_objs[r], 5000 + r * 10 + pass, nget, bt);
+			});
+		// ranged GetObjects of the same objects: inside one block, across two, from the middle of the first block to the object's end
+		for (int r = 0; r < readers; ++r)
+			th.emplace_back([&, r] {
+				const Object &o = old_objs[(size_t)r];
+				uint64_t total = 0;
+				for (const auto &b : o.blocks)
+					total += b.size();
+				const uint64_t bb = block_bytes;
+				const uint64_t ranges[][2] = {{bb / 3, bb / 3 + 1000}, {bb - 100, bb + 100}, {bb / 2, total}, {0, 1}, {total - 5, total + 50},
+							      {2 * bb + 17, std::min<uint64_t>(total, 5 * bb - 3)}};
+				for (size_t q = 0; q < sizeof ranges / sizeof ranges[0]; ++q)
+					if (ranges[q][0] < total && ranges[q][0] < ranges[q][1])
+						get_object_range(mg, o, ranges[q][0], ranges[q][1], 6000 + (uint64_t)r * 10 + q, nranges);
 			});
 		// two UploadPartCopy requests beside them (their puts are untagged and counted below)
 		for (int c = 0; c < ncopiers; ++c)
@@ -262,6 +308,7 @@ int main(int argc, char **argv)
 	const double mean_put_ms = blocks ? put_ns.load() / 1e6 / (double)blocks : 0.0;
 	CHECK(blocks == (uint64_t)(requests + ncopiers) * per_object && nput.load() + ncopied.load() == blocks);
 	CHECK(nget.load() == (uint64_t)readers * 3 * per_object);
+	CHECK(readers == 0 || nranges.load() >= (uint64_t)readers * 4);
 	// coalescing: concurrent requests share device batches
 	if (requests >= 4)
 		CHECK(batches < blocks && st1[2] >= 2);
@@ -333,11 +380,11 @@ int main(int argc, char **argv)
 		CHECK(gbm_node_order_violations(mg, nd) == 0);
 
 	const double mib = (double)blocks * (double)block_bytes / (1 << 20);
-	printf("put_get_callers: backend %s, %d device(s), %d PutObjects x %d blocks of %zu bytes (<=%d in flight each) beside %d GetObjects (prefetch %d) and %d UploadPartCopies: "
+	printf("put_get_callers: backend %s, %d device(s), %d PutObjects x %d blocks of %zu bytes (<=%d in flight each) beside %d GetObjects (prefetch %d), %llu ranged GetObjects and %d UploadPartCopies: "
 	       "%llu blocks in %llu device batches (largest %llu), mean put %.3f ms, %.2f GiB/s put; %llu blocks read in %llu batches (largest %llu); "
 	       "0 order violations; all bytes round-trip: OK\n",
 	       gec_codec_backend(codec) == GEC_BACKEND_CPU ? "cpu" : "hip", ndev, requests, per_object, block_bytes, PUT_BLOCKS_MAX_PARALLEL, readers,
-	       GET_PREFETCH, ncopiers, (unsigned long long)blocks, (unsigned long long)batches, (unsigned long long)st1[2],
+	       GET_PREFETCH, (unsigned long long)nranges.load(), ncopiers, (unsigned long long)blocks, (unsigned long long)batches, (unsigned long long)st1[2],
 	       mean_put_ms, mib / 1024.0 / secs, (unsigned long long)gst[1], (unsigned long long)gst[0], (unsigned long long)gst[2]);
 	gbm_batcher_destroy(bt);
 	gbm_destroy(mg);

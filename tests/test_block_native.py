@@ -749,3 +749,82 @@ def test_streaming_compressed_block_is_decoded_incrementally(backend):
     mgr.node_corrupt_shard(who[0], h, 0, 64, 0x02, fix_checksum=True)
     rc, chunks, _ = _timed_stream(mgr, h)
     assert rc == bn.GBM_E_CORRUPT_DATA
+
+
+def test_range_get_reads_only_the_shards_it_touches(codec):
+    """body_from_blocks_range (src/api/s3/get.rs:650-743): the reference streams the whole block and cuts it; here a
+    range of a Plain block is served from the data shards it touches -- and from the whole-block stream when a shard
+    is missing, does not match, or the block is stored Compressed."""
+    k, m = codec.k, codec.m
+    mgr = bn.NativeBlockManager(codec, k + m + 2)
+    L = 1_000_003
+    data = bytes(np.random.default_rng(41).integers(0, 256, L, dtype=np.uint8))
+    h = bn.blake2sum(data)
+    mgr.rpc_put_block(h, data)
+    S = g.shard_len(k, L)
+    who = mgr.storage_nodes_of(h)
+
+    def ranged(b, e, **kw):
+        before = mgr.metrics["bytes_read"]
+        chunks = mgr.rpc_get_block_range(h, L, b, e, **kw)
+        return b"".join(chunks), mgr.metrics["bytes_read"] - before, chunks
+
+    # inside one shard / across a shard boundary / to the ragged end / the whole block / nothing
+    got, read, _ = ranged(S + 5, S + 1005)
+    assert got == data[S + 5:S + 1005] and read == S
+    got, read, chunks = ranged(S - 100, 2 * S + 100, chunk_bytes=4096)
+    assert got == data[S - 100:2 * S + 100] and read == 3 * S and max(map(len, chunks)) <= 4096
+    got, read, _ = ranged(L - 10, L + 500)                 # the end is clamped to the block
+    assert got == data[L - 10:] and read == S
+    got, read, _ = ranged(0, L)
+    assert got == data and read == k * S
+    got, read, _ = ranged(777, 777)
+    assert got == b"" and read == 0
+    got, read, _ = ranged(L + 5, L + 50)                   # beyond the block: the stored block decides -- nothing
+    assert got == b""
+    with pytest.raises(bn.BlockError):
+        mgr.rpc_get_block_range(h, L, 10, 5)
+    with pytest.raises(bn.MissingBlock):
+        mgr.rpc_get_block_range(bytes(32), L, 0, 10)
+
+    # the shard the range needs is not there: the whole-block stream (parity + decode) serves the same bytes
+    rebuilt = mgr.metrics["ec_reconstructs"]
+    mgr.node_set_down(who[1], True)
+    got, read, _ = ranged(S + 5, S + 1005)
+    assert got == data[S + 5:S + 1005] and mgr.metrics["ec_reconstructs"] == rebuilt + 1
+    # ... and takes over mid-range, from the byte the range had reached
+    got, _, _ = ranged(10, 2 * S + 7)
+    assert got == data[10:2 * S + 7]
+    mgr.node_set_down(who[1], False)
+
+    # a shard that does not match its checksum is never delivered: set aside, queued, served by the decode
+    mgr.node_corrupt_shard(who[0], h, 0, 100, 0x40, fix_checksum=False)
+    corrupt = mgr.metrics["corruption_counter"]
+    got, _, _ = ranged(50, 5000)
+    assert got == data[50:5000] and mgr.metrics["corruption_counter"] == corrupt + 1
+    assert mgr.resync_queue_len() >= 1
+
+    # the caller's block_size is wrong (a stale version table): the stored geometry wins, the bytes are still right
+    got, _, _ = ranged(S + 5, S + 1005)
+    assert mgr.rpc_get_block_range(h, L + 4096 * k, S + 5, S + 1005) == [data[S + 5:S + 1005]]
+
+
+def test_range_get_of_a_compressed_block_goes_through_the_decoder(backend):
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    mgr = bn.NativeBlockManager(codec, 14, compression_level=1)
+    data = pattern_block(2 << 20, 9)
+    h = bn.blake2sum(data)
+    mgr.rpc_put_block(h, data)
+    assert mgr.rpc_get_raw_block(h)[0].is_compressed()
+    for b, e in [(0, 100), (123_456, 987_654), ((2 << 20) - 77, 2 << 20), (5, (2 << 20) + 9)]:
+        assert b"".join(mgr.rpc_get_block_range(h, len(data), b, e, chunk_bytes=50_000)) == data[b:e]
+    # the consumer stops the stream: GBM_E_ABORTED, as for the whole-block forms
+    seen = []
+
+    def sink(_ctx, p, n):
+        seen.append(n)
+        return 1
+
+    cb = bn.CHUNK_FN(sink)
+    rc = bn.lib.gbm_rpc_get_block_range_streaming(mgr._h, h, None, len(data), 10, 500_000, 4096, cb, None)
+    assert rc == bn.GBM_E_ABORTED and seen == [4086]     # the first chunk of the stream, cut to the range

@@ -4,7 +4,8 @@ OrderTag per block (/root/reference/src/api/s3/put.rs:42,486-511), beside GetObj
 (src/api/s3/get.rs:429), and UploadPartCopy requests that stream their source blocks in through
 gbm_rpc_get_block_streaming (two in flight, in order), re-encrypt them and put them untagged under their new names while the
 next one is read (src/api/s3/copy.rs:520-551,606-630; src/api/s3/encryption.rs:269-280), through gbm_batcher_submit /
-gbm_batcher_wait and gbm_rpc_get_block.  The harness asserts
+gbm_batcher_wait and gbm_rpc_get_block, and ranged GetObjects (body_from_blocks_range, src/api/s3/get.rs:650-743) through
+gbm_rpc_get_block_range_streaming.  The harness asserts
 coalescing (gbm_batcher_stats), zero gbm_node_order_violations, RAM-permit back-pressure and that every byte round-trips;
 here it runs (1) under ThreadSanitizer over the product's CPU backend, (2) against the real libraries on the CPU
 backend, (3) on the GPU with 1 MiB blocks -- and each of the three again over a MULTI-DEVICE manager (gbm_create_multi:

@@ -224,6 +224,8 @@ def small_trip_rates() -> dict:
             if m:
                 out.setdefault(f"streaming_get_{mib}MiB_ms", {})[key] = {"first_chunk": float(m.group(1)), "last_chunk": float(m.group(2)),
                                                                              "call_returns": float(m.group(3))}
+    for m in re.finditer(r"ranged get,\s+(\d+) bytes of a 4 MiB block: median ([0-9.]+) ms, (\d+) KiB of shards read", txt):
+        out.setdefault("ranged_get_of_4MiB_block", {})[f"{m.group(1)}_bytes"] = {"median_ms": float(m.group(2)), "shard_KiB_read": int(m.group(3))}
     for mo, key in (("off", "off"), ("rebuilt-only", "rebuilt"), ("always", "always")):
         m = re.search(rf"48 readers x 20 gets through the batcher, mode {mo}\s*: ([0-9.]+) GiB/s, median ([0-9.]+) ms, p99 ([0-9.]+) ms", txt)
         if m:

@@ -170,6 +170,23 @@ int main(int argc, char **argv)
 				printf("streaming get, %zu MiB block, mode %-12s: first chunk %.3f ms, last chunk %.3f ms, call returns %.3f ms (medians)\n",
 				       sz[w] >> 20, mode_name[mi], median(f + 5, 25), median(l + 5, 25), median(e + 5, 25));
 			}
+		/* ---- ranged gets (body_from_blocks_range): only the data shards the range touches are read */
+		CHECK(gbm_set_verify_block_hash(mg, GBM_VERIFY_OFF) == GBM_OK);
+		const size_t rb[3][2] = {{300000, 364000}, {100000, 600000}, {0, 4u << 20}};
+		for (int q = 0; q < 3; q++) {
+			double e[30];
+			uint64_t m0[6], m1[6];
+			CHECK(gbm_metrics(mg, m0) == GBM_OK);
+			for (int i = 0; i < 30; i++) {
+				struct sink s = {now_ms(), 0, 0, 0};
+				CHECK(gbm_rpc_get_block_range_streaming(mg, hb, NULL, 4u << 20, rb[q][0], rb[q][1], 65536, sink_fn, &s) == GBM_OK &&
+				      s.bytes == rb[q][1] - rb[q][0]);
+				e[i] = now_ms() - s.t0;
+			}
+			CHECK(gbm_metrics(mg, m1) == GBM_OK);
+			printf("ranged get, %7zu bytes of a 4 MiB block: median %.3f ms, %.0f KiB of shards read per call\n", rb[q][1] - rb[q][0], median(e + 5, 25),
+			       (double)(m1[1] - m0[1]) / 30 / 1024);
+		}
 		free(big);
 	}
 	/* ---- R readers through the batcher's read side */
