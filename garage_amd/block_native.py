@@ -33,12 +33,47 @@ SYMBOLS = [
     "gbm_batcher_submit", "gbm_batcher_wait", "gbm_set_maintenance_class", "gbm_batcher_get_block", "gbm_batcher_get_stats",
     "gbm_create_multi", "gbm_device_count", "gbm_device_of_hash", "gbm_device_codec", "gbm_device_background_codec",
     "gbm_device_metrics", "gbm_batcher_device_stats", "gbm_get_verify_block_hash", "gbm_rpc_get_block_range_streaming",
+    "gbm_scrub_worker_start", "gbm_scrub_worker_stop", "gbm_scrub_worker_command", "gbm_scrub_worker_status",
+    "gbm_block_metrics_get", "gbm_histogram_bounds", "gbm_metrics_prometheus",
 ]
 
 
 class OrderTag(ctypes.Structure):
     """OrderTag(stream, order), src/net/message.rs:66-89."""
     _fields_ = [("stream_id", ctypes.c_uint64), ("order", ctypes.c_uint64)]
+
+
+class ScrubStatus(ctypes.Structure):
+    """gbm_scrub_status: WorkerStatus of the ScrubWorker + ScrubWorkerPersisted (src/block/repair.rs:185-194,411-447)."""
+    _fields_ = [("state", ctypes.c_int32), ("tranquility", ctypes.c_uint32), ("progress", ctypes.c_double),
+                ("corruptions_detected", ctypes.c_uint64), ("time_last_complete_scrub_ms", ctypes.c_uint64),
+                ("time_next_run_scrub_ms", ctypes.c_uint64), ("resume_at_ms", ctypes.c_uint64), ("blocks_scrubbed", ctypes.c_uint64),
+                ("checkpoints_saved", ctypes.c_uint64), ("errors", ctypes.c_uint64)]
+
+
+HISTOGRAM_BUCKETS = 33
+
+
+class Histogram(ctypes.Structure):
+    """gbm_histogram: a value recorder over the reference exporter's boundaries (src/garage/server.rs:36-44), cumulative."""
+    _fields_ = [("count", ctypes.c_uint64), ("sum_s", ctypes.c_double), ("bucket", ctypes.c_uint64 * (HISTOGRAM_BUCKETS + 1))]
+
+
+class BlockMetrics(ctypes.Structure):
+    """gbm_block_metrics: BlockManagerMetrics (src/block/metrics.rs:10-143) + this engine's own counters."""
+    _fields_ = ([(n, ctypes.c_uint64) for n in ("compression_level", "rc_size", "resync_queue_length", "resync_errored_blocks", "ram_buffer_free_kb",
+                                               "resync_counter", "resync_error_counter", "resync_send_counter", "resync_recv_counter",
+                                               "bytes_read", "bytes_written", "delete_counter", "corruption_counter")]
+                + [(n, Histogram) for n in ("resync_duration", "block_read_duration", "block_write_duration")]
+                + [(n, ctypes.c_uint64) for n in ("ec_reconstructs", "blocks_put", "blocks_get", "gpu_hashed", "hedged_reads",
+                                                 "scrub_corruptions_detected", "scrub_time_last_complete_ms", "tranquilized_ms",
+                                                 "batcher_put_batches", "batcher_put_blocks", "batcher_get_batches", "batcher_get_blocks")]
+                + [("devices", ctypes.c_uint32)])
+
+
+SCRUB_START, SCRUB_PAUSE, SCRUB_RESUME, SCRUB_CANCEL = 0, 1, 2, 3            # ScrubWorkerCommand (repair.rs:300-305)
+SCRUB_NO_WORKER, SCRUB_FINISHED, SCRUB_RUNNING, SCRUB_PAUSED = -1, 0, 1, 2   # ScrubWorkerState (:272-286)
+SCRUB_INTERVAL_MS = 25 * 24 * 3600 * 1000
 
 
 class DataBlockHeader(ctypes.Structure):
@@ -133,6 +168,14 @@ def _load():
     lib.gbm_scrub_all.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint64)]
     lib.gbm_scrub_state.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.gbm_repair_all.argtypes = [vp, ctypes.POINTER(sz)]
+    lib.gbm_scrub_worker_start.argtypes = [vp, ctypes.c_char_p, sz, ctypes.c_uint64]
+    lib.gbm_scrub_worker_stop.argtypes = [vp]
+    lib.gbm_scrub_worker_command.argtypes = [vp, ci, ctypes.c_uint64]
+    lib.gbm_scrub_worker_status.argtypes = [vp, ctypes.POINTER(ScrubStatus)]
+    lib.gbm_block_metrics_get.argtypes = [vp, vp, ctypes.POINTER(BlockMetrics)]
+    lib.gbm_histogram_bounds.argtypes = []
+    lib.gbm_histogram_bounds.restype = ctypes.POINTER(ctypes.c_double)
+    lib.gbm_metrics_prometheus.argtypes = [vp, vp, ctypes.c_char_p, sz, ctypes.POINTER(sz)]
     lib.gbm_node_set_down.argtypes = [vp, ci, ci]
     lib.gbm_node_has_shard.argtypes = [vp, ci, ctypes.c_char_p, ci]
     lib.gbm_node_delete_shard.argtypes = [vp, ci, ctypes.c_char_p, ci]
@@ -448,6 +491,47 @@ class NativeBlockManager:
         out = (ctypes.c_uint64 * 2)()
         _check(lib.gbm_scrub_state(self._h, out), "scrub_state")
         return int(out[0]), int(out[1])
+
+    def set_tranquility(self, scrub: int = -1, resync: int = -1) -> None:
+        """scrub-tranquility / resync-tranquility (src/block/repair.rs:26-27, resync.rs:46); -1 leaves a value as it is."""
+        _check(lib.gbm_set_tranquility(self._h, scrub, resync), "set_tranquility")
+
+    def scrub_worker_start(self, persist_path: str | None = None, batch_blocks: int = 0, checkpoint_interval_ms: int = 0) -> None:
+        """The continuously running ScrubWorker (src/block/repair.rs:156-500); its state file survives a restart."""
+        _check(lib.gbm_scrub_worker_start(self._h, persist_path.encode() if persist_path else None, batch_blocks, checkpoint_interval_ms),
+               "scrub_worker_start")
+
+    def scrub_worker_stop(self) -> None:
+        _check(lib.gbm_scrub_worker_stop(self._h), "scrub_worker_stop")
+
+    def scrub_worker_command(self, cmd: int, pause_ms: int = 0) -> None:
+        """ScrubWorkerCommand::{Start, Pause(d), Resume, Cancel}; a command that does not fit the state raises."""
+        _check(lib.gbm_scrub_worker_command(self._h, cmd, pause_ms), "scrub_worker_command")
+
+    def scrub_worker_status(self) -> dict:
+        st = ScrubStatus()
+        _check(lib.gbm_scrub_worker_status(self._h, ctypes.byref(st)), "scrub_worker_status")
+        return {name: getattr(st, name) for name, _ in ScrubStatus._fields_}
+
+    def block_metrics(self, batcher=None) -> dict:
+        """BlockManagerMetrics (src/block/metrics.rs) as a dict; histograms as {count, sum_s, bucket: [cumulative...]}."""
+        x = BlockMetrics()
+        _check(lib.gbm_block_metrics_get(self._h, batcher._h if batcher is not None else None, ctypes.byref(x)), "block_metrics_get")
+        out = {}
+        for name, ty in BlockMetrics._fields_:
+            v = getattr(x, name)
+            out[name] = {"count": int(v.count), "sum_s": float(v.sum_s), "bucket": [int(c) for c in v.bucket]} if ty is Histogram else int(v)
+        return out
+
+    def metrics_prometheus(self, batcher=None) -> str:
+        """The same as Prometheus text exposition (the admin API's /metrics)."""
+        bh = batcher._h if batcher is not None else None
+        need = ctypes.c_size_t()
+        rc = lib.gbm_metrics_prometheus(self._h, bh, None, 0, ctypes.byref(need))
+        assert rc == GBM_E_BUFFER_TOO_SMALL, rc
+        buf = ctypes.create_string_buffer(need.value + 4096)   # (the counters may have grown a digit since)
+        _check(lib.gbm_metrics_prometheus(self._h, bh, buf, len(buf), ctypes.byref(need)), "metrics_prometheus")
+        return buf.value.decode()
 
     def repair_all(self) -> int:
         n = ctypes.c_size_t()

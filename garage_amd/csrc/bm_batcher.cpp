@@ -472,6 +472,26 @@ gbm_batcher *lane_for(gbm_batcher *b, const uint8_t *hash)
 
 }  // namespace
 
+void gbmimpl::batcher_snapshot(gbm_batcher *b, uint64_t out[5])
+{
+	std::fill(out, out + 5, 0);
+	auto add = [&](gbm_batcher *q) {
+		{
+			std::lock_guard<std::mutex> g(q->mu);
+			out[0] += q->ram_permits_kb > q->ram_in_use_kb ? q->ram_permits_kb - q->ram_in_use_kb : 0;
+			out[1] += q->batches;
+			out[2] += q->blocks;
+		}
+		std::lock_guard<std::mutex> g(q->gmu);
+		out[3] += q->gbatches;
+		out[4] += q->gblocks;
+	};
+	if (b->lanes.empty())
+		add(b);
+	for (gbm_batcher *l : b->lanes)
+		add(l);
+}
+
 extern "C" {
 
 int gbm_batcher_create(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, gbm_batcher **out)

@@ -348,6 +348,7 @@ int create_one(const gec_codec *codec, int nnodes, const char *const *node_dirs,
 void destroy_one(gbm_manager *m)
 {
 	gbm_resync_worker_stop(m);
+	gbm_scrub_worker_stop(m);
 	m->async.reset();  // drains: abandoned hedged requests still point at the nodes
 	if (m->bg_codec_owned)
 		gec_codec_destroy(m->bg_codec_owned);
@@ -562,8 +563,11 @@ int gbm_set_tranquility(gbm_manager *m, int scrub_tranquility, int resync_tranqu
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
 	GBM_EACH(m, x, {
-		if (scrub_tranquility >= 0)
+		if (scrub_tranquility >= 0) {
 			x->scrub_tranquility = (uint32_t)scrub_tranquility;
+			x->scrub_tranquility_set = true;
+			scrub_worker_tranquility_changed(x);
+		}
 		if (resync_tranquility >= 0)
 			x->resync_tranquility = (uint32_t)resync_tranquility;
 	});
@@ -638,6 +642,7 @@ int gbm_clock_advance(gbm_manager *m, uint64_t ms)
 	GBM_EACH(m, x, {
 		x->clock_skew_ms += ms;
 		x->rs_cv.notify_all();
+		scrub_worker_wake(x);  // a pause may be over, the next run may be due
 	});
 	return GBM_OK;
 }
@@ -766,6 +771,211 @@ int gbm_metrics(const gbm_manager *m, uint64_t out[6])
 			out[i] += l->metrics[i].load();
 	}
 	return GBM_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ BlockManagerMetrics (src/block/metrics.rs)
+namespace {
+
+void add_hist(const gbmimpl::Histogram &h, gbm_histogram &o)
+{
+	o.count += h.count.load(std::memory_order_relaxed);
+	o.sum_s += (double)h.sum_ns.load(std::memory_order_relaxed) * 1e-9;
+	for (int i = 0; i <= GBM_HISTOGRAM_BUCKETS; ++i)
+		o.bucket[i] += h.bucket[i].load(std::memory_order_relaxed);  // per bucket here; made cumulative at the end
+}
+
+void add_one(gbm_manager *x, gbm_block_metrics &o)
+{
+	for (auto &st : x->rc) {
+		std::lock_guard<std::mutex> g(st.mu);
+		o.rc_size += st.map.size();
+	}
+	{
+		std::lock_guard<std::mutex> g(x->rs_mu);
+		o.resync_queue_length += x->rs_queue.size();
+		o.resync_errored_blocks += x->rs_errors.size();
+	}
+	o.resync_counter += x->bmx.resync_counter.load();
+	o.resync_error_counter += x->bmx.resync_error_counter.load();
+	o.resync_send_counter += x->bmx.resync_send_counter.load();
+	o.resync_recv_counter += x->bmx.resync_recv_counter.load();
+	o.delete_counter += x->bmx.delete_counter.load();
+	o.bytes_written += x->metrics[0].load();
+	o.bytes_read += x->metrics[1].load();
+	o.corruption_counter += x->metrics[2].load();
+	o.ec_reconstructs += x->metrics[3].load();
+	o.blocks_put += x->metrics[4].load();
+	o.blocks_get += x->metrics[5].load();
+	add_hist(x->bmx.resync_duration, o.resync_duration);
+	add_hist(x->bmx.read_duration, o.block_read_duration);
+	add_hist(x->bmx.write_duration, o.block_write_duration);
+	o.gpu_hashed += x->gpu_hashed.load();
+	o.hedged_reads += x->hedged_reads.load();
+	o.scrub_corruptions_detected += x->scrub_corruptions.load();
+	o.scrub_time_last_complete_ms = std::max<uint64_t>(o.scrub_time_last_complete_ms, x->scrub_last_complete_ms.load());
+	o.tranquilized_ms += x->tranquilized_ms.load();
+}
+
+void cumulate(gbm_histogram &h)
+{
+	for (int i = 1; i <= GBM_HISTOGRAM_BUCKETS; ++i)
+		h.bucket[i] += h.bucket[i - 1];
+}
+
+void collect(const gbm_manager *cm, gbm_batcher *b, gbm_block_metrics &o, bool one_lane_only = false)
+{
+	gbm_manager *m = const_cast<gbm_manager *>(cm);
+	o = gbm_block_metrics{};
+	o.compression_level = m->compress.load() ? (uint64_t)std::max(0, m->compression_level.load()) : 0;
+	o.devices = m->is_front() && !one_lane_only ? (uint32_t)m->lanes.size() : 1;
+	add_one(m, o);
+	if (!one_lane_only)
+		for (auto &l : m->lanes)
+			add_one(l.get(), o);
+	cumulate(o.resync_duration);
+	cumulate(o.block_read_duration);
+	cumulate(o.block_write_duration);
+	if (b) {
+		uint64_t q[5];
+		batcher_snapshot(b, q);
+		o.ram_buffer_free_kb = q[0];
+		o.batcher_put_batches = q[1];
+		o.batcher_put_blocks = q[2];
+		o.batcher_get_batches = q[3];
+		o.batcher_get_blocks = q[4];
+	}
+}
+
+void put_line(std::string &s, const char *name, const char *labels, double v)
+{
+	char buf[96];
+	if (v == (double)(uint64_t)v && v < 1e18)
+		std::snprintf(buf, sizeof(buf), "%llu", (unsigned long long)v);
+	else
+		std::snprintf(buf, sizeof(buf), "%.9g", v);
+	s += name;
+	s += labels;
+	s += ' ';
+	s += buf;
+	s += '\n';
+}
+
+void put_metric(std::string &s, const char *name, const char *type, const char *help, double v)
+{
+	s += std::string("# HELP ") + name + " " + help + "\n# TYPE " + name + " " + type + "\n";
+	put_line(s, name, "", v);
+}
+
+void put_hist(std::string &s, const char *name, const char *help, const gbm_histogram &h)
+{
+	s += std::string("# HELP ") + name + " " + help + "\n# TYPE " + name + " histogram\n";
+	const double *b = gbmimpl::Histogram::bounds();
+	const std::string bn = std::string(name) + "_bucket";
+	char lab[48];
+	for (int i = 0; i < GBM_HISTOGRAM_BUCKETS; ++i) {
+		std::snprintf(lab, sizeof(lab), "{le=\"%g\"}", b[i]);
+		put_line(s, bn.c_str(), lab, (double)h.bucket[i]);
+	}
+	put_line(s, bn.c_str(), "{le=\"+Inf\"}", (double)h.bucket[GBM_HISTOGRAM_BUCKETS]);
+	put_line(s, (std::string(name) + "_sum").c_str(), "", h.sum_s);
+	put_line(s, (std::string(name) + "_count").c_str(), "", (double)h.count);
+}
+
+}  // namespace
+
+extern "C" {
+
+const double *gbm_histogram_bounds(void) { return gbmimpl::Histogram::bounds(); }
+
+int gbm_block_metrics_get(const gbm_manager *m, gbm_batcher *b, gbm_block_metrics *out)
+{
+	if (!m || !out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	collect(m, b, *out);
+	return GBM_OK;
+}
+
+int gbm_metrics_prometheus(const gbm_manager *m, gbm_batcher *b, char *buf, size_t cap, size_t *len_out)
+{
+	if (!m || !len_out || (!buf && cap))
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	try {
+		gbm_block_metrics x;
+		collect(m, b, x);
+		std::string s;
+		s.reserve(16384);
+		// the descriptions are the reference's (src/block/metrics.rs:40-143)
+		put_metric(s, "block_compression_level", "gauge", "Garage compression level for node", (double)x.compression_level);
+		put_metric(s, "block_rc_size", "gauge", "Number of blocks known to the reference counter", (double)x.rc_size);
+		put_metric(s, "block_resync_queue_length", "gauge", "Number of block hashes queued for local check and possible resync",
+			   (double)x.resync_queue_length);
+		put_metric(s, "block_resync_errored_blocks", "gauge", "Number of block hashes whose last resync resulted in an error",
+			   (double)x.resync_errored_blocks);
+		if (b)
+			put_metric(s, "block_ram_buffer_free_kb", "gauge",
+				   "Available RAM in KiB to use for buffering data blocks to be written to remote nodes", (double)x.ram_buffer_free_kb);
+		put_metric(s, "block_resync_counter", "counter", "Number of calls to resync_block", (double)x.resync_counter);
+		put_metric(s, "block_resync_error_counter", "counter", "Number of calls to resync_block that returned an error",
+			   (double)x.resync_error_counter);
+		put_hist(s, "block_resync_duration", "Duration of resync_block operations", x.resync_duration);
+		put_metric(s, "block_resync_send_counter", "counter", "Number of blocks sent to another node in resync operations",
+			   (double)x.resync_send_counter);
+		put_metric(s, "block_resync_recv_counter", "counter", "Number of blocks received from other nodes in resync operations",
+			   (double)x.resync_recv_counter);
+		put_metric(s, "block_bytes_read", "counter", "Number of bytes read from disk", (double)x.bytes_read);
+		put_hist(s, "block_read_duration", "Duration of block read operations", x.block_read_duration);
+		put_metric(s, "block_bytes_written", "counter", "Number of bytes written to disk", (double)x.bytes_written);
+		put_hist(s, "block_write_duration", "Duration of block write operations", x.block_write_duration);
+		put_metric(s, "block_delete_counter", "counter", "Number of blocks deleted", (double)x.delete_counter);
+		put_metric(s, "block_corruption_counter", "counter", "Data corruptions detected on block reads", (double)x.corruption_counter);
+		// this engine's own
+		put_metric(s, "block_ec_reconstructs", "counter", "Blocks that went through a decode, on a read or in a resync pass", (double)x.ec_reconstructs);
+		put_metric(s, "block_ec_blocks_put", "counter", "Blocks stored through rpc_put_block", (double)x.blocks_put);
+		put_metric(s, "block_ec_blocks_get", "counter", "Blocks read through rpc_get_block", (double)x.blocks_get);
+		put_metric(s, "block_ec_device_hashed", "counter", "Messages (blocks, shards) whose checksum the device computed", (double)x.gpu_hashed);
+		put_metric(s, "block_ec_hedged_reads", "counter", "Extra shard requests sent by hedged reads", (double)x.hedged_reads);
+		put_metric(s, "block_ec_scrub_corruptions_detected", "counter", "Corrupt blocks found by the scrub", (double)x.scrub_corruptions_detected);
+		put_metric(s, "block_ec_scrub_time_last_complete_ms", "gauge", "When the last complete scrub ended (ms since the epoch)",
+			   (double)x.scrub_time_last_complete_ms);
+		put_metric(s, "block_ec_tranquilized_ms", "counter", "Time the maintenance workers slept for the tranquilizer", (double)x.tranquilized_ms);
+		if (b) {
+			put_metric(s, "block_ec_batcher_put_batches", "counter", "Device batches the coalescing queue formed out of puts",
+				   (double)x.batcher_put_batches);
+			put_metric(s, "block_ec_batcher_put_blocks", "counter", "Blocks put through the coalescing queue", (double)x.batcher_put_blocks);
+			put_metric(s, "block_ec_batcher_get_batches", "counter", "Device batches the coalescing queue formed out of gets",
+				   (double)x.batcher_get_batches);
+			put_metric(s, "block_ec_batcher_get_blocks", "counter", "Blocks read through the coalescing queue", (double)x.batcher_get_blocks);
+		}
+		put_metric(s, "block_ec_devices", "gauge", "Devices this manager encodes on", (double)x.devices);
+		if (m->is_front()) {  // each device's share, under names of their own (a metric's samples must stay in one group)
+			static const char *const names[6] = {"block_ec_device_bytes_written", "block_ec_device_bytes_read",
+							     "block_ec_device_corruption_counter", "block_ec_device_reconstructs",
+							     "block_ec_device_blocks_put", "block_ec_device_blocks_get"};
+			for (int j = 0; j < 6; ++j) {
+				s += std::string("# HELP ") + names[j] + " Per device (gec_device_of_hash): see the total of the same name\n# TYPE " +
+				     names[j] + " counter\n";
+				for (size_t d = 0; d < m->lanes.size(); ++d) {
+					char lab[32];
+					std::snprintf(lab, sizeof(lab), "{device=\"%zu\"}", d);
+					put_line(s, names[j], lab, (double)m->lanes[d]->metrics[j].load());
+				}
+			}
+		}
+		*len_out = s.size();
+		if (cap) {
+			const size_t n = std::min(cap, s.size());
+			std::memcpy(buf, s.data(), n);
+			if (n < cap)
+				buf[n] = 0;
+		}
+		if (s.size() > cap)
+			return fail(GBM_E_BUFFER_TOO_SMALL, "metrics text does not fit the buffer");
+		return GBM_OK;
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("gbm_metrics_prometheus: ") + e.what());
+	}
 }
 
 }  // extern "C"

@@ -441,6 +441,9 @@ struct Node {
 	virtual void set_fsync(bool) {}
 	// every hash this node holds a shard of (BlockStoreIterator, src/block/repair.rs:196-233,634-752)
 	virtual void list(std::set<Hash> &out) = 0;
+	// the same, restricted to the hashes whose first byte is h0: one first-level directory of the store, the unit the
+	// ScrubWorker's iterator walks and checkpoints by (BsiTodo::Directory, src/block/repair.rs:196-233,684-752)
+	virtual void list_prefix(int h0, std::set<Hash> &out) = 0;
 
 	// the node's endpoint (StreamingEndpointHandler<BlockRpc>::handle, src/block/manager.rs:692-707);
 	// false = could not be contacted
@@ -473,6 +476,50 @@ struct ErrorCounter {
 		return base << std::min<uint64_t>(errors - 1, GBM_RESYNC_RETRY_MAX_BACKOFF_POWER);
 	}
 	uint64_t next_try(uint64_t base) const { return last_try + delay_ms(base); }
+};
+
+struct ScrubWorker;  // bm_scrub.cpp
+
+// BlockManagerMetrics (src/block/metrics.rs:10-143): the value recorders as histograms over the boundaries the
+// reference's Prometheus exporter is set up with (src/garage/server.rs:36-44), the counters the manager's metrics[] do
+// not already hold.  Everything is a relaxed atomic: a recorder costs two increments on the request path.
+struct Histogram {
+	static constexpr int NB = GBM_HISTOGRAM_BUCKETS;
+	static const double *bounds()
+	{
+		static const double b[NB] = {0.001, 0.0015, 0.002, 0.003, 0.005, 0.007, 0.01, 0.015, 0.02, 0.03, 0.05, 0.07, 0.1, 0.15, 0.2, 0.3, 0.5,
+					     0.7,   1.,     1.5,   2.,    3.,    5.,    7.,   10.,   15.,  20.,  30.,  40.,  50., 60.,  70., 100.};
+		return b;
+	}
+	std::atomic<uint64_t> bucket[NB + 1] = {};  // bucket[i]: observations in (bounds[i-1], bounds[i]]; [NB]: above the last bound
+	std::atomic<uint64_t> count{0}, sum_ns{0};
+	void record(std::chrono::nanoseconds d)
+	{
+		const double s = (double)d.count() * 1e-9;
+		const double *b = bounds();
+		int i = 0;
+		while (i < NB && s > b[i])
+			++i;
+		bucket[i].fetch_add(1, std::memory_order_relaxed);
+		count.fetch_add(1, std::memory_order_relaxed);
+		sum_ns.fetch_add((uint64_t)std::max<int64_t>(0, d.count()), std::memory_order_relaxed);
+	}
+};
+// RecordDuration (src/util/metrics.rs:8-57) as a scope: the time from its construction to the end of the scope
+struct DurationScope {
+	Histogram *h;
+	std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+	explicit DurationScope(Histogram &hist) : h(&hist) {}
+	void cancel() { h = nullptr; }
+	~DurationScope()
+	{
+		if (h)
+			h->record(std::chrono::steady_clock::now() - t0);
+	}
+};
+struct BlockMetrics {
+	std::atomic<uint64_t> resync_counter{0}, resync_error_counter{0}, resync_send_counter{0}, resync_recv_counter{0}, delete_counter{0};
+	Histogram resync_duration, read_duration, write_duration;
 };
 
 }  // namespace gbmimpl
@@ -554,7 +601,12 @@ struct gbm_manager {
 
 	// ScrubWorkerPersisted (src/block/repair.rs:169-194)
 	std::atomic<uint64_t> scrub_corruptions{0}, scrub_last_complete_ms{0};
+	// the continuously running ScrubWorker (repair.rs:156-500): gbm_scrub_worker_start creates it (one per lane)
+	std::mutex scrub_worker_mu;
+	std::shared_ptr<gbmimpl::ScrubWorker> scrub_worker;
+	std::atomic<bool> scrub_tranquility_set{false};  // gbm_set_tranquility has been called: INITIAL_SCRUB_TRANQUILITY does not apply
 	std::atomic<uint64_t> metrics[6] = {};
+	gbmimpl::BlockMetrics bmx;  // the rest of BlockManagerMetrics (gbm_block_metrics_get, gbm_metrics_prometheus)
 	std::atomic<uint64_t> gpu_hashed{0};
 	std::atomic<bool> compress{false};    // Config.compression_level (src/util/config.rs:52-58); Garage's default is Some(1)
 	std::atomic<int> compression_level{1};
@@ -735,5 +787,12 @@ void assemble(const Gathered &g, int k, uint8_t *dst);
 int one_block_rc(int rc1);
 // every hash any reachable node holds a shard of (bm_scrub.cpp)
 void list_all_nodes(gbm_manager *mg, std::set<Hash> &all);
+// the coalescing queue's figures for the metrics: out[0] = free RAM permits (KiB), [1] put batches, [2] put blocks,
+// [3] get batches, [4] get blocks; summed over the lanes of a front (bm_batcher.cpp)
+void batcher_snapshot(gbm_batcher *b, uint64_t out[5]);
+// gbm_set_tranquility changed the scrub's value: a running ScrubWorker persists it (repair.rs:26-27)
+void scrub_worker_tranquility_changed(gbm_manager *mg);
+// the clock moved (gbm_clock_advance): a pause may be over, the next run may be due
+void scrub_worker_wake(gbm_manager *mg);
 
 }  // namespace gbmimpl

@@ -135,6 +135,15 @@ struct MemoryNode : Node {
 				out.insert(kv.first.substr(0, 32));
 		}
 	}
+	void list_prefix(int h0, std::set<Hash> &out) override
+	{
+		for (Stripe &st : stripes) {
+			std::lock_guard<std::mutex> g(st.mu);
+			for (auto &kv : st.files)
+				if ((unsigned char)kv.first[0] == (unsigned)h0)
+					out.insert(kv.first.substr(0, 32));
+		}
+	}
 };
 
 // <root>/<h0>/<h1>/<hex>.s<idx>, tmp file + rename (write_block_inner, manager.rs:720-805);
@@ -292,32 +301,41 @@ struct DirNode : Node {
 		std::string p = path(h, idx);
 		std::rename(p.c_str(), (p + ".corrupted").c_str());
 	}
-	void list(std::set<Hash> &out) override
+	// <root>/<h0>/<h1>/<64 hex digits>.s<idx>
+	static void each_entry(const std::string &d, const std::function<void(const std::string &)> &fn)
 	{
-		// <root>/<h0>/<h1>/<64 hex digits>.s<idx>
-		auto each = [](const std::string &d, const std::function<void(const std::string &)> &fn) {
-			if (DIR *dp = ::opendir(d.c_str())) {
-				while (struct dirent *e = ::readdir(dp))
-					if (e->d_name[0] != '.')
-						fn(e->d_name);
-				::closedir(dp);
-			}
-		};
-		each(root, [&](const std::string &a) {
-			each(root + "/" + a, [&](const std::string &b) {
-				each(root + "/" + a + "/" + b, [&](const std::string &f) {
-					const size_t dot = f.find(".s");
-					if (dot != 64 || f.find_first_not_of("0123456789", dot + 2) != std::string::npos || f.size() == dot + 2)
-						return;
-					Hash h(32, 0);
-					for (int i = 0; i < 32; ++i) {
-						auto nib = [](char c) { return c >= 'a' ? c - 'a' + 10 : c - '0'; };
-						h[i] = (char)((nib(f[2 * i]) << 4) | nib(f[2 * i + 1]));
-					}
-					out.insert(h);
-				});
+		if (DIR *dp = ::opendir(d.c_str())) {
+			while (struct dirent *e = ::readdir(dp))
+				if (e->d_name[0] != '.')
+					fn(e->d_name);
+			::closedir(dp);
+		}
+	}
+	// every hash with a shard file under <root>/<a>
+	void list_first_level(const std::string &a, std::set<Hash> &out) const
+	{
+		each_entry(root + "/" + a, [&](const std::string &b) {
+			each_entry(root + "/" + a + "/" + b, [&](const std::string &f) {
+				const size_t dot = f.find(".s");
+				if (dot != 64 || f.find_first_not_of("0123456789", dot + 2) != std::string::npos || f.size() == dot + 2)
+					return;
+				Hash h(32, 0);
+				for (int i = 0; i < 32; ++i) {
+					auto nib = [](char c) { return c >= 'a' ? c - 'a' + 10 : c - '0'; };
+					h[i] = (char)((nib(f[2 * i]) << 4) | nib(f[2 * i + 1]));
+				}
+				out.insert(h);
 			});
 		});
+	}
+	void list(std::set<Hash> &out) override
+	{
+		each_entry(root, [&](const std::string &a) { list_first_level(a, out); });
+	}
+	void list_prefix(int h0, std::set<Hash> &out) override
+	{
+		static const char *hx = "0123456789abcdef";
+		list_first_level(std::string{hx[(h0 >> 4) & 15], hx[h0 & 15]}, out);
 	}
 };
 

@@ -390,6 +390,17 @@ int gbm_put_to_resync(gbm_manager *m, const uint8_t hash[32], uint64_t delay_ms)
 	return GBM_OK;
 }
 
+// resync_counter / resync_error_counter (resync.rs:298-302), blocks sent and received (:441-497), blocks deleted
+// (manager.rs:827) -- per shard here: this manager stands in front of all its nodes
+static void note_resync(gbm_manager *mg, const ResyncStats &st)
+{
+	mg->bmx.resync_counter += st.taken;
+	mg->bmx.resync_error_counter += st.errors;
+	mg->bmx.resync_send_counter += st.offloaded;
+	mg->bmx.resync_recv_counter += st.rebuilt;
+	mg->bmx.delete_counter += st.deleted;
+}
+
 // One pass of resync_iter over everything that is due (resync.rs:255-337).
 int gbm_resync_run(gbm_manager *mg, size_t max_blocks, uint64_t stats[8])
 {
@@ -437,12 +448,17 @@ int gbm_resync_run(gbm_manager *mg, size_t max_blocks, uint64_t stats[8])
 	for (size_t i = 0; i < taken.size(); ++i)
 		tasks[i].h = taken[i].second;
 	int result = GBM_OK;
-	try {
-		resync_blocks(mg, tasks, st);
-	} catch (const std::exception &e) {
-		for (auto &t : tasks)
-			if (t.error.empty())
-				t.error = e.what();
+	{
+		DurationScope pass_time(mg->bmx.resync_duration);  // block.resync_duration (resync.rs:290-296): one pass over what is due
+		if (tasks.empty())
+			pass_time.cancel();
+		try {
+			resync_blocks(mg, tasks, st);
+		} catch (const std::exception &e) {
+			for (auto &t : tasks)
+				if (t.error.empty())
+					t.error = e.what();
+		}
 	}
 	{
 		std::lock_guard<std::mutex> g(mg->rs_mu);
@@ -460,6 +476,7 @@ int gbm_resync_run(gbm_manager *mg, size_t max_blocks, uint64_t stats[8])
 			mg->rs_queue.insert({ec.next_try(base), t.h});
 		}
 	}
+	note_resync(mg, st);
 	if (stats) {
 		const uint64_t v[8] = {st.taken, st.ok, st.errors, st.skipped, st.rebuilt, st.deleted, st.offloaded, st.device_calls};
 		std::copy(v, v + 8, stats);
@@ -475,11 +492,19 @@ int gbm_resync_block(gbm_manager *mg, const uint8_t hash[32], int *changed)
 	std::vector<ResyncTask> tasks(1);
 	tasks[0].h.assign((const char *)hash, 32);
 	ResyncStats st;
-	try {
-		resync_blocks(mg, tasks, st);
-	} catch (const std::exception &e) {
-		return fail(GBM_E_IO, std::string("resync_block: ") + e.what());
+	st.taken = 1;
+	{
+		DurationScope one_time(mg->bmx.resync_duration);
+		try {
+			resync_blocks(mg, tasks, st);
+		} catch (const std::exception &e) {
+			st.errors = 1;
+			note_resync(mg, st);
+			return fail(GBM_E_IO, std::string("resync_block: ") + e.what());
+		}
 	}
+	st.errors = tasks[0].error.empty() ? 0 : 1;
+	note_resync(mg, st);
 	if (changed)
 		*changed = tasks[0].changed;
 	if (!tasks[0].error.empty())

@@ -343,6 +343,7 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 	for (size_t b = 0; b < nb; ++b)
 		if (!data[b] && len[b])
 			return fail_all(GBM_E_INVALID_ARG, "NULL block pointer");
+	DurationScope write_time(mg->bmx.write_duration);  // block.write_duration (metrics.rs:127-131): one observation per call
 	if (rcs)
 		std::fill(rcs, rcs + nb, GBM_OK);
 	const int k = mg->k, m = mg->m, n = mg->n;
@@ -758,6 +759,7 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 {
 	if (!mg || (nb && (!hashes || !out || !cap || !len_out || !rcs)))
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	DurationScope read_time(mg->bmx.read_duration);  // block.read_duration (metrics.rs:117-121): one observation per call
 	const int k = mg->k;
 	std::vector<Hash> hs(nb);
 	for (size_t b = 0; b < nb; ++b)
@@ -1546,6 +1548,7 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 	if (!m || !hash || !sink)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
 	m = m->route(hash);
+	DurationScope read_time(m->bmx.read_duration);
 	const int k = m->k;
 	std::vector<Hash> hs(1, Hash((const char *)hash, 32));
 	StreamOut out(sink, ctx, chunk_bytes);
@@ -1641,10 +1644,12 @@ int get_range(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order
 	if (begin > end)
 		return fail(GBM_E_INVALID_ARG, "range begins after its end");
 	m = m->route(hash);
+	DurationScope read_time(m->bmx.read_duration);
 	const int k = m->k;
 	const size_t ch = chunk_bytes ? chunk_bytes : 65536;
 	size_t pos = begin;  // the next byte of the block the consumer is owed
 	auto whole_block = [&]() {
+		read_time.cancel();  // (the whole-block stream records its own)
 		RangeSlice rs{sink, ctx, pos, end};
 		int rc = get_streaming(m, hash, order_tag, nullptr, chunk_bytes, RangeSlice::fn, &rs, false);
 		if (rc == GBM_E_ABORTED && rs.done && !rs.consumer_stopped)

@@ -352,6 +352,50 @@ int gbm_scrub_all(gbm_manager *m, size_t batch_blocks, uint64_t stats[4]);
 /* out[0] = corruptions_detected so far, out[1] = time_last_complete_scrub (ms; ScrubWorkerPersisted, :169-194) */
 int gbm_scrub_state(const gbm_manager *m, uint64_t out[2]);
 
+/* The ScrubWorker as the reference runs it (src/block/repair.rs:156-500): a continuously running task that walks the
+ * whole store, starts by itself every SCRUB_INTERVAL (25 days + a random 0..10 days, :23-24,245-256), can be started,
+ * paused, resumed and cancelled at run time (ScrubWorkerCommand, :300-305; `garage repair scrub start|pause|resume|
+ * cancel`), and survives a restart: its state -- tranquility, time_last_complete_scrub, time_next_run_scrub,
+ * corruptions_detected and a CHECKPOINT of its iterator (ScrubWorkerPersisted, :185-194) -- is saved on every command,
+ * every checkpoint_interval_ms while running (the reference: 60 s, :463-467) and when a pass ends; a worker started over a
+ * state file that holds a checkpoint carries on from it (ScrubWorker::new, :307-326).
+ *   The iterator (BlockStoreIterator, :196-233,634-752) walks the store one first-level directory (first hash byte) at a
+ * time, in hash order; a checkpoint is "everything up to this hash is done".  Each step is one batch of up to
+ * batch_blocks (0 = 1024) stripes -- shards gathered from the nodes while the previous batch is on the device, ONE
+ * gec_verify_hash_batch trip on the BACKGROUND codec, leave-one-out location of a silently wrong shard, corrupt blocks
+ * counted and queued for resync: gbm_scrub_all's step -- followed by the tranquilizer's pause (gbm_set_tranquility; the
+ * persisted value wins over the manager's at start, INITIAL_SCRUB_TRANQUILITY = 4 applies when neither exists).
+ *   persist_path: the state file (NULL: the state lives in memory only).  It is this library's own little-endian record,
+ * written to <path>.tmp and renamed; a file that does not decode is ignored like Persister::load's error is
+ * (PersisterShared::new, src/util/persister.rs:97-101).  On a multi-device manager there is one worker and one file
+ * (<path>.dev<i>) per device, each walking the hashes its device owns; commands go to all of them, the status is their
+ * aggregate (running if any runs, progress = mean, counters summed, times: the earliest). */
+enum { GBM_SCRUB_CMD_START = 0, GBM_SCRUB_CMD_PAUSE = 1, GBM_SCRUB_CMD_RESUME = 2, GBM_SCRUB_CMD_CANCEL = 3 };
+enum { GBM_SCRUB_NO_WORKER = -1, GBM_SCRUB_FINISHED = 0, GBM_SCRUB_RUNNING = 1, GBM_SCRUB_PAUSED = 2 };
+#define GBM_SCRUB_INTERVAL_MS (25ull * 24 * 3600 * 1000) /* SCRUB_INTERVAL, src/block/repair.rs:24 */
+#define GBM_INITIAL_SCRUB_TRANQUILITY 4                   /* :27 */
+typedef struct {
+	int32_t state;        /* GBM_SCRUB_* */
+	uint32_t tranquility; /* WorkerStatus.tranquility */
+	double progress;      /* 0..1 (BlockStoreIterator::progress, :664-674); 1 when no pass is under way */
+	uint64_t corruptions_detected;        /* WorkerStatus.persistent_errors */
+	uint64_t time_last_complete_scrub_ms; /* 0: never */
+	uint64_t time_next_run_scrub_ms;
+	uint64_t resume_at_ms;                /* Paused: when the pause ends by itself */
+	uint64_t blocks_scrubbed;             /* by this worker object, over all its passes */
+	uint64_t checkpoints_saved;           /* state-file writes that carried a checkpoint */
+	uint64_t errors;                      /* steps that failed as a whole (device / IO); the step is retried */
+} gbm_scrub_status;
+int gbm_scrub_worker_start(gbm_manager *m, const char *persist_path, size_t batch_blocks, uint64_t checkpoint_interval_ms);
+int gbm_scrub_worker_stop(gbm_manager *m); /* also done by gbm_destroy; the state file keeps the last checkpoint */
+/* Start: only when no pass is under way ("Cannot start scrub worker: already running!").  Pause(pause_ms): a running or
+ * paused worker; saves the checkpoint; the pass resumes by itself after pause_ms.  Resume: only when paused.  Cancel: a
+ * running or paused pass is dropped, the checkpoint cleared.  A command that does not fit the state returns
+ * GBM_E_INVALID_ARG with the reference's message and changes nothing.  The step in flight when a command arrives is
+ * not counted: it is done again when the pass goes on. */
+int gbm_scrub_worker_command(gbm_manager *m, int cmd, uint64_t pause_ms);
+int gbm_scrub_worker_status(const gbm_manager *m, gbm_scrub_status *out);
+
 /* Fault injection / inspection for tests. */
 int gbm_node_set_down(gbm_manager *m, int node, int down);
 int gbm_node_has_shard(gbm_manager *m, int node, const uint8_t hash[32], int idx);
@@ -383,6 +427,57 @@ int gbm_node_set_latency(gbm_manager *m, int node, uint64_t latency_us);
 int gbm_metrics(const gbm_manager *m, uint64_t out[6]);
 /* number of messages (shards / blocks) whose blake2sum was computed on the GPU */
 uint64_t gbm_gpu_hashed(const gbm_manager *m);
+
+/* BlockManagerMetrics (src/block/metrics.rs:10-143), instrument by instrument and under the reference's names, so that the
+ * Rust side's OTel observers -- or an operator's existing dashboards (script/telemetry/) -- read the same things off an
+ * erasure-coded node.  The value recorders are histograms over the boundaries the reference's Prometheus exporter is
+ * configured with (src/garage/server.rs:36-44: 1 ms .. 100 s); bucket[i] is CUMULATIVE (observations <= bound i, the last
+ * entry = +Inf = count), as the exposition format wants it.
+ *   What one observation is: block.write_duration / block.read_duration time one manager call (a put or get of one
+ * block, or of a batch that makes one device trip: every block of the batch took that long), where the reference times
+ * one node's write_block / read_block (manager.rs:518-527,555-574); block.resync_duration times one pass of the resync
+ * loop over what is due (one batched reconstruct) where the reference times one resync_block (resync.rs:290-296).
+ * bytes_written / bytes_read / delete_counter are summed over this manager's nodes (shard bytes, shards).
+ * resync_send_counter = shards offloaded to the node that should hold them, resync_recv_counter = shards rebuilt and
+ * stored (resync.rs:441-497).  ram_buffer_free_kb needs the coalescing queue that holds the permits (`b`; 0 without).
+ * On a multi-device manager every figure is the sum over the devices (histograms added bucket by bucket). */
+#define GBM_HISTOGRAM_BUCKETS 33
+typedef struct {
+	uint64_t count;
+	double sum_s;
+	uint64_t bucket[GBM_HISTOGRAM_BUCKETS + 1];
+} gbm_histogram;
+typedef struct {
+	/* value observers */
+	uint64_t compression_level;     /* block.compression_level (0: none) */
+	uint64_t rc_size;               /* block.rc_size: blocks known to the reference counter */
+	uint64_t resync_queue_length;   /* block.resync_queue_length */
+	uint64_t resync_errored_blocks; /* block.resync_errored_blocks */
+	uint64_t ram_buffer_free_kb;    /* block.ram_buffer_free_kb */
+	/* counters */
+	uint64_t resync_counter, resync_error_counter, resync_send_counter, resync_recv_counter;
+	uint64_t bytes_read, bytes_written, delete_counter, corruption_counter;
+	/* value recorders */
+	gbm_histogram resync_duration, block_read_duration, block_write_duration;
+	/* this engine's own */
+	uint64_t ec_reconstructs;      /* blocks that went through a decode: on a read, or in a resync pass */
+	uint64_t blocks_put, blocks_get;
+	uint64_t gpu_hashed;           /* messages whose checksum the device computed */
+	uint64_t hedged_reads;
+	uint64_t scrub_corruptions_detected, scrub_time_last_complete_ms;
+	uint64_t tranquilized_ms;
+	uint64_t batcher_put_batches, batcher_put_blocks, batcher_get_batches, batcher_get_blocks;
+	uint32_t devices;
+} gbm_block_metrics;
+int gbm_block_metrics_get(const gbm_manager *m, gbm_batcher *b /* may be NULL */, gbm_block_metrics *out);
+/* the GBM_HISTOGRAM_BUCKETS upper bounds, in seconds (static storage) */
+const double *gbm_histogram_bounds(void);
+/* The same as Prometheus text exposition (what `/metrics` of the admin API serves, src/api/admin/api_server.rs): the
+ * reference's instruments under the names its exporter gives them (block_bytes_read, block_read_duration_bucket{le=..},
+ * ...), this engine's own as block_ec_*; on a multi-device manager the per-device counters follow with a device="i"
+ * label.  Writes at most cap bytes (NUL-terminated when there is room) and reports the full length in *len_out:
+ * GBM_E_BUFFER_TOO_SMALL when cap was not enough. */
+int gbm_metrics_prometheus(const gbm_manager *m, gbm_batcher *b, char *buf, size_t cap, size_t *len_out);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <string>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -814,8 +815,110 @@ static void run_put_vs_resync_delete(int k, int m)
 	printf("put vs resync delete RS(%d,%d): OK\n", k, m);
 }
 
+// The continuously running ScrubWorker (src/block/repair.rs:156-500) under the sanitizers: passes started, paused, resumed
+// and cancelled from two threads while a third keeps putting and reading blocks, the tranquility and the manager's clock
+// moved under it, a corruption found on the way, the worker stopped mid-pass and a second one carrying on from the file.
+static void run_scrub_worker(int k, int m, const char *dir_root)
+{
+	gec_codec *codec = stub_codec_create(k, m);
+	gbm_manager *mg = nullptr;
+	CHECK(gbm_create(codec, k + m + 2, nullptr, 0, &mg) == GBM_OK);
+	const int NB = 64;
+	std::vector<std::vector<uint8_t>> blocks(NB);
+	std::vector<uint8_t> hashes(NB * 32);
+	std::vector<const uint8_t *> ptr(NB);
+	std::vector<size_t> len(NB);
+	for (int i = 0; i < NB; ++i) {
+		blocks[i] = pattern(20000 + 777 * i, 9100 + i);
+		gbm_blake2sum(blocks[i].data(), blocks[i].size(), hashes.data() + 32 * i);
+		ptr[i] = blocks[i].data();
+		len[i] = blocks[i].size();
+	}
+	CHECK(gbm_rpc_put_blocks(mg, NB, hashes.data(), ptr.data(), len.data(), nullptr, nullptr) == GBM_OK);
+	for (int i = 0; i < NB; ++i)
+		CHECK(gbm_block_incref(mg, hashes.data() + 32 * i) == GBM_OK);
+	const std::string state = dir_root ? std::string(dir_root) + "/scrub_info" : std::string();
+	gbm_scrub_status st;
+	CHECK(gbm_scrub_worker_status(mg, &st) == GBM_OK && st.state == GBM_SCRUB_NO_WORKER);
+	CHECK(gbm_scrub_worker_command(mg, GBM_SCRUB_CMD_START, 0) == GBM_E_INVALID_ARG);
+	CHECK(gbm_scrub_worker_start(mg, dir_root ? state.c_str() : nullptr, 4, 1) == GBM_OK);
+	CHECK(gbm_scrub_worker_start(mg, nullptr, 0, 0) == GBM_OK);  // a second start is a no-op
+	CHECK(gbm_scrub_worker_status(mg, &st) == GBM_OK && st.state == GBM_SCRUB_FINISHED && st.tranquility == GBM_INITIAL_SCRUB_TRANQUILITY);
+	CHECK(gbm_scrub_worker_command(mg, GBM_SCRUB_CMD_PAUSE, 10) == GBM_E_INVALID_ARG);
+	CHECK(gbm_set_tranquility(mg, 1, -1) == GBM_OK);
+	std::atomic<bool> done{false};
+	std::thread traffic([&] {
+		std::vector<uint8_t> out(200000);
+		for (int r = 0; !done.load(); ++r) {
+			const int i = r % NB;
+			size_t got = 0;
+			CHECK(gbm_rpc_get_block(mg, hashes.data() + 32 * i, nullptr, out.data(), out.size(), &got) == GBM_OK && got == blocks[i].size());
+			CHECK(gbm_rpc_put_block(mg, hashes.data() + 32 * i, blocks[i].data(), blocks[i].size(), 0, nullptr) == GBM_OK);
+		}
+	});
+	auto commander = [&](int salt) {
+		for (int r = 0; r < 40; ++r) {
+			const int cmd = (r * 7 + salt) % 4;
+			(void)gbm_scrub_worker_command(mg, cmd, 3);  // whatever the state is: GBM_OK or a refusal, never anything else
+			gbm_scrub_status s;
+			CHECK(gbm_scrub_worker_status(mg, &s) == GBM_OK && s.progress >= 0.0 && s.progress <= 1.0);
+			if (r % 9 == 0)
+				CHECK(gbm_set_tranquility(mg, r % 3, -1) == GBM_OK);
+			if (r % 11 == 0)
+				CHECK(gbm_clock_advance(mg, 5) == GBM_OK);
+			std::this_thread::sleep_for(std::chrono::milliseconds(2));
+		}
+	};
+	std::thread c1(commander, 0), c2(commander, 1);
+	c1.join();
+	c2.join();
+	done = true;
+	traffic.join();
+	// settle: whatever state the commands left, one complete pass from the start
+	CHECK(gbm_set_tranquility(mg, 0, -1) == GBM_OK);
+	(void)gbm_scrub_worker_command(mg, GBM_SCRUB_CMD_CANCEL, 0);
+	CHECK(gbm_scrub_worker_status(mg, &st) == GBM_OK && st.state == GBM_SCRUB_FINISHED);
+	const uint64_t before = st.time_last_complete_scrub_ms;
+	// a silently wrong parity shard (m >= 2: located; m == 1: only detected)
+	int who[64];
+	CHECK(gbm_storage_nodes_of(mg, hashes.data() + 32 * 5, who) == GBM_OK);
+	CHECK(gbm_node_corrupt_shard(mg, who[k], hashes.data() + 32 * 5, k, 33, 0x04, /*fix_checksum=*/1) == GBM_OK);
+	const uint64_t corr0 = st.corruptions_detected;
+	CHECK(gbm_scrub_worker_command(mg, GBM_SCRUB_CMD_START, 0) == GBM_OK);
+	for (int spin = 0; spin < 20000; ++spin) {
+		CHECK(gbm_scrub_worker_status(mg, &st) == GBM_OK);
+		if (st.state == GBM_SCRUB_FINISHED && st.time_last_complete_scrub_ms > before)
+			break;
+		std::this_thread::sleep_for(std::chrono::milliseconds(1));
+	}
+	CHECK(st.state == GBM_SCRUB_FINISHED && st.time_last_complete_scrub_ms > before && st.corruptions_detected == corr0 + 1);
+	CHECK(st.time_next_run_scrub_ms >= st.time_last_complete_scrub_ms + GBM_SCRUB_INTERVAL_MS);
+	int changed = 0;
+	CHECK(gbm_resync_all(mg, &changed) == GBM_OK);
+	// stop mid-pass, carry on with a second worker object
+	CHECK(gbm_set_tranquility(mg, 100, -1) == GBM_OK);
+	CHECK(gbm_scrub_worker_command(mg, GBM_SCRUB_CMD_START, 0) == GBM_OK);
+	std::this_thread::sleep_for(std::chrono::milliseconds(30));
+	CHECK(gbm_scrub_worker_stop(mg) == GBM_OK);
+	CHECK(gbm_scrub_worker_status(mg, &st) == GBM_OK && st.state == GBM_SCRUB_NO_WORKER);
+	CHECK(gbm_scrub_worker_start(mg, dir_root ? state.c_str() : nullptr, 16, 0) == GBM_OK);
+	CHECK(gbm_scrub_worker_status(mg, &st) == GBM_OK);
+	CHECK(st.state == (dir_root ? GBM_SCRUB_RUNNING : GBM_SCRUB_FINISHED));  // only a state file carries a pass over
+	CHECK(gbm_set_tranquility(mg, 0, -1) == GBM_OK);
+	for (int spin = 0; spin < 20000 && st.state != GBM_SCRUB_FINISHED; ++spin) {
+		std::this_thread::sleep_for(std::chrono::milliseconds(1));
+		CHECK(gbm_scrub_worker_status(mg, &st) == GBM_OK);
+	}
+	CHECK(st.state == GBM_SCRUB_FINISHED && st.errors == 0);
+	gbm_destroy(mg);  // stops the worker
+	stub_codec_destroy(codec);
+	printf("scrub worker RS(%d,%d)%s: OK\n", k, m, dir_root ? " with a state file" : "");
+}
+
 int main(int argc, char **argv)
 {
+	run_scrub_worker(3, 1, nullptr);
+	run_scrub_worker(10, 4, argc > 1 ? argv[1] : nullptr);
 	run_hedged(3, 1);
 	run_hedged(10, 4);
 	run_round2(3, 1);

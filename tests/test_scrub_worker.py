@@ -1,0 +1,194 @@
+"""The continuously running ScrubWorker (src/block/repair.rs:156-500) in libgarage_block: the state machine and its
+commands (Start / Pause / Resume / Cancel with the reference's refusals), the schedule (SCRUB_INTERVAL + 0..10 days, driven
+here by the manager's clock), the persisted record (tranquility, times, corruptions, CHECKPOINT) and a restart that
+carries on from the checkpoint -- on the CPU backend everywhere and on the HIP backend on a GPU box."""
+import os
+import time
+
+import pytest
+
+import garage_amd as g
+from garage_amd import block_native as bn
+from tests.block_manager_cases import pattern_block
+
+DAY = 24 * 3600 * 1000
+
+
+@pytest.fixture(params=["cpu", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request):
+    return request.param
+
+
+def _store(mgr, n, size=40_000, salt=7000):
+    blocks = [pattern_block(size + 64 * i, salt + i) for i in range(n)]
+    hashes = [bn.blake2sum(b) for b in blocks]
+    mgr.rpc_put_blocks(list(zip(hashes, blocks)))
+    for h in hashes:
+        mgr.block_incref(h)
+    return hashes, blocks
+
+
+def _wait(cond, what, timeout=30.0):
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        if cond():
+            return
+        time.sleep(0.005)
+    raise AssertionError(f"timed out waiting for: {what}")
+
+
+def test_commands_follow_the_reference_state_machine(backend, tmp_path):
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    mgr = bn.NativeBlockManager(codec, 16)
+    hashes, _ = _store(mgr, 60)
+    assert mgr.scrub_worker_status()["state"] == bn.SCRUB_NO_WORKER
+    with pytest.raises(bn.BlockError, match="no scrub worker"):
+        mgr.scrub_worker_command(bn.SCRUB_START)
+    state = str(tmp_path / "scrub_info")
+    t0 = int(time.time() * 1000)
+    mgr.scrub_worker_start(state, batch_blocks=8)
+    st = mgr.scrub_worker_status()
+    # ScrubWorkerPersisted::default: nothing done, the first run 25..35 days away, INITIAL_SCRUB_TRANQUILITY
+    assert st["state"] == bn.SCRUB_FINISHED and st["progress"] == 1.0 and st["time_last_complete_scrub_ms"] == 0
+    assert t0 + 25 * DAY - 1000 <= st["time_next_run_scrub_ms"] <= t0 + 35 * DAY + 60_000
+    assert st["tranquility"] == 4
+    mgr.set_tranquility(scrub=0)
+    # commands that do not fit the state are refused with the reference's words (repair.rs:349,370,383,397)
+    for cmd, msg in [(bn.SCRUB_PAUSE, "Cannot pause scrub worker: not running!"), (bn.SCRUB_RESUME, "Cannot resume scrub worker: not paused!"),
+                     (bn.SCRUB_CANCEL, "Cannot cancel scrub worker: not running!")]:
+        with pytest.raises(bn.BlockError, match=msg):
+            mgr.scrub_worker_command(cmd)
+    with pytest.raises(bn.BlockError, match="unknown scrub worker command"):
+        mgr.scrub_worker_command(17)
+
+    # Start: a pass over everything, then Finished again with the times moved on
+    mgr.scrub_worker_command(bn.SCRUB_START)
+    _wait(lambda: mgr.scrub_worker_status()["time_last_complete_scrub_ms"] > 0, "the pass to complete")
+    st = mgr.scrub_worker_status()
+    assert st["state"] == bn.SCRUB_FINISHED and st["blocks_scrubbed"] == 60 and st["corruptions_detected"] == 0 and st["errors"] == 0
+    assert st["time_last_complete_scrub_ms"] >= t0 and st["time_next_run_scrub_ms"] >= st["time_last_complete_scrub_ms"] + 25 * DAY
+    assert mgr.scrub_state()[1] == st["time_last_complete_scrub_ms"]
+
+    # Pause right behind Start: the pass stands still where it is, Start is refused, Pause may be repeated, Resume ends it
+    mgr.set_tranquility(scrub=50)       # slow steps: the pause lands inside the pass
+    mgr.scrub_worker_command(bn.SCRUB_START)
+    with pytest.raises(bn.BlockError, match="Cannot start scrub worker: already running!"):
+        mgr.scrub_worker_command(bn.SCRUB_START)
+    mgr.scrub_worker_command(bn.SCRUB_PAUSE, 3600_000)
+    st = mgr.scrub_worker_status()
+    assert st["state"] == bn.SCRUB_PAUSED and st["progress"] < 1.0 and st["resume_at_ms"] >= int(time.time() * 1000) + 3500_000
+    with pytest.raises(bn.BlockError, match="already running"):
+        mgr.scrub_worker_command(bn.SCRUB_START)
+    mgr.scrub_worker_command(bn.SCRUB_PAUSE, 7200_000)
+    time.sleep(0.05)
+    frozen = mgr.scrub_worker_status()
+    time.sleep(0.1)
+    again = mgr.scrub_worker_status()
+    assert again["blocks_scrubbed"] == frozen["blocks_scrubbed"] and again["progress"] == frozen["progress"]
+    mgr.set_tranquility(scrub=0)
+    mgr.scrub_worker_command(bn.SCRUB_RESUME)
+    _wait(lambda: mgr.scrub_worker_status()["state"] == bn.SCRUB_FINISHED, "the resumed pass to complete")
+    assert mgr.scrub_worker_status()["blocks_scrubbed"] >= 120          # every block once per pass (a dropped step is done again)
+
+    # a pause ends by itself when its time is up (wait_for_work, :500-505) -- the manager's clock is moved
+    mgr.set_tranquility(scrub=50)
+    mgr.scrub_worker_command(bn.SCRUB_START)
+    mgr.scrub_worker_command(bn.SCRUB_PAUSE, 60_000)
+    mgr.set_tranquility(scrub=0)
+    assert mgr.scrub_worker_status()["state"] == bn.SCRUB_PAUSED
+    mgr.clock_advance(61_000)
+    _wait(lambda: mgr.scrub_worker_status()["state"] == bn.SCRUB_FINISHED, "the pause to end and the pass to complete")
+
+    # Cancel drops the pass and the checkpoint
+    mgr.set_tranquility(scrub=50)
+    mgr.scrub_worker_command(bn.SCRUB_START)
+    mgr.scrub_worker_command(bn.SCRUB_CANCEL)
+    st = mgr.scrub_worker_status()
+    assert st["state"] == bn.SCRUB_FINISHED and st["progress"] == 1.0
+    mgr.set_tranquility(scrub=0)
+
+    # the schedule: nothing happens before time_next_run_scrub, a pass starts by itself once it is reached
+    before = mgr.scrub_worker_status()
+    mgr.clock_advance(24 * DAY)
+    time.sleep(0.1)
+    assert mgr.scrub_worker_status()["blocks_scrubbed"] == before["blocks_scrubbed"]
+    mgr.clock_advance(12 * DAY)
+    _wait(lambda: mgr.scrub_worker_status()["time_last_complete_scrub_ms"] > before["time_last_complete_scrub_ms"], "the scheduled pass")
+    st = mgr.scrub_worker_status()
+    assert st["blocks_scrubbed"] == before["blocks_scrubbed"] + 60
+    assert st["time_next_run_scrub_ms"] >= st["time_last_complete_scrub_ms"] + 25 * DAY
+    mgr.scrub_worker_stop()
+    assert mgr.scrub_worker_status()["state"] == bn.SCRUB_NO_WORKER
+    assert os.path.getsize(state) == 72
+
+
+@pytest.mark.parametrize("on_disk", [False, True], ids=["memory", "directories"])
+def test_a_restart_carries_on_from_the_checkpoint(backend, tmp_path, on_disk):
+    """ScrubWorker::new over a state file that holds a checkpoint: Running from there (repair.rs:307-326).  The second
+    worker object scrubs what the first had not reached -- not the whole store again -- and the counters it inherits
+    (corruptions_detected, tranquility) are the persisted ones."""
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    dirs = [str(tmp_path / f"node{i}") for i in range(16)] if on_disk else None
+    mgr = bn.NativeBlockManager(codec, 16, dirs)
+    hashes, blocks = _store(mgr, 96, size=30_000)
+    order = sorted(hashes)
+    # one block far down the walk is silently wrong (checksum "fixed"): only the device's RS verify can see it
+    victim = order[80]
+    who = mgr.storage_nodes_of(victim)
+    mgr.node_corrupt_shard(who[11], victim, 11, 99, 0x10, fix_checksum=True)
+    state = str(tmp_path / "scrub_info")
+    mgr.set_tranquility(scrub=7)
+    mgr.scrub_worker_start(state, batch_blocks=8, checkpoint_interval_ms=1)
+    mgr.set_tranquility(scrub=200)          # (after the start: the steps crawl, the stop lands mid-pass)
+    mgr.scrub_worker_command(bn.SCRUB_START)
+    _wait(lambda: mgr.scrub_worker_status()["blocks_scrubbed"] >= 16, "two steps")
+    mgr.scrub_worker_stop()                 # the process "dies" here; the state file holds the walk's position
+    mgr.set_tranquility(scrub=7)
+    first = os.path.getsize(state)
+    assert first == 72
+
+    mgr.scrub_worker_start(state, batch_blocks=8)
+    st = mgr.scrub_worker_status()
+    assert st["tranquility"] == 200                                     # the persisted value wins (repair.rs:26-27)
+    mgr.set_tranquility(scrub=0)
+    _wait(lambda: mgr.scrub_worker_status()["state"] == bn.SCRUB_FINISHED, "the carried-on pass to complete")
+    st = mgr.scrub_worker_status()
+    assert 0 < st["blocks_scrubbed"] <= 96 - 16, st                      # only what was left
+    assert st["corruptions_detected"] == 1 and st["time_last_complete_scrub_ms"] > 0
+    assert not mgr.node_has_shard(who[11], victim, 11)                   # located, set aside ...
+    assert mgr.resync_run()["rebuilt"] == 1                              # ... and rebuilt by the resync it queued
+    assert mgr.rpc_get_blocks(hashes, 60_000) == blocks
+    mgr.scrub_worker_stop()
+
+    # a third worker object: no checkpoint in the file any more -> Finished, the counters still there
+    mgr.scrub_worker_start(state)
+    st3 = mgr.scrub_worker_status()
+    assert st3["state"] == bn.SCRUB_FINISHED and st3["corruptions_detected"] == 1 and st3["tranquility"] == 0
+    assert st3["time_last_complete_scrub_ms"] == st["time_last_complete_scrub_ms"]
+    assert st3["time_next_run_scrub_ms"] == st["time_next_run_scrub_ms"]
+    mgr.scrub_worker_stop()
+
+    # a state file that does not decode is ignored (Persister::load's error -> Default, persister.rs:97-101)
+    with open(state, "wb") as f:
+        f.write(b"not a scrub record")
+    mgr.scrub_worker_start(state)
+    st4 = mgr.scrub_worker_status()
+    assert st4["state"] == bn.SCRUB_FINISHED and st4["corruptions_detected"] == 0 and st4["time_last_complete_scrub_ms"] == 0
+
+
+def test_one_worker_per_device_of_a_multi_device_manager(tmp_path):
+    """gbm_create_multi: a worker and a state file per device, each walking the hashes gec_device_of_hash gives it."""
+    codecs = [g.ReedSolomon(3, 1, backend="cpu") for _ in range(3)]
+    mgr = bn.NativeBlockManager(codecs, 6)
+    hashes, _ = _store(mgr, 45, size=9_000)
+    state = str(tmp_path / "scrub_info")
+    mgr.set_tranquility(scrub=0)
+    mgr.scrub_worker_start(state, batch_blocks=4)
+    assert mgr.scrub_worker_status()["state"] == bn.SCRUB_FINISHED
+    mgr.scrub_worker_command(bn.SCRUB_START)
+    _wait(lambda: mgr.scrub_worker_status()["state"] == bn.SCRUB_FINISHED and mgr.scrub_worker_status()["blocks_scrubbed"] == 45,
+          "every device's pass")
+    st = mgr.scrub_worker_status()
+    assert st["corruptions_detected"] == 0 and st["time_last_complete_scrub_ms"] > 0 and st["progress"] == 1.0
+    mgr.scrub_worker_stop()
+    assert sorted(os.listdir(tmp_path)) == ["scrub_info.dev0", "scrub_info.dev1", "scrub_info.dev2"]
