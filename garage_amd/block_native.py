@@ -34,7 +34,7 @@ SYMBOLS = [
     "gbm_create_multi", "gbm_device_count", "gbm_device_of_hash", "gbm_device_codec", "gbm_device_background_codec",
     "gbm_device_metrics", "gbm_batcher_device_stats", "gbm_get_verify_block_hash", "gbm_rpc_get_block_range_streaming",
     "gbm_scrub_worker_start", "gbm_scrub_worker_stop", "gbm_scrub_worker_command", "gbm_scrub_worker_status",
-    "gbm_block_metrics_get", "gbm_histogram_bounds", "gbm_metrics_prometheus",
+    "gbm_block_metrics_get", "gbm_histogram_bounds", "gbm_metrics_prometheus", "gbm_list_resync_errors", "gbm_resync_clear_backoff",
 ]
 
 
@@ -49,6 +49,12 @@ class ScrubStatus(ctypes.Structure):
                 ("corruptions_detected", ctypes.c_uint64), ("time_last_complete_scrub_ms", ctypes.c_uint64),
                 ("time_next_run_scrub_ms", ctypes.c_uint64), ("resume_at_ms", ctypes.c_uint64), ("blocks_scrubbed", ctypes.c_uint64),
                 ("checkpoints_saved", ctypes.c_uint64), ("errors", ctypes.c_uint64)]
+
+
+class ResyncErrorInfo(ctypes.Structure):
+    """BlockResyncErrorInfo (src/block/manager.rs:105-111)."""
+    _fields_ = [("hash", ctypes.c_uint8 * 32), ("refcount", ctypes.c_uint64), ("error_count", ctypes.c_uint64),
+                ("last_try_ms", ctypes.c_uint64), ("next_try_ms", ctypes.c_uint64)]
 
 
 HISTOGRAM_BUCKETS = 33
@@ -172,6 +178,8 @@ def _load():
     lib.gbm_scrub_worker_stop.argtypes = [vp]
     lib.gbm_scrub_worker_command.argtypes = [vp, ci, ctypes.c_uint64]
     lib.gbm_scrub_worker_status.argtypes = [vp, ctypes.POINTER(ScrubStatus)]
+    lib.gbm_list_resync_errors.argtypes = [vp, ctypes.POINTER(ResyncErrorInfo), sz, ctypes.POINTER(sz)]
+    lib.gbm_resync_clear_backoff.argtypes = [vp, ctypes.c_char_p]
     lib.gbm_block_metrics_get.argtypes = [vp, vp, ctypes.POINTER(BlockMetrics)]
     lib.gbm_histogram_bounds.argtypes = []
     lib.gbm_histogram_bounds.restype = ctypes.POINTER(ctypes.c_double)
@@ -414,6 +422,19 @@ class NativeBlockManager:
         d = dict(zip(self.RESYNC_STATS, [int(x) for x in st]))
         d["rc"] = rc
         return d
+
+    def list_resync_errors(self) -> list[dict]:
+        """BlockManager::list_resync_errors (`garage block list-errors`)."""
+        n = ctypes.c_size_t()
+        _check(lib.gbm_list_resync_errors(self._h, None, 0, ctypes.byref(n)), "list_resync_errors")
+        arr = (ResyncErrorInfo * max(1, n.value))()
+        _check(lib.gbm_list_resync_errors(self._h, arr, n.value, ctypes.byref(n)), "list_resync_errors")
+        return [{"hash": bytes(e.hash), "refcount": int(e.refcount), "error_count": int(e.error_count), "last_try_ms": int(e.last_try_ms),
+                 "next_try_ms": int(e.next_try_ms)} for e in arr[:min(n.value, len(arr))]]
+
+    def resync_clear_backoff(self, hash_: bytes) -> None:
+        """BlockResyncManager::clear_backoff (`garage block retry-now`)."""
+        _check(lib.gbm_resync_clear_backoff(self._h, hash_), "resync_clear_backoff")
 
     def put_to_resync(self, hash_: bytes, delay_ms: int = 0) -> None:
         _check(lib.gbm_put_to_resync(self._h, hash_, delay_ms), "put_to_resync")

@@ -553,6 +553,64 @@ size_t gbm_resync_errors_len(const gbm_manager *m)
 	return total + m->rs_errors.size();
 }
 
+int gbm_list_resync_errors(gbm_manager *m, gbm_resync_error_info *out, size_t cap, size_t *n_out)
+{
+	if (!m || !n_out || (cap && !out))
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	try {
+		std::vector<gbm_resync_error_info> all;
+		auto one = [&](gbm_manager *x) {
+			const uint64_t base = x->retry_delay_ms.load();
+			const size_t first = all.size();
+			{
+				std::lock_guard<std::mutex> g(x->rs_mu);
+				for (auto &kv : x->rs_errors) {
+					gbm_resync_error_info e{};
+					std::memcpy(e.hash, kv.first.data(), 32);
+					e.error_count = kv.second.errors;
+					e.last_try_ms = kv.second.last_try;
+					e.next_try_ms = kv.second.next_try(base);
+					all.push_back(e);
+				}
+			}
+			for (size_t i = first; i < all.size(); ++i) {  // (outside the queue's lock, as the reference's second loop)
+				const RcEntry rc = x->get_rc(Hash((const char *)all[i].hash, 32));
+				all[i].refcount = rc.kind == RcEntry::Present ? rc.v : 0;  // RcEntry::as_u64 (rc.rs:234-240)
+			}
+		};
+		one(m);
+		for (auto &l : m->lanes)
+			one(l.get());
+		std::sort(all.begin(), all.end(),
+			  [](const gbm_resync_error_info &a, const gbm_resync_error_info &b) { return std::memcmp(a.hash, b.hash, 32) < 0; });
+		*n_out = all.size();
+		std::copy(all.begin(), all.begin() + (ptrdiff_t)std::min(cap, all.size()), out);
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("gbm_list_resync_errors: ") + e.what());
+	}
+	return GBM_OK;
+}
+
+int gbm_resync_clear_backoff(gbm_manager *m, const uint8_t hash[32])
+{
+	if (!m || !hash)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	m = m->route(hash);
+	const Hash h((const char *)hash, 32);
+	const uint64_t now = m->now(), base = m->retry_delay_ms.load();
+	{
+		std::lock_guard<std::mutex> g(m->rs_mu);
+		auto it = m->rs_errors.find(h);
+		if (it == m->rs_errors.end() || it->second.errors == 0)
+			return fail(GBM_E_INVALID_ARG, "Block " + hex(h) + " was not in an errored state");
+		const uint64_t d = it->second.delay_ms(base);
+		it->second.last_try = now > d ? now - d : 0;
+		m->rs_queue.insert({now, h});
+	}
+	m->rs_cv.notify_all();
+	return GBM_OK;
+}
+
 int gbm_resync_worker_start(gbm_manager *m)
 {
 	if (!m)

@@ -332,6 +332,17 @@ int gbm_resync_block(gbm_manager *m, const uint8_t hash[32], int *changed);
 int gbm_resync_all(gbm_manager *m, int *changed);
 size_t gbm_resync_queue_len(const gbm_manager *m);   /* all entries, due or not */
 size_t gbm_resync_errors_len(const gbm_manager *m);  /* blocks in error back-off */
+/* BlockManager::list_resync_errors (src/block/manager.rs:429-449; `garage block list-errors`): the blocks whose last
+ * resync failed, with their refcount, error count, last and next try.  Up to cap entries are written, *n_out is the
+ * number there are.  gbm_resync_clear_backoff = BlockResyncManager::clear_backoff (resync.rs:119-134; `garage block
+ * retry-now`): the block's back-off is taken as served and it is queued for now; a block that is not in an errored state
+ * is refused with the reference's message. */
+typedef struct {
+	uint8_t hash[32];
+	uint64_t refcount, error_count, last_try_ms, next_try_ms;
+} gbm_resync_error_info;
+int gbm_list_resync_errors(gbm_manager *m, gbm_resync_error_info *out, size_t cap, size_t *n_out);
+int gbm_resync_clear_backoff(gbm_manager *m, const uint8_t hash[32]);
 /* Background worker (ResyncWorker, src/block/resync.rs:523-602): wakes when an entry becomes due. */
 int gbm_resync_worker_start(gbm_manager *m);
 int gbm_resync_worker_stop(gbm_manager *m);

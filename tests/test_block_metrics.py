@@ -122,6 +122,20 @@ def test_every_reference_instrument_moves_with_the_path(backend):
     m6 = mgr.block_metrics(bt)
     assert m6["resync_error_counter"] == m5["resync_error_counter"] + 1 and m6["resync_errored_blocks"] == 1
 
+    # `garage block list-errors` / `garage block retry-now` (manager.rs:429-449, resync.rs:119-134)
+    errs = mgr.list_resync_errors()
+    assert [e["hash"] for e in errs] == [hashes[2]] and errs[0]["error_count"] == 1 and errs[0]["refcount"] == 1
+    assert errs[0]["next_try_ms"] == errs[0]["last_try_ms"] + 60_000                   # RESYNC_RETRY_DELAY << (errors - 1)
+    assert mgr.resync_run(check=False)["skipped"] >= 0 and mgr.block_metrics(bt)["resync_counter"] == m6["resync_counter"]   # inside its back-off
+    with pytest.raises(bn.BlockError, match=f"Block {hashes[3].hex()} was not in an errored state"):
+        mgr.resync_clear_backoff(hashes[3])
+    mgr.resync_clear_backoff(hashes[2])                                                # tried again at once ...
+    st = mgr.resync_run(check=False)
+    assert st["taken"] == 1 and st["errors"] == 1                                      # ... and it fails again: the back-off doubles
+    errs = mgr.list_resync_errors()
+    assert errs[0]["error_count"] == 2 and errs[0]["next_try_ms"] == errs[0]["last_try_ms"] + 120_000
+    m6 = mgr.block_metrics(bt)
+
     # ---- the same as Prometheus text
     text = mgr.metrics_prometheus(bt)
     samples, types = _parse(text)
