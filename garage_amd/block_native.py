@@ -35,6 +35,7 @@ SYMBOLS = [
     "gbm_device_metrics", "gbm_batcher_device_stats", "gbm_get_verify_block_hash", "gbm_rpc_get_block_range_streaming",
     "gbm_scrub_worker_start", "gbm_scrub_worker_stop", "gbm_scrub_worker_command", "gbm_scrub_worker_status",
     "gbm_block_metrics_get", "gbm_histogram_bounds", "gbm_metrics_prometheus", "gbm_list_resync_errors", "gbm_resync_clear_backoff",
+    "gbm_zstd_encode", "gbm_zstd_decode",
 ]
 
 
@@ -178,6 +179,8 @@ def _load():
     lib.gbm_scrub_worker_stop.argtypes = [vp]
     lib.gbm_scrub_worker_command.argtypes = [vp, ci, ctypes.c_uint64]
     lib.gbm_scrub_worker_status.argtypes = [vp, ctypes.POINTER(ScrubStatus)]
+    lib.gbm_zstd_encode.argtypes = [ctypes.c_char_p, sz, ci, ctypes.c_char_p, sz, ctypes.POINTER(sz)]
+    lib.gbm_zstd_decode.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p, sz, ctypes.POINTER(sz)]
     lib.gbm_list_resync_errors.argtypes = [vp, ctypes.POINTER(ResyncErrorInfo), sz, ctypes.POINTER(sz)]
     lib.gbm_resync_clear_backoff.argtypes = [vp, ctypes.c_char_p]
     lib.gbm_block_metrics_get.argtypes = [vp, vp, ctypes.POINTER(BlockMetrics)]
@@ -244,6 +247,21 @@ def blake2sum_batch(blocks) -> list:
     out = ctypes.create_string_buffer(32 * n)
     _check(lib.gbm_blake2sum_batch(n, ptrs, lens, out), "gbm_blake2sum_batch")
     return [out.raw[32 * i:32 * i + 32] for i in range(n)]
+
+
+def zstd_encode(data: bytes, level: int = 1) -> bytes:
+    """garage_block::zstd_encode (src/block/block.rs:99-106): one frame with its content checksum."""
+    n = ctypes.c_size_t()
+    buf = ctypes.create_string_buffer(len(data) + len(data) // 128 + 1024)
+    _check(lib.gbm_zstd_encode(data, len(data), level, buf, len(buf), ctypes.byref(n)), "gbm_zstd_encode")
+    return buf.raw[:n.value]
+
+
+def zstd_decode(frame: bytes, max_len: int = 1 << 26) -> bytes:
+    n = ctypes.c_size_t()
+    buf = ctypes.create_string_buffer(max(1, max_len))
+    _check(lib.gbm_zstd_decode(frame, len(frame), buf, max_len, ctypes.byref(n)), "gbm_zstd_decode")
+    return buf.raw[:n.value]
 
 
 def shardsum(data: bytes) -> bytes:

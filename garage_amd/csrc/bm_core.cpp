@@ -887,6 +887,50 @@ void put_hist(std::string &s, const char *name, const char *help, const gbm_hist
 
 extern "C" {
 
+int gbm_zstd_encode(const uint8_t *data, size_t len, int level, uint8_t *out, size_t cap, size_t *len_out)
+{
+	if ((!data && len) || (!out && cap) || !len_out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	try {
+		static const uint8_t kEmpty = 0;
+		std::vector<uint8_t> frame;
+		if (!zstd().encode(data ? data : &kEmpty, len, level, frame))
+			return fail(GBM_E_IO, zstd().ok ? "zstd encoder error" : "libzstd.so.1 is not available");
+		*len_out = frame.size();
+		if (frame.size() > cap)
+			return fail(GBM_E_BUFFER_TOO_SMALL, "the frame does not fit the buffer");
+		std::memcpy(out, frame.data(), frame.size());
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("gbm_zstd_encode: ") + e.what());
+	}
+	return GBM_OK;
+}
+
+int gbm_zstd_decode(const uint8_t *frame, size_t len, uint8_t *out, size_t cap, size_t *len_out)
+{
+	if (!frame || (!out && cap) || !len_out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	try {
+		if (!zstd().ok)
+			return fail(GBM_E_IO, "libzstd.so.1 is not available");
+		std::vector<uint8_t> plain;
+		if (!zstd().decode(frame, len, cap, plain)) {
+			// larger than the caller's buffer, or not a frame that decodes cleanly (block.rs:78-83)
+			if (cap < kMaxDecompressed && zstd().decode(frame, len, kMaxDecompressed, plain)) {
+				*len_out = plain.size();
+				return fail(GBM_E_BUFFER_TOO_SMALL, "the decoded bytes do not fit the buffer");
+			}
+			return fail(GBM_E_CORRUPT_DATA, "zstd frame does not decode (content checksum or framing)");
+		}
+		*len_out = plain.size();
+		if (!plain.empty())
+			std::memcpy(out, plain.data(), plain.size());
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("gbm_zstd_decode: ") + e.what());
+	}
+	return GBM_OK;
+}
+
 const double *gbm_histogram_bounds(void) { return gbmimpl::Histogram::bounds(); }
 
 int gbm_block_metrics_get(const gbm_manager *m, gbm_batcher *b, gbm_block_metrics *out)

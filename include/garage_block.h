@@ -98,6 +98,15 @@ void gbm_shardsum(const uint8_t *data, size_t len, uint8_t out[32]);
  * written) or GBM_E_IO (out of memory). */
 int gbm_blake2sum_batch(size_t n, const uint8_t *const *data, const size_t *len, uint8_t *out);
 
+/* garage_block::zstd_encode (src/block/block.rs:99-106, re-exported at src/block/lib.rs:13): one zstd frame WITH its
+ * content checksum at `level`, what DataBlock::from_buffer stores and what the SSE-C path compresses with before it
+ * encrypts (EncryptionParams::encrypt_block, src/api/s3/encryption.rs:303-316).  *len_out = the frame's length;
+ * GBM_E_BUFFER_TOO_SMALL when it exceeds cap (nothing useful is in out), GBM_E_IO when the encoder fails or libzstd is
+ * not there.  gbm_zstd_decode is the bounded inverse (the frame checksum is verified: GBM_E_CORRUPT_DATA; at most cap
+ * bytes are produced: GBM_E_BUFFER_TOO_SMALL with *len_out = the frame's declared size when it says one). */
+int gbm_zstd_encode(const uint8_t *data, size_t len, int level, uint8_t *out, size_t cap, size_t *len_out);
+int gbm_zstd_decode(const uint8_t *frame, size_t len, uint8_t *out, size_t cap, size_t *len_out);
+
 /* node_dirs == NULL: in-memory nodes; otherwise nnodes directory roots using
  * Garage's naming <root>/<h0>/<h1>/<hex>.s<idx> (src/block/layout.rs:286-291).
  * write_quorum <= 0: k + ceil(m/2).  nnodes must be >= k+m

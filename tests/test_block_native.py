@@ -828,3 +828,37 @@ def test_range_get_of_a_compressed_block_goes_through_the_decoder(backend):
     cb = bn.CHUNK_FN(sink)
     rc = bn.lib.gbm_rpc_get_block_range_streaming(mgr._h, h, None, len(data), 10, 500_000, 4096, cb, None)
     assert rc == bn.GBM_E_ABORTED and seen == [4086]     # the first chunk of the stream, cut to the range
+
+
+def test_zstd_encode_is_the_reexport_the_ssec_path_uses():
+    """garage_block::zstd_encode (src/block/block.rs:99-106, re-exported at lib.rs:13): EncryptionParams::encrypt_block
+    compresses with it before it encrypts and stores the result with prevent_compression (encryption.rs:303-316).  One frame,
+    content checksum on: the stored form of a Compressed DataBlock is byte for byte what this returns."""
+    data = pattern_block(700_000, 5)
+    frame = bn.zstd_encode(data, 3)
+    assert frame[:4] == b"\x28\xb5\x2f\xfd" and frame[4] & 0x04, "zstd magic + the content-checksum flag of the frame header"
+    assert len(frame) < len(data) // 4 and bn.zstd_decode(frame) == data
+    assert bn.zstd_encode(b"", 1)[:4] == b"\x28\xb5\x2f\xfd" and bn.zstd_decode(bn.zstd_encode(b"", 1)) == b""
+    # what DataBlock::from_buffer stores for this block at this level is the same frame
+    codec = g.ReedSolomon(3, 1, backend="cpu")
+    mgr = bn.NativeBlockManager(codec, 4, compression_level=3)
+    h = bn.blake2sum(data)
+    mgr.rpc_put_block(h, data)
+    hdr, raw = mgr.rpc_get_raw_block(h)
+    assert hdr.is_compressed() and raw == frame
+    # a flipped bit fails the frame checksum (DataBlock::verify, block.rs:78-83); a short buffer says how much is needed
+    for pos in (len(frame) - 1, 9):                   # the checksum itself; the first block's header
+        bad = bytearray(frame)
+        bad[pos] ^= 0x10
+        with pytest.raises(bn.CorruptData):
+            bn.zstd_decode(bytes(bad))
+    n = ctypes.c_size_t()
+    buf = ctypes.create_string_buffer(1000)
+    assert bn.lib.gbm_zstd_decode(frame, len(frame), buf, 1000, ctypes.byref(n)) == bn.GBM_E_BUFFER_TOO_SMALL and n.value == len(data)
+    assert bn.lib.gbm_zstd_encode(data, len(data), 3, buf, 1000, ctypes.byref(n)) == bn.GBM_E_BUFFER_TOO_SMALL and n.value == len(frame)
+    # the SSE-C shape: the caller's own (compressed, then encrypted) bytes go in with prevent_compression and come back untouched
+    blob = bytes(x ^ 0x5A for x in frame)
+    hb = bn.blake2sum(blob)
+    mgr.rpc_put_block(hb, blob, prevent_compression=True)
+    hdr, raw = mgr.rpc_get_raw_block(hb)
+    assert not hdr.is_compressed() and raw == blob
