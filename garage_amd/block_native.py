@@ -35,7 +35,8 @@ SYMBOLS = [
     "gbm_device_metrics", "gbm_batcher_device_stats", "gbm_get_verify_block_hash", "gbm_rpc_get_block_range_streaming",
     "gbm_scrub_worker_start", "gbm_scrub_worker_stop", "gbm_scrub_worker_command", "gbm_scrub_worker_status",
     "gbm_block_metrics_get", "gbm_histogram_bounds", "gbm_metrics_prometheus", "gbm_list_resync_errors", "gbm_resync_clear_backoff",
-    "gbm_zstd_encode", "gbm_zstd_decode",
+    "gbm_zstd_encode", "gbm_zstd_decode", "gbm_set_resync_workers", "gbm_get_resync_workers", "gbm_resync_config_persist",
+    "gbm_get_tranquility",
 ]
 
 
@@ -181,6 +182,10 @@ def _load():
     lib.gbm_scrub_worker_status.argtypes = [vp, ctypes.POINTER(ScrubStatus)]
     lib.gbm_zstd_encode.argtypes = [ctypes.c_char_p, sz, ci, ctypes.c_char_p, sz, ctypes.POINTER(sz)]
     lib.gbm_zstd_decode.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p, sz, ctypes.POINTER(sz)]
+    lib.gbm_get_tranquility.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
+    lib.gbm_set_resync_workers.argtypes = [vp, ci]
+    lib.gbm_get_resync_workers.argtypes = [vp]
+    lib.gbm_resync_config_persist.argtypes = [vp, ctypes.c_char_p]
     lib.gbm_list_resync_errors.argtypes = [vp, ctypes.POINTER(ResyncErrorInfo), sz, ctypes.POINTER(sz)]
     lib.gbm_resync_clear_backoff.argtypes = [vp, ctypes.c_char_p]
     lib.gbm_block_metrics_get.argtypes = [vp, vp, ctypes.POINTER(BlockMetrics)]
@@ -440,6 +445,29 @@ class NativeBlockManager:
         d = dict(zip(self.RESYNC_STATS, [int(x) for x in st]))
         d["rc"] = rc
         return d
+
+    def get_tranquility(self) -> tuple[int, int]:
+        out = (ctypes.c_uint32 * 2)()
+        _check(lib.gbm_get_tranquility(self._h, out), "get_tranquility")
+        return int(out[0]), int(out[1])
+
+    def resync_worker_start(self) -> None:
+        _check(lib.gbm_resync_worker_start(self._h), "resync_worker_start")
+
+    def resync_worker_stop(self) -> None:
+        _check(lib.gbm_resync_worker_stop(self._h), "resync_worker_stop")
+
+    def set_resync_workers(self, n: int) -> None:
+        """`resync-worker-count` (src/block/resync.rs:136-152): 1..MAX_RESYNC_WORKERS."""
+        _check(lib.gbm_set_resync_workers(self._h, n), "set_resync_workers")
+
+    @property
+    def resync_workers(self) -> int:
+        return int(lib.gbm_get_resync_workers(self._h))
+
+    def resync_config_persist(self, path: str) -> None:
+        """ResyncPersistedConfig (resync.rs:58-71): worker count + tranquility, loaded from / saved to `path`."""
+        _check(lib.gbm_resync_config_persist(self._h, path.encode()), "resync_config_persist")
 
     def list_resync_errors(self) -> list[dict]:
         """BlockManager::list_resync_errors (`garage block list-errors`)."""

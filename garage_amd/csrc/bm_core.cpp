@@ -568,9 +568,21 @@ int gbm_set_tranquility(gbm_manager *m, int scrub_tranquility, int resync_tranqu
 			x->scrub_tranquility_set = true;
 			scrub_worker_tranquility_changed(x);
 		}
-		if (resync_tranquility >= 0)
+		if (resync_tranquility >= 0) {
 			x->resync_tranquility = (uint32_t)resync_tranquility;
+			x->resync_tranquility_set = true;
+			resync_config_changed(x);
+		}
 	});
+	return GBM_OK;
+}
+
+int gbm_get_tranquility(const gbm_manager *m, uint32_t out[2])
+{
+	if (!m || !out)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	out[0] = m->scrub_tranquility.load();
+	out[1] = m->resync_tranquility.load();
 	return GBM_OK;
 }
 

@@ -29,6 +29,7 @@
 #include <thread>
 #include <tuple>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -591,8 +592,14 @@ struct gbm_manager {
 	std::condition_variable rs_cv;
 	std::set<std::pair<uint64_t, Hash>> rs_queue;
 	std::unordered_map<Hash, ErrorCounter> rs_errors;
-	std::thread rs_worker;
+	// ResyncWorker x n_workers (resync.rs:513-602; `resync-worker-count`, 1..MAX_RESYNC_WORKERS, :136-152): each runs passes
+	// over what is due; a hash one pass has taken is in the busy set until that pass is over (BusySet, :74-85,339-352)
+	std::vector<std::thread> rs_workers;
 	bool rs_worker_stop = false;
+	int rs_n_workers = 1;
+	std::unordered_set<Hash> rs_busy;
+	std::string rs_cfg_path;  // ResyncPersistedConfig's file ("" = not persisted); gbm_resync_config_persist
+	std::atomic<bool> resync_tranquility_set{false};
 
 	std::atomic<uint64_t> gc_delay_ms{GBM_BLOCK_GC_DELAY_MS}, retry_delay_ms{GBM_RESYNC_RETRY_DELAY_MS},
 		incref_delay_ms{2 * 300000ull};  // 2 * rpc_timeout, DEFAULT_TIMEOUT = 300 s (rpc_helper.rs:33)
@@ -792,6 +799,8 @@ void list_all_nodes(gbm_manager *mg, std::set<Hash> &all);
 void batcher_snapshot(gbm_batcher *b, uint64_t out[5]);
 // gbm_set_tranquility changed the scrub's value: a running ScrubWorker persists it (repair.rs:26-27)
 void scrub_worker_tranquility_changed(gbm_manager *mg);
+// the resync workers' settings changed (gbm_set_tranquility, gbm_set_resync_workers): ResyncPersistedConfig is saved
+void resync_config_changed(gbm_manager *mg);
 // the clock moved (gbm_clock_advance): a pause may be over, the next run may be due
 void scrub_worker_wake(gbm_manager *mg);
 

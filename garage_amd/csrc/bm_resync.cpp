@@ -430,6 +430,10 @@ int gbm_resync_run(gbm_manager *mg, size_t max_blocks, uint64_t stats[8])
 			if (max_blocks && taken.size() >= max_blocks)
 				break;
 			const Hash &h = it->second;
+			if (mg->rs_busy.count(h)) {  // another worker's pass has this block in hand (get_block_to_resync, resync.rs:339-352)
+				++it;
+				continue;
+			}
 			auto ec = mg->rs_errors.find(h);
 			if (ec != mg->rs_errors.end() && now < ec->second.next_try(base)) {
 				// still inside the back-off: keep the entry, at the time it may be retried
@@ -442,6 +446,8 @@ int gbm_resync_run(gbm_manager *mg, size_t max_blocks, uint64_t stats[8])
 				taken.push_back(*it);
 			it = mg->rs_queue.erase(it);
 		}
+		for (auto &t : taken)
+			mg->rs_busy.insert(t.second);
 	}
 	st.taken = taken.size();
 	tasks.resize(taken.size());
@@ -475,7 +481,11 @@ int gbm_resync_run(gbm_manager *mg, size_t max_blocks, uint64_t stats[8])
 			ec.last_try = now + 1;
 			mg->rs_queue.insert({ec.next_try(base), t.h});
 		}
+		for (auto &t : taken)  // BusyBlock's drop (resync.rs:506-511)
+			mg->rs_busy.erase(t.second);
 	}
+	if (!taken.empty())
+		mg->rs_cv.notify_all();  // entries another worker had to pass over may be taken now
 	note_resync(mg, st);
 	if (stats) {
 		const uint64_t v[8] = {st.taken, st.ok, st.errors, st.skipped, st.rebuilt, st.deleted, st.offloaded, st.device_calls};
@@ -611,36 +621,47 @@ int gbm_resync_clear_backoff(gbm_manager *m, const uint8_t hash[32])
 	return GBM_OK;
 }
 
+static void resync_worker_loop(gbm_manager *m)
+{
+	std::unique_lock<std::mutex> lk(m->rs_mu);
+	while (!m->rs_worker_stop) {
+		const uint64_t now = m->now();
+		bool due = false;  // something is due that no other worker has in hand
+		for (auto it = m->rs_queue.begin(); it != m->rs_queue.end() && it->first <= now && !due; ++it)
+			due = !m->rs_busy.count(it->second);
+		if (due) {
+			lk.unlock();
+			(void)gbm_resync_run(m, 1024, nullptr);
+			lk.lock();
+			continue;
+		}
+		// idle until the first entry is due, something is queued, another worker's pass ends, or 10 s pass (resync.rs:325-336)
+		uint64_t wait_ms = 10000;
+		if (!m->rs_queue.empty() && m->rs_queue.begin()->first > now)
+			wait_ms = std::min<uint64_t>(wait_ms, m->rs_queue.begin()->first - now);
+		m->rs_cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(std::max<uint64_t>(wait_ms, 1)));
+	}
+}
+
 int gbm_resync_worker_start(gbm_manager *m)
 {
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
-	if (m->is_front()) {  // one ResyncWorker per device queue
+	if (m->is_front()) {  // ResyncWorkers per device queue
 		for (auto &l : m->lanes)
 			(void)gbm_resync_worker_start(l.get());
 		return GBM_OK;
 	}
-	std::lock_guard<std::mutex> g(m->rs_mu);
-	if (m->rs_worker.joinable())
-		return GBM_OK;
-	m->rs_worker_stop = false;
-	m->rs_worker = std::thread([m] {
-		std::unique_lock<std::mutex> lk(m->rs_mu);
-		while (!m->rs_worker_stop) {
-			const uint64_t now = m->now();
-			if (!m->rs_queue.empty() && m->rs_queue.begin()->first <= now) {
-				lk.unlock();
-				(void)gbm_resync_run(m, 1024, nullptr);
-				lk.lock();
-				continue;
-			}
-			// idle until the first entry is due, something is queued, or 10 s pass (resync.rs:325-336)
-			uint64_t wait_ms = 10000;
-			if (!m->rs_queue.empty())
-				wait_ms = std::min<uint64_t>(wait_ms, m->rs_queue.begin()->first - now);
-			m->rs_cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(std::max<uint64_t>(wait_ms, 1)));
-		}
-	});
+	try {
+		std::lock_guard<std::mutex> g(m->rs_mu);
+		if (!m->rs_workers.empty())
+			return GBM_OK;
+		m->rs_worker_stop = false;
+		for (int i = 0; i < m->rs_n_workers; ++i)
+			m->rs_workers.emplace_back([m] { resync_worker_loop(m); });
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("gbm_resync_worker_start: ") + e.what());
+	}
 	return GBM_OK;
 }
 
@@ -650,17 +671,117 @@ int gbm_resync_worker_stop(gbm_manager *m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
 	for (auto &l : m->lanes)
 		(void)gbm_resync_worker_stop(l.get());
-	std::thread t;
+	std::vector<std::thread> ts;
 	{
 		std::lock_guard<std::mutex> g(m->rs_mu);
-		if (!m->rs_worker.joinable())
+		if (m->rs_workers.empty())
 			return GBM_OK;
 		m->rs_worker_stop = true;
-		t = std::move(m->rs_worker);
+		ts.swap(m->rs_workers);
 	}
 	m->rs_cv.notify_all();
-	t.join();
+	for (auto &t : ts)
+		t.join();
+	return GBM_OK;
+}
+
+// ResyncPersistedConfig (resync.rs:58-71): this library's own 16-byte little-endian record, <path>.tmp + rename
+static void resync_config_save(gbm_manager *m)
+{
+	std::string path;
+	uint32_t n;
+	{
+		std::lock_guard<std::mutex> g(m->rs_mu);
+		path = m->rs_cfg_path;
+		n = (uint32_t)m->rs_n_workers;
+	}
+	if (path.empty())
+		return;
+	const uint32_t tq = m->resync_tranquility.load();
+	uint8_t b[16] = {'G', 'B', 'M', 'r', 'c', 'f', 'g', '1'};
+	for (int i = 0; i < 4; ++i) {
+		b[8 + i] = (uint8_t)(n >> (8 * i));
+		b[12 + i] = (uint8_t)(tq >> (8 * i));
+	}
+	const std::string tmp = path + ".tmp";
+	bool ok = false;
+	if (FILE *f = std::fopen(tmp.c_str(), "wb")) {
+		ok = std::fwrite(b, 1, sizeof(b), f) == sizeof(b);
+		ok = (std::fclose(f) == 0) && ok;
+	}
+	if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) {
+		std::remove(tmp.c_str());
+		std::fprintf(stderr, "garage_block: could not save the resync configuration to %s\n", path.c_str());
+	}
+}
+
+int gbm_set_resync_workers(gbm_manager *m, int n_workers)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	if (n_workers < 1 || n_workers > GBM_MAX_RESYNC_WORKERS)
+		return fail(GBM_E_INVALID_ARG, "Invalid number of resync workers, must be between 1 and " + std::to_string(GBM_MAX_RESYNC_WORKERS));
+	auto one = [&](gbm_manager *x) {
+		bool running;
+		{
+			std::lock_guard<std::mutex> g(x->rs_mu);
+			running = !x->rs_workers.empty();
+			if (x->rs_n_workers == n_workers)
+				return;
+			x->rs_n_workers = n_workers;
+		}
+		if (running && !x->is_front()) {
+			(void)gbm_resync_worker_stop(x);
+			(void)gbm_resync_worker_start(x);
+		}
+	};
+	one(m);
+	for (auto &l : m->lanes)
+		one(l.get());
+	resync_config_save(m);
+	return GBM_OK;
+}
+
+int gbm_get_resync_workers(const gbm_manager *m)
+{
+	if (!m)
+		return 0;
+	std::lock_guard<std::mutex> g(m->rs_mu);
+	return m->rs_n_workers;
+}
+
+int gbm_resync_config_persist(gbm_manager *m, const char *path)
+{
+	if (!m || !path || !*path)
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	uint8_t b[17];
+	size_t n = 0;
+	if (FILE *f = std::fopen(path, "rb")) {
+		n = std::fread(b, 1, sizeof(b), f);
+		std::fclose(f);
+	}
+	{
+		std::lock_guard<std::mutex> g(m->rs_mu);
+		m->rs_cfg_path = path;
+	}
+	auto u32 = [&](int off) { return (uint32_t)b[off] | (uint32_t)b[off + 1] << 8 | (uint32_t)b[off + 2] << 16 | (uint32_t)b[off + 3] << 24; };
+	if (n == 16 && std::memcmp(b, "GBMrcfg1", 8) == 0 && u32(8) >= 1 && u32(8) <= GBM_MAX_RESYNC_WORKERS) {
+		// the persisted values win (PersisterShared::new, persister.rs:97-101)
+		const int rc = gbm_set_tranquility(m, -1, (int)std::min<uint32_t>(u32(12), 0x7fffffff));
+		if (rc)
+			return rc;
+		return gbm_set_resync_workers(m, (int)u32(8));
+	}
+	// no record (or one that does not decode): ResyncPersistedConfig::default, unless the caller has chosen already
+	if (!m->resync_tranquility_set.load())
+		(void)gbm_set_tranquility(m, -1, GBM_INITIAL_RESYNC_TRANQUILITY);
+	resync_config_save(m);
 	return GBM_OK;
 }
 
 }  // extern "C"
+
+void gbmimpl::resync_config_changed(gbm_manager *mg)
+{
+	resync_config_save(mg);
+}

@@ -177,6 +177,7 @@ int gbm_set_host_block_hash_max(gbm_manager *m, size_t nblocks);
  * no pause; a negative argument keeps the current value.  On top of that, maintenance always runs on a
  * BACKGROUND-class codec whose device work yields to the request path's (include/garage_ec.h). */
 int gbm_set_tranquility(gbm_manager *m, int scrub_tranquility, int resync_tranquility);
+int gbm_get_tranquility(const gbm_manager *m, uint32_t out[2]); /* out[0] = scrub, out[1] = resync */
 uint64_t gbm_tranquilized_ms(const gbm_manager *m);   /* total time slept by the tranquilizer */
 /* The codec maintenance runs on (the manager's own BACKGROUND-class sibling of the codec it was given, or that
  * codec itself when no sibling could be created).  Borrowed. */
@@ -352,9 +353,22 @@ typedef struct {
 } gbm_resync_error_info;
 int gbm_list_resync_errors(gbm_manager *m, gbm_resync_error_info *out, size_t cap, size_t *n_out);
 int gbm_resync_clear_backoff(gbm_manager *m, const uint8_t hash[32]);
-/* Background worker (ResyncWorker, src/block/resync.rs:523-602): wakes when an entry becomes due. */
+/* Background workers (ResyncWorker, src/block/resync.rs:513-602): they wake when an entry becomes due and run passes
+ * (gbm_resync_run) over what is due.  gbm_set_resync_workers is the `resync-worker-count` variable (:136-152): 1 (the
+ * default) .. GBM_MAX_RESYNC_WORKERS workers per device queue; a hash one worker's pass has taken is not taken by
+ * another until that pass is over (the reference's busy set, :74-85,339-352), so several workers overlap one pass's
+ * gather with another's device trip.  The count applies to workers that are running (they are restarted) and to later
+ * starts.  gbm_resync_config_persist is ResyncPersistedConfig (:58-71, file `resync_cfg`): the worker count and the
+ * resync tranquility are loaded from `path` when it holds a record (otherwise the current values are written there --
+ * tranquility INITIAL_RESYNC_TRANQUILITY = 2 unless gbm_set_tranquility has set one), and every later change of either
+ * is saved; one file for all devices. */
+#define GBM_MAX_RESYNC_WORKERS 8         /* MAX_RESYNC_WORKERS, src/block/resync.rs:43 */
+#define GBM_INITIAL_RESYNC_TRANQUILITY 2 /* :46 */
 int gbm_resync_worker_start(gbm_manager *m);
 int gbm_resync_worker_stop(gbm_manager *m);
+int gbm_set_resync_workers(gbm_manager *m, int n_workers);
+int gbm_get_resync_workers(const gbm_manager *m);
+int gbm_resync_config_persist(gbm_manager *m, const char *path);
 
 /* Batch verify on the device: bad_out[i] = 1 if block i is inconsistent or
  * not fully readable. */

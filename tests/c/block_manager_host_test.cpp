@@ -845,7 +845,15 @@ static void run_scrub_worker(int k, int m, const char *dir_root)
 	CHECK(gbm_scrub_worker_start(mg, nullptr, 0, 0) == GBM_OK);  // a second start is a no-op
 	CHECK(gbm_scrub_worker_status(mg, &st) == GBM_OK && st.state == GBM_SCRUB_FINISHED && st.tranquility == GBM_INITIAL_SCRUB_TRANQUILITY);
 	CHECK(gbm_scrub_worker_command(mg, GBM_SCRUB_CMD_PAUSE, 10) == GBM_E_INVALID_ARG);
-	CHECK(gbm_set_tranquility(mg, 1, -1) == GBM_OK);
+	CHECK(gbm_set_tranquility(mg, 1, 0) == GBM_OK);
+	// three ResyncWorkers over the one queue (resync-worker-count), re-counted while they run
+	CHECK(gbm_set_resync_workers(mg, 0) == GBM_E_INVALID_ARG && gbm_set_resync_workers(mg, 9) == GBM_E_INVALID_ARG);
+	CHECK(gbm_set_resync_workers(mg, 3) == GBM_OK && gbm_get_resync_workers(mg) == 3);
+	if (dir_root)
+		CHECK(gbm_resync_config_persist(mg, (std::string(dir_root) + "/resync_cfg").c_str()) == GBM_OK);
+	CHECK(gbm_resync_worker_start(mg) == GBM_OK);
+	for (int i = 0; i < NB; ++i)
+		CHECK(gbm_put_to_resync(mg, hashes.data() + 32 * i, 0) == GBM_OK);
 	std::atomic<bool> done{false};
 	std::thread traffic([&] {
 		std::vector<uint8_t> out(200000);
@@ -866,6 +874,10 @@ static void run_scrub_worker(int k, int m, const char *dir_root)
 				CHECK(gbm_set_tranquility(mg, r % 3, -1) == GBM_OK);
 			if (r % 11 == 0)
 				CHECK(gbm_clock_advance(mg, 5) == GBM_OK);
+			if (r % 13 == 0) {
+				CHECK(gbm_set_resync_workers(mg, 1 + (r + salt) % 4) == GBM_OK);
+				CHECK(gbm_put_to_resync(mg, hashes.data() + 32 * (r % NB), 0) == GBM_OK);
+			}
 			std::this_thread::sleep_for(std::chrono::milliseconds(2));
 		}
 	};

@@ -192,3 +192,55 @@ def test_one_worker_per_device_of_a_multi_device_manager(tmp_path):
     assert st["corruptions_detected"] == 0 and st["time_last_complete_scrub_ms"] > 0 and st["progress"] == 1.0
     mgr.scrub_worker_stop()
     assert sorted(os.listdir(tmp_path)) == ["scrub_info.dev0", "scrub_info.dev1", "scrub_info.dev2"]
+
+
+# ------------------------------------------------------------------ the resync workers' variables (resync.rs:58-71,136-166)
+def test_resync_worker_count_and_persisted_config(tmp_path):
+    """`resync-worker-count` (1..MAX_RESYNC_WORKERS) and `resync-tranquility`, kept in `resync_cfg` over restarts
+    (ResyncPersistedConfig); several workers share one queue without ever holding the same block (the busy set)."""
+    cfg = str(tmp_path / "resync_cfg")
+    codec = g.ReedSolomon(10, 4, backend="cpu")
+    mgr = bn.NativeBlockManager(codec, 16)
+    assert mgr.resync_workers == 1
+    for n in (0, 9, -3):
+        with pytest.raises(bn.BlockError, match="Invalid number of resync workers, must be between 1 and 8"):
+            mgr.set_resync_workers(n)
+    mgr.resync_config_persist(cfg)                       # no record yet: ResyncPersistedConfig::default is written
+    assert mgr.get_tranquility()[1] == 2 and mgr.resync_workers == 1 and os.path.getsize(cfg) == 16
+    mgr.set_resync_workers(4)
+    mgr.set_tranquility(resync=5)
+    mgr2 = bn.NativeBlockManager(codec, 16)
+    mgr2.set_tranquility(resync=9)
+    mgr2.resync_config_persist(cfg)                      # the persisted values win
+    assert mgr2.resync_workers == 4 and mgr2.get_tranquility()[1] == 5
+    mgr2.set_tranquility(resync=0)
+    mgr3 = bn.NativeBlockManager(codec, 16)
+    mgr3.resync_config_persist(cfg)
+    assert mgr3.resync_workers == 4 and mgr3.get_tranquility()[1] == 0
+    with open(cfg, "wb") as f:
+        f.write(b"garbage")
+    mgr4 = bn.NativeBlockManager(codec, 16)
+    mgr4.resync_config_persist(cfg)                      # does not decode: defaults, and the file is made good again
+    assert mgr4.resync_workers == 1 and mgr4.get_tranquility()[1] == 2 and os.path.getsize(cfg) == 16
+
+    # four workers over one queue: 120 blocks each lost a shard on one node and one on another; every block is
+    # resynced exactly once, everything is back, the workers can be re-counted while they run
+    hashes, blocks = _store(mgr, 120, size=20_000, salt=300)
+    for h in hashes:
+        who = mgr.storage_nodes_of(h)
+        mgr.node_delete_shard(who[2], h, 2)
+        mgr.node_delete_shard(who[11], h, 11)
+    before = mgr.block_metrics()
+    mgr.set_tranquility(resync=0)
+    mgr.resync_worker_start()
+    for i, h in enumerate(hashes):
+        mgr.put_to_resync(h, 0)
+        if i == 60:
+            mgr.set_resync_workers(2)                    # restarts the running workers with the new count
+    _wait(lambda: mgr.block_metrics()["resync_recv_counter"] == before["resync_recv_counter"] + 240, "the workers to rebuild every shard")
+    assert mgr.resync_queue_len() == 120                 # what is left are block_incref's presence checks, 2 x rpc_timeout away
+    mgr.resync_worker_stop()
+    after = mgr.block_metrics()
+    assert after["resync_counter"] == before["resync_counter"] + 120 and after["resync_error_counter"] == before["resync_error_counter"]
+    assert mgr.scrub(hashes) == [] and mgr.rpc_get_blocks(hashes, 60_000) == blocks
+    assert mgr.resync_workers == 2
