@@ -445,6 +445,12 @@ struct Node {
 	// the same, restricted to the hashes whose first byte is h0: one first-level directory of the store, the unit the
 	// ScrubWorker's iterator walks and checkpoints by (BsiTodo::Directory, src/block/repair.rs:196-233,684-752)
 	virtual void list_prefix(int h0, std::set<Hash> &out) = 0;
+	// several consecutive first-level directories, lo <= h0 < hi (a sparse store is walked a few directories at a time)
+	virtual void list_prefix_range(int lo, int hi, std::set<Hash> &out)
+	{
+		for (int p = lo; p < hi; ++p)
+			list_prefix(p, out);
+	}
 
 	// the node's endpoint (StreamingEndpointHandler<BlockRpc>::handle, src/block/manager.rs:692-707);
 	// false = could not be contacted

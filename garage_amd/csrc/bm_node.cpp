@@ -135,13 +135,16 @@ struct MemoryNode : Node {
 				out.insert(kv.first.substr(0, 32));
 		}
 	}
-	void list_prefix(int h0, std::set<Hash> &out) override
+	void list_prefix(int h0, std::set<Hash> &out) override { list_prefix_range(h0, h0 + 1, out); }
+	void list_prefix_range(int lo, int hi, std::set<Hash> &out) override  // one scan whatever the width
 	{
 		for (Stripe &st : stripes) {
 			std::lock_guard<std::mutex> g(st.mu);
-			for (auto &kv : st.files)
-				if ((unsigned char)kv.first[0] == (unsigned)h0)
+			for (auto &kv : st.files) {
+				const int h0 = (unsigned char)kv.first[0];
+				if (h0 >= lo && h0 < hi)
 					out.insert(kv.first.substr(0, 32));
+			}
 		}
 	}
 };

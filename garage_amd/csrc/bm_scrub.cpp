@@ -211,11 +211,14 @@ struct ScrubWorker {
 	uint64_t generation = 0;  // moves with every command that drops the step in flight
 	uint64_t blocks = 0, cps = 0, errors = 0;
 
-	// the listing of one first-level directory over all nodes (the worker thread's own)
+	// the listing of a few consecutive first-level directories over all nodes (the worker thread's own)
 	struct Listing {
-		int prefix = -1;
+		int lo = -1, hi = -1;  // directories lo <= h0 < hi
 		std::vector<Hash> hashes;
+		bool holds(int prefix) const { return lo <= prefix && prefix < hi; }
+		void drop() { lo = hi = -1; }
 	} listing;
+	int width = 1;  // directories per listing: doubled while a listing holds less than a step, halved when it holds several
 
 	// randomize_next_scrub_run_time (:245-256): SCRUB_INTERVAL plus a random 0..10 days, "to balance scrub load across
 	// different cluster nodes"
@@ -303,37 +306,45 @@ struct ScrubWorker {
 	}
 
 	// ---- the iterator
-	void list_prefix(int prefix)
+	void list_from(int prefix)
 	{
+		const int lo = prefix, hi = std::min(256, prefix + width);
 		std::vector<std::set<Hash>> per(mg->nodes.size());
 		mg->pool->parallel_for(mg->nodes.size(), [&](size_t i) {
 			if (!mg->nodes[i]->down.load())
-				mg->nodes[i]->list_prefix(prefix, per[i]);
+				mg->nodes[i]->list_prefix_range(lo, hi, per[i]);
 		});
 		std::set<Hash> all;
 		for (auto &st : per)
 			for (const Hash &h : st)
 				if (mg->owns(h))
 					all.insert(h);
-		listing.prefix = prefix;
+		listing.lo = lo;
+		listing.hi = hi;
 		listing.hashes.assign(all.begin(), all.end());
+		if (listing.hashes.size() < batch_blocks)
+			width = std::min(256, width * 2);
+		else if (listing.hashes.size() > 4 * batch_blocks)
+			width = std::max(1, width / 2);
 	}
 	// the next (at most) n hashes behind c, and where the walk stands once they are done
 	std::vector<Hash> take(ScrubCursor &c, size_t n)
 	{
 		std::vector<Hash> out;
 		while (out.size() < n && c.prefix < 256) {
-			if (listing.prefix != c.prefix)
-				list_prefix(c.prefix);
+			if (!listing.holds(c.prefix))
+				list_from(c.prefix);
 			const auto &L = listing.hashes;
-			auto first = c.after.empty() ? L.begin() : std::upper_bound(L.begin(), L.end(), c.after);
+			// behind `after`, or at the first hash of directory `prefix` (a one-byte string sorts in front of them all)
+			auto first = c.after.empty() ? std::lower_bound(L.begin(), L.end(), Hash(1, (char)c.prefix)) : std::upper_bound(L.begin(), L.end(), c.after);
 			const size_t avail = (size_t)(L.end() - first), t = std::min(n - out.size(), avail);
 			out.insert(out.end(), first, first + (ptrdiff_t)t);
-			if (t == avail) {  // this directory is done
-				++c.prefix;
+			if (t == avail) {  // these directories are done
+				c.prefix = listing.hi;
 				c.after.clear();
 			} else {
 				c.after = out.back();
+				c.prefix = (unsigned char)c.after[0];
 			}
 		}
 		return out;
@@ -436,7 +447,7 @@ struct ScrubWorker {
 					ahead.valid = false;
 				} else {
 					drop_ahead();
-					listing.prefix = -1;  // the first step after a command or a restart: the directory is listed afresh
+					listing.drop();  // the first step after a command or a restart: the directories are listed afresh
 					cur = read_scrub_batch(mg, take(to, batch_blocks));
 				}
 				if (to.prefix < 256) {
@@ -462,7 +473,7 @@ struct ScrubWorker {
 				// Worker::work returned Err: the step is logged and tried again (util/background/worker.rs)
 				++errors;
 				std::fprintf(stderr, "garage_block: scrub worker: %s\n", gbm_last_error());
-				listing.prefix = -1;
+				listing.drop();
 				lk.unlock();
 				drop_ahead();
 				lk.lock();
@@ -471,7 +482,7 @@ struct ScrubWorker {
 				continue;
 			}
 			if (gen != generation) {  // a command came in meanwhile: this step is done again when (if) the pass goes on
-				listing.prefix = -1;
+				listing.drop();
 				continue;
 			}
 			it = to;

@@ -295,6 +295,24 @@ def maintenance_rates(nb: int = 512, root: str = "") -> dict:
             st = {}
             t_scrub, _ = _best(lambda: st.update(mgr.scrub_all(256)), 2)
             assert st["scrubbed"] == nb and st["corruptions"] == 0
+            # the same store through the ScrubWorker (directory-by-directory iterator, checkpoints, the worker thread): one pass
+            mgr.set_tranquility(scrub=0)
+            mgr.scrub_worker_start(None, 256)
+            t_worker = None
+            for _ in range(2):
+                last = mgr.scrub_worker_status()["time_last_complete_scrub_ms"]
+                t0 = time.perf_counter()
+                mgr.scrub_worker_command(bn.SCRUB_START)
+                while True:
+                    ws = mgr.scrub_worker_status()
+                    if ws["state"] == bn.SCRUB_FINISHED and ws["time_last_complete_scrub_ms"] > last:
+                        break
+                    time.sleep(0.0005)
+                dt = time.perf_counter() - t0
+                t_worker = dt if t_worker is None else min(t_worker, dt)
+                time.sleep(0.002)   # (time_last_complete is in milliseconds: the next pass must end in a later one)
+            assert ws["blocks_scrubbed"] == 2 * nb and ws["corruptions_detected"] == 0 and ws["errors"] == 0
+            mgr.scrub_worker_stop()
             # lose everything node 3 holds, queue every block, one resync pass rebuilds it
             lost = 0
             for h in hashes:
@@ -312,6 +330,7 @@ def maintenance_rates(nb: int = 512, root: str = "") -> dict:
                 **({"rpc_put_blocks_GiBps": round(gib / t_put, 2), "rpc_get_blocks_GiBps": round(gib / t_get, 2)}
                    if kind == "directories" else {}),   # memory nodes: block_manager_rates' numbers
                 "scrub_all_GiBps": round(gib / t_scrub, 2),
+                "scrub_worker_pass_GiBps": round(gib / t_worker, 2),
                 "resync_one_lost_node": {"blocks_queued": nb, "shards_rebuilt": lost, "seconds": round(t_resync, 4),
                                          "GiBps_of_blocks_repaired": round(lost * L / 2**30 / t_resync, 2),
                                          "device_calls": rs_.get("device_calls", rs_.get("batches"))},
