@@ -307,6 +307,8 @@ def maintenance_rates(nb: int = 512, root: str = "") -> dict:
                     ws = mgr.scrub_worker_status()
                     if ws["state"] == bn.SCRUB_FINISHED and ws["time_last_complete_scrub_ms"] > last:
                         break
+                    if time.perf_counter() - t0 > 60:
+                        raise TimeoutError(f"the ScrubWorker's pass did not complete: {ws}")
                     time.sleep(0.0005)
                 dt = time.perf_counter() - t0
                 t_worker = dt if t_worker is None else min(t_worker, dt)
