@@ -622,17 +622,39 @@ int gbm_repair_all(gbm_manager *mg, size_t *queued)
 		}
 		return rc;
 	}
-	std::set<Hash> all;
-	for (auto &st : mg->rc) {
-		std::lock_guard<std::mutex> g(st.mu);
-		for (auto &kv : st.map)
-			all.insert(kv.first);
+	// phase 1: every hash of the refcount table; phase 2: every hash a node stores ("blocks we are storing but don't
+	// actually need"), one first-level directory at a time -- the walk never holds more than a 256th of the store
+	size_t total = 0;
+	try {
+		std::set<Hash> known;
+		for (auto &st : mg->rc) {
+			std::lock_guard<std::mutex> g(st.mu);
+			for (auto &kv : st.map)
+				known.insert(kv.first);
+		}
+		for (const Hash &h : known)
+			mg->put_to_resync(h, 0);
+		total = known.size();
+		for (int p = 0; p < 256; ++p) {
+			std::vector<std::set<Hash>> per(mg->nodes.size());
+			mg->pool->parallel_for(mg->nodes.size(), [&](size_t i) {
+				if (!mg->nodes[i]->down.load())
+					mg->nodes[i]->list_prefix(p, per[i]);
+			});
+			std::set<Hash> stored;
+			for (auto &st : per)
+				for (const Hash &h : st)
+					if (mg->owns(h) && !known.count(h))
+						stored.insert(h);
+			for (const Hash &h : stored)
+				mg->put_to_resync(h, 0);
+			total += stored.size();
+		}
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("repair_all: ") + e.what());
 	}
-	list_all_nodes(mg, all);
-	for (const Hash &h : all)
-		mg->put_to_resync(h, 0);
 	if (queued)
-		*queued = all.size();
+		*queued = total;
 	return GBM_OK;
 }
 
