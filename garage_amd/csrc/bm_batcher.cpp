@@ -438,9 +438,15 @@ gbm_batcher *make_lane(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, 
 	b->max_wait_us = max_wait_us;
 	const int nworkers = env().batcher_workers;
 	for (int i = 0; i < nworkers; ++i)
-		b->workers.emplace_back([b] { b->run(); });
+		b->workers.emplace_back([b] {
+			name_thread("gbm-batch-put");
+			b->run();
+		});
 	for (int i = 0; i < nworkers; ++i)
-		b->gworkers.emplace_back([b] { b->run_gets(); });
+		b->gworkers.emplace_back([b] {
+			name_thread("gbm-batch-get");
+			b->run_gets();
+		});
 	return b;
 }
 

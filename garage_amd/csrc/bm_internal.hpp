@@ -12,6 +12,8 @@
 
 #include "../../include/garage_block.h"
 
+#include <pthread.h>
+
 #include <algorithm>
 #include <array>
 #include <atomic>
@@ -173,6 +175,16 @@ uint64_t real_now_ms();
 // ------------------------------------------------------------------ thread pool
 // fork-join: fn(i) for i in [0, n) on the workers and the calling thread.  Several callers may use it at
 // once (they queue on call_mu_); work items must not call parallel_for themselves.
+// Thread names (top -H, perf, tools/cpu_where.py): every thread the library starts says what it is.
+inline void name_thread(const char *name)
+{
+#ifdef __linux__
+	(void)pthread_setname_np(pthread_self(), name);  // <= 15 characters
+#else
+	(void)name;
+#endif
+}
+
 class Pool {
 public:
 	explicit Pool(unsigned n) { resize(n); }
@@ -183,7 +195,10 @@ public:
 		stop_all();
 		stop_ = false;
 		for (unsigned i = 0; i < n; ++i)
-			workers_.emplace_back([this] { run(); });
+			workers_.emplace_back([this] {
+				name_thread("gbm-pool");
+				run();
+			});
 	}
 	void parallel_for(size_t n, const std::function<void(size_t)> &fn)
 	{
@@ -275,7 +290,10 @@ public:
 	explicit Async(unsigned n)
 	{
 		for (unsigned i = 0; i < n; ++i)
-			workers_.emplace_back([this] { run(); });
+			workers_.emplace_back([this] {
+				name_thread("gbm-async");
+				run();
+			});
 	}
 	~Async()
 	{

@@ -658,7 +658,10 @@ int gbm_resync_worker_start(gbm_manager *m)
 			return GBM_OK;
 		m->rs_worker_stop = false;
 		for (int i = 0; i < m->rs_n_workers; ++i)
-			m->rs_workers.emplace_back([m] { resync_worker_loop(m); });
+			m->rs_workers.emplace_back([m] {
+				name_thread("gbm-resync");
+				resync_worker_loop(m);
+			});
 	} catch (const std::exception &e) {
 		return fail(GBM_E_IO, std::string("gbm_resync_worker_start: ") + e.what());
 	}

@@ -613,7 +613,10 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 		}
 	} joiner{helper};
 	if (overlap)
-		helper = std::thread(overlap);
+		helper = std::thread([&overlap] {
+			name_thread("gbm-get-helper");
+			overlap();
+		});
 	std::vector<uint8_t> todo(nb, 1);
 	for (int round = 0; round <= n; ++round) {
 		if (round == 1 && helper.joinable())
@@ -999,7 +1002,10 @@ int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const 
 		};
 		std::vector<std::thread> others;
 		for (int t = 1; t < kThreads; ++t)
-			others.emplace_back(run);
+			others.emplace_back([&run] {
+				name_thread("gbm-put-slice");
+				run();
+			});
 		run();
 		for (auto &t : others)
 			t.join();
@@ -1150,6 +1156,7 @@ struct TailHash {
 	void start()
 	{
 		th = std::thread([this] {
+			name_thread("gbm-tail-hash");
 			for (;;) {
 				std::pair<Bytes, std::pair<const uint8_t *, size_t>> seg;
 				{

@@ -3,6 +3,8 @@
 // argument checking -- and the dispatch to the codec's backend (ec_cpu.cpp / ec_hip_*.cpp).  No HIP in this file.
 #include "ec_internal.hpp"
 
+#include <pthread.h>
+
 #include <algorithm>
 #include <new>
 
@@ -35,7 +37,12 @@ int check_km(int k, int m)
 ForkJoinPool::ForkJoinPool(unsigned n)
 {
 	for (unsigned i = 0; i < n; ++i)
-		workers_.emplace_back([this] { run(); });
+		workers_.emplace_back([this] {
+#ifdef __linux__
+			(void)pthread_setname_np(pthread_self(), "gec-pool");  // top -H, perf, tools/cpu_where.py
+#endif
+			run();
+		});
 }
 
 ForkJoinPool::~ForkJoinPool()

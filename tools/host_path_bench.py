@@ -190,6 +190,53 @@ def block_manager_rates(nb: int = 512, threads: int = 48) -> dict:
     return res
 
 
+def host_cpu_cost(nb: int = 256) -> dict:
+    """What the offload is for: the host-core time a put and a get of the same blocks cost through the SAME manager code
+    on the HIP codec and on the product's CPU codec (GFNI / AVX-512 on these hosts), process-wide (every pool thread
+    counted: getrusage).  On the HIP codec the cores copy payload into pinned shard buffers, fan shards out and verify
+    nothing themselves; on the CPU codec they also encode, decode and hash."""
+    import resource
+
+    import garage_amd as g
+    from garage_amd import block_native as bn
+
+    rng = np.random.default_rng(11)
+    blocks = [rng.integers(0, 256, L, dtype=np.uint8).tobytes() for _ in range(nb)]
+    gib = nb * L / 2**30
+    out = {"what": "host core-seconds per GiB of payload (user + system, all threads) and GiB/s, RS(10,4), 1 MiB blocks, 16 memory nodes",
+           "nblocks": nb, "host_cores": os.cpu_count()}
+
+    def cpu_s():
+        r = resource.getrusage(resource.RUSAGE_SELF)
+        return r.ru_utime + r.ru_stime
+
+    for backend in ("hip", "cpu"):
+        try:
+            codec = g.ReedSolomon(K, M, backend=backend)
+            mgr = bn.NativeBlockManager(codec, 16)
+            hashes = [bn.blake2sum(b) for b in blocks]
+            items = list(zip(hashes, blocks))
+            outs = [np.empty(L, dtype=np.uint8) for _ in range(nb)]
+            for _ in range(3):
+                mgr.rpc_put_blocks(items)
+            mgr.rpc_get_blocks(hashes, L, out=outs)
+            reps = 4
+            c0, t0 = cpu_s(), time.perf_counter()
+            for _ in range(reps):
+                mgr.rpc_put_blocks(items)
+            c1, t1 = cpu_s(), time.perf_counter()
+            for _ in range(reps):
+                mgr.rpc_get_blocks(hashes, L, out=outs)
+            c2, t2 = cpu_s(), time.perf_counter()
+            assert outs[5].tobytes() == blocks[5]
+            out[backend] = {"put_core_s_per_GiB": round((c1 - c0) / (reps * gib), 4), "put_GiBps": round(reps * gib / (t1 - t0), 2),
+                            "get_core_s_per_GiB": round((c2 - c1) / (reps * gib), 4), "get_GiBps": round(reps * gib / (t2 - t1), 2)}
+            mgr.close()
+        except Exception as e:  # noqa: BLE001
+            out[backend] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
 def small_trip_rates() -> dict:
     """tools/small_trip_bench (native): one put / a PutObject's three through the batcher, one get per verify mode (healthy and
     degraded), streaming gets (first / last chunk), 48 readers through the batcher per mode."""
@@ -350,5 +397,7 @@ if __name__ == "__main__":
     nb = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     if len(sys.argv) > 2 and sys.argv[2] == "maintenance":
         print(json.dumps({"maintenance": maintenance_rates(nb)}))
+    elif len(sys.argv) > 2 and sys.argv[2] == "host_cpu":
+        print(json.dumps({"host_cpu": host_cpu_cost(nb)}))
     else:
         print(json.dumps({"pcie_inclusive": pcie_inclusive_rates(nb), "block_manager": block_manager_rates(nb)}))
