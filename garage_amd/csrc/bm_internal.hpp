@@ -439,6 +439,7 @@ struct ShardRpc {
 struct ShardResp {
 	bool ok = false;      // PutShard stored / GetShard found / DeleteShard had something to delete
 	bool needed = false;  // NeedShardReply
+	bool have_hd = false; // NeedShardReply of a shard that is there: shard.hd holds its header (no payload)
 	bool pending = false; // PutShard: parked beside a shard of another geometry, waiting for CommitShard
 	Shard shard;          // answer to GetShard
 };
@@ -453,6 +454,10 @@ struct Node {
 	virtual bool put(const Hash &h, int idx, const Shard &s, bool *pending = nullptr) = 0;
 	virtual bool get(const Hash &h, int idx, Shard &s) = 0;  // false: absent / unreadable
 	virtual bool has(const Hash &h, int idx) = 0;
+	// the header of the shard in place, without its payload (false: no such shard, or a header that does not parse): what
+	// the presence scan of a resync learns a shard's GEOMETRY from -- shards of a block are only usable together when they
+	// were cut from the same payload the same way
+	virtual bool header(const Hash &h, int idx, ShardHeader &hd) = 0;
 	virtual bool del(const Hash &h, int idx) = 0;
 	virtual bool commit(const Hash &h, int idx) = 0;  // a parked shard takes the place of the one in place
 	virtual bool abort(const Hash &h, int idx) = 0;   // a parked shard is dropped

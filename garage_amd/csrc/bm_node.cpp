@@ -28,7 +28,8 @@ bool Node::handle(const ShardRpc &rq, ShardResp &rs)
 		return true;
 	case RpcKind::NeedShardQuery:
 		rs.ok = true;
-		rs.needed = !has(*rq.hash, rq.idx);
+		rs.have_hd = header(*rq.hash, rq.idx, rs.shard.hd);
+		rs.needed = !rs.have_hd && !has(*rq.hash, rq.idx);  // (a shard whose header does not parse is there all the same)
 		return true;
 	case RpcKind::DeleteShard:
 		rs.ok = del(*rq.hash, rq.idx);
@@ -119,6 +120,16 @@ struct MemoryNode : Node {
 		Stripe &st = stripe_of(h);
 		std::lock_guard<std::mutex> g(st.mu);
 		return st.files.count(shard_key(h, idx)) != 0;
+	}
+	bool header(const Hash &h, int idx, ShardHeader &hd) override
+	{
+		Stripe &st = stripe_of(h);
+		std::lock_guard<std::mutex> g(st.mu);
+		auto it = st.files.find(shard_key(h, idx));
+		if (it == st.files.end())
+			return false;
+		hd = it->second.hd;
+		return true;
 	}
 	bool del(const Hash &h, int idx) override
 	{
@@ -288,6 +299,7 @@ struct DirNode : Node {
 		struct stat st;
 		return ::stat(path(h, idx).c_str(), &st) == 0;
 	}
+	bool header(const Hash &h, int idx, ShardHeader &hd) override { return header_in_place(path(h, idx), hd); }
 	bool del(const Hash &h, int idx) override
 	{
 		std::remove((path(h, idx) + ".parked").c_str());

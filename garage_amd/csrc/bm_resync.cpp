@@ -28,6 +28,14 @@ struct ResyncTask {
 	int changed = 0;
 	// rebuild
 	std::vector<int> want;             // absent on a reachable current node, not recoverable by offload
+	// the geometry of the shard each current node holds (NeedShardReply carries the header): shards of a block are only
+	// usable together when they were cut from the same payload the same way.  A node that was down while the block was
+	// put again with another compression setting still holds a shard of the OLD geometry: present, readable, useless --
+	// it is replaced like an absent one (PutShard parks the new shard beside it, CommitShard swaps them).
+	std::vector<ShardHeader> geo;
+	std::vector<uint8_t> have_geo;
+	bool mixed = false;                // the shards in place are not all of one geometry
+	std::vector<int> replace;          // of `want`: a shard of another geometry is in place
 	Gathered g;
 };
 
@@ -38,6 +46,9 @@ void scan_block(gbm_manager *mg, ResyncTask &t)
 	mg->nodes_of(t.h, vcur, t.who);
 	t.present_cur.assign(n, 0);
 	t.reachable.assign(n, 0);
+	t.geo.assign(n, ShardHeader());
+	t.have_geo.assign(n, 0);
+	int first = -1;
 	for (int j = 0; j < n; ++j) {
 		ShardRpc rq{RpcKind::NeedShardQuery, &t.h, j, Shard(), nullptr};
 		ShardResp rs;
@@ -45,6 +56,14 @@ void scan_block(gbm_manager *mg, ResyncTask &t)
 			t.reachable[j] = 1;
 			t.present_cur[j] = rs.needed ? 0 : 1;
 			t.exists = t.exists || !rs.needed;
+			if (rs.have_hd && rs.shard.hd.version == 2) {
+				t.geo[j] = rs.shard.hd;
+				t.have_geo[j] = 1;
+				if (first < 0)
+					first = j;
+				else if (!t.geo[j].same_geometry(t.geo[first]))
+					t.mixed = true;
+			}
 		}
 	}
 	std::vector<int> who;
@@ -154,7 +173,7 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 	st.offloaded += offloaded.load();
 	tr.lap("delete / offload");
 	for (size_t i = 0; i < tasks.size(); ++i)
-		if (!tasks[i].want.empty())
+		if (!tasks[i].want.empty() || (tasks[i].mixed && tasks[i].rc.is_needed(now)))
 			rebuild.push_back(i);
 	// "fetching absent but needed block" (resync.rs:485-499): gather exactly k shards per block, rebuild what is wanted,
 	// PutShard.  First pass: shards are accepted on their headers and ONE device trip per group both rebuilds and
@@ -190,11 +209,17 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 					if (mg->nodes[t.who[j]]->handle(rq, rs) && rs.needed)
 						t.want.push_back(j);
 				}
-			// shards of a minority geometry are stale: overwrite them
-			if (t.g.mixed)
-				for (int j = 0; j < n; ++j)
-					if (t.reachable[j] && t.g.shard[j].empty() && std::find(t.want.begin(), t.want.end(), j) == t.want.end())
+			// shards of another geometry than the one the block is read in (the gather's choice: the largest consistent
+			// group) are stale: they are replaced.  Where the scan could not read a header, the gather's own verdict decides.
+			if (t.mixed || t.g.mixed)
+				for (int j = 0; j < n; ++j) {
+					if (!t.reachable[j] || !t.g.shard[j].empty() || std::find(t.want.begin(), t.want.end(), j) != t.want.end())
+						continue;
+					if (t.have_geo[j] ? !t.geo[j].same_geometry(t.g.meta) : t.g.mixed) {
 						t.want.push_back(j);
+						t.replace.push_back(j);
+					}
+				}
 		}
 		// ONE device call per shard length: inside it gec_reconstruct_hash_batch buckets the blocks by (which shards
 		// are in hand, which are wanted) -- one decode plan and one kernel launch per such erasure pattern, the patterns'
@@ -283,8 +308,19 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 					return;
 				ResyncTask &t = tasks[ids[q]];
 				for (int j : t.want) {
+					bool pend = false;
 					if (send_shard(mg, t.who[j], t.h, j, outb[q][j], S, t.g.meta.orig_len, t.g.meta.compressed != 0,
-						       out_sums.data() + (q * n + j) * 32, nullptr)) {
+						       out_sums.data() + (q * n + j) * 32, nullptr, &pend)) {
+						if (pend) {
+							// a shard of another geometry was in place: the node parked the new one beside it; the block is
+							// being read in the new shard's geometry (>= k shards of it exist), so it takes the old one's place
+							ShardRpc cq{RpcKind::CommitShard, &t.h, j, Shard(), nullptr};
+							ShardResp cs;
+							if (!mg->nodes[t.who[j]]->handle(cq, cs) || !cs.ok) {
+								t.error = "CommitShard of a rebuilt shard failed";
+								continue;
+							}
+						}
 						++t.changed;
 						++rebuilt;
 					} else {

@@ -756,13 +756,61 @@ void assemble(const Gathered &g, int k, uint8_t *dst)
 	}
 }
 
+static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
+			   const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate);
+
 // raw == true: rpc_get_raw_block (stored bytes + header); false: rpc_get_block (plain bytes).
+// While a layout change is being followed (more than one version is active) resync MOVES shards: PutShard to the new owner,
+// then DeleteShard at the old one.  A read that asked the new owners before the puts and the old ones after the deletes
+// finds the block "missing" although it was whole the whole time -- the reference's readers have the same window
+// (block_read_nodes_of walks the versions in order, rpc_helper.rs:570-619) and leave it to the client's retry; with k
+// holders to hear from instead of one it is wider here, so a block that comes back Missing during a transition is asked
+// for ONCE more: moves only go forward, the second walk meets the shards where the first one's came from.
 int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
 		    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate)
 {
 	if (!mg || (nb && (!hashes || !out || !cap || !len_out || !rcs)))
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
 	DurationScope read_time(mg->bmx.read_duration);  // block.read_duration (metrics.rs:117-121): one observation per call
+	int rc = get_blocks_once(mg, nb, hashes, tags, out, cap, len_out, rcs, raw, headers, gate);
+	if (rc != GBM_OK || mg->layout_cur.load() == mg->layout_oldest.load())
+		return rc;
+	std::vector<size_t> again;
+	for (size_t b = 0; b < nb; ++b)
+		if (rcs[b] == GBM_E_MISSING_BLOCK)
+			again.push_back(b);
+	if (again.empty())
+		return rc;
+	const size_t na = again.size();
+	std::vector<uint8_t> hh(na * 32);
+	std::vector<gbm_order_tag> tt(tags ? na : 0);
+	std::vector<uint8_t *> oo(na);
+	std::vector<size_t> cc(na), ll(na, 0);
+	std::vector<int> rr(na, GBM_E_MISSING_BLOCK);
+	std::vector<gbm_data_block_header> hd(headers ? na : 0);
+	for (size_t i = 0; i < na; ++i) {
+		std::memcpy(hh.data() + 32 * i, hashes + 32 * again[i], 32);
+		if (tags)
+			tt[i] = tags[again[i]];
+		oo[i] = out[again[i]];
+		cc[i] = cap[again[i]];
+	}
+	rc = get_blocks_once(mg, na, hh.data(), tags ? tt.data() : nullptr, oo.data(), cc.data(), ll.data(), rr.data(), raw,
+			     headers ? hd.data() : nullptr, gate);
+	if (rc != GBM_OK)
+		return rc;
+	for (size_t i = 0; i < na; ++i) {
+		rcs[again[i]] = rr[i];
+		len_out[again[i]] = ll[i];
+		if (headers)
+			headers[again[i]] = hd[i];
+	}
+	return GBM_OK;
+}
+
+static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
+			   const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate)
+{
 	const int k = mg->k;
 	std::vector<Hash> hs(nb);
 	for (size_t b = 0; b < nb; ++b)
@@ -1600,8 +1648,14 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 			break;
 		pos += len;
 	}
-	if (handover)
-		return stream_general(m, hs, hash, order_tag, hdr, raw, out, pos, opened ? &geom : nullptr);
+	if (handover) {
+		int rc = stream_general(m, hs, hash, order_tag, hdr, raw, out, pos, opened ? &geom : nullptr);
+		// (a block whose shards were being moved to their new owners under the walk -- get_blocks_impl has the story -- is asked
+		// for once more, as long as no byte has gone out)
+		if (rc == GBM_E_MISSING_BLOCK && !opened && pos == 0 && m->layout_cur.load() != m->layout_oldest.load())
+			rc = stream_general(m, hs, hash, order_tag, hdr, raw, out, 0, nullptr);
+		return rc;
+	}
 	tr.lap("last shard delivered");
 	int rc = out.finish(hash);
 	if (rc == GBM_OK)

@@ -106,9 +106,14 @@ int verify_scrub_batch(gbm_manager *mg, ScrubBatch &cur, uint64_t st[4], Trace &
 	std::vector<Hash> &batch = cur.batch;
 	std::vector<Gathered> &g = cur.g;
 	std::map<size_t, std::vector<size_t>> by_len;
-	auto unreadable = [&](size_t b) {
+	// a needed block that is not fully readable is queued for resync.  It counts as a corruption only when something that
+	// was read did not match (a checksum, the code): the reference's scrub counts Error::CorruptData and nothing else
+	// (repair.rs:455-458) -- a shard that is simply not there (a node that is down, a put that is still catching up) is
+	// the resync's business, not a corruption.
+	auto unreadable = [&](size_t b, bool corrupt) {
 		if (mg->get_rc(batch[b]).is_nonzero()) {
-			++st[1];  // a needed block that is not fully readable
+			if (corrupt)
+				++st[1];
 			mg->put_to_resync(batch[b], 0);
 		}
 	};
@@ -117,7 +122,7 @@ int verify_scrub_batch(gbm_manager *mg, ScrubBatch &cur, uint64_t st[4], Trace &
 		if (g[b].count == mg->n)
 			by_len[g[b].meta.shard_len].push_back(b);
 		else
-			unreadable(b);
+			unreadable(b, g[b].corrupt_seen);
 	}
 	for (auto &kv : by_len) {
 		const std::vector<size_t> &ids = kv.second;
@@ -150,7 +155,7 @@ int verify_scrub_batch(gbm_manager *mg, ScrubBatch &cur, uint64_t st[4], Trace &
 				}
 			}
 			if (sum_bad) {
-				unreadable(ids[i]);
+				unreadable(ids[i], true);
 				continue;
 			}
 			if (ok[i])

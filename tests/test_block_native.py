@@ -862,3 +862,40 @@ def test_zstd_encode_is_the_reexport_the_ssec_path_uses():
     mgr.rpc_put_block(hb, blob, prevent_compression=True)
     hdr, raw = mgr.rpc_get_raw_block(hb)
     assert not hdr.is_compressed() and raw == blob
+
+
+@pytest.mark.parametrize("on_disk", [False, True], ids=["memory", "directories"])
+def test_resync_replaces_a_shard_of_a_stale_geometry(tmp_path, on_disk, backend):
+    """A node that was down while a block was put AGAIN with another compression setting comes back holding a shard of the
+    old geometry: present, readable, useless beside the thirteen new ones.  The presence scan learns every shard's geometry
+    (NeedShardReply carries the header), the resync replaces the odd one -- PutShard parks the new shard beside it,
+    CommitShard swaps them -- and the block scrubs clean again.  (Found by tools/soak_manager.py: the scan only asked
+    "is a shard there?", so such a block was flagged by every scrub and repaired by none.)"""
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    dirs = [str(tmp_path / f"node{i}") for i in range(16)] if on_disk else None
+    mgr = bn.NativeBlockManager(codec, 16, dirs, compression_level=1)
+    data = pattern_block(300_000, 77)
+    h = bn.blake2sum(data)
+    mgr.rpc_put_block(h, data, prevent_compression=True)
+    mgr.block_incref(h)
+    who = mgr.storage_nodes_of(h)
+    plain_hdr = mgr.node_shard_header(who[10], h, 10)
+    mgr.node_set_down(who[10], True)
+    mgr.node_set_down(who[3], True)
+    mgr.rpc_put_block(h, data)                       # Compressed now; twelve nodes take it: the write quorum
+    mgr.node_set_down(who[10], False)
+    mgr.node_set_down(who[3], False)
+    assert mgr.node_shard_header(who[10], h, 10) == plain_hdr and mgr.rpc_get_block(h) == data
+    assert mgr.scrub([h]) == [h]                     # fourteen shards, two of them of another geometry
+    mgr.put_to_resync(h, 0)
+    st = mgr.resync_run()
+    assert st["rebuilt"] == 2 and st["errors"] == 0
+    new_hdr = mgr.node_shard_header(who[10], h, 10)
+    assert new_hdr != plain_hdr and new_hdr[8] == 1                     # the compressed flag of the header
+    assert new_hdr[12:24] == mgr.node_shard_header(who[0], h, 0)[12:24]   # orig_len, shard_len: the stripe's
+    assert mgr.scrub([h]) == [] and mgr.rpc_get_block(h) == data
+    assert mgr.rpc_get_raw_block(h)[0].is_compressed()
+    if on_disk:
+        left = [f for nd in range(16) for _, _, fs in os.walk(tmp_path / f"node{nd}") for f in fs if not re.fullmatch(r"[0-9a-f]{64}\.s\d+", f)]
+        assert left == [], left                      # no .parked / .tmp files stay behind
+    assert mgr.resync_run()["rebuilt"] == 0

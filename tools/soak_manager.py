@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Soak of the BlockManager mirror (libgarage_block) against a model: random puts (plain / compressed / through the
+coalescing queue, ragged sizes down to empty), gets (whole, streaming, ranged, raw, through the queue), nodes going down
+and coming back, shards deleted or corrupted under the readers, refcounts dropped and the clock moved past the GC delay
+-- while THREE resync workers and the ScrubWorker run in the background the whole time.  Every byte read is compared
+with what was put; at every quiesce point (all nodes up, resync drained) every live block must scrub clean and read
+back, and the metrics must add up.
+At some quiesce points the cluster layout changes (every block's nodes move; the old version is trimmed once a repair
+pass has offloaded the strays) and a shard rots silently (checksum intact: only the scrub's RS verify can find it).
+usage: soak_manager.py [seconds] [backend: hip|cpu] [max block bytes] [seed] [devices] [directory-nodes root]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import garage_amd as g  # noqa: E402
+from garage_amd import block_native as bn  # noqa: E402
+
+
+def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, seed: int = 2026, k: int = 10, m: int = 4,
+         state_dir: str | None = None, verbose: bool = True, node_dirs_root: str | None = None, ndev: int = 1, layout_changes: bool = True) -> dict:
+    rng = np.random.default_rng(seed)
+    codec = g.ReedSolomon(k, m, backend=backend) if ndev == 1 else [g.ReedSolomon(k, m, backend=backend) for _ in range(ndev)]
+    n, nnodes = k + m, k + m + 2
+    dirs = [os.path.join(node_dirs_root, f"node{i}") for i in range(nnodes)] if node_dirs_root else None
+    mgr = bn.NativeBlockManager(codec, nnodes, dirs, compression_level=1)
+    bt = bn.Batcher(mgr, max_blocks=32, max_wait_us=100)
+    mgr.set_tranquility(scrub=0, resync=0)
+    mgr.set_resync_workers(3)
+    mgr.resync_worker_start()
+    mgr.scrub_worker_start(os.path.join(state_dir, "scrub_info") if state_dir else None, batch_blocks=16, checkpoint_interval_ms=50)
+    live: dict[bytes, bytes] = {}
+    down: set[int] = set()
+    damaged: dict[bytes, int] = {}          # shards of a live block deleted / corrupted since the last quiesce
+    ops = dict(put=0, get=0, stream=0, range=0, raw=0, queue_get=0, queue_put=0, down=0, up=0, corrupt=0, delete=0, decref=0, clock=0,
+               quiesce=0, scrub_start=0, layout_update=0, silent_rot=0)
+    layout_pending = False
+    nbytes = 0
+
+    def new_block():
+        kind = rng.random()
+        if kind < 0.08:
+            ln = int(rng.integers(0, 64))
+        elif kind < 0.3:
+            ln = int(rng.integers(64, 5000))
+        else:
+            ln = int(rng.integers(5000, max_len + 1))
+        if rng.random() < 0.5:                                   # compressible: the block is stored as a zstd frame
+            return bytes(np.repeat(rng.integers(0, 256, ln // 97 + 1, dtype=np.uint8), 97)[:ln])
+        return rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+
+    def check_read(h, data):
+        nonlocal nbytes
+        how = rng.random()
+        nbytes += len(data)
+        if how < 0.3:
+            ops["get"] += 1
+            assert mgr.rpc_get_block(h, max_len + 4096) == data, "rpc_get_block"
+        elif how < 0.5:
+            ops["stream"] += 1
+            assert b"".join(mgr.rpc_get_block_streaming(h, chunk_bytes=int(rng.choice([0, 4096, 100_000])))) == data, "streaming get"
+        elif how < 0.7 and len(data):
+            ops["range"] += 1
+            b = int(rng.integers(0, len(data)))
+            e = int(rng.integers(b, len(data) + 1 + (rng.random() < 0.1) * 1000))
+            assert b"".join(mgr.rpc_get_block_range(h, len(data), b, e, chunk_bytes=int(rng.choice([0, 8192])))) == data[b:e], "ranged get"
+        elif how < 0.8:
+            ops["raw"] += 1
+            hdr, raw = mgr.rpc_get_raw_block(h, max_len + 4096)
+            assert (bn.zstd_decode(raw, max_len + 4096) if hdr.is_compressed() else raw) == data, "raw get"
+        else:
+            ops["queue_get"] += 1
+            assert bt.get_block(h, max_len + 4096) == data, "get through the queue"
+
+    def diagnose(bad, what):
+        """What a block that fails a check looks like right now (and a moment later: a repair may have been in flight)."""
+        lines = [what]
+        for h in bad[:4]:
+            who = mgr.storage_nodes_of(h)
+            hdrs = []
+            for j in range(n):
+                try:
+                    b = mgr.node_shard_header(who[j], h, j)
+                    hdrs.append((j, b[8], int.from_bytes(b[12:20], "little"), int.from_bytes(b[20:24], "little")))
+                except bn.BlockError:
+                    hdrs.append((j, None))
+            lines.append(f"  {h.hex()[:16]} dev {mgr.device_of_hash(h)} rc {mgr.block_rc(h)} len {len(live.get(h, b''))} again-bad {mgr.scrub([h]) == [h]} "
+                         f"queue {mgr.resync_queue_len()} errors {[e for e in mgr.list_resync_errors() if e['hash'] == h]} shards {hdrs}")
+        time.sleep(0.3)
+        lines.append(f"  0.3 s later still bad: {[h.hex()[:16] for h in mgr.scrub(bad[:4])]}; scrub worker {mgr.scrub_worker_status()}")
+        return "\n".join(lines)
+
+    def settled_scrub(hs):
+        """gbm_scrub wants all n shards of a block in hand.  While a layout change is being followed the background workers
+        MOVE shards (PutShard to the new owner, then DeleteShard at the old one): a gather that asked the new owner before the
+        put and the old one after the delete misses that shard -- the block is whole the whole time (a read needs any k), the
+        verdict "not all there" is a snapshot of a move.  What is still bad after the moves have settled is bad."""
+        bad = mgr.scrub(hs)
+        for _ in range(40):
+            if not bad:
+                break
+            ops["transient_scrub"] = ops.get("transient_scrub", 0) + 1
+            time.sleep(0.02)
+            bad = mgr.scrub(bad)
+        return bad
+
+    def quiesce():
+        ops["quiesce"] += 1
+        for nd in list(down):
+            mgr.node_set_down(nd, False)
+        down.clear()
+        for h in damaged:
+            mgr.put_to_resync(h, 0)
+        deadline = time.time() + 60
+        while True:                                              # the background workers (and this call) drain what is due
+            mgr.resync_all()
+            errs = mgr.list_resync_errors()
+            for e in errs:                                       # a block that failed while nodes were down: retry now
+                try:
+                    mgr.resync_clear_backoff(e["hash"])
+                except bn.BlockError:
+                    pass                                         # (a background worker has just cleared it)
+            if not errs and not mgr.scrub(list(damaged)):
+                break
+            assert time.time() < deadline, f"resync does not converge: {len(errs)} errored blocks"
+            time.sleep(0.01)
+        damaged.clear()
+        hs = list(live)
+        bad = settled_scrub(hs)
+        assert bad == [], diagnose(bad, "a live block does not scrub clean after the resync")
+        for i in range(0, len(hs), 64):
+            part = hs[i:i + 64]
+            assert mgr.rpc_get_blocks(part, max_len + 4096) == [live[h] for h in part], "bulk get after the resync"
+        met = mgr.block_metrics(bt)
+        assert met["resync_errored_blocks"] == 0 and met["rc_size"] >= len(live)
+        assert met["block_write_duration"]["count"] > 0 and met["block_read_duration"]["bucket"][-1] == met["block_read_duration"]["count"]
+        st = mgr.scrub_worker_status()
+        assert st["errors"] == 0, st
+        nonlocal layout_pending
+        if layout_pending:
+            # everything stored has been walked since the layout changed: strays offloaded to their new owners, the old
+            # version can go (reads stop consulting it) -- and every block must still be all there
+            mgr.repair_all()
+            mgr.resync_all()
+            assert mgr.list_resync_errors() == []
+            mgr.layout_trim()
+            layout_pending = False
+            bad = settled_scrub(hs)
+            assert bad == [], diagnose(bad, "a block is not whole on its new nodes after the layout change")
+        if hs and ops["quiesce"] % 3 == 0:
+            # bit rot BEFORE checksumming in one shard of one block (the checksum still matches): no read in the default mode
+            # can see it, the scrub's RS verify does -- it locates the shard, sets it aside, the resync rebuilds it
+            h = hs[int(rng.integers(len(hs)))]
+            if len(live[h]):
+                ops["silent_rot"] += 1
+                who = mgr.storage_nodes_of(h)
+                j = int(rng.integers(k, n))                      # a parity shard: healthy reads do not touch it
+                mgr.node_corrupt_shard(who[j], h, j, int(rng.integers(0, 64)), 1 << int(rng.integers(8)), fix_checksum=True)
+                assert mgr.scrub([h]) == [h]
+                found = mgr.scrub_all(64)
+                assert found["corruptions"] >= 1 and found["located"] >= 1, found
+                mgr.resync_all()
+                assert mgr.scrub([h]) == [] and mgr.rpc_get_block(h, max_len + 4096) == live[h]
+        if layout_changes and ops["quiesce"] % 4 == 1:
+            ops["layout_update"] += 1
+            mgr.layout_update()                                  # every block's nodes move; reads consult both versions
+            layout_pending = True
+
+    t0 = time.time()
+    it = 0
+    while time.time() - t0 < seconds:
+        it += 1
+        r = rng.random()
+        if r < 0.30 or len(live) < 8:
+            data = new_block()
+            h = bn.blake2sum(data)
+            pc = bool(rng.random() < 0.3)
+            if rng.random() < 0.4:
+                ops["queue_put"] += 1
+                bt.put_block(h, data, prevent_compression=pc)
+            else:
+                ops["put"] += 1
+                mgr.rpc_put_block(h, data, prevent_compression=pc)
+            if h not in live:
+                mgr.block_incref(h)
+            live[h] = data
+            nbytes += len(data)
+        elif r < 0.62:
+            h = list(live)[int(rng.integers(len(live)))]
+            check_read(h, live[h])
+        elif r < 0.67 and len(down) < 2:
+            nd = int(rng.integers(nnodes))
+            if nd not in down:
+                ops["down"] += 1
+                down.add(nd)
+                mgr.node_set_down(nd, True)
+        elif r < 0.72 and down:
+            ops["up"] += 1
+            nd = down.pop()
+            mgr.node_set_down(nd, False)
+        elif r < 0.80:
+            # one shard of a live block goes away or goes bad (its checksum no longer matches): with <= 2 nodes down and
+            # <= 1 damaged shard per block since the last quiesce, every block keeps >= k good shards
+            h = list(live)[int(rng.integers(len(live)))]
+            if damaged.get(h, 0) == 0 and len(live[h]) > 0:
+                who = mgr.storage_nodes_of(h)
+                j = int(rng.integers(n))
+                if who[j] not in down and mgr.node_has_shard(who[j], h, j):
+                    damaged[h] = 1
+                    if rng.random() < 0.5:
+                        ops["delete"] += 1
+                        mgr.node_delete_shard(who[j], h, j)
+                    else:
+                        ops["corrupt"] += 1
+                        mgr.node_corrupt_shard(who[j], h, j, int(rng.integers(0, 64)), 1 << int(rng.integers(8)), fix_checksum=False)
+        elif r < 0.84 and len(live) > 16:
+            ops["decref"] += 1
+            h = list(live)[int(rng.integers(len(live)))]
+            mgr.block_decref(h)
+            del live[h]
+            damaged.pop(h, None)
+        elif r < 0.88:
+            ops["clock"] += 1
+            mgr.clock_advance(int(rng.integers(1000, 400_000)))     # GC delays, back-offs and the scrub's pauses run out
+        elif r < 0.91:
+            try:
+                mgr.scrub_worker_command(int(rng.choice([bn.SCRUB_START, bn.SCRUB_START, bn.SCRUB_PAUSE, bn.SCRUB_RESUME, bn.SCRUB_CANCEL])), 20)
+                ops["scrub_start"] += 1
+            except bn.BlockError:
+                pass                                                # does not fit the worker's state: refused, nothing changes
+        if it % 150 == 0:
+            quiesce()
+    quiesce()
+    st = mgr.scrub_worker_status()
+    met = mgr.block_metrics(bt)
+    mgr.scrub_worker_stop()
+    mgr.resync_worker_stop()
+    bt.close()
+    res = {"seconds": round(time.time() - t0, 1), "backend": backend, "iterations": it, "live_blocks": len(live), "GiB_checked": round(nbytes / 2**30, 2),
+           "ops": ops, "scrub_worker": {x: st[x] for x in ("blocks_scrubbed", "corruptions_detected", "checkpoints_saved", "errors")},
+           "metrics": {x: met[x] for x in ("blocks_put", "blocks_get", "ec_reconstructs", "corruption_counter", "resync_counter", "resync_error_counter",
+                                           "resync_recv_counter", "delete_counter")}}
+    mgr.close()
+    if verbose:
+        print("soak_manager OK:", res)
+    return res
+
+
+if __name__ == "__main__":
+    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+    backend = sys.argv[2] if len(sys.argv) > 2 else "hip"
+    max_len = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
+    seed = int(sys.argv[4]) if len(sys.argv) > 4 else 2026
+    ndev = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    root = sys.argv[6] if len(sys.argv) > 6 else None            # directory nodes under this path (a tmpfs, preferably)
+    soak(secs, backend, max_len, seed, ndev=ndev, node_dirs_root=root)
