@@ -746,7 +746,7 @@ struct Gathered {
 	ShardHeader meta;
 	bool have_meta = false;
 	int count = 0;
-	size_t next = 0;  // next candidate (version-major, shard index minor) to try
+	std::vector<uint8_t> tried;  // candidates (version-major, shard index minor) that have been asked
 	bool mixed = false;
 	bool settled = false;  // a geometry has been chosen; later candidates must match it
 	bool corrupt_seen = false;  // a shard of this block was there but failed its header / checksum check during this read

@@ -558,19 +558,39 @@ int gbm_resync_block(gbm_manager *mg, const uint8_t hash[32], int *changed)
 	return GBM_OK;
 }
 
+// true once no pass of any worker has a block of this manager (or of its lanes) in hand; waits for that at most wait_ms
+static bool resync_passes_over(gbm_manager *mg, uint64_t wait_ms)
+{
+	auto one = [&](gbm_manager *x) {
+		std::unique_lock<std::mutex> lk(x->rs_mu);
+		return x->rs_cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(wait_ms), [&] { return x->rs_busy.empty(); });
+	};
+	bool over = one(mg);
+	for (auto &l : mg->lanes)
+		over = one(l.get()) && over;
+	return over;
+}
+
+// gbm_resync_run until nothing is due any more -- and no OTHER worker's pass is still under way: a background worker takes
+// its entries out of the queue for the length of its pass, so an empty queue alone does not mean that everything due has
+// been done (a caller that trims the layout on the strength of this call would strand the shards such a pass was about to
+// move).
 int gbm_resync_all(gbm_manager *mg, int *changed)
 {
 	if (!mg)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
 	int total = 0, result = GBM_OK;
-	for (int round = 0; round < 64; ++round) {
+	for (int round = 0; round < 256; ++round) {
 		uint64_t st[8];
 		int rc = gbm_resync_run(mg, 0, st);
 		if (rc)
 			result = rc;
 		total += (int)(st[4] + st[5] + st[6]);
-		if (st[0] == 0)
-			break;
+		if (st[0] != 0)
+			continue;
+		if (resync_passes_over(mg, 0))
+			break;  // nothing was due and nothing is in flight
+		(void)resync_passes_over(mg, 1000);  // another worker's pass: what it leaves behind (errors re-queued, follow-ups) is looked at next
 	}
 	if (changed)
 		*changed = total;

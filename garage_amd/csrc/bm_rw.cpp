@@ -71,11 +71,18 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 	auto next_candidate = [&](size_t b, const std::function<bool(int)> &taken, std::vector<int> &who, int &who_v,
 				  int &j_out) -> bool {
 		Gathered &g = gs[b];
-		while (g.next < ncand) {
-			const size_t c = g.next++;
+		if (g.tried.size() != ncand)
+			g.tried.assign(ncand, 0);
+		// a candidate is consumed when it is ASKED, not when it is passed over: shard j being covered by a request that is
+		// still in flight says nothing about j's other holders, which are needed the moment that request fails (a hedge
+		// timer that fired while all n first requests were in flight used to use up every older-version candidate)
+		for (size_t c = 0; c < ncand; ++c) {
+			if (g.tried[c])
+				continue;
 			const int v = vcur - (int)(c / n), j = (int)(c % n);
 			if (have(g, j) || taken(j))
 				continue;
+			g.tried[c] = 1;
 			if (v != who_v) {
 				mg->nodes_of(hs[b], v, who);
 				who_v = v;
@@ -198,14 +205,26 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 			}
 			// (system_clock: pthread_cond_timedwait, which ThreadSanitizer understands; gcc 11's does not know
 			// the pthread_cond_clockwait a steady_clock deadline turns into)
-			const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(hedge_us);
-			if (!rd->cv.wait_until(lk, deadline, [&] { return rd->unsatisfied == 0; })) {
-				uint64_t hedges = 0;
+			for (;;) {
+				const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(hedge_us);
+				if (!rd->cv.wait_until(lk, deadline, [&] { return rd->unsatisfied == 0; })) {
+					uint64_t hedges = 0;
+					for (size_t b = 0; b < hs.size(); ++b)
+						if (!rd->satisfied(b))
+							hedges += launch(b, rd->need[b] - rd->ok[b]);
+					mg->hedged_reads += hedges;
+					rd->cv.wait(lk, [&] { return rd->unsatisfied == 0; });
+				}
+				// "start another on each failure" (try_call_many_inner, rpc_helper.rs:323-411): a block whose requests have all
+				// come back and that is still short asks its next holders -- the parity shards' nodes, then the older layout
+				// versions' -- instead of ending the round empty-handed (a block whose shards are all still on the previous
+				// layout's nodes was "missing" to a hedged read)
+				int more = 0;
 				for (size_t b = 0; b < hs.size(); ++b)
-					if (!rd->satisfied(b))
-						hedges += launch(b, rd->need[b] - rd->ok[b]);
-				mg->hedged_reads += hedges;
-				rd->cv.wait(lk, [&] { return rd->unsatisfied == 0; });
+					if ((!only || (*only)[b]) && rd->ok[b] < rd->need[b] && rd->outstanding[b] == 0)
+						more += launch(b, rd->need[b] - rd->ok[b]);
+				if (!more)
+					break;
 			}
 			rd->over = true;
 			for (auto &f : flights)

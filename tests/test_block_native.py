@@ -899,3 +899,38 @@ def test_resync_replaces_a_shard_of_a_stale_geometry(tmp_path, on_disk, backend)
         left = [f for nd in range(16) for _, _, fs in os.walk(tmp_path / f"node{nd}") for f in fs if not re.fullmatch(r"[0-9a-f]{64}\.s\d+", f)]
         assert left == [], left                      # no .parked / .tmp files stay behind
     assert mgr.resync_run()["rebuilt"] == 0
+
+
+def test_hedged_reads_walk_on_to_the_next_holders_when_requests_fail(backend):
+    """try_call_many_inner (rpc_helper.rs:323-411): "start another on each failure".  The hedged gather launched more requests
+    only for holders that were SLOW; when the first k holders all answered "no such shard" at once -- every shard still on
+    the previous layout version's nodes -- the round ended empty-handed and the block was Missing to every hedged read
+    (found by tools/soak_manager.py).  Absent shards, down nodes and an older layout version, each with hedging on."""
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    mgr = bn.NativeBlockManager(codec, 16)
+    blocks = [pattern_block(60_000 + 64 * i, 900 + i) for i in range(12)]
+    hashes = [bn.blake2sum(b) for b in blocks]
+    mgr.rpc_put_blocks(list(zip(hashes, blocks)))
+    for h in hashes:
+        mgr.block_incref(h)
+    mgr.set_read_hedge(300)
+    # data shards absent on nodes that answer at once: the parity holders are asked in the same round
+    who = mgr.storage_nodes_of(hashes[0])
+    for j in (0, 4, 9):
+        mgr.node_delete_shard(who[j], hashes[0], j)
+    assert mgr.rpc_get_block(hashes[0]) == blocks[0]
+    # nodes that cannot be contacted at all
+    mgr.node_set_down(who[1], True)
+    assert mgr.rpc_get_block(hashes[0]) == blocks[0] and b"".join(mgr.rpc_get_block_streaming(hashes[0])) == blocks[0]
+    mgr.node_set_down(who[1], False)
+    # the layout moves on: every shard is on the PREVIOUS version's nodes until resync has offloaded it
+    mgr.layout_update()
+    assert [mgr.rpc_get_block(h) for h in hashes] == blocks
+    assert mgr.rpc_get_blocks(hashes, 100_000) == blocks
+    assert b"".join(mgr.rpc_get_block_streaming(hashes[3])) == blocks[3]
+    assert b"".join(mgr.rpc_get_block_range(hashes[3], len(blocks[3]), 100, 40_000)) == blocks[3][100:40_000]
+    assert mgr.scrub(hashes[1:]) == []               # all n shards of a block, over both versions
+    mgr.repair_all()
+    mgr.resync_all()
+    mgr.layout_trim()
+    assert [mgr.rpc_get_block(h) for h in hashes] == blocks and mgr.scrub(hashes) == []

@@ -10,6 +10,7 @@ pass has offloaded the strays) and a shard rots silently (checksum intact: only 
 usage: soak_manager.py [seconds] [backend: hip|cpu] [max block bytes] [seed] [devices] [directory-nodes root]"""
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,7 +23,8 @@ from garage_amd import block_native as bn  # noqa: E402
 
 
 def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, seed: int = 2026, k: int = 10, m: int = 4,
-         state_dir: str | None = None, verbose: bool = True, node_dirs_root: str | None = None, ndev: int = 1, layout_changes: bool = True) -> dict:
+         state_dir: str | None = None, verbose: bool = True, node_dirs_root: str | None = None, ndev: int = 1, layout_changes: bool = True,
+         nreaders: int = 2) -> dict:
     rng = np.random.default_rng(seed)
     codec = g.ReedSolomon(k, m, backend=backend) if ndev == 1 else [g.ReedSolomon(k, m, backend=backend) for _ in range(ndev)]
     n, nnodes = k + m, k + m + 2
@@ -36,9 +38,50 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
     live: dict[bytes, bytes] = {}
     down: set[int] = set()
     damaged: dict[bytes, int] = {}          # shards of a live block deleted / corrupted since the last quiesce
+    pinned: dict[bytes, bytes] = {}        # blocks that are never dereferenced: what the concurrent readers read
+    reader_stop = threading.Event()
+    reader_fail: list[str] = []
+    reader_ops = [0, 0]
+
+    def reader(idx):
+        """A GetObject beside everything else: whole, streaming, ranged and queued reads of blocks that stay referenced, while
+        the main thread takes nodes down, damages shards, changes the layout and the background workers repair."""
+        r2 = np.random.default_rng(seed * 1000 + idx)
+        while not reader_stop.is_set():
+            items = list(pinned.items())
+            if not items:
+                time.sleep(0.001)
+                continue
+            h, data = items[int(r2.integers(len(items)))]
+            how = r2.random()
+            try:
+                if how < 0.3:
+                    got = mgr.rpc_get_block(h, max_len + 4096)
+                elif how < 0.55:
+                    got = b"".join(mgr.rpc_get_block_streaming(h, chunk_bytes=int(r2.choice([0, 8192]))))
+                elif how < 0.75 and len(data):
+                    b = int(r2.integers(0, len(data)))
+                    e = int(r2.integers(b, len(data) + 1))
+                    got = b"".join(mgr.rpc_get_block_range(h, len(data), b, e))
+                    data = data[b:e]
+                else:
+                    got = bt.get_block(h, max_len + 4096)
+                if got != data:
+                    reader_fail.append(f"reader {idx}: wrong bytes for {h.hex()[:16]} ({len(got)} vs {len(data)})")
+                    return
+                reader_ops[0] += 1
+                reader_ops[1] += len(data)
+            except bn.BlockError as e:
+                reader_fail.append(f"reader {idx}: {h.hex()[:16]}: {e}")
+                return
+
+    readers = [threading.Thread(target=reader, args=(i,)) for i in range(nreaders)]
+    for t in readers:
+        t.start()
     ops = dict(put=0, get=0, stream=0, range=0, raw=0, queue_get=0, queue_put=0, down=0, up=0, corrupt=0, delete=0, decref=0, clock=0,
                quiesce=0, scrub_start=0, layout_update=0, silent_rot=0)
     layout_pending = False
+    settings = {"hedge_us": 0, "verify": "off"}
     nbytes = 0
 
     def new_block():
@@ -88,6 +131,8 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
                     hdrs.append((j, b[8], int.from_bytes(b[12:20], "little"), int.from_bytes(b[20:24], "little")))
                 except bn.BlockError:
                     hdrs.append((j, None))
+            elsewhere = {j: [nd for nd in range(nnodes) if nd != who[j] and mgr.node_has_shard(nd, h, j)] for j in range(n)}
+            lines.append(f"  shards on OTHER nodes than the current layout's: { {j: v for j, v in elsewhere.items() if v} }")
             lines.append(f"  {h.hex()[:16]} dev {mgr.device_of_hash(h)} rc {mgr.block_rc(h)} len {len(live.get(h, b''))} again-bad {mgr.scrub([h]) == [h]} "
                          f"queue {mgr.resync_queue_len()} errors {[e for e in mgr.list_resync_errors() if e['hash'] == h]} shards {hdrs}")
         time.sleep(0.3)
@@ -188,10 +233,16 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
             if h not in live:
                 mgr.block_incref(h)
             live[h] = data
+            if len(pinned) < 64:
+                pinned[h] = data
             nbytes += len(data)
         elif r < 0.62:
             h = list(live)[int(rng.integers(len(live)))]
-            check_read(h, live[h])
+            try:
+                check_read(h, live[h])
+            except (bn.BlockError, AssertionError) as e:
+                raise AssertionError(diagnose([h], f"a read of a live block failed: {e!r}; nodes down {sorted(down)}, damaged {damaged.get(h, 0)}, "
+                                                   f"settings {settings}")) from e
         elif r < 0.67 and len(down) < 2:
             nd = int(rng.integers(nnodes))
             if nd not in down:
@@ -220,6 +271,8 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
         elif r < 0.84 and len(live) > 16:
             ops["decref"] += 1
             h = list(live)[int(rng.integers(len(live)))]
+            if h in pinned:
+                continue
             mgr.block_decref(h)
             del live[h]
             damaged.pop(h, None)
@@ -234,13 +287,23 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
                 pass                                                # does not fit the worker's state: refused, nothing changes
         if it % 150 == 0:
             quiesce()
+            settings["hedge_us"] = int(rng.choice([0, 0, 300]))      # the hedged gather on some stretches
+            settings["verify"] = str(rng.choice(["off", "off", "rebuilt", "always"]))
+            mgr.set_read_hedge(settings["hedge_us"])
+            mgr.set_verify_block_hash(settings["verify"])
+        assert not reader_fail, reader_fail
     quiesce()
+    reader_stop.set()
+    for t in readers:
+        t.join()
+    assert not reader_fail, reader_fail
     st = mgr.scrub_worker_status()
     met = mgr.block_metrics(bt)
     mgr.scrub_worker_stop()
     mgr.resync_worker_stop()
     bt.close()
     res = {"seconds": round(time.time() - t0, 1), "backend": backend, "iterations": it, "live_blocks": len(live), "GiB_checked": round(nbytes / 2**30, 2),
+           "concurrent_readers": {"threads": nreaders, "reads": reader_ops[0], "GiB": round(reader_ops[1] / 2**30, 2)},
            "ops": ops, "scrub_worker": {x: st[x] for x in ("blocks_scrubbed", "corruptions_detected", "checkpoints_saved", "errors")},
            "metrics": {x: met[x] for x in ("blocks_put", "blocks_get", "ec_reconstructs", "corruption_counter", "resync_counter", "resync_error_counter",
                                            "resync_recv_counter", "delete_counter")}}
