@@ -73,7 +73,7 @@ class BlockMetrics(ctypes.Structure):
                                                "resync_counter", "resync_error_counter", "resync_send_counter", "resync_recv_counter",
                                                "bytes_read", "bytes_written", "delete_counter", "corruption_counter")]
                 + [(n, Histogram) for n in ("resync_duration", "block_read_duration", "block_write_duration")]
-                + [(n, ctypes.c_uint64) for n in ("ec_reconstructs", "blocks_put", "blocks_get", "gpu_hashed", "hedged_reads",
+                + [(n, ctypes.c_uint64) for n in ("ec_reconstructs", "blocks_put", "blocks_get", "gpu_hashed", "hedged_reads", "unconfirmed_verdicts",
                                                  "scrub_corruptions_detected", "scrub_time_last_complete_ms", "tranquilized_ms",
                                                  "batcher_put_batches", "batcher_put_blocks", "batcher_get_batches", "batcher_get_blocks")]
                 + [("devices", ctypes.c_uint32)])

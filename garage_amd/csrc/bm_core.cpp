@@ -360,6 +360,17 @@ void destroy_one(gbm_manager *m)
 
 using namespace gbmimpl;
 
+bool gbmimpl::confirmed_corrupt(gbm_manager *mg, const uint8_t *data, size_t S, const uint8_t header_sum[32], const char *who)
+{
+	uint8_t sum[32];
+	shardsum(data, S, sum);
+	if (std::memcmp(sum, header_sum, 32) != 0)
+		return true;
+	mg->bmx.unconfirmed_verdicts++;
+	std::fprintf(stderr, "garage_block: %s reported a checksum mismatch that the host does not confirm (shard of %zu bytes): the shard stays\n", who, S);
+	return false;
+}
+
 // `expr` on the manager itself, or on every lane of a front (and on the front, whose copy of the setting only
 // answers the getters)
 #define GBM_EACH(m, var, expr)                          \
@@ -814,6 +825,7 @@ void add_one(gbm_manager *x, gbm_block_metrics &o)
 	o.resync_send_counter += x->bmx.resync_send_counter.load();
 	o.resync_recv_counter += x->bmx.resync_recv_counter.load();
 	o.delete_counter += x->bmx.delete_counter.load();
+	o.unconfirmed_verdicts += x->bmx.unconfirmed_verdicts.load();
 	o.bytes_written += x->metrics[0].load();
 	o.bytes_read += x->metrics[1].load();
 	o.corruption_counter += x->metrics[2].load();
@@ -991,6 +1003,9 @@ int gbm_metrics_prometheus(const gbm_manager *m, gbm_batcher *b, char *buf, size
 		put_metric(s, "block_ec_blocks_put", "counter", "Blocks stored through rpc_put_block", (double)x.blocks_put);
 		put_metric(s, "block_ec_blocks_get", "counter", "Blocks read through rpc_get_block", (double)x.blocks_get);
 		put_metric(s, "block_ec_device_hashed", "counter", "Messages (blocks, shards) whose checksum the device computed", (double)x.gpu_hashed);
+		put_metric(s, "block_ec_unconfirmed_verdicts", "counter",
+			   "Checksum mismatches reported by a device trip or the pool that the host's own check did not confirm (the shard stayed)",
+			   (double)x.unconfirmed_verdicts);
 		put_metric(s, "block_ec_hedged_reads", "counter", "Extra shard requests sent by hedged reads", (double)x.hedged_reads);
 		put_metric(s, "block_ec_scrub_corruptions_detected", "counter", "Corrupt blocks found by the scrub", (double)x.scrub_corruptions_detected);
 		put_metric(s, "block_ec_scrub_time_last_complete_ms", "gauge", "When the last complete scrub ended (ms since the epoch)",

@@ -549,6 +549,7 @@ struct DurationScope {
 };
 struct BlockMetrics {
 	std::atomic<uint64_t> resync_counter{0}, resync_error_counter{0}, resync_send_counter{0}, resync_recv_counter{0}, delete_counter{0};
+	std::atomic<uint64_t> unconfirmed_verdicts{0};  // "checksum does not match" from a trip that the host's own check did not confirm
 	Histogram resync_duration, read_duration, write_duration;
 };
 
@@ -821,6 +822,12 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 		 std::vector<uint8_t> *changed = nullptr, const FanoutGate *gate = nullptr, std::vector<uint8_t> *have_sum = nullptr);
 void assemble(const Gathered &g, int k, uint8_t *dst);
 int one_block_rc(int rc1);
+// A shard is set aside (renamed *.corrupted, rebuilt by resync) only on the HOST's word.  Whoever found a checksum that does
+// not match -- a device trip, the pool -- has the shard's bytes in hand, and corruption is rare: the verdict is confirmed
+// with the host's own restatement of the checksum before anything is renamed.  A verdict that is not confirmed is counted
+// (block_ec_unconfirmed_verdicts), logged, and the shard stays where it is: a fault in the checker must not become the loss
+// of the k good shards it was shown.  true = the shard really does not match `header_sum`.  (bm_core.cpp)
+bool confirmed_corrupt(gbm_manager *mg, const uint8_t *data, size_t S, const uint8_t header_sum[32], const char *who);
 // every hash any reachable node holds a shard of (bm_scrub.cpp)
 void list_all_nodes(gbm_manager *mg, std::set<Hash> &all);
 // the coalescing queue's figures for the metrics: out[0] = free RAM permits (KiB), [1] put batches, [2] put blocks,

@@ -221,6 +221,52 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 					}
 				}
 		}
+		// A wanted shard that the gather has brought in all the same -- from another holder than the one the scan asked: a
+		// previous layout version's node that was unreachable a moment ago, a stray the offload branch could not fetch -- is not
+		// rebuilt, it is handed to its owner as it is (its checksum is verified first: nobody has looked at it yet).  It must
+		// not reach the trip as "present AND wanted": the codec skips a block nothing is wanted of, its in_sums stay whatever
+		// they were, and comparing those with the headers set aside all k good shards of the block.
+		for (size_t i : todo) {
+			ResyncTask &t = tasks[i];
+			if (!t.g.have_meta || t.want.empty())  // (an error noted by the scan -- a node that is down -- does not stop this: the
+				continue;                      // task is tried again later, what can be done now is done now)
+			const std::string noted = t.error;
+			t.error.clear();
+			for (auto it = t.want.begin(); it != t.want.end();) {
+				const int j = *it;
+				if (t.g.shard[j].empty()) {
+					++it;
+					continue;
+				}
+				uint8_t sum[32];
+				shardsum(t.g.shard[j].data(), t.g.meta.shard_len, sum);
+				if (std::memcmp(sum, t.g.sum[j].data(), 32) != 0) {
+					mg->metrics[2]++;
+					if (t.g.node[j] >= 0)
+						mg->nodes[t.g.node[j]]->mark_corrupted(t.h, j);
+					t.error = "a shard fetched for hand-over does not match its checksum";  // the block is tried again: fewer holders now
+					break;
+				}
+				bool pend = false;
+				if (send_shard(mg, t.who[j], t.h, j, t.g.shard[j], t.g.meta.shard_len, t.g.meta.orig_len, t.g.meta.compressed != 0,
+					       t.g.sum[j].data(), nullptr, &pend)) {
+					if (pend) {
+						ShardRpc cq{RpcKind::CommitShard, &t.h, j, Shard(), nullptr};
+						ShardResp cs;
+						(void)mg->nodes[t.who[j]]->handle(cq, cs);
+					}
+					++t.changed;
+					++st.offloaded;
+				} else {
+					t.error = "PutShard of a shard in hand to its owner failed";
+				}
+				it = t.want.erase(it);
+			}
+			if (!t.error.empty())
+				t.want.clear();
+			else
+				t.error = noted;
+		}
 		// ONE device call per shard length: inside it gec_reconstruct_hash_batch buckets the blocks by (which shards
 		// are in hand, which are wanted) -- one decode plan and one kernel launch per such erasure pattern, the patterns'
 		// chunks pipelined through the link without a host round trip in between (one call per pattern: 14 calls,
@@ -289,13 +335,27 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 							continue;
 						++seen;
 						if (std::memcmp(in_sums.data() + (q * n + j) * 32, t.g.sum[j].data(), 32) != 0) {
+							std::string who = "gec_reconstruct_hash_batch (shard " + std::to_string(j) + ", in hand:";
+							for (int x = 0; x < n; ++x)
+								if (!t.g.shard[x].empty())
+									who += " " + std::to_string(x);
+							who += "; wanted:";
+							for (int x : t.want)
+								who += " " + std::to_string(x);
+							who += ")";
+							if (!confirmed_corrupt(mg, t.g.shard[j].data(), S, t.g.sum[j].data(), who.c_str())) {
+								t.error = "the rebuild trip's shard checksums are not what the host computes: nothing was set aside";
+								good[q] = 0;
+								t.want.clear();
+								break;
+							}
 							mg->metrics[2]++;
 							if (t.g.node[j] >= 0)
 								mg->nodes[t.g.node[j]]->mark_corrupted(t.h, j);
 							good[q] = 0;
 						}
 					}
-					if (!good[q]) {
+					if (!good[q] && t.error.empty()) {
 						t.want.clear();  // decided again by the second pass
 						again.push_back(ids[q]);
 					}

@@ -252,7 +252,8 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 		for (size_t i = 0; i < cands.size(); ++i) {
 			Cand &c = *cands[i];
 			Gathered &g = gs[c.b];
-			if (verify && std::memcmp(sums.data() + 32 * i, c.s.hd.checksum, 32) != 0) {
+			if (verify && std::memcmp(sums.data() + 32 * i, c.s.hd.checksum, 32) != 0 &&
+			    confirmed_corrupt(mg, c.s.data.data(), c.s.hd.shard_len, c.s.hd.checksum, "the gather's checksum pass")) {
 				mg->metrics[2]++;
 				mg->nodes[c.node]->mark_corrupted(hs[c.b], c.j);
 				mg->put_to_resync(hs[c.b], 0);
@@ -713,6 +714,8 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 						continue;
 					++seen;
 					if (std::memcmp(ssums.data() + (i * n + j) * 32, gb.sum[j].data(), 32) != 0) {
+						if (!confirmed_corrupt(mg, gb.shard[j].data(), S, gb.sum[j].data(), "gec_decode_verify_batch"))
+							return fail(GBM_E_EC, "a read trip's shard checksums are not what the host computes: nothing was set aside, the read is refused");
 						mg->metrics[2]++;
 						if (gb.node[j] >= 0)
 							mg->nodes[gb.node[j]]->mark_corrupted(hs[b], j);
@@ -1668,11 +1671,13 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 		pos += len;
 	}
 	if (handover) {
+		const size_t sent_before = out.sent.size();
 		int rc = stream_general(m, hs, hash, order_tag, hdr, raw, out, pos, opened ? &geom : nullptr);
 		// (a block whose shards were being moved to their new owners under the walk -- get_blocks_impl has the story -- is asked
-		// for once more, as long as no byte has gone out)
-		if (rc == GBM_E_MISSING_BLOCK && !opened && pos == 0 && m->layout_cur.load() != m->layout_oldest.load())
-			rc = stream_general(m, hs, hash, order_tag, hdr, raw, out, 0, nullptr);
+		// for once more, as long as the general form has not delivered anything itself: it takes up at byte `pos` again)
+		if ((rc == GBM_E_MISSING_BLOCK || rc == GBM_E_CORRUPT_DATA) && out.sent.size() == sent_before && !out.aborted && !out.frame_bad &&
+		    m->layout_cur.load() != m->layout_oldest.load())
+			rc = stream_general(m, hs, hash, order_tag, hdr, raw, out, pos, opened ? &geom : nullptr);
 		return rc;
 	}
 	tr.lap("last shard delivered");

@@ -147,6 +147,8 @@ int verify_scrub_batch(gbm_manager *mg, ScrubBatch &cur, uint64_t st[4], Trace &
 			for (int j = 0; j < mg->n; ++j) {
 				const Gathered &gb = g[ids[i]];
 				if (std::memcmp(sums.data() + (i * mg->n + j) * 32, gb.sum[j].data(), 32) != 0) {
+					if (!confirmed_corrupt(mg, gb.shard[j].data(), kv.first, gb.sum[j].data(), "gec_verify_hash_batch"))
+						return fail(GBM_E_EC, "the scrub trip's shard checksums are not what the host computes: nothing was set aside");
 					mg->metrics[2]++;
 					if (gb.node[j] >= 0)
 						mg->nodes[gb.node[j]]->mark_corrupted(batch[ids[i]], j);

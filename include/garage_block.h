@@ -498,6 +498,7 @@ typedef struct {
 	uint64_t blocks_put, blocks_get;
 	uint64_t gpu_hashed;           /* messages whose checksum the device computed */
 	uint64_t hedged_reads;
+	uint64_t unconfirmed_verdicts; /* checksum mismatches a trip reported that the host's own check did not confirm: the shard stayed */
 	uint64_t scrub_corruptions_detected, scrub_time_last_complete_ms;
 	uint64_t tranquilized_ms;
 	uint64_t batcher_put_batches, batcher_put_blocks, batcher_get_batches, batcher_get_blocks;

@@ -244,7 +244,9 @@ int gec_reconstruct_batch(const gec_codec *c, size_t nblocks,
 
 /* gec_reconstruct_batch plus, from the same trip, the shard checksums (gec_shardsum_batch) of the k shards that
  * were READ for every block (in_sums[32*(b*n + j)] for the first k present shards j; other entries untouched) and
- * of the shards that were WRITTEN (out_sums[32*(b*n + j)]).  The resync worker's rebuild
+ * of the shards that were WRITTEN (out_sums[32*(b*n + j)]).  A block of which nothing is wanted (every out entry NULL, or
+ * only entries of shards that are present) is not read at all: its in_sums entries are untouched too -- a caller must not
+ * compare them with anything.  The resync worker's rebuild
  * (src/block/resync.rs:485-499, "fetching absent but needed block") in one pass over the link: the caller
  * compares in_sums with the shard headers it read and stamps out_sums into the headers it writes.  Pinned
  * buffers: one pointer-table kernel per erasure pattern that also mirrors what it reads and writes into device

@@ -934,3 +934,45 @@ def test_hedged_reads_walk_on_to_the_next_holders_when_requests_fail(backend):
     mgr.resync_all()
     mgr.layout_trim()
     assert [mgr.rpc_get_block(h) for h in hashes] == blocks and mgr.scrub(hashes) == []
+
+
+def test_reconstruct_hash_batch_leaves_a_block_nothing_is_wanted_of_untouched(backend):
+    """The contract the resync relies on (include/garage_ec.h): a block of which nothing is wanted -- every out entry NULL, or
+    only entries of shards that are PRESENT as well -- is not read at all, and its in_sums / out_sums entries stay as they
+    were.  The resync's rebuild pass used to send such blocks along (a wanted shard that the gather had fetched from another
+    holder after all), compared the untouched in_sums with the shard headers, and set aside all k good shards of the block
+    (found by tools/soak_manager.py).  It now hands a shard it has in hand to its owner instead."""
+    import numpy as np
+    from garage_amd import _lib
+    k, m, S, nb = 10, 4, 4160, 3
+    n = k + m
+    rs = g.ReedSolomon(k, m, backend=backend)
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 256, (nb, k, S), dtype=np.uint8)
+    parity = np.zeros((nb, m, S), dtype=np.uint8)
+    u8pp = ctypes.POINTER(ctypes.c_uint8)
+    dp = (ctypes.c_void_p * nb)(*[data[b].ctypes.data for b in range(nb)])
+    pp = (ctypes.c_void_p * nb)(*[parity[b].ctypes.data for b in range(nb)])
+    lens = (ctypes.c_size_t * nb)(*[k * S] * nb)
+    _lib.check(_lib.lib.gec_encode_batch(rs._h, nb, dp, lens, S, pp), "gec_encode_batch")
+    full = np.concatenate([data, parity], axis=1)
+    sp = (ctypes.c_void_p * (nb * n))()
+    op = (ctypes.c_void_p * (nb * n))()
+    outs = np.full((nb, n, S), 0xEE, dtype=np.uint8)
+    # block 0: shard 3 lost and wanted; block 1: nothing lost, shard 5 "wanted" although it is present; block 2: shard 12 lost, not wanted
+    for b in range(nb):
+        for j in range(n):
+            sp[b * n + j] = full[b, j].ctypes.data
+    sp[0 * n + 3] = None
+    op[0 * n + 3] = outs[0, 3].ctypes.data
+    op[1 * n + 5] = outs[1, 5].ctypes.data
+    sp[2 * n + 12] = None
+    ins = np.full((nb, n, 32), 0xAA, dtype=np.uint8)
+    osum = np.full((nb, n, 32), 0xBB, dtype=np.uint8)
+    _lib.check(_lib.lib.gec_reconstruct_hash_batch(rs._h, nb, sp, op, S, 0, ins.ctypes.data_as(u8pp), osum.ctypes.data_as(u8pp)),
+               "gec_reconstruct_hash_batch")
+    assert np.array_equal(outs[0, 3], full[0, 3]) and osum[0, 3].tobytes() == g.shardsum(full[0, 3].tobytes())
+    read0 = [j for j in range(n) if j != 3][:k]
+    assert all(ins[0, j].tobytes() == g.shardsum(full[0, j].tobytes()) for j in read0)
+    for b in (1, 2):                                   # nothing wanted: not read, nothing written
+        assert (ins[b] == 0xAA).all() and (osum[b] == 0xBB).all() and (outs[b] == 0xEE).all()

@@ -24,7 +24,7 @@ from garage_amd import block_native as bn  # noqa: E402
 
 def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, seed: int = 2026, k: int = 10, m: int = 4,
          state_dir: str | None = None, verbose: bool = True, node_dirs_root: str | None = None, ndev: int = 1, layout_changes: bool = True,
-         nreaders: int = 2) -> dict:
+         nreaders: int = 2, nwriters: int = 1) -> dict:
     rng = np.random.default_rng(seed)
     codec = g.ReedSolomon(k, m, backend=backend) if ndev == 1 else [g.ReedSolomon(k, m, backend=backend) for _ in range(ndev)]
     n, nnodes = k + m, k + m + 2
@@ -41,6 +41,7 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
     pinned: dict[bytes, bytes] = {}        # blocks that are never dereferenced: what the concurrent readers read
     reader_stop = threading.Event()
     reader_fail: list[str] = []
+    fail_hashes: list[bytes] = []
     reader_ops = [0, 0]
 
     def reader(idx):
@@ -73,9 +74,49 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
                 reader_ops[1] += len(data)
             except bn.BlockError as e:
                 reader_fail.append(f"reader {idx}: {h.hex()[:16]}: {e}")
+                fail_hashes.append(h)
                 return
 
-    readers = [threading.Thread(target=reader, args=(i,)) for i in range(nreaders)]
+    writer_ops = [0]
+
+    def writer(idx):
+        """A PutObject beside everything else: its blocks go through the queue as futures, three in flight, tagged with the
+        request's OrderTag stream (put.rs:486-511), each read back as soon as it is stored, then dereferenced again."""
+        r3 = np.random.default_rng(seed * 77 + idx)
+        stream = 1_000_000 * (idx + 1)
+        while not reader_stop.is_set():
+            stream += 1
+            blocks = [r3.integers(0, 256, int(r3.integers(1, min(max_len, 200_000))), dtype=np.uint8).tobytes() for _ in range(int(r3.integers(1, 7)))]
+            hashes = [bn.blake2sum(b) for b in blocks]
+            pend = []
+            try:
+                for order, (h, b) in enumerate(zip(hashes, blocks)):
+                    pend.append(bt.submit(h, b, order_tag=(stream, order)))
+                    mgr.block_incref(h)
+                    if len(pend) == 3:
+                        bt.wait(pend.pop(0))
+                for tk in pend:
+                    bt.wait(tk)
+                for h, b in zip(hashes, blocks):
+                    if mgr.rpc_get_block(h, max_len + 4096) != b:
+                        reader_fail.append(f"writer {idx}: wrong bytes read back for {h.hex()[:16]}")
+                        return
+                    mgr.block_decref(h)
+                writer_ops[0] += len(blocks)
+            except bn.Quorum:
+                for tk in pend:                                    # (the tickets own the queue's view of the buffers: wait them all out)
+                    try:
+                        bt.wait(tk)
+                    except bn.BlockError:
+                        pass
+                for h in hashes:                                   # (more nodes down than the write quorum allows: the put is refused)
+                    mgr.block_decref(h)
+            except bn.BlockError as e:
+                reader_fail.append(f"writer {idx}: {e}")
+                fail_hashes.extend(hashes)
+                return
+
+    readers = [threading.Thread(target=reader, args=(i,)) for i in range(nreaders)] + [threading.Thread(target=writer, args=(i,)) for i in range(nwriters)]
     for t in readers:
         t.start()
     ops = dict(put=0, get=0, stream=0, range=0, raw=0, queue_get=0, queue_put=0, down=0, up=0, corrupt=0, delete=0, decref=0, clock=0,
@@ -131,6 +172,10 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
                     hdrs.append((j, b[8], int.from_bytes(b[12:20], "little"), int.from_bytes(b[20:24], "little")))
                 except bn.BlockError:
                     hdrs.append((j, None))
+            if node_dirs_root:
+                import glob
+                files = sorted(os.path.relpath(f, node_dirs_root) for f in glob.glob(os.path.join(node_dirs_root, "node*", h.hex()[:2], h.hex()[2:4], h.hex() + "*")))
+                lines.append(f"  files of {h.hex()[:16]}: {[f.replace(h.hex(), '<h>') for f in files]}")
             elsewhere = {j: [nd for nd in range(nnodes) if nd != who[j] and mgr.node_has_shard(nd, h, j)] for j in range(n)}
             lines.append(f"  shards on OTHER nodes than the current layout's: { {j: v for j, v in elsewhere.items() if v} }")
             lines.append(f"  {h.hex()[:16]} dev {mgr.device_of_hash(h)} rc {mgr.block_rc(h)} len {len(live.get(h, b''))} again-bad {mgr.scrub([h]) == [h]} "
@@ -160,7 +205,7 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
         down.clear()
         for h in damaged:
             mgr.put_to_resync(h, 0)
-        deadline = time.time() + 60
+        deadline = time.time() + 20
         while True:                                              # the background workers (and this call) drain what is due
             mgr.resync_all()
             errs = mgr.list_resync_errors()
@@ -171,7 +216,9 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
                     pass                                         # (a background worker has just cleared it)
             if not errs and not mgr.scrub(list(damaged)):
                 break
-            assert time.time() < deadline, f"resync does not converge: {len(errs)} errored blocks"
+            assert time.time() < deadline, diagnose([e["hash"] for e in errs] + mgr.scrub(list(damaged)),
+                                                    f"resync does not converge: errored {[(e['hash'].hex()[:12], e['error_count'], e['refcount']) for e in errs][:6]}, "
+                                                    f"damaged still bad {len(mgr.scrub(list(damaged)))}, last error {bn.lib.gbm_last_error()!r}")
             time.sleep(0.01)
         damaged.clear()
         hs = list(live)
@@ -190,8 +237,18 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
             # everything stored has been walked since the layout changed: strays offloaded to their new owners, the old
             # version can go (reads stop consulting it) -- and every block must still be all there
             mgr.repair_all()
-            mgr.resync_all()
-            assert mgr.list_resync_errors() == []
+            for attempt in range(200):
+                mgr.resync_all()
+                errs = mgr.list_resync_errors()       # (a writer's block whose put has not landed yet is "missing" to a pass)
+                if not errs:
+                    break
+                for e in errs:
+                    try:
+                        mgr.resync_clear_backoff(e["hash"])
+                    except bn.BlockError:
+                        pass
+                time.sleep(0.01)
+            assert not errs, diagnose([e["hash"] for e in errs], "the repair pass after a layout change leaves errors")
             mgr.layout_trim()
             layout_pending = False
             bad = settled_scrub(hs)
@@ -217,96 +274,108 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
 
     t0 = time.time()
     it = 0
-    while time.time() - t0 < seconds:
-        it += 1
-        r = rng.random()
-        if r < 0.30 or len(live) < 8:
-            data = new_block()
-            h = bn.blake2sum(data)
-            pc = bool(rng.random() < 0.3)
-            if rng.random() < 0.4:
-                ops["queue_put"] += 1
-                bt.put_block(h, data, prevent_compression=pc)
-            else:
-                ops["put"] += 1
-                mgr.rpc_put_block(h, data, prevent_compression=pc)
-            if h not in live:
-                mgr.block_incref(h)
-            live[h] = data
-            if len(pinned) < 64:
-                pinned[h] = data
-            nbytes += len(data)
-        elif r < 0.62:
-            h = list(live)[int(rng.integers(len(live)))]
-            try:
-                check_read(h, live[h])
-            except (bn.BlockError, AssertionError) as e:
-                raise AssertionError(diagnose([h], f"a read of a live block failed: {e!r}; nodes down {sorted(down)}, damaged {damaged.get(h, 0)}, "
-                                                   f"settings {settings}")) from e
-        elif r < 0.67 and len(down) < 2:
-            nd = int(rng.integers(nnodes))
-            if nd not in down:
-                ops["down"] += 1
-                down.add(nd)
-                mgr.node_set_down(nd, True)
-        elif r < 0.72 and down:
-            ops["up"] += 1
-            nd = down.pop()
-            mgr.node_set_down(nd, False)
-        elif r < 0.80:
-            # one shard of a live block goes away or goes bad (its checksum no longer matches): with <= 2 nodes down and
-            # <= 1 damaged shard per block since the last quiesce, every block keeps >= k good shards
-            h = list(live)[int(rng.integers(len(live)))]
-            if damaged.get(h, 0) == 0 and len(live[h]) > 0:
-                who = mgr.storage_nodes_of(h)
-                j = int(rng.integers(n))
-                if who[j] not in down and mgr.node_has_shard(who[j], h, j):
-                    damaged[h] = 1
-                    if rng.random() < 0.5:
-                        ops["delete"] += 1
-                        mgr.node_delete_shard(who[j], h, j)
-                    else:
-                        ops["corrupt"] += 1
-                        mgr.node_corrupt_shard(who[j], h, j, int(rng.integers(0, 64)), 1 << int(rng.integers(8)), fix_checksum=False)
-        elif r < 0.84 and len(live) > 16:
-            ops["decref"] += 1
-            h = list(live)[int(rng.integers(len(live)))]
-            if h in pinned:
-                continue
-            mgr.block_decref(h)
-            del live[h]
-            damaged.pop(h, None)
-        elif r < 0.88:
-            ops["clock"] += 1
-            mgr.clock_advance(int(rng.integers(1000, 400_000)))     # GC delays, back-offs and the scrub's pauses run out
-        elif r < 0.91:
-            try:
-                mgr.scrub_worker_command(int(rng.choice([bn.SCRUB_START, bn.SCRUB_START, bn.SCRUB_PAUSE, bn.SCRUB_RESUME, bn.SCRUB_CANCEL])), 20)
-                ops["scrub_start"] += 1
-            except bn.BlockError:
-                pass                                                # does not fit the worker's state: refused, nothing changes
-        if it % 150 == 0:
-            quiesce()
-            settings["hedge_us"] = int(rng.choice([0, 0, 300]))      # the hedged gather on some stretches
-            settings["verify"] = str(rng.choice(["off", "off", "rebuilt", "always"]))
-            mgr.set_read_hedge(settings["hedge_us"])
-            mgr.set_verify_block_hash(settings["verify"])
-        assert not reader_fail, reader_fail
-    quiesce()
-    reader_stop.set()
-    for t in readers:
-        t.join()
+    try:
+        while time.time() - t0 < seconds:
+            it += 1
+            r = rng.random()
+            if r < 0.30 or len(live) < 8:
+                data = new_block()
+                h = bn.blake2sum(data)
+                pc = bool(rng.random() < 0.3)
+                if rng.random() < 0.4:
+                    ops["queue_put"] += 1
+                    bt.put_block(h, data, prevent_compression=pc)
+                else:
+                    ops["put"] += 1
+                    mgr.rpc_put_block(h, data, prevent_compression=pc)
+                if h not in live:
+                    mgr.block_incref(h)
+                if down:
+                    # the shards of the nodes that are down did not get written (the put went through on its write quorum; they
+                    # are queued as stragglers): until the next quiesce this block is as damaged as the model lets a block be
+                    damaged[h] = max(damaged.get(h, 0), len(down))
+                live[h] = data
+                if len(pinned) < 64:
+                    pinned[h] = data
+                nbytes += len(data)
+            elif r < 0.62:
+                h = list(live)[int(rng.integers(len(live)))]
+                try:
+                    check_read(h, live[h])
+                except (bn.BlockError, AssertionError) as e:
+                    raise AssertionError(diagnose([h], f"a read of a live block failed: {e!r}; nodes down {sorted(down)}, damaged {damaged.get(h, 0)}, "
+                                                       f"settings {settings}")) from e
+            elif r < 0.67 and len(down) < 2:
+                nd = int(rng.integers(nnodes))
+                if nd not in down:
+                    ops["down"] += 1
+                    down.add(nd)
+                    mgr.node_set_down(nd, True)
+            elif r < 0.72 and down:
+                ops["up"] += 1
+                nd = down.pop()
+                mgr.node_set_down(nd, False)
+            elif r < 0.80:
+                # one shard of a live block goes away or goes bad (its checksum no longer matches): with <= 2 nodes down and
+                # <= 1 damaged shard per block since the last quiesce, every block keeps >= k good shards
+                h = list(live)[int(rng.integers(len(live)))]
+                if damaged.get(h, 0) == 0 and len(live[h]) > 0:
+                    who = mgr.storage_nodes_of(h)
+                    j = int(rng.integers(n))
+                    if who[j] not in down and mgr.node_has_shard(who[j], h, j):
+                        damaged[h] = 1
+                        if rng.random() < 0.5:
+                            ops["delete"] += 1
+                            mgr.node_delete_shard(who[j], h, j)
+                        else:
+                            ops["corrupt"] += 1
+                            mgr.node_corrupt_shard(who[j], h, j, int(rng.integers(0, 64)), 1 << int(rng.integers(8)), fix_checksum=False)
+            elif r < 0.84 and len(live) > 16:
+                ops["decref"] += 1
+                h = list(live)[int(rng.integers(len(live)))]
+                if h in pinned:
+                    continue
+                mgr.block_decref(h)
+                del live[h]
+                damaged.pop(h, None)
+            elif r < 0.88:
+                ops["clock"] += 1
+                mgr.clock_advance(int(rng.integers(1000, 400_000)))     # GC delays, back-offs and the scrub's pauses run out
+            elif r < 0.91:
+                try:
+                    mgr.scrub_worker_command(int(rng.choice([bn.SCRUB_START, bn.SCRUB_START, bn.SCRUB_PAUSE, bn.SCRUB_RESUME, bn.SCRUB_CANCEL])), 20)
+                    ops["scrub_start"] += 1
+                except bn.BlockError:
+                    pass                                                # does not fit the worker's state: refused, nothing changes
+            if it % 150 == 0:
+                quiesce()
+                settings["hedge_us"] = int(rng.choice([0, 0, 300]))      # the hedged gather on some stretches
+                settings["verify"] = str(rng.choice(["off", "off", "rebuilt", "always"]))
+                mgr.set_read_hedge(settings["hedge_us"])
+                mgr.set_verify_block_hash(settings["verify"])
+            assert not reader_fail, diagnose(fail_hashes, f"{reader_fail}; nodes down {sorted(down)}, settings {settings}")
+        quiesce()
+    finally:
+        reader_stop.set()                                        # (also when a check fails: the threads must not outlive the walk)
+        for t in readers:
+            t.join()
     assert not reader_fail, reader_fail
     st = mgr.scrub_worker_status()
     met = mgr.block_metrics(bt)
+    # every "checksum does not match" a trip reported was confirmed by the host before a shard was set aside: a verdict the host
+    # does not confirm means the checker was wrong (a block the codec skipped, a device fault) -- none must have happened
+    assert met["unconfirmed_verdicts"] == 0, f"{met['unconfirmed_verdicts']} checksum verdicts were not confirmed by the host"
+    violations = sum(mgr.node_order_violations(nd) for nd in range(nnodes))
+    assert violations == 0, f"{violations} PutShard deliveries out of their stream's order"
     mgr.scrub_worker_stop()
     mgr.resync_worker_stop()
     bt.close()
     res = {"seconds": round(time.time() - t0, 1), "backend": backend, "iterations": it, "live_blocks": len(live), "GiB_checked": round(nbytes / 2**30, 2),
            "concurrent_readers": {"threads": nreaders, "reads": reader_ops[0], "GiB": round(reader_ops[1] / 2**30, 2)},
+           "concurrent_writers": {"threads": nwriters, "blocks_put_tagged_and_read_back": writer_ops[0], "order_violations": violations},
            "ops": ops, "scrub_worker": {x: st[x] for x in ("blocks_scrubbed", "corruptions_detected", "checkpoints_saved", "errors")},
            "metrics": {x: met[x] for x in ("blocks_put", "blocks_get", "ec_reconstructs", "corruption_counter", "resync_counter", "resync_error_counter",
-                                           "resync_recv_counter", "delete_counter")}}
+                                           "resync_recv_counter", "resync_send_counter", "delete_counter", "unconfirmed_verdicts")}}
     mgr.close()
     if verbose:
         print("soak_manager OK:", res)
