@@ -976,3 +976,38 @@ def test_reconstruct_hash_batch_leaves_a_block_nothing_is_wanted_of_untouched(ba
     assert all(ins[0, j].tobytes() == g.shardsum(full[0, j].tobytes()) for j in read0)
     for b in (1, 2):                                   # nothing wanted: not read, nothing written
         assert (ins[b] == 0xAA).all() and (osum[b] == 0xBB).all() and (outs[b] == 0xEE).all()
+
+
+def test_resync_hands_over_a_wanted_shard_that_turned_up_in_hand(backend):
+    """The scan finds shard 2 absent; before the gather a put of the same block (a client's retry) writes it again; the
+    gather -- which asks the first k holders, shard 2's among them -- brings it in.  Present AND wanted: the codec skips
+    such a block (nothing is wanted of it) and leaves its in_sums untouched; the rebuild pass used to compare those with
+    the headers of the k shards it had read and set all ten of them aside.  The window is held open with a slow node."""
+    import threading
+    import time as _t
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    mgr = bn.NativeBlockManager(codec, 16)
+    data = pattern_block(200_000, 31)
+    h = bn.blake2sum(data)
+    mgr.rpc_put_block(h, data)
+    mgr.block_incref(h)
+    who = mgr.storage_nodes_of(h)
+    mgr.node_delete_shard(who[2], h, 2)
+    before = mgr.block_metrics()
+    mgr.node_set_latency(who[13], 150_000)           # the scan asks the nodes in shard order: 150 ms between "2 is absent" and the gather
+    mgr.put_to_resync(h, 0)
+
+    def retry_put():
+        _t.sleep(0.03)
+        mgr.rpc_put_block(h, data)
+
+    t = threading.Thread(target=retry_put)
+    t.start()
+    st = mgr.resync_run()
+    t.join()
+    mgr.node_set_latency(who[13], 0)
+    assert st["errors"] == 0
+    assert all(mgr.node_has_shard(who[j], h, j) for j in range(14)), [mgr.node_has_shard(who[j], h, j) for j in range(14)]
+    after = mgr.block_metrics()
+    assert after["corruption_counter"] == before["corruption_counter"] and after["unconfirmed_verdicts"] == 0
+    assert mgr.scrub([h]) == [] and mgr.rpc_get_block(h) == data
