@@ -29,12 +29,65 @@ namespace {
 
 // Which single shard of an RS-inconsistent stripe is the wrong one?  For every candidate j the stripe is re-derived
 // from the first k of the OTHER shards; the candidate is the culprit iff all the others then agree with what is
-// stored (needs m >= 2).  One gec_reconstruct_batch call: the n candidates are n "blocks" with n erasure patterns.
-int locate_bad_shard(gbm_manager *mg, const Gathered &g)
+// stored (needs m >= 2; with m == 1 the block's own name decides: locate_by_content).  One gec_reconstruct_batch call: the n candidates are n "blocks" with n erasure patterns.
+// With ONE parity shard there is nothing to compare a re-derived stripe with -- but the block's name is the hash of its
+// plain bytes (and a compressed block is a zstd frame with its content checksum): the candidate without which the data
+// shards, rebuilt from the rest, give back the block that the name promises is the culprit.  k + 1 small decodes and as
+// many hashes of one block on the host, for a stripe the scrub has already found inconsistent.
+int locate_by_content(gbm_manager *mg, const Hash &h, const Gathered &g)
+{
+	const int n = mg->n, k = mg->k;
+	const size_t S = g.meta.shard_len, L = g.meta.orig_len;
+	if (L > (size_t)k * S)
+		return -1;
+	auto names_the_block = [&](const std::vector<const uint8_t *> &data_shard) {
+		std::vector<uint8_t> stored(L);
+		for (int j = 0; j < k; ++j) {
+			const size_t lo = (size_t)j * S;
+			if (lo < L)
+				std::memcpy(stored.data() + lo, data_shard[j], std::min(S, L - lo));
+		}
+		if (g.meta.compressed) {  // DataBlock::verify of a Compressed block: the frame decodes cleanly (block.rs:78-83)
+			std::vector<uint8_t> plain;
+			return zstd().decode(stored.data(), stored.size(), kMaxDecompressed, plain);
+		}
+		uint8_t sum[32];
+		blake2sum(stored.data(), stored.size(), sum);
+		return std::memcmp(sum, h.data(), 32) == 0;
+	};
+	std::vector<const uint8_t *> data_shard(k);
+	for (int j = 0; j < k; ++j)
+		data_shard[j] = g.shard[j].data();
+	if (names_the_block(data_shard))
+		return k;  // the data is sound: the parity shard is the odd one
+	int culprit = -1;
+	for (int c = 0; c < k; ++c) {  // data shard c erased and rebuilt from the others
+		std::vector<const uint8_t *> sp(n, nullptr);
+		std::vector<uint8_t *> op(n, nullptr);
+		for (int j = 0; j < n; ++j)
+			if (j != c)
+				sp[j] = g.shard[j].data();
+		Bytes rebuilt = mg->bufs->get(S);
+		op[c] = rebuilt.mut();
+		if (gec_reconstruct_batch(mg->bg_codec(), 1, sp.data(), op.data(), S, 1) != GEC_OK)
+			return -1;
+		data_shard[c] = rebuilt.data();
+		const bool sound = names_the_block(data_shard);
+		data_shard[c] = g.shard[c].data();
+		if (sound) {
+			if (culprit >= 0)
+				return -1;  // ambiguous
+			culprit = c;
+		}
+	}
+	return culprit;
+}
+
+int locate_bad_shard(gbm_manager *mg, const Hash &h, const Gathered &g)
 {
 	const int n = mg->n, k = mg->k;
 	if (mg->m < 2)
-		return -1;
+		return locate_by_content(mg, h, g);
 	const size_t S = g.meta.shard_len;
 	std::vector<const uint8_t *> sp((size_t)n * n, nullptr);
 	std::vector<uint8_t *> op((size_t)n * n, nullptr);
@@ -165,7 +218,7 @@ int verify_scrub_batch(gbm_manager *mg, ScrubBatch &cur, uint64_t st[4], Trace &
 			++st[1];
 			mg->metrics[2]++;
 			const Gathered &gb = g[ids[i]];
-			const int bad = locate_bad_shard(mg, gb);
+			const int bad = locate_bad_shard(mg, batch[ids[i]], gb);
 			if (bad >= 0 && gb.node[bad] >= 0) {
 				mg->nodes[gb.node[bad]]->mark_corrupted(batch[ids[i]], bad);
 				++st[3];

@@ -7,7 +7,7 @@ with what was put; at every quiesce point (all nodes up, resync drained) every l
 back, and the metrics must add up.
 At some quiesce points the cluster layout changes (every block's nodes move; the old version is trimmed once a repair
 pass has offloaded the strays) and a shard rots silently (checksum intact: only the scrub's RS verify can find it).
-usage: soak_manager.py [seconds] [backend: hip|cpu] [max block bytes] [seed] [devices] [directory-nodes root]"""
+usage: soak_manager.py [seconds] [backend: hip|cpu] [max block bytes] [seed] [devices] [directory-nodes root or ""] [k m]"""
 import os
 import sys
 import threading
@@ -28,6 +28,7 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
     rng = np.random.default_rng(seed)
     codec = g.ReedSolomon(k, m, backend=backend) if ndev == 1 else [g.ReedSolomon(k, m, backend=backend) for _ in range(ndev)]
     n, nnodes = k + m, k + m + 2
+    max_down = m // 2                       # nodes down at a time; the other half of the budget of m is for damaged shards
     dirs = [os.path.join(node_dirs_root, f"node{i}") for i in range(nnodes)] if node_dirs_root else None
     mgr = bn.NativeBlockManager(codec, nnodes, dirs, compression_level=1)
     bt = bn.Batcher(mgr, max_blocks=32, max_wait_us=100)
@@ -306,7 +307,7 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
                 except (bn.BlockError, AssertionError) as e:
                     raise AssertionError(diagnose([h], f"a read of a live block failed: {e!r}; nodes down {sorted(down)}, damaged {damaged.get(h, 0)}, "
                                                        f"settings {settings}")) from e
-            elif r < 0.67 and len(down) < 2:
+            elif r < 0.67 and len(down) < max_down:
                 nd = int(rng.integers(nnodes))
                 if nd not in down:
                     ops["down"] += 1
@@ -320,7 +321,7 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
                 # one shard of a live block goes away or goes bad (its checksum no longer matches): with <= 2 nodes down and
                 # <= 1 damaged shard per block since the last quiesce, every block keeps >= k good shards
                 h = list(live)[int(rng.integers(len(live)))]
-                if damaged.get(h, 0) == 0 and len(live[h]) > 0:
+                if damaged.get(h, 0) == 0 and len(live[h]) > 0 and m - max_down >= 1:
                     who = mgr.storage_nodes_of(h)
                     j = int(rng.integers(n))
                     if who[j] not in down and mgr.node_has_shard(who[j], h, j):
@@ -389,5 +390,6 @@ if __name__ == "__main__":
     max_len = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
     seed = int(sys.argv[4]) if len(sys.argv) > 4 else 2026
     ndev = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-    root = sys.argv[6] if len(sys.argv) > 6 else None            # directory nodes under this path (a tmpfs, preferably)
-    soak(secs, backend, max_len, seed, ndev=ndev, node_dirs_root=root)
+    root = (sys.argv[6] or None) if len(sys.argv) > 6 else None  # directory nodes under this path (a tmpfs, preferably); "" = memory
+    k, m = (int(sys.argv[7]), int(sys.argv[8])) if len(sys.argv) > 8 else (10, 4)
+    soak(secs, backend, max_len, seed, k=k, m=m, ndev=ndev, node_dirs_root=root)
