@@ -695,6 +695,26 @@ int gbm_repair_all(gbm_manager *mg, size_t *queued)
 		for (const Hash &h : known)
 			mg->put_to_resync(h, 0);
 		total = known.size();
+		// Phase 2 hands "blocks we are storing but don't actually need" to a resync that DELETES what nothing references
+		// (RcEntry::Absent is deletable, rc.rs:222-228).  The reference's refcount table is durable; this mirror's lives in
+		// memory, so right after a restart it is empty and every stored block would look unneeded.  An empty table beside a
+		// store that is not empty is that situation, not a cluster full of garbage: refused.
+		if (known.empty()) {
+			std::set<Hash> any;
+			for (int p = 0; p < 256 && any.empty(); ++p)
+				for (auto &nd : mg->nodes)
+					if (!nd->down.load()) {
+						nd->list_prefix(p, any);
+						if (!any.empty())
+							break;
+					}
+			bool mine = false;
+			for (const Hash &h : any)
+				mine = mine || mg->owns(h);
+			if (mine)
+				return fail(GBM_E_INVALID_ARG, "the refcount table is empty while blocks are stored: count the references again "
+								   "(gbm_block_incref) before a repair -- resync deletes what nothing references");
+		}
 		for (int p = 0; p < 256; ++p) {
 			std::vector<std::set<Hash>> per(mg->nodes.size());
 			mg->pool->parallel_for(mg->nodes.size(), [&](size_t i) {

@@ -375,7 +375,11 @@ int gbm_resync_config_persist(gbm_manager *m, const char *path);
 int gbm_scrub(gbm_manager *m, size_t n, const uint8_t *hashes, uint8_t *bad_out);
 
 /* RepairWorker (src/block/repair.rs:30-150): queue every hash of the refcount table and every hash that is stored on
- * some node for resync, now.  *queued = distinct hashes. */
+ * some node for resync, now.  *queued = distinct hashes.
+ * The resync deletes a stored block that nothing references (RcEntry::Absent is deletable, src/block/rc.rs:222-228) -- in
+ * the reference the refcount table is durable; in this mirror it lives in memory: after a restart the references must be
+ * counted again (gbm_block_incref, from the block_ref table) BEFORE anything is repaired or resynced.  A repair over an empty
+ * refcount table beside a store that is not empty is refused (GBM_E_INVALID_ARG). */
 int gbm_repair_all(gbm_manager *m, size_t *queued);
 /* ScrubWorker (src/block/repair.rs:234-500): verify EVERYTHING that is stored, batch_blocks (0 = 1024) stripes per device
  * call; corrupt blocks are counted (corruptions_detected) and queued for resync.  For an RS-inconsistent stripe

@@ -244,3 +244,46 @@ def test_resync_worker_count_and_persisted_config(tmp_path):
     assert after["resync_counter"] == before["resync_counter"] + 120 and after["resync_error_counter"] == before["resync_error_counter"]
     assert mgr.scrub(hashes) == [] and mgr.rpc_get_blocks(hashes, 60_000) == blocks
     assert mgr.resync_workers == 2
+
+
+def test_a_new_manager_over_the_same_directories(tmp_path):
+    """A daemon restart: the manager object is gone, the shard files and the workers' records stay.  A new manager over the same
+    node directories reads every block (reads need no refcount), carries the scrub on from the checkpoint the old one left,
+    keeps the resync variables -- and refuses to repair before the references have been counted again."""
+    codec = g.ReedSolomon(10, 4, backend="cpu")
+    dirs = [str(tmp_path / f"node{i}") for i in range(16)]
+    state, cfg = str(tmp_path / "scrub_info"), str(tmp_path / "resync_cfg")
+    mgr = bn.NativeBlockManager(codec, 16, dirs, compression_level=1)
+    hashes, blocks = _store(mgr, 80, size=25_000, salt=4100)
+    mgr.resync_config_persist(cfg)
+    mgr.set_resync_workers(3)
+    mgr.set_tranquility(scrub=100, resync=1)
+    mgr.scrub_worker_start(state, batch_blocks=8, checkpoint_interval_ms=1)
+    mgr.scrub_worker_command(bn.SCRUB_START)
+    _wait(lambda: mgr.scrub_worker_status()["blocks_scrubbed"] >= 16, "two steps")
+    mgr.close()                                         # gbm_destroy stops the workers; the scrub's record holds its position
+
+    mgr2 = bn.NativeBlockManager(codec, 16, dirs, compression_level=1)
+    assert mgr2.rpc_get_blocks(hashes, 60_000) == blocks
+    mgr2.resync_config_persist(cfg)
+    assert mgr2.resync_workers == 3 and mgr2.get_tranquility()[1] == 1
+    mgr2.scrub_worker_start(state, batch_blocks=8)
+    st = mgr2.scrub_worker_status()
+    assert st["state"] == bn.SCRUB_RUNNING and st["tranquility"] == 100 and 0 < st["progress"] < 1
+    mgr2.set_tranquility(scrub=0)
+    _wait(lambda: mgr2.scrub_worker_status()["state"] == bn.SCRUB_FINISHED, "the carried-on pass")
+    st = mgr2.scrub_worker_status()
+    assert 0 < st["blocks_scrubbed"] <= 80 - 16 and st["corruptions_detected"] == 0
+    # The refcount table did not survive (the reference keeps it in its metadata DB; the mirror's is in memory): until the
+    # references are counted again every stored block looks unneeded, and the resync DELETES what nothing references
+    # (RcEntry::Absent is deletable, rc.rs:222-228).  A repair in that state is refused; after the increfs it repairs.
+    who = mgr2.storage_nodes_of(hashes[5])
+    mgr2.node_delete_shard(who[7], hashes[5], 7)
+    with pytest.raises(bn.BlockError, match="the refcount table is empty while blocks are stored"):
+        mgr2.repair_all()
+    for h in hashes:
+        mgr2.block_incref(h)
+    assert mgr2.repair_all() == 80
+    st = mgr2.resync_run()
+    assert st["rebuilt"] == 1 and st["deleted"] == 0 and mgr2.scrub(hashes) == []
+    assert mgr2.rpc_get_blocks(hashes, 60_000) == blocks
