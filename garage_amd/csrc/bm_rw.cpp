@@ -799,7 +799,7 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 		return rc;
 	std::vector<size_t> again;
 	for (size_t b = 0; b < nb; ++b)
-		if (rcs[b] == GBM_E_MISSING_BLOCK)
+		if (rcs[b] == GBM_E_MISSING_BLOCK || rcs[b] == GBM_E_CORRUPT_DATA)  // (Corrupt: a bad shard was met AND too few others were found)
 			again.push_back(b);
 	if (again.empty())
 		return rc;
