@@ -154,13 +154,13 @@ static void run(int k, int m, const char *dir_root)
 	CHECK(gbm_rpc_get_block(mg, hashes.data() + 32 * 3, nullptr, out.data(), out.size(), &got) == GBM_E_MISSING_BLOCK);
 
 	// ScrubWorker over everything that is stored (memory stripes / directory walk): block 2 still carries the silent
-	// corruption inflicted above (parity shard k, checksum re-stamped).  The scrub finds it; with m >= 2 it also says
-	// WHICH shard is wrong, sets it aside, and the resync that follows rebuilds it.
+	// corruption inflicted above (parity shard k, checksum re-stamped).  The scrub finds it and says WHICH shard is wrong
+	// (m >= 2: by leave-one-out decodes; m == 1: by the block's own hash), sets it aside, and the resync that follows rebuilds it.
 	uint64_t ss[4], sstate[2];
 	CHECK(gbm_scrub_all(mg, 3, ss) == GBM_OK);
-	CHECK(ss[0] >= 3 && ss[1] == 1 && ss[2] >= 1 && ss[3] == (m >= 2 ? 1u : 0u));
+	CHECK(ss[0] >= 3 && ss[1] == 1 && ss[2] >= 1 && ss[3] == 1u);
 	CHECK(gbm_scrub_state(mg, sstate) == GBM_OK && sstate[0] == 1 && sstate[1] > 0);
-	if (m >= 2) {
+	{
 		CHECK(!gbm_node_has_shard(mg, who[k], h, k));
 		CHECK(gbm_resync_all(mg, &changed) == GBM_OK && changed >= 1);
 		CHECK(gbm_node_has_shard(mg, who[k], h, k));
