@@ -69,7 +69,7 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 	// (`taken(j)`: shard j is already covered this round; a j whose request failed is asked again from the holder
 	// in the next older layout version)
 	auto next_candidate = [&](size_t b, const std::function<bool(int)> &taken, std::vector<int> &who, int &who_v,
-				  int &j_out) -> bool {
+				  int &j_out, size_t *c_out = nullptr) -> bool {
 		Gathered &g = gs[b];
 		if (g.tried.size() != ncand)
 			g.tried.assign(ncand, 0);
@@ -83,6 +83,8 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 			if (have(g, j) || taken(j))
 				continue;
 			g.tried[c] = 1;
+			if (c_out)
+				*c_out = c;
 			if (v != who_v) {
 				mg->nodes_of(hs[b], v, who);
 				who_v = v;
@@ -123,7 +125,7 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 			// asked as well, and a block moves on as soon as it has its shards from whoever answered
 			// first.  Requests that lose the race are abandoned, not cancelled: they own their state.
 			struct Flight {
-				size_t b;
+				size_t b, cand = 0;  // cand: the candidate's index (it is given back when the request is abandoned)
 				int j, node;
 				Hash h;
 				gbm_order_tag tag;
@@ -158,10 +160,12 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 					}
 					return false;
 				};
-				while (launched < count && next_candidate(b, taken, who[b], who_v[b], j)) {
+				size_t cand = 0;
+				while (launched < count && next_candidate(b, taken, who[b], who_v[b], j, &cand)) {
 					flights_of[b].push_back(flights.size());
 					auto f = std::make_shared<Flight>();
 					f->b = b;
+					f->cand = cand;
 					f->j = j;
 					f->node = who[b][j];
 					f->h = hs[b];
@@ -227,9 +231,16 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 					break;
 			}
 			rd->over = true;
-			for (auto &f : flights)
+			for (auto &f : flights) {
 				if (f->done && f->answered && f->rs.ok)
 					accept(per[f->b], f->b, f->j, f->node, std::move(f->rs.shard));
+				else if (!f->done)
+					// abandoned, not answered: its holder has not been heard -- if what the round did bring in does not hold
+					// up (a shard that fails its checksum), the next round may ask it again.  (A round that was satisfied by a
+					// parity shard which then proved corrupt used to find the slow data shard's holder "already asked" and
+					// gave the block up as corrupt, with one good shard more than it needed still out there.)
+					gs[f->b].tried[f->cand] = 0;
+			}
 		}
 		std::vector<Cand *> cands;
 		for (auto &v : per)

@@ -1038,3 +1038,25 @@ def test_scrub_locates_silent_rot_with_one_parity_shard(backend, compress):
         assert not mgr.node_has_shard(mgr.storage_nodes_of(hashes[victim])[idx], hashes[victim], idx)
     assert mgr.resync_run()["rebuilt"] == 3
     assert mgr.scrub(hashes) == [] and mgr.rpc_get_blocks(hashes, 200_000) == blocks
+
+
+def test_a_hedged_round_satisfied_by_a_corrupt_parity_shard_asks_the_slow_holder_again(backend):
+    """RS(3,1), hedging on, data shard 2's node slow, the parity shard corrupt.  The hedge timer fires, the parity holder answers,
+    the round has its three answers and abandons the slow request -- then the parity shard fails its checksum.  The slow
+    holder was "already asked", so the read gave the block up as corrupt with a good shard still out there (found by
+    tools/soak_manager.py on RS(3,1)); an abandoned request's holder is asked again now."""
+    codec = g.ReedSolomon(3, 1, backend=backend)
+    mgr = bn.NativeBlockManager(codec, 6)
+    data = pattern_block(120_000, 17)
+    h = bn.blake2sum(data)
+    mgr.rpc_put_block(h, data)
+    mgr.block_incref(h)
+    who = mgr.storage_nodes_of(h)
+    mgr.node_corrupt_shard(who[3], h, 3, 11, 0x02, fix_checksum=False)
+    mgr.node_set_latency(who[2], 40_000)
+    mgr.set_read_hedge(300)
+    for _ in range(3):
+        assert mgr.rpc_get_block(h) == data
+    assert b"".join(mgr.rpc_get_block_streaming(h)) == data
+    mgr.node_set_latency(who[2], 0)
+    assert mgr.hedged_reads >= 1 and mgr.metrics["corruption_counter"] >= 1
