@@ -7,6 +7,7 @@ with what was put; at every quiesce point (all nodes up, resync drained) every l
 back, and the metrics must add up.
 At some quiesce points the cluster layout changes (every block's nodes move; the old version is trimmed once a repair
 pass has offloaded the strays) and a shard rots silently (checksum intact: only the scrub's RS verify can find it).
+SOAK_READERS / SOAK_WRITERS: reader and writer threads beside the walk (2 / 1).
 usage: soak_manager.py [seconds] [backend: hip|cpu] [max block bytes] [seed] [devices] [directory-nodes root or ""] [k m]"""
 import os
 import sys
@@ -392,4 +393,5 @@ if __name__ == "__main__":
     ndev = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     root = (sys.argv[6] or None) if len(sys.argv) > 6 else None  # directory nodes under this path (a tmpfs, preferably); "" = memory
     k, m = (int(sys.argv[7]), int(sys.argv[8])) if len(sys.argv) > 8 else (10, 4)
-    soak(secs, backend, max_len, seed, k=k, m=m, ndev=ndev, node_dirs_root=root)
+    soak(secs, backend, max_len, seed, k=k, m=m, ndev=ndev, node_dirs_root=root, nreaders=int(os.environ.get("SOAK_READERS", "2")),
+         nwriters=int(os.environ.get("SOAK_WRITERS", "1")))
