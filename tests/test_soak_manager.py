@@ -25,3 +25,14 @@ def test_soak_on_the_hip_backend(tmp_path):
     res = soak_manager.soak(12.0, "hip", 1 << 20, 11, state_dir=str(tmp_path), verbose=False)
     assert res["ops"]["quiesce"] >= 2 and res["scrub_worker"]["errors"] == 0 and res["iterations"] > 300
     assert res["metrics"]["ec_reconstructs"] > 0 and res["metrics"]["resync_recv_counter"] > 0
+
+
+def test_soak_over_directory_nodes_with_daemon_restarts(tmp_path):
+    """Directory nodes (two devices): now and then the manager is destroyed and a new one opened over the same directories --
+    references counted again from the model, the ScrubWorker carrying on from its record -- with the reader and writer threads
+    picking up where they stood."""
+    root = tmp_path / "nodes"
+    root.mkdir()
+    res = soak_manager.soak(10.0, "cpu", 80_000, 5, state_dir=str(tmp_path), node_dirs_root=str(root), ndev=2, verbose=False)
+    assert res["ops"].get("restart", 0) >= 1 and res["ops"]["quiesce"] >= 3 and res["scrub_worker"]["errors"] == 0
+    assert res["concurrent_readers"]["reads"] > 100 and res["concurrent_writers"]["order_violations"] == 0

@@ -5,6 +5,8 @@ and coming back, shards deleted or corrupted under the readers, refcounts droppe
 -- while THREE resync workers and the ScrubWorker run in the background the whole time.  Every byte read is compared
 with what was put; at every quiesce point (all nodes up, resync drained) every live block must scrub clean and read
 back, and the metrics must add up.
+Over directory nodes the daemon is restarted now and then: a new manager over the same directories, the references
+counted again from the model, the ScrubWorker carrying on from its record.
 At some quiesce points the cluster layout changes (every block's nodes move; the old version is trimmed once a repair
 pass has offloaded the strays) and a shard rots silently (checksum intact: only the scrub's RS verify can find it).
 SOAK_READERS / SOAK_WRITERS: reader and writer threads beside the walk (2 / 1).
@@ -31,12 +33,39 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
     n, nnodes = k + m, k + m + 2
     max_down = m // 2                       # nodes down at a time; the other half of the budget of m is for damaged shards
     dirs = [os.path.join(node_dirs_root, f"node{i}") for i in range(nnodes)] if node_dirs_root else None
-    mgr = bn.NativeBlockManager(codec, nnodes, dirs, compression_level=1)
-    bt = bn.Batcher(mgr, max_blocks=32, max_wait_us=100)
-    mgr.set_tranquility(scrub=0, resync=0)
-    mgr.set_resync_workers(3)
-    mgr.resync_worker_start()
-    mgr.scrub_worker_start(os.path.join(state_dir, "scrub_info") if state_dir else None, batch_blocks=16, checkpoint_interval_ms=50)
+    layout_version = 0                      # how often the layout has changed (the manager's own counter does not survive a restart)
+
+    def open_manager():
+        m_ = bn.NativeBlockManager(codec, nnodes, dirs, compression_level=1)
+        for _ in range(layout_version):    # the cluster layout is the cluster's: a restarted daemon learns the current version again
+            m_.layout_update()
+        m_.layout_trim()
+        b_ = bn.Batcher(m_, max_blocks=32, max_wait_us=100)
+        m_.set_tranquility(scrub=0, resync=0)
+        m_.set_resync_workers(3)
+        return m_, b_
+
+    def start_workers():
+        mgr.resync_worker_start()
+        mgr.scrub_worker_start(os.path.join(state_dir, "scrub_info") if state_dir else None, batch_blocks=16, checkpoint_interval_ms=50)
+        mgr.set_tranquility(scrub=0)       # (a persisted record's value wins at the start)
+
+    mgr, bt = open_manager()
+    start_workers()
+    # the reader and writer threads stand still while the manager is being replaced (a daemon restart)
+    gate = threading.Condition()
+    active, pausing = [0], [False]
+
+    def enter():
+        with gate:
+            while pausing[0]:
+                gate.wait()
+            active[0] += 1
+
+    def leave():
+        with gate:
+            active[0] -= 1
+            gate.notify_all()
     live: dict[bytes, bytes] = {}
     down: set[int] = set()
     damaged: dict[bytes, int] = {}          # shards of a live block deleted / corrupted since the last quiesce
@@ -57,6 +86,7 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
                 continue
             h, data = items[int(r2.integers(len(items)))]
             how = r2.random()
+            enter()
             try:
                 if how < 0.3:
                     got = mgr.rpc_get_block(h, max_len + 4096)
@@ -78,6 +108,8 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
                 reader_fail.append(f"reader {idx}: {h.hex()[:16]}: {e}")
                 fail_hashes.append(h)
                 return
+            finally:
+                leave()
 
     writer_ops = [0]
 
@@ -91,6 +123,7 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
             blocks = [r3.integers(0, 256, int(r3.integers(1, min(max_len, 200_000))), dtype=np.uint8).tobytes() for _ in range(int(r3.integers(1, 7)))]
             hashes = [bn.blake2sum(b) for b in blocks]
             pend = []
+            enter()
             try:
                 for order, (h, b) in enumerate(zip(hashes, blocks)):
                     pend.append(bt.submit(h, b, order_tag=(stream, order)))
@@ -117,6 +150,8 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
                 reader_fail.append(f"writer {idx}: {e}")
                 fail_hashes.extend(hashes)
                 return
+            finally:
+                leave()
 
     readers = [threading.Thread(target=reader, args=(i,)) for i in range(nreaders)] + [threading.Thread(target=writer, args=(i,)) for i in range(nwriters)]
     for t in readers:
@@ -234,7 +269,7 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
         assert met["block_write_duration"]["count"] > 0 and met["block_read_duration"]["bucket"][-1] == met["block_read_duration"]["count"]
         st = mgr.scrub_worker_status()
         assert st["errors"] == 0, st
-        nonlocal layout_pending
+        nonlocal layout_pending, layout_version
         if layout_pending:
             # everything stored has been walked since the layout changed: strays offloaded to their new owners, the old
             # version can go (reads stop consulting it) -- and every block must still be all there
@@ -273,7 +308,45 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
         if layout_changes and ops["quiesce"] % 4 == 1:
             ops["layout_update"] += 1
             mgr.layout_update()                                  # every block's nodes move; reads consult both versions
+            layout_version += 1
             layout_pending = True
+        elif node_dirs_root and state_dir and not layout_pending and ops["quiesce"] % 5 == 2:
+            restart()
+
+    def restart():
+        """The daemon goes down and comes back over the same directories: the shard files, scrub_info and resync_cfg are what
+        survives; the refcounts are counted again from the model (the reference's block_ref table) BEFORE any worker runs."""
+        nonlocal mgr, bt
+        ops["restart"] = ops.get("restart", 0) + 1
+        with gate:
+            pausing[0] = True
+            while active[0]:
+                gate.wait()
+        try:
+            mgr.scrub_worker_stop()
+            mgr.resync_worker_stop()
+            bt.close()
+            mgr.close()
+            mgr, bt = open_manager()
+            try:
+                mgr.repair_all()
+                raise AssertionError("a repair over an empty refcount table was not refused")
+            except bn.BlockError:
+                pass
+            for h in live:
+                mgr.block_incref(h)
+            mgr.set_read_hedge(settings["hedge_us"])
+            mgr.set_verify_block_hash(settings["verify"])
+            start_workers()
+            hs = list(live)
+            for i in range(0, len(hs), 64):
+                part = hs[i:i + 64]
+                assert mgr.rpc_get_blocks(part, max_len + 4096) == [live[h] for h in part], "bulk get after the restart"
+            assert settled_scrub(hs) == [], "a block does not scrub clean after the restart"
+        finally:
+            with gate:
+                pausing[0] = False
+                gate.notify_all()
 
     t0 = time.time()
     it = 0
@@ -393,5 +466,5 @@ if __name__ == "__main__":
     ndev = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     root = (sys.argv[6] or None) if len(sys.argv) > 6 else None  # directory nodes under this path (a tmpfs, preferably); "" = memory
     k, m = (int(sys.argv[7]), int(sys.argv[8])) if len(sys.argv) > 8 else (10, 4)
-    soak(secs, backend, max_len, seed, k=k, m=m, ndev=ndev, node_dirs_root=root, nreaders=int(os.environ.get("SOAK_READERS", "2")),
+    soak(secs, backend, max_len, seed, k=k, m=m, ndev=ndev, node_dirs_root=root, state_dir=root, nreaders=int(os.environ.get("SOAK_READERS", "2")),
          nwriters=int(os.environ.get("SOAK_WRITERS", "1")))
