@@ -791,6 +791,8 @@ void assemble(const Gathered &g, int k, uint8_t *dst)
 
 static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
 			   const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate);
+static int get_blocks_again(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
+			    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate);
 
 // raw == true: rpc_get_raw_block (stored bytes + header); false: rpc_get_block (plain bytes).
 // While a layout change is being followed (more than one version is active) resync MOVES shards: PutShard to the new owner,
@@ -798,7 +800,7 @@ static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, co
 // finds the block "missing" although it was whole the whole time -- the reference's readers have the same window
 // (block_read_nodes_of walks the versions in order, rpc_helper.rs:570-619) and leave it to the client's retry; with k
 // holders to hear from instead of one it is wider here, so a block that comes back Missing during a transition is asked
-// for ONCE more: moves only go forward, the second walk meets the shards where the first one's came from.
+// for again (twice at most): moves only go forward, a later walk meets the shards where an earlier one's came from.
 int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
 		    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate)
 {
@@ -806,8 +808,28 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
 	DurationScope read_time(mg->bmx.read_duration);  // block.read_duration (metrics.rs:117-121): one observation per call
 	int rc = get_blocks_once(mg, nb, hashes, tags, out, cap, len_out, rcs, raw, headers, gate);
-	if (rc != GBM_OK || mg->layout_cur.load() == mg->layout_oldest.load())
-		return rc;
+	// (twice more at most, a millisecond and five apart: a slow reader beside a fast mover can lose several shards of one block to
+	// the window in one walk; the mover is done with a block in well under that)
+	for (int attempt = 1; attempt <= 2 && rc == GBM_OK && mg->layout_cur.load() != mg->layout_oldest.load(); ++attempt) {
+		bool any = false;
+		for (size_t b = 0; b < nb && !any; ++b)
+			any = rcs[b] == GBM_E_MISSING_BLOCK || rcs[b] == GBM_E_CORRUPT_DATA;
+		if (!any)
+			break;
+		if (attempt == 2)
+			std::this_thread::sleep_for(std::chrono::milliseconds(5));
+		else
+			std::this_thread::sleep_for(std::chrono::milliseconds(1));
+		rc = get_blocks_again(mg, nb, hashes, tags, out, cap, len_out, rcs, raw, headers, gate);
+	}
+	return rc;
+}
+
+// the blocks of a call that came back Missing (or Corrupt with too few shards found), asked for once more
+static int get_blocks_again(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
+			    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate)
+{
+	int rc = GBM_OK;
 	std::vector<size_t> again;
 	for (size_t b = 0; b < nb; ++b)
 		if (rcs[b] == GBM_E_MISSING_BLOCK || rcs[b] == GBM_E_CORRUPT_DATA)  // (Corrupt: a bad shard was met AND too few others were found)
@@ -1686,9 +1708,12 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 		int rc = stream_general(m, hs, hash, order_tag, hdr, raw, out, pos, opened ? &geom : nullptr);
 		// (a block whose shards were being moved to their new owners under the walk -- get_blocks_impl has the story -- is asked
 		// for once more, as long as the general form has not delivered anything itself: it takes up at byte `pos` again)
-		if ((rc == GBM_E_MISSING_BLOCK || rc == GBM_E_CORRUPT_DATA) && out.sent.size() == sent_before && !out.aborted && !out.frame_bad &&
-		    m->layout_cur.load() != m->layout_oldest.load())
+		for (int attempt = 1; attempt <= 2 && (rc == GBM_E_MISSING_BLOCK || rc == GBM_E_CORRUPT_DATA) && out.sent.size() == sent_before &&
+				      !out.aborted && !out.frame_bad && m->layout_cur.load() != m->layout_oldest.load();
+		     ++attempt) {
+			std::this_thread::sleep_for(std::chrono::milliseconds(attempt == 1 ? 1 : 5));
 			rc = stream_general(m, hs, hash, order_tag, hdr, raw, out, pos, opened ? &geom : nullptr);
+		}
 		return rc;
 	}
 	tr.lap("last shard delivered");

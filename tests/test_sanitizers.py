@@ -41,3 +41,13 @@ def test_block_manager_batcher_under_tsan(tmp_path):
     if "FATAL: ThreadSanitizer: unexpected memory mapping" in r.stderr:
         pytest.skip("TSan cannot run in this container (ASLR/memory layout)")
     assert r.returncode == 0 and "all scenarios OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_manager_soak_under_tsan():
+    """tools/soak_tsan.sh: the manager's soak (random walk + three resync workers + the ScrubWorker + reader and writer threads)
+    over ThreadSanitizer builds of libgarage_block and of libgarage_ec's host path, loaded into python with libtsan preloaded.
+    Passes when the soak passes AND ThreadSanitizer has nothing to report."""
+    r = subprocess.run([os.path.join(HERE, "..", "tools", "soak_tsan.sh"), "8", "3"], capture_output=True, text=True, timeout=900)
+    if r.returncode == 77:
+        pytest.skip("TSan cannot run in this container")
+    assert r.returncode == 0 and "ThreadSanitizer reports: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -1,0 +1,44 @@
+#!/bin/bash
+# The manager's soak (tools/soak_manager.py) over ThreadSanitizer builds of the two libraries' host sources: libgarage_block and
+# libgarage_ec's C ABI + CPU backend (no HIP backend: tests/c/ec_nodevice.cpp stands in, as in the other sanitizer builds), loaded
+# into an ordinary python with libtsan preloaded.  Everything happens in a scratch copy of the tree; the tree itself is not touched.
+# usage: tools/soak_tsan.sh [seconds] [seed] [devices] [directory-nodes root or ""]      exit 0 = the soak passed AND TSan reported nothing
+set -eu
+R="$(cd "$(dirname "$0")/.." && pwd)"
+SECS="${1:-10}"; SEED="${2:-3}"; NDEV="${3:-1}"; ROOT="${4:-}"
+W="$(mktemp -d /tmp/soak_tsan.XXXXXX)"
+trap 'rm -rf "$W"' EXIT
+mkdir -p "$W/garage_amd/csrc" "$W/tests/c" "$W/tools" "$W/include" "$W/oracle" "$W/tests"
+cp -r "$R/garage_amd/"*.py "$W/garage_amd/"
+cp "$R/garage_amd/csrc/"*.cpp "$R/garage_amd/csrc/"*.hpp "$W/garage_amd/csrc/"
+cp "$R/tests/c/ec_nodevice.cpp" "$W/tests/c/"
+cp "$R/tests/__init__.py" "$W/tests/" 2>/dev/null || true
+cp "$R/tests/block_manager_cases.py" "$W/tests/"
+cp "$R/tools/soak_manager.py" "$W/tools/"
+cp "$R/include/"*.h "$W/include/"
+cp -r "$R/oracle/"*.py "$R/oracle/"*.so "$W/oracle/" 2>/dev/null || true
+cat > "$W/stubs.cpp" <<'STUBS'
+// the HIP-only exports of libgarage_ec, absent from a host-only link (the python binding resolves every symbol when it loads)
+extern "C" {
+#define STUB(name) int name() { return -100; }
+STUB(gec_get_kernel_variant) STUB(gec_group_allgather_decode) STUB(gec_group_alltoall_decode) STUB(gec_group_bytes_exchanged)
+STUB(gec_group_create) STUB(gec_group_create_with_transport) STUB(gec_group_create_with_transport2) STUB(gec_group_destroy)
+STUB(gec_group_rank) STUB(gec_group_size) STUB(gec_group_slots) STUB(gec_group_unique_id) STUB(gec_launch_geometry) STUB(gec_set_kernel_variant)
+}
+STUBS
+F="-O1 -g -fsanitize=thread -fno-omit-frame-pointer -std=c++17 -fPIC -shared"
+( cd "$W/garage_amd/csrc" &&
+  g++ $F -o ../libgarage_ec.so ec_api.cpp ec_env.cpp ec_cpu.cpp ../../tests/c/ec_nodevice.cpp "$W/stubs.cpp" -lpthread -ldl &&
+  g++ $F -o ../libgarage_block.so bm_core.cpp bm_node.cpp bm_rw.cpp bm_resync.cpp bm_scrub.cpp bm_batcher.cpp -L.. -lgarage_ec -lpthread -ldl -Wl,-rpath,'$ORIGIN' )
+TSAN_LIB="$(gcc -print-file-name=libtsan.so)"
+cd "$W"
+set +e
+LD_PRELOAD="$TSAN_LIB" TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=0" python tools/soak_manager.py "$SECS" cpu 60000 "$SEED" "$NDEV" "$ROOT" > "$W/out.log" 2>&1
+RC=$?
+set -e
+N=$(grep -c "WARNING: ThreadSanitizer" "$W/out.log" || true)
+if grep -q "FATAL: ThreadSanitizer" "$W/out.log"; then echo "soak_tsan: ThreadSanitizer cannot run here"; grep "FATAL: ThreadSanitizer" "$W/out.log" | head -2; exit 77; fi
+tail -1 "$W/out.log" | cut -c1-400
+if [ "$N" != "0" ]; then grep -A14 "WARNING: ThreadSanitizer" "$W/out.log" | head -80; fi
+echo "soak_tsan: soak exit $RC, ThreadSanitizer reports: $N"
+[ "$RC" = "0" ] && [ "$N" = "0" ]
