@@ -2,7 +2,10 @@
 # The manager's soak (tools/soak_manager.py) over ThreadSanitizer builds of the two libraries' host sources: libgarage_block and
 # libgarage_ec's C ABI + CPU backend (no HIP backend: tests/c/ec_nodevice.cpp stands in, as in the other sanitizer builds), loaded
 # into an ordinary python with libtsan preloaded.  Everything happens in a scratch copy of the tree; the tree itself is not touched.
-# usage: tools/soak_tsan.sh [seconds] [seed] [devices] [directory-nodes root or ""]      exit 0 = the soak passed AND TSan reported nothing
+# SAN=address: the same with AddressSanitizer + UBSan builds (use-after-free of a recycled pinned buffer, overruns; python's own
+# leaks are not looked at).
+# usage: [SAN=thread|address] tools/soak_tsan.sh [seconds] [seed] [devices] [directory-nodes root or ""]
+# exit 0 = the soak passed AND the sanitizer reported nothing
 set -eu
 R="$(cd "$(dirname "$0")/.." && pwd)"
 SECS="${1:-10}"; SEED="${2:-3}"; NDEV="${3:-1}"; ROOT="${4:-}"
@@ -26,19 +29,30 @@ STUB(gec_group_create) STUB(gec_group_create_with_transport) STUB(gec_group_crea
 STUB(gec_group_rank) STUB(gec_group_size) STUB(gec_group_slots) STUB(gec_group_unique_id) STUB(gec_launch_geometry) STUB(gec_set_kernel_variant)
 }
 STUBS
-F="-O1 -g -fsanitize=thread -fno-omit-frame-pointer -std=c++17 -fPIC -shared"
+SAN="${SAN:-thread}"
+if [ "$SAN" = "address" ]; then
+  F="-O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -std=c++17 -fPIC -shared"
+  PRE="$(gcc -print-file-name=libasan.so)"
+  export ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0:abort_on_error=0:exitcode=99" UBSAN_OPTIONS="print_stacktrace=1"
+  PAT="ERROR: AddressSanitizer\|runtime error:"
+else
+  F="-O1 -g -fsanitize=thread -fno-omit-frame-pointer -std=c++17 -fPIC -shared"
+  PRE="$(gcc -print-file-name=libtsan.so)"
+  export TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=0"
+  PAT="WARNING: ThreadSanitizer"
+fi
 ( cd "$W/garage_amd/csrc" &&
   g++ $F -o ../libgarage_ec.so ec_api.cpp ec_env.cpp ec_cpu.cpp ../../tests/c/ec_nodevice.cpp "$W/stubs.cpp" -lpthread -ldl &&
   g++ $F -o ../libgarage_block.so bm_core.cpp bm_node.cpp bm_rw.cpp bm_resync.cpp bm_scrub.cpp bm_batcher.cpp -L.. -lgarage_ec -lpthread -ldl -Wl,-rpath,'$ORIGIN' )
-TSAN_LIB="$(gcc -print-file-name=libtsan.so)"
 cd "$W"
 set +e
-LD_PRELOAD="$TSAN_LIB" TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=0" python tools/soak_manager.py "$SECS" cpu 60000 "$SEED" "$NDEV" "$ROOT" > "$W/out.log" 2>&1
+LD_PRELOAD="$PRE" python tools/soak_manager.py "$SECS" cpu 60000 "$SEED" "$NDEV" "$ROOT" > "$W/out.log" 2>&1
 RC=$?
 set -e
-N=$(grep -c "WARNING: ThreadSanitizer" "$W/out.log" || true)
-if grep -q "FATAL: ThreadSanitizer" "$W/out.log"; then echo "soak_tsan: ThreadSanitizer cannot run here"; grep "FATAL: ThreadSanitizer" "$W/out.log" | head -2; exit 77; fi
+N=$(grep -c "$PAT" "$W/out.log" || true)
+if grep -q "FATAL: ThreadSanitizer\|Shadow memory range interleaves\|ASan runtime does not come first" "$W/out.log"; then
+  echo "soak_tsan: the sanitizer cannot run here"; grep "FATAL\|Shadow memory\|does not come first" "$W/out.log" | head -2; exit 77; fi
 tail -1 "$W/out.log" | cut -c1-400
-if [ "$N" != "0" ]; then grep -A14 "WARNING: ThreadSanitizer" "$W/out.log" | head -80; fi
-echo "soak_tsan: soak exit $RC, ThreadSanitizer reports: $N"
+if [ "$N" != "0" ]; then grep -A18 "$PAT" "$W/out.log" | head -90; fi
+echo "soak_tsan: soak exit $RC, $SAN sanitizer reports: $N"
 [ "$RC" = "0" ] && [ "$N" = "0" ]
