@@ -830,6 +830,19 @@ int one_block_rc(int rc1);
 bool confirmed_corrupt(gbm_manager *mg, const uint8_t *data, size_t S, const uint8_t header_sum[32], const char *who);
 // every hash any reachable node holds a shard of (bm_scrub.cpp)
 void list_all_nodes(gbm_manager *mg, std::set<Hash> &all);
+// One step of the scrub (bm_scrub.cpp; gbm_scrub_all and the ScrubWorker take the same steps): a batch of hashes with their
+// shards as the nodes hold them -- accepted on their headers: the checksums come back from the same device trip that checks the
+// stripe against the code --, then that trip and the bookkeeping of what it found.  st: [0] blocks scrubbed, [1] corruptions
+// detected, [2] device verify calls, [3] shards located and set aside; after_trip(t) is called behind every device trip with
+// the time it took (the tranquilizer's place).
+struct ScrubBatch {
+	std::vector<Hash> batch;
+	std::vector<Gathered> g;
+	int rc = GBM_OK;
+	std::string err;
+};
+ScrubBatch read_scrub_batch(gbm_manager *mg, std::vector<Hash> hashes);
+int verify_scrub_batch(gbm_manager *mg, ScrubBatch &cur, uint64_t st[4], Trace &tr, const std::function<void(std::chrono::nanoseconds)> &after_trip);
 // the coalescing queue's figures for the metrics: out[0] = free RAM permits (KiB), [1] put batches, [2] put blocks,
 // [3] get batches, [4] get blocks; summed over the lanes of a front (bm_batcher.cpp)
 void batcher_snapshot(gbm_batcher *b, uint64_t out[5]);
