@@ -3,9 +3,12 @@
 // Layout of the library (include/garage_block.h is the contract; reference anchors are cited there):
 //   bm_core.cpp     errors, zstd, the environment table, manager life cycle and settings, test hooks, metrics
 //   bm_node.cpp     the storage nodes behind ShardRpc: memory- and directory-backed (shard files, two-phase replace)
-//   bm_rw.cpp       rpc_put_block(s) / rpc_get_block(s): gather, fan-out, the one-trip device calls, assembly
-//   bm_resync.cpp   refcounts (RcEntry), the resync queue and its worker, resync_block(s)
-//   bm_scrub.cpp    ScrubWorker / RepairWorker: gbm_scrub, gbm_scrub_all, gbm_repair_all
+//   bm_gather.cpp   the shard gather every read-side path starts with (plain and hedged), PutShard to one node
+//   bm_rw.cpp       rpc_put_block(s) / rpc_get_block(s): fan-out, the one-trip device calls, assembly, retries during a layout change
+//   bm_stream.cpp   the streaming gets and the ranged get
+//   bm_resync.cpp   refcounts (RcEntry), the resync queue and its workers, resync_block(s), list-errors / retry-now
+//   bm_scrub.cpp    the scrub's steps, gbm_scrub, gbm_scrub_all, gbm_repair_all (RepairWorker)
+//   bm_scrub_worker.cpp  the ScrubWorker's life cycle: commands, schedule, persisted checkpoint
 //   bm_batcher.cpp  the coalescing queue in front of the FFI (PUT_BLOCKS_MAX_PARALLEL callers -> device batches)
 // Pure host code: every shard byte and every large checksum batch is computed by libgarage_ec (include/garage_ec.h).
 #pragma once
@@ -775,7 +778,7 @@ struct Gathered {
 	}
 };
 
-// Fetch shards until every block has `want` valid ones of one geometry in hand (or ran out of nodes) -- bm_rw.cpp
+// Fetch shards until every block has `want` valid ones of one geometry in hand (or ran out of nodes) -- bm_gather.cpp
 int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, int want, std::vector<Gathered> &gs,
 		bool verify = true, const std::vector<uint8_t> *only = nullptr);
 // PutShard to one node; false = the node could not be contacted or refused

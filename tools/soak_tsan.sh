@@ -43,13 +43,13 @@ else
 fi
 ( cd "$W/garage_amd/csrc" && cp ../../tests/c/ec_nodevice.cpp "$W/stubs.cpp" . &&
   CF="${F% -shared}" && pids="" &&
-  for src in ec_api ec_env ec_cpu ec_nodevice stubs bm_core bm_node bm_rw bm_resync bm_scrub bm_scrub_worker bm_batcher; do   # side by side: twelve units, ~12 s instead of ~40
+  for src in ec_api ec_env ec_cpu ec_nodevice stubs bm_core bm_node bm_gather bm_rw bm_stream bm_resync bm_scrub bm_scrub_worker bm_batcher; do   # side by side: fourteen units, ~12 s instead of ~40
     g++ $CF -c -o $src.o $src.cpp &
     pids="$pids $!"
   done &&
   for p in $pids; do wait $p; done &&
   g++ $F -o ../libgarage_ec.so ec_api.o ec_env.o ec_cpu.o ec_nodevice.o stubs.o -lpthread -ldl &&
-  g++ $F -o ../libgarage_block.so bm_core.o bm_node.o bm_rw.o bm_resync.o bm_scrub.o bm_scrub_worker.o bm_batcher.o -L.. -lgarage_ec -lpthread -ldl -Wl,-rpath,'$ORIGIN' )
+  g++ $F -o ../libgarage_block.so bm_core.o bm_node.o bm_gather.o bm_rw.o bm_stream.o bm_resync.o bm_scrub.o bm_scrub_worker.o bm_batcher.o -L.. -lgarage_ec -lpthread -ldl -Wl,-rpath,'$ORIGIN' )
 cd "$W"
 set +e
 LD_PRELOAD="$PRE" python tools/soak_manager.py "$SECS" cpu 60000 "$SEED" "$NDEV" "$ROOT" > "$W/out.log" 2>&1
