@@ -36,7 +36,7 @@ SYMBOLS = [
     "gbm_scrub_worker_start", "gbm_scrub_worker_stop", "gbm_scrub_worker_command", "gbm_scrub_worker_status",
     "gbm_block_metrics_get", "gbm_histogram_bounds", "gbm_metrics_prometheus", "gbm_list_resync_errors", "gbm_resync_clear_backoff",
     "gbm_zstd_encode", "gbm_zstd_decode", "gbm_set_resync_workers", "gbm_get_resync_workers", "gbm_resync_config_persist",
-    "gbm_get_tranquility",
+    "gbm_get_tranquility", "gbm_set_put_spot_check", "gbm_test_corrupt_put_sums",
 ]
 
 
@@ -74,6 +74,7 @@ class BlockMetrics(ctypes.Structure):
                                                "bytes_read", "bytes_written", "delete_counter", "corruption_counter")]
                 + [(n, Histogram) for n in ("resync_duration", "block_read_duration", "block_write_duration")]
                 + [(n, ctypes.c_uint64) for n in ("ec_reconstructs", "blocks_put", "blocks_get", "gpu_hashed", "hedged_reads", "unconfirmed_verdicts",
+                                                 "put_spot_checks", "put_spot_check_failures",
                                                  "scrub_corruptions_detected", "scrub_time_last_complete_ms", "tranquilized_ms",
                                                  "batcher_put_batches", "batcher_put_blocks", "batcher_get_batches", "batcher_get_blocks")]
                 + [("devices", ctypes.c_uint32)])
@@ -182,6 +183,8 @@ def _load():
     lib.gbm_scrub_worker_status.argtypes = [vp, ctypes.POINTER(ScrubStatus)]
     lib.gbm_zstd_encode.argtypes = [ctypes.c_char_p, sz, ci, ctypes.c_char_p, sz, ctypes.POINTER(sz)]
     lib.gbm_zstd_decode.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p, sz, ctypes.POINTER(sz)]
+    lib.gbm_set_put_spot_check.argtypes = [vp, ctypes.c_uint]
+    lib.gbm_test_corrupt_put_sums.argtypes = [vp, ci]
     lib.gbm_get_tranquility.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
     lib.gbm_set_resync_workers.argtypes = [vp, ci]
     lib.gbm_get_resync_workers.argtypes = [vp]
@@ -445,6 +448,10 @@ class NativeBlockManager:
         d = dict(zip(self.RESYNC_STATS, [int(x) for x in st]))
         d["rc"] = rc
         return d
+
+    def set_put_spot_check(self, every_n: int) -> None:
+        """Every Nth put trip one device-computed shard checksum is re-computed on the host before anything is sent (0 = never)."""
+        _check(lib.gbm_set_put_spot_check(self._h, every_n), "set_put_spot_check")
 
     def get_tranquility(self) -> tuple[int, int]:
         out = (ctypes.c_uint32 * 2)()

@@ -39,6 +39,7 @@ const EnvRow kEnvRows[] = {
 	{"GBM_BATCHER_GAP_US", "clamp(linger / 10, 20, 100)", "the batcher's linger ends once nobody has arrived for this long (A/B; 0 = the default)"},
 	{"GBM_BATCHER_LONE_SKIP", "1", "1 = a block that arrives alone (nothing in flight, the previous batch a single block) goes without the linger (0 = always linger; A/B)"},
 	{"GBM_BATCHER_DEVICE_TURN", "1", "one put batch and one get batch of a device's queue on the link at a time, the others prepare / fan out meanwhile: 1 = until the codec call returns, 2 = until its bulk transfers are over (gec_thread_link_release: the next batch's upload runs beside this one's last checksum kernels), 0 = trips overlap freely"},
+	{"GBM_PUT_SPOT_CHECK", "16", "every Nth put trip one device-computed shard checksum is re-computed on the host before anything is sent to a node (0 = never, 1 = every trip; gbm_set_put_spot_check overrides it per manager)"},
 	{"GBM_CPU_BLAKE2", "auto", "the manager's own BLAKE2b (block hashes of small gets, shard checks): auto = eight messages at a time with AVX-512, scalar = one at a time (A/B)"},
 };
 long env_long(const char *name, long def)
@@ -67,6 +68,8 @@ const Env &env()
 		v.batcher_lone_skip = env_long("GBM_BATCHER_LONE_SKIP", 1) != 0;
 		const long gp = env_long("GBM_BATCHER_GAP_US", 0);
 		v.batcher_gap_us = (unsigned)(gp > 0 && gp < 100000 ? gp : 0);
+		const long sc = env_long("GBM_PUT_SPOT_CHECK", 16);
+		v.put_spot_check = (unsigned)(sc >= 0 && sc <= 1000000 ? sc : 16);
 		const char *b2 = std::getenv("GBM_CPU_BLAKE2");
 		if (b2 && b2[0] == 's')
 			b2host::mb_mode().store(0);
@@ -337,6 +340,7 @@ int create_one(const gec_codec *codec, int nnodes, const char *const *node_dirs,
 	}
 	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
 	mg->pool.reset(new Pool(std::min(15u, hw - 1)));
+	mg->put_spot_every = env().put_spot_check;
 	// maintenance gets a background-class sibling of the codec (its own staging slots, low-priority streams on a
 	// subset of the CUs, small chunks that yield to the request path); without one it shares the request path's codec
 	if (gec_codec_background(codec, &mg->bg_codec_owned) != GEC_OK)
@@ -588,6 +592,22 @@ int gbm_set_tranquility(gbm_manager *m, int scrub_tranquility, int resync_tranqu
 	return GBM_OK;
 }
 
+int gbm_set_put_spot_check(gbm_manager *m, unsigned every_n)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	GBM_EACH(m, x, x->put_spot_every = every_n);
+	return GBM_OK;
+}
+
+int gbm_test_corrupt_put_sums(gbm_manager *m, int trips)
+{
+	if (!m || trips < 0)
+		return fail(GBM_E_INVALID_ARG, "bad argument");
+	GBM_EACH(m, x, x->test_bad_put_sums = trips);
+	return GBM_OK;
+}
+
 int gbm_get_tranquility(const gbm_manager *m, uint32_t out[2])
 {
 	if (!m || !out)
@@ -826,6 +846,8 @@ void add_one(gbm_manager *x, gbm_block_metrics &o)
 	o.resync_recv_counter += x->bmx.resync_recv_counter.load();
 	o.delete_counter += x->bmx.delete_counter.load();
 	o.unconfirmed_verdicts += x->bmx.unconfirmed_verdicts.load();
+	o.put_spot_checks += x->bmx.put_spot_checks.load();
+	o.put_spot_check_failures += x->bmx.put_spot_check_failures.load();
 	o.bytes_written += x->metrics[0].load();
 	o.bytes_read += x->metrics[1].load();
 	o.corruption_counter += x->metrics[2].load();
@@ -1006,6 +1028,10 @@ int gbm_metrics_prometheus(const gbm_manager *m, gbm_batcher *b, char *buf, size
 		put_metric(s, "block_ec_unconfirmed_verdicts", "counter",
 			   "Checksum mismatches reported by a device trip or the pool that the host's own check did not confirm (the shard stayed)",
 			   (double)x.unconfirmed_verdicts);
+		put_metric(s, "block_ec_put_spot_checks", "counter", "Put trips of which one device-computed shard checksum was re-computed on the host",
+			   (double)x.put_spot_checks);
+		put_metric(s, "block_ec_put_spot_check_failures", "counter", "Put trips refused because the host did not get the device's checksum",
+			   (double)x.put_spot_check_failures);
 		put_metric(s, "block_ec_hedged_reads", "counter", "Extra shard requests sent by hedged reads", (double)x.hedged_reads);
 		put_metric(s, "block_ec_scrub_corruptions_detected", "counter", "Corrupt blocks found by the scrub", (double)x.scrub_corruptions_detected);
 		put_metric(s, "block_ec_scrub_time_last_complete_ms", "gauge", "When the last complete scrub ended (ms since the epoch)",

@@ -64,6 +64,7 @@ struct Env {
 	int batcher_device_turn;  // GBM_BATCHER_DEVICE_TURN
 	unsigned batcher_gap_us;  // GBM_BATCHER_GAP_US
 	bool batcher_lone_skip;   // GBM_BATCHER_LONE_SKIP
+	unsigned put_spot_check;  // GBM_PUT_SPOT_CHECK
 };
 const Env &env();
 const char *env_table_text();
@@ -553,6 +554,7 @@ struct DurationScope {
 struct BlockMetrics {
 	std::atomic<uint64_t> resync_counter{0}, resync_error_counter{0}, resync_send_counter{0}, resync_recv_counter{0}, delete_counter{0};
 	std::atomic<uint64_t> unconfirmed_verdicts{0};  // "checksum does not match" from a trip that the host's own check did not confirm
+	std::atomic<uint64_t> put_spot_checks{0}, put_spot_check_failures{0};  // gbm_set_put_spot_check
 	Histogram resync_duration, read_duration, write_duration;
 };
 
@@ -645,6 +647,11 @@ struct gbm_manager {
 	std::mutex scrub_worker_mu;
 	std::shared_ptr<gbmimpl::ScrubWorker> scrub_worker;
 	std::atomic<bool> scrub_tranquility_set{false};  // gbm_set_tranquility has been called: INITIAL_SCRUB_TRANQUILITY does not apply
+	// Put batches whose device-computed shard checksums are spot-checked on the host (every Nth; 0 = never), and -- a test hook --
+	// how many of the next put trips come back with one checksum falsified (a device fault, simulated)
+	std::atomic<uint32_t> put_spot_every{16};
+	std::atomic<uint64_t> put_trips{0};
+	std::atomic<int> test_bad_put_sums{0};
 	std::atomic<uint64_t> metrics[6] = {};
 	gbmimpl::BlockMetrics bmx;  // the rest of BlockManagerMetrics (gbm_block_metrics_get, gbm_metrics_prometheus)
 	std::atomic<uint64_t> gpu_hashed{0};

@@ -104,6 +104,33 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 			return ec_fail(rc, "gec_encode_hash_batch");
 		}
 		mg->gpu_hashed += gn * (size_t)n;
+		if (mg->test_bad_put_sums.load() > 0 && mg->test_bad_put_sums.fetch_sub(1) > 0)
+			gsums[(gn - 1) * (size_t)n * 32 + 5] ^= 0x40;  // (test hook: the device got shard 0 of the trip's last block wrong)
+		// The spot check (gbm_set_put_spot_check): one shard of one block of this trip -- data or parity -- is hashed again on
+		// the host before anything is sent; a trip whose checksums the host cannot reproduce stores nothing.  ("every trip"
+		// looks at shard 0 of every block as well: the setting of the tests and of the paranoid.)
+		if (const uint32_t every = mg->put_spot_every.load()) {
+			const uint64_t trip = mg->put_trips.fetch_add(1);
+			if (trip % every == 0) {
+				auto matches = [&](size_t i, size_t j) {
+					const uint8_t *p = j < (size_t)k ? prep[ids[i]].block.data() + j * S : prep[ids[i]].parity.data() + (j - (size_t)k) * S;
+					uint8_t host_sum[32];
+					shardsum(p, S, host_sum);
+					return std::memcmp(host_sum, gsums.data() + (i * (size_t)n + j) * 32, 32) == 0;
+				};
+				const uint64_t draw = (trip / every) * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+				mg->bmx.put_spot_checks++;
+				bool ok = matches((size_t)(draw >> 33) % gn, (size_t)(draw >> 11) % (size_t)n);
+				for (size_t i = 0; every == 1 && ok && i < gn; ++i)
+					ok = matches(i, 0);
+				if (!ok) {
+					mg->bmx.put_spot_check_failures++;
+					if (rcs)
+						std::fill(rcs, rcs + nb, GBM_E_EC);
+					return fail(GBM_E_EC, "a put trip's shard checksums are not what the host computes: nothing was sent to any node");
+				}
+			}
+		}
 		for (size_t i = 0; i < gn; ++i)
 			std::memcpy(sums.data() + ids[i] * (size_t)n * 32, gsums.data() + i * (size_t)n * 32, (size_t)n * 32);
 	}

@@ -178,6 +178,16 @@ int gbm_set_host_block_hash_max(gbm_manager *m, size_t nblocks);
  * BACKGROUND-class codec whose device work yields to the request path's (include/garage_ec.h). */
 int gbm_set_tranquility(gbm_manager *m, int scrub_tranquility, int resync_tranquility);
 int gbm_get_tranquility(const gbm_manager *m, uint32_t out[2]); /* out[0] = scrub, out[1] = resync */
+/* The other half of "a shard is set aside only on the host's word": a shard is WRITTEN with a checksum the device computed
+ * (gec_encode_hash_batch: parity and all k+m checksums from one trip), and a device that computed it wrongly would stamp
+ * every shard of its puts with a checksum nobody can ever confirm.  Every `every_n`-th put trip (default: GBM_PUT_SPOT_CHECK
+ * = 16; 0 = never, 1 = every trip) one shard of one block of the trip -- data or parity, picked at random -- is hashed
+ * again on the host BEFORE anything is sent to a node; if the host does not get the device's checksum the whole trip is
+ * refused with GBM_E_EC, nothing is stored, and block_ec_put_spot_check_failures counts it.  One shard's checksum is
+ * ~35 us for a 1 MiB block: 2 us per trip at the default rate. */
+int gbm_set_put_spot_check(gbm_manager *m, unsigned every_n);
+/* Test hook: the next `trips` put trips come back from the codec with one shard checksum falsified (a faulty device). */
+int gbm_test_corrupt_put_sums(gbm_manager *m, int trips);
 uint64_t gbm_tranquilized_ms(const gbm_manager *m);   /* total time slept by the tranquilizer */
 /* The codec maintenance runs on (the manager's own BACKGROUND-class sibling of the codec it was given, or that
  * codec itself when no sibling could be created).  Borrowed. */
@@ -503,6 +513,7 @@ typedef struct {
 	uint64_t gpu_hashed;           /* messages whose checksum the device computed */
 	uint64_t hedged_reads;
 	uint64_t unconfirmed_verdicts; /* checksum mismatches a trip reported that the host's own check did not confirm: the shard stayed */
+	uint64_t put_spot_checks, put_spot_check_failures; /* gbm_set_put_spot_check */
 	uint64_t scrub_corruptions_detected, scrub_time_last_complete_ms;
 	uint64_t tranquilized_ms;
 	uint64_t batcher_put_batches, batcher_put_blocks, batcher_get_batches, batcher_get_blocks;

@@ -1060,3 +1060,42 @@ def test_a_hedged_round_satisfied_by_a_corrupt_parity_shard_asks_the_slow_holder
     assert b"".join(mgr.rpc_get_block_streaming(h)) == data
     mgr.node_set_latency(who[2], 0)
     assert mgr.hedged_reads >= 1 and mgr.metrics["corruption_counter"] >= 1
+
+
+def test_a_put_trip_whose_checksums_the_host_cannot_reproduce_stores_nothing(backend):
+    """gbm_set_put_spot_check: the device computes parity AND every shard's checksum; a device that got a checksum wrong would
+    stamp shards with checksums nobody can ever confirm.  With the check on every trip, a trip that comes back with a
+    falsified checksum (test hook) is refused -- GBM_E_EC, nothing reaches a node, the counters say so -- both for a direct put
+    and for callers of the coalescing queue; the next trip goes through."""
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    mgr = bn.NativeBlockManager(codec, 16)
+    blocks = [pattern_block(150_000 + 64 * i, 500 + i) for i in range(9)]
+    hashes = [bn.blake2sum(b) for b in blocks]
+    mgr.set_put_spot_check(1)
+    mgr.rpc_put_blocks(list(zip(hashes[:3], blocks[:3])))
+    m0 = mgr.block_metrics()
+    assert m0["put_spot_checks"] == 1 and m0["put_spot_check_failures"] == 0
+    assert bn.lib.gbm_test_corrupt_put_sums(mgr._h, 1) == 0
+    with pytest.raises(bn.BlockError, match="not what the host computes"):
+        mgr.rpc_put_blocks(list(zip(hashes[3:6], blocks[3:6])))
+    for h in hashes[3:6]:
+        who = mgr.storage_nodes_of(h)
+        assert not any(mgr.node_has_shard(who[j], h, j) for j in range(14))
+        with pytest.raises(bn.MissingBlock):
+            mgr.rpc_get_block(h)
+    bt = bn.Batcher(mgr, max_blocks=8, max_wait_us=100)
+    assert bn.lib.gbm_test_corrupt_put_sums(mgr._h, 1) == 0
+    with pytest.raises(bn.BlockError, match="not what the host computes"):
+        bt.put_block(hashes[6], blocks[6])
+    bt.put_block(hashes[6], blocks[6])                  # the retry: a trip the host can vouch for
+    mgr.rpc_put_blocks(list(zip(hashes[3:6], blocks[3:6])))
+    assert mgr.rpc_get_blocks(hashes[:7], 200_000) == blocks[:7]
+    m1 = mgr.block_metrics()
+    assert m1["put_spot_check_failures"] == 2 and m1["put_spot_checks"] == 5 and m1["blocks_put"] == 3 + 1 + 3
+    bt.close()
+    # the default rate: one trip in sixteen is looked at
+    mgr2 = bn.NativeBlockManager(codec, 16)
+    for h, b in zip(hashes, blocks):
+        for _ in range(4):
+            mgr2.rpc_put_block(h, b)
+    assert mgr2.block_metrics()["put_spot_checks"] == 3    # trips 0, 16, 32 of 36
