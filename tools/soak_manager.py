@@ -43,6 +43,7 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
         b_ = bn.Batcher(m_, max_blocks=32, max_wait_us=100)
         m_.set_tranquility(scrub=0, resync=0)
         m_.set_resync_workers(3)
+        m_.set_put_spot_check(1)           # every put trip: one random shard + every block's first, hashed again on the host
         return m_, b_
 
     def start_workers():
@@ -441,6 +442,7 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
     # every "checksum does not match" a trip reported was confirmed by the host before a shard was set aside: a verdict the host
     # does not confirm means the checker was wrong (a block the codec skipped, a device fault) -- none must have happened
     assert met["unconfirmed_verdicts"] == 0, f"{met['unconfirmed_verdicts']} checksum verdicts were not confirmed by the host"
+    assert met["put_spot_check_failures"] == 0 and met["put_spot_checks"] > 0, (met["put_spot_checks"], met["put_spot_check_failures"])
     violations = sum(mgr.node_order_violations(nd) for nd in range(nnodes))
     assert violations == 0, f"{violations} PutShard deliveries out of their stream's order"
     mgr.scrub_worker_stop()
@@ -451,7 +453,8 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
            "concurrent_writers": {"threads": nwriters, "blocks_put_tagged_and_read_back": writer_ops[0], "order_violations": violations},
            "ops": ops, "scrub_worker": {x: st[x] for x in ("blocks_scrubbed", "corruptions_detected", "checkpoints_saved", "errors")},
            "metrics": {x: met[x] for x in ("blocks_put", "blocks_get", "ec_reconstructs", "corruption_counter", "resync_counter", "resync_error_counter",
-                                           "resync_recv_counter", "resync_send_counter", "delete_counter", "unconfirmed_verdicts")}}
+                                           "resync_recv_counter", "resync_send_counter", "delete_counter", "unconfirmed_verdicts", "put_spot_checks",
+                                           "put_spot_check_failures")}}
     mgr.close()
     if verbose:
         print("soak_manager OK:", res)
