@@ -80,7 +80,15 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 		for (size_t c = 0; c < ncand; ++c) {
 			if (g.tried[c])
 				continue;
-			const int v = vcur - (int)(c / n), j = (int)(c % n);
+			// The layout versions are walked OLDEST FIRST, shard by shard -- block_read_nodes_of's order (rpc_helper.rs:559-563,
+			// 583-603: "ask the preferred node in all layout versions (older to newer)", because most blocks were saved before
+			// the change).  Here it is also what makes a read safe beside the mover: resync moves a shard with PutShard to its new
+			// owner and only then DeleteShard at the old one, so whoever asks the OLD holder first cannot miss a shard in motion --
+			// it is either still there, or already at the new owner by the time that one is asked.  Newest-first (rounds 2 - 3)
+			// had a window: new owner asked before the put, old one after the delete; with k holders to hear from instead of one
+			// that window made whole blocks read as Missing under the soak.  The price, for the length of the transition: one missed request for every
+			// shard that has already moved (and n of them for a block written after the change).
+			const int v = vold + (int)(c / n), j = (int)(c % n);
 			if (have(g, j) || taken(j))
 				continue;
 			g.tried[c] = 1;

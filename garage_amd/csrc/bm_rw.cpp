@@ -468,11 +468,12 @@ static int get_blocks_again(gbm_manager *mg, size_t nb, const uint8_t *hashes, c
 
 // raw == true: rpc_get_raw_block (stored bytes + header); false: rpc_get_block (plain bytes).
 // While a layout change is being followed (more than one version is active) resync MOVES shards: PutShard to the new owner,
-// then DeleteShard at the old one.  A read that asked the new owners before the puts and the old ones after the deletes
-// finds the block "missing" although it was whole the whole time -- the reference's readers have the same window
-// (block_read_nodes_of walks the versions in order, rpc_helper.rs:570-619) and leave it to the client's retry; with k
-// holders to hear from instead of one it is wider here, so a block that comes back Missing during a transition is asked
-// for again (twice at most): moves only go forward, a later walk meets the shards where an earlier one's came from.
+// then DeleteShard at the old one.  The gather asks a shard's holders oldest version first (bm_gather.cpp, block_read_nodes_of's
+// order, rpc_helper.rs:559-603), so a single move cannot hide a shard from it.  What is left for the retry below: a shard whose
+// old holder was DOWN when it was asked and whose move completed in between, and a walk that met a corrupt copy at one holder
+// while the other one was still on its way -- a block that comes back Missing (or Corrupt with too few shards) during a
+// transition is asked for again, twice at most: moves only go forward, a later walk meets the shards where an earlier one's
+// went to.  (The reference leaves the same cases to the client's retry.)
 int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
 		    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate)
 {

@@ -468,7 +468,9 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 	StreamOut out(sink, ctx, chunk_bytes);
 	auto fs = std::make_shared<Fast>(k, hs[0], order_tag);
 	std::vector<int> who;
-	m->nodes_of(hs[0], who);
+	// (the oldest active layout version's holders -- where the general form's walk starts as well, bm_gather.cpp; in the
+	// steady state that is the current version)
+	m->nodes_of(hs[0], m->layout_oldest.load(), who);
 	fast_fetch(m, fs, who, 0, k - 1);
 	Trace tr("streaming get");
 	StreamGeom geom;
@@ -591,7 +593,7 @@ int get_range(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order
 	Hash h((const char *)hash, 32);
 	auto fs = std::make_shared<Fast>(k, h, order_tag);
 	std::vector<int> who;
-	m->nodes_of(h, who);
+	m->nodes_of(h, m->layout_oldest.load(), who);
 	Trace tr("range get");
 	fast_fetch(m, fs, who, j0, j1);
 	for (int j = j0; j <= j1; ++j) {

@@ -351,6 +351,43 @@ def test_layout_change_offloads_shards_to_their_new_owners(backend):
     assert mgr.rpc_get_blocks(hashes, 200_000) == blocks
 
 
+def test_reads_walk_the_layout_versions_oldest_first():
+    """block_read_nodes_of asks "the preferred node in all layout versions (older to newer)" (rpc_helper.rs:559-563).  Here the
+    order is also what keeps a read safe beside the mover (PutShard at the new owner, THEN DeleteShard at the old one): the old
+    holder is asked first.  Seen from outside: right after a layout change, before anything has moved, a read never touches a
+    node that only the NEW version names -- such nodes answer after 150 ms here, and the read does not notice."""
+    import time
+
+    codec = g.ReedSolomon(3, 1, backend="cpu")
+    mgr = bn.NativeBlockManager(codec, 9)
+    blocks = [pattern_block(50_000, 4200 + i) for i in range(12)]
+    hashes = [bn.blake2sum(b) for b in blocks]
+    mgr.rpc_put_blocks(list(zip(hashes, blocks)))
+    old = [mgr.storage_nodes_of(h) for h in hashes]
+    assert mgr.layout_update() == 1
+    new = [mgr.storage_nodes_of(h) for h in hashes]
+    picked = [i for i in range(len(blocks)) if set(new[i][:3]) - set(old[i])]   # a data shard's new owner holds nothing of the block
+    assert picked
+    for i in picked[:4]:
+        slow = set(new[i]) - set(old[i])
+        for nd in slow:
+            mgr.node_set_latency(nd, 150_000)
+        t0 = time.perf_counter()
+        assert mgr.rpc_get_block(hashes[i]) == blocks[i]
+        assert b"".join(mgr.rpc_get_block_streaming(hashes[i])) == blocks[i]
+        assert time.perf_counter() - t0 < 0.15, "a node only the new layout version names was asked before the old holders"
+        for nd in slow:
+            mgr.node_set_latency(nd, 0)
+    # a shard that HAS moved is found at its new owner once the old one has said no
+    h, o, n_ = hashes[picked[0]], old[picked[0]], new[picked[0]]
+    mgr.block_incref(h)
+    mgr.put_to_resync(h)
+    assert mgr.resync_run()["offloaded"] > 0
+    assert all(mgr.node_has_shard(n_[j], h, j) and (o[j] == n_[j] or not mgr.node_has_shard(o[j], h, j)) for j in range(4))
+    assert mgr.rpc_get_block(h) == blocks[picked[0]]
+    mgr.close()
+
+
 def test_batcher_coalesces_concurrent_puts(backend):
     """16 caller threads (think: 16 PutObject requests) each put 6 blocks through the
     batcher; every call blocks until ITS block is stored; the worker coalesces them into

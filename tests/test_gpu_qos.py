@@ -43,7 +43,9 @@ def test_tranquility_pauses_the_scrub():
     t0 = time.perf_counter()
     mgr.scrub_all()
     slow = time.perf_counter() - t0
-    assert bn.lib.gbm_tranquilized_ms(mgr._h) > 0 and slow > plain
+    slept = bn.lib.gbm_tranquilized_ms(mgr._h) / 1e3
+    # the pause is part of the second pass's wall time; comparing with `plain` alone is at the mercy of whatever else the box runs
+    assert slept > 0 and slow >= slept and plain > 0
     mgr.close()
 
 
