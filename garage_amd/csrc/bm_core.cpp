@@ -535,7 +535,7 @@ int gbm_device_metrics(const gbm_manager *m, int dev, uint64_t out[6])
 }
 
 int gbm_set_threads(gbm_manager *m, int nthreads)
-{
+try {
 	if (!m || nthreads < 1 || nthreads > 256)
 		return fail(GBM_E_INVALID_ARG, "need 1 <= nthreads <= 256");
 	GBM_EACH(m, x, {
@@ -545,6 +545,7 @@ int gbm_set_threads(gbm_manager *m, int nthreads)
 	});
 	return GBM_OK;
 }
+GBM_CATCH
 
 int gbm_set_host_block_hash_max(gbm_manager *m, size_t nblocks)
 {
@@ -691,7 +692,7 @@ int gbm_clock_advance(gbm_manager *m, uint64_t ms)
 }
 
 int gbm_storage_nodes_of(const gbm_manager *m, const uint8_t hash[32], int *nodes_out)
-{
+try {
 	if (!m || !hash || !nodes_out)
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
 	std::vector<int> who;
@@ -699,6 +700,7 @@ int gbm_storage_nodes_of(const gbm_manager *m, const uint8_t hash[32], int *node
 	std::copy(who.begin(), who.end(), nodes_out);
 	return GBM_OK;
 }
+GBM_CATCH
 
 int gbm_layout_update(gbm_manager *m)
 {

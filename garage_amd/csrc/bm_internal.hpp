@@ -23,6 +23,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <exception>
 #include <functional>
 #include <future>
 #include <map>
@@ -46,6 +47,20 @@ namespace gbmimpl {
 
 // sets the calling thread's gbm_last_error() text and returns `code`
 int fail(int code, const std::string &msg);
+// function-try-block tail for the C entry points that allocate outside a try of their own: nothing may unwind across the C ABI
+#define GBM_CATCH                                                                \
+	catch (const std::exception &e)                                          \
+	{                                                                        \
+		try {                                                            \
+			return ::gbmimpl::fail(GBM_E_IO, e.what());              \
+		} catch (...) {                                                  \
+			return GBM_E_IO;                                         \
+		}                                                                \
+	}                                                                        \
+	catch (...)                                                              \
+	{                                                                        \
+		return GBM_E_IO;                                                 \
+	}
 const std::string &last_error();
 int ec_fail(int rc, const char *what);
 
@@ -225,6 +240,7 @@ public:
 			n_ = n;
 			next_ = 0;
 			pending_ = n;
+			err_ = nullptr;
 			++epoch_;
 		}
 		cv_.notify_all();
@@ -232,6 +248,16 @@ public:
 		std::unique_lock<std::mutex> g(mu_);
 		done_cv_.wait(g, [this] { return pending_ == 0; });
 		fn_ = nullptr;
+		// An item that threw (bad_alloc, as a rule): the items not yet started were skipped, every thread has left fn -- whose
+		// captures live in the caller's frame -- and the first exception goes on from HERE, on the caller's thread, where the
+		// C ABI's catch turns it into a code.  (Thrown straight out of work() it unwound that frame under the workers' feet;
+		// thrown on a worker it was std::terminate.)
+		if (err_) {
+			std::exception_ptr e = err_;
+			err_ = nullptr;
+			g.unlock();
+			std::rethrow_exception(e);
+		}
 	}
 
 private:
@@ -251,14 +277,24 @@ private:
 		for (;;) {
 			size_t i;
 			const std::function<void(size_t)> *fn;
+			bool skip;
 			{
 				std::lock_guard<std::mutex> g(mu_);
 				if (!fn_ || next_ >= n_)
 					return;
 				i = next_++;
 				fn = fn_;
+				skip = (bool)err_;
 			}
-			(*fn)(i);
+			if (!skip) {
+				try {
+					(*fn)(i);
+				} catch (...) {
+					std::lock_guard<std::mutex> g(mu_);
+					if (!err_)
+						err_ = std::current_exception();
+				}
+			}
 			std::lock_guard<std::mutex> g(mu_);
 			if (--pending_ == 0)
 				done_cv_.notify_all();
@@ -285,6 +321,7 @@ private:
 	size_t n_ = 0, next_ = 0, pending_ = 0;
 	uint64_t epoch_ = 0;
 	bool stop_ = false;
+	std::exception_ptr err_;  // the first exception of the call in flight (under mu_)
 };
 
 // Fire-and-forget tasks for requests that may be abandoned (hedged reads): a task owns everything it touches

@@ -785,7 +785,7 @@ int gbm_resync_worker_start(gbm_manager *m)
 }
 
 int gbm_resync_worker_stop(gbm_manager *m)
-{
+try {
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
 	for (auto &l : m->lanes)
@@ -803,6 +803,7 @@ int gbm_resync_worker_stop(gbm_manager *m)
 		t.join();
 	return GBM_OK;
 }
+GBM_CATCH
 
 // ResyncPersistedConfig (resync.rs:58-71): this library's own 16-byte little-endian record, <path>.tmp + rename
 static void resync_config_save(gbm_manager *m)

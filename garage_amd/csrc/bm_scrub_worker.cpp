@@ -473,7 +473,7 @@ int gbm_scrub_worker_stop(gbm_manager *m)
 }
 
 int gbm_scrub_worker_command(gbm_manager *m, int cmd, uint64_t pause_ms)
-{
+try {
 	if (!m)
 		return fail(GBM_E_INVALID_ARG, "NULL manager");
 	if (m->is_front()) {
@@ -498,6 +498,7 @@ int gbm_scrub_worker_command(gbm_manager *m, int cmd, uint64_t pause_ms)
 	std::lock_guard<std::mutex> g(w->mu);
 	return w->command(cmd, pause_ms);
 }
+GBM_CATCH
 
 int gbm_scrub_worker_status(const gbm_manager *cm, gbm_scrub_status *out)
 {

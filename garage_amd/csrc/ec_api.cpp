@@ -22,6 +22,27 @@ int fail(int code, const std::string &detail)
 	return code;
 }
 
+int on_exception() noexcept
+{
+	try {
+		throw;
+	} catch (const std::bad_alloc &) {
+		try {
+			return fail(GEC_E_NOMEM, "out of host memory");
+		} catch (...) {
+			return GEC_E_NOMEM;
+		}
+	} catch (const std::exception &e) {
+		try {
+			return fail(GEC_E_DEVICE, std::string("internal error: ") + e.what());
+		} catch (...) {
+			return GEC_E_DEVICE;
+		}
+	} catch (...) {
+		return GEC_E_DEVICE;
+	}
+}
+
 int check_km(int k, int m)
 {
 	if (k <= 0)
@@ -75,6 +96,8 @@ void ForkJoinPool::parallel_for(size_t n, const std::function<void(size_t)> &fn)
 		grab_ = std::max<size_t>(1, n / (4 * (workers_.size() + 1)));
 		next_.store(0, std::memory_order_relaxed);
 		pending_ = n;
+		failed_.store(false, std::memory_order_relaxed);
+		err_ = nullptr;
 		++epoch_;
 	}
 	cv_.notify_all();
@@ -82,6 +105,14 @@ void ForkJoinPool::parallel_for(size_t n, const std::function<void(size_t)> &fn)
 	std::unique_lock<std::mutex> g(mu_);
 	done_cv_.wait(g, [this] { return pending_ == 0 && active_ == 0; });
 	fn_ = nullptr;
+	// an item threw (bad_alloc, as a rule): what had not started was skipped, every thread has left fn -- whose captures
+	// live in the caller's frame -- and the first exception goes on from here, on the caller's thread, to the C ABI's catch
+	if (err_) {
+		std::exception_ptr e = err_;
+		err_ = nullptr;
+		g.unlock();
+		std::rethrow_exception(e);
+	}
 }
 
 void ForkJoinPool::work()
@@ -98,16 +129,26 @@ void ForkJoinPool::work()
 		++active_;  // parallel_for does not return (and fn stays alive) while a registered thread is in here
 	}
 	size_t done = 0;
+	std::exception_ptr err;
 	for (;;) {
 		const size_t i0 = next_.fetch_add(grab, std::memory_order_relaxed);
 		if (i0 >= n)
 			break;
 		const size_t i1 = std::min(n, i0 + grab);
-		for (size_t i = i0; i < i1; ++i)
-			(*fn)(i);
-		done += i1 - i0;
+		if (!failed_.load(std::memory_order_relaxed)) {
+			try {
+				for (size_t i = i0; i < i1; ++i)
+					(*fn)(i);
+			} catch (...) {
+				err = std::current_exception();
+				failed_.store(true, std::memory_order_relaxed);
+			}
+		}
+		done += i1 - i0;  // (items skipped after a failure count as handed out)
 	}
 	std::lock_guard<std::mutex> g(mu_);
+	if (err && !err_)
+		err_ = err;
 	pending_ -= done;
 	--active_;
 	if (pending_ == 0 && active_ == 0)
@@ -349,7 +390,7 @@ size_t gec_shard_len(int k, size_t block_len)
 }
 
 int gec_build_matrix_ex(int k, int m, int matrix, uint8_t *out)
-{
+try {
 	int rc = check_km(k, m);
 	if (rc)
 		return rc;
@@ -362,11 +403,12 @@ int gec_build_matrix_ex(int k, int m, int matrix, uint8_t *out)
 	std::memcpy(out, enc.v.data(), enc.v.size());
 	return GEC_OK;
 }
+GEC_CATCH
 
 int gec_build_matrix(int k, int m, uint8_t *out) { return gec_build_matrix_ex(k, m, GEC_MATRIX_VANDERMONDE, out); }
 
 int gec_build_decode_matrix(int k, int m, const uint8_t *present, int32_t *valid_out, uint8_t *out)
-{
+try {
 	int rc = check_km(k, m);
 	if (rc)
 		return rc;
@@ -389,24 +431,28 @@ int gec_build_decode_matrix(int k, int m, const uint8_t *present, int32_t *valid
 	std::memcpy(out, dec.v.data(), dec.v.size());
 	return GEC_OK;
 }
+GEC_CATCH
 
 // ------------------------------------------------------------------ codec
 int gec_codec_create(int k, int m, int backend, int device, gec_codec **out)
-{
+try {
 	return create_codec(k, m, backend, device, GEC_MATRIX_VANDERMONDE, GEC_CLASS_FOREGROUND, out);
 }
+GEC_CATCH
 
 int gec_codec_create_ex(int k, int m, int backend, int device, int matrix, gec_codec **out)
-{
+try {
 	return create_codec(k, m, backend, device, matrix, GEC_CLASS_FOREGROUND, out);
 }
+GEC_CATCH
 
 int gec_codec_background(const gec_codec *c, gec_codec **out)
-{
+try {
 	if (!c)
 		return fail(GEC_E_INVALID_ARG, "NULL codec");
 	return create_codec(c->k, c->m, c->backend, c->device, c->matrix, GEC_CLASS_BACKGROUND, out);
 }
+GEC_CATCH
 
 void gec_codec_destroy(gec_codec *c) { delete c; }
 
@@ -417,15 +463,16 @@ int gec_codec_backend(const gec_codec *c) { return c ? c->backend : -1; }
 int gec_codec_class(const gec_codec *c) { return c ? c->qos_class : -1; }
 
 int gec_parity_matrix(const gec_codec *c, uint8_t *out)
-{
+try {
 	if (!c || !out)
 		return fail(GEC_E_INVALID_ARG, "NULL argument");
 	std::memcpy(out, c->enc.row(c->k), (size_t)c->m * c->k);
 	return GEC_OK;
 }
+GEC_CATCH
 
 int gec_codec_cache_stats(const gec_codec *c, uint64_t *cached, uint64_t *inversions)
-{
+try {
 	if (!c)
 		return fail(GEC_E_INVALID_ARG, "NULL codec");
 	std::lock_guard<std::mutex> g(c->cache_mu);
@@ -435,6 +482,7 @@ int gec_codec_cache_stats(const gec_codec *c, uint64_t *cached, uint64_t *invers
 		*inversions = c->inversions;
 	return GEC_OK;
 }
+GEC_CATCH
 
 // ------------------------------------------------------------------ host-pointer entry points
 static int encode_common(const gec_codec *c, size_t nblocks, const uint8_t *const *blocks, const size_t *block_len, size_t S,
@@ -459,18 +507,20 @@ static int encode_common(const gec_codec *c, size_t nblocks, const uint8_t *cons
 
 int gec_encode_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *blocks, const size_t *block_len, size_t S,
 		     uint8_t *const *parity)
-{
+try {
 	return encode_common(c, nblocks, blocks, block_len, S, parity, nullptr);
 }
+GEC_CATCH
 
 int gec_encode_hash_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *blocks, const size_t *block_len, size_t S,
 			  uint8_t *const *parity, uint8_t *shard_sums)
-{
+try {
 	LinkReleaseScope release;
 	if (!shard_sums)
 		return fail(GEC_E_INVALID_ARG, "NULL shard_sums");
 	return encode_common(c, nblocks, blocks, block_len, S, parity, shard_sums);
 }
+GEC_CATCH
 
 static int verify_common(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, size_t S, uint8_t *ok, uint8_t *shard_sums,
 			 bool want_sums)
@@ -491,15 +541,17 @@ static int verify_common(const gec_codec *c, size_t nblocks, const uint8_t *cons
 }
 
 int gec_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, size_t S, uint8_t *ok)
-{
+try {
 	return verify_common(c, nblocks, shards, S, ok, nullptr, false);
 }
+GEC_CATCH
 
 int gec_verify_hash_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, size_t S, uint8_t *ok,
 			  uint8_t *shard_sums)
-{
+try {
 	return verify_common(c, nblocks, shards, S, ok, shard_sums, true);
 }
+GEC_CATCH
 
 static int reconstruct_common(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, uint8_t *const *out, size_t S,
 			      int data_only, uint8_t *in_sums, uint8_t *out_sums)
@@ -525,21 +577,23 @@ static int reconstruct_common(const gec_codec *c, size_t nblocks, const uint8_t 
 
 int gec_reconstruct_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, uint8_t *const *out, size_t S,
 			  int data_only)
-{
+try {
 	return reconstruct_common(c, nblocks, shards, out, S, data_only, nullptr, nullptr);
 }
+GEC_CATCH
 
 int gec_reconstruct_hash_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, uint8_t *const *out, size_t S,
 			       int data_only, uint8_t *in_sums, uint8_t *out_sums)
-{
+try {
 	if (!in_sums || !out_sums)
 		return fail(GEC_E_INVALID_ARG, "NULL checksum output");
 	return reconstruct_common(c, nblocks, shards, out, S, data_only, in_sums, out_sums);
 }
+GEC_CATCH
 
 int gec_decode_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *const *shards, size_t S, const size_t *block_len,
 			    uint8_t *const *rebuilt, uint8_t *shard_sums, uint8_t *block_sums)
-{
+try {
 	LinkReleaseScope release;
 	if (!c)
 		return fail(GEC_E_INVALID_ARG, "NULL codec");
@@ -565,6 +619,7 @@ int gec_decode_verify_batch(const gec_codec *c, size_t nblocks, const uint8_t *c
 	}
 	return c->be->decode_verify_batch(nblocks, shards, S, block_len, rebuilt, shard_sums, block_sums);
 }
+GEC_CATCH
 
 static int hash_common(const gec_codec *c, size_t n, const uint8_t *const *msgs, const size_t *lens, uint8_t *out, bool tree)
 {
@@ -581,19 +636,21 @@ static int hash_common(const gec_codec *c, size_t n, const uint8_t *const *msgs,
 }
 
 int gec_blake2sum_batch(const gec_codec *c, size_t n, const uint8_t *const *msgs, const size_t *lens, uint8_t *out)
-{
+try {
 	return hash_common(c, n, msgs, lens, out, false);
 }
+GEC_CATCH
 
 int gec_shardsum_batch(const gec_codec *c, size_t n, const uint8_t *const *msgs, const size_t *lens, uint8_t *out)
-{
+try {
 	return hash_common(c, n, msgs, lens, out, true);
 }
+GEC_CATCH
 
 // ------------------------------------------------------------------ device-resident entry points
 int gec_encode_batch_dev(const gec_codec *c, size_t nblocks, const void *d_data, size_t data_stride, size_t S, void *d_parity,
 			 size_t parity_stride, void *hip_stream)
-{
+try {
 	if (!c)
 		return fail(GEC_E_INVALID_ARG, "NULL codec");
 	if (nblocks == 0)
@@ -606,10 +663,11 @@ int gec_encode_batch_dev(const gec_codec *c, size_t nblocks, const void *d_data,
 		return rc;
 	return c->be->encode_batch_dev(nblocks, d_data, data_stride, S, d_parity, parity_stride, hip_stream);
 }
+GEC_CATCH
 
 int gec_verify_batch_dev(const gec_codec *c, size_t nblocks, const void *d_stripes, size_t stride, size_t S, uint32_t *d_bad,
 			 void *hip_stream)
-{
+try {
 	if (!c || !d_bad)
 		return fail(GEC_E_INVALID_ARG, "NULL argument");
 	if (nblocks == 0)
@@ -619,10 +677,11 @@ int gec_verify_batch_dev(const gec_codec *c, size_t nblocks, const void *d_strip
 		return rc;
 	return c->be->verify_batch_dev(nblocks, d_stripes, stride, S, d_bad, hip_stream);
 }
+GEC_CATCH
 
 int gec_reconstruct_range_dev(const gec_codec *c, size_t nblocks, void *d_stripes, size_t stride, size_t S, const uint8_t *present,
 			      int data_only, size_t byte_off, size_t byte_len, void *hip_stream)
-{
+try {
 	if (!c || !present)
 		return fail(GEC_E_INVALID_ARG, "NULL argument");
 	if (nblocks == 0)
@@ -634,10 +693,11 @@ int gec_reconstruct_range_dev(const gec_codec *c, size_t nblocks, void *d_stripe
 		return fail(GEC_E_INVALID_ARG, "byte range must be 16-byte aligned and inside the shard");
 	return c->be->reconstruct_dev(nblocks, d_stripes, stride, nullptr, S, present, data_only, byte_off, byte_len, hip_stream);
 }
+GEC_CATCH
 
 int gec_reconstruct_scattered_dev(const gec_codec *c, size_t nblocks, void *d_base, size_t block_stride, const size_t *shard_off,
 				  size_t S, const uint8_t *present, int data_only, size_t byte_off, size_t byte_len, void *hip_stream)
-{
+try {
 	if (!c || !present || !shard_off)
 		return fail(GEC_E_INVALID_ARG, "NULL argument");
 	if (nblocks == 0)
@@ -652,12 +712,14 @@ int gec_reconstruct_scattered_dev(const gec_codec *c, size_t nblocks, void *d_ba
 		return fail(GEC_E_INVALID_ARG, "byte range must be 16-byte aligned and inside the shard");
 	return c->be->reconstruct_dev(nblocks, d_base, block_stride, shard_off, S, present, data_only, byte_off, byte_len, hip_stream);
 }
+GEC_CATCH
 
 int gec_reconstruct_batch_dev(const gec_codec *c, size_t nblocks, void *d_stripes, size_t stride, size_t S, const uint8_t *present,
 			      int data_only, void *hip_stream)
-{
+try {
 	return gec_reconstruct_range_dev(c, nblocks, d_stripes, stride, S, present, data_only, 0, S, hip_stream);
 }
+GEC_CATCH
 
 static int hash_dev_common(const gec_codec *c, size_t n, const void *d_base, size_t stride, size_t len, void *d_out, void *hip_stream,
 			   bool tree)
@@ -674,18 +736,20 @@ static int hash_dev_common(const gec_codec *c, size_t n, const void *d_base, siz
 }
 
 int gec_blake2sum_batch_dev(const gec_codec *c, size_t n, const void *d_base, size_t stride, size_t len, void *d_out, void *hip_stream)
-{
+try {
 	return hash_dev_common(c, n, d_base, stride, len, d_out, hip_stream, false);
 }
+GEC_CATCH
 
 int gec_shardsum_batch_dev(const gec_codec *c, size_t n, const void *d_base, size_t stride, size_t len, void *d_out, void *hip_stream)
-{
+try {
 	return hash_dev_common(c, n, d_base, stride, len, d_out, hip_stream, true);
 }
+GEC_CATCH
 
 int gec_encode_hash_batch_dev(const gec_codec *c, size_t nblocks, void *d_stripes, size_t stride, size_t S, void *d_sums,
 			      void *hip_stream)
-{
+try {
 	if (!c || !d_sums)
 		return fail(GEC_E_INVALID_ARG, "NULL argument");
 	if (nblocks == 0)
@@ -697,5 +761,6 @@ int gec_encode_hash_batch_dev(const gec_codec *c, size_t nblocks, void *d_stripe
 		return fail(GEC_E_INVALID_ARG, "d_sums must be 16-byte aligned");
 	return c->be->encode_hash_batch_dev(nblocks, d_stripes, stride, S, d_sums, hip_stream);
 }
+GEC_CATCH
 
 }  // extern "C"

@@ -317,7 +317,7 @@ int host_alltoall_decode(gec_group *g, size_t nobjects, const uint8_t *local, si
 extern "C" {
 
 int gec_group_unique_id(uint8_t id[GEC_GROUP_ID_BYTES])
-{
+try {
 	static_assert(sizeof(ncclUniqueId) == GEC_GROUP_ID_BYTES, "GEC_GROUP_ID_BYTES must equal sizeof(ncclUniqueId)");
 	if (!id)
 		return fail(GEC_E_INVALID_ARG, "NULL id");
@@ -331,6 +331,7 @@ int gec_group_unique_id(uint8_t id[GEC_GROUP_ID_BYTES])
 	std::memcpy(id, &u, sizeof(u));
 	return GEC_OK;
 }
+GEC_CATCH
 
 static int check_dev_layout(const void *p, size_t stride, size_t S, size_t need)
 {
@@ -366,7 +367,7 @@ static int group_new(const gec_codec *c, int rank, int nranks, gec_group **out, 
 }
 
 int gec_group_create(const gec_codec *c, int rank, int nranks, const uint8_t id[GEC_GROUP_ID_BYTES], gec_group **out)
-{
+try {
 	std::unique_ptr<gec_group> g;
 	int rc = group_new(c, rank, nranks, out, g);
 	if (rc)
@@ -392,10 +393,11 @@ int gec_group_create(const gec_codec *c, int rank, int nranks, const uint8_t id[
 	*out = g.release();
 	return GEC_OK;
 }
+GEC_CATCH
 
 int gec_group_create_with_transport2(const gec_codec *c, int rank, int nranks, gec_allgather_fn all_gather,
 				     gec_alltoall_fn all_to_all, void *ctx, gec_group **out)
-{
+try {
 	std::unique_ptr<gec_group> g;
 	int rc = group_new(c, rank, nranks, out, g);
 	if (rc)
@@ -408,12 +410,14 @@ int gec_group_create_with_transport2(const gec_codec *c, int rank, int nranks, g
 	*out = g.release();
 	return GEC_OK;
 }
+GEC_CATCH
 
 int gec_group_create_with_transport(const gec_codec *c, int rank, int nranks, gec_allgather_fn all_gather, void *ctx,
 				    gec_group **out)
-{
+try {
 	return gec_group_create_with_transport2(c, rank, nranks, all_gather, nullptr, ctx, out);
 }
+GEC_CATCH
 
 void gec_group_destroy(gec_group *g)
 {
@@ -452,7 +456,7 @@ size_t gec_group_slots(const gec_group *g)
 
 int gec_group_allgather_decode(gec_group *g, size_t nobjects, const void *d_local_slots, size_t S,
 			       const uint8_t *present, int data_only, int complete, void *d_gathered, void *hip_stream)
-{
+try {
 	if (!g || !present)
 		return fail(GEC_E_INVALID_ARG, "NULL argument");
 	if (nobjects == 0)
@@ -546,12 +550,13 @@ int gec_group_allgather_decode(gec_group *g, size_t nobjects, const void *d_loca
 	ra.packed = g->d_recv;
 	return launch_range_unpack(ra, send_bytes / 16 * N, stream);
 }
+GEC_CATCH
 
 uint64_t gec_group_bytes_exchanged(const gec_group *g) { return g ? g->bytes_exchanged : 0; }
 
 int gec_group_alltoall_decode(gec_group *g, size_t nobjects, const void *d_local_slots, size_t S, const uint8_t *present,
 			      int data_only, int complete, void *d_rebuilt, void *hip_stream)
-{
+try {
 	if (!g || !present || !d_rebuilt)
 		return fail(GEC_E_INVALID_ARG, "NULL argument");
 	if (!g->all_to_all)
@@ -683,5 +688,6 @@ int gec_group_alltoall_decode(gec_group *g, size_t nobjects, const void *d_local
 	}
 	return launch_rebuilt_unpack(ua, (size_t)ua.nranks_in * nmiss * nobjects * max_cols, stream);
 }
+GEC_CATCH
 
 }  // extern "C"

@@ -472,7 +472,13 @@ void *gec_host_alloc(size_t bytes)
 			fail(GEC_E_NOMEM, "aligned_alloc failed");
 			return nullptr;
 		}
-		pinned().add(p, n, true, 0, /*plain=*/true);
+		try {
+			pinned().add(p, n, true, 0, /*plain=*/true);
+		} catch (...) {  // the registry could not grow
+			std::free(p);
+			(void)on_exception();
+			return nullptr;
+		}
 		return p;
 	}
 	hipError_t e = hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocPortable);
@@ -480,7 +486,13 @@ void *gec_host_alloc(size_t bytes)
 		fail(e == hipErrorOutOfMemory ? GEC_E_NOMEM : GEC_E_DEVICE, std::string("hipHostMalloc: ") + hipGetErrorString(e));
 		return nullptr;
 	}
-	pinned().add(p, std::max<size_t>(bytes, 1), true);
+	try {
+		pinned().add(p, std::max<size_t>(bytes, 1), true);
+	} catch (...) {
+		(void)hipHostFree(p);
+		(void)on_exception();
+		return nullptr;
+	}
 	return p;
 }
 
@@ -496,7 +508,7 @@ void gec_host_free(void *p)
 }
 
 int gec_host_register(void *p, size_t bytes)
-{
+try {
 	if (!p || bytes == 0)
 		return fail(GEC_E_INVALID_ARG, "NULL / empty range");
 	HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
@@ -506,9 +518,10 @@ int gec_host_register(void *p, size_t bytes)
 	pinned().add(p, bytes, false, reinterpret_cast<intptr_t>(dptr) - reinterpret_cast<intptr_t>(p));
 	return GEC_OK;
 }
+GEC_CATCH
 
 int gec_host_unregister(void *p)
-{
+try {
 	bool owned = false, plain = false;
 	if (!p || !pinned().remove(p, owned, plain))
 		return fail(GEC_E_INVALID_ARG, "not a registered range");
@@ -522,6 +535,7 @@ int gec_host_unregister(void *p)
 	HIP_TRY(hipHostUnregister(p));
 	return GEC_OK;
 }
+GEC_CATCH
 
 int gec_host_is_pinned(const void *p, size_t bytes) { return pinned().contains(p, bytes) ? 1 : 0; }
 

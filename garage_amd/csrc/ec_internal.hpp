@@ -18,6 +18,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <list>
 #include <memory>
@@ -33,6 +34,16 @@ namespace gecimpl {
 
 // Sets the calling thread's gec_last_error() text and returns `code`.
 int fail(int code, const std::string &detail);
+
+// Nothing may unwind across the C ABI (the caller is Rust, C or ctypes): every extern "C" entry point that can allocate is a
+// function-try-block ending in GEC_CATCH, which turns whatever was thrown into a code (bad_alloc -> GEC_E_NOMEM, anything
+// else -> GEC_E_DEVICE with the exception's text in gec_last_error()).
+int on_exception() noexcept;
+#define GEC_CATCH                                  \
+	catch (...)                                \
+	{                                          \
+		return ::gecimpl::on_exception();  \
+	}
 
 // same order of checks as ReedSolomon::new [EXT]
 int check_km(int k, int m);
@@ -63,6 +74,8 @@ private:
 	const std::function<void(size_t)> *fn_ = nullptr;
 	size_t n_ = 0, grab_ = 1, pending_ = 0, active_ = 0;
 	std::atomic<size_t> next_{0};
+	std::atomic<bool> failed_{false};
+	std::exception_ptr err_;  // the first exception of the call in flight (under mu_)
 	uint64_t epoch_ = 0;
 	bool stop_ = false;
 };

@@ -12,6 +12,8 @@
 #include <vector>
 
 #include "../../include/garage_block.h"
+#include "../../garage_amd/csrc/bm_internal.hpp"  // the two fork-join pools (run_pools_carry_exceptions)
+#include "../../garage_amd/csrc/ec_internal.hpp"
 
 static gec_codec *stub_codec_create(int k, int m)
 {
@@ -927,8 +929,52 @@ static void run_scrub_worker(int k, int m, const char *dir_root)
 	printf("scrub worker RS(%d,%d)%s: OK\n", k, m, dir_root ? " with a state file" : "");
 }
 
+// An item of a fork-join call that throws (bad_alloc, as a rule): the call ends only when every thread has left fn -- its
+// captures live in the caller's frame -- the items not yet started are skipped, and the exception arrives on the CALLING
+// thread, where the C entry points catch it.  Before: std::terminate when it was a worker's item, the caller's frame unwound
+// under the workers when it was the caller's.  Both pools, many rounds, under ASan and TSan; the pool works afterwards.
+template <class P> static void pool_carries(P &pool, const char *what)
+{
+	for (int round = 0; round < 200; ++round) {
+		std::vector<int> seen(512, 0);  // the caller's frame: must outlive every item
+		std::atomic<int> ran{0};
+		const size_t bad = (size_t)(round * 37 % 512);
+		bool caught = false;
+		try {
+			pool.parallel_for(seen.size(), [&](size_t i) {
+				if (i == bad)
+					throw std::bad_alloc();
+				seen[i] = 1;
+				ran++;
+			});
+		} catch (const std::bad_alloc &) {
+			caught = true;
+		}
+		if (!caught || ran.load() > 511) {
+			fprintf(stderr, "%s: round %d: caught=%d ran=%d\n", what, round, (int)caught, ran.load());
+			exit(1);
+		}
+		std::atomic<int> after{0};
+		pool.parallel_for(64, [&](size_t) { after++; });
+		if (after.load() != 64) {
+			fprintf(stderr, "%s: the pool lost items after an exception\n", what);
+			exit(1);
+		}
+	}
+	printf("%s carries an item's exception to the caller: OK\n", what);
+}
+
+static void run_pools_carry_exceptions()
+{
+	gbmimpl::Pool a(5);
+	pool_carries(a, "gbmimpl::Pool");
+	gecimpl::ForkJoinPool b(5);
+	pool_carries(b, "gecimpl::ForkJoinPool");
+}
+
 int main(int argc, char **argv)
 {
+	run_pools_carry_exceptions();
 	run_scrub_worker(3, 1, nullptr);
 	run_scrub_worker(10, 4, argc > 1 ? argv[1] : nullptr);
 	run_hedged(3, 1);

@@ -252,3 +252,27 @@ def test_link_release_hook_fires_once_per_armed_call():
     lib.gec_thread_link_release(FN(), None)  # disarm
     assert encode(sums.ctypes.data_as(u8p)) == _lib.GEC_OK and fired == [7, 8]
     assert sums[:32].tobytes() == g.shardsum(data[:S].tobytes())
+
+
+def test_a_call_that_cannot_get_memory_returns_nomem_and_the_codec_works_afterwards():
+    """Nothing may unwind across the C ABI (the caller is Rust): every gec_* entry point that allocates is a function-try-block,
+    and an item of the codec's fork-join pool that throws is carried to the calling thread instead of std::terminate on the worker
+    or unwinding the caller's frame under the other workers.  tests/c/oom_probe.py starves one gec_encode_hash_batch of address
+    space (RLIMIT_AS a few MiB above what the process holds) in a process of its own."""
+    import subprocess
+    import sys
+
+    probe = os.path.join(ROOT, "tests", "c", "oom_probe.py")
+    starved = 0
+    for margin in (1, 2, 4, 8):
+        r = subprocess.run([sys.executable, probe, str(margin)], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            # glibc itself gives up when a thread's first touch of a thread-local block cannot be served; nothing of ours
+            assert "cannot allocate memory for thread-local data" in r.stderr + r.stdout, r.stdout + r.stderr
+            continue
+        rc1, rc2, same = r.stdout.split()[:3]
+        assert int(rc1) in (_lib.GEC_E_NOMEM, _lib.GEC_OK) and int(rc2) == _lib.GEC_OK and same == "1", r.stdout
+        if int(rc1) == _lib.GEC_E_NOMEM:
+            assert "memory" in r.stdout
+            starved += 1
+    assert starved >= 1
