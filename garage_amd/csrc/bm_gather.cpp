@@ -190,7 +190,12 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 					async->submit([rd, f, nd] {
 						ShardRpc rq{RpcKind::GetShard, &f->h, f->j, Shard(), f->has_tag ? &f->tag : nullptr};
 						ShardResp rs;
-						const bool answered = !rd->over.load() && nd->handle(rq, rs);
+						bool answered = false;
+						try {
+							answered = !rd->over.load() && nd->handle(rq, rs);
+						} catch (...) {  // (out of memory for the shard's copy, as a rule) a holder that did not answer
+							rs = ShardResp();
+						}
 						{
 							std::lock_guard<std::mutex> g(rd->mu);
 							f->rs = std::move(rs);

@@ -368,7 +368,12 @@ private:
 				fn = std::move(q_.front());
 				q_.pop_front();
 			}
-			fn();
+			try {
+				fn();
+			} catch (...) {
+				// last resort (a task reports its own failures to whoever waits for it): an exception that leaves a
+				// thread function is std::terminate for the whole process
+			}
 		}
 	}
 	std::vector<std::thread> workers_;

@@ -306,6 +306,7 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 	if (grc)
 		return grc;
 	tr.lap("gather");
+	std::exception_ptr helper_err;  // what the overlapped work threw: carried to this thread (on the helper it would be std::terminate)
 	std::thread helper;
 	struct Joiner {
 		std::thread &t;
@@ -316,14 +317,23 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 		}
 	} joiner{helper};
 	if (overlap)
-		helper = std::thread([&overlap] {
+		helper = std::thread([&overlap, &helper_err] {
 			name_thread("gbm-get-helper");
-			overlap();
+			try {
+				overlap();
+			} catch (...) {
+				helper_err = std::current_exception();
+			}
 		});
+	auto join_helper = [&] {
+		helper.join();
+		if (helper_err)
+			std::rethrow_exception(helper_err);
+	};
 	std::vector<uint8_t> todo(nb, 1);
 	for (int round = 0; round <= n; ++round) {
 		if (round == 1 && helper.joinable())
-			helper.join();
+			join_helper();
 		std::map<size_t, std::vector<size_t>> by_s;
 		for (size_t b = 0; b < nb; ++b) {
 			if (!todo[b])
@@ -381,7 +391,7 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 			}
 			tr.lap("decode+verify");
 			if (helper.joinable())
-				helper.join();  // the overlapped host work reads g: it must be done before the results below change it
+				join_helper();  // the overlapped host work reads g: it must be done before the results below change it
 			tr.lap("join overlapped assembly");
 			if (rc)
 				return ec_fail(rc, "gec_decode_verify_batch");
@@ -439,7 +449,7 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 		if (!any_again)
 			break;
 		if (helper.joinable())
-			helper.join();
+			join_helper();
 		grc = gather_many(mg, hs, tags, k, g, /*verify=*/false, &again);  // the next nodes, for the blocks that lost a shard
 		if (grc)
 			return grc;
@@ -777,11 +787,16 @@ int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const 
 			}
 		};
 		std::vector<std::thread> others;
-		for (int t = 1; t < kThreads; ++t)
-			others.emplace_back([&run] {
-				name_thread("gbm-put-slice");
-				run();
-			});
+		try {
+			for (int t = 1; t < kThreads; ++t)
+				others.emplace_back([&run] {
+					name_thread("gbm-put-slice");
+					run();
+				});
+		} catch (...) {
+			// no further thread to be had: the ones that started and this one share the slices (unwinding past joinable
+			// threads would be std::terminate)
+		}
 		run();
 		for (auto &t : others)
 			t.join();

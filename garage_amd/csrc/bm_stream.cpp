@@ -425,15 +425,19 @@ void fast_fetch(gbm_manager *m, const std::shared_ptr<Fast> &fs, const std::vect
 		ShardRpc rq{RpcKind::GetShard, &fs->h, j, Shard(), fs->has_tag ? &fs->tag : nullptr};
 		ShardResp rs;
 		int v = -1;
-		if (nd->handle(rq, rs) && rs.ok) {
-			const ShardHeader &hd = rs.shard.hd;
-			if (hd.version == 2 && hd.idx == j && hd.k == mk && hd.m == mm && hd.shard_len > 0 && hd.shard_len % 64 == 0 &&
-			    rs.shard.data.n == hd.shard_len) {
-				uint8_t sum[32];
-				shardsum(rs.shard.data.data(), hd.shard_len, sum);
-				if (std::memcmp(sum, hd.checksum, 32) == 0)
-					v = 1;
+		try {
+			if (nd->handle(rq, rs) && rs.ok) {
+				const ShardHeader &hd = rs.shard.hd;
+				if (hd.version == 2 && hd.idx == j && hd.k == mk && hd.m == mm && hd.shard_len > 0 && hd.shard_len % 64 == 0 &&
+				    rs.shard.data.n == hd.shard_len) {
+					uint8_t sum[32];
+					shardsum(rs.shard.data.data(), hd.shard_len, sum);
+					if (std::memcmp(sum, hd.checksum, 32) == 0)
+						v = 1;
+				}
 			}
+		} catch (...) {  // (no memory for the shard's copy, as a rule) "not there": the general form takes over; on a helper
+			v = -1;  // thread nothing may escape, and whoever waits in arrived(j) must be woken
 		}
 		{
 			std::lock_guard<std::mutex> lk(fs->mu);
