@@ -22,7 +22,7 @@ CDIR = os.path.join(HERE, "c")
 
 
 def _make(target):
-    r = subprocess.run(["make", "-C", CDIR, target], capture_output=True, text=True)
+    r = subprocess.run(["make", "-j8", "-C", CDIR, target], capture_output=True, text=True)
     if r.returncode != 0 and "fsanitize" in (r.stdout + r.stderr) and "cannot find" in (r.stdout + r.stderr):
         pytest.skip("sanitizer runtime not installed")
     assert r.returncode == 0, r.stdout + r.stderr
