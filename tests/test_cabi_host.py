@@ -276,3 +276,15 @@ def test_a_call_that_cannot_get_memory_returns_nomem_and_the_codec_works_afterwa
             assert "memory" in r.stdout
             starved += 1
     assert starved >= 1
+
+
+@pytest.mark.parametrize("seed", [3, 10, 27])
+def test_arbitrary_arguments_come_back_with_a_code(seed):
+    """tests/c/abi_fuzz.py: NULL pointers, S that is no multiple of 64, empty batches, blocks longer than k*S, fewer than k shards
+    present ... through every host-pointer entry point of a CPU codec; the process must live to print its last line."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "c", "abi_fuzz.py"), str(seed)], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("done"), r.stdout[-500:] + r.stderr[-2000:]
