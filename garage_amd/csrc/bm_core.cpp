@@ -729,14 +729,14 @@ int gbm_node_set_down(gbm_manager *m, int node, int down)
 
 int gbm_node_has_shard(gbm_manager *m, int node, const uint8_t hash[32], int idx)
 {
-	if (!m || node < 0 || node >= (int)m->nodes.size())
+	if (!m || !hash || node < 0 || node >= (int)m->nodes.size())
 		return 0;
 	return m->nodes[node]->has(Hash((const char *)hash, 32), idx) ? 1 : 0;
 }
 
 int gbm_node_delete_shard(gbm_manager *m, int node, const uint8_t hash[32], int idx)
 {
-	if (!m || node < 0 || node >= (int)m->nodes.size())
+	if (!m || !hash || node < 0 || node >= (int)m->nodes.size())
 		return fail(GBM_E_INVALID_ARG, "bad node index");
 	m->nodes[node]->del(Hash((const char *)hash, 32), idx);
 	return GBM_OK;
@@ -745,7 +745,7 @@ int gbm_node_delete_shard(gbm_manager *m, int node, const uint8_t hash[32], int 
 int gbm_node_corrupt_shard(gbm_manager *m, int node, const uint8_t hash[32], int idx, size_t offset, uint8_t mask,
 			   int fix_checksum)
 {
-	if (!m || node < 0 || node >= (int)m->nodes.size())
+	if (!m || !hash || node < 0 || node >= (int)m->nodes.size())
 		return fail(GBM_E_INVALID_ARG, "bad node index");
 	Hash h((const char *)hash, 32);
 	Shard s;

@@ -489,6 +489,9 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 {
 	if (!mg || (nb && (!hashes || !out || !cap || !len_out || !rcs)))
 		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	for (size_t b = 0; b < nb; ++b)
+		if (!out[b] && cap[b])
+			return fail(GBM_E_INVALID_ARG, "NULL output buffer with a capacity");
 	DurationScope read_time(mg->bmx.read_duration);  // block.read_duration (metrics.rs:117-121): one observation per call
 	int rc = get_blocks_once(mg, nb, hashes, tags, out, cap, len_out, rcs, raw, headers, gate);
 	// (twice more at most, a millisecond and five apart: a slow reader beside a fast mover can lose several shards of one block to

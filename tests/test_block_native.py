@@ -388,6 +388,20 @@ def test_reads_walk_the_layout_versions_oldest_first():
     mgr.close()
 
 
+@pytest.mark.parametrize("seed,ndev", [(1, 1), (6, 1), (7, 2)])
+def test_arbitrary_arguments_come_back_with_a_code(seed, ndev):
+    """tests/c/bm_abi_fuzz.py, a process of its own: NULL manager / hash / data / outputs, node and shard indices out of range,
+    zero capacities, ranges beyond the block, unknown hashes, a NULL sink -- 400 calls around a manager that holds blocks.  (It found
+    gbm_node_has_shard / _delete_shard / _corrupt_shard building a Hash from NULL -- std::logic_error, terminate -- and a get
+    writing through a NULL output buffer that came with a capacity.)"""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "c", "bm_abi_fuzz.py"), str(seed), "cpu", str(ndev)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("done 400"), r.stdout[-500:] + r.stderr[-2000:]
+
+
 def test_batcher_coalesces_concurrent_puts(backend):
     """16 caller threads (think: 16 PutObject requests) each put 6 blocks through the
     batcher; every call blocks until ITS block is stored; the worker coalesces them into
