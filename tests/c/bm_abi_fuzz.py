@@ -32,9 +32,23 @@ sz = ctypes.c_size_t
 calls = 0
 
 
-def hsh():
+damaged = set()   # blocks the walk has already taken a shard from (or rotted one of): one per block at most, so that m = 1 can repair
+
+
+def hsh(harm=False):
     r = rng.random()
-    return None if r < 0.15 else os.urandom(32) if r < 0.35 else rng.choice(hashes)
+    if r < 0.15:
+        return None
+    if r < 0.35:
+        return os.urandom(32)
+    if not harm:
+        return rng.choice(hashes)
+    sound = [h for h in hashes if h not in damaged]
+    if not sound:
+        return os.urandom(32)
+    h = rng.choice(sound)
+    damaged.add(h)
+    return h
 
 
 def mg():
@@ -70,9 +84,9 @@ for it in range(400):
         out = ctypes.create_string_buffer(64)
         L.gbm_node_shard_header(mg(), node, hsh(), idx, out)
     elif op == 7:
-        L.gbm_node_corrupt_shard(mg(), node, hsh(), idx, rng.choice([0, 63, 1 << 40]), rng.choice([0, 1, 255]), rng.choice([0, 1]))
+        L.gbm_node_corrupt_shard(mg(), node, hsh(True), idx, rng.choice([0, 63, 1 << 40]), rng.choice([0, 1, 255]), rng.choice([0, 1]))
     elif op == 8:
-        L.gbm_node_delete_shard(mg(), node, hsh(), idx)
+        L.gbm_node_delete_shard(mg(), node, hsh(True), idx)
     elif op == 9:
         nodes = (ctypes.c_int * (k + m))()
         L.gbm_storage_nodes_of(mg(), hsh(), nodes if rng.random() > 0.1 else None)
@@ -89,7 +103,8 @@ for it in range(400):
         L.gbm_batcher_get_block(bt._h if rng.random() > 0.1 else None, hsh(), buf, cap, ctypes.byref(ln))
     elif op == 13:
         d = os.urandom(rng.choice([0, 1, 5000]))
-        L.gbm_batcher_put_block(bt._h if rng.random() > 0.1 else None, bn.blake2sum(d) if rng.random() > 0.3 else hsh(), d, len(d), 0, None)
+        L.gbm_batcher_put_block(bt._h if rng.random() > 0.1 else None, bn.blake2sum(d) if rng.random() > 0.3 else (None if rng.random() < 0.3 else os.urandom(32)), d, len(d), 0,
+                                None)
     elif op == 14:
         L.gbm_set_threads(mg(), rng.choice([-1, 0, 1, 4, 300]))
         L.gbm_set_tranquility(mg(), rng.choice([-5, -1, 0, 3]), rng.choice([-5, -1, 0, 3]))
@@ -102,20 +117,24 @@ for it in range(400):
         L.gbm_block_rc(mg(), hsh(), ctypes.byref(rc) if rng.random() > 0.1 else None)
         L.gbm_device_of_hash(mg(), hsh())
     calls += 1
-# what the walk may have damaged on purpose (deleted / corrupted shards) is at most the fuzz's own doing: repair, then read
+# the walk took at most one shard from a block (deleted, flipped a byte, or rotted it under a valid checksum): the scrub finds the
+# rot, the resync puts everything back, and every block reads back under the end-to-end hash
 mgr.set_verify_block_hash("always")
 for node in range(k + m + 2):
     L.gbm_node_set_down(H, node, 0)
-for h in hashes:
-    mgr.put_to_resync(h)
-for _ in range(4):
+mgr.scrub_all()
+for _ in range(3):
+    for h in hashes:
+        mgr.put_to_resync(h)
     mgr.resync_run()
 bad = 0
 for h, b in zip(hashes, blocks):
     try:
         bad += mgr.rpc_get_block(h) != b
-    except bn.BlockError:
-        bad += 1   # more than m shards of a block deleted or damaged by the walk itself: possible, must be reported -- not crash
+    except bn.BlockError as e:
+        print("unreadable:", h.hex()[:16], e)
+        bad += 1
 bt.close()
 mgr.close()
 print("done", calls, "unreadable", bad)
+sys.exit(1 if bad else 0)

@@ -399,7 +399,7 @@ def test_arbitrary_arguments_come_back_with_a_code(seed, ndev):
 
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "c", "bm_abi_fuzz.py"), str(seed), "cpu", str(ndev)],
                        capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("done 400"), r.stdout[-500:] + r.stderr[-2000:]
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "done 400 unreadable 0", r.stdout[-500:] + r.stderr[-2000:]
 
 
 def test_batcher_coalesces_concurrent_puts(backend):
