@@ -402,6 +402,17 @@ def test_arbitrary_arguments_come_back_with_a_code(seed, ndev):
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "done 400 unreadable 0", r.stdout[-500:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("seed", [2, 11])
+def test_arbitrary_arguments_to_the_rest_of_the_api(seed):
+    """tests/c/bm_abi_fuzz2.py: creation, batched calls with NULL entries, helpers, listings, worker controls."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "c", "bm_abi_fuzz2.py"), str(seed)], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "done", r.stdout[-500:] + r.stderr[-2000:]
+
+
 def test_batcher_coalesces_concurrent_puts(backend):
     """16 caller threads (think: 16 PutObject requests) each put 6 blocks through the
     batcher; every call blocks until ITS block is stored; the worker coalesces them into
