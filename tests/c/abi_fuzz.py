@@ -22,6 +22,8 @@ for it in range(300):
     nb = rng.choice([0, 1, 2, 7])
     op = rng.choice(["enc", "enchash", "verify", "recon", "reconhash", "decver", "hash"])
     keep = []
+    if os.environ.get("FUZZ_TRACE"):
+        print(it, op, "S", S, "nb", nb, flush=True)
     def ptrs(count, size, null_p=0.0):
         a = (ctypes.c_void_p * max(count, 1))()
         for i in range(count):

@@ -22,7 +22,11 @@ bt = bn.Batcher(mgr, max_blocks=8, max_wait_us=100)
 L = bn.lib
 blocks = [bytes([i]) * rng.choice([0, 1, 63, 4096, 70_001, 300_000]) + os.urandom(rng.choice([0, 7, 1000])) for i in range(12)]
 hashes = [bn.blake2sum(b) for b in blocks]
+if os.environ.get("FUZZ_TRACE"):
+    print("setup", (k, m), [len(b) for b in blocks], flush=True)
 mgr.rpc_put_blocks(list(zip(hashes, blocks)))
+if os.environ.get("FUZZ_TRACE"):
+    print("setup done", flush=True)
 for h in hashes:
     mgr.block_incref(h)
 H = mgr._h
@@ -57,6 +61,8 @@ def mg():
 
 for it in range(400):
     op = rng.randrange(16)
+    if os.environ.get("FUZZ_TRACE"):
+        print(it, "op", op, flush=True)
     cap = rng.choice([0, 1, 64, 400_000])
     buf = ctypes.create_string_buffer(max(cap, 1))
     ln = sz(0)

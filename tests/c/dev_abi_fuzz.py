@@ -51,6 +51,8 @@ for it in range(400):
     b0, bl = rng.choice([0, 16, 8, S, 2 * S]), rng.choice([0, 16, 24, S, max(S - 16, 0), 2 * S])
     op = rng.randrange(8)
     p = ctypes.c_void_p(base + off) if rng.random() > 0.05 else None
+    if os.environ.get("FUZZ_TRACE"):
+        print(it, "op", op, (k, m), "S", S, "nb", nb, "stride", stride, "off", off, list(present), data_only, b0, bl, flush=True)
     h = rs._h if rng.random() > 0.03 else None
     if op == 0:
         pstride = rng.choice([0, m * S, m * S + 16, m * S + 8])
