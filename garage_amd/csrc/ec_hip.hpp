@@ -3,6 +3,8 @@
 // in ec_hip_launch.hip, which exports the launch_* / blake2_dev wrappers declared at the bottom of this file.
 #pragma once
 
+#include <exception>
+
 #include "ec_internal.hpp"
 
 #include <hip/hip_runtime_api.h>  // host API only: the device code is in ec_hip_launch.hip
@@ -217,6 +219,7 @@ inline HipBackend &hip_of(const gec_codec *c) { return *static_cast<HipBackend *
 struct StagingLease {
 	const gec_codec *c;
 	Staging st;
+	int unwinding_at_entry = 0;  // std::uncaught_exceptions() when the slot was taken (see the destructor)
 	explicit StagingLease(const gec_codec *cc);
 	~StagingLease();
 };

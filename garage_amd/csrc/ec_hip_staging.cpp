@@ -313,7 +313,7 @@ void Staging::release()
 }
 
 
-StagingLease::StagingLease(const gec_codec *cc) : c(cc)
+StagingLease::StagingLease(const gec_codec *cc) : c(cc), unwinding_at_entry(std::uncaught_exceptions())
 {
 	HipBackend &hb = hip_of(c);
 	{
@@ -328,6 +328,17 @@ StagingLease::StagingLease(const gec_codec *cc) : c(cc)
 
 StagingLease::~StagingLease()
 {
+	if (std::uncaught_exceptions() > unwinding_at_entry) {
+		// the call is being unwound (bad_alloc in its host code, as a rule) with work possibly still queued on this slot's
+		// streams: that work reads the slot's tables and reads / writes the caller's buffers, which the caller is free to
+		// release the moment the error code is back -- nothing of it may outlive the call
+		int prev = -1;
+		(void)hipGetDevice(&prev);
+		if (hipSetDevice(c->device) == hipSuccess)
+			(void)hipDeviceSynchronize();
+		if (prev >= 0)
+			(void)hipSetDevice(prev);
+	}
 	HipBackend &hb = hip_of(c);
 	std::lock_guard<std::mutex> g(hb.pool_mu);
 	hb.pool.push_back(st);
