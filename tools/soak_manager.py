@@ -24,6 +24,10 @@ import numpy as np  # noqa: E402
 import garage_amd as g  # noqa: E402
 from garage_amd import block_native as bn  # noqa: E402
 
+# the walk's own patience (how long moves may take to settle, a resync to converge) is wall-clock time: sanitizer builds run the
+# library ten to twenty times slower, and tools/soak_tsan.sh stretches it accordingly
+TIME_SCALE = float(os.environ.get("SOAK_TIME_SCALE", "1"))
+
 
 def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, seed: int = 2026, k: int = 10, m: int = 4,
          state_dir: str | None = None, verbose: bool = True, node_dirs_root: str | None = None, ndev: int = 1, layout_changes: bool = True,
@@ -228,7 +232,7 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
         put and the old one after the delete misses that shard -- the block is whole the whole time (a read needs any k), the
         verdict "not all there" is a snapshot of a move.  What is still bad after the moves have settled is bad."""
         bad = mgr.scrub(hs)
-        for _ in range(40):
+        for _ in range(int(40 * TIME_SCALE)):
             if not bad:
                 break
             ops["transient_scrub"] = ops.get("transient_scrub", 0) + 1
@@ -243,7 +247,7 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
         down.clear()
         for h in damaged:
             mgr.put_to_resync(h, 0)
-        deadline = time.time() + 20
+        deadline = time.time() + 20 * TIME_SCALE
         while True:                                              # the background workers (and this call) drain what is due
             mgr.resync_all()
             errs = mgr.list_resync_errors()

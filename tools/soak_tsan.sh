@@ -52,7 +52,7 @@ fi
   g++ $F -o ../libgarage_block.so bm_core.o bm_node.o bm_gather.o bm_rw.o bm_stream.o bm_resync.o bm_scrub.o bm_scrub_worker.o bm_batcher.o -L.. -lgarage_ec -lpthread -ldl -Wl,-rpath,'$ORIGIN' )
 cd "$W"
 set +e
-LD_PRELOAD="$PRE" python tools/soak_manager.py "$SECS" cpu 60000 "$SEED" "$NDEV" "$ROOT" > "$W/out.log" 2>&1
+SOAK_TIME_SCALE="${SOAK_TIME_SCALE:-5}" LD_PRELOAD="$PRE" python tools/soak_manager.py "$SECS" cpu 60000 "$SEED" "$NDEV" "$ROOT" > "$W/out.log" 2>&1
 RC=$?
 set -e
 N=$(grep -c "$PAT" "$W/out.log" || true)
