@@ -538,7 +538,28 @@ def run_procs(args) -> None:
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     g.set_kernel_variant(args.variant)
     if args.op == "striped-decode":
-        out = striped_decode_bench(args, R, distrib)
+        # the same watchdog as the striped_decode object of the default run: a collective that never returns must not
+        # keep N processes alive until the driver's own limit
+        box, done = {}, threading.Event()
+
+        def give_up():
+            if not done.wait(args.striped_timeout):
+                if rank == 0:
+                    print(json.dumps({"metric": "RS(20,8) striped-object decode", "n_gpus": world,
+                                      "error": f"no result within {args.striped_timeout:.0f} s (watchdog)", **box}), flush=True)
+                os._exit(0)
+
+        threading.Thread(target=give_up, daemon=True).start()
+        try:
+            out = striped_decode_bench(args, R, distrib, box)
+        except Exception as e:  # noqa: BLE001
+            done.set()
+            if rank == 0:
+                print(json.dumps({"metric": "RS(20,8) striped-object decode", "n_gpus": world,
+                                  "error": f"{type(e).__name__}: {e}"[:400], **box}), flush=True)
+            sys.stdout.flush()
+            os._exit(0)   # peers may be inside a collective: do not wait for them in the teardown
+        done.set()
         if rank == 0:
             print(json.dumps(out), flush=True)
         distrib.shutdown(R)
@@ -675,8 +696,8 @@ def run_procs(args) -> None:
     # real exchange step.  Guarded by a watchdog so that a collective that hangs cannot take the
     # headline line with it.
     striped_failed = False
-    dry = os.environ.get("GARAGE_DRYRUN_ONE_GPU") == "1"  # gloo stand-in on one device: no RCCL to measure
-    if (world > 1 and not args.no_striped and not dry) or args.striped:
+    # (GARAGE_DRYRUN_ONE_GPU=1: the same flow over a gloo-backed caller transport, labelled as such in the object)
+    if (world > 1 and not args.no_striped) or args.striped:
         box = {}
         done = threading.Event()
 
@@ -933,8 +954,20 @@ def striped_decode_bench(args, R, distrib, progress=None) -> dict:
     rs = g.ReedSolomon(k, m, device=R.local_rank)
     lost = (0, 1, 5, 9, 13, 19, 21, 27)
     present = [j not in lost for j in range(k + m)]
+    dry = os.environ.get("GARAGE_DRYRUN_ONE_GPU") == "1" and R.distributed
+    # fault injection for the rehearsal tests (tests/test_world8_rehearsal.py): one rank never reaches the collective
+    hang_rank = os.environ.get("GARAGE_BENCH_STRIPED_HANG_RANK")
+    if hang_rank is not None and int(hang_rank) == R.rank:
+        progress["stage"] = f"rank {R.rank} sleeps (GARAGE_BENCH_STRIPED_HANG_RANK)"
+        time.sleep(3600)
     use_cabi = args.collective == "cabi" and dist.get_backend() == "nccl"
-    grp = g.Group.from_torch_distributed(rs) if use_cabi else None
+    keep_alive = None
+    if dry and args.collective == "cabi":
+        # DRY RUN (every rank on device 0, where RCCL refuses a second rank): the PRODUCT's group code (range split, packs,
+        # byte-range rebuild, second exchange) over a caller transport that stages through host memory and gloo
+        grp, keep_alive = dry_gloo_group(g, rs, R)
+    else:
+        grp = g.Group.from_torch_distributed(rs) if use_cabi else None
     progress["stage"] = "group created"
 
     from garage_amd.striped import striped_reconstruct_alltoall
@@ -984,10 +1017,11 @@ def striped_decode_bench(args, R, distrib, progress=None) -> dict:
     gen = torch.Generator(device=R.device)
     gen.manual_seed(0x6761726167650005 + 1 + R.rank)
     local = torch.randint(0, 256, (nobj, layout.slots, S), dtype=torch.uint8, device=R.device, generator=gen)
-    steps = max(5, min(50, args.steps // 20))
+    steps = args.striped_steps or (1 if dry else max(5, min(50, args.steps // 20)))
+    nwarm = 0 if dry else 3
 
     def timed(fn, out):
-        for _ in range(3):
+        for _ in range(nwarm):
             fn(local, out)
         torch.cuda.synchronize()
         distrib.barrier(R)
@@ -1014,10 +1048,15 @@ def striped_decode_bench(args, R, distrib, progress=None) -> dict:
         "bit_exact": ok_all, "bit_exact_objects": ncheck,
         "bit_exact_against": "stripes encoded by the CPU oracle (oracle/rs_oracle.c) on the host; every rebuilt shard compared on every rank",
         "rccl_ranks": (grp.nranks if grp is not None else dist.get_world_size()),
+        "collective_backend": ("DRY RUN: gloo through a host-staging gec_allgather_fn / gec_alltoall_fn (every rank on device 0; "
+                               "timings meaningless)" if dry and grp is not None
+                               else "rccl (gec_group_create: ncclCommInitRank from libgarage_ec)" if grp is not None
+                               else f"torch.distributed {dist.get_backend()}"),
         "config": {"workload": f"BASELINE config 5: RS(20,8), {nobj} x 4 MiB objects striped over the ranks, 8 erasures",
                    "k": k, "m": m, "shard_len": S, "slots_per_rank": layout.slots,
                    "allgather_bytes_per_rank": nobj * layout.slots * S, "parallelism": f"stripe x{R.world}",
-                   "collective": "gec_group_allgather_decode (C ABI, RCCL ncclAllGather)" if grp is not None
+                   "collective": ("gec_group_allgather_decode (C ABI, caller transport: gloo, DRY RUN)" if dry and grp is not None
+                                  else "gec_group_allgather_decode (C ABI, RCCL ncclAllGather)") if grp is not None
                                  else f"torch.distributed all_gather_into_tensor ({dist.get_backend()}) + gec_reconstruct_scattered_dev"},
         # the two exchanges side by side (all-gather = the project brief's, and the `value` above)
         "exchange": {
@@ -1031,11 +1070,56 @@ def striped_decode_bench(args, R, distrib, progress=None) -> dict:
     }
     if grp is not None:
         grp.close()
+    del keep_alive   # the dry run's transport callbacks had to outlive the group
     if own_pg:
         dist.destroy_process_group()
     if not (ok_all and ok_a2a_all):
         res["error"] = "striped decode result differs from the oracle's stripes"
     return res
+
+
+def dry_gloo_group(g, rs, R):
+    """GARAGE_DRYRUN_ONE_GPU=1 with N > 1 processes: a gec_group over gec_group_create_with_transport2 whose all-gather and
+    all-to-all stage the device buffers through host memory and torch.distributed's gloo group.  Plumbing only -- it lets the
+    N-rank control flow of the product's group code run end to end on one GPU.  Returns (group, objects to keep alive)."""
+    import ctypes
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from garage_amd import _lib
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    D2H, H2D = 2, 1
+    world = R.world
+
+    def exchange(send, recv, nbytes, stream, a2a):
+        if not nbytes:
+            return 0
+        if hip.hipStreamSynchronize(stream):
+            return 1
+        mine = np.empty(nbytes * (world if a2a else 1), dtype=np.uint8)
+        if hip.hipMemcpy(mine.ctypes.data, send, mine.size, D2H):
+            return 1
+        got = np.empty(nbytes * world, dtype=np.uint8)
+        if a2a:
+            dist.all_to_all_single(torch.from_numpy(got), torch.from_numpy(mine))
+        else:
+            dist.all_gather(list(torch.from_numpy(got).chunk(world)), torch.from_numpy(mine))
+        return 1 if hip.hipMemcpy(recv, got.ctypes.data, got.size, H2D) else 0
+
+    @_lib.ALLGATHER_FN
+    def all_gather(_ctx, send, recv, nbytes, stream):
+        return exchange(send, recv, nbytes, stream, False)
+
+    @_lib.ALLGATHER_FN
+    def all_to_all(_ctx, send, recv, nbytes, stream):
+        return exchange(send, recv, nbytes, stream, True)
+
+    return g.Group(rs, R.rank, world, transport=(all_gather, all_to_all, None)), (all_gather, all_to_all, hip)
 
 
 # ------------------------------------------------- every GPU fed from host memory at once
@@ -1220,6 +1304,7 @@ def main() -> None:
     ap.add_argument("--no-striped", action="store_true", help="N>1: skip the BASELINE config 5 striped_decode object")
     ap.add_argument("--striped", action="store_true", help="N=1: also run the striped_decode object (RCCL with one rank)")
     ap.add_argument("--striped-objects", type=int, default=256)
+    ap.add_argument("--striped-steps", type=int, default=0, help="timed steps of each striped-decode exchange (0 = from --steps)")
     ap.add_argument("--striped-timeout", type=float, default=150.0,
                     help="watchdog for the striped_decode object: after this many seconds the line is printed without it")
     ap.add_argument("--precondition-ms", type=float, default=200.0,
