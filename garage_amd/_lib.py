@@ -31,6 +31,7 @@ GEC_E_INVALID_ARG = -102
 GEC_MATRIX_VANDERMONDE, GEC_MATRIX_CAUCHY = 0, 1
 GEC_BACKEND_CPU, GEC_BACKEND_HIP, GEC_BACKEND_AUTO = 0, 1, 2
 GEC_CLASS_FOREGROUND, GEC_CLASS_BACKGROUND = 0, 1
+GEC_SHARDSUM_DEFAULT, GEC_SHARDSUM_BLAKE2B_TREE, GEC_SHARDSUM_MLH64 = 0, 2, 3
 
 # every symbol include/garage_ec.h declares (tests/test_cabi_host.py::test_every_declared_symbol_is_exported checks
 # this list against the header and against the built library)
@@ -38,7 +39,8 @@ SYMBOLS = [
     "gec_version", "gec_device_count", "gec_device_of_hash", "gec_thread_link_release", "gec_strerror", "gec_last_error", "gec_env_table",
     "gec_cpu_isa",
     "gec_shard_len", "gec_build_matrix", "gec_build_matrix_ex", "gec_build_decode_matrix",
-    "gec_codec_create", "gec_codec_create_ex", "gec_codec_destroy", "gec_codec_k", "gec_codec_m",
+    "gec_codec_create", "gec_codec_create_ex", "gec_codec_create_ex2", "gec_codec_with_shardsum", "gec_codec_shardsum", "gec_shardsum_host",
+    "gec_codec_destroy", "gec_codec_k", "gec_codec_m",
     "gec_codec_device", "gec_parity_matrix", "gec_codec_cache_stats",
     "gec_codec_background", "gec_codec_class", "gec_codec_backend", "gec_qos_yields", "gec_cu_masks_active",
     "gec_encode_batch", "gec_verify_batch", "gec_verify_hash_batch", "gec_reconstruct_batch", "gec_reconstruct_hash_batch",
@@ -105,6 +107,10 @@ def _load() -> ctypes.CDLL:
     lib.gec_build_matrix_ex.argtypes = [ci, ci, ci, u8p]
     lib.gec_codec_create_ex.argtypes = [ci, ci, ci, ci, ci, pp]
     lib.gec_codec_background.argtypes = [vp, pp]
+    lib.gec_codec_create_ex2.argtypes = [ci, ci, ci, ci, ci, ci, pp]
+    lib.gec_codec_with_shardsum.argtypes = [vp, ci, pp]
+    lib.gec_codec_shardsum.argtypes = [vp]
+    lib.gec_shardsum_host.argtypes = [ci, ctypes.c_char_p, sz, ctypes.c_char_p]
     lib.gec_env_table.restype = ctypes.c_char_p
     lib.gec_cpu_isa.restype = ctypes.c_char_p
     lib.gec_qos_yields.argtypes = [ci]

@@ -60,17 +60,19 @@ class ReedSolomon:
     GPU when there is one."""
 
     def __init__(self, data_shards: int, parity_shards: int, device: int = 0, matrix: str = "vandermonde",
-                 backend: str = "hip", _handle=None):
+                 backend: str = "hip", shardsum: int = 0, _handle=None):
         """matrix="vandermonde" is the crate-compatible default; "cauchy" is the extra family
-        of include/garage_ec.h (not interchangeable with the default)."""
+        of include/garage_ec.h (not interchangeable with the default).  shardsum: which shard checksum the *_hash
+        methods produce -- 3 = MLH64 (the default, 0), 2 = BLAKE2b tree mode (shard header version 2)."""
         h = ctypes.c_void_p()
         if _handle is not None:
             h = _handle
         else:
-            check(lib.gec_codec_create_ex(data_shards, parity_shards, BACKENDS[backend], device, MATRIX_KINDS[matrix],
-                                          ctypes.byref(h)), "gec_codec_create_ex")
+            check(lib.gec_codec_create_ex2(data_shards, parity_shards, BACKENDS[backend], device, MATRIX_KINDS[matrix],
+                                           shardsum, ctypes.byref(h)), "gec_codec_create_ex2")
         self.matrix = matrix
         self._h = h
+        self.shardsum_kind = int(lib.gec_codec_shardsum(h))
         self.k = data_shards
         self.m = parity_shards
         self.n = data_shards + parity_shards
@@ -81,6 +83,12 @@ class ReedSolomon:
         """gec_codec_background: a sibling codec whose work is classed BACKGROUND (scrub, resync)."""
         h = ctypes.c_void_p()
         check(lib.gec_codec_background(self._h, ctypes.byref(h)), "gec_codec_background")
+        return ReedSolomon(self.k, self.m, self.device, self.matrix, self.backend, _handle=h)
+
+    def with_shardsum(self, kind: int) -> "ReedSolomon":
+        """gec_codec_with_shardsum: a sibling codec that produces the other kind of shard checksum."""
+        h = ctypes.c_void_p()
+        check(lib.gec_codec_with_shardsum(self._h, kind, ctypes.byref(h)), "gec_codec_with_shardsum")
         return ReedSolomon(self.k, self.m, self.device, self.matrix, self.backend, _handle=h)
 
     @property
@@ -379,13 +387,47 @@ class ReedSolomon:
 
 
 SHARDSUM_LEAF = 4096
+_MLH_KEYS = None
 
 
-def shardsum(data: bytes) -> bytes:
-    """The shard checksum, restated with hashlib (test oracle and host mirror): BLAKE2b tree mode, 4 KiB leaves,
-    unlimited fanout, depth 2, 64-byte inner digests, root truncated to 32 bytes (include/garage_ec.h)."""
+def shardsum3(data: bytes) -> bytes:
+    """Shard checksum v3 (GEC_SHARDSUM_MLH64, include/garage_ec.h) in numpy + hashlib: the host mirror of the definition.
+    (The tests' oracle for it is oracle/mlh64.py, which shares nothing with this.)"""
+    import hashlib
+    import struct
+
+    global _MLH_KEYS
+    if _MLH_KEYS is None:
+        M = (1 << 64) - 1
+        keys = []
+        for i in range(SHARDSUM_LEAF // 4):
+            x = (0x6761726167654D4C + (i + 1) * 0x9E3779B97F4A7C15) & M
+            x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+            x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+            keys.append(((x ^ (x >> 31)) >> 32) | 1)
+        _MLH_KEYS = np.array(keys, dtype=np.uint64)
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    msg = [b"GECSUM3\0", struct.pack("<Q", buf.size)]
+    for lo in range(0, buf.size, SHARDSUM_LEAF):
+        leaf = buf[lo:lo + SHARDSUM_LEAF]
+        if leaf.size % 4:
+            leaf = np.concatenate([leaf, np.zeros(-leaf.size % 4, dtype=np.uint8)])
+        w = leaf.view("<u4").astype(np.uint64)
+        with np.errstate(over="ignore"):
+            msg.append(struct.pack("<Q", int((w * _MLH_KEYS[:w.size]).sum(dtype=np.uint64))))
+    return hashlib.blake2b(b"".join(msg), digest_size=64).digest()[:32]
+
+
+def shardsum(data: bytes, kind: int = 3) -> bytes:
+    """The shard checksum of the given kind, restated in Python (host mirror): kind 3 = MLH64 (the default of every codec),
+    kind 2 = BLAKE2b tree mode, 4 KiB leaves, unlimited fanout, depth 2, 64-byte inner digests, root truncated to 32 bytes
+    (include/garage_ec.h)."""
     import hashlib
 
+    if kind == 3:
+        return shardsum3(data)
+    if kind != 2:
+        raise ValueError("shard checksum kinds are 2 (BLAKE2b tree) and 3 (MLH64)")
     n = max(1, -(-len(data) // SHARDSUM_LEAF))
     leaves = b"".join(
         hashlib.blake2b(data[i * SHARDSUM_LEAF:(i + 1) * SHARDSUM_LEAF], digest_size=64, fanout=0, depth=2, leaf_size=SHARDSUM_LEAF,

@@ -9,6 +9,7 @@
 #include <new>
 
 #include "ec_env.hpp"
+#include "mlh64_host.hpp"
 
 namespace gecimpl {
 
@@ -281,7 +282,7 @@ int check_dev_layout(const void *p, size_t stride, size_t S, size_t need)
 	return GEC_OK;
 }
 
-int create_codec(int k, int m, int backend, int device, int matrix, int qos_class, gec_codec **out)
+int create_codec(int k, int m, int backend, int device, int matrix, int qos_class, gec_codec **out, int sumkind = GEC_SHARDSUM_DEFAULT)
 {
 	if (!out)
 		return fail(GEC_E_INVALID_ARG, "NULL out");
@@ -289,6 +290,10 @@ int create_codec(int k, int m, int backend, int device, int matrix, int qos_clas
 	int rc = check_km(k, m);  // argument errors are reported before any device is touched
 	if (rc)
 		return rc;
+	if (sumkind == GEC_SHARDSUM_DEFAULT)
+		sumkind = GEC_SHARDSUM_MLH64;
+	if (sumkind != GEC_SHARDSUM_BLAKE2B_TREE && sumkind != GEC_SHARDSUM_MLH64)
+		return fail(GEC_E_INVALID_ARG, "unknown shard checksum kind");
 	if (matrix != GEC_MATRIX_VANDERMONDE && matrix != GEC_MATRIX_CAUCHY)
 		return fail(GEC_E_INVALID_ARG, "unknown matrix family");
 	if (backend != GEC_BACKEND_CPU && backend != GEC_BACKEND_HIP && backend != GEC_BACKEND_AUTO)
@@ -303,6 +308,7 @@ int create_codec(int k, int m, int backend, int device, int matrix, int qos_clas
 	c->backend = backend;
 	c->matrix = matrix;
 	c->qos_class = qos_class;
+	c->sumkind = sumkind;
 	rc = build_matrix_kind(k, m, matrix, c->enc);
 	if (rc)
 		return rc;
@@ -446,11 +452,42 @@ try {
 }
 GEC_CATCH
 
+int gec_codec_create_ex2(int k, int m, int backend, int device, int matrix, int shardsum, gec_codec **out)
+try {
+	return create_codec(k, m, backend, device, matrix, GEC_CLASS_FOREGROUND, out, shardsum);
+}
+GEC_CATCH
+
 int gec_codec_background(const gec_codec *c, gec_codec **out)
 try {
 	if (!c)
 		return fail(GEC_E_INVALID_ARG, "NULL codec");
-	return create_codec(c->k, c->m, c->backend, c->device, c->matrix, GEC_CLASS_BACKGROUND, out);
+	return create_codec(c->k, c->m, c->backend, c->device, c->matrix, GEC_CLASS_BACKGROUND, out, c->sumkind);
+}
+GEC_CATCH
+
+// a sibling of `c` (same code, backend, device and class) that produces the other kind of shard checksum
+int gec_codec_with_shardsum(const gec_codec *c, int shardsum, gec_codec **out)
+try {
+	if (!c)
+		return fail(GEC_E_INVALID_ARG, "NULL codec");
+	return create_codec(c->k, c->m, c->backend, c->device, c->matrix, c->qos_class, out, shardsum);
+}
+GEC_CATCH
+
+int gec_codec_shardsum(const gec_codec *c) { return c ? c->sumkind : -1; }
+
+int gec_shardsum_host(int shardsum, const uint8_t *data, size_t len, uint8_t out[32])
+try {
+	if ((!data && len) || !out)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (shardsum == GEC_SHARDSUM_MLH64)
+		mlh::shardsum3(data, len, out);
+	else if (shardsum == GEC_SHARDSUM_BLAKE2B_TREE)
+		b2host::shardsum(data, len, out);
+	else
+		return fail(GEC_E_INVALID_ARG, "unknown shard checksum kind");
+	return GEC_OK;
 }
 GEC_CATCH
 

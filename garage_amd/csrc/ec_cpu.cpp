@@ -30,6 +30,7 @@
 #include <map>
 
 #include "blake2b_mb.hpp"
+#include "mlh64_host.hpp"
 #include "ec_env.hpp"
 
 namespace gecimpl {
@@ -331,9 +332,14 @@ struct CpuBackend : Backend {
 	{
 		constexpr size_t kShardTaskMax = 16;
 		// (one shard per task where a core hashes one chain at a time: the scalar fallback keeps the pool busy)
-		const size_t kShardTask = b2host::mb_available() ? kShardTaskMax : 1;
+		const size_t kShardTask = b2host::mb_available() || c->sumkind == GEC_SHARDSUM_MLH64 ? kShardTaskMax : 1;
 		pool->parallel_for((list.size() + kShardTask - 1) / kShardTask, [&](size_t g) {
 			const size_t i0 = g * kShardTask, cnt = std::min(kShardTask, list.size() - i0);
+			if (c->sumkind == GEC_SHARDSUM_MLH64) {  // checksum v3: memory speed on one core (mlh64_host.hpp)
+				for (size_t i = 0; i < cnt; ++i)
+					mlh::shardsum3(list[i0 + i].p, S, list[i0 + i].dst);
+				return;
+			}
 			const uint8_t *ptr[kShardTaskMax];
 			uint8_t *dst[kShardTaskMax];
 			size_t len[kShardTaskMax];
@@ -611,7 +617,10 @@ struct CpuBackend : Backend {
 		const size_t per = !b2host::mb_available() ? 1 : tree ? 16 : 8;
 		pool->parallel_for((nmsg + per - 1) / per, [&](size_t g) {
 			const size_t i0 = g * per, cnt = std::min(per, nmsg - i0);
-			if (tree)
+			if (tree && c->sumkind == GEC_SHARDSUM_MLH64)
+				for (size_t i = i0; i < i0 + cnt; ++i)
+					mlh::shardsum3(msgs[i], lens[i], out + 32 * i);
+			else if (tree)
 				b2host::shardsum_many(msgs + i0, lens + i0, cnt, out + 32 * i0);
 			else
 				b2host::blake2sum_many(msgs + i0, lens + i0, cnt, out + 32 * i0);

@@ -45,7 +45,7 @@ const Row kRows[] = {
 	{"GEC_FUSED_GET_MAX_LEAVES", "4400", "the same for a read trip (gec_decode_verify_batch without block checksums: k leaves per tile, 260 per 1 MiB RS(10,4) block: up to 16 such blocks)"},
 	{"GEC_BG_HOME_RATE_GBPS", "20", "a background-class codec writes rebuilt shards into host memory (resync's rebuilds on their way home) no faster than this (0 = unpaced)"},
 	{"GEC_MAX_COLS_PER_LAUNCH", "0", "test hook: cap on the 16-byte columns one launch covers, to exercise the multi-launch split on small inputs"},
-	{"GEC_RCCL_LIB", "librccl.so.1", "RCCL to dlopen for gec_group_*"},
+	{"GEC_RCCL_LIB", "librccl.so.1", "RCCL to dlopen for gec_group_* (when set: that library or GEC_E_DEVICE, no fallback)"},
 };
 
 const char *get(const char *name) { return std::getenv(name); }

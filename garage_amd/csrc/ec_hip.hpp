@@ -337,9 +337,22 @@ int run_pipeline(const gec_codec *c, size_t nchunks, size_t slot_bytes, size_t n
 // in + b*in_stride + in_base_off[t], row r written at out + b*out_stride +
 // out_base_off[r]; only bytes [byte_off, byte_off+byte_len) of every shard are
 // touched.  Rows go out in groups of RMAX per launch.
+// sum != NULL (shard checksum v3, whole shards only: byte_off = 0, byte_len = S): the launch also leaves the MLH64 leaf sums
+// of what it reads and writes (compare mode: checks) in device memory,
+//   lsum[((b * slots_total + slot0 + slot) * nleaf_max) + leaf],  slot = input t (when `inputs`), then (k if inputs) + row r
+// for mlh_roots_dev to turn into 32-byte checksums.
+struct SumOut {
+	uint64_t *lsum;
+	uint32_t nleaf_max, slots_total, slot0;
+	bool inputs;
+};
 int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_t *out, size_t out_stride, uint32_t *bad,
 		 size_t byte_off, size_t byte_len, size_t nblocks, const size_t *in_base_off, const size_t *out_base_off, int nout,
-		 const uint8_t *coef /* nout x k */, int mode, hipStream_t stream);
+		 const uint8_t *coef /* nout x k */, int mode, hipStream_t stream, const SumOut *sum = nullptr);
+// The roots of n shards' leaf sums: shard i's sums at lsum[(slot_map ? slot_map[i] : i) * nleaf_max] (slot_map: device-
+// addressable, may be NULL), its length d_len[i] (NULL: len), its 32-byte checksum placed like blake2_dev places results.
+int mlh_roots_dev(const gec_codec *c, size_t n, const uint64_t *lsum, uint32_t nleaf_max, const uint64_t *d_len, size_t len,
+		  uint8_t *d_out, hipStream_t stream, const uint32_t *slot_map = nullptr, uint32_t group = 0, uint32_t out_group = 0);
 
 // out[b][r] = XOR_t coef[r][t] * in[b][t] over shards that stay in the caller's pinned memory (gf_apply_ptrs):
 // in[b*k + t] / valid[b*k + t] name the k input shards of block b and how many of their S bytes exist,

@@ -104,6 +104,26 @@ int encode_hash_dev(const gec_codec *c, size_t nblocks, uint8_t *d_stripes, size
 		    hipStream_t stream, Staging &aux)
 {
 	const size_t k = c->k, m = c->m, n = k + m;
+	if (c->sumkind == GEC_SHARDSUM_MLH64) {
+		// checksum v3: ONE pass -- the encode kernel leaves the leaf sums of the k shards it reads and the m rows it writes,
+		// from the registers that hold them (no second read of the stripe); then one lane per shard for the roots
+		const uint32_t nleaf_max = (uint32_t)((S + gec::SHARDSUM_LEAF - 1) / gec::SHARDSUM_LEAF);
+		uint8_t *scratch = nullptr;
+		int rc = leaf_scratch(c, stream, nblocks * n * nleaf_max * 8, &scratch);
+		if (rc)
+			return rc;
+		const SumOut so{reinterpret_cast<uint64_t *>(scratch), nleaf_max, (uint32_t)n, 0u, true};
+		std::vector<size_t> in_off(k), out_off(m);
+		for (size_t t = 0; t < k; ++t)
+			in_off[t] = t * S;
+		for (size_t r = 0; r < m; ++r)
+			out_off[r] = (k + r) * S;
+		rc = launch_apply(c, d_stripes, stride, d_stripes, stride, nullptr, 0, S, nblocks, in_off.data(), out_off.data(), (int)m,
+				  c->enc.row((int)k), gec::MODE_STORE, stream, &so);
+		if (rc)
+			return rc;
+		return mlh_roots_dev(c, nblocks * n, so.lsum, nleaf_max, nullptr, S, d_sums, stream);
+	}
 	const bool fork = env().hash_fork;  // A/B switch
 	if (fork) {
 		HIP_TRY(hipEventRecord(aux.ev_fork, stream));

@@ -39,8 +39,9 @@ const Rccl &rccl()
 		Rccl x;
 		std::vector<std::string> names;
 		if (!env().rccl_lib.empty())
-			names.push_back(env().rccl_lib);
-		names.insert(names.end(), {"librccl.so.1", "librccl.so"});
+			names.push_back(env().rccl_lib);  // an explicit GEC_RCCL_LIB is authoritative: no fallback to another RCCL
+		else
+			names.insert(names.end(), {"librccl.so.1", "librccl.so"});
 		for (const std::string &n : names) {
 			x.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
 			if (x.handle)

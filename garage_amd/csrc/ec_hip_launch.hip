@@ -11,6 +11,7 @@
 #include "kernels.hpp"
 #include "blake2b.hpp"
 #include "fused.hpp"
+#include "mlh64_dev.hpp"
 
 namespace gecimpl {
 
@@ -110,33 +111,42 @@ Geometry pick_geometry(int k, int rows_left, bool rows16_allowed)
 	return g;
 }
 
-template <int MW, int MODE, int TPB>
+template <int MW, int MODE, int KC, int TPB, bool SUM>
+void launch_one(const gec::ApplyArgs &a, const gec::LogExp *le, unsigned grid, size_t lds, hipStream_t s)
+{
+	if constexpr (SUM)
+		hipLaunchKernelGGL((gec::gf_apply_nibble_sum<MW, MODE, KC, true, TPB>), dim3(grid), dim3(TPB), lds, s, a, le);
+	else
+		hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, KC, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, a, le);
+}
+
+// SUM: the form that also leaves the shard checksums' leaf sums (mlh64_dev.hpp); 4- and 8-byte table entries only
+template <int MW, int MODE, int TPB, bool SUM = false>
 void launch_nibble(const gec::ApplyArgs &a, const gec::LogExp *le, int kc, unsigned grid, size_t lds, hipStream_t s)
 {
 	if constexpr (MW == 2) {
 		if (kc == 10) {
-			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 10, kCPT, true, 256>), dim3(grid), dim3(256), lds, s, a, le);
+			launch_one<MW, MODE, 10, 256, SUM>(a, le, grid, lds, s);
 			return;
 		}
 	}
 	if constexpr (MW == 1) {
 		if (kc == 10) {
-			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 10, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, a, le);
+			launch_one<MW, MODE, 10, TPB, SUM>(a, le, grid, lds, s);
 			return;
 		}
 		if (kc == 12) {
-			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 12, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, a, le);
+			launch_one<MW, MODE, 12, TPB, SUM>(a, le, grid, lds, s);
 			return;
 		}
 		if (kc == 16) {
-			hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, 16, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, a, le);
+			launch_one<MW, MODE, 16, TPB, SUM>(a, le, grid, lds, s);
 			return;
 		}
 	}
-#define GEC_CASE(KC)                                                                                              \
-	case KC:                                                                                                  \
-		hipLaunchKernelGGL((gec::gf_apply_nibble<MW, MODE, KC, kCPT, true, TPB>), dim3(grid), dim3(TPB), lds, s, \
-				   a, le);                                                                        \
+#define GEC_CASE(KC)                                                \
+	case KC:                                                    \
+		launch_one<MW, MODE, KC, TPB, SUM>(a, le, grid, lds, s); \
 		break;
 	if constexpr (MW == 4) {
 		switch (kc) {
@@ -158,6 +168,13 @@ void launch_nibble(const gec::ApplyArgs &a, const gec::LogExp *le, int kc, unsig
 #undef GEC_CASE
 }
 
+// LDS the SUM form adds: the waves' term regions + wsum (mlh64_dev.hpp), behind the tables at a 16-byte boundary
+size_t sum_lds_bytes(const Geometry &g, int k, int nsl)
+{
+	const int cap = g.threads > 256 ? 8 : 16;
+	return ((g.lds + 15) & ~(size_t)15) + gec::mlh_lds_bytes(cap, g.threads / 64, nsl) - g.lds;
+}
+
 }  // namespace
 
 // out[r] = XOR_t coef[r][t] * in[t] for r < nout: shard t of block b is read at
@@ -167,7 +184,7 @@ void launch_nibble(const gec::ApplyArgs &a, const gec::LogExp *le, int kc, unsig
 int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_t *out, size_t out_stride,
 		 uint32_t *bad, size_t byte_off, size_t byte_len, size_t nblocks, const size_t *in_base_off,
 		 const size_t *out_base_off, int nout, const uint8_t *coef /* nout x k */, int mode,
-		 hipStream_t stream)
+		 hipStream_t stream, const SumOut *sum)
 {
 	const int k = c->k;
 	const HipBackend &hb = hip_of(c);
@@ -191,10 +208,19 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 			return fail(GEC_E_INVALID_ARG, "stripe too large");
 		a.in_off[t] = (uint32_t)(in_base_off[t] / 16);
 	}
-	const int variant = g_variant.load(std::memory_order_relaxed);
+	const int variant = sum ? 0 : g_variant.load(std::memory_order_relaxed);
+	if (sum) {
+		// leaves are 256 columns of a WHOLE shard: the sums of a byte range would not be the shard's
+		if (byte_off != 0 || byte_len % 16 || (size_t)sum->nleaf_max < (byte_len + gec::SHARDSUM_LEAF - 1) / gec::SHARDSUM_LEAF)
+			return fail(GEC_E_INVALID_ARG, "checksummed launch: whole shards only");
+		a.lsum = sum->lsum;
+		a.sum_nleaf_max = sum->nleaf_max;
+		a.sum_slots_total = sum->slots_total;
+	}
 	int rows = 0;
 	for (int r0 = 0; r0 < nout; r0 += rows) {
-		const Geometry geo = pick_geometry(k, nout - r0, variant == 0 && env().rows16 != 0);
+		// (the SUM form exists for 4- and 8-byte table entries: more than 8 rows go out in groups of 8)
+		const Geometry geo = pick_geometry(k, nout - r0, variant == 0 && env().rows16 != 0 && !sum);
 		rows = variant == 1 ? std::min(gec::RMAX, nout - r0) : geo.rows;  // the baseline kernel takes up to 8 rows
 		a.rows = (uint32_t)rows;
 		const int mw = variant == 1 ? 2 : geo.mw;
@@ -234,8 +260,15 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 		if (a.cols > max_cols)
 			return fail(GEC_E_INVALID_ARG, "shard too large for one launch");
 		const uint64_t blocks_per_launch = std::max<uint64_t>(1, max_cols / a.cols);
-		const size_t lds = geo.lds;
+		size_t lds = geo.lds;
 		gec::ApplyArgs la = a;
+		if (sum) {
+			// inputs are summed by the first row group only; rows by the group that produces (or checks) them
+			la.sum_inputs = (r0 == 0 && sum->inputs) ? 1u : 0u;
+			la.sum_slot0 = sum->slot0 + (la.sum_inputs ? 0u : (sum->inputs ? (uint32_t)k : 0u) + (uint32_t)r0);
+			la.tiles_per_block = (uint32_t)((a.cols + tile_cols - 1) / tile_cols);
+			lds += sum_lds_bytes(geo, k, (la.sum_inputs ? k : 0) + rows);
+		}
 		for (uint64_t b0 = 0; b0 < nblocks; b0 += blocks_per_launch) {
 			const uint64_t nb = std::min<uint64_t>(blocks_per_launch, nblocks - b0);
 			la.in = in + b0 * in_stride;
@@ -244,7 +277,21 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 			la.nblocks = (uint32_t)nb;
 			la.total_cols = (uint32_t)(nb * a.cols);
 			// multiple of 8: the kernel hands each XCD a contiguous range of tiles
-			const unsigned grid = (unsigned)(((la.total_cols + tile_cols - 1) / tile_cols + 7) / 8 * 8);
+			unsigned grid = (unsigned)(((la.total_cols + tile_cols - 1) / tile_cols + 7) / 8 * 8);
+			if (sum) {
+				la.lsum = sum->lsum + b0 * sum->slots_total * sum->nleaf_max;
+				grid = (unsigned)((nb * la.tiles_per_block + 7) / 8 * 8);  // tiles are cut per block (blocks_per_launch keeps this in range: a ragged tile per block at most)
+				if (mw == 1 && mode == gec::MODE_STORE)
+					launch_nibble<1, gec::MODE_STORE, kThreadsMW1, true>(la, hb.d_logexp, geo.kc, grid, lds, stream);
+				else if (mw == 1)
+					launch_nibble<1, gec::MODE_COMPARE, kThreadsMW1, true>(la, hb.d_logexp, geo.kc, grid, lds, stream);
+				else if (mode == gec::MODE_STORE)
+					launch_nibble<2, gec::MODE_STORE, kThreadsMW2, true>(la, hb.d_logexp, geo.kc, grid, lds, stream);
+				else
+					launch_nibble<2, gec::MODE_COMPARE, kThreadsMW2, true>(la, hb.d_logexp, geo.kc, grid, lds, stream);
+				HIP_TRY(hipGetLastError());
+				continue;
+			}
 			if (mw == 1 && mode == gec::MODE_STORE)
 				launch_nibble<1, gec::MODE_STORE, kThreadsMW1>(la, hb.d_logexp, geo.kc, grid, lds, stream);
 			else if (mw == 1 && rows == 4)  // all four row slots real: stored rows prefetched behind the data loads
@@ -291,6 +338,24 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 	a.group = group;
 	a.group_stride = group_stride;
 	a.out_group = out_group;
+	if (tree && c->sumkind == GEC_SHARDSUM_MLH64) {
+		// shard checksum v3: a streaming pass for the leaf sums (8 bytes per 4 KiB), then one lane per shard for the roots
+		const size_t longest = d_len ? max_len : len;
+		const uint32_t nleaf_max = (uint32_t)std::max<size_t>(1, (longest + mlh::LEAF_BYTES - 1) / mlh::LEAF_BYTES);
+		const uint64_t leaves = (uint64_t)n * nleaf_max;
+		if ((leaves + 3) / 4 > 0x7fffffffull)
+			return fail(GEC_E_INVALID_ARG, "too many leaves for one call");
+		uint8_t *scratch = nullptr;
+		int rc = leaf_scratch(c, stream, leaves * 8, &scratch);
+		if (rc)
+			return rc;
+		hipLaunchKernelGGL(gec::mlh_leaves, dim3((unsigned)((leaves + 3) / 4)), dim3(256), 0, stream, a, nleaf_max, reinterpret_cast<uint64_t *>(scratch));
+		HIP_TRY(hipGetLastError());
+		hipLaunchKernelGGL(gec::mlh_roots, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a, nleaf_max,
+				   reinterpret_cast<const uint64_t *>(scratch), static_cast<const uint32_t *>(nullptr));
+		HIP_TRY(hipGetLastError());
+		return GEC_OK;
+	}
 	if (tree) {
 		const size_t longest = d_len ? max_len : len;
 		const uint32_t nleaf = (uint32_t)std::max<size_t>(1, (longest + gec::SHARDSUM_LEAF - 1) / gec::SHARDSUM_LEAF);
@@ -337,6 +402,29 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 		else
 			hipLaunchKernelGGL(gec::blake2b_batch<1>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a);
 	}
+	HIP_TRY(hipGetLastError());
+	return GEC_OK;
+}
+
+int mlh_roots_dev(const gec_codec *c, size_t n, const uint64_t *lsum, uint32_t nleaf_max, const uint64_t *d_len, size_t len,
+		  uint8_t *d_out, hipStream_t stream, const uint32_t *slot_map, uint32_t group, uint32_t out_group)
+{
+	if (n == 0)
+		return GEC_OK;
+	if (n > 0xffffffffull)
+		return fail(GEC_E_INVALID_ARG, "too many shards for one call");
+	gec::Blake2Args a;
+	a.base = nullptr;
+	a.off = nullptr;
+	a.len = d_len;
+	a.stride = 0;
+	a.uniform_len = len;
+	a.out = d_out;
+	a.n = (uint32_t)n;
+	a.group = group;
+	a.group_stride = 0;
+	a.out_group = out_group;
+	hipLaunchKernelGGL(gec::mlh_roots, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a, nleaf_max, lsum, slot_map);
 	HIP_TRY(hipGetLastError());
 	return GEC_OK;
 }

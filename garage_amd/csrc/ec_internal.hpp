@@ -119,6 +119,7 @@ struct gec_codec {
 	int device = -1;                // HIP device index; -1 for a CPU codec
 	int matrix = GEC_MATRIX_VANDERMONDE;
 	int qos_class = GEC_CLASS_FOREGROUND;
+	int sumkind = GEC_SHARDSUM_MLH64;  // which shard checksum the *_hash / shardsum entry points produce
 	gec::Matrix enc;                // (k+m) x k
 
 	// decode-plan LRU, keyed by present bitmap + data_only (the crate keeps an LRU of decode matrices [EXT])

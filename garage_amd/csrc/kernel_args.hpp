@@ -41,6 +41,10 @@ struct ApplyArgs {
 	// coef[t][r] = mat[r][t]: one 8-byte row per input shard.  The 16-row kernel (MW = 4) reads the
 	// same bytes as a flat [k][16] array (k <= K16MAX).
 	uint8_t coef[KMAX][RMAX];
+	// SUM forms only (shard checksum v3, mlh64_dev.hpp): leaf sums of block b go to
+	//   lsum[((b * sum_slots_total + sum_slot0 + slot) * sum_nleaf_max) + leaf],   slot = input t (sum_inputs) then row r
+	uint64_t *lsum;
+	uint32_t sum_nleaf_max, sum_slots_total, sum_slot0, sum_inputs;
 };
 
 // exp[512] | log[256], filled by the host from gec::Field (768 bytes).

@@ -33,6 +33,7 @@
 #include <stdint.h>
 
 #include "kernel_args.hpp"  // argument structs and limits shared with the host-only translation units
+#include "mlh64_dev.hpp"    // shard checksum v3: the lane terms the SUM forms of the kernels below accumulate
 
 namespace gec {
 
@@ -138,7 +139,11 @@ __device__ __forceinline__ void st16(u32x4 v, u32x4 *p)
 		*p = v;
 }
 
-template <int MW, int MODE, int KC, int CPT, bool NT, int TPB>
+// SUM: the kernel also leaves the MLH64 leaf sums (shard checksum v3, mlh64.hpp) of every shard it reads and of every row it
+// writes (compare modes: of every stored row it checks) in a.lsum -- from the registers that hold the bytes anyway.  Tiles
+// are then cut per block (tile = TPB columns of ONE block, i.e. TPB/256 whole leaves of each of its shards; the last tile of
+// a block is ragged) so that a leaf's 256 terms meet inside one workgroup.
+template <int MW, int MODE, int KC, int CPT, bool NT, int TPB, bool SUM = false>
 __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const LogExp *__restrict__ le)
 {
 	constexpr int ENT = 4 * MW;            // bytes per table entry
@@ -182,23 +187,38 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 	// to a multiple of 8; surplus workgroups exit here, before any barrier.
 	const uint32_t chunk = gridDim.x >> 3;
 	const uint32_t tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-	if ((uint64_t)tile_id * (nthr * CPT) >= a.total_cols)
-		return;
-	const uint32_t g0 = tile_id * (nthr * CPT);
 	bool live[CPT];
 	uint32_t bb[CPT];
 	const u32x4 *srcp[CPT];
 	u32x4 *dstp[CPT];
+	uint32_t sum_tile = 0;  // SUM: this tile's index inside its block (its first leaf = sum_tile * TPB / 256)
+	if constexpr (SUM) {
+		static_assert(CPT == 1 && TPB % 256 == 0, "a leaf is 256 columns: one column per lane, whole leaves per workgroup");
+		if (tile_id >= a.nblocks * a.tiles_per_block)
+			return;
+		bb[0] = tile_id / a.tiles_per_block;
+		sum_tile = tile_id - bb[0] * a.tiles_per_block;
+		uint32_t col = sum_tile * nthr + tid;
+		live[0] = col < a.cols;
+		if (!live[0])
+			col = sum_tile * nthr;  // lanes past the end of the shard shadow the tile's first column (loads only)
+		srcp[0] = reinterpret_cast<const u32x4 *>(a.in + (uint64_t)bb[0] * a.in_stride) + a.col0 + col;
+		dstp[0] = reinterpret_cast<u32x4 *>(a.out + (uint64_t)bb[0] * a.out_stride) + a.col0 + col;
+	} else {
+		if ((uint64_t)tile_id * (nthr * CPT) >= a.total_cols)
+			return;
+		const uint32_t g0 = tile_id * (nthr * CPT);
 #pragma unroll
-	for (int c = 0; c < CPT; ++c) {
-		uint32_t gcol = g0 + tid + c * nthr;
-		live[c] = gcol < a.total_cols;
-		if (!live[c])
-			gcol = g0;  // lanes past the end shadow the tile's first column (loads only)
-		bb[c] = gcol / a.cols;
-		const uint32_t col = gcol - bb[c] * a.cols;
-		srcp[c] = reinterpret_cast<const u32x4 *>(a.in + (uint64_t)bb[c] * a.in_stride) + a.col0 + col;
-		dstp[c] = reinterpret_cast<u32x4 *>(a.out + (uint64_t)bb[c] * a.out_stride) + a.col0 + col;
+		for (int c = 0; c < CPT; ++c) {
+			uint32_t gcol = g0 + tid + c * nthr;
+			live[c] = gcol < a.total_cols;
+			if (!live[c])
+				gcol = g0;  // lanes past the end shadow the tile's first column (loads only)
+			bb[c] = gcol / a.cols;
+			const uint32_t col = gcol - bb[c] * a.cols;
+			srcp[c] = reinterpret_cast<const u32x4 *>(a.in + (uint64_t)bb[c] * a.in_stride) + a.col0 + col;
+			dstp[c] = reinterpret_cast<u32x4 *>(a.out + (uint64_t)bb[c] * a.out_stride) + a.col0 + col;
+		}
 	}
 
 	// -- prologue 0: log/antilog image (768 B) and coefficient rows (k*CR B) are
@@ -210,6 +230,17 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 	const uint32_t ncw = k * (CR / 4);  // coefficient dwords
 	const uint32_t coef_idx = tid < ncw ? tid : ncw - 1;
 	const uint32_t coef_word = reinterpret_cast<const uint32_t *>(&a.coef[0][0])[coef_idx];
+	// SUM: this lane's four checksum keys (its column's place in its leaf), zero for a lane past the end of the shard
+	mlh_u32x4 k4 = {0, 0, 0, 0};
+	constexpr int SUMCAP = TPB > 256 ? 8 : 16;  // slots a wave's LDS region holds between two flushes (>= KC, see the host)
+	WaveSums<SUMCAP> ws;
+	if constexpr (SUM) {
+		static_assert(KC <= SUMCAP, "a batch of loads must fit the wave's region");
+		k4 = mlh_keys_of(tid);
+		if (!live[0])
+			k4 = mlh_u32x4{0, 0, 0, 0};
+		ws.init(lds + ((k * TBL + 768 + k * CR + 15) & ~15u), tid, TPB / 64);
+	}
 
 	// -- first batch of data loads goes out now; HBM latency covers the table expansion
 	u32x4 d[KC][CPT];
@@ -285,10 +316,18 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 					d[j][c] = ld16<NT>(srcp[c] + off);
 			}
 		}
+		if constexpr (SUM) {
+			if (a.sum_inputs && ws.full(KC))
+				ws.flush();
+		}
 #pragma unroll
 		for (int j = 0; j < KC; ++j) {
 			if (t0 + j >= k)
 				break;
+			if constexpr (SUM) {
+				if (a.sum_inputs)
+					ws.put(mlh_col(d[j][0], k4));
+			}
 			// absolute LDS byte address of this shard's lo table (wave-uniform -> SGPR)
 			const uint32_t tb = __builtin_amdgcn_readfirstlane(lds_base + (t0 + j) * TBL);
 #pragma unroll
@@ -320,7 +359,7 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 			for (int w = 0; w < 4; ++w)
 				transpose4x4(acc[c][w][0][h], acc[c][w][1][h], acc[c][w][2][h], acc[c][w][3][h],
 					     P[4 * h + 0][w], P[4 * h + 1][w], P[4 * h + 2][w], P[4 * h + 3][w]);
-		if (!live[c])
+		if (!SUM && !live[c])
 			continue;
 #pragma unroll
 		for (int r = 0; r < 4 * MW; ++r) {
@@ -328,19 +367,41 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 				continue;
 			u32x4 v = {P[r][0], P[r][1], P[r][2], P[r][3]};
 			u32x4 *o = dstp[c] + a.out_off[r];
+			if constexpr (SUM) {  // (rows go into the wave's region in groups of at most eight)
+				if ((r & 7) == 0 && ws.full(rows - r < 8 ? rows - r : 8))
+					ws.flush();
+			}
 			if (MODE == MODE_COMPARE || MODE == MODE_COMPARE_PF) {
 				u32x4 old;
 				if constexpr (MODE == MODE_COMPARE_PF)
 					old = oldv[c][r < NOLD ? r : 0];
 				else
-					old = ld16<NT>(o);
+					old = ld16<NT>(o);  // (a lane past the end reads the tile's first column: valid memory, term zeroed by k4)
 				diff |= (v.x ^ old.x) | (v.y ^ old.y) | (v.z ^ old.z) | (v.w ^ old.w);
+				if constexpr (SUM)
+					ws.put(mlh_col(old, k4));  // the STORED row: what the shard's header vouches for
 			} else {
-				st16<NT>(v, o);
+				if (!SUM || live[c])
+					st16<NT>(v, o);
+				if constexpr (SUM)
+					ws.put(mlh_col(v, k4));
 			}
 		}
-		if ((MODE == MODE_COMPARE || MODE == MODE_COMPARE_PF) && diff)
+		if ((MODE == MODE_COMPARE || MODE == MODE_COMPARE_PF) && diff && live[c])
 			a.bad[bb[c]] = 1u;
+	}
+	if constexpr (SUM) {
+		// the waves' totals meet: one barrier at the very end of the tile, then 8 bytes per (slot, leaf)
+		ws.flush();
+		__syncthreads();
+		const uint32_t nsl = (a.sum_inputs ? k : 0u) + rows;
+		const uint32_t leaf0 = sum_tile * (TPB / 256);
+		uint64_t *dst = a.lsum + ((uint64_t)bb[0] * a.sum_slots_total + a.sum_slot0) * a.sum_nleaf_max;
+		const uint32_t nleaf = (a.cols + 255) >> 8;
+		ws.combine(tid, nthr, nsl, [&](uint32_t slot, uint32_t g, uint64_t v) {
+			if (leaf0 + g < nleaf)
+				dst[(uint64_t)slot * a.sum_nleaf_max + leaf0 + g] = v;
+		});
 	}
 }
 
@@ -348,6 +409,13 @@ template <int MW, int MODE, int KC, int CPT, bool NT, int TPB>
 __global__ __launch_bounds__(TPB) void gf_apply_nibble(const ApplyArgs a, const LogExp *__restrict__ le)
 {
 	gf_apply_nibble_body<MW, MODE, KC, CPT, NT, TPB>(a, le);
+}
+
+// the same kernel leaving the shard checksums' leaf sums behind (see SUM above)
+template <int MW, int MODE, int KC, bool NT, int TPB>
+__global__ __launch_bounds__(TPB) void gf_apply_nibble_sum(const ApplyArgs a, const LogExp *__restrict__ le)
+{
+	gf_apply_nibble_body<MW, MODE, KC, 1, NT, TPB, true>(a, le);
 }
 
 template <int MW, int MODE, int KC, int CPT, bool NT, int TPB, int MINW>

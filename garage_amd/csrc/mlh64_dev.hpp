@@ -1,0 +1,205 @@
+// mlh64_dev.hpp -- shard checksum v3 on gfx950 (definition and rationale: mlh64.hpp).
+//
+// Three producers of LEAF SUMS (8 bytes per 4 KiB leaf, lsum[shard * nleaf_max + leaf]) and one consumer:
+//   * the RS kernels themselves (kernels.hpp: gf_apply_nibble<.., SUM>, gf_apply_ptrs<.., SUM>) -- every lane already holds
+//     16 bytes of each input shard (d[j]) and of each output row (P[r]) in registers; four v_mad_u64_u32 turn them into the
+//     lane's term of the leaf sum.  No extra HBM or link traffic: the checksum costs VALU slots only
+//     (4 half-rate ops per 16 bytes = 0.5 full-rate op per byte, tools/csum_probe);
+//   * mlh_leaves: a plain streaming kernel for shards that no RS kernel is touching (gec_shardsum_batch[_dev], the shards
+//     a read uploads);
+//   * mlh_roots: one lane per shard, BLAKE2b over "GECSUM3\0" || len || leaf sums (two compressions for a 104 KiB shard).
+//
+// Cross-lane reduction (WaveSums).  A lane's term must meet the other 255 terms of its leaf.  DPP butterflies over 14-28
+// 64-bit values cost more VALU than the multiplies; LDS atomics serialize.  So: every wave owns an LDS region
+// [64 lanes][CAP slots] of 64-bit terms (lane-major, 8 bytes of padding per lane: conflict-free writes), a lane drops its
+// term for slot s there as soon as it has it (one ds_write_b64, nothing kept in registers), and when the region is full --
+// or at the end of the tile -- the wave sums it up: lane (s, q) adds the terms of lanes 8q..8q+7 for slot s (8 ds_read_b64),
+// three xor-shuffles finish the 64 -> 1, and the wave's total goes to wsum[slot][wave].  One barrier at the very end of the
+// tile, then (slot, leaf) threads add the four waves of a leaf and store 8 bytes.  Wave-private regions need no barrier
+// while the tile is being computed (LDS operations of one wave execute in order).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "blake2b.hpp"
+#include "mlh64.hpp"
+
+namespace gec {
+
+__device__ const mlh::KeyTable MLH_KEYS = mlh::make_keys();
+
+typedef uint32_t mlh_u32x4 __attribute__((ext_vector_type(4)));
+
+// the four keys of 16-byte column `col` (0..255) of a leaf
+__device__ __forceinline__ mlh_u32x4 mlh_keys_of(uint32_t col)
+{
+	return reinterpret_cast<const mlh_u32x4 *>(MLH_KEYS.k)[col & 255u];
+}
+
+// a lane's term: K[4c..4c+3] . (the column's four words), mod 2^64 -- four v_mad_u64_u32
+__device__ __forceinline__ uint64_t mlh_col(const mlh_u32x4 d, const mlh_u32x4 k)
+{
+	uint64_t s = (uint64_t)k.x * d.x;
+	s += (uint64_t)k.y * d.y;
+	s += (uint64_t)k.z * d.z;
+	s += (uint64_t)k.w * d.w;
+	return s;
+}
+
+constexpr uint32_t mlh_region_bytes(int cap) { return 64u * (8u * cap + 8u); }
+
+// LDS a workgroup of `waves` waves needs for nsl slots: the wave regions + wsum[nsl][waves]
+constexpr uint32_t mlh_lds_bytes(int cap, int waves, int nsl) { return waves * mlh_region_bytes(cap) + (uint32_t)nsl * waves * 8u; }
+
+template <int CAP>
+struct WaveSums {
+	typedef __attribute__((address_space(3))) uint64_t lds_u64;
+	uint8_t *region;   // this wave's [64][CAP] (+8 bytes per lane)
+	uint64_t *wsum;    // [nsl][waves]
+	uint32_t lane, wave, waves;
+	uint32_t pend = 0, base = 0;  // slots waiting in the region / slots already summed up (wave-uniform)
+
+	__device__ __forceinline__ void init(uint8_t *lds_area, uint32_t tid, uint32_t nwaves)
+	{
+		lane = tid & 63u;
+		wave = tid >> 6;
+		waves = nwaves;
+		region = lds_area + wave * mlh_region_bytes(CAP);
+		wsum = reinterpret_cast<uint64_t *>(lds_area + nwaves * mlh_region_bytes(CAP));
+	}
+	// this lane's term for the next slot (slots are pushed in ascending order by every lane of the wave)
+	__device__ __forceinline__ void put(uint64_t v)
+	{
+		*reinterpret_cast<uint64_t *>(region + lane * (8u * CAP + 8u) + 8u * pend) = v;
+		++pend;
+	}
+	__device__ __forceinline__ bool full(uint32_t more) const { return pend + more > (uint32_t)CAP; }
+	// sums the region up: wsum[base + s][wave] for s < pend
+	__device__ __forceinline__ void flush()
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const uint32_t q = lane & 7u;
+		for (uint32_t s0 = 0; s0 < pend; s0 += 8) {  // (wave-uniform trip count)
+			const uint32_t s = s0 + (lane >> 3);
+			uint64_t acc = 0;
+			if (s < pend) {
+				const uint8_t *p = region + (q * 8u) * (8u * CAP + 8u) + 8u * s;
+#pragma unroll
+				for (int i = 0; i < 8; ++i)
+					acc += *reinterpret_cast<const uint64_t *>(p + i * (8u * CAP + 8u));
+			}
+			acc += __shfl_xor(acc, 1);
+			acc += __shfl_xor(acc, 2);
+			acc += __shfl_xor(acc, 4);
+			if (q == 0 && s < pend)
+				wsum[(base + s) * waves + wave] = acc;
+		}
+		base += pend;
+		pend = 0;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+	// After the workgroup's barrier: thread t < nsl * leaves adds the waves of (slot, leaf-of-the-tile) and hands the
+	// sum to store(slot, leaf_in_tile, value).  leaves = waves / 4.
+	template <class Store>
+	__device__ __forceinline__ void combine(uint32_t tid, uint32_t nthr, uint32_t nsl, Store store) const
+	{
+		const uint32_t leaves = waves >> 2;
+		for (uint32_t t = tid; t < nsl * leaves; t += nthr) {
+			const uint32_t slot = t / leaves, g = t - slot * leaves;
+			const uint64_t *w = wsum + slot * waves + 4 * g;
+			store(slot, g, w[0] + w[1] + w[2] + w[3]);
+		}
+	}
+};
+
+// ---------------------------------------------------------------------------
+// mlh_leaves: leaf sums of n shards that sit in memory (device, or pinned host memory read over the link).
+// One wave per leaf, four 16-byte columns per lane (the whole leaf is requested before the first multiply), addressed
+// like the BLAKE2b kernels (Blake2Args: base + stride / group / per-message offsets and lengths; bytes past a
+// shard's length read as zero).  lsum[shard * nleaf_max + leaf].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mlh_leaves(const Blake2Args a, uint32_t nleaf_max, uint64_t *__restrict__ lsum)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint64_t total = (uint64_t)a.n * nleaf_max;
+	const uint64_t wl = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (shard, leaf) of this wave
+	if (wl >= total)
+		return;
+	const uint32_t s = (uint32_t)(wl / nleaf_max), l = (uint32_t)(wl - (uint64_t)s * nleaf_max);
+	const uint64_t slen = a.len ? a.len[s] : a.uniform_len;
+	const uint32_t nleaf = (uint32_t)((slen + mlh::LEAF_BYTES - 1) / mlh::LEAF_BYTES);
+	if (l >= nleaf)
+		return;
+	const uint8_t *p = b2_msg_ptr(a, s) + (uint64_t)l * mlh::LEAF_BYTES;
+	const uint64_t left = slen - (uint64_t)l * mlh::LEAF_BYTES;  // bytes of the shard from the start of this leaf
+	const bool al16 = ((uintptr_t)p & 15u) == 0;
+	mlh_u32x4 d[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const uint32_t off = (uint32_t)(i * 64 + lane) * 16u;
+		if (al16 && (uint64_t)off + 16 <= left) {
+			d[i] = __builtin_nontemporal_load(reinterpret_cast<const mlh_u32x4 *>(p + off));
+		} else {
+			uint32_t w[4] = {0, 0, 0, 0};
+			for (uint32_t b = 0; b < 16 && (uint64_t)off + b < left; ++b)  // the ragged end, or an unaligned buffer
+				w[b >> 2] |= (uint32_t)p[off + b] << (8 * (b & 3));
+			d[i] = mlh_u32x4{w[0], w[1], w[2], w[3]};
+		}
+	}
+	uint64_t acc = 0;
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+		acc += mlh_col(d[i], mlh_keys_of(i * 64 + lane));
+	acc += __shfl_xor(acc, 1);
+	acc += __shfl_xor(acc, 2);
+	acc += __shfl_xor(acc, 4);
+	acc += __shfl_xor(acc, 8);
+	acc += __shfl_xor(acc, 16);
+	acc += __shfl_xor(acc, 32);
+	if (lane == 0)
+		lsum[wl] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// mlh_roots: one lane per shard.  Message = MAGIC || len || s_0 .. s_{nleaf-1}; placement of the 32-byte result like the
+// BLAKE2b kernels (b2_out_ptr).  slot_map != NULL: shard i's leaf sums are at lsum[slot_map[i] * nleaf_max] (the RS kernels
+// number their sums (block, slot); the caller wants (block, shard index)), otherwise at lsum[i * nleaf_max].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mlh_roots(const Blake2Args a, uint32_t nleaf_max, const uint64_t *__restrict__ lsum,
+						const uint32_t *__restrict__ slot_map)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= a.n)
+		return;
+	const uint64_t slen = a.len ? a.len[i] : a.uniform_len;
+	const uint32_t nleaf = (uint32_t)((slen + mlh::LEAF_BYTES - 1) / mlh::LEAF_BYTES);
+	const uint64_t *sums = lsum + (uint64_t)(slot_map ? slot_map[i] : i) * nleaf_max;
+	const uint64_t len = mlh::ROOT_HEADER_BYTES + 8ull * nleaf;
+	uint64_t h[8] = {0x6a09e667f3bcc908ULL ^ 0x01010040ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+			 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+	uint64_t m[16];
+	// word w of the message: 0 = magic, 1 = length, 2 + j = leaf sum j
+	auto word = [&](uint64_t w) -> uint64_t { return w == 0 ? mlh::ROOT_MAGIC : w == 1 ? slen : (w - 2 < nleaf ? sums[w - 2] : 0); };
+	uint64_t done = 0;
+	while (len - done > 128) {
+#pragma unroll
+		for (int j = 0; j < 16; ++j)
+			m[j] = word(done / 8 + j);
+		done += 128;
+		b2_compress<0>(h, m, done, false);
+	}
+#pragma unroll
+	for (int j = 0; j < 16; ++j)
+		m[j] = done + 8 * j < len ? word(done / 8 + j) : 0;
+	b2_compress<0>(h, m, len, true);
+	u64x2 *o = reinterpret_cast<u64x2 *>(b2_out_ptr(a, i));
+	o[0] = u64x2{h[0], h[1]};
+	o[1] = u64x2{h[2], h[3]};
+}
+
+}  // namespace gec
