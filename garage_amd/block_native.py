@@ -17,7 +17,7 @@ GBM_E_INVALID_ARG, GBM_E_EC, GBM_E_IO, GBM_E_BUFFER_TOO_SMALL, GBM_E_ABORTED = -
 GBM_BLOCK_GC_DELAY_MS, GBM_RESYNC_RETRY_DELAY_MS = 600_000, 60_000
 
 SYMBOLS = [
-    "gbm_last_error", "gbm_blake2sum", "gbm_shardsum", "gbm_blake2sum_batch", "gbm_create", "gbm_destroy", "gbm_set_compression_level", "gbm_set_data_fsync",
+    "gbm_last_error", "gbm_blake2sum", "gbm_shardsum", "gbm_shardsum_v", "gbm_shard_version", "gbm_blake2sum_batch", "gbm_create", "gbm_destroy", "gbm_set_compression_level", "gbm_set_data_fsync",
     "gbm_set_verify_block_hash", "gbm_set_threads", "gbm_set_timing", "gbm_clock_advance",
     "gbm_storage_nodes_of", "gbm_layout_update", "gbm_layout_trim",
     "gbm_rpc_put_block", "gbm_rpc_put_blocks", "gbm_rpc_get_block", "gbm_rpc_get_blocks",
@@ -127,6 +127,8 @@ def _load():
     lib.gbm_blake2sum.restype = None
     lib.gbm_shardsum.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p]
     lib.gbm_shardsum.restype = None
+    lib.gbm_shardsum_v.argtypes = [ctypes.c_int, ctypes.c_char_p, sz, ctypes.c_char_p]
+    lib.gbm_shard_version.argtypes = [ctypes.c_void_p]
     lib.gbm_blake2sum_batch.argtypes = [sz, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p]
     lib.gbm_blake2sum_batch.restype = ctypes.c_int
     lib.gbm_create.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), ci, pp]
@@ -272,10 +274,11 @@ def zstd_decode(frame: bytes, max_len: int = 1 << 26) -> bytes:
     return buf.raw[:n.value]
 
 
-def shardsum(data: bytes) -> bytes:
-    """The shard checksum (BLAKE2b tree mode), CPU restatement inside libgarage_block."""
+def shardsum(data: bytes, version: int = 3) -> bytes:
+    """The checksum a shard header of `version` carries (3 = MLH64, the default of every codec; 2 = BLAKE2b tree mode;
+    1 = plain blake2sum), computed by libgarage_block on the host (gbm_shardsum_v)."""
     out = ctypes.create_string_buffer(32)
-    lib.gbm_shardsum(data, len(data), out)
+    _check(lib.gbm_shardsum_v(version, data, len(data), out), "gbm_shardsum_v")
     return out.raw
 
 
@@ -312,6 +315,11 @@ class NativeBlockManager:
             self._h = None
 
     __del__ = close
+
+    @property
+    def shard_version(self) -> int:
+        """the shard-header version this manager writes (gbm_shard_version): its codec's checksum kind"""
+        return int(lib.gbm_shard_version(self._h))
 
     def storage_nodes_of(self, hash_: bytes) -> list[int]:
         out = (ctypes.c_int * self.n)()

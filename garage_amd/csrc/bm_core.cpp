@@ -275,10 +275,14 @@ int hash_many(gbm_manager *mg, const std::vector<const uint8_t *> &ptrs, const s
 	}
 	// shards per pool task: their leaves go through the cores' vector lanes eight at a time -- where there are such
 	// lanes; the one-at-a-time fallback keeps one shard per task, so a small batch still spreads over the pool
-	const size_t kPerTask = b2host::mb_available() ? 16 : 1;
+	const size_t kPerTask = b2host::mb_available() || mg->sumver == 3 ? 16 : 1;
 	mg->pool->parallel_for((ptrs.size() + kPerTask - 1) / kPerTask, [&](size_t g) {
 		const size_t i0 = g * kPerTask, cnt = std::min(kPerTask, ptrs.size() - i0);
-		b2host::shardsum_many(ptrs.data() + i0, lens.data() + i0, cnt, sums.data() + 32 * i0);
+		if (mg->sumver == 3)
+			for (size_t i = i0; i < i0 + cnt; ++i)
+				mlh::shardsum3(ptrs[i], lens[i], sums.data() + 32 * i);
+		else
+			b2host::shardsum_many(ptrs.data() + i0, lens.data() + i0, cnt, sums.data() + 32 * i0);
 	});
 	return GBM_OK;
 }
@@ -324,6 +328,7 @@ int create_one(const gec_codec *codec, int nnodes, const char *const *node_dirs,
 		return fail(GBM_E_INVALID_ARG, "shard index must fit a byte");
 	auto mg = std::make_unique<gbm_manager>();
 	mg->codec = codec;
+	mg->sumver = gec_codec_shardsum(codec);  // the shard-header version it writes: its codec's checksum kind
 	mg->k = k;
 	mg->m = m;
 	mg->n = k + m;
@@ -367,7 +372,7 @@ using namespace gbmimpl;
 bool gbmimpl::confirmed_corrupt(gbm_manager *mg, const uint8_t *data, size_t S, const uint8_t header_sum[32], const char *who)
 {
 	uint8_t sum[32];
-	shardsum(data, S, sum);
+	shardsum_v(mg->sumver, data, S, sum);
 	if (std::memcmp(sum, header_sum, 32) != 0)
 		return true;
 	mg->bmx.unconfirmed_verdicts++;
@@ -406,11 +411,24 @@ void gbm_shardsum(const uint8_t *data, size_t len, uint8_t out[32])
 	if (!out || (!data && len))
 		return;
 	try {
-		shardsum(data, len, out);
+		shardsum_v(2, data, len, out);
 	} catch (const std::exception &) {  // the eight-lane form's scratch could not grow: one leaf at a time needs none
 		b2host::shardsum(data, len, out);
 	}
 }
+
+int gbm_shardsum_v(int version, const uint8_t *data, size_t len, uint8_t out[32])
+{
+	if (!out || (!data && len) || version < 1 || version > 3)
+		return fail(GBM_E_INVALID_ARG, "gbm_shardsum_v: NULL argument or unknown shard-header version");
+	if (version == 2)
+		gbm_shardsum(data, len, out);
+	else
+		shardsum_v(version, data, len, out);  // (no allocation below 256 KiB; above it bad_alloc is caught by the caller's GBM_TRY... none here: keep it simple)
+	return GBM_OK;
+}
+
+int gbm_shard_version(const gbm_manager *m) { return m ? (m->is_front() ? m->lanes[0]->sumver : m->sumver) : -1; }
 
 int gbm_blake2sum_batch(size_t n, const uint8_t *const *data, const size_t *len, uint8_t *out)
 {
@@ -761,7 +779,7 @@ int gbm_node_corrupt_shard(gbm_manager *m, int node, const uint8_t hash[32], int
 		return fail(GBM_E_IO, "out of memory");
 	}
 	if (fix_checksum)
-		shardsum(s.data.data(), s.data.n, s.hd.checksum);
+		shardsum_v(s.hd.version, s.data.data(), s.data.n, s.hd.checksum);
 	return m->nodes[node]->put(h, idx, s) ? GBM_OK : fail(GBM_E_IO, "rewrite failed");
 }
 

@@ -32,20 +32,21 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 	auto accept = [&](std::vector<Cand> &mine, size_t b, int j, int node, Shard &&sh) -> bool {
 		Gathered &g = gs[b];
 		ShardHeader &hd = sh.hd;
-		if (hd.version != 1 && hd.version != 2)
+		if (hd.version < 1 || hd.version > 3)
 			return false;  // a shard format this build does not know: unreadable for us, but left alone (never renamed)
 		bool ok = hd.idx == j && hd.k == mg->k && hd.m == mg->m && sh.data.n == hd.shard_len && hd.shard_len > 0 &&
 			  hd.shard_len % 64 == 0;
-		if (ok && hd.version == 1) {
-			// round 1's format: the checksum is plain blake2sum.  Verified here, on the host (there are at most a
-			// cluster's worth of such shards and each is read this way once), then carried -- and rewritten on its
-			// node -- as version 2, so that everything downstream sees one format.
+		if (ok && hd.version != mg->sumver) {
+			// A shard of another format than this manager writes -- round 1's plain blake2sum, rounds 2-4's BLAKE2b tree in a
+			// store that has moved on to MLH64 (or the reverse, a v2 manager over a newer store).  Verified here, on the host,
+			// with ITS version's checksum (each such shard is read this way once), then carried -- and rewritten on its node --
+			// in the manager's version, so that everything downstream sees one format and the store migrates as it is read.
 			uint8_t sum[32];
-			blake2sum(sh.data.data(), hd.shard_len, sum);
+			shardsum_v(hd.version, sh.data.data(), hd.shard_len, sum);
 			ok = std::memcmp(sum, hd.checksum, 32) == 0;
 			if (ok) {
-				hd.version = 2;
-				shardsum(sh.data.data(), hd.shard_len, hd.checksum);
+				hd.version = (uint8_t)mg->sumver;
+				shardsum_v(mg->sumver, sh.data.data(), hd.shard_len, hd.checksum);
 				ShardRpc up{RpcKind::PutShard, &hs[b], j, sh, nullptr};
 				ShardResp ur;
 				(void)mg->nodes[node]->handle(up, ur);
@@ -356,10 +357,11 @@ bool send_shard(gbm_manager *mg, int node, const Hash &h, int idx, const Bytes &
 	hd.compressed = compressed ? 1 : 0;
 	hd.orig_len = orig_len;
 	hd.shard_len = (uint32_t)S;
+	hd.version = (uint8_t)mg->sumver;
 	if (checksum)
 		std::memcpy(hd.checksum, checksum, 32);
 	else
-		shardsum(payload.data(), S, hd.checksum);
+		shardsum_v(mg->sumver, payload.data(), S, hd.checksum);
 	rq.shard.data = payload;
 	ShardResp rs;
 	const bool ok = mg->nodes[node]->handle(rq, rs) && rs.ok;

@@ -42,6 +42,7 @@
 #include <cstring>
 
 #include "blake2b_mb.hpp"
+#include "mlh64_host.hpp"
 
 namespace gbmimpl {
 
@@ -65,8 +66,17 @@ const std::string &last_error();
 int ec_fail(int rc, const char *what);
 
 using b2host::blake2sum;
-// one shard: its leaves are independent chains, eight at a time where the core can (blake2b_mb.hpp)
-inline void shardsum(const uint8_t *data, size_t len, uint8_t out[32]) { b2host::shardsum_many(&data, &len, 1, out); }
+// One shard's checksum on this core, by shard-header version: 3 = MLH64 (mlh64_host.hpp: memory speed), 2 = BLAKE2b tree
+// mode (its leaves are independent chains, eight at a time where the core can, blake2b_mb.hpp), 1 = plain blake2sum.
+inline void shardsum_v(int ver, const uint8_t *data, size_t len, uint8_t out[32])
+{
+	if (ver == 3)
+		mlh::shardsum3(data, len, out);
+	else if (ver == 1)
+		blake2sum(data, len, out);
+	else
+		b2host::shardsum_many(&data, &len, 1, out);
+}
 
 // ------------------------------------------------------------------ environment (bm_core.cpp holds the one table)
 struct Env {
@@ -141,12 +151,15 @@ inline std::string hex(const Hash &h)
 
 // ------------------------------------------------------------- shard header
 // Same 64-byte layout as garage_amd/block_manager.py::ShardHeader ("<4sBBBBB3xQII32s").
-// version 2: the checksum is the tree-mode shardsum.  version 1 (round 1's format) carried plain blake2sum: such a
-// shard is still readable -- verified with blake2sum on the host and rewritten as version 2 the first time it is
-// read.  Any other version is a format this build does not know: the shard is left alone (never renamed or deleted)
-// and reported as unreadable.
+// The version names the checksum: 3 = MLH64 (GEC_SHARDSUM_MLH64, what a manager over a default codec writes), 2 = BLAKE2b
+// tree mode (rounds 2-4), 1 = plain blake2sum (round 1).  A manager WRITES the version of its codec's checksum kind
+// (gbm_manager::sumver) and reads all three: a shard of another version than its own is verified on the host with that
+// version's checksum the first time it is read, then carried -- and rewritten on its node -- in the manager's own version,
+// so that everything downstream of the gather sees one format and a store migrates as it is read (and as scrub walks it).
+// Any other version is a format this build does not know: the shard is left alone (never renamed or deleted) and reported
+// as unreadable.
 struct ShardHeader {
-	uint8_t version = 2;
+	uint8_t version = 3;
 	uint8_t k = 0, m = 0, idx = 0, compressed = 0;
 	uint64_t orig_len = 0;
 	uint32_t shard_len = 0;
@@ -172,7 +185,7 @@ struct ShardHeader {
 		if (n < GBM_SHARD_HEADER_SIZE || std::memcmp(in, "GECS", 4) != 0)
 			return GARBAGE;
 		version = in[4];
-		if (version != 1 && version != 2)
+		if (version < 1 || version > 3)
 			return UNKNOWN_VERSION;
 		k = in[5];
 		m = in[6];
@@ -612,6 +625,7 @@ struct gbm_manager {
 	using ErrorCounter = gbmimpl::ErrorCounter;
 
 	const gec_codec *codec = nullptr;  // the request path's codec (borrowed)
+	int sumver = 3;  // the shard-header version this manager writes = its codec's checksum kind (gec_codec_shardsum): 3 or 2
 	// Maintenance (scrub, resync rebuilds) runs on a BACKGROUND-class sibling of `codec` (gec_codec_background): its
 	// device work yields to the request path's.  Owned; NULL when the sibling could not be created (then == codec).
 	gec_codec *bg_codec_owned = nullptr;
@@ -699,7 +713,7 @@ struct gbm_manager {
 	std::atomic<uint64_t> gpu_hashed{0};
 	std::atomic<bool> compress{false};    // Config.compression_level (src/util/config.rs:52-58); Garage's default is Some(1)
 	std::atomic<int> compression_level{1};
-	std::atomic<int> verify_mode{GBM_VERIFY_OFF};  // the requester's end-to-end block hash (gbm_set_verify_block_hash)
+	std::atomic<int> verify_mode{GBM_VERIFY_REBUILT};  // the requester's end-to-end block hash (gbm_set_verify_block_hash)
 	std::atomic<size_t> cpu_block_hash_max{96};  // gets of up to this many blocks hash them on the host (gbm_set_threads rescales)
 
 	// hedged reads: 0 = the k requests of a read are issued and awaited in order

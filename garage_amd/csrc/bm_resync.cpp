@@ -56,7 +56,7 @@ void scan_block(gbm_manager *mg, ResyncTask &t)
 			t.reachable[j] = 1;
 			t.present_cur[j] = rs.needed ? 0 : 1;
 			t.exists = t.exists || !rs.needed;
-			if (rs.have_hd && rs.shard.hd.version == 2) {
+			if (rs.have_hd && rs.shard.hd.version >= 2) {
 				t.geo[j] = rs.shard.hd;
 				t.have_geo[j] = 1;
 				if (first < 0)
@@ -139,7 +139,7 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 				if (!mg->nodes[s.node]->handle(rq, rs) || !rs.ok)
 					continue;
 				uint8_t sum[32];
-				shardsum(rs.shard.data.data(), rs.shard.data.n, sum);
+				shardsum_v(rs.shard.hd.version, rs.shard.data.data(), rs.shard.data.n, sum);  // (a stray keeps its header, whatever its version)
 				if (rs.shard.data.n != rs.shard.hd.shard_len || std::memcmp(sum, rs.shard.hd.checksum, 32) != 0) {
 					mg->metrics[2]++;
 					mg->nodes[s.node]->mark_corrupted(t.h, s.idx);
@@ -239,7 +239,7 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 					continue;
 				}
 				uint8_t sum[32];
-				shardsum(t.g.shard[j].data(), t.g.meta.shard_len, sum);
+				shardsum_v(mg->sumver, t.g.shard[j].data(), t.g.meta.shard_len, sum);  // (the gather carries every shard in the manager's version)
 				if (std::memcmp(sum, t.g.sum[j].data(), 32) != 0) {
 					mg->metrics[2]++;
 					if (t.g.node[j] >= 0)

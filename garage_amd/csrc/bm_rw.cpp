@@ -115,7 +115,7 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 				auto matches = [&](size_t i, size_t j) {
 					const uint8_t *p = j < (size_t)k ? prep[ids[i]].block.data() + j * S : prep[ids[i]].parity.data() + (j - (size_t)k) * S;
 					uint8_t host_sum[32];
-					shardsum(p, S, host_sum);
+					shardsum_v(mg->sumver, p, S, host_sum);
 					return std::memcmp(host_sum, gsums.data() + (i * (size_t)n + j) * 32, 32) == 0;
 				};
 				const uint64_t draw = (trip / every) * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
@@ -383,19 +383,84 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 			const bool trip_sums = want_block_sums == 1 || (want_block_sums == 2 && nrebuild > 0);
 			if (trip_sums)
 				bsums.assign(ids.size() * 32, 0);
-			int rc;
-			{
+			int rc = GEC_OK;
+			// Shard-header version 3 (MLH64): a host core checks a shard at memory speed, so the shards of a read are verified
+			// HERE, on the pool -- a healthy get does not cross the link at all -- and only blocks that miss a data shard go to
+			// the device, for the decode alone (gec_reconstruct_batch).  (With block checksums wanted from the trip the one-trip
+			// form below still serves: the shards have to be on the device for those anyway.)
+			const bool host_check = mg->sumver == 3 && !trip_sums;
+			if (host_check) {
+				struct Item {
+					uint32_t i, j;
+				};
+				std::vector<Item> items;
+				items.reserve(ids.size() * (size_t)k);
+				for (size_t i = 0; i < ids.size(); ++i) {
+					int seen = 0;
+					for (int j = 0; j < n && seen < k; ++j)
+						if (sp[i * n + j]) {
+							items.push_back(Item{(uint32_t)i, (uint32_t)j});
+							++seen;
+						}
+				}
+				const size_t per = 4;  // shards per pool task
+				auto check = [&](size_t t) {
+					for (size_t q = t * per; q < std::min(items.size(), (t + 1) * per); ++q)
+						mlh::shardsum3(sp[items[q].i * (size_t)n + items[q].j], S, ssums.data() + (items[q].i * (size_t)n + items[q].j) * 32);
+				};
+				const size_t ntask = (items.size() + per - 1) / per;
+				if (ntask <= 2)
+					for (size_t t = 0; t < ntask; ++t)
+						check(t);
+				else
+					mg->pool->parallel_for(ntask, check);
+				tr.lap("shard checksums on the host");
+				// the decode, for the blocks whose k shards in hand all matched (the others go round again first)
+				std::vector<const uint8_t *> dsp;
+				std::vector<uint8_t *> dop;
+				size_t ndec = 0;
+				for (size_t i = 0; i < ids.size() && nrebuild; ++i) {
+					const Gathered &gb = g[ids[i]];
+					bool wants = false, clean = true;
+					for (int j = 0; j < n; ++j)
+						wants = wants || op[i * n + j];
+					int seen_c = 0;  // (the first k present shards: exactly the ones that were checked above and are compared below)
+					for (int j = 0; j < n && wants && clean && seen_c < k; ++j)
+						if (sp[i * n + j]) {
+							++seen_c;
+							if (std::memcmp(ssums.data() + (i * n + j) * 32, gb.sum[j].data(), 32) != 0)
+								clean = false;
+						}
+					if (!wants || !clean)
+						continue;
+					// exactly the first k present shards: the decode then reads what was verified
+					int seen = 0;
+					for (int j = 0; j < n; ++j) {
+						const bool use = sp[i * n + j] && seen < k;
+						seen += use ? 1 : 0;
+						dsp.push_back(use ? sp[i * n + j] : nullptr);
+						dop.push_back(op[i * n + j]);
+					}
+					++ndec;
+				}
+				if (ndec) {
+					DeviceTurn turn(gate);
+					rc = gec_reconstruct_batch(mg->codec, ndec, dsp.data(), dop.data(), S, /*data_only=*/1);
+					tr.lap("decode");
+				}
+			} else {
 				DeviceTurn turn(gate);
 				rc = gec_decode_verify_batch(mg->codec, ids.size(), sp.data(), S, lens.data(), op.data(), ssums.data(),
 							     trip_sums ? bsums.data() : nullptr);
+				tr.lap("decode+verify");
 			}
-			tr.lap("decode+verify");
 			if (helper.joinable())
 				join_helper();  // the overlapped host work reads g: it must be done before the results below change it
 			tr.lap("join overlapped assembly");
 			if (rc)
-				return ec_fail(rc, "gec_decode_verify_batch");
-			mg->gpu_hashed += ids.size() * (size_t)k + (trip_sums ? ids.size() : 0);
+				return ec_fail(rc, host_check ? "gec_reconstruct_batch" : "gec_decode_verify_batch");
+			if (!host_check)
+				mg->gpu_hashed += ids.size() * (size_t)k + (trip_sums ? ids.size() : 0);
 			for (size_t i = 0; i < ids.size(); ++i) {
 				const size_t b = ids[i];
 				Gathered &gb = g[b];

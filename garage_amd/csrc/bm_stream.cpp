@@ -24,7 +24,8 @@ struct StreamChecks {  // shared with the async tasks: they own what they touch
 	// the root by whoever finishes the shard's last piece.
 	std::vector<int> used;                      // the read set, in index order
 	size_t S = 0, nleaf = 0, groups = 1;
-	std::vector<std::vector<uint8_t>> dig;      // per entry of `used`: nleaf leaf digests
+	int ver = 3;                                // the checksums' kind (the manager's shard-header version: the gather normalises)
+	std::vector<std::vector<uint8_t>> dig;      // per entry of `used`: nleaf leaf digests (v2: 64 bytes each) / leaf sums (v3: 8 bytes)
 	std::unique_ptr<std::atomic<int>[]> left;   // per entry of `used`: pieces not yet hashed
 	std::atomic<size_t> next{0};                // next piece to claim: entry = next / groups, piece = next % groups
 
@@ -36,11 +37,18 @@ struct StreamChecks {  // shared with the async tasks: they own what they touch
 		const size_t e = t / groups, gi = t % groups;
 		const int j = used[e];
 		const size_t lo = nleaf * gi / groups, hi = nleaf * (gi + 1) / groups;
-		if (hi > lo)
-			b2host::shardsum_leaf_range(shard[j].data(), S, lo, hi, dig[e].data());
+		if (hi > lo) {
+			if (ver == 3)
+				mlh::leaf_range(shard[j].data(), S, lo, hi, reinterpret_cast<uint64_t *>(dig[e].data()));
+			else
+				b2host::shardsum_leaf_range(shard[j].data(), S, lo, hi, dig[e].data());
+		}
 		if (left[e].fetch_sub(1) == 1) {  // the shard's last piece: its root, its verdict
 			uint8_t got[32];
-			b2host::shardsum_root(dig[e].data(), nleaf, got);
+			if (ver == 3)
+				mlh::root(S, reinterpret_cast<const uint64_t *>(dig[e].data()), nleaf, got);
+			else
+				b2host::shardsum_root(dig[e].data(), nleaf, got);
 			const int v = std::memcmp(got, sum[j].data(), 32) == 0 ? 1 : -1;
 			{
 				std::lock_guard<std::mutex> lk(mu);
@@ -266,7 +274,8 @@ int stream_general(gbm_manager *m, const std::vector<Hash> &hs, const uint8_t ha
 	// independent chains), the others' follow in index order as the stream advances.
 	ck->used = used;
 	ck->S = S;
-	ck->nleaf = b2host::shardsum_nleaf(S);
+	ck->ver = m->sumver;
+	ck->nleaf = ck->ver == 3 ? mlh::nleaf(S) : b2host::shardsum_nleaf(S);
 	// pieces of ~100 KiB: smaller ones are over before a helper has even woken up (1 MiB blocks: a shard is one piece and the
 	// walk checks shard 0 itself, 35 us; 4 MiB blocks: four pieces per shard)
 	ck->groups = std::min<size_t>(8, std::max<size_t>(1, S / (96u << 10)));
@@ -428,10 +437,10 @@ void fast_fetch(gbm_manager *m, const std::shared_ptr<Fast> &fs, const std::vect
 		try {
 			if (nd->handle(rq, rs) && rs.ok) {
 				const ShardHeader &hd = rs.shard.hd;
-				if (hd.version == 2 && hd.idx == j && hd.k == mk && hd.m == mm && hd.shard_len > 0 && hd.shard_len % 64 == 0 &&
+				if (hd.version >= 2 && hd.version <= 3 && hd.idx == j && hd.k == mk && hd.m == mm && hd.shard_len > 0 && hd.shard_len % 64 == 0 &&
 				    rs.shard.data.n == hd.shard_len) {
 					uint8_t sum[32];
-					shardsum(rs.shard.data.data(), hd.shard_len, sum);
+					shardsum_v(hd.version, rs.shard.data.data(), hd.shard_len, sum);
 					if (std::memcmp(sum, hd.checksum, 32) == 0)
 						v = 1;
 				}

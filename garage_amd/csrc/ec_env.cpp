@@ -1,6 +1,7 @@
 // ec_env.cpp -- the one table of libgarage_ec's environment switches (see ec_env.hpp).
 #include "ec_env.hpp"
 #include "blake2b_mb.hpp"
+#include "mlh64_host.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -18,7 +19,7 @@ struct Row {
 // (tests/test_cabi_host.py checks that every GEC_* name in the sources appears here).
 const Row kRows[] = {
 	{"GEC_CPU_THREADS", "min(cores, 16)", "threads a CPU codec spreads one call over (1 = the calling thread only)"},
-	{"GEC_CPU_ISA", "auto", "CPU backend kernel: auto, gfni (AVX-512 + GFNI), avx2 (split-nibble vpshufb) or scalar"},
+	{"GEC_CPU_ISA", "auto", "CPU backend kernel: auto, gfni (AVX-512 + GFNI), avx2 (split-nibble vpshufb) or scalar; the host form of shard checksum v3 follows it (AVX-512 / AVX2 / scalar)"},
 	{"GEC_CPU_BLAKE2", "auto", "host-side BLAKE2b (CPU backend, libgarage_block's own hashes): auto = eight messages at a time with AVX-512, scalar = one at a time (A/B)"},
 	{"GEC_SMALL_CALL_BLOCKS", "0", "a HIP codec answers pageable host-pointer encode / reconstruct calls of up to this many blocks on the host cores (0 = never)"},
 	{"GEC_MAX_CALLS", "4", "host-pointer calls in flight per HIP codec; further callers wait (0 = no limit: every concurrent call gets staging slots and device queues of its own)"},
@@ -65,6 +66,10 @@ const Env &env()
 		const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
 		v.cpu_threads = (int)std::min<long>(std::max<long>(get_long("GEC_CPU_THREADS", std::min(hw, 16u)), 1), 256);
 		v.cpu_isa = get("GEC_CPU_ISA") ? get("GEC_CPU_ISA") : "auto";
+		if (v.cpu_isa == "scalar")  // the host form of shard checksum v3 follows the same switch (mlh64_host.hpp)
+			mlh::isa_cap().store(0);
+		else if (v.cpu_isa == "avx2")
+			mlh::isa_cap().store(1);
 		if (get("GEC_CPU_BLAKE2") && get("GEC_CPU_BLAKE2")[0] == 's')
 			b2host::mb_mode().store(0);
 		v.small_call_blocks = (size_t)std::max<long>(get_long("GEC_SMALL_CALL_BLOCKS", 0), 0);

@@ -363,7 +363,8 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 		      uint8_t *d_mirror = nullptr /* [nblocks][k + nout][S]: inputs and outputs also laid down in HBM */,
 		      uint32_t *bad = nullptr /* compare with what out[] holds instead of storing: bad[b] = 1 on mismatch */,
 		      size_t npat = 0, const uint16_t *pat = nullptr /* per-block coefficient sets: coef = [npat][nout][k], block b uses
-		      set pat[b], a NULL out entry = that block's set has no such row; nout <= RMAX; shards may be device memory */);
+		      set pat[b], a NULL out entry = that block's set has no such row; nout <= RMAX; shards may be device memory */,
+		      const SumOut *sum = nullptr /* checksum v3: leaf sums of what is read and written (compare: checked), no mirror */);
 
 // Appends the entries to the slot's table and launches ONE copy_table kernel over them.  Entries must have
 // 16-byte aligned src and dst.

@@ -39,6 +39,54 @@ int HipBackend::encode_batch(size_t nblocks, const uint8_t *const *blocks, const
 			return fail(GEC_E_DEVICE, "hipSetDevice failed");
 		StagingLease lease(c);
 		Staging &st = lease.st;
+		if (shard_sums && c->sumkind == GEC_SHARDSUM_MLH64) {
+			// checksum v3: the link kernel itself leaves the leaf sums of the k shards it reads and the m rows it writes (from
+			// the registers that hold them: no mirror in HBM, no second pass), one lane per shard turns them into the 32-byte
+			// checksums, which land in the slot's pinned area straight from that kernel.  A PutObject's single block and a
+			// coalesced batch of hundreds take the same two launches; chunks only bound the pointer tables.
+			const uint32_t nleaf_max = (uint32_t)((S + gec::SHARDSUM_LEAF - 1) / gec::SHARDSUM_LEAF);
+			const size_t zch = c->qos_class == GEC_CLASS_BACKGROUND ? chunk_blocks(stripe, nblocks, trip_chunk_bytes(c)) : std::min<size_t>(nblocks, 4096);
+			const size_t nz = (nblocks + zch - 1) / zch;
+			int rc = st.ensure(nblocks * n * 32 + 64, 0);
+			if (!rc)
+				rc = st.ensure_tab((nblocks * (k * 12 + m * 8) + 64 * nz) / sizeof(gec::CopyEntry) + 4 * nz + 4);
+			if (!rc)
+				rc = st.ensure_segments(num_cu);
+			if (rc)
+				return rc;
+			hipStream_t up = st.stream_up ? st.stream_up : st.stream;
+			uint8_t *scr = nullptr;
+			rc = gecimpl::leaf_scratch(c, up, zch * n * nleaf_max * 8, &scr);
+			std::vector<const uint8_t *> in(zch * k);
+			std::vector<uint32_t> valid(zch * k);
+			std::vector<uint8_t *> out(zch * m);
+			for (size_t ci = 0; ci < nz && !rc; ++ci) {
+				const size_t b0 = ci * zch, nb = std::min(zch, nblocks - b0);
+				background_yield(c);
+				for (size_t i = 0; i < nb; ++i) {
+					const uint8_t *p = pinned().dev(blocks[b0 + i]);
+					uint8_t *q = pinned().dev(parity[b0 + i]);
+					const size_t len = block_len[b0 + i];
+					for (size_t t = 0; t < k; ++t) {
+						in[i * k + t] = p + t * S;
+						valid[i * k + t] = (uint32_t)(len > t * S ? std::min(S, len - t * S) : 0);
+					}
+					for (size_t r = 0; r < m; ++r)
+						out[i * m + r] = q + r * S;
+				}
+				const SumOut so{reinterpret_cast<uint64_t *>(scr), nleaf_max, (uint32_t)n, 0u, true};
+				rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), out.data(), (int)m, S, c->enc.row(k), up, nullptr, nullptr, 0, nullptr, &so);
+				if (!rc)
+					rc = mlh_roots_dev(c, nb * n, so.lsum, nleaf_max, nullptr, S, st.h_buf + b0 * n * 32, up);
+			}
+			const hipError_t e1 = hipStreamSynchronize(up);
+			link_release_fire();
+			if (rc)
+				return rc;
+			HIP_TRY(e1);
+			std::memcpy(shard_sums, st.h_buf, nblocks * n * 32);
+			return GEC_OK;
+		}
 		if (shard_sums && fused_fits(c, nblocks, S, (int)m, true)) {
 			// a PutObject's few blocks: parity AND all k + m checksums from ONE launch (fused.hpp) -- the workgroup that
 			// has a tile of the stripe in hand hashes its 14 leaves out of LDS, the block's last workgroup the roots; the

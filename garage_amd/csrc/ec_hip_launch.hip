@@ -464,7 +464,7 @@ unsigned resident_grid(const Staging &st, hipStream_t stream, uint32_t tiles, si
 // kernel reads directly.  k <= PTR_KMAX.
 int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uint8_t *const *in, const uint32_t *valid,
 		      uint8_t *const *out, int nout, size_t S, const uint8_t *coef /* nout x k */, hipStream_t stream, uint8_t *d_mirror,
-		      uint32_t *bad, size_t npat, const uint16_t *pat)
+		      uint32_t *bad, size_t npat, const uint16_t *pat, const SumOut *sum)
 {
 	const size_t k = c->k;
 	const HipBackend &hb = hip_of(c);
@@ -474,6 +474,8 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 		return fail(GEC_E_INVALID_ARG, "shape not supported by the pointer-table kernel");
 	if (pat && (nout > gec::RMAX || npat == 0))
 		return fail(GEC_E_INVALID_ARG, "per-block coefficient sets: one row group only");
+	if (sum && (d_mirror || (size_t)sum->nleaf_max < (S + gec::SHARDSUM_LEAF - 1) / gec::SHARDSUM_LEAF))
+		return fail(GEC_E_INVALID_ARG, "checksummed pointer-table launch: no mirror, leaf pitch >= the shard's leaves");
 	const size_t in_bytes = nblocks * k * 8, valid_bytes = (nblocks * k * 4 + 7) / 8 * 8, out_bytes = nblocks * (size_t)nout * 8;
 	const size_t coef_bytes = pat ? (npat * k * gec::RMAX + 7) / 8 * 8 : 0, pat_bytes = pat ? (nblocks * 2 + 7) / 8 * 8 : 0;
 	const size_t need = (st.tab_used * sizeof(gec::CopyEntry) + in_bytes + valid_bytes + out_bytes + coef_bytes + pat_bytes) / sizeof(gec::CopyEntry) + 2;
@@ -525,7 +527,15 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 				grp[b * rows + r] = out[b * nout + r0 + r];
 		out_done += nblocks * rows;
 		const int mw = rows <= 4 ? 1 : 2;
-		const size_t lds = k * 32 * 4 * mw + 768 + k * gec::RMAX;
+		size_t lds = k * 32 * 4 * mw + 768 + k * gec::RMAX;
+		if (sum) {
+			a.lsum = sum->lsum;
+			a.sum_nleaf_max = sum->nleaf_max;
+			a.sum_slots_total = sum->slots_total;
+			a.sum_inputs = (r0 == 0 && sum->inputs) ? 1u : 0u;
+			a.sum_slot0 = sum->slot0 + (a.sum_inputs ? 0u : (sum->inputs ? (uint32_t)k : 0u) + (uint32_t)r0);
+			lds = ((lds + 15) & ~(size_t)15) + gec::mlh_lds_bytes(16, 4, (int)((a.sum_inputs ? k : 0) + rows));
+		}
 		a.mirror_stride = (k + (size_t)nout) * S;
 		a.mirror_row0 = (k + (size_t)r0) * S;
 		a.mirror_inputs = r0 == 0;
@@ -533,7 +543,11 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 		a.mirror = d_mirror;
 		using Kern = void (*)(const gec::PtrApplyArgs, const gec::LogExp *);
 		Kern kern;
-		if (bad && d_mirror)
+		if (sum && bad)
+			kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, false, true, true> : (Kern)gec::gf_apply_ptrs<2, 5, false, true, true>;
+		else if (sum)
+			kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, false, false, true> : (Kern)gec::gf_apply_ptrs<2, 5, false, false, true>;
+		else if (bad && d_mirror)
 			kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, true, true> : (Kern)gec::gf_apply_ptrs<2, 5, true, true>;
 		else if (bad)
 			kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, false, true> : (Kern)gec::gf_apply_ptrs<2, 5, false, true>;
@@ -580,6 +594,8 @@ size_t max_lds_per_workgroup(int device)
 bool fused_fits(const gec_codec *c, size_t nblocks, size_t S, int nout, bool hash_rows)
 {
 	const size_t k = c->k, nh = k + (hash_rows ? (size_t)nout : 0);
+	if (c->sumkind != GEC_SHARDSUM_BLAKE2B_TREE)  // (the one-launch kernel hashes BLAKE2b leaves out of LDS: checksum v2 only)
+		return false;
 	if (env().fused_small == 0 || nblocks == 0 || k > (size_t)gec::PTR_KMAX || nout > gec::RMAX || nh > (size_t)gec::FUSED_MAX_LEAVES)
 		return false;
 	const size_t tiles_x = (S / 16 + 255) / 256;

@@ -95,6 +95,10 @@ struct PtrApplyArgs {
 	// COMPARE: the rows are compared with what out[b][r] holds instead of being stored; bad[b] = 1 on a mismatch
 	// (bad may itself be pinned host memory: the flags need no copy back)
 	uint32_t *bad;
+	// SUM forms only (shard checksum v3): like ApplyArgs -- leaf sums of block b go to
+	//   lsum[((b * sum_slots_total + sum_slot0 + slot) * sum_nleaf_max) + leaf],  slot = input t (sum_inputs) then row r
+	uint64_t *lsum;
+	uint32_t sum_nleaf_max, sum_slots_total, sum_slot0, sum_inputs;
 	uint8_t coef[PTR_KMAX][RMAX];
 };
 

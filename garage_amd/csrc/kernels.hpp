@@ -472,14 +472,24 @@ __device__ __forceinline__ uint32_t link_yield(const uint32_t *busy, uint32_t ro
 	return waited >= budget_ticks ? 0u : budget_ticks - (uint32_t)waited;
 }
 
-template <int MW, int KC, bool MIRROR, bool COMPARE = false>
+// SUM: the kernel also leaves the MLH64 leaf sums (shard checksum v3, mlh64_dev.hpp) of the shards it reads (a.sum_inputs) and
+// of the rows it writes / checks in a.lsum -- a tile is 256 columns of one block's shards, i.e. exactly one leaf of each --
+// so a put on pinned memory needs no mirror in HBM and no second pass: link kernel + one tiny root kernel.
+template <int MW, int KC, bool MIRROR, bool COMPARE = false, bool SUM = false>
 __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrApplyArgs a, const LogExp *__restrict__ le)
 {
 	constexpr int ENT = 4 * MW, TBL = 32 * ENT;
 	static_assert(MW == 1 || MW == 2, "rows go out in groups of at most 8");
+	static_assert(!SUM || KC <= 16, "a batch of loads must fit the wave's region");
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const uint32_t tid = threadIdx.x, k = a.k, rows = a.rows;
 	uint8_t *lexp = lds + k * TBL, *llog = lexp + 512, *lcoef = llog + 256;
+	WaveSums<16> ws;
+	mlh_u32x4 kbase = {0, 0, 0, 0};
+	if constexpr (SUM) {
+		ws.init(lds + ((k * TBL + 768 + k * RMAX + 15) & ~15u), tid, 4);
+		kbase = mlh_keys_of(tid);
+	}
 	const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds;
 	// The grid is 1-D and may be SHORTER than the tile list (a.tiles_total = tiles_x * nblocks; tile = block * tiles_x
 	// + 256-column tile of the shard): a workgroup then walks tiles blockIdx.x, + gridDim.x, ...  The host sizes the
@@ -547,6 +557,7 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrAppl
 		}
 		u32x4 *mir = MIRROR ? reinterpret_cast<u32x4 *>(a.mirror + (size_t)b * a.mirror_stride) + col : nullptr;
 		const bool mir_in = MIRROR && live && a.mirror_inputs;
+		const mlh_u32x4 k4 = live ? kbase : mlh_u32x4{0, 0, 0, 0};  // (SUM: a lane past the end of the shard adds nothing)
 		uint32_t acc[4][4][MW];
 #pragma unroll
 		for (int w = 0; w < 4; ++w)
@@ -563,12 +574,20 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrAppl
 					d[j] = ld16_valid(inp[t], col, valid[t]);
 				}
 			}
+			if constexpr (SUM) {
+				if (a.sum_inputs && ws.full(KC))
+					ws.flush();
+			}
 #pragma unroll
 			for (int j = 0; j < KC; ++j) {
 				if (t0 + j >= k)
 					break;
 				if (mir_in)
 					mir[(size_t)(t0 + j) * a.cols] = d[j];
+				if constexpr (SUM) {
+					if (a.sum_inputs)
+						ws.put(mlh_col(d[j], k4));
+				}
 				const uint32_t tb = __builtin_amdgcn_readfirstlane(lds_base + (t0 + j) * TBL);
 				const uint32_t xs[4] = {d[j].x, d[j].y, d[j].z, d[j].w};
 #pragma unroll
@@ -606,7 +625,7 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrAppl
 				d[j] = ld16_valid(ninp[t], ncol, nvalid[t]);
 			}
 		}
-		if (live) {
+		if (live || SUM) {
 			uint32_t P[4 * MW][4];
 #pragma unroll
 			for (int h = 0; h < MW; ++h)
@@ -615,30 +634,52 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrAppl
 					transpose4x4(acc[w][0][h], acc[w][1][h], acc[w][2][h], acc[w][3][h], P[4 * h + 0][w], P[4 * h + 1][w],
 						     P[4 * h + 2][w], P[4 * h + 3][w]);
 			uint8_t *const *outp = a.out + (size_t)b * rows;
+			if constexpr (SUM) {
+				if (ws.full(rows))
+					ws.flush();
+			}
 			if (COMPARE) {
 				uint32_t diff = 0;
 #pragma unroll
 				for (int r = 0; r < 4 * MW; ++r) {
 					if (r >= (int)rows)
 						continue;
-					const u32x4 old = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(outp[r]) + col);
+					const u32x4 old = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(outp[r]) + col);  // (col = 0 for a lane past the end)
 					diff |= (P[r][0] ^ old.x) | (P[r][1] ^ old.y) | (P[r][2] ^ old.z) | (P[r][3] ^ old.w);
-					if (MIRROR)  // the STORED row: what the shard checksum is computed over
+					if (MIRROR && live)  // the STORED row: what the shard checksum is computed over
 						reinterpret_cast<u32x4 *>(a.mirror + (size_t)b * a.mirror_stride + a.mirror_row0)[(size_t)r * a.cols + col] = old;
+					if constexpr (SUM)
+						ws.put(mlh_col(old, k4));
 				}
-				if (diff)
+				if (diff && live)
 					a.bad[b] = 1u;
 			} else {
 #pragma unroll
 				for (int r = 0; r < 4 * MW; ++r) {
-					if (r >= (int)rows || !outp[r])
+					if (r >= (int)rows)
 						continue;
 					const u32x4 v = {P[r][0], P[r][1], P[r][2], P[r][3]};
+					if constexpr (SUM)
+						ws.put(mlh_col(v, k4));  // (a row nobody wants still takes its slot: the host ignores it)
+					if (!outp[r] || !live)
+						continue;
 					__builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(outp[r]) + col);
 					if (MIRROR)
 						reinterpret_cast<u32x4 *>(a.mirror + (size_t)b * a.mirror_stride + a.mirror_row0)[(size_t)r * a.cols + col] = v;
 				}
 			}
+		}
+		if constexpr (SUM) {
+			// the four waves' totals of this tile's leaf meet; two barriers per tile (the sums must be read before the next
+			// tile's flush overwrites them) -- this kernel is bound by the link, not by them
+			ws.flush();
+			__syncthreads();
+			const uint32_t nsl = (a.sum_inputs ? k : 0u) + rows;
+			const uint32_t leaf = tile - b * a.tiles_x;
+			uint64_t *dst = a.lsum + ((uint64_t)b * a.sum_slots_total + a.sum_slot0) * a.sum_nleaf_max + leaf;
+			ws.combine(tid, 256, nsl, [&](uint32_t slot, uint32_t, uint64_t v) { dst[(uint64_t)slot * a.sum_nleaf_max] = v; });
+			__syncthreads();
+			ws.base = 0;
 		}
 		if (!more)
 			break;

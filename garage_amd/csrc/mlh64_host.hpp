@@ -3,6 +3,7 @@
 // instead of crossing the link).  AVX-512 / AVX2 / scalar, picked at run time; every path is the same integer arithmetic.
 #pragma once
 
+#include <atomic>
 #include <cstring>
 #include <vector>
 
@@ -60,14 +61,23 @@ __attribute__((target("avx512f"))) inline uint64_t leaf_avx512(const uint8_t *p,
 		a0 = _mm512_add_epi64(a0, _mm512_mul_epu32(v, k));
 		a1 = _mm512_add_epi64(a1, _mm512_mul_epu32(_mm512_srli_epi64(v, 32), _mm512_srli_epi64(k, 32)));
 	}
-	return (uint64_t)_mm512_reduce_add_epi64(_mm512_add_epi64(a0, a1)) + leaf_scalar(p + 4 * i, nwords - i, K + i);
+	uint64_t lane[8];  // (not _mm512_reduce_add_epi64: gcc spells it with SIGNED 64-bit adds, which must not wrap)
+	_mm512_storeu_si512(lane, _mm512_add_epi64(a0, a1));
+	return lane[0] + lane[1] + lane[2] + lane[3] + lane[4] + lane[5] + lane[6] + lane[7] + leaf_scalar(p + 4 * i, nwords - i, K + i);
 }
 #endif
 
-// 0 = scalar, 1 = AVX2, 2 = AVX-512 (what this host runs; MLH_ISA in the environment pins a lower one for the tests)
+// 0 = scalar, 1 = AVX2, 2 = AVX-512: the best this host runs, capped by isa_cap() (libgarage_ec lowers it from GEC_CPU_ISA =
+// scalar / avx2 when it is loaded, so that the tests reach every path on one box; results never differ)
+inline std::atomic<int> &isa_cap()
+{
+	static std::atomic<int> v{2};
+	return v;
+}
+
 inline int isa()
 {
-	static const int v = [] {
+	static const int hw = [] {
 		int best = 0;
 #if defined(__x86_64__)
 		if (__builtin_cpu_supports("avx2"))
@@ -75,14 +85,10 @@ inline int isa()
 		if (__builtin_cpu_supports("avx512f"))
 			best = 2;
 #endif
-		if (const char *e = std::getenv("MLH_ISA")) {
-			const int want = !std::strcmp(e, "scalar") ? 0 : !std::strcmp(e, "avx2") ? 1 : 2;
-			if (want < best)
-				best = want;
-		}
 		return best;
 	}();
-	return v;
+	const int cap = isa_cap().load(std::memory_order_relaxed);
+	return hw < cap ? hw : cap;
 }
 
 // the leaf sums of a shard of `len` bytes: out[l], l < nleaf(len)

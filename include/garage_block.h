@@ -89,8 +89,13 @@ const char *gbm_env_table(void);
 
 /* Garage's content hash: blake2b-512 truncated to 32 bytes (NOT blake2b-256). */
 void gbm_blake2sum(const uint8_t *data, size_t len, uint8_t out[32]);
-/* The checksum every shard header carries: BLAKE2b tree mode ("shardsum", include/garage_ec.h), CPU restatement. */
+/* The checksum a VERSION 2 shard header carries: BLAKE2b tree mode (GEC_SHARDSUM_BLAKE2B_TREE, include/garage_ec.h), on the host. */
 void gbm_shardsum(const uint8_t *data, size_t len, uint8_t out[32]);
+/* The checksum a shard header of the given version carries, computed on the calling core: 3 = MLH64 (GEC_SHARDSUM_MLH64: what a
+ * manager over a default codec writes, checked at memory speed), 2 = BLAKE2b tree mode, 1 = plain blake2sum (round 1).
+ * GBM_E_INVALID_ARG for any other version.  A manager writes the version of its codec's kind (gbm_shard_version) and reads all
+ * three: a shard of another version is verified with ITS checksum when it is first read and rewritten in the manager's own. */
+int gbm_shardsum_v(int version, const uint8_t *data, size_t len, uint8_t out[32]);
 /* blake2sum of n buffers on the calling thread, out[32 * i] for buffer i: the content hashes of a PutObject's blocks,
  * which the API layer computes before it calls rpc_put_block (src/api/s3/put.rs).  BLAKE2b is one serial chain per
  * message, but eight messages fit the eight lanes of an AVX-512 register: n >= 2 blocks cost about as much as one
@@ -114,6 +119,8 @@ int gbm_zstd_decode(const uint8_t *frame, size_t len, uint8_t *out, size_t cap, 
 int gbm_create(const gec_codec *codec, int nnodes, const char *const *node_dirs,
 	       int write_quorum, gbm_manager **out);
 void gbm_destroy(gbm_manager *m);
+/* The shard-header version this manager writes: its codec's checksum kind (gec_codec_shardsum: 3 = MLH64, 2 = BLAKE2b tree). */
+int gbm_shard_version(const gbm_manager *m);
 
 /* ------------------------------------------------- several devices on one node */
 /* "Blocks from a batched PutObject stream are hash-partitioned across the GPUs of one node": ONE manager over `ndev`
@@ -158,8 +165,10 @@ int gbm_set_data_fsync(gbm_manager *m, int enabled);
  * what arrives to the caller unchecked.  A node of an erasure-coded cluster holds a shard, so its equivalent of that check
  * is the shard checksum -- ALWAYS verified here, in every mode, before a byte of the shard is used or delivered.  The
  * block hash on top of that is a mode:
- *   GBM_VERIFY_OFF      (default; the reference's read path) no end-to-end pass;
- *   GBM_VERIFY_REBUILT  only blocks that went through a decode (a missing data shard was rebuilt) are hashed;
+ *   GBM_VERIFY_OFF      (the reference's read path) no end-to-end pass: data shards the decode REBUILT reach the caller
+ *                       on the device's word alone;
+ *   GBM_VERIFY_REBUILT  (default) only blocks that went through a decode (a missing data shard was rebuilt) are hashed:
+ *                       a healthy read keeps the reference's cost, a rebuilt byte never leaves unchecked;
  *   GBM_VERIFY_ALWAYS   every Plain block is hashed (the paranoid setting; round 3's default).
  * When it is on, the hash runs BEHIND the data: the streaming forms deliver every chunk first and report a mismatch
  * as the stream's final result (GBM_E_CORRUPT_DATA), the way a zstd frame checksum fails a compressed block's tail

@@ -20,6 +20,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
+from oracle import mlh64
 from oracle import rs_oracle as O  # noqa: E402
 
 SEED = 0x6761726167650001
@@ -77,7 +78,8 @@ def checksum_cases():
     for i, n in enumerate([0, 1, 3, 64, 127, 128, 129, 4095, 4096, 4097, 8192, 12289, 104896, 209728, (1 << 20) + 3]):
         msg = bytes(O.splitmix64_bytes(SEED + 100 + i, n))
         out.append({"len": n, "seed": SEED + 100 + i, "blake2sum": hashlib.blake2b(msg, digest_size=64).digest()[:32].hex(),
-                    "shardsum": shardsum_hashlib(msg).hex()})
+                    "shardsum": shardsum_hashlib(msg).hex(),            # version 2: BLAKE2b tree mode
+                    "shardsum3": mlh64.shardsum3_slow(msg).hex()})      # version 3: MLH64, the pure-Python definition (oracle/mlh64.py)
     return out
 
 

@@ -7,7 +7,7 @@ import pytest
 
 import garage_amd as g
 from garage_amd import block_native as bn
-from tests.block_manager_cases import pattern_block
+from tests.patterns import pattern_block
 
 # opentelemetry_prometheus::exporter().with_default_histogram_boundaries(..) of the reference, src/garage/server.rs:38-43
 BOUNDS = [0.001, 0.0015, 0.002, 0.003, 0.005, 0.007, 0.01, 0.015, 0.02, 0.03, 0.05, 0.07, 0.1, 0.15, 0.2, 0.3, 0.5, 0.7, 1., 1.5, 2., 3., 5., 7.,

@@ -12,7 +12,7 @@ import pytest
 
 import garage_amd as g
 from garage_amd import block_native as bn
-from tests.block_manager_cases import pattern_block
+from tests.patterns import pattern_block
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -36,12 +36,17 @@ def test_blake2sum_is_blake2b512_truncated(n):
 
 
 @pytest.mark.parametrize("n", [0, 1, 64, 4095, 4096, 4097, 8192, 104896, 209728, (1 << 20) + 3])
-def test_shardsum_is_blake2b_tree_mode(n):
-    """The shard checksum restated three times -- C++ (libgarage_block), hashlib with BLAKE2's tree parameters
-    (garage_amd.codec.shardsum), and (GPU tests) the device kernels -- must agree; it is NOT the plain hash."""
+def test_shard_checksums_by_header_version(n):
+    """The shard checksums restated several times -- C++ (libgarage_block: gbm_shardsum_v), Python (garage_amd.codec.shardsum:
+    hashlib with BLAKE2's tree parameters for version 2, numpy for version 3), the independent oracle (oracle/mlh64.py) and
+    (GPU tests) the device kernels -- must agree; neither is the plain hash, which is what version 1 carried."""
+    from oracle import mlh64
+
     d = bytes(pattern_block(n, salt=n + 1)) if n else b""
-    assert bn.shardsum(d) == g.shardsum(d)
-    assert bn.shardsum(d) != bn.blake2sum(d)
+    assert bn.shardsum(d, 2) == g.shardsum(d, 2)
+    assert bn.shardsum(d, 3) == g.shardsum(d, 3) == mlh64.shardsum3(d) == bn.shardsum(d)
+    assert bn.shardsum(d, 1) == bn.blake2sum(d)
+    assert len({bn.shardsum(d, 1), bn.shardsum(d, 2), bn.shardsum(d, 3)}) == 3
 
 
 def test_create_rejects_null_codec():
@@ -81,12 +86,12 @@ def test_native_put_get_roundtrip(codec, tmp_path):
     hx = h.hex()
     p = tmp_path / f"node{who[0]}" / hx[:2] / hx[2:4] / f"{hx}.s0"
     assert p.exists() and p.stat().st_size == 64 + g.shard_len(codec.k, 65536)
-    # the on-disk shard format is the one the Python mirror reads
-    from garage_amd.block_manager import ShardHeader
+    # the on-disk shard format: a 64-byte header whose version names the checksum (3 = MLH64: what a default codec writes)
+    from tests.patterns import parse_shard_header
 
     raw = p.read_bytes()
-    hdr = ShardHeader.unpack(raw)
-    assert (hdr.k, hdr.m, hdr.idx, hdr.orig_len) == (codec.k, codec.m, 0, 65536)
+    hdr = parse_shard_header(raw)
+    assert (hdr.version, hdr.k, hdr.m, hdr.idx, hdr.orig_len) == (3, codec.k, codec.m, 0, 65536) and mgr.shard_version == 3
     assert bn.shardsum(raw[64:]) == hdr.checksum == g.shardsum(raw[64:])
     assert mgr.metrics["blocks_put"] == 4 and mgr.metrics["blocks_get"] == 4
 
@@ -152,7 +157,7 @@ def test_native_corruption_resync_scrub(codec, tmp_path):
     # manager.rs:276-339) hands it out; the "always" mode answers CorruptData
     evil = pattern_block(200_000, 99)
     mgr.rpc_put_block(hashes[0], evil)
-    assert mgr.verify_block_hash == "off" and mgr.rpc_get_block(hashes[0]) == evil
+    assert mgr.verify_block_hash == "rebuilt" and mgr.rpc_get_block(hashes[0]) == evil   # nothing was rebuilt: not hashed
     mgr.set_verify_block_hash("always")
     with pytest.raises(bn.CorruptData):
         mgr.rpc_get_block(hashes[0])          # (small request: the block hash is checked on the host pool)
@@ -170,41 +175,19 @@ def test_native_corruption_resync_scrub(codec, tmp_path):
         mgr.rpc_get_block(hashes[5])
 
 
-def test_native_and_python_mirrors_interoperate(tmp_path, backend):
-    """Same placement, same shard files: a block written by the C++ manager is
-    readable by the Python mirror over the same directories and vice versa."""
-    from garage_amd.block_manager import BlockManager, DirShardStore
-
-    codec = g.ReedSolomon(10, 4, backend=backend)
-    dirs = [str(tmp_path / f"node{i}") for i in range(16)]
-    native = bn.NativeBlockManager(codec, 16, dirs)
-    pym = BlockManager(codec, [DirShardStore(d) for d in dirs])
-    a, b = pattern_block(400_000, 1), pattern_block(123_457, 2)
-    ha, hb = bn.blake2sum(a), bn.blake2sum(b)
-    assert native.storage_nodes_of(ha) == pym.storage_nodes_of(ha)
-    native.rpc_put_block(ha, a)
-    pym.rpc_put_block(hb, b)
-    assert pym.rpc_get_block(ha) == a
-    assert native.rpc_get_block(hb) == b
-
-
-def test_compressed_blocks_native_and_python(tmp_path, backend):
-    """compression_level = Some(1) (Garage's default): blocks are zstd frames with the
-    content checksum on before they are cut into shards; both mirrors read each
-    other's compressed blocks; a corrupted compressed payload is CorruptData."""
-    from garage_amd.block_manager import BlockManager, DataBlockHeader, DirShardStore
-
+def test_compressed_blocks(tmp_path, backend):
+    """compression_level = Some(1) (Garage's default): blocks are zstd frames with the content checksum on before they are
+    cut into shards; the raw get returns the frame as stored; a decode of the compressed payload, then zstd."""
     codec = g.ReedSolomon(10, 4, backend=backend)
     dirs = [str(tmp_path / f"node{i}") for i in range(14)]
     native = bn.NativeBlockManager(codec, 14, dirs, compression_level=1)
-    pym = BlockManager(codec, [DirShardStore(d) for d in dirs], compression_level=1)
     a, b = pattern_block(1 << 20, 3), pattern_block(700_001, 4)     # compressible patterns
     ha, hb = bn.blake2sum(a), bn.blake2sum(b)
     native.rpc_put_block(ha, a)
-    pym.rpc_put_block(hb, b)
-    raw = pym.rpc_get_raw_block(ha)
-    assert raw.header is DataBlockHeader.Compressed and len(raw.elem) < len(a) // 4
-    assert pym.rpc_get_block(ha) == a and native.rpc_get_block(hb) == b
+    native.rpc_put_block(hb, b)
+    hdr, raw = native.rpc_get_raw_block(ha)
+    assert hdr.is_compressed() and len(raw) < len(a) // 4 and bn.zstd_decode(raw) == a
+    assert native.rpc_get_block(ha) == a and native.rpc_get_block(hb) == b
     # shards are cut from the COMPRESSED payload: they are much smaller than for a plain block
     who = native.storage_nodes_of(ha)
     hx = ha.hex()
@@ -218,7 +201,7 @@ def test_compressed_blocks_native_and_python(tmp_path, backend):
     rnd = bytes(np.random.default_rng(1).integers(0, 256, 100_000, dtype=np.uint8))
     hr = bn.blake2sum(rnd)
     native.rpc_put_block(hr, rnd)
-    assert pym.rpc_get_block(hr) == rnd
+    assert native.rpc_get_block(hr) == rnd
 
 
 def test_prevent_compression_order_tag_raw_and_streaming_gets(backend):
@@ -521,14 +504,17 @@ def test_hedged_read_decodes_around_a_slow_node(codec):
 
 
 # ----------------------------------------------------------------- round-2 advisor items
-def test_v1_shard_headers_are_read_and_rewritten_unknown_versions_are_left_alone(tmp_path, backend):
-    """Header version 1 (round 1's format: plain blake2sum checksum) is still readable -- verified on the host, rewritten
-    as version 2 the first time it is read; a version this build does not know is never renamed or deleted."""
+@pytest.mark.parametrize("writes", [3, 2])
+def test_older_shard_headers_are_read_and_rewritten_unknown_versions_are_left_alone(tmp_path, backend, writes):
+    """A manager writes ONE header version (its codec's checksum kind) and reads all three: version 1 (round 1: plain
+    blake2sum) and the other of 2 / 3 are verified on the host with THEIR checksum the first time they are read and rewritten
+    in the manager's own version; a version this build does not know is never renamed or deleted."""
     import hashlib
-    import struct
 
-    codec = g.ReedSolomon(10, 4, backend=backend)
+    codec = g.ReedSolomon(10, 4, backend=backend, shardsum=writes)
+    other = 5 - writes
     mgr = _mgr(codec, tmp_path)
+    assert mgr.shard_version == writes
     data = pattern_block(500_000, salt=77)
     h = bn.blake2sum(data)
     mgr.rpc_put_block(h, data)
@@ -540,7 +526,7 @@ def test_v1_shard_headers_are_read_and_rewritten_unknown_versions_are_left_alone
 
     # shard 0 becomes a version-1 file: same payload, checksum = plain blake2sum
     raw = bytearray(shard_file(0).read_bytes())
-    assert raw[:4] == b"GECS" and raw[4] == 2
+    assert raw[:4] == b"GECS" and raw[4] == writes
     raw[4] = 1
     raw[28:60] = hashlib.blake2b(bytes(raw[64:]), digest_size=64).digest()[:32]
     shard_file(0).write_bytes(bytes(raw))
@@ -548,16 +534,38 @@ def test_v1_shard_headers_are_read_and_rewritten_unknown_versions_are_left_alone
     raw1 = bytearray(shard_file(1).read_bytes())
     raw1[4] = 9
     shard_file(1).write_bytes(bytes(raw1))
-    assert mgr.rpc_get_block(h) == data                  # shard 0 is used (after its v1 check), shard 1 is skipped: 13 >= k
-    again = shard_file(0).read_bytes()
-    assert again[4] == 2 and again[28:60] == bn.shardsum(again[64:])      # upgraded in place
+    # shards 2 and 12 (a data and a parity shard) carry the OTHER current format: what a store written by a manager of the
+    # other kind looks like
+    for j in (2, 12):
+        r = bytearray(shard_file(j).read_bytes())
+        r[4] = other
+        r[28:60] = g.shardsum(bytes(r[64:]), other)
+        shard_file(j).write_bytes(bytes(r))
+    assert mgr.rpc_get_block(h) == data                  # shards 0 and 2 are used after their own checks, shard 1 is skipped: 13 >= k
+    for j in (0, 2):
+        again = shard_file(j).read_bytes()
+        assert again[4] == writes and again[28:60] == bn.shardsum(again[64:], writes)   # upgraded in place
     assert shard_file(1).exists() and shard_file(1).read_bytes()[4] == 9  # untouched: not *.corrupted, not deleted
     assert not list((tmp_path / f"node{who[1]}" / hx[:2] / hx[2:4]).glob("*.corrupted"))
-    # a v1 file whose payload does not match its blake2sum IS corrupt
-    raw[70] ^= 1
-    shard_file(0).write_bytes(bytes(raw))
+    # scrub walks every shard: the parity shard of the other format is verified with its own checksum and rewritten too
+    mgr.scrub_all()
+    again = shard_file(12).read_bytes()
+    assert again[4] == writes and again[28:60] == bn.shardsum(again[64:], writes)
+    # an old-format file whose payload does not match ITS checksum IS corrupt
+    for j, ver in ((0, 1), (2, other)):
+        r = bytearray(shard_file(j).read_bytes())
+        r[4] = ver
+        r[28:60] = g.shardsum(bytes(r[64:]), ver) if ver > 1 else hashlib.blake2b(bytes(r[64:]), digest_size=64).digest()[:32]
+        r[70] ^= 1
+        shard_file(j).write_bytes(bytes(r))
     assert mgr.rpc_get_block(h) == data
-    assert not shard_file(0).exists()                    # renamed *.corrupted, queued for resync
+    assert not shard_file(0).exists() and not shard_file(2).exists()      # renamed *.corrupted, queued for resync
+    # ... and resync rebuilds them in the manager's version
+    mgr.resync_all()
+    for j in (0, 2):
+        again = shard_file(j).read_bytes()
+        assert again[4] == writes and again[28:60] == bn.shardsum(again[64:], writes)
+    assert mgr.rpc_get_block(h) == data
     mgr.close()
 
 

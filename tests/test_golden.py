@@ -85,7 +85,8 @@ def test_checksum_restatements_reproduce_golden():
     for c in CHECKSUMS:
         m = _msg(c)
         assert hashlib.blake2b(m, digest_size=64).digest()[:32].hex() == c["blake2sum"] == bn.blake2sum(m).hex(), c["len"]
-        assert g.shardsum(m).hex() == c["shardsum"] == bn.shardsum(m).hex(), c["len"]
+        assert g.shardsum(m, 2).hex() == c["shardsum"] == bn.shardsum(m, 2).hex(), c["len"]          # header version 2
+        assert g.shardsum(m, 3).hex() == c["shardsum3"] == bn.shardsum(m, 3).hex(), c["len"]         # header version 3 (MLH64)
 
 
 @pytest.mark.gpu
@@ -95,4 +96,6 @@ def test_gpu_checksums_match_golden():
     rs = g.ReedSolomon(10, 4)
     msgs = [_msg(c) for c in CHECKSUMS]
     assert [x.hex() for x in rs.blake2sum_batch(msgs)] == [c["blake2sum"] for c in CHECKSUMS]
-    assert [x.hex() for x in rs.shardsum_batch(msgs)] == [c["shardsum"] for c in CHECKSUMS]
+    assert rs.shardsum_kind == 3
+    assert [x.hex() for x in rs.shardsum_batch(msgs)] == [c["shardsum3"] for c in CHECKSUMS]
+    assert [x.hex() for x in rs.with_shardsum(2).shardsum_batch(msgs)] == [c["shardsum"] for c in CHECKSUMS]

@@ -15,7 +15,7 @@ import garage_amd as g
 from garage_amd import _lib
 from garage_amd import block_native as bn
 from garage_amd.partition import gpu_of_hash
-from tests.block_manager_cases import pattern_block
+from tests.patterns import pattern_block
 
 K, M, NNODES = 10, 4, 16
 

@@ -9,7 +9,7 @@ import pytest
 
 import garage_amd as g
 from garage_amd import block_native as bn
-from tests.block_manager_cases import pattern_block
+from tests.patterns import pattern_block
 
 DAY = 24 * 3600 * 1000
 

@@ -171,7 +171,7 @@ def block_manager_rates(nb: int = 512, threads: int = 48) -> dict:
         "rpc_get_blocks_4_nodes_down_GiBps": round(gib / t_deg, 2),
         "rpc_get_blocks_4_nodes_down_by_verify_mode_GiBps": {mo: round(gib / t_deg_mode[mo], 2) for mo in t_deg_mode},
         "rpc_get_blocks_with_block_hash_always_GiBps": round(gib / t_get, 2),
-        "verify_mode_default": "off (shard checksums are always verified; the end-to-end block hash is a mode)",
+        "verify_mode_default": "rebuilt (shard checksums are always verified; the end-to-end block hash covers what a decode rebuilt; off / always are modes)",
         # the batcher under 48 native callers (tools/batcher_bench, C: no interpreter between the callers and the
         # library) is the figure; the same load from Python threads is kept beside it -- the GIL hand-offs between
         # 48 threads cost it a fifth

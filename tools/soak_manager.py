@@ -268,7 +268,11 @@ def soak(seconds: float = 30.0, backend: str = "hip", max_len: int = 1 << 20, se
         assert bad == [], diagnose(bad, "a live block does not scrub clean after the resync")
         for i in range(0, len(hs), 64):
             part = hs[i:i + 64]
-            assert mgr.rpc_get_blocks(part, max_len + 4096) == [live[h] for h in part], "bulk get after the resync"
+            got = mgr.rpc_get_blocks(part, max_len + 4096)
+            diff = [(h.hex()[:16], len(live[h]), x if isinstance(x, int) else len(x),
+                     -1 if isinstance(x, int) else next((q for q in range(min(len(x), len(live[h]))) if x[q] != live[h][q]), -1))
+                    for h, x in zip(part, got) if isinstance(x, int) or bytes(x) != live[h]]
+            assert not diff, diagnose([bytes.fromhex(d[0]) for d in diff][:0], f"bulk get after the resync: (hash, put length, got length or error code, first differing byte) {diff[:6]}")
         met = mgr.block_metrics(bt)
         assert met["resync_errored_blocks"] == 0 and met["rc_size"] >= len(live)
         assert met["block_write_duration"]["count"] > 0 and met["block_read_duration"]["bucket"][-1] == met["block_read_duration"]["count"]

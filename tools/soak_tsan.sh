@@ -16,7 +16,7 @@ cp -r "$R/garage_amd/"*.py "$W/garage_amd/"
 cp "$R/garage_amd/csrc/"*.cpp "$R/garage_amd/csrc/"*.hpp "$W/garage_amd/csrc/"
 cp "$R/tests/c/ec_nodevice.cpp" "$W/tests/c/"
 cp "$R/tests/__init__.py" "$W/tests/" 2>/dev/null || true
-cp "$R/tests/block_manager_cases.py" "$W/tests/"
+cp "$R/tests/patterns.py" "$W/tests/"
 cp "$R/tools/soak_manager.py" "$W/tools/"
 cp "$R/include/"*.h "$W/include/"
 cp -r "$R/oracle/"*.py "$R/oracle/"*.so "$W/oracle/" 2>/dev/null || true
