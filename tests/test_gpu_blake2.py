@@ -21,7 +21,7 @@ def ref(b: bytes) -> bytes:
 
 @pytest.fixture(scope="module")
 def rs():
-    return g.ReedSolomon(10, 4)
+    return g.ReedSolomon(10, 4, shardsum=2)   # this file is about the BLAKE2b kernels: checksum kind 2 (kind 3: tests/test_gpu_shardsum3.py)
 
 
 def test_rfc7693_abc(rs):
@@ -62,7 +62,7 @@ def test_encode_hash_dev_fork_join(coracle, k, m, S, nb):
     the RS kernel, the parity checksums behind it; parity vs the oracle, every checksum vs the hashlib restatement
     of the shard checksum (BLAKE2b tree mode, garage_amd.codec.shardsum) --
     repeated back to back so that a missing stream dependency would show as a stale checksum."""
-    rs = g.ReedSolomon(k, m)
+    rs = g.ReedSolomon(k, m, shardsum=2)
     for rep in range(3):
         data = O.splitmix64_bytes(7000 + rep, nb * k * S).reshape(nb, k, S)
         st = torch.zeros((nb, k + m, S), dtype=torch.uint8, device="cuda:0")
@@ -74,7 +74,7 @@ def test_encode_hash_dev_fork_join(coracle, k, m, S, nb):
         got = sums.cpu().numpy()
         for b in range(nb):
             for j in range(k + m):
-                assert got[b, j].tobytes() == g.shardsum(full[b, j].tobytes()), (rep, b, j)
+                assert got[b, j].tobytes() == g.shardsum(full[b, j].tobytes(), 2), (rep, b, j)
 
 
 def test_blake2_quad_and_lane_kernels_agree_on_tails(rs):
@@ -88,7 +88,7 @@ def test_blake2_quad_and_lane_kernels_agree_on_tails(rs):
 import hashlib, sys
 sys.path.insert(0, %r)
 import garage_amd as g
-rs = g.ReedSolomon(10, 4)
+rs = g.ReedSolomon(10, 4, shardsum=2)
 lens = list(range(0, 300)) + [383, 384, 385, 4095, 4096, 4097, 104896]
 msgs = [bytes((i * 7 + j) & 255 for j in range(n)) for i, n in enumerate(lens)]
 want = [hashlib.blake2b(x, digest_size=64).digest()[:32] for x in msgs]
@@ -96,7 +96,7 @@ assert rs.blake2sum_batch(msgs) == want
 # the shard checksum's leaves and roots have the same two forms (four lanes per leaf / root below 40000 leaves)
 tl = [0, 1, 63, 64, 65, 127, 128, 129, 4095, 4096, 4097, 8191, 8192, 8193, 12288, 12289, 104896, 209728, (1 << 20) + 5]
 tm = [bytes((i * 11 + j * 3) & 255 for j in range(n)) for i, n in enumerate(tl)]
-assert rs.shardsum_batch(tm) == [g.shardsum(x) for x in tm]
+assert rs.shardsum_batch(tm) == [g.shardsum(x, 2) for x in tm]
 print("ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for kern in ("quad", "lane"):
@@ -116,7 +116,7 @@ def test_encode_hash_batch_sums_every_shard(coracle, rs):
         assert np.array_equal(pars[b], want_par)
         for j in range(k + m):
             payload = shards[j] if j < k else want_par[j - k]
-            assert sums[b, j].tobytes() == g.shardsum(payload.tobytes()), (b, j)
+            assert sums[b, j].tobytes() == g.shardsum(payload.tobytes(), 2), (b, j)
 
 
 @pytest.mark.parametrize("k,m,L,nb", [(10, 4, 1 << 20, 200), (3, 1, 300_000, 7), (10, 12, 70_000, 5)],
@@ -131,7 +131,7 @@ def test_encode_hash_batch_zero_copy_pinned(coracle, k, m, L, nb):
     from garage_amd.codec import host_alloc, host_free
 
     lib = _lib.lib
-    rs_ = g.ReedSolomon(k, m)
+    rs_ = g.ReedSolomon(k, m, shardsum=2)
     n = k + m
     S = g.shard_len(k, L)
     rng = np.random.default_rng(nb)
@@ -156,7 +156,7 @@ def test_encode_hash_batch_zero_copy_pinned(coracle, k, m, L, nb):
     for b in list(range(0, nb, max(1, nb // 16))) + [nb - 1]:
         for j in range(n):
             payload = shards[b, j] if j < k else want[b, j - k]
-            assert sums[b, j].tobytes() == g.shardsum(payload.tobytes()), (b, j)
+            assert sums[b, j].tobytes() == g.shardsum(payload.tobytes(), 2), (b, j)
     host_free(arena)
     host_free(par)
 
@@ -174,7 +174,7 @@ import hashlib, sys
 import numpy as np, torch
 import garage_amd as g
 from oracle import rs_oracle as O
-rs = g.ReedSolomon(10, 4)
+rs = g.ReedSolomon(10, 4, shardsum=2)
 ref = lambda b: hashlib.blake2b(b, digest_size=64).digest()[:32]
 lens = [0, 1, 31, 32, 33, 64, 96, 127, 128, 129, 160, 255, 256, 257, 1000, 4097, 104896, 300001]
 msgs = [bytes(O.splitmix64_bytes(50 + i, n)) for i, n in enumerate(lens)] + [bytes([i]) * (i * 7 % 400) for i in range(150)]
@@ -235,7 +235,7 @@ def test_shardsum_tree_mode_against_hashlib(rs):
 
     lens = [0, 1, 63, 64, 127, 128, 129, 4095, 4096, 4097, 8191, 8192, 8193, 12288, 104896, 209728, 1 << 20, (1 << 20) + 5]
     msgs = [bytes(O.splitmix64_bytes(300 + i, n)) for i, n in enumerate(lens)]
-    assert rs.shardsum_batch(msgs) == [g.shardsum(x) for x in msgs]
+    assert rs.shardsum_batch(msgs) == [g.shardsum(x, 2) for x in msgs]
     assert rs.shardsum_batch([b"abc"])[0] != ref(b"abc"), "the shard checksum is not the plain hash"
     for S in (64, 4096, 4160, 104896):
         n = 97
@@ -244,7 +244,7 @@ def test_shardsum_tree_mode_against_hashlib(rs):
         torch.cuda.synchronize()
         got = out.cpu().numpy()
         for i in range(n):
-            assert got[i].tobytes() == g.shardsum(data[i].tobytes()), (S, i)
+            assert got[i].tobytes() == g.shardsum(data[i].tobytes(), 2), (S, i)
     pinned = [host_alloc(max(len(x), 16)) for x in msgs]
     for p_, x in zip(pinned, msgs):
         p_[:len(x)] = np.frombuffer(x, dtype=np.uint8)
@@ -253,6 +253,6 @@ def test_shardsum_tree_mode_against_hashlib(rs):
     clens = (ctypes.c_size_t * n)(*lens)
     out = np.zeros((n, 32), dtype=np.uint8)
     check(lib.gec_shardsum_batch(rs._h, n, ptrs, clens, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), "pinned shardsum")
-    assert [out[i].tobytes() for i in range(n)] == [g.shardsum(x) for x in msgs]
+    assert [out[i].tobytes() for i in range(n)] == [g.shardsum(x, 2) for x in msgs]
     for p_ in pinned:
         host_free(p_)

@@ -1,7 +1,9 @@
-"""The one-launch small trip (garage_amd/csrc/fused.hpp): gec_encode_hash_batch and
-gec_decode_verify_batch on pinned caller memory, for batches small enough that launches -- not bytes -- are what they cost.
-Parity and rebuilt shards against the CPU oracle, every checksum against hashlib's BLAKE2b tree mode, the same calls again
-with GEC_FUSED_SMALL=0 (the streaming paths) as an A/B, and a kernel count from rocprofv3 where it is installed."""
+"""Small trips on pinned caller memory -- gec_encode_hash_batch and gec_decode_verify_batch for batches small enough that
+launches, not bytes, are what they cost -- for BOTH shard checksum kinds:
+  kind 3 (MLH64, the default): the link kernel leaves the leaf sums itself (gf_apply_ptrs SUM form) + one root kernel;
+  kind 2 (BLAKE2b tree): the one-launch kernel of round 4 (garage_amd/csrc/fused.hpp).
+Parity and rebuilt shards against the CPU oracle, every checksum against the restatement of its kind, the same calls again
+with GEC_FUSED_SMALL=0 (the streaming paths) as an A/B, and kernel counts from rocprofv3 where it is installed."""
 import ctypes
 import os
 import subprocess
@@ -42,10 +44,12 @@ def _put(rs, k, m, S, lens, seed):
 
 
 @pytest.mark.parametrize("k,m,L,nb", [(10, 4, 1 << 20, 1), (10, 4, 1 << 20, 3), (10, 4, 1 << 20, 48), (3, 1, 65536, 16), (10, 4, 70_000, 20),
-                                      (20, 8, 4 << 20, 2), (6, 3, 4096 * 6, 5), (10, 4, 640, 9)],
-                         ids=["one_block", "a_putobjects_three", "48_callers", "config1_rs3_1", "small_blocks", "rs20_8_4mib", "one_leaf_shards", "64_byte_shards"])
-def test_put_in_one_launch_parity_and_checksums(coracle, k, m, L, nb):
-    rs = g.ReedSolomon(k, m)
+                                      (20, 8, 4 << 20, 2), (6, 3, 4096 * 6, 5), (10, 4, 640, 9), (10, 12, 70_000, 5), (10, 4, 1 << 20, 200)],
+                         ids=["one_block", "a_putobjects_three", "48_callers", "config1_rs3_1", "small_blocks", "rs20_8_4mib", "one_leaf_shards", "64_byte_shards",
+                              "rs10_12_two_row_groups", "200_blocks"])
+@pytest.mark.parametrize("kind", [3, 2], ids=["mlh64", "blake2b_tree"])
+def test_put_in_one_launch_parity_and_checksums(coracle, k, m, L, nb, kind):
+    rs = g.ReedSolomon(k, m, shardsum=kind)
     S = g.shard_len(k, L)
     rng = np.random.default_rng(nb + k)
     lens = [L if b % 4 != 1 else int(rng.integers(0, L + 1)) for b in range(nb)]
@@ -57,7 +61,7 @@ def test_put_in_one_launch_parity_and_checksums(coracle, k, m, L, nb):
     for b in range(nb):
         for j in range(k + m):
             payload = data[b, j] if j < k else want[b, j - k]
-            assert sums[b, j].tobytes() == g.shardsum(payload.tobytes()), (b, j)
+            assert sums[b, j].tobytes() == g.shardsum(payload.tobytes(), kind), (b, j)
     # twice more on the same codec: the per-block tile counters must be back at zero after every launch
     for _ in range(2):
         _, par2, sums2 = _put(rs, k, m, S, lens, seed=nb)
@@ -96,12 +100,13 @@ def _get(rs, k, m, S, full, lost, with_block_sums=False):
                                       (3, 1, 65536, 12), (20, 8, 1 << 20, 6), (10, 4, 1 << 20, 96), (10, 4, 300_000, 130), (20, 8, 4 << 20, 50)],
                          ids=["one_block", "14_blocks_many_patterns", "20_blocks_streaming", "24_blocks_in_two_pieces", "rs3_1", "rs20_8",
                               "96_blocks_in_pieces", "130_blocks_in_pieces", "rs20_8_50_blocks_in_pieces"])
-def test_get_in_one_launch_many_erasure_patterns(coracle, k, m, L, nb):
+@pytest.mark.parametrize("kind", [3, 2], ids=["mlh64", "blake2b_tree"])
+def test_get_in_one_launch_many_erasure_patterns(coracle, k, m, L, nb, kind):
     """One launch serves a batch whose blocks lost DIFFERENT shards (a coefficient set per block): checksums of exactly
     the first k shards in hand, every missing data shard rebuilt, blocks that need no decode beside blocks that do.
     (Past GEC_FUSED_GET_MAX_LEAVES the streaming path takes over, and from 24 blocks on the trip goes in PIECES -- upload / checksums +
     decode / rebuilt shards home pipelined on three streams, ec_hip_host.cpp: the same assertions.)"""
-    rs = g.ReedSolomon(k, m)
+    rs = g.ReedSolomon(k, m, shardsum=kind)
     n, S = k + m, g.shard_len(k, L)
     rng = np.random.default_rng(7 * k + nb)
     data = rng.integers(0, 256, (nb, k, S), dtype=np.uint8)
@@ -118,7 +123,7 @@ def test_get_in_one_launch_many_erasure_patterns(coracle, k, m, L, nb):
         present = [j for j in range(n) if j not in lost[b]][:k]
         for j in range(n):
             if j in present:
-                assert ssums[b, j].tobytes() == g.shardsum(full[b, j].tobytes()), (b, j, lost[b])
+                assert ssums[b, j].tobytes() == g.shardsum(full[b, j].tobytes(), kind), (b, j, lost[b])
             else:
                 assert not ssums[b, j].any(), (b, j)
         for j in lost[b]:
@@ -137,7 +142,7 @@ import garage_amd as g
 from oracle import rs_oracle as O
 from tests.test_gpu_fused import _put, _get
 k, m = 10, 4
-rs = g.ReedSolomon(k, m)
+rs = g.ReedSolomon(k, m, shardsum=2)
 S = g.shard_len(k, 1 << 20)
 data, par, sums = _put(rs, k, m, S, [1 << 20, 1 << 20, 777_777], seed=5)
 full = np.concatenate([data, par], axis=1)
@@ -180,3 +185,39 @@ print("DIGEST", h.hexdigest())
     assert len(fused_names) == 2, counts["1"]                       # one put + one get
     assert len(counts["1"]) == 2, counts["1"]                       # ... and nothing else
     assert len(counts["0"]) >= len(counts["1"]) + 4, (len(counts["0"]), len(counts["1"]))
+
+
+def test_a_v3_put_is_the_link_kernel_and_a_root_kernel(tmp_path):
+    """Checksum kind 3 under rocprofv3: a put of three blocks on pinned memory is exactly TWO launches -- the pointer-table
+    kernel in its SUM form and mlh_roots -- and no BLAKE2b leaf kernel, no mirror copy, nothing else."""
+    rocprof = "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        pytest.skip("rocprofv3 not installed")
+    code = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import garage_amd as g
+from oracle import mlh64
+from tests.test_gpu_fused import _put
+k, m = 10, 4
+rs = g.ReedSolomon(k, m)
+assert rs.shardsum_kind == 3
+S = g.shard_len(k, 1 << 20)
+data, par, sums = _put(rs, k, m, S, [1 << 20, 1 << 20, 777_777], seed=5)
+full = np.concatenate([data, par], axis=1)
+assert all(sums[b, j].tobytes() == mlh64.shardsum3(full[b, j].tobytes()) for b in range(3) for j in range(14))
+''' % ROOT
+    out = tmp_path / "prof"
+    r = subprocess.run([rocprof, "--kernel-trace", "--stats", "-d", str(out), "-o", "t", "--output-format", "csv", "--", sys.executable, "-c", code],
+                       cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    names = []
+    for dirpath, _, files in os.walk(out):
+        for f in files:
+            if f.endswith("kernel_trace.csv"):
+                import csv
+
+                with open(os.path.join(dirpath, f)) as fh:
+                    names += [row["Kernel_Name"] for row in csv.DictReader(fh) if not row["Kernel_Name"].startswith("__amd_rocclr")]
+    assert len(names) == 2 and "gf_apply_ptrs<1, 5, false, false, true>" in names[0] and "mlh_roots" in names[1], names
