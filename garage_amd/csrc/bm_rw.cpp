@@ -403,6 +403,47 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 							++seen;
 						}
 				}
+				// The decode does not wait for the verdicts: it reads the same (immutable) shard buffers the pool is checking, so it
+				// runs BESIDE the check -- on the device, from a thread of its own -- and what it rebuilt from a shard that then
+				// fails its checksum is simply not used (the block goes round again below).  Exactly the first k present shards
+				// of a block are handed over: the decode reads what is being verified.
+				std::vector<const uint8_t *> dsp;
+				std::vector<uint8_t *> dop;
+				size_t ndec = 0;
+				for (size_t i = 0; i < ids.size() && nrebuild; ++i) {
+					bool wants = false;
+					for (int j = 0; j < k; ++j)
+						wants = wants || op[i * n + j];
+					if (!wants)
+						continue;
+					int seen = 0;
+					for (int j = 0; j < n; ++j) {
+						const bool use = sp[i * n + j] && seen < k;
+						seen += use ? 1 : 0;
+						dsp.push_back(use ? sp[i * n + j] : nullptr);
+						dop.push_back(op[i * n + j]);
+					}
+					++ndec;
+				}
+				int drc = GEC_OK;
+				std::string derr;
+				std::thread decoder;
+				if (ndec)
+					decoder = std::thread([&] {
+						name_thread("gbm-get-decode");
+						DeviceTurn turn(gate);
+						drc = gec_reconstruct_batch(mg->codec, ndec, dsp.data(), dop.data(), S, /*data_only=*/1);
+						if (drc)
+							derr = gec_last_error();  // (thread-local over there: carried to the caller's thread)
+					});
+				struct JoinDecoder {
+					std::thread &t;
+					~JoinDecoder()
+					{
+						if (t.joinable())
+							t.join();
+					}
+				} join_decoder{decoder};
 				const size_t per = 4;  // shards per pool task
 				auto check = [&](size_t t) {
 					for (size_t q = t * per; q < std::min(items.size(), (t + 1) * per); ++q)
@@ -415,39 +456,12 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 				else
 					mg->pool->parallel_for(ntask, check);
 				tr.lap("shard checksums on the host");
-				// the decode, for the blocks whose k shards in hand all matched (the others go round again first)
-				std::vector<const uint8_t *> dsp;
-				std::vector<uint8_t *> dop;
-				size_t ndec = 0;
-				for (size_t i = 0; i < ids.size() && nrebuild; ++i) {
-					const Gathered &gb = g[ids[i]];
-					bool wants = false, clean = true;
-					for (int j = 0; j < n; ++j)
-						wants = wants || op[i * n + j];
-					int seen_c = 0;  // (the first k present shards: exactly the ones that were checked above and are compared below)
-					for (int j = 0; j < n && wants && clean && seen_c < k; ++j)
-						if (sp[i * n + j]) {
-							++seen_c;
-							if (std::memcmp(ssums.data() + (i * n + j) * 32, gb.sum[j].data(), 32) != 0)
-								clean = false;
-						}
-					if (!wants || !clean)
-						continue;
-					// exactly the first k present shards: the decode then reads what was verified
-					int seen = 0;
-					for (int j = 0; j < n; ++j) {
-						const bool use = sp[i * n + j] && seen < k;
-						seen += use ? 1 : 0;
-						dsp.push_back(use ? sp[i * n + j] : nullptr);
-						dop.push_back(op[i * n + j]);
-					}
-					++ndec;
-				}
-				if (ndec) {
-					DeviceTurn turn(gate);
-					rc = gec_reconstruct_batch(mg->codec, ndec, dsp.data(), dop.data(), S, /*data_only=*/1);
-					tr.lap("decode");
-				}
+				if (decoder.joinable())
+					decoder.join();
+				if (ndec)
+					tr.lap("decode (beside the checks)");
+				if (drc)
+					return fail(GBM_E_EC, std::string("gec_reconstruct_batch: ") + gec_strerror(drc) + " (" + derr + ")");
 			} else {
 				DeviceTurn turn(gate);
 				rc = gec_decode_verify_batch(mg->codec, ids.size(), sp.data(), S, lens.data(), op.data(), ssums.data(),
