@@ -522,6 +522,129 @@ def base_line(args, world: int, elapsed: float, blocks_all: int, per_rank, nb0: 
     }
 
 
+def _timed_on_stream(torch, stream, fn, steps: int, warm_ms: float) -> float:
+    """avg ms per call of fn over `steps` back-to-back calls, HIP events on the launch stream, behind `warm_ms` of the same calls"""
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < warm_ms:
+        for _ in range(10):
+            fn()
+        stream.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)
+    for _ in range(steps):
+        fn()
+    ev1.record(stream)
+    stream.synchronize()
+    return ev0.elapsed_time(ev1) / steps
+
+
+def static_pmc(key: str):
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
+
+
+def encode_hash_object(args, job) -> dict:
+    """The device-resident PUT trip on config 2: RS(10,4) encode AND the checksum of all 14 shards of every block
+    (gec_encode_hash_batch_dev) -- one pass: the encode kernel's SUM form leaves the MLH64 leaf sums from its registers, one lane
+    per shard makes the roots.  Checked after the timed loop: parity against the C oracle and all 14 checksums against
+    oracle/mlh64.py on a strided sample of blocks."""
+    import numpy as np
+
+    from oracle import mlh64
+    from oracle import rs_oracle as O
+
+    torch, g = job.torch, job.g
+    n, S, nb = K + M, job.S, job.nb
+    sums = torch.empty((nb, n, 32), dtype=torch.uint8, device=job.dev)
+    rs3 = job.rs if job.rs.shardsum_kind == 3 else job.rs.with_shardsum(3)
+
+    def step():
+        rc = job.lib.gec_encode_hash_batch_dev(rs3._h, nb, job.base, n * S, S, sums.data_ptr(), job.stream.cuda_stream)
+        if rc:
+            g._lib.check(rc, "gec_encode_hash_batch_dev")
+
+    job.st[:, K:] = 0
+    steps = max(20, min(args.steps, 200))
+    ms = _timed_on_stream(torch, job.stream, step, steps, min(args.precondition_ms, 100.0))
+    enc_ms = _timed_on_stream(torch, job.stream, job.step, steps, 0.0)   # the encode alone, same clocks, for the ratio
+    # -- after the timed loops
+    idx = sorted(set(np.linspace(0, nb - 1, 16).astype(int).tolist()))
+    host = job.st[torch.as_tensor(idx, device=job.dev)].cpu().numpy()
+    hs = sums[torch.as_tensor(idx, device=job.dev)].cpu().numpy()
+    co = O.COracle()
+    want = co.encode_batch(K, M, np.ascontiguousarray(host[:, :K]), co.AVX2 if co.has_avx2() else co.SCALAR, threads=4)
+    ok = bool(np.array_equal(host[:, K:], want))
+    ok = ok and all(hs[i, j].tobytes() == mlh64.shardsum3(host[i, j].tobytes()) for i in range(len(idx)) for j in range(n))
+    assert bool(job.rs.verify_dev(job.st).all()), "verify failed after encode_hash"
+    ab = algo_bytes(nb, S)
+    out = {
+        "what": "BASELINE config 2 with the checksum of every shard: gec_encode_hash_batch_dev, RS(10,4), 1 MiB blocks, device-resident "
+                "(shard checksum v3 = MLH64: leaf sums accumulated by the encode kernel from its registers + one root kernel)",
+        "value": round(nb * BLOCK_LEN / (ms * 1e-3) / 2**30, 2), "unit": "GiB/s", "ms": round(ms, 4), "blocks": nb, "steps": steps,
+        "checksums_per_launch": nb * n, "encode_alone_ms": round(enc_ms, 4), "over_encode_alone": round(ms / enc_ms, 3) if enc_ms else None,
+        "roofline": {"bound": "hbm", "achieved": round(ab / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": ab,
+                     "note": "same algorithmic bytes as the encode (read k*S, write m*S): the checksums read nothing twice; "
+                             "both launches of the trip are inside `ms`",
+                     "kernels": ["gf_apply_nibble_sum<1,0,10,true,256>", "mlh_roots"]},
+        "binding_resource": static_pmc("rs10_4_encode_hash_secondary_bounds"),
+        "traffic": (static_pmc("rs10_4_encode_hash_1MiB_x1024") or {}).get("traffic_bytes"),
+        "bit_exact": ok, "checked": f"{len(idx)} strided blocks: parity vs the C oracle, all {n} checksums vs oracle/mlh64.py; gec_verify_batch_dev over the batch",
+    }
+    if not ok:
+        out["error"] = "encode_hash output differs from the oracles"
+    return out
+
+
+def rs20_8_object(args, dev, stream) -> dict:
+    """BASELINE config 5's code on one GPU: RS(20,8) encode of 256 x 4 MiB blocks, device-resident; every block's parity against
+    the C oracle after the timed loop."""
+    import numpy as np
+    import torch
+
+    import garage_amd as g
+    from oracle import rs_oracle as O
+
+    k, m, L, nb = 20, 8, 4 << 20, 256
+    n, S = k + m, g.shard_len(k, 4 << 20)
+    rs = g.ReedSolomon(k, m, device=dev.index)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x6761726167650005)
+    st = torch.zeros((nb, n, S), dtype=torch.uint8, device=dev)
+    st[:, :k].reshape(nb, k * S)[:, :L] = torch.randint(0, 256, (nb, L), dtype=torch.uint8, device=dev, generator=gen)
+    base = st.data_ptr()
+    lib = g._lib.lib
+
+    def step():
+        rc = lib.gec_encode_batch_dev(rs._h, nb, base, n * S, S, base + k * S, n * S, stream.cuda_stream)
+        if rc:
+            g._lib.check(rc, "gec_encode_batch_dev")
+
+    steps = max(20, min(args.steps, 200))
+    ms = _timed_on_stream(torch, stream, step, steps, min(args.precondition_ms, 100.0))
+    host = st.cpu().numpy()
+    co = O.COracle()
+    want = co.encode_batch(k, m, np.ascontiguousarray(host[:, :k]), co.AVX2 if co.has_avx2() else co.SCALAR, threads=max(1, min(16, os.cpu_count() or 1)))
+    ok = bool(np.array_equal(host[:, k:], want))
+    ab = n * S * nb
+    rec = static_pmc("rs20_8_encode_4MiB_x256") or {}
+    out = {
+        "what": "BASELINE config 5's code on one GPU: RS(20,8) encode, 256 x 4 MiB blocks, device-resident",
+        "value": round(nb * L / (ms * 1e-3) / 2**30, 2), "unit": "GiB/s", "kernel_ms": round(ms, 4), "blocks": nb, "steps": steps, "shard_len": S,
+        "roofline": {"bound": "hbm", "achieved": round(ab / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": ab,
+                     "traffic": rec.get("traffic_bytes"), "traffic_source": "static: profiles/pmc_traffic.json (" + rec.get("source", "") + ")" if rec else None,
+                     "kernel": "gf_apply_nibble<2,0,5,1,true,512>", "secondary": static_pmc("rs20_8_secondary_bounds")},
+        "bit_exact": ok, "checked": f"parity of all {nb} blocks vs the C oracle, after the timed loop",
+    }
+    if not ok:
+        out["error"] = "RS(20,8) parity differs from the C oracle"
+    return out
+
+
 # --------------------------------------------------------------- one process per GPU
 def run_procs(args) -> None:
     import numpy as np
@@ -637,6 +760,15 @@ def run_procs(args) -> None:
             "roofline_frac": round((K + len(job.lost)) * S * blocks_all / world / (dt / dsteps) / 1e9 / HBM_PEAK_GBS, 4),
         }
 
+    # ---- N = 1: the put trip (config 2 + the checksum of every shard) and config 5's code, beside the headline
+    extra = {}
+    if world == 1 and rank == 0 and nb and not args.no_extra and args.variant == 0:
+        for key, fn in (("encode_hash", lambda: encode_hash_object(args, job)), ("rs20_8_encode", lambda: rs20_8_object(args, R.device, job.stream))):
+            try:
+                extra[key] = fn()
+            except Exception as e:  # noqa: BLE001 -- a secondary object must never cost the headline line
+                extra[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+
     out = None
     if rank == 0:
         out = base_line(args, world, elapsed, blocks_all, per_rank, nb, S,
@@ -655,6 +787,7 @@ def run_procs(args) -> None:
         out["collective_backend"] = rccl["backend"]
         if decode:
             out["decode"] = decode
+        out.update(extra)
     del job
     torch.cuda.empty_cache()
 
@@ -1301,6 +1434,7 @@ def main() -> None:
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-oracle-check", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the pcie_inclusive / block_manager objects (N=1)")
+    ap.add_argument("--no-extra", action="store_true", help="N=1: skip the encode_hash / rs20_8_encode objects")
     ap.add_argument("--no-striped", action="store_true", help="N>1: skip the BASELINE config 5 striped_decode object")
     ap.add_argument("--striped", action="store_true", help="N=1: also run the striped_decode object (RCCL with one rank)")
     ap.add_argument("--striped-objects", type=int, default=256)

@@ -44,7 +44,7 @@ SYMBOLS = [
     "gec_codec_device", "gec_parity_matrix", "gec_codec_cache_stats",
     "gec_codec_background", "gec_codec_class", "gec_codec_backend", "gec_qos_yields", "gec_cu_masks_active",
     "gec_encode_batch", "gec_verify_batch", "gec_verify_hash_batch", "gec_reconstruct_batch", "gec_reconstruct_hash_batch",
-    "gec_encode_batch_dev", "gec_verify_batch_dev", "gec_reconstruct_batch_dev",
+    "gec_encode_batch_dev", "gec_verify_batch_dev", "gec_reconstruct_batch_dev", "gec_reconstruct_batch_dev_ex",
     "gec_reconstruct_range_dev", "gec_reconstruct_scattered_dev", "gec_blake2sum_batch_dev", "gec_blake2sum_batch",
     "gec_encode_hash_batch", "gec_set_kernel_variant", "gec_get_kernel_variant",
     "gec_group_unique_id", "gec_group_create", "gec_group_create_with_transport", "gec_group_destroy",
@@ -131,6 +131,7 @@ def _load() -> ctypes.CDLL:
     lib.gec_encode_batch_dev.argtypes = [vp, sz, vp, sz, sz, vp, sz, vp]
     lib.gec_verify_batch_dev.argtypes = [vp, sz, vp, sz, sz, vp, vp]
     lib.gec_reconstruct_batch_dev.argtypes = [vp, sz, vp, sz, sz, u8p, ci, vp]
+    lib.gec_reconstruct_batch_dev_ex.argtypes = [vp, sz, vp, sz, sz, u8p, ci, vp]
     lib.gec_reconstruct_range_dev.argtypes = [vp, sz, vp, sz, sz, u8p, ci, sz, sz, vp]
     lib.gec_reconstruct_scattered_dev.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), sz, u8p, ci, sz, sz, vp]
     lib.gec_blake2sum_batch_dev.argtypes = [vp, sz, vp, sz, sz, vp, vp]

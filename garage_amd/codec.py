@@ -189,6 +189,26 @@ class ReedSolomon:
               "gec_reconstruct_range_dev")
         return stripes
 
+    def reconstruct_dev_ex(self, stripes, present, data_only: bool = False):
+        """gec_reconstruct_batch_dev_ex: `present` is (nblocks, k+m) -- an erasure pattern PER BLOCK, rebuilt in place by one
+        launch.  (A CPU codec runs the same call on a CPU tensor.)"""
+        import torch
+
+        on_host = self.backend == "cpu"
+        if on_host:
+            if not (isinstance(stripes, torch.Tensor) and not stripes.is_cuda and stripes.dtype == torch.uint8 and stripes.dim() == 3
+                    and stripes.shape[1] == self.n and stripes.is_contiguous()):
+                raise TypeError("stripes must be a contiguous uint8 CPU tensor (nblocks, k+m, S)")
+        else:
+            self._check_dev(stripes, self.n, "stripes")
+        nb, _, S = stripes.shape
+        pres = np.ascontiguousarray(np.asarray(present, dtype=np.uint8))
+        if pres.shape != (nb, self.n):
+            raise GecError(_lib.GEC_E_INVALID_INDEX, "present", "must be (nblocks, k+m)")
+        check(lib.gec_reconstruct_batch_dev_ex(self._h, nb, stripes.data_ptr(), self.n * S, S, _u8p(pres), int(bool(data_only)),
+                                               None if on_host else _stream_handle(self.device)), "gec_reconstruct_batch_dev_ex")
+        return stripes
+
     def reconstruct_scattered_dev(self, buf, nblocks: int, block_stride: int, shard_off: Sequence[int], S: int,
                                   present: Sequence[int], data_only: bool = False,
                                   byte_range: Optional[tuple[int, int]] = None):

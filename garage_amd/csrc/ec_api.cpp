@@ -242,6 +242,7 @@ int no_dev() { return fail(GEC_E_DEVICE, "this codec runs on the host cores (GEC
 int Backend::encode_batch_dev(size_t, const void *, size_t, size_t, void *, size_t, void *) { return no_dev(); }
 int Backend::verify_batch_dev(size_t, const void *, size_t, size_t, uint32_t *, void *) { return no_dev(); }
 int Backend::reconstruct_dev(size_t, void *, size_t, const size_t *, size_t, const uint8_t *, int, size_t, size_t, void *) { return no_dev(); }
+int Backend::reconstruct_dev_ex(size_t, void *, size_t, size_t, const uint8_t *, int, void *) { return no_dev(); }
 int Backend::hash_batch_dev(size_t, const void *, size_t, size_t, void *, void *, bool) { return no_dev(); }
 int Backend::encode_hash_batch_dev(size_t, void *, size_t, size_t, void *, void *) { return no_dev(); }
 
@@ -755,6 +756,29 @@ int gec_reconstruct_batch_dev(const gec_codec *c, size_t nblocks, void *d_stripe
 			      int data_only, void *hip_stream)
 try {
 	return gec_reconstruct_range_dev(c, nblocks, d_stripes, stride, S, present, data_only, 0, S, hip_stream);
+}
+GEC_CATCH
+
+int gec_reconstruct_batch_dev_ex(const gec_codec *c, size_t nblocks, void *d_stripes, size_t stride, size_t S, const uint8_t *present,
+				 int data_only, void *hip_stream)
+try {
+	if (!c || !present)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (nblocks == 0)
+		return GEC_OK;
+	int rc = check_dev_layout(d_stripes, stride, S, (size_t)(c->k + c->m) * S);
+	if (rc)
+		return rc;
+	// every block's pattern is checked before anything is enqueued: a batch is rebuilt whole or not at all
+	const size_t n = (size_t)c->k + c->m;
+	for (size_t b = 0; b < nblocks; ++b) {
+		int have = 0;
+		for (size_t j = 0; j < n; ++j)
+			have += present[b * n + j] ? 1 : 0;
+		if (have < c->k)
+			return fail(GEC_E_TOO_FEW_PRESENT, "block " + std::to_string(b) + ": fewer than k shards present");
+	}
+	return c->be->reconstruct_dev_ex(nblocks, d_stripes, stride, S, present, data_only, hip_stream);
 }
 GEC_CATCH
 

@@ -467,6 +467,24 @@ struct CpuBackend : Backend {
 		return reconstruct_batch(nblocks, sp.data(), op.data(), byte_len, data_only, nullptr, nullptr);
 	}
 
+	// ... with a pattern per block: the pointer form takes any mix of patterns in one call
+	int reconstruct_dev_ex(size_t nblocks, void *d_stripes, size_t stride, size_t S, const uint8_t *present, int data_only, void *) override
+	{
+		const size_t k = c->k, n = (size_t)c->k + c->m;
+		std::vector<const uint8_t *> sp(nblocks * n, nullptr);
+		std::vector<uint8_t *> op(nblocks * n, nullptr);
+		uint8_t *base = static_cast<uint8_t *>(d_stripes);
+		for (size_t b = 0; b < nblocks; ++b)
+			for (size_t j = 0; j < n; ++j) {
+				uint8_t *p = base + b * stride + j * S;
+				if (present[b * n + j])
+					sp[b * n + j] = p;
+				else if (!(data_only && j >= k))
+					op[b * n + j] = p;
+			}
+		return reconstruct_batch(nblocks, sp.data(), op.data(), S, data_only, nullptr, nullptr);
+	}
+
 	int reconstruct_batch(size_t nblocks, const uint8_t *const *shards, uint8_t *const *out, size_t S, int data_only, uint8_t *in_sums,
 			      uint8_t *out_sums) override
 	{

@@ -209,6 +209,8 @@ struct HipBackend : Backend {
 	int verify_batch_dev(size_t nblocks, const void *d_stripes, size_t stride, size_t S, uint32_t *d_bad, void *hip_stream) override;
 	int reconstruct_dev(size_t nblocks, void *d_base, size_t block_stride, const size_t *shard_off, size_t S, const uint8_t *present,
 			    int data_only, size_t byte_off, size_t byte_len, void *hip_stream) override;
+	int reconstruct_dev_ex(size_t nblocks, void *d_stripes, size_t stride, size_t S, const uint8_t *present, int data_only,
+			       void *hip_stream) override;
 	int hash_batch_dev(size_t n, const void *d_base, size_t stride, size_t len, void *d_out, void *hip_stream, bool tree) override;
 	int encode_hash_batch_dev(size_t nblocks, void *d_stripes, size_t stride, size_t S, void *d_sums, void *hip_stream) override;
 };
@@ -349,6 +351,9 @@ struct SumOut {
 int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_t *out, size_t out_stride, uint32_t *bad,
 		 size_t byte_off, size_t byte_len, size_t nblocks, const size_t *in_base_off, const size_t *out_base_off, int nout,
 		 const uint8_t *coef /* nout x k */, int mode, hipStream_t stream, const SumOut *sum = nullptr);
+// One launch, a decode plan per block: block b is rebuilt in place with plans[pat_of_block[b]] (<= 8 missing shards each).
+int launch_apply_pat(const gec_codec *c, uint8_t *d_base, size_t stride, size_t S, size_t nblocks,
+		     const std::vector<std::shared_ptr<const Plan>> &plans, const std::vector<uint16_t> &pat_of_block, hipStream_t stream);
 // The roots of n shards' leaf sums: shard i's sums at lsum[(slot_map ? slot_map[i] : i) * nleaf_max] (slot_map: device-
 // addressable, may be NULL), its length d_len[i] (NULL: len), its 32-byte checksum placed like blake2_dev places results.
 int mlh_roots_dev(const gec_codec *c, size_t n, const uint64_t *lsum, uint32_t nleaf_max, const uint64_t *d_len, size_t len,

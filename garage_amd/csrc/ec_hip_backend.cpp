@@ -276,6 +276,58 @@ int HipBackend::reconstruct_dev(size_t nblocks, void *d_base, size_t block_strid
 					byte_off, byte_len, static_cast<hipStream_t>(hip_stream));
 }
 
+// One erasure pattern PER BLOCK (the crate's reconstruct is per call; a device-resident batch gathered from a degraded
+// cluster has a mix): the blocks are grouped by pattern on the host -- one decode plan per distinct pattern, cached like any
+// other -- and rebuilt by ONE launch in which every workgroup expands the table of the block it is at (gf_apply_nibble_pat).
+int HipBackend::reconstruct_dev_ex(size_t nblocks, void *d_stripes, size_t stride, size_t S, const uint8_t *present, int data_only,
+				   void *hip_stream)
+{
+	DeviceGuard g(device);
+	if (!g.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	const size_t n = (size_t)c->k + c->m;
+	hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+	std::unordered_map<std::string, uint16_t> seen;
+	std::vector<std::shared_ptr<const Plan>> plans;
+	std::vector<uint16_t> pat(nblocks);
+	std::vector<size_t> wide;  // blocks whose pattern has more than RMAX rows (codes with m > 8): one at a time
+	for (size_t b = 0; b < nblocks; ++b) {
+		std::string key(reinterpret_cast<const char *>(present + b * n), n);
+		for (char &ch : key)
+			ch = ch ? 1 : 0;
+		auto it = seen.find(key);
+		if (it == seen.end()) {
+			if (plans.size() >= 0xffff)
+				return fail(GEC_E_INVALID_ARG, "more than 65535 distinct erasure patterns in one call");
+			std::shared_ptr<const Plan> plan;
+			int rc = get_plan(c, present + b * n, data_only != 0, plan);
+			if (rc)
+				return rc;
+			it = seen.emplace(key, (uint16_t)plans.size()).first;
+			plans.push_back(plan);
+		}
+		pat[b] = it->second;
+		if (plans[pat[b]]->missing.size() > (size_t)gec::RMAX)
+			wide.push_back(b);
+	}
+	if (!wide.empty()) {
+		// rare (m > 8 and more than 8 shards of a block gone): those blocks alone, the uniform way; the rest below
+		std::shared_ptr<Plan> none(new Plan(*plans[0]));
+		none->missing.clear();
+		const std::vector<size_t> off = stripe_offsets(c, S);
+		for (size_t b : wide) {
+			int rc = gecimpl::reconstruct_dev(c, 1, static_cast<uint8_t *>(d_stripes) + b * stride, stride, off.data(), present + b * n, data_only != 0, 0, S, stream);
+			if (rc)
+				return rc;
+			if (plans.size() >= 0xffff)
+				return fail(GEC_E_INVALID_ARG, "more than 65535 distinct erasure patterns in one call");
+			pat[b] = (uint16_t)plans.size();
+		}
+		plans.push_back(none);  // "nothing to do" for the blocks that have just been rebuilt
+	}
+	return launch_apply_pat(c, static_cast<uint8_t *>(d_stripes), stride, S, nblocks, plans, pat, stream);
+}
+
 int HipBackend::hash_batch_dev(size_t n, const void *d_base, size_t stride, size_t len, void *d_out, void *hip_stream, bool tree)
 {
 	DeviceGuard g(device);

@@ -406,6 +406,101 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 	return GEC_OK;
 }
 
+// One launch, a coefficient set per block (gec_reconstruct_batch_dev_ex): block b is rebuilt with plans[pat_of_block[b]] -- its
+// valid shards in, its missing shards out, in place in the stripe (shard j of block b at d_base + b*stride + j*S).
+int launch_apply_pat(const gec_codec *c, uint8_t *d_base, size_t stride, size_t S, size_t nblocks,
+		     const std::vector<std::shared_ptr<const Plan>> &plans, const std::vector<uint16_t> &pat_of_block, hipStream_t stream)
+{
+	const int k = c->k;
+	const HipBackend &hb = hip_of(c);
+	if (nblocks == 0 || plans.empty())
+		return GEC_OK;
+	size_t max_rows = 0;
+	for (const auto &pl : plans)
+		max_rows = std::max(max_rows, pl->missing.size());
+	if (max_rows == 0)
+		return GEC_OK;
+	if (max_rows > (size_t)gec::RMAX || plans.size() > 0xffff || nblocks > 0xffffffffull || S / 16 > 0x7fffffffull)
+		return fail(GEC_E_INVALID_ARG, "per-block erasure patterns: at most 8 missing shards per block, 65535 patterns");
+	const uint32_t kp = ((uint32_t)k + 3) & ~3u;
+	const uint32_t ent = (4 * kp + 4 * gec::RMAX + 16 + (uint32_t)k * gec::RMAX + 15) & ~15u;
+	const size_t pat_bytes = (nblocks * 2 + 15) & ~(size_t)15;
+	std::vector<uint8_t> host(pat_bytes + plans.size() * ent, 0);
+	std::memcpy(host.data(), pat_of_block.data(), nblocks * 2);
+	for (size_t p = 0; p < plans.size(); ++p) {
+		uint8_t *e = host.data() + pat_bytes + p * ent;
+		uint32_t *in_off = reinterpret_cast<uint32_t *>(e), *out_off = in_off + kp;
+		const Plan &pl = *plans[p];
+		for (int t = 0; t < k; ++t)
+			in_off[t] = (uint32_t)((size_t)pl.valid[t] * S / 16);
+		for (size_t r = 0; r < pl.missing.size(); ++r)
+			out_off[r] = (uint32_t)((size_t)pl.missing[r] * S / 16);
+		out_off[gec::RMAX] = (uint32_t)pl.missing.size();
+		uint8_t *coef = reinterpret_cast<uint8_t *>(out_off + gec::RMAX + 4);
+		for (int t = 0; t < k; ++t)
+			for (size_t r = 0; r < pl.missing.size(); ++r)
+				coef[(size_t)t * gec::RMAX + r] = pl.rows.v[r * (size_t)k + t];
+	}
+	uint8_t *d_tab = nullptr;
+	int rc = leaf_scratch(c, stream, host.size(), &d_tab);
+	if (rc)
+		return rc;
+	HIP_TRY(hipMemcpyAsync(d_tab, host.data(), host.size(), hipMemcpyHostToDevice, stream));  // (pageable source: staged before the call returns)
+	gec::ApplyArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.in = d_base;
+	a.out = d_base;
+	a.in_stride = a.out_stride = stride;
+	a.cols = (uint32_t)(S / 16);
+	a.k = (uint32_t)k;
+	a.rows = (uint32_t)max_rows;
+	a.pat = reinterpret_cast<const uint16_t *>(d_tab);
+	a.pat_tab = d_tab + pat_bytes;
+	a.pat_stride = ent;
+	const Geometry geo = pick_geometry(k, (int)max_rows, false);
+	const uint64_t tile_cols = (uint64_t)geo.threads;
+	a.tiles_per_block = (uint32_t)((a.cols + tile_cols - 1) / tile_cols);
+	const uint64_t blocks_per_launch = std::max<uint64_t>(1, std::min<uint64_t>(0xfffff000ull / a.cols, (0xffffffffull / geo.threads - 8) / a.tiles_per_block));
+	for (uint64_t b0 = 0; b0 < nblocks; b0 += blocks_per_launch) {
+		const uint64_t nb = std::min<uint64_t>(blocks_per_launch, nblocks - b0);
+		gec::ApplyArgs la = a;
+		la.in = la.out = d_base + b0 * stride;
+		la.pat = a.pat + b0;
+		la.nblocks = (uint32_t)nb;
+		la.total_cols = (uint32_t)(nb * a.cols);
+		const unsigned grid = (unsigned)((nb * a.tiles_per_block + 7) / 8 * 8);
+		const int kc = geo.kc;
+#define GEC_PAT(MW, KC, TPB) hipLaunchKernelGGL((gec::gf_apply_nibble_pat<MW, KC, true, TPB>), dim3(grid), dim3(TPB), geo.lds, stream, la, hb.d_logexp)
+		if (geo.mw == 1) {
+			switch (kc) {
+			case 1: GEC_PAT(1, 1, 256); break;
+			case 2: GEC_PAT(1, 2, 256); break;
+			case 3: GEC_PAT(1, 3, 256); break;
+			case 4: GEC_PAT(1, 4, 256); break;
+			case 5: GEC_PAT(1, 5, 256); break;
+			case 6: GEC_PAT(1, 6, 256); break;
+			case 10: GEC_PAT(1, 10, 256); break;
+			case 12: GEC_PAT(1, 12, 256); break;
+			default: GEC_PAT(1, 16, 256); break;
+			}
+		} else if (kc == 10) {
+			GEC_PAT(2, 10, 256);
+		} else {
+			switch (kc) {
+			case 1: GEC_PAT(2, 1, 512); break;
+			case 2: GEC_PAT(2, 2, 512); break;
+			case 3: GEC_PAT(2, 3, 512); break;
+			case 4: GEC_PAT(2, 4, 512); break;
+			case 5: GEC_PAT(2, 5, 512); break;
+			default: GEC_PAT(2, 6, 512); break;
+			}
+		}
+#undef GEC_PAT
+		HIP_TRY(hipGetLastError());
+	}
+	return GEC_OK;
+}
+
 int mlh_roots_dev(const gec_codec *c, size_t n, const uint64_t *lsum, uint32_t nleaf_max, const uint64_t *d_len, size_t len,
 		  uint8_t *d_out, hipStream_t stream, const uint32_t *slot_map, uint32_t group, uint32_t out_group)
 {

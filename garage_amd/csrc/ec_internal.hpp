@@ -106,6 +106,9 @@ struct Backend {
 	// shard_off == NULL: contiguous stripes (shard j at j*S)
 	virtual int reconstruct_dev(size_t nblocks, void *d_base, size_t block_stride, const size_t *shard_off, size_t S,
 				    const uint8_t *present, int data_only, size_t byte_off, size_t byte_len, void *hip_stream);
+	// one erasure pattern per block: present[b * (k+m) + j]
+	virtual int reconstruct_dev_ex(size_t nblocks, void *d_stripes, size_t stride, size_t S, const uint8_t *present, int data_only,
+				       void *hip_stream);
 	virtual int hash_batch_dev(size_t n, const void *d_base, size_t stride, size_t len, void *d_out, void *hip_stream, bool tree);
 	virtual int encode_hash_batch_dev(size_t nblocks, void *d_stripes, size_t stride, size_t S, void *d_sums, void *hip_stream);
 };

@@ -45,6 +45,11 @@ struct ApplyArgs {
 	//   lsum[((b * sum_slots_total + sum_slot0 + slot) * sum_nleaf_max) + leaf],   slot = input t (sum_inputs) then row r
 	uint64_t *lsum;
 	uint32_t sum_nleaf_max, sum_slots_total, sum_slot0, sum_inputs;
+	// PAT form only: per-block coefficient sets.  Block b uses entry pat[b] of pat_tab (pat_stride bytes apart, 16-byte
+	// aligned): [in_off kp x u32][out_off RMAX x u32][rows, 3 x pad u32][coef k x RMAX bytes], kp = k rounded up to 4
+	const uint8_t *pat_tab;
+	const uint16_t *pat;
+	uint32_t pat_stride;
 };
 
 // exp[512] | log[256], filled by the host from gec::Field (768 bytes).

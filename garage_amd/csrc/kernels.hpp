@@ -143,7 +143,10 @@ __device__ __forceinline__ void st16(u32x4 v, u32x4 *p)
 // writes (compare modes: of every stored row it checks) in a.lsum -- from the registers that hold the bytes anyway.  Tiles
 // are then cut per block (tile = TPB columns of ONE block, i.e. TPB/256 whole leaves of each of its shards; the last tile of
 // a block is ragged) so that a leaf's 256 terms meet inside one workgroup.
-template <int MW, int MODE, int KC, int CPT, bool NT, int TPB, bool SUM = false>
+// PAT: one coefficient set PER BLOCK (a device-resident batch whose blocks lost different shards, decoded in one launch):
+// block b uses entry a.pat[b] of a.pat_tab -- [in_off k x u32][out_off RMAX x u32][rows u32][pad][coef k x RMAX bytes] --
+// instead of the launch's own in_off / out_off / coef.  Tiles are cut per block, as for SUM (a workgroup builds ONE table).
+template <int MW, int MODE, int KC, int CPT, bool NT, int TPB, bool SUM = false, bool PAT = false>
 __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const LogExp *__restrict__ le)
 {
 	constexpr int ENT = 4 * MW;            // bytes per table entry
@@ -165,7 +168,7 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 #endif
 	const uint32_t tid = threadIdx.x;
 	const uint32_t k = a.k;
-	const uint32_t rows = a.rows;
+	uint32_t rows = a.rows;
 	uint8_t *lexp = lds + k * TBL;
 	uint8_t *llog = lexp + 512;
 	uint8_t *lcoef = llog + 256;
@@ -192,7 +195,7 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 	const u32x4 *srcp[CPT];
 	u32x4 *dstp[CPT];
 	uint32_t sum_tile = 0;  // SUM: this tile's index inside its block (its first leaf = sum_tile * TPB / 256)
-	if constexpr (SUM) {
+	if constexpr (SUM || PAT) {
 		static_assert(CPT == 1 && TPB % 256 == 0, "a leaf is 256 columns: one column per lane, whole leaves per workgroup");
 		if (tile_id >= a.nblocks * a.tiles_per_block)
 			return;
@@ -225,11 +228,22 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 	//    requested FIRST, so their wait does not drain the data loads behind them
 	//    (index-clamped and stored unconditionally below: a `tid <` branch would let
 	//    hipcc sink the load into it, behind the data loads, where it waits vmcnt(0))
+	// where this tile's offsets and coefficients come from: the launch's argument block, or the block's pattern entry
+	const uint32_t *pin = a.in_off, *pout = a.out_off;
+	const uint32_t *pcoef = reinterpret_cast<const uint32_t *>(&a.coef[0][0]);
+	if constexpr (PAT) {
+		static_assert(MW <= 2, "pattern entries carry RMAX rows");
+		const uint8_t *pe = a.pat_tab + (uint64_t)a.pat[bb[0]] * a.pat_stride;
+		pin = reinterpret_cast<const uint32_t *>(pe);
+		pout = pin + ((k + 3) & ~3u);
+		rows = pout[RMAX];
+		pcoef = pout + RMAX + 4;  // (16-byte aligned: the entry is, and kp + RMAX + 4 words are a multiple of four)
+	}
 	const uint32_t le_idx = tid < 192 ? tid : 191;
 	const uint32_t le_word = reinterpret_cast<const uint32_t *>(le)[le_idx];
 	const uint32_t ncw = k * (CR / 4);  // coefficient dwords
 	const uint32_t coef_idx = tid < ncw ? tid : ncw - 1;
-	const uint32_t coef_word = reinterpret_cast<const uint32_t *>(&a.coef[0][0])[coef_idx];
+	const uint32_t coef_word = pcoef[coef_idx];
 	// SUM: this lane's four checksum keys (its column's place in its leaf), zero for a lane past the end of the shard
 	mlh_u32x4 k4 = {0, 0, 0, 0};
 	constexpr int SUMCAP = TPB > 256 ? 8 : 16;  // slots a wave's LDS region holds between two flushes (>= KC, see the host)
@@ -246,7 +260,7 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 	u32x4 d[KC][CPT];
 #pragma unroll
 	for (int j = 0; j < KC; ++j) {
-		const uint32_t off = a.in_off[(uint32_t)j < k ? j : k - 1];
+		const uint32_t off = pin[(uint32_t)j < k ? j : k - 1];
 #pragma unroll
 		for (int c = 0; c < CPT; ++c)
 			d[j][c] = ld16<NT>(srcp[c] + off);
@@ -259,7 +273,7 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 	if (MODE == MODE_COMPARE_PF) {
 #pragma unroll
 		for (int r = 0; r < NOLD; ++r) {
-			const uint32_t ooff = a.out_off[(uint32_t)r < rows ? r : rows - 1];
+			const uint32_t ooff = pout[(uint32_t)r < rows ? r : rows - 1];
 #pragma unroll
 			for (int c = 0; c < CPT; ++c)
 				oldv[c][r] = ld16<NT>(reinterpret_cast<const u32x4 *>(dstp[c]) + ooff);
@@ -271,7 +285,7 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 	reinterpret_cast<uint32_t *>(lcoef)[coef_idx] = coef_word;
 #pragma unroll 1
 	for (uint32_t i = tid + nthr; i < ncw; i += nthr)  // k > TPB/2 only
-		reinterpret_cast<uint32_t *>(lcoef)[i] = reinterpret_cast<const uint32_t *>(&a.coef[0][0])[i];
+		reinterpret_cast<uint32_t *>(lcoef)[i] = pcoef[i];
 	__syncthreads();
 	// -- prologue 2: expand coef[k][rows] into wide nibble product tables
 	for (uint32_t idx = tid; idx < k * 32; idx += nthr) {
@@ -310,7 +324,7 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 		if (t0 > 0) {
 #pragma unroll
 			for (int j = 0; j < KC; ++j) {
-				const uint32_t off = a.in_off[t0 + j < k ? t0 + j : k - 1];
+				const uint32_t off = pin[t0 + j < k ? t0 + j : k - 1];
 #pragma unroll
 				for (int c = 0; c < CPT; ++c)
 					d[j][c] = ld16<NT>(srcp[c] + off);
@@ -366,7 +380,7 @@ __device__ __forceinline__ void gf_apply_nibble_body(const ApplyArgs &a, const L
 			if (r >= (int)rows)  // `continue`, not `break`: with 16 rows hipcc keeps a `break` loop rolled and spills P[] to scratch
 				continue;
 			u32x4 v = {P[r][0], P[r][1], P[r][2], P[r][3]};
-			u32x4 *o = dstp[c] + a.out_off[r];
+			u32x4 *o = dstp[c] + pout[r];
 			if constexpr (SUM) {  // (rows go into the wave's region in groups of at most eight)
 				if ((r & 7) == 0 && ws.full(rows - r < 8 ? rows - r : 8))
 					ws.flush();
@@ -409,6 +423,13 @@ template <int MW, int MODE, int KC, int CPT, bool NT, int TPB>
 __global__ __launch_bounds__(TPB) void gf_apply_nibble(const ApplyArgs a, const LogExp *__restrict__ le)
 {
 	gf_apply_nibble_body<MW, MODE, KC, CPT, NT, TPB>(a, le);
+}
+
+// the same kernel with a coefficient set per block (see PAT above)
+template <int MW, int KC, bool NT, int TPB>
+__global__ __launch_bounds__(TPB) void gf_apply_nibble_pat(const ApplyArgs a, const LogExp *__restrict__ le)
+{
+	gf_apply_nibble_body<MW, MODE_STORE, KC, 1, NT, TPB, false, true>(a, le);
 }
 
 // the same kernel leaving the shard checksums' leaf sums behind (see SUM above)

@@ -301,6 +301,14 @@ int gec_reconstruct_batch_dev(const gec_codec *c, size_t nblocks,
 			      const uint8_t *present, int data_only,
 			      void *hip_stream);
 
+/* A pattern PER BLOCK: present[b*(k+m) + j] (host, 0/1) -- ReedSolomon::reconstruct is per call [EXT], and a device-resident
+ * batch gathered from a degraded cluster holds a mix.  The blocks are grouped by pattern on the host (one cached decode
+ * matrix per distinct pattern) and rebuilt by ONE launch in which every workgroup expands the coefficient table of the
+ * block it is at.  Every block must have >= k shards present (GEC_E_TOO_FEW_PRESENT names the first that has not, before
+ * anything is enqueued).  With a GEC_BACKEND_CPU codec the same call works on HOST memory at d_stripes. */
+int gec_reconstruct_batch_dev_ex(const gec_codec *c, size_t nblocks, void *d_stripes, size_t stride, size_t S,
+				 const uint8_t *present, int data_only, void *hip_stream);
+
 /* Same, restricted to bytes [byte_off, byte_off+byte_len) of every shard
  * (both multiples of 16): after the all-gather of a striped object each GPU
  * rebuilds its 1/n byte-range of every missing shard. */
