@@ -311,19 +311,20 @@ int HipBackend::reconstruct_dev_ex(size_t nblocks, void *d_stripes, size_t strid
 			wide.push_back(b);
 	}
 	if (!wide.empty()) {
-		// rare (m > 8 and more than 8 shards of a block gone): those blocks alone, the uniform way; the rest below
-		std::shared_ptr<Plan> none(new Plan(*plans[0]));
-		none->missing.clear();
+		// rare (m > 8 and more than 8 shards of a block gone): those blocks alone, the uniform way -- and their patterns
+		// become "nothing to do" for the launch below, which takes the rest
 		const std::vector<size_t> off = stripe_offsets(c, S);
 		for (size_t b : wide) {
 			int rc = gecimpl::reconstruct_dev(c, 1, static_cast<uint8_t *>(d_stripes) + b * stride, stride, off.data(), present + b * n, data_only != 0, 0, S, stream);
 			if (rc)
 				return rc;
-			if (plans.size() >= 0xffff)
-				return fail(GEC_E_INVALID_ARG, "more than 65535 distinct erasure patterns in one call");
-			pat[b] = (uint16_t)plans.size();
 		}
-		plans.push_back(none);  // "nothing to do" for the blocks that have just been rebuilt
+		for (auto &pl : plans)
+			if (pl->missing.size() > (size_t)gec::RMAX) {
+				std::shared_ptr<Plan> none(new Plan(*pl));
+				none->missing.clear();
+				pl = none;
+			}
 	}
 	return launch_apply_pat(c, static_cast<uint8_t *>(d_stripes), stride, S, nblocks, plans, pat, stream);
 }
