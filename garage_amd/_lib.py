@@ -50,10 +50,12 @@ SYMBOLS = [
     "gec_group_unique_id", "gec_group_create", "gec_group_create_with_transport", "gec_group_destroy",
     "gec_group_rank", "gec_group_size", "gec_group_slots", "gec_group_allgather_decode",
     "gec_group_create_with_transport2", "gec_group_alltoall_decode", "gec_group_bytes_exchanged",
+    "gec_group_peer_decode", "gec_ipc_export", "gec_ipc_open", "gec_ipc_close",
     "gec_launch_geometry",
     "gec_encode_hash_batch_dev", "gec_decode_verify_batch", "gec_shardsum_batch", "gec_shardsum_batch_dev", "gec_host_alloc", "gec_host_free", "gec_host_register", "gec_host_unregister", "gec_host_is_pinned",
 ]
 GEC_GROUP_ID_BYTES = 128
+GEC_IPC_HANDLE_BYTES = 64
 # int (*gec_allgather_fn)(void *ctx, const void *d_send, void *d_recv, size_t bytes, void *hip_stream)
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
@@ -164,6 +166,10 @@ def _load() -> ctypes.CDLL:
     lib.gec_group_create_with_transport2.argtypes = [vp, ci, ci, vp, vp, vp, pp]
     lib.gec_group_alltoall_decode.argtypes = [vp, sz, vp, sz, u8p, ci, ci, vp, vp]
     lib.gec_group_bytes_exchanged.argtypes = [vp]
+    lib.gec_group_peer_decode.argtypes = [vp, sz, pp, sz, u8p, ci, ci, vp, vp]
+    lib.gec_ipc_export.argtypes = [vp, ctypes.c_char_p]
+    lib.gec_ipc_open.argtypes = [ctypes.c_char_p, ci, pp]
+    lib.gec_ipc_close.argtypes = [vp]
     lib.gec_group_bytes_exchanged.restype = ctypes.c_uint64
     return lib
 

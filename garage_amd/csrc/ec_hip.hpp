@@ -351,6 +351,10 @@ struct SumOut {
 int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_t *out, size_t out_stride, uint32_t *bad,
 		 size_t byte_off, size_t byte_len, size_t nblocks, const size_t *in_base_off, const size_t *out_base_off, int nout,
 		 const uint8_t *coef /* nout x k */, int mode, hipStream_t stream, const SumOut *sum = nullptr);
+// The pointer-table kernel over tables in DEVICE memory (inputs may live on peer devices): see ec_hip_launch.hip.
+size_t ptrs_dev_scratch_bytes(size_t nblocks, size_t k, int nout);
+int launch_apply_ptrs_dev(const gec_codec *c, uint8_t *d_scratch, size_t nblocks, const uint8_t *const *in, uint8_t *const *out, int nout,
+			  uint32_t cols, const uint8_t *coef /* nout x k */, hipStream_t stream);
 // One launch, a decode plan per block: block b is rebuilt in place with plans[pat_of_block[b]] (<= 8 missing shards each).
 int launch_apply_pat(const gec_codec *c, uint8_t *d_base, size_t stride, size_t S, size_t nblocks,
 		     const std::vector<std::shared_ptr<const Plan>> &plans, const std::vector<uint16_t> &pat_of_block, hipStream_t stream);

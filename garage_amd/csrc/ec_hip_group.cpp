@@ -87,6 +87,10 @@ struct gec_group {
 	// scratch for the exchange of the rebuilt ranges (step 3)
 	uint8_t *d_send = nullptr, *d_recv = nullptr;
 	size_t send_cap = 0, recv_cap = 0;
+	// peer-pointer exchange: pointer tables of the one decode launch, and the tokens of its barriers
+	uint8_t *d_tab = nullptr, *d_tok = nullptr;
+	size_t tab_cap = 0;
+	std::vector<int> peer_enabled;  // devices hipDeviceEnablePeerAccess has been called for
 };
 
 namespace {
@@ -313,6 +317,84 @@ int host_alltoall_decode(gec_group *g, size_t nobjects, const uint8_t *local, si
 	return GEC_OK;
 }
 
+// gec_group_peer_decode on host buffers (CPU codec): the "peers' slot buffers" are plain pointers of this address space
+// (ranks that are threads of one process, or shared memory the caller mapped)
+int host_peer_decode(gec_group *g, size_t nobjects, const uint8_t *const *peer_slots, size_t S, const uint8_t *present, int data_only,
+		     int complete, uint8_t *rebuilt)
+{
+	const gec_codec *c = g->c;
+	const size_t k = c->k, n = (size_t)c->k + c->m, N = (size_t)g->nranks, slots = gec_group_slots(g);
+	for (size_t q = 0; q < N; ++q) {
+		int rc = check_host_layout(peer_slots[q], S);
+		if (rc)
+			return rc;
+	}
+	std::shared_ptr<const Plan> plan;
+	int rc = get_plan(c, present, data_only != 0, plan);
+	if (rc)
+		return rc;
+	g->bytes_exchanged = 0;
+	const size_t nmiss = plan->missing.size();
+	if (nmiss == 0)
+		return GEC_OK;
+	const size_t cols = S / 16;
+	size_t max_cols = 0;
+	for (size_t r = 0; r < N; ++r)
+		max_cols = std::max(max_cols, range_lo(cols, r + 1, N) - range_lo(cols, r, N));
+	const size_t my_lo = range_lo(cols, g->rank, N), my_cols = range_lo(cols, g->rank + 1, N) - my_lo;
+	const size_t packed_bytes = nmiss * nobjects * max_cols * 16;
+	size_t tok_cap = g->tab_cap;
+	rc = host_scratch(&g->d_send, &g->send_cap, packed_bytes);
+	if (!rc)
+		rc = host_scratch(&g->d_recv, &g->recv_cap, packed_bytes * N);
+	if (!rc)
+		rc = host_scratch(&g->d_tok, &tok_cap, 16 * (N + 1));
+	if (rc)
+		return rc;
+	g->tab_cap = tok_cap;
+	// every rank's slot buffer is final: the barrier is a 16-byte all-gather through the group's transport
+	rc = g->all_gather(g->ctx, g->d_tok, g->d_tok + 16, 16, nullptr);
+	if (rc)
+		return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+	if (my_cols) {
+		std::vector<const uint8_t *> sp(nobjects * n, nullptr);
+		std::vector<uint8_t *> op(nobjects * n, nullptr);
+		for (size_t o = 0; o < nobjects; ++o) {
+			for (size_t t = 0; t < k; ++t) {
+				const size_t v = (size_t)plan->valid[t];
+				sp[o * n + v] = peer_slots[v % N] + o * slots * S + (v / N) * S + my_lo * 16;
+				if (v % N != (size_t)g->rank)
+					g->bytes_exchanged += my_cols * 16;
+			}
+			for (size_t i = 0; i < nmiss; ++i)
+				op[o * n + plan->missing[i]] = g->d_send + (i * nobjects + o) * max_cols * 16;
+		}
+		rc = c->be->reconstruct_batch(nobjects, sp.data(), op.data(), my_cols * 16, data_only, nullptr, nullptr);
+		if (rc)
+			return rc;
+	}
+	auto unpack = [&](const uint8_t *packed, size_t r) {
+		const size_t rlo = range_lo(cols, r, N), rn = range_lo(cols, r + 1, N) - rlo;
+		for (size_t i = 0; i < nmiss; ++i)
+			for (size_t o = 0; o < nobjects; ++o)
+				std::memcpy(rebuilt + (i * nobjects + o) * S + rlo * 16, packed + (i * nobjects + o) * max_cols * 16, rn * 16);
+	};
+	if (complete && N > 1) {
+		g->bytes_exchanged += packed_bytes * (N - 1);
+		rc = g->all_gather(g->ctx, g->d_send, g->d_recv, packed_bytes, nullptr);  // (also: everybody is done reading)
+		if (rc)
+			return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+		for (size_t r = 0; r < N; ++r)
+			unpack(g->d_recv + r * packed_bytes, r);
+	} else {
+		unpack(g->d_send, g->rank);
+		rc = g->all_gather(g->ctx, g->d_tok, g->d_tok + 16, 16, nullptr);  // nobody's slot buffer changes while a peer still reads it
+		if (rc)
+			return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+	}
+	return GEC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -429,6 +511,7 @@ void gec_group_destroy(gec_group *g)
 		std::free(g->d_recv);
 		std::free(g->d_a2a_send);
 		std::free(g->d_a2a_recv);
+		std::free(g->d_tok);
 		delete g;
 		return;
 	}
@@ -442,6 +525,10 @@ void gec_group_destroy(gec_group *g)
 			(void)hipFree(g->d_a2a_send);
 		if (g->d_a2a_recv)
 			(void)hipFree(g->d_a2a_recv);
+		if (g->d_tab)
+			(void)hipFree(g->d_tab);
+		if (g->d_tok)
+			(void)hipFree(g->d_tok);
 		if (g->comm)
 			(void)rccl().CommDestroy(g->comm);
 	}
@@ -686,6 +773,177 @@ try {
 		ua.packed = g->d_send;
 		ua.first_rank = (uint32_t)g->rank;
 		ua.nranks_in = 1;
+	}
+	return launch_rebuilt_unpack(ua, (size_t)ua.nranks_in * nmiss * nobjects * max_cols, stream);
+}
+GEC_CATCH
+
+// ---------------------------------------------------------------- peer-pointer exchange
+int gec_ipc_export(const void *d_ptr, uint8_t handle[GEC_IPC_HANDLE_BYTES])
+try {
+	static_assert(sizeof(hipIpcMemHandle_t) == GEC_IPC_HANDLE_BYTES, "GEC_IPC_HANDLE_BYTES must equal sizeof(hipIpcMemHandle_t)");
+	if (!d_ptr || !handle)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	hipIpcMemHandle_t h;
+	HIP_TRY(hipIpcGetMemHandle(&h, const_cast<void *>(d_ptr)));
+	std::memcpy(handle, &h, sizeof(h));
+	return GEC_OK;
+}
+GEC_CATCH
+
+int gec_ipc_open(const uint8_t handle[GEC_IPC_HANDLE_BYTES], int device, void **d_ptr)
+try {
+	if (!handle || !d_ptr)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	*d_ptr = nullptr;
+	DeviceGuard dg(device);
+	if (!dg.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	hipIpcMemHandle_t h;
+	std::memcpy(&h, handle, sizeof(h));
+	HIP_TRY(hipIpcOpenMemHandle(d_ptr, h, hipIpcMemLazyEnablePeerAccess));
+	return GEC_OK;
+}
+GEC_CATCH
+
+int gec_ipc_close(void *d_ptr)
+try {
+	if (!d_ptr)
+		return GEC_OK;
+	HIP_TRY(hipIpcCloseMemHandle(d_ptr));
+	return GEC_OK;
+}
+GEC_CATCH
+
+int gec_group_peer_decode(gec_group *g, size_t nobjects, const void *const *d_peer_slots, size_t S, const uint8_t *present,
+			  int data_only, int complete, void *d_rebuilt, void *hip_stream)
+try {
+	if (!g || !present || !d_rebuilt || !d_peer_slots)
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	if (nobjects == 0)
+		return GEC_OK;
+	const gec_codec *c = g->c;
+	const size_t k = c->k, N = (size_t)g->nranks, slots = gec_group_slots(g);
+	for (size_t q = 0; q < N; ++q)
+		if (!d_peer_slots[q])
+			return fail(GEC_E_INVALID_ARG, "NULL peer slot buffer");
+	if (c->backend != GEC_BACKEND_HIP)
+		return host_peer_decode(g, nobjects, reinterpret_cast<const uint8_t *const *>(d_peer_slots), S, present, data_only, complete,
+					static_cast<uint8_t *>(d_rebuilt));
+	for (size_t q = 0; q < N; ++q) {
+		int rc = check_dev_layout(d_peer_slots[q], slots * S, S, slots * S);
+		if (rc)
+			return rc;
+	}
+	if (reinterpret_cast<uintptr_t>(d_rebuilt) % 16)
+		return fail(GEC_E_INVALID_ARG, "d_rebuilt must be 16-byte aligned");
+	if (nobjects > 0xffffffffull || S / 16 > 0xffffffffull)
+		return fail(GEC_E_INVALID_ARG, "batch too large for one call");
+	hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+	DeviceGuard dg(c->device);
+	if (!dg.ok)
+		return fail(GEC_E_DEVICE, "hipSetDevice failed");
+	std::shared_ptr<const Plan> plan;  // before anything is exchanged: a bad pattern fails on every rank alike, no rank hangs
+	int rc = get_plan(c, present, data_only != 0, plan);
+	if (rc)
+		return rc;
+	g->bytes_exchanged = 0;
+	const size_t nmiss = plan->missing.size();
+	if (nmiss == 0)
+		return GEC_OK;
+	// a peer's buffer that lives on another device of this process: make it addressable from the codec's device
+	// (pointers opened with gec_ipc_open already are)
+	for (size_t q = 0; q < N; ++q) {
+		hipPointerAttribute_t at;
+		if (hipPointerGetAttributes(&at, d_peer_slots[q]) != hipSuccess) {
+			(void)hipGetLastError();
+			continue;
+		}
+		const int dev = at.device;
+		if (dev == c->device || std::find(g->peer_enabled.begin(), g->peer_enabled.end(), dev) != g->peer_enabled.end())
+			continue;
+		const hipError_t e = hipDeviceEnablePeerAccess(dev, 0);
+		if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+			return fail(GEC_E_DEVICE, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+		(void)hipGetLastError();
+		g->peer_enabled.push_back(dev);
+	}
+	const size_t cols = S / 16;
+	auto range_lo = [&](size_t r) { return cols * r / N; };
+	size_t max_cols = 0;
+	for (size_t r = 0; r < N; ++r)
+		max_cols = std::max(max_cols, range_lo(r + 1) - range_lo(r));
+	const size_t my_lo = range_lo(g->rank), my_cols = range_lo(g->rank + 1) - my_lo;
+	const size_t packed_bytes = nmiss * nobjects * max_cols * 16;
+	const size_t tab_bytes = ptrs_dev_scratch_bytes(nobjects, k, (int)nmiss);
+	if (packed_bytes > g->send_cap || packed_bytes * N > g->recv_cap || tab_bytes > g->tab_cap || !g->d_tok) {
+		HIP_TRY(hipStreamSynchronize(stream));  // earlier calls may still use the old buffers
+		for (uint8_t **p : {&g->d_send, &g->d_recv, &g->d_tab, &g->d_tok})
+			if (*p) {
+				(void)hipFree(*p);
+				*p = nullptr;
+			}
+		g->send_cap = g->recv_cap = g->tab_cap = 0;
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_send), packed_bytes));
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_recv), packed_bytes * N));
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_tab), tab_bytes));
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_tok), 16 * (N + 1)));
+		HIP_TRY(hipMemsetAsync(g->d_send, 0, packed_bytes, stream));  // pad columns: defined bytes on the wire
+		HIP_TRY(hipMemsetAsync(g->d_tok, 0, 16 * (N + 1), stream));
+		g->send_cap = packed_bytes;
+		g->recv_cap = packed_bytes * N;
+		g->tab_cap = tab_bytes;
+	}
+	// (0) every rank's slot buffer is final: a 16-byte all-gather through the group's transport is the barrier -- stream-ordered
+	//     behind whatever filled the slots on each rank, ahead of the kernel that reads them here
+	rc = g->all_gather(g->ctx, g->d_tok, g->d_tok + 16, 16, hip_stream);
+	if (rc)
+		return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+	// (1) ONE launch: my byte range of the k shards the decode reads -- wherever they live -- in, my range of every missing shard
+	//     out.  No pack, no staging buffer, 1/N of the all-gather's bytes over each link.
+	if (my_cols) {
+		std::vector<const uint8_t *> in(nobjects * k);
+		std::vector<uint8_t *> out(nobjects * nmiss);
+		for (size_t o = 0; o < nobjects; ++o) {
+			for (size_t t = 0; t < k; ++t) {
+				const size_t v = (size_t)plan->valid[t];
+				in[o * k + t] = static_cast<const uint8_t *>(d_peer_slots[v % N]) + o * slots * S + (v / N) * S + my_lo * 16;
+				if (v % N != (size_t)g->rank)
+					g->bytes_exchanged += my_cols * 16;
+			}
+			for (size_t i = 0; i < nmiss; ++i)
+				out[o * nmiss + i] = g->d_send + (i * nobjects + o) * max_cols * 16;
+		}
+		rc = launch_apply_ptrs_dev(c, g->d_tab, nobjects, in.data(), out.data(), (int)nmiss, (uint32_t)my_cols, plan->rows.v.data(), stream);
+		if (rc)
+			return rc;
+	}
+	// (2) the rebuilt ranges: mine only, or everybody's after a (small) all-gather -- which is also the "done reading" barrier
+	gec::RebuiltArgs ua;
+	std::memset(&ua, 0, sizeof(ua));
+	ua.rebuilt = static_cast<uint8_t *>(d_rebuilt);
+	ua.nobj = (uint32_t)nobjects;
+	ua.nmiss = (uint32_t)nmiss;
+	ua.cols = (uint32_t)cols;
+	ua.max_cols = (uint32_t)max_cols;
+	ua.world = (uint32_t)N;
+	if (complete && N > 1) {
+		g->bytes_exchanged += packed_bytes * (N - 1);
+		rc = g->all_gather(g->ctx, g->d_send, g->d_recv, packed_bytes, hip_stream);
+		if (rc)
+			return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+		ua.packed = g->d_recv;
+		ua.first_rank = 0;
+		ua.nranks_in = (uint32_t)N;
+	} else {
+		ua.packed = g->d_send;
+		ua.first_rank = (uint32_t)g->rank;
+		ua.nranks_in = 1;
+		if (N > 1) {
+			rc = g->all_gather(g->ctx, g->d_tok, g->d_tok + 16, 16, hip_stream);  // nobody's slots change while a peer still reads them
+			if (rc)
+				return rc > 0 ? fail(GEC_E_DEVICE, "all_gather transport failed") : rc;
+		}
 	}
 	return launch_rebuilt_unpack(ua, (size_t)ua.nranks_in * nmiss * nobjects * max_cols, stream);
 }

@@ -662,6 +662,70 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 	return GEC_OK;
 }
 
+// The pointer-table kernel over DEVICE-resident tables (gec_group_peer_decode: the inputs are byte ranges of shards that live in
+// OTHER devices' memory, read over xGMI): in[b*k + t] / out[b*nout + r] are host arrays of device-addressable pointers, every
+// input has `cols` 16-byte columns; they are laid down in d_scratch (>= ptrs_dev_scratch_bytes) behind whatever `stream` holds.
+size_t ptrs_dev_scratch_bytes(size_t nblocks, size_t k, int nout) { return nblocks * k * 8 + ((nblocks * k * 4 + 15) & ~(size_t)15) + nblocks * (size_t)nout * 8; }
+
+int launch_apply_ptrs_dev(const gec_codec *c, uint8_t *d_scratch, size_t nblocks, const uint8_t *const *in, uint8_t *const *out, int nout,
+			  uint32_t cols, const uint8_t *coef /* nout x k */, hipStream_t stream)
+{
+	const size_t k = c->k;
+	const HipBackend &hb = hip_of(c);
+	if (nblocks == 0 || nout == 0 || cols == 0)
+		return GEC_OK;
+	if (k > (size_t)gec::PTR_KMAX)
+		return fail(GEC_E_INVALID_ARG, "shape not supported by the pointer-table kernel (k > 128)");
+	const unsigned gx = (cols + 255) / 256;
+	if ((uint64_t)gx * nblocks > 0xffffffffull)
+		return fail(GEC_E_INVALID_ARG, "too many tiles for one launch");
+	const size_t in_bytes = nblocks * k * 8, valid_bytes = (nblocks * k * 4 + 15) & ~(size_t)15, out_bytes = nblocks * (size_t)nout * 8;
+	std::vector<uint8_t> host(in_bytes + valid_bytes + out_bytes);
+	std::memcpy(host.data(), in, in_bytes);
+	uint32_t *v = reinterpret_cast<uint32_t *>(host.data() + in_bytes);
+	for (size_t i = 0; i < nblocks * k; ++i)
+		v[i] = cols * 16u;
+	// outputs: row groups of at most RMAX rows, each group's table [nblocks][rows] contiguous
+	uint8_t **o = reinterpret_cast<uint8_t **>(host.data() + in_bytes + valid_bytes);
+	size_t done = 0;
+	for (int r0 = 0; r0 < nout; r0 += gec::RMAX) {
+		const int rows = std::min(gec::RMAX, nout - r0);
+		for (size_t b = 0; b < nblocks; ++b)
+			for (int r = 0; r < rows; ++r)
+				o[done + b * rows + r] = out[b * nout + r0 + r];
+		done += nblocks * rows;
+	}
+	HIP_TRY(hipMemcpyAsync(d_scratch, host.data(), host.size(), hipMemcpyHostToDevice, stream));  // (pageable source: staged before the call returns)
+	gec::PtrApplyArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.in = reinterpret_cast<const uint8_t *const *>(d_scratch);
+	a.in_valid = reinterpret_cast<const uint32_t *>(d_scratch + in_bytes);
+	a.cols = cols;
+	a.k = (uint32_t)k;
+	a.tiles_x = gx;
+	a.tiles_total = (uint32_t)(gx * nblocks);
+	a.link_role = gec::LINK_NONE;
+	done = 0;
+	for (int r0 = 0; r0 < nout; r0 += gec::RMAX) {
+		const int rows = std::min(gec::RMAX, nout - r0);
+		a.rows = (uint32_t)rows;
+		for (int r = 0; r < gec::RMAX; ++r)
+			for (size_t t = 0; t < k; ++t)
+				a.coef[t][r] = r < rows ? coef[(size_t)(r0 + r) * k + t] : 0;
+		a.out = reinterpret_cast<uint8_t *const *>(d_scratch + in_bytes + valid_bytes) + done;
+		done += nblocks * rows;
+		const int mw = rows <= 4 ? 1 : 2;
+		const size_t lds = k * 32 * 4 * mw + 768 + k * gec::RMAX;
+		const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(gec::RESIDENT_WGS, (160u << 10) / lds));
+		const unsigned grid = (unsigned)std::min<uint64_t>(a.tiles_total, (uint64_t)hb.num_cu * per_cu);
+		using Kern = void (*)(const gec::PtrApplyArgs, const gec::LogExp *);
+		const Kern kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, false> : (Kern)gec::gf_apply_ptrs<2, 5, false>;
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, hb.d_logexp);
+		HIP_TRY(hipGetLastError());
+	}
+	return GEC_OK;
+}
+
 // ---- the fused small-trip kernel (fused.hpp)
 namespace {
 size_t fused_lds_bytes(size_t k, size_t nh, int mw)

@@ -118,6 +118,33 @@ class Group:
               "gec_group_alltoall_decode")
         return out
 
+    def peer_decode(self, local_slots, peer_ptrs: Sequence[int], present: Sequence[int], data_only: bool = False, complete: bool = True,
+                    out=None):
+        """Peer-pointer exchange (gec_group_peer_decode): ``peer_ptrs[q]`` is rank q's slot buffer as an address this process can
+        use on the codec's device (``tensor.data_ptr()`` of a thread-rank's buffer, or what ``ipc_open`` returned; entry [rank] is
+        overwritten with ``local_slots``).  Returns the rebuilt shards (nmiss, nobjects, S) like ``alltoall_decode``."""
+        import torch
+
+        on_host = self.codec.backend == "cpu"
+        if not (isinstance(local_slots, torch.Tensor) and local_slots.is_cuda != on_host and local_slots.dtype == torch.uint8
+                and local_slots.dim() == 3 and local_slots.shape[1] == self.slots and local_slots.is_contiguous()):
+            raise TypeError(f"local_slots must be a contiguous uint8 {'CPU' if on_host else 'CUDA'} tensor (nobjects, {self.slots}, S)")
+        nobj, slots, S = local_slots.shape
+        pres = np.ascontiguousarray(np.asarray(present, dtype=np.uint8))
+        if pres.size != self.codec.n or len(peer_ptrs) != self.nranks:
+            raise GecError(_lib.GEC_E_INVALID_INDEX, "present / peer_ptrs", "need k+m flags and one pointer per rank")
+        ptrs = list(peer_ptrs)
+        ptrs[self.rank] = local_slots.data_ptr()
+        arr = (ctypes.c_void_p * self.nranks)(*ptrs)
+        nmiss = sum(1 for j in range(self.codec.n) if not pres[j] and not (data_only and j >= self.codec.k))
+        if out is None:
+            out = torch.zeros((nmiss, nobj, S), dtype=torch.uint8, device=local_slots.device)
+        if nmiss == 0:
+            return out
+        check(lib.gec_group_peer_decode(self._h, nobj, arr, S, _u8p(pres), int(bool(data_only)), int(bool(complete)), out.data_ptr(),
+                                        None if on_host else _stream_handle(self.codec.device)), "gec_group_peer_decode")
+        return out
+
     def bytes_exchanged(self) -> int:
         """bytes this rank received from other ranks in the last decode call"""
         return int(lib.gec_group_bytes_exchanged(self._h))
@@ -132,3 +159,21 @@ class Group:
             self.close()
         except Exception:  # pragma: no cover - interpreter shutdown
             pass
+
+
+def ipc_export(tensor) -> bytes:
+    """gec_ipc_export: a 64-byte handle another process passes to ipc_open to address this CUDA tensor's memory."""
+    buf = ctypes.create_string_buffer(_lib.GEC_IPC_HANDLE_BYTES)
+    check(lib.gec_ipc_export(tensor.data_ptr(), buf), "gec_ipc_export")
+    return buf.raw
+
+
+def ipc_open(handle: bytes, device: int = 0) -> int:
+    """gec_ipc_open: the device address (int) of the memory another process exported; release with ipc_close."""
+    p = ctypes.c_void_p()
+    check(lib.gec_ipc_open(handle, device, ctypes.byref(p)), "gec_ipc_open")
+    return int(p.value)
+
+
+def ipc_close(ptr: int) -> None:
+    check(lib.gec_ipc_close(ptr), "gec_ipc_close")

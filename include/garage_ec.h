@@ -417,8 +417,28 @@ int gec_group_alltoall_decode(gec_group *g, size_t nobjects,
 			      const void *d_local_slots, size_t S,
 			      const uint8_t *present, int data_only, int complete,
 			      void *d_rebuilt, void *hip_stream);
-/* bytes this rank received from other ranks during the last *_decode call on the group (both exchanges) */
+/* bytes this rank received from other ranks during the last *_decode call on the group (every exchange; for the peer form:
+ * bytes its kernel read out of other ranks' memory, plus the rebuilt ranges) */
 uint64_t gec_group_bytes_exchanged(const gec_group *g);
+
+/* PEER-POINTER variant: no exchange buffer at all.  On MI355X every GPU addresses every other GPU's memory over the xGMI
+ * full mesh, and the decode kernel already takes its inputs as pointer tables -- so each rank builds ONE table whose inputs
+ * are ITS byte range of the k shards the decode reads, WHEREVER they live (slot v/N of rank v%N's slot buffer), and rebuilds
+ * its range of every missing shard in one launch: no pack, no unpack, no RCCL staging, the same 1/N of the all-gather's
+ * bytes per link as the all-to-all form.  d_peer_slots[q] = rank q's slot buffer [nobjects][slots][S] as an address THIS
+ * process can use on the codec's device ([rank] = its own): a plain pointer when the ranks are threads of one process (peer
+ * access is enabled here on first use), or what gec_ipc_open returned for the handle rank q made with gec_ipc_export
+ * (hipIpcGetMemHandle / hipIpcOpenMemHandle) when they are processes.  The group's transport carries only two 16-byte
+ * barriers (every slot buffer is final before a peer reads it; nobody's changes while a peer still does) and -- with
+ * complete != 0 -- the rebuilt ranges, exactly as in the all-to-all form, whose result layout this call shares:
+ * d_rebuilt [nmiss][nobjects][S].  Over a GEC_BACKEND_CPU codec the same call runs on host pointers. */
+#define GEC_IPC_HANDLE_BYTES 64 /* sizeof(hipIpcMemHandle_t) */
+int gec_ipc_export(const void *d_ptr, uint8_t handle[GEC_IPC_HANDLE_BYTES]);
+int gec_ipc_open(const uint8_t handle[GEC_IPC_HANDLE_BYTES], int device, void **d_ptr);
+int gec_ipc_close(void *d_ptr);
+int gec_group_peer_decode(gec_group *g, size_t nobjects, const void *const *d_peer_slots, size_t S,
+			  const uint8_t *present, int data_only, int complete,
+			  void *d_rebuilt, void *hip_stream);
 
 /* ------------------------------------------------------- blake2sum on the GPU
  * SURVEY.md section 8 row f4.  Garage's content hash `blake2sum` = blake2b-512

@@ -313,3 +313,99 @@ def test_group_rccl_world1_alltoall(coracle):
     for i, j in enumerate(lost):
         assert np.array_equal(out[i].cpu().numpy(), full[:, j])
     grp.close()
+
+
+# ------------------------------------------------------------------ the peer-pointer exchange (gec_group_peer_decode)
+from tests.test_group_peer import CASES as PEER_CASES, check as peer_check, run_thread_ranks  # noqa: E402
+
+
+@pytest.mark.parametrize("k,m,world,S,nobj,lost,data_only,complete", PEER_CASES + [(20, 8, 8, 209728, 4, (0, 1, 5, 9, 13, 19, 21, 27), False, True)])
+def test_peer_decode_logical_ranks_on_one_device(loopback, k, m, world, S, nobj, lost, data_only, complete):
+    """N logical ranks as threads on the one visible device: every rank's decode launch reads its byte range of the survivors
+    straight out of the OTHER ranks' slot buffers (all pointers local here: the table, the ranges and the second step are what
+    is under test), the loopback transport carries the barriers and the rebuilt ranges.  Against the oracle's stripes; the last
+    case is config 5's full shard length."""
+    handle = loopback.lb_create(world)
+    fn = loopback.lb_all_gather_ptr()
+
+    def transport(r):
+        return (fn, None, loopback.lb_rank_ctx(handle, r))
+
+    outs, full, layout = run_thread_ranks(lambda: g.ReedSolomon(k, m), k, m, world, S, nobj, lost, data_only, complete,
+                                          to_device=lambda t: t.to(DEV), transport_factory=transport)
+    loopback.lb_destroy(handle)
+    peer_check(outs, full, layout, k, S, lost, data_only, complete)
+
+
+def test_peer_decode_two_processes_through_ipc_handles(tmp_path):
+    """Two PROCESSES on the one device: each exports its slot buffer (gec_ipc_export = hipIpcGetMemHandle), opens the other's
+    (gec_ipc_open), and decodes out of it; the barriers and rebuilt ranges go over gloo through a host-staging transport.
+    What the Rust host does across the ranks of a node."""
+    code = r'''
+import ctypes, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import garage_amd as g
+from garage_amd import _lib
+from garage_amd.group import ipc_export, ipc_open, ipc_close
+from garage_amd.striped import StripeLayout, scatter_stripes
+from oracle import rs_oracle as O
+rank, world = int(os.environ["RANK"]), 2
+dist.init_process_group("gloo", rank=rank, world_size=world)
+k, m, S, nobj = 10, 4, 4160, 6
+lost = (0, 3, 7, 11)
+data = O.splitmix64_bytes(321, nobj * k * S).reshape(nobj, k, S)
+full = np.concatenate([data, np.stack([O.encode(k, m, d) for d in data])], axis=1)
+broken = full.copy(); broken[:, list(lost)] = 0xEE
+layout = StripeLayout(k, m, world)
+local = scatter_stripes(torch.from_numpy(broken), layout, rank).contiguous().to("cuda:0")
+torch.cuda.synchronize()
+hip = ctypes.CDLL("libamdhip64.so")
+hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+@_lib.ALLGATHER_FN
+def all_gather(_ctx, send, recv, nbytes, stream):
+    hip.hipStreamSynchronize(stream)
+    mine = np.empty(nbytes, dtype=np.uint8)
+    hip.hipMemcpy(mine.ctypes.data, send, nbytes, 2)
+    got = np.empty(nbytes * world, dtype=np.uint8)
+    dist.all_gather(list(torch.from_numpy(got).chunk(world)), torch.from_numpy(mine))
+    hip.hipMemcpy(recv, got.ctypes.data, got.size, 1)
+    return 0
+handles = [None, None]
+dist.all_gather_object(handles, ipc_export(local))
+peer = ipc_open(handles[1 - rank], 0)
+ptrs = [0, 0]
+ptrs[1 - rank] = peer
+rs = g.ReedSolomon(k, m)
+grp = g.Group(rs, rank, world, transport=(all_gather, None, None))
+reb = grp.peer_decode(local, ptrs, [j not in lost for j in range(k + m)])
+torch.cuda.synchronize()
+got = reb.cpu().numpy()
+ok = all(np.array_equal(got[i], full[:, j]) for i, j in enumerate(sorted(lost)))
+moved = grp.bytes_exchanged()
+grp.close()
+dist.barrier()
+ipc_close(peer)
+flags = [None, None]
+dist.all_gather_object(flags, (bool(ok), int(moved)))
+if rank == 0:
+    print("RESULT", flags)
+dist.destroy_process_group()
+''' % os.path.dirname(HERE)
+    import socket
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("RESULT")][0]
+    flags = eval(line[len("RESULT "):])
+    assert all(ok for ok, _ in flags), flags
+    # each rank read its half of the 5 valid shards the other rank holds, then received the other's rebuilt ranges
+    assert all(moved > 0 for _, moved in flags), flags

@@ -26,7 +26,7 @@ extern "C" {
 #define STUB(name) int name() { return -100; }
 STUB(gec_get_kernel_variant) STUB(gec_group_allgather_decode) STUB(gec_group_alltoall_decode) STUB(gec_group_bytes_exchanged)
 STUB(gec_group_create) STUB(gec_group_create_with_transport) STUB(gec_group_create_with_transport2) STUB(gec_group_destroy)
-STUB(gec_group_rank) STUB(gec_group_size) STUB(gec_group_slots) STUB(gec_group_unique_id) STUB(gec_launch_geometry) STUB(gec_set_kernel_variant)
+STUB(gec_group_peer_decode) STUB(gec_ipc_export) STUB(gec_ipc_open) STUB(gec_ipc_close) STUB(gec_group_rank) STUB(gec_group_size) STUB(gec_group_slots) STUB(gec_group_unique_id) STUB(gec_launch_geometry) STUB(gec_set_kernel_variant)
 }
 STUBS
 SAN="${SAN:-thread}"
