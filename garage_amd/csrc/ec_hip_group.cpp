@@ -779,14 +779,26 @@ try {
 GEC_CATCH
 
 // ---------------------------------------------------------------- peer-pointer exchange
+// The handle is hipIpcMemHandle_t of the ALLOCATION d_ptr lies in, followed by d_ptr's offset inside it: a tensor of a caching
+// allocator (torch's, a Rust arena) rarely starts its allocation, and hipIpcOpenMemHandle maps allocations.
+namespace {
+std::mutex g_ipc_mu;
+std::unordered_map<void *, void *> g_ipc_base;  // what gec_ipc_open returned -> the mapping's base (what must be closed)
+}  // namespace
+
 int gec_ipc_export(const void *d_ptr, uint8_t handle[GEC_IPC_HANDLE_BYTES])
 try {
-	static_assert(sizeof(hipIpcMemHandle_t) == GEC_IPC_HANDLE_BYTES, "GEC_IPC_HANDLE_BYTES must equal sizeof(hipIpcMemHandle_t)");
+	static_assert(sizeof(hipIpcMemHandle_t) + 8 == GEC_IPC_HANDLE_BYTES, "GEC_IPC_HANDLE_BYTES must equal sizeof(hipIpcMemHandle_t) + 8");
 	if (!d_ptr || !handle)
 		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	hipDeviceptr_t base = nullptr;
+	size_t size = 0;
+	HIP_TRY(hipMemGetAddressRange(&base, &size, const_cast<void *>(d_ptr)));
 	hipIpcMemHandle_t h;
-	HIP_TRY(hipIpcGetMemHandle(&h, const_cast<void *>(d_ptr)));
+	HIP_TRY(hipIpcGetMemHandle(&h, base));
+	const uint64_t off = (uint64_t)(static_cast<const uint8_t *>(d_ptr) - static_cast<const uint8_t *>(base));
 	std::memcpy(handle, &h, sizeof(h));
+	std::memcpy(handle + sizeof(h), &off, 8);
 	return GEC_OK;
 }
 GEC_CATCH
@@ -800,8 +812,14 @@ try {
 	if (!dg.ok)
 		return fail(GEC_E_DEVICE, "hipSetDevice failed");
 	hipIpcMemHandle_t h;
+	uint64_t off = 0;
 	std::memcpy(&h, handle, sizeof(h));
-	HIP_TRY(hipIpcOpenMemHandle(d_ptr, h, hipIpcMemLazyEnablePeerAccess));
+	std::memcpy(&off, handle + sizeof(h), 8);
+	void *base = nullptr;
+	HIP_TRY(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+	*d_ptr = static_cast<uint8_t *>(base) + off;
+	std::lock_guard<std::mutex> lk(g_ipc_mu);
+	g_ipc_base[*d_ptr] = base;
 	return GEC_OK;
 }
 GEC_CATCH
@@ -810,7 +828,16 @@ int gec_ipc_close(void *d_ptr)
 try {
 	if (!d_ptr)
 		return GEC_OK;
-	HIP_TRY(hipIpcCloseMemHandle(d_ptr));
+	void *base = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(g_ipc_mu);
+		auto it = g_ipc_base.find(d_ptr);
+		if (it == g_ipc_base.end())
+			return fail(GEC_E_INVALID_ARG, "not a pointer gec_ipc_open returned");
+		base = it->second;
+		g_ipc_base.erase(it);
+	}
+	HIP_TRY(hipIpcCloseMemHandle(base));
 	return GEC_OK;
 }
 GEC_CATCH

@@ -162,7 +162,7 @@ class Group:
 
 
 def ipc_export(tensor) -> bytes:
-    """gec_ipc_export: a 64-byte handle another process passes to ipc_open to address this CUDA tensor's memory."""
+    """gec_ipc_export: a 72-byte handle another process passes to ipc_open to address this CUDA tensor's memory."""
     buf = ctypes.create_string_buffer(_lib.GEC_IPC_HANDLE_BYTES)
     check(lib.gec_ipc_export(tensor.data_ptr(), buf), "gec_ipc_export")
     return buf.raw

@@ -432,7 +432,7 @@ uint64_t gec_group_bytes_exchanged(const gec_group *g);
  * barriers (every slot buffer is final before a peer reads it; nobody's changes while a peer still does) and -- with
  * complete != 0 -- the rebuilt ranges, exactly as in the all-to-all form, whose result layout this call shares:
  * d_rebuilt [nmiss][nobjects][S].  Over a GEC_BACKEND_CPU codec the same call runs on host pointers. */
-#define GEC_IPC_HANDLE_BYTES 64 /* sizeof(hipIpcMemHandle_t) */
+#define GEC_IPC_HANDLE_BYTES 72 /* hipIpcMemHandle_t of the allocation + the pointer's offset inside it */
 int gec_ipc_export(const void *d_ptr, uint8_t handle[GEC_IPC_HANDLE_BYTES]);
 int gec_ipc_open(const uint8_t handle[GEC_IPC_HANDLE_BYTES], int device, void **d_ptr);
 int gec_ipc_close(void *d_ptr);

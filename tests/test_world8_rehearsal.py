@@ -100,6 +100,10 @@ def test_world8_striped_decode_op_at_full_config5_size():
     # all-gather: 7 peers' slot buffers; all-to-all: only this rank's byte range of the k valid shards -- an order less
     assert d["exchange"]["allgather"]["bytes_received_per_rank"] == 7 * 256 * 4 * 209728
     assert d["exchange"]["alltoall"]["bytes_received_per_rank"] * 5 < d["exchange"]["allgather"]["bytes_received_per_rank"]
+    # the peer-pointer form across 8 PROCESSES: every rank maps the 7 others' slot buffers (HIP IPC) and its decode launch reads
+    # its byte range of the 20 survivors out of them -- 1/8 of 17-18 remote shards per object instead of 7 ranks' whole slot buffers
+    peer = d["exchange"]["peer"]
+    assert peer["bit_exact"] is True and 0 < peer["bytes_read_from_peers_memory_per_rank"] * 10 < d["exchange"]["allgather"]["bytes_received_per_rank"]
 
 
 @pytest.mark.gpu
