@@ -304,10 +304,19 @@ int for_lanes(gbm_manager *front, const std::function<int(gbm_manager *, size_t)
 		if (rcs[i])
 			errs[i] = last_error();
 	};
+	// (a thread that cannot be started -- the process is at its limit -- must not unwind past joinable ones: std::terminate
+	// inside a C entry point; its lane, and the ones behind it, then run here, one after the other)
 	std::vector<std::thread> th;
-	for (size_t i = 1; i < nl; ++i)
-		th.emplace_back(one, i);
+	size_t started = 1;
+	try {
+		th.reserve(nl);
+		for (; started < nl; ++started)
+			th.emplace_back(one, started);
+	} catch (const std::exception &) {
+	}
 	one(0);
+	for (size_t i = started; i < nl; ++i)
+		one(i);
 	for (auto &t : th)
 		t.join();
 	for (size_t i = nl; i-- > 0;)

@@ -563,6 +563,12 @@ static int get_blocks_again(gbm_manager *mg, size_t nb, const uint8_t *hashes, c
 // while the other one was still on its way -- a block that comes back Missing (or Corrupt with too few shards) during a
 // transition is asked for again, twice at most: moves only go forward, a later walk meets the shards where an earlier one's
 // went to.  (The reference leaves the same cases to the client's retry.)
+// What get_blocks_once says about the blocks it could not return (per call, on the calling thread): 1 = its walk found SOME of the
+// block (a shard, or a corrupt copy) but too little -- what a move in progress looks like, worth another walk; 0 = nothing of it was
+// seen at any holder of any version (the block simply is not there), or its bytes were read and failed the end-to-end check: a
+// retry cannot change either.
+static thread_local std::vector<uint8_t> t_worth_retry;
+
 int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
 		    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate)
 {
@@ -578,8 +584,8 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 	for (int attempt = 1; attempt <= 2 && rc == GBM_OK && mg->layout_cur.load() != mg->layout_oldest.load(); ++attempt) {
 		bool any = false;
 		for (size_t b = 0; b < nb && !any; ++b)
-			any = rcs[b] == GBM_E_MISSING_BLOCK || rcs[b] == GBM_E_CORRUPT_DATA;
-		if (!any)
+			any = (rcs[b] == GBM_E_MISSING_BLOCK || rcs[b] == GBM_E_CORRUPT_DATA) && b < t_worth_retry.size() && t_worth_retry[b];
+		if (!any)  // (a block nobody holds and a block whose content does not match its name are final: no sleep, no second walk)
 			break;
 		if (attempt == 2)
 			std::this_thread::sleep_for(std::chrono::milliseconds(5));
@@ -596,8 +602,9 @@ static int get_blocks_again(gbm_manager *mg, size_t nb, const uint8_t *hashes, c
 {
 	int rc = GBM_OK;
 	std::vector<size_t> again;
+	const std::vector<uint8_t> worth = t_worth_retry;  // (the call below overwrites it)
 	for (size_t b = 0; b < nb; ++b)
-		if (rcs[b] == GBM_E_MISSING_BLOCK || rcs[b] == GBM_E_CORRUPT_DATA)  // (Corrupt: a bad shard was met AND too few others were found)
+		if ((rcs[b] == GBM_E_MISSING_BLOCK || rcs[b] == GBM_E_CORRUPT_DATA) && b < worth.size() && worth[b])  // (Corrupt: a bad shard was met AND too few others were found)
 			again.push_back(b);
 	if (again.empty())
 		return rc;
@@ -619,12 +626,15 @@ static int get_blocks_again(gbm_manager *mg, size_t nb, const uint8_t *hashes, c
 			     headers ? hd.data() : nullptr, gate);
 	if (rc != GBM_OK)
 		return rc;
+	std::vector<uint8_t> worth2(nb, 0);
 	for (size_t i = 0; i < na; ++i) {
 		rcs[again[i]] = rr[i];
 		len_out[again[i]] = ll[i];
 		if (headers)
 			headers[again[i]] = hd[i];
+		worth2[again[i]] = i < t_worth_retry.size() ? t_worth_retry[i] : 0;
 	}
+	t_worth_retry = worth2;
 	return GBM_OK;
 }
 
@@ -637,6 +647,7 @@ static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, co
 		hs[b].assign((const char *)hashes + 32 * b, 32);
 	std::vector<Gathered> g;
 	std::vector<uint8_t> block_sums, changed, have_sum, early(nb, 0);
+	std::vector<uint8_t> final_verdict(nb, 0);  // the block's bytes were read and failed a content check: no walk can change that
 	// The requester's end-to-end check (gbm_set_verify_block_hash): every Plain block, only the blocks that went through a
 	// decode, or -- the default, the reference's read path -- none: the shard checksums of the same trip are the serving
 	// node's verify (read_block_from, manager.rs:577-609), and they are always checked.
@@ -694,6 +705,7 @@ static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, co
 		const bool check = verify && !z && (!only_rebuilt || (changed[b] & 2));
 		if (check && !cpu_hash && have_sum[b] && std::memcmp(block_sums.data() + 32 * b, hashes + 32 * b, 32) != 0) {
 			rcs[b] = GBM_E_CORRUPT_DATA;
+			final_verdict[b] = 1;
 			return;
 		}
 		if (z && !raw) {
@@ -701,6 +713,7 @@ static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, co
 			assemble(g[b], k, frame.data());
 			if (!zstd().decode(frame.data(), L, kMaxDecompressed, plain)) {
 				rcs[b] = GBM_E_CORRUPT_DATA;
+				final_verdict[b] = 1;
 				return;
 			}
 			len_out[b] = plain.size();
@@ -750,14 +763,20 @@ static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, co
 			b2host::blake2sum_many(ptr, len, cnt, sums);
 			for (size_t i = 0; i < cnt; ++i) {
 				const size_t b = idx[i0 + i];
-				if (std::memcmp(sums + 32 * i, hashes + 32 * b, 32) != 0)
+				if (std::memcmp(sums + 32 * i, hashes + 32 * b, 32) != 0) {
 					rcs[b] = GBM_E_CORRUPT_DATA;
-				else
+					final_verdict[b] = 1;
+				} else {
 					mg->metrics[5]++;
+				}
 			}
 		});
 	}
 	tr.lap("finish");
+	t_worth_retry.assign(nb, 0);
+	for (size_t b = 0; b < nb; ++b)
+		if ((rcs[b] == GBM_E_MISSING_BLOCK || rcs[b] == GBM_E_CORRUPT_DATA) && !final_verdict[b] && b < g.size())
+			t_worth_retry[b] = g[b].count > 0 || g[b].corrupt_seen || g[b].have_meta;
 	g.clear();
 	tr.lap("release");
 	return GBM_OK;

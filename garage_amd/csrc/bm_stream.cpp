@@ -142,7 +142,10 @@ struct StreamOut {
 		raw = raw_;
 		if (z && !raw && zstd().streaming) {
 			zs.reset(new Zstd::Stream(zstd()));
-			zbuf.reserve(ch);
+			if (!zs->ds)
+				zs.reset();  // no decoder (an allocation failed): the whole-frame form below serves -- NOT "corrupt data"
+			else
+				zbuf.reserve(ch);
 		}
 	}
 	void start_hash()  // (from the first byte: whatever went out before is hashed first)

@@ -13,9 +13,9 @@
 // 64-bit values cost more VALU than the multiplies; LDS atomics serialize.  So: every wave owns an LDS region
 // [64 lanes][CAP slots] of 64-bit terms (lane-major, 8 bytes of padding per lane: conflict-free writes), a lane drops its
 // term for slot s there as soon as it has it (one ds_write_b64, nothing kept in registers), and when the region is full --
-// or at the end of the tile -- the wave sums it up: lane (s, q) adds the terms of lanes 8q..8q+7 for slot s (8 ds_read_b64),
-// three xor-shuffles finish the 64 -> 1, and the wave's total goes to wsum[slot][wave].  One barrier at the very end of the
-// tile, then (slot, leaf) threads add the four waves of a leaf and store 8 bytes.  Wave-private regions need no barrier
+// or at the end of the tile -- the wave sums it up: lane (s, q) adds the terms of lanes 8q..8q+7 for slot s (8 ds_read_b64,
+// conflict-free), two DPP steps add the four q of a quad, and the wave's two partial sums go to wsum[slot][2 wave + half].  One
+// barrier at the very end of the tile, then (slot, leaf) threads add the eight partial sums of a leaf and store 8 bytes.  Wave-private regions need no barrier
 // while the tile is being computed (LDS operations of one wave execute in order).
 #pragma once
 
@@ -49,14 +49,24 @@ __device__ __forceinline__ uint64_t mlh_col(const mlh_u32x4 d, const mlh_u32x4 k
 
 constexpr uint32_t mlh_region_bytes(int cap) { return 64u * (8u * cap + 8u); }
 
-// LDS a workgroup of `waves` waves needs for nsl slots: the wave regions + wsum[nsl][waves]
-constexpr uint32_t mlh_lds_bytes(int cap, int waves, int nsl) { return waves * mlh_region_bytes(cap) + (uint32_t)nsl * waves * 8u; }
+// LDS a workgroup of `waves` waves needs for nsl slots: the wave regions + wsum[nsl][2 * waves]
+constexpr uint32_t mlh_lds_bytes(int cap, int waves, int nsl) { return waves * mlh_region_bytes(cap) + (uint32_t)nsl * waves * 16u; }
+
+// x + (x of the lane DPP control `CTRL` names), both halves of the 64-bit value: two v_mov_b32_dpp and one 64-bit add
+template <int CTRL>
+__device__ __forceinline__ uint64_t mlh_add_dpp(uint64_t x)
+{
+	const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+	const uint32_t plo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, true);
+	const uint32_t phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, true);
+	return x + (((uint64_t)phi << 32) | plo);
+}
 
 template <int CAP>
 struct WaveSums {
-	typedef __attribute__((address_space(3))) uint64_t lds_u64;
-	uint8_t *region;   // this wave's [64][CAP] (+8 bytes per lane)
-	uint64_t *wsum;    // [nsl][waves]
+	static constexpr uint32_t PITCH = 8u * CAP + 8u;  // bytes per lane: CAP terms + 8 bytes so that a slot's 64 writes spread over all banks
+	uint8_t *region;   // this wave's [64 lanes][CAP slots]
+	uint64_t *wsum;    // [nsl][2 * waves]: a wave leaves two partial sums per slot (lanes 0-31 / 32-63 of the summing pass)
 	uint32_t lane, wave, waves;
 	uint32_t pend = 0, base = 0;  // slots waiting in the region / slots already summed up (wave-uniform)
 
@@ -71,31 +81,32 @@ struct WaveSums {
 	// this lane's term for the next slot (slots are pushed in ascending order by every lane of the wave)
 	__device__ __forceinline__ void put(uint64_t v)
 	{
-		*reinterpret_cast<uint64_t *>(region + lane * (8u * CAP + 8u) + 8u * pend) = v;
+		*reinterpret_cast<uint64_t *>(region + lane * PITCH + 8u * pend) = v;
 		++pend;
 	}
 	__device__ __forceinline__ bool full(uint32_t more) const { return pend + more > (uint32_t)CAP; }
-	// sums the region up: wsum[base + s][wave] for s < pend
+	// Sums the region up: wsum[base + s][2 * wave + half] for s < pend.  Lane l of a pass takes slot s = (l >> 2) & 7 and the
+	// terms of lanes 8q .. 8q + 7, q = (l & 3) + 4 * (l >> 5): within either half of the wave the 32 reads of one step fall on
+	// 32 different bank pairs (lane pitch 34 dwords: bank = 16 q + 34 i + 2 s mod 64, q < 4), so the transposition costs no
+	// bank conflicts; the four q of a quad then meet through two DPP steps -- no ds_bpermute, no barrier.
 	__device__ __forceinline__ void flush()
 	{
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		const uint32_t q = lane & 7u;
+		const uint32_t half = lane >> 5, q = (lane & 3u) + 4u * half;
 		for (uint32_t s0 = 0; s0 < pend; s0 += 8) {  // (wave-uniform trip count)
-			const uint32_t s = s0 + (lane >> 3);
+			const uint32_t s = s0 + ((lane >> 2) & 7u);
+			const uint32_t sc = s < pend ? s : pend - 1;  // (a lane without a slot shadows the last one: no divergence, its sum is not stored)
+			const uint8_t *p = region + (q * 8u) * PITCH + 8u * sc;
 			uint64_t acc = 0;
-			if (s < pend) {
-				const uint8_t *p = region + (q * 8u) * (8u * CAP + 8u) + 8u * s;
 #pragma unroll
-				for (int i = 0; i < 8; ++i)
-					acc += *reinterpret_cast<const uint64_t *>(p + i * (8u * CAP + 8u));
-			}
-			acc += __shfl_xor(acc, 1);
-			acc += __shfl_xor(acc, 2);
-			acc += __shfl_xor(acc, 4);
-			if (q == 0 && s < pend)
-				wsum[(base + s) * waves + wave] = acc;
+			for (int i = 0; i < 8; ++i)
+				acc += *reinterpret_cast<const uint64_t *>(p + i * PITCH);
+			acc = mlh_add_dpp<0xB1>(acc);  // quad_perm [1,0,3,2]
+			acc = mlh_add_dpp<0x4E>(acc);  // quad_perm [2,3,0,1]
+			if ((lane & 3u) == 0 && s < pend)
+				wsum[(base + s) * (2 * waves) + 2 * wave + half] = acc;
 		}
 		base += pend;
 		pend = 0;
@@ -103,16 +114,16 @@ struct WaveSums {
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	}
-	// After the workgroup's barrier: thread t < nsl * leaves adds the waves of (slot, leaf-of-the-tile) and hands the
-	// sum to store(slot, leaf_in_tile, value).  leaves = waves / 4.
+	// After the workgroup's barrier: thread t < nsl * leaves adds the 8 partial sums of (slot, leaf-of-the-tile) -- four waves, two
+	// halves each -- and hands the sum to store(slot, leaf_in_tile, value).  leaves = waves / 4.
 	template <class Store>
 	__device__ __forceinline__ void combine(uint32_t tid, uint32_t nthr, uint32_t nsl, Store store) const
 	{
 		const uint32_t leaves = waves >> 2;
 		for (uint32_t t = tid; t < nsl * leaves; t += nthr) {
 			const uint32_t slot = t / leaves, g = t - slot * leaves;
-			const uint64_t *w = wsum + slot * waves + 4 * g;
-			store(slot, g, w[0] + w[1] + w[2] + w[3]);
+			const uint64_t *w = wsum + slot * (2 * waves) + 8 * g;
+			store(slot, g, ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7])));
 		}
 	}
 };
