@@ -17,7 +17,7 @@ GBM_E_INVALID_ARG, GBM_E_EC, GBM_E_IO, GBM_E_BUFFER_TOO_SMALL, GBM_E_ABORTED = -
 GBM_BLOCK_GC_DELAY_MS, GBM_RESYNC_RETRY_DELAY_MS = 600_000, 60_000
 
 SYMBOLS = [
-    "gbm_last_error", "gbm_blake2sum", "gbm_shardsum", "gbm_shardsum_v", "gbm_shard_version", "gbm_blake2sum_batch", "gbm_create", "gbm_destroy", "gbm_set_compression_level", "gbm_set_data_fsync",
+    "gbm_last_error", "gbm_blake2sum", "gbm_shardsum", "gbm_shardsum_v", "gbm_shard_version", "gbm_node_requests", "gbm_blake2sum_batch", "gbm_create", "gbm_destroy", "gbm_set_compression_level", "gbm_set_data_fsync",
     "gbm_set_verify_block_hash", "gbm_set_threads", "gbm_set_timing", "gbm_clock_advance",
     "gbm_storage_nodes_of", "gbm_layout_update", "gbm_layout_trim",
     "gbm_rpc_put_block", "gbm_rpc_put_blocks", "gbm_rpc_get_block", "gbm_rpc_get_blocks",
@@ -129,6 +129,8 @@ def _load():
     lib.gbm_shardsum.restype = None
     lib.gbm_shardsum_v.argtypes = [ctypes.c_int, ctypes.c_char_p, sz, ctypes.c_char_p]
     lib.gbm_shard_version.argtypes = [ctypes.c_void_p]
+    lib.gbm_node_requests.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.gbm_node_requests.restype = ctypes.c_uint64
     lib.gbm_blake2sum_batch.argtypes = [sz, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p]
     lib.gbm_blake2sum_batch.restype = ctypes.c_int
     lib.gbm_create.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), ci, pp]
@@ -320,6 +322,10 @@ class NativeBlockManager:
     def shard_version(self) -> int:
         """the shard-header version this manager writes (gbm_shard_version): its codec's checksum kind"""
         return int(lib.gbm_shard_version(self._h))
+
+    def node_requests(self, node: int) -> int:
+        """requests of any kind the node has been handed so far (test hook)"""
+        return int(lib.gbm_node_requests(self._h, node))
 
     def storage_nodes_of(self, hash_: bytes) -> list[int]:
         out = (ctypes.c_int * self.n)()

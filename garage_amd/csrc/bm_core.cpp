@@ -803,6 +803,13 @@ int gbm_node_shard_header(gbm_manager *m, int node, const uint8_t hash[32], int 
 	return GBM_OK;
 }
 
+uint64_t gbm_node_requests(gbm_manager *m, int node)
+{
+	if (!m || node < 0 || node >= (int)m->nodes.size())
+		return 0;
+	return m->nodes[node]->requests.load();
+}
+
 uint64_t gbm_node_order_violations(gbm_manager *m, int node)
 {
 	if (!m || node < 0 || node >= (int)m->nodes.size())

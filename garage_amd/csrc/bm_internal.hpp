@@ -507,6 +507,7 @@ struct Node {
 	std::atomic<bool> down{false};  // flipped by gbm_node_set_down while other threads are talking to the node
 	std::atomic<uint64_t> order_violations{0};
 	std::atomic<uint64_t> latency_us{0};  // test hook: every request to this node takes this long
+	std::atomic<uint64_t> requests{0};    // test hook: requests this node has been handed (down or not)
 	std::shared_ptr<BufPool> bufs;
 	virtual ~Node() = default;
 	// stores the shard; *pending = it was parked because a shard of another geometry is in place

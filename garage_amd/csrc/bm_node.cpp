@@ -14,6 +14,7 @@ namespace gbmimpl {
 
 bool Node::handle(const ShardRpc &rq, ShardResp &rs)
 {
+	requests.fetch_add(1, std::memory_order_relaxed);
 	if (down.load(std::memory_order_acquire))
 		return false;
 	if (const uint64_t us = latency_us.load(std::memory_order_relaxed))

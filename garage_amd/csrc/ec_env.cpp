@@ -28,16 +28,12 @@ const Row kRows[] = {
 	{"GEC_UPLOAD_CUS", "16", "CUs reserved for kernels that read / write host memory (0 = no CU masks)"},
 	{"GEC_VERIFY_SEGMENTS", "min(k, 16)", "A/B: upload stages of gec_decode_verify_batch (1 = upload, then hash)"},
 	{"GEC_PINNED_CHUNK_MB", "128", "chunk size of the staged path for pinned memory"},
-	{"GEC_HASH_FORK", "1", "A/B: 0 = encode + checksums on one stream instead of the data-shard checksums beside the encode"},
 	{"GEC_BG_CUS", "64", "CUs a background-class codec's kernels may occupy (0 = no mask; link kernels stay on GEC_UPLOAD_CUS)"},
 	{"GEC_BG_CHUNK_MB", "32", "chunk size of a background-class codec's host-pointer trips (a foreground call waits for at most one)"},
 	{"GEC_BG_YIELD_US", "2000", "a background chunk waits up to this long for foreground calls on the same device to drain (0 = never waits)"},
 	{"GEC_BG_LINK_WAIT_US", "200", "a background link kernel's workgroups sleep while foreground link kernels run on the device, at most this long per launch (0 = the classes share the link as it comes)"},
 	{"GEC_HOME_RATE_GBPS", "25", "the read path sends rebuilt shards home no faster than this while checksum chains run (0 = unpaced, one workgroup per tile): a link saturated with writes backs up into the fabric and every other kernel's loads wait"},
-	{"GEC_RESIDENT_GRID", "1", "A/B: 0 = link kernels launch one workgroup per tile instead of a grid that fits the stream's CUs and walks the tiles"},
-	{"GEC_ROWS16", "1", "A/B: 0 = 9..16 output rows as 8-row passes instead of one 16-row pass"},
 	{"GEC_BLAKE2_KERNEL", "auto", "A/B: lane or quad forces one of the two forms of the blake2 kernels (plain hashes, and the leaves / roots of the shard checksums)"},
-	{"GEC_B2_ADD", "0", "A/B: 1 = 64-bit adds of the blake2 kernels spelled as 32-bit add / addc"},
 	{"GEC_PUT_CHUNKS", "1", "A/B: gec_encode_hash_batch on pinned memory cuts a trip of 16 or more blocks into at least this many chunks, the checksums of one beside the link kernel of the next (1 = only the size-based chunking: one link kernel, one leaf and one root kernel -- 10-15 % faster per trip at 16-32 blocks, profiles/r04_trip_bench.txt)"},
 	{"GEC_GET_PIECES_MIN", "24", "read trips of at least this many blocks go in pieces (a piece has at least 12 blocks)"},
 	{"GEC_GET_PIECES", "4", "a big read trip without block checksums goes in up to this many pieces, upload / checksums + decode / rebuilt shards home pipelined on three streams (0 = one piece: upload, then everything else; A/B)"},
@@ -80,17 +76,13 @@ const Env &env()
 		v.upload_cus = (int)get_long("GEC_UPLOAD_CUS", 16);
 		v.verify_segments = (int)get_long("GEC_VERIFY_SEGMENTS", 0);
 		v.pinned_chunk_mb = (size_t)std::max<long>(get_long("GEC_PINNED_CHUNK_MB", 128), 1);
-		v.hash_fork = get_long("GEC_HASH_FORK", 1) != 0;
 		v.bg_cus = (int)get_long("GEC_BG_CUS", 64);
 		v.bg_chunk_mb = (size_t)std::max<long>(get_long("GEC_BG_CHUNK_MB", 32), 1);
 		v.bg_yield_us = (unsigned)std::max<long>(get_long("GEC_BG_YIELD_US", 2000), 0);
 		v.bg_link_wait_us = (unsigned)std::min<long>(std::max<long>(get_long("GEC_BG_LINK_WAIT_US", 200), 0), 1000000);
 		v.home_rate_gbps = (unsigned)std::max<long>(get_long("GEC_HOME_RATE_GBPS", 25), 0);
-		v.resident_grid = (int)get_long("GEC_RESIDENT_GRID", 1);
-		v.rows16 = (int)get_long("GEC_ROWS16", 1);
 		const char *bk = get("GEC_BLAKE2_KERNEL");
 		v.blake2_kernel = !bk ? 0 : (bk[0] == 'l' ? 1 : (bk[0] == 'q' ? 2 : 0));
-		v.b2_add = (int)get_long("GEC_B2_ADD", 0);
 		v.put_chunks = (int)std::min<long>(std::max<long>(get_long("GEC_PUT_CHUNKS", 1), 1), 16);
 		v.get_pieces_min = (int)std::min<long>(std::max<long>(get_long("GEC_GET_PIECES_MIN", 24), 1), 1 << 20);
 		v.get_pieces = (int)std::min<long>(std::max<long>(get_long("GEC_GET_PIECES", 4), 0), 16);

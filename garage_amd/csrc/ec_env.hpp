@@ -22,7 +22,6 @@ struct Env {
 	int upload_cus;         // GEC_UPLOAD_CUS
 	unsigned bg_link_wait_us; // GEC_BG_LINK_WAIT_US
 	unsigned home_rate_gbps; // GEC_HOME_RATE_GBPS
-	int resident_grid;      // GEC_RESIDENT_GRID
 	int verify_segments;    // GEC_VERIFY_SEGMENTS (0 = the built-in maximum)
 	int put_chunks;         // GEC_PUT_CHUNKS
 	int get_pieces;         // GEC_GET_PIECES
@@ -32,15 +31,12 @@ struct Env {
 	size_t fused_get_max_leaves;  // GEC_FUSED_GET_MAX_LEAVES
 	unsigned bg_home_rate_gbps;  // GEC_BG_HOME_RATE_GBPS
 	size_t pinned_chunk_mb; // GEC_PINNED_CHUNK_MB
-	bool hash_fork;         // GEC_HASH_FORK
 	// ---- HIP backend: background class
 	int bg_cus;             // GEC_BG_CUS
 	size_t bg_chunk_mb;     // GEC_BG_CHUNK_MB
 	unsigned bg_yield_us;   // GEC_BG_YIELD_US
 	// ---- HIP backend: kernels (A/B)
-	int rows16;             // GEC_ROWS16
 	int blake2_kernel;      // GEC_BLAKE2_KERNEL: 0 auto, 1 lane, 2 quad
-	int b2_add;             // GEC_B2_ADD
 	uint64_t max_cols_per_launch;  // GEC_MAX_COLS_PER_LAUNCH (0 = no cap)
 	// ---- multi-GPU
 	std::string rccl_lib;   // GEC_RCCL_LIB ("" = librccl.so.1, then librccl.so)

@@ -124,7 +124,7 @@ int encode_hash_dev(const gec_codec *c, size_t nblocks, uint8_t *d_stripes, size
 			return rc;
 		return mlh_roots_dev(c, nblocks * n, so.lsum, nleaf_max, nullptr, S, d_sums, stream);
 	}
-	const bool fork = env().hash_fork;  // A/B switch
+	const bool fork = true;  // (one stream for everything lost its A/B by 2x: the data shards' chains hide behind the RS kernel)
 	if (fork) {
 		HIP_TRY(hipEventRecord(aux.ev_fork, stream));
 		HIP_TRY(hipStreamWaitEvent(aux.stream2, aux.ev_fork, 0));

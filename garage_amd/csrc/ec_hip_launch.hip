@@ -220,7 +220,7 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 	int rows = 0;
 	for (int r0 = 0; r0 < nout; r0 += rows) {
 		// (the SUM form exists for 4- and 8-byte table entries: more than 8 rows go out in groups of 8)
-		const Geometry geo = pick_geometry(k, nout - r0, variant == 0 && env().rows16 != 0 && !sum);
+		const Geometry geo = pick_geometry(k, nout - r0, variant == 0 && !sum);
 		rows = variant == 1 ? std::min(gec::RMAX, nout - r0) : geo.rows;  // the baseline kernel takes up to 8 rows
 		a.rows = (uint32_t)rows;
 		const int mw = variant == 1 ? 2 : geo.mw;
@@ -366,7 +366,6 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 		int rc = leaf_scratch(c, stream, lanes * 64, &scratch);
 		if (rc)
 			return rc;
-		const int addmode = env().b2_add;  // A/B, see blake2b.hpp
 		const dim3 lgrid((unsigned)((lanes + 63) / 64));
 		// few leaves (a PutObject's blocks, a GetObject's): four lanes per leaf, like the plain hash below
 		const int forced_leaf = env().blake2_kernel;
@@ -375,10 +374,8 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 			return fail(GEC_E_INVALID_ARG, "too many leaves for one call of the four-lane kernel");
 		if (quad_tree)
 			hipLaunchKernelGGL(gec::blake2b_batch_quad<gec::B2Q_LEAF>, dim3((unsigned)((lanes + 15) / 16)), dim3(64), 0, stream, a, nleaf, scratch);
-		else if (addmode == 0)
-			hipLaunchKernelGGL(gec::shardsum_leaves<0>, lgrid, dim3(64), 0, stream, a, nleaf, scratch);
 		else
-			hipLaunchKernelGGL(gec::shardsum_leaves<1>, lgrid, dim3(64), 0, stream, a, nleaf, scratch);
+			hipLaunchKernelGGL(gec::shardsum_leaves<0>, lgrid, dim3(64), 0, stream, a, nleaf, scratch);
 		HIP_TRY(hipGetLastError());
 		if (quad_tree)
 			hipLaunchKernelGGL(gec::blake2b_batch_quad<gec::B2Q_ROOT>, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, stream, a, nleaf, scratch);
@@ -395,13 +392,7 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 	if (quad)
 		hipLaunchKernelGGL(gec::blake2b_batch_quad<gec::B2Q_PLAIN>, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, stream, a, 0u, static_cast<uint8_t *>(nullptr));
 	else
-		{
-		const int addmode = env().b2_add;
-		if (addmode == 0)
-			hipLaunchKernelGGL(gec::blake2b_batch<0>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a);
-		else
-			hipLaunchKernelGGL(gec::blake2b_batch<1>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a);
-	}
+		hipLaunchKernelGGL(gec::blake2b_batch<0>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a);
 	HIP_TRY(hipGetLastError());
 	return GEC_OK;
 }
@@ -530,7 +521,6 @@ int mlh_roots_dev(const gec_codec *c, size_t n, const uint64_t *lsum, uint32_t n
 // dispatcher wait for as long, whatever CUs THEY are confined to.  That is how a scrub's 600 us link kernel (800
 // workgroups onto 8 CUs) made a PutObject's 140 us checksum kernel take 660 us in some process runs and not in others
 // (which queues share a dispatcher is decided when they are created): tools/dispatch_probe, profiles/r03_qos.txt.
-// GEC_RESIDENT_GRID=0: one workgroup per tile (A/B).
 namespace {
 unsigned resident_grid(const Staging &st, hipStream_t stream, uint32_t tiles, size_t lds_bytes = 0)
 {
@@ -538,8 +528,6 @@ unsigned resident_grid(const Staging &st, hipStream_t stream, uint32_t tiles, si
 	// kernels are meant to overlap too -- the read path's upload stages beside its checksum segments: with one
 	// workgroup per tile, a get whose upload queue happened to share a dispatcher with its chain queue ran every
 	// segment BEHIND the next stage's upload (17.7 instead of 15.8 ms for the same 512 blocks, process by process).
-	if (env().resident_grid == 0)
-		return tiles;
 	// gec::RESIDENT_WGS workgroups per CU is what the kernels' __launch_bounds__ guarantees room for (the occupancy
 	// query of the runtime does not count scalar registers and promised 8 for a kernel that fits 7 times: the
 	// workgroups that did not fit started when the others were done, and held the dispatcher until then)
@@ -922,7 +910,7 @@ int gec_launch_geometry(int k, int rows_left, int *rows, int *entry_bytes, int *
 {
 	if (k < 1 || k > GEC_MAX_SHARDS - 1 || rows_left < 1)
 		return fail(GEC_E_INVALID_ARG, "need 1 <= k <= 255 and rows_left >= 1");
-	const Geometry g = pick_geometry(k, rows_left, env().rows16 != 0);
+	const Geometry g = pick_geometry(k, rows_left, true);
 	if (rows)
 		*rows = g.rows;
 	if (entry_bytes)

@@ -466,6 +466,8 @@ int gbm_node_shard_header(gbm_manager *m, int node, const uint8_t hash[32], int 
 			  uint8_t out[GBM_SHARD_HEADER_SIZE]);
 /* PutShard deliveries to this node whose order tag was lower than one it had already seen for the same stream */
 uint64_t gbm_node_order_violations(gbm_manager *m, int node);
+/* Test hook: requests of any kind this node has been handed so far (who a read asked, without a clock in the assertion). */
+uint64_t gbm_node_requests(gbm_manager *m, int node);
 
 /* Hedged reads (the template is try_call_many_inner,
  * /root/reference/src/rpc/rpc_helper.rs:323-411: launch exactly quorum requests in request_order, start another on
