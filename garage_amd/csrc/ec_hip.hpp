@@ -347,10 +347,6 @@ struct SumOut {
 	uint64_t *lsum;
 	uint32_t nleaf_max, slots_total, slot0;
 	bool inputs;
-	// pointer-table kernel only: roots != NULL -- the 32-byte checksums come out of the same launch (the block's last workgroup
-	// makes them): roots[(b * slots_total + slot) * 32], `done` = nblocks zeroed counters (done_counters())
-	uint8_t *roots = nullptr;
-	uint32_t *done = nullptr;
 };
 int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_t *out, size_t out_stride, uint32_t *bad,
 		 size_t byte_off, size_t byte_len, size_t nblocks, const size_t *in_base_off, const size_t *out_base_off, int nout,

@@ -57,13 +57,6 @@ int HipBackend::encode_batch(size_t nblocks, const uint8_t *const *blocks, const
 			hipStream_t up = st.stream_up ? st.stream_up : st.stream;
 			uint8_t *scr = nullptr;
 			rc = gecimpl::leaf_scratch(c, up, zch * n * nleaf_max * 8, &scr);
-			// a small trip (a PutObject's few blocks: launches, not bytes, are what it costs) gets its roots from the link kernel's
-			// last workgroup per block: ONE launch; a big batch keeps the separate root kernel (14 lanes of one wave per block would
-			// trail behind a kernel that is otherwise done)
-			uint32_t *done = nullptr;
-			const bool one_launch = nblocks * n * nleaf_max < env().fused_max_leaves && env().fused_small != 0;
-			if (!rc && one_launch)
-				rc = gecimpl::done_counters(c, up, zch, &done);
 			std::vector<const uint8_t *> in(zch * k);
 			std::vector<uint32_t> valid(zch * k);
 			std::vector<uint8_t *> out(zch * m);
@@ -81,13 +74,9 @@ int HipBackend::encode_batch(size_t nblocks, const uint8_t *const *blocks, const
 					for (size_t r = 0; r < m; ++r)
 						out[i * m + r] = q + r * S;
 				}
-				SumOut so{reinterpret_cast<uint64_t *>(scr), nleaf_max, (uint32_t)n, 0u, true};
-				if (one_launch) {
-					so.roots = st.h_buf + b0 * n * 32;
-					so.done = done;
-				}
+				const SumOut so{reinterpret_cast<uint64_t *>(scr), nleaf_max, (uint32_t)n, 0u, true};
 				rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), out.data(), (int)m, S, c->enc.row(k), up, nullptr, nullptr, 0, nullptr, &so);
-				if (!rc && !one_launch)
+				if (!rc)
 					rc = mlh_roots_dev(c, nb * n, so.lsum, nleaf_max, nullptr, S, st.h_buf + b0 * n * 32, up);
 			}
 			const hipError_t e1 = hipStreamSynchronize(up);

@@ -617,10 +617,7 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 			a.sum_slots_total = sum->slots_total;
 			a.sum_inputs = (r0 == 0 && sum->inputs) ? 1u : 0u;
 			a.sum_slot0 = sum->slot0 + (a.sum_inputs ? 0u : (sum->inputs ? (uint32_t)k : 0u) + (uint32_t)r0);
-			lds = ((lds + 15) & ~(size_t)15) + gec::mlh_lds_bytes(16, 4, (int)((a.sum_inputs ? k : 0) + rows)) + 16;
-			a.sum_roots = sum->roots;
-			a.sum_done = sum->done;
-			a.sum_len = S;
+			lds = ((lds + 15) & ~(size_t)15) + gec::mlh_lds_bytes(16, 4, (int)((a.sum_inputs ? k : 0) + rows));
 		}
 		a.mirror_stride = (k + (size_t)nout) * S;
 		a.mirror_row0 = (k + (size_t)r0) * S;

@@ -104,12 +104,6 @@ struct PtrApplyArgs {
 	//   lsum[((b * sum_slots_total + sum_slot0 + slot) * sum_nleaf_max) + leaf],  slot = input t (sum_inputs) then row r
 	uint64_t *lsum;
 	uint32_t sum_nleaf_max, sum_slots_total, sum_slot0, sum_inputs;
-	// sum_roots != NULL: the block's LAST workgroup (a counter per block in sum_done, all zero before and after the launch) turns
-	// the leaf sums of this launch's slots into the 32-byte checksums itself -- sum_roots[(b * sum_slots_total + slot) * 32], shards
-	// of sum_len bytes -- so a small trip is ONE launch
-	uint8_t *sum_roots;
-	uint32_t *sum_done;
-	uint64_t sum_len;
 	uint8_t coef[PTR_KMAX][RMAX];
 };
 

@@ -699,26 +699,6 @@ __global__ __launch_bounds__(256, RESIDENT_WGS) void gf_apply_ptrs(const PtrAppl
 			const uint32_t leaf = tile - b * a.tiles_x;
 			uint64_t *dst = a.lsum + ((uint64_t)b * a.sum_slots_total + a.sum_slot0) * a.sum_nleaf_max + leaf;
 			ws.combine(tid, 256, nsl, [&](uint32_t slot, uint32_t, uint64_t v) { dst[(uint64_t)slot * a.sum_nleaf_max] = v; });
-			if (a.sum_roots) {
-				// the block's last workgroup makes the roots (the pattern of fused.hpp: sums out, fence, count, fence, read)
-				uint32_t *flag = reinterpret_cast<uint32_t *>(ws.wsum + (size_t)nsl * 8);  // (behind wsum[nsl][8]: the host adds 16 bytes)
-				__threadfence();
-				__syncthreads();
-				if (tid == 0) {
-					const uint32_t before = __hip_atomic_fetch_add(a.sum_done + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					flag[0] = before + 1 == a.tiles_x ? 1u : 0u;
-				}
-				__syncthreads();
-				if (flag[0]) {  // (workgroup-uniform)
-					__threadfence();
-					const uint64_t *row0 = a.lsum + ((uint64_t)b * a.sum_slots_total + a.sum_slot0) * a.sum_nleaf_max;
-					for (uint32_t t = tid; t < nsl; t += 256)
-						mlh_root_one(a.sum_len, row0 + (uint64_t)t * a.sum_nleaf_max,
-							     a.sum_roots + ((uint64_t)b * a.sum_slots_total + a.sum_slot0 + t) * 32);
-					if (tid == 0)
-						a.sum_done[b] = 0;  // the counters are all zero again when the launch is over
-				}
-			}
 			__syncthreads();
 			ws.base = 0;
 		}

@@ -176,10 +176,20 @@ __global__ __launch_bounds__(256) void mlh_leaves(const Blake2Args a, uint32_t n
 		lsum[wl] = acc;
 }
 
-// The root of one shard's leaf sums (this lane's work): BLAKE2b-512 over MAGIC || len || s_0 .. s_{nleaf-1}, first 32 bytes to out.
-__device__ __forceinline__ void mlh_root_one(uint64_t slen, const uint64_t *__restrict__ sums, uint8_t *out)
+// ---------------------------------------------------------------------------
+// mlh_roots: one lane per shard.  Message = MAGIC || len || s_0 .. s_{nleaf-1}; placement of the 32-byte result like the
+// BLAKE2b kernels (b2_out_ptr).  slot_map != NULL: shard i's leaf sums are at lsum[slot_map[i] * nleaf_max] (the RS kernels
+// number their sums (block, slot); the caller wants (block, shard index)), otherwise at lsum[i * nleaf_max].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mlh_roots(const Blake2Args a, uint32_t nleaf_max, const uint64_t *__restrict__ lsum,
+						const uint32_t *__restrict__ slot_map)
 {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= a.n)
+		return;
+	const uint64_t slen = a.len ? a.len[i] : a.uniform_len;
 	const uint32_t nleaf = (uint32_t)((slen + mlh::LEAF_BYTES - 1) / mlh::LEAF_BYTES);
+	const uint64_t *sums = lsum + (uint64_t)(slot_map ? slot_map[i] : i) * nleaf_max;
 	const uint64_t len = mlh::ROOT_HEADER_BYTES + 8ull * nleaf;
 	uint64_t h[8] = {0x6a09e667f3bcc908ULL ^ 0x01010040ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
 			 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
@@ -198,24 +208,9 @@ __device__ __forceinline__ void mlh_root_one(uint64_t slen, const uint64_t *__re
 	for (int j = 0; j < 16; ++j)
 		m[j] = done + 8 * j < len ? word(done / 8 + j) : 0;
 	b2_compress<0>(h, m, len, true);
-	u64x2 *o = reinterpret_cast<u64x2 *>(out);
+	u64x2 *o = reinterpret_cast<u64x2 *>(b2_out_ptr(a, i));
 	o[0] = u64x2{h[0], h[1]};
 	o[1] = u64x2{h[2], h[3]};
-}
-
-// ---------------------------------------------------------------------------
-// mlh_roots: one lane per shard.  Message = MAGIC || len || s_0 .. s_{nleaf-1}; placement of the 32-byte result like the
-// BLAKE2b kernels (b2_out_ptr).  slot_map != NULL: shard i's leaf sums are at lsum[slot_map[i] * nleaf_max] (the RS kernels
-// number their sums (block, slot); the caller wants (block, shard index)), otherwise at lsum[i * nleaf_max].
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void mlh_roots(const Blake2Args a, uint32_t nleaf_max, const uint64_t *__restrict__ lsum,
-						const uint32_t *__restrict__ slot_map)
-{
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= a.n)
-		return;
-	const uint64_t slen = a.len ? a.len[i] : a.uniform_len;
-	mlh_root_one(slen, lsum + (uint64_t)(slot_map ? slot_map[i] : i) * nleaf_max, b2_out_ptr(a, i));
 }
 
 }  // namespace gec

@@ -187,9 +187,9 @@ print("DIGEST", h.hexdigest())
     assert len(counts["0"]) >= len(counts["1"]) + 4, (len(counts["0"]), len(counts["1"]))
 
 
-def test_a_v3_put_is_one_launch(tmp_path):
-    """Checksum kind 3 under rocprofv3: a put of three blocks on pinned memory is exactly ONE launch -- the pointer-table kernel in
-    its SUM form, leaf sums from its registers, roots by each block's last workgroup -- no BLAKE2b leaf kernel, no mirror copy."""
+def test_a_v3_put_is_the_link_kernel_and_a_root_kernel(tmp_path):
+    """Checksum kind 3 under rocprofv3: a put of three blocks on pinned memory is exactly TWO launches -- the pointer-table
+    kernel in its SUM form and mlh_roots -- and no BLAKE2b leaf kernel, no mirror copy, nothing else."""
     rocprof = "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         pytest.skip("rocprofv3 not installed")
@@ -220,6 +220,4 @@ assert all(sums[b, j].tobytes() == mlh64.shardsum3(full[b, j].tobytes()) for b i
 
                 with open(os.path.join(dirpath, f)) as fh:
                     names += [row["Kernel_Name"] for row in csv.DictReader(fh) if not row["Kernel_Name"].startswith("__amd_rocclr")]
-    # ONE launch: the link kernel in its SUM form, whose last workgroup per block also makes the 14 roots (a batch of hundreds of
-    # blocks takes the separate mlh_roots kernel instead: tests/test_gpu_shardsum3.py, the "200_blocks" case above)
-    assert len(names) == 1 and "gf_apply_ptrs<1, 5, false, false, true>" in names[0], names
+    assert len(names) == 2 and "gf_apply_ptrs<1, 5, false, false, true>" in names[0] and "mlh_roots" in names[1], names
