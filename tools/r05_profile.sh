@@ -18,8 +18,8 @@ import csv, glob, os
 for f in glob.glob("gpurun_out/r05_prof/**/*kernel_trace.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
     keep = [r for r in rows if r["Kernel_Name"].startswith(("gec::", "void gec::"))]
-    cols = ["Kernel_Name", "Start_Timestamp", "End_Timestamp", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Scratch_Size"]
-    cols = [c for c in cols if keep and c in keep[0]]
+    cols = [c for c in (keep[0] if keep else []) if c in ("Kernel_Name", "Start_Timestamp", "End_Timestamp", "LDS_Block_Size", "VGPR_Count", "Scratch_Size")
+            or c.startswith(("Grid_Size", "Workgroup_Size"))]
     with open(f, "w", newline="") as out:
         w = csv.DictWriter(out, fieldnames=cols)
         w.writeheader()
