@@ -884,9 +884,13 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 		    const uint8_t *prevent_compression, const gbm_order_tag *tags, int *rcs, const FanoutGate *gate = nullptr);
 // want_block_sums: 0 = no, 1 = the blake2sum of every block, 2 = of the blocks of every trip that rebuilds something
 // (block_sums[32*b..] is only meaningful where have_sum[b] is set)
+// overlap: host work done while the first device trip is in flight (the caller's early assembly); overlap_block(b): the same work
+// for ONE block -- given, a big batch whose shards are checked on the host (header version 3) does check and assembly of a block in
+// one pool task (the shard is copied while it is still in that core's cache) instead of two passes that queue on the pool
 int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs,
 		 int want_block_sums, std::vector<uint8_t> &block_sums, const std::function<void()> &overlap = nullptr,
-		 std::vector<uint8_t> *changed = nullptr, const FanoutGate *gate = nullptr, std::vector<uint8_t> *have_sum = nullptr);
+		 std::vector<uint8_t> *changed = nullptr, const FanoutGate *gate = nullptr, std::vector<uint8_t> *have_sum = nullptr,
+		 const std::function<void(size_t)> *overlap_block = nullptr);
 void assemble(const Gathered &g, int k, uint8_t *dst);
 int one_block_rc(int rc1);
 // A shard is set aside (renamed *.corrupted, rebuilt by resync) only on the HOST's word.  Whoever found a checksum that does

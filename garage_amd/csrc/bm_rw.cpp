@@ -289,7 +289,7 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 // changed after that point (bit 0: a shard failed its checksum and was replaced, bit 1: a data shard was rebuilt).
 int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs,
 		 int want_block_sums, std::vector<uint8_t> &block_sums, const std::function<void()> &overlap,
-		 std::vector<uint8_t> *changed, const FanoutGate *gate, std::vector<uint8_t> *have_sum)
+		 std::vector<uint8_t> *changed, const FanoutGate *gate, std::vector<uint8_t> *have_sum, const std::function<void(size_t)> *overlap_block)
 {
 	const int k = mg->k, n = mg->n;
 	const size_t nb = hs.size();
@@ -316,7 +316,10 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 				t.join();
 		}
 	} joiner{helper};
-	if (overlap)
+	// header version 3, a batch of some size, no block checksums wanted from a device trip: the early assembly rides in the
+	// shard-check tasks below (one pool task per block: check its k shards, then copy them out while they are in that core's cache)
+	const bool fused_host = overlap_block && mg->sumver == 3 && want_block_sums == 0 && nb >= 16;
+	if (overlap && !fused_host)
 		helper = std::thread([&overlap, &helper_err] {
 			name_thread("gbm-get-helper");
 			try {
@@ -450,11 +453,23 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 						mlh::shardsum3(sp[items[q].i * (size_t)n + items[q].j], S, ssums.data() + (items[q].i * (size_t)n + items[q].j) * 32);
 				};
 				const size_t ntask = (items.size() + per - 1) / per;
-				if (ntask <= 2)
+				if (fused_host && round == 0) {
+					// one task per block: its shards are consecutive in `items` (k of them, the first k present)
+					mg->pool->parallel_for(ids.size(), [&](size_t i) {
+						int seen = 0;
+						for (int j = 0; j < n && seen < k; ++j)
+							if (sp[i * n + j]) {
+								mlh::shardsum3(sp[i * n + j], S, ssums.data() + (i * (size_t)n + j) * 32);
+								++seen;
+							}
+						(*overlap_block)(ids[i]);
+					});
+				} else if (ntask <= 2) {
 					for (size_t t = 0; t < ntask; ++t)
 						check(t);
-				else
+				} else {
 					mg->pool->parallel_for(ntask, check);
+				}
 				tr.lap("shard checksums on the host");
 				if (decoder.joinable())
 					decoder.join();
@@ -663,8 +678,7 @@ static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, co
 	// contents are unspecified on error) or is assembled again from the replaced shards.
 	// (a block with data shards to rebuild gets the shards it has; the rebuilt ones follow after the trip)
 	std::vector<std::vector<uint8_t>> missing_early(nb);  // data shard indices that were not in hand at that point
-	auto assemble_early = [&] {
-		mg->pool->parallel_for(nb, [&](size_t b) {
+	const std::function<void(size_t)> assemble_one = [&](size_t b) {
 			const Gathered &gb = g[b];
 			if (!gb.have_meta || gb.count < k || gb.meta.compressed || gb.meta.orig_len > (uint64_t)k * gb.meta.shard_len ||
 			    cap[b] < gb.meta.orig_len)
@@ -677,11 +691,11 @@ static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, co
 					std::memcpy(out[b] + (size_t)j * S, gb.shard[j].data(), std::min(S, L - (size_t)j * S));
 			}
 			early[b] = 1;
-		});
-	};
+		};
+	auto assemble_early = [&] { mg->pool->parallel_for(nb, assemble_one); };
 	Trace tr("get (whole call)");
 	int frc = fetch_blocks(mg, hs, tags, g, rcs, verify && !cpu_hash ? (only_rebuilt ? 2 : 1) : 0, block_sums, assemble_early, &changed,
-			       gate, &have_sum);
+			       gate, &have_sum, &assemble_one);
 	if (frc)
 		return frc;
 	tr.lap("fetch");
