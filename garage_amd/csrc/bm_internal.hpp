@@ -150,7 +150,7 @@ inline std::string hex(const Hash &h)
 }
 
 // ------------------------------------------------------------- shard header
-// Same 64-byte layout as garage_amd/block_manager.py::ShardHeader ("<4sBBBBB3xQII32s").
+// 64-byte layout "<4sBBBBB3xQII32s" (tests/patterns.py parses it).
 // The version names the checksum: 3 = MLH64 (GEC_SHARDSUM_MLH64, what a manager over a default codec writes), 2 = BLAKE2b
 // tree mode (rounds 2-4), 1 = plain blake2sum (round 1).  A manager WRITES the version of its codec's checksum kind
 // (gbm_manager::sumver) and reads all three: a shard of another version than its own is verified on the host with that
