@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define GEC_VERSION 0x00030000u /* major.minor.patch = 0.3.0 (0.3: backend argument of gec_codec_create) */
+#define GEC_VERSION 0x00040000u /* major.minor.patch = 0.4.0 (0.4: shard checksum kinds, default MLH64; peer-pointer striped decode; per-block erasure patterns) */
 #define GEC_MAX_SHARDS 256      /* GF(2^8): k + m <= 256 [EXT] */
 
 typedef struct gec_codec gec_codec; /* opaque */
@@ -486,7 +486,7 @@ int gec_blake2sum_batch(const gec_codec *c, size_t n,
  * kernel is written (profiles/r02_valu_probe.txt), 5x the RS encode beside them.  26 independent leaves per
  * shard fill the machine.  Block NAMES remain plain blake2sum: they are Garage's (src/util/data.rs:130-138). */
 #define GEC_SHARDSUM_LEAF 4096
-/* n shards of `len` bytes, shard i at d_base + i*stride; d_out receives 32 bytes each.  Async. */
+/* n shards of `len` bytes, shard i at d_base + i*stride; d_out receives 32 bytes each (the codec's kind).  Async. */
 int gec_shardsum_batch_dev(const gec_codec *c, size_t n, const void *d_base,
 			   size_t stride, size_t len, void *d_out,
 			   void *hip_stream);
@@ -495,9 +495,11 @@ int gec_shardsum_batch(const gec_codec *c, size_t n,
 		       const uint8_t *const *msgs, const size_t *lens,
 		       uint8_t *out);
 
-/* gec_encode_batch + the shardsum of all k+m shards of every block, computed on
+/* gec_encode_batch + the shardsum (of the codec's kind) of all k+m shards of every block, computed on
  * the device while the stripe is resident: shard_sums[(b*(k+m) + j)*32 ..] is the
- * checksum of shard j of block b (data shards as zero-extended to S bytes). */
+ * checksum of shard j of block b (data shards as zero-extended to S bytes).
+ * Kind 3 (MLH64): the kernel that reads the data shards and writes the parity accumulates the leaf sums of all of them from
+ * its registers -- pinned buffers: ONE link kernel + one root kernel, nothing mirrored in HBM, no second pass. */
 int gec_encode_hash_batch(const gec_codec *c, size_t nblocks,
 			  const uint8_t *const *blocks, const size_t *block_len,
 			  size_t S, uint8_t *const *parity, uint8_t *shard_sums);
@@ -526,9 +528,9 @@ int gec_decode_verify_batch(const gec_codec *c, size_t nblocks,
 
 /* Device-resident form: stripes already in HBM (shard j of block b at d_stripes + b*stride + j*S), parity
  * written in place, d_sums (16-byte aligned device memory, nblocks*(k+m)*32 bytes) receives the checksums.
- * Asynchronous: everything is ordered behind / ahead of the work on `hip_stream`; internally the checksums
- * of the k data shards run on a second stream beside the RS kernel (they do not depend on it) and only the
- * m parity checksums follow it. */
+ * Asynchronous: everything is ordered behind / ahead of the work on `hip_stream`.  Kind 3: the encode kernel's SUM form +
+ * the root kernel (BASELINE config 2: 0.29 ms against 0.25 for the encode alone).  Kind 2: the checksums of the k data shards
+ * run on a second stream beside the RS kernel (they do not depend on it), the m parity checksums follow it (1.3 ms). */
 int gec_encode_hash_batch_dev(const gec_codec *c, size_t nblocks, void *d_stripes,
 			      size_t stride, size_t S, void *d_sums,
 			      void *hip_stream);

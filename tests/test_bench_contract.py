@@ -57,6 +57,24 @@ def test_recorded_line_has_the_contract_fields():
     assert "native callers" in d["block_manager"]["batcher_48_threads_put_source"]
 
 
+def test_round5_line_carries_the_put_trip_and_config5s_code():
+    """profiles/r05_bench_line.json = `python bench.py` with no flags on an MI355X (round 5)."""
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")).read().strip().splitlines()[-1])
+    for k, t in TOP.items():
+        assert isinstance(d[k], t), k
+    r = d["roofline"]
+    assert r["algorithmic_bytes_per_launch"] == 1503789056 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] >= r["algorithmic_bytes_per_launch"] and "round 05" in r["traffic_source"]
+    eh, r2 = d["encode_hash"], d["rs20_8_encode"]
+    assert eh["bit_exact"] is True and eh["ms"] <= 0.35 and eh["roofline"]["bound"] == "hbm"                     # VERDICT r04 item 2's bar
+    assert abs(eh["roofline"]["frac"] - eh["roofline"]["algorithmic_bytes_per_launch"] / (eh["ms"] * 1e-3) / 1e9 / 8000) < 2e-3
+    assert 0 < eh["binding_resource"]["valu_busy_frac"] < 1 and 1.0 <= eh["traffic"] / eh["roofline"]["algorithmic_bytes_per_launch"] < 1.05
+    assert r2["bit_exact"] is True and abs(r2["roofline"]["frac"] - 28 * 209728 * 256 / (r2["kernel_ms"] * 1e-3) / 1e9 / 8000) < 2e-3
+    bm = d["block_manager"]
+    assert bm["small_trips"]["get_one_block_healthy_ms"]["rebuilt"] < 0.1 and bm["rpc_get_blocks_GiBps"] >= 35
+    assert "rebuilt" in bm["verify_mode_default"]
+
+
 def test_bench_source_still_emits_every_field():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for key in list(TOP) + ["vs_baseline"] + list(ROOFLINE) + ["traffic", "secondary", "cold_burst_frac", "traffic_source"] + list(CPU) + [

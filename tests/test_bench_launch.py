@@ -131,3 +131,11 @@ def test_gpu_n1_modes_agree():
     for d in (a, b):
         assert d["roofline"]["bound"] == "hbm" and 0.3 < d["roofline"]["frac"] < 1.0
         assert d["roofline"]["cold_burst_frac"] > 0
+    # round 5: the put trip (config 2 + the checksum of every shard) and config 5's code ride in the driver-run line, each checked
+    # against its oracles after its own timed loop
+    eh, r2 = a["encode_hash"], a["rs20_8_encode"]
+    assert eh["bit_exact"] is True and eh["checksums_per_launch"] == 1024 * 14 and eh["roofline"]["algorithmic_bytes_per_launch"] == 1503789056
+    assert eh["ms"] < 2.0 * eh["encode_alone_ms"] and 0.3 < eh["roofline"]["frac"] < a["roofline"]["frac"] + 0.05
+    assert eh["binding_resource"]["valu_busy_frac"] > 0 and eh["traffic"] >= eh["roofline"]["algorithmic_bytes_per_launch"]
+    assert r2["bit_exact"] is True and r2["blocks"] == 256 and r2["shard_len"] == 209728 and 0.3 < r2["roofline"]["frac"] < 1.0
+    assert r2["roofline"]["traffic"] >= r2["roofline"]["algorithmic_bytes_per_launch"] == 28 * 209728 * 256

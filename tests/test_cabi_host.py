@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_version_and_strerror():
-    assert _lib.lib.gec_version() == 0x00030000
+    assert _lib.lib.gec_version() == 0x00040000
     assert _lib.lib.gec_strerror(0) == b"ok"
     assert b"present" in _lib.lib.gec_strerror(_lib.GEC_E_TOO_FEW_PRESENT)
     assert _lib.lib.gec_device_count() >= 0
