@@ -101,7 +101,7 @@ def test_world8_striped_decode_op_at_full_config5_size():
     # (plus the second step both share: the 7 other ranks' rebuilt ranges of the 8 missing shards, padded to the longest range)
     second = 7 * 8 * 256 * (-(-(209728 // 16) // 8)) * 16
     assert d["exchange"]["allgather"]["bytes_received_per_rank"] == 7 * 256 * 4 * 209728 + second
-    assert (d["exchange"]["alltoall"]["bytes_received_per_rank"] - second) * 8 < d["exchange"]["allgather"]["bytes_received_per_rank"] - second
+    assert (d["exchange"]["alltoall"]["bytes_received_per_rank"] - second) * 7 < d["exchange"]["allgather"]["bytes_received_per_rank"] - second   # 1/8 of it (slots padded alike)
     # the peer-pointer form across 8 PROCESSES: every rank maps the 7 others' slot buffers (HIP IPC) and its decode launch reads
     # its byte range of the 20 survivors out of them -- 1/8 of 17-18 remote shards per object instead of 7 ranks' whole slot buffers
     peer = d["exchange"]["peer"]
