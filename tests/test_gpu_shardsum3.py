@@ -156,3 +156,68 @@ def test_truncation_extension_and_leaf_swaps_are_detected():
     assert M.shardsum3(swapped.tobytes()) != s                                                 # same leaf sums, other order
     z = np.zeros(8192, dtype=np.uint8)
     assert M.shardsum3(z.tobytes()) != M.shardsum3(z[:4096].tobytes())
+
+
+def test_a_healthy_get_launches_no_kernel(tmp_path):
+    """Header version 3: the requester's cores check the shards (gec_shardsum_host's arithmetic on the manager's pool), so a healthy
+    rpc_get_blocks / rpc_get_block / streaming get over a HIP codec issues NO device work at all -- asserted under rocprofv3: the
+    traced process only reads (the store was written by another process), and its kernel trace holds no kernel of the library.
+    A degraded get of the same blocks then launches exactly the decode."""
+    import csv
+    import os
+    import subprocess
+    import sys
+
+    rocprof = "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        pytest.skip("rocprofv3 not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    store = tmp_path / "store"
+    common = r'''
+import sys, os
+sys.path.insert(0, %r)
+import garage_amd as g
+from garage_amd import block_native as bn
+from tests.patterns import pattern_block
+dirs = [os.path.join(%r, "node%%d" %% i) for i in range(16)]
+blocks = [pattern_block(1 << 20, 900 + i) for i in range(24)]
+hashes = [bn.blake2sum(b) for b in blocks]
+codec = g.ReedSolomon(10, 4)
+mgr = bn.NativeBlockManager(codec, 16, dirs)
+assert mgr.shard_version == 3
+''' % (root, str(store))
+    r = subprocess.run([sys.executable, "-c", common + "mgr.rpc_put_blocks(list(zip(hashes, blocks)))\nmgr.close()\n"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def traced(body, tag):
+        out = tmp_path / tag
+        rr = subprocess.run([rocprof, "--kernel-trace", "--output-format", "csv", "-d", str(out), "-o", "t", "--", sys.executable, "-c", common + body],
+                            cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=900)
+        assert rr.returncode == 0 and "GETS OK" in rr.stdout, rr.stdout[-1500:] + rr.stderr[-1500:]
+        names = []
+        for dirpath, _, files in os.walk(out):
+            for f in files:
+                if f.endswith("kernel_trace.csv"):
+                    with open(os.path.join(dirpath, f)) as fh:
+                        names += [row["Kernel_Name"] for row in csv.DictReader(fh)]
+        return [x for x in names if "gec::" in x]
+
+    healthy = r'''
+got = mgr.rpc_get_blocks(hashes, 1 << 20)
+assert [bytes(x) for x in got] == blocks
+assert mgr.rpc_get_block(hashes[3]) == blocks[3]
+assert b"".join(mgr.rpc_get_block_streaming(hashes[5])) == blocks[5]
+print("GETS OK")
+'''
+    assert traced(healthy, "healthy") == []
+    degraded = r'''
+for h in hashes[:6]:
+    who = mgr.storage_nodes_of(h)
+    mgr.node_delete_shard(who[2], h, 2)
+mgr.set_verify_block_hash("off")
+got = mgr.rpc_get_blocks(hashes, 1 << 20)
+assert [bytes(x) for x in got] == blocks
+print("GETS OK")
+'''
+    names = traced(degraded, "degraded")
+    assert len(names) == 1 and "gf_apply_ptrs" in names[0], names      # the decode of the six blocks that miss a data shard, nothing else
