@@ -1174,7 +1174,7 @@ int HipBackend::verify_hash_batch(size_t nblocks, const uint8_t *const *shards, 
 	int rc = st.ensure(nblocks * n * 32 + 64, nblocks);
 	if (!rc)
 		rc = st.ensure_tab((nblocks * (k * 12 + m * 8) + 64 * nz) / sizeof(gec::CopyEntry) + 4 * nz + 4);
-	if (!rc)
+	if (!rc && c->sumkind != GEC_SHARDSUM_MLH64)
 		rc = st.ensure_big(2 * (zch * stripe + zch * n * 32));
 	if (!rc)
 		rc = st.ensure_segments(num_cu);
@@ -1186,6 +1186,13 @@ int HipBackend::verify_hash_batch(size_t nblocks, const uint8_t *const *shards, 
 	std::vector<const uint8_t *> in(zch * k);
 	std::vector<uint32_t> valid(zch * k, (uint32_t)S);
 	std::vector<uint8_t *> par(zch * m);
+	// checksum kind 3: the compare form of the link kernel also leaves the leaf sums of the k shards it reads and of the m STORED rows
+	// it checks, from its registers: nothing is mirrored in HBM, the roots follow on the same stream
+	const bool v3 = c->sumkind == GEC_SHARDSUM_MLH64;
+	const uint32_t nleaf_max = (uint32_t)((S + gec::SHARDSUM_LEAF - 1) / gec::SHARDSUM_LEAF);
+	uint8_t *scr = nullptr;
+	if (v3)
+		rc = gecimpl::leaf_scratch(c, up, zch * n * nleaf_max * 8, &scr);
 	for (size_t ci = 0; ci < nz && !rc; ++ci) {
 		const size_t b0 = ci * zch, nb = std::min(zch, nblocks - b0);
 		background_yield(c);
@@ -1194,6 +1201,13 @@ int HipBackend::verify_hash_batch(size_t nblocks, const uint8_t *const *shards, 
 				in[i * k + t] = pinned().dev(shards[(b0 + i) * n + t]);
 			for (size_t r = 0; r < m; ++r)
 				par[i * m + r] = const_cast<uint8_t *>(pinned().dev(shards[(b0 + i) * n + k + r]));
+		}
+		if (v3) {
+			const SumOut so{reinterpret_cast<uint64_t *>(scr), nleaf_max, (uint32_t)n, 0u, true};
+			rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), par.data(), (int)m, S, c->enc.row((int)k), up, nullptr, st.h_bad + b0, 0, nullptr, &so);
+			if (!rc)
+				rc = mlh_roots_dev(c, nb * n, so.lsum, nleaf_max, nullptr, S, st.h_buf + b0 * n * 32, up);
+			continue;
 		}
 		uint8_t *mir = st.d_big + (ci & 1) * (zch * stripe + zch * n * 32);
 		if (ci >= 2 && hipStreamWaitEvent(up, st.ev_seg[2 + (ci & 1)], 0) != hipSuccess)
