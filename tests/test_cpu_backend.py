@@ -430,3 +430,78 @@ print("ok")
     for mode in ("auto", "scalar"):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GEC_CPU_BLAKE2=mode, GBM_CPU_BLAKE2=mode, GEC_CPU_THREADS="3"))
         assert r.returncode == 0 and "ok" in r.stdout, (mode, r.stdout, r.stderr[-2000:])
+
+
+# ------------------------------------------------------------------ round 5: checksum kind 3 and per-block patterns on the host cores
+def test_shardsum3_every_isa_path_agrees_with_the_oracle():
+    """mlh64_host.hpp has an AVX-512, an AVX2 and a scalar form (GEC_CPU_ISA caps which one a process uses): all three -- each in a
+    process of its own -- equal oracle/mlh64.py on lengths around every word, vector and leaf boundary."""
+    import subprocess
+    import sys
+
+    code = r'''
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, %r)
+from garage_amd import _lib
+from oracle import mlh64
+rng = np.random.default_rng(8)
+for n in [0, 1, 3, 4, 5, 31, 32, 33, 63, 64, 65, 4092, 4093, 4095, 4096, 4097, 4160, 8191, 8192, 104896, 300001]:
+    d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    out = ctypes.create_string_buffer(32)
+    assert _lib.lib.gec_shardsum_host(3, d, n, out) == 0 and out.raw == mlh64.shardsum3(d), n
+    assert _lib.lib.gec_shardsum_host(2, d, n, out) == 0 and out.raw != mlh64.shardsum3(d)
+assert _lib.lib.gec_shardsum_host(7, b"x", 1, out) == _lib.GEC_E_INVALID_ARG
+print("ok")
+''' % ROOT
+    for isa in ("auto", "avx2", "scalar"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GEC_CPU_ISA=isa), timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, (isa, r.stdout, r.stderr[-1500:])
+
+
+def test_cpu_codec_checksum_kinds_and_siblings():
+    from oracle import mlh64
+
+    rs = g.ReedSolomon(10, 4, backend="cpu")
+    assert rs.shardsum_kind == 3 and rs.background().shardsum_kind == 3
+    rs2 = rs.with_shardsum(2)
+    assert rs2.shardsum_kind == 2 and rs2.background().shardsum_kind == 2 and rs2.with_shardsum(3).shardsum_kind == 3
+    blocks = [bytes(O.splitmix64_bytes(40 + i, n)) for i, n in enumerate([1 << 20, 70_001, 0, 4096 * 10])]
+    S = g.shard_len(10, 1 << 20)
+    p3, s3 = rs.encode_hash_blocks(blocks, S)
+    p2, s2 = rs2.encode_hash_blocks(blocks, S)
+    for b, blk in enumerate(blocks):
+        shards = O.split_block(10, blk, S)
+        assert np.array_equal(p3[b], p2[b])
+        for j in range(14):
+            payload = (shards[j] if j < 10 else p3[b][j - 10]).tobytes()
+            assert s3[b, j].tobytes() == mlh64.shardsum3(payload) and s2[b, j].tobytes() == g.shardsum(payload, 2)
+    h = ctypes.c_void_p()
+    assert _lib.lib.gec_codec_create_ex2(10, 4, _lib.GEC_BACKEND_CPU, 0, 0, 5, ctypes.byref(h)) == _lib.GEC_E_INVALID_ARG   # no such kind
+    assert _lib.lib.gec_codec_with_shardsum(None, 3, ctypes.byref(h)) == _lib.GEC_E_INVALID_ARG and _lib.lib.gec_codec_shardsum(None) == -1
+
+
+@pytest.mark.parametrize("k,m,S,nb", [(10, 4, 4160, 40), (3, 1, 64, 9), (10, 12, 1088, 12)])
+def test_reconstruct_dev_ex_on_host_memory(coracle, k, m, S, nb):
+    """gec_reconstruct_batch_dev_ex over a CPU codec: the strided call on HOST memory, an erasure pattern per block."""
+    import torch
+
+    rs = g.ReedSolomon(k, m, backend="cpu")
+    rng = np.random.default_rng(k + S)
+    data = rng.integers(0, 256, (nb, k, S), dtype=np.uint8)
+    full = np.concatenate([data, coracle.encode_batch(k, m, data, coracle.AVX2)], axis=1)
+    pres = np.ones((nb, k + m), dtype=np.uint8)
+    for b in range(1, nb):
+        pres[b, rng.choice(k + m, size=int(rng.integers(0, m + 1)), replace=False)] = 0
+    for data_only in (False, True):
+        broken = full.copy()
+        broken[pres == 0] = 0xEE
+        st = torch.from_numpy(broken.copy())
+        rs.reconstruct_dev_ex(st, pres, data_only=data_only)
+        for b in range(nb):
+            assert np.array_equal(st[b].numpy(), O.reconstruct(k, m, broken[b], pres[b], data_only=data_only)), (b, data_only)
+    bad = pres.copy()
+    bad[2, :m + 1] = 0
+    with pytest.raises(g.GecError) as ei:
+        rs.reconstruct_dev_ex(torch.from_numpy(full.copy()), bad)
+    assert ei.value.code == _lib.GEC_E_TOO_FEW_PRESENT
