@@ -1337,10 +1337,13 @@ int HipBackend::reconstruct_batch(size_t nblocks, const uint8_t *const *shards, 
 		}
 		const size_t zch = std::min(zch_cap, std::max<size_t>(max_ids, 1));
 		const size_t half = zch * n * S + zch * n * 32;
+		// checksum kind 3: the link kernel leaves the leaf sums of what it reads and writes itself (SUM form): no mirror, one stream
+		const bool v3 = sums && c->sumkind == GEC_SHARDSUM_MLH64;
+		const uint32_t nleaf_max = (uint32_t)((S + gec::SHARDSUM_LEAF - 1) / gec::SHARDSUM_LEAF);
 		int rc = st.ensure(sums ? sum_bytes + 64 : 64, 0);
 		if (!rc)
 			rc = st.ensure_tab(tab_bytes / sizeof(gec::CopyEntry) + 4 * (work.size() + nchunks_total) + 4);
-		if (!rc && sums)
+		if (!rc && sums && !v3)
 			rc = st.ensure_big(2 * half);
 		if (!rc && sums)
 			rc = st.ensure_segments(num_cu);
@@ -1348,6 +1351,9 @@ int HipBackend::reconstruct_batch(size_t nblocks, const uint8_t *const *shards, 
 			return rc;
 		hipStream_t up = sums && st.stream_up ? st.stream_up : st.stream;
 		hipStream_t chain = sums && st.stream_chain ? st.stream_chain : st.stream2;
+		uint8_t *scr = nullptr;
+		if (v3)
+			rc = gecimpl::leaf_scratch(c, up, zch * n * nleaf_max * 8, &scr);
 		size_t q = 0, sum_off = 0;  // running chunk number, running offset into the pinned checksum area
 		std::vector<size_t> sum_base(work.size());
 		for (size_t wi = 0; wi < work.size() && !rc; ++wi) {
@@ -1372,6 +1378,15 @@ int HipBackend::reconstruct_batch(size_t nblocks, const uint8_t *const *shards, 
 						in[i * k + t] = pinned().dev(shards[ids[i0 + i] * n + w.plan->valid[t]]);
 					for (size_t r = 0; r < nmiss; ++r)
 						outp[i * nmiss + r] = pinned().dev(out[ids[i0 + i] * n + w.plan->missing[r]]);
+				}
+				if (v3) {
+					const SumOut so{reinterpret_cast<uint64_t *>(scr), nleaf_max, (uint32_t)per, 0u, true};
+					rc = launch_apply_ptrs(c, st, nb, in.data(), valid.data(), outp.data(), (int)nmiss, S, w.plan->rows.v.data(), up, nullptr, nullptr, 0,
+							       nullptr, &so);
+					if (!rc)
+						rc = mlh_roots_dev(c, nb * per, so.lsum, nleaf_max, nullptr, S, st.h_buf + sum_off, up);
+					sum_off += nb * per * 32;
+					continue;
 				}
 				uint8_t *mir = sums ? st.d_big + (q & 1) * half : nullptr;
 				if (sums && q >= 2 && hipStreamWaitEvent(up, st.ev_seg[2 + (q & 1)], 0) != hipSuccess)
