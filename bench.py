@@ -828,28 +828,15 @@ def run_procs(args) -> None:
     # ---- BASELINE config 5 beside it when there is more than one GPU (or on request): the path's one
     # real exchange step.  Guarded by a watchdog so that a collective that hangs cannot take the
     # headline line with it.
-    striped_failed = False
+    # Every rank runs it in a CHILD process (its own process group on another port): the exchanges have never met N > 1 hardware, and
+    # neither a collective that hangs (the child's watchdog), nor one that cannot start, nor a process that dies inside RCCL or on
+    # a peer's memory may take the headline line -- which is not printed yet -- with it.
     # (GARAGE_DRYRUN_ONE_GPU=1: the same flow over a gloo-backed caller transport, labelled as such in the object)
     if (world > 1 and not args.no_striped) or args.striped:
-        box = {}
-        done = threading.Event()
-
-        def emit_and_exit():
-            if not done.wait(args.striped_timeout):
-                if rank == 0:
-                    out["striped_decode"] = {"error": f"no result within {args.striped_timeout:.0f} s (watchdog)", **box}
-                    print(json.dumps(out), flush=True)
-                os._exit(0)
-
-        threading.Thread(target=emit_and_exit, daemon=True).start()
-        try:
-            res = striped_decode_bench(args, R, distrib, box)
-        except Exception as e:  # noqa: BLE001 -- reported in the line, the headline number stands
-            res = {"error": f"{type(e).__name__}: {e}"[:400], **box}
-            striped_failed = True
-        done.set()
+        res = striped_decode_in_children(args, R)
         if rank == 0:
             out["striped_decode"] = res
+        barrier()
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
@@ -857,11 +844,6 @@ def run_procs(args) -> None:
         if world == 1 and not args.no_host_path:
             out.update(host_path_objects())
         print(json.dumps(out), flush=True)
-    if striped_failed:
-        # a rank that fell out of the striped decode may have left its peers inside a collective: the line is out,
-        # do not wait for them in the process group's teardown
-        sys.stdout.flush()
-        os._exit(0)
     distrib.shutdown(R)
 
 
@@ -1064,6 +1046,45 @@ def threads_group_check(world: int, dry: bool) -> dict:
             "bit_exact": all(oks), "bit_exact_objects": nobj, "bit_exact_against": "stripes encoded by the CPU oracle; all three exchanges (all-gather, all-to-all, peer pointers), every rank",
             "allgather_decode_ms": round(max(times) * 1e3, 3),
             "config": {"workload": f"BASELINE config 5 check: RS(20,8), {nobj} x 4 MiB objects striped over {world} ranks, 8 erasures", "shard_len": S}}
+
+
+def child_group_env(parent_env, rank: int, world: int, port: int) -> dict:
+    """The environment of a rank's child that forms a process group of its own.  torch.distributed.run's agent variables must NOT
+    travel: with TORCHELASTIC_USE_AGENT_STORE set, env:// rendezvous expects the AGENT to host the store at MASTER_PORT and rank 0
+    never starts one -- on a port of our own every child would wait for a server that nobody runs."""
+    env = {k: v for k, v in parent_env.items() if not k.startswith("TORCHELASTIC_") and k not in ("GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE")}
+    env.update(RANK=str(rank), LOCAL_RANK=parent_env.get("LOCAL_RANK", "0"), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=parent_env.get("LOCAL_WORLD_SIZE", str(world)),
+               MASTER_ADDR=parent_env.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port), GARAGE_BENCH_CHILD="1")
+    return env
+
+
+def striped_decode_in_children(args, R) -> dict:
+    """`bench.py --op striped-decode` as a child process of every rank, with the ranks' own RANK / LOCAL_RANK / WORLD_SIZE and a
+    process group of its own (MASTER_PORT + 23); rank 0's child prints the object, which is returned on rank 0 (other ranks: {}).
+    Whatever happens to a child -- a watchdog exit, a non-zero return code, a signal, no output -- becomes an `error` entry."""
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 23 if R.distributed else free_port()
+    env = child_group_env(os.environ, R.rank, R.world, port)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(R.world), "--op", "striped-decode", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--striped-objects", str(args.striped_objects), "--striped-timeout", str(args.striped_timeout), "--collective", args.collective]
+    if args.striped_steps:
+        cmd += ["--striped-steps", str(args.striped_steps)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.striped_timeout + 60)
+    except subprocess.TimeoutExpired:
+        return {"error": f"the striped-decode child did not end within {args.striped_timeout + 60:.0f} s"}
+    except OSError as e:
+        return {"error": f"could not start the striped-decode child: {e}"[:300]}
+    if R.rank != 0:
+        return {}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"striped-decode child: rc {r.returncode}, {len(lines)} JSON lines; stderr tail: {r.stderr[-300:]}"}
+    try:
+        res = json.loads(lines[-1])
+    except ValueError as e:
+        return {"error": f"striped-decode child printed no JSON: {e}"[:200]}
+    res["ran_in"] = "a child process per rank (own process group): a failure in here cannot cost the encode line"
+    return res
 
 
 # ------------------------------------------------------------------ BASELINE config 5

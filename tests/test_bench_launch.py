@@ -58,6 +58,19 @@ def test_world_size_mismatch_is_an_error():
     assert r.returncode != 0 and "does not match --gpus" in (r.stderr + r.stdout)
 
 
+def test_a_ranks_child_group_gets_a_rendezvous_of_its_own():
+    """The striped decode runs in a child process per rank with its own process group (so that nothing in there can cost the encode
+    line).  Under torch.distributed.run the parent's environment says "the agent hosts the store": that must not reach the child."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    parent = {"TORCHELASTIC_USE_AGENT_STORE": "True", "TORCHELASTIC_RUN_ID": "x", "GROUP_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29500",
+              "RANK": "3", "LOCAL_RANK": "3", "WORLD_SIZE": "8", "LOCAL_WORLD_SIZE": "8", "PATH": "/bin", "GARAGE_DRYRUN_ONE_GPU": "1"}
+    env = bench.child_group_env(parent, 3, 8, 29523)
+    assert not [k for k in env if k.startswith("TORCHELASTIC_")] and "GROUP_RANK" not in env
+    assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_PORT"], env["GARAGE_DRYRUN_ONE_GPU"]) == ("3", "3", "8", "29523", "1")
+
+
 SMALL = ["--steps", "5", "--warmup", "2", "--precondition-ms", "0", "--batch", "64", "--no-cpu-baseline"]
 
 
