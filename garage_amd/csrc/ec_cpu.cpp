@@ -4,8 +4,8 @@
 // Why it exists (SURVEY.md Appendix B's `backend` argument, BASELINE config 1): a Garage node that has no GPU, or has
 // lost it, must still be able to read and repair its erasure-coded blocks; and the insertion point of the codec is a
 // blocking call on a tokio blocking-pool thread either way (src/block/block.rs:85-96), so the caller does not care
-// which backend answers.  It is not the product's fast path and it is never used behind a HIP codec's back (the one
-// opt-in exception: GEC_SMALL_CALL_BLOCKS, ec_hip_host.cpp).  Nothing here includes, links or calls anything under
+// which backend answers.  It is not the product's fast path and it is never used behind a HIP codec's back: a HIP codec
+// computes Reed-Solomon on the device or fails (round 5 removed the one opt-in detour there was).  Nothing here includes, links or calls anything under
 // oracle/ -- the oracle checks this backend exactly like it checks the kernels (tests/test_cpu_backend.py).
 //
 // The arithmetic: out[r] = XOR_t coef[r][t] * in[t] over GF(2^8)/0x11D, the same product the kernels compute

@@ -21,7 +21,6 @@ const Row kRows[] = {
 	{"GEC_CPU_THREADS", "min(cores, 16)", "threads a CPU codec spreads one call over (1 = the calling thread only)"},
 	{"GEC_CPU_ISA", "auto", "CPU backend kernel: auto, gfni (AVX-512 + GFNI), avx2 (split-nibble vpshufb) or scalar; the host form of shard checksum v3 follows it (AVX-512 / AVX2 / scalar)"},
 	{"GEC_CPU_BLAKE2", "auto", "host-side BLAKE2b (CPU backend, libgarage_block's own hashes): auto = eight messages at a time with AVX-512, scalar = one at a time (A/B)"},
-	{"GEC_SMALL_CALL_BLOCKS", "0", "a HIP codec answers pageable host-pointer encode / reconstruct calls of up to this many blocks on the host cores (0 = never)"},
 	{"GEC_MAX_CALLS", "4", "host-pointer calls in flight per HIP codec; further callers wait (0 = no limit: every concurrent call gets staging slots and device queues of its own)"},
 	{"GEC_COPY_THREADS", "7", "staging-copy threads per HIP codec for pageable caller memory (0 = copy on the calling thread)"},
 	{"GEC_ZERO_COPY", "1", "A/B: 0 = pinned caller memory goes through the device staging pipeline instead of being read in place"},
@@ -68,7 +67,6 @@ const Env &env()
 			mlh::isa_cap().store(1);
 		if (get("GEC_CPU_BLAKE2") && get("GEC_CPU_BLAKE2")[0] == 's')
 			b2host::mb_mode().store(0);
-		v.small_call_blocks = (size_t)std::max<long>(get_long("GEC_SMALL_CALL_BLOCKS", 0), 0);
 		v.max_calls = (unsigned)std::max<long>(get_long("GEC_MAX_CALLS", 4), 0);
 		v.copy_threads = get("GEC_COPY_THREADS") ? (unsigned)std::min<unsigned long>(std::strtoul(get("GEC_COPY_THREADS"), nullptr, 0), 64ul)
 							 : std::min(7u, hw - 1);

@@ -14,7 +14,6 @@ struct Env {
 	// ---- both backends
 	int cpu_threads;        // GEC_CPU_THREADS: worker threads of a CPU codec (0 = the calling thread only)
 	std::string cpu_isa;    // GEC_CPU_ISA: auto | gfni | avx2 | scalar
-	size_t small_call_blocks;  // GEC_SMALL_CALL_BLOCKS: a HIP codec answers pageable host-pointer calls of up to this many blocks on the host cores
 	// ---- HIP backend: host-pointer paths
 	unsigned copy_threads;  // GEC_COPY_THREADS
 	bool zero_copy;         // GEC_ZERO_COPY

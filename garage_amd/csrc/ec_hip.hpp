@@ -187,11 +187,6 @@ struct HipBackend : Backend {
 	mutable std::unique_ptr<ForkJoinPool> copy_threads;
 	ForkJoinPool &copy_pool() const;
 
-	// small pageable calls answered on the host cores (GEC_SMALL_CALL_BLOCKS): created on first use
-	mutable std::once_flag cpu_once;
-	mutable std::unique_ptr<Backend> cpu_helper;
-	Backend *small_call_helper() const;
-
 	~HipBackend() override;
 
 	int encode_batch(size_t nblocks, const uint8_t *const *blocks, const size_t *block_len, size_t S, uint8_t *const *parity,

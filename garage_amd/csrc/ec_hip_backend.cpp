@@ -167,18 +167,6 @@ ForkJoinPool &HipBackend::copy_pool() const
 	return *copy_threads;
 }
 
-Backend *HipBackend::small_call_helper() const
-{
-	if (env().small_call_blocks == 0)
-		return nullptr;
-	std::call_once(cpu_once, [this] {
-		std::unique_ptr<Backend> be;
-		if (make_cpu_backend(const_cast<gec_codec *>(c), be) == GEC_OK)
-			cpu_helper = std::move(be);
-	});
-	return cpu_helper.get();
-}
-
 HipBackend::~HipBackend()
 {
 	if (qos.background)

@@ -23,11 +23,6 @@ int HipBackend::encode_batch(size_t nblocks, const uint8_t *const *blocks, const
 	for (size_t b = 0; b < nblocks && all_pinned; ++b)
 		all_pinned = aligned16(blocks[b]) && aligned16(parity[b]) && pinned().contains(blocks[b], block_len[b]) &&
 			     pinned().contains(parity[b], m * S);
-	// a handful of blocks in ordinary memory: a host core is done before a staged device trip has started
-	// (one 1 MiB block: 57 us on one AVX2 core against 94 us; profiles/r02_host_api_latency.txt).  Off by default.
-	if (!all_pinned && !shard_sums && nblocks <= env().small_call_blocks)
-		if (Backend *cpu = small_call_helper())
-			return cpu->encode_batch(nblocks, blocks, block_len, S, parity, nullptr);
 	if (all_pinned && k <= (size_t)gec::PTR_KMAX && env().zero_copy) {
 		// every buffer is device-addressable: ONE kernel reads the data shards and writes the parity in place
 		// over the link; nothing is staged in HBM, no host copy.  With checksums requested the same kernel also
@@ -1264,16 +1259,6 @@ int HipBackend::reconstruct_batch(size_t nblocks, const uint8_t *const *shards, 
 			return fail(GEC_E_TOO_FEW_PRESENT, "fewer than k shards present");
 		if (nwanted)
 			buckets[key].push_back(b);
-	}
-	// a handful of blocks in ordinary memory: the host cores are done before a staged device trip has started
-	// (GEC_SMALL_CALL_BLOCKS, off by default)
-	if (!in_sums && nblocks <= env().small_call_blocks) {
-		bool any_pinned = false;
-		for (size_t i = 0; i < nblocks * n && !any_pinned; ++i)
-			any_pinned = shards[i] && pinned().contains(shards[i], S);
-		if (!any_pinned)
-			if (Backend *cpu = small_call_helper())
-				return cpu->reconstruct_batch(nblocks, shards, out, S, data_only, nullptr, nullptr);
 	}
 	ForkJoinPool &pool = copy_pool();
 	// one decode plan per bucket, cut down to the rows the caller wants
