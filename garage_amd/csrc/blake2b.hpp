@@ -354,6 +354,49 @@ __device__ __forceinline__ void b2q_compress(uint64_t &ha, uint64_t &hb, const u
 	b2q_compress_off<(ODD ? B2Q_SLOT1 : 0u), (ODD ? 0u : B2Q_SLOT1)>(ha, hb, wa, q, t, last, x, y, last_node);
 }
 
+// `nblk` blocks of a message that lies in LDS at byte address `msg`, four lanes per message (lane q owns column q of the
+// 4x4 state), with blake2b.hpp's compression: the message words of a round gathered a round ahead, the first words of the
+// NEXT block during the last round of the current one, (a + x) formed off the dependency chain.  wa[r][i] = LDS address of
+// the word this lane needs at round r of block 0; two blocks per trip (immediate offsets 0 / 128 / 256 on the ds_reads),
+// then all forty addresses move on by 256.  t_before = bytes of the message hashed before these blocks; `finishes`: the
+// message (total_len bytes) ends with them.  (The look-ahead reads up to 128 bytes past the last block: LDS, harmless.)
+__device__ __forceinline__ void b2q_hash_lds(uint64_t &ha, uint64_t &hb, uint32_t msg, uint32_t nblk, uint64_t t_before,
+					     uint64_t total_len, bool finishes, bool last_node, uint32_t q)
+{
+	constexpr B2QSchedule SCH = b2q_schedule();
+	const uint32_t q7 = q * 7;
+	uint32_t wa[10][4];
+#pragma unroll
+	for (int r = 0; r < 10; ++r)
+#pragma unroll
+		for (int w = 0; w < 4; ++w) {
+			wa[r][w] = msg + __builtin_amdgcn_ubfe(SCH.w[r][w], q7, 7);
+			asm("" : "+v"(wa[r][w]));  // opaque: otherwise the sums are re-formed inside the loop
+		}
+	uint64_t x = *reinterpret_cast<lds_u64_t *>(wa[0][0]), y = *reinterpret_cast<lds_u64_t *>(wa[0][1]);
+	uint32_t i = 0;
+	// pairs with nothing to decide: neither block is the message's last
+	const uint32_t plain = finishes ? (nblk ? nblk - 1 : 0) : nblk;  // blocks that are certainly not final
+	for (; i + 2 <= plain; i += 2) {
+		b2q_compress_off<0, 128>(ha, hb, wa, q, t_before + 128ull * (i + 1), false, x, y);
+		b2q_compress_off<128, 256>(ha, hb, wa, q, t_before + 128ull * (i + 2), false, x, y);
+#pragma unroll
+		for (int r = 0; r < 10; ++r)
+#pragma unroll
+			for (int w = 0; w < 4; ++w)
+				wa[r][w] += 256;
+	}
+	for (; i < nblk; ++i) {  // the last one or two
+		const bool last = finishes && i + 1 == nblk;
+		b2q_compress_off<0, 128>(ha, hb, wa, q, last ? total_len : t_before + 128ull * (i + 1), last, x, y, last_node);
+#pragma unroll
+		for (int r = 0; r < 10; ++r)
+#pragma unroll
+			for (int w = 0; w < 4; ++w)
+				wa[r][w] += 128;
+	}
+}
+
 // Lane q's 32-byte quarter of the 128-byte block that starts at byte `off` of a `len`-byte message,
 // zero beyond the end; never reads past p + len.  Full quarters (all but a message's tail) are two
 // 16-byte streaming loads.

@@ -175,6 +175,18 @@ size_t sum_lds_bytes(const Geometry &g, int k, int nsl)
 	return ((g.lds + 15) & ~(size_t)15) + gec::mlh_lds_bytes(cap, g.threads / 64, nsl) - g.lds;
 }
 
+
+// The roots of `a.n` shards from their leaf sums: four lanes per shard while a shard's message fits the workgroup's LDS (every
+// geometry of the BASELINE configs: 26 and 52 leaves), one lane per shard beyond.
+int launch_mlh_roots(const gec::Blake2Args &a, uint32_t nleaf_max, const uint64_t *lsum, const uint32_t *slot_map, hipStream_t stream)
+{
+	if (gec::mlh_roots_quad_fits(nleaf_max))
+		hipLaunchKernelGGL(gec::mlh_roots_quad, dim3((a.n + 15) / 16), dim3(64), gec::mlh_rootq_lds_bytes(nleaf_max), stream, a, nleaf_max, lsum, slot_map);
+	else
+		hipLaunchKernelGGL(gec::mlh_roots, dim3((a.n + 63) / 64), dim3(64), 0, stream, a, nleaf_max, lsum, slot_map);
+	HIP_TRY(hipGetLastError());
+	return GEC_OK;
+}
 }  // namespace
 
 // out[r] = XOR_t coef[r][t] * in[t] for r < nout: shard t of block b is read at
@@ -351,10 +363,7 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 			return rc;
 		hipLaunchKernelGGL(gec::mlh_leaves, dim3((unsigned)((leaves + 3) / 4)), dim3(256), 0, stream, a, nleaf_max, reinterpret_cast<uint64_t *>(scratch));
 		HIP_TRY(hipGetLastError());
-		hipLaunchKernelGGL(gec::mlh_roots, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a, nleaf_max,
-				   reinterpret_cast<const uint64_t *>(scratch), static_cast<const uint32_t *>(nullptr));
-		HIP_TRY(hipGetLastError());
-		return GEC_OK;
+		return launch_mlh_roots(a, nleaf_max, reinterpret_cast<const uint64_t *>(scratch), nullptr, stream);
 	}
 	if (tree) {
 		const size_t longest = d_len ? max_len : len;
@@ -510,9 +519,7 @@ int mlh_roots_dev(const gec_codec *c, size_t n, const uint64_t *lsum, uint32_t n
 	a.group = group;
 	a.group_stride = 0;
 	a.out_group = out_group;
-	hipLaunchKernelGGL(gec::mlh_roots, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a, nleaf_max, lsum, slot_map);
-	HIP_TRY(hipGetLastError());
-	return GEC_OK;
+	return launch_mlh_roots(a, nleaf_max, lsum, slot_map, stream);
 }
 
 // Grid of a tile-walking kernel (gf_apply_ptrs, copy_table) on a CU-masked stream: no more workgroups than the

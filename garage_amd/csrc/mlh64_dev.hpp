@@ -213,4 +213,48 @@ __global__ __launch_bounds__(64) void mlh_roots(const Blake2Args a, uint32_t nle
 	o[1] = u64x2{h[2], h[3]};
 }
 
+// ---------------------------------------------------------------------------
+// mlh_roots_quad: FOUR lanes per shard (blake2b.hpp's quad layout: lane q owns column q of the 4x4 state).  The root of a
+// handful of shards -- one put's 14, a PutObject's 42 -- is one lone wave's dependency chain however idle the chip is:
+// two compressions of ~2700 dependent VALU instructions with one lane per shard (9.6 us), a quarter of that with the G
+// functions of a step in four lanes.  The message (16 + 8 * nleaf bytes) is staged in LDS whole, zero-padded to whole
+// blocks, at a pitch of 128 * nblk_max + 16 bytes per quad (the 16: the quads' reads of the same word fall into different
+// banks); the last quad's look-ahead reads run into the 144 spare bytes the launch adds.  Same results as mlh_roots, which
+// stays for shards too long for LDS (the launch picks: mlh_roots_quad_fits).
+// ---------------------------------------------------------------------------
+constexpr uint32_t MLH_ROOTQ_MAX_BLOCKS = 24;  // 16 quads x (24 x 128 + 16) = 48.25 KiB of LDS; shards up to 1.49 MiB
+__host__ __device__ constexpr uint32_t mlh_rootq_blocks(uint32_t nleaf) { return (2 + nleaf + 15) / 16; }  // >= 1: an empty shard's message is the 16-byte header
+__host__ __device__ constexpr uint32_t mlh_rootq_pitch(uint32_t nleaf_max) { return 128u * mlh_rootq_blocks(nleaf_max) + 16u; }
+__host__ __device__ constexpr uint32_t mlh_rootq_lds_bytes(uint32_t nleaf_max) { return 16u * mlh_rootq_pitch(nleaf_max) + 144u; }
+__host__ __device__ constexpr bool mlh_roots_quad_fits(uint32_t nleaf_max) { return mlh_rootq_blocks(nleaf_max) <= MLH_ROOTQ_MAX_BLOCKS; }
+
+__global__ __launch_bounds__(64) void mlh_roots_quad(const Blake2Args a, uint32_t nleaf_max, const uint64_t *__restrict__ lsum,
+						     const uint32_t *__restrict__ slot_map)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t mlh_rootq_lds[];
+	typedef __attribute__((address_space(3))) uint64_t lds_u64_w;
+	const uint32_t tid = threadIdx.x, quad = tid >> 2, q = tid & 3;
+	const uint32_t i = blockIdx.x * 16 + quad;
+	const bool live = i < a.n;
+	const uint32_t ii = live ? i : a.n - 1;  // dead quads shadow the last shard (no stores)
+	const uint64_t slen = a.len ? a.len[ii] : a.uniform_len;
+	const uint32_t nleaf = (uint32_t)((slen + mlh::LEAF_BYTES - 1) / mlh::LEAF_BYTES);
+	const uint64_t *sums = lsum + (uint64_t)(slot_map ? slot_map[ii] : ii) * nleaf_max;
+	const uint32_t nblk = mlh_rootq_blocks(nleaf), words = 16 * nblk;
+	const uint32_t msg = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)mlh_rootq_lds + quad * mlh_rootq_pitch(nleaf_max);
+	// word w of the message: 0 = magic, 1 = length, 2 + j = leaf sum j, zero beyond; lane q stages words q, q + 4, ...
+	for (uint32_t w = q; w < words; w += 4) {
+		const uint64_t v = w == 0 ? mlh::ROOT_MAGIC : w == 1 ? slen : (w - 2 < nleaf ? sums[w - 2] : 0);
+		*reinterpret_cast<lds_u64_w *>(msg + 8 * w) = v;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	uint64_t ha = q == 0 ? (0x6a09e667f3bcc908ULL ^ 0x01010040ULL) : q == 1 ? 0xbb67ae8584caa73bULL : q == 2 ? 0x3c6ef372fe94f82bULL : 0xa54ff53a5f1d36f1ULL;
+	uint64_t hb = q == 0 ? 0x510e527fade682d1ULL : q == 1 ? 0x9b05688c2b3e6c1fULL : q == 2 ? 0x1f83d9abfb41bd6bULL : 0x5be0cd19137e2179ULL;
+	b2q_hash_lds(ha, hb, msg, nblk, 0, mlh::ROOT_HEADER_BYTES + 8ull * nleaf, true, false, q);
+	if (live)
+		reinterpret_cast<uint64_t *>(b2_out_ptr(a, i))[q] = ha;  // h[0..3]: the first 32 bytes of the digest, 8 per lane
+}
+
 }  // namespace gec

@@ -44,6 +44,17 @@ def test_host_buffers_of_ragged_lengths(torch_mod):
         assert out.raw == M.shardsum3(x), len(x)
 
 
+def test_shards_too_long_for_the_four_lane_roots(torch_mod):
+    """The root kernel gives a shard four lanes while its message (16 + 8 bytes per leaf) fits the workgroup's LDS -- shards up to
+    1.49 MiB -- and one lane beyond; a call's longest shard decides for the call.  Both sides of the limit, and the limit itself."""
+    rs = g.ReedSolomon(10, 4)
+    rng = np.random.default_rng(31)
+    edge = (24 * 16 - 2) * 4096                       # 382 leaves: the last length with four lanes
+    for lens in ([0, 5000, edge - 1, edge], [0, 5000, edge + 1], [17, 1 << 21, (1 << 21) + 4097]):
+        msgs = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in lens]
+        assert rs.shardsum_batch(msgs) == [M.shardsum3(x) for x in msgs], lens
+
+
 def test_pinned_buffers_are_read_in_place(torch_mod):
     from garage_amd.codec import host_alloc, host_free
 

@@ -127,6 +127,9 @@ int main(int argc, char **argv)
 		printf("put, a PutObject's three in flight:       median %.3f ms for the three\n", median(l3, NP / 3));
 	}
 
+	if (argc > 3 && strcmp(argv[3], "puts") == 0)  /* an A/B of the put trip: the first section only */
+		return 0;
+
 	/* ---- single gets */
 	uint8_t *out = malloc(4u << 20);
 	int who[14];
