@@ -1140,22 +1140,40 @@ def striped_decode_bench(args, R, distrib, progress=None) -> dict:
     from garage_amd.group import ipc_close, ipc_export, ipc_open
 
     def open_peers(t):
-        """-> (pointer per rank, pointers to close)"""
+        """-> (pointer per rank, pointers to close).  Control flow stays collective: a rank that cannot export its buffer or map a
+        peer's (first contact with N > 1 hardware) says so in the exchange, and then EVERY rank gives the peer form up -- one rank
+        raising alone would leave the others inside the decode's barriers until the watchdog."""
         if grp is None:
             return None, []
         if R.world == 1:
             return [t.data_ptr()], []
         torch.cuda.synchronize()
+        err = None
+        try:
+            if os.environ.get("GARAGE_BENCH_PEER_FAIL_RANK") == str(R.rank):  # (fault injection: tests/test_world8_rehearsal.py)
+                raise RuntimeError("injected: this rank cannot export its buffer")
+            mine_h = ipc_export(t)
+        except Exception as e:  # noqa: BLE001
+            mine_h, err = None, f"export: {type(e).__name__}: {e}"
         handles = [None] * R.world
-        dist.all_gather_object(handles, ipc_export(t))
+        dist.all_gather_object(handles, mine_h)
         ptrs, opened = [], []
         for q in range(R.world):
             if q == R.rank:
                 ptrs.append(t.data_ptr())
-            else:
-                p_ = ipc_open(handles[q], R.device.index or 0)
-                ptrs.append(p_)
-                opened.append(p_)
+            elif err is None and handles[q] is not None:
+                try:
+                    p_ = ipc_open(handles[q], R.device.index or 0)
+                    ptrs.append(p_)
+                    opened.append(p_)
+                except Exception as e:  # noqa: BLE001
+                    err = f"open rank {q}'s buffer: {type(e).__name__}: {e}"
+            elif err is None:
+                err = f"rank {q} could not export its buffer"
+        bad = distrib.sum_over_ranks(R, int(err is not None))
+        if bad:
+            close_peers(opened)
+            raise RuntimeError(f"{bad} of {R.world} ranks could not map their peers' buffers ({err or 'this rank could'})"[:280])
         return ptrs, opened
 
     def close_peers(opened):

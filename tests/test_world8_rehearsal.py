@@ -123,6 +123,16 @@ def test_headline_survives_a_rank_that_never_reaches_the_collective():
     assert "watchdog" in d["striped_decode"]["error"]
 
 
+@pytest.mark.gpu
+def test_a_rank_that_cannot_map_its_peers_costs_only_the_peer_form():
+    """The peer-pointer exchange needs HIP IPC mappings between the ranks -- the one step of the striped decode that has only ever
+    run on one device.  A rank that fails there says so inside the exchange of handles, every rank drops the peer form together,
+    and the all-gather / all-to-all figures and their oracle checks are reported as usual (no watchdog, no hang)."""
+    d = _run(_torchrun(2, "--op", "striped-decode", "--striped-objects", "16", "--steps", "20"), dict(DRY, GARAGE_BENCH_PEER_FAIL_RANK="1"))
+    assert d["bit_exact"] is True and d["exchange"]["alltoall"]["bit_exact"] is True
+    assert "could not map" in d["exchange"]["peer"]["error"], d["exchange"]["peer"]
+
+
 def test_the_recorded_rehearsal_is_complete():
     """profiles/r05_world8_rehearsal.txt (tools/world8_rehearsal.py on one MI355X): N = 2, 4, 8 x four invocations, the N = 1
     line and both fault injections -- every one rc 0, one JSON line, within its 300 s."""
