@@ -589,7 +589,7 @@ def encode_hash_object(args, job) -> dict:
                      "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": ab,
                      "note": "same algorithmic bytes as the encode (read k*S, write m*S): the checksums read nothing twice; "
                              "both launches of the trip are inside `ms`",
-                     "kernels": ["gf_apply_nibble_sum<1,0,10,true,256>", "mlh_roots"]},
+                     "kernels": ["gf_apply_nibble_sum<1,0,10,true,256>", "mlh_roots_quad"]},
         "binding_resource": static_pmc("rs10_4_encode_hash_secondary_bounds"),
         "traffic": (static_pmc("rs10_4_encode_hash_1MiB_x1024") or {}).get("traffic_bytes"),
         "bit_exact": ok, "checked": f"{len(idx)} strided blocks: parity vs the C oracle, all {n} checksums vs oracle/mlh64.py; gec_verify_batch_dev over the batch",
