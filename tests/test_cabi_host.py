@@ -133,6 +133,21 @@ def test_env_tables_name_every_switch_the_sources_read():
             assert name in gec or name in gbm, f"{name} ({f}) is not in the environment tables"
 
 
+def test_the_documents_list_exactly_the_switches_the_libraries_read():
+    """DESIGN.md section 0 sorts every switch into what it is for, INTEGRATION.md section 6 prints the libraries' tables: both
+    name exactly the switches of gec_env_table / gbm_env_table -- a switch added or removed in the sources shows up here."""
+    from garage_amd import block_native as bn
+
+    table = {ln.split("\t")[0] for ln in (_lib.lib.gec_env_table() + b"\n" + bn.lib.gbm_env_table()).decode().splitlines() if ln.strip()}
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    para = design[design.index("**Switches** ("):design.index("## 1. Scope")]
+    assert int(re.search(r"\*\*Switches\*\* \((\d+);", para).group(1)) == len(table)
+    assert set(re.findall(r"`(GEC_[A-Z0-9_]+|GBM_[A-Z0-9_]+)`", para)) == table
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rows = re.findall(r"^\| `(GEC_[A-Z0-9_]+|GBM_[A-Z0-9_]+)` \|", integ, flags=re.M)
+    assert set(rows) == table and len(rows) == len(table)
+
+
 def test_group_entry_points_reject_bad_arguments_without_a_gpu():
     """gec_group_*: argument checks come before any device / RCCL work."""
     import ctypes
