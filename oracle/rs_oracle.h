@@ -10,7 +10,10 @@
  * in Cargo.lock, so no version number can be quoted.
  * The oracle is instead pinned to the upstream crate's / Backblaze
  * JavaReedSolomon's published known-answer vectors as listed in SURVEY.md
- * Appendix A (tests/test_oracle_kat.py checks every one of them).
+ * Appendix A (tests/test_oracle_kat.py checks every one of them), and to the
+ * worked example printed in Backblaze's article on JavaReedSolomon (4 + 2:
+ * coding rows 1b 1c 12 14 / 1c 1b 14 12, "ABCD EFGH IJKL MNOP" ->
+ * 51 52 53 49 / 55 56 57 25).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * link or call this.  The product library (libgarage_ec.so) never does.

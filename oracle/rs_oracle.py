@@ -6,7 +6,8 @@ The two are written independently so that they check each other.
 
 PARITY UNPINNED by /root/reference (Garage has no erasure coding,
 doc/book/design/goals.md:27; the crate is not vendored).  Pinned instead to the
-upstream known-answer vectors of SURVEY.md Appendix A.4 (tests/test_oracle_kat.py).
+upstream known-answer vectors of SURVEY.md Appendix A.4 and to the worked 4 + 2 example of
+Backblaze's article on JavaReedSolomon (tests/test_oracle_kat.py).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  garage_amd/ never does.

@@ -51,6 +51,18 @@ def test_kat_one_encode_5_5_through_cabi():
     assert not par[0, :, 2:].any()
 
 
+def test_kat_backblaze_4_plus_2_through_cabi():
+    """The worked example of the article that introduced the algorithm (tests/test_oracle_kat.py: the 4 + 2 coding matrix
+    1b 1c 12 14 / 1c 1b 14 12 and "ABCD EFGH IJKL MNOP" -> 51 52 53 49 / 55 56 57 25), through the gfx950 kernel."""
+    rs = g.ReedSolomon(4, 2)
+    assert rs.parity_matrix().tolist() == [[0x1B, 0x1C, 0x12, 0x14], [0x1C, 0x1B, 0x14, 0x12]]
+    data = np.zeros((1, 4, 64), dtype=np.uint8)
+    data[0, :, :4] = np.frombuffer(b"ABCDEFGHIJKLMNOP", dtype=np.uint8).reshape(4, 4)
+    par = gpu_encode(rs, data)
+    assert par[0, :, :4].tolist() == [[0x51, 0x52, 0x53, 0x49], [0x55, 0x56, 0x57, 0x25]]
+    assert not par[0, :, 4:].any()
+
+
 @pytest.mark.parametrize("k,m,L,digest", [
     (3, 1, 64, "a1a2e6472297a6c8fc595265fbc01ecb82954e148bc46107d916c1f876f5dbb6"),
     (10, 4, 64, "716c5f64eecea82d320f527c7837757e9a9effaaf219169d6e52e2e5f80b021d"),

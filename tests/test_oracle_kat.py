@@ -130,6 +130,43 @@ def test_parity_rows_listed():
         143, 174, 91, 112, 208, 205, 84, 67, 57, 163, 201, 88, 27, 187, 179, 24, 27, 28, 18, 20]
 
 
+BACKBLAZE_4_2_PARITY = [[0x51, 0x52, 0x53, 0x49], [0x55, 0x56, 0x57, 0x25]]
+
+
+def test_backblaze_4_plus_2_coding_matrix(coracle):
+    """The one coding matrix the algorithm's authors printed: Backblaze's 2015 article that introduced JavaReedSolomon (the code the
+    crate is a port of, [EXT]) shows the 6 x 4 matrix for 4 data + 2 parity shards -- identity on top, then the rows
+    1b 1c 12 14 / 1c 1b 14 12.  Recalled from that figure, not from /root/reference (which holds no RS code): an anchor that is
+    neither this project's own restatement nor a self-generated digest.  Field 0x11D, vandermonde(6,4) x inverse(top 4x4)."""
+    want = [[0x1B, 0x1C, 0x12, 0x14], [0x1C, 0x1B, 0x14, 0x12]]
+    M = O.build_matrix(4, 2)
+    assert np.array_equal(M[:4], np.eye(4, dtype=np.uint8)) and M[4:].tolist() == want
+    assert coracle.build_matrix(4, 2)[4:].tolist() == want
+    # ... and through the product's own matrix builder (libgarage_ec, CPU codec: no device needed)
+    import garage_amd as g
+
+    assert g.ReedSolomon(4, 2, backend="cpu").parity_matrix().tolist() == want
+    # the same figure's worked example: the data "ABCD" / "EFGH" / "IJKL" / "MNOP" (one row per shard) encodes to the parity
+    # rows 51 52 53 49 / 55 56 57 25 -- written down here from the figure BEFORE the oracle was run on it
+    data = np.frombuffer(b"ABCDEFGHIJKLMNOP", dtype=np.uint8).reshape(4, 4)
+    assert O.encode(4, 2, data).tolist() == BACKBLAZE_4_2_PARITY
+    padded = np.zeros((1, 4, 64), dtype=np.uint8)          # the product's shard geometry is 64-byte multiples: columns are independent
+    padded[0, :, :4] = data
+    for variant in (coracle.SCALAR, coracle.AVX2):
+        if variant == coracle.AVX2 and not coracle.has_avx2():
+            continue
+        got = coracle.encode_batch(4, 2, padded, variant)[0]
+        assert got[:, :4].tolist() == BACKBLAZE_4_2_PARITY and not got[:, 4:].any()
+    rs = g.ReedSolomon(4, 2, backend="cpu")
+    par = rs.encode_blocks([padded[0].tobytes()], 64)[0]
+    assert np.asarray(par)[:, :4].tolist() == BACKBLAZE_4_2_PARITY
+    # ... and lose any two of the six: the article's point
+    full = np.concatenate([padded[0], np.asarray(par)], axis=0)
+    for lost in ((0, 1), (2, 5), (4, 5), (1, 4)):
+        rec = rs.reconstruct([[None if j in lost else full[j] for j in range(6)]])
+        assert all(np.array_equal(rec[0][j], full[j]) for j in lost), lost
+
+
 # A.4.6 --------------------------------------------------------------------
 GOLDEN_ENCODE = [
     (3, 1, 64, "a1a2e6472297a6c8fc595265fbc01ecb82954e148bc46107d916c1f876f5dbb6", [130, 141, 136, 147, 158, 169, 180, 191]),
