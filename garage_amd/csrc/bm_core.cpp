@@ -859,10 +859,12 @@ namespace {
 
 void add_hist(const gbmimpl::Histogram &h, gbm_histogram &o)
 {
-	o.count += h.count.load(std::memory_order_relaxed);
 	o.sum_s += (double)h.sum_ns.load(std::memory_order_relaxed) * 1e-9;
-	for (int i = 0; i <= GBM_HISTOGRAM_BUCKETS; ++i)
-		o.bucket[i] += h.bucket[i].load(std::memory_order_relaxed);  // per bucket here; made cumulative at the end
+	for (int i = 0; i <= GBM_HISTOGRAM_BUCKETS; ++i) {
+		const uint64_t c = h.bucket[i].load(std::memory_order_relaxed);
+		o.bucket[i] += c;  // per bucket here; made cumulative at the end
+		o.count += c;      // readers and writers keep observing while this is read: count = what the buckets say, always
+	}
 }
 
 void add_one(gbm_manager *x, gbm_block_metrics &o)

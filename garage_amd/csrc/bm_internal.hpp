@@ -582,7 +582,8 @@ struct Histogram {
 		return b;
 	}
 	std::atomic<uint64_t> bucket[NB + 1] = {};  // bucket[i]: observations in (bounds[i-1], bounds[i]]; [NB]: above the last bound
-	std::atomic<uint64_t> count{0}, sum_ns{0};
+	std::atomic<uint64_t> sum_ns{0};  // (no separate count: a snapshot's count IS the sum of the buckets it read -- what the exposition
+					  // format demands of the +Inf bucket -- however many observations land while it is being taken)
 	void record(std::chrono::nanoseconds d)
 	{
 		const double s = (double)d.count() * 1e-9;
@@ -591,7 +592,6 @@ struct Histogram {
 		while (i < NB && s > b[i])
 			++i;
 		bucket[i].fetch_add(1, std::memory_order_relaxed);
-		count.fetch_add(1, std::memory_order_relaxed);
 		sum_ns.fetch_add((uint64_t)std::max<int64_t>(0, d.count()), std::memory_order_relaxed);
 	}
 };

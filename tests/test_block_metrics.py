@@ -171,3 +171,49 @@ def test_compression_level_and_several_devices():
     by_dev = [sum(1 for h in hashes if mgr.device_of_hash(h) == d) for d in range(2)]
     assert [per['{device="0"}'], per['{device="1"}']] == by_dev and min(by_dev) > 0
     assert sum(samples["block_ec_device_bytes_written"].values()) == samples["block_bytes_written"][""]
+
+
+def test_a_snapshot_taken_while_requests_are_running_is_a_valid_histogram():
+    """The exposition format wants the +Inf bucket to equal _count.  Readers and writers keep observing while gbm_block_metrics
+    walks the buckets, so a snapshot's count is what its buckets say (the manager's soak found a snapshot whose separately kept
+    count was one observation ahead of its buckets)."""
+    import threading
+
+    codec = g.ReedSolomon(4, 2, backend="cpu")
+    mgr = bn.NativeBlockManager(codec, 8)
+    blocks = [pattern_block(20_000 + 64 * i, 40 + i) for i in range(24)]
+    hashes = [bn.blake2sum(b) for b in blocks]
+    mgr.rpc_put_blocks(list(zip(hashes, blocks)))
+    stop = threading.Event()
+
+    def reader(off):
+        i = off
+        while not stop.is_set():
+            assert mgr.rpc_get_block(hashes[i % len(hashes)]) == blocks[i % len(hashes)]
+            i += 1
+
+    def writer():
+        i = 0
+        while not stop.is_set():
+            mgr.rpc_put_block(hashes[i % len(hashes)], blocks[i % len(hashes)])
+            i += 1
+
+    threads = [threading.Thread(target=reader, args=(q,)) for q in range(3)] + [threading.Thread(target=writer)]
+    for t in threads:
+        t.start()
+    try:
+        last = 0
+        for _ in range(400):
+            met = mgr.block_metrics()
+            for name in ("block_read_duration", "block_write_duration"):
+                h = met[name]
+                assert h["bucket"][-1] == h["count"], (name, h)
+                assert all(a <= b for a, b in zip(h["bucket"], h["bucket"][1:])), (name, h)
+            assert met["block_read_duration"]["count"] >= last
+            last = met["block_read_duration"]["count"]
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
+    assert last > 0
+    mgr.close()

@@ -38,7 +38,12 @@ if [ "$SAN" = "address" ]; then
 else
   F="-O1 -g -fsanitize=thread -fno-omit-frame-pointer -std=c++17 -fPIC -shared"
   PRE="$(gcc -print-file-name=libtsan.so)"
-  export TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=0"
+  # One report is the runtime's own and not looked at: when a thread that used a thread_local vector of the libraries ends,
+  # its destructor reads the vector (__call_tls_dtors); whoever joins that thread later frees its TLS block inside ld.so
+  # (_dl_deallocate_tls), and gcc 11's libtsan does not see the join between the two -- "data race ... in _dl_deallocate_tls",
+  # every frame in libc / ld.so / ~vector, once in ~20 runs of 120 s (the soak's reader and writer threads end at different times).
+  printf 'race:_dl_deallocate_tls\n' > "$W/tsan.supp"
+  export TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=0 suppressions=$W/tsan.supp"
   PAT="WARNING: ThreadSanitizer"
 fi
 ( cd "$W/garage_amd/csrc" && cp ../../tests/c/ec_nodevice.cpp "$W/stubs.cpp" . &&
@@ -59,6 +64,7 @@ N=$(grep -c "$PAT" "$W/out.log" || true)
 if grep -q "FATAL: ThreadSanitizer\|Shadow memory range interleaves\|ASan runtime does not come first" "$W/out.log"; then
   echo "soak_tsan: the sanitizer cannot run here"; grep "FATAL\|Shadow memory\|does not come first" "$W/out.log" | head -2; exit 77; fi
 tail -1 "$W/out.log" | cut -c1-400
+if [ "$RC" != "0" ]; then echo "--- the soak's last lines:"; tail -40 "$W/out.log" | cut -c1-600; fi
 if [ "$N" != "0" ]; then grep -A18 "$PAT" "$W/out.log" | head -90; fi
 echo "soak_tsan: soak exit $RC, $SAN sanitizer reports: $N"
 [ "$RC" = "0" ] && [ "$N" = "0" ]
