@@ -226,6 +226,18 @@ def test_a_table_free_restatement_agrees_with_both_oracles(coracle):
         want = [[_dot(M[k + r], [int(data[t, c]) for t in range(k)]) for c in range(64)] for r in range(m)]
         assert O.encode(k, m, data).tolist() == want
         assert coracle.encode_batch(k, m, data[None], coracle.SCALAR)[0].tolist() == want
+        # reconstruct, the crate's way [EXT core.rs reconstruct_internal]: the first k shards present, in index order, invert
+        # their rows of the coding matrix, data = inverse x survivors; then the lost parity from the data
+        full = [[int(v) for v in row] for row in data.tolist()] + want
+        lost = sorted({0, k - 1, k, (3 * k) // 4} if m >= 4 else {k - 1})[:m]
+        rows = [j for j in range(k + m) if j not in lost][:k]
+        dec = mat_inverse([M[j] for j in rows])
+        rebuilt_data = [[_dot(dec[t], [full[j][c] for j in rows]) for c in range(64)] for t in range(k)]
+        assert rebuilt_data == full[:k]
+        broken = np.array(full, dtype=np.uint8)
+        broken[lost] = 0xA5
+        rec = O.reconstruct(k, m, broken, [j not in lost for j in range(k + m)])
+        assert rec.tolist() == full
 
 
 # A.4.6 --------------------------------------------------------------------
