@@ -451,18 +451,21 @@ class EncodeJob:
             self.step()
         self.sync()
 
-    def decode_setup(self):
+    def decode_setup(self, lost=(0, 3, 7, 9)):
+        """Erase the shards of `lost` in every block of the (encoded) batch; keeps what a decode must bring back."""
         import numpy as np
 
-        self.lost = (0, 3, 7, 9)
+        self.lost = tuple(lost)
         self.present = np.array([j not in self.lost for j in range(K + M)], dtype=np.uint8)
-        self.ref = self.st[:4].clone()
-        self.lost_ref = self.st[:, list(self.lost)].clone()   # the payload about to be erased: what a decode must return
+        self.lost_ref = self.st[:, list(self.lost)].clone()   # the shards about to be erased: what a decode must return
         self.st[:, list(self.lost)] = 0
 
     def decode_step(self):
         with self.torch.cuda.stream(self.stream):
             self.rs.reconstruct_dev(self.st, self.present)
+
+    def decode_erase(self):
+        self.st[:, list(self.lost)] = 0
 
 
 def algo_bytes(nb: int, S: int) -> int:
@@ -645,6 +648,81 @@ def rs20_8_object(args, dev, stream) -> dict:
     return out
 
 
+DECODE_PATTERNS = ((0, 3, 7, 9), (0, 3, 7, 11))
+
+
+def decode_object(args, job, R, distrib, barrier, blocks_all: int, world: int) -> dict:
+    """BASELINE config 3 on the rank's resident batch, once per erasure pattern: erase, ONE cold call (host 10x10 inversion
+    included), a timed loop of warm calls (cached decode matrix; wall clock MAX over ranks for `value`, HIP events on the launch
+    stream for the roofline), and after the loop every rebuilt shard of every block against the shards that were erased, the
+    kernel's own compare mode over the completed stripes, and the CPU oracle's reconstruct on a strided sample of blocks."""
+    import numpy as np
+    import torch
+
+    from oracle import rs_oracle as O
+
+    S, nb = job.S, job.nb
+    dsteps = max(5, args.steps // 2)
+    per = []
+    for lost in DECODE_PATTERNS:
+        job.decode_setup(lost)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        job.decode_step()                     # cold: includes the host 10x10 inversion
+        torch.cuda.synchronize()
+        cold_dec_ms = (time.perf_counter() - c0) * 1e3
+        assert torch.equal(job.st[:, list(lost)], job.lost_ref), "reconstruct mismatch (first call)"
+        job.decode_erase()
+        barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        d0 = time.perf_counter()
+        ev0.record(job.stream)
+        for _ in range(dsteps):
+            job.decode_step()                 # warm: cached decode matrix
+        ev1.record(job.stream)
+        torch.cuda.synchronize()
+        barrier()
+        dt = distrib.max_over_ranks(R, time.perf_counter() - d0)
+        kern_ms = ev0.elapsed_time(ev1) / dsteps
+        # -- after the timed loop
+        exact = bool(torch.equal(job.st[:, list(lost)], job.lost_ref))
+        exact = exact and bool(job.rs.verify_dev(job.st).all())
+        idx = sorted(set(np.linspace(0, nb - 1, min(nb, 16)).astype(int).tolist()))
+        host = job.st[torch.as_tensor(idx, device=job.dev)].cpu().numpy()
+        co = O.COracle()
+        broken = host.copy()  # the oracle rebuilds the same erasures from the survivors alone
+        broken[:, list(lost)] = 0
+        want = co.reconstruct_batch(K, M, broken, [j not in lost for j in range(K + M)], threads=4)
+        exact = exact and bool(np.array_equal(want, host))
+        exact_all = distrib.sum_over_ranks(R, int(exact)) == world
+        ab = (K + len(lost)) * S * nb     # read k surviving shards, write the 4 lost ones: the encode's algorithmic bytes
+        per.append({
+            "lost": list(lost),
+            "value": round(blocks_all * BLOCK_LEN * dsteps / dt / 2**30, 2), "unit": "GiB/s",
+            "ms_per_step": round(dt / dsteps * 1e3, 4), "kernel_ms": round(kern_ms, 4), "cold_first_call_ms": round(cold_dec_ms, 3),
+            "roofline": {"bound": "hbm", "achieved": round(ab / (kern_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ab / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": ab,
+                         "kernel": "gf_apply_nibble<1,0,10,1,true,256>", "kernel_ms": round(kern_ms, 4),
+                         "note": "one launch rebuilds all four shards (a lost parity row is composed with the decode matrix on the host)"},
+            "bit_exact": exact_all,
+        })
+    first = per[0]
+    out = {
+        "workload": "BASELINE config 3: RS(10,4) reconstruct with 4 erasures, 1 MiB blocks, the rank's resident batch; patterns "
+                    + ", ".join("{" + ",".join(map(str, p["lost"])) + "}" for p in per),
+        "value": first["value"], "unit": "GiB/s", "ms_per_step": first["ms_per_step"], "cold_first_call_ms": first["cold_first_call_ms"],
+        "roofline_frac": first["roofline"]["frac"], "roofline": first["roofline"],
+        "bit_exact": all(p["bit_exact"] for p in per),
+        "checked": "after each timed loop: every rebuilt shard of every block equals the erased one, gec_verify_batch_dev over the "
+                   "completed stripes, and the CPU oracle's reconstruct of 16 strided blocks from the survivors alone",
+        "patterns": per,
+    }
+    if not out["bit_exact"]:
+        out["error"] = "a decode result differs from the erased shards / the oracle"
+    return out
+
+
 # --------------------------------------------------------------- one process per GPU
 def run_procs(args) -> None:
     import numpy as np
@@ -728,37 +806,11 @@ def run_procs(args) -> None:
     checked = 0 if args.no_oracle_check else oracle_check_sample(job.st, nb, S)
     checked_all = distrib.sum_over_ranks(R, checked)
 
-    # ---- decode (BASELINE config 3): 4 data shards lost, reconstruct in place
+    # ---- decode (BASELINE config 3): 4 shards lost, reconstruct in place -- both patterns BASELINE.md section 3 names:
+    #      four data shards {0,3,7,9}, and three data + one parity {0,3,7,11} (the decode matrix known answer of SURVEY.md A.4.7)
     decode = None
     if not args.no_decode and nb:
-        job.decode_setup()
-        torch.cuda.synchronize()
-        c0 = time.perf_counter()
-        job.decode_step()                     # cold: includes the host 10x10 inversion
-        torch.cuda.synchronize()
-        cold_dec_ms = (time.perf_counter() - c0) * 1e3
-        assert torch.equal(job.st[:4], job.ref), "reconstruct mismatch"
-        dsteps = max(5, args.steps // 2)
-        barrier()
-        torch.cuda.synchronize()
-        d0 = time.perf_counter()
-        for _ in range(dsteps):
-            job.decode_step()                 # warm: cached decode matrix
-        torch.cuda.synchronize()
-        barrier()
-        dt = distrib.max_over_ranks(R, time.perf_counter() - d0)
-        # after the timed loop: every rebuilt shard of every block against the payload that was erased
-        assert torch.equal(job.st[:, list(job.lost)], job.lost_ref), "reconstruct mismatch after the timed loop"
-        decode = {
-            "workload": "RS(10,4) reconstruct, data shards {0,3,7,9} lost, 1 MiB blocks",
-            "value": round(blocks_all * BLOCK_LEN * dsteps / dt / 2**30, 2),
-            "unit": "GiB/s",
-            "ms_per_step": round(dt / dsteps * 1e3, 4),
-            "cold_first_call_ms": round(cold_dec_ms, 3),
-            "checked": "every rebuilt shard of every block equals the erased payload, after the timed loop",
-            # same algorithmic bytes as encode: read k surviving shards, write the 4 lost ones
-            "roofline_frac": round((K + len(job.lost)) * S * blocks_all / world / (dt / dsteps) / 1e9 / HBM_PEAK_GBS, 4),
-        }
+        decode = decode_object(args, job, R, distrib, barrier, blocks_all, world)
 
     # ---- N = 1: the put trip (config 2 + the checksum of every shard) and config 5's code, beside the headline
     extra = {}
@@ -1087,6 +1139,29 @@ def striped_decode_in_children(args, R) -> dict:
     return res
 
 
+def striped_valid_stripes(torch, rs, dev, nobj: int, k: int, m: int, S: int, L: int):
+    """(nobj, k+m, S) uint8 on `dev`: nobj complete RS(k,m) stripes of L-byte objects.  Payload word i (64-bit) is a splitmix-style
+    mix of i in wrapping int64 arithmetic -- no generator state, so every rank of a job builds the same bytes whatever its device;
+    parity by the encode kernel."""
+    full = torch.zeros((nobj, k + m, S), dtype=torch.uint8, device=dev)
+    wpo = L // 8                              # 64-bit words per object
+    pay = full[:, :k].reshape(nobj, k * S)    # a view: the k data shards of an object are contiguous
+    for o0 in range(0, nobj, 32):
+        o1 = min(nobj, o0 + 32)
+        x = torch.arange(o0 * wpo, o1 * wpo, dtype=torch.int64, device=dev)
+        x = x * -7046029254386353131 + 0x6761726167650005      # 0x9E3779B97F4A7C15 as int64
+        x ^= x >> 30
+        x *= -4658895280553007687                              # 0xBF58476D1CE4E5B9
+        x ^= x >> 27
+        x *= -7723592293110705685                              # 0x94D049BB133111EB
+        x ^= x >> 31
+        pay[o0:o1, :L] = x.view(torch.uint8).view(o1 - o0, L)
+        del x
+    rs.encode_dev(full)
+    torch.cuda.synchronize()
+    return full
+
+
 # ------------------------------------------------------------------ BASELINE config 5
 def striped_decode_bench(args, R, distrib, progress=None) -> dict:
     """BASELINE config 5 (secondary to the headline metric): RS(20,8), 4 MiB objects, shard j on
@@ -1232,16 +1307,39 @@ def striped_decode_bench(args, R, distrib, progress=None) -> dict:
     del full, broken, got, reb, mine
     progress["stage"] = "bit-exact checks done"
 
-    # -- timing: contents do not affect it
-    gen = torch.Generator(device=R.device)
-    gen.manual_seed(0x6761726167650005 + 1 + R.rank)
-    local = torch.randint(0, 256, (nobj, layout.slots, S), dtype=torch.uint8, device=R.device, generator=gen)
+    # -- timing, on VALID stripes, and every object of the timed batch checked on every rank after each exchange's loop.
+    #    The payload is integer arithmetic on the byte index (no RNG: identical on every device by construction); the parity is
+    #    the encode kernel's (gec_encode_batch_dev, itself checked against the C oracle on a strided sample right here); the
+    #    erased shards are overwritten with 0xEE and scattered: `local` is what this rank would hold of 256 degraded objects.
+    full = striped_valid_stripes(torch, rs, R.device, nobj, k, m, S, L)
+    sample = sorted(set(np.linspace(0, nobj - 1, min(nobj, 4)).astype(int).tolist()))
+    sample_t = torch.as_tensor(sample, device=R.device)
+    host_full = full[sample_t].cpu().numpy()
+    want_par = co.encode_batch(k, m, np.ascontiguousarray(host_full[:, :k]), co.AVX2 if co.has_avx2() else co.SCALAR, threads=4)
+    timed_batch_ok = bool(np.array_equal(host_full[:, k:], want_par))     # the batch the loops run on IS a batch of RS(20,8) stripes
+    lost_t = torch.as_tensor(lost_sorted, device=R.device)
+    local = scatter_stripes(full.index_fill(1, lost_t, 0xEE), layout, R.rank)
     steps = args.striped_steps or (1 if dry else max(5, min(50, args.steps // 20)))
     nwarm = 0 if dry else 3
+    # fault injection (tests/test_world8_rehearsal.py): one byte of one rank's slot buffer flipped between the warm-up and the timed
+    # loop of the named exchange ("all": every exchange) -- the line must then say bit_exact false for it
+    flip_rank = os.environ.get("GARAGE_BENCH_STRIPED_FLIP_RANK")
+    flip_what = os.environ.get("GARAGE_BENCH_STRIPED_FLIP_EXCHANGE", "all")
+    mine_present = [j for j in layout.shards_of(R.rank) if present[j]]
 
-    def timed(fn, out):
+    def flip(name, undo=False):
+        if flip_rank is None or int(flip_rank) != R.rank or flip_what not in ("all", name):
+            return
+        if not mine_present:
+            raise RuntimeError(f"rank {R.rank} holds no surviving shard to corrupt")
+        torch.cuda.synchronize()
+        local[nobj // 2, layout.slot(mine_present[0]), S // 2 + 5] ^= 0x40
+        torch.cuda.synchronize()
+
+    def timed(name, fn, out):
         for _ in range(nwarm):
             fn(local, out)
+        flip(name)
         torch.cuda.synchronize()
         distrib.barrier(R)
         t0 = time.perf_counter()
@@ -1249,38 +1347,88 @@ def striped_decode_bench(args, R, distrib, progress=None) -> dict:
             fn(local, out)
         torch.cuda.synchronize()
         distrib.barrier(R)
-        return distrib.max_over_ranks(R, time.perf_counter() - t0)
+        dt_ = distrib.max_over_ranks(R, time.perf_counter() - t0)
+        flip(name, undo=True)
+        return dt_
 
+    def check_rebuilt(reb_of):
+        """What the LAST timed call left behind against the stripes the batch was cut from.  reb_of(i, j) -> the (nobj, S) view of
+        rebuilt shard j (i-th missing).  Returns {objects whose 8 rebuilt shards all match, on the rank where fewest do;
+        gec_verify_batch_dev over the completed stripes; the C oracle's own reconstruct of a strided sample}."""
+        bad = torch.zeros(nobj, dtype=torch.bool, device=R.device)
+        done = full.clone()
+        for i, j in enumerate(lost_sorted):
+            r_ = reb_of(i, j)
+            bad |= (r_ != full[:, j]).any(dim=1)
+            done[:, j] = r_
+        n_ok = nobj - int(bad.sum().item())
+        verified = bool(rs.verify_dev(done).all())
+        # the oracle rebuilds the sample from the survivors alone: no kernel of this project made `want`
+        broken = host_full.copy()
+        broken[:, lost_sorted] = 0
+        want = co.reconstruct_batch(k, m, broken, present, threads=4)
+        got_s = done[sample_t][:, lost_t].cpu().numpy()
+        oracle_ok = bool(np.array_equal(got_s, want[:, lost_sorted]))
+        del done
+        n_ok_all = -distrib.max_over_ranks(R, -n_ok)            # the worst rank's count
+        all_ok = distrib.sum_over_ranks(R, int(n_ok == nobj and verified and oracle_ok and timed_batch_ok)) == R.world
+        return {"bit_exact": all_ok, "bit_exact_objects": int(n_ok_all), "of": nobj,
+                "verify_batch_dev": verified, "oracle_sample_objects": len(sample) if oracle_ok else 0}
+
+    CHECKED = ("after the timed loop, on every rank: all rebuilt shards of all objects of the TIMED batch against the stripes it was cut "
+               "from, gec_verify_batch_dev over the completed stripes, and the C oracle's reconstruct of a strided sample from the survivors alone")
     out = torch.empty((R.world, nobj, layout.slots, S), dtype=torch.uint8, device=R.device) if grp is not None else None
-    dt = timed(run, out)
+    if grp is None:
+        box = {}
+        dt = timed("allgather", lambda l_, o_: box.__setitem__("out", run(l_)), None)
+        out = box.pop("out")
+    else:
+        dt = timed("allgather", run, out)
     ag_bytes = grp.bytes_exchanged() if grp is not None else nobj * layout.slots * S * (R.world - 1)
+    ag_check = check_rebuilt(lambda i, j: out[layout.owner(j), :, layout.slot(j)])
+    if ag_check["bit_exact"]:   # the all-gather form also returns the survivors: they must be the ones that were sent
+        surv_ok = all(bool(torch.equal(out[layout.owner(j), :, layout.slot(j)], full[:, j])) for j in range(k + m) if present[j])
+        ag_check["bit_exact"] = distrib.sum_over_ranks(R, int(surv_ok)) == R.world
     del out
-    progress["stage"] = "all-gather timed"
-    out2 = torch.empty((len(lost), nobj, S), dtype=torch.uint8, device=R.device) if grp is not None else None
-    dt2 = timed(run_a2a, out2)
+    progress["stage"] = "all-gather timed and checked"
+    out2 = torch.empty((len(lost), nobj, S), dtype=torch.uint8, device=R.device)
+    if grp is None:
+        box = {}
+        dt2 = timed("alltoall", lambda l_, o_: box.__setitem__("out", run_a2a(l_)), None)
+        out2 = box.pop("out")
+    else:
+        dt2 = timed("alltoall", run_a2a, out2)
     a2a_bytes = grp.bytes_exchanged() if grp is not None else None
+    a2a_check = check_rebuilt(lambda i, j: out2[i])
+    progress["stage"] = "all-to-all timed and checked"
     peer = {"skipped": "needs the C ABI group (--collective cabi)"} if grp is None else {"error": peer_err} if peer_err else None
     if peer is None:
         try:
+            out2.fill_(0)
             ptrs, opened = open_peers(local)
-            dt3 = timed(lambda l_, o_: grp.peer_decode(l_, ptrs, present, out=o_), out2)
+            dt3 = timed("peer", lambda l_, o_: grp.peer_decode(l_, ptrs, present, out=o_), out2)
             peer_bytes = grp.bytes_exchanged()
+            peer_check = check_rebuilt(lambda i, j: out2[i])
             close_peers(opened)
             peer = {"ms_per_step": round(dt3 / steps * 1e3, 3), "GiBps": round(nobj * L * steps / dt3 / 2**30, 2),
                     "bytes_received_per_rank": peer_bytes, "bytes_read_from_peers_memory_per_rank": peer_bytes - (R.world - 1) * len(lost) * nobj * (-(-(S // 16) // R.world)) * 16 if R.world > 1 else 0,
-                    "bit_exact": ok_peer_all,
+                    **peer_check, "small_batch_bit_exact": ok_peer_all,
                     "what": "gec_group_peer_decode: ONE decode launch per rank reads its byte range of the k valid shards out of the other "
                             "ranks' slot buffers (HIP IPC mappings, xGMI), no pack / unpack / staging; the transport carries two 16-byte "
                             "barriers and the rebuilt ranges"}
         except Exception as e:  # noqa: BLE001
             peer = {"error": f"{type(e).__name__}: {e}"[:300]}
+    del out2, full, local
+    timed_ok = ag_check["bit_exact"] and a2a_check["bit_exact"] and (peer.get("bit_exact", True) is not False)
     res = {
         "metric": "RS(20,8) striped-object decode payload throughput, 4 MiB objects (all-gather + range reconstruct + range exchange)",
         "value": round(nobj * L * steps / dt / 2**30, 2), "unit": "GiB/s", "n_gpus": R.world, "steps": steps,
         "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "bit_exact": ok_all, "bit_exact_objects": ncheck,
-        "bit_exact_against": "stripes encoded by the CPU oracle (oracle/rs_oracle.c) on the host; every rebuilt shard compared on every rank",
+        "bit_exact": ok_all and ag_check["bit_exact"], "bit_exact_objects": ag_check["bit_exact_objects"], "timed_batch_objects": nobj,
+        "bit_exact_against": f"(1) before the timing, {ncheck} objects whose stripes the CPU oracle (oracle/rs_oracle.c) encoded on the host; (2) " + CHECKED,
+        "timed_batch": "valid RS(20,8) stripes: payload = integer arithmetic on the byte index (the same on every rank), parity by "
+                       "gec_encode_batch_dev, checked against the C oracle on a strided sample: " + ("ok" if timed_batch_ok else "MISMATCH"),
         "rccl_ranks": (grp.nranks if grp is not None else dist.get_world_size()),
         "collective_backend": ("DRY RUN: gloo through a host-staging gec_allgather_fn / gec_alltoall_fn (every rank on device 0; "
                                "timings meaningless)" if dry and grp is not None
@@ -1295,9 +1443,9 @@ def striped_decode_bench(args, R, distrib, progress=None) -> dict:
         # the two exchanges side by side (all-gather = the project brief's, and the `value` above)
         "exchange": {
             "allgather": {"ms_per_step": round(dt / steps * 1e3, 3), "GiBps": round(nobj * L * steps / dt / 2**30, 2),
-                          "bytes_received_per_rank": ag_bytes, "bit_exact": ok_all},
+                          "bytes_received_per_rank": ag_bytes, **ag_check, "small_batch_bit_exact": ok_all},
             "alltoall": {"ms_per_step": round(dt2 / steps * 1e3, 3), "GiBps": round(nobj * L * steps / dt2 / 2**30, 2),
-                         "bytes_received_per_rank": a2a_bytes, "bit_exact": ok_a2a_all,
+                         "bytes_received_per_rank": a2a_bytes, **a2a_check, "small_batch_bit_exact": ok_a2a_all,
                          "what": "gec_group_alltoall_decode: each rank receives only its byte range of the k valid shards "
                                  "(grouped ncclSend/ncclRecv); returns the rebuilt shards only"},
             "peer": peer,
@@ -1308,8 +1456,8 @@ def striped_decode_bench(args, R, distrib, progress=None) -> dict:
     del keep_alive   # the dry run's transport callbacks had to outlive the group
     if own_pg:
         dist.destroy_process_group()
-    if not (ok_all and ok_a2a_all) or ok_peer_all is False:
-        res["error"] = "striped decode result differs from the oracle's stripes"
+    if not (ok_all and ok_a2a_all) or ok_peer_all is False or not timed_ok:
+        res["error"] = "striped decode result differs from the oracle's stripes" + ("" if timed_ok else " (the timed batch)")
     return res
 
 

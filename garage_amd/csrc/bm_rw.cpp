@@ -306,6 +306,26 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 	if (grc)
 		return grc;
 	tr.lap("gather");
+	// want_block_sums == 2 asks the device trip for the end-to-end hash of the blocks it REBUILDS.  When the gather came back
+	// healthy -- or with few enough degraded blocks that the pool hashes them at once (cpu_block_hash_max, the same bound
+	// get_blocks_once applies to a whole request) -- no block needs a hash from the trip: the batch takes the host check
+	// (fused with the copy-out for a big batch), blocks that miss a data shard go to the device for the decode alone, and
+	// the caller hashes what was rebuilt afterwards (its have_sum[b] stays 0).  A fully healthy default-mode get is then the
+	// same work as GBM_VERIFY_OFF.
+	if (want_block_sums == 2 && mg->sumver == 3) {
+		size_t need = 0;
+		for (size_t b = 0; b < nb; ++b) {
+			if (!g[b].have_meta || g[b].count < k)
+				continue;
+			for (int j = 0; j < k; ++j)
+				if (g[b].shard[j].empty()) {
+					++need;
+					break;
+				}
+		}
+		if (need <= mg->cpu_block_hash_max.load())
+			want_block_sums = 0;
+	}
 	std::exception_ptr helper_err;  // what the overlapped work threw: carried to this thread (on the helper it would be std::terminate)
 	std::thread helper;
 	struct Joiner {
@@ -433,11 +453,22 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 				std::thread decoder;
 				if (ndec)
 					decoder = std::thread([&] {
-						name_thread("gbm-get-decode");
-						DeviceTurn turn(gate);
-						drc = gec_reconstruct_batch(mg->codec, ndec, dsp.data(), dop.data(), S, /*data_only=*/1);
-						if (drc)
-							derr = gec_last_error();  // (thread-local over there: carried to the caller's thread)
+						// (a thread of its own inside a C entry point: nothing may leave it -- an exception here would be std::terminate)
+						try {
+							name_thread("gbm-get-decode");
+							DeviceTurn turn(gate);
+							drc = gec_reconstruct_batch(mg->codec, ndec, dsp.data(), dop.data(), S, /*data_only=*/1);
+							if (drc)
+								derr = gec_last_error();  // (thread-local over there: carried to the caller's thread)
+						} catch (const std::exception &e) {
+							drc = GEC_E_NOMEM;
+							try {
+								derr = e.what();
+							} catch (...) {
+							}
+						} catch (...) {
+							drc = GEC_E_NOMEM;
+						}
 					});
 				struct JoinDecoder {
 					std::thread &t;
@@ -566,9 +597,11 @@ void assemble(const Gathered &g, int k, uint8_t *dst)
 }
 
 static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
-			   const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate);
+			   const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate,
+			   std::vector<uint8_t> &worth_retry);
 static int get_blocks_again(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
-			    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate);
+			    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate,
+			    std::vector<uint8_t> &worth_retry);
 
 // raw == true: rpc_get_raw_block (stored bytes + header); false: rpc_get_block (plain bytes).
 // While a layout change is being followed (more than one version is active) resync MOVES shards: PutShard to the new owner,
@@ -578,11 +611,11 @@ static int get_blocks_again(gbm_manager *mg, size_t nb, const uint8_t *hashes, c
 // while the other one was still on its way -- a block that comes back Missing (or Corrupt with too few shards) during a
 // transition is asked for again, twice at most: moves only go forward, a later walk meets the shards where an earlier one's
 // went to.  (The reference leaves the same cases to the client's retry.)
-// What get_blocks_once says about the blocks it could not return (per call, on the calling thread): 1 = its walk found SOME of the
-// block (a shard, or a corrupt copy) but too little -- what a move in progress looks like, worth another walk; 0 = nothing of it was
-// seen at any holder of any version (the block simply is not there), or its bytes were read and failed the end-to-end check: a
-// retry cannot change either.
-static thread_local std::vector<uint8_t> t_worth_retry;
+// What get_blocks_once says about the blocks it could not return (`worth_retry`, one flag per block of the call): 1 = its walk
+// found SOME of the block (a shard, or a corrupt copy) but too little, or every holder it asked was DOWN while shards are being
+// moved -- what a move in progress looks like, worth another walk; 0 = every holder of every version answered and none had
+// anything of it (the block simply is not there), or its bytes were read and failed the end-to-end check: a retry cannot change
+// either.
 
 int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
 		    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate)
@@ -593,31 +626,32 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 		if (!out[b] && cap[b])
 			return fail(GBM_E_INVALID_ARG, "NULL output buffer with a capacity");
 	DurationScope read_time(mg->bmx.read_duration);  // block.read_duration (metrics.rs:117-121): one observation per call
-	int rc = get_blocks_once(mg, nb, hashes, tags, out, cap, len_out, rcs, raw, headers, gate);
+	std::vector<uint8_t> worth_retry;
+	int rc = get_blocks_once(mg, nb, hashes, tags, out, cap, len_out, rcs, raw, headers, gate, worth_retry);
 	// (twice more at most, a millisecond and five apart: a slow reader beside a fast mover can lose several shards of one block to
 	// the window in one walk; the mover is done with a block in well under that)
 	for (int attempt = 1; attempt <= 2 && rc == GBM_OK && mg->layout_cur.load() != mg->layout_oldest.load(); ++attempt) {
 		bool any = false;
 		for (size_t b = 0; b < nb && !any; ++b)
-			any = (rcs[b] == GBM_E_MISSING_BLOCK || rcs[b] == GBM_E_CORRUPT_DATA) && b < t_worth_retry.size() && t_worth_retry[b];
+			any = (rcs[b] == GBM_E_MISSING_BLOCK || rcs[b] == GBM_E_CORRUPT_DATA) && b < worth_retry.size() && worth_retry[b];
 		if (!any)  // (a block nobody holds and a block whose content does not match its name are final: no sleep, no second walk)
 			break;
 		if (attempt == 2)
 			std::this_thread::sleep_for(std::chrono::milliseconds(5));
 		else
 			std::this_thread::sleep_for(std::chrono::milliseconds(1));
-		rc = get_blocks_again(mg, nb, hashes, tags, out, cap, len_out, rcs, raw, headers, gate);
+		rc = get_blocks_again(mg, nb, hashes, tags, out, cap, len_out, rcs, raw, headers, gate, worth_retry);
 	}
 	return rc;
 }
 
 // the blocks of a call that came back Missing (or Corrupt with too few shards found), asked for once more
 static int get_blocks_again(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
-			    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate)
+			    const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate,
+			    std::vector<uint8_t> &worth)
 {
 	int rc = GBM_OK;
 	std::vector<size_t> again;
-	const std::vector<uint8_t> worth = t_worth_retry;  // (the call below overwrites it)
 	for (size_t b = 0; b < nb; ++b)
 		if ((rcs[b] == GBM_E_MISSING_BLOCK || rcs[b] == GBM_E_CORRUPT_DATA) && b < worth.size() && worth[b])  // (Corrupt: a bad shard was met AND too few others were found)
 			again.push_back(b);
@@ -637,8 +671,9 @@ static int get_blocks_again(gbm_manager *mg, size_t nb, const uint8_t *hashes, c
 		oo[i] = out[again[i]];
 		cc[i] = cap[again[i]];
 	}
+	std::vector<uint8_t> worth_sub;
 	rc = get_blocks_once(mg, na, hh.data(), tags ? tt.data() : nullptr, oo.data(), cc.data(), ll.data(), rr.data(), raw,
-			     headers ? hd.data() : nullptr, gate);
+			     headers ? hd.data() : nullptr, gate, worth_sub);
 	if (rc != GBM_OK)
 		return rc;
 	std::vector<uint8_t> worth2(nb, 0);
@@ -647,15 +682,17 @@ static int get_blocks_again(gbm_manager *mg, size_t nb, const uint8_t *hashes, c
 		len_out[again[i]] = ll[i];
 		if (headers)
 			headers[again[i]] = hd[i];
-		worth2[again[i]] = i < t_worth_retry.size() ? t_worth_retry[i] : 0;
+		worth2[again[i]] = i < worth_sub.size() ? worth_sub[i] : 0;
 	}
-	t_worth_retry = worth2;
+	worth = worth2;
 	return GBM_OK;
 }
 
 static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm_order_tag *tags, uint8_t *const *out,
-			   const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate)
+			   const size_t *cap, size_t *len_out, int *rcs, bool raw, gbm_data_block_header *headers, const FanoutGate *gate,
+			   std::vector<uint8_t> &worth_retry)
 {
+	worth_retry.assign(nb, 0);
 	const int k = mg->k;
 	std::vector<Hash> hs(nb);
 	for (size_t b = 0; b < nb; ++b)
@@ -787,10 +824,9 @@ static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, co
 		});
 	}
 	tr.lap("finish");
-	t_worth_retry.assign(nb, 0);
 	for (size_t b = 0; b < nb; ++b)
 		if ((rcs[b] == GBM_E_MISSING_BLOCK || rcs[b] == GBM_E_CORRUPT_DATA) && !final_verdict[b] && b < g.size())
-			t_worth_retry[b] = g[b].count > 0 || g[b].corrupt_seen || g[b].have_meta;
+			worth_retry[b] = g[b].count > 0 || g[b].corrupt_seen || g[b].have_meta || g[b].down_seen;
 	g.clear();
 	tr.lap("release");
 	return GBM_OK;

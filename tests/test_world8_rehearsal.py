@@ -93,8 +93,14 @@ def test_world8_threads_mode():
 @pytest.mark.gpu
 def test_world8_striped_decode_op_at_full_config5_size():
     d = _run(_torchrun(8, "--op", "striped-decode", *DRIVER_FLAGS), DRY)
-    assert d["n_gpus"] == 8 and d["bit_exact"] is True and d["bit_exact_objects"] == 8 and "oracle" in d["bit_exact_against"]
-    assert d["exchange"]["alltoall"]["bit_exact"] is True and d["rccl_ranks"] == 8 and "DRY RUN" in d["collective_backend"]
+    assert d["n_gpus"] == 8 and d["bit_exact"] is True and "oracle" in d["bit_exact_against"]
+    # every object of the TIMED batch, on every rank, after each of the three exchanges' timed loops
+    assert d["bit_exact_objects"] == 256 == d["timed_batch_objects"] and d["timed_batch"].endswith(": ok")
+    for name in ("allgather", "alltoall", "peer"):
+        ex = d["exchange"][name]
+        assert ex["bit_exact"] is True and ex["bit_exact_objects"] == 256 and ex["verify_batch_dev"] is True and ex["oracle_sample_objects"] >= 4, (name, ex)
+        assert ex["small_batch_bit_exact"] is True
+    assert d["rccl_ranks"] == 8 and "DRY RUN" in d["collective_backend"]
     cfg = d["config"]
     assert (cfg["k"], cfg["m"], cfg["shard_len"], cfg["slots_per_rank"]) == (20, 8, 209728, 4) and "256 x 4 MiB" in cfg["workload"]
     # all-gather: 7 peers' slot buffers; all-to-all: only this rank's byte range of the k valid shards -- an order less
@@ -106,6 +112,25 @@ def test_world8_striped_decode_op_at_full_config5_size():
     # its byte range of the 20 survivors out of them -- 1/8 of 17-18 remote shards per object instead of 7 ranks' whole slot buffers
     peer = d["exchange"]["peer"]
     assert peer["bit_exact"] is True and 0 < peer["bytes_read_from_peers_memory_per_rank"] * 10 < d["exchange"]["allgather"]["bytes_received_per_rank"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["allgather", "alltoall", "peer"])
+def test_one_flipped_byte_in_one_ranks_slot_buffer_turns_the_line_red(exchange):
+    """Negative test of the timed batch's check: GARAGE_BENCH_STRIPED_FLIP_RANK flips ONE byte of one surviving shard in one
+    rank's slot buffer between the warm-up and the timed loop of one exchange.  That exchange must report bit_exact false with
+    255 of 256 objects intact, the line carries `error`, and the two other exchanges (same buffers, byte restored) stay green --
+    i.e. a cross-device visibility bug on real hardware cannot print a fast, wrong, green line."""
+    d = _run(_torchrun(4, "--op", "striped-decode", "--striped-objects", "64", "--steps", "20"),
+             dict(DRY, GARAGE_BENCH_STRIPED_FLIP_RANK="2", GARAGE_BENCH_STRIPED_FLIP_EXCHANGE=exchange))
+    assert "timed batch" in d["error"]
+    for name in ("allgather", "alltoall", "peer"):
+        ex = d["exchange"][name]
+        if name == exchange:
+            assert ex["bit_exact"] is False and ex["bit_exact_objects"] == 63 and ex["verify_batch_dev"] is False, ex
+        else:
+            assert ex["bit_exact"] is True and ex["bit_exact_objects"] == 64, (name, ex)
+    assert d["bit_exact"] is (exchange != "allgather")
 
 
 @pytest.mark.gpu

@@ -88,6 +88,10 @@ def summarize(d, n):
         s["striped_decode"] = {k: sd.get(k) for k in ("bit_exact", "bit_exact_objects", "rccl_ranks", "ranks", "collective_backend", "transport", "error") if k in sd}
         if "exchange" in sd:
             s["striped_decode"]["alltoall_bit_exact"] = sd["exchange"]["alltoall"]["bit_exact"]
+            # round 6: every object of the TIMED batch is checked on every rank after each exchange's loop
+            s["striped_decode"]["timed_batch_objects"] = sd.get("timed_batch_objects")
+            s["striped_decode"]["bit_exact_objects_per_exchange"] = {name: (ex or {}).get("bit_exact_objects", (ex or {}).get("error", (ex or {}).get("skipped")))
+                                                                     for name, ex in sd["exchange"].items()}
         if "config" in sd:
             s["striped_decode"]["workload"] = sd["config"].get("workload")
     return s
@@ -95,7 +99,7 @@ def summarize(d, n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_world8_rehearsal.txt"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06_world8_rehearsal.txt"))
     ap.add_argument("--worlds", default="2,4,8")
     ap.add_argument("--quick", action="store_true", help="world 8 only, no self-launched twin")
     ap.add_argument("--limit", type=float, default=300.0, help="wall-time budget per invocation (the driver's is 1800 s)")
@@ -140,6 +144,14 @@ def main():
     sd = (d or {}).get("striped_decode") or {}
     record("fault: rank 1 never reaches the collective (watchdog 20 s), N=2", 2, rc, wall, d, nl, err,
            extra_ok="watchdog" in str(sd.get("error")) and (d or {}).get("value", 0) > 0)
+
+    for ex_name in ("allgather", "alltoall", "peer"):
+        rc, wall, d, nl, err = run(torchrun(4, "--op", "striped-decode", "--striped-objects", "64", *drv),
+                                   dict(dry, GARAGE_BENCH_STRIPED_FLIP_RANK="2", GARAGE_BENCH_STRIPED_FLIP_EXCHANGE=ex_name))
+        ex = ((d or {}).get("exchange") or {}).get(ex_name) or {}
+        others = [((d or {}).get("exchange") or {}).get(o, {}).get("bit_exact") for o in ("allgather", "alltoall", "peer") if o != ex_name]
+        record(f"fault: one byte of rank 2's slot buffer flipped before the timed {ex_name} loop, N=4 (must print bit_exact false)", 4, rc, wall, d, nl, err,
+               extra_ok=ex.get("bit_exact") is False and ex.get("bit_exact_objects") == 63 and others == [True, True] and "error" in (d or {}))
 
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
