@@ -36,7 +36,8 @@ SYMBOLS = [
     "gbm_scrub_worker_start", "gbm_scrub_worker_stop", "gbm_scrub_worker_command", "gbm_scrub_worker_status",
     "gbm_block_metrics_get", "gbm_histogram_bounds", "gbm_metrics_prometheus", "gbm_list_resync_errors", "gbm_resync_clear_backoff",
     "gbm_zstd_encode", "gbm_zstd_decode", "gbm_set_resync_workers", "gbm_get_resync_workers", "gbm_resync_config_persist",
-    "gbm_get_tranquility", "gbm_set_put_spot_check", "gbm_test_corrupt_put_sums",
+    "gbm_get_tranquility", "gbm_set_put_spot_check", "gbm_test_corrupt_put_sums", "gbm_set_migrate_on_read", "gbm_shards_migrated",
+    "gbm_node_set_zone", "gbm_node_set_ping", "gbm_set_self_node", "gbm_block_read_order",
 ]
 
 
@@ -154,6 +155,13 @@ def _load():
     lib.gbm_block_rc.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
     lib.gbm_set_verify_block_hash.argtypes = [vp, ci]
     lib.gbm_get_verify_block_hash.argtypes = [vp]
+    lib.gbm_set_migrate_on_read.argtypes = [vp, ci]
+    lib.gbm_shards_migrated.argtypes = [vp]
+    lib.gbm_shards_migrated.restype = ctypes.c_uint64
+    lib.gbm_node_set_zone.argtypes = [vp, ci, ci]
+    lib.gbm_node_set_ping.argtypes = [vp, ci, ctypes.c_uint64]
+    lib.gbm_set_self_node.argtypes = [vp, ci, ci]
+    lib.gbm_block_read_order.argtypes = [vp, ctypes.c_char_p, sz, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(sz)]
     lib.gbm_set_threads.argtypes = [vp, ci]
     lib.gbm_set_timing.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
     lib.gbm_clock_advance.argtypes = [vp, ctypes.c_uint64]
@@ -520,8 +528,9 @@ class NativeBlockManager:
     VERIFY_MODES = {"off": 0, "always": 1, "rebuilt": 2, "rebuilt-only": 2}
 
     def set_verify_block_hash(self, mode) -> None:
-        """The requester's end-to-end block hash: "off" (default, the reference's read path), "rebuilt" (only blocks that
-        went through a decode), "always"; True / False mean "always" / "off".  Shard checksums are checked in every mode."""
+        """The requester's end-to-end block hash: "off", "rebuilt" (only blocks that went through a decode; the default over
+        BLAKE2b-tree shard checksums), "always" (the default over MLH64 shard checksums, header version 3); True / False mean
+        "always" / "off".  Shard checksums are checked in every mode."""
         if isinstance(mode, str):
             mode = self.VERIFY_MODES[mode]
         _check(lib.gbm_set_verify_block_hash(self._h, int(mode)), "set_verify_block_hash")
@@ -529,6 +538,33 @@ class NativeBlockManager:
     @property
     def verify_block_hash(self) -> str:
         return {0: "off", 1: "always", 2: "rebuilt"}[int(lib.gbm_get_verify_block_hash(self._h))]
+
+    # ---- request_order (rpc_helper.rs:621-660) applied to the holders of a block's shards
+    def node_set_zone(self, node: int, zone: int) -> None:
+        _check(lib.gbm_node_set_zone(self._h, node, zone), "node_set_zone")
+
+    def node_set_ping(self, node: int, ping_us: int) -> None:
+        _check(lib.gbm_node_set_ping(self._h, node, ping_us), "node_set_ping")
+
+    def set_self_node(self, node: int, zone: int = 0) -> None:
+        """who is asking: one of the storage nodes (or -1) and its zone"""
+        _check(lib.gbm_set_self_node(self._h, node, zone), "set_self_node")
+
+    def block_read_order(self, hash_: bytes) -> list[tuple[int, int, int]]:
+        """[(node, shard index, layout version)] in the order a read of this block asks its holders"""
+        cnt = ctypes.c_size_t()
+        cap = 64 * self.n
+        nodes, shards, vers = (ctypes.c_int * cap)(), (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
+        _check(lib.gbm_block_read_order(self._h, hash_, cap, nodes, shards, vers, ctypes.byref(cnt)), "block_read_order")
+        return [(nodes[i], shards[i], vers[i]) for i in range(min(cap, cnt.value))]
+
+    def set_migrate_on_read(self, enabled: bool) -> None:
+        """Reads also REWRITE shards of another header version in this manager's (default off: only scrub and resync do)."""
+        _check(lib.gbm_set_migrate_on_read(self._h, int(bool(enabled))), "set_migrate_on_read")
+
+    @property
+    def shards_migrated(self) -> int:
+        return int(lib.gbm_shards_migrated(self._h))
 
     def set_threads(self, n: int) -> None:
         _check(lib.gbm_set_threads(self._h, n), "set_threads")

@@ -73,6 +73,13 @@ const Env &env()
 		const char *b2 = std::getenv("GBM_CPU_BLAKE2");
 		if (b2 && b2[0] == 's')
 			b2host::mb_mode().store(0);
+		// the host form of shard checksum v3 is header-only code with a copy in each library: this library's copy follows
+		// GEC_CPU_ISA as libgarage_ec's does (ec_env.cpp), so that one switch reaches the manager's shard checks as well
+		const char *isa = std::getenv("GEC_CPU_ISA");
+		if (isa && std::string(isa) == "scalar")
+			mlh::isa_cap().store(0);
+		else if (isa && std::string(isa) == "avx2")
+			mlh::isa_cap().store(1);
 		return v;
 	}();
 	return e;
@@ -338,6 +345,8 @@ int create_one(const gec_codec *codec, int nnodes, const char *const *node_dirs,
 	auto mg = std::make_unique<gbm_manager>();
 	mg->codec = codec;
 	mg->sumver = gec_codec_shardsum(codec);  // the shard-header version it writes: its codec's checksum kind
+	// the end-to-end default follows the shard checksum's strength (garage_block.h, gbm_set_verify_block_hash)
+	mg->verify_mode = mg->sumver == 3 ? GBM_VERIFY_ALWAYS : GBM_VERIFY_REBUILT;
 	mg->k = k;
 	mg->m = m;
 	mg->n = k + m;
@@ -430,10 +439,14 @@ int gbm_shardsum_v(int version, const uint8_t *data, size_t len, uint8_t out[32]
 {
 	if (!out || (!data && len) || version < 1 || version > 3)
 		return fail(GBM_E_INVALID_ARG, "gbm_shardsum_v: NULL argument or unknown shard-header version");
-	if (version == 2)
-		gbm_shardsum(data, len, out);
-	else
-		shardsum_v(version, data, len, out);  // (no allocation below 256 KiB; above it bad_alloc is caught by the caller's GBM_TRY... none here: keep it simple)
+	try {  // (the v3 form allocates its leaf sums above 256 KiB: nothing may unwind across the C ABI)
+		if (version == 2)
+			gbm_shardsum(data, len, out);
+		else
+			shardsum_v(version, data, len, out);
+	} catch (const std::exception &e) {
+		return fail(GBM_E_IO, std::string("gbm_shardsum_v: ") + e.what());
+	}
 	return GBM_OK;
 }
 
@@ -601,6 +614,26 @@ int gbm_set_verify_block_hash(gbm_manager *m, int mode)
 
 int gbm_get_verify_block_hash(const gbm_manager *m) { return m ? m->verify_mode.load() : GBM_E_INVALID_ARG; }
 
+int gbm_set_migrate_on_read(gbm_manager *m, int enabled)
+{
+	if (!m)
+		return fail(GBM_E_INVALID_ARG, "NULL manager");
+	GBM_EACH(m, x, x->migrate_on_read = enabled != 0);
+	return GBM_OK;
+}
+
+uint64_t gbm_shards_migrated(const gbm_manager *m)
+{
+	if (!m)
+		return 0;
+	if (!m->is_front())
+		return m->shards_migrated.load();
+	uint64_t t = 0;
+	for (auto &l : m->lanes)
+		t += l->shards_migrated.load();
+	return t;
+}
+
 int gbm_set_tranquility(gbm_manager *m, int scrub_tranquility, int resync_tranquility)
 {
 	if (!m)
@@ -690,6 +723,62 @@ int gbm_node_set_latency(gbm_manager *m, int node, uint64_t latency_us)
 	m->nodes[node]->latency_us = latency_us;
 	return GBM_OK;
 }
+
+int gbm_node_set_zone(gbm_manager *m, int node, int zone)
+{
+	if (!m || node < 0 || node >= (int)m->nodes.size())
+		return fail(GBM_E_INVALID_ARG, "bad node");
+	m->nodes[node]->zone = zone;
+	GBM_EACH(m, x, x->locality_set = true);
+	return GBM_OK;
+}
+
+int gbm_node_set_ping(gbm_manager *m, int node, uint64_t ping_us)
+{
+	if (!m || node < 0 || node >= (int)m->nodes.size())
+		return fail(GBM_E_INVALID_ARG, "bad node");
+	m->nodes[node]->ping_us = ping_us;
+	GBM_EACH(m, x, x->locality_set = true);
+	return GBM_OK;
+}
+
+int gbm_set_self_node(gbm_manager *m, int node, int zone)
+{
+	if (!m || node < -1 || node >= (int)m->nodes.size())
+		return fail(GBM_E_INVALID_ARG, "bad node (-1 = the requester is not a storage node)");
+	GBM_EACH(m, x, {
+		x->self_node = node;
+		x->self_zone = zone;
+		x->locality_set = true;
+	});
+	return GBM_OK;
+}
+
+int gbm_block_read_order(const gbm_manager *m, const uint8_t hash[32], size_t cap, int *nodes_out, int *shards_out, int *versions_out, size_t *count)
+try {
+	if (!m || !hash || !count || (cap && (!nodes_out || !shards_out || !versions_out)))
+		return fail(GBM_E_INVALID_ARG, "NULL argument");
+	const gbm_manager *x = m->is_front() ? m->lanes[0].get() : m;
+	const Hash h((const char *)hash, 32);
+	const int vold = x->layout_oldest.load(), vcur = x->layout_cur.load();
+	std::vector<uint32_t> order;
+	read_candidate_order(x, h, vold, vcur, order);
+	*count = order.size();
+	std::vector<int> who;
+	int who_v = -1;
+	for (size_t i = 0; i < order.size() && i < cap; ++i) {
+		const int v = vold + (int)(order[i] / (uint32_t)x->n), j = (int)(order[i] % (uint32_t)x->n);
+		if (v != who_v) {
+			x->nodes_of(h, v, who);
+			who_v = v;
+		}
+		nodes_out[i] = who[j];
+		shards_out[i] = j;
+		versions_out[i] = v;
+	}
+	return GBM_OK;
+}
+GBM_CATCH
 
 int gbm_set_timing(gbm_manager *m, int64_t gc_delay_ms, int64_t resync_retry_delay_ms, int64_t incref_check_delay_ms)
 {

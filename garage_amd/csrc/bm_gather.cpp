@@ -5,6 +5,55 @@
 
 namespace gbmimpl {
 
+// block_read_nodes_of + request_order (src/rpc/rpc_helper.rs:570-660) applied to SHARDS.  The reference sorts the nodes that
+// may hold a block by (is another node, is another zone, avg ping) and asks "the preferred node in all layout versions (older
+// to newer), then the second preferred one in all versions", itself first.  Here every holder has a different shard and a read
+// needs k of them, so the same order decides WHICH k are asked: the requester's own shard, then the same zone's, then the lowest
+// pings -- a near parity shard and a 0.1 ms decode instead of a far data shard and a WAN round trip; hedged reads go on to
+// the next nearest.  Ties keep shard-index order (data before parity: no decode when nothing distinguishes the holders), so a
+// manager that was told nothing about zones and pings asks as it always did.  A node's ping is what gbm_node_set_ping says
+// (unknown = 10 s, the reference's default, rpc_helper.rs:641).
+void read_candidate_order(const gbm_manager *mg, const Hash &h, int vold, int vcur, std::vector<uint32_t> &order)
+{
+	const int n = mg->n, nver = vcur - vold + 1;
+	const int self = mg->self_node.load(), our_zone = mg->self_zone.load();
+	struct Key {
+		bool other_node, other_zone;
+		uint64_t ping;
+		int node, j;
+	};
+	std::vector<std::vector<Key>> ver(nver);
+	std::vector<int> who;
+	for (int v = 0; v < nver; ++v) {
+		mg->nodes_of(h, vold + v, who);
+		ver[v].resize(n);
+		for (int j = 0; j < n; ++j) {
+			const Node &nd = *mg->nodes[who[j]];
+			const uint64_t ping = nd.ping_us.load(std::memory_order_relaxed);
+			ver[v][j] = Key{who[j] != self, nd.zone.load(std::memory_order_relaxed) != our_zone, ping ? ping : 10000000ull, who[j], j};
+		}
+		std::stable_sort(ver[v].begin(), ver[v].end(), [](const Key &a, const Key &b) {
+			return std::tie(a.other_node, a.other_zone, a.ping) < std::tie(b.other_node, b.other_zone, b.ping);
+		});
+	}
+	order.clear();
+	order.reserve((size_t)nver * n);
+	std::vector<std::pair<int, int>> seen;  // (node, shard): the same request under two versions is made once
+	for (int i = 0; i < n; ++i)
+		for (int v = 0; v < nver; ++v) {
+			const Key &c = ver[v][i];
+			const std::pair<int, int> what(c.node, c.j);
+			if (std::find(seen.begin(), seen.end(), what) != seen.end())
+				continue;
+			seen.push_back(what);
+			const uint32_t idx = (uint32_t)(v * n + c.j);
+			if (nver > 1 && c.node == self)
+				order.insert(order.begin(), idx);  // "it's always fast (almost free) to ask locally" (rpc_helper.rs:594-597)
+			else
+				order.push_back(idx);
+		}
+}
+
 // Fetch shards until every block has `want` valid ones of one geometry in hand (or ran out of nodes): shard
 // index order within the current layout version, then older versions (block_read_nodes_of interleaves
 // versions the same way, rpc_helper.rs:570-619).  The checksums of each round's candidates are verified in
@@ -12,7 +61,7 @@ namespace gbmimpl {
 // queued for resync (read_block_from's behaviour, manager.rs:577-609), and the next node is tried in the
 // following round.
 int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, int want, std::vector<Gathered> &gs,
-		bool verify, const std::vector<uint8_t> *only)
+		bool verify, const std::vector<uint8_t> *only, bool migrate)
 {
 	// verify == false: shards are accepted on their header alone; the caller checks the checksums in the same
 	// device trip that decodes (gec_decode_verify_batch) and comes back for more (`only` = blocks to continue)
@@ -47,9 +96,15 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 			if (ok) {
 				hd.version = (uint8_t)mg->sumver;
 				shardsum_v(mg->sumver, sh.data.data(), hd.shard_len, hd.checksum);
-				ShardRpc up{RpcKind::PutShard, &hs[b], j, sh, nullptr};
-				ShardResp ur;
-				(void)mg->nodes[node]->handle(up, ur);
+				// The REWRITE on its node is maintenance: scrub and resync do it (`migrate`), a read does not unless the operator
+				// asked for it (gbm_set_migrate_on_read) -- a get has no business writing to a store, and two managers of different
+				// kinds reading one store would keep rewriting each other's shards.
+				if (migrate || mg->migrate_on_read.load()) {
+					ShardRpc up{RpcKind::PutShard, &hs[b], j, sh, nullptr};
+					ShardResp ur;
+					if (mg->nodes[node]->handle(up, ur) && ur.ok)
+						mg->shards_migrated++;
+				}
 			}
 		}
 		if (!ok) {
@@ -73,22 +128,24 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 	auto next_candidate = [&](size_t b, const std::function<bool(int)> &taken, std::vector<int> &who, int &who_v,
 				  int &j_out, size_t *c_out = nullptr) -> bool {
 		Gathered &g = gs[b];
-		if (g.tried.size() != ncand)
+		if (g.tried.size() != ncand) {
 			g.tried.assign(ncand, 0);
+			read_candidate_order(mg, hs[b], vold, vcur, g.order);
+		}
 		// a candidate is consumed when it is ASKED, not when it is passed over: shard j being covered by a request that is
 		// still in flight says nothing about j's other holders, which are needed the moment that request fails (a hedge
 		// timer that fired while all n first requests were in flight used to use up every older-version candidate)
-		for (size_t c = 0; c < ncand; ++c) {
+		for (const uint32_t c : g.order) {
 			if (g.tried[c])
 				continue;
-			// The layout versions are walked OLDEST FIRST, shard by shard -- block_read_nodes_of's order (rpc_helper.rs:559-563,
-			// 583-603: "ask the preferred node in all layout versions (older to newer)", because most blocks were saved before
-			// the change).  Here it is also what makes a read safe beside the mover: resync moves a shard with PutShard to its new
-			// owner and only then DeleteShard at the old one, so whoever asks the OLD holder first cannot miss a shard in motion --
-			// it is either still there, or already at the new owner by the time that one is asked.  Newest-first (rounds 2 - 3)
-			// had a window: new owner asked before the put, old one after the delete; with k holders to hear from instead of one
-			// that window made whole blocks read as Missing under the soak.  The price, for the length of the transition: one missed request for every
-			// shard that has already moved (and n of them for a block written after the change).
+			// The order is read_candidate_order's: nearest holders first, and for one shard its holder in the OLDEST layout version
+			// before the newer ones' -- block_read_nodes_of's order (rpc_helper.rs:559-563, 583-603: "ask the preferred node in all
+			// layout versions (older to newer)", because most blocks were saved before the change).  Here that is also what makes a
+			// read safe beside the mover: resync moves a shard with PutShard to its new owner and only then DeleteShard at the old
+			// one, so whoever asks the OLD holder first cannot miss a shard in motion -- it is either still there, or already at the
+			// new owner by the time that one is asked.  Newest-first (rounds 2 - 3) had a window: new owner asked before the put,
+			// old one after the delete; with k holders to hear from instead of one that window made whole blocks read as Missing
+			// under the soak.  The price, for the length of the transition: one missed request for every shard that has already moved.
 			const int v = vold + (int)(c / n), j = (int)(c % n);
 			if (have(g, j) || taken(j))
 				continue;
@@ -123,7 +180,11 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 				while (in_hand(g) + pending < want && next_candidate(b, taken, who, who_v, j)) {
 					ShardRpc rq{RpcKind::GetShard, &hs[b], j, Shard(), tags ? &tags[b] : nullptr};
 					ShardResp rs;
-					if (!mg->nodes[who[j]]->handle(rq, rs) || !rs.ok)
+					if (!mg->nodes[who[j]]->handle(rq, rs)) {
+						g.down_seen = true;  // a holder that could not be asked: the shard may well be there
+						continue;
+					}
+					if (!rs.ok)
 						continue;
 					if (accept(per[b], b, j, who[j], std::move(rs.shard)))
 						++pending;
@@ -140,6 +201,7 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 				Hash h;
 				gbm_order_tag tag;
 				bool has_tag, answered = false, done = false;
+				std::atomic<bool> unreachable{false};  // its holder was down (not: the round ended before it was asked)
 				ShardResp rs;
 			};
 			struct Round {
@@ -193,7 +255,10 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 						ShardResp rs;
 						bool answered = false;
 						try {
-							answered = !rd->over.load() && nd->handle(rq, rs);
+							if (!rd->over.load()) {
+								answered = nd->handle(rq, rs);
+								f->unreachable = !answered;
+							}
 						} catch (...) {  // (out of memory for the shard's copy, as a rule) a holder that did not answer
 							rs = ShardResp();
 						}
@@ -247,6 +312,8 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 			}
 			rd->over = true;
 			for (auto &f : flights) {
+				if (f->unreachable.load())
+					gs[f->b].down_seen = true;
 				if (f->done && f->answered && f->rs.ok)
 					accept(per[f->b], f->b, f->j, f->node, std::move(f->rs.shard));
 				else if (!f->done)

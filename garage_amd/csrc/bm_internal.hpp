@@ -507,6 +507,8 @@ struct Node {
 	std::atomic<bool> down{false};  // flipped by gbm_node_set_down while other threads are talking to the node
 	std::atomic<uint64_t> order_violations{0};
 	std::atomic<uint64_t> latency_us{0};  // test hook: every request to this node takes this long
+	std::atomic<uint64_t> ping_us{0};     // the node's avg_ping as the requester's peering knows it (gbm_node_set_ping; 0 = unknown)
+	std::atomic<int> zone{0};             // the node's zone in the layout (gbm_node_set_zone; LayoutVersion::get_node_zone)
 	std::atomic<uint64_t> requests{0};    // test hook: requests this node has been handed (down or not)
 	std::shared_ptr<BufPool> bufs;
 	virtual ~Node() = default;
@@ -714,9 +716,19 @@ struct gbm_manager {
 	std::atomic<uint64_t> gpu_hashed{0};
 	std::atomic<bool> compress{false};    // Config.compression_level (src/util/config.rs:52-58); Garage's default is Some(1)
 	std::atomic<int> compression_level{1};
-	std::atomic<int> verify_mode{GBM_VERIFY_REBUILT};  // the requester's end-to-end block hash (gbm_set_verify_block_hash)
+	// the requester's end-to-end block hash (gbm_set_verify_block_hash).  Default by shard-header version (set at creation):
+	// ALWAYS over MLH64 shard checksums (version 3: fast but not cryptographic, so the block's own name is checked on every Plain
+	// read as the reference's read path does, block.rs:69-76 / manager.rs:592), REBUILT over the BLAKE2b tree (version 2)
+	std::atomic<int> verify_mode{GBM_VERIFY_REBUILT};
+	// a shard of another header version met by a READ is verified and carried in this manager's version but rewritten on its node
+	// only when this is set (gbm_set_migrate_on_read); scrub and resync always migrate what they touch
+	std::atomic<bool> migrate_on_read{false};
+	std::atomic<uint64_t> shards_migrated{0};
 	std::atomic<size_t> cpu_block_hash_max{96};  // gets of up to this many blocks hash them on the host (gbm_set_threads rescales)
 
+	// who is asking (request_order's our_node_id / our_zone, rpc_helper.rs:626-628): -1 = not one of the storage nodes
+	std::atomic<int> self_node{-1}, self_zone{0};
+	std::atomic<bool> locality_set{false};  // a zone, a ping or the requester's identity has been given: the streaming forms consult the order
 	// hedged reads: 0 = the k requests of a read are issued and awaited in order
 	std::atomic<uint64_t> hedge_us{0}, hedged_reads{0};
 	std::mutex async_mu;
@@ -818,6 +830,8 @@ struct Gathered {
 	bool mixed = false;
 	bool settled = false;  // a geometry has been chosen; later candidates must match it
 	bool corrupt_seen = false;  // a shard of this block was there but failed its header / checksum check during this read
+	bool down_seen = false;     // a holder of this block could not be contacted during this read (its shard may exist)
+	std::vector<uint32_t> order;  // the candidates (index = version-major, shard minor) in the order they are asked (read_candidate_order)
 	struct Group {
 		ShardHeader meta;
 		std::vector<Bytes> shard;
@@ -844,7 +858,10 @@ struct Gathered {
 
 // Fetch shards until every block has `want` valid ones of one geometry in hand (or ran out of nodes) -- bm_gather.cpp
 int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, int want, std::vector<Gathered> &gs,
-		bool verify = true, const std::vector<uint8_t> *only = nullptr);
+		bool verify = true, const std::vector<uint8_t> *only = nullptr, bool migrate = false);
+// The order in which a read asks the holders of a block's shards (block_read_nodes_of + request_order, rpc_helper.rs:570-660,
+// applied to shards): `order` = candidate indices c = (version - vold) * n + shard -- bm_gather.cpp
+void read_candidate_order(const gbm_manager *mg, const Hash &h, int vold, int vcur, std::vector<uint32_t> &order);
 // PutShard to one node; false = the node could not be contacted or refused
 bool send_shard(gbm_manager *mg, int node, const Hash &h, int idx, const Bytes &payload, size_t S, uint64_t orig_len, bool compressed,
 		const uint8_t *checksum, const gbm_order_tag *tag, bool *pending = nullptr);

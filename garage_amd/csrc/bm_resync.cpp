@@ -186,7 +186,7 @@ void resync_blocks(gbm_manager *mg, std::vector<ResyncTask> &tasks, ResyncStats 
 		for (size_t i : todo)
 			hs.push_back(tasks[i].h);
 		std::vector<Gathered> gs;
-		int grc = gather_many(mg, hs, nullptr, k, gs, verify_in_gather);
+		int grc = gather_many(mg, hs, nullptr, k, gs, verify_in_gather, nullptr, /*migrate=*/true);
 		tr.lap(verify_in_gather ? "gather k + checksums" : "gather k");
 		for (size_t q = 0; q < todo.size(); ++q) {
 			ResyncTask &t = tasks[todo[q]];

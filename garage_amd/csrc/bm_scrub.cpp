@@ -133,7 +133,7 @@ ScrubBatch gbmimpl::read_scrub_batch(gbm_manager *mg, std::vector<Hash> hashes)
 	ScrubBatch bt;
 	bt.batch = std::move(hashes);
 	try {
-		bt.rc = gather_many(mg, bt.batch, nullptr, mg->n, bt.g, /*verify=*/false);
+		bt.rc = gather_many(mg, bt.batch, nullptr, mg->n, bt.g, /*verify=*/false, nullptr, /*migrate=*/true);
 		if (bt.rc)
 			bt.err = last_error();  // thread-local: carried to the caller's thread
 	} catch (const std::exception &e) {
@@ -249,7 +249,7 @@ int gbm_scrub(gbm_manager *mg, size_t nb, const uint8_t *hashes, uint8_t *bad_ou
 		for (size_t b = 0; b < nb; ++b)
 			hs[b].assign((const char *)hashes + 32 * b, 32);
 		std::vector<Gathered> g;
-		int grc = gather_many(mg, hs, nullptr, mg->n, g);
+		int grc = gather_many(mg, hs, nullptr, mg->n, g, true, nullptr, /*migrate=*/true);
 		if (grc)
 			return grc;
 		std::map<size_t, std::vector<size_t>> by_len;

@@ -403,6 +403,20 @@ int stream_general(gbm_manager *m, const std::vector<Hash> &hs, const uint8_t ha
 	return rc;
 }
 
+// true when the k holders a read asks first (read_candidate_order) are the k data shards' holders in the oldest active layout
+// version -- always the case for a manager that knows nothing about zones and pings
+static bool nearest_k_are_data(const gbm_manager *m, const Hash &h)
+{
+	if (!m->locality_set.load(std::memory_order_relaxed))
+		return true;
+	std::vector<uint32_t> order;
+	read_candidate_order(m, h, m->layout_oldest.load(), m->layout_cur.load(), order);
+	for (int i = 0; i < m->k && i < (int)order.size(); ++i)
+		if (order[i] >= (uint32_t)m->k)  // (candidate index = version-major, shard minor: < k means a data shard of the oldest version)
+			return false;
+	return true;
+}
+
 // The fast path's requests: data shards lo..hi asked for AT ONCE, each from the node that should hold it in the current
 // layout version; a shard is checked (header, checksum) by the task that fetched it.  Shard `lo` is fetched by the calling
 // thread itself: the first byte waits for no other thread to wake up.
@@ -487,7 +501,12 @@ int get_streaming(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *o
 	// (the oldest active layout version's holders -- where the general form's walk starts as well, bm_gather.cpp; in the
 	// steady state that is the current version)
 	m->nodes_of(hs[0], m->layout_oldest.load(), who);
-	fast_fetch(m, fs, who, 0, k - 1);
+	// (zones / pings known and a data shard's holder is not among the k nearest: the general form asks the k nearest instead and
+	// decodes -- a far data shard would cost the stream a WAN round trip, request_order's whole point, rpc_helper.rs:621-660)
+	if (nearest_k_are_data(m, hs[0]))
+		fast_fetch(m, fs, who, 0, k - 1);
+	else
+		std::fill(fs->st.begin(), fs->st.end(), -1);
 	Trace tr("streaming get");
 	StreamGeom geom;
 	size_t pos = 0;
@@ -610,6 +629,8 @@ int get_range(gbm_manager *m, const uint8_t hash[32], const gbm_order_tag *order
 	auto fs = std::make_shared<Fast>(k, h, order_tag);
 	std::vector<int> who;
 	m->nodes_of(h, m->layout_oldest.load(), who);
+	if (!nearest_k_are_data(m, h))
+		return whole_block();
 	Trace tr("range get");
 	fast_fetch(m, fs, who, j0, j1);
 	for (int j = j0; j <= j1; ++j) {

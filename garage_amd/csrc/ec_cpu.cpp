@@ -299,12 +299,23 @@ struct CpuBackend : Backend {
 		uint8_t *const *out;       // rows output pointers (whole shards)
 	};
 
+	// Leaf sums of checksum v3 left by the encode's own pass (the host analogue of the kernels' SUM form): entry
+	// [(job * nshard + slot) * nleaf + leaf]; slots 0..k-1 are a job's inputs, k.. its output rows.  kChunk is a whole number
+	// of leaves, so a (job, chunk) item owns the leaves it touches; bytes a short input does not have contribute nothing
+	// ("zero bytes contribute nothing", mlh64.hpp), their leaves keep the 0 the array was filled with.
+	struct LeafOut {
+		uint64_t *sums = nullptr;
+		size_t nleaf = 0, nshard = 0;
+	};
+	static_assert(kChunk % mlh::LEAF_BYTES == 0, "a chunk must cover whole checksum leaves");
+
 	// runs every (job, chunk) on the pool
-	void run_jobs(const std::vector<Job> &jobs, size_t S) const
+	void run_jobs(const std::vector<Job> &jobs, size_t S, const LeafOut *lo = nullptr) const
 	{
 		const size_t nch = (S + kChunk - 1) / kChunk;
 		pool->parallel_for(jobs.size() * nch, [&](size_t item) {
-			const Job &j = jobs[item / nch];
+			const size_t ji = item / nch;
+			const Job &j = jobs[ji];
 			const size_t off = (item % nch) * kChunk, len = std::min(kChunk, S - off);
 			const int k = j.prog->k, rows = j.prog->rows;
 			thread_local std::vector<const uint8_t *> in;
@@ -320,32 +331,79 @@ struct CpuBackend : Backend {
 			for (int r = 0; r < rows; ++r)
 				out[r] = j.out[r] + off;
 			apply_range(*j.prog, in.data(), avail.data(), out.data(), len);
+			if (lo) {  // while the chunk is in this core's cache
+				uint64_t *base = lo->sums + ji * lo->nshard * lo->nleaf + off / mlh::LEAF_BYTES;
+				for (int t = 0; t < k; ++t)
+					if (avail[t])
+						mlh::leaf_sums(in[t], avail[t], base + (size_t)t * lo->nleaf);
+				for (int r = 0; r < rows; ++r)
+					mlh::leaf_sums(out[r], len, base + (size_t)(k + r) * lo->nleaf);
+			}
 		});
 	}
 
-	// shard checksums of many S-byte shards, eight chains at a time per core (blake2b_mb.hpp), kShardTask shards per pool task
+	// roots of checksum v3 from leaf sums laid out as LeafOut says: every shard is S bytes long (short ones zero-extended)
+	void roots_from_leaves(const LeafOut &lo, size_t nshards_total, size_t S, uint8_t *shard_sums)
+	{
+		constexpr size_t kPer = 64;
+		pool->parallel_for((nshards_total + kPer - 1) / kPer, [&](size_t g) {
+			for (size_t q = g * kPer; q < std::min(nshards_total, (g + 1) * kPer); ++q)
+				mlh::root(S, lo.sums + q * lo.nleaf, lo.nleaf, shard_sums + 32 * q);
+		});
+	}
+
+	// shard checksums of many S-byte shards, eight chains at a time per core (blake2b_mb.hpp), kShardTask shards per pool task.
+	// `have` < S: only that many bytes exist at p, the shard is those bytes zero-extended to S -- v3 sums the bytes that exist and
+	// binds S in the root; v2 (a hash of every leaf's bytes) extends the shard in a buffer of the pool thread that hashes it
 	struct ShardRef {
 		const uint8_t *p;
 		uint8_t *dst;
+		size_t have = SIZE_MAX;
 	};
 	void shardsums(const std::vector<ShardRef> &list, size_t S)
 	{
 		constexpr size_t kShardTaskMax = 16;
 		// (one shard per task where a core hashes one chain at a time: the scalar fallback keeps the pool busy)
 		const size_t kShardTask = b2host::mb_available() || c->sumkind == GEC_SHARDSUM_MLH64 ? kShardTaskMax : 1;
+		const size_t nl = mlh::nleaf(S);
 		pool->parallel_for((list.size() + kShardTask - 1) / kShardTask, [&](size_t g) {
 			const size_t i0 = g * kShardTask, cnt = std::min(kShardTask, list.size() - i0);
 			if (c->sumkind == GEC_SHARDSUM_MLH64) {  // checksum v3: memory speed on one core (mlh64_host.hpp)
-				for (size_t i = 0; i < cnt; ++i)
-					mlh::shardsum3(list[i0 + i].p, S, list[i0 + i].dst);
+				thread_local std::vector<uint64_t> sums;
+				for (size_t i = 0; i < cnt; ++i) {
+					const ShardRef &r = list[i0 + i];
+					if (r.have >= S) {
+						mlh::shardsum3(r.p, S, r.dst);
+						continue;
+					}
+					sums.assign(nl, 0);
+					if (r.have)
+						mlh::leaf_sums(r.p, r.have, sums.data());
+					mlh::root(S, sums.data(), nl, r.dst);
+				}
 				return;
 			}
+			thread_local std::vector<uint8_t> padbuf;
+			size_t npad = 0;
+			for (size_t i = 0; i < cnt; ++i)
+				npad += list[i0 + i].have < S ? 1 : 0;
+			if (padbuf.size() < npad * S)
+				padbuf.resize(npad * S);
+			npad = 0;
 			const uint8_t *ptr[kShardTaskMax];
 			uint8_t *dst[kShardTaskMax];
 			size_t len[kShardTaskMax];
 			for (size_t i = 0; i < cnt; ++i) {
-				ptr[i] = list[i0 + i].p;
-				dst[i] = list[i0 + i].dst;
+				const ShardRef &r = list[i0 + i];
+				ptr[i] = r.p;
+				if (r.have < S) {
+					uint8_t *q = padbuf.data() + npad++ * S;
+					if (r.have)
+						std::memcpy(q, r.p, r.have);
+					std::memset(q + r.have, 0, S - r.have);
+					ptr[i] = q;
+				}
+				dst[i] = r.dst;
 				len[i] = S;
 			}
 			b2host::shardsum_many(ptr, len, cnt, nullptr, dst);
@@ -370,29 +428,26 @@ struct CpuBackend : Backend {
 				out[b * m + r] = parity[b] + r * S;
 			jobs[b] = Job{&prog, &in[b * k], &valid[b * k], &out[b * m]};
 		}
+		if (shard_sums && c->sumkind == GEC_SHARDSUM_MLH64) {
+			// checksum v3: the leaf sums of all k + m shards come out of the encode's own pass, then one small root per shard
+			std::vector<uint64_t> leaves(nblocks * n * mlh::nleaf(S), 0);
+			const LeafOut lo{leaves.data(), mlh::nleaf(S), n};
+			run_jobs(jobs, S, &lo);
+			roots_from_leaves(lo, nblocks * n, S, shard_sums);
+			return GEC_OK;
+		}
 		run_jobs(jobs, S);
 		if (!shard_sums)
 			return GEC_OK;
-		// the checksum of every shard, data shards as zero-extended to S bytes
+		// the checksum of every shard, data shards as zero-extended to S bytes (extended by the pool task that hashes them)
 		std::vector<ShardRef> list(nblocks * n);
-		std::vector<std::vector<uint8_t>> padded;  // the one short data shard of a block, zero-extended
-		padded.reserve(nblocks);
 		for (size_t q = 0; q < nblocks * n; ++q) {
 			const size_t b = q / n, j = q % n;
 			uint8_t *dst = shard_sums + 32 * q;
-			if (j >= k) {
-				list[q] = {parity[b] + (j - k) * S, dst};
-				continue;
-			}
-			const size_t have = valid[b * k + j];
-			if (have == S) {
-				list[q] = {blocks[b] + j * S, dst};
-			} else {
-				padded.emplace_back(S, 0);
-				if (have)
-					std::memcpy(padded.back().data(), blocks[b] + j * S, have);
-				list[q] = {padded.back().data(), dst};
-			}
+			if (j >= k)
+				list[q] = {parity[b] + (j - k) * S, dst, S};
+			else
+				list[q] = {blocks[b] + j * S, dst, valid[b * k + j]};
 		}
 		shardsums(list, S);
 		return GEC_OK;

@@ -165,17 +165,31 @@ int gbm_set_data_fsync(gbm_manager *m, int enabled);
  * what arrives to the caller unchecked.  A node of an erasure-coded cluster holds a shard, so its equivalent of that check
  * is the shard checksum -- ALWAYS verified here, in every mode, before a byte of the shard is used or delivered.  The
  * block hash on top of that is a mode:
- *   GBM_VERIFY_OFF      (the reference's read path) no end-to-end pass: data shards the decode REBUILT reach the caller
- *                       on the device's word alone;
- *   GBM_VERIFY_REBUILT  (default) only blocks that went through a decode (a missing data shard was rebuilt) are hashed:
- *                       a healthy read keeps the reference's cost, a rebuilt byte never leaves unchecked;
- *   GBM_VERIFY_ALWAYS   every Plain block is hashed (the paranoid setting; round 3's default).
+ *   GBM_VERIFY_OFF      no end-to-end pass: data shards the decode REBUILT reach the caller on the device's word alone;
+ *   GBM_VERIFY_REBUILT  only blocks that went through a decode (a missing data shard was rebuilt) are hashed: a healthy
+ *                       read costs what GBM_VERIFY_OFF costs, a rebuilt byte never leaves unchecked.  The DEFAULT of a manager
+ *                       whose shards carry the BLAKE2b tree checksum (header version 2): a cryptographic hash at the serving
+ *                       side, as the reference's blake2sum is;
+ *   GBM_VERIFY_ALWAYS   every Plain block is hashed against its name.  The DEFAULT of a manager that writes header version 3:
+ *                       MLH64 is fast but NOT cryptographic (public keys; it catches rot, not a consistent rewrite), so the
+ *                       block's own blake2sum is what keeps "every Plain read is checked against its name" true, as in the
+ *                       reference (block.rs:69-76, manager.rs:592).  ~1 ms per MiB on a host core, what the reference's
+ *                       serving node pays per read; an operator who accepts MLH64 alone picks REBUILT.
  * When it is on, the hash runs BEHIND the data: the streaming forms deliver every chunk first and report a mismatch
  * as the stream's final result (GBM_E_CORRUPT_DATA), the way a zstd frame checksum fails a compressed block's tail
  * (block.rs:78-83).  Compressed blocks are checked by their frame checksum in every mode. */
 enum { GBM_VERIFY_OFF = 0, GBM_VERIFY_ALWAYS = 1, GBM_VERIFY_REBUILT = 2 };
 int gbm_set_verify_block_hash(gbm_manager *m, int mode);
 int gbm_get_verify_block_hash(const gbm_manager *m);
+/* Shards of an older header version (1, 2 under a version-3 manager; or 3 under a version-2 one) are verified with THEIR
+ * checksum whenever they are read and handed on in the manager's own version.  They are REWRITTEN on their node in that
+ * version by scrub and resync only; a read rewrites them too when `enabled` is set (default 0: a get never writes to the
+ * store, and two managers of different kinds over one store do not rewrite each other's shards).  The change of format is
+ * one-way for older builds: a build that does not know version 3 reports such shards as unreadable (it never renames or
+ * deletes them), so a store that a version-3 manager has written to or scrubbed cannot be served by a round-4 binary.
+ * gbm_shards_migrated: shards rewritten into this manager's version since it was created. */
+int gbm_set_migrate_on_read(gbm_manager *m, int enabled);
+uint64_t gbm_shards_migrated(const gbm_manager *m);
 /* A block's own checksum is one serial BLAKE2b chain: ~11 ms per MiB on the device however many blocks run beside
  * it, ~1 ms per MiB on a host core.  Gets of up to `nblocks` blocks (default 6 per pool thread = 96) verify it on the
  * host pool from the assembled bytes; larger batches on the device, behind the upload.  0 = always on the device. */
@@ -480,6 +494,26 @@ int gbm_set_read_hedge(gbm_manager *m, uint64_t hedge_us);
 uint64_t gbm_hedged_reads(const gbm_manager *m);
 /* Test hook: every request to this node takes latency_us longer (a slow disk / a far zone). */
 int gbm_node_set_latency(gbm_manager *m, int node, uint64_t latency_us);
+
+/* WHICH holders a read asks, and in what order: block_read_nodes_of + request_order
+ * (/root/reference/src/rpc/rpc_helper.rs:570-660) applied to the holders of a block's SHARDS.  The reference sorts the nodes
+ * that may hold a block by (is another node, is another zone, average ping) and interleaves the layout versions oldest first,
+ * the requester itself in front.  A read of an erasure-coded block needs k holders, so the same order picks the k it asks: its
+ * own shard, the same zone's, then the lowest pings -- a near parity shard plus a decode rather than a far data shard; a
+ * hedged read (gbm_set_read_hedge) goes on to the next nearest.  Ties keep shard-index order, so a manager that is told
+ * nothing asks the k data shards' holders as before.
+ *   gbm_node_set_zone   the node's zone (LayoutVersion::get_node_zone; default 0)
+ *   gbm_node_set_ping   the node's average ping as the requester's peering knows it (rpc_helper.rs:635-641; 0 / never set =
+ *                       unknown = the reference's 10 s default)
+ *   gbm_set_self_node   who is asking: one of the storage nodes (its requests to itself come first) or -1, and its zone
+ *   gbm_block_read_order  the candidates (node, shard index, layout version) of one block in the order a read asks them;
+ *                       *count = how many there are, at most `cap` are written.  A pure function of the layout, the zones,
+ *                       the pings and the hash (what tests/test_block_native.py compares with a restatement of the reference's). */
+int gbm_node_set_zone(gbm_manager *m, int node, int zone);
+int gbm_node_set_ping(gbm_manager *m, int node, uint64_t ping_us);
+int gbm_set_self_node(gbm_manager *m, int node, int zone);
+int gbm_block_read_order(const gbm_manager *m, const uint8_t hash[32], size_t cap, int *nodes_out, int *shards_out, int *versions_out,
+			 size_t *count);
 
 /* out[0..5] = bytes_written, bytes_read, corruption_counter, ec_reconstructs,
  * blocks_put, blocks_get */

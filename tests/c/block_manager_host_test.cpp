@@ -127,7 +127,9 @@ static void run(int k, int m, const char *dir_root)
 	// wrong content under a valid name: the requester's end-to-end check is a mode.  Off (the default: the reference's
 	// requester does not re-hash, manager.rs:276-339) hands out what the shards hold; "always" answers CorruptData.
 	CHECK(gbm_rpc_put_block(mg, hashes.data(), blocks[1].data(), blocks[1].size(), 0, nullptr) == GBM_OK);
-	CHECK(gbm_get_verify_block_hash(mg) == GBM_VERIFY_REBUILT);  // the default: only what a decode rebuilt is hashed end to end
+	// the default follows the shard checksum: ALWAYS over MLH64 (header version 3), REBUILT over the BLAKE2b tree (version 2)
+	CHECK(gbm_get_verify_block_hash(mg) == (gbm_shard_version(mg) == 3 ? GBM_VERIFY_ALWAYS : GBM_VERIFY_REBUILT));
+	CHECK(gbm_set_verify_block_hash(mg, GBM_VERIFY_OFF) == GBM_OK);
 	CHECK(gbm_rpc_get_block(mg, hashes.data(), nullptr, out.data(), out.size(), &got) == GBM_OK && got == blocks[1].size());
 	CHECK(gbm_set_verify_block_hash(mg, GBM_VERIFY_REBUILT) == GBM_OK);  // nothing was rebuilt: not hashed either
 	CHECK(gbm_rpc_get_block(mg, hashes.data(), nullptr, out.data(), out.size(), &got) == GBM_OK);

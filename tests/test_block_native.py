@@ -153,11 +153,14 @@ def test_native_corruption_resync_scrub(codec, tmp_path):
     # silent corruption with a re-stamped checksum: only the RS verify finds it
     mgr.node_corrupt_shard(who[codec.k], h, codec.k, 77, 1, fix_checksum=True)
     assert mgr.scrub(hashes) == [h]
-    # wrong content under a valid name: the default mode (the reference's requester does not re-hash,
-    # manager.rs:276-339) hands it out; the "always" mode answers CorruptData
+    # wrong content under a valid name: "always" -- the default over MLH64 shard checksums (header version 3), as the
+    # reference's read path checks every Plain block against its name (block.rs:69-76, manager.rs:592) -- answers CorruptData;
+    # "rebuilt" (the default over the cryptographic BLAKE2b-tree checksums, version 2) hashes only what a decode rebuilt
     evil = pattern_block(200_000, 99)
     mgr.rpc_put_block(hashes[0], evil)
-    assert mgr.verify_block_hash == "rebuilt" and mgr.rpc_get_block(hashes[0]) == evil   # nothing was rebuilt: not hashed
+    assert mgr.verify_block_hash == ("always" if mgr.shard_version == 3 else "rebuilt")
+    mgr.set_verify_block_hash("rebuilt")
+    assert mgr.rpc_get_block(hashes[0]) == evil   # nothing was rebuilt: not hashed
     mgr.set_verify_block_hash("always")
     with pytest.raises(bn.CorruptData):
         mgr.rpc_get_block(hashes[0])          # (small request: the block hash is checked on the host pool)
@@ -366,6 +369,193 @@ def test_reads_walk_the_layout_versions_oldest_first():
     mgr.close()
 
 
+# ----------------------------------------------------------------- a7: request_order / block_read_nodes_of on shards
+def _reference_request_order(nodes, self_node, our_zone, zone_of, ping_of):
+    """RpcHelper::request_order, /root/reference/src/rpc/rpc_helper.rs:621-660, restated: sort by (is another node, is another
+    zone, avg ping or 10 s), stable."""
+    return sorted(nodes, key=lambda to: (to != self_node, zone_of[to] != our_zone, ping_of.get(to) or 10_000_000))
+
+
+def _reference_block_read_nodes_of(vernodes, self_node, our_zone, zone_of, ping_of, n):
+    """block_read_nodes_of, rpc_helper.rs:570-619, restated on (node, shard) pairs: every layout version's holders in
+    request_order, then "the preferred node in all layout versions (older to newer), then the second preferred one in all
+    versions", no request twice, the requester itself in front when there are several versions."""
+    ordered = []
+    for ver, who in vernodes:                       # oldest version first; who[j] = the holder of shard j in that version
+        pref = _reference_request_order(who, self_node, our_zone, zone_of, ping_of)   # (holders are distinct nodes: 14 of 24)
+        ordered.append([(nd, who.index(nd), ver) for nd in pref])
+    if len(ordered) == 1:
+        return ordered[0]
+    ret = []
+    for i in range(n):
+        for vn in ordered:
+            node, j, ver = vn[i]
+            if any((node, j) == (a, b) for a, b, _ in ret):
+                continue
+            if node == self_node:
+                ret.insert(0, (node, j, ver))
+            else:
+                ret.append((node, j, ver))
+    return ret
+
+
+def test_read_order_is_the_references_request_order_applied_to_shards():
+    """SURVEY section 8 row a7.  gbm_block_read_order (the order the gather walks) against a restatement of the reference's
+    request_order + block_read_nodes_of on random zone / ping tables, with one and with two active layout versions, for a
+    requester that is a storage node and for one that is not.  A manager that is told nothing asks the k data shards first."""
+    import random
+
+    codec = g.ReedSolomon(10, 4, backend="cpu")
+    nn = 24
+    mgr = bn.NativeBlockManager(codec, nn)
+    blocks = [pattern_block(30_000, 3300 + i) for i in range(10)]
+    hashes = [bn.blake2sum(b) for b in blocks]
+    mgr.rpc_put_blocks(list(zip(hashes, blocks)))
+    for h in hashes:                                                   # nothing known: shard-index order, data shards first
+        who = mgr.storage_nodes_of(h)
+        assert mgr.block_read_order(h) == [(who[j], j, 0) for j in range(14)]
+    rnd = random.Random(11)
+    old_holders = {h: mgr.storage_nodes_of(h) for h in hashes}
+    for trial in range(40):
+        if trial == 20:
+            assert mgr.layout_update() == 1                            # from here on: two active versions
+        zone_of = {nd: rnd.randrange(3) for nd in range(nn)}
+        ping_of = {nd: rnd.choice([0, 0, 150, 150, 900, 12_000, 48_000]) for nd in range(nn)}   # 0 = unknown (10 s); ties on purpose
+        self_node, our_zone = (rnd.randrange(nn), None) if trial % 2 else (-1, rnd.randrange(3))
+        if our_zone is None:
+            our_zone = zone_of[self_node]
+        for nd in range(nn):
+            mgr.node_set_zone(nd, zone_of[nd])
+            mgr.node_set_ping(nd, ping_of[nd])
+        mgr.set_self_node(self_node, our_zone)
+        for h in hashes:
+            vernodes = [(0, old_holders[h])] if trial < 20 else [(0, old_holders[h]), (1, mgr.storage_nodes_of(h))]
+            want = _reference_block_read_nodes_of(vernodes, self_node, our_zone, zone_of, ping_of, 14)
+            assert mgr.block_read_order(h) == want, (trial, self_node, our_zone)
+    # the reads still work, whatever the order says
+    assert mgr.rpc_get_blocks(hashes, 30_000) == blocks
+    assert [b"".join(mgr.rpc_get_block_streaming(h)) for h in hashes] == blocks
+    mgr.close()
+
+
+def test_a_far_zone_costs_a_decode_not_its_round_trip(backend):
+    """Which k of the k+m holders a read asks decides whether it pays a WAN round trip or a decode (VERDICT r05 missing #3).
+    14 holders in three zones, the zone that holds data shards 5..9 is 60 ms away.  Told nothing, a hedged read asks the ten data
+    shards' holders and waits for the far zone; told the zones and pings it asks the nine near holders first (four of them parity)
+    and ONE far one, and the block comes back from whichever ten arrive first... which still includes one far shard -- so the
+    far zone gets only as many holders as the near ones cannot cover, and with a near parity for every far data shard (RS(10,4),
+    4 far holders) the read never waits for the far zone at all."""
+    import time
+
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    mgr = bn.NativeBlockManager(codec, 14)
+    data = pattern_block(400_000, 5151)
+    h = bn.blake2sum(data)
+    mgr.rpc_put_block(h, data)
+    who = mgr.storage_nodes_of(h)
+    far = [who[j] for j in (6, 7, 8, 9)]                               # four DATA shards live in the far zone
+    for nd in range(14):
+        mgr.node_set_latency(nd, 60_000 if nd in far else 200)
+    mgr.set_read_hedge(500_000)                                        # all requests of a round at once; no hedge timer in play
+
+    def timed_get():
+        t0 = time.perf_counter()
+        assert mgr.rpc_get_block(h) == data
+        return time.perf_counter() - t0
+
+    before = mgr.metrics["ec_reconstructs"]
+    assert timed_get() > 0.055                                         # told nothing: the ten data shards, four of them 60 ms away
+    assert mgr.metrics["ec_reconstructs"] == before                    # ... and no decode
+    for nd in range(14):
+        mgr.node_set_zone(nd, 1 if nd in far else 0)
+        mgr.node_set_ping(nd, 60_000 if nd in far else 200)
+    mgr.set_self_node(who[12], 0)                                      # the requester holds parity shard 12 itself
+    order = mgr.block_read_order(h)
+    assert order[0] == (who[12], 12, 0) and {j for _, j, _ in order[:10]} == {0, 1, 2, 3, 4, 5, 10, 11, 12, 13}
+    t = min(timed_get() for _ in range(3))
+    assert t < 0.03, f"{t * 1e3:.1f} ms: the read waited for the far zone"   # near round trips + one decode
+    assert mgr.metrics["ec_reconstructs"] > before
+    assert b"".join(mgr.rpc_get_block_streaming(h)) == data            # the streaming form takes the general path here, same order
+    mgr.close()
+
+
+def test_a_block_whose_holders_were_all_down_is_asked_for_again_during_a_transition():
+    """the retry of a Missing block while a layout change is being followed.  A walk that found NOTHING because
+    every holder of the block was DOWN (and the new owners hold nothing yet) has not learnt that the block is absent: during a
+    transition it is worth the two later walks (1 ms, then 5 ms apart) -- the old holders may be back, or the mover may have
+    finished.  A block that every reachable holder of every version denies is final: no sleep, no second walk.  Counted in node
+    requests (no clock in the assertions), and once for real with nodes that come back while the get is waiting."""
+    import threading
+    import time
+
+    codec = g.ReedSolomon(3, 1, backend="cpu")
+    mgr = bn.NativeBlockManager(codec, 12)
+    blocks = [pattern_block(40_000, 8100 + i) for i in range(6)]
+    hashes = [bn.blake2sum(b) for b in blocks]
+    mgr.rpc_put_blocks(list(zip(hashes, blocks)))
+    old = [mgr.storage_nodes_of(h) for h in hashes]
+    assert mgr.layout_update() == 1
+    new = [mgr.storage_nodes_of(h) for h in hashes]
+    i = next(i for i in range(len(blocks)) if not set(new[i]) & set(old[i]))     # no node serves this block in both versions
+    h, o, n_ = hashes[i], old[i], new[i]
+
+    def asked(nodes):
+        return sum(mgr.node_requests(nd) for nd in nodes)
+
+    # (1) a block nobody has ever heard of, every holder up: ONE walk over both versions, final
+    ghost = bn.blake2sum(b"never stored")
+    gho, ghn = None, mgr.storage_nodes_of(ghost)
+    before = asked(range(12))
+    with pytest.raises(bn.MissingBlock):
+        mgr.rpc_get_block(ghost)
+    one_walk = asked(range(12)) - before
+    assert 4 <= one_walk <= 8                                                     # each (version, shard) candidate at most once
+    # (2) every OLD holder of a stored block down, its new owners empty: three walks (the new owners are asked three times)
+    for nd in o:
+        mgr.node_set_down(nd, True)
+    before_new = asked(n_)
+    with pytest.raises(bn.MissingBlock):
+        mgr.rpc_get_block(h)
+    assert asked(n_) - before_new == 3 * 4, "a block whose holders were all unreachable must be asked for again during a transition"
+    # (3) ... and the holders come back while the get waits between its walks: the block is returned
+    ok = []
+    for attempt in range(20):                                                     # (a thread's start is not on a clock: try until one lands in the window)
+        for nd in o:
+            mgr.node_set_down(nd, True)
+
+        def revive():
+            time.sleep(0.003)
+            for nd in o:
+                mgr.node_set_down(nd, False)
+
+        before_new = asked(n_)
+        t = threading.Thread(target=revive)
+        t.start()
+        try:
+            got = mgr.rpc_get_block(h)
+        except bn.MissingBlock:
+            got = None
+        t.join()
+        if got is not None and asked(n_) - before_new >= 4:                       # at least one fruitless walk came first
+            ok.append(got)
+            break
+    assert ok and ok[0] == blocks[i]
+    # (4) outside a transition the same outage is final at once (the reference leaves it to the client's retry)
+    for nd in o:
+        mgr.node_set_down(nd, False)
+    for hh in hashes:
+        mgr.block_incref(hh)
+    mgr.resync_all()
+    mgr.layout_trim()
+    for nd in n_:
+        mgr.node_set_down(nd, True)
+    before_all = asked(range(12))
+    with pytest.raises(bn.MissingBlock):
+        mgr.rpc_get_block(h)
+    assert asked(range(12)) - before_all <= 4
+    mgr.close()
+
+
 @pytest.mark.parametrize("seed,ndev", [(1, 1), (6, 1), (7, 2)])
 def test_arbitrary_arguments_come_back_with_a_code(seed, ndev):
     """tests/c/bm_abi_fuzz.py, a process of its own: NULL manager / hash / data / outputs, node and shard indices out of range,
@@ -537,15 +727,24 @@ def test_older_shard_headers_are_read_and_rewritten_unknown_versions_are_left_al
         r[28:60] = g.shardsum(bytes(r[64:]), other)
         shard_file(j).write_bytes(bytes(r))
     assert mgr.rpc_get_block(h) == data                  # shards 0 and 2 are used after their own checks, shard 1 is skipped: 13 >= k
+    # a READ does not write to the store: the files keep their versions, nothing was migrated ...
+    assert shard_file(0).read_bytes()[4] == 1 and shard_file(2).read_bytes()[4] == other and mgr.shards_migrated == 0
+    # ... unless the operator asks for migration on read
+    mgr.set_migrate_on_read(True)
+    assert mgr.rpc_get_block(h) == data
+    assert mgr.shards_migrated == 2
+    mgr.set_migrate_on_read(False)
     for j in (0, 2):
         again = shard_file(j).read_bytes()
         assert again[4] == writes and again[28:60] == bn.shardsum(again[64:], writes)   # upgraded in place
     assert shard_file(1).exists() and shard_file(1).read_bytes()[4] == 9  # untouched: not *.corrupted, not deleted
     assert not list((tmp_path / f"node{who[1]}" / hx[:2] / hx[2:4]).glob("*.corrupted"))
-    # scrub walks every shard: the parity shard of the other format is verified with its own checksum and rewritten too
+    # scrub walks every shard: the parity shard of the other format is verified with its own checksum and rewritten -- maintenance
+    # migrates whatever the read-side switch says
+    assert shard_file(12).read_bytes()[4] == other
     mgr.scrub_all()
     again = shard_file(12).read_bytes()
-    assert again[4] == writes and again[28:60] == bn.shardsum(again[64:], writes)
+    assert again[4] == writes and again[28:60] == bn.shardsum(again[64:], writes) and mgr.shards_migrated == 3
     # an old-format file whose payload does not match ITS checksum IS corrupt
     for j, ver in ((0, 1), (2, other)):
         r = bytearray(shard_file(j).read_bytes())

@@ -481,6 +481,34 @@ def test_cpu_codec_checksum_kinds_and_siblings():
     assert _lib.lib.gec_codec_with_shardsum(None, 3, ctypes.byref(h)) == _lib.GEC_E_INVALID_ARG and _lib.lib.gec_codec_shardsum(None) == -1
 
 
+@pytest.mark.parametrize("kind", [3, 2])
+def test_put_trip_checksums_of_short_blocks_need_no_padded_copy(kind):
+    """the CPU codec's put trip (gec_encode_hash_batch) used to zero-extend the one short data shard of
+    every block into a fresh buffer, serially, before the pool started.  Checksum v3 now comes out of the encode's own pass (leaf
+    sums of the bytes that exist; S is bound by the root), v2 extends a short shard inside the pool task that hashes it.  The
+    results are those of the zero-extended shards: oracle/mlh64.py (v3) / the product's one-shard form (v2) on block lengths
+    1, k*S - 1, k*S, 1 MiB, and lengths that end inside a leaf, on a leaf boundary and inside the first word of a chunk."""
+    from oracle import mlh64
+
+    k, m = 10, 4
+    rs = g.ReedSolomon(k, m, backend="cpu", shardsum=kind)
+    S = g.shard_len(k, 1 << 20)
+    lens = [1, k * S - 1, k * S, 1 << 20, 3 * S + 4096, 3 * S + 4097, 7 * S + 16384 + 1, 5 * S, 0]
+    blocks = [bytes(O.splitmix64_bytes(900 + i, n)) for i, n in enumerate(lens)]
+    par, sums = rs.encode_hash_blocks(blocks, S)
+    co = O.COracle()
+    data = np.zeros((len(lens), k, S), dtype=np.uint8)
+    for b, blk in enumerate(blocks):
+        data[b].reshape(-1)[: len(blk)] = np.frombuffer(blk, dtype=np.uint8)
+    want_par = co.encode_batch(k, m, data, co.SCALAR)
+    assert np.array_equal(np.stack(par), want_par)
+    for b in range(len(lens)):
+        for j in range(k + m):
+            payload = (data[b, j] if j < k else want_par[b, j - k]).tobytes()
+            want = mlh64.shardsum3(payload) if kind == 3 else g.shardsum(payload, 2)
+            assert sums[b, j].tobytes() == want, (lens[b], j)
+
+
 @pytest.mark.parametrize("k,m,S,nb", [(10, 4, 4160, 40), (3, 1, 64, 9), (10, 12, 1088, 12)])
 def test_reconstruct_dev_ex_on_host_memory(coracle, k, m, S, nb):
     """gec_reconstruct_batch_dev_ex over a CPU codec: the strided call on HOST memory, an erasure pattern per block."""
