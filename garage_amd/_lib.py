@@ -53,6 +53,7 @@ SYMBOLS = [
     "gec_group_peer_decode", "gec_ipc_export", "gec_ipc_open", "gec_ipc_close",
     "gec_launch_geometry",
     "gec_encode_hash_batch_dev", "gec_decode_verify_batch", "gec_shardsum_batch", "gec_shardsum_batch_dev", "gec_host_alloc", "gec_host_free", "gec_host_register", "gec_host_unregister", "gec_host_is_pinned",
+    "gec_codec_numa_node", "gec_codec_numa_cpus", "gec_host_alloc_near", "gec_numa_bind_thread", "gec_numa_node_of",
 ]
 GEC_GROUP_ID_BYTES = 128
 GEC_IPC_HANDLE_BYTES = 72
@@ -153,6 +154,12 @@ def _load() -> ctypes.CDLL:
     lib.gec_host_register.argtypes = [vp, sz]
     lib.gec_host_unregister.argtypes = [vp]
     lib.gec_host_is_pinned.argtypes = [vp, sz]
+    lib.gec_codec_numa_node.argtypes = [vp]
+    lib.gec_codec_numa_cpus.argtypes = [vp, sz, ctypes.POINTER(ci), ctypes.POINTER(sz)]
+    lib.gec_host_alloc_near.argtypes = [vp, sz]
+    lib.gec_host_alloc_near.restype = vp
+    lib.gec_numa_bind_thread.argtypes = [vp]
+    lib.gec_numa_node_of.argtypes = [vp]
     lib.gec_group_unique_id.argtypes = [u8p]
     lib.gec_group_create.argtypes = [vp, ci, ci, u8p, pp]
     lib.gec_group_create_with_transport.argtypes = [vp, ci, ci, vp, vp, pp]

@@ -95,6 +95,27 @@ class ReedSolomon:
     def qos_class(self) -> int:
         return int(lib.gec_codec_class(self._h))
 
+    # ---- NUMA placement of the codec's host side (include/garage_ec.h, gec_codec_numa_node)
+    @property
+    def numa_node(self) -> int:
+        """the memory node the codec keeps its copy threads and pinned memory on (-1: CPU codec, one node, GEC_NUMA=0)"""
+        return int(lib.gec_codec_numa_node(self._h))
+
+    @property
+    def numa_cpus(self) -> list[int]:
+        cnt = ctypes.c_size_t()
+        check(lib.gec_codec_numa_cpus(self._h, 0, None, ctypes.byref(cnt)), "gec_codec_numa_cpus")
+        arr = (ctypes.c_int * max(cnt.value, 1))()
+        check(lib.gec_codec_numa_cpus(self._h, cnt.value, arr, ctypes.byref(cnt)), "gec_codec_numa_cpus")
+        return list(arr[: cnt.value])
+
+    def host_alloc(self, nbytes: int) -> np.ndarray:
+        """gec_host_alloc_near: pinned memory on this codec's memory node (release with garage_amd.host_free)"""
+        p = lib.gec_host_alloc_near(self._h, nbytes)
+        if not p:
+            raise GecError(_lib.GEC_E_NOMEM, "gec_host_alloc_near", (lib.gec_last_error() or b"").decode("utf-8", "replace"))
+        return np.ctypeslib.as_array((ctypes.c_uint8 * max(nbytes, 1)).from_address(p))[:nbytes]
+
     def close(self) -> None:
         h, self._h = getattr(self, "_h", None), None
         if h:

@@ -67,7 +67,7 @@ inline void run_job_scalar(const Job &j)
 }
 
 #ifdef B2MB_X86
-// 0 = one message at a time everywhere (GEC_CPU_BLAKE2 / GBM_CPU_BLAKE2 = scalar, set by each library when it is loaded:
+// 0 = one message at a time everywhere (GEC_CPU_ISA = scalar / avx2, applied by each library when it is loaded:
 // A/B, and how the tests reach the fallback on an AVX-512 box)
 inline std::atomic<int> &mb_mode()
 {

@@ -154,9 +154,9 @@ struct gbm_batcher {
 		// in flight again the batch goes the moment as many blocks are queued (a single put: 0.20 -> 0.17 ms; three: no 30 us
 		// gap behind the third).  As soon as trips overlap -- the batch is formed while another is in flight -- the size of
 		// the crowd is unknown and the linger is back.
-		const size_t crowd = env().batcher_lone_skip && busy_now == 0 && last_size != kCrowdUnknown ? std::max<size_t>(last_size, 1) : 0;
+		const size_t crowd = busy_now == 0 && last_size != kCrowdUnknown ? std::max<size_t>(last_size, 1) : 0;
 		const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(max_wait_us);
-		const unsigned gap_us = env().batcher_gap_us ? env().batcher_gap_us : std::min(100u, std::max(20u, max_wait_us / 10));
+		const unsigned gap_us = std::min(100u, std::max(20u, max_wait_us / 10));  // (a tenth of the linger, within 20..100 us)
 		const auto gap = std::chrono::microseconds(gap_us);
 		size_t seen = q.size();
 		while (!(crowd && q.size() >= crowd) && !stopping && q.size() < max_blocks) {
@@ -203,14 +203,8 @@ struct gbm_batcher {
 		{
 			mu->lock();
 			held = true;
-			if (env().batcher_device_turn > 1)
-				gec_thread_link_release(&LinkTurn::release, this);
 		}
-		void exit()
-		{
-			gec_thread_link_release(nullptr, nullptr);
-			release(this);
-		}
+		void exit() { release(this); }
 	};
 
 	// The linger is a timed wait of a few tens of microseconds; a thread's default timer slack (50 us) would double it.
@@ -244,10 +238,8 @@ struct gbm_batcher {
 			std::vector<std::string> errs(nb);
 			FanoutGate gate;
 			LinkTurn turn{&gdev_mu};
-			if (env().batcher_device_turn) {
-				gate.device_enter = [&] { turn.enter(); };
-				gate.device_exit = [&] { turn.exit(); };
-			}
+			gate.device_enter = [&] { turn.enter(); };
+			gate.device_exit = [&] { turn.exit(); };
 			try {
 				std::vector<uint8_t> hashes(nb * 32);
 				std::vector<uint8_t *> outs(nb);
@@ -345,10 +337,8 @@ struct gbm_batcher {
 				}
 				FanoutGate gate;
 				LinkTurn turn{&dev_mu};
-				if (env().batcher_device_turn) {
-					gate.device_enter = [&] { turn.enter(); };
-					gate.device_exit = [&] { turn.exit(); };
-				}
+				gate.device_enter = [&] { turn.enter(); };
+				gate.device_exit = [&] { turn.exit(); };
 				if (seq) {
 					// tagged blocks in submission order (the queue's), untagged ones behind them
 					for (size_t i = 0; i < nb; ++i)
@@ -439,12 +429,12 @@ gbm_batcher *make_lane(gbm_manager *m, size_t max_blocks, unsigned max_wait_us, 
 	const int nworkers = env().batcher_workers;
 	for (int i = 0; i < nworkers; ++i)
 		b->workers.emplace_back([b] {
-			name_thread("gbm-batch-put");
+			lane_thread("gbm-batch-put", b->mg->is_front() ? nullptr : b->mg->codec);
 			b->run();
 		});
 	for (int i = 0; i < nworkers; ++i)
 		b->gworkers.emplace_back([b] {
-			name_thread("gbm-batch-get");
+			lane_thread("gbm-batch-get", b->mg->is_front() ? nullptr : b->mg->codec);
 			b->run_gets();
 		});
 	return b;

@@ -36,11 +36,7 @@ const EnvRow kEnvRows[] = {
 	{"GBM_BATCHER_WORKERS", "2", "batches the coalescing batcher keeps in flight (per device)"},
 	{"GBM_BATCHER_SPLIT_MIN", "12", "a batcher worker that finds this many blocks queued while other workers are idle takes only its share of them, and half of a queue twice this long even when none is idle (0 = never split)"},
 	{"GBM_BATCHER_GET_SPLIT_MIN", "16", "the same rule for the queue's read side (a big read batch goes in pipelined pieces of its own: it is cut later than a put batch)"},
-	{"GBM_BATCHER_GAP_US", "clamp(linger / 10, 20, 100)", "the batcher's linger ends once nobody has arrived for this long (A/B; 0 = the default)"},
-	{"GBM_BATCHER_LONE_SKIP", "1", "1 = a block that arrives alone (nothing in flight, the previous batch a single block) goes without the linger (0 = always linger; A/B)"},
-	{"GBM_BATCHER_DEVICE_TURN", "1", "one put batch and one get batch of a device's queue on the link at a time, the others prepare / fan out meanwhile: 1 = until the codec call returns, 2 = until its bulk transfers are over (gec_thread_link_release: the next batch's upload runs beside this one's last checksum kernels), 0 = trips overlap freely"},
 	{"GBM_PUT_SPOT_CHECK", "16", "every Nth put trip one device-computed shard checksum is re-computed on the host before anything is sent to a node (0 = never, 1 = every trip; gbm_set_put_spot_check overrides it per manager)"},
-	{"GBM_CPU_BLAKE2", "auto", "the manager's own BLAKE2b (block hashes of small gets, shard checks): auto = eight messages at a time with AVX-512, scalar = one at a time (A/B)"},
 };
 long env_long(const char *name, long def)
 {
@@ -64,29 +60,25 @@ const Env &env()
 		v.batcher_split_min = (size_t)(sm >= 0 ? sm : 12);
 		const long gsm = env_long("GBM_BATCHER_GET_SPLIT_MIN", 16);
 		v.batcher_get_split_min = (size_t)(gsm >= 0 ? gsm : 16);
-		v.batcher_device_turn = (int)std::min<long>(std::max<long>(env_long("GBM_BATCHER_DEVICE_TURN", 1), 0), 2);
-		v.batcher_lone_skip = env_long("GBM_BATCHER_LONE_SKIP", 1) != 0;
-		const long gp = env_long("GBM_BATCHER_GAP_US", 0);
-		v.batcher_gap_us = (unsigned)(gp > 0 && gp < 100000 ? gp : 0);
 		const long sc = env_long("GBM_PUT_SPOT_CHECK", 16);
 		v.put_spot_check = (unsigned)(sc >= 0 && sc <= 1000000 ? sc : 16);
-		const char *b2 = std::getenv("GBM_CPU_BLAKE2");
-		if (b2 && b2[0] == 's')
-			b2host::mb_mode().store(0);
-		// the host form of shard checksum v3 is header-only code with a copy in each library: this library's copy follows
-		// GEC_CPU_ISA as libgarage_ec's does (ec_env.cpp), so that one switch reaches the manager's shard checks as well
+		// the host forms of shard checksum v3 and of BLAKE2b are header-only code with a copy in each library: this library's
+		// copies follow GEC_CPU_ISA as libgarage_ec's do (ec_env.cpp), so that one switch reaches the manager's shard checks and
+		// block hashes as well (scalar / avx2: no AVX-512 forms)
 		const char *isa = std::getenv("GEC_CPU_ISA");
 		if (isa && std::string(isa) == "scalar")
 			mlh::isa_cap().store(0);
 		else if (isa && std::string(isa) == "avx2")
 			mlh::isa_cap().store(1);
+		if (isa && (std::string(isa) == "scalar" || std::string(isa) == "avx2"))
+			b2host::mb_mode().store(0);
 		return v;
 	}();
 	return e;
 }
 
 namespace {
-const bool kEnvReadAtLoad = (env(), true);  // GBM_CPU_BLAKE2 acts on header-only code: in force from the first hash on
+const bool kEnvReadAtLoad = (env(), true);  // GEC_CPU_ISA acts on header-only code: in force from the first hash on
 }  // namespace
 
 const char *env_table_text()
@@ -362,7 +354,8 @@ int create_one(const gec_codec *codec, int nnodes, const char *const *node_dirs,
 		}
 	}
 	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-	mg->pool.reset(new Pool(std::min(15u, hw - 1)));
+	mg->bufs->near = codec;  // shard buffers on the codec's memory node (numa.hpp; before the first buffer is drawn)
+	mg->pool.reset(new Pool(std::min(15u, hw - 1), codec));
 	mg->put_spot_every = env().put_spot_check;
 	// maintenance gets a background-class sibling of the codec (its own staging slots, low-priority streams on a
 	// subset of the CUs, small chunks that yield to the request path); without one it shares the request path's codec

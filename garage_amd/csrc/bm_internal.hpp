@@ -86,9 +86,6 @@ struct Env {
 	int batcher_workers;      // GBM_BATCHER_WORKERS
 	size_t batcher_split_min; // GBM_BATCHER_SPLIT_MIN
 	size_t batcher_get_split_min; // GBM_BATCHER_GET_SPLIT_MIN
-	int batcher_device_turn;  // GBM_BATCHER_DEVICE_TURN
-	unsigned batcher_gap_us;  // GBM_BATCHER_GAP_US
-	bool batcher_lone_skip;   // GBM_BATCHER_LONE_SKIP
 	unsigned put_spot_check;  // GBM_PUT_SPOT_CHECK
 };
 const Env &env();
@@ -217,9 +214,18 @@ inline void name_thread(const char *name)
 #endif
 }
 
+// Threads a lane starts for itself run on its codec's memory node (gec_numa_bind_thread, include/garage_ec.h: a no-op for a CPU
+// codec, a one-node box, GEC_NUMA=0): what they touch -- the lane's pinned shard buffers, the codec's staging slots -- lives there.
+inline void lane_thread(const char *name, const gec_codec *near)
+{
+	name_thread(name);
+	if (near)
+		(void)gec_numa_bind_thread(near);
+}
+
 class Pool {
 public:
-	explicit Pool(unsigned n) { resize(n); }
+	explicit Pool(unsigned n, const gec_codec *near = nullptr) : near_(near) { resize(n); }
 	~Pool() { stop_all(); }
 	void resize(unsigned n)
 	{
@@ -228,7 +234,7 @@ public:
 		stop_ = false;
 		for (unsigned i = 0; i < n; ++i)
 			workers_.emplace_back([this] {
-				name_thread("gbm-pool");
+				lane_thread("gbm-pool", near_);
 				run();
 			});
 	}
@@ -327,6 +333,7 @@ private:
 			work();
 		}
 	}
+	const gec_codec *near_ = nullptr;  // declared before the workers: they read it as they start
 	std::vector<std::thread> workers_;
 	std::mutex mu_, call_mu_;
 	std::condition_variable cv_, done_cv_;
@@ -341,11 +348,11 @@ private:
 // through shared_ptrs, so nobody has to wait for a slow one.
 class Async {
 public:
-	explicit Async(unsigned n)
+	explicit Async(unsigned n, const gec_codec *near = nullptr)
 	{
 		for (unsigned i = 0; i < n; ++i)
-			workers_.emplace_back([this] {
-				name_thread("gbm-async");
+			workers_.emplace_back([this, near] {
+				lane_thread("gbm-async", near);
 				run();
 			});
 	}
@@ -419,6 +426,7 @@ struct Bytes {
 class BufPool : public std::enable_shared_from_this<BufPool> {
 public:
 	static constexpr size_t kRetainMax = 2ull << 30;  // bytes kept for reuse; beyond that buffers are freed
+	const gec_codec *near = nullptr;                  // the lane's codec (set once, before the first get)
 	~BufPool()
 	{
 		for (auto &kv : free_)
@@ -438,8 +446,8 @@ public:
 				retained_ -= cap;
 			}
 		}
-		if (!raw)
-			raw = static_cast<uint8_t *>(gec_host_alloc(cap));
+		if (!raw)  // (pinned, on the lane's codec's memory node whatever device the calling thread has current)
+			raw = static_cast<uint8_t *>(near ? gec_host_alloc_near(near, cap) : gec_host_alloc(cap));
 		if (!raw)
 			throw std::bad_alloc();
 		std::weak_ptr<BufPool> self = shared_from_this();
@@ -737,7 +745,7 @@ struct gbm_manager {
 	{
 		std::lock_guard<std::mutex> g(async_mu);
 		if (!async)
-			async = std::make_shared<Async>(32);
+			async = std::make_shared<Async>(32, codec);
 		return async;
 	}
 

@@ -775,7 +775,7 @@ int gbm_resync_worker_start(gbm_manager *m)
 		m->rs_worker_stop = false;
 		for (int i = 0; i < m->rs_n_workers; ++i)
 			m->rs_workers.emplace_back([m] {
-				name_thread("gbm-resync");
+				lane_thread("gbm-resync", m->codec);
 				resync_worker_loop(m);
 			});
 	} catch (const std::exception &e) {

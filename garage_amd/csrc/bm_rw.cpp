@@ -940,8 +940,8 @@ int gbm_rpc_put_blocks(gbm_manager *mg, size_t nb, const uint8_t *hashes, const 
 		std::vector<std::thread> others;
 		try {
 			for (int t = 1; t < kThreads; ++t)
-				others.emplace_back([&run] {
-					name_thread("gbm-put-slice");
+				others.emplace_back([&run, mg] {
+					lane_thread("gbm-put-slice", mg->codec);
 					run();
 				});
 		} catch (...) {

@@ -431,8 +431,8 @@ int gbm_scrub_worker_start(gbm_manager *m, const char *persist_path, size_t batc
 		if (w->t_last_complete > m->scrub_last_complete_ms.load())
 			m->scrub_last_complete_ms = w->t_last_complete;
 		ScrubWorker *raw = w.get();
-		w->th = std::thread([raw] {
-			name_thread("gbm-scrub");
+		w->th = std::thread([raw, m] {
+			lane_thread("gbm-scrub", m->codec);
 			raw->run();
 		});
 		m->scrub_worker = std::move(w);

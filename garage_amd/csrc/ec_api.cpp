@@ -10,6 +10,7 @@
 
 #include "ec_env.hpp"
 #include "mlh64_host.hpp"
+#include "numa.hpp"
 
 namespace gecimpl {
 
@@ -55,14 +56,17 @@ int check_km(int k, int m)
 	return GEC_OK;
 }
 
+void *Backend::host_alloc(size_t bytes) const { return gec_host_alloc(bytes); }
+
 // ------------------------------------------------------------------ ForkJoinPool
-ForkJoinPool::ForkJoinPool(unsigned n)
+ForkJoinPool::ForkJoinPool(unsigned n, const std::vector<int> &cpus)
 {
 	for (unsigned i = 0; i < n; ++i)
-		workers_.emplace_back([this] {
+		workers_.emplace_back([this, cpus] {
 #ifdef __linux__
 			(void)pthread_setname_np(pthread_self(), "gec-pool");  // top -H, perf, tools/cpu_where.py
 #endif
+			(void)gecnuma::bind_this_thread(cpus);
 			run();
 		});
 }
@@ -499,6 +503,39 @@ int gec_codec_m(const gec_codec *c) { return c ? c->m : 0; }
 int gec_codec_device(const gec_codec *c) { return c ? c->device : -1; }
 int gec_codec_backend(const gec_codec *c) { return c ? c->backend : -1; }
 int gec_codec_class(const gec_codec *c) { return c ? c->qos_class : -1; }
+
+int gec_codec_numa_node(const gec_codec *c) { return c && c->be ? c->be->numa_node() : -1; }
+
+int gec_codec_numa_cpus(const gec_codec *c, size_t cap, int *cpus, size_t *count)
+{
+	if (!c || !count || (cap && !cpus))
+		return fail(GEC_E_INVALID_ARG, "NULL argument");
+	const std::vector<int> *v = c->be ? c->be->numa_cpus() : nullptr;
+	*count = v ? v->size() : 0;
+	for (size_t i = 0; v && i < v->size() && i < cap; ++i)
+		cpus[i] = (*v)[i];
+	return GEC_OK;
+}
+
+void *gec_host_alloc_near(const gec_codec *c, size_t bytes)
+{
+	if (!c || !c->be)
+		return gec_host_alloc(bytes);
+	try {
+		return c->be->host_alloc(bytes);
+	} catch (...) {
+		(void)on_exception();
+		return nullptr;
+	}
+}
+
+int gec_numa_node_of(const void *p) { return p ? gecnuma::node_of_address(p) : -1; }
+
+int gec_numa_bind_thread(const gec_codec *c)
+{
+	const std::vector<int> *v = c && c->be ? c->be->numa_cpus() : nullptr;
+	return v && gecnuma::bind_this_thread(*v) ? 1 : 0;
+}
 
 int gec_parity_matrix(const gec_codec *c, uint8_t *out)
 try {

@@ -686,7 +686,7 @@ struct CpuBackend : Backend {
 	int hash_batch(size_t nmsg, const uint8_t *const *msgs, const size_t *lens, uint8_t *out, bool tree) override
 	{
 		// eight chains at a time per core: tasks of 8 (plain) / 16 (tree: the leaves are the chains) messages
-		// (one message per task without such lanes: GEC_CPU_BLAKE2=scalar, or a host without AVX-512)
+		// (one message per task without such lanes: GEC_CPU_ISA=scalar / avx2, or a host without AVX-512)
 		const size_t per = !b2host::mb_available() ? 1 : tree ? 16 : 8;
 		pool->parallel_for((nmsg + per - 1) / per, [&](size_t g) {
 			const size_t i0 = g * per, cnt = std::min(per, nmsg - i0);

@@ -19,28 +19,21 @@ struct Row {
 // (tests/test_cabi_host.py checks that every GEC_* name in the sources appears here).
 const Row kRows[] = {
 	{"GEC_CPU_THREADS", "min(cores, 16)", "threads a CPU codec spreads one call over (1 = the calling thread only)"},
-	{"GEC_CPU_ISA", "auto", "CPU backend kernel: auto, gfni (AVX-512 + GFNI), avx2 (split-nibble vpshufb) or scalar; the host form of shard checksum v3 follows it (AVX-512 / AVX2 / scalar)"},
-	{"GEC_CPU_BLAKE2", "auto", "host-side BLAKE2b (CPU backend, libgarage_block's own hashes): auto = eight messages at a time with AVX-512, scalar = one at a time (A/B)"},
+	{"GEC_CPU_ISA", "auto", "CPU backend kernel: auto, gfni (AVX-512 + GFNI), avx2 (split-nibble vpshufb) or scalar; the host forms of shard checksum v3 (AVX-512 / AVX2 / scalar) and of BLAKE2b (eight messages at a time with AVX-512, else one) follow it, in libgarage_block as well"},
 	{"GEC_MAX_CALLS", "4", "host-pointer calls in flight per HIP codec; further callers wait (0 = no limit: every concurrent call gets staging slots and device queues of its own)"},
 	{"GEC_COPY_THREADS", "7", "staging-copy threads per HIP codec for pageable caller memory (0 = copy on the calling thread)"},
-	{"GEC_ZERO_COPY", "1", "A/B: 0 = pinned caller memory goes through the device staging pipeline instead of being read in place"},
 	{"GEC_UPLOAD_CUS", "16", "CUs reserved for kernels that read / write host memory (0 = no CU masks)"},
-	{"GEC_VERIFY_SEGMENTS", "min(k, 16)", "A/B: upload stages of gec_decode_verify_batch (1 = upload, then hash)"},
 	{"GEC_PINNED_CHUNK_MB", "128", "chunk size of the staged path for pinned memory"},
 	{"GEC_BG_CUS", "64", "CUs a background-class codec's kernels may occupy (0 = no mask; link kernels stay on GEC_UPLOAD_CUS)"},
 	{"GEC_BG_CHUNK_MB", "32", "chunk size of a background-class codec's host-pointer trips (a foreground call waits for at most one)"},
 	{"GEC_BG_YIELD_US", "2000", "a background chunk waits up to this long for foreground calls on the same device to drain (0 = never waits)"},
 	{"GEC_BG_LINK_WAIT_US", "200", "a background link kernel's workgroups sleep while foreground link kernels run on the device, at most this long per launch (0 = the classes share the link as it comes)"},
 	{"GEC_HOME_RATE_GBPS", "25", "the read path sends rebuilt shards home no faster than this while checksum chains run (0 = unpaced, one workgroup per tile): a link saturated with writes backs up into the fabric and every other kernel's loads wait"},
-	{"GEC_BLAKE2_KERNEL", "auto", "A/B: lane or quad forces one of the two forms of the blake2 kernels (plain hashes, and the leaves / roots of the shard checksums)"},
-	{"GEC_PUT_CHUNKS", "1", "A/B: gec_encode_hash_batch on pinned memory cuts a trip of 16 or more blocks into at least this many chunks, the checksums of one beside the link kernel of the next (1 = only the size-based chunking: one link kernel, one leaf and one root kernel -- 10-15 % faster per trip at 16-32 blocks, profiles/r04_trip_bench.txt)"},
-	{"GEC_GET_PIECES_MIN", "24", "read trips of at least this many blocks go in pieces (a piece has at least 12 blocks)"},
-	{"GEC_GET_PIECES", "4", "a big read trip without block checksums goes in up to this many pieces, upload / checksums + decode / rebuilt shards home pipelined on three streams (0 = one piece: upload, then everything else; A/B)"},
-	{"GEC_FUSED_SMALL", "1", "A/B: 0 = small pinned trips (a PutObject's / GetObject's few blocks) go through the streaming paths (link kernel + leaf kernel + root kernel [+ one decode launch per erasure pattern]) instead of the one-launch kernel"},
 	{"GEC_FUSED_MAX_LEAVES", "3300", "a put trip (gec_encode_hash_batch) with fewer 4 KiB leaves to hash than this takes the one-launch kernel (a 1 MiB RS(10,4) block has 364: up to 9 such blocks; from there on the link kernel + the one-lane-per-leaf checksum kernels are faster per trip, profiles/r04_trip_bench.txt)"},
 	{"GEC_FUSED_GET_MAX_LEAVES", "4400", "the same for a read trip (gec_decode_verify_batch without block checksums: k leaves per tile, 260 per 1 MiB RS(10,4) block: up to 16 such blocks)"},
 	{"GEC_BG_HOME_RATE_GBPS", "20", "a background-class codec writes rebuilt shards into host memory (resync's rebuilds on their way home) no faster than this (0 = unpaced)"},
 	{"GEC_MAX_COLS_PER_LAUNCH", "0", "test hook: cap on the 16-byte columns one launch covers, to exercise the multi-launch split on small inputs"},
+	{"GEC_NUMA", "1", "a HIP codec keeps its host side on its device's memory node: copy threads run on that node's CPUs, pinned staging slots and gec_host_alloc_near memory are bound to it (libgarage_block does the same with a lane's pool / batcher threads and shard buffers); 0 = off: threads and pages go where the scheduler and the HIP runtime put them; far = test hook: the node the device is NOT on (the forced-far leg of profiles/r06_numa.txt)"},
 	{"GEC_RCCL_LIB", "librccl.so.1", "RCCL to dlopen for gec_group_* (when set: that library or GEC_E_DEVICE, no fallback)"},
 };
 
@@ -65,31 +58,25 @@ const Env &env()
 			mlh::isa_cap().store(0);
 		else if (v.cpu_isa == "avx2")
 			mlh::isa_cap().store(1);
-		if (get("GEC_CPU_BLAKE2") && get("GEC_CPU_BLAKE2")[0] == 's')
+		if (v.cpu_isa == "scalar" || v.cpu_isa == "avx2")  // ... and so does the host-side BLAKE2b: one message at a time without AVX-512
 			b2host::mb_mode().store(0);
 		v.max_calls = (unsigned)std::max<long>(get_long("GEC_MAX_CALLS", 4), 0);
 		v.copy_threads = get("GEC_COPY_THREADS") ? (unsigned)std::min<unsigned long>(std::strtoul(get("GEC_COPY_THREADS"), nullptr, 0), 64ul)
 							 : std::min(7u, hw - 1);
-		v.zero_copy = !(get("GEC_ZERO_COPY") && get("GEC_ZERO_COPY")[0] == '0');
 		v.upload_cus = (int)get_long("GEC_UPLOAD_CUS", 16);
-		v.verify_segments = (int)get_long("GEC_VERIFY_SEGMENTS", 0);
 		v.pinned_chunk_mb = (size_t)std::max<long>(get_long("GEC_PINNED_CHUNK_MB", 128), 1);
 		v.bg_cus = (int)get_long("GEC_BG_CUS", 64);
 		v.bg_chunk_mb = (size_t)std::max<long>(get_long("GEC_BG_CHUNK_MB", 32), 1);
 		v.bg_yield_us = (unsigned)std::max<long>(get_long("GEC_BG_YIELD_US", 2000), 0);
 		v.bg_link_wait_us = (unsigned)std::min<long>(std::max<long>(get_long("GEC_BG_LINK_WAIT_US", 200), 0), 1000000);
 		v.home_rate_gbps = (unsigned)std::max<long>(get_long("GEC_HOME_RATE_GBPS", 25), 0);
-		const char *bk = get("GEC_BLAKE2_KERNEL");
-		v.blake2_kernel = !bk ? 0 : (bk[0] == 'l' ? 1 : (bk[0] == 'q' ? 2 : 0));
-		v.put_chunks = (int)std::min<long>(std::max<long>(get_long("GEC_PUT_CHUNKS", 1), 1), 16);
-		v.get_pieces_min = (int)std::min<long>(std::max<long>(get_long("GEC_GET_PIECES_MIN", 24), 1), 1 << 20);
-		v.get_pieces = (int)std::min<long>(std::max<long>(get_long("GEC_GET_PIECES", 4), 0), 16);
-		v.fused_small = (int)get_long("GEC_FUSED_SMALL", 1);
 		v.fused_max_leaves = (size_t)std::max<long>(get_long("GEC_FUSED_MAX_LEAVES", 3300), 0);
 		v.fused_get_max_leaves = (size_t)std::max<long>(get_long("GEC_FUSED_GET_MAX_LEAVES", 4400), 0);
 		v.bg_home_rate_gbps = (unsigned)std::max<long>(get_long("GEC_BG_HOME_RATE_GBPS", 20), 0);
 		v.max_cols_per_launch = get("GEC_MAX_COLS_PER_LAUNCH") ? std::strtoull(get("GEC_MAX_COLS_PER_LAUNCH"), nullptr, 0) : 0ull;
 		v.rccl_lib = get("GEC_RCCL_LIB") ? get("GEC_RCCL_LIB") : "";
+		const char *nu = get("GEC_NUMA");
+		v.numa = !nu || !*nu ? 1 : (nu[0] == '0' ? 0 : (nu[0] == 'f' ? 2 : 1));
 		return v;
 	}();
 	return e;

@@ -16,16 +16,10 @@ struct Env {
 	std::string cpu_isa;    // GEC_CPU_ISA: auto | gfni | avx2 | scalar
 	// ---- HIP backend: host-pointer paths
 	unsigned copy_threads;  // GEC_COPY_THREADS
-	bool zero_copy;         // GEC_ZERO_COPY
 	unsigned max_calls;     // GEC_MAX_CALLS
 	int upload_cus;         // GEC_UPLOAD_CUS
 	unsigned bg_link_wait_us; // GEC_BG_LINK_WAIT_US
 	unsigned home_rate_gbps; // GEC_HOME_RATE_GBPS
-	int verify_segments;    // GEC_VERIFY_SEGMENTS (0 = the built-in maximum)
-	int put_chunks;         // GEC_PUT_CHUNKS
-	int get_pieces;         // GEC_GET_PIECES
-	int get_pieces_min;  // GEC_GET_PIECES_MIN
-	int fused_small;        // GEC_FUSED_SMALL
 	size_t fused_max_leaves;  // GEC_FUSED_MAX_LEAVES
 	size_t fused_get_max_leaves;  // GEC_FUSED_GET_MAX_LEAVES
 	unsigned bg_home_rate_gbps;  // GEC_BG_HOME_RATE_GBPS
@@ -34,9 +28,8 @@ struct Env {
 	int bg_cus;             // GEC_BG_CUS
 	size_t bg_chunk_mb;     // GEC_BG_CHUNK_MB
 	unsigned bg_yield_us;   // GEC_BG_YIELD_US
-	// ---- HIP backend: kernels (A/B)
-	int blake2_kernel;      // GEC_BLAKE2_KERNEL: 0 auto, 1 lane, 2 quad
 	uint64_t max_cols_per_launch;  // GEC_MAX_COLS_PER_LAUNCH (0 = no cap)
+	int numa;               // GEC_NUMA: 1 near (default), 0 off, 2 far (test hook)
 	// ---- multi-GPU
 	std::string rccl_lib;   // GEC_RCCL_LIB ("" = librccl.so.1, then librccl.so)
 };

@@ -13,6 +13,7 @@
 
 #include "ec_env.hpp"
 #include "kernel_args.hpp"
+#include "numa.hpp"
 
 namespace gecimpl {
 
@@ -85,7 +86,20 @@ struct QosPolicy {
 	int compute_cus_plan = 0;  // GEC_BG_CUS as every codec of the process sees it: the CUs set aside for the background class
 	int num_cu = 0;
 	int device = 0;
+	int numa_node = -1;        // the memory node the codec keeps its host side on (-1: unknown / GEC_NUMA=0: nothing is placed)
 };
+
+// hipHostMalloc with the pages on `node` (the codec's: numa.hpp).  The runtime puts pinned memory near the calling thread's CURRENT
+// device unless hipHostMallocNumaUser is given, and then follows the thread's memory policy: so the placement is said out
+// loud -- a lane of device 5 that allocates from a thread whose current device is 0 gets its pages near device 5 all the same.
+// node < 0 (or a kernel that refuses the policy call): the runtime's own choice.
+inline hipError_t host_malloc_on_node(void **p, size_t bytes, unsigned flags, int node)
+{
+	if (node < 0)
+		return hipHostMalloc(p, bytes, flags);
+	gecnuma::ScopedBind bind(node);
+	return hipHostMalloc(p, bytes, bind.ok() ? (flags | hipHostMallocNumaUser) : flags);
+}
 
 // Staging resources for the host-pointer entry points (one per in-flight call).
 struct Staging {
@@ -157,6 +171,10 @@ struct HipBackend : Backend {
 	const gec_codec *c = nullptr;
 	int device = 0;
 	int num_cu = 256;
+	// where the host side of this codec lives (resolved once, at creation: the device's PCI address -> sysfs): the node its copy
+	// threads run on and its pinned memory is bound to.  -1 / empty: unknown, one-node box, or GEC_NUMA=0.
+	int numa_node_ = -1, numa_node_of_device = -1;
+	std::vector<int> numa_cpus_;
 	gec::LogExp *d_logexp = nullptr;
 	QosPolicy qos;
 
@@ -188,6 +206,9 @@ struct HipBackend : Backend {
 	ForkJoinPool &copy_pool() const;
 
 	~HipBackend() override;
+	int numa_node() const override { return numa_node_; }
+	const std::vector<int> *numa_cpus() const override { return numa_cpus_.empty() ? nullptr : &numa_cpus_; }
+	void *host_alloc(size_t bytes) const override;
 
 	int encode_batch(size_t nblocks, const uint8_t *const *blocks, const size_t *block_len, size_t S, uint8_t *const *parity,
 			 uint8_t *shard_sums) override;

@@ -162,7 +162,7 @@ ForkJoinPool &HipBackend::copy_pool() const
 		// a background codec keeps to a couple of copy threads: the staging copies of a scrub must not take the
 		// memory bandwidth a PutObject's copies need
 		const unsigned n = env().copy_threads;
-		copy_threads.reset(new ForkJoinPool(qos.background ? std::min(n, 2u) : n));
+		copy_threads.reset(new ForkJoinPool(qos.background ? std::min(n, 2u) : n, numa_cpus_));  // (on the device's node: numa.hpp)
 	});
 	return *copy_threads;
 }
@@ -206,6 +206,20 @@ int make_hip_backend(gec_codec *c, int device, std::unique_ptr<Backend> &out)
 	hb->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	hb->qos.num_cu = hb->num_cu;
 	hb->qos.device = device;
+	// the device's memory node: PCI address -> /sys/bus/pci/devices/<bdf>/numa_node (numa.hpp; GEC_NUMA)
+	char bdf[64] = {0};
+	if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) == hipSuccess)
+		hb->numa_node_of_device = gecnuma::node_of_pci(bdf);
+	else
+		(void)hipGetLastError();
+	const int nnodes = gecnuma::node_count();
+	if (env().numa != 0 && hb->numa_node_of_device >= 0 && nnodes > 1) {
+		hb->numa_node_ = env().numa == 2 ? (hb->numa_node_of_device + 1) % nnodes : hb->numa_node_of_device;
+		hb->numa_cpus_ = gecnuma::cpus_of_node(hb->numa_node_);
+		if (hb->numa_cpus_.empty())
+			hb->numa_node_ = -1;
+	}
+	hb->qos.numa_node = hb->numa_node_;
 	hb->qos.compute_cus_plan = env().bg_cus > 0 && env().bg_cus < hb->num_cu ? env().bg_cus : 0;
 	if (c->qos_class == GEC_CLASS_BACKGROUND) {
 		// low-priority streams (the hardware scheduler hands free CUs to the foreground queues first) and a CU mask

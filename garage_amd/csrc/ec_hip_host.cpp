@@ -23,7 +23,7 @@ int HipBackend::encode_batch(size_t nblocks, const uint8_t *const *blocks, const
 	for (size_t b = 0; b < nblocks && all_pinned; ++b)
 		all_pinned = aligned16(blocks[b]) && aligned16(parity[b]) && pinned().contains(blocks[b], block_len[b]) &&
 			     pinned().contains(parity[b], m * S);
-	if (all_pinned && k <= (size_t)gec::PTR_KMAX && env().zero_copy) {
+	if (all_pinned && k <= (size_t)gec::PTR_KMAX) {
 		// every buffer is device-addressable: ONE kernel reads the data shards and writes the parity in place
 		// over the link; nothing is staged in HBM, no host copy.  With checksums requested the same kernel also
 		// lays everything it reads and computes down in HBM (the bytes still cross the link once), chunk by
@@ -119,8 +119,6 @@ int HipBackend::encode_batch(size_t nblocks, const uint8_t *const *blocks, const
 		// with checksums a trip of a few dozen blocks (a batch of the coalescing queue) goes in three chunks rather than one:
 		// the checksum kernels of chunk i run beside the link kernel of chunk i+1, and only the last third's are left over
 		// when the link falls idle (one chunk: the whole batch's, a fifth of the trip)
-		if (shard_sums && nblocks >= 16 && env().put_chunks > 1)
-			zch = std::min(zch, (nblocks + (size_t)env().put_chunks - 1) / (size_t)env().put_chunks);
 		const size_t nz = (nblocks + zch - 1) / zch;
 		int rc = st.ensure(shard_sums ? nblocks * n * 32 + 64 : 64, 0);
 		if (!rc)
@@ -286,7 +284,7 @@ int HipBackend::hash_batch(size_t n, const uint8_t *const *msgs, const size_t *l
 	// (b) long messages (a BLAKE2b chain costs ~4000 cycles per 128-byte block however many messages run
 	//     beside it: 14 ms per MiB): everything is first moved into ONE device buffer through two pinned
 	//     staging pieces, then hashed by ONE launch -- chunked launches would pay the chain once per chunk.
-	if (all_pinned && tree && env().zero_copy && n > 1) {
+	if (all_pinned && tree && n > 1) {
 		// Shard checksums of pinned messages: lanes that each stream a 4 KiB leaf out of host memory read the link in
 		// 16-byte pieces (22 GiB/s); a copy kernel moves the same bytes coalesced at the link's rate, so the messages
 		// go to HBM chunk by chunk (copy_table on the upload stream's CUs) and are hashed there beside the next
@@ -684,7 +682,7 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 	// healthy one, instead of upload + decode + a whole chain (24.7 -> see profiles/r03_get_degraded.txt).
 	// One stage unless every shard is pinned (the staged path uploads dense device ranges block by block) and the
 	// chains are long enough to be worth hiding.  GEC_VERIFY_SEGMENTS (A/B): 1 = upload everything, then hash.
-	const int seg_max = env().verify_segments > 0 ? std::min(env().verify_segments, (int)Staging::kMaxSeg) : (int)Staging::kMaxSeg;
+	const int seg_max = (int)Staging::kMaxSeg;
 	const size_t nseg = (all_pinned && block_sums && longest >= (256u << 10)) ? std::min<size_t>(k, (size_t)seg_max) : 1;
 	auto stage_of_slot = [&](size_t slot) {
 		size_t sg = 0;
@@ -772,12 +770,15 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 	// shard checksums, the decodes, the rebuilt shards' way home -- 17 ms with 4 of 16 nodes down.  In pieces instead:
 	// piece c+1 is on its way up while piece c is hashed and decoded and piece c-1's rebuilt shards travel down (the link
 	// is full duplex) -- three streams, one event per piece and direction.
-	if (all_pinned && !block_sums && nblocks >= (size_t)env().get_pieces_min && env().get_pieces != 0) {
+	// (24 blocks and four pieces: a piece keeps at least a dozen blocks -- below that the per-piece launches cost more than the
+	// overlap returns; more than four pieces did not shorten a 512-block trip, profiles/r04_trip_bench.txt)
+	constexpr size_t kGetPiecesMin = 24, kGetPieces = 4;
+	if (all_pinned && !block_sums && nblocks >= kGetPiecesMin) {
 		struct Part {
 			Bucket *bk;
 			size_t first, count;
 		};
-		const size_t npieces = std::max<size_t>(1, std::min<size_t>({(size_t)Staging::kMaxSeg, (size_t)std::max(1, env().get_pieces), nblocks / 12}));
+		const size_t npieces = std::max<size_t>(1, std::min<size_t>({(size_t)Staging::kMaxSeg, kGetPieces, nblocks / 12}));
 		const size_t per_piece = (nblocks + npieces - 1) / npieces;
 		std::vector<std::vector<Part>> pieces(1);
 		size_t in_piece = 0;
@@ -1078,7 +1079,7 @@ int HipBackend::verify_batch(size_t nblocks, const uint8_t *const *shards, size_
 	const size_t n = c->k + c->m;
 	const size_t stripe = n * S;
 	ForegroundScope fg(c);
-	bool all_pinned = (size_t)c->k <= (size_t)gec::PTR_KMAX && env().zero_copy;
+	bool all_pinned = (size_t)c->k <= (size_t)gec::PTR_KMAX;
 	for (size_t i = 0; i < nblocks * n && all_pinned; ++i)
 		all_pinned = aligned16(shards[i]) && pinned().contains(shards[i], S);
 	if (all_pinned) {
@@ -1144,7 +1145,7 @@ int HipBackend::verify_hash_batch(size_t nblocks, const uint8_t *const *shards, 
 {
 	const size_t k = c->k, m = c->m, n = k + m;
 	ForegroundScope fg(c);
-	bool all_pinned = k <= (size_t)gec::PTR_KMAX && env().zero_copy;
+	bool all_pinned = k <= (size_t)gec::PTR_KMAX;
 	for (size_t i = 0; i < nblocks * n && all_pinned; ++i)
 		all_pinned = aligned16(shards[i]) && pinned().contains(shards[i], S);
 	if (!all_pinned) {
@@ -1302,7 +1303,7 @@ int HipBackend::reconstruct_batch(size_t nblocks, const uint8_t *const *shards, 
 		tab_bytes += ids.size() * (k * 12 + nmiss * 8) + 64;
 		work.push_back({&ids, sub, all_pinned});
 	}
-	if (!work.empty() && every_pinned && k <= (size_t)gec::PTR_KMAX && env().zero_copy) {
+	if (!work.empty() && every_pinned && k <= (size_t)gec::PTR_KMAX) {
 		// every shard and every output is device-addressable: one gf_apply_ptrs launch per erasure pattern reads
 		// the k shards the decode uses and writes the rebuilt ones straight over the link
 		DeviceGuard dg(c->device);

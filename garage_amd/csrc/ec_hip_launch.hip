@@ -18,6 +18,12 @@ namespace gecimpl {
 namespace {
 
 std::atomic<int> g_variant{0};
+// gec_set_kernel_variant(2) / (3): the BLAKE2 kernels with one lane / four lanes per message whatever the batch size (0 = by size)
+static inline int test_route_blake2()
+{
+	const int v = g_variant.load(std::memory_order_relaxed);
+	return v == 2 ? 1 : v == 3 ? 2 : 0;
+}
 
 // Launch geometry of the default kernel, tuned on MI355X with tools/kbench
 // (profiles/r01_kbench_*.txt): one tile per workgroup, 1 column per thread.
@@ -220,7 +226,7 @@ int launch_apply(const gec_codec *c, const uint8_t *in, size_t in_stride, uint8_
 			return fail(GEC_E_INVALID_ARG, "stripe too large");
 		a.in_off[t] = (uint32_t)(in_base_off[t] / 16);
 	}
-	const int variant = sum ? 0 : g_variant.load(std::memory_order_relaxed);
+	const int variant = sum ? 0 : (g_variant.load(std::memory_order_relaxed) == 1 ? 1 : 0);  // (2..4 are routes of other kernels)
 	if (sum) {
 		// leaves are 256 columns of a WHOLE shard: the sums of a byte range would not be the shard's
 		if (byte_off != 0 || byte_len % 16 || (size_t)sum->nleaf_max < (byte_len + gec::SHARDSUM_LEAF - 1) / gec::SHARDSUM_LEAF)
@@ -377,7 +383,7 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 			return rc;
 		const dim3 lgrid((unsigned)((lanes + 63) / 64));
 		// few leaves (a PutObject's blocks, a GetObject's): four lanes per leaf, like the plain hash below
-		const int forced_leaf = env().blake2_kernel;
+		const int forced_leaf = test_route_blake2();
 		const bool quad_tree = forced_leaf ? forced_leaf == 2 : lanes < 40000;
 		if (quad_tree && (lanes + 15) / 16 > 0x7fffffffull)  // (the quad kernel indexes its messages in 32 bits)
 			return fail(GEC_E_INVALID_ARG, "too many leaves for one call of the four-lane kernel");
@@ -395,8 +401,8 @@ int blake2_dev(const gec_codec *c, size_t n, const uint8_t *d_base, const uint64
 	}
 	// one lane per message is the faster kernel once there are enough messages to put a
 	// wave on every SIMD (1024 SIMDs x 64 lanes); below that the quad kernel (4 lanes per
-	// message, ~4x shorter chain) wins.  GEC_BLAKE2_KERNEL=lane|quad forces one (A/B).
-	const int forced = env().blake2_kernel;
+	// message, ~4x shorter chain) wins.  (gec_set_kernel_variant(2 | 3) forces one: the tests reach both on one input.)
+	const int forced = test_route_blake2();
 	const bool quad = d_state ? true : forced ? forced == 2 : n < 40000;  // segments: the quad kernel only
 	if (quad)
 		hipLaunchKernelGGL(gec::blake2b_batch_quad<gec::B2Q_PLAIN>, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, stream, a, 0u, static_cast<uint8_t *>(nullptr));
@@ -662,6 +668,8 @@ int launch_apply_ptrs(const gec_codec *c, Staging &st, size_t nblocks, const uin
 // input has `cols` 16-byte columns; they are laid down in d_scratch (>= ptrs_dev_scratch_bytes) behind whatever `stream` holds.
 size_t ptrs_dev_scratch_bytes(size_t nblocks, size_t k, int nout) { return nblocks * k * 8 + ((nblocks * k * 4 + 15) & ~(size_t)15) + nblocks * (size_t)nout * 8; }
 
+// `in` == NULL: d_scratch already holds the tables of an earlier call with the same nblocks / nout / pointers (the caller keys
+// them: a steady-state peer decode is then the launch alone -- no host table, no upload).
 int launch_apply_ptrs_dev(const gec_codec *c, uint8_t *d_scratch, size_t nblocks, const uint8_t *const *in, uint8_t *const *out, int nout,
 			  uint32_t cols, const uint8_t *coef /* nout x k */, hipStream_t stream)
 {
@@ -675,22 +683,24 @@ int launch_apply_ptrs_dev(const gec_codec *c, uint8_t *d_scratch, size_t nblocks
 	if ((uint64_t)gx * nblocks > 0xffffffffull)
 		return fail(GEC_E_INVALID_ARG, "too many tiles for one launch");
 	const size_t in_bytes = nblocks * k * 8, valid_bytes = (nblocks * k * 4 + 15) & ~(size_t)15, out_bytes = nblocks * (size_t)nout * 8;
-	std::vector<uint8_t> host(in_bytes + valid_bytes + out_bytes);
-	std::memcpy(host.data(), in, in_bytes);
-	uint32_t *v = reinterpret_cast<uint32_t *>(host.data() + in_bytes);
-	for (size_t i = 0; i < nblocks * k; ++i)
-		v[i] = cols * 16u;
-	// outputs: row groups of at most RMAX rows, each group's table [nblocks][rows] contiguous
-	uint8_t **o = reinterpret_cast<uint8_t **>(host.data() + in_bytes + valid_bytes);
 	size_t done = 0;
-	for (int r0 = 0; r0 < nout; r0 += gec::RMAX) {
-		const int rows = std::min(gec::RMAX, nout - r0);
-		for (size_t b = 0; b < nblocks; ++b)
-			for (int r = 0; r < rows; ++r)
-				o[done + b * rows + r] = out[b * nout + r0 + r];
-		done += nblocks * rows;
+	if (in) {
+		std::vector<uint8_t> host(in_bytes + valid_bytes + out_bytes);
+		std::memcpy(host.data(), in, in_bytes);
+		uint32_t *v = reinterpret_cast<uint32_t *>(host.data() + in_bytes);
+		for (size_t i = 0; i < nblocks * k; ++i)
+			v[i] = cols * 16u;
+		// outputs: row groups of at most RMAX rows, each group's table [nblocks][rows] contiguous
+		uint8_t **o = reinterpret_cast<uint8_t **>(host.data() + in_bytes + valid_bytes);
+		for (int r0 = 0; r0 < nout; r0 += gec::RMAX) {
+			const int rows = std::min(gec::RMAX, nout - r0);
+			for (size_t b = 0; b < nblocks; ++b)
+				for (int r = 0; r < rows; ++r)
+					o[done + b * rows + r] = out[b * nout + r0 + r];
+			done += nblocks * rows;
+		}
+		HIP_TRY(hipMemcpyAsync(d_scratch, host.data(), host.size(), hipMemcpyHostToDevice, stream));  // (pageable source: staged before the call returns)
 	}
-	HIP_TRY(hipMemcpyAsync(d_scratch, host.data(), host.size(), hipMemcpyHostToDevice, stream));  // (pageable source: staged before the call returns)
 	gec::PtrApplyArgs a;
 	std::memset(&a, 0, sizeof(a));
 	a.in = reinterpret_cast<const uint8_t *const *>(d_scratch);
@@ -712,6 +722,7 @@ int launch_apply_ptrs_dev(const gec_codec *c, uint8_t *d_scratch, size_t nblocks
 		const int mw = rows <= 4 ? 1 : 2;
 		const size_t lds = k * 32 * 4 * mw + 768 + k * gec::RMAX;
 		const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(gec::RESIDENT_WGS, (160u << 10) / lds));
+		// (a grid of what is resident at once: 2x, 4x and one workgroup per tile were 3 - 7 % slower at world 1, profiles/r06_striped.txt)
 		const unsigned grid = (unsigned)std::min<uint64_t>(a.tiles_total, (uint64_t)hb.num_cu * per_cu);
 		using Kern = void (*)(const gec::PtrApplyArgs, const gec::LogExp *);
 		const Kern kern = mw == 1 ? (Kern)gec::gf_apply_ptrs<1, 5, false> : (Kern)gec::gf_apply_ptrs<2, 5, false>;
@@ -750,7 +761,7 @@ bool fused_fits(const gec_codec *c, size_t nblocks, size_t S, int nout, bool has
 	const size_t k = c->k, nh = k + (hash_rows ? (size_t)nout : 0);
 	if (c->sumkind != GEC_SHARDSUM_BLAKE2B_TREE)  // (the one-launch kernel hashes BLAKE2b leaves out of LDS: checksum v2 only)
 		return false;
-	if (env().fused_small == 0 || nblocks == 0 || k > (size_t)gec::PTR_KMAX || nout > gec::RMAX || nh > (size_t)gec::FUSED_MAX_LEAVES)
+	if (g_variant.load(std::memory_order_relaxed) == 4 || nblocks == 0 || k > (size_t)gec::PTR_KMAX || nout > gec::RMAX || nh > (size_t)gec::FUSED_MAX_LEAVES)
 		return false;
 	const size_t tiles_x = (S / 16 + 255) / 256;
 	if (S % 16 || tiles_x * nblocks > 0xffffffffull)
@@ -933,7 +944,7 @@ int gec_launch_geometry(int k, int rows_left, int *rows, int *entry_bytes, int *
 
 int gec_set_kernel_variant(int variant)
 {
-	if (variant < 0 || variant > 1)
+	if (variant < 0 || variant > 4)
 		return fail(GEC_E_INVALID_ARG, "unknown kernel variant");
 	g_variant.store(variant);
 	return GEC_OK;

@@ -225,7 +225,7 @@ int Staging::ensure_tab(size_t entries)
 		(void)hipHostFree(h_tab);
 	h_tab = nullptr;
 	tab_cap = 0;
-	HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_tab), entries * sizeof(gec::CopyEntry), hipHostMallocDefault));
+	HIP_TRY(host_malloc_on_node(reinterpret_cast<void **>(&h_tab), entries * sizeof(gec::CopyEntry), hipHostMallocDefault, qos.numa_node));
 	tab_cap = entries;
 	return GEC_OK;
 }
@@ -250,7 +250,7 @@ int Staging::ensure(size_t bytes, size_t nbad)
 			(void)hipFree(d_buf);
 		h_buf = d_buf = nullptr;
 		cap = 0;
-		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_buf), bytes, hipHostMallocDefault));
+		HIP_TRY(host_malloc_on_node(reinterpret_cast<void **>(&h_buf), bytes, hipHostMallocDefault, qos.numa_node));
 		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_buf), bytes));
 		cap = bytes;
 	}
@@ -261,7 +261,7 @@ int Staging::ensure(size_t bytes, size_t nbad)
 			(void)hipFree(d_bad);
 		h_bad = d_bad = nullptr;
 		bad_cap = 0;
-		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_bad), nbad * sizeof(uint32_t), hipHostMallocDefault));
+		HIP_TRY(host_malloc_on_node(reinterpret_cast<void **>(&h_bad), nbad * sizeof(uint32_t), hipHostMallocDefault, qos.numa_node));
 		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_bad), nbad * sizeof(uint32_t)));
 		bad_cap = nbad;
 	}
@@ -466,6 +466,25 @@ size_t pinned_chunk_bytes(const gec_codec *c)
 }  // namespace gecimpl
 
 using namespace gecimpl;
+
+// gec_host_alloc_near: pinned like gec_host_alloc's, with the pages on this codec's memory node
+void *HipBackend::host_alloc(size_t bytes) const
+{
+	void *p = nullptr;
+	DeviceGuard g(device);
+	hipError_t e = host_malloc_on_node(&p, std::max<size_t>(bytes, 1), hipHostMallocPortable, numa_node_);
+	if (e != hipSuccess) {
+		fail(e == hipErrorOutOfMemory ? GEC_E_NOMEM : GEC_E_DEVICE, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+		return nullptr;
+	}
+	try {
+		pinned().add(p, std::max<size_t>(bytes, 1), true);
+	} catch (...) {
+		(void)hipHostFree(p);
+		throw;
+	}
+	return p;
+}
 
 extern "C" {
 

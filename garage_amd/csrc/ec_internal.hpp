@@ -60,7 +60,8 @@ struct Plan {
 // well below PCIe Gen5), the CPU backend one per codec for the arithmetic itself.
 class ForkJoinPool {
 public:
-	explicit ForkJoinPool(unsigned nworkers);
+	// `cpus` (optional): the workers are restricted to these CPUs (a HIP codec's copy threads run on its device's memory node)
+	explicit ForkJoinPool(unsigned nworkers, const std::vector<int> &cpus = {});
 	~ForkJoinPool();
 	void parallel_for(size_t n, const std::function<void(size_t)> &fn);
 	unsigned workers() const { return (unsigned)workers_.size(); }
@@ -84,6 +85,11 @@ private:
 // pointers, S, shard counts) before any of these is called; nblocks / n is > 0.
 struct Backend {
 	virtual ~Backend() = default;
+	// where the codec's host side lives (numa.hpp): -1 / NULL for a CPU codec, a one-node box, or GEC_NUMA=0
+	virtual int numa_node() const { return -1; }
+	virtual const std::vector<int> *numa_cpus() const { return nullptr; }
+	// pinned memory near the codec's device (gec_host_alloc_near); a CPU codec hands out what gec_host_alloc does
+	virtual void *host_alloc(size_t bytes) const;
 
 	// ---- host-pointer entry points (both backends)
 	// shard_sums == NULL: gec_encode_batch, else gec_encode_hash_batch

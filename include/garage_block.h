@@ -99,7 +99,7 @@ int gbm_shardsum_v(int version, const uint8_t *data, size_t len, uint8_t out[32]
 /* blake2sum of n buffers on the calling thread, out[32 * i] for buffer i: the content hashes of a PutObject's blocks,
  * which the API layer computes before it calls rpc_put_block (src/api/s3/put.rs).  BLAKE2b is one serial chain per
  * message, but eight messages fit the eight lanes of an AVX-512 register: n >= 2 blocks cost about as much as one
- * (GBM_CPU_BLAKE2=scalar: one at a time).  GBM_OK, GBM_E_INVALID_ARG (a NULL pointer with a non-zero length: nothing is
+ * (GEC_CPU_ISA=scalar or avx2: one at a time).  GBM_OK, GBM_E_INVALID_ARG (a NULL pointer with a non-zero length: nothing is
  * written) or GBM_E_IO (out of memory). */
 int gbm_blake2sum_batch(size_t n, const uint8_t *const *data, const size_t *len, uint8_t *out);
 
@@ -308,7 +308,7 @@ int gbm_rpc_get_block_range_streaming(gbm_manager *m, const uint8_t hash[32], co
  * the block has been encoded and fanned out; a worker thread turns everything queued within
  * max_wait_us (or max_blocks) into ONE device call, GBM_BATCHER_WORKERS (default 2) such batches in flight at a
  * time: a worker that finds the others idle takes only its share of a long queue (GBM_BATCHER_SPLIT_MIN), and one
- * batch at a time is on the link (GBM_BATCHER_DEVICE_TURN), so that one batch's host stages overlap the other's
+ * batch at a time is on the link, so that one batch's host stages overlap the other's
  * device trip instead of all callers moving in lock step.  Batches that carry order tags hand their shards to the
  * nodes in the order the batches were formed, so blocks of one OrderTag stream reach every node in `order` order
  * even when they land in different batches -- and, on a multi-device manager (one queue per device), on different

@@ -208,7 +208,7 @@ int gec_codec_cache_stats(const gec_codec *c, uint64_t *cached,
  * memory; when every buffer of a gec_encode_batch / gec_reconstruct_batch call lies inside a range
  * obtained here (and is 16-byte aligned) the kernel reads the shards out of the caller's memory and
  * writes its results into it over PCIe -- no host copy, no staging in device memory, one launch
- * (50 GiB/s of payload on a Gen5 x16 link, 39 us for one 1 MiB block; GEC_ZERO_COPY=0 disables) --
+ * (50 GiB/s of payload on a Gen5 x16 link, 39 us for one 1 MiB block) --
  * while ordinary pageable buffers are first copied through the library's own pinned staging slots.  The Rust
  * shim would draw the block buffers PutObject fills (src/api/s3/put.rs:440-456) and the parity
  * buffers from a pool allocated with gec_host_alloc, or register its existing arena once.
@@ -220,6 +220,25 @@ void gec_host_free(void *p);
 int gec_host_register(void *p, size_t bytes);   /* pin caller-owned memory (hipHostRegister) */
 int gec_host_unregister(void *p);
 int gec_host_is_pinned(const void *p, size_t bytes); /* 1 if [p, p+bytes) lies inside one such range */
+
+/* NUMA placement of a codec's host side.  No reference counterpart (Garage has no device; the nearest it has is one set of
+ * resources per use: the data-dir shards of /root/reference/src/block/manager.rs:679-689, the RAM buffer permits of :156 and
+ * :380-385).  The deployable paths are host-fed: a device's DMA engines and link kernels read pinned host memory that the
+ * codec's copy threads (and the caller's) fill, and on a two-socket node half the GPUs hang off each socket.  A HIP codec
+ * therefore resolves its device's memory node once, at creation (PCI address -> /sys/bus/pci/devices/<bdf>/numa_node), runs its
+ * copy threads on that node's CPUs and binds its pinned staging slots to it; GEC_NUMA=0 switches all of it off.
+ *   gec_codec_numa_node   that node; -1 = a CPU codec, a box with one node, an unknown topology, or GEC_NUMA=0
+ *   gec_codec_numa_cpus   the node's CPUs (*count = how many; at most cap are written)
+ *   gec_host_alloc_near   gec_host_alloc with the pages bound to the codec's node whatever device the calling thread has
+ *                         current (free with gec_host_free).  What a lane's shard buffers should come from.
+ *   gec_numa_bind_thread  restricts the CALLING thread to the codec's node's CPUs (a host that dedicates threads to a lane --
+ *                         libgarage_block's pool, batcher workers -- calls it once per thread); 1 = bound, 0 = nothing done
+ *   gec_numa_node_of      the node the page at p is on right now (move_pages in query mode); -1 = not resident / not allowed */
+int gec_codec_numa_node(const gec_codec *c);
+int gec_codec_numa_cpus(const gec_codec *c, size_t cap, int *cpus, size_t *count);
+void *gec_host_alloc_near(const gec_codec *c, size_t bytes);
+int gec_numa_bind_thread(const gec_codec *c);
+int gec_numa_node_of(const void *p);
 
 /* == ReedSolomon::encode_sep(&data, &mut parity) [EXT], batched.
  * Replaces the "clone the same Bytes to rf nodes" fan-out payload of
@@ -544,9 +563,11 @@ int gec_encode_hash_batch_dev(const gec_codec *c, size_t nblocks, void *d_stripe
 int gec_launch_geometry(int k, int rows_left, int *rows, int *entry_bytes,
 			int *loads_per_batch, int *threads, size_t *lds_bytes);
 
-/* Kernel selection for A/B measurements (bench.py --variant).  0 = default
- * (nibble product tables in LDS), 1 = log/antilog tables in LDS (the literal
- * north_star formulation, kept as the measured baseline).  Process-wide. */
+/* Kernel selection for A/B measurements and tests, process-wide.  0 = default (nibble product tables in LDS; every
+ * other choice by size), 1 = the RS kernel with log/antilog tables in LDS (the literal north_star formulation, kept as
+ * the measured baseline: bench.py --variant 1).  Test routes -- they pick between kernels the default already uses at
+ * different sizes, so that one input reaches both: 2 / 3 = the BLAKE2b kernels with one lane / four lanes per message,
+ * 4 = small pinned trips of a checksum-v2 codec take the streaming kernels instead of the one-launch kernel. */
 int gec_set_kernel_variant(int variant);
 int gec_get_kernel_variant(void);
 

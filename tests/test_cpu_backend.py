@@ -428,7 +428,7 @@ for n in range(1, 18):
 print("ok")
 """ % ROOT
     for mode in ("auto", "scalar"):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GEC_CPU_BLAKE2=mode, GBM_CPU_BLAKE2=mode, GEC_CPU_THREADS="3"))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GEC_CPU_ISA=mode, GEC_CPU_THREADS="3"))
         assert r.returncode == 0 and "ok" in r.stdout, (mode, r.stdout, r.stderr[-2000:])
 
 

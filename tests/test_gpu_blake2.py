@@ -88,6 +88,7 @@ def test_blake2_quad_and_lane_kernels_agree_on_tails(rs):
 import hashlib, sys
 sys.path.insert(0, %r)
 import garage_amd as g
+g.set_kernel_variant(int(sys.argv[1]))   # 2 / 3: the BLAKE2b kernels with one lane / four lanes per message (include/garage_ec.h)
 rs = g.ReedSolomon(10, 4, shardsum=2)
 lens = list(range(0, 300)) + [383, 384, 385, 4095, 4096, 4097, 104896]
 msgs = [bytes((i * 7 + j) & 255 for j in range(n)) for i, n in enumerate(lens)]
@@ -99,8 +100,8 @@ tm = [bytes((i * 11 + j * 3) & 255 for j in range(n)) for i, n in enumerate(tl)]
 assert rs.shardsum_batch(tm) == [g.shardsum(x, 2) for x in tm]
 print("ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for kern in ("quad", "lane"):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GEC_BLAKE2_KERNEL=kern))
+    for kern, variant in (("quad", "3"), ("lane", "2")):
+        r = subprocess.run([sys.executable, "-c", code, variant], capture_output=True, text=True)
         assert r.returncode == 0 and "ok" in r.stdout, (kern, r.stdout, r.stderr[-2000:])
 
 
@@ -164,7 +165,7 @@ def test_encode_hash_batch_zero_copy_pinned(coracle, k, m, L, nb):
 @pytest.mark.parametrize("kernel", ["lane", "quad"])
 def test_both_kernels_forced(kernel):
     """The host picks the one-lane or the four-lane kernel by batch size; force each
-    (GEC_BLAKE2_KERNEL is read once per process) and check ragged + uniform inputs."""
+    (gec_set_kernel_variant 2 / 3, a process of its own) and check ragged + uniform inputs."""
     import os
     import subprocess
     import sys
@@ -173,6 +174,7 @@ def test_both_kernels_forced(kernel):
 import hashlib, sys
 import numpy as np, torch
 import garage_amd as g
+g.set_kernel_variant(int(sys.argv[1]))
 from oracle import rs_oracle as O
 rs = g.ReedSolomon(10, 4, shardsum=2)
 ref = lambda b: hashlib.blake2b(b, digest_size=64).digest()[:32]
@@ -184,9 +186,8 @@ out = rs.blake2sum_dev(torch.from_numpy(data).to("cuda:0")).cpu().numpy()
 assert all(out[i].tobytes() == ref(data[i].tobytes()) for i in range(70)), "uniform"
 print("OK")
 '''
-    env = dict(os.environ, GEC_BLAKE2_KERNEL=kernel)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", code, {"lane": "2", "quad": "3"}[kernel]], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 

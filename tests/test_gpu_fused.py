@@ -3,7 +3,7 @@ launches, not bytes, are what they cost -- for BOTH shard checksum kinds:
   kind 3 (MLH64, the default): the link kernel leaves the leaf sums itself (gf_apply_ptrs SUM form) + one root kernel;
   kind 2 (BLAKE2b tree): the one-launch kernel of round 4 (garage_amd/csrc/fused.hpp).
 Parity and rebuilt shards against the CPU oracle, every checksum against the restatement of its kind, the same calls again
-with GEC_FUSED_SMALL=0 (the streaming paths) as an A/B, and kernel counts from rocprofv3 where it is installed."""
+with gec_set_kernel_variant(4) (the streaming paths) as an A/B, and kernel counts from rocprofv3 where it is installed."""
 import ctypes
 import os
 import subprocess
@@ -132,7 +132,7 @@ def test_get_in_one_launch_many_erasure_patterns(coracle, k, m, L, nb, kind):
 
 
 def test_fused_and_streaming_paths_agree_and_fused_launches_fewer_kernels(tmp_path):
-    """A/B in two subprocesses (GEC_FUSED_SMALL is read once per process): identical bytes and checksums either way; under
+    """A/B in two subprocesses (gec_set_kernel_variant(4) = the streaming route): identical bytes and checksums either way; under
     rocprofv3 the small put is ONE kernel launch and the degraded small get ONE (three to five and four-plus before)."""
     code = r'''
 import sys, hashlib, json
@@ -141,6 +141,7 @@ sys.path.insert(0, %r)
 import garage_amd as g
 from oracle import rs_oracle as O
 from tests.test_gpu_fused import _put, _get
+g.set_kernel_variant(0 if sys.argv[1] == "1" else 4)
 k, m = 10, 4
 rs = g.ReedSolomon(k, m, shardsum=2)
 S = g.shard_len(k, 1 << 20)
@@ -158,8 +159,7 @@ print("DIGEST", h.hexdigest())
 ''' % ROOT
     digests = {}
     for fused in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, GEC_FUSED_SMALL=fused), capture_output=True,
-                           text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", code, fused], cwd=ROOT, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         digests[fused] = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0]
     assert digests["1"] == digests["0"]
@@ -169,8 +169,8 @@ print("DIGEST", h.hexdigest())
     counts = {}
     for fused in ("1", "0"):
         out = tmp_path / f"prof{fused}"
-        r = subprocess.run([rocprof, "--kernel-trace", "--stats", "-d", str(out), "-o", "t", "--output-format", "csv", "--", sys.executable, "-c", code],
-                           cwd="/tmp", env=dict(os.environ, GEC_FUSED_SMALL=fused, TMPDIR="/tmp"), capture_output=True, text=True, timeout=900)
+        r = subprocess.run([rocprof, "--kernel-trace", "--stats", "-d", str(out), "-o", "t", "--output-format", "csv", "--", sys.executable, "-c", code, fused],
+                           cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         names = []
         for dirpath, _, files in os.walk(out):

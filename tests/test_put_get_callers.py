@@ -51,7 +51,7 @@ def test_callers_under_tsan_multi_device_cpu_backend():
     """a TSan run of the caller pattern over the multi manager -- four logical devices."""
     _make("put_get_callers_tsan")
     r = subprocess.run([os.path.join(CDIR, "put_get_callers_tsan"), "8", "9", "65536", "3", "4"], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, GEC_CPU_THREADS="2", GBM_BATCHER_DEVICE_TURN="2"))  # turns end at the codec's link-release call
+                       env=dict(os.environ, GEC_CPU_THREADS="2"))
     if "FATAL: ThreadSanitizer: unexpected memory mapping" in r.stderr:
         pytest.skip("TSan cannot run in this container (ASLR/memory layout)")
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
@@ -75,13 +75,11 @@ def test_callers_on_the_real_libraries_cpu_backend():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("turn", ["1", "2"])
-def test_callers_on_the_gpu_one_mib_blocks(turn):
-    """16 PutObjects x 12 blocks of 1 MiB (48 puts in flight: the batcher's design load) beside 4 GetObjects; a batch's turn on the
-    link ends when its codec call returns (1) or when the call's bulk transfers are over (2, gec_thread_link_release)."""
+def test_callers_on_the_gpu_one_mib_blocks():
+    """16 PutObjects x 12 blocks of 1 MiB (48 puts in flight: the batcher's design load) beside 4 GetObjects; one batch of a
+    device's queue on the link at a time (its turn ends when its codec call returns)."""
     _make("put_get_callers")
-    r = subprocess.run([os.path.join(CDIR, "put_get_callers"), "16", "12", "1048576", "4"], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, GBM_BATCHER_DEVICE_TURN=turn))
+    r = subprocess.run([os.path.join(CDIR, "put_get_callers"), "16", "12", "1048576", "4"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     _check(r.stdout, "hip")
     print(r.stdout)

@@ -56,7 +56,7 @@ def main():
         res[f"encode_hash_dev_{nblocks}_stripes"] = {"ms": round(ms, 3), "encode_only_ms": round(ms_enc, 3),
                                                       "hashed_GBps": round(nblocks * 14 * S / ms / 1e6, 1)}
         del st
-    print(json.dumps({"what": "GPU blake2sum of 104896-byte shards, device-resident, kernel = " + os.environ.get("GEC_BLAKE2_KERNEL", "auto (quad < 40000 messages <= lane)"), "results": res}))
+    print(json.dumps({"what": "GPU blake2sum of 104896-byte shards, device-resident, kernel = " + "auto (quad < 40000 messages <= lane)", "results": res}))
 
 
 if __name__ == "__main__":

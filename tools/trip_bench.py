@@ -42,7 +42,7 @@ def main():
     arena = host_alloc(NB * n * S)
     arena[:] = np.random.default_rng(5).integers(0, 256, arena.size, dtype=np.uint8)
     out = host_alloc(NB * m * S)
-    tag = " ".join(f"{v}={os.environ[v]}" for v in ("GEC_FUSED_MAX_LEAVES", "GEC_PUT_CHUNKS", "GEC_GET_PIECES", "GEC_FUSED_SMALL") if v in os.environ)
+    tag = " ".join(f"{v}={os.environ[v]}" for v in ("GEC_FUSED_MAX_LEAVES", "GEC_FUSED_GET_MAX_LEAVES") if v in os.environ)
     print(f"# trip_bench RS(10,4) 1 MiB blocks, pinned memory, median of {reps}; {tag or 'defaults'}")
     print("# blocks   put ms  GiB/s   get ms  GiB/s   degraded get ms  GiB/s")
     for nb in (1, 2, 3, 4, 6, 8, 12, 16, 20, 24, 32, 48, 64):
