@@ -237,7 +237,9 @@ public:
 				lane_thread("gbm-pool", near_);
 				run();
 			});
+		nworkers_ = n;
 	}
+	unsigned workers() const { return nworkers_.load(std::memory_order_relaxed); }
 	void parallel_for(size_t n, const std::function<void(size_t)> &fn)
 	{
 		if (n == 0)
@@ -334,6 +336,7 @@ private:
 		}
 	}
 	const gec_codec *near_ = nullptr;  // declared before the workers: they read it as they start
+	std::atomic<unsigned> nworkers_{0};
 	std::vector<std::thread> workers_;
 	std::mutex mu_, call_mu_;
 	std::condition_variable cv_, done_cv_;
@@ -907,6 +910,11 @@ int get_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const gbm
 		    const FanoutGate *gate = nullptr);
 int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uint8_t *const *data, const size_t *len,
 		    const uint8_t *prevent_compression, const gbm_order_tag *tags, int *rcs, const FanoutGate *gate = nullptr);
+// hash_early(blocks, n, sums, ok): the blake2sum of n blocks the caller has ALREADY assembled (overlap_block), eight chains at a
+// time; ok[i] = 0 where block i was not assembled (compressed, a short buffer): then nothing is written for it.  Given (with
+// overlap_block), a big want_block_sums == 1 batch over header version 3 is SHARED between the device trip and the pool: the pool
+// checks, assembles and hashes as many healthy blocks as it gets through while the device does the same for the rest.
+using EarlyHashFn = std::function<void(const size_t *blocks, size_t n, uint8_t *sums, uint8_t *ok)>;
 // want_block_sums: 0 = no, 1 = the blake2sum of every block, 2 = of the blocks of every trip that rebuilds something
 // (block_sums[32*b..] is only meaningful where have_sum[b] is set)
 // overlap: host work done while the first device trip is in flight (the caller's early assembly); overlap_block(b): the same work
@@ -915,7 +923,7 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs,
 		 int want_block_sums, std::vector<uint8_t> &block_sums, const std::function<void()> &overlap = nullptr,
 		 std::vector<uint8_t> *changed = nullptr, const FanoutGate *gate = nullptr, std::vector<uint8_t> *have_sum = nullptr,
-		 const std::function<void(size_t)> *overlap_block = nullptr);
+		 const std::function<void(size_t)> *overlap_block = nullptr, const EarlyHashFn *hash_early = nullptr);
 void assemble(const Gathered &g, int k, uint8_t *dst);
 int one_block_rc(int rc1);
 // A shard is set aside (renamed *.corrupted, rebuilt by resync) only on the HOST's word.  Whoever found a checksum that does

@@ -289,7 +289,8 @@ int put_blocks_impl(gbm_manager *mg, size_t nb, const uint8_t *hashes, const uin
 // changed after that point (bit 0: a shard failed its checksum and was replaced, bit 1: a data shard was rebuilt).
 int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_tag *tags, std::vector<Gathered> &g, int *rcs,
 		 int want_block_sums, std::vector<uint8_t> &block_sums, const std::function<void()> &overlap,
-		 std::vector<uint8_t> *changed, const FanoutGate *gate, std::vector<uint8_t> *have_sum, const std::function<void(size_t)> *overlap_block)
+		 std::vector<uint8_t> *changed, const FanoutGate *gate, std::vector<uint8_t> *have_sum, const std::function<void(size_t)> *overlap_block,
+		 const EarlyHashFn *hash_early)
 {
 	const int k = mg->k, n = mg->n;
 	const size_t nb = hs.size();
@@ -339,7 +340,11 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 	// header version 3, a batch of some size, no block checksums wanted from a device trip: the early assembly rides in the
 	// shard-check tasks below (one pool task per block: check its k shards, then copy them out while they are in that core's cache)
 	const bool fused_host = overlap_block && mg->sumver == 3 && want_block_sums == 0 && nb >= 16;
-	if (overlap && !fused_host)
+	// ... and with the hash of EVERY block wanted (GBM_VERIFY_ALWAYS, the default over header version 3) a big batch is shared: the
+	// device trip is ~11 ms of BLAKE2b chain per MiB of block however few blocks it carries, and the pool idles beside it -- so the
+	// pool takes as many healthy blocks as it checks, assembles and hashes in that time (`shared` below)
+	const bool shared_ok = overlap_block && hash_early && mg->sumver == 3 && want_block_sums == 1 && nb >= 64;
+	if (overlap && !fused_host && !shared_ok)
 		helper = std::thread([&overlap, &helper_err] {
 			name_thread("gbm-get-helper");
 			try {
@@ -407,6 +412,8 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 			if (trip_sums)
 				bsums.assign(ids.size() * 32, 0);
 			int rc = GEC_OK;
+			bool shared_now = false;             // this group went through the shared form below
+			std::vector<uint8_t> host_sum_ok;    // ... and bsums[32*i] is meaningful for these
 			// Shard-header version 3 (MLH64): a host core checks a shard at memory speed, so the shards of a read are verified
 			// HERE, on the pool -- a healthy get does not cross the link at all -- and only blocks that miss a data shard go to
 			// the device, for the decode alone (gec_reconstruct_batch).  (With block checksums wanted from the trip the one-trip
@@ -508,6 +515,101 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 					tr.lap("decode (beside the checks)");
 				if (drc)
 					return fail(GBM_E_EC, std::string("gec_reconstruct_batch: ") + gec_strerror(drc) + " (" + derr + ")");
+			} else if (shared_ok && round == 0 && trip_sums) {
+				// -- the shared form.  How many blocks the pool takes: what it gets through (check 1.0 + copy 1.0 + hash 1.0 bytes per
+				// byte: ~1 GB/s per thread with eight chains per core) while the device needs max(its share over the link at ~50 GB/s,
+				// one block's chain: ~11 ms per MiB) + ~2 ms for the rest.  Blocks that miss a data shard stay with the device.
+				const double Lb = (double)k * (double)S, nthr = (double)mg->pool->workers() + 1.0;
+				const double t_host = Lb / 1.0e9 / nthr, t_link = Lb / 50.0e9, t_chain = 11e-3 * Lb / 1048576.0, t_fixed = 2e-3;
+				std::vector<uint8_t> healthy(ids.size(), 0);
+				size_t nhealthy = 0;
+				for (size_t i = 0; i < ids.size(); ++i) {
+					bool whole = true;
+					for (int j = 0; j < k; ++j)
+						whole = whole && sp[i * n + j];
+					healthy[i] = whole;
+					nhealthy += whole;
+				}
+				double want_host = (t_chain + t_fixed) / t_host;                               // chain-bound device share
+				if (((double)ids.size() - want_host) * t_link > t_chain)                        // link-bound device share
+					want_host = (t_fixed + (double)ids.size() * t_link) / (t_host + t_link);
+				const size_t nhost = std::min(nhealthy, (size_t)std::max(0.0, want_host));
+				std::vector<size_t> host_i, dev_i;
+				for (size_t i = 0; i < ids.size(); ++i)
+					(healthy[i] && host_i.size() < nhost ? host_i : dev_i).push_back(i);
+				// the device's share, on a thread of its own (contiguous argument arrays for the sub-batch, results scattered back)
+				const size_t nd = dev_i.size();
+				std::vector<const uint8_t *> dsp(nd * n);
+				std::vector<uint8_t *> dop(nd * n);
+				std::vector<size_t> dlens(nd);
+				std::vector<uint8_t> dss(nd * (size_t)n * 32), dbs(nd * 32);
+				for (size_t q = 0; q < nd; ++q) {
+					std::copy(sp.begin() + dev_i[q] * n, sp.begin() + (dev_i[q] + 1) * n, dsp.begin() + q * n);
+					std::copy(op.begin() + dev_i[q] * n, op.begin() + (dev_i[q] + 1) * n, dop.begin() + q * n);
+					dlens[q] = lens[dev_i[q]];
+				}
+				int drc = GEC_OK;
+				std::string derr;
+				std::thread trip;
+				struct JoinTrip {
+					std::thread &t;
+					~JoinTrip()
+					{
+						if (t.joinable())
+							t.join();
+					}
+				} join_trip{trip};
+				if (nd)
+					trip = std::thread([&] {
+						try {  // (a thread of its own inside a C entry point: nothing may leave it)
+							name_thread("gbm-get-trip");
+							DeviceTurn turn(gate);
+							drc = gec_decode_verify_batch(mg->codec, nd, dsp.data(), S, dlens.data(), dop.data(), dss.data(), dbs.data());
+							if (drc)
+								derr = gec_last_error();
+						} catch (...) {
+							drc = GEC_E_NOMEM;
+						}
+					});
+				// the pool's share: eight blocks per task (the eight chains of one core), check -> assemble -> hash while the block is
+				// in that core's cache; then the early assembly of the device's blocks (what the helper thread does otherwise)
+				host_sum_ok.assign(ids.size(), 0);
+				const size_t ngrp = (host_i.size() + 7) / 8;
+				mg->pool->parallel_for(ngrp + nd, [&](size_t t) {
+					if (t >= ngrp) {
+						(*overlap_block)(ids[dev_i[t - ngrp]]);
+						return;
+					}
+					size_t bs[8];
+					uint8_t ok8[8] = {0}, sums8[8 * 32];
+					const size_t i0 = t * 8, cnt = std::min<size_t>(8, host_i.size() - i0);
+					for (size_t q = 0; q < cnt; ++q) {
+						const size_t i = host_i[i0 + q];
+						for (int j = 0; j < k; ++j)  // (healthy: the first k present shards are the data shards)
+							mlh::shardsum3(sp[i * n + j], S, ssums.data() + (i * (size_t)n + j) * 32);
+						bs[q] = ids[i];
+						(*overlap_block)(bs[q]);
+					}
+					(*hash_early)(bs, cnt, sums8, ok8);
+					for (size_t q = 0; q < cnt; ++q)
+						if (ok8[q]) {
+							std::memcpy(bsums.data() + 32 * host_i[i0 + q], sums8 + 32 * q, 32);
+							host_sum_ok[host_i[i0 + q]] = 1;
+						}
+				});
+				tr.lap("the pool's share: check + assemble + hash");
+				if (trip.joinable())
+					trip.join();
+				tr.lap("the device's share: decode+verify");
+				if (drc)
+					return fail(GBM_E_EC, std::string("gec_decode_verify_batch: ") + gec_strerror(drc) + " (" + derr + ")");
+				for (size_t q = 0; q < nd; ++q) {
+					std::memcpy(ssums.data() + dev_i[q] * (size_t)n * 32, dss.data() + q * (size_t)n * 32, (size_t)n * 32);
+					std::memcpy(bsums.data() + 32 * dev_i[q], dbs.data() + 32 * q, 32);
+					host_sum_ok[dev_i[q]] = 1;
+				}
+				shared_now = true;
+				mg->gpu_hashed += nd * (size_t)k + nd;
 			} else {
 				DeviceTurn turn(gate);
 				rc = gec_decode_verify_batch(mg->codec, ids.size(), sp.data(), S, lens.data(), op.data(), ssums.data(),
@@ -519,7 +621,7 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 			tr.lap("join overlapped assembly");
 			if (rc)
 				return ec_fail(rc, host_check ? "gec_reconstruct_batch" : "gec_decode_verify_batch");
-			if (!host_check)
+			if (!host_check && !shared_now)
 				mg->gpu_hashed += ids.size() * (size_t)k + (trip_sums ? ids.size() : 0);
 			for (size_t i = 0; i < ids.size(); ++i) {
 				const size_t b = ids[i];
@@ -562,7 +664,7 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 					if (changed)
 						(*changed)[b] |= 2;  // missing data shards were filled in
 				}
-				if (trip_sums) {
+				if (trip_sums && (!shared_now || host_sum_ok[i])) {  // (shared form: a block the pool could not hash early is hashed by the caller)
 					std::memcpy(block_sums.data() + 32 * b, bsums.data() + 32 * i, 32);
 					if (have_sum)
 						(*have_sum)[b] = 1;
@@ -730,9 +832,30 @@ static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, co
 			early[b] = 1;
 		};
 	auto assemble_early = [&] { mg->pool->parallel_for(nb, assemble_one); };
+	// the blake2sum of blocks assemble_one has just laid down in the caller's buffers (the shared form of fetch_blocks): eight at a time
+	const EarlyHashFn hash_early = [&](const size_t *bs, size_t n8, uint8_t *sums, uint8_t *ok) {
+		const uint8_t *ptr[8] = {};
+		size_t len[8] = {}, at[8] = {}, cnt = 0;
+		for (size_t i = 0; i < n8 && i < 8; ++i) {
+			ok[i] = 0;
+			if (!early[bs[i]] || !missing_early[bs[i]].empty())
+				continue;
+			ptr[cnt] = out[bs[i]];
+			len[cnt] = g[bs[i]].meta.orig_len;
+			at[cnt++] = i;
+		}
+		if (!cnt)
+			return;
+		uint8_t tmp[8 * 32];
+		b2host::blake2sum_many(ptr, len, cnt, tmp);
+		for (size_t c = 0; c < cnt; ++c) {
+			std::memcpy(sums + 32 * at[c], tmp + 32 * c, 32);
+			ok[at[c]] = 1;
+		}
+	};
 	Trace tr("get (whole call)");
 	int frc = fetch_blocks(mg, hs, tags, g, rcs, verify && !cpu_hash ? (only_rebuilt ? 2 : 1) : 0, block_sums, assemble_early, &changed,
-			       gate, &have_sum, &assemble_one);
+			       gate, &have_sum, &assemble_one, &hash_early);
 	if (frc)
 		return frc;
 	tr.lap("fetch");

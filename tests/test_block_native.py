@@ -12,6 +12,7 @@ import pytest
 
 import garage_amd as g
 from garage_amd import block_native as bn
+from oracle import rs_oracle as O
 from tests.patterns import pattern_block
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -366,6 +367,52 @@ def test_reads_walk_the_layout_versions_oldest_first():
     assert mgr.resync_run()["offloaded"] > 0
     assert all(mgr.node_has_shard(n_[j], h, j) and (o[j] == n_[j] or not mgr.node_has_shard(o[j], h, j)) for j in range(4))
     assert mgr.rpc_get_block(h) == blocks[picked[0]]
+    mgr.close()
+
+
+# ----------------------------------------------------------------- round 6: the default mode's big gets, shared between pool and device
+@pytest.mark.parametrize("block_len", [40_000, 1 << 20], ids=["40KB", "1MiB"])
+def test_a_big_always_get_is_shared_between_the_pool_and_the_device_trip(backend, block_len):
+    """GBM_VERIFY_ALWAYS is the default over header version 3, and the hash of every block is what a big get then
+    costs: ~11 ms of BLAKE2b chain per MiB on the device however few blocks the trip carries, with the pool idle beside it.
+    fetch_blocks' shared form gives the pool as many healthy blocks as it checks, assembles and hashes in that time and the device
+    the rest (every block that misses a data shard among them).  Both shares must behave as one get: the right bytes, CorruptData
+    for content that does not match its name whichever share the block falls into, a shard that fails its checksum replaced, a
+    compressed block untouched by the name check.  (1 MiB blocks: both shares are populated; 40 KB: the pool takes every healthy block.)"""
+    codec = g.ReedSolomon(10, 4, backend=backend)
+    mgr = bn.NativeBlockManager(codec, 16)
+    assert mgr.verify_block_hash == "always"
+    nb = 160 if block_len > 100_000 else 220
+    mgr.set_host_block_hash_max(8)                      # (so that a batch of this size is not simply hashed by the pool afterwards)
+    blocks = [bytes(O.splitmix64_bytes(6000 + i, block_len - (i % 7) * 13)) for i in range(nb)]
+    hashes = [bn.blake2sum(b) for b in blocks]
+    mgr.rpc_put_blocks(list(zip(hashes, blocks)))
+    evil = {3: bytes(O.splitmix64_bytes(1, len(blocks[3]))), 97: bytes(O.splitmix64_bytes(2, len(blocks[97]))), nb - 1: b"x" * 5000}
+    for i, content in evil.items():                     # wrong content under a valid name
+        mgr.rpc_put_block(hashes[i], content)
+    degraded = [5, 97, 120]                             # these miss a data shard: the device's share (97 is evil AND degraded)
+    for i in degraded:
+        who = mgr.storage_nodes_of(hashes[i])
+        mgr.node_delete_shard(who[2], hashes[i], 2)
+    who = mgr.storage_nodes_of(hashes[40])
+    mgr.node_corrupt_shard(who[6], hashes[40], 6, 1000, 0x10)   # a healthy block of the pool's share with a rotten shard
+    before = mgr.metrics["corruption_counter"]
+    got = mgr.rpc_get_blocks(hashes, block_len)
+    for i in range(nb):
+        if i in evil:
+            assert got[i] == bn.GBM_E_CORRUPT_DATA, i
+        else:
+            assert got[i] == blocks[i], i
+    assert mgr.metrics["corruption_counter"] == before + 1
+    # the same get in the other modes and through the unshared paths gives the same answers where the modes agree
+    mgr.set_verify_block_hash("off")
+    got_off = mgr.rpc_get_blocks(hashes, block_len)
+    assert [got_off[i] for i in range(nb) if i not in evil] == [blocks[i] for i in range(nb) if i not in evil]
+    assert got_off[3] == evil[3]
+    mgr.set_verify_block_hash("always")
+    mgr.set_host_block_hash_max(10_000)                 # everything hashed by the pool after the fetch
+    got2 = mgr.rpc_get_blocks(hashes, block_len)
+    assert got2 == got
     mgr.close()
 
 

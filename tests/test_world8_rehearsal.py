@@ -1,7 +1,7 @@
 """World-8 rehearsal: what the driver's 8-GPU pass will run, on ONE GPU (GARAGE_DRYRUN_ONE_GPU=1: every
 rank / codec on device 0, gloo instead of RCCL -- labelled as such in the line; numbers meaningless, control flow identical).
 tools/world8_rehearsal.py runs the whole matrix (N = 2, 4, 8; four invocations each) and records wall times in
-profiles/r05_world8_rehearsal.txt; these tests assert the world-8 column and the two fault injections in about a minute."""
+profiles/r06_world8_rehearsal.txt; these tests assert the world-8 column and the fault injections in about two minutes."""
 import json
 import os
 import socket
@@ -159,11 +159,13 @@ def test_a_rank_that_cannot_map_its_peers_costs_only_the_peer_form():
 
 
 def test_the_recorded_rehearsal_is_complete():
-    """profiles/r05_world8_rehearsal.txt (tools/world8_rehearsal.py on one MI355X): N = 2, 4, 8 x four invocations, the N = 1
-    line and both fault injections -- every one rc 0, one JSON line, within its 300 s."""
-    path = os.path.join(ROOT, "profiles", "r05_world8_rehearsal.txt")
+    """profiles/r06_world8_rehearsal.txt (tools/world8_rehearsal.py on one MI355X): N = 2, 4, 8 x four invocations, the N = 1
+    line, the two fault injections that must leave the headline intact and the three that must turn one exchange red -- every one
+    rc 0, one JSON line, within its 300 s; every striped decode of the matrix with 256 of 256 objects of its TIMED batch exact
+    after each of the three exchanges."""
+    path = os.path.join(ROOT, "profiles", "r06_world8_rehearsal.txt")
     rows = [json.loads(ln) for ln in open(path) if ln.startswith("{")]
-    assert len(rows) == 15 and all(r["ok"] and r["rc"] == 0 and r["json_lines"] == 1 and r["wall_s"] < 300 for r in rows)
+    assert len(rows) == 18 and all(r["ok"] and r["rc"] == 0 and r["json_lines"] == 1 and r["wall_s"] < 300 for r in rows)
     for n in (2, 4, 8):
         kinds = [r["what"][:3] for r in rows if r["n"] == n and r["what"].startswith("(")]
         assert sorted(kinds) == ["(a'", "(a)", "(b)", "(c)"], (n, kinds)
@@ -171,3 +173,11 @@ def test_the_recorded_rehearsal_is_complete():
             if r["n"] == n and r["what"].startswith(("(a", "(b")):
                 assert r["summary"]["blocks_per_rank"] == _expected_partition(n)
                 assert r["summary"]["striped_decode"]["bit_exact"] is True and len(r["summary"]["roofline_frac_per_gpu"]) == n
+            if r["n"] == n and r["what"].startswith(("(a", "(c")):
+                sd = r["summary"]["striped_decode"]
+                assert sd["timed_batch_objects"] == 256 and sd["bit_exact_objects_per_exchange"] == {"allgather": 256, "alltoall": 256, "peer": 256}
+    flips = [r for r in rows if "flipped" in r["what"]]
+    assert len(flips) == 3
+    for r, hit in zip(flips, ("allgather", "alltoall", "peer")):
+        per = r["summary"]["striped_decode"]["bit_exact_objects_per_exchange"]
+        assert hit in r["what"] and per[hit] == 63 and sorted(per.values()) == [63, 64, 64]
