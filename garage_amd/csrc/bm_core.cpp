@@ -326,6 +326,18 @@ int for_lanes(gbm_manager *front, const std::function<int(gbm_manager *, size_t)
 
 namespace {
 // one complete manager over one codec; `nodes` non-empty: share these storage nodes (a lane of a front)
+// Workers of a lane's pool (the calling thread works too): a quarter of the host's CPUs shared among the lanes, between 16 and 32
+// threads in all, never more than the host has.  16 is what every path was tuned with (rounds 2 - 5); a lone lane on a big host
+// takes 32 -- the default end-to-end mode hashes every block of a big get on the pool (bm_rw.cpp, the shared form): 34.6 -> 41.8
+// GiB/s for 512 x 1 MiB at 32 threads, the other paths unchanged, 48 threads worse everywhere (profiles/r06_experiments.txt, 5).
+unsigned default_pool_workers(int lanes)
+{
+	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+	const unsigned share = hw / (4u * (unsigned)std::max(1, lanes));
+	const unsigned threads = std::min(32u, std::max(16u, share));
+	return std::min(hw - 1, threads - 1);
+}
+
 int create_one(const gec_codec *codec, int nnodes, const char *const *node_dirs, int write_quorum,
 	       const std::vector<std::shared_ptr<Node>> *nodes, std::unique_ptr<gbm_manager> &out)
 {
@@ -353,9 +365,9 @@ int create_one(const gec_codec *codec, int nnodes, const char *const *node_dirs,
 			mg->nodes.back()->bufs = mg->bufs;
 		}
 	}
-	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
 	mg->bufs->near = codec;  // shard buffers on the codec's memory node (numa.hpp; before the first buffer is drawn)
-	mg->pool.reset(new Pool(std::min(15u, hw - 1), codec));
+	mg->pool.reset(new Pool(default_pool_workers(1), codec));
+	mg->cpu_block_hash_max = 6 * ((size_t)mg->pool->workers() + 1);
 	mg->put_spot_every = env().put_spot_check;
 	// maintenance gets a background-class sibling of the codec (its own staging slots, low-priority streams on a
 	// subset of the CUs, small chunks that yield to the request path); without one it shares the request path's codec
@@ -502,6 +514,10 @@ int gbm_create_multi(const gec_codec *const *codecs, int ndev, int nnodes, const
 			}
 			lane->lane_idx = d;
 			lane->lane_cnt = ndev;
+			if (lane->pool && lane->pool->workers() != default_pool_workers(ndev)) {  // (the lanes share the host's CPUs)
+				lane->pool->resize(default_pool_workers(ndev));
+				lane->cpu_block_hash_max = 6 * ((size_t)lane->pool->workers() + 1);
+			}
 			if (d == 0) {
 				front->nodes = lane->nodes;
 				front->k = lane->k;

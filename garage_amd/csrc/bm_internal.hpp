@@ -735,6 +735,7 @@ struct gbm_manager {
 	// only when this is set (gbm_set_migrate_on_read); scrub and resync always migrate what they touch
 	std::atomic<bool> migrate_on_read{false};
 	std::atomic<uint64_t> shards_migrated{0};
+	std::atomic<uint64_t> shared_host_rate{2000000000ull};  // bytes/s one pool thread checks + assembles + hashes (measured by the shared form)
 	std::atomic<size_t> cpu_block_hash_max{96};  // gets of up to this many blocks hash them on the host (gbm_set_threads rescales)
 
 	// who is asking (request_order's our_node_id / our_zone, rpc_helper.rs:626-628): -1 = not one of the storage nodes

@@ -519,8 +519,11 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 				// -- the shared form.  How many blocks the pool takes: what it gets through (check 1.0 + copy 1.0 + hash 1.0 bytes per
 				// byte: ~1 GB/s per thread with eight chains per core) while the device needs max(its share over the link at ~50 GB/s,
 				// one block's chain: ~11 ms per MiB) + ~2 ms for the rest.  Blocks that miss a data shard stay with the device.
+				// (the pool's rate is MEASURED: every shared call leaves what its share achieved per thread -- 2.5 GB/s on a Zen 5
+				// core with eight chains at a time, a third of that on a host without AVX-512 -- and the next call splits by it)
 				const double Lb = (double)k * (double)S, nthr = (double)mg->pool->workers() + 1.0;
-				const double t_host = Lb / 1.0e9 / nthr, t_link = Lb / 50.0e9, t_chain = 11e-3 * Lb / 1048576.0, t_fixed = 2e-3;
+				const double host_rate = std::min(8e9, std::max(0.2e9, (double)mg->shared_host_rate.load(std::memory_order_relaxed)));
+				const double t_host = Lb / host_rate / nthr, t_link = Lb / 50.0e9, t_chain = 11e-3 * Lb / 1048576.0, t_fixed = 2e-3;
 				std::vector<uint8_t> healthy(ids.size(), 0);
 				size_t nhealthy = 0;
 				for (size_t i = 0; i < ids.size(); ++i) {
@@ -575,6 +578,7 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 				// in that core's cache; then the early assembly of the device's blocks (what the helper thread does otherwise)
 				host_sum_ok.assign(ids.size(), 0);
 				const size_t ngrp = (host_i.size() + 7) / 8;
+				const auto pool_t0 = std::chrono::steady_clock::now();
 				mg->pool->parallel_for(ngrp + nd, [&](size_t t) {
 					if (t >= ngrp) {
 						(*overlap_block)(ids[dev_i[t - ngrp]]);
@@ -597,6 +601,13 @@ int fetch_blocks(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_t
 							host_sum_ok[host_i[i0 + q]] = 1;
 						}
 				});
+				if (host_i.size() >= 32) {  // (enough blocks for the figure to mean something: half old, half new)
+					const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - pool_t0).count();
+					if (dt > 0) {
+						const double seen = (double)host_i.size() * Lb / dt / nthr;
+						mg->shared_host_rate = (uint64_t)(0.5 * host_rate + 0.5 * std::min(8e9, std::max(0.2e9, seen)));
+					}
+				}
 				tr.lap("the pool's share: check + assemble + hash");
 				if (trip.joinable())
 					trip.join();

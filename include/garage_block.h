@@ -191,7 +191,7 @@ int gbm_get_verify_block_hash(const gbm_manager *m);
 int gbm_set_migrate_on_read(gbm_manager *m, int enabled);
 uint64_t gbm_shards_migrated(const gbm_manager *m);
 /* A block's own checksum is one serial BLAKE2b chain: ~11 ms per MiB on the device however many blocks run beside
- * it, ~1 ms per MiB on a host core.  Gets of up to `nblocks` blocks (default 6 per pool thread = 96) verify it on the
+ * it, ~1 ms per MiB on a host core.  Gets of up to `nblocks` blocks (default 6 per pool thread: 96 with the usual 16 threads, 192 where a lone lane on a big host runs 32) verify it on the
  * host pool from the assembled bytes; larger batches on the device, behind the upload.  0 = always on the device. */
 int gbm_set_host_block_hash_max(gbm_manager *m, size_t nblocks);
 
