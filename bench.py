@@ -855,12 +855,16 @@ def run_procs(args) -> None:
                 cols[kind] = {"t0": distrib.gather_ints(R, int(sec[kind]["t0"] * 1e6)), "t1": distrib.gather_ints(R, int(sec[kind]["t1"] * 1e6)),
                               "rate": distrib.gather_ints(R, int(sec[kind]["GiBps"] * 1000)),
                               "exact": distrib.gather_ints(R, int(sec[kind]["bit_exact"])), "checked": distrib.gather_ints(R, sec[kind]["checked"])}
+            lane_nodes = distrib.gather_ints(R, rs_h.numa_node)      # where each rank's codec keeps its host side (-1: not placed)
             if rank == 0:
                 for q in range(world):
                     per.append({kind: {"t0": cols[kind]["t0"][q] / 1e6, "t1": cols[kind]["t1"][q] / 1e6, "GiBps": cols[kind]["rate"][q] / 1000,
                                        "bit_exact": bool(cols[kind]["exact"][q]), "checked": cols[kind]["checked"][q]}
                                 for kind in ("pinned", "pageable")})
                 out["host_fed"] = host_fed_object(per, args.host_blocks, reps)
+                out["host_fed"]["numa_node_per_gpu"] = lane_nodes
+                out["host_fed"]["numa"] = ("each codec's copy threads and pinned staging memory are on its device's memory node "
+                                           "(GEC_NUMA, garage_amd/csrc/numa.hpp); -1 = not placed (one node, or switched off)")
             del rs_h
         except Exception as e:  # noqa: BLE001 -- a secondary object must never cost the headline line
             if rank == 0:
@@ -956,7 +960,7 @@ def run_threads(args) -> None:
                 job.st = None
                 hf = host_fed_section(job.rs, args.host_blocks, hf_reps, bar.wait, seed=100 + t)
             res[t] = {"t0": t0, "t1": t1, "nb": nb, "kern_ms": ev0.elapsed_time(ev1) / args.steps, "cold": cold,
-                      "checked": checked, "host_fed": hf}
+                      "checked": checked, "host_fed": hf, "numa_node": job.rs.numa_node}
         except BaseException as e:  # noqa: BLE001
             err.append(f"thread {t}: {type(e).__name__}: {e}")
             bar.abort()
@@ -983,6 +987,7 @@ def run_threads(args) -> None:
     out["collective_backend"] = "none (single process; the encode path has no collective)"
     if all(r["host_fed"] for r in res):
         out["host_fed"] = host_fed_object([r["host_fed"] for r in res], args.host_blocks, hf_reps)
+        out["host_fed"]["numa_node_per_gpu"] = [r["numa_node"] for r in res]
         # ... and the same node through the PRODUCT's multi-device manager: gbm_create_multi over the N codecs, one
         # coalescing queue per device, native callers through gbm_batcher_put_block / _get_block (tools/multi_bench), beside
         # the raw gec_encode_hash_batch figures above

@@ -326,16 +326,14 @@ int for_lanes(gbm_manager *front, const std::function<int(gbm_manager *, size_t)
 
 namespace {
 // one complete manager over one codec; `nodes` non-empty: share these storage nodes (a lane of a front)
-// Workers of a lane's pool (the calling thread works too): a quarter of the host's CPUs shared among the lanes, between 16 and 32
-// threads in all, never more than the host has.  16 is what every path was tuned with (rounds 2 - 5); a lone lane on a big host
-// takes 32 -- the default end-to-end mode hashes every block of a big get on the pool (bm_rw.cpp, the shared form): 34.6 -> 41.8
-// GiB/s for 512 x 1 MiB at 32 threads, the other paths unchanged, 48 threads worse everywhere (profiles/r06_experiments.txt, 5).
-unsigned default_pool_workers(int lanes)
+// Workers of a lane's pool (the calling thread works too): 16 threads in all, fewer on a small host -- what every path was tuned
+// with.  Tried in round 6 (profiles/r06_experiments.txt, 5): 32 threads for a lone lane on a 256-CPU host lift the default mode's
+// big gets (the pool hashes every block) from 35 to 42 GiB/s, and cost the coalescing queue a fifth of its rate (48 writers: 30 ->
+// 18 - 24 GiB/s) and a lone put 20 - 80 us: not taken.  gbm_set_threads is there for a deployment that reads in bulk.
+unsigned default_pool_workers(int)
 {
 	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-	const unsigned share = hw / (4u * (unsigned)std::max(1, lanes));
-	const unsigned threads = std::min(32u, std::max(16u, share));
-	return std::min(hw - 1, threads - 1);
+	return std::min(15u, hw - 1);
 }
 
 int create_one(const gec_codec *codec, int nnodes, const char *const *node_dirs, int write_quorum,

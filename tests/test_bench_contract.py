@@ -75,6 +75,34 @@ def test_round5_line_carries_the_put_trip_and_config5s_code():
     assert "rebuilt" in bm["verify_mode_default"]
 
 
+def test_round6_line_times_both_decode_patterns_and_reports_the_default_mode():
+    """profiles/r06_bench_line.json = `python bench.py` with no flags on an MI355X (round 6)."""
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_line.json")).read().strip().splitlines()[-1])
+    for k, t in TOP.items():
+        assert isinstance(d[k], t), k
+    r = d["roofline"]
+    assert r["algorithmic_bytes_per_launch"] == 1503789056 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frac"] > 0.7
+    assert r["traffic"] >= r["algorithmic_bytes_per_launch"] and "round 06" in r["traffic_source"]
+    # config 3: both patterns BASELINE.md names, each timed, checked after its loop, with a roofline object that names the kernel
+    dec = d["decode"]
+    assert [p["lost"] for p in dec["patterns"]] == [[0, 3, 7, 9], [0, 3, 7, 11]] and dec["bit_exact"] is True
+    for p in dec["patterns"]:
+        rf = p["roofline"]
+        assert p["bit_exact"] is True and rf["bound"] == "hbm" and rf["kernel"].startswith("gf_apply_nibble<1,0,10")
+        assert abs(rf["frac"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9 / 8000) < 2e-3 and 0.6 < rf["frac"] < 1
+        assert p["kernel_ms"] <= p["ms_per_step"] * 1.02
+    assert dec["roofline"] == dec["patterns"][0]["roofline"] and "oracle" in dec["checked"]
+    # the CPU backend's put trip: all 14 checksums for at most a fifth more than the encode (was 6x)
+    cb = d["cpu_baseline"]["cpu_backend"]
+    assert cb["encode_plus_14_checksums_GiBps"] >= 0.8 * cb["value"]
+    # the manager: the DEFAULT mode is what rpc_get_blocks_GiBps reports, and a healthy rebuilt-mode get costs what an off-mode get costs
+    bm = d["block_manager"]
+    modes = bm["rpc_get_blocks_by_verify_mode_GiBps"]
+    assert bm["verify_mode_default"].startswith("always") and bm["rpc_get_blocks_GiBps"] == modes["always"]
+    assert modes["rebuilt"] >= 0.9 * modes["off"]          # (two runs of one box differ by more than the 5 % the paths differ by)
+    assert bm["small_trips"]["get_one_block_healthy_ms"]["rebuilt"] < 0.1 and bm["small_trips"]["put_one_block_ms"] < 0.13
+
+
 def test_bench_source_still_emits_every_field():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for key in list(TOP) + ["vs_baseline"] + list(ROOFLINE) + ["traffic", "secondary", "cold_burst_frac", "traffic_source"] + list(CPU) + [

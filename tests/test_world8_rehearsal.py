@@ -63,7 +63,7 @@ def _check_encode_line(d, world):
     assert len(fr) == world and all(f is not None and 0 < f < 1 for f in fr)
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["algorithmic_bytes_per_launch"] == 14 * 104896 * per[0]
     hf = d["host_fed"]
-    assert hf["n_gpus"] == world
+    assert hf["n_gpus"] == world and len(hf["numa_node_per_gpu"]) == world      # (round 6: each lane's memory node, -1 = not placed)
     for kind in ("pinned", "pageable"):
         assert len(hf[kind]["per_gpu_GiBps"]) == world and hf[kind]["bit_exact_vs_oracle"] is True
     mm = hf["block_manager_multi"]                                          # (d) the product's multi-device manager over `world` codecs
