@@ -681,7 +681,7 @@ int HipBackend::decode_verify_batch(size_t nblocks, const uint8_t *const *shards
 	// lost data shards (a node of each stripe down) finishes a chain step after the last byte arrived, like a
 	// healthy one, instead of upload + decode + a whole chain (24.7 -> see profiles/r03_get_degraded.txt).
 	// One stage unless every shard is pinned (the staged path uploads dense device ranges block by block) and the
-	// chains are long enough to be worth hiding.  GEC_VERIFY_SEGMENTS (A/B): 1 = upload everything, then hash.
+	// chains are long enough to be worth hiding.  (One stage -- upload everything, then hash -- was the A/B: slower from 24 blocks on.)
 	const int seg_max = (int)Staging::kMaxSeg;
 	const size_t nseg = (all_pinned && block_sums && longest >= (256u << 10)) ? std::min<size_t>(k, (size_t)seg_max) : 1;
 	auto stage_of_slot = [&](size_t slot) {

@@ -944,7 +944,7 @@ int gec_launch_geometry(int k, int rows_left, int *rows, int *entry_bytes, int *
 
 int gec_set_kernel_variant(int variant)
 {
-	if (variant < 0 || variant > 4)
+	if (variant < 0 || variant > 5)
 		return fail(GEC_E_INVALID_ARG, "unknown kernel variant");
 	g_variant.store(variant);
 	return GEC_OK;

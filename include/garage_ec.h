@@ -567,7 +567,8 @@ int gec_launch_geometry(int k, int rows_left, int *rows, int *entry_bytes,
  * other choice by size), 1 = the RS kernel with log/antilog tables in LDS (the literal north_star formulation, kept as
  * the measured baseline: bench.py --variant 1).  Test routes -- they pick between kernels the default already uses at
  * different sizes, so that one input reaches both: 2 / 3 = the BLAKE2b kernels with one lane / four lanes per message,
- * 4 = small pinned trips of a checksum-v2 codec take the streaming kernels instead of the one-launch kernel. */
+ * 4 = small pinned trips of a checksum-v2 codec take the streaming kernels instead of the one-launch kernel, 5 = gec_group_peer_decode
+ * always through pointer tables (by default only when the peers' buffers are more than 64 GiB apart in this process's address space). */
 int gec_set_kernel_variant(int variant);
 int gec_get_kernel_variant(void);
 

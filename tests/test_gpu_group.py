@@ -320,7 +320,7 @@ from tests.test_group_peer import CASES as PEER_CASES, check as peer_check, run_
 
 
 @pytest.mark.parametrize("k,m,world,S,nobj,lost,data_only,complete", PEER_CASES + [(20, 8, 8, 209728, 4, (0, 1, 5, 9, 13, 19, 21, 27), False, True)])
-def test_peer_decode_logical_ranks_on_one_device(loopback, k, m, world, S, nobj, lost, data_only, complete):
+def test_peer_decode_logical_ranks_on_one_device(loopback, k, m, world, S, nobj, lost, data_only, complete, peer_route):
     """N logical ranks as threads on the one visible device: every rank's decode launch reads its byte range of the survivors
     straight out of the OTHER ranks' slot buffers (all pointers local here: the table, the ranges and the second step are what
     is under test), the loopback transport carries the barriers and the rebuilt ranges.  Against the oracle's stripes; the last
@@ -337,8 +337,17 @@ def test_peer_decode_logical_ranks_on_one_device(loopback, k, m, world, S, nobj,
     peer_check(outs, full, layout, k, S, lost, data_only, complete)
 
 
+@pytest.fixture(params=[0, 5], ids=["strided_when_addressable", "pointer_tables"])
+def peer_route(request):
+    """gec_group_peer_decode reads the peers' buffers with the strided kernel when they are within 64 GiB of each other (always on one
+    device) and through pointer tables otherwise; gec_set_kernel_variant(5) is the tests' route to the latter."""
+    g.set_kernel_variant(request.param)
+    yield request.param
+    g.set_kernel_variant(0)
+
+
 @pytest.mark.parametrize("complete", [True, False])
-def test_peer_decode_reuses_its_pointer_tables_and_stores_in_place(coracle, complete):
+def test_peer_decode_reuses_its_pointer_tables_and_stores_in_place(coracle, complete, peer_route):
     """Round 6: a peer decode out of the same slot buffers, with the same pattern, geometry, destination and
     stream, finds its pointer tables on the device from the call before -- the steady-state call is the launch and the barriers --
     and a group of one (or complete=0) stores the rebuilt ranges straight into the destination, no unpack pass.  The tables hold

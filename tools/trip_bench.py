@@ -2,7 +2,7 @@
 """One device trip on pinned memory, by block count: gec_encode_hash_batch (a put batch: parity + 14 checksums) and
 gec_decode_verify_batch (a get batch without block checksums: healthy, and with 4 of 14 shards of every block gone),
 RS(10,4), 1 MiB blocks.  Median of `reps` calls after warm-up.  Which path a count takes is decided by the library
-(GEC_FUSED_MAX_LEAVES, GEC_PUT_CHUNKS, GEC_GET_PIECES); the A/B is by environment.  usage: trip_bench.py [reps]"""
+(GEC_FUSED_MAX_LEAVES, GEC_FUSED_GET_MAX_LEAVES); the A/B is by environment.  usage: trip_bench.py [reps]"""
 import ctypes
 import os
 import sys
