@@ -333,9 +333,12 @@ struct CpuBackend : Backend {
 			apply_range(*j.prog, in.data(), avail.data(), out.data(), len);
 			if (lo) {  // while the chunk is in this core's cache
 				uint64_t *base = lo->sums + ji * lo->nshard * lo->nleaf + off / mlh::LEAF_BYTES;
+				// (while the chunk's inputs are summed out of this core's cache, the same shards' NEXT chunk -- the pool's next
+				// item on this block -- is requested from memory: a core that only sums leaves the memory system idle for a third
+				// of the item on a host that is bound by it)
 				for (int t = 0; t < k; ++t)
 					if (avail[t])
-						mlh::leaf_sums(in[t], avail[t], base + (size_t)t * lo->nleaf);
+						mlh::leaf_sums(in[t], avail[t], base + (size_t)t * lo->nleaf, -1, j.valid[t] > off + 2 * kChunk ? kChunk : 0);
 				for (int r = 0; r < rows; ++r)
 					mlh::leaf_sums(out[r], len, base + (size_t)(k + r) * lo->nleaf);
 			}

@@ -51,6 +51,26 @@ __attribute__((target("avx2"))) inline uint64_t leaf_avx2(const uint8_t *p, size
 	return lane[0] + lane[1] + lane[2] + lane[3] + leaf_scalar(p + 4 * i, nwords - i, K + i);
 }
 
+// ahead != 0: while a line is summed, the line `ahead` bytes further on is requested (into L2) -- the caller is about to stream there
+// (ec_cpu.cpp: the next chunk of the same shard), and a core that only sums what is already in its cache leaves the memory idle
+template <bool PF>
+__attribute__((target("avx512f"))) inline uint64_t leaf_avx512_t(const uint8_t *p, size_t nwords, const uint32_t *K, size_t ahead)
+{
+	__m512i a0 = _mm512_setzero_si512(), a1 = _mm512_setzero_si512();
+	size_t i = 0;
+	for (; i + 16 <= nwords; i += 16) {
+		if (PF)
+			_mm_prefetch(reinterpret_cast<const char *>(p + 4 * i + ahead), _MM_HINT_T1);
+		const __m512i v = _mm512_loadu_si512(p + 4 * i);
+		const __m512i k = _mm512_loadu_si512(K + i);
+		a0 = _mm512_add_epi64(a0, _mm512_mul_epu32(v, k));
+		a1 = _mm512_add_epi64(a1, _mm512_mul_epu32(_mm512_srli_epi64(v, 32), _mm512_srli_epi64(k, 32)));
+	}
+	uint64_t lane[8];  // (not _mm512_reduce_add_epi64: gcc spells it with SIGNED 64-bit adds, which must not wrap)
+	_mm512_storeu_si512(lane, _mm512_add_epi64(a0, a1));
+	return lane[0] + lane[1] + lane[2] + lane[3] + lane[4] + lane[5] + lane[6] + lane[7] + leaf_scalar(p + 4 * i, nwords - i, K + i);
+}
+
 __attribute__((target("avx512f"))) inline uint64_t leaf_avx512(const uint8_t *p, size_t nwords, const uint32_t *K)
 {
 	__m512i a0 = _mm512_setzero_si512(), a1 = _mm512_setzero_si512();
@@ -91,8 +111,8 @@ inline int isa()
 	return hw < cap ? hw : cap;
 }
 
-// the leaf sums of a shard of `len` bytes: out[l], l < nleaf(len)
-inline void leaf_sums(const uint8_t *data, size_t len, uint64_t *out, int force_isa = -1)
+// the leaf sums of a shard of `len` bytes: out[l], l < nleaf(len).  prefetch_ahead (AVX-512 form only): see leaf_avx512_t.
+inline void leaf_sums(const uint8_t *data, size_t len, uint64_t *out, int force_isa = -1, size_t prefetch_ahead = 0)
 {
 	const uint32_t *K = keys();
 	const int how = force_isa >= 0 ? force_isa : isa();
@@ -103,7 +123,9 @@ inline void leaf_sums(const uint8_t *data, size_t len, uint64_t *out, int force_
 		const size_t nw = n / 4;
 		uint64_t s;
 #if defined(__x86_64__)
-		if (how == 2)
+		if (how == 2 && prefetch_ahead)
+			s = leaf_avx512_t<true>(p, nw, K, prefetch_ahead);
+		else if (how == 2)
 			s = leaf_avx512(p, nw, K);
 		else if (how == 1)
 			s = leaf_avx2(p, nw, K);

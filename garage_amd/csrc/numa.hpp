@@ -143,8 +143,9 @@ inline int node_of_address(const void *p)
 #endif
 }
 
-// While alive, pages the calling thread faults in (or a driver pins on its behalf) come from `node` (MPOL_BIND); the default
-// policy is restored on the way out.  node < 0 = no-op.  ok() says whether the kernel took it.
+// While alive, pages the calling thread faults in (or a driver pins on its behalf) come from `node` (MPOL_PREFERRED: from that node
+// while it has memory, from the others when it is full -- a lane must not fail to allocate because ITS socket is the busy one); the
+// default policy is restored on the way out.  node < 0 = no-op.  ok() says whether the kernel took it.
 class ScopedBind {
 public:
 	explicit ScopedBind(int node)
@@ -154,7 +155,7 @@ public:
 			return;
 		unsigned long mask[16] = {0};
 		mask[node / (8 * sizeof(unsigned long))] = 1ul << (node % (8 * sizeof(unsigned long)));
-		set_ = syscall(SYS_set_mempolicy, /*MPOL_BIND*/ 2, mask, sizeof mask * 8) == 0;
+		set_ = syscall(SYS_set_mempolicy, /*MPOL_PREFERRED*/ 1, mask, sizeof mask * 8) == 0;
 #else
 		(void)node;
 #endif
