@@ -195,28 +195,31 @@ def cpu_backend_rate(S: int, nb: int = 512) -> dict:
     ptrs = (ctypes.c_void_p * nb)(*[big.ctypes.data + b * K * S for b in range(nb)])
     optrs = (ctypes.c_void_p * nb)(*[outb.ctypes.data + b * M * S for b in range(nb)])
     lens = (ctypes.c_size_t * nb)(*[BLOCK_LEN] * nb)
-    best = None
-    for _ in range(5):
+    # the encode alone and the encode with the 14 shard checksums of every stripe (what a put costs a node without a GPU), turn and
+    # turn about: on a shared host the rate drifts by a quarter within seconds, and two figures taken one after the other would
+    # mostly measure that
+    sums = np.zeros(nb * (K + M) * 32, dtype=np.uint8)
+    sp = sums.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    check(lib.gec_encode_batch(rs._h, nb, ptrs, lens, S, optrs), "gec_encode_batch")
+    best = hbest = None
+    for _ in range(6):
         t0 = time.perf_counter()
         check(lib.gec_encode_batch(rs._h, nb, ptrs, lens, S, optrs), "gec_encode_batch")
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    # ... and with the 14 shard checksums of every stripe (what a put costs a node without a GPU: a hashing path)
-    hbest = None
-    try:
-        sums = np.zeros(nb * (K + M) * 32, dtype=np.uint8)
-        for _ in range(3):
+        try:
             t0 = time.perf_counter()
-            check(lib.gec_encode_hash_batch(rs._h, nb, ptrs, lens, S, optrs, sums.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), "gec_encode_hash_batch")
+            check(lib.gec_encode_hash_batch(rs._h, nb, ptrs, lens, S, optrs, sp), "gec_encode_hash_batch")
             dt = time.perf_counter() - t0
             hbest = dt if hbest is None else min(hbest, dt)
-    except Exception:  # noqa: BLE001
-        hbest = None
+        except Exception:  # noqa: BLE001
+            hbest = None
+            break
     return {"value": round(nb * BLOCK_LEN / best / 2**30, 2), "unit": "GiB/s", "kernel": lib.gec_cpu_isa().decode(),
             "encode_plus_14_checksums_GiBps": round(nb * BLOCK_LEN / hbest / 2**30, 2) if hbest else None,
             "cpus_allowed": len(os.sched_getaffinity(0)),
             "threads": int(os.environ.get("GEC_CPU_THREADS", "0")) or min(os.cpu_count() or 1, 16),
-            "sample": f"{nb} blocks x 1 MiB RS(10,4) gec_encode_batch on a GEC_BACKEND_CPU codec, best of 5"}
+            "sample": f"{nb} blocks x 1 MiB RS(10,4) gec_encode_batch / gec_encode_hash_batch on a GEC_BACKEND_CPU codec, best of 6 each, interleaved"}
 
 
 def _proc_snapshot():
