@@ -935,9 +935,10 @@ static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, co
 				idx.push_back(b);
 		// eight blocks per task where a core hashes eight chains at once (AVX-512); one block per task otherwise, so the
 		// scalar fallback keeps one message per pool thread (8 x 1 MiB: 6.7 ms either way instead of 16 ms on one core)
-		// ... but only when there are more blocks than threads: eight chains in lockstep take about three times as long as one
-		// chain alone, so a GetObject's few blocks -- the default mode over checksum v3 hashes every one -- are back sooner one
-		// per thread (3 blocks: 1.1 ms instead of 3; 16: 1.2).  Beyond one round the eight-lane form's 2.5x lower CPU cost wins:
+		// ... but only when there are more blocks than threads: eight chains in lockstep take 2.3 times as long as one chain
+		// alone (2.3 against 1.0 ms per MiB on a Zen 5 core), so a GetObject's few blocks -- the default mode over checksum v3
+		// hashes every one -- are back sooner one per thread (3 blocks: 1.2 ms instead of 1.7; 8: 1.2 - 2.0 instead of 2.3).
+		// Beyond one round the eight-lane form's 3.5x lower CPU cost per block wins:
 		// the coalescing queue's batches of ~30 under 48 readers lost a fifth of their rate with one block per task.
 		const size_t nthr = (size_t)mg->pool->workers() + 1;
 		const size_t per = b2host::mb_available() && idx.size() > nthr ? 8 : 1;
