@@ -130,6 +130,7 @@ struct gbm_batcher {
 		int rc = GBM_OK;
 		std::string err;
 		bool done = false;
+		bool needs_hash = false;  // delivered, but its end-to-end hash is the waiting caller's to do (FanoutGate::defer_block_hash)
 	};
 	std::mutex gmu;
 	std::condition_variable gcv_work, gcv_done;
@@ -236,11 +237,14 @@ struct gbm_batcher {
 			std::vector<int> rcs;
 			std::vector<size_t> lens;
 			std::vector<std::string> errs(nb);
+			std::vector<uint8_t> deferred;
 			FanoutGate gate;
 			LinkTurn turn{&gdev_mu};
 			gate.device_enter = [&] { turn.enter(); };
 			gate.device_exit = [&] { turn.exit(); };
 			try {
+				deferred.assign(nb, 0);
+				gate.defer_block_hash = &deferred;
 				std::vector<uint8_t> hashes(nb * 32);
 				std::vector<uint8_t *> outs(nb);
 				std::vector<size_t> caps(nb);
@@ -254,8 +258,13 @@ struct gbm_batcher {
 				auto fetch = [&](size_t i0, size_t cnt) {
 					int rc;
 					try {
+						// (the deferral flags are indexed by the call's blocks: a sub-call gets its own window of them)
+						std::vector<uint8_t> win(cnt, 0);
+						FanoutGate g2 = gate;
+						g2.defer_block_hash = &win;
 						rc = get_blocks_impl(mg, cnt, hashes.data() + 32 * i0, nullptr, outs.data() + i0, caps.data() + i0,
-								     lens.data() + i0, rcs.data() + i0, false, nullptr, &gate);
+								     lens.data() + i0, rcs.data() + i0, false, nullptr, &g2);
+						std::copy(win.begin(), win.end(), deferred.begin() + i0);
 					} catch (const std::exception &e) {
 						rc = fail(GBM_E_IO, std::string("batched get: ") + e.what());
 					}
@@ -274,6 +283,7 @@ struct gbm_batcher {
 			} catch (const std::exception &e) {  // the vectors above
 				rcs.assign(nb, GBM_E_IO);
 				lens.assign(nb, 0);
+				deferred.clear();
 				for (auto &s : errs)
 					s = e.what();
 			}
@@ -282,6 +292,7 @@ struct gbm_batcher {
 				batch[i]->rc = rcs[i];
 				batch[i]->len = lens[i];
 				batch[i]->err = std::move(errs[i]);
+				batch[i]->needs_hash = rcs[i] == GBM_OK && i < deferred.size() && deferred[i];
 				batch[i]->done = true;
 			}
 			--gbusy;
@@ -631,6 +642,14 @@ int gbm_batcher_get_block(gbm_batcher *b, const uint8_t hash[32], uint8_t *out, 
 		b->gcv_done.wait(lk, [&] { return it.done; });
 	}
 	*len_out = it.len;
+	if (it.rc == GBM_OK && it.needs_hash) {
+		// DataBlock::verify (block.rs:69-77) by the reader itself: the batch delivered the block on its shards' checksums, the
+		// name is checked here, on this caller's core, beside the other readers' (GBM_VERIFY_ALWAYS through the queue)
+		uint8_t sum[32];
+		blake2sum(out, it.len, sum);
+		if (std::memcmp(sum, hash, 32) != 0)
+			return one_block_rc(GBM_E_CORRUPT_DATA);
+	}
 	if (it.rc == GBM_OK)
 		return GBM_OK;
 	if (it.rc == GBM_E_MISSING_BLOCK || it.rc == GBM_E_CORRUPT_DATA || it.rc == GBM_E_BUFFER_TOO_SMALL)

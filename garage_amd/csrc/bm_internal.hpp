@@ -890,6 +890,11 @@ struct FanoutGate {
 	// whichever device had it -- and after_block(b).
 	const std::vector<size_t> *block_order = nullptr;
 	std::function<void(size_t)> before_block, after_block;
+	// gets through the coalescing queue under GBM_VERIFY_ALWAYS: the end-to-end hash of a healthy Plain block is left to the
+	// CALLER that waits for it ((*defer_block_hash)[b] = 1: "delivered, not yet checked against its name") -- every reader hashes
+	// its own block on its own thread, as every request of the reference verifies its own read, instead of the batch's one
+	// pool doing all of them; blocks that went through a decode are still hashed by the batch
+	std::vector<uint8_t> *defer_block_hash = nullptr;
 };
 // RAII form of device_enter / device_exit
 struct DeviceTurn {

@@ -784,11 +784,21 @@ static int get_blocks_again(gbm_manager *mg, size_t nb, const uint8_t *hashes, c
 		oo[i] = out[again[i]];
 		cc[i] = cap[again[i]];
 	}
-	std::vector<uint8_t> worth_sub;
+	std::vector<uint8_t> worth_sub, defer_sub(na, 0);
+	FanoutGate sub_gate;
+	if (gate) {
+		sub_gate = *gate;
+		if (gate->defer_block_hash)
+			sub_gate.defer_block_hash = &defer_sub;  // (indexed by the sub-call's blocks: mapped back below)
+	}
 	rc = get_blocks_once(mg, na, hh.data(), tags ? tt.data() : nullptr, oo.data(), cc.data(), ll.data(), rr.data(), raw,
-			     headers ? hd.data() : nullptr, gate, worth_sub);
+			     headers ? hd.data() : nullptr, gate ? &sub_gate : nullptr, worth_sub);
 	if (rc != GBM_OK)
 		return rc;
+	if (gate && gate->defer_block_hash)
+		for (size_t i = 0; i < na; ++i)
+			if (again[i] < gate->defer_block_hash->size())
+				(*gate->defer_block_hash)[again[i]] = defer_sub[i];
 	std::vector<uint8_t> worth2(nb, 0);
 	for (size_t i = 0; i < na; ++i) {
 		rcs[again[i]] = rr[i];
@@ -816,7 +826,9 @@ static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, co
 	// The requester's end-to-end check (gbm_set_verify_block_hash): every Plain block, only the blocks that went through a
 	// decode, or -- the default, the reference's read path -- none: the shard checksums of the same trip are the serving
 	// node's verify (read_block_from, manager.rs:577-609), and they are always checked.
-	const int mode = mg->verify_mode.load();
+	const int asked = mg->verify_mode.load();
+	const bool defer = gate && gate->defer_block_hash && asked == GBM_VERIFY_ALWAYS && gate->defer_block_hash->size() >= nb;
+	const int mode = defer ? GBM_VERIFY_REBUILT : asked;  // (the callers check the healthy blocks themselves: FanoutGate)
 	const bool verify = mode != GBM_VERIFY_OFF, only_rebuilt = mode == GBM_VERIFY_REBUILT;
 	// Where the block's own checksum is computed.  It is one serial BLAKE2b chain per block: ~11 ms per MiB on the
 	// device however many blocks run beside it, ~1 ms per MiB on a host core.  Small requests -- a GetObject reads
@@ -888,6 +900,8 @@ static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, co
 		// from the same device trip that decoded it (or is computed below, cpu_hash); Compressed = the zstd frame
 		// (with its checksum) decodes
 		const bool check = verify && !z && (!only_rebuilt || (changed[b] & 2));
+		if (defer && !z && !check && !raw)
+			(*gate->defer_block_hash)[b] = 1;  // (cleared below if the block turns out not to be deliverable)
 		if (check && !cpu_hash && have_sum[b] && std::memcmp(block_sums.data() + 32 * b, hashes + 32 * b, 32) != 0) {
 			rcs[b] = GBM_E_CORRUPT_DATA;
 			final_verdict[b] = 1;
@@ -964,6 +978,10 @@ static int get_blocks_once(gbm_manager *mg, size_t nb, const uint8_t *hashes, co
 		});
 	}
 	tr.lap("finish");
+	if (defer)
+		for (size_t b = 0; b < nb; ++b)
+			if (rcs[b] != GBM_OK)
+				(*gate->defer_block_hash)[b] = 0;
 	for (size_t b = 0; b < nb; ++b)
 		if ((rcs[b] == GBM_E_MISSING_BLOCK || rcs[b] == GBM_E_CORRUPT_DATA) && !final_verdict[b] && b < g.size())
 			worth_retry[b] = g[b].count > 0 || g[b].corrupt_seen || g[b].have_meta || g[b].down_seen;
