@@ -94,12 +94,15 @@ int gather_many(gbm_manager *mg, const std::vector<Hash> &hs, const gbm_order_ta
 			shardsum_v(hd.version, sh.data.data(), hd.shard_len, sum);
 			ok = std::memcmp(sum, hd.checksum, 32) == 0;
 			if (ok) {
+				const int was = hd.version;
 				hd.version = (uint8_t)mg->sumver;
 				shardsum_v(mg->sumver, sh.data.data(), hd.shard_len, hd.checksum);
-				// The REWRITE on its node is maintenance: scrub and resync do it (`migrate`), a read does not unless the operator
-				// asked for it (gbm_set_migrate_on_read) -- a get has no business writing to a store, and two managers of different
-				// kinds reading one store would keep rewriting each other's shards.
-				if (migrate || mg->migrate_on_read.load()) {
+				// The REWRITE on its node is maintenance: scrub and resync do it (`migrate`), and only UPWARDS (an older header
+				// version into this manager's newer one) -- a manager of the older kind reads newer shards and leaves them as
+				// they are, so two managers of different kinds over one store converge instead of rewriting each other's shards
+				// at every scrub.  A read rewrites (either way) only when the operator asked for it (gbm_set_migrate_on_read):
+				// a get has no business writing to a store.
+				if ((migrate && was < mg->sumver) || mg->migrate_on_read.load()) {
 					ShardRpc up{RpcKind::PutShard, &hs[b], j, sh, nullptr};
 					ShardResp ur;
 					if (mg->nodes[node]->handle(up, ur) && ur.ok)

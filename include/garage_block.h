@@ -183,7 +183,8 @@ int gbm_set_verify_block_hash(gbm_manager *m, int mode);
 int gbm_get_verify_block_hash(const gbm_manager *m);
 /* Shards of an older header version (1, 2 under a version-3 manager; or 3 under a version-2 one) are verified with THEIR
  * checksum whenever they are read and handed on in the manager's own version.  They are REWRITTEN on their node in that
- * version by scrub and resync only; a read rewrites them too when `enabled` is set (default 0: a get never writes to the
+ * version by scrub and resync only, and only UPWARDS (an older version into this manager's newer one: a version-2 manager leaves
+ * version-3 shards as they are, so two managers of different kinds over one store converge); a read rewrites them too when `enabled` is set (default 0: a get never writes to the
  * store, and two managers of different kinds over one store do not rewrite each other's shards).  The change of format is
  * one-way for older builds: a build that does not know version 3 reports such shards as unreadable (it never renames or
  * deletes them), so a store that a version-3 manager has written to or scrubbed cannot be served by a round-4 binary.
