@@ -595,13 +595,20 @@ def test_device_api_is_hipgraph_capturable(coracle, rs104):
     present = [j not in lost for j in range(k + m)]
     rs104.reconstruct_dev(st.clone(), present)     # builds + caches the decode plan outside the capture
     torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        rs104.encode_dev(st)
-        ok = rs104.verify_dev(st)
-        for j in lost:                              # plain slice fills: capturable (list indexing is not)
-            st[:, j].zero_()
-        rs104.reconstruct_dev(st, present)
+    import gc
+
+    gc.collect()                                    # nothing may be torn down (hipFree, stream destruction) while the stream captures:
+    gc.disable()                                    # the collector freeing an earlier test's codec in here would invalidate the capture
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            rs104.encode_dev(st)
+            ok = rs104.verify_dev(st)
+            for j in lost:                          # plain slice fills: capturable (list indexing is not)
+                st[:, j].zero_()
+            rs104.reconstruct_dev(st, present)
+    finally:
+        gc.enable()
     for rep in range(3):
         st[:, k:] = 0x77                            # clobber parity, replay must rebuild everything
         graph.replay()
