@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/syscall.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 static void put(int fd, const char *s) { if (write(fd, s, strlen(s)) < 0) {} }
@@ -51,6 +52,31 @@ static void dump(int fd, int sig)
 	put(fd, "=== end abort_trace\n");
 }
 
+/* ABORT_TRACE_GDB=<file>: before the process dies, rocgdb attaches to it and lists the device's queues, dispatches and waves
+ * (a queue exception leaves the faulting waves halted: "info threads" names the kernel they are in). */
+static void gdb_snapshot(void)
+{
+	const char *out = getenv("ABORT_TRACE_GDB");
+	if (!out || !*out)
+		return;
+	char pid[32];
+	snprintf(pid, sizeof pid, "%d", (int)getpid());
+	pid_t child = fork();
+	if (child == 0) {
+		int fd = open(out, O_WRONLY | O_CREAT | O_APPEND, 0644);
+		if (fd >= 0) { dup2(fd, 1); dup2(fd, 2); }
+		unsetenv("LD_PRELOAD");
+		alarm(240);
+		execl("/opt/rocm/bin/rocgdb", "rocgdb", "-q", "-batch", "-p", pid, "-ex", "set pagination off", "-ex", "info agents", "-ex", "info queues",
+		      "-ex", "info dispatches", "-ex", "info threads", "-ex", "thread apply all bt 14", (char *)NULL);
+		_exit(127);
+	}
+	if (child > 0) {
+		int st;
+		waitpid(child, &st, 0);
+	}
+}
+
 static void handler(int sig)
 {
 	dump(2, sig);
@@ -59,6 +85,8 @@ static void handler(int sig)
 		int fd = open(path, O_WRONLY | O_CREAT | O_APPEND, 0644);
 		if (fd >= 0) { dump(fd, sig); close(fd); }
 	}
+	if (sig == SIGABRT)
+		gdb_snapshot();
 	signal(sig, SIG_DFL);
 	raise(sig);
 }
