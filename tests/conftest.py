@@ -1,7 +1,17 @@
 import os
 import sys
 
-import pytest
+# Before anything initialises the HIP runtime (the variable is read once, at initialisation; subprocesses inherit it): the tests move
+# numpy arrays to the device and back with torch's plain `.to()` / `.cpu()`, i.e. SYNCHRONOUS copies from / to PAGEABLE memory.  For
+# those the runtime's default is to lock the caller's pages for the device ("Locking to pool ... HostPtr = <heap address>") and let
+# the DMA engine read them in place -- and about one full GPU suite run in eight died right there: "Memory access fault by GPU ... on
+# address <the first page just locked>", one millisecond after the lock, with nothing of this repository between the two lines
+# (profiles/r06_gpu_suite_abort.txt has the runtime's own log of it and the probes).  With a floor this high the runtime takes its
+# other path -- the bytes travel through ITS pinned staging buffer, no caller page is ever mapped for the device -- which is also
+# what the library under test does with pageable caller memory (ec_hip_host.cpp: its own pinned slots).  Value in KiB.
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
+
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
