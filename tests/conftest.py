@@ -38,8 +38,9 @@ def _cyclic_garbage_is_collected_between_tests():
     """Codecs, groups and managers own device resources and threads, and Python frees the ones caught in reference cycles (an
     exception's traceback -> frame -> locals is the usual one: every `pytest.raises` makes it) whenever its collector happens to run
     -- which can be in the middle of ANOTHER test: a gbm_destroy / gec_codec_destroy (hipFree, hipStreamDestroy, thread joins) inside
-    a stream capture invalidates the capture, and the GPU suite saw exactly that about once in eight runs.  Collect after every test
-    instead: whatever a test leaves behind is torn down before the next one starts."""
+    a stream capture invalidates the capture.  Collect after every test instead: whatever a test leaves behind is torn down before
+    the next one starts.  (This was first taken for the cause of the abort that ended one GPU suite run in eight; it was not -- that
+    one is the runtime's, see the top of this file.)"""
     yield
     import gc
 
