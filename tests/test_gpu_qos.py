@@ -50,10 +50,11 @@ def test_tranquility_pauses_the_scrub():
 
 
 def _qos_attempts(args, what, check, attempts=3):
-    """tools/qos_bench compares p99 latencies over 1.5 s phases on a box that runs other things too: one scheduling hiccup among
-    ~200 samples moves a p99 by 2x (the suite saw 2.8-2.9x about once in three runs where the recorded figure is 0.98-1.44x).
-    The property under test is what the class CAN hold, so up to three attempts are made and the first that meets the bounds
-    passes; the assertion message of the last one is what a failure reports."""
+    """tools/qos_bench compares p99 latencies over 1.5 s phases on a box that runs other things too.  Round 6's record (tools/qos_dist.sh
+    and six suite runs on fresh leases): puts with the class 1.00-1.14x solo four times out of four and 2.9x once in a suite run; gets
+    with the class 1.05-1.15x three times out of four, 4.2x once (that run's "without" was 5.2x: the whole run was disturbed), 2.8x once
+    in a suite run.  The property under test is what the class CAN hold, so up to three attempts are made and the first that meets the
+    bounds passes; the assertion message of the last one is what a failure reports."""
     exe = os.path.join(ROOT, "tools", "qos_bench")
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "qos_bench"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
