@@ -545,7 +545,12 @@ try {
 	void *dptr = p;
 	if (hipHostGetDevicePointer(&dptr, p, 0) != hipSuccess || !dptr)
 		dptr = p;
-	pinned().add(p, bytes, false, reinterpret_cast<intptr_t>(dptr) - reinterpret_cast<intptr_t>(p));
+	try {
+		pinned().add(p, bytes, false, reinterpret_cast<intptr_t>(dptr) - reinterpret_cast<intptr_t>(p));
+	} catch (...) {  // the registry could not grow: the range must not stay mapped behind a call that failed
+		(void)hipHostUnregister(p);
+		throw;
+	}
 	return GEC_OK;
 }
 GEC_CATCH
